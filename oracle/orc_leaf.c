@@ -1,0 +1,608 @@
+/*
+ * orc_leaf.c — leaf operators of the oracle (TEST INFRASTRUCTURE ONLY, see vvc_oracle.h).
+ * Plain scalar C restatement of the reference's CommonLib operators on the intra RDO path.
+ */
+#include "vvc_oracle.h"
+#include "orc_tables.h"
+#include "orc_internal.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * Transforms.  The reference's partial-butterfly kernels (CL/TrQuant_EMT.cpp:51-1653) are exact
+ * factorisations of the integer matrices in CL/RomTr.cpp, so dst[k*line+j] = (sum_i M[k][i]*src[j*n+i]
+ * + rnd) >> shift is bit-identical (checked against oracle/_ref for every size in tests/golden).
+ * ---------------------------------------------------------------------------------------------- */
+const int8_t *orc_tr_matrix(int tr, int n)
+{
+  switch (tr * 100 + n) {
+    case 2: return ORC_DCT2_2; case 4: return ORC_DCT2_4; case 8: return ORC_DCT2_8; case 16: return ORC_DCT2_16;
+    case 32: return ORC_DCT2_32; case 64: return ORC_DCT2_64;
+    case 104: return ORC_DCT8_4; case 108: return ORC_DCT8_8; case 116: return ORC_DCT8_16; case 132: return ORC_DCT8_32;
+    case 204: return ORC_DST7_4; case 208: return ORC_DST7_8; case 216: return ORC_DST7_16; case 232: return ORC_DST7_32;
+  }
+  return 0;
+}
+
+/* CL/TrQuant_EMT.cpp:51 fastForwardDCT2_B4 ... (signature src,dst,shift,line,iSkipLine,iSkipLine2):
+ * the last skip1 lines are not computed and read back as zero, the last skip2 coefficients are zero. */
+void orc_fwd_1d(int tr, int n, const int *src, int *dst, int shift, int line, int skip1, int skip2)
+{
+  const int8_t *m = orc_tr_matrix(tr, n);
+  const int rnd = shift > 0 ? 1 << (shift - 1) : 0;
+  const int red = line - skip1, cut = n - skip2;
+  for (int k = 0; k < n; k++)
+    for (int j = 0; j < line; j++) {
+      int v = 0;
+      if (j < red && k < cut) {
+        int s = 0;
+        for (int i = 0; i < n; i++) s += m[k * n + i] * src[j * n + i];
+        v = (s + rnd) >> shift;
+      }
+      dst[k * line + j] = v;
+    }
+}
+
+/* CL/TrQuant_EMT.cpp:85 fastInverseDCT2_B4 ...: dst[j*n+i] = clip((sum_k M[k][i]*src[k*line+j]+rnd)>>shift) */
+void orc_inv_1d(int tr, int n, const int *src, int *dst, int shift, int line, int skip1, int skip2, int cmin, int cmax)
+{
+  const int8_t *m = orc_tr_matrix(tr, n);
+  const int rnd = 1 << (shift - 1);
+  const int red = line - skip1, cut = n - skip2;
+  for (int j = 0; j < line; j++)
+    for (int i = 0; i < n; i++) {
+      int v = 0;
+      if (j < red) {
+        int s = 0;
+        for (int k = 0; k < cut; k++) s += m[k * n + i] * src[k * line + j];
+        v = (s + rnd) >> shift;
+        v = v < cmin ? cmin : v > cmax ? cmax : v;
+      }
+      dst[j * n + i] = v;
+    }
+}
+
+static int ilog2(int v) { int r = 0; while (v > 1) { v >>= 1; r++; } return r; }
+
+/* CL/TrQuant.cpp:835-915 xT, DCT2/DCT2, no LFNST: zero-out above 32 (853-854), shifts 892-893 */
+void orc_fwd_2d(const int16_t *resi, int stride, int w, int h, int bit_depth, int *coef)
+{
+  int *block = (int *) malloc(sizeof(int) * w * h * 2), *tmp = block + w * h;
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) block[y * w + x] = resi[y * stride + x];
+  const int skipW = w > 32 ? w - 32 : 0, skipH = h > 32 ? h - 32 : 0;
+  const int shift1 = ilog2(w) + bit_depth + 6 - 15;
+  const int shift2 = ilog2(h) + 6;
+  orc_fwd_1d(0, w, block, tmp, shift1, h, 0, skipW);
+  orc_fwd_1d(0, h, tmp, coef, shift2, w, skipW, skipH);
+  free(block);
+}
+
+/* CL/TrQuant.cpp:917-992 xIT */
+void orc_inv_2d(const int *coef, int w, int h, int bit_depth, int16_t *resi, int stride)
+{
+  int *tmp = (int *) malloc(sizeof(int) * w * h * 2), *block = tmp + w * h;
+  const int skipW = w > 32 ? w - 32 : 0, skipH = h > 32 ? h - 32 : 0;
+  const int cmin = -(1 << 15), cmax = (1 << 15) - 1;
+  const int shift1 = 6 + 1, shift2 = (6 + 15 - 1) - bit_depth;
+  orc_inv_1d(0, h, coef, tmp, shift1, w, skipW, skipH, cmin, cmax);
+  orc_inv_1d(0, w, tmp, block, shift2, h, 0, skipW, cmin, cmax);
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) resi[y * stride + x] = (int16_t) block[y * w + x];
+  free(tmp);
+}
+
+/* CL/Quant.cpp:994-1089 Quant::quant without scaling lists / sign hiding; I-slice rounding 171<<(qbits-9).
+ * returns uiAbsSum */
+int orc_quant(const int *coef, int w, int h, int bit_depth, int qp, int16_t *level)
+{
+  const int lw = ilog2(w), lh = ilog2(h);
+  const int need_sqrt = (lw + lh) & 1;                         /* CL/UnitTools.cpp:4650-4660 */
+  const int scale = ORC_QUANT_SCALES[need_sqrt * 6 + qp % 6];
+  const int tr_shift = 15 - bit_depth - ((lw + lh) >> 1) + (need_sqrt ? -1 : 0);   /* CL/Quant.h getTransformShift */
+  const int qbits = 14 + qp / 6 + tr_shift;
+  const int64_t add = (int64_t) 171 << (qbits - 9);
+  int abs_sum = 0;
+  for (int i = 0; i < w * h; i++) {
+    const int c = coef[i];
+    const int64_t t = (int64_t) (c < 0 ? -c : c) * scale;
+    int q = (int) ((t + add) >> qbits);
+    abs_sum += q;
+    if (c < 0) q = -q;
+    q = q < -32768 ? -32768 : q > 32767 ? 32767 : q;
+    level[i] = (int16_t) q;
+  }
+  return abs_sum;
+}
+
+/* CL/Quant.cpp:423-549 Quant::dequant, flat scaling */
+void orc_dequant(const int16_t *level, int w, int h, int bit_depth, int qp, int *coef)
+{
+  const int lw = ilog2(w), lh = ilog2(h);
+  const int need_sqrt = (lw + lh) & 1;
+  const int scale = ORC_INV_QUANT_SCALES[need_sqrt * 6 + qp % 6];
+  const int tr_shift = 15 - bit_depth - ((lw + lh) >> 1) + (need_sqrt ? -1 : 0);
+  const int right_shift = 6 - (tr_shift + qp / 6);
+  const int scale_bits = 6 + 1;
+  int tbd = 32 + right_shift - scale_bits; if (tbd > 16) tbd = 16;
+  const int in_min = -(1 << (tbd - 1)), in_max = (1 << (tbd - 1)) - 1;
+  for (int i = 0; i < w * h; i++) {
+    int q = level[i]; q = q < in_min ? in_min : q > in_max ? in_max : q;
+    int v;
+    if (right_shift > 0) v = (q * scale + (1 << (right_shift - 1))) >> right_shift;
+    else v = (q * scale) << (-right_shift);
+    coef[i] = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Distortion: CL/RdCost.cpp xGetSAD (generic), xGetSSE, xGetHADs 2746-2861 and its kernels.
+ * ---------------------------------------------------------------------------------------------- */
+uint64_t orc_sad(const int16_t *a, int sa, const int16_t *b, int sb, int w, int h)
+{
+  uint64_t s = 0;
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) s += (uint64_t) abs(a[y * sa + x] - b[y * sb + x]);
+  return s;
+}
+uint64_t orc_sse(const int16_t *a, int sa, const int16_t *b, int sb, int w, int h)
+{
+  uint64_t s = 0;
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) { const int d = a[y * sa + x] - b[y * sb + x]; s += (uint64_t) (d * d); }
+  return s;
+}
+/* Walsh-Hadamard of a bw x bh tile of differences: sum of absolute transform coefficients.  The
+ * reference's butterflies (xCalcHADs4x4 2118, 8x8 2214, 16x8 2311, 8x16 2457, 4x8 2593, 8x4 2667)
+ * compute the same coefficient set in another order; the normalisation per tile shape is the
+ * reference's: 4x4 (s+1)>>1 (2209), 8x8 (s+2)>>2 (2306), non-square (int)(s/sqrt(bw*bh)*2) (2452...). */
+static uint64_t had_tile(const int16_t *a, int sa, const int16_t *b, int sb, int bw, int bh)
+{
+  int m[16 * 16];
+  for (int y = 0; y < bh; y++) for (int x = 0; x < bw; x++) m[y * bw + x] = a[y * sa + x] - b[y * sb + x];
+  for (int y = 0; y < bh; y++)
+    for (int len = 1; len < bw; len <<= 1)
+      for (int i = 0; i < bw; i += 2 * len)
+        for (int j = i; j < i + len; j++) { int p = m[y * bw + j], q = m[y * bw + j + len]; m[y * bw + j] = p + q; m[y * bw + j + len] = p - q; }
+  for (int x = 0; x < bw; x++)
+    for (int len = 1; len < bh; len <<= 1)
+      for (int i = 0; i < bh; i += 2 * len)
+        for (int j = i; j < i + len; j++) { int p = m[j * bw + x], q = m[(j + len) * bw + x]; m[j * bw + x] = p + q; m[(j + len) * bw + x] = p - q; }
+  int s = 0;
+  for (int i = 0; i < bw * bh; i++) s += abs(m[i]);
+  if (bw == 2 && bh == 2) return (uint64_t) s;                 /* 2110-2115: no normalisation */
+  if (bw == 4 && bh == 4) return (uint64_t) ((s + 1) >> 1);
+  if (bw == 8 && bh == 8) return (uint64_t) ((s + 2) >> 2);
+  return (uint64_t) (int) (s / sqrt((double) bw * bh) * 2);
+}
+void orc_satd_tile_shape(int w, int h, int *bw, int *bh)
+{
+  if (w > h && (h & 7) == 0 && (w & 15) == 0) { *bw = 16; *bh = 8; }
+  else if (w < h && (w & 7) == 0 && (h & 15) == 0) { *bw = 8; *bh = 16; }
+  else if (w > h && (h & 3) == 0 && (w & 7) == 0) { *bw = 8; *bh = 4; }
+  else if (w < h && (w & 3) == 0 && (h & 7) == 0) { *bw = 4; *bh = 8; }
+  else if ((h & 7) == 0 && (w & 7) == 0) { *bw = 8; *bh = 8; }
+  else if ((h & 3) == 0 && (w & 3) == 0) { *bw = 4; *bh = 4; }
+  else { *bw = 2; *bh = 2; }
+}
+uint64_t orc_satd(const int16_t *a, int sa, const int16_t *b, int sb, int w, int h)
+{
+  int bw, bh; orc_satd_tile_shape(w, h, &bw, &bh);
+  uint64_t s = 0;
+  for (int y = 0; y < h; y += bh) for (int x = 0; x < w; x += bw) s += had_tile(a + y * sa + x, sa, b + y * sb + x, sb, bw, bh);
+  return s;
+}
+
+/* CL/RdCost.cpp:63-88: DistScale = 2^15/lambda ; cost = DistScale*double(dist) + double(fracBits) */
+double orc_calc_rd_cost(double lambda, uint64_t frac_bits, uint64_t dist)
+{
+  const double dist_scale = (double) (1 << 15) / lambda;
+  const double a = dist_scale * (double) dist;
+  return a + (double) frac_bits;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CABAC probability model: CL/Contexts.h:86-155, CL/Contexts.cpp:135-151 (JVET_O0065 init), 1818-1833
+ * ---------------------------------------------------------------------------------------------- */
+void orc_ctx_init(int qp, uint16_t *s0, uint16_t *s1)
+{
+  if (qp < 0) qp = 0;
+  if (qp > 63) qp = 63;
+  for (int k = 0; k < ORC_NUM_CTX; k++) {
+    const int id = ORC_CTX_INIT_I[k];
+    const int slope = (id >> 3) - 4, offset = ((id & 7) * 18) + 1;
+    int st = ((slope * (qp - 16)) >> 1) + offset;
+    st = st < 1 ? 1 : st > 127 ? 127 : st;
+    const int p1 = st << 8;
+    s0[k] = (uint16_t) (p1 & 0x7FE0);
+    s1[k] = (uint16_t) (p1 & 0x7FFE);
+  }
+}
+uint64_t orc_ctx_code_bins(uint16_t *s0, uint16_t *s1, int ctx_id, const uint8_t *bins, int n)
+{
+  orc_cabac c; memset(&c, 0, sizeof c);
+  c.s0[ctx_id] = *s0; c.s1[ctx_id] = *s1;
+  for (int i = 0; i < n; i++) orc_enc_bin(&c, bins[i], ctx_id);
+  *s0 = c.s0[ctx_id]; *s1 = c.s1[ctx_id];
+  return c.bits;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Reference samples: CL/IntraPrediction.cpp:1215-1468 xFillReferenceSamples.  Layout of the output
+ * like m_piYuvExt: stride = 2w+1+mrl, row 0 = top-left + above row, column 0 = left column.
+ * Availability of a neighbouring unit (isAbove/Left/...Available 1524-1663 → cs.isDecomp +
+ * getCURestricted) is supplied as a byte map `avail` with one entry per (1<<unit_log2)^2 samples of
+ * this component: value == tag ⇔ already coded in the current partition path, same slice and tile
+ * (the tag is tile id + 1, so other tiles' samples read as unavailable).
+ * ---------------------------------------------------------------------------------------------- */
+static int unit_avail(const uint8_t *avail, int avail_stride, int unit_log2, int pic_w, int pic_h, int px, int py, int tag)
+{
+  if (px < 0 || py < 0 || px >= pic_w || py >= pic_h) return 0;
+  return avail[(py >> unit_log2) * avail_stride + (px >> unit_log2)] == tag;
+}
+
+void orc_fill_ref_samples(const int16_t *reco, int stride, int pic_w, int pic_h, const uint8_t *avail, int avail_stride,
+                          int unit_log2, int tag, int x, int y, int w, int h, int mrl, int bit_depth, int16_t *ref)
+{
+  const int predSize = 2 * w, predHSize = 2 * h;
+  const int predStride = predSize + 1 + mrl;
+  /* unit size: pcv.minCUWidth (4) for luma, >>1 for 4:2:0 chroma (1239-1240); the caller passes the
+   * granularity of its availability map, the unit size follows the reference */
+  const int unitW = unit_log2 == 2 ? 4 : 2, unitH = unitW;
+  const int totalAbove = (predSize + unitW - 1) / unitW, totalLeft = (predHSize + unitH - 1) / unitH;
+  const int totalUnits = totalAbove + totalLeft + 1;
+  const int numAbove = w / unitW > 1 ? w / unitW : 1, numLeft = h / unitH > 1 ? h / unitH : 1;
+  const int numAboveRight = totalAbove - numAbove, numLeftBelow = totalLeft - numLeft;
+  uint8_t flags[4 * 32 + 1 + 64];
+  memset(flags, 0, sizeof flags);
+  int numIntra = 0;
+  /* the availability map is indexed in 4x4 (luma) or 4x4-chroma units by the caller: chroma units of 2
+   * samples share the entry of their enclosing 4x4 chroma block */
+  const int alog = unit_log2;
+#define AV(px, py) unit_avail(avail, avail_stride, alog, pic_w, pic_h, (px), (py), tag)
+  flags[totalLeft] = (uint8_t) AV(x - 1, y - 1);
+  numIntra += flags[totalLeft];
+  for (int i = 0; i < numAbove; i++) { if (!AV(x + i * unitW, y - 1)) break; flags[totalLeft + 1 + i] = 1; numIntra++; }
+  for (int i = 0; i < numAboveRight; i++) { if (!AV(x + w - 1 + unitW + i * unitW, y - 1)) break; flags[totalLeft + 1 + numAbove + i] = 1; numIntra++; }
+  for (int i = 0; i < numLeft; i++) { if (!AV(x - 1, y + i * unitH)) break; flags[totalLeft - 1 - i] = 1; numIntra++; }
+  for (int i = 0; i < numLeftBelow; i++) { if (!AV(x - 1, y + h - 1 + unitH + i * unitH)) break; flags[totalLeft - 1 - numLeft - i] = 1; numIntra++; }
+#undef AV
+  const int16_t *src = reco + y * stride + x;
+  const int16_t dc = (int16_t) (1 << (bit_depth - 1));
+  if (numIntra == 0) {
+    for (int j = 0; j <= predSize + mrl; j++) ref[j] = dc;
+    for (int i = 1; i <= predHSize + mrl; i++) ref[i * predStride] = dc;
+  } else if (numIntra == totalUnits) {
+    const int16_t *p = src - (1 + mrl) * stride - (1 + mrl);
+    for (int j = 0; j <= predSize + mrl; j++) ref[j] = p[j];
+    p = src - mrl * stride - (1 + mrl);
+    for (int i = 1; i <= predHSize + mrl; i++) { ref[i * predStride] = *p; p += stride; }
+  } else {
+    const int16_t *p = src - (1 + mrl) * stride - (1 + mrl);
+    int16_t *d = ref;
+    if (flags[totalLeft]) {
+      d[0] = p[0];
+      for (int i = 1; i <= mrl; i++) { d[i] = p[i]; d[i * predStride] = p[i * stride]; }
+    }
+    p += (1 + mrl) * stride; d += (1 + mrl) * predStride;
+    for (int u = totalLeft - 1; u > 0; u--) {
+      if (flags[u]) for (int i = 0; i < unitH; i++) d[i * predStride] = p[i * stride];
+      p += unitH * stride; d += unitH * predStride;
+    }
+    if (flags[0]) {
+      const int last = (predHSize % unitH == 0) ? unitH : predHSize % unitH;
+      for (int i = 0; i < last; i++) d[i * predStride] = p[i * stride];
+    }
+    p = src - stride * (1 + mrl); d = ref + 1 + mrl;
+    for (int u = totalLeft + 1; u < totalUnits - 1; u++) {
+      if (flags[u]) for (int j = 0; j < unitW; j++) d[j] = p[j];
+      p += unitW; d += unitW;
+    }
+    if (flags[totalUnits - 1]) {
+      const int last = (predSize % unitW == 0) ? unitW : predSize % unitW;
+      for (int j = 0; j < last; j++) d[j] = p[j];
+    }
+    /* pad unavailable (1359-1458) */
+    d = ref;
+    int lastAvail = 0;
+    if (!flags[0]) {
+      int first = 1;
+      while (first < totalUnits && !flags[first]) first++;
+      int row = 0, col = 0;
+      if (first < totalLeft) row = (totalLeft - first) * unitH + mrl;
+      else if (first == totalLeft) row = mrl;
+      else col = (first - totalLeft - 1) * unitW + 1 + mrl;
+      const int16_t v = d[col + row * predStride];
+      for (int i = predHSize + mrl; i > row; i--) d[i * predStride] = v;
+      for (int j = 0; j < col; j++) d[j] = v;
+      lastAvail = first;
+    }
+    int cur = lastAvail + 1;
+    while (cur < totalUnits) {
+      if (!flags[cur]) {
+        int row = 0, col = 0;
+        if (lastAvail < totalLeft) row = (totalLeft - lastAvail - 1) * unitH + mrl + 1;
+        else if (lastAvail == totalLeft) col = mrl;
+        else col = (lastAvail - totalLeft) * unitW + mrl;
+        const int16_t v = d[col + row * predStride];
+        if (cur < totalLeft) {
+          for (int i = row - 1; i >= row - unitH; i--) d[i * predStride] = v;
+        } else if (cur == totalLeft) {
+          for (int i = 1; i < mrl + 1; i++) d[i * predStride] = v;
+          for (int j = 0; j < mrl + 1; j++) d[j] = v;
+        } else {
+          const int n = (cur == totalUnits - 1) ? ((predSize % unitW == 0) ? unitW : predSize % unitW) : unitW;
+          for (int j = col + 1; j <= col + n; j++) d[j] = v;
+        }
+      }
+      lastAvail = cur;
+      cur++;
+    }
+  }
+}
+
+/* CL/IntraPrediction.cpp:1470-1522 xFilterReferenceSamples ([1 2 1]/4) */
+void orc_filter_ref_samples(const int16_t *unf, int16_t *flt, int w, int h, int mrl)
+{
+  const int predSize = 2 * w + mrl, predHSize = 2 * h + mrl;
+  const int st = predSize + 1;
+  const int16_t *s = unf + st * predHSize;
+  int16_t *d = flt + st * predHSize;
+  *d = *s; d -= st; s -= st;
+  for (int i = 1; i < predHSize; i++, d -= st, s -= st) *d = (int16_t) ((s[st] + 2 * s[0] + s[-st] + 2) >> 2);
+  *d = (int16_t) ((s[st] + 2 * s[0] + s[1] + 2) >> 2);
+  d++; s++;
+  for (int i = 1; i < predSize; i++, d++, s++) *d = (int16_t) ((s[1] + 2 * s[0] + s[-1] + 2) >> 2);
+  *d = *s;
+}
+
+/* CL/IntraPrediction.cpp:76 g_intraGaussFilter (VVC spec table 8-? fG), data */
+static const int8_t gauss_filter[32][4] = {
+  {16,32,16,0},{15,29,17,3},{15,29,17,3},{14,29,18,3},{13,29,18,4},{13,28,19,4},{13,28,19,4},{12,28,20,4},
+  {11,28,20,5},{11,27,21,5},{10,27,22,5},{9,27,22,6},{9,26,23,6},{9,26,23,6},{8,25,24,7},{8,25,24,7},
+  {8,24,24,8},{7,24,25,8},{7,24,25,8},{6,23,26,9},{6,23,26,9},{6,22,27,9},{5,22,27,10},{5,21,27,11},
+  {5,20,28,11},{4,20,28,12},{4,19,28,13},{4,19,28,13},{4,18,29,13},{3,18,29,14},{3,17,29,15},{3,17,29,15} };
+static const int16_t ang_table[32] = { 0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 39, 45, 51, 57, 64, 73, 86, 102, 128, 171, 256, 341, 512, 1024 };
+static const int16_t inv_ang_table[32] = { 0, 16384, 8192, 5461, 4096, 2731, 2048, 1638, 1365, 1170, 1024, 910, 819, 712, 630, 565,
+  512, 468, 420, 364, 321, 287, 256, 224, 191, 161, 128, 96, 64, 48, 32, 16 };
+static const uint8_t intra_filter_thr[8] = { 24, 24, 24, 14, 2, 0, 0, 0 };  /* m_aucIntraFilter 58-74 */
+
+/* CL/IntraPrediction.cpp:287-303 getWideAngle + 487-618 initPredIntraParams (no ISP/MIP/BDPCM) */
+void orc_init_pred_params(int w, int h, int is_luma, int mode, int mrl, orc_ipa *p)
+{
+  int pm = mode;
+  if (pm > ORC_DC && pm <= ORC_VDIA) {
+    static const int modeShift[] = { 0, 6, 10, 12, 14, 15 };
+    const int ds = abs(ilog2(w) - ilog2(h));
+    if (w > h && pm < 2 + modeShift[ds]) pm += ORC_VDIA - 1;
+    else if (h > w && pm > ORC_VDIA - modeShift[ds]) pm -= ORC_VDIA - 1;
+  }
+  p->pred_mode = pm;
+  p->is_ver = pm >= ORC_DIA;
+  p->mrl = is_luma ? mrl : 0;
+  p->ref_filter = 0; p->interp = 0;
+  p->pdpc = ((w >= 4 && h >= 4) || !is_luma) && p->mrl == 0;
+  p->angle = 0; p->inv_angle = 0; p->ang_scale = -1;
+  const int am = p->is_ver ? pm - ORC_VER : -(pm - ORC_HOR);
+  int absAng = 0;
+  if (mode > ORC_DC && mode < ORC_NUM_LUMA_MODE) {
+    const int a = abs(am);
+    absAng = ang_table[a];
+    p->inv_angle = inv_ang_table[a];
+    p->angle = am < 0 ? -absAng : absAng;
+    if (am < 0) p->pdpc = 0;
+    else if (am > 0) {
+      const int side = p->is_ver ? h : w;
+      int sc = ilog2(side) - (ilog2(3 * p->inv_angle - 2) - 8);
+      if (sc > 2) sc = 2;
+      p->ang_scale = sc;
+      p->pdpc &= sc >= 0;
+    }
+  }
+  if (!is_luma || p->mrl || mode == ORC_DC) { /* no ref filter (559-575) */ }
+  else if (mode == ORC_PLANAR) p->ref_filter = w * h > 32;
+  else {
+    const int d1 = abs(pm - ORC_HOR), d2 = abs(pm - ORC_VER);
+    const int diff = d1 < d2 ? d1 : d2;
+    const int log2Size = (ilog2(w) + ilog2(h)) >> 1;
+    if (diff > intra_filter_thr[log2Size]) {
+      const int is_int = (absAng & 0x1F) == 0;          /* isIntegerSlope */
+      p->ref_filter = is_int;
+      p->interp = !is_int;
+    }
+  }
+}
+
+static int16_t clip_pel(int v, int bit_depth) { const int mx = (1 << bit_depth) - 1; return (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
+
+/* CL/IntraPrediction.cpp:316-398 predIntraAng (dispatch + planar/DC PDPC), 426-479 planar,
+ * 248-285/480 DC, 633-935 xPredIntraAng */
+void orc_pred_intra(const int16_t *ref_unf, const int16_t *ref_flt, int w, int h, int is_luma, int mode, int mrl,
+                    int bit_depth, int16_t *pred, int ps)
+{
+  orc_ipa ip; orc_init_pred_params(w, h, is_luma, mode, mrl, &ip);
+  mrl = ip.mrl;
+  const int16_t *src = ip.ref_filter ? ref_flt : ref_unf;
+  const int st = 2 * w + 1 + mrl;
+#define TOP(i) src[(i)]
+#define LEFT(i) src[(i) * st]
+  if (mode == ORC_PLANAR) {
+    int leftCol[ORC_MAX_CU + 1], topRow[ORC_MAX_CU + 1], bottomRow[ORC_MAX_CU], rightCol[ORC_MAX_CU];
+    const int l2w = ilog2(w), l2h = ilog2(h);
+    for (int k = 0; k < w + 1; k++) topRow[k] = TOP(k + 1);
+    for (int k = 0; k < h + 1; k++) leftCol[k] = LEFT(k + 1);
+    const int bl = leftCol[h], tr = topRow[w];
+    for (int k = 0; k < w; k++) { bottomRow[k] = bl - topRow[k]; topRow[k] <<= l2h; }
+    for (int k = 0; k < h; k++) { rightCol[k] = tr - leftCol[k]; leftCol[k] <<= l2w; }
+    const int fs = 1 + l2w + l2h, off = 1 << (l2w + l2h);
+    for (int y = 0; y < h; y++) {
+      int hp = leftCol[y];
+      for (int x = 0; x < w; x++) {
+        hp += rightCol[y]; topRow[x] += bottomRow[x];
+        pred[y * ps + x] = (int16_t) (((hp << l2h) + (topRow[x] << l2w) + off) >> fs);
+      }
+    }
+  } else if (mode == ORC_DC) {
+    int sum = 0;
+    const int denom = (w == h) ? (w << 1) : (w > h ? w : h);
+    if (w >= h) for (int i = 0; i < w; i++) sum += TOP(mrl + 1 + i);
+    if (w <= h) for (int i = 0; i < h; i++) sum += LEFT(mrl + 1 + i);
+    const int16_t dcv = (int16_t) ((sum + (denom >> 1)) >> ilog2(denom));
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) pred[y * ps + x] = dcv;
+  } else {
+    int16_t refAbove[2 * ORC_MAX_CU + 3 + 33 * 3], refLeft[2 * ORC_MAX_CU + 3 + 33 * 3];
+    int16_t *refMain, *refSide;
+    const int ang = ip.angle, inv = ip.inv_angle, ver = ip.is_ver;
+    int W = w, H = h;
+    if (ang < 0) {
+      for (int x = 0; x <= w + 1 + mrl; x++) refAbove[x + h] = TOP(x);
+      for (int y = 0; y <= h + 1 + mrl; y++) refLeft[y + w] = LEFT(y);
+      refMain = ver ? refAbove + h : refLeft + w;
+      refSide = ver ? refLeft + w : refAbove + h;
+      const int sizeSide = ver ? h : w;
+      for (int k = -sizeSide; k <= -1; k++) { int idx = (-k * inv + 256) >> 9; if (idx > sizeSide) idx = sizeSide; refMain[k] = refSide[idx]; }
+    } else {
+      for (int x = 0; x <= 2 * w + mrl; x++) refAbove[x] = TOP(x);
+      for (int y = 0; y <= 2 * h + mrl; y++) refLeft[y] = LEFT(y);
+      refMain = ver ? refAbove : refLeft;
+      refSide = ver ? refLeft : refAbove;
+      const int lr = ilog2(w) - ilog2(h);
+      int s = ver ? lr : -lr; if (s < 0) s = 0;
+      const int maxIndex = (mrl << s) + 2;
+      const int refLength = ver ? 2 * w : 2 * h;
+      const int16_t val = refMain[refLength + mrl];
+      for (int z = 1; z <= maxIndex; z++) refMain[refLength + mrl + z] = val;
+    }
+    int16_t tmp[ORC_MAX_CU * ORC_MAX_CU];
+    int16_t *dst = ver ? pred : tmp;
+    const int ds = ver ? ps : ORC_MAX_CU;
+    if (!ver) { W = h; H = w; }
+    refMain += mrl; refSide += mrl;
+    if (ang == 0) {
+      for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) dst[y * ds + x] = refMain[x + 1];
+        if (ip.pdpc) {
+          const int scale = (ilog2(W) + ilog2(H) - 2) >> 2;
+          const int16_t topLeft = refMain[0], left = refSide[1 + y];
+          const int lim = (3 << scale) < W ? (3 << scale) : W;
+          for (int x = 0; x < lim; x++) {
+            const int wL = 32 >> (2 * x >> scale);
+            const int16_t val = dst[y * ds + x];
+            dst[y * ds + x] = clip_pel(val + ((wL * (left - topLeft) + 32) >> 6), bit_depth);
+          }
+        }
+      }
+    } else {
+      const int is_int = (abs(ang) & 0x1F) == 0;
+      for (int y = 0, deltaPos = ang * (1 + mrl); y < H; y++, deltaPos += ang) {
+        const int di = deltaPos >> 5, df = deltaPos & 31;
+        int16_t *row = dst + y * ds;
+        if (!is_int) {
+          if (is_luma) {
+            const int8_t *f = ip.interp ? gauss_filter[df] : &ORC_CUBIC_FILTER[df * 4];
+            for (int x = 0; x < W; x++) {
+              const int v = (f[0] * refMain[di + x] + f[1] * refMain[di + x + 1] + f[2] * refMain[di + x + 2] + f[3] * refMain[di + x + 3] + 32) >> 6;
+              row[x] = clip_pel((int16_t) v, bit_depth);
+            }
+          } else {
+            for (int x = 0; x < W; x++) {
+              const int p0 = refMain[di + x + 1], p1 = refMain[di + x + 2];
+              row[x] = (int16_t) (p0 + ((df * (p1 - p0) + 16) >> 5));
+            }
+          }
+        } else for (int x = 0; x < W; x++) row[x] = refMain[x + di + 1];
+        if (ip.pdpc) {
+          const int scale = ip.ang_scale;
+          int invSum = 256;
+          const int lim = (3 << scale) < W ? (3 << scale) : W;
+          for (int x = 0; x < lim; x++) {
+            invSum += inv;
+            const int wL = 32 >> (2 * x >> scale);
+            const int16_t left = refSide[y + (invSum >> 9) + 1];
+            row[x] = (int16_t) (row[x] + ((wL * (left - row[x]) + 32) >> 6));
+          }
+        }
+      }
+    }
+    if (!ver) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) pred[x * ps + y] = dst[y * ds + x];
+  }
+  /* PDPC for planar / DC (354-378) */
+  if (ip.pdpc && (mode == ORC_PLANAR || mode == ORC_DC)) {
+    const int scale = (ilog2(w) - 2 + ilog2(h) - 2 + 2) >> 2;
+    for (int y = 0; y < h; y++) {
+      int sh = (y << 1) >> scale; if (sh > 31) sh = 31;
+      const int wT = 32 >> sh;
+      const int16_t left = LEFT(y + 1);
+      for (int x = 0; x < w; x++) {
+        int shx = (x << 1) >> scale; if (shx > 31) shx = 31;
+        const int wL = 32 >> shx;
+        const int16_t top = TOP(x + 1), val = pred[y * ps + x];
+        pred[y * ps + x] = (int16_t) (val + ((wL * (left - val) + wT * (top - val) + 32) >> 6));
+      }
+    }
+  }
+#undef TOP
+#undef LEFT
+}
+
+/* CL/UnitTools.cpp:508-640 PU::getIntraMPMs given the two neighbour directions */
+void orc_get_mpms(int L, int A, unsigned mpm[6])
+{
+  const int offset = 61, mod = 64;
+  mpm[0] = ORC_PLANAR; mpm[1] = ORC_DC; mpm[2] = ORC_VER; mpm[3] = ORC_HOR; mpm[4] = ORC_VER - 4; mpm[5] = ORC_VER + 4;
+  if (L == A) {
+    if (L > ORC_DC) {
+      mpm[0] = ORC_PLANAR; mpm[1] = L;
+      mpm[2] = ((L + offset) % mod) + 2; mpm[3] = ((L - 1) % mod) + 2;
+      mpm[4] = ((L + offset - 1) % mod) + 2; mpm[5] = (L % mod) + 2;
+    }
+  } else if (L > ORC_DC && A > ORC_DC) {
+    mpm[0] = ORC_PLANAR; mpm[1] = L; mpm[2] = A;
+    const int mx = mpm[1] > mpm[2] ? 1 : 2, mn = mpm[1] > mpm[2] ? 2 : 1;
+    const int d = (int) mpm[mx] - (int) mpm[mn];
+    if (d == 1) { mpm[3] = ((mpm[mn] + offset) % mod) + 2; mpm[4] = ((mpm[mx] - 1) % mod) + 2; mpm[5] = ((mpm[mn] + offset - 1) % mod) + 2; }
+    else if (d >= 62) { mpm[3] = ((mpm[mn] - 1) % mod) + 2; mpm[4] = ((mpm[mx] + offset) % mod) + 2; mpm[5] = (mpm[mn] % mod) + 2; }
+    else if (d == 2) { mpm[3] = ((mpm[mn] - 1) % mod) + 2; mpm[4] = ((mpm[mn] + offset) % mod) + 2; mpm[5] = ((mpm[mx] - 1) % mod) + 2; }
+    else { mpm[3] = ((mpm[mn] + offset) % mod) + 2; mpm[4] = ((mpm[mn] - 1) % mod) + 2; mpm[5] = ((mpm[mx] + offset) % mod) + 2; }
+  } else if (L + A >= 2) {
+    mpm[0] = ORC_PLANAR; mpm[1] = (unsigned) (L < A ? A : L);
+    mpm[2] = ((mpm[1] + offset) % mod) + 2; mpm[3] = ((mpm[1] - 1) % mod) + 2;
+    mpm[4] = ((mpm[1] + offset - 1) % mod) + 2; mpm[5] = (mpm[1] % mod) + 2;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Scan order: CL/Rom.cpp:87-131 ScanGenerator (SCAN_DIAG) and 319-370 grouped 4x4 scan over the
+ * min(32,w) x min(32,h) region.  Returns number of real scan positions.
+ * ---------------------------------------------------------------------------------------------- */
+static int diag_scan(int bw, int bh, uint8_t *xs, uint8_t *ys)
+{
+  int line = 0, col = 0, n = 0;
+  for (; n < bw * bh; n++) {
+    xs[n] = (uint8_t) col; ys[n] = (uint8_t) line;
+    if (col == bw - 1 || line == 0) {
+      line += col + 1; col = 0;
+      if (line >= bh) { col += line - (bh - 1); line = bh - 1; }
+    } else { col++; line--; }
+  }
+  return n;
+}
+/* g_log2SbbSize (CL/Rom.cpp:250-261): coefficient-group shape by log2 block size, data */
+void orc_cg_shape(int w, int h, int *lcw, int *lch)
+{
+  const int lw = ilog2(w), lh = ilog2(h);
+  if (lw >= 2 && lh >= 2) { *lcw = 2; *lch = 2; return; }
+  if (lh == 1) { *lcw = lw >= 3 ? 3 : lw; *lch = 1; if (lw == 2) *lcw = 1; return; }   /* Nx2: {1,1} for 4x2, {3,1} for >=8 */
+  /* 2xN (not reachable in 4:2:0 dual tree) */
+  *lcw = 1; *lch = lh >= 3 ? 3 : lh; if (lh == 2) *lch = 1;
+}
+int orc_scan_order(int w, int h, uint16_t *idx)
+{
+  int lcw, lch; orc_cg_shape(w, h, &lcw, &lch);
+  const int zw = w < 32 ? w : 32, zh = h < 32 ? h : 32;
+  const int gw = zw >> lcw, gh = zh >> lch, cw = 1 << lcw, ch = 1 << lch;
+  uint8_t gx[64], gy[64], ix[16], iy[16];
+  diag_scan(gw, gh, gx, gy);
+  diag_scan(cw, ch, ix, iy);
+  int n = 0;
+  for (int g = 0; g < gw * gh; g++)
+    for (int i = 0; i < cw * ch; i++) idx[n++] = (uint16_t) ((gy[g] * ch + iy[i]) * w + gx[g] * cw + ix[i]);
+  return n;
+}

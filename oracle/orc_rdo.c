@@ -1,0 +1,1014 @@
+/*
+ * orc_rdo.c — recursion level of the oracle (TEST INFRASTRUCTURE ONLY, see vvc_oracle.h).
+ *
+ * Sequential, depth-first restatement of
+ *   EL/EncCu.cpp        compressCtu 428, xCompressCU 727, xCheckModeSplit 1918, xCheckRDCostIntra 2402,
+ *                       xCheckBestMode 677, xEncodeDontSplit 5649
+ *   EL/EncModeCtrl.cpp  initCULevel 1203, tryMode 1557, useModeResult 2089, nextMode 154
+ *   EL/IntraSearch.cpp  estIntraPredLumaQT 289, xRecurIntraCodingLumaQT 3282, xIntraCodingTUBlock 2694,
+ *                       estIntraPredChromaQT 1382, xRecurIntraChromaCodingQT 3779, rate helpers 2345-2692, 4263
+ *   EL/CABACWriter.cpp  split_cu_mode 1010, intra_luma_pred_mode 1762, extend_ref_line 1566,
+ *                       intra_chroma_pred_mode 1891, cbf_comp 3400, transform_unit 3514, coding_tree 474
+ *   CL/UnitPartitioner.cpp canSplit 379, getImplicitSplit 530, splitCurrArea 278, nextPart 636
+ *   CL/ContextModelling.cpp CtxSplit 154
+ * for the tool subset "P0": all 67 angular modes + PDPC + MRL, DCT-II only, plain quantisation
+ * (RDOQ/DepQuant/sign-hiding off), no MIP/ISP/LFNST/MTS/TS/BDPCM/CCLM/JointCbCr/LMCS, dual tree,
+ * CU-result reuse (BestEncInfoCache) off.  Recursion-level parity is UNPINNED (see vvc_oracle.h).
+ */
+#include "orc_internal.h"
+#include <stdlib.h>
+#include <stdio.h>
+#include <math.h>
+
+static char g_err[256];
+const char *orc_last_error(void) { return g_err; }
+
+static int ilog2(int v) { int r = 0; while (v > 1) { v >>= 1; r++; } return r; }
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+enum { SPLIT_NONE = 0, SPLIT_QT = 1, SPLIT_BH = 2, SPLIT_BV = 3, SPLIT_TH = 4, SPLIT_TV = 5 };   /* PartSplit values, CL/UnitPartitioner.h:56-65 */
+enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V };
+
+typedef struct { int x, y, w, h; } area_t;   /* luma samples (UnitArea::Y) */
+
+typedef struct {       /* per 4x4-luma-unit record of the CU covering it, one map per channel type */
+  uint8_t valid, tile, qt_depth, mt_depth, bt_depth, depth, dir, mrl, cbf, lw, lh;
+  int16_t x, y;        /* CU origin in channel samples */
+  uint64_t split_series;
+} unit_t;
+
+typedef struct {       /* PartLevel + Partitioner (CL/UnitPartitioner.h:85-189) */
+  int split; area_t parts[4]; int nparts, idx;
+  int impl_checked, is_implicit, impl_split;
+} part_level;
+typedef struct {
+  part_level st[20]; int n;
+  int depth, qt_depth, bt_depth, mt_depth, impl_bt_depth, ch;
+  area_t cur;
+} partitioner;
+
+typedef struct {       /* what the mode controller reads from a CodingStructure */
+  double cost; uint64_t dist, bits;
+  int n_cu, is_split;
+  int f_bt, f_depth, f_mt, f_cbf, f_w, f_h;     /* cus.front() */
+  int l_bt, l_w, l_h;                            /* cus.back() */
+  int max_qt;
+} cs_sum;
+
+#define MAX_DEPTH 20
+typedef struct {       /* per recursion level: saved best reconstruction of the node */
+  int16_t *rec[3], *lev[3]; unit_t *units;
+} store_t;
+
+struct orc_enc {
+  orc_cfg cfg; orc_slice sl;
+  int wl, hl, wc, hc;                 /* plane dims */
+  int16_t *org[3], *rec[3], *lev[3];  /* original, reconstruction, quantised levels (plane layout) */
+  int stride[3];
+  unit_t *um[2]; uint8_t *avail[2]; int uw, uh;
+  int ctus_w, ctus_h; int *ctu_tile; int cur_tile;
+  orc_cabac cabac;
+  store_t store[MAX_DEPTH];
+  double sqrt_lambda_fp;              /* sqrtLambdaForFirstPass */
+  uint64_t cnt_satd, cnt_rd, cnt_rdpix, cnt_nodes;
+  /* scratch */
+  int16_t *ref_unf, *ref_flt, *pred, *resi, *tmp_rec[2], *tmp_lev[2], *best_rec[2], *best_lev[2];
+  int *coef;
+};
+
+/* ------------------------------------------------------------------------------------------------ */
+orc_enc *orc_create(const orc_cfg *cfg)
+{
+  if (cfg->tools & ~(uint32_t) ORC_TOOL_MRL) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (P0 = MRL only)", cfg->tools); return 0; }
+  if (!cfg->dual_tree || cfg->ctu_size != 128) { snprintf(g_err, sizeof g_err, "oracle: only DualITree=1, CTUSize=128"); return 0; }
+  if ((cfg->pic_w & 7) || (cfg->pic_h & 7)) { snprintf(g_err, sizeof g_err, "oracle: picture size must be a multiple of 8 (EncAppCfg.cpp:2709)"); return 0; }
+  orc_enc *e = (orc_enc *) calloc(1, sizeof *e);
+  e->cfg = *cfg;
+  e->wl = cfg->pic_w; e->hl = cfg->pic_h; e->wc = e->wl >> 1; e->hc = e->hl >> 1;
+  for (int c = 0; c < 3; c++) {
+    const int w = c ? e->wc : e->wl, h = c ? e->hc : e->hl;
+    e->stride[c] = w;
+    e->org[c] = (int16_t *) calloc((size_t) w * h, 2); e->rec[c] = (int16_t *) calloc((size_t) w * h, 2); e->lev[c] = (int16_t *) calloc((size_t) w * h, 2);
+  }
+  e->uw = (e->wl + 3) >> 2; e->uh = (e->hl + 3) >> 2;
+  for (int k = 0; k < 2; k++) { e->um[k] = (unit_t *) calloc((size_t) e->uw * e->uh, sizeof(unit_t)); e->avail[k] = (uint8_t *) calloc((size_t) e->uw * e->uh, 1); }
+  e->ctus_w = (e->wl + 127) >> 7; e->ctus_h = (e->hl + 127) >> 7;
+  e->ctu_tile = (int *) calloc((size_t) e->ctus_w * e->ctus_h, sizeof(int));
+  for (int d = 0; d < MAX_DEPTH; d++) {
+    for (int c = 0; c < 3; c++) { e->store[d].rec[c] = (int16_t *) malloc(128 * 128 * 2); e->store[d].lev[c] = (int16_t *) malloc(128 * 128 * 2); }
+    e->store[d].units = (unit_t *) malloc(32 * 32 * sizeof(unit_t));
+  }
+  e->ref_unf = (int16_t *) malloc(2 * 300 * 300); e->ref_flt = (int16_t *) malloc(2 * 300 * 300);
+  e->pred = (int16_t *) malloc(128 * 128 * 2); e->resi = (int16_t *) malloc(128 * 128 * 2); e->coef = (int *) malloc(128 * 128 * 4);
+  for (int k = 0; k < 2; k++) { e->tmp_rec[k] = (int16_t *) malloc(128 * 128 * 2); e->tmp_lev[k] = (int16_t *) malloc(128 * 128 * 2); e->best_rec[k] = (int16_t *) malloc(128 * 128 * 2); e->best_lev[k] = (int16_t *) malloc(128 * 128 * 2); }
+  return e;
+}
+void orc_destroy(orc_enc *e)
+{
+  if (!e) return;
+  for (int c = 0; c < 3; c++) { free(e->org[c]); free(e->rec[c]); free(e->lev[c]); }
+  for (int k = 0; k < 2; k++) { free(e->um[k]); free(e->avail[k]); free(e->tmp_rec[k]); free(e->tmp_lev[k]); free(e->best_rec[k]); free(e->best_lev[k]); }
+  for (int d = 0; d < MAX_DEPTH; d++) { for (int c = 0; c < 3; c++) { free(e->store[d].rec[c]); free(e->store[d].lev[c]); } free(e->store[d].units); }
+  free(e->ctu_tile); free(e->ref_unf); free(e->ref_flt); free(e->pred); free(e->resi); free(e->coef); free(e);
+}
+int orc_set_slice(orc_enc *e, const orc_slice *s)
+{
+  e->sl = *s;
+  /* EL/IntraSearch.cpp:297: getMotionLambda()*FRAC_BITS_SCALE = sqrt(lambda)/32768 (CL/RdCost.cpp:80) */
+  e->sqrt_lambda_fp = sqrt(s->lambda) * (1.0 / (double) (1 << 15));
+  return 0;
+}
+int orc_load_frame(orc_enc *e, const void *const org[3], const int stride[3], int bps)
+{
+  for (int c = 0; c < 3; c++) {
+    const int w = c ? e->wc : e->wl, h = c ? e->hc : e->hl;
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++)
+      e->org[c][y * e->stride[c] + x] = bps == 1 ? ((const uint8_t *) org[c])[y * stride[c] + x] : (int16_t) ((const uint16_t *) org[c])[y * stride[c] + x];
+    memset(e->rec[c], 0, (size_t) w * h * 2); memset(e->lev[c], 0, (size_t) w * h * 2);
+  }
+  for (int k = 0; k < 2; k++) { memset(e->um[k], 0, (size_t) e->uw * e->uh * sizeof(unit_t)); memset(e->avail[k], 0, (size_t) e->uw * e->uh); }
+  /* uniform tile grid (CL/Slice.cpp PPS uniform spacing): boundary i = i*N/T */
+  for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++) {
+    int tc = 0, tr = 0;
+    for (int i = 0; i < e->cfg.tile_cols; i++) if (rx >= (i * e->ctus_w) / e->cfg.tile_cols) tc = i;
+    for (int i = 0; i < e->cfg.tile_rows; i++) if (ry >= (i * e->ctus_h) / e->cfg.tile_rows) tr = i;
+    e->ctu_tile[ry * e->ctus_w + rx] = tr * e->cfg.tile_cols + tc;
+  }
+  return 0;
+}
+int orc_get_reco(orc_enc *e, void *const reco[3], const int stride[3], int bps)
+{
+  for (int c = 0; c < 3; c++) {
+    const int w = c ? e->wc : e->wl, h = c ? e->hc : e->hl;
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+      const int16_t v = e->rec[c][y * e->stride[c] + x];
+      if (bps == 1) ((uint8_t *) reco[c])[y * stride[c] + x] = (uint8_t) v; else ((uint16_t *) reco[c])[y * stride[c] + x] = (uint16_t) v;
+    }
+  }
+  return 0;
+}
+void orc_get_counters(orc_enc *e, uint64_t out[4]) { out[0] = e->cnt_satd; out[1] = e->cnt_rd; out[2] = e->cnt_rdpix; out[3] = e->cnt_nodes; }
+
+static double rd_cost(const orc_enc *e, uint64_t bits, uint64_t dist) { return orc_calc_rd_cost(e->sl.lambda, bits, dist); }
+
+/* ------------------------------------------------------------------------------------------------
+ * neighbour CU lookup: cs.getCU / getCURestricted reduced to "coded in the current partition path,
+ * same tile" (CL/CodingStructure.cpp:291-348,1629-1658).  px,py in samples of channel type ch.
+ * ---------------------------------------------------------------------------------------------- */
+static const unit_t *get_cu(const orc_enc *e, int ch, int px, int py)
+{
+  const int W = ch ? e->wc : e->wl, H = ch ? e->hc : e->hl, ul = ch ? 1 : 2;
+  if (px < 0 || py < 0 || px >= W || py >= H) return 0;
+  const unit_t *u = &e->um[ch][(py >> ul) * e->uw + (px >> ul)];
+  return (u->valid && u->tile == e->cur_tile) ? u : 0;
+}
+static void set_units(orc_enc *e, int ch, area_t a, const unit_t *proto, int valid)
+{
+  /* a in luma samples; clip to picture */
+  const int x1 = imin(a.x + a.w, e->wl), y1 = imin(a.y + a.h, e->hl);
+  for (int y = a.y >> 2; y < (y1 + 3) >> 2; y++) for (int x = a.x >> 2; x < (x1 + 3) >> 2; x++) {
+    unit_t *u = &e->um[ch][y * e->uw + x];
+    if (proto) *u = *proto;
+    u->valid = (uint8_t) valid; u->tile = (uint8_t) e->cur_tile;
+    e->avail[ch][y * e->uw + x] = valid ? (uint8_t) (e->cur_tile + 1) : 0;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Partitioner
+ * ---------------------------------------------------------------------------------------------- */
+static void part_init_ctu(partitioner *P, area_t ctu, int ch)
+{
+  memset(P, 0, sizeof *P);
+  P->ch = ch; P->cur = ctu; P->n = 1;
+  P->st[0].split = 0; P->st[0].parts[0] = ctu; P->st[0].nparts = 1;
+}
+static uint64_t part_split_series(const partitioner *P)
+{
+  uint64_t s = 0; int d = 0;
+  for (int i = 0; i < P->n; i++) { if (P->st[i].split == 0) continue; s += (uint64_t) P->st[i].split << (d * 5); d++; }
+  return s;
+}
+/* getImplicitSplit, CL/UnitPartitioner.cpp:530-581 */
+static int part_implicit_split(const orc_enc *e, partitioner *P)
+{
+  part_level *L = &P->st[P->n - 1];
+  if (L->impl_checked) return L->impl_split;
+  int split = SPLIT_NONE;
+  const area_t a = P->cur;
+  const int blIn = a.x < e->wl && (a.y + a.h - 1) < e->hl;       /* picture.contains(bottomLeft) */
+  const int trIn = (a.x + a.w - 1) < e->wl && a.y < e->hl;
+  const int maxBt = e->cfg.max_bt_size[P->ch], minQt = e->cfg.min_qt[P->ch];
+  const int btAllowed = a.w <= maxBt && a.h <= maxBt;
+  const int qtAllowed = a.w > minQt && a.h > minQt && P->bt_depth == 0;
+  if (!blIn && !trIn && qtAllowed) split = SPLIT_QT;
+  else if (!blIn && btAllowed) split = SPLIT_BH;
+  else if (!trIn && btAllowed) split = SPLIT_BV;
+  else if (!blIn || !trIn) split = SPLIT_QT;
+  if (e->cfg.dual_tree && (a.w > 64 || a.h > 64)) split = SPLIT_QT;
+  if ((!blIn || !trIn) && (a.w > 64 || a.h > 64)) split = SPLIT_QT;
+  L->impl_checked = 1; L->is_implicit = split != SPLIT_NONE; L->impl_split = split;
+  return split;
+}
+/* canSplit, CL/UnitPartitioner.cpp:379-466; can[] = {no, qt, bh, bv, th, tv} */
+static void part_can_split(const orc_enc *e, partitioner *P, int can[6])
+{
+  const int impl = part_implicit_split(e, P);
+  const int ch = P->ch;
+  const int maxBTD = e->cfg.max_bt_depth[ch] + P->impl_bt_depth;
+  const int maxBt = e->cfg.max_bt_size[ch], minBt = 4, maxTt = e->cfg.max_tt_size[ch], minTt = 4, minQt = e->cfg.min_qt[ch];
+  const area_t a = P->cur;
+  const int cw = a.w >> 1, chh = a.h >> 1;      /* areaC */
+  for (int i = 0; i < 6; i++) can[i] = 1;
+  int canBtt = P->mt_depth < maxBTD;
+  const part_level *L = &P->st[P->n - 1];
+  const int last = L->split;
+  const int parl = last == SPLIT_TH ? SPLIT_BH : SPLIT_BV;
+  if (last != 0 && last != SPLIT_QT) can[1] = 0;
+  if (a.w <= minQt) can[1] = 0;
+  if (ch == 1 && cw <= 4) can[1] = 0;
+  if (impl != SPLIT_NONE) { can[0] = can[4] = can[5] = 0; can[2] = impl == SPLIT_BH; can[3] = impl == SPLIT_BV; return; }
+  if ((last == SPLIT_TH || last == SPLIT_TV) && L->idx == 1) { can[2] = parl != SPLIT_BH; can[3] = parl != SPLIT_BV; }
+  if (canBtt && (a.w <= minBt && a.h <= minBt) && (a.w <= minTt && a.h <= minTt)) canBtt = 0;
+  if (canBtt && (a.w > maxBt || a.h > maxBt) && (a.w > maxTt || a.h > maxTt)) canBtt = 0;
+  if (!canBtt) { can[2] = can[3] = can[4] = can[5] = 0; return; }
+  if (a.w > maxBt || a.h > maxBt) can[2] = can[3] = 0;
+  if (a.h <= minBt) can[2] = 0;
+  if (a.w > 64 && a.h <= 64) can[2] = 0;
+  if (ch == 1 && cw * chh <= 16) can[2] = 0;
+  if (a.w <= minBt) can[3] = 0;
+  if (a.w <= 64 && a.h > 64) can[3] = 0;
+  if (ch == 1 && cw * chh <= 16) can[3] = 0;
+  if (a.h <= 2 * minTt || a.h > maxTt || a.w > maxTt) can[4] = 0;
+  if (a.w > 64 || a.h > 64) can[4] = 0;
+  if (ch == 1 && cw * chh <= 32) can[4] = 0;
+  if (a.w <= 2 * minTt || a.w > maxTt || a.h > maxTt) can[5] = 0;
+  if (a.w > 64 || a.h > 64) can[5] = 0;
+  if (ch == 1 && cw * chh <= 32) can[5] = 0;
+}
+static int part_can(const orc_enc *e, partitioner *P, int split) { int c[6]; part_can_split(e, P, c); return c[split]; }
+/* splitCurrArea 278-377 + getCUSubPartitions 785-... */
+static void part_split(const orc_enc *e, partitioner *P, int split)
+{
+  const int isImpl = split == part_implicit_split(e, P);
+  const area_t a = P->cur;
+  part_level *L = &P->st[P->n++];
+  memset(L, 0, sizeof *L);
+  L->split = split;
+  switch (split) {
+    case SPLIT_QT: L->nparts = 4;
+      for (int i = 0; i < 4; i++) { L->parts[i].w = a.w >> 1; L->parts[i].h = a.h >> 1; L->parts[i].x = a.x + ((i & 1) ? a.w >> 1 : 0); L->parts[i].y = a.y + ((i >= 2) ? a.h >> 1 : 0); }
+      break;
+    case SPLIT_BH: L->nparts = 2;
+      L->parts[0] = (area_t) { a.x, a.y, a.w, a.h >> 1 }; L->parts[1] = (area_t) { a.x, a.y + (a.h >> 1), a.w, a.h >> 1 }; break;
+    case SPLIT_BV: L->nparts = 2;
+      L->parts[0] = (area_t) { a.x, a.y, a.w >> 1, a.h }; L->parts[1] = (area_t) { a.x + (a.w >> 1), a.y, a.w >> 1, a.h }; break;
+    case SPLIT_TH: L->nparts = 3;
+      L->parts[0] = (area_t) { a.x, a.y, a.w, a.h >> 2 }; L->parts[1] = (area_t) { a.x, a.y + (a.h >> 2), a.w, a.h >> 1 }; L->parts[2] = (area_t) { a.x, a.y + (a.h >> 2) + (a.h >> 1), a.w, a.h >> 2 }; break;
+    case SPLIT_TV: L->nparts = 3;
+      L->parts[0] = (area_t) { a.x, a.y, a.w >> 2, a.h }; L->parts[1] = (area_t) { a.x + (a.w >> 2), a.y, a.w >> 1, a.h }; L->parts[2] = (area_t) { a.x + (a.w >> 2) + (a.w >> 1), a.y, a.w >> 2, a.h }; break;
+  }
+  P->depth++;
+  P->cur = L->parts[0];
+  if (split != SPLIT_QT) {
+    P->bt_depth++;
+    if (isImpl) P->impl_bt_depth++;
+    P->mt_depth++;
+    if (split == SPLIT_TH || split == SPLIT_TV) P->bt_depth++;
+  } else { P->mt_depth = 0; P->bt_depth = 0; P->qt_depth++; }
+}
+/* exitCurrSplit 583-634 */
+static void part_exit(partitioner *P)
+{
+  const int split = P->st[P->n - 1].split, idx = P->st[P->n - 1].idx;
+  P->n--;
+  P->depth--;
+  part_level *L = &P->st[P->n - 1];
+  P->cur = L->parts[L->idx];
+  if (split != SPLIT_QT) {
+    P->mt_depth--;
+    if (L->is_implicit) P->impl_bt_depth--;
+    P->bt_depth--;
+    if ((split == SPLIT_TH || split == SPLIT_TV) && idx != 1) P->bt_depth--;
+  } else P->qt_depth--;
+}
+/* nextPart 636-675 (autoPop = false) */
+static int part_next(partitioner *P)
+{
+  part_level *L = &P->st[P->n - 1];
+  const int idx = ++L->idx;
+  L->impl_checked = 0; L->is_implicit = 0;
+  if (idx < L->nparts) {
+    if (L->split == SPLIT_TH || L->split == SPLIT_TV) { if (idx == 1) P->bt_depth--; else P->bt_depth++; }
+    P->cur = L->parts[idx];
+    return 1;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Syntax on the estimator
+ * ---------------------------------------------------------------------------------------------- */
+/* DeriveCtx::CtxSplit (CL/ContextModelling.cpp:154-250): ctx = {split, qt, hv, hor12, ver12} */
+static void derive_split_ctx(const orc_enc *e, const partitioner *P, const int can[6], unsigned ctx[5])
+{
+  const int ch = P->ch, sh = ch ? 1 : 0;
+  const int bx = P->cur.x >> sh, by = P->cur.y >> sh, bw = P->cur.w >> sh, bh = P->cur.h >> sh;
+  const unit_t *cuL = get_cu(e, ch, bx - 1, by), *cuA = get_cu(e, ch, bx, by - 1);
+  unsigned ctxSpl = 0;
+  if (cuL) ctxSpl += ((1 << cuL->lh) < bh) ? 1 : 0;
+  if (cuA) ctxSpl += ((1 << cuA->lw) < bw) ? 1 : 0;
+  unsigned numSplit = 0;
+  if (can[1]) numSplit += 2;
+  for (int i = 2; i < 6; i++) if (can[i]) numSplit += 1;
+  if (numSplit > 0) numSplit--;
+  ctxSpl += 3 * (numSplit >> 1);
+  unsigned ctxQt = (cuL && cuL->qt_depth > P->qt_depth) ? 1 : 0;
+  ctxQt += (cuA && cuA->qt_depth > P->qt_depth) ? 1 : 0;
+  ctxQt += P->qt_depth < 2 ? 0 : 3;
+  unsigned ctxHv = 0;
+  const unsigned numHor = (unsigned) (can[2] + can[4]), numVer = (unsigned) (can[3] + can[5]);
+  if (numVer == numHor) {
+    const unsigned wAbove = cuA ? (1u << cuA->lw) : 1, hLeft = cuL ? (1u << cuL->lh) : 1;
+    const unsigned depAbove = (unsigned) bw / wAbove, depLeft = (unsigned) bh / hLeft;
+    if (depAbove == depLeft || !cuL || !cuA) ctxHv = 0; else if (depAbove < depLeft) ctxHv = 1; else ctxHv = 2;
+  } else if (numVer < numHor) ctxHv = 3; else ctxHv = 4;
+  ctx[0] = ctxSpl; ctx[1] = ctxQt; ctx[2] = ctxHv; ctx[3] = P->mt_depth <= 1 ? 1 : 0; ctx[4] = P->mt_depth <= 1 ? 3 : 2;
+}
+/* CABACWriter::split_cu_mode (EL/CABACWriter.cpp:1010-1069) */
+static void enc_split_cu_mode(orc_enc *e, partitioner *P, int split)
+{
+  int can[6]; part_can_split(e, P, can);
+  unsigned cx[5]; derive_split_ctx(e, P, can, cx);
+  const unsigned ctxSpl = cx[0], ctxQt = cx[1], ctxHv = cx[2], ctxH12 = cx[3], ctxV12 = cx[4];
+
+  const int canSplit = can[1] || can[2] || can[3] || can[4] || can[5];
+  const int isNo = split == SPLIT_NONE;
+  if (can[0] && canSplit) orc_enc_bin(&e->cabac, !isNo, ORC_CTX_SplitFlag + (int) ctxSpl);
+  if (isNo) return;
+  const int canBtt = can[2] || can[3] || can[4] || can[5];
+  const int isQt = split == SPLIT_QT;
+  if (can[1] && canBtt) orc_enc_bin(&e->cabac, (unsigned) isQt, ORC_CTX_SplitQtFlag + (int) ctxQt);
+  if (isQt) return;
+  const int canHor = can[2] || can[4], canVer = can[3] || can[5];
+  const int isVer = split == SPLIT_BV || split == SPLIT_TV;
+  if (canVer && canHor) orc_enc_bin(&e->cabac, (unsigned) isVer, ORC_CTX_SplitHvFlag + (int) ctxHv);
+  const int can14 = isVer ? can[5] : can[4], can12 = isVer ? can[3] : can[2];
+  const int is12 = isVer ? (split == SPLIT_BV) : (split == SPLIT_BH);
+  if (can12 && can14) orc_enc_bin(&e->cabac, (unsigned) is12, ORC_CTX_Split12Flag + (int) (isVer ? ctxV12 : ctxH12));
+}
+
+/* PU::getIntraMPMs neighbour lookup (CL/UnitTools.cpp:516-532): left PU at bottom-left, above PU at
+ * top-right and only inside the same CTU */
+static void get_mpms(const orc_enc *e, int x, int y, int w, int h, unsigned mpm[6])
+{
+  int L = ORC_PLANAR, A = ORC_PLANAR;
+  const unit_t *uL = get_cu(e, 0, x - 1, y + h - 1);
+  if (uL) L = uL->dir;
+  const unit_t *uA = get_cu(e, 0, x + w - 1, y - 1);
+  if (uA && ((y - 1) >> 7) == (y >> 7)) A = uA->dir;
+  orc_get_mpms(L, A, mpm);
+}
+
+/* CABACWriter::intra_luma_pred_mode (1762-1845) with extend_ref_line (1566-1591); mip_flag / isp_mode
+ * write nothing when the tools are off in the SPS */
+static void enc_intra_luma_pred_mode(orc_enc *e, int x, int y, int w, int h, int dir, int mrl)
+{
+  orc_cabac *c = &e->cabac;
+  const int firstLine = (y & 127) == 0;
+  if (!firstLine) {
+    orc_enc_bin(c, mrl != 0, ORC_CTX_MultiRefLineIdx + 0);
+    if (mrl != 0) orc_enc_bin(c, mrl != 1, ORC_CTX_MultiRefLineIdx + 1);
+  }
+  unsigned mpm[6]; get_mpms(e, x, y, w, h, mpm);
+  int mpm_idx = 6;
+  for (int i = 0; i < 6; i++) if ((unsigned) dir == mpm[i]) { mpm_idx = i; break; }
+  if (!mrl) orc_enc_bin(c, mpm_idx < 6, ORC_CTX_IntraLumaMpmFlag);
+  if (mpm_idx < 6) {
+    if (mrl == 0) orc_enc_bin(c, mpm_idx > 0, ORC_CTX_IntraLumaPlanarFlag + 1);   /* ctx 1: ispMode == NOT_INTRA_SUBPARTITIONS */
+    if (mpm_idx) orc_enc_ep(c, 1);
+    if (mpm_idx > 1) orc_enc_ep(c, 1);
+    if (mpm_idx > 2) orc_enc_ep(c, 1);
+    if (mpm_idx > 3) orc_enc_ep(c, 1);
+  } else {
+    /* std::sort + rank, then xWriteTruncBinCode(ipred, 61): thresh 5, val 32, b 29 → 5 bits if < 3 else 6 */
+    unsigned s[6]; memcpy(s, mpm, sizeof s);
+    for (int i = 1; i < 6; i++) { unsigned v = s[i]; int j = i - 1; while (j >= 0 && s[j] > v) { s[j + 1] = s[j]; j--; } s[j + 1] = v; }
+    unsigned m = (unsigned) dir;
+    for (int i = 5; i >= 0; i--) if (m > s[i]) m--;
+    orc_enc_ep(c, m < 3 ? 5 : 6);
+  }
+}
+/* PU::getCoLocatedIntraLumaMode (CL/UnitTools.cpp:949-960) + getIntraChromaCandModes (840-873) */
+static int colocated_luma_mode(const orc_enc *e, area_t a)
+{
+  const int px = a.x + (a.w >> 1), py = a.y + (a.h >> 1);
+  return e->um[0][(py >> 2) * e->uw + (px >> 2)].dir;
+}
+static void chroma_cand_modes(const orc_enc *e, area_t a, int list[8])
+{
+  list[0] = ORC_PLANAR; list[1] = ORC_VER; list[2] = ORC_HOR; list[3] = ORC_DC; list[4] = 67; list[5] = 68; list[6] = 69; list[7] = ORC_DM_CHROMA;
+  const int lm = colocated_luma_mode(e, a);
+  for (int i = 0; i < 4; i++) if (lm == list[i]) { list[i] = ORC_VDIA; break; }
+}
+/* CABACWriter::intra_chroma_pred_mode (1891-1933), CCLM off */
+static void enc_intra_chroma_pred_mode(orc_enc *e, area_t a, int dir)
+{
+  orc_cabac *c = &e->cabac;
+  const int isDM = dir == ORC_DM_CHROMA;
+  orc_enc_bin(c, isDM ? 0 : 1, ORC_CTX_IntraChromaPredMode);
+  if (isDM) return;
+  orc_enc_ep(c, 2);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * one transform block: pred (already in e->pred) → resi → T → Q → Q⁻¹ → T⁻¹ → reco → SSE
+ * (EL/IntraSearch.cpp:2852-3168, CL/TrQuant.cpp:1127-1235)
+ * comp: 0 Y 1 Cb 2 Cr; x,y,w,h in component samples; writes rec_out / lev_out tiles (stride w)
+ * ---------------------------------------------------------------------------------------------- */
+static uint64_t code_tu_block(orc_enc *e, int comp, int x, int y, int w, int h, int16_t *rec_out, int16_t *lev_out, int *cbf)
+{
+  const int st = e->stride[comp], bd = e->cfg.bit_depth;
+  const int16_t *org = e->org[comp] + y * st + x;
+  const int qp = comp ? e->sl.qp_c[comp - 1] : e->sl.qp;
+  for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) e->resi[j * w + i] = (int16_t) (org[j * st + i] - e->pred[j * w + i]);
+  orc_fwd_2d(e->resi, w, w, h, bd, e->coef);
+  const int abs_sum = orc_quant(e->coef, w, h, bd, qp, lev_out);
+  if (abs_sum > 0) { orc_dequant(lev_out, w, h, bd, qp, e->coef); orc_inv_2d(e->coef, w, h, bd, e->resi, w); }
+  else memset(e->resi, 0, (size_t) w * h * 2);
+  const int mx = (1 << bd) - 1;
+  for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) { int v = e->pred[j * w + i] + e->resi[j * w + i]; rec_out[j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
+  *cbf = abs_sum > 0;
+  uint64_t d = orc_sse(org, st, rec_out, w, w, h);
+  if (comp) d = (uint64_t) (e->sl.dist_weight[comp - 1] * (double) d);    /* CL/RdCost.cpp:405-408 */
+  e->cnt_rd++; e->cnt_rdpix += (uint64_t) w * h;
+  return d;
+}
+
+static void build_refs(orc_enc *e, int comp, int x, int y, int w, int h, int mrl, int filter)
+{
+  const int ch = comp ? 1 : 0;
+  orc_fill_ref_samples(e->rec[comp], e->stride[comp], comp ? e->wc : e->wl, comp ? e->hc : e->hl, e->avail[ch], e->uw,
+                       ch ? 1 : 2, e->cur_tile + 1, x, y, w, h, mrl, e->cfg.bit_depth, e->ref_unf);
+  if (filter) orc_filter_ref_samples(e->ref_unf, e->ref_flt, w, h, mrl);
+}
+
+/* updateCandList (CL/UnitTools.h:261-306) for a (mode,mrl) list with costs */
+typedef struct { int mode, mrl; } minfo;
+static void update_cand_list(minfo m, double cost, minfo *list, double *costs, int *size, int fastNum)
+{
+  int shift = 0;
+  const int cur = imin(fastNum, *size);
+  while (shift < fastNum && shift < cur && cost < costs[cur - 1 - shift]) shift++;
+  if (*size >= fastNum && shift != 0) {
+    for (int i = 1; i < shift; i++) { list[cur - i] = list[cur - 1 - i]; costs[cur - i] = costs[cur - 1 - i]; }
+    list[cur - shift] = m; costs[cur - shift] = cost;
+  } else if (cur < fastNum) {
+    const int pos = *size - shift;
+    for (int i = *size; i > pos; i--) { list[i] = list[i - 1]; costs[i] = costs[i - 1]; }
+    list[pos] = m; costs[pos] = cost; (*size)++;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * estIntraPredLumaQT (EL/IntraSearch.cpp:289-1380), P0 subset.  Leaves the winner's reco/levels in
+ * e->best_rec[0]/best_lev[0] (stride w).  Returns dist; *dir,*mrl,*cbf the winner.
+ * ---------------------------------------------------------------------------------------------- */
+static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out_mrl, int *out_cbf)
+{
+  const int x = a.x, y = a.y, w = a.w, h = a.h, bd = e->cfg.bit_depth;
+  orc_cabac ctxStart; orc_ctx_copy(&ctxStart, &e->cabac);
+  const int16_t *org = e->org[0] + y * e->stride[0] + x;
+  int numRd = ORC_MODE_NUM_FAST_2D[(ilog2(w) - 2) * 6 + (ilog2(h) - 2)];
+  minfo rdList[80]; double rdCost[80]; int rdSize = 0;
+  minfo hadList[8]; double hadCost[8]; int hadSize = 0;
+  uint8_t checked[ORC_NUM_LUMA_MODE]; memset(checked, 0, sizeof checked);
+  const int firstLine = (y & 127) == 0;
+  const int numRefPasses = (firstLine || !(e->cfg.tools & ORC_TOOL_MRL)) ? 1 : 3;
+
+  /* stage A: SATD pre-selection (483-682).  initIntraPatternChType(cu, Y, forceRefFilter=true) */
+  build_refs(e, 0, x, y, w, h, 0, 1);
+#define SATD_COST(mode_, mrl_, cost_out, had_out) do { \
+    orc_pred_intra(e->ref_unf, e->ref_flt, w, h, 1, (mode_), (mrl_), bd, e->pred, w); \
+    const uint64_t sad_ = orc_sad(org, e->stride[0], e->pred, w, w, h), satd_ = orc_satd(org, e->stride[0], e->pred, w, w, h); \
+    const uint64_t msh_ = sad_ * 2 < satd_ ? sad_ * 2 : satd_; \
+    orc_ctx_copy(&e->cabac, &ctxStart); e->cabac.bits = 0; \
+    enc_intra_luma_pred_mode(e, x, y, w, h, (mode_), (mrl_)); \
+    (cost_out) = (double) msh_ + (double) e->cabac.bits * e->sqrt_lambda_fp; (had_out) = (double) msh_; e->cnt_satd++; } while (0)
+  for (int mode = 0; mode < ORC_NUM_LUMA_MODE; mode++) {
+    if (mode > ORC_DC && (mode & 1)) continue;
+    checked[mode] = 1;
+    double cost, had; SATD_COST(mode, 0, cost, had);
+    update_cand_list((minfo) { mode, 0 }, cost, rdList, rdCost, &rdSize, numRd);
+    update_cand_list((minfo) { mode, 0 }, had, hadList, hadCost, &hadSize, 3);
+  }
+  {
+    minfo parent[80]; memcpy(parent, rdList, sizeof(minfo) * (size_t) numRd);
+    for (int i = 0; i < numRd; i++) {
+      const int pm = parent[i].mode;
+      if (pm > (ORC_DC + 1) && pm < (ORC_NUM_LUMA_MODE - 1))
+        for (int s = -1; s <= 1; s += 2) {
+          const int mode = pm + s;
+          if (!checked[mode]) {
+            double cost, had; SATD_COST(mode, 0, cost, had);
+            update_cand_list((minfo) { mode, 0 }, cost, rdList, rdCost, &rdSize, numRd);
+            update_cand_list((minfo) { mode, 0 }, had, hadList, hadCost, &hadSize, 3);
+            checked[mode] = 1;
+          }
+        }
+    }
+  }
+  {
+    unsigned mpm[6]; get_mpms(e, x, y, w, h, mpm);
+    static const int MRL_IDX[3] = { 0, 1, 3 };
+    for (int r = 1; r < numRefPasses; r++) {
+      const int mrl = MRL_IDX[r];
+      build_refs(e, 0, x, y, w, h, mrl, 1);
+      for (int k = 1; k < 6; k++) {
+        double cost, had; SATD_COST((int) mpm[k], mrl, cost, had);
+        update_cand_list((minfo) { (int) mpm[k], mrl }, cost, rdList, rdCost, &rdSize, numRd);
+        update_cand_list((minfo) { (int) mpm[k], mrl }, had, hadList, hadCost, &hadSize, 3);
+      }
+    }
+  }
+#undef SATD_COST
+  {
+    /* EL/IntraSearch.cpp:784-802: numCand = PU::getIntraMPMs(...) (1 if left==above dir else 2) */
+    unsigned mpm[6];
+    int L = ORC_PLANAR, A = ORC_PLANAR;
+    const unit_t *uL = get_cu(e, 0, x - 1, y + h - 1); if (uL) L = uL->dir;
+    const unit_t *uA = get_cu(e, 0, x + w - 1, y - 1); if (uA && ((y - 1) >> 7) == (y >> 7)) A = uA->dir;
+    orc_get_mpms(L, A, mpm);
+    const int numCand = (L == A) ? 1 : 2;
+    for (int j = 0; j < numCand; j++) {
+      int incl = 0;
+      for (int i = 0; i < numRd; i++) incl |= (rdList[i].mode == (int) mpm[j] && rdList[i].mrl == 0);
+      if (!incl) { rdList[numRd] = (minfo) { (int) mpm[j], 0 }; rdCost[numRd] = 0; numRd++; }
+    }
+  }
+
+  /* stage B: full RD (1158-1358) */
+  double bestCost = ORC_MAX_DOUBLE; uint64_t bestDist = 0; int bestDir = 0, bestMrl = 0, bestCbf = 0;
+  for (int m = 0; m < numRd; m++) {
+    const int dir = rdList[m].mode, mrl = rdList[m].mrl;
+    orc_ctx_copy(&e->cabac, &ctxStart);
+    /* xIntraCodingTUBlock: initIntraPatternChType without forced filter */
+    orc_ipa ip; orc_init_pred_params(w, h, 1, dir, mrl, &ip);
+    build_refs(e, 0, x, y, w, h, mrl, ip.ref_filter);
+    orc_pred_intra(e->ref_unf, e->ref_flt, w, h, 1, dir, mrl, bd, e->pred, w);
+    int cbf;
+    const uint64_t dist = code_tu_block(e, 0, x, y, w, h, e->tmp_rec[0], e->tmp_lev[0], &cbf);
+    /* xGetIntraFracBitsQT(luma): header + cbf + coefficients */
+    e->cabac.bits = 0;
+    enc_intra_luma_pred_mode(e, x, y, w, h, dir, mrl);
+    orc_enc_bin(&e->cabac, (unsigned) cbf, ORC_CTX_QtCbf[0] + 0);
+    if (cbf) orc_residual_coding(&e->cabac, e->tmp_lev[0], w, h, 0);
+    const double cost = rd_cost(e, e->cabac.bits, dist);
+    if (cost < bestCost) {
+      bestCost = cost; bestDist = dist; bestDir = dir; bestMrl = mrl; bestCbf = cbf;
+      memcpy(e->best_rec[0], e->tmp_rec[0], (size_t) w * h * 2); memcpy(e->best_lev[0], e->tmp_lev[0], (size_t) w * h * 2);
+    }
+  }
+  orc_ctx_copy(&e->cabac, &ctxStart);
+  *out_dir = bestDir; *out_mrl = bestMrl; *out_cbf = bestCbf;
+  return bestDist;
+}
+
+/* estIntraPredChromaQT (1382-1686) + xRecurIntraChromaCodingQT (3779-4207), CCLM/JCCR off.
+ * a in luma samples.  Winner left in best_rec[0..1]/best_lev[0..1] (Cb,Cr; stride cw). */
+static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int *out_dir, int *out_cbf)
+{
+  const int cx = a.x >> 1, cy = a.y >> 1, cw = a.w >> 1, chh = a.h >> 1, bd = e->cfg.bit_depth;
+  orc_cabac ctxStart; orc_ctx_copy(&ctxStart, &e->cabac);
+  int cand[8]; chroma_cand_modes(e, a, cand);
+  double bestCost = ORC_MAX_DOUBLE; uint64_t bestDist = 0; int bestMode = 0, bestCbf = 0;
+  int16_t *rec2[2], *lev2[2];
+  rec2[0] = e->tmp_rec[0]; rec2[1] = e->tmp_rec[1]; lev2[0] = e->tmp_lev[0]; lev2[1] = e->tmp_lev[1];
+  for (int k = 0; k < 8; k++) {
+    const int cm = cand[k];
+    if (cm >= 67 && cm <= 69) continue;                       /* LM modes not enabled (1588-1591) */
+    orc_ctx_copy(&e->cabac, &ctxStart);
+    const int fm = cm == ORC_DM_CHROMA ? colocated_luma_mode(e, a) : cm;   /* PU::getFinalIntraMode 921 */
+    int cbf[2]; uint64_t dist = 0;
+    for (int c = 1; c <= 2; c++) {
+      build_refs(e, c, cx, cy, cw, chh, 0, 0);
+      orc_pred_intra(e->ref_unf, e->ref_flt, cw, chh, 0, fm, 0, bd, e->pred, cw);
+      dist += code_tu_block(e, c, cx, cy, cw, chh, rec2[c - 1], lev2[c - 1], &cbf[c - 1]);
+      /* xGetIntraFracBitsQTChroma (2625-2692): contexts advance, bits only feed per-component costs */
+      orc_enc_bin(&e->cabac, (unsigned) cbf[c - 1], ORC_CTX_QtCbf[c] + (c == 2 ? cbf[0] : 0));
+      if (cbf[c - 1]) orc_residual_coding(&e->cabac, lev2[c - 1], cw, chh, 1);
+    }
+    /* 1611-1621: contexts are NOT reset (transform skip off); xGetIntraFracBitsQT(chroma) */
+    e->cabac.bits = 0;
+    enc_intra_chroma_pred_mode(e, a, cm);
+    orc_enc_bin(&e->cabac, (unsigned) cbf[0], ORC_CTX_QtCbf[1] + 0);
+    orc_enc_bin(&e->cabac, (unsigned) cbf[1], ORC_CTX_QtCbf[2] + cbf[0]);
+    if (cbf[0]) orc_residual_coding(&e->cabac, lev2[0], cw, chh, 1);
+    if (cbf[1]) orc_residual_coding(&e->cabac, lev2[1], cw, chh, 1);
+    const double cost = rd_cost(e, e->cabac.bits, dist);
+    if (cost < bestCost) {
+      bestCost = cost; bestDist = dist; bestMode = cm; bestCbf = (cbf[0] ? 2 : 0) | (cbf[1] ? 4 : 0);
+      for (int c = 0; c < 2; c++) { memcpy(e->best_rec[c], rec2[c], (size_t) cw * chh * 2); memcpy(e->best_lev[c], lev2[c], (size_t) cw * chh * 2); }
+    }
+  }
+  orc_ctx_copy(&e->cabac, &ctxStart);
+  *out_dir = bestMode; *out_cbf = bestCbf;
+  return bestDist;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * node store: copy node area between picture planes/maps and the per-level store
+ * ---------------------------------------------------------------------------------------------- */
+static void store_save_from_picture(orc_enc *e, int d, int ch, area_t a)
+{
+  const int x1 = imin(a.x + a.w, e->wl), y1 = imin(a.y + a.h, e->hl);
+  const int c0 = ch ? 1 : 0, c1 = ch ? 2 : 0, sh = ch ? 1 : 0;
+  for (int c = c0; c <= c1; c++) {
+    const int X0 = a.x >> sh, Y0 = a.y >> sh, X1 = x1 >> sh, Y1 = y1 >> sh, W = a.w >> sh;
+    for (int y = Y0; y < Y1; y++) { memcpy(e->store[d].rec[c] + (y - Y0) * W, e->rec[c] + y * e->stride[c] + X0, (size_t) (X1 - X0) * 2);
+                                    memcpy(e->store[d].lev[c] + (y - Y0) * W, e->lev[c] + y * e->stride[c] + X0, (size_t) (X1 - X0) * 2); }
+  }
+  for (int y = a.y >> 2; y < (y1 + 3) >> 2; y++) memcpy(e->store[d].units + (y - (a.y >> 2)) * 32, e->um[ch] + y * e->uw + (a.x >> 2), (size_t) (((x1 + 3) >> 2) - (a.x >> 2)) * sizeof(unit_t));
+}
+static void store_restore_to_picture(orc_enc *e, int d, int ch, area_t a)
+{
+  const int x1 = imin(a.x + a.w, e->wl), y1 = imin(a.y + a.h, e->hl);
+  const int c0 = ch ? 1 : 0, c1 = ch ? 2 : 0, sh = ch ? 1 : 0;
+  for (int c = c0; c <= c1; c++) {
+    const int X0 = a.x >> sh, Y0 = a.y >> sh, X1 = x1 >> sh, Y1 = y1 >> sh, W = a.w >> sh;
+    for (int y = Y0; y < Y1; y++) { memcpy(e->rec[c] + y * e->stride[c] + X0, e->store[d].rec[c] + (y - Y0) * W, (size_t) (X1 - X0) * 2);
+                                    memcpy(e->lev[c] + y * e->stride[c] + X0, e->store[d].lev[c] + (y - Y0) * W, (size_t) (X1 - X0) * 2); }
+  }
+  for (int y = a.y >> 2; y < (y1 + 3) >> 2; y++) {
+    memcpy(e->um[ch] + y * e->uw + (a.x >> 2), e->store[d].units + (y - (a.y >> 2)) * 32, (size_t) (((x1 + 3) >> 2) - (a.x >> 2)) * sizeof(unit_t));
+    for (int x = a.x >> 2; x < (x1 + 3) >> 2; x++) e->avail[ch][y * e->uw + x] = e->um[ch][y * e->uw + x].valid ? (uint8_t) (e->cur_tile + 1) : 0;
+  }
+}
+/* an intra CU result (tiles with stride w) into the store of level d */
+static void store_save_intra(orc_enc *e, int d, int ch, area_t a, const unit_t *cu)
+{
+  const int sh = ch ? 1 : 0, W = a.w >> sh, H = a.h >> sh;
+  if (!ch) { memcpy(e->store[d].rec[0], e->best_rec[0], (size_t) W * H * 2); memcpy(e->store[d].lev[0], e->best_lev[0], (size_t) W * H * 2); }
+  else for (int c = 0; c < 2; c++) { memcpy(e->store[d].rec[c + 1], e->best_rec[c], (size_t) W * H * 2); memcpy(e->store[d].lev[c + 1], e->best_lev[c], (size_t) W * H * 2); }
+  for (int y = 0; y < (a.h + 3) >> 2; y++) for (int x = 0; x < (a.w + 3) >> 2; x++) { e->store[d].units[y * 32 + x] = *cu; e->store[d].units[y * 32 + x].valid = 1; e->store[d].units[y * 32 + x].tile = (uint8_t) e->cur_tile; }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * xCompressCU and friends
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {            /* ComprCUCtx (EL/EncModeCtrl.h:182-249), intra-relevant part */
+  int modes[8], nmodes;     /* stack, popped from the back */
+  int min_depth, max_depth;
+  int did_horz, did_vert, did_quad, do_trih, do_triv, qt_before_bt, max_qt_sub_depth;
+  cs_sum *best;             /* bestCS (NULL until a mode result was accepted) */
+} cu_ctx;
+
+static int mode_to_split(int m) { return m == ETM_SPLIT_QT ? SPLIT_QT : m == ETM_SPLIT_BT_H ? SPLIT_BH : m == ETM_SPLIT_BT_V ? SPLIT_BV : m == ETM_SPLIT_TT_H ? SPLIT_TH : m == ETM_SPLIT_TT_V ? SPLIT_TV : SPLIT_NONE; }
+
+/* EncModeCtrlMTnoRQT::tryMode (EL/EncModeCtrl.cpp:1557-2068), I-slice / intra-only subset */
+static int try_mode(orc_enc *e, partitioner *P, cu_ctx *C, int mode)
+{
+  const int impl = part_implicit_split(e, P);
+  if (impl != SPLIT_NONE && mode != ETM_SPLIT_QT) return mode_to_split(mode) == impl;
+  else if (impl != SPLIT_NONE) return part_can(e, P, SPLIT_QT);
+  const area_t a = P->cur;
+  if (C->min_depth > P->qt_depth && part_can(e, P, SPLIT_QT)) return mode == ETM_SPLIT_QT;
+  else if (mode == ETM_SPLIT_QT && C->max_depth <= P->qt_depth) return 0;
+  if (mode == ETM_INTRA) {
+    if (a.w * a.h > 4096) return 0;               /* LCTUFast (1642) */
+    if (a.w > 64 || a.h > 64) return 0;           /* dual tree (1647) */
+    return 1;
+  }
+  if (mode == ETM_POST_DONT_SPLIT) return 0;      /* bookkeeping only (2005-2067) */
+  const int split = mode_to_split(mode);
+  if (!part_can(e, P, split)) {
+    if (split == SPLIT_BH) C->did_horz = 0;
+    if (split == SPLIT_BV) C->did_vert = 0;
+    if (split == SPLIT_QT) C->did_quad = 0;
+    return 0;
+  }
+  const cs_sum *b = C->best;
+  int feat = -1;
+  switch (split) {
+    case SPLIT_QT:
+      if (!C->qt_before_bt && b) {
+        const int maxBTD = e->cfg.max_bt_depth[P->ch];
+        if (((b->f_bt == 0 && maxBTD >= 3) || (b->f_bt == 1 && b->l_bt == 1 && maxBTD >= 4)) && (a.w <= 64 && a.h <= 64) && C->did_horz && C->did_vert) return 0;
+      }
+      break;
+    case SPLIT_BH: feat = 0; break;
+    case SPLIT_BV: feat = 1; break;
+    case SPLIT_TH:
+      if (C->did_horz && b && b->f_bt == P->bt_depth && !b->f_cbf) return 0;
+      if (!C->do_trih) return 0;
+      break;
+    case SPLIT_TV:
+      if (C->did_vert && b && b->f_bt == P->bt_depth && !b->f_cbf) return 0;
+      if (!C->do_triv) return 0;
+      break;
+  }
+  if (split != SPLIT_QT && C->qt_before_bt && C->did_quad && C->max_qt_sub_depth > P->qt_depth + 1) {
+    if (feat == 0) C->did_horz = 0; else if (feat == 1) C->did_vert = 0;
+    return 0;
+  }
+  if (split == SPLIT_QT) C->did_quad = 1;
+  return 1;
+}
+static int next_mode(orc_enc *e, partitioner *P, cu_ctx *C)
+{
+  C->nmodes--;
+  while (C->nmodes > 0 && !try_mode(e, P, C, C->modes[C->nmodes - 1])) C->nmodes--;
+  return C->nmodes > 0;
+}
+/* initCULevel (1203-1549) */
+static void init_cu_level(orc_enc *e, partitioner *P, cu_ctx *C)
+{
+  memset(C, 0, sizeof *C);
+  const int ch = P->ch, sh = ch ? 1 : 0;
+  C->min_depth = 0; C->max_depth = 7 - ilog2(e->cfg.min_qt[ch]);     /* plain QTBTPartitioner: no adaptive depth (EL/EncCu.cpp:472) */
+  const area_t a = P->cur;
+  const unit_t *cuL = get_cu(e, ch, (a.x >> sh) - 1, a.y >> sh), *cuA = get_cu(e, ch, a.x >> sh, (a.y >> sh) - 1);
+  C->qt_before_bt = ((cuL && cuA && cuL->qt_depth > P->qt_depth && cuA->qt_depth > P->qt_depth)
+                  || (cuL && !cuA && cuL->qt_depth > P->qt_depth) || (!cuL && cuA && cuA->qt_depth > P->qt_depth)
+                  || (!cuA && !cuL && a.w >= 32)) && (a.w > (e->cfg.min_qt[ch] << 1));
+  C->do_trih = C->do_triv = 1;
+  if (!C->qt_before_bt) C->modes[C->nmodes++] = ETM_SPLIT_QT;
+  if (part_can(e, P, SPLIT_TV)) C->modes[C->nmodes++] = ETM_SPLIT_TT_V;
+  if (part_can(e, P, SPLIT_TH)) C->modes[C->nmodes++] = ETM_SPLIT_TT_H;
+  if (part_can(e, P, SPLIT_BV)) { C->modes[C->nmodes++] = ETM_SPLIT_BT_V; C->did_vert = 1; }
+  if (part_can(e, P, SPLIT_BH)) { C->modes[C->nmodes++] = ETM_SPLIT_BT_H; C->did_horz = 1; }
+  if (C->qt_before_bt) C->modes[C->nmodes++] = ETM_SPLIT_QT;
+  C->modes[C->nmodes++] = ETM_POST_DONT_SPLIT;
+  C->modes[C->nmodes++] = ETM_INTRA;
+  if (!try_mode(e, P, C, C->modes[C->nmodes - 1])) next_mode(e, P, C);
+}
+/* useModeResult (2089-2200) */
+static int use_mode_result(orc_enc *e, partitioner *P, cu_ctx *C, int mode, const cs_sum *t)
+{
+  if (mode == ETM_SPLIT_QT) C->max_qt_sub_depth = t->max_qt;
+  const int maxMtD = e->cfg.max_bt_depth[P->ch] + P->impl_bt_depth;
+  const int sh = P->ch ? 1 : 0;
+  if (mode == ETM_SPLIT_BT_H && t->n_cu > 2) { const int h2 = (P->cur.h >> sh) / 2; C->do_trih = t->f_h < h2 || t->l_h < h2 || P->mt_depth + 1 == maxMtD; }
+  else if (mode == ETM_SPLIT_BT_V && t->n_cu > 2) { const int w2 = (P->cur.w >> sh) / 2; C->do_triv = t->f_w < w2 || t->l_w < w2 || P->mt_depth + 1 == maxMtD; }
+  return t->cost != ORC_MAX_DOUBLE && (!C->best || t->cost < C->best->cost);
+}
+
+static void compress_cu(orc_enc *e, partitioner *P, int d, double maxCostAllowed, cs_sum *best);
+
+/* xCheckRDCostIntra (EL/EncCu.cpp:2402-2777), single pass (no LFNST/MTS loops) */
+static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs_sum *best, orc_cabac *ctxStart, orc_cabac *ctxBest)
+{
+  const area_t a = P->cur; const int ch = P->ch, sh = ch ? 1 : 0;
+  cs_sum t; memset(&t, 0, sizeof t);
+  unit_t cu; memset(&cu, 0, sizeof cu);
+  cu.x = (int16_t) (a.x >> sh); cu.y = (int16_t) (a.y >> sh); cu.lw = (uint8_t) ilog2(a.w >> sh); cu.lh = (uint8_t) ilog2(a.h >> sh);
+  cu.qt_depth = (uint8_t) P->qt_depth; cu.mt_depth = (uint8_t) P->mt_depth; cu.bt_depth = (uint8_t) P->bt_depth; cu.depth = (uint8_t) P->depth;
+  cu.split_series = part_split_series(P);
+  int dir = 0, mrl = 0, cbf = 0;
+  if (!ch) t.dist = est_intra_pred_luma(e, a, &dir, &mrl, &cbf), cbf = cbf ? 1 : 0;
+  else t.dist = est_intra_pred_chroma(e, a, &dir, &cbf);
+  cu.dir = (uint8_t) dir; cu.mrl = (uint8_t) mrl; cu.cbf = (uint8_t) cbf;
+  /* CU-level rate from the node's start contexts (2593-2620) */
+  e->cabac.bits = 0;
+  if (!ch) {
+    enc_intra_luma_pred_mode(e, a.x, a.y, a.w, a.h, dir, mrl);
+    orc_enc_bin(&e->cabac, (unsigned) (cbf & 1), ORC_CTX_QtCbf[0]);
+    if (cbf & 1) orc_residual_coding(&e->cabac, e->best_lev[0], a.w, a.h, 0);
+  } else {
+    enc_intra_chroma_pred_mode(e, a, dir);
+    orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 2), ORC_CTX_QtCbf[1]);
+    orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 4), ORC_CTX_QtCbf[2] + !!(cbf & 2));
+    if (cbf & 2) orc_residual_coding(&e->cabac, e->best_lev[0], a.w >> 1, a.h >> 1, 1);
+    if (cbf & 4) orc_residual_coding(&e->cabac, e->best_lev[1], a.w >> 1, a.h >> 1, 1);
+  }
+  t.bits = e->cabac.bits;
+  t.cost = rd_cost(e, t.bits, t.dist);
+  /* xEncodeDontSplit (5649-5662) */
+  e->cabac.bits = 0;
+  enc_split_cu_mode(e, P, SPLIT_NONE);
+  t.bits += e->cabac.bits;
+  t.cost = rd_cost(e, t.bits, t.dist);
+  t.n_cu = 1; t.is_split = 0;
+  t.f_bt = t.l_bt = P->bt_depth; t.f_depth = P->depth; t.f_mt = P->mt_depth; t.f_cbf = cbf != 0;
+  t.f_w = t.l_w = a.w >> sh; t.f_h = t.l_h = a.h >> sh; t.max_qt = P->qt_depth;
+  /* xCheckBestMode (677-724) */
+  if (use_mode_result(e, P, C, ETM_INTRA, &t)) {
+    *best = t; C->best = best;
+    store_save_intra(e, d, ch, a, &cu);
+    orc_ctx_copy(ctxBest, &e->cabac);
+  }
+  orc_ctx_copy(&e->cabac, ctxStart);
+}
+
+/* xCheckModeSplit (EL/EncCu.cpp:1918-2399) */
+static void check_mode_split(orc_enc *e, partitioner *P, int d, cu_ctx *C, int mode, double maxCostAllowed, cs_sum *best, orc_cabac *ctxStart, orc_cabac *ctxBest)
+{
+  const int split = mode_to_split(mode), ch = P->ch;
+  const area_t a = P->cur;
+  orc_ctx_copy(&e->cabac, ctxStart);
+  e->cabac.bits = 0;
+  enc_split_cu_mode(e, P, split);
+  const uint64_t splitBits = e->cabac.bits;
+  orc_ctx_copy(&e->cabac, ctxStart);            /* sub-contexts restored (1967-1972) */
+  const double factor = e->sl.qp > 30 ? 1.1 : 1.075;
+  const double cost = rd_cost(e, (uint64_t) ((double) splitBits + ((double) best->bits / factor)), (uint64_t) ((double) best->dist / factor));
+  if (cost > best->cost) return;                 /* xCheckBestMode with empty tempCS: nothing */
+  cs_sum t; memset(&t, 0, sizeof t);
+  t.is_split = 1;
+  part_split(e, P, split);
+  set_units(e, ch, a, 0, 0);                     /* tempCS->initStructData: nothing of this node is coded yet */
+  int first = 1;
+  do {
+    const area_t s = P->cur;
+    if (s.x < e->wl && s.y < e->hl) {
+      double newMax = !ch ? fmin(maxCostAllowed, best->cost - rd_cost(e, t.bits, t.dist)) : ORC_MAX_DOUBLE;
+      newMax = fmax(0.0, newMax);
+      cs_sum sub; memset(&sub, 0, sizeof sub); sub.cost = ORC_MAX_DOUBLE;
+      compress_cu(e, P, d + 1, newMax, &sub);
+      if (sub.cost == ORC_MAX_DOUBLE) { fprintf(stderr, "oracle: sub-CU without encoding (not expected in I slices)\n"); abort(); }
+      t.dist += sub.dist; t.bits += sub.bits;
+      if (first) { t.f_bt = sub.f_bt; t.f_depth = sub.f_depth; t.f_mt = sub.f_mt; t.f_cbf = sub.f_cbf; t.f_w = sub.f_w; t.f_h = sub.f_h; first = 0; }
+      t.l_bt = sub.l_bt; t.l_w = sub.l_w; t.l_h = sub.l_h;
+      t.n_cu += sub.n_cu; t.max_qt = imax(t.max_qt, sub.max_qt);
+    }
+  } while (part_next(P));
+  part_exit(P);
+  const int enforceQT = part_implicit_split(e, P) == SPLIT_QT;
+  if (!enforceQT) {
+    e->cabac.bits = 0;
+    enc_split_cu_mode(e, P, split);               /* from the contexts left by the last child (2322-2329) */
+    t.bits += e->cabac.bits;
+  }
+  t.cost = rd_cost(e, t.bits, t.dist);
+  if (use_mode_result(e, P, C, mode, &t)) {
+    *best = t; C->best = best;
+    store_save_from_picture(e, d, ch, a);
+    orc_ctx_copy(ctxBest, &e->cabac);
+  }
+  orc_ctx_copy(&e->cabac, ctxStart);
+}
+
+/* xCompressCU (EL/EncCu.cpp:727-1638) */
+static void compress_cu(orc_enc *e, partitioner *P, int d, double maxCostAllowed, cs_sum *best)
+{
+  cu_ctx C;
+  const area_t a = P->cur; const int ch = P->ch;
+  e->cnt_nodes++;
+  init_cu_level(e, P, &C);
+  orc_cabac ctxStart, ctxBest;
+  orc_ctx_copy(&ctxStart, &e->cabac); orc_ctx_copy(&ctxBest, &e->cabac);
+  memset(best, 0, sizeof *best); best->cost = ORC_MAX_DOUBLE;
+  if (C.nmodes == 0) return;
+  int lastWasBest = 0;
+  do {
+    const int mode = C.modes[C.nmodes - 1];
+    const cs_sum *before = C.best; const double costBefore = best->cost;
+    if (mode == ETM_INTRA) check_rd_cost_intra(e, P, d, &C, best, &ctxStart, &ctxBest);
+    else check_mode_split(e, P, d, &C, mode, maxCostAllowed, best, &ctxStart, &ctxBest);
+    lastWasBest = (C.best != before) || (best->cost != costBefore);
+  } while (next_mode(e, P, &C));
+  (void) lastWasBest;
+  if (best->cost == ORC_MAX_DOUBLE) return;
+  orc_ctx_copy(&e->cabac, &ctxBest);
+  /* picture ← bestCS reco (1581-1582); CU info of the winner becomes visible to later nodes */
+  store_restore_to_picture(e, d, ch, a);
+}
+
+/* final estimator pass over the coded CTU: CABACWriter::coding_tree_unit / coding_tree (254-309, 474-984)
+ * advances the contexts for the next CTU of the tile (EL/EncSlice.cpp:1775-1776).  SAO/ALF CTU syntax
+ * touches contexts the CU search never reads and is left out. */
+static void walk_tree(orc_enc *e, partitioner *P)
+{
+  const area_t a = P->cur; const int ch = P->ch, sh = ch ? 1 : 0;
+  const unit_t *u = &e->um[ch][(a.y >> 2) * e->uw + (a.x >> 2)];
+  const int split = (int) ((u->split_series >> (P->depth * 5)) & 31);   /* CU::getSplitAtDepth */
+  enc_split_cu_mode(e, P, split ? split : SPLIT_NONE);
+  if (split) {
+    part_split(e, P, split);
+    do { if (P->cur.x < e->wl && P->cur.y < e->hl) walk_tree(e, P); } while (part_next(P));
+    part_exit(P);
+    return;
+  }
+  /* coding_unit: cu_pred_data + cu_residual */
+  const int W = a.w >> sh, H = a.h >> sh;
+  int16_t *lv = e->tmp_lev[0];
+  if (!ch) {
+    enc_intra_luma_pred_mode(e, a.x, a.y, a.w, a.h, u->dir, u->mrl);
+    orc_enc_bin(&e->cabac, u->cbf & 1, ORC_CTX_QtCbf[0]);
+    if (u->cbf & 1) { for (int y = 0; y < H; y++) memcpy(lv + y * W, e->lev[0] + (a.y + y) * e->stride[0] + a.x, (size_t) W * 2); orc_residual_coding(&e->cabac, lv, W, H, 0); }
+  } else {
+    enc_intra_chroma_pred_mode(e, a, u->dir);
+    orc_enc_bin(&e->cabac, !!(u->cbf & 2), ORC_CTX_QtCbf[1]);
+    orc_enc_bin(&e->cabac, !!(u->cbf & 4), ORC_CTX_QtCbf[2] + !!(u->cbf & 2));
+    for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c)) {
+      for (int y = 0; y < H; y++) memcpy(lv + y * W, e->lev[c] + ((a.y >> 1) + y) * e->stride[c] + (a.x >> 1), (size_t) W * 2);
+      orc_residual_coding(&e->cabac, lv, W, H, 1);
+    }
+  }
+}
+static void advance_ctx_ctu(orc_enc *e, area_t ctu)
+{
+  partitioner PL, PC;
+  part_init_ctu(&PL, ctu, 0); part_init_ctu(&PC, ctu, 1);
+  /* 128x128 root: implicit QT for both trees, no bins; then luma/chroma interleaved per 64x64 (867-908) */
+  enc_split_cu_mode(e, &PL, SPLIT_QT);
+  part_split(e, &PL, SPLIT_QT); part_split(e, &PC, SPLIT_QT);
+  int go = 1;
+  while (go) {
+    if (PL.cur.x < e->wl && PL.cur.y < e->hl) walk_tree(e, &PL);
+    go = part_next(&PL);
+    if (e->cfg.chroma && PC.cur.x < e->wl && PC.cur.y < e->hl) walk_tree(e, &PC);
+    part_next(&PC);
+  }
+}
+
+/* compressCtu (EL/EncCu.cpp:428-558) */
+static void compress_ctu(orc_enc *e, int rx, int ry, orc_ctu_result *res)
+{
+  const area_t ctu = { rx << 7, ry << 7, 128, 128 };
+  orc_cabac ctuStart; orc_ctx_copy(&ctuStart, &e->cabac);
+  partitioner P; cs_sum best;
+  part_init_ctu(&P, ctu, 0);
+  compress_cu(e, &P, 0, ORC_MAX_DOUBLE, &best);
+  res->dist = best.dist; res->frac_bits = best.bits; res->cost = best.cost; res->n_cu = best.n_cu;
+  if (e->cfg.chroma) {
+    orc_ctx_copy(&e->cabac, &ctuStart);
+    part_init_ctu(&P, ctu, 1);
+    compress_cu(e, &P, 0, ORC_MAX_DOUBLE, &best);
+    res->dist += best.dist; res->frac_bits += best.bits; res->cost += best.cost; res->n_cu += best.n_cu;
+  }
+  orc_ctx_copy(&e->cabac, &ctuStart);
+  advance_ctx_ctu(e, ctu);
+}
+
+int orc_compress_frame(orc_enc *e, orc_ctu_result *res, orc_cu *cus, int max_cus, int *n_cus)
+{
+  const int ntiles = e->cfg.tile_cols * e->cfg.tile_rows;
+  for (int t = 0; t < ntiles; t++) {
+    e->cur_tile = t;
+    orc_ctx_init(e->sl.qp, e->cabac.s0, e->cabac.s1);       /* contexts reset at tile start (EL/EncSlice.cpp:1640-1647) */
+    for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++)
+      if (e->ctu_tile[ry * e->ctus_w + rx] == t) compress_ctu(e, rx, ry, &res[ry * e->ctus_w + rx]);
+  }
+  /* final CU table: CTU raster order, per CTU luma CUs then chroma CUs, each in raster order of their origin */
+  int n = 0;
+  for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++)
+    for (int ch = 0; ch < (e->cfg.chroma ? 2 : 1); ch++) {
+      const int ul = ch ? 1 : 2;
+      for (int uy = ry * 32; uy < imin(ry * 32 + 32, e->uh); uy++) for (int ux = rx * 32; ux < imin(rx * 32 + 32, e->uw); ux++) {
+        const unit_t *u = &e->um[ch][uy * e->uw + ux];
+        if (!u->valid || (u->x >> ul) != ux || (u->y >> ul) != uy) continue;
+        if (n < max_cus) {
+          orc_cu *o = &cus[n];
+          o->x = u->x; o->y = u->y; o->w = (int16_t) (1 << u->lw); o->h = (int16_t) (1 << u->lh); o->ch_type = (uint8_t) ch;
+          o->qt_depth = u->qt_depth; o->bt_depth = u->bt_depth; o->mt_depth = u->mt_depth; o->depth = u->depth;
+          o->intra_dir = u->dir; o->mrl_idx = u->mrl; o->cbf = u->cbf; o->split_series = u->split_series;
+        }
+        n++;
+      }
+    }
+  *n_cus = n;
+  return n > max_cus ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * test hooks (used by tests/test_oracle_golden.py against vectors from the real reference)
+ * nb rows: {ch, x, y, w, h (luma coordinates), qtDepth, dir}
+ * ---------------------------------------------------------------------------------------------- */
+static orc_enc *test_env(int pic_w, int pic_h, const int *nb, int n_nb)
+{
+  orc_cfg cfg; memset(&cfg, 0, sizeof cfg);
+  cfg.pic_w = pic_w; cfg.pic_h = pic_h; cfg.bit_depth = 8; cfg.ctu_size = 128; cfg.min_qt[0] = 8; cfg.min_qt[1] = 4;
+  cfg.max_bt_depth[0] = cfg.max_bt_depth[1] = 3; cfg.max_bt_size[0] = 32; cfg.max_bt_size[1] = 64; cfg.max_tt_size[0] = cfg.max_tt_size[1] = 32;
+  cfg.dual_tree = 1; cfg.tile_cols = cfg.tile_rows = 1; cfg.tools = ORC_TOOL_MRL; cfg.chroma = 1;
+  orc_enc *e = orc_create(&cfg);
+  for (int i = 0; i < n_nb; i++) {
+    const int *r = nb + 7 * i; const int ch = r[0], sh = ch ? 1 : 0;
+    unit_t u; memset(&u, 0, sizeof u);
+    u.x = (int16_t) (r[1] >> sh); u.y = (int16_t) (r[2] >> sh); u.lw = (uint8_t) ilog2(r[3] >> sh); u.lh = (uint8_t) ilog2(r[4] >> sh);
+    u.qt_depth = (uint8_t) r[5]; u.dir = (uint8_t) r[6];
+    set_units(e, ch, (area_t) { r[1], r[2], r[3], r[4] }, &u, 1);
+  }
+  return e;
+}
+int orc_test_partition(int pic_w, int pic_h, int ch, int ctux, int ctuy, const int *nb, int n_nb, const int *path, int npath,
+                       int *can, unsigned *ctx, int *implicit, int *area)
+{
+  orc_enc *e = test_env(pic_w, pic_h, nb, n_nb);
+  partitioner P; part_init_ctu(&P, (area_t) { ctux, ctuy, 128, 128 }, ch);
+  for (int i = 0; i < npath; i++) { part_split(e, &P, path[2 * i]); for (int k = 0; k < path[2 * i + 1]; k++) part_next(&P); }
+  part_can_split(e, &P, can);
+  *implicit = part_implicit_split(e, &P);
+  derive_split_ctx(e, &P, can, ctx);
+  area[0] = P.cur.x; area[1] = P.cur.y; area[2] = P.cur.w; area[3] = P.cur.h; area[4] = P.qt_depth; area[5] = P.bt_depth; area[6] = P.mt_depth; area[7] = P.depth;
+  orc_destroy(e);
+  return 0;
+}
+int orc_test_mpm(int pic_w, int pic_h, const int *nb, int n_nb, int x, int y, int w, int h, unsigned *mpm)
+{
+  orc_enc *e = test_env(pic_w, pic_h, nb, n_nb);
+  get_mpms(e, x, y, w, h, mpm);
+  orc_destroy(e);
+  return 0;
+}

@@ -1,0 +1,140 @@
+/*
+ * vvc_oracle.h — CPU restatement ("oracle") of the VTM 6.1 intra CU-partition RDO hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product library links, includes or calls this code; it is
+ * used by tests/, by __graft_entry__.smoke() as the checker and by bench.py's cpu_baseline leg.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - leaf operators (transforms, SAD/SATD/SSE, CABAC probability model, calcRdCost, reference-sample
+ *     fill/filter, planar/DC/angular/PDPC prediction, MPM list, split contexts, scan order): pinned
+ *     bit-exactly against the real reference code compiled into oracle/_ref (tests/golden/).
+ *   - recursion-level decisions (EncCu / EncModeCtrl / IntraSearch / CABACWriter restatements):
+ *     PARITY UNPINNED — the reference encoder as a whole cannot be built here without stand-in headers
+ *     (EL/EncCu.cpp:59 and EL/CABACWriter.h:44 include <opencv2/opencv.hpp>, absent from the image).
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/VVC_project/source/Lib; CL = CommonLib, EL = EncoderLib).
+ */
+#ifndef VVC_ORACLE_H
+#define VVC_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_CU 128
+#define ORC_NUM_LUMA_MODE 67
+#define ORC_PLANAR 0
+#define ORC_DC 1
+#define ORC_HOR 18
+#define ORC_DIA 34
+#define ORC_VER 50
+#define ORC_VDIA 66
+#define ORC_DM_CHROMA 70
+#define ORC_MAX_DOUBLE 1.7e+308
+
+/* tool flags (bit mask) — which parts of BIN/encoder_intra.cfg are enabled.  Round 1 restates the
+ * subset "P0"; the remaining flags are accepted by the C-ABI and rejected with an error until built. */
+enum {
+  ORC_TOOL_MRL   = 1 << 0,  /* multi-reference-line (compile-time always on in the reference) */
+  ORC_TOOL_MIP   = 1 << 1, ORC_TOOL_ISP = 1 << 2, ORC_TOOL_LFNST = 1 << 3, ORC_TOOL_MTS = 1 << 4,
+  ORC_TOOL_TS    = 1 << 5, ORC_TOOL_DEPQUANT = 1 << 6, ORC_TOOL_RDOQ = 1 << 7, ORC_TOOL_CCLM = 1 << 8,
+  ORC_TOOL_JCCR  = 1 << 9, ORC_TOOL_LMCS = 1 << 10, ORC_TOOL_CU_REUSE = 1 << 11
+};
+
+typedef struct {
+  int pic_w, pic_h;        /* luma samples */
+  int bit_depth;           /* 8 or 10 */
+  int ctu_size;            /* 128 (cfg CTUSize) */
+  int min_qt[2];           /* MinQTLumaISlice 8, MinQTChromaISlice 4 */
+  int max_bt_depth[2];     /* MaxBTDepthISliceL/C 3,3 */
+  int max_bt_size[2];      /* MAX_BT_SIZE 32, MAX_BT_SIZE_C 64 (CL/CommonDef.h:427-437) */
+  int max_tt_size[2];      /* MAX_TT_SIZE 32, MAX_TT_SIZE_C 32 */
+  int dual_tree;           /* DualITree 1 */
+  int tile_cols, tile_rows;/* uniform tile grid in CTUs (1,1 = one stream per frame) */
+  uint32_t tools;          /* ORC_TOOL_* */
+  int chroma;              /* 1: code the chroma tree as well */
+} orc_cfg;
+
+typedef struct {
+  int    qp;               /* slice QP (luma) */
+  int    qp_c[2];          /* mapped chroma QP for Cb, Cr */
+  double lambda;           /* RdCost lambda (EL/EncSlice.cpp:754-845) */
+  double dist_weight[2];   /* chroma distortion weights (EL/EncSlice.cpp:125) */
+} orc_slice;
+
+/* one final coding unit, ≙ the fields D_BLOCK_STATISTICS_CODED prints (CL/dtrace_blockstatistics.cpp) */
+typedef struct {
+  int16_t  x, y, w, h;     /* luma samples for ch_type 0, chroma samples for ch_type 1 */
+  uint8_t  ch_type;        /* 0 luma tree, 1 chroma tree */
+  uint8_t  qt_depth, bt_depth, mt_depth, depth;
+  uint8_t  intra_dir;      /* luma mode, or chroma mode (70 = DM) */
+  uint8_t  mrl_idx;        /* multiRefIdx 0/1/3 */
+  uint8_t  cbf;            /* bit0 Y, bit1 Cb, bit2 Cr */
+  uint64_t split_series;
+} orc_cu;
+
+typedef struct {
+  uint64_t dist;           /* Σ SSE of the CTU (luma tree + weighted chroma tree) */
+  uint64_t frac_bits;      /* Σ estimated bits, 2^-15 units */
+  double   cost;           /* luma-tree root cost + chroma-tree root cost */
+  int      n_cu;
+} orc_ctu_result;
+
+typedef struct orc_enc orc_enc;
+
+orc_enc *orc_create(const orc_cfg *cfg);
+void     orc_destroy(orc_enc *e);
+int      orc_set_slice(orc_enc *e, const orc_slice *s);
+/* planes: 3 pointers (Y,U,V) of bytes_per_sample 1 or 2, strides in samples */
+int      orc_load_frame(orc_enc *e, const void *const org[3], const int stride[3], int bytes_per_sample);
+/* compress every CTU of the loaded frame (tiles in raster order, CTUs in raster order inside a tile) */
+int      orc_compress_frame(orc_enc *e, orc_ctu_result *res /* [n_ctus] */, orc_cu *cus, int max_cus, int *n_cus);
+int      orc_get_reco(orc_enc *e, void *const reco[3], const int stride[3], int bytes_per_sample);
+const char *orc_last_error(void);
+/* work counters for the bench's diagnostic model */
+void     orc_get_counters(orc_enc *e, uint64_t out[4]); /* satd candidates, rd candidates, rd pixels, nodes */
+
+/* ---------------- leaf operators (individually testable; used by the golden-vector tests) -------- */
+/* CL/TrQuant_EMT.cpp 1-D kernels restated as plain matrix products: tr 0=DCT2 1=DCT8 2=DST7 */
+void orc_fwd_1d(int tr, int n, const int *src, int *dst, int shift, int line, int skip1, int skip2);
+void orc_inv_1d(int tr, int n, const int *src, int *dst, int shift, int line, int skip1, int skip2, int cmin, int cmax);
+/* CL/TrQuant.cpp:835-992 (xT / xIT), DCT2 both directions */
+void orc_fwd_2d(const int16_t *resi, int stride, int w, int h, int bit_depth, int *coef);
+void orc_inv_2d(const int *coef, int w, int h, int bit_depth, int16_t *resi, int stride);
+/* CL/Quant.cpp:994-1089 (plain quant, I-slice offset 171) and 423-549 (dequant) */
+int  orc_quant(const int *coef, int w, int h, int bit_depth, int qp, int16_t *level);
+void orc_dequant(const int16_t *level, int w, int h, int bit_depth, int qp, int *coef);
+/* CL/RdCost.cpp xGetSAD / xGetHADs / xGetSSE */
+uint64_t orc_sad(const int16_t *a, int sa, const int16_t *b, int sb, int w, int h);
+uint64_t orc_satd(const int16_t *a, int sa, const int16_t *b, int sb, int w, int h);
+uint64_t orc_sse(const int16_t *a, int sa, const int16_t *b, int sb, int w, int h);
+/* CL/RdCost.cpp:63-88 */
+double orc_calc_rd_cost(double lambda, uint64_t frac_bits, uint64_t dist);
+/* CL/Contexts.cpp:135-151,1818-1833: context init for an I slice */
+void orc_ctx_init(int qp, uint16_t *s0, uint16_t *s1);
+uint64_t orc_ctx_code_bins(uint16_t *s0, uint16_t *s1, int ctx_id, const uint8_t *bins, int n);
+/* CL/IntraPrediction.cpp:1215-1522 + 426-935: build reference samples from a reco plane with an
+ * availability map (one byte per 4x4 luma unit / per 2x2.. see .c) and predict one mode.
+ * ref buffers hold (2h+1+mrl) rows x (2w+1+mrl) stride like the reference's m_piYuvExt. */
+void orc_fill_ref_samples(const int16_t *reco, int stride, int pic_w, int pic_h, const uint8_t *avail4, int avail_stride,
+                          int unit_log2, int tag, int x, int y, int w, int h, int mrl, int bit_depth, int16_t *ref_unf);
+void orc_filter_ref_samples(const int16_t *ref_unf, int16_t *ref_flt, int w, int h, int mrl);
+void orc_pred_intra(const int16_t *ref_unf, const int16_t *ref_flt, int w, int h, int is_luma, int mode, int mrl,
+                    int bit_depth, int16_t *pred, int pred_stride);
+/* CL/UnitTools.cpp:508-640 */
+void orc_get_mpms(int left_dir, int above_dir, unsigned mpm[6]);
+/* scan order (CL/Rom.cpp:87-370): fills idx[] with raster positions in coding order, returns count */
+int  orc_scan_order(int w, int h, uint16_t *idx);
+/* EL/CABACWriter.cpp:3773-3883 (+4102, 4164): estimated bits of residual_coding for one block; updates ctx */
+uint64_t orc_residual_bits(uint16_t *s0, uint16_t *s1, const int16_t *level, int w, int h, int is_chroma);
+
+/* test hooks: partition legality / split contexts / MPM list in a picture with given coded neighbour CUs */
+int orc_test_partition(int pic_w, int pic_h, int ch, int ctux, int ctuy, const int *nb, int n_nb, const int *path, int npath,
+                       int *can, unsigned *ctx, int *implicit, int *area);
+int orc_test_mpm(int pic_w, int pic_h, const int *nb, int n_nb, int x, int y, int w, int h, unsigned *mpm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

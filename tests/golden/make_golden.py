@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REAL reference code (oracle/_ref/libvtmref.so = the reference's
+CommonLib compiled from /root/reference with plain g++, see oracle/Makefile).
+
+Runs only in the authoring container.  The outputs (tests/golden/*.npz) are data: seeded inputs plus the
+reference's outputs.  tests/test_oracle_golden.py checks the CPU oracle against them everywhere
+(including the GPU box, where /root/reference does not exist).
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+R = C.CDLL(os.path.join(ROOT, "oracle/_ref/libvtmref.so"))
+R.ref_hads.restype = R.ref_sad.restype = R.ref_sse.restype = C.c_uint64
+R.ref_calc_rd_cost.restype = C.c_double
+R.ref_calc_rd_cost.argtypes = [C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]
+R.ref_ctx_code_bins.restype = C.c_uint64
+R.ref_ctx_code_bins.argtypes = [C.c_void_p, C.c_void_p, C.c_uint8, C.c_void_p, C.c_int]
+R.ref_env_create.restype = C.c_void_p
+R.ref_env_reset.argtypes = [C.c_void_p]
+R.ref_env_set_reco.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+R.ref_env_add_cu.argtypes = [C.c_void_p] + [C.c_int] * 8
+R.ref_env_pred.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p]
+R.ref_env_partition.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+
+rng = np.random.default_rng(20261003)
+P = lambda a: a.ctypes.data_as(C.c_void_p)
+
+
+def gen_transforms():
+    out = {}
+    cases = []
+    for tr in (0, 1, 2):
+        for n in (2, 4, 8, 16, 32, 64):
+            if tr and n in (2, 64):
+                continue
+            for line in sorted({2, 4, n, 16}):
+                z = n // 2 if ((tr == 0 and n == 64) or (tr != 0 and n == 32)) else 0   # the only zero-out combinations xT/xIT use (CL/TrQuant.cpp:853-854)
+                for (s1, s2) in ((0, 0), (0, z), (line // 2 if line >= 4 else 0, z)):
+                    cases.append((tr, n, line, s1, s2))
+    fwd_in, fwd_out, inv_in, inv_out, meta = [], [], [], [], []
+    for (tr, n, line, s1, s2) in cases:
+        src = rng.integers(-512, 512, n * line).astype(np.int32)
+        dst = np.zeros(n * line, np.int32)
+        shift = int(np.log2(n)) + 8 + 6 - 15 + (2 if n == 2 else 0)
+        shift = max(shift, 1)
+        assert R.ref_fwd_1d(tr, int(np.log2(n)), P(src), P(dst), shift, line, s1, s2) == 0
+        fwd_in.append(src); fwd_out.append(dst.copy())
+        src2 = rng.integers(-2000, 2000, n * line).astype(np.int32)
+        # zero the skipped coefficients like the encoder guarantees
+        m = src2.reshape(n, line); m[n - s2:, :] = 0 if s2 else m[n - s2:, :]; m[:, line - s1:] = 0 if s1 else m[:, line - s1:]
+        dst2 = np.zeros(n * line, np.int32)
+        assert R.ref_inv_1d(tr, int(np.log2(n)), P(src2), P(dst2), 7, line, s1, s2, -32768, 32767) == 0
+        inv_in.append(src2); inv_out.append(dst2.copy())
+        meta.append((tr, n, line, s1, s2, shift))
+    out["meta"] = np.array(meta, np.int32)
+    out["fwd_in"] = np.concatenate(fwd_in); out["fwd_out"] = np.concatenate(fwd_out)
+    out["inv_in"] = np.concatenate(inv_in); out["inv_out"] = np.concatenate(inv_out)
+    np.savez_compressed(os.path.join(HERE, "transforms.npz"), **out)
+
+
+def gen_dist():
+    shapes = [(w, h) for w in (4, 8, 16, 32, 64) for h in (2, 4, 8, 16, 32, 64) if not (h == 2 and w < 4)]
+    rows, a_all, b_all = [], [], []
+    for (w, h) in shapes:
+        for bd in (8, 10):
+            for k in range(3):
+                a = rng.integers(0, 1 << bd, (h, w)).astype(np.int16)
+                if k == 0:
+                    b = np.clip(a + rng.integers(-6, 7, (h, w)), 0, (1 << bd) - 1).astype(np.int16)
+                else:
+                    b = rng.integers(0, 1 << bd, (h, w)).astype(np.int16)
+                had = R.ref_hads(P(a), w, P(b), w, w, h, bd)
+                sad = R.ref_sad(P(a), w, P(b), w, w, h, bd)
+                sse = R.ref_sse(P(a), w, P(b), w, w, h, bd)
+                rows.append((w, h, bd, had, sad, sse)); a_all.append(a.ravel()); b_all.append(b.ravel())
+    np.savez_compressed(os.path.join(HERE, "dist.npz"), rows=np.array(rows, np.int64), a=np.concatenate(a_all), b=np.concatenate(b_all))
+
+
+def gen_cabac():
+    n = R.ref_ctx_count()
+    qps = [17, 22, 27, 32, 37, 42, 51]
+    s0 = np.zeros((len(qps), n), np.uint16); s1 = np.zeros((len(qps), n), np.uint16); rate = np.zeros((len(qps), n), np.uint8)
+    for i, qp in enumerate(qps):
+        R.ref_ctx_init(qp, 2, P(s0[i]), P(s1[i]), P(rate[i]))
+    # bin strings through individual models
+    seqs = []
+    for k in range(64):
+        ctx = int(rng.integers(0, n)); qi = int(rng.integers(0, len(qps)))
+        bins = (rng.random(200) < rng.random()).astype(np.uint8)
+        a = np.array([s0[qi, ctx]], np.uint16); b = np.array([s1[qi, ctx]], np.uint16)
+        bits = R.ref_ctx_code_bins(P(a), P(b), int(rate[qi, ctx]), P(bins), len(bins))
+        seqs.append((ctx, qi, bits, int(a[0]), int(b[0]), bins))
+    rd = []
+    for k in range(64):
+        lam = float(0.57 * 2.0 ** ((rng.integers(17, 45) - 12) / 3.0) * rng.choice([1.0, 2.0 ** (0.25 / 3)]))
+        fb = int(rng.integers(0, 1 << 30)); d = int(rng.integers(0, 1 << 28))
+        sq = C.c_double()
+        c = R.ref_calc_rd_cost(lam, 8, fb, d, C.byref(sq))
+        rd.append((lam, fb, d, c, sq.value))
+    np.savez_compressed(os.path.join(HERE, "cabac.npz"), qps=np.array(qps), s0=s0, s1=s1, rate=rate,
+                        seq_meta=np.array([(s[0], s[1], s[2], s[3], s[4]) for s in seqs], np.int64),
+                        seq_bins=np.stack([s[5] for s in seqs]),
+                        rd=np.array(rd, np.float64))
+
+
+def gen_scan():
+    out = {}
+    for w in (4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            idx = np.zeros(w * h, np.uint16)
+            R.ref_scan(w, h, P(idx))
+            out["s%dx%d" % (w, h)] = idx
+    np.savez_compressed(os.path.join(HERE, "scan.npz"), **out)
+
+
+def gen_intra():
+    """Random partial reconstructions of a 256x256 picture + all modes, real availability logic."""
+    W = H = 192
+    cases = []
+    for bd in (8, 10):
+        env = R.ref_env_create(W, H, bd)
+        for trial in range(6):
+            # low-entropy but non-trivial content (ramps + sparse noise) so that filters and clipping matter
+            reco = []
+            for c in range(3):
+                hh, ww = H >> (c > 0), W >> (c > 0)
+                base = ((np.arange(ww)[None, :] * int(rng.integers(1, 5)) + np.arange(hh)[:, None] * int(rng.integers(1, 5))) % (1 << bd))
+                noise = rng.integers(0, 1 << bd, (hh, ww)) * (rng.random((hh, ww)) < 0.08)
+                reco.append(np.clip(np.where(noise > 0, noise, base), 0, (1 << bd) - 1).astype(np.int16))
+            for c in range(3):
+                R.ref_env_set_reco(env, c, P(reco[c]), reco[c].shape[1])
+            for ch in (0, 1):
+                # choose current block
+                lw = int(rng.choice([4, 8, 16, 32, 64] if ch == 0 else [8, 16, 32, 64]))
+                lh = int(rng.choice([4, 8, 16, 32, 64] if ch == 0 else [4, 8, 16, 32, 64]))
+                if ch == 1 and lw * lh < 64:
+                    lh = 8
+                x = int(rng.integers(0, (W - lw) // lw + 1)) * lw
+                y = int(rng.integers(0, (H - lh) // lh + 1)) * lh
+                if trial % 5 == 0:
+                    x = 0
+                if trial % 7 == 0:
+                    y = 128 if trial % 2 else 0
+                R.ref_env_reset(env)
+                # coded neighbourhood: 8x8-luma granularity CUs over a random "already coded" region
+                coded = np.zeros((H // 8, W // 8), np.uint8)
+                mode = trial % 4
+                for by in range(H // 8):
+                    for bx in range(W // 8):
+                        px, py = bx * 8, by * 8
+                        inside = (px < x + lw and px + 8 > x and py < y + lh and py + 8 > y)
+                        if inside:
+                            continue
+                        if mode == 0:
+                            c_ = (py < y) or (py < y + lh and px < x)
+                        elif mode == 1:
+                            c_ = (py + 8 <= y) or (px + 8 <= x and py < y + 2 * lh)
+                        elif mode == 2:
+                            c_ = rng.random() < 0.6 and ((py < y + 2 * lh and px < x) or py < y)
+                        else:
+                            c_ = (py < y) or (px < x)
+                        coded[by, bx] = c_
+                nb = []
+                for by in range(H // 8):
+                    for bx in range(W // 8):
+                        if coded[by, bx]:
+                            d = int(rng.integers(0, 67)) if ch == 0 else int(rng.integers(0, 67))
+                            R.ref_env_add_cu(env, ch, bx * 8, by * 8, 8, 8, d, 3, 1)
+                            nb.append((bx * 8, by * 8, d))
+                comps = (0,) if ch == 0 else (1, 2)
+                modes = list(range(67))
+                for comp in comps:
+                    for dirm in modes:
+                        mrls = (0, 1, 3) if (ch == 0 and dirm != 0 and (y % 128) != 0) else (0,)
+                        for mrl in mrls:
+                            for force in ((0, 1) if ch == 0 and dirm % 7 == 0 else (0,)):
+                                cw, chh = (lw, lh) if ch == 0 else (lw // 2, lh // 2)
+                                pred = np.zeros(cw * chh, np.int16)
+                                mpm = np.zeros(6, np.uint32)
+                                R.ref_env_reset(env)
+                                for (nx, ny, d) in nb:
+                                    R.ref_env_add_cu(env, ch, nx, ny, 8, 8, d, 3, 1)
+                                rc = R.ref_env_pred(env, comp, x, y, lw, lh, dirm, mrl, force, P(pred), P(mpm))
+                                assert rc == 0
+                                cases.append(dict(bd=bd, trial=trial, comp=comp, x=x, y=y, w=lw, h=lh, dir=dirm, mrl=mrl, force=force,
+                                                  pred=pred, mpm=mpm.copy(), key=(bd, trial, ch)))
+                # remember environment for this (bd, trial, ch)
+                cases.append(dict(envdef=True, key=(bd, trial, ch), reco=[r.copy() for r in reco], coded=coded.copy(),
+                                  dirs=np.array(nb, np.int32).reshape(-1, 3)))
+    # pack
+    envs = [c for c in cases if c.get("envdef")]
+    preds = [c for c in cases if not c.get("envdef")]
+    out = {}
+    for i, e in enumerate(envs):
+        out["env%d_key" % i] = np.array(e["key"], np.int32)
+        for c in range(3):
+            out["env%d_reco%d" % (i, c)] = e["reco"][c]
+        out["env%d_coded" % i] = e["coded"]
+        out["env%d_dirs" % i] = e["dirs"]
+    keyidx = {tuple(e["key"]): i for i, e in enumerate(envs)}
+    out["n_env"] = np.array(len(envs))
+    out["case_meta"] = np.array([(keyidx[c["key"]], c["bd"], c["comp"], c["x"], c["y"], c["w"], c["h"], c["dir"], c["mrl"], c["force"]) for c in preds], np.int32)
+    out["case_mpm"] = np.stack([c["mpm"] for c in preds]).astype(np.uint8)
+    out["case_pred"] = np.concatenate([c["pred"] for c in preds])
+    np.savez_compressed(os.path.join(HERE, "intra.npz"), **out)
+    print("intra cases", len(preds), "envs", len(envs))
+
+
+def gen_partition():
+    """canSplit / implicit split / split contexts along random split paths, picture 416x240 (boundary CTUs)."""
+    W, H = 416, 240
+    env = R.ref_env_create(W, H, 8)
+    rows = []
+    for trial in range(2500):
+        ch = int(rng.integers(0, 2))
+        ctux = int(rng.integers(0, 4)) * 128; ctuy = int(rng.integers(0, 2)) * 128
+        path = []
+        ok = True
+        can = np.zeros(6, np.int32); ctx = np.zeros(5, np.uint32); impl = C.c_int(); area = np.zeros(8, np.int32)
+        depth = int(rng.integers(0, 7))
+        R.ref_env_reset(env)
+        # neighbours left/above of the CTU with random sizes so that the contexts vary
+        nbs = []
+        for k in range(0, 128, 32):
+            sz = int(rng.choice([8, 16, 32]))
+            if ctux > 0 and ctuy + k + sz <= H:
+                nbs.append((ch, ctux - sz, ctuy + k, sz, sz, int(rng.integers(1, 5)), 0))
+            if ctuy > 0 and ctux + k + sz <= W:
+                nbs.append((ch, ctux + k, ctuy - sz, sz, sz, int(rng.integers(1, 5)), 0))
+        for nb in nbs:
+            R.ref_env_add_cu(env, nb[0], nb[1], nb[2], nb[3], nb[4], nb[6], nb[5], 0)
+        for d in range(depth):
+            p = np.array(path, np.int32)
+            rc = R.ref_env_partition(env, ch, ctux, ctuy, P(p) if len(path) else None, len(path) // 2, P(can), P(ctx), C.byref(impl), P(area))
+            if rc != 0:
+                ok = False; break
+            options = [s for s in range(1, 6) if can[s]]
+            if not options:
+                break
+            s = int(rng.choice(options))
+            nparts = 4 if s == 1 else 2 if s in (2, 3) else 3
+            path += [s, int(rng.integers(0, nparts))]
+        if not ok:
+            continue
+        p = np.array(path, np.int32)
+        rc = R.ref_env_partition(env, ch, ctux, ctuy, P(p) if len(path) else None, len(path) // 2, P(can), P(ctx), C.byref(impl), P(area))
+        if rc != 0:
+            continue
+        if area[0] >= W or area[1] >= H:
+            continue
+        pad = np.zeros(16, np.int32); pad[:len(path)] = path
+        nbpad = np.zeros(8 * 7, np.int32)
+        if nbs:
+            nbpad[:len(nbs) * 7] = np.array(nbs, np.int32).ravel()
+        rows.append(np.concatenate([np.array([ch, ctux, ctuy, len(path) // 2], np.int32), pad, can, ctx.astype(np.int32), np.array([impl.value], np.int32), area, np.array([len(nbs)], np.int32), nbpad]).astype(np.int32))
+    np.savez_compressed(os.path.join(HERE, "partition.npz"), rows=np.stack(rows))
+    print("partition cases", len(rows))
+
+
+if __name__ == "__main__":
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition()
+    print("done")

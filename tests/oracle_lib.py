@@ -1,0 +1,119 @@
+"""ctypes binding of the CPU oracle (oracle/build/liboracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "build", "liboracle.so")
+
+
+class OrcCfg(C.Structure):
+    _fields_ = [("pic_w", C.c_int), ("pic_h", C.c_int), ("bit_depth", C.c_int), ("ctu_size", C.c_int),
+                ("min_qt", C.c_int * 2), ("max_bt_depth", C.c_int * 2), ("max_bt_size", C.c_int * 2),
+                ("max_tt_size", C.c_int * 2), ("dual_tree", C.c_int), ("tile_cols", C.c_int), ("tile_rows", C.c_int),
+                ("tools", C.c_uint32), ("chroma", C.c_int)]
+
+
+class OrcSlice(C.Structure):
+    _fields_ = [("qp", C.c_int), ("qp_c", C.c_int * 2), ("lam", C.c_double), ("dist_weight", C.c_double * 2)]
+
+
+class OrcCu(C.Structure):
+    _fields_ = [("x", C.c_int16), ("y", C.c_int16), ("w", C.c_int16), ("h", C.c_int16), ("ch_type", C.c_uint8),
+                ("qt_depth", C.c_uint8), ("bt_depth", C.c_uint8), ("mt_depth", C.c_uint8), ("depth", C.c_uint8),
+                ("intra_dir", C.c_uint8), ("mrl_idx", C.c_uint8), ("cbf", C.c_uint8), ("split_series", C.c_uint64)]
+
+
+class OrcCtuResult(C.Structure):
+    _fields_ = [("dist", C.c_uint64), ("frac_bits", C.c_uint64), ("cost", C.c_double), ("n_cu", C.c_int)]
+
+
+CU_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("ch_type", "u1"), ("qt_depth", "u1"),
+                     ("bt_depth", "u1"), ("mt_depth", "u1"), ("depth", "u1"), ("intra_dir", "u1"), ("mrl_idx", "u1"),
+                     ("cbf", "u1"), ("split_series", "<u8")], align=True)
+CTU_DTYPE = np.dtype([("dist", "<u8"), ("frac_bits", "<u8"), ("cost", "<f8"), ("n_cu", "<i4")], align=True)
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            build()
+        L = C.CDLL(SO)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(OrcCfg)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_slice.argtypes = [C.c_void_p, C.POINTER(OrcSlice)]
+        L.orc_load_frame.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
+        L.orc_compress_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.orc_get_reco.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
+        L.orc_get_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_sad.restype = L.orc_satd.restype = L.orc_sse.restype = C.c_uint64
+        L.orc_calc_rd_cost.restype = C.c_double
+        L.orc_calc_rd_cost.argtypes = [C.c_double, C.c_uint64, C.c_uint64]
+        L.orc_residual_bits.restype = C.c_uint64
+        L.orc_ctx_code_bins.restype = C.c_uint64
+        _lib = L
+    return _lib
+
+
+TOOL_MRL = 1
+
+
+def default_cfg(w, h, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOL_MRL):
+    c = OrcCfg()
+    c.pic_w, c.pic_h, c.bit_depth, c.ctu_size = w, h, bit_depth, 128
+    c.min_qt[0], c.min_qt[1] = 8, 4
+    c.max_bt_depth[0], c.max_bt_depth[1] = 3, 3
+    c.max_bt_size[0], c.max_bt_size[1] = 32, 64
+    c.max_tt_size[0], c.max_tt_size[1] = 32, 32
+    c.dual_tree, c.tile_cols, c.tile_rows, c.tools, c.chroma = 1, tile_cols, tile_rows, tools, chroma
+    return c
+
+
+def make_slice(sp):
+    s = OrcSlice()
+    s.qp = sp["qp"]
+    s.qp_c[0], s.qp_c[1] = sp["qp_c"]
+    s.lam = sp["lam"]
+    s.dist_weight[0], s.dist_weight[1] = sp["dist_weight"]
+    return s
+
+
+def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1):
+    """Run the oracle on one frame; returns (ctu results, cu table, reco planes, counters)."""
+    L = lib()
+    cfg = default_cfg(w, h, bit_depth, tile_cols, tile_rows, chroma)
+    e = L.orc_create(C.byref(cfg))
+    if not e:
+        raise RuntimeError(L.orc_last_error().decode())
+    try:
+        sl = make_slice(sp)
+        L.orc_set_slice(e, C.byref(sl))
+        bps = planes[0].dtype.itemsize
+        planes = [np.ascontiguousarray(p) for p in planes]
+        ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+        strides = (C.c_int * 3)(*[p.shape[1] for p in planes])
+        L.orc_load_frame(e, ptrs, strides, bps)
+        nctu = ((w + 127) // 128) * ((h + 127) // 128)
+        res = np.zeros(nctu, CTU_DTYPE)
+        cus = np.zeros(nctu * 2048, CU_DTYPE)
+        n = C.c_int()
+        rc = L.orc_compress_frame(e, res.ctypes.data, cus.ctypes.data, len(cus), C.byref(n))
+        assert rc == 0
+        reco = [np.zeros_like(p) for p in planes]
+        rptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in reco])
+        L.orc_get_reco(e, rptrs, strides, bps)
+        cnt = np.zeros(4, np.uint64)
+        L.orc_get_counters(e, cnt.ctypes.data)
+        return res, cus[:n.value].copy(), reco, cnt
+    finally:
+        L.orc_destroy(e)

@@ -1,0 +1,126 @@
+"""CPU tests: the oracle (oracle/*.c) against golden vectors produced by the REAL reference code
+(tests/golden/make_golden.py → oracle/_ref/libvtmref.so).  Bit-exact for every integer quantity; calcRdCost
+must be identical doubles (same two roundings, no FMA)."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+import oracle_lib as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+P = lambda a: a.ctypes.data_as(C.c_void_p)
+
+
+def test_transforms_1d():
+    L = O.lib()
+    g = np.load(os.path.join(G, "transforms.npz"))
+    off = 0
+    for (tr, n, line, s1, s2, shift) in g["meta"]:
+        k = n * line
+        src = np.ascontiguousarray(g["fwd_in"][off:off + k]); dst = np.zeros(k, np.int32)
+        L.orc_fwd_1d(int(tr), int(n), P(src), P(dst), int(shift), int(line), int(s1), int(s2))
+        assert np.array_equal(dst, g["fwd_out"][off:off + k]), ("fwd", tr, n, line, s1, s2)
+        src = np.ascontiguousarray(g["inv_in"][off:off + k]); dst = np.zeros(k, np.int32)
+        L.orc_inv_1d(int(tr), int(n), P(src), P(dst), 7, int(line), int(s1), int(s2), -32768, 32767)
+        assert np.array_equal(dst, g["inv_out"][off:off + k]), ("inv", tr, n, line, s1, s2)
+        off += k
+
+
+def test_distortion():
+    L = O.lib()
+    g = np.load(os.path.join(G, "dist.npz"))
+    off = 0
+    for (w, h, bd, had, sad, sse) in g["rows"]:
+        k = int(w * h)
+        a = np.ascontiguousarray(g["a"][off:off + k]); b = np.ascontiguousarray(g["b"][off:off + k]); off += k
+        assert L.orc_satd(P(a), int(w), P(b), int(w), int(w), int(h)) == had, ("satd", w, h)
+        assert L.orc_sad(P(a), int(w), P(b), int(w), int(w), int(h)) == sad
+        assert L.orc_sse(P(a), int(w), P(b), int(w), int(w), int(h)) == sse
+
+
+def test_cabac_model_and_rdcost():
+    L = O.lib()
+    g = np.load(os.path.join(G, "cabac.npz"))
+    n = g["s0"].shape[1]
+    for i, qp in enumerate(g["qps"]):
+        s0 = np.zeros(n, np.uint16); s1 = np.zeros(n, np.uint16)
+        L.orc_ctx_init(int(qp), P(s0), P(s1))
+        assert np.array_equal(s0, g["s0"][i]) and np.array_equal(s1, g["s1"][i])
+    for (ctx, qi, bits, e0, e1), bins in zip(g["seq_meta"], g["seq_bins"]):
+        a = np.array([g["s0"][qi, ctx]], np.uint16); b = np.array([g["s1"][qi, ctx]], np.uint16)
+        bins = np.ascontiguousarray(bins)
+        got = L.orc_ctx_code_bins(P(a), P(b), int(ctx), P(bins), len(bins))
+        assert (got, int(a[0]), int(b[0])) == (bits, e0, e1)
+    for (lam, fb, d, cost, sq) in g["rd"]:
+        assert L.orc_calc_rd_cost(C.c_double(lam), int(fb), int(d)) == cost      # identical double
+        assert np.sqrt(lam) == sq
+
+
+def test_scan_order():
+    L = O.lib()
+    g = np.load(os.path.join(G, "scan.npz"))
+    for key in g.files:
+        w, h = map(int, key[1:].split("x"))
+        idx = np.zeros(w * h, np.uint16)
+        n = L.orc_scan_order(w, h, P(idx))
+        assert n == min(w, 32) * min(h, 32)
+        assert np.array_equal(idx[:n], g[key][:n]), key
+
+
+def _avail_map(coded, W, H):
+    """coded: 8x8-luma granularity → one byte per 4x4 luma unit (value 1 = tag)."""
+    a = np.zeros((H // 4, W // 4), np.uint8)
+    a[:] = np.repeat(np.repeat(coded, 2, axis=0), 2, axis=1)
+    return a
+
+
+def test_intra_prediction_and_mpm():
+    L = O.lib()
+    g = np.load(os.path.join(G, "intra.npz"))
+    n_env = int(g["n_env"])
+    envs = []
+    for i in range(n_env):
+        reco = [np.ascontiguousarray(g["env%d_reco%d" % (i, c)]) for c in range(3)]
+        coded = g["env%d_coded" % i]
+        dirs = g["env%d_dirs" % i]
+        H, W = reco[0].shape
+        envs.append((reco, _avail_map(coded, W, H), dirs, W, H))
+    off = 0
+    nchk = 0
+    for (ei, bd, comp, x, y, w, h, dirm, mrl, force), mpm in zip(g["case_meta"], g["case_mpm"]):
+        reco, avail, dirs, W, H = envs[ei]
+        ch = 1 if comp else 0
+        cw, chh = (w, h) if not ch else (w // 2, h // 2)
+        cx, cy = (x, y) if not ch else (x // 2, y // 2)
+        exp = g["case_pred"][off:off + cw * chh]; off += cw * chh
+        ref_unf = np.zeros(4 * 300 * 300, np.int16); ref_flt = np.zeros_like(ref_unf)
+        plane = reco[comp]
+        L.orc_fill_ref_samples(P(plane), plane.shape[1], plane.shape[1], plane.shape[0], P(avail), avail.shape[1],
+                               1 if ch else 2, 1, int(cx), int(cy), int(cw), int(chh), int(mrl), int(bd), P(ref_unf))
+        L.orc_filter_ref_samples(P(ref_unf), P(ref_flt), int(cw), int(chh), int(mrl))
+        pred = np.zeros(cw * chh, np.int16)
+        L.orc_pred_intra(P(ref_unf), P(ref_flt), int(cw), int(chh), 0 if ch else 1, int(dirm), int(mrl), int(bd), P(pred), int(cw))
+        assert np.array_equal(pred, exp), ("pred", ei, comp, x, y, w, h, dirm, mrl, force)
+        if not ch and dirm == 0:
+            nb = np.array([(0, d[0], d[1], 8, 8, 3, d[2]) for d in dirs], np.int32).reshape(-1, 7)
+            got = np.zeros(6, np.uint32)
+            L.orc_test_mpm(int(W), int(H), P(nb), len(nb), int(x), int(y), int(w), int(h), P(got))
+            assert np.array_equal(got, mpm.astype(np.uint32)), ("mpm", ei, x, y, w, h)
+        nchk += 1
+    assert nchk > 1000
+
+
+def test_partitioner_and_split_contexts():
+    L = O.lib()
+    rows = np.load(os.path.join(G, "partition.npz"))["rows"]
+    for r in rows:
+        ch, ctux, ctuy, npath = map(int, r[:4])
+        path = np.ascontiguousarray(r[4:20]); can_e = r[20:26]; ctx_e = r[26:31]; impl_e = int(r[31]); area_e = r[32:40]
+        n_nb = int(r[40]); nb = np.ascontiguousarray(r[41:41 + 56])
+        can = np.zeros(6, np.int32); ctx = np.zeros(5, np.uint32); impl = C.c_int(); area = np.zeros(8, np.int32)
+        L.orc_test_partition(416, 240, ch, ctux, ctuy, P(nb), n_nb, P(path), npath, P(can), P(ctx), C.byref(impl), P(area))
+        impl_ref = {0: 0, 2000: 0}.get(impl_e, impl_e)
+        assert np.array_equal(area, area_e), ("area", r[:20])
+        assert np.array_equal(can, can_e), ("can", r[:20], can, can_e)
+        assert impl.value == impl_ref
+        assert np.array_equal(ctx.astype(np.int32), ctx_e), ("ctx", r[:20], ctx, ctx_e)
