@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""bench.py — CTUs/sec of the intra CU-partition RDO hot path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch: one 1920x1080 8-bit 4:2:0 All-Intra frame (135 CTUs of
+128x128) at QP 32, full RDO (no early termination) with the tool subset built so far (see config.tools).
+The frame is cut into a uniform 15x9 tile grid so that every CTU is an independent stream (one workgroup per
+stream); original planes are resident in HBM before the timed region.  With --gpus N every rank
+encodes its own frame per step (weak scaling, no data-path collective; frames are independent in All-Intra).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against HBM bandwidth with the
+algorithmic bytes of SURVEY.md §8d (49 152 B per 8-bit CTU); `cpu_baseline` times the CPU oracle (a port of the
+reference path, oracle/) on a bounded sample of the same workload on this host.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+B_CTU_8BIT = 49152          # 2 x 1.5 x 128 x 128 x 1 byte  
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=1, help="frames per step and rank")
+    ap.add_argument("--tiles", type=str, default="auto", help="CxR uniform tile grid; auto = one tile per CTU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-ctus", type=int, default=12)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.cuda.current_device()
+
+    pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+    W, H = args.width, args.height
+    ctus_w, ctus_h = (W + 127) // 128, (H + 127) // 128
+    if args.tiles == "auto":
+        tc, tr = ctus_w, ctus_h
+    else:
+        tc, tr = map(int, args.tiles.lower().split("x"))
+    sp = pkg.slice_params(args.qp)
+    enc = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, chroma=True, max_frames=args.frames, device=dev)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    frames = []
+    for f in range(args.frames):
+        planes = pkg.synth_frame(W, H, f, 8, 1000 + rank * 100 + f)
+        org = [torch.from_numpy(p).cuda() for p in planes]
+        rec = [torch.zeros_like(t) for t in org]
+        frames.append((org, rec))
+    bind = [([t.data_ptr() for t in o], [t.data_ptr() for t in r], [t.shape[1] for t in o]) for o, r in frames]
+    ctus_per_step = args.frames * ctus_w * ctus_h
+
+    def step():
+        enc.bind_frames(bind)                      # resets every stream to its tile start; planes stay in HBM
+        res = enc.compress_bound_frames()
+        return res, enc.last_kernel_ms()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    res = None
+    for _ in range(args.steps):
+        res, ms = step()
+        kernel_ms.append(ms)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    counters = enc.counters()
+
+    if rank == 0:
+        total_ctus = ctus_per_step * args.steps * world
+        value = total_ctus / elapsed
+        avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
+        achieved = ctus_per_step * B_CTU_8BIT / avg_kernel_s / 1e9
+        out = {
+            "metric": "CTUs/sec (All-Intra, QP32)", "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int16/int32 samples+coefficients, fp64 RD cost", "data": "synthetic",
+            "config": {"workload": "%dx%d 8-bit 4:2:0 All-Intra QP%d full RDO, %d frame(s)/step/GPU, %dx%d uniform tiles = %d CTU streams per frame"
+                                   % (W, H, args.qp, args.frames, tc, tr, tc * tr),
+                       "tools": "P0: 67 intra modes + PDPC + MRL, DCT-II, plain quant, dual tree; MIP/ISP/LFNST/MTS/TS/CCLM/JCCR/LMCS/DepQuant/RDOQ/CU-reuse not built yet",
+                       "ctus_per_step": ctus_per_step, "parallelism": "1 workgroup per CTU stream, frames sharded over ranks"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "vvcx_compress_kernel_u8", "kernel_ms": 1e3 * avg_kernel_s,
+                         "algorithmic_bytes_per_launch": ctus_per_step * B_CTU_8BIT},
+            "work": {"satd_candidates_per_launch": int(counters[0]), "rd_tu_evaluations_per_launch": int(counters[1]),
+                     "rd_pixels_per_launch": int(counters[2]), "nodes_per_launch": int(counters[3]),
+                     "rd_pixels_per_s": float(counters[2]) / avg_kernel_s},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            import oracle_lib as O
+            n = max(1, min(args.cpu_sample_ctus, ctus_w * ctus_h))
+            cw = min(ctus_w, 4)
+            chh = max(1, n // cw)
+            sw, sh = min(W, cw * 128), min(H, chh * 128)
+            planes = pkg.synth_frame(W, H, 0, 8, 1000)
+            crop = [planes[0][:sh, :sw], planes[1][:sh // 2, :sw // 2], planes[2][:sh // 2, :sw // 2]]
+            t1 = time.perf_counter()
+            O.compress_frame(crop, sw, sh, sp, tile_cols=(sw + 127) // 128, tile_rows=(sh + 127) // 128)
+            dt = time.perf_counter() - t1
+            nct = ((sw + 127) // 128) * ((sh + 127) // 128)
+            out["cpu_baseline"] = {"value": nct / dt, "unit": "CTU/s", "cores": 1, "kind": "port",
+                                   "sample": "top-left %dx%d crop (%d CTUs, one tile per CTU) of the same frame, same QP/tools, oracle/ built -O2 -mavx2, %.1f s" % (sw, sh, nct, dt)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

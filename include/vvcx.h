@@ -1,0 +1,124 @@
+/*
+ * vvcx.h — C-ABI of the MI355X-native VVC intra CU-partition RDO path.
+ *
+ * Drop-in boundary: the reference has no FFI; the functional seam is the member call
+ *     void EncCu::compressCtu(CodingStructure& cs, const UnitArea& area, unsigned ctuRsAddr,
+ *                             const int prevQP[], const int currQP[]);          // EL/EncCu.h:177
+ * invoked once per CTU from EncSlice::encodeCtus (EL/EncSlice.cpp:1768), plus its set-up contract
+ * create()/init()/destroy() (EL/EncCu.h:167-174) and the per-slice state the caller pushes before
+ * the CTU loop (lambda, QP, contexts: EL/EncSlice.cpp:1568-1572,1640-1661).  Each entry point below
+ * names the reference interface it replaces.  Plain C structs, no exceptions across the ABI: every
+ * function returns 0 on success or a negative vvcx_status; vvcx_last_error() gives the text.
+ * A handle is not thread-safe (one per GPU / host thread), like one EncCu instance per worker
+ * (EL/EncLib.cpp:115-125).
+ *
+ * Paths in comments are relative to /root/reference/VVC_project/source/Lib (EL = EncoderLib, CL = CommonLib).
+ */
+#ifndef VVCX_H
+#define VVCX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  VVCX_OK = 0, VVCX_ERR_ARG = -1, VVCX_ERR_UNSUPPORTED = -2, VVCX_ERR_DEVICE = -3, VVCX_ERR_STATE = -4, VVCX_ERR_NO_ENCODING = -5
+} vvcx_status;
+
+/* encoder tools of BIN/encoder_intra.cfg that reach the hot path.  Requesting a tool that
+ * is not built yet fails with VVCX_ERR_UNSUPPORTED instead of silently changing the result. */
+enum {
+  VVCX_TOOL_MRL = 1 << 0, VVCX_TOOL_MIP = 1 << 1, VVCX_TOOL_ISP = 1 << 2, VVCX_TOOL_LFNST = 1 << 3, VVCX_TOOL_MTS = 1 << 4,
+  VVCX_TOOL_TS = 1 << 5, VVCX_TOOL_DEPQUANT = 1 << 6, VVCX_TOOL_RDOQ = 1 << 7, VVCX_TOOL_CCLM = 1 << 8,
+  VVCX_TOOL_JCCR = 1 << 9, VVCX_TOOL_LMCS = 1 << 10, VVCX_TOOL_CU_REUSE = 1 << 11
+};
+
+/* ≙ the EncCfg/SPS fields EncCu::create/init read (EL/EncCu.cpp:167-236, CL/Slice.h PreCalcValues 2229-2275) */
+typedef struct {
+  int32_t pic_w, pic_h;          /* luma samples, multiples of 8 (APP/EncAppCfg.cpp:2709) */
+  int32_t bit_depth;             /* InternalBitDepth: 8 (uint8 planes) or 10 (uint16 planes) */
+  int32_t ctu_size;              /* CTUSize 128 */
+  int32_t min_qt[2];             /* MinQTLumaISlice, MinQTChromaISlice */
+  int32_t max_bt_depth[2];       /* MaxBTDepthISliceL / C */
+  int32_t max_bt_size[2];        /* MAX_BT_SIZE / MAX_BT_SIZE_C (CL/CommonDef.h:427,437) */
+  int32_t max_tt_size[2];        /* MAX_TT_SIZE / MAX_TT_SIZE_C */
+  int32_t dual_tree;             /* DualITree */
+  int32_t tile_cols, tile_rows;  /* uniform tile grid; every tile is an independent CTU stream */
+  uint32_t tools;                /* VVCX_TOOL_* */
+  int32_t chroma;                /* 1 = code the chroma tree too (4:2:0) */
+  int32_t max_frames;            /* frames resident per batch */
+  int32_t device;                /* HIP device ordinal */
+} vvcx_cfg;
+
+/* ≙ per-slice state pushed by EncSlice before the CTU loop: setUpLambda (EL/EncSlice.cpp:107-149),
+ * slice QP, mapped chroma QPs; CABAC contexts are (re)initialised at each tile start (1640-1647) */
+typedef struct {
+  int32_t qp;
+  int32_t qp_c[2];
+  double  lambda;
+  double  dist_weight[2];
+} vvcx_slice;
+
+/* one picture of a batch: DEVICE pointers to planar 4:2:0 samples (uint8 for 8 bit, uint16 for 10 bit),
+ * strides in samples.  ≙ cs.picture->getOrigBuf()/getRecoBuf() (CL/Picture.h); reco is written in place */
+typedef struct {
+  const void *org[3];
+  void       *reco[3];
+  int32_t     stride[3];
+} vvcx_frame;
+
+/* ≙ arguments of compressCtu: which CTU of which bound picture */
+typedef struct { int32_t frame; int32_t ctu_rs_addr; } vvcx_ctu_task;
+
+/* ≙ bestCS->dist / fracBits / cost after compressCtu (CL/CodingStructure.h:178-184), luma + chroma tree */
+typedef struct {
+  uint64_t dist;
+  uint64_t frac_bits;            /* 2^-15 bit units (CL/CommonDef.h:354) */
+  double   cost;
+  int32_t  n_cu;
+} vvcx_ctu_result;
+
+/* ≙ the CodingUnit/PredictionUnit/TransformUnit fields of the final CUs appended to cs (CL/Unit.h:292-470) */
+typedef struct {
+  int16_t  x, y, w, h;           /* luma samples for ch_type 0, chroma samples for ch_type 1 */
+  uint8_t  ch_type;
+  uint8_t  qt_depth, bt_depth, mt_depth, depth;
+  uint8_t  intra_dir;            /* luma mode 0..66; chroma mode (70 = DM) */
+  uint8_t  mrl_idx;              /* multiRefIdx */
+  uint8_t  cbf;                  /* bit0 Y, bit1 Cb, bit2 Cr */
+  uint64_t split_series;         /* CU::splitSeries, 5 bits per depth */
+} vvcx_cu;
+
+typedef struct vvcx_handle vvcx_handle;
+
+/* ≙ EncCu::create(EncCfg*) + init(EncLib*, const SPS&)  (EL/EncCu.h:167-171) */
+int  vvcx_create(const vvcx_cfg *cfg, vvcx_handle **h);
+/* ≙ EncCu::destroy() (EL/EncCu.h:173) */
+void vvcx_destroy(vvcx_handle *h);
+/* ≙ EncSlice::setUpLambda + slice QP (EL/EncSlice.cpp:107-149, 1568-1572) */
+int  vvcx_set_slice(vvcx_handle *h, const vvcx_slice *s);
+/* bind n pictures (device pointers) as the current batch and reset every CTU stream to its tile start
+ * (≙ Picture::finalInit + the context reset of EL/EncSlice.cpp:1640-1647) */
+int  vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n);
+/* ≙ n calls of EncCu::compressCtu (EL/EncCu.cpp:428) followed by the estimator pass
+ * CABACWriter::coding_tree_unit that advances the contexts (EL/EncSlice.cpp:1775-1776).
+ * Tasks of one (frame, tile) stream must appear in raster order of the tile and continue where the last
+ * call stopped; different streams run concurrently, one workgroup per stream.  `out` is host memory [n].
+ * `hip_stream` is a hipStream_t (NULL = default stream); the call returns after the work completed. */
+int  vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int n, vvcx_ctu_result *out, void *hip_stream);
+/* convenience: all CTUs of all bound frames in stream order (one launch) */
+int  vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out /* [n_frames * ctus_per_frame], host */, void *hip_stream);
+/* final CU table of one bound frame (CTU raster order; per CTU luma CUs then chroma CUs, by origin).
+ * ≙ walking cs.cus after the CTU loop; same fields D_BLOCK_STATISTICS_CODED traces */
+int  vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus, int *n_cus);
+/* device time of the last compress launch, measured with HIP events on the launch stream (ms) */
+float vvcx_last_kernel_ms(const vvcx_handle *h);
+/* work counters of the last launch: [0] SATD-stage candidates, [1] full-RD TU evaluations, [2] RD pixels, [3] nodes */
+int  vvcx_get_counters(vvcx_handle *h, uint64_t out[4]);
+const char *vvcx_last_error(void);
+int  vvcx_ctus_per_frame(const vvcx_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,3 @@
+"""MI355X-native VVC intra CU-partition RDO path.  Host-side Python mirror of include/vvcx.h."""
+from .vvcx import VvcxEncoder, VvcxError, load_library, TOOL_MRL  # noqa: F401
+from .synth import synth_frame, slice_params  # noqa: F401

@@ -1,0 +1,268 @@
+// vvcx_api.hip — host side of the C-ABI declared in include/vvcx.h: owns the device-resident state of a
+// batch of pictures (level planes, CU maps, per-stream contexts and scratch), turns compressCtu-style
+// tasks into one launch of the persistent per-stream kernel and reads results back.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+#include "vvcx.h"
+#include "vvcx_dev.h"
+#include "vvcx_tables.h"      // host copy of the constant tables (context init values)
+
+extern "C" __global__ void vvcx_compress_kernel_u8(VxParams p);
+extern "C" __global__ void vvcx_compress_kernel_u16(VxParams p);
+
+static thread_local char g_err[512];
+extern "C" const char *vvcx_last_error(void) { return g_err; }
+static int fail(int code, const char *fmt, ...)
+{
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+  return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(VVCX_ERR_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+struct vvcx_handle {
+  vvcx_cfg cfg; vvcx_slice sl; bool have_slice;
+  int ctus_w, ctus_h, uw, uh, ntiles;
+  std::vector<int> ctu_tile;                    // tile of each CTU (raster address)
+  std::vector<std::vector<int>> tile_ctus;      // CTUs of each tile in coding (raster-in-tile) order
+  int n_frames;
+  std::vector<VxFrameDev> frames_h;
+  std::vector<int> next_idx;                    // per (frame, tile): how many CTUs of the stream are done
+  // device memory
+  VxFrameDev *frames_d; int16_t *lev_d; VxUnit *units_d; uint16_t *stream_ctx_d;
+  uint8_t *scratch_d; size_t scratch_cap;
+  VxStreamDesc *streams_d; int32_t *task_ctu_d; VxCtuRes *results_d; int task_cap, stream_cap;
+  unsigned long long *counters_d;
+  hipEvent_t ev0, ev1; float last_ms;
+  size_t lev_plane[3], lev_frame, units_plane, units_frame;
+};
+
+static const uint32_t kBuiltTools = VVCX_TOOL_MRL;
+
+extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
+{
+  if (!cfg || !out) return fail(VVCX_ERR_ARG, "null argument");
+  if (cfg->tools & ~kBuiltTools) return fail(VVCX_ERR_UNSUPPORTED, "tool set 0x%x not built yet (available: 0x%x)", cfg->tools, kBuiltTools);
+  if (cfg->ctu_size != 128 || !cfg->dual_tree) return fail(VVCX_ERR_UNSUPPORTED, "only CTUSize 128 with DualITree 1");
+  if ((cfg->pic_w & 7) || (cfg->pic_h & 7) || cfg->pic_w <= 0 || cfg->pic_h <= 0) return fail(VVCX_ERR_ARG, "picture size must be a positive multiple of 8");
+  if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return fail(VVCX_ERR_UNSUPPORTED, "bit depth %d", cfg->bit_depth);
+  if (cfg->max_frames < 1 || cfg->tile_cols < 1 || cfg->tile_rows < 1) return fail(VVCX_ERR_ARG, "max_frames / tile grid");
+  vvcx_handle *h = new vvcx_handle();
+  h->cfg = *cfg; h->have_slice = false; h->n_frames = 0; h->last_ms = 0.f;
+  h->ctus_w = (cfg->pic_w + 127) >> 7; h->ctus_h = (cfg->pic_h + 127) >> 7;
+  if (cfg->tile_cols > h->ctus_w || cfg->tile_rows > h->ctus_h) { delete h; return fail(VVCX_ERR_ARG, "more tiles than CTUs"); }
+  h->uw = (cfg->pic_w + 3) >> 2; h->uh = (cfg->pic_h + 3) >> 2;
+  h->ntiles = cfg->tile_cols * cfg->tile_rows;
+  h->ctu_tile.resize((size_t) h->ctus_w * h->ctus_h);
+  h->tile_ctus.assign((size_t) h->ntiles, std::vector<int>());
+  for (int ry = 0; ry < h->ctus_h; ry++) for (int rx = 0; rx < h->ctus_w; rx++) {
+    int tc = 0, tr = 0;                          // uniform spacing: boundary i = i*N/T
+    for (int i = 0; i < cfg->tile_cols; i++) if (rx >= (i * h->ctus_w) / cfg->tile_cols) tc = i;
+    for (int i = 0; i < cfg->tile_rows; i++) if (ry >= (i * h->ctus_h) / cfg->tile_rows) tr = i;
+    const int t = tr * cfg->tile_cols + tc;
+    h->ctu_tile[(size_t) ry * h->ctus_w + rx] = t;
+    h->tile_ctus[(size_t) t].push_back(ry * h->ctus_w + rx);
+  }
+  if (hipSetDevice(cfg->device) != hipSuccess) { delete h; return fail(VVCX_ERR_DEVICE, "hipSetDevice(%d) failed", cfg->device); }
+  const int wc = cfg->pic_w >> 1, hc = cfg->pic_h >> 1;
+  h->lev_plane[0] = (size_t) cfg->pic_w * cfg->pic_h; h->lev_plane[1] = h->lev_plane[2] = (size_t) wc * hc;
+  h->lev_frame = h->lev_plane[0] + 2 * h->lev_plane[1];
+  h->units_plane = (size_t) h->uw * h->uh; h->units_frame = 2 * h->units_plane;
+  h->frames_d = nullptr; h->lev_d = nullptr; h->units_d = nullptr; h->stream_ctx_d = nullptr; h->scratch_d = nullptr; h->scratch_cap = 0;
+  h->streams_d = nullptr; h->task_ctu_d = nullptr; h->results_d = nullptr; h->task_cap = 0; h->stream_cap = 0; h->counters_d = nullptr;
+  const int F = cfg->max_frames;
+  if (hipMalloc((void **) &h->frames_d, sizeof(VxFrameDev) * F) != hipSuccess || hipMalloc((void **) &h->lev_d, h->lev_frame * 2 * F) != hipSuccess ||
+      hipMalloc((void **) &h->units_d, h->units_frame * sizeof(VxUnit) * F) != hipSuccess ||
+      hipMalloc((void **) &h->stream_ctx_d, (size_t) F * h->ntiles * 2 * VXD_NUM_CTX * 2) != hipSuccess ||
+      hipMalloc((void **) &h->counters_d, 4 * sizeof(unsigned long long)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
+  hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
+  *out = h;
+  return VVCX_OK;
+}
+
+extern "C" void vvcx_destroy(vvcx_handle *h)
+{
+  if (!h) return;
+  hipFree(h->frames_d); hipFree(h->lev_d); hipFree(h->units_d); hipFree(h->stream_ctx_d); hipFree(h->scratch_d);
+  hipFree(h->streams_d); hipFree(h->task_ctu_d); hipFree(h->results_d); hipFree(h->counters_d);
+  hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+  delete h;
+}
+
+extern "C" int vvcx_set_slice(vvcx_handle *h, const vvcx_slice *s)
+{
+  if (!h || !s) return fail(VVCX_ERR_ARG, "null argument");
+  if (!(s->lambda > 0.0) || s->qp < 0 || s->qp > 63) return fail(VVCX_ERR_ARG, "bad slice parameters");
+  h->sl = *s; h->have_slice = true;
+  return VVCX_OK;
+}
+
+// CtxStore::init for an I slice (CL/Contexts.cpp:135-151 JVET_O0065 form, 1818-1833)
+static void ctx_init_islice(int qp, uint16_t *s0, uint16_t *s1)
+{
+  qp = qp < 0 ? 0 : qp > 63 ? 63 : qp;
+  for (int k = 0; k < VXD_NUM_CTX; k++) {
+    const int id = VX_CTX_INIT_I[k];
+    const int slope = (id >> 3) - 4, offset = ((id & 7) * 18) + 1;
+    int st = ((slope * (qp - 16)) >> 1) + offset;
+    st = st < 1 ? 1 : st > 127 ? 127 : st;
+    const int p1 = st << 8;
+    s0[k] = (uint16_t) (p1 & 0x7FE0); s1[k] = (uint16_t) (p1 & 0x7FFE);
+  }
+}
+
+extern "C" int vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n)
+{
+  if (!h || !frames) return fail(VVCX_ERR_ARG, "null argument");
+  if (n < 1 || n > h->cfg.max_frames) return fail(VVCX_ERR_ARG, "n_frames %d outside 1..%d", n, h->cfg.max_frames);
+  if (!h->have_slice) return fail(VVCX_ERR_STATE, "vvcx_set_slice must precede vvcx_bind_frames");
+  h->frames_h.resize((size_t) n);
+  for (int f = 0; f < n; f++) {
+    VxFrameDev &d = h->frames_h[(size_t) f];
+    for (int c = 0; c < 3; c++) {
+      if (!frames[f].org[c] || !frames[f].reco[c]) return fail(VVCX_ERR_ARG, "frame %d plane %d is null", f, c);
+      d.org[c] = frames[f].org[c]; d.rec[c] = frames[f].reco[c]; d.stride[c] = frames[f].stride[c];
+      if (d.stride[c] < (c ? h->cfg.pic_w >> 1 : h->cfg.pic_w)) return fail(VVCX_ERR_ARG, "frame %d plane %d stride too small", f, c);
+    }
+    int16_t *lev = h->lev_d + (size_t) f * h->lev_frame;
+    d.lev[0] = lev; d.lev[1] = lev + h->lev_plane[0]; d.lev[2] = lev + h->lev_plane[0] + h->lev_plane[1];
+    d.lstride[0] = h->cfg.pic_w; d.lstride[1] = d.lstride[2] = h->cfg.pic_w >> 1;
+    d.units[0] = h->units_d + (size_t) f * h->units_frame; d.units[1] = d.units[0] + h->units_plane;
+  }
+  HIPCHK(hipMemcpy(h->frames_d, h->frames_h.data(), sizeof(VxFrameDev) * (size_t) n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(h->units_d, 0, h->units_frame * sizeof(VxUnit) * (size_t) n));
+  HIPCHK(hipMemset(h->lev_d, 0, h->lev_frame * 2 * (size_t) n));
+  std::vector<uint16_t> ctx((size_t) n * h->ntiles * 2 * VXD_NUM_CTX);
+  for (size_t s = 0; s < (size_t) n * h->ntiles; s++) ctx_init_islice(h->sl.qp, &ctx[s * 2 * VXD_NUM_CTX], &ctx[s * 2 * VXD_NUM_CTX + VXD_NUM_CTX]);
+  HIPCHK(hipMemcpy(h->stream_ctx_d, ctx.data(), ctx.size() * 2, hipMemcpyHostToDevice));
+  h->n_frames = n;
+  h->next_idx.assign((size_t) n * h->ntiles, 0);
+  return VVCX_OK;
+}
+
+extern "C" int vvcx_ctus_per_frame(const vvcx_handle *h) { return h ? h->ctus_w * h->ctus_h : 0; }
+
+extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int n, vvcx_ctu_result *out, void *hip_stream)
+{
+  if (!h || !tasks || !out || n < 0) return fail(VVCX_ERR_ARG, "bad argument");
+  if (h->n_frames == 0) return fail(VVCX_ERR_STATE, "no frames bound");
+  if (n == 0) return VVCX_OK;
+  hipStream_t stream = (hipStream_t) hip_stream;
+  const int nctu = h->ctus_w * h->ctus_h;
+  // group tasks by stream, keeping their order; validate that every stream continues in tile raster order
+  std::vector<std::vector<int>> by_stream((size_t) h->n_frames * h->ntiles);
+  for (int i = 0; i < n; i++) {
+    if (tasks[i].frame < 0 || tasks[i].frame >= h->n_frames || tasks[i].ctu_rs_addr < 0 || tasks[i].ctu_rs_addr >= nctu) return fail(VVCX_ERR_ARG, "task %d out of range", i);
+    by_stream[(size_t) tasks[i].frame * h->ntiles + h->ctu_tile[(size_t) tasks[i].ctu_rs_addr]].push_back(i);
+  }
+  std::vector<VxStreamDesc> sd; std::vector<int32_t> task_ctu; std::vector<int> task_src;
+  std::vector<int> new_next = h->next_idx;
+  for (size_t s = 0; s < by_stream.size(); s++) {
+    if (by_stream[s].empty()) continue;
+    const int tile = (int) (s % h->ntiles);
+    VxStreamDesc d; d.frame = (int) (s / h->ntiles); d.tile = tile; d.first_task = (int) task_ctu.size(); d.n_tasks = (int) by_stream[s].size();
+    for (int i : by_stream[s]) {
+      const std::vector<int> &order = h->tile_ctus[(size_t) tile];
+      if (new_next[s] >= (int) order.size() || order[(size_t) new_next[s]] != tasks[i].ctu_rs_addr)
+        return fail(VVCX_ERR_STATE, "task %d (frame %d, CTU %d) is not the next CTU of its stream", i, tasks[i].frame, tasks[i].ctu_rs_addr);
+      new_next[s]++;
+      task_ctu.push_back(tasks[i].ctu_rs_addr); task_src.push_back(i);
+    }
+    sd.push_back(d);
+  }
+  const int ns = (int) sd.size();
+  if (ns > h->stream_cap) { hipFree(h->streams_d); h->streams_d = nullptr; HIPCHK(hipMalloc((void **) &h->streams_d, sizeof(VxStreamDesc) * (size_t) ns)); h->stream_cap = ns; }
+  if (n > h->task_cap) {
+    hipFree(h->task_ctu_d); hipFree(h->results_d); h->task_ctu_d = nullptr; h->results_d = nullptr;
+    HIPCHK(hipMalloc((void **) &h->task_ctu_d, sizeof(int32_t) * (size_t) n)); HIPCHK(hipMalloc((void **) &h->results_d, sizeof(VxCtuRes) * (size_t) n)); h->task_cap = n;
+  }
+  const size_t need = (size_t) ns * VXD_SCRATCH_BYTES;
+  if (need > h->scratch_cap) { hipFree(h->scratch_d); h->scratch_d = nullptr; HIPCHK(hipMalloc((void **) &h->scratch_d, need)); h->scratch_cap = need; }
+  HIPCHK(hipMemcpyAsync(h->streams_d, sd.data(), sizeof(VxStreamDesc) * (size_t) ns, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(h->task_ctu_d, task_ctu.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemsetAsync(h->counters_d, 0, 4 * sizeof(unsigned long long), stream));
+
+  VxParams p; memset(&p, 0, sizeof p);
+  p.pic_w = h->cfg.pic_w; p.pic_h = h->cfg.pic_h; p.bit_depth = h->cfg.bit_depth; p.chroma = h->cfg.chroma; p.tools = h->cfg.tools;
+  for (int k = 0; k < 2; k++) { p.min_qt[k] = h->cfg.min_qt[k]; p.max_bt_depth[k] = h->cfg.max_bt_depth[k]; p.max_bt_size[k] = h->cfg.max_bt_size[k]; p.max_tt_size[k] = h->cfg.max_tt_size[k]; p.qp_c[k] = h->sl.qp_c[k]; p.dist_weight[k] = h->sl.dist_weight[k]; }
+  p.ctus_w = h->ctus_w; p.ctus_h = h->ctus_h; p.uw = h->uw; p.uh = h->uh; p.qp = h->sl.qp;
+  p.lambda = h->sl.lambda;
+  p.dist_scale = (double) (1 << 15) / h->sl.lambda;                       // CL/RdCost.cpp:79
+  p.sqrt_lambda_fp = sqrt(h->sl.lambda) * (1.0 / (double) (1 << 15));     // EL/IntraSearch.cpp:297
+  p.frames = h->frames_d; p.streams = h->streams_d; p.task_ctu = h->task_ctu_d; p.results = h->results_d; p.stream_ctx = h->stream_ctx_d;
+  p.scratch = h->scratch_d; p.scratch_per_stream = VXD_SCRATCH_BYTES; p.counters = h->counters_d; p.ntiles = h->ntiles;
+
+  HIPCHK(hipEventRecord(h->ev0, stream));
+  if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_compress_kernel_u8, dim3((unsigned) ns), dim3(VXD_NT), 0, stream, p);
+  else hipLaunchKernelGGL(vvcx_compress_kernel_u16, dim3((unsigned) ns), dim3(VXD_NT), 0, stream, p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev1, stream));
+  std::vector<VxCtuRes> res((size_t) n);
+  HIPCHK(hipMemcpyAsync(res.data(), h->results_d, sizeof(VxCtuRes) * (size_t) n, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  h->next_idx = new_next;
+  for (int k = 0; k < n; k++) {
+    vvcx_ctu_result &o = out[task_src[(size_t) k]];
+    o.dist = res[(size_t) k].dist; o.frac_bits = res[(size_t) k].bits; o.cost = res[(size_t) k].cost; o.n_cu = res[(size_t) k].n_cu;
+    if (!(res[(size_t) k].cost < 1.7e+308)) return fail(VVCX_ERR_NO_ENCODING, "no possible encoding found for task %d (EL/EncCu.cpp:555-557)", task_src[(size_t) k]);
+  }
+  return VVCX_OK;
+}
+
+extern "C" int vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out, void *hip_stream)
+{
+  if (!h || !out) return fail(VVCX_ERR_ARG, "null argument");
+  const int nctu = h->ctus_w * h->ctus_h;
+  std::vector<vvcx_ctu_task> tasks; std::vector<int> dst;
+  for (int f = 0; f < h->n_frames; f++) for (int t = 0; t < h->ntiles; t++) {
+    const std::vector<int> &order = h->tile_ctus[(size_t) t];
+    for (size_t k = (size_t) h->next_idx[(size_t) f * h->ntiles + t]; k < order.size(); k++) { vvcx_ctu_task tk; tk.frame = f; tk.ctu_rs_addr = order[k]; tasks.push_back(tk); dst.push_back(f * nctu + order[k]); }
+  }
+  std::vector<vvcx_ctu_result> tmp(tasks.size());
+  const int rc = vvcx_compress_ctus(h, tasks.data(), (int) tasks.size(), tmp.data(), hip_stream);
+  if (rc != VVCX_OK) return rc;
+  for (size_t k = 0; k < tasks.size(); k++) out[dst[k]] = tmp[k];
+  return VVCX_OK;
+}
+
+extern "C" int vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus, int *n_cus)
+{
+  if (!h || !n_cus || frame < 0 || frame >= h->n_frames) return fail(VVCX_ERR_ARG, "bad argument");
+  std::vector<VxUnit> um(h->units_frame);
+  HIPCHK(hipMemcpy(um.data(), h->units_d + (size_t) frame * h->units_frame, h->units_frame * sizeof(VxUnit), hipMemcpyDeviceToHost));
+  int n = 0;
+  for (int ry = 0; ry < h->ctus_h; ry++) for (int rx = 0; rx < h->ctus_w; rx++)
+    for (int ch = 0; ch < (h->cfg.chroma ? 2 : 1); ch++) {
+      const int ul = ch ? 1 : 2;
+      for (int uy = ry * 32; uy < std::min(ry * 32 + 32, h->uh); uy++) for (int ux = rx * 32; ux < std::min(rx * 32 + 32, h->uw); ux++) {
+        const VxUnit &u = um[(size_t) ch * h->units_plane + (size_t) uy * h->uw + ux];
+        if (!u.tag || (u.x >> ul) != ux || (u.y >> ul) != uy) continue;
+        if (cus && n < max_cus) {
+          vvcx_cu &o = cus[n];
+          o.x = u.x; o.y = u.y; o.w = (int16_t) (1 << u.lw); o.h = (int16_t) (1 << u.lh); o.ch_type = (uint8_t) ch;
+          o.qt_depth = u.qt; o.bt_depth = u.bt; o.mt_depth = u.mt; o.depth = u.depth; o.intra_dir = u.dir; o.mrl_idx = u.mrl; o.cbf = u.cbf; o.split_series = u.ss;
+        }
+        n++;
+      }
+    }
+  *n_cus = n;
+  return (cus && n > max_cus) ? fail(VVCX_ERR_ARG, "CU table too small (%d > %d)", n, max_cus) : VVCX_OK;
+}
+
+extern "C" float vvcx_last_kernel_ms(const vvcx_handle *h) { return h ? h->last_ms : 0.f; }
+
+extern "C" int vvcx_get_counters(vvcx_handle *h, uint64_t out[4])
+{
+  if (!h || !out) return fail(VVCX_ERR_ARG, "null argument");
+  unsigned long long c[4];
+  HIPCHK(hipMemcpy(c, h->counters_d, sizeof c, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 4; i++) out[i] = c[i];
+  return VVCX_OK;
+}

@@ -1,0 +1,62 @@
+// vvcx_dev.h — structures shared by the host side of the C-ABI (vvcx_api.hip) and the device kernel
+// (vvcx_kernel.hip).  Plain PODs, laid out for HBM residency (see DESIGN.md "Data layout").
+#pragma once
+#include <stdint.h>
+
+#define VXD_NT 256          // threads per workgroup = one CTU stream
+#define VXD_NW 4            // wavefronts (64 lanes) per workgroup
+#define VXD_MAXD 14         // recursion levels kept in LDS
+#define VXD_NUM_CTX 386     // flat context array, same indexing as the reference's ContextSetCfg
+
+// one 4x4-luma unit of a channel-type map: the CU that covers it (≙ the fields of CodingUnit /
+// PredictionUnit / TransformUnit the path reads from neighbours and the caller reads at the end)
+struct VxUnit {
+  uint64_t ss;              // splitSeries
+  int16_t  x, y;            // CU origin, samples of this channel type
+  uint8_t  lw, lh;          // log2 size, samples of this channel type
+  uint8_t  qt, mt, bt, depth;
+  uint8_t  dir, mrl, cbf, pad;
+  uint16_t tag;             // 0 = not coded in the current path; else tile index + 1
+};
+
+struct VxFrameDev {         // one bound picture
+  const void *org[3];       // caller's planes (uint8 / uint16)
+  void       *rec[3];
+  int32_t     stride[3];
+  int16_t    *lev[3];       // quantised levels, plane layout (owned by the handle)
+  int32_t     lstride[3];
+  VxUnit     *units[2];     // luma-tree / chroma-tree maps, uw x uh
+};
+
+struct VxStreamDesc { int32_t frame, tile, first_task, n_tasks; };
+
+struct VxCtuRes { uint64_t dist, bits; double cost; int32_t n_cu, pad; };
+
+struct VxParams {
+  int32_t pic_w, pic_h, bit_depth, chroma;
+  uint32_t tools;
+  int32_t min_qt[2], max_bt_depth[2], max_bt_size[2], max_tt_size[2];
+  int32_t ctus_w, ctus_h, uw, uh;
+  int32_t qp, qp_c[2];
+  double  lambda, dist_scale, sqrt_lambda_fp, dist_weight[2];
+  const VxFrameDev   *frames;
+  const VxStreamDesc *streams;
+  const int32_t      *task_ctu;      // CTU raster address per task
+  VxCtuRes           *results;       // per task
+  uint16_t           *stream_ctx;    // per (frame*ntiles+tile): 2*VXD_NUM_CTX states carried CTU -> CTU
+  uint8_t            *scratch;       // per launched stream
+  uint64_t            scratch_per_stream;
+  unsigned long long *counters;      // 4 global work counters
+  int32_t             ntiles;
+};
+
+// per-stream scratch layout (bytes)
+#define VXD_STORE_REC   (128 * 128 * 2)
+#define VXD_STORE_UNITS (32 * 32 * (int) sizeof(VxUnit))
+#define VXD_STORE_LEVEL (2 * VXD_STORE_REC + VXD_STORE_UNITS)                 // rec + lev + units
+#define VXD_CTXSNAP     (2 * VXD_NUM_CTX * 2)                                 // s0 + s1
+#define VXD_OFF_STORE   0
+#define VXD_OFF_CTX     (VXD_OFF_STORE + VXD_MAXD * VXD_STORE_LEVEL)          // [MAXD + NW + 1][2] snapshots {start, best}: levels, per-wave parking, CTU start
+#define VXD_OFF_SLOTS   (VXD_OFF_CTX + (VXD_MAXD + VXD_NW + 1) * 2 * VXD_CTXSNAP) // big-block slots: [NW][2][2*4096] int16
+#define VXD_SLOT_ELEMS  (2 * 4096)
+#define VXD_SCRATCH_BYTES (VXD_OFF_SLOTS + VXD_NW * 2 * VXD_SLOT_ELEMS * 2)

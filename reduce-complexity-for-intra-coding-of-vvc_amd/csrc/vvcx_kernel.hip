@@ -1,0 +1,1517 @@
+// vvcx_kernel.hip — the device side of the hot path: one persistent workgroup (4 wavefronts) per CTU
+// stream runs the whole QT/BT/TT partition recursion of its CTUs on the GPU.
+//
+//   * thread 0 is the sequential "mode controller": an explicit-stack state machine that replays the
+//     reference's decision order (EL/EncCu.cpp xCompressCU 727 / xCheckModeSplit 1918 / xCheckRDCostIntra
+//     2402, EL/EncModeCtrl.cpp initCULevel 1203 / tryMode 1557 / useModeResult 2089).  It never touches
+//     pixels; it posts one parallel operation at a time.
+//   * all 256 threads execute the posted operation: LDS staging of the node's original tile and its
+//     L-shaped reference samples (CL/IntraPrediction.cpp:1215-1522), one wavefront per candidate for the
+//     SATD stage (prediction 426-935 + CL/RdCost.cpp SAD/Hadamard) and for the full-RD stage
+//     (residual → DCT-II → quant → estimated bits → dequant → inverse → reco → SSE;
+//     EL/IntraSearch.cpp:2694-3168, CL/TrQuant.cpp:835-992, CL/Quant.cpp:423-1089), wave reductions for
+//     the distortions, and the node-area copies between the picture planes and the per-level stores.
+//
+// Results are bit-identical to the CPU oracle by construction of the arithmetic (same integer
+// operations, fp64 cost arithmetic compiled with -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#define VX_QUAL static __device__ const
+#include "vvcx_tables.h"
+#include "vvcx_dev.h"
+
+#define NT VXD_NT
+#define NW VXD_NW
+#define MAXD VXD_MAXD
+#define NCTX VXD_NUM_CTX
+#define MAX_DOUBLE 1.7e+308
+
+enum { SPLIT_NONE = 0, SPLIT_QT = 1, SPLIT_BH = 2, SPLIT_BV = 3, SPLIT_TH = 4, SPLIT_TV = 5 };
+enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V };
+enum { PLANAR = 0, DC = 1, HOR = 18, DIA = 34, VER = 50, VDIA = 66, DM_CHROMA = 70 };
+enum { OP_NONE, OP_DONE, OP_LUMA_PREP, OP_STAGE_A, OP_STAGE_B, OP_CHROMA_RD, OP_SAVE_INTRA, OP_SAVE_PIC, OP_RESTORE_PIC,
+       OP_CLEAR_UNITS, OP_CTX_COPY };
+enum { PH_ENTER, PH_RUN, PH_A1_DONE, PH_A2_DONE, PH_B_DONE, PH_INTRA_SAVED, PH_CHILD, PH_CHILD_RET, PH_SPLIT_SAVED, PH_ADVANCE, PH_EXIT, PH_EXIT2 };
+enum { CTX_CUR = 0, CTX_START = 1, CTX_BEST = 2, CTX_WAVE = 3 };   // OP_CTX_COPY endpoints
+
+struct Ctx { uint16_t s0[NCTX], s1[NCTX]; };
+struct Cab { Ctx *c; uint64_t bits; };
+
+struct Sum {                       // what the mode controller reads from a CodingStructure
+  double cost; uint64_t dist, bits;
+  int16_t n_cu, f_bt, f_cbf, f_w, f_h, l_bt, l_w, l_h, max_qt, valid;
+};
+
+struct Frame {                     // one recursion level: partitioner level + ComprCUCtx + temp/best summaries
+  int16_t x, y, w, h;              // node area, luma samples
+  uint8_t depth, qt, bt, mt, impl_bt, last_split, part_idx, phase;
+  uint8_t impl_checked, impl_split, nmodes, did_h, did_v, did_q, do_th, do_tv;
+  uint8_t qt_before_bt, max_qt_sub, has_best, cur_mode, cur_split, child, nparts, first;
+  uint8_t modes[8];
+  int16_t px[4], py[4], pw[4], ph[4];
+  uint64_t ss;
+  double max_cost;
+  Sum best, temp;
+};
+
+struct Cand { uint8_t mode, mrl; };
+
+struct CtlState {            // controller-private working set (touched by thread 0 only)
+  Cand rdList[80]; double rdCost[80]; int rdSize, numRd;
+  uint8_t checked[67];
+  int n_a2;
+};
+
+struct Lds {
+  Ctx cur;                         // the estimator's contexts
+  Ctx wctx[NW];                    // per-wave working copies
+  int16_t org[4096];               // node's original tile: luma w*h, or Cb | Cr (cw*ch each)
+  int16_t refs[4][2][140];         // luma: set 0 mrl0 unfiltered, 1 mrl0 filtered, 2 mrl1, 3 mrl3; chroma: set 0 Cb, 1 Cr. [0]=top [1]=left
+  int32_t tmp[NW][2048];           // per-wave transform scratch / Hadamard scratch
+  int16_t slot[NW][2][2048];       // per-wave candidate slots (T = being evaluated, B = wave best): rec | lev
+  uint8_t flags[72]; int8_t src_unit[72];
+  Frame fr[MAXD];
+  // posted operation
+  int op, op_a, op_b, op_c, op_d, op_ch;
+  int nx, ny, nw, nh, nd;          // node of the posted op (luma coordinates) and its level
+  // candidates
+  Cand cand[64]; double cand_cost[64]; double cand_had[64]; int n_cand;
+  Cand rd[16]; double rd_cost[16]; uint64_t rd_dist[16]; uint64_t rd_bits[16]; uint8_t rd_cbf[16]; int n_rd;
+  int wave_best[NW], wave_slot[NW]; // candidate index of each wave's best and the slot that holds it
+  CtlState S; VxUnit cu;           // controller working set; CU record of the intra candidate being evaluated
+  unsigned mpm[6]; int mpm_n;
+  int dc_val[4];
+  int cur_tile, frame, ctu_x, ctu_y, tree_ch;
+  int d;                           // current recursion level
+  // intra result of the node being evaluated
+  int win_idx, win_wave;
+  unsigned long long cnt[4];
+};
+
+__shared__ Lds L;
+
+// ------------------------------------------------------------------------------------------------ utilities
+__device__ inline int ilog2i(int v) { return 31 - __clz(v); }
+__device__ inline int imin(int a, int b) { return a < b ? a : b; }
+__device__ inline int imax(int a, int b) { return a > b ? a : b; }
+__device__ inline int iabs(int a) { return a < 0 ? -a : a; }
+__device__ inline void wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ inline unsigned long long wave_sum_u64(unsigned long long v)
+{
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ inline int wave_sum_i32(int v)
+{
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ inline double rd_cost(const VxParams &p, uint64_t bits, uint64_t dist)
+{
+  // CL/RdCost.cpp:63-74: two roundings (mul, add); the file is built with -ffp-contract=off
+  const double a = p.dist_scale * (double) dist;
+  return a + (double) bits;
+}
+template <typename T> __device__ inline int ld_px(const void *plane, int idx) { return (int) ((const T *) plane)[idx]; }
+template <typename T> __device__ inline void st_px(void *plane, int idx, int v) { ((T *) plane)[idx] = (T) v; }
+
+// ------------------------------------------------------------------------------------------------ CABAC estimator
+// BinProbModel_Std + BitEstimator (CL/Contexts.h:86-155, EL/BinEncoder.h:238-303)
+__device__ inline void enc_bin(Cab &cb, unsigned bin, int ctx)
+{
+  Ctx *c = cb.c;
+  const unsigned st = (unsigned) (c->s0[ctx] + c->s1[ctx]) >> 8;
+  cb.bits += VX_BIN_FRAC_BITS[st * 2 + bin];
+  const int rate = VX_CTX_RATE[ctx];
+  const int r0 = 2 + ((rate >> 2) & 3), r1 = 3 + r0 + (rate & 3);
+  unsigned a = c->s0[ctx], b = c->s1[ctx];
+  a -= (a >> r0) & 0x7FE0u; b -= (b >> r1) & 0x7FFEu;
+  if (bin) { a += (0x7fffu >> r0) & 0x7FE0u; b += (0x7fffu >> r1) & 0x7FFEu; }
+  c->s0[ctx] = (uint16_t) a; c->s1[ctx] = (uint16_t) b;
+}
+__device__ inline void enc_ep(Cab &cb, int n) { cb.bits += (uint64_t) n << 15; }
+
+__device__ void cg_shape(int w, int h, int &lcw, int &lch)     // g_log2SbbSize, CL/Rom.cpp:250-261
+{
+  const int lw = ilog2i(w), lh = ilog2i(h);
+  if (lw >= 2 && lh >= 2) { lcw = 2; lch = 2; return; }
+  if (lh == 1) { lcw = lw >= 3 ? 3 : 1; lch = 1; return; }
+  lcw = 1; lch = lh >= 3 ? 3 : 1;
+}
+// position of scan index sp inside a bw x bh diagonal scan (CL/Rom.cpp:87-131), closed form by walking
+__device__ void diag_pos(int bw, int bh, int n, int &ox, int &oy)
+{
+  int line = 0, col = 0;
+  for (int i = 0; i < n; i++) {
+    if (col == bw - 1 || line == 0) { line += col + 1; col = 0; if (line >= bh) { col += line - (bh - 1); line = bh - 1; } }
+    else { col++; line--; }
+  }
+  ox = col; oy = line;
+}
+__device__ inline void enc_rem_abs(Cab &cb, unsigned bins, unsigned rice)       // EL/BinEncoder.cpp:444-472
+{
+  const unsigned thr = 5u << rice;
+  if (bins < thr) { enc_ep(cb, (int) ((bins >> rice) + 1 + rice)); return; }
+  const unsigned maxPrefix = 32 - 5 - 15;
+  unsigned prefix = 0, suffix, code = (bins >> rice) - 5;
+  if (code >= ((1u << maxPrefix) - 1)) { prefix = maxPrefix; suffix = 15; }
+  else { while (code > ((2u << prefix) - 2)) prefix++; suffix = prefix + rice + 1; }
+  enc_ep(cb, (int) (5 + prefix + suffix));
+}
+struct Cctx { int w, h, ch, tmpl_diag, tmpl_sum1; };
+__device__ int sig_ctx(Cctx &c, const int16_t *coeff, int blk)      // CL/ContextModelling.h:107-156 (state 0)
+{
+  const int W = c.w, H = c.h, posY = blk / W, posX = blk - posY * W;
+  const int16_t *p = coeff + blk;
+  const int diag = posX + posY;
+  int numPos = 0, sumAbs = 0;
+#define UPD(v) { int a = iabs(v); sumAbs += imin(4 + (a & 1), a); numPos += !!a; }
+  if (posX < W - 1) { UPD(p[1]); if (posX < W - 2) UPD(p[2]); if (posY < H - 1) UPD(p[W + 1]); }
+  if (posY < H - 1) { UPD(p[W]); if (posY < H - 2) UPD(p[W << 1]); }
+#undef UPD
+  int ofs = imin((sumAbs + 1) >> 1, 3) + (diag < 2 ? 4 : 0);
+  if (c.ch == 0) ofs += diag < 5 ? 4 : 0;
+  c.tmpl_diag = diag; c.tmpl_sum1 = sumAbs - numPos;
+  return VX_CTX_SigFlag[c.ch] + ofs;
+}
+__device__ int tmpl_abs_sum(const Cctx &c, const int16_t *coeff, int blk, int base)
+{
+  const int W = c.w, H = c.h, posY = blk / W, posX = blk - posY * W;
+  const int16_t *p = coeff + blk;
+  int sum = 0;
+  if (posX < W - 1) { sum += iabs(p[1]); if (posX < W - 2) sum += iabs(p[2]); if (posY < H - 1) sum += iabs(p[W + 1]); }
+  if (posY < H - 1) { sum += iabs(p[W]); if (posY < H - 2) sum += iabs(p[W << 1]); }
+  return imax(imin(sum - 5 * base, 31), 0);
+}
+// EL/CABACWriter.cpp residual_coding 3773-3883, last_sig_coeff 4102-4160, residual_coding_subblock 4164-4304
+// (regular residual, DepQuant off, sign hiding off).  Executed by ONE lane; coefficient tile stride = w.
+__device__ __noinline__ void residual_coding(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma)
+{
+  Cctx c; c.w = w; c.h = h; c.ch = is_chroma; c.tmpl_diag = -1; c.tmpl_sum1 = -1;
+  int lcw, lch; cg_shape(w, h, lcw, lch);
+  const int lcg = lcw + lch, cw = 1 << lcw, chh = 1 << lch;
+  const int zw = imin(32, w), zh = imin(32, h), wg = zw >> lcw, hg = zh >> lch;
+  const int ngroups = wg * hg, cgSize = 1 << lcg;
+  // inner scan of a coefficient group (<= 16 positions) and CG scan (<= 64 groups)
+  uint8_t ix[16], iy[16], gxs[64], gys[64];
+  { int line = 0, col = 0;
+    for (int n = 0; n < cgSize; n++) { ix[n] = (uint8_t) col; iy[n] = (uint8_t) line;
+      if (col == cw - 1 || line == 0) { line += col + 1; col = 0; if (line >= chh) { col += line - (chh - 1); line = chh - 1; } } else { col++; line--; } } }
+  { int line = 0, col = 0;
+    for (int n = 0; n < ngroups; n++) { gxs[n] = (uint8_t) col; gys[n] = (uint8_t) line;
+      if (col == wg - 1 || line == 0) { line += col + 1; col = 0; if (line >= hg) { col += line - (hg - 1); line = hg - 1; } } else { col++; line--; } } }
+#define BLK(sp) (((int) gys[(sp) >> lcg] * chh + iy[(sp) & (cgSize - 1)]) * w + (int) gxs[(sp) >> lcg] * cw + ix[(sp) & (cgSize - 1)])
+  const int nscan = zw * zh;
+  int scanPosLast = -1;
+  unsigned long long sigGroups = 0;      // by scan CG index
+  for (int sp = 0; sp < nscan; sp++) if (coeff[BLK(sp)]) { scanPosLast = sp; sigGroups |= 1ull << (sp >> lcg); }
+  if (scanPosLast < 0) return;
+  const int l2w = ilog2i(w), l2h = ilog2i(h);
+  int offx = 0, offy = 0, shx, shy;
+  if (is_chroma) { shx = imin(2, w >> 3); shy = imin(2, h >> 3); }
+  else { const int pc[8] = { 0, 0, 0, 3, 6, 10, 15, 21 }; offx = pc[l2w]; offy = pc[l2h]; shx = (l2w + 1) >> 2; shy = (l2h + 1) >> 2; }
+  {
+    const int blk = BLK(scanPosLast);
+    const int posY = blk / w, posX = blk - posY * w;
+    const int gx = VX_GROUP_IDX[posX], gy = VX_GROUP_IDX[posY];
+    const int maxX = VX_GROUP_IDX[zw - 1], maxY = VX_GROUP_IDX[zh - 1];
+    int k;
+    for (k = 0; k < gx; k++) enc_bin(cb, 1, VX_CTX_LastX[c.ch] + offx + (k >> shx));
+    if (gx < maxX) enc_bin(cb, 0, VX_CTX_LastX[c.ch] + offx + (k >> shx));
+    for (k = 0; k < gy; k++) enc_bin(cb, 1, VX_CTX_LastY[c.ch] + offy + (k >> shy));
+    if (gy < maxY) enc_bin(cb, 0, VX_CTX_LastY[c.ch] + offy + (k >> shy));
+    if (gx > 3) enc_ep(cb, (gx - 2) >> 1);
+    if (gy > 3) enc_ep(cb, (gy - 2) >> 1);
+  }
+  int regBins = (zw * zh * 28) >> 4;
+  unsigned long long sigPos = 0;         // m_sigCoeffGroupFlag by CG raster position
+  for (int sub = scanPosLast >> lcg; sub >= 0; sub--) {
+    const int cgX = gxs[sub], cgY = gys[sub], cgPos = cgY * wg + cgX;
+    const int minSub = sub << lcg, maxSub = minSub + cgSize - 1;
+    if ((sigGroups >> sub) & 1) sigPos |= 1ull << cgPos;
+    const int sigRight = (cgX + 1) < wg ? (int) ((sigPos >> (cgPos + 1)) & 1) : 0;
+    const int sigLower = (cgY + 1) < hg ? (int) ((sigPos >> (cgPos + wg)) & 1) : 0;
+    const int sigGroupCtx = VX_CTX_SigCoeffGroup[c.ch] + (sigRight | sigLower);
+    const int isLast = (scanPosLast >> lcg) == sub, isNotFirst = sub != 0;
+    const int firstSigPos = isLast ? scanPosLast : maxSub;
+    int nextSigPos = firstSigPos;
+    if (!isLast && isNotFirst) {
+      if ((sigPos >> cgPos) & 1) enc_bin(cb, 1, sigGroupCtx);
+      else { enc_bin(cb, 0, sigGroupCtx); continue; }
+    }
+    const int inferSigPos = nextSigPos != scanPosLast ? (isNotFirst ? minSub : -1) : nextSigPos;
+    int numNonZero = 0, remRegBins = regBins;
+    for (; nextSigPos >= minSub && remRegBins >= 4; nextSigPos--) {
+      const int blk = BLK(nextSigPos);
+      const int cf = coeff[blk];
+      const unsigned sigFlag = cf != 0;
+      if (numNonZero || nextSigPos != inferSigPos) { const int ctx = sig_ctx(c, coeff, blk); enc_bin(cb, sigFlag, ctx); remRegBins--; }
+      else if (nextSigPos != scanPosLast) sig_ctx(c, coeff, blk);
+      if (sigFlag) {
+        int off = 0;                       // ctxOffsetAbs (158-167)
+        if (c.tmpl_diag != -1) {
+          off = imin(c.tmpl_sum1, 4) + 1;
+          off += (!c.tmpl_diag ? (c.ch == 0 ? 15 : 5) : c.ch == 0 ? (c.tmpl_diag < 3 ? 10 : (c.tmpl_diag < 10 ? 5 : 0)) : 0);
+        }
+        numNonZero++;
+        int rem = iabs(cf) - 1;
+        const unsigned gt1 = !!rem;
+        enc_bin(cb, gt1, VX_CTX_GtxFlag[c.ch + 2] + off); remRegBins--;
+        if (gt1) {
+          rem -= 1;
+          enc_bin(cb, rem & 1, VX_CTX_ParFlag[c.ch] + off); rem >>= 1; remRegBins--;
+          enc_bin(cb, !!rem, VX_CTX_GtxFlag[c.ch] + off); remRegBins--;
+        }
+      }
+    }
+    const int firstPosMode2 = nextSigPos;
+    regBins = remRegBins;
+    for (int sp = firstSigPos; sp > firstPosMode2; sp--) {
+      const int blk = BLK(sp);
+      const unsigned a = (unsigned) iabs(coeff[blk]);
+      if (a >= 4) enc_rem_abs(cb, (a - 4) >> 1, VX_GORICE_PARS[tmpl_abs_sum(c, coeff, blk, 4)]);
+    }
+    for (int sp = firstPosMode2; sp >= minSub; sp--) {
+      const int blk = BLK(sp);
+      const unsigned a = (unsigned) iabs(coeff[blk]);
+      const int sumAll = tmpl_abs_sum(c, coeff, blk, 0);
+      const unsigned rice = VX_GORICE_PARS[sumAll], pos0 = VX_GORICE_POS0[sumAll];
+      enc_rem_abs(cb, a == 0 ? pos0 : a <= pos0 ? a - 1 : a, rice);
+      if (a) numNonZero++;
+    }
+    enc_ep(cb, numNonZero);
+  }
+#undef BLK
+}
+
+// ------------------------------------------------------------------------------------------------ partitioner (thread 0)
+__device__ int implicit_split(const VxParams &p, Frame &f, int ch)      // CL/UnitPartitioner.cpp:530-581
+{
+  if (f.impl_checked) return f.impl_split;
+  int split = SPLIT_NONE;
+  const int blIn = f.x < p.pic_w && (f.y + f.h - 1) < p.pic_h;
+  const int trIn = (f.x + f.w - 1) < p.pic_w && f.y < p.pic_h;
+  const int maxBt = p.max_bt_size[ch], minQt = p.min_qt[ch];
+  const int btAllowed = f.w <= maxBt && f.h <= maxBt;
+  const int qtAllowed = f.w > minQt && f.h > minQt && f.bt == 0;
+  if (!blIn && !trIn && qtAllowed) split = SPLIT_QT;
+  else if (!blIn && btAllowed) split = SPLIT_BH;
+  else if (!trIn && btAllowed) split = SPLIT_BV;
+  else if (!blIn || !trIn) split = SPLIT_QT;
+  if (f.w > 64 || f.h > 64) split = SPLIT_QT;                // dual tree (566-569)
+  f.impl_checked = 1; f.impl_split = (uint8_t) split;
+  return split;
+}
+__device__ __noinline__ void can_split(const VxParams &p, Frame &f, int ch, int can[6])   // CL/UnitPartitioner.cpp:379-466
+{
+  const int impl = implicit_split(p, f, ch);
+  const int maxBTD = p.max_bt_depth[ch] + f.impl_bt;
+  const int maxBt = p.max_bt_size[ch], minBt = 4, maxTt = p.max_tt_size[ch], minTt = 4, minQt = p.min_qt[ch];
+  const int cw = f.w >> 1, chh = f.h >> 1;
+  for (int i = 0; i < 6; i++) can[i] = 1;
+  int canBtt = f.mt < maxBTD;
+  const int last = f.last_split;
+  const int parl = last == SPLIT_TH ? SPLIT_BH : SPLIT_BV;
+  if (last != 0 && last != SPLIT_QT) can[1] = 0;
+  if (f.w <= minQt) can[1] = 0;
+  if (ch == 1 && cw <= 4) can[1] = 0;
+  if (impl != SPLIT_NONE) { can[0] = can[4] = can[5] = 0; can[2] = impl == SPLIT_BH; can[3] = impl == SPLIT_BV; return; }
+  if ((last == SPLIT_TH || last == SPLIT_TV) && f.part_idx == 1) { can[2] = parl != SPLIT_BH; can[3] = parl != SPLIT_BV; }
+  if (canBtt && (f.w <= minBt && f.h <= minBt) && (f.w <= minTt && f.h <= minTt)) canBtt = 0;
+  if (canBtt && (f.w > maxBt || f.h > maxBt) && (f.w > maxTt || f.h > maxTt)) canBtt = 0;
+  if (!canBtt) { can[2] = can[3] = can[4] = can[5] = 0; return; }
+  if (f.w > maxBt || f.h > maxBt) can[2] = can[3] = 0;
+  if (f.h <= minBt) can[2] = 0;
+  if (f.w > 64 && f.h <= 64) can[2] = 0;
+  if (ch == 1 && cw * chh <= 16) can[2] = 0;
+  if (f.w <= minBt) can[3] = 0;
+  if (f.w <= 64 && f.h > 64) can[3] = 0;
+  if (ch == 1 && cw * chh <= 16) can[3] = 0;
+  if (f.h <= 2 * minTt || f.h > maxTt || f.w > maxTt) can[4] = 0;
+  if (f.w > 64 || f.h > 64) can[4] = 0;
+  if (ch == 1 && cw * chh <= 32) can[4] = 0;
+  if (f.w <= 2 * minTt || f.w > maxTt || f.h > maxTt) can[5] = 0;
+  if (f.w > 64 || f.h > 64) can[5] = 0;
+  if (ch == 1 && cw * chh <= 32) can[5] = 0;
+}
+__device__ int can_do(const VxParams &p, Frame &f, int ch, int split) { int c[6]; can_split(p, f, ch, c); return c[split]; }
+
+// neighbour CU lookup (cs.getCU / getCURestricted → "coded in the current path and same tile")
+__device__ const VxUnit *get_cu(const VxParams &p, const VxFrameDev &fd, int ch, int px, int py, int tile)
+{
+  const int W = ch ? p.pic_w >> 1 : p.pic_w, H = ch ? p.pic_h >> 1 : p.pic_h, ul = ch ? 1 : 2;
+  if (px < 0 || py < 0 || px >= W || py >= H) return nullptr;
+  const VxUnit *u = &fd.units[ch][(py >> ul) * p.uw + (px >> ul)];
+  return u->tag == (uint16_t) (tile + 1) ? u : nullptr;
+}
+// DeriveCtx::CtxSplit (CL/ContextModelling.cpp:154-250) + CABACWriter::split_cu_mode (EL/CABACWriter.cpp:1010-1069)
+__device__ __noinline__ void enc_split_cu_mode(const VxParams &p, const VxFrameDev &fd, Cab &cb, Frame &f, int ch, int tile, int split)
+{
+  int can[6]; can_split(p, f, ch, can);
+  const int sh = ch ? 1 : 0;
+  const int bx = f.x >> sh, by = f.y >> sh, bw = f.w >> sh, bh = f.h >> sh;
+  const VxUnit *cuL = get_cu(p, fd, ch, bx - 1, by, tile), *cuA = get_cu(p, fd, ch, bx, by - 1, tile);
+  unsigned ctxSpl = 0;
+  if (cuL) ctxSpl += ((1 << cuL->lh) < bh) ? 1 : 0;
+  if (cuA) ctxSpl += ((1 << cuA->lw) < bw) ? 1 : 0;
+  unsigned numSplit = 0;
+  if (can[1]) numSplit += 2;
+  for (int i = 2; i < 6; i++) if (can[i]) numSplit += 1;
+  if (numSplit > 0) numSplit--;
+  ctxSpl += 3 * (numSplit >> 1);
+  unsigned ctxQt = (cuL && cuL->qt > f.qt) ? 1 : 0;
+  ctxQt += (cuA && cuA->qt > f.qt) ? 1 : 0;
+  ctxQt += f.qt < 2 ? 0 : 3;
+  unsigned ctxHv = 0;
+  const unsigned numHor = (unsigned) (can[2] + can[4]), numVer = (unsigned) (can[3] + can[5]);
+  if (numVer == numHor) {
+    const unsigned wAbove = cuA ? (1u << cuA->lw) : 1, hLeft = cuL ? (1u << cuL->lh) : 1;
+    const unsigned depAbove = (unsigned) bw / wAbove, depLeft = (unsigned) bh / hLeft;
+    if (depAbove == depLeft || !cuL || !cuA) ctxHv = 0; else if (depAbove < depLeft) ctxHv = 1; else ctxHv = 2;
+  } else if (numVer < numHor) ctxHv = 3; else ctxHv = 4;
+  const unsigned ctxH12 = f.mt <= 1 ? 1 : 0, ctxV12 = f.mt <= 1 ? 3 : 2;
+  const int canSplit = can[1] || can[2] || can[3] || can[4] || can[5];
+  const int isNo = split == SPLIT_NONE;
+  if (can[0] && canSplit) enc_bin(cb, !isNo, VX_CTX_SplitFlag + (int) ctxSpl);
+  if (isNo) return;
+  const int canBtt = can[2] || can[3] || can[4] || can[5];
+  const int isQt = split == SPLIT_QT;
+  if (can[1] && canBtt) enc_bin(cb, (unsigned) isQt, VX_CTX_SplitQtFlag + (int) ctxQt);
+  if (isQt) return;
+  const int canHor = can[2] || can[4], canVer = can[3] || can[5];
+  const int isVer = split == SPLIT_BV || split == SPLIT_TV;
+  if (canVer && canHor) enc_bin(cb, (unsigned) isVer, VX_CTX_SplitHvFlag + (int) ctxHv);
+  const int can14 = isVer ? can[5] : can[4], can12 = isVer ? can[3] : can[2];
+  const int is12 = isVer ? (split == SPLIT_BV) : (split == SPLIT_BH);
+  if (can12 && can14) enc_bin(cb, (unsigned) is12, VX_CTX_Split12Flag + (int) (isVer ? ctxV12 : ctxH12));
+}
+
+// PU::getIntraMPMs (CL/UnitTools.cpp:508-640)
+__device__ void derive_mpms(int Ld, int Ad, unsigned mpm[6])
+{
+  const int offset = 61, mod = 64;
+  mpm[0] = PLANAR; mpm[1] = DC; mpm[2] = VER; mpm[3] = HOR; mpm[4] = VER - 4; mpm[5] = VER + 4;
+  if (Ld == Ad) {
+    if (Ld > DC) { mpm[0] = PLANAR; mpm[1] = Ld; mpm[2] = ((Ld + offset) % mod) + 2; mpm[3] = ((Ld - 1) % mod) + 2; mpm[4] = ((Ld + offset - 1) % mod) + 2; mpm[5] = (Ld % mod) + 2; }
+  } else if (Ld > DC && Ad > DC) {
+    mpm[0] = PLANAR; mpm[1] = Ld; mpm[2] = Ad;
+    const int mx = mpm[1] > mpm[2] ? 1 : 2, mn = mpm[1] > mpm[2] ? 2 : 1;
+    const int d = (int) mpm[mx] - (int) mpm[mn];
+    if (d == 1) { mpm[3] = ((mpm[mn] + offset) % mod) + 2; mpm[4] = ((mpm[mx] - 1) % mod) + 2; mpm[5] = ((mpm[mn] + offset - 1) % mod) + 2; }
+    else if (d >= 62) { mpm[3] = ((mpm[mn] - 1) % mod) + 2; mpm[4] = ((mpm[mx] + offset) % mod) + 2; mpm[5] = (mpm[mn] % mod) + 2; }
+    else if (d == 2) { mpm[3] = ((mpm[mn] - 1) % mod) + 2; mpm[4] = ((mpm[mn] + offset) % mod) + 2; mpm[5] = ((mpm[mx] - 1) % mod) + 2; }
+    else { mpm[3] = ((mpm[mn] + offset) % mod) + 2; mpm[4] = ((mpm[mn] - 1) % mod) + 2; mpm[5] = ((mpm[mx] + offset) % mod) + 2; }
+  } else if (Ld + Ad >= 2) {
+    mpm[0] = PLANAR; mpm[1] = (unsigned) (Ld < Ad ? Ad : Ld);
+    mpm[2] = ((mpm[1] + offset) % mod) + 2; mpm[3] = ((mpm[1] - 1) % mod) + 2; mpm[4] = ((mpm[1] + offset - 1) % mod) + 2; mpm[5] = (mpm[1] % mod) + 2;
+  }
+}
+// CABACWriter::intra_luma_pred_mode 1762-1845 + extend_ref_line 1566-1591 (MIP/ISP off); MPMs from L.mpm
+__device__ void enc_intra_luma_pred_mode(Cab &cb, int y, int dir, int mrl)
+{
+  if ((y & 127) != 0) {
+    enc_bin(cb, mrl != 0, VX_CTX_MultiRefLineIdx + 0);
+    if (mrl != 0) enc_bin(cb, mrl != 1, VX_CTX_MultiRefLineIdx + 1);
+  }
+  int mpm_idx = 6;
+  for (int i = 0; i < 6; i++) if ((unsigned) dir == L.mpm[i]) { mpm_idx = i; break; }
+  if (!mrl) enc_bin(cb, mpm_idx < 6, VX_CTX_IntraLumaMpmFlag);
+  if (mpm_idx < 6) {
+    if (mrl == 0) enc_bin(cb, mpm_idx > 0, VX_CTX_IntraLumaPlanarFlag + 1);
+    enc_ep(cb, imin(mpm_idx, 4));
+  } else {
+    unsigned s[6];
+    for (int i = 0; i < 6; i++) s[i] = L.mpm[i];
+    for (int i = 1; i < 6; i++) { unsigned v = s[i]; int j = i - 1; while (j >= 0 && s[j] > v) { s[j + 1] = s[j]; j--; } s[j + 1] = v; }
+    unsigned m = (unsigned) dir;
+    for (int i = 5; i >= 0; i--) if (m > s[i]) m--;
+    enc_ep(cb, m < 3 ? 5 : 6);                   // xWriteTruncBinCode(m, 61)
+  }
+}
+__device__ void enc_intra_chroma_pred_mode(Cab &cb, int dir)      // 1891-1933, CCLM off
+{
+  const int isDM = dir == DM_CHROMA;
+  enc_bin(cb, isDM ? 0 : 1, VX_CTX_IntraChromaPredMode);
+  if (!isDM) enc_ep(cb, 2);
+}
+
+// ------------------------------------------------------------------------------------------------ intra prediction
+struct Ipa { int pred_mode, is_ver, mrl, ref_filter, interp, pdpc, angle, inv_angle, ang_scale; };
+static __device__ const int16_t ANG_TABLE[32] = { 0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 39, 45, 51, 57, 64, 73, 86, 102, 128, 171, 256, 341, 512, 1024 };
+static __device__ const int16_t INV_ANG_TABLE[32] = { 0, 16384, 8192, 5461, 4096, 2731, 2048, 1638, 1365, 1170, 1024, 910, 819, 712, 630, 565,
+  512, 468, 420, 364, 321, 287, 256, 224, 191, 161, 128, 96, 64, 48, 32, 16 };
+static __device__ const uint8_t INTRA_FILTER_THR[8] = { 24, 24, 24, 14, 2, 0, 0, 0 };
+static __device__ const int8_t GAUSS_FILTER[32][4] = {     // g_intraGaussFilter (spec table), CL/IntraPrediction.cpp:76
+  {16,32,16,0},{15,29,17,3},{15,29,17,3},{14,29,18,3},{13,29,18,4},{13,28,19,4},{13,28,19,4},{12,28,20,4},
+  {11,28,20,5},{11,27,21,5},{10,27,22,5},{9,27,22,6},{9,26,23,6},{9,26,23,6},{8,25,24,7},{8,25,24,7},
+  {8,24,24,8},{7,24,25,8},{7,24,25,8},{6,23,26,9},{6,23,26,9},{6,22,27,9},{5,22,27,10},{5,21,27,11},
+  {5,20,28,11},{4,20,28,12},{4,19,28,13},{4,19,28,13},{4,18,29,13},{3,18,29,14},{3,17,29,15},{3,17,29,15} };
+
+// getWideAngle 287-303 + initPredIntraParams 487-618
+__device__ void init_pred_params(int w, int h, int is_luma, int mode, int mrl, Ipa &p)
+{
+  int pm = mode;
+  if (pm > DC && pm <= VDIA) {
+    const int modeShift[6] = { 0, 6, 10, 12, 14, 15 };
+    const int ds = iabs(ilog2i(w) - ilog2i(h));
+    if (w > h && pm < 2 + modeShift[ds]) pm += VDIA - 1;
+    else if (h > w && pm > VDIA - modeShift[ds]) pm -= VDIA - 1;
+  }
+  p.pred_mode = pm; p.is_ver = pm >= DIA; p.mrl = is_luma ? mrl : 0; p.ref_filter = 0; p.interp = 0;
+  p.pdpc = ((w >= 4 && h >= 4) || !is_luma) && p.mrl == 0;
+  p.angle = 0; p.inv_angle = 0; p.ang_scale = -1;
+  const int am = p.is_ver ? pm - VER : -(pm - HOR);
+  int absAng = 0;
+  if (mode > DC && mode < 67) {
+    const int a = iabs(am);
+    absAng = ANG_TABLE[a]; p.inv_angle = INV_ANG_TABLE[a]; p.angle = am < 0 ? -absAng : absAng;
+    if (am < 0) p.pdpc = 0;
+    else if (am > 0) {
+      const int side = p.is_ver ? h : w;
+      int sc = ilog2i(side) - (ilog2i(3 * p.inv_angle - 2) - 8);
+      if (sc > 2) sc = 2;
+      p.ang_scale = sc; p.pdpc &= sc >= 0;
+    }
+  }
+  if (!is_luma || p.mrl || mode == DC) {}
+  else if (mode == PLANAR) p.ref_filter = w * h > 32;
+  else {
+    const int d1 = iabs(pm - HOR), d2 = iabs(pm - VER);
+    const int diff = d1 < d2 ? d1 : d2;
+    const int log2Size = (ilog2i(w) + ilog2i(h)) >> 1;
+    if (diff > INTRA_FILTER_THR[log2Size]) { const int is_int = (absAng & 0x1F) == 0; p.ref_filter = is_int; p.interp = !is_int; }
+  }
+}
+__device__ inline int clip_bd(int v, int bd) { const int mx = (1 << bd) - 1; return v < 0 ? 0 : v > mx ? mx : v; }
+
+// one predicted sample.  top[i] = pSrc.at(i,0), left[i] = pSrc.at(0,i) of the (un)filtered reference
+// buffer for this mrl; closed forms of xPredIntraPlanar 426-479, DC 248-285, xPredIntraAng 633-935 and
+// the planar/DC PDPC 354-378.
+__device__ int pred_sample(const int16_t *top, const int16_t *left, int w, int h, int px, int py, const Ipa &ip,
+                           int mode, int is_luma, int bd, int dcv)
+{
+  const int mrl = ip.mrl;
+  int v;
+  if (mode == PLANAR) {
+    const int l2w = ilog2i(w), l2h = ilog2i(h);
+    const int lft = left[py + 1], tp = top[px + 1];
+    const int hor = (lft << l2w) + (px + 1) * (top[w + 1] - lft);
+    const int ver = (tp << l2h) + (py + 1) * (left[h + 1] - tp);
+    v = ((hor << l2h) + (ver << l2w) + (1 << (l2w + l2h))) >> (1 + l2w + l2h);
+  } else if (mode == DC) {
+    v = dcv;
+  } else {
+    const int ver = ip.is_ver, ang = ip.angle, inv = ip.inv_angle;
+    const int W = ver ? w : h, H = ver ? h : w;
+    const int xx = ver ? px : py, yy = ver ? py : px;
+    const int16_t *mainp = ver ? top : left, *sidep = ver ? left : top;
+    const int sizeSide = H;
+    const int refLen = 2 * W;
+#define MAINR(i_) ({ int k_ = (i_) + mrl; int r_; if (k_ >= 0) { if (ang >= 0 && k_ > refLen + mrl) k_ = refLen + mrl; r_ = mainp[k_]; } \
+                     else { int j_ = (-k_ * inv + 256) >> 9; if (j_ > sizeSide) j_ = sizeSide; r_ = sidep[j_]; } r_; })
+#define SIDER(i_) ((int) sidep[(i_) + mrl])
+    if (ang == 0) {
+      v = MAINR(xx + 1);
+      if (ip.pdpc) {
+        const int scale = (ilog2i(W) + ilog2i(H) - 2) >> 2;
+        if (xx < imin(3 << scale, W)) {
+          const int wL = 32 >> (2 * xx >> scale);
+          v = clip_bd(v + ((wL * (SIDER(1 + yy) - MAINR(0)) + 32) >> 6), bd);
+        }
+      }
+    } else {
+      const int deltaPos = ang * (yy + 1 + mrl);
+      const int di = deltaPos >> 5, df = deltaPos & 31;
+      if ((iabs(ang) & 0x1F) != 0) {
+        if (is_luma) {
+          const int8_t *f = ip.interp ? GAUSS_FILTER[df] : &VX_CUBIC_FILTER[df * 4];
+          const int s = f[0] * MAINR(di + xx) + f[1] * MAINR(di + xx + 1) + f[2] * MAINR(di + xx + 2) + f[3] * MAINR(di + xx + 3);
+          v = clip_bd((int) (int16_t) ((s + 32) >> 6), bd);
+        } else {
+          const int p0 = MAINR(di + xx + 1), p1 = MAINR(di + xx + 2);
+          v = p0 + ((df * (p1 - p0) + 16) >> 5);
+        }
+      } else v = MAINR(xx + di + 1);
+      if (ip.pdpc) {
+        const int scale = ip.ang_scale;
+        if (xx < imin(3 << scale, W)) {
+          const int invSum = 256 + (xx + 1) * inv;
+          const int wL = 32 >> (2 * xx >> scale);
+          const int lft = SIDER(yy + (invSum >> 9) + 1);
+          v = v + ((wL * (lft - v) + 32) >> 6);
+        }
+      }
+    }
+#undef MAINR
+#undef SIDER
+  }
+  if (ip.pdpc && (mode == PLANAR || mode == DC)) {
+    const int scale = (ilog2i(w) - 2 + ilog2i(h) - 2 + 2) >> 2;
+    const int wT = 32 >> imin(31, (py << 1) >> scale), wL = 32 >> imin(31, (px << 1) >> scale);
+    v = v + ((wL * (left[py + 1] - v) + wT * (top[px + 1] - v) + 32) >> 6);
+  }
+  return (int) (int16_t) v;
+}
+
+// DC value of a reference set (xGetPredValDc 248-285): executed by one thread
+__device__ int dc_value(const int16_t *top, const int16_t *left, int w, int h, int mrl)
+{
+  int sum = 0;
+  const int denom = (w == h) ? (w << 1) : imax(w, h);
+  if (w >= h) for (int i = 0; i < w; i++) sum += top[mrl + 1 + i];
+  if (w <= h) for (int i = 0; i < h; i++) sum += left[mrl + 1 + i];
+  return (sum + (denom >> 1)) >> ilog2i(denom);
+}
+
+// ------------------------------------------------------------------------------------------------ reference samples (all threads)
+// xFillReferenceSamples 1215-1468 in parallel form: every reference sample either copies its own picture
+// sample (its unit is available) or the sample the sequential padding pass would have propagated to it:
+// the last sample of the nearest preceding available unit in scan order (bottom-left → top-right), or the
+// first sample of the first available unit when nothing precedes.  set layout: refs[set][0]=top, [1]=left.
+template <typename T>
+__device__ __noinline__ void build_refs(const VxParams &p, const VxFrameDev &fd, int comp, int x, int y, int w, int h, int tile, int nsets)
+{
+  const int tid = threadIdx.x;
+  const int ch = comp ? 1 : 0;
+  const int unit = ch ? 2 : 4, ul = ch ? 1 : 2;
+  const int W = ch ? p.pic_w >> 1 : p.pic_w, H = ch ? p.pic_h >> 1 : p.pic_h;
+  const int predW = 2 * w, predH = 2 * h;
+  const int totalAbove = predW / unit, totalLeft = predH / unit, totalUnits = totalAbove + totalLeft + 1;
+  const int numAbove = w / unit, numLeft = h / unit;
+  if (tid < totalUnits) {
+    int ux, uy;                         // a sample position inside the unit
+    if (tid < totalLeft) { ux = x - 1; uy = y + (totalLeft - 1 - tid) * unit; }
+    else if (tid == totalLeft) { ux = x - 1; uy = y - 1; }
+    else { ux = x + (tid - totalLeft - 1) * unit; uy = y - 1; }
+    int a = 0;
+    if (ux >= 0 && uy >= 0 && ux < W && uy < H) a = fd.units[ch][(uy >> ul) * p.uw + (ux >> ul)].tag == (uint16_t) (tile + 1);
+    L.flags[tid] = (uint8_t) a;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // isAbove/Left/...Available stop at the first missing unit of their segment (1544-1662)
+    int ok = 1; for (int i = 0; i < numAbove; i++) { ok &= L.flags[totalLeft + 1 + i]; L.flags[totalLeft + 1 + i] = (uint8_t) ok; }
+    ok = 1; for (int i = numAbove; i < totalAbove; i++) { ok &= L.flags[totalLeft + 1 + i]; L.flags[totalLeft + 1 + i] = (uint8_t) ok; }
+    ok = 1; for (int i = 0; i < numLeft; i++) { ok &= L.flags[totalLeft - 1 - i]; L.flags[totalLeft - 1 - i] = (uint8_t) ok; }
+    ok = 1; for (int i = numLeft; i < totalLeft; i++) { ok &= L.flags[totalLeft - 1 - i]; L.flags[totalLeft - 1 - i] = (uint8_t) ok; }
+    int firstAvail = -1;
+    for (int u = 0; u < totalUnits; u++) if (L.flags[u]) { firstAvail = u; break; }
+    int prev = -1;
+    for (int u = 0; u < totalUnits; u++) {
+      if (L.flags[u]) { prev = u; L.src_unit[u] = (int8_t) u; }
+      else L.src_unit[u] = (int8_t) (prev >= 0 ? prev : (firstAvail >= 0 ? -2 - firstAvail : -1));   // -1: nothing available
+    }
+  }
+  __syncthreads();
+  const void *rec = fd.rec[comp]; const int st = fd.stride[comp];
+  const int dcv = 1 << (p.bit_depth - 1);
+  for (int s = 0; s < nsets; s++) {
+    const int mrl = comp ? 0 : (s == 0 ? 0 : s == 1 ? 1 : 3);
+    const int set = comp ? (comp - 1) : (s == 0 ? 0 : s + 1);
+    const int nLeft = predH + mrl, nTop = predW + mrl;              // left[1..nLeft], top[1..nTop], corner = [0]
+    for (int i = tid; i < nLeft + nTop + 1; i += NT) {
+      int isTop, idx;                    // which array entry
+      if (i < nLeft) { isTop = 0; idx = nLeft - i; } else if (i == nLeft) { isTop = 0; idx = 0; } else { isTop = 1; idx = i - nLeft; }
+      int u;
+      if (idx <= mrl) u = totalLeft;
+      else if (isTop) u = totalLeft + 1 + (idx - 1 - mrl) / unit;
+      else u = totalLeft - 1 - (idx - 1 - mrl) / unit;
+      int sx, sy, val;
+      const int su = L.src_unit[u];
+      if (su == -1) val = dcv;
+      else {
+        if (su == u) { if (isTop) { sx = x - 1 - mrl + idx; sy = y - 1 - mrl; } else { sx = x - 1 - mrl; sy = y - 1 - mrl + idx; } }
+        else if (su >= 0) {              // last sample (scan order) of unit su
+          if (su < totalLeft) { sx = x - 1 - mrl; sy = y + (totalLeft - 1 - su) * unit; }
+          else if (su == totalLeft) { sx = x - 1; sy = y - 1 - mrl; }
+          else { sx = x + (su - totalLeft - 1) * unit + unit - 1; sy = y - 1 - mrl; }
+        } else {                         // first sample (scan order) of the first available unit
+          const int fu = -2 - su;
+          if (fu < totalLeft) { sx = x - 1 - mrl; sy = y + (totalLeft - 1 - fu) * unit + unit - 1; }
+          else if (fu == totalLeft) { sx = x - 1 - mrl; sy = y - 1; }
+          else { sx = x + (fu - totalLeft - 1) * unit; sy = y - 1 - mrl; }
+        }
+        val = ld_px<T>(rec, sy * st + sx);
+      }
+      if (idx == 0) { L.refs[set][0][0] = (int16_t) val; L.refs[set][1][0] = (int16_t) val; }
+      else L.refs[set][isTop ? 0 : 1][idx] = (int16_t) val;
+    }
+  }
+  __syncthreads();
+  if (!comp) {
+    // xFilterReferenceSamples 1470-1522 for mrl 0 → set 1
+    const int nLeft = predH, nTop = predW;
+    for (int i = tid; i < nLeft + nTop + 1; i += NT) {
+      const int16_t *t = L.refs[0][0], *l = L.refs[0][1];
+      if (i == 0) { const int v = (l[1] + 2 * t[0] + t[1] + 2) >> 2; L.refs[1][0][0] = (int16_t) v; L.refs[1][1][0] = (int16_t) v; }
+      else if (i <= nTop) { const int j = i; L.refs[1][0][j] = (int16_t) (j == nTop ? t[j] : (t[j + 1] + 2 * t[j] + t[j - 1] + 2) >> 2); }
+      else { const int j = i - nTop; L.refs[1][1][j] = (int16_t) (j == nLeft ? l[j] : (l[j + 1] + 2 * l[j] + (j == 1 ? t[0] : l[j - 1]) + 2) >> 2); }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ distortion (one wave)
+template <int N> __device__ inline void had1d(int *v)
+{
+#pragma unroll
+  for (int len = 1; len < N; len <<= 1)
+#pragma unroll
+    for (int i = 0; i < N; i += 2 * len)
+#pragma unroll
+      for (int j = i; j < i + len; j++) { const int a = v[j], b = v[j + len]; v[j] = a + b; v[j + len] = a - b; }
+}
+__device__ inline void had1d_n(int *v, int n)
+{
+  switch (n) { case 2: had1d<2>(v); break; case 4: had1d<4>(v); break; case 8: had1d<8>(v); break; default: had1d<16>(v); break; }
+}
+__device__ void satd_tile_shape(int w, int h, int &bw, int &bh)       // CL/RdCost.cpp:2764-2854
+{
+  if (w > h && (h & 7) == 0 && (w & 15) == 0) { bw = 16; bh = 8; }
+  else if (w < h && (w & 7) == 0 && (h & 15) == 0) { bw = 8; bh = 16; }
+  else if (w > h && (h & 3) == 0 && (w & 7) == 0) { bw = 8; bh = 4; }
+  else if (w < h && (w & 3) == 0 && (h & 7) == 0) { bw = 4; bh = 8; }
+  else if ((h & 7) == 0 && (w & 7) == 0) { bw = 8; bh = 8; }
+  else if ((h & 3) == 0 && (w & 3) == 0) { bw = 4; bh = 4; }
+  else { bw = 2; bh = 2; }
+}
+// SAD and SATD (xGetHADs) of org vs pred, both w*h tiles with stride w, by one wavefront; scratch >= w*h int16
+__device__ __noinline__ void wave_sad_satd(const int16_t *org, const int16_t *pred, int w, int h, int16_t *scr, int lane,
+                              unsigned long long &sad_out, unsigned long long &satd_out)
+{
+  const int P = w * h;
+  int bw, bh; satd_tile_shape(w, h, bw, bh);
+  const int tilesX = w / bw, tsz = bw * bh;
+  int sad = 0;
+  // rows: one row segment of a Hadamard tile per lane
+  for (int s = lane; s < P / bw; s += 64) {
+    const int t = s / bh, r = s - t * bh, tx = t % tilesX, ty = t / tilesX;
+    const int base = (ty * bh + r) * w + tx * bw;
+    int v[16];
+    for (int i = 0; i < bw; i++) { v[i] = org[base + i] - pred[base + i]; sad += iabs(v[i]); }
+    had1d_n(v, bw);
+    for (int i = 0; i < bw; i++) scr[t * tsz + r * bw + i] = (int16_t) v[i];
+  }
+  wave_sync();
+  unsigned long long satd = 0;
+  const int ncols = P / bh;               // column segments, bw consecutive lanes share a tile
+  for (int it = 0; it * 64 < ncols; it++) {
+    const int q = it * 64 + lane;
+    int s = 0;
+    if (q < ncols) {
+      const int t = q / bw, i = q - t * bw;
+      int v[16];
+      for (int r = 0; r < bh; r++) v[r] = scr[t * tsz + r * bw + i];
+      had1d_n(v, bh);
+      for (int r = 0; r < bh; r++) s += iabs(v[r]);
+    }
+    for (int m = 1; m < bw; m <<= 1) s += __shfl_xor(s, m);     // tile total on every lane of the group
+    if (q < ncols && (lane & (bw - 1)) == 0) {
+      unsigned long long n;
+      if (bw == 2) n = (unsigned long long) s;
+      else if (bw == 4 && bh == 4) n = (unsigned long long) ((s + 1) >> 1);
+      else if (bw == 8 && bh == 8) n = (unsigned long long) ((s + 2) >> 2);
+      else { const double c = tsz == 128 ? 0x1.6a09e667f3bcdp+3 : 0x1.6a09e667f3bcdp+2; n = (unsigned long long) (int) ((double) s / c * 2); }
+      satd += n;
+    }
+  }
+  wave_sync();
+  sad_out = wave_sum_u64((unsigned long long) sad);
+  satd_out = wave_sum_u64(satd);
+}
+
+// ------------------------------------------------------------------------------------------------ transform + quant (one wave)
+__device__ const int8_t *dct2_matrix(int n)
+{
+  switch (n) { case 2: return VX_DCT2_2; case 4: return VX_DCT2_4; case 8: return VX_DCT2_8; case 16: return VX_DCT2_16; case 32: return VX_DCT2_32; default: return VX_DCT2_64; }
+}
+// residual (org - pred) → DCT-II (TrQuant::xT 835-915) → plain quant (Quant::quant 994-1089) → levels;
+// if any level: dequant (423-549) → inverse DCT-II (xIT 917-992) → reco = clip(pred + resi) written over pred.
+// Returns SSE(org, reco) and abs-sum via out params.  rec/lev tiles have stride w.
+__device__ __noinline__ void wave_code_block(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp,
+                                int lane, unsigned long long &sse_out, int &cbf_out)
+{
+  const int P = w * h, lw = ilog2i(w), lh = ilog2i(h);
+  const int zw = imin(w, 32), zh = imin(h, 32);
+  const int8_t *Mw = dct2_matrix(w), *Mh = dct2_matrix(h);
+  const int shift1 = lw + bd + 6 - 15, shift2 = lh + 6;
+  const int rnd1 = shift1 > 0 ? 1 << (shift1 - 1) : 0, rnd2 = 1 << (shift2 - 1);
+  // stage 1 (horizontal): tmp[k*h + j] = (sum_i Mw[k][i] * resi[j][i] + rnd) >> shift1, k < zw
+  for (int o = lane; o < zw * h; o += 64) {
+    const int k = o / h, j = o - k * h;
+    int s = 0;
+    for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + i] - rec[j * w + i]);
+    tmp[o] = (s + rnd1) >> shift1;
+  }
+  wave_sync();
+  // quant parameters
+  const int need_sqrt = (lw + lh) & 1;
+  const int qscale = VX_QUANT_SCALES[need_sqrt * 6 + qp % 6];
+  const int tr_shift = 15 - bd - ((lw + lh) >> 1) + (need_sqrt ? -1 : 0);
+  const int qbits = 14 + qp / 6 + tr_shift;
+  const long long qadd = (long long) 171 << (qbits - 9);
+  // stage 2 (vertical) + quant: coef[m*w + k], m < zh, k < zw
+  if (w > 32 || h > 32) { for (int o = lane; o < P; o += 64) lev[o] = 0; wave_sync(); }
+  int abs_sum = 0;
+  for (int o = lane; o < zw * zh; o += 64) {
+    const int m = o / zw, k = o - m * zw;
+    int s = 0;
+    for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
+    const int c = (s + rnd2) >> shift2;
+    const long long t = (long long) iabs(c) * qscale;
+    int q = (int) ((t + qadd) >> qbits);
+    abs_sum += q;
+    if (c < 0) q = -q;
+    q = q < -32768 ? -32768 : q > 32767 ? 32767 : q;
+    lev[m * w + k] = (int16_t) q;
+  }
+  abs_sum = wave_sum_i32(abs_sum);
+  wave_sync();
+  unsigned long long sse = 0;
+  if (abs_sum > 0) {
+    const int iscale = VX_INV_QUANT_SCALES[need_sqrt * 6 + qp % 6];
+    const int right_shift = 6 - (tr_shift + qp / 6);
+    int tbd = 32 + right_shift - 7; if (tbd > 16) tbd = 16;
+    const int in_min = -(1 << (tbd - 1)), in_max = (1 << (tbd - 1)) - 1;
+    // inverse stage 1 (vertical): t[j*h + i] = clip((sum_k Mh[k][i] * deq(lev[k*w + j]) + 64) >> 7), j < zw
+    for (int o = lane; o < zw * h; o += 64) {
+      const int j = o / h, i = o - j * h;
+      int s = 0;
+      for (int k = 0; k < zh; k++) {
+        int q = lev[k * w + j]; q = q < in_min ? in_min : q > in_max ? in_max : q;
+        int v = right_shift > 0 ? (q * iscale + (1 << (right_shift - 1))) >> right_shift : (q * iscale) << (-right_shift);
+        v = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+        s += Mh[k * h + i] * v;
+      }
+      int v = (s + 64) >> 7;
+      tmp[o] = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+    }
+    wave_sync();
+    const int ishift2 = (6 + 15 - 1) - bd, irnd2 = 1 << (ishift2 - 1);
+    const int mx = (1 << bd) - 1;
+    for (int o = lane; o < P; o += 64) {
+      const int j2 = o / w, i2 = o - j2 * w;
+      int s = 0;
+      for (int k = 0; k < zw; k++) s += Mw[k * w + i2] * tmp[k * h + j2];
+      int r = (s + irnd2) >> ishift2;
+      r = r < -32768 ? -32768 : r > 32767 ? 32767 : r;
+      int v = rec[o] + (int) (int16_t) r;
+      v = v < 0 ? 0 : v > mx ? mx : v;
+      rec[o] = (int16_t) v;
+      const int d = org[o] - v;
+      sse += (unsigned long long) (d * d);
+    }
+  } else {
+    for (int o = lane; o < P; o += 64) { const int d = org[o] - rec[o]; sse += (unsigned long long) (d * d); }
+  }
+  wave_sync();
+  sse_out = wave_sum_u64(sse);
+  cbf_out = abs_sum > 0;
+}
+
+// ------------------------------------------------------------------------------------------------ parallel operations
+__device__ inline int16_t *slot_rec(uint8_t *scratch, int P, int wave, int which)
+{ return P <= 1024 ? &L.slot[wave][which][0] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS; }
+__device__ inline int16_t *slot_lev(uint8_t *scratch, int P, int wave, int which)
+{ return P <= 1024 ? &L.slot[wave][which][1024] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS + 4096; }
+
+__device__ void ctx_copy_all(Ctx *dst, const Ctx *src)
+{
+  uint32_t *d = (uint32_t *) dst; const uint32_t *s = (const uint32_t *) src;
+  for (int i = threadIdx.x; i < NCTX; i += NT) d[i] = s[i];       // s0 and s1 are 2*NCTX uint16 = NCTX uint32
+}
+__device__ Ctx *ctx_ptr(uint8_t *scratch, int which, int d, int wave)
+{
+  if (which == CTX_CUR) return &L.cur;
+  if (which == CTX_WAVE) return &L.wctx[wave];
+  return (Ctx *) (scratch + VXD_OFF_CTX + (size_t) (d * 2 + (which == CTX_BEST ? 1 : 0)) * VXD_CTXSNAP);
+}
+
+// OP_LUMA_PREP: stage the node's original luma tile and its reference samples (mrl 0,1,3) in LDS
+template <typename T>
+__device__ __noinline__ void op_luma_prep(const VxParams &p, const VxFrameDev &fd)
+{
+  const int x = L.nx, y = L.ny, w = L.nw, h = L.nh;
+  const void *org = fd.org[0]; const int st = fd.stride[0];
+  for (int i = threadIdx.x; i < w * h; i += NT) { const int r = i / w, c = i - r * w; L.org[i] = (int16_t) ld_px<T>(org, (y + r) * st + x + c); }
+  const int nsets = ((y & 127) == 0 || !(p.tools & 1)) ? 1 : 3;
+  build_refs<T>(p, fd, 0, x, y, w, h, L.cur_tile, nsets);
+  if (threadIdx.x < 4) {
+    const int s = threadIdx.x;           // dc per set (filtered set never used for DC)
+    if (s != 1 && (s == 0 || nsets == 3)) L.dc_val[s] = dc_value(L.refs[s][0], L.refs[s][1], w, h, s == 0 ? 0 : s == 2 ? 1 : 3);
+  }
+  __syncthreads();
+}
+__device__ inline int luma_set(int mrl, int filt) { return mrl == 0 ? (filt ? 1 : 0) : (mrl == 1 ? 2 : 3); }
+
+// OP_STAGE_A: SATD-stage cost of every candidate in L.cand[op_a .. op_b) (EL/IntraSearch.cpp:489-682), one wave per candidate
+__device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = L.nw, h = L.nh, P = w * h, bd = p.bit_depth;
+  int16_t *pred = slot_rec(scratch, P, wave, 0);
+  int16_t *scr = (int16_t *) L.tmp[wave];
+  for (int c = L.op_a + wave; c < L.op_b; c += NW) {
+    const int mode = L.cand[c].mode, mrl = L.cand[c].mrl;
+    Ipa ip; init_pred_params(w, h, 1, mode, mrl, ip);
+    const int set = luma_set(mrl, ip.ref_filter);
+    const int16_t *top = L.refs[set][0], *left = L.refs[set][1];
+    const int dcv = L.dc_val[luma_set(mrl, 0)];
+    for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; pred[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
+    wave_sync();
+    unsigned long long sad, satd;
+    wave_sad_satd(L.org, pred, w, h, scr, lane, sad, satd);
+    if (lane == 0) {
+      const unsigned long long msh = sad * 2 < satd ? sad * 2 : satd;
+      // xFracModeBitsIntra 4263-4288 from the node's start contexts (every bin uses a distinct context)
+      Ctx *wc = &L.wctx[wave];
+      const int ids[5] = { VX_CTX_MultiRefLineIdx, VX_CTX_MultiRefLineIdx + 1, VX_CTX_IntraLumaMpmFlag, VX_CTX_IntraLumaPlanarFlag, VX_CTX_IntraLumaPlanarFlag + 1 };
+      for (int k = 0; k < 5; k++) { wc->s0[ids[k]] = L.cur.s0[ids[k]]; wc->s1[ids[k]] = L.cur.s1[ids[k]]; }
+      Cab cb; cb.c = wc; cb.bits = 0;
+      enc_intra_luma_pred_mode(cb, L.ny, mode, mrl);
+      const double a = (double) cb.bits * p.sqrt_lambda_fp;
+      L.cand_cost[c] = (double) msh + a;
+      L.cand_had[c] = (double) msh;
+    }
+    wave_sync();
+  }
+  __syncthreads();
+}
+
+// OP_STAGE_B: full RD of L.rd[0..n_rd) (EL/IntraSearch.cpp:1158-1358 → xRecurIntraCodingLumaQT → xIntraCodingTUBlock)
+__device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = L.nw, h = L.nh, P = w * h, bd = p.bit_depth;
+  if (lane == 0) L.wave_best[wave] = -1;
+  double wbest = MAX_DOUBLE;
+  int cur = 0;                                    // slot being written; the other one holds the wave's best so far
+  for (int c = wave; c < L.n_rd; c += NW) {
+    const int mode = L.rd[c].mode, mrl = L.rd[c].mrl;
+    int16_t *rec = slot_rec(scratch, P, wave, cur), *lev = slot_lev(scratch, P, wave, cur);
+    Ipa ip; init_pred_params(w, h, 1, mode, mrl, ip);
+    const int set = luma_set(mrl, ip.ref_filter);
+    const int16_t *top = L.refs[set][0], *left = L.refs[set][1];
+    const int dcv = L.dc_val[luma_set(mrl, 0)];
+    for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
+    wave_sync();
+    unsigned long long sse; int cbf;
+    wave_code_block(L.org, rec, lev, L.tmp[wave], w, h, bd, p.qp, lane, sse, cbf);
+    // xGetIntraFracBitsQT: header + cbf + residual from the node's start contexts
+    { uint32_t *d = (uint32_t *) &L.wctx[wave]; const uint32_t *s = (const uint32_t *) &L.cur; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
+    wave_sync();
+    double cost = 0;
+    if (lane == 0) {
+      Cab cb; cb.c = &L.wctx[wave]; cb.bits = 0;
+      enc_intra_luma_pred_mode(cb, L.ny, mode, mrl);
+      enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[0]);
+      if (cbf) residual_coding(cb, lev, w, h, 0);
+      cost = rd_cost(p, cb.bits, sse);
+      L.rd_cost[c] = cost; L.rd_dist[c] = sse; L.rd_bits[c] = cb.bits; L.rd_cbf[c] = (uint8_t) cbf;
+    }
+    cost = __shfl(cost, 0);
+    if (cost < wbest) {
+      wbest = cost;
+      if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = cur; }
+      cur ^= 1;
+      // keep the end-of-candidate contexts of the wave's best: they are the CU's end contexts (same syntax as
+      // cu_pred_data + cu_residual of xCheckRDCostIntra 2593-2619 for a luma-tree CU)
+      Ctx *keep = ctx_ptr(scratch, CTX_BEST, MAXD + wave, 0);
+      { uint32_t *d = (uint32_t *) keep; const uint32_t *s = (const uint32_t *) &L.wctx[wave]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
+    }
+    wave_sync();
+  }
+  __syncthreads();
+}
+
+// OP_CHROMA_RD: estIntraPredChromaQT 1382-1686 + xRecurIntraChromaCodingQT 3779-4207 (CCLM / JointCbCr off):
+// one wave per chroma mode, Cb then Cr; winner kept per wave like stage B.
+template <typename T>
+__device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int x = L.nx >> 1, y = L.ny >> 1, w = L.nw >> 1, h = L.nh >> 1, P = w * h, bd = p.bit_depth;
+  for (int c = 1; c <= 2; c++) {
+    const void *org = fd.org[c]; const int st = fd.stride[c];
+    for (int i = threadIdx.x; i < P; i += NT) { const int r = i / w, cc = i - r * w; L.org[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
+    build_refs<T>(p, fd, c, x, y, w, h, L.cur_tile, 1);
+  }
+  if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
+  __syncthreads();
+  if (lane == 0) L.wave_best[wave] = -1;
+  double wbest = MAX_DOUBLE;
+  int cur = 0;
+  const int big = 2 * P > 1024;
+  for (int c = wave; c < L.n_rd; c += NW) {
+    const int cm = L.rd[c].mode;                      // chroma mode (70 = DM); final mode in .mrl field
+    const int fm = L.rd[c].mrl;
+    int16_t *recb = big ? (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + cur) * VXD_SLOT_ELEMS : &L.slot[wave][cur][0];
+    int16_t *levb = recb + (big ? 4096 : 1024);
+    { uint32_t *d = (uint32_t *) &L.wctx[wave]; const uint32_t *s = (const uint32_t *) &L.cur; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
+    wave_sync();
+    unsigned long long dist = 0; int cbfs[2];
+    Ipa ip; init_pred_params(w, h, 0, fm, 0, ip);
+    for (int k = 0; k < 2; k++) {
+      int16_t *rec = recb + k * P, *lev = levb + k * P;
+      const int16_t *top = L.refs[k][0], *left = L.refs[k][1];
+      for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
+      wave_sync();
+      unsigned long long sse; int cbf;
+      wave_code_block(L.org + k * P, rec, lev, L.tmp[wave], w, h, bd, p.qp_c[k], lane, sse, cbf);
+      cbfs[k] = cbf;
+      dist += (unsigned long long) (p.dist_weight[k] * (double) sse);             // CL/RdCost.cpp:405-408
+      if (lane == 0) {     // xGetIntraFracBitsQTChroma 2625-2692: contexts advance
+        Cab cb; cb.c = &L.wctx[wave]; cb.bits = 0;
+        enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[k + 1] + (k == 1 ? cbfs[0] : 0));
+        if (cbf) residual_coding(cb, lev, w, h, 1);
+      }
+      wave_sync();
+    }
+    double cost = 0;
+    if (lane == 0) {       // 1611-1621: contexts not reset; xGetIntraFracBitsQT(chroma)
+      Cab cb; cb.c = &L.wctx[wave]; cb.bits = 0;
+      enc_intra_chroma_pred_mode(cb, cm);
+      enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]);
+      enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]);
+      if (cbfs[0]) residual_coding(cb, levb, w, h, 1);
+      if (cbfs[1]) residual_coding(cb, levb + P, w, h, 1);
+      cost = rd_cost(p, cb.bits, dist);
+      L.rd_cost[c] = cost; L.rd_dist[c] = dist; L.rd_cbf[c] = (uint8_t) ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 4 : 0));
+    }
+    cost = __shfl(cost, 0);
+    if (cost < wbest) { wbest = cost; if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = cur; } cur ^= 1; }
+    wave_sync();
+  }
+  __syncthreads();
+}
+
+// area copies between the picture (planes + unit map) and the level store / candidate slots
+template <typename T>
+__device__ __noinline__ void op_save_pic(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch, int restore)
+{
+  const int ch = L.tree_ch, d = L.nd;
+  const int x1 = imin(L.nx + L.nw, p.pic_w), y1 = imin(L.ny + L.nh, p.pic_h);
+  uint8_t *lvl = scratch + VXD_OFF_STORE + (size_t) d * VXD_STORE_LEVEL;
+  const int sh = ch ? 1 : 0, ncomp = ch ? 2 : 1;
+  const int X0 = L.nx >> sh, Y0 = L.ny >> sh, Wn = L.nw >> sh, cw = (x1 >> sh) - X0, chh = (y1 >> sh) - Y0;
+  for (int k = 0; k < ncomp; k++) {
+    const int comp = ch ? k + 1 : 0;
+    int16_t *srec = (int16_t *) lvl + k * (Wn * (L.nh >> sh)), *slev = (int16_t *) (lvl + VXD_STORE_REC) + k * (Wn * (L.nh >> sh));
+    void *rec = fd.rec[comp]; int16_t *lev = fd.lev[comp]; const int st = fd.stride[comp], ls = fd.lstride[comp];
+    for (int i = threadIdx.x; i < cw * chh; i += NT) {
+      const int r = i / cw, c = i - r * cw;
+      if (restore) { st_px<T>(rec, (Y0 + r) * st + X0 + c, srec[r * Wn + c]); lev[(Y0 + r) * ls + X0 + c] = slev[r * Wn + c]; }
+      else { srec[r * Wn + c] = (int16_t) ld_px<T>(rec, (Y0 + r) * st + X0 + c); slev[r * Wn + c] = lev[(Y0 + r) * ls + X0 + c]; }
+    }
+  }
+  VxUnit *su = (VxUnit *) (lvl + 2 * VXD_STORE_REC);
+  const int ux0 = L.nx >> 2, uy0 = L.ny >> 2, ucw = ((x1 + 3) >> 2) - ux0, uch = ((y1 + 3) >> 2) - uy0;
+  for (int i = threadIdx.x; i < ucw * uch; i += NT) {
+    const int r = i / ucw, c = i - r * ucw;
+    if (restore) fd.units[ch][(uy0 + r) * p.uw + ux0 + c] = su[r * 32 + c];
+    else su[r * 32 + c] = fd.units[ch][(uy0 + r) * p.uw + ux0 + c];
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+// winner of the intra check (slot B of wave L.win_wave) + its CU record → level store
+__device__ __noinline__ void op_save_intra(const VxParams &p, uint8_t *scratch, const VxUnit &cu)
+{
+  const int ch = L.tree_ch, d = L.nd, sh = ch ? 1 : 0;
+  const int W = L.nw >> sh, H = L.nh >> sh, P = W * H;
+  uint8_t *lvl = scratch + VXD_OFF_STORE + (size_t) d * VXD_STORE_LEVEL;
+  const int wave = L.win_wave, which = L.op_a;
+  const int big = (ch ? 2 * P : P) > 1024;
+  const int16_t *rec = big ? (const int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS : &L.slot[wave][which][0];
+  const int16_t *lev = rec + (big ? 4096 : 1024);
+  int16_t *srec = (int16_t *) lvl, *slev = (int16_t *) (lvl + VXD_STORE_REC);
+  const int n = ch ? 2 * P : P;
+  for (int i = threadIdx.x; i < n; i += NT) { srec[i] = rec[i]; slev[i] = lev[i]; }
+  VxUnit *su = (VxUnit *) (lvl + 2 * VXD_STORE_REC);
+  const int ucw = (L.nw + 3) >> 2, uch = (L.nh + 3) >> 2;
+  for (int i = threadIdx.x; i < ucw * uch; i += NT) su[(i / ucw) * 32 + (i % ucw)] = cu;
+  __threadfence_block();
+  __syncthreads();
+}
+__device__ __noinline__ void op_clear_units(const VxParams &p, const VxFrameDev &fd)
+{
+  const int ch = L.tree_ch;
+  const int x1 = imin(L.nx + L.nw, p.pic_w), y1 = imin(L.ny + L.nh, p.pic_h);
+  const int ux0 = L.nx >> 2, uy0 = L.ny >> 2, ucw = ((x1 + 3) >> 2) - ux0, uch = ((y1 + 3) >> 2) - uy0;
+  for (int i = threadIdx.x; i < ucw * uch; i += NT) fd.units[ch][(uy0 + i / ucw) * p.uw + ux0 + (i % ucw)].tag = 0;
+  __threadfence_block();
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ mode controller (thread 0)
+__device__ inline int mode_to_split(int m) { return m == ETM_SPLIT_QT ? SPLIT_QT : m == ETM_SPLIT_BT_H ? SPLIT_BH : m == ETM_SPLIT_BT_V ? SPLIT_BV : m == ETM_SPLIT_TT_H ? SPLIT_TH : m == ETM_SPLIT_TT_V ? SPLIT_TV : SPLIT_NONE; }
+
+// EncModeCtrlMTnoRQT::tryMode (EL/EncModeCtrl.cpp:1557-2068), I-slice subset
+__device__ __noinline__ int try_mode(const VxParams &p, Frame &f, int ch, int mode)
+{
+  const int impl = implicit_split(p, f, ch);
+  if (impl != SPLIT_NONE && mode != ETM_SPLIT_QT) return mode_to_split(mode) == impl;
+  else if (impl != SPLIT_NONE) return can_do(p, f, ch, SPLIT_QT);
+  const int maxDepth = 7 - ilog2i(p.min_qt[ch]);
+  if (mode == ETM_SPLIT_QT && maxDepth <= f.qt) return 0;
+  if (mode == ETM_INTRA) { if (f.w * f.h > 4096) return 0; if (f.w > 64 || f.h > 64) return 0; return 1; }
+  if (mode == ETM_POST_DONT_SPLIT) return 0;
+  const int split = mode_to_split(mode);
+  if (!can_do(p, f, ch, split)) {
+    if (split == SPLIT_BH) f.did_h = 0;
+    if (split == SPLIT_BV) f.did_v = 0;
+    if (split == SPLIT_QT) f.did_q = 0;
+    return 0;
+  }
+  const Sum *b = f.has_best ? &f.best : nullptr;
+  int feat = -1;
+  switch (split) {
+    case SPLIT_QT:
+      if (!f.qt_before_bt && b) {
+        const int maxBTD = p.max_bt_depth[ch];
+        if (((b->f_bt == 0 && maxBTD >= 3) || (b->f_bt == 1 && b->l_bt == 1 && maxBTD >= 4)) && (f.w <= 64 && f.h <= 64) && f.did_h && f.did_v) return 0;
+      }
+      break;
+    case SPLIT_BH: feat = 0; break;
+    case SPLIT_BV: feat = 1; break;
+    case SPLIT_TH:
+      if (f.did_h && b && b->f_bt == f.bt && !b->f_cbf) return 0;
+      if (!f.do_th) return 0;
+      break;
+    case SPLIT_TV:
+      if (f.did_v && b && b->f_bt == f.bt && !b->f_cbf) return 0;
+      if (!f.do_tv) return 0;
+      break;
+  }
+  if (split != SPLIT_QT && f.qt_before_bt && f.did_q && f.max_qt_sub > f.qt + 1) {
+    if (feat == 0) f.did_h = 0; else if (feat == 1) f.did_v = 0;
+    return 0;
+  }
+  if (split == SPLIT_QT) f.did_q = 1;
+  return 1;
+}
+__device__ int next_mode(const VxParams &p, Frame &f, int ch)
+{
+  f.nmodes--;
+  while (f.nmodes > 0 && !try_mode(p, f, ch, f.modes[f.nmodes - 1])) f.nmodes--;
+  return f.nmodes > 0;
+}
+__device__ __noinline__ void init_cu_level(const VxParams &p, const VxFrameDev &fd, Frame &f, int ch, int tile)       // initCULevel 1203-1549
+{
+  const int sh = ch ? 1 : 0;
+  const VxUnit *cuL = get_cu(p, fd, ch, (f.x >> sh) - 1, f.y >> sh, tile), *cuA = get_cu(p, fd, ch, f.x >> sh, (f.y >> sh) - 1, tile);
+  f.qt_before_bt = (uint8_t) (((cuL && cuA && cuL->qt > f.qt && cuA->qt > f.qt) || (cuL && !cuA && cuL->qt > f.qt) || (!cuL && cuA && cuA->qt > f.qt)
+                   || (!cuA && !cuL && f.w >= 32)) && (f.w > (p.min_qt[ch] << 1)));
+  f.do_th = f.do_tv = 1; f.did_h = f.did_v = f.did_q = 0; f.max_qt_sub = 0; f.has_best = 0; f.nmodes = 0;
+  if (!f.qt_before_bt) f.modes[f.nmodes++] = ETM_SPLIT_QT;
+  if (can_do(p, f, ch, SPLIT_TV)) f.modes[f.nmodes++] = ETM_SPLIT_TT_V;
+  if (can_do(p, f, ch, SPLIT_TH)) f.modes[f.nmodes++] = ETM_SPLIT_TT_H;
+  if (can_do(p, f, ch, SPLIT_BV)) { f.modes[f.nmodes++] = ETM_SPLIT_BT_V; f.did_v = 1; }
+  if (can_do(p, f, ch, SPLIT_BH)) { f.modes[f.nmodes++] = ETM_SPLIT_BT_H; f.did_h = 1; }
+  if (f.qt_before_bt) f.modes[f.nmodes++] = ETM_SPLIT_QT;
+  f.modes[f.nmodes++] = ETM_POST_DONT_SPLIT;
+  f.modes[f.nmodes++] = ETM_INTRA;
+  if (!try_mode(p, f, ch, f.modes[f.nmodes - 1])) next_mode(p, f, ch);
+}
+__device__ int use_mode_result(const VxParams &p, Frame &f, int ch, int mode, const Sum &t)       // useModeResult 2089-2200
+{
+  if (mode == ETM_SPLIT_QT) f.max_qt_sub = (uint8_t) t.max_qt;
+  const int maxMtD = p.max_bt_depth[ch] + f.impl_bt, sh = ch ? 1 : 0;
+  if (mode == ETM_SPLIT_BT_H && t.n_cu > 2) { const int h2 = (f.h >> sh) / 2; f.do_th = (uint8_t) (t.f_h < h2 || t.l_h < h2 || f.mt + 1 == maxMtD); }
+  else if (mode == ETM_SPLIT_BT_V && t.n_cu > 2) { const int w2 = (f.w >> sh) / 2; f.do_tv = (uint8_t) (t.f_w < w2 || t.l_w < w2 || f.mt + 1 == maxMtD); }
+  return t.cost != MAX_DOUBLE && (!f.has_best || t.cost < f.best.cost);
+}
+// updateCandList (CL/UnitTools.h:261-306)
+__device__ void update_cand_list(Cand m, double cost, Cand *list, double *costs, int &size, int fastNum)
+{
+  int shift = 0;
+  const int cur = imin(fastNum, size);
+  while (shift < fastNum && shift < cur && cost < costs[cur - 1 - shift]) shift++;
+  if (size >= fastNum && shift != 0) {
+    for (int i = 1; i < shift; i++) { list[cur - i] = list[cur - 1 - i]; costs[cur - i] = costs[cur - 1 - i]; }
+    list[cur - shift] = m; costs[cur - shift] = cost;
+  } else if (cur < fastNum) {
+    const int pos = size - shift;
+    for (int i = size; i > pos; i--) { list[i] = list[i - 1]; costs[i] = costs[i - 1]; }
+    list[pos] = m; costs[pos] = cost; size++;
+  }
+}
+
+__device__ void post(int op) { L.op = op; }
+__device__ void set_node(const Frame &f, int d) { L.nx = f.x; L.ny = f.y; L.nw = f.w; L.nh = f.h; L.nd = d; }
+
+// one controller step: runs until a parallel operation is posted (returns) or the CTU tree is finished (posts OP_DONE)
+__device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
+{
+  CtlState &S = L.S;
+  const int ch = L.tree_ch, tile = L.cur_tile, sh = ch ? 1 : 0;
+  for (;;) {
+    if (L.d < 0) { post(OP_DONE); return; }
+    Frame &f = L.fr[L.d];
+    const int d = L.d;
+    switch (f.phase) {
+    case PH_ENTER: {                                    // xCompressCU entry (EL/EncCu.cpp:727-1286)
+      L.cnt[3]++;
+      init_cu_level(p, fd, f, ch, tile);
+      f.best.cost = MAX_DOUBLE; f.best.dist = 0; f.best.bits = 0; f.best.valid = 0;
+      if (f.nmodes == 0) { f.phase = PH_EXIT2; break; }
+      f.phase = PH_RUN;
+      L.op_a = CTX_START; L.op_b = CTX_CUR; L.op_c = d; post(OP_CTX_COPY); return;     // m_CurrCtx->start = ctx
+    }
+    case PH_RUN: {
+      const int mode = f.modes[f.nmodes - 1];
+      f.cur_mode = (uint8_t) mode;
+      set_node(f, d);
+      if (mode == ETM_INTRA) {
+        // CU record (partitioner.setCUData, EL/EncCu.cpp:2478-2496)
+        VxUnit &cu = L.cu;
+        cu.ss = f.ss; cu.x = (int16_t) (f.x >> sh); cu.y = (int16_t) (f.y >> sh); cu.lw = (uint8_t) ilog2i(f.w >> sh); cu.lh = (uint8_t) ilog2i(f.h >> sh);
+        cu.qt = f.qt; cu.mt = f.mt; cu.bt = f.bt; cu.depth = f.depth; cu.dir = 0; cu.mrl = 0; cu.cbf = 0; cu.pad = 0; cu.tag = (uint16_t) (tile + 1);
+        if (!ch) {
+          // MPM list of the node (PU::getIntraMPMs neighbours, CL/UnitTools.cpp:516-532)
+          int Ld = PLANAR, Ad = PLANAR;
+          const VxUnit *uL = get_cu(p, fd, 0, f.x - 1, f.y + f.h - 1, tile); if (uL) Ld = uL->dir;
+          const VxUnit *uA = get_cu(p, fd, 0, f.x + f.w - 1, f.y - 1, tile); if (uA && ((f.y - 1) >> 7) == (f.y >> 7)) Ad = uA->dir;
+          derive_mpms(Ld, Ad, L.mpm); L.mpm_n = (Ld == Ad) ? 1 : 2;
+          // stage A candidate list, phase 1: 35 even modes + MRL MPM candidates (costs are order independent)
+          int n = 0;
+          for (int m = 0; m < 67; m++) { S.checked[m] = 0; if (m > DC && (m & 1)) continue; L.cand[n].mode = (uint8_t) m; L.cand[n].mrl = 0; n++; S.checked[m] = 1; }
+          if ((f.y & 127) != 0 && (p.tools & 1))
+            for (int r = 1; r < 3; r++) for (int k = 1; k < 6; k++) { L.cand[n].mode = (uint8_t) L.mpm[k]; L.cand[n].mrl = (uint8_t) (r == 1 ? 1 : 3); n++; }
+          L.n_cand = n;
+          f.phase = PH_A1_DONE;
+          L.op_a = 0; L.op_b = n; L.op_c = 1; post(OP_LUMA_PREP); return;      // prep, then stage A on [0,n)
+        } else {
+          // chroma candidate modes (PU::getIntraChromaCandModes, CL/UnitTools.cpp:840-873), LM modes disabled
+          const int cx = f.x + (f.w >> 1), cy = f.y + (f.h >> 1);
+          const int lm = fd.units[0][(cy >> 2) * p.uw + (cx >> 2)].dir;      // getCoLocatedIntraLumaMode 949-960
+          int list[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };
+          for (int i = 0; i < 4; i++) if (lm == list[i]) { list[i] = VDIA; break; }
+          for (int i = 0; i < 5; i++) { L.rd[i].mode = (uint8_t) list[i]; L.rd[i].mrl = (uint8_t) (list[i] == DM_CHROMA ? lm : list[i]); }
+          L.n_rd = 5;
+          f.phase = PH_B_DONE;
+          post(OP_CHROMA_RD); return;
+        }
+      }
+      if (mode == ETM_POST_DONT_SPLIT) { f.phase = PH_ADVANCE; break; }
+      // ---- xCheckModeSplit (EL/EncCu.cpp:1918-2399)
+      const int split = mode_to_split(mode);
+      f.cur_split = (uint8_t) split;
+      {
+        Cab cb; cb.c = &L.wctx[0]; cb.bits = 0;
+        const int ids0 = VX_CTX_SplitFlag;           // split contexts occupy [SplitFlag, Split12Flag+4)
+        for (int k = ids0; k < VX_CTX_Split12Flag + 4; k++) { L.wctx[0].s0[k] = L.cur.s0[k]; L.wctx[0].s1[k] = L.cur.s1[k]; }
+        enc_split_cu_mode(p, fd, cb, f, ch, tile, split);
+        const double factor = p.qp > 30 ? 1.1 : 1.075;
+        const double cost = rd_cost(p, (uint64_t) ((double) cb.bits + ((double) f.best.bits / factor)), (uint64_t) ((double) f.best.dist / factor));
+        if (cost > f.best.cost) { f.phase = PH_ADVANCE; break; }
+      }
+      {
+        Sum &t = f.temp; t.cost = 0; t.dist = 0; t.bits = 0; t.n_cu = 0; t.max_qt = 0; t.valid = 0;
+        const int x = f.x, y = f.y, w = f.w, h = f.h;
+        switch (split) {
+          case SPLIT_QT: f.nparts = 4; for (int i = 0; i < 4; i++) { f.pw[i] = (int16_t) (w >> 1); f.ph[i] = (int16_t) (h >> 1); f.px[i] = (int16_t) (x + ((i & 1) ? w >> 1 : 0)); f.py[i] = (int16_t) (y + ((i >= 2) ? h >> 1 : 0)); } break;
+          case SPLIT_BH: f.nparts = 2; for (int i = 0; i < 2; i++) { f.px[i] = (int16_t) x; f.pw[i] = (int16_t) w; f.ph[i] = (int16_t) (h >> 1); f.py[i] = (int16_t) (y + i * (h >> 1)); } break;
+          case SPLIT_BV: f.nparts = 2; for (int i = 0; i < 2; i++) { f.py[i] = (int16_t) y; f.ph[i] = (int16_t) h; f.pw[i] = (int16_t) (w >> 1); f.px[i] = (int16_t) (x + i * (w >> 1)); } break;
+          case SPLIT_TH: f.nparts = 3; for (int i = 0; i < 3; i++) { f.px[i] = (int16_t) x; f.pw[i] = (int16_t) w; } f.ph[0] = f.ph[2] = (int16_t) (h >> 2); f.ph[1] = (int16_t) (h >> 1); f.py[0] = (int16_t) y; f.py[1] = (int16_t) (y + (h >> 2)); f.py[2] = (int16_t) (y + (h >> 2) + (h >> 1)); break;
+          default:       f.nparts = 3; for (int i = 0; i < 3; i++) { f.py[i] = (int16_t) y; f.ph[i] = (int16_t) h; } f.pw[0] = f.pw[2] = (int16_t) (w >> 2); f.pw[1] = (int16_t) (w >> 1); f.px[0] = (int16_t) x; f.px[1] = (int16_t) (x + (w >> 2)); f.px[2] = (int16_t) (x + (w >> 2) + (w >> 1)); break;
+        }
+        f.child = 0; f.first = 1;
+        f.phase = PH_CHILD;
+        post(OP_CLEAR_UNITS); return;          // tempCS->initStructData: nothing of this node is coded yet
+      }
+    }
+    case PH_A1_DONE: {                                  // EL/IntraSearch.cpp:489-623
+      const int numRd0 = VX_MODE_NUM_FAST_2D[(ilog2i(f.w) - 2) * 6 + (ilog2i(f.h) - 2)];
+      S.numRd = numRd0; S.rdSize = 0;
+      for (int c = 0; c < 35; c++) update_cand_list(L.cand[c], L.cand_cost[c], S.rdList, S.rdCost, S.rdSize, S.numRd);
+      L.cnt[0] += (unsigned long long) L.n_cand;
+      int n = L.n_cand; S.n_a2 = 0;
+      for (int i = 0; i < S.numRd; i++) {
+        const int pm = S.rdList[i].mode;
+        if (pm > (DC + 1) && pm < 66)
+          for (int s = -1; s <= 1; s += 2) { const int m = pm + s; if (!S.checked[m]) { S.checked[m] = 1; L.cand[n].mode = (uint8_t) m; L.cand[n].mrl = 0; n++; S.n_a2++; } }
+      }
+      // NOTE: the reference derives the ±1 candidates from a snapshot of the list (parentCandList 574) ✓ (list not yet modified here)
+      f.phase = PH_A2_DONE;
+      if (S.n_a2 > 0) { L.op_a = L.n_cand; L.op_b = n; L.op_c = 0; post(OP_STAGE_A); return; }
+      break;
+    }
+    case PH_A2_DONE: {                                  // 577-682 inserts, 777-802 MPM append, then stage B
+      const int n1 = L.n_cand;
+      for (int c = n1; c < n1 + S.n_a2; c++) update_cand_list(L.cand[c], L.cand_cost[c], S.rdList, S.rdCost, S.rdSize, S.numRd);
+      L.cnt[0] += (unsigned long long) S.n_a2;
+      for (int c = 35; c < n1; c++) update_cand_list(L.cand[c], L.cand_cost[c], S.rdList, S.rdCost, S.rdSize, S.numRd);
+      for (int j = 0; j < L.mpm_n; j++) {
+        int incl = 0;
+        for (int i = 0; i < S.numRd; i++) incl |= (S.rdList[i].mode == L.mpm[j] && S.rdList[i].mrl == 0);
+        if (!incl) { S.rdList[S.numRd].mode = (uint8_t) L.mpm[j]; S.rdList[S.numRd].mrl = 0; S.rdCost[S.numRd] = 0; S.numRd++; }
+      }
+      for (int i = 0; i < S.numRd; i++) L.rd[i] = S.rdList[i];
+      L.n_rd = S.numRd;
+      f.phase = PH_B_DONE;
+      post(OP_STAGE_B); return;
+    }
+    case PH_B_DONE: {                                   // pick winner (strict <, list order), CU-level rate, xCheckBestMode
+      int best = -1; double bc = MAX_DOUBLE;
+      for (int c = 0; c < L.n_rd; c++) if (L.rd_cost[c] < bc) { bc = L.rd_cost[c]; best = c; }
+      L.cnt[1] += (unsigned long long) (ch ? 2 * L.n_rd : L.n_rd); L.cnt[2] += (unsigned long long) (ch ? 2 * L.n_rd * ((f.w >> 1) * (f.h >> 1)) : L.n_rd * f.w * f.h);
+      int ww = 0; for (int w2 = 0; w2 < NW; w2++) if (L.wave_best[w2] == best) ww = w2;
+      L.win_idx = best; L.win_wave = ww;
+      L.op_a = L.wave_slot[ww];                         // slot of that wave holding the winner's reco / levels
+      Sum &t = f.temp;
+      t.dist = L.rd_dist[best];
+      Cab cb; cb.bits = 0;
+      VxUnit &cu = L.cu;
+      if (!ch) {
+        cu.dir = L.rd[best].mode; cu.mrl = L.rd[best].mrl; cu.cbf = L.rd_cbf[best];
+        // luma CU: cu_pred_data + cu_residual == the stage-B syntax from the same start contexts
+        t.bits = L.rd_bits[best];
+        // end contexts of the winner were parked in scratch by its wave
+        const Ctx *keep = ctx_ptr(scratch, CTX_BEST, MAXD + ww, 0);
+        for (int i = 0; i < NCTX; i++) { L.wctx[0].s0[i] = keep->s0[i]; L.wctx[0].s1[i] = keep->s1[i]; }
+        cb.c = &L.wctx[0];
+      } else {
+        cu.dir = L.rd[best].mode; cu.mrl = 0; cu.cbf = L.rd_cbf[best];
+        // chroma CU: recompute from the start contexts (EL/EncCu.cpp:2593-2619)
+        for (int i = 0; i < NCTX; i++) { L.wctx[0].s0[i] = L.cur.s0[i]; L.wctx[0].s1[i] = L.cur.s1[i]; }
+        cb.c = &L.wctx[0];
+        const int P = (f.w >> 1) * (f.h >> 1);
+        const int big = 2 * P > 1024;
+        const int16_t *levb = (big ? (const int16_t *) (scratch + VXD_OFF_SLOTS) + (ww * 2 + L.op_a) * VXD_SLOT_ELEMS + 4096 : &L.slot[ww][L.op_a][1024]);
+        enc_intra_chroma_pred_mode(cb, cu.dir);
+        enc_bin(cb, (unsigned) !!(cu.cbf & 2), VX_CTX_QtCbf[1]);
+        enc_bin(cb, (unsigned) !!(cu.cbf & 4), VX_CTX_QtCbf[2] + !!(cu.cbf & 2));
+        if (cu.cbf & 2) residual_coding(cb, levb, f.w >> 1, f.h >> 1, 1);
+        if (cu.cbf & 4) residual_coding(cb, levb + P, f.w >> 1, f.h >> 1, 1);
+        t.bits = cb.bits;
+      }
+      cb.bits = 0;
+      enc_split_cu_mode(p, fd, cb, f, ch, tile, SPLIT_NONE);          // xEncodeDontSplit 5649-5662
+      t.bits += cb.bits;
+      t.cost = rd_cost(p, t.bits, t.dist);
+      t.n_cu = 1; t.f_bt = t.l_bt = f.bt; t.f_cbf = cu.cbf != 0; t.f_w = t.l_w = (int16_t) (f.w >> sh); t.f_h = t.l_h = (int16_t) (f.h >> sh); t.max_qt = f.qt; t.valid = 1;
+      if (use_mode_result(p, f, ch, ETM_INTRA, t)) {
+        f.best = t; f.has_best = 1;
+        // ctxBest[d] ← wctx[0] (the CU's end contexts), store ← winner slot
+        Ctx *bs = ctx_ptr(scratch, CTX_BEST, d, 0);
+        for (int i = 0; i < NCTX; i++) { bs->s0[i] = L.wctx[0].s0[i]; bs->s1[i] = L.wctx[0].s1[i]; }
+        f.phase = PH_ADVANCE;
+        set_node(f, d);
+        post(OP_SAVE_INTRA); return;
+      }
+      f.phase = PH_ADVANCE; break;
+    }
+    case PH_CHILD: {                                    // children loop of xCheckModeSplit (2065-2177)
+      if (f.child >= f.nparts) {
+        // 2297-2333: split flag bits from the contexts left by the last child, cost, xCheckBestMode
+        Sum &t = f.temp;
+        f.impl_checked = 0;
+        const int enforceQT = implicit_split(p, f, ch) == SPLIT_QT;
+        if (!enforceQT) { Cab cb; cb.c = &L.cur; cb.bits = 0; enc_split_cu_mode(p, fd, cb, f, ch, tile, f.cur_split); t.bits += cb.bits; }
+        t.cost = rd_cost(p, t.bits, t.dist); t.valid = 1;
+        if (use_mode_result(p, f, ch, f.cur_mode, t)) {
+          f.best = t; f.has_best = 1;
+          f.phase = PH_SPLIT_SAVED;
+          set_node(f, d);
+          L.op_a = CTX_BEST; L.op_b = CTX_CUR; L.op_c = d; post(OP_CTX_COPY); return;
+        }
+        f.phase = PH_ADVANCE; break;
+      }
+      const int i = f.child;
+      if (f.px[i] >= p.pic_w || f.py[i] >= p.pic_h) { f.child++; break; }
+      Frame &c = L.fr[d + 1];
+      c.x = f.px[i]; c.y = f.py[i]; c.w = f.pw[i]; c.h = f.ph[i];
+      c.depth = (uint8_t) (f.depth + 1); c.last_split = f.cur_split; c.part_idx = (uint8_t) i; c.impl_checked = 0; c.impl_split = 0;
+      c.ss = f.ss | ((uint64_t) f.cur_split << (f.depth * 5));
+      if (f.cur_split == SPLIT_QT) { c.qt = (uint8_t) (f.qt + 1); c.bt = 0; c.mt = 0; c.impl_bt = f.impl_bt; }
+      else {
+        const int isImpl = f.cur_split == implicit_split(p, f, ch);
+        const int tt = f.cur_split == SPLIT_TH || f.cur_split == SPLIT_TV;
+        c.qt = f.qt; c.mt = (uint8_t) (f.mt + 1); c.bt = (uint8_t) (f.bt + (tt ? (i == 1 ? 1 : 2) : 1)); c.impl_bt = (uint8_t) (f.impl_bt + (isImpl ? 1 : 0));
+      }
+      double newMax = MAX_DOUBLE;
+      if (!ch) { const double a = f.best.cost - rd_cost(p, f.temp.bits, f.temp.dist); newMax = f.max_cost < a ? f.max_cost : a; }
+      if (newMax < 0.0) newMax = 0.0;
+      c.max_cost = newMax;
+      c.phase = PH_ENTER;
+      f.phase = PH_CHILD_RET;
+      L.d = d + 1;
+      break;
+    }
+    case PH_CHILD_RET: {
+      const Sum &sub = L.fr[d + 1].best;
+      Sum &t = f.temp;
+      // sub.cost == MAX cannot happen in I slices (every in-picture leaf can be intra coded)
+      t.dist += sub.dist; t.bits += sub.bits;
+      if (f.first) { t.f_bt = sub.f_bt; t.f_cbf = sub.f_cbf; t.f_w = sub.f_w; t.f_h = sub.f_h; f.first = 0; }
+      t.l_bt = sub.l_bt; t.l_w = sub.l_w; t.l_h = sub.l_h;
+      t.n_cu = (int16_t) (t.n_cu + sub.n_cu); t.max_qt = (int16_t) imax(t.max_qt, sub.max_qt);
+      f.child++;
+      f.phase = PH_CHILD;
+      break;
+    }
+    case PH_SPLIT_SAVED: { f.phase = PH_ADVANCE; set_node(f, d); post(OP_SAVE_PIC); return; }
+    case PH_INTRA_SAVED: { f.phase = PH_ADVANCE; break; }
+    case PH_ADVANCE: {                                  // ctx ← start (xCheckBestMode 721), next mode
+      if (next_mode(p, f, ch)) f.phase = PH_RUN; else f.phase = PH_EXIT;
+      L.op_a = CTX_CUR; L.op_b = CTX_START; L.op_c = d; post(OP_CTX_COPY); return;
+    }
+    case PH_EXIT: {                                     // EL/EncCu.cpp:1533-1583
+      if (f.best.cost == MAX_DOUBLE) { f.phase = PH_EXIT2; break; }
+      f.phase = PH_EXIT2;
+      set_node(f, d);
+      L.op_a = CTX_CUR; L.op_b = CTX_BEST; L.op_c = d; L.op_d = 1; post(OP_RESTORE_PIC); return;   // picture ← bestCS, ctx ← best
+    }
+    case PH_EXIT2: { L.d = d - 1; break; }
+    }
+  }
+}
+
+// final estimator pass over the coded CTU (CABACWriter::coding_tree_unit 254-309 / coding_tree 474-984): advances
+// L.cur for the next CTU of the stream.  Thread 0 only.
+template <typename T>
+__device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, Cab &cb, int ch, int tile, Frame *st, int d, int16_t *lv)
+{
+  // iterative pre-order walk with an explicit stack of frames st[d..]
+  int top = d;
+  st[top].child = 0; st[top].phase = 0;
+  while (top >= d) {
+    Frame &f = st[top];
+    if (f.phase == 0) {
+      const VxUnit *u = &fd.units[ch][(f.y >> 2) * p.uw + (f.x >> 2)];
+      const int split = (int) ((u->ss >> (f.depth * 5)) & 31);
+      f.impl_checked = 0;
+      enc_split_cu_mode(p, fd, cb, f, ch, tile, split);
+      if (!split) {
+        const int sh = ch ? 1 : 0, W = f.w >> sh, H = f.h >> sh;
+        if (!ch) {
+          int Ld = PLANAR, Ad = PLANAR;
+          const VxUnit *uL = get_cu(p, fd, 0, f.x - 1, f.y + f.h - 1, tile); if (uL) Ld = uL->dir;
+          const VxUnit *uA = get_cu(p, fd, 0, f.x + f.w - 1, f.y - 1, tile); if (uA && ((f.y - 1) >> 7) == (f.y >> 7)) Ad = uA->dir;
+          derive_mpms(Ld, Ad, L.mpm);
+          enc_intra_luma_pred_mode(cb, f.y, u->dir, u->mrl);
+          enc_bin(cb, u->cbf & 1, VX_CTX_QtCbf[0]);
+          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; residual_coding(cb, lv, W, H, 0); }
+        } else {
+          enc_intra_chroma_pred_mode(cb, u->dir);
+          enc_bin(cb, (unsigned) !!(u->cbf & 2), VX_CTX_QtCbf[1]);
+          enc_bin(cb, (unsigned) !!(u->cbf & 4), VX_CTX_QtCbf[2] + !!(u->cbf & 2));
+          for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c)) {
+            for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[c][((f.y >> 1) + yy) * fd.lstride[c] + (f.x >> 1) + xx];
+            residual_coding(cb, lv, W, H, 1);
+          }
+        }
+        top--; continue;
+      }
+      f.cur_split = (uint8_t) split;
+      const int x = f.x, y = f.y, w = f.w, h = f.h;
+      switch (split) {
+        case SPLIT_QT: f.nparts = 4; for (int i = 0; i < 4; i++) { f.pw[i] = (int16_t) (w >> 1); f.ph[i] = (int16_t) (h >> 1); f.px[i] = (int16_t) (x + ((i & 1) ? w >> 1 : 0)); f.py[i] = (int16_t) (y + ((i >= 2) ? h >> 1 : 0)); } break;
+        case SPLIT_BH: f.nparts = 2; for (int i = 0; i < 2; i++) { f.px[i] = (int16_t) x; f.pw[i] = (int16_t) w; f.ph[i] = (int16_t) (h >> 1); f.py[i] = (int16_t) (y + i * (h >> 1)); } break;
+        case SPLIT_BV: f.nparts = 2; for (int i = 0; i < 2; i++) { f.py[i] = (int16_t) y; f.ph[i] = (int16_t) h; f.pw[i] = (int16_t) (w >> 1); f.px[i] = (int16_t) (x + i * (w >> 1)); } break;
+        case SPLIT_TH: f.nparts = 3; for (int i = 0; i < 3; i++) { f.px[i] = (int16_t) x; f.pw[i] = (int16_t) w; } f.ph[0] = f.ph[2] = (int16_t) (h >> 2); f.ph[1] = (int16_t) (h >> 1); f.py[0] = (int16_t) y; f.py[1] = (int16_t) (y + (h >> 2)); f.py[2] = (int16_t) (y + (h >> 2) + (h >> 1)); break;
+        default:       f.nparts = 3; for (int i = 0; i < 3; i++) { f.py[i] = (int16_t) y; f.ph[i] = (int16_t) h; } f.pw[0] = f.pw[2] = (int16_t) (w >> 2); f.pw[1] = (int16_t) (w >> 1); f.px[0] = (int16_t) x; f.px[1] = (int16_t) (x + (w >> 2)); f.px[2] = (int16_t) (x + (w >> 2) + (w >> 1)); break;
+      }
+      f.child = 0; f.phase = 1;
+    }
+    // next child
+    if (f.child >= f.nparts) { top--; continue; }
+    const int i = f.child++;
+    if (f.px[i] >= p.pic_w || f.py[i] >= p.pic_h) continue;
+    Frame &c = st[top + 1];
+    c.x = f.px[i]; c.y = f.py[i]; c.w = f.pw[i]; c.h = f.ph[i];
+    c.depth = (uint8_t) (f.depth + 1); c.last_split = f.cur_split; c.part_idx = (uint8_t) i; c.impl_checked = 0;
+    if (f.cur_split == SPLIT_QT) { c.qt = (uint8_t) (f.qt + 1); c.bt = 0; c.mt = 0; c.impl_bt = f.impl_bt; }
+    else {
+      f.impl_checked = 0;
+      const int isImpl = f.cur_split == implicit_split(p, f, ch);
+      const int tt = f.cur_split == SPLIT_TH || f.cur_split == SPLIT_TV;
+      c.qt = f.qt; c.mt = (uint8_t) (f.mt + 1); c.bt = (uint8_t) (f.bt + (tt ? (i == 1 ? 1 : 2) : 1)); c.impl_bt = (uint8_t) (f.impl_bt + (isImpl ? 1 : 0));
+    }
+    c.phase = 0; c.child = 0;
+    top++;
+  }
+}
+template <typename T>
+__device__ __noinline__ void advance_ctx_ctu(const VxParams &p, const VxFrameDev &fd, int tile, int ctu_x, int ctu_y)
+{
+  Cab cb; cb.c = &L.cur; cb.bits = 0;
+  int16_t *lv = (int16_t *) L.tmp[0];
+  // 128x128 root: implicit QT for both trees (no bins); luma / chroma sub-trees interleaved per 64x64 (867-908)
+  for (int q = 0; q < 4; q++) {
+    const int qx = ctu_x + ((q & 1) ? 64 : 0), qy = ctu_y + ((q >= 2) ? 64 : 0);
+    if (qx >= p.pic_w || qy >= p.pic_h) continue;
+    for (int ch = 0; ch < (p.chroma ? 2 : 1); ch++) {
+      Frame &f = L.fr[1];
+      f.x = (int16_t) qx; f.y = (int16_t) qy; f.w = 64; f.h = 64; f.depth = 1; f.qt = 1; f.bt = 0; f.mt = 0; f.impl_bt = 0; f.last_split = SPLIT_QT; f.part_idx = (uint8_t) q;
+      walk_tree<T>(p, fd, cb, ch, tile, L.fr, 1, lv);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel
+template <typename T>
+__device__ void run_stream(const VxParams &p)
+{
+  const VxStreamDesc sd = p.streams[blockIdx.x];
+  const VxFrameDev &fd = p.frames[sd.frame];
+  uint8_t *scratch = p.scratch + (size_t) blockIdx.x * p.scratch_per_stream;
+  Ctx *carry = (Ctx *) (p.stream_ctx + (size_t) (sd.frame * p.ntiles + sd.tile) * 2 * NCTX);
+  const int tid = threadIdx.x;
+  if (tid == 0) { L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; }
+  ctx_copy_all(&L.cur, carry);
+  __syncthreads();
+  for (int t = 0; t < sd.n_tasks; t++) {
+    const int addr = p.task_ctu[sd.first_task + t];
+    const int ctu_x = (addr % p.ctus_w) << 7, ctu_y = (addr / p.ctus_w) << 7;
+    // contexts at CTU start → snapshot slot (MAXD-1) "start"
+    ctx_copy_all(ctx_ptr(scratch, CTX_START, MAXD + NW, 0), &L.cur);
+    __syncthreads();
+    VxCtuRes res; res.dist = 0; res.bits = 0; res.cost = 0; res.n_cu = 0; res.pad = 0;
+    for (int ch = 0; ch < (p.chroma ? 2 : 1); ch++) {
+      if (tid == 0) {
+        L.tree_ch = ch; L.d = 0;
+        Frame &f = L.fr[0];
+        f.x = (int16_t) ctu_x; f.y = (int16_t) ctu_y; f.w = 128; f.h = 128; f.depth = 0; f.qt = 0; f.bt = 0; f.mt = 0; f.impl_bt = 0;
+        f.last_split = 0; f.part_idx = 0; f.impl_checked = 0; f.ss = 0; f.max_cost = MAX_DOUBLE; f.phase = PH_ENTER;
+      }
+      if (ch == 1) ctx_copy_all(&L.cur, ctx_ptr(scratch, CTX_START, MAXD + NW, 0));     // EL/EncCu.cpp:521
+      __syncthreads();
+      for (;;) {
+        if (tid == 0) control_step(p, fd, scratch);
+        __syncthreads();
+        const int op = L.op;
+        if (op == OP_DONE) break;
+        switch (op) {
+          case OP_LUMA_PREP: op_luma_prep<T>(p, fd); if (L.op_c) op_stage_a(p, scratch); break;
+          case OP_STAGE_A: op_stage_a(p, scratch); break;
+          case OP_STAGE_B: op_stage_b(p, scratch); break;
+          case OP_CHROMA_RD: op_chroma_rd<T>(p, fd, scratch); break;
+          case OP_SAVE_INTRA: op_save_intra(p, scratch, L.cu); break;
+          case OP_SAVE_PIC: op_save_pic<T>(p, fd, scratch, 0); break;
+          case OP_RESTORE_PIC: ctx_copy_all(ctx_ptr(scratch, L.op_a, L.op_c, 0), ctx_ptr(scratch, L.op_b, L.op_c, 0)); op_save_pic<T>(p, fd, scratch, 1); break;
+          case OP_CLEAR_UNITS: op_clear_units(p, fd); break;
+          case OP_CTX_COPY: ctx_copy_all(ctx_ptr(scratch, L.op_a, L.op_c, 0), ctx_ptr(scratch, L.op_b, L.op_c, 0)); __threadfence_block(); break;
+        }
+        __syncthreads();
+      }
+      if (tid == 0) { const Sum &b = L.fr[0].best; res.dist += b.dist; res.bits += b.bits; res.cost += b.cost; res.n_cu += b.n_cu; }
+      __syncthreads();
+    }
+    // contexts back to the CTU start, then the estimator pass advances them (EL/EncCu.cpp:543, EL/EncSlice.cpp:1775-1776)
+    ctx_copy_all(&L.cur, ctx_ptr(scratch, CTX_START, MAXD + NW, 0));
+    __syncthreads();
+    if (tid == 0) { advance_ctx_ctu<T>(p, fd, sd.tile, ctu_x, ctu_y); p.results[sd.first_task + t] = res; }
+    __syncthreads();
+  }
+  ctx_copy_all(carry, &L.cur);
+  if (tid == 0) for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]);
+}
+
+extern "C" __global__ void __launch_bounds__(NT) vvcx_compress_kernel_u8(VxParams p) { run_stream<uint8_t>(p); }
+extern "C" __global__ void __launch_bounds__(NT) vvcx_compress_kernel_u16(VxParams p) { run_stream<uint16_t>(p); }

@@ -1,0 +1,93 @@
+// tools/hipemu/hip/hip_runtime.h — a tiny single-process HIP *emulator* for the CPU debug build.
+//
+// TEST INFRASTRUCTURE ONLY.  It lets the unmodified product sources (csrc/*.hip) be compiled with g++
+// (-I tools/hipemu) so that the device code's control logic, indexing and barrier placement can be
+// exercised, sanitised (ASan/UBSan) and compared with the oracle in this GPU-less container.  Every
+// thread of a workgroup is a ucontext fiber; __syncthreads / wave barriers / shuffles are fiber
+// rendezvous.  Workgroups run one after another.  It is never loaded by the product (vvcx.py loads the
+// gfx950 library only) and is not a fallback path.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <vector>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __noinline__ __attribute__((noinline))
+#define __forceinline__ inline
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+
+namespace hipemu {
+struct Fiber { void *sp; char *stack; dim3 tidx; bool done; };
+extern "C" void hipemu_switch(void **save_sp, void *load_sp);
+struct Block {
+  std::vector<Fiber> fibers; unsigned n; unsigned arrived, gen;
+  unsigned warrived[32], wgen[32]; uint64_t wslot[32][64];
+};
+extern Block *g_block; extern Fiber *g_cur; extern void *g_sched_sp; extern dim3 g_blockIdx, g_blockDim, g_gridDim;
+inline void yield() { hipemu_switch(&g_cur->sp, g_sched_sp); }
+inline void syncthreads()
+{
+  Block &b = *g_block; const unsigned gen = b.gen;
+  if (++b.arrived == b.n) { b.arrived = 0; b.gen++; } else while (b.gen == gen) yield();
+}
+inline void wave_barrier()
+{
+  Block &b = *g_block; const unsigned w = g_cur->tidx.x >> 6; const unsigned gen = b.wgen[w];
+  unsigned nw = b.n - w * 64; if (nw > 64) nw = 64;
+  if (++b.warrived[w] == nw) { b.warrived[w] = 0; b.wgen[w]++; } else while (b.wgen[w] == gen) yield();
+}
+template <typename T> inline T shfl_idx(T v, int src)
+{
+  Block &b = *g_block; const unsigned w = g_cur->tidx.x >> 6, l = g_cur->tidx.x & 63;
+  uint64_t bits = 0; memcpy(&bits, &v, sizeof(T));
+  b.wslot[w][l] = bits; wave_barrier();
+  const uint64_t r = b.wslot[w][src & 63]; wave_barrier();
+  T out; memcpy(&out, &r, sizeof(T)); return out;
+}
+void launch(std::function<void()> body, dim3 grid, dim3 block);
+}
+
+#define threadIdx (hipemu::g_cur->tidx)
+#define blockIdx (hipemu::g_blockIdx)
+#define blockDim (hipemu::g_blockDim)
+#define gridDim (hipemu::g_gridDim)
+
+inline void __syncthreads() { hipemu::syncthreads(); }
+inline void __threadfence_block() {}
+inline void __threadfence() {}
+#define __builtin_amdgcn_fence(order, scope) ((void) 0)
+inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); }
+template <typename T> inline T __shfl_xor(T v, int mask) { return hipemu::shfl_idx(v, (int) ((hipemu::g_cur->tidx.x & 63) ^ (unsigned) mask)); }
+template <typename T> inline T __shfl(T v, int src) { return hipemu::shfl_idx(v, src); }
+inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned) v); }
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
+
+// ---- the few host runtime calls the C-ABI layer uses
+typedef int hipError_t; typedef void *hipStream_t; typedef void *hipEvent_t;
+enum { hipSuccess = 0 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipMalloc(void **p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : 2; }
+inline hipError_t hipFree(void *p) { free(p); return 0; }
+inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return 0; }
+inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch([&]() { kernel(__VA_ARGS__); }, (grid), (block))
