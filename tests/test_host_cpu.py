@@ -33,7 +33,7 @@ def emu_so():
 def test_library_exports_every_declared_symbol(hip_lib):
     hdr = open(os.path.join(ROOT, "include", "vvcx.h")).read()
     names = set(re.findall(r"\b(vvcx_[a-z_]+)\s*\(", hdr))
-    assert len(names) >= 12
+    assert len(names) >= 11
     for n in names:
         assert hasattr(hip_lib, n), n
 
