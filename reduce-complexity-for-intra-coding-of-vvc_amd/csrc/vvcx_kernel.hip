@@ -25,6 +25,16 @@
 #define MAXD VXD_MAXD
 #define NCTX VXD_NUM_CTX
 #define MAX_DOUBLE 1.7e+308
+#ifndef VVCX_STAMP
+#define VVCX_STAMP 0          // 1: diagnostic build with shader-clock stamps per operation kind
+#endif
+#if VVCX_STAMP == 1
+#define STAMP() clock64()
+#elif VVCX_STAMP == 2
+#define STAMP() wall_clock64()
+#else
+#define STAMP() 0ll
+#endif
 
 enum { SPLIT_NONE = 0, SPLIT_QT = 1, SPLIT_BH = 2, SPLIT_BV = 3, SPLIT_TH = 4, SPLIT_TV = 5 };
 enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V };
@@ -62,10 +72,23 @@ struct CtlState {            // controller-private working set (touched by threa
   int n_a2;
 };
 
+struct Tables {                    // constant tables staged once per workgroup (LDS latency instead of global latency
+  uint32_t bin_frac[512];          //  on the controller's and the rate estimator's dependent chains)
+  int32_t  qscale[12], iqscale[12];
+  int16_t  ang[32], inv_ang[32];
+  int8_t   gauss[128], cubic[128];
+  uint8_t  last_prefix[8], mode_shift[8];
+  uint8_t  ctx_rate[NCTX + 2], gorice_pars[32], gorice_pos0[96], group_idx[64], mode_num[36], intra_thr[8];
+  int8_t   dct[4 + 16 + 64 + 256 + 1024 + 4096];
+};
+
 struct Lds {
+  Tables t;
   Ctx cur;                         // the estimator's contexts
   Ctx wctx[NW];                    // per-wave working copies
+  Ctx wpark[NW];                   // end-of-candidate contexts of each wave's best full-RD candidate
   int16_t org[4096];               // node's original tile: luma w*h, or Cb | Cr (cw*ch each)
+  uint8_t scan_tab[NW][160];       // per-wave scratch of residual_coding: CG inner scan x/y (16+16) and CG scan x/y (64+64)
   int16_t refs[4][2][140];         // luma: set 0 mrl0 unfiltered, 1 mrl0 filtered, 2 mrl1, 3 mrl3; chroma: set 0 Cb, 1 Cr. [0]=top [1]=left
   int32_t tmp[NW][2048];           // per-wave transform scratch / Hadamard scratch
   int16_t slot[NW][2][2048];       // per-wave candidate slots (T = being evaluated, B = wave best): rec | lev
@@ -79,13 +102,15 @@ struct Lds {
   Cand rd[16]; double rd_cost[16]; uint64_t rd_dist[16]; uint64_t rd_bits[16]; uint8_t rd_cbf[16]; int n_rd;
   int wave_best[NW], wave_slot[NW]; // candidate index of each wave's best and the slot that holds it
   CtlState S; VxUnit cu;           // controller working set; CU record of the intra candidate being evaluated
-  unsigned mpm[6]; int mpm_n;
+  unsigned mpm[6], mpm_sorted[6]; int mpm_n;
   int dc_val[4];
   int cur_tile, frame, ctu_x, ctu_y, tree_ch;
   int d;                           // current recursion level
   // intra result of the node being evaluated
   int win_idx, win_wave;
+  unsigned long long cu_bits;      // cu_pred_data + cu_residual bits of the winner (contexts left in wctx[0])
   unsigned long long cnt[4];
+  unsigned long long prof[16];    // shader-clock ticks per operation kind (diagnostic, see vvcx_get_profile)
 };
 
 __shared__ Lds L;
@@ -95,6 +120,17 @@ __device__ inline int ilog2i(int v) { return 31 - __clz(v); }
 __device__ inline int imin(int a, int b) { return a < b ? a : b; }
 __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 __device__ inline int iabs(int a) { return a < 0 ? -a : a; }
+// Values that are uniform across the workgroup / wavefront at run time but that the compiler sees in VGPRs
+// (LDS loads, threadIdx-derived wave index, arguments of non-inlined functions) are moved to SGPRs before they
+// steer any control flow that contains a barrier, a wave barrier or a shuffle: the structurizer may otherwise
+// serialise what it believes to be divergent paths around those convergent operations.
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline double uni_d(double v)
+{
+  union { double d; int i[2]; } u; u.d = v;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]); u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
 __device__ inline void wave_sync()
 {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -125,8 +161,8 @@ __device__ inline void enc_bin(Cab &cb, unsigned bin, int ctx)
 {
   Ctx *c = cb.c;
   const unsigned st = (unsigned) (c->s0[ctx] + c->s1[ctx]) >> 8;
-  cb.bits += VX_BIN_FRAC_BITS[st * 2 + bin];
-  const int rate = VX_CTX_RATE[ctx];
+  cb.bits += L.t.bin_frac[st * 2 + bin];
+  const int rate = L.t.ctx_rate[ctx];
   const int r0 = 2 + ((rate >> 2) & 3), r1 = 3 + r0 + (rate & 3);
   unsigned a = c->s0[ctx], b = c->s1[ctx];
   a -= (a >> r0) & 0x7FE0u; b -= (b >> r1) & 0x7FFEu;
@@ -197,7 +233,7 @@ __device__ __noinline__ void residual_coding(Cab &cb, const int16_t *coeff, int 
   const int zw = imin(32, w), zh = imin(32, h), wg = zw >> lcw, hg = zh >> lch;
   const int ngroups = wg * hg, cgSize = 1 << lcg;
   // inner scan of a coefficient group (<= 16 positions) and CG scan (<= 64 groups)
-  uint8_t ix[16], iy[16], gxs[64], gys[64];
+  uint8_t *ix = L.scan_tab[threadIdx.x >> 6], *iy = ix + 16, *gxs = ix + 32, *gys = ix + 96;
   { int line = 0, col = 0;
     for (int n = 0; n < cgSize; n++) { ix[n] = (uint8_t) col; iy[n] = (uint8_t) line;
       if (col == cw - 1 || line == 0) { line += col + 1; col = 0; if (line >= chh) { col += line - (chh - 1); line = chh - 1; } } else { col++; line--; } } }
@@ -213,12 +249,12 @@ __device__ __noinline__ void residual_coding(Cab &cb, const int16_t *coeff, int 
   const int l2w = ilog2i(w), l2h = ilog2i(h);
   int offx = 0, offy = 0, shx, shy;
   if (is_chroma) { shx = imin(2, w >> 3); shy = imin(2, h >> 3); }
-  else { const int pc[8] = { 0, 0, 0, 3, 6, 10, 15, 21 }; offx = pc[l2w]; offy = pc[l2h]; shx = (l2w + 1) >> 2; shy = (l2h + 1) >> 2; }
+  else { offx = L.t.last_prefix[l2w]; offy = L.t.last_prefix[l2h]; shx = (l2w + 1) >> 2; shy = (l2h + 1) >> 2; }
   {
     const int blk = BLK(scanPosLast);
     const int posY = blk / w, posX = blk - posY * w;
-    const int gx = VX_GROUP_IDX[posX], gy = VX_GROUP_IDX[posY];
-    const int maxX = VX_GROUP_IDX[zw - 1], maxY = VX_GROUP_IDX[zh - 1];
+    const int gx = L.t.group_idx[posX], gy = L.t.group_idx[posY];
+    const int maxX = L.t.group_idx[zw - 1], maxY = L.t.group_idx[zh - 1];
     int k;
     for (k = 0; k < gx; k++) enc_bin(cb, 1, VX_CTX_LastX[c.ch] + offx + (k >> shx));
     if (gx < maxX) enc_bin(cb, 0, VX_CTX_LastX[c.ch] + offx + (k >> shx));
@@ -273,13 +309,13 @@ __device__ __noinline__ void residual_coding(Cab &cb, const int16_t *coeff, int 
     for (int sp = firstSigPos; sp > firstPosMode2; sp--) {
       const int blk = BLK(sp);
       const unsigned a = (unsigned) iabs(coeff[blk]);
-      if (a >= 4) enc_rem_abs(cb, (a - 4) >> 1, VX_GORICE_PARS[tmpl_abs_sum(c, coeff, blk, 4)]);
+      if (a >= 4) enc_rem_abs(cb, (a - 4) >> 1, L.t.gorice_pars[tmpl_abs_sum(c, coeff, blk, 4)]);
     }
     for (int sp = firstPosMode2; sp >= minSub; sp--) {
       const int blk = BLK(sp);
       const unsigned a = (unsigned) iabs(coeff[blk]);
       const int sumAll = tmpl_abs_sum(c, coeff, blk, 0);
-      const unsigned rice = VX_GORICE_PARS[sumAll], pos0 = VX_GORICE_POS0[sumAll];
+      const unsigned rice = L.t.gorice_pars[sumAll], pos0 = L.t.gorice_pos0[sumAll];
       enc_rem_abs(cb, a == 0 ? pos0 : a <= pos0 ? a - 1 : a, rice);
       if (a) numNonZero++;
     }
@@ -409,6 +445,9 @@ __device__ void derive_mpms(int Ld, int Ad, unsigned mpm[6])
     mpm[0] = PLANAR; mpm[1] = (unsigned) (Ld < Ad ? Ad : Ld);
     mpm[2] = ((mpm[1] + offset) % mod) + 2; mpm[3] = ((mpm[1] - 1) % mod) + 2; mpm[4] = ((mpm[1] + offset - 1) % mod) + 2; mpm[5] = (mpm[1] % mod) + 2;
   }
+  // ascending copy for the non-MPM rank (std::sort in intra_luma_pred_mode, EL/CABACWriter.cpp:1833)
+  for (int i = 0; i < 6; i++) L.mpm_sorted[i] = mpm[i];
+  for (int i = 1; i < 6; i++) { unsigned v = L.mpm_sorted[i]; int j = i - 1; while (j >= 0 && L.mpm_sorted[j] > v) { L.mpm_sorted[j + 1] = L.mpm_sorted[j]; j--; } L.mpm_sorted[j + 1] = v; }
 }
 // CABACWriter::intra_luma_pred_mode 1762-1845 + extend_ref_line 1566-1591 (MIP/ISP off); MPMs from L.mpm
 __device__ void enc_intra_luma_pred_mode(Cab &cb, int y, int dir, int mrl)
@@ -424,13 +463,34 @@ __device__ void enc_intra_luma_pred_mode(Cab &cb, int y, int dir, int mrl)
     if (mrl == 0) enc_bin(cb, mpm_idx > 0, VX_CTX_IntraLumaPlanarFlag + 1);
     enc_ep(cb, imin(mpm_idx, 4));
   } else {
-    unsigned s[6];
-    for (int i = 0; i < 6; i++) s[i] = L.mpm[i];
-    for (int i = 1; i < 6; i++) { unsigned v = s[i]; int j = i - 1; while (j >= 0 && s[j] > v) { s[j + 1] = s[j]; j--; } s[j + 1] = v; }
     unsigned m = (unsigned) dir;
-    for (int i = 5; i >= 0; i--) if (m > s[i]) m--;
+    for (int i = 5; i >= 0; i--) if (m > L.mpm_sorted[i]) m--;
     enc_ep(cb, m < 3 ? 5 : 6);                   // xWriteTruncBinCode(m, 61)
   }
+}
+// xFracModeBitsIntra (EL/IntraSearch.cpp:4263-4288) from the node's start contexts.  Every context-coded bin of
+// intra_luma_pred_mode uses a different context, so the bits are a pure function of the start states.
+__device__ inline unsigned frac_bits_of(const Ctx &c, int ctx, unsigned bin)
+{ return L.t.bin_frac[(((unsigned) (c.s0[ctx] + c.s1[ctx]) >> 8) << 1) + bin]; }
+__device__ unsigned long long luma_mode_bits(const Ctx &c, int y, int dir, int mrl)
+{
+  unsigned long long bits = 0;
+  if ((y & 127) != 0) {
+    bits += frac_bits_of(c, VX_CTX_MultiRefLineIdx, mrl != 0);
+    if (mrl != 0) bits += frac_bits_of(c, VX_CTX_MultiRefLineIdx + 1, mrl != 1);
+  }
+  int mpm_idx = 6;
+  for (int i = 0; i < 6; i++) if ((unsigned) dir == L.mpm[i]) { mpm_idx = i; break; }
+  if (!mrl) bits += frac_bits_of(c, VX_CTX_IntraLumaMpmFlag, mpm_idx < 6);
+  if (mpm_idx < 6) {
+    if (mrl == 0) bits += frac_bits_of(c, VX_CTX_IntraLumaPlanarFlag + 1, mpm_idx > 0);
+    bits += (unsigned long long) imin(mpm_idx, 4) << 15;
+  } else {
+    unsigned m = (unsigned) dir;
+    for (int i = 5; i >= 0; i--) if (m > L.mpm_sorted[i]) m--;
+    bits += (unsigned long long) (m < 3 ? 5 : 6) << 15;
+  }
+  return bits;
 }
 __device__ void enc_intra_chroma_pred_mode(Cab &cb, int dir)      // 1891-1933, CCLM off
 {
@@ -445,6 +505,8 @@ static __device__ const int16_t ANG_TABLE[32] = { 0, 1, 2, 3, 4, 6, 8, 10, 12, 1
 static __device__ const int16_t INV_ANG_TABLE[32] = { 0, 16384, 8192, 5461, 4096, 2731, 2048, 1638, 1365, 1170, 1024, 910, 819, 712, 630, 565,
   512, 468, 420, 364, 321, 287, 256, 224, 191, 161, 128, 96, 64, 48, 32, 16 };
 static __device__ const uint8_t INTRA_FILTER_THR[8] = { 24, 24, 24, 14, 2, 0, 0, 0 };
+static __device__ const uint8_t LAST_PREFIX_CTX[8] = { 0, 0, 0, 3, 6, 10, 15, 21 };     // CL/ContextModelling.cpp:106
+static __device__ const uint8_t MODE_SHIFT[8] = { 0, 6, 10, 12, 14, 15, 0, 0 };          // CL/IntraPrediction.cpp:291
 static __device__ const int8_t GAUSS_FILTER[32][4] = {     // g_intraGaussFilter (spec table), CL/IntraPrediction.cpp:76
   {16,32,16,0},{15,29,17,3},{15,29,17,3},{14,29,18,3},{13,29,18,4},{13,28,19,4},{13,28,19,4},{12,28,20,4},
   {11,28,20,5},{11,27,21,5},{10,27,22,5},{9,27,22,6},{9,26,23,6},{9,26,23,6},{8,25,24,7},{8,25,24,7},
@@ -456,10 +518,9 @@ __device__ void init_pred_params(int w, int h, int is_luma, int mode, int mrl, I
 {
   int pm = mode;
   if (pm > DC && pm <= VDIA) {
-    const int modeShift[6] = { 0, 6, 10, 12, 14, 15 };
-    const int ds = iabs(ilog2i(w) - ilog2i(h));
-    if (w > h && pm < 2 + modeShift[ds]) pm += VDIA - 1;
-    else if (h > w && pm > VDIA - modeShift[ds]) pm -= VDIA - 1;
+    const int ms = L.t.mode_shift[iabs(ilog2i(w) - ilog2i(h))];
+    if (w > h && pm < 2 + ms) pm += VDIA - 1;
+    else if (h > w && pm > VDIA - ms) pm -= VDIA - 1;
   }
   p.pred_mode = pm; p.is_ver = pm >= DIA; p.mrl = is_luma ? mrl : 0; p.ref_filter = 0; p.interp = 0;
   p.pdpc = ((w >= 4 && h >= 4) || !is_luma) && p.mrl == 0;
@@ -468,7 +529,7 @@ __device__ void init_pred_params(int w, int h, int is_luma, int mode, int mrl, I
   int absAng = 0;
   if (mode > DC && mode < 67) {
     const int a = iabs(am);
-    absAng = ANG_TABLE[a]; p.inv_angle = INV_ANG_TABLE[a]; p.angle = am < 0 ? -absAng : absAng;
+    absAng = L.t.ang[a]; p.inv_angle = L.t.inv_ang[a]; p.angle = am < 0 ? -absAng : absAng;
     if (am < 0) p.pdpc = 0;
     else if (am > 0) {
       const int side = p.is_ver ? h : w;
@@ -483,7 +544,7 @@ __device__ void init_pred_params(int w, int h, int is_luma, int mode, int mrl, I
     const int d1 = iabs(pm - HOR), d2 = iabs(pm - VER);
     const int diff = d1 < d2 ? d1 : d2;
     const int log2Size = (ilog2i(w) + ilog2i(h)) >> 1;
-    if (diff > INTRA_FILTER_THR[log2Size]) { const int is_int = (absAng & 0x1F) == 0; p.ref_filter = is_int; p.interp = !is_int; }
+    if (diff > L.t.intra_thr[log2Size]) { const int is_int = (absAng & 0x1F) == 0; p.ref_filter = is_int; p.interp = !is_int; }
   }
 }
 __device__ inline int clip_bd(int v, int bd) { const int mx = (1 << bd) - 1; return v < 0 ? 0 : v > mx ? mx : v; }
@@ -528,7 +589,7 @@ __device__ int pred_sample(const int16_t *top, const int16_t *left, int w, int h
       const int di = deltaPos >> 5, df = deltaPos & 31;
       if ((iabs(ang) & 0x1F) != 0) {
         if (is_luma) {
-          const int8_t *f = ip.interp ? GAUSS_FILTER[df] : &VX_CUBIC_FILTER[df * 4];
+          const int8_t *f = ip.interp ? &L.t.gauss[df * 4] : &L.t.cubic[df * 4];
           const int s = f[0] * MAINR(di + xx) + f[1] * MAINR(di + xx + 1) + f[2] * MAINR(di + xx + 2) + f[3] * MAINR(di + xx + 3);
           v = clip_bd((int) (int16_t) ((s + 32) >> 6), bd);
         } else {
@@ -576,6 +637,7 @@ template <typename T>
 __device__ __noinline__ void build_refs(const VxParams &p, const VxFrameDev &fd, int comp, int x, int y, int w, int h, int tile, int nsets)
 {
   const int tid = threadIdx.x;
+  comp = uni(comp); x = uni(x); y = uni(y); w = uni(w); h = uni(h); tile = uni(tile); nsets = uni(nsets);
   const int ch = comp ? 1 : 0;
   const int unit = ch ? 2 : 4, ul = ch ? 1 : 2;
   const int W = ch ? p.pic_w >> 1 : p.pic_w, H = ch ? p.pic_h >> 1 : p.pic_h;
@@ -665,10 +727,6 @@ template <int N> __device__ inline void had1d(int *v)
 #pragma unroll
       for (int j = i; j < i + len; j++) { const int a = v[j], b = v[j + len]; v[j] = a + b; v[j + len] = a - b; }
 }
-__device__ inline void had1d_n(int *v, int n)
-{
-  switch (n) { case 2: had1d<2>(v); break; case 4: had1d<4>(v); break; case 8: had1d<8>(v); break; default: had1d<16>(v); break; }
-}
 __device__ void satd_tile_shape(int w, int h, int &bw, int &bh)       // CL/RdCost.cpp:2764-2854
 {
   if (w > h && (h & 7) == 0 && (w & 15) == 0) { bw = 16; bh = 8; }
@@ -679,55 +737,97 @@ __device__ void satd_tile_shape(int w, int h, int &bw, int &bh)       // CL/RdCo
   else if ((h & 3) == 0 && (w & 3) == 0) { bw = 4; bh = 4; }
   else { bw = 2; bh = 2; }
 }
-// SAD and SATD (xGetHADs) of org vs pred, both w*h tiles with stride w, by one wavefront; scratch >= w*h int16
-__device__ __noinline__ void wave_sad_satd(const int16_t *org, const int16_t *pred, int w, int h, int16_t *scr, int lane,
-                              unsigned long long &sad_out, unsigned long long &satd_out)
+// SAD and SATD (xGetHADs) of org vs pred, both w*h tiles with stride w, by one wavefront; scratch >= w*h int16.
+// Templated on the Hadamard tile shape so that the per-lane row/column vectors stay in registers.
+template <int BW, int BH>
+__device__ inline void sad_satd_tiles(const int16_t *org, const int16_t *pred, int w, int P, int16_t *scr, int lane, int &sad_out, int &satd_out)
 {
-  const int P = w * h;
-  int bw, bh; satd_tile_shape(w, h, bw, bh);
-  const int tilesX = w / bw, tsz = bw * bh;
+  const int tilesX = w / BW, tsz = BW * BH;
   int sad = 0;
-  // rows: one row segment of a Hadamard tile per lane
-  for (int s = lane; s < P / bw; s += 64) {
-    const int t = s / bh, r = s - t * bh, tx = t % tilesX, ty = t / tilesX;
-    const int base = (ty * bh + r) * w + tx * bw;
-    int v[16];
-    for (int i = 0; i < bw; i++) { v[i] = org[base + i] - pred[base + i]; sad += iabs(v[i]); }
-    had1d_n(v, bw);
-    for (int i = 0; i < bw; i++) scr[t * tsz + r * bw + i] = (int16_t) v[i];
+  for (int s = lane; s < P / BW; s += 64) {            // one row segment of a tile per lane
+    const int t = s / BH, r = s - t * BH, tx = t % tilesX, ty = t / tilesX;
+    const int base = (ty * BH + r) * w + tx * BW;
+    int v[BW];
+#pragma unroll
+    for (int i = 0; i < BW; i++) { v[i] = org[base + i] - pred[base + i]; sad += iabs(v[i]); }
+    had1d<BW>(v);
+#pragma unroll
+    for (int i = 0; i < BW; i++) scr[t * tsz + r * BW + i] = (int16_t) v[i];
   }
   wave_sync();
-  unsigned long long satd = 0;
-  const int ncols = P / bh;               // column segments, bw consecutive lanes share a tile
+  int satd = 0;
+  const int ncols = P / BH;                             // column segments; BW consecutive lanes share a tile
   for (int it = 0; it * 64 < ncols; it++) {
     const int q = it * 64 + lane;
     int s = 0;
     if (q < ncols) {
-      const int t = q / bw, i = q - t * bw;
-      int v[16];
-      for (int r = 0; r < bh; r++) v[r] = scr[t * tsz + r * bw + i];
-      had1d_n(v, bh);
-      for (int r = 0; r < bh; r++) s += iabs(v[r]);
+      const int t = q / BW, i = q - t * BW;
+      int v[BH];
+#pragma unroll
+      for (int r = 0; r < BH; r++) v[r] = scr[t * tsz + r * BW + i];
+      had1d<BH>(v);
+#pragma unroll
+      for (int r = 0; r < BH; r++) s += iabs(v[r]);
     }
-    for (int m = 1; m < bw; m <<= 1) s += __shfl_xor(s, m);     // tile total on every lane of the group
-    if (q < ncols && (lane & (bw - 1)) == 0) {
-      unsigned long long n;
-      if (bw == 2) n = (unsigned long long) s;
-      else if (bw == 4 && bh == 4) n = (unsigned long long) ((s + 1) >> 1);
-      else if (bw == 8 && bh == 8) n = (unsigned long long) ((s + 2) >> 2);
-      else { const double c = tsz == 128 ? 0x1.6a09e667f3bcdp+3 : 0x1.6a09e667f3bcdp+2; n = (unsigned long long) (int) ((double) s / c * 2); }
+#pragma unroll
+    for (int m = 1; m < BW; m <<= 1) s += __shfl_xor(s, m);       // tile total on every lane of the group
+    if (q < ncols && (lane & (BW - 1)) == 0) {
+      int n;
+      if (BW == 2) n = s;                                 // CL/RdCost.cpp:2110-2115
+      else if (BW == 4 && BH == 4) n = (s + 1) >> 1;      // 2209
+      else if (BW == 8 && BH == 8) n = (s + 2) >> 2;      // 2306
+      else { const double c = tsz == 128 ? 0x1.6a09e667f3bcdp+3 : 0x1.6a09e667f3bcdp+2; n = (int) ((double) s / c * 2); }   // 2452,2589,2662,2741
       satd += n;
     }
   }
   wave_sync();
-  sad_out = wave_sum_u64((unsigned long long) sad);
-  satd_out = wave_sum_u64(satd);
+  sad_out = sad; satd_out = satd;
+}
+__device__ __noinline__ void wave_sad_satd(const int16_t *org, const int16_t *pred, int w, int h, int16_t *scr, int lane,
+                              unsigned long long &sad_out, unsigned long long &satd_out)
+{
+  w = uni(w); h = uni(h);
+  const int P = w * h;
+  int bw, bh; satd_tile_shape(w, h, bw, bh);
+  int a = 0, b = 0;
+  switch (bw * 100 + bh) {
+    case 1608: sad_satd_tiles<16, 8>(org, pred, w, P, scr, lane, a, b); break;
+    case 816:  sad_satd_tiles<8, 16>(org, pred, w, P, scr, lane, a, b); break;
+    case 804:  sad_satd_tiles<8, 4>(org, pred, w, P, scr, lane, a, b); break;
+    case 408:  sad_satd_tiles<4, 8>(org, pred, w, P, scr, lane, a, b); break;
+    case 808:  sad_satd_tiles<8, 8>(org, pred, w, P, scr, lane, a, b); break;
+    case 404:  sad_satd_tiles<4, 4>(org, pred, w, P, scr, lane, a, b); break;
+    default:   sad_satd_tiles<2, 2>(org, pred, w, P, scr, lane, a, b); break;
+  }
+  // both sums fit 32 bits (<= 4096 * 1023 * 16): two independent 32-bit butterflies
+  for (int m = 32; m >= 1; m >>= 1) { const int ta = __shfl_xor(a, m), tb = __shfl_xor(b, m); a += ta; b += tb; }
+  sad_out = (unsigned long long) (unsigned) a;
+  satd_out = (unsigned long long) (unsigned) b;
 }
 
 // ------------------------------------------------------------------------------------------------ transform + quant (one wave)
-__device__ const int8_t *dct2_matrix(int n)
+__device__ inline const int8_t *dct2_matrix(int n)
 {
-  switch (n) { case 2: return VX_DCT2_2; case 4: return VX_DCT2_4; case 8: return VX_DCT2_8; case 16: return VX_DCT2_16; case 32: return VX_DCT2_32; default: return VX_DCT2_64; }
+  switch (n) { case 2: return L.t.dct; case 4: return L.t.dct + 4; case 8: return L.t.dct + 20; case 16: return L.t.dct + 84; case 32: return L.t.dct + 340; default: return L.t.dct + 1364; }
+}
+__device__ void load_tables()
+{
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 512; i += NT) L.t.bin_frac[i] = VX_BIN_FRAC_BITS[i];
+  for (int i = tid; i < NCTX; i += NT) L.t.ctx_rate[i] = VX_CTX_RATE[i];
+  if (tid < 12) { L.t.qscale[tid] = VX_QUANT_SCALES[tid]; L.t.iqscale[tid] = VX_INV_QUANT_SCALES[tid]; }
+  if (tid < 32) { L.t.ang[tid] = ANG_TABLE[tid]; L.t.inv_ang[tid] = INV_ANG_TABLE[tid]; L.t.gorice_pars[tid] = VX_GORICE_PARS[tid]; }
+  if (tid < 128) { L.t.gauss[tid] = GAUSS_FILTER[tid >> 2][tid & 3]; L.t.cubic[tid] = VX_CUBIC_FILTER[tid]; }
+  if (tid < 96) L.t.gorice_pos0[tid] = VX_GORICE_POS0[tid];
+  if (tid < 64) L.t.group_idx[tid] = VX_GROUP_IDX[tid];
+  if (tid < 36) L.t.mode_num[tid] = VX_MODE_NUM_FAST_2D[tid];
+  if (tid < 8) { L.t.intra_thr[tid] = INTRA_FILTER_THR[tid]; L.t.last_prefix[tid] = LAST_PREFIX_CTX[tid]; L.t.mode_shift[tid] = MODE_SHIFT[tid]; }
+  for (int i = tid; i < 4; i += NT) L.t.dct[i] = VX_DCT2_2[i];
+  for (int i = tid; i < 16; i += NT) L.t.dct[4 + i] = VX_DCT2_4[i];
+  for (int i = tid; i < 64; i += NT) L.t.dct[20 + i] = VX_DCT2_8[i];
+  for (int i = tid; i < 256; i += NT) L.t.dct[84 + i] = VX_DCT2_16[i];
+  for (int i = tid; i < 1024; i += NT) L.t.dct[340 + i] = VX_DCT2_32[i];
+  for (int i = tid; i < 4096; i += NT) L.t.dct[1364 + i] = VX_DCT2_64[i];
 }
 // residual (org - pred) → DCT-II (TrQuant::xT 835-915) → plain quant (Quant::quant 994-1089) → levels;
 // if any level: dequant (423-549) → inverse DCT-II (xIT 917-992) → reco = clip(pred + resi) written over pred.
@@ -735,6 +835,7 @@ __device__ const int8_t *dct2_matrix(int n)
 __device__ __noinline__ void wave_code_block(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp,
                                 int lane, unsigned long long &sse_out, int &cbf_out)
 {
+  w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp);
   const int P = w * h, lw = ilog2i(w), lh = ilog2i(h);
   const int zw = imin(w, 32), zh = imin(h, 32);
   const int8_t *Mw = dct2_matrix(w), *Mh = dct2_matrix(h);
@@ -750,7 +851,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org, int16_t *rec, i
   wave_sync();
   // quant parameters
   const int need_sqrt = (lw + lh) & 1;
-  const int qscale = VX_QUANT_SCALES[need_sqrt * 6 + qp % 6];
+  const int qscale = L.t.qscale[need_sqrt * 6 + qp % 6];
   const int tr_shift = 15 - bd - ((lw + lh) >> 1) + (need_sqrt ? -1 : 0);
   const int qbits = 14 + qp / 6 + tr_shift;
   const long long qadd = (long long) 171 << (qbits - 9);
@@ -769,11 +870,11 @@ __device__ __noinline__ void wave_code_block(const int16_t *org, int16_t *rec, i
     q = q < -32768 ? -32768 : q > 32767 ? 32767 : q;
     lev[m * w + k] = (int16_t) q;
   }
-  abs_sum = wave_sum_i32(abs_sum);
+  abs_sum = uni(wave_sum_i32(abs_sum));
   wave_sync();
   unsigned long long sse = 0;
   if (abs_sum > 0) {
-    const int iscale = VX_INV_QUANT_SCALES[need_sqrt * 6 + qp % 6];
+    const int iscale = L.t.iqscale[need_sqrt * 6 + qp % 6];
     const int right_shift = 6 - (tr_shift + qp / 6);
     int tbd = 32 + right_shift - 7; if (tbd > 16) tbd = 16;
     const int in_min = -(1 << (tbd - 1)), in_max = (1 << (tbd - 1)) - 1;
@@ -835,45 +936,46 @@ __device__ Ctx *ctx_ptr(uint8_t *scratch, int which, int d, int wave)
 template <typename T>
 __device__ __noinline__ void op_luma_prep(const VxParams &p, const VxFrameDev &fd)
 {
-  const int x = L.nx, y = L.ny, w = L.nw, h = L.nh;
+  const int x = uni(L.nx), y = uni(L.ny), w = uni(L.nw), h = uni(L.nh);
+  const long long ts = STAMP();
   const void *org = fd.org[0]; const int st = fd.stride[0];
   for (int i = threadIdx.x; i < w * h; i += NT) { const int r = i / w, c = i - r * w; L.org[i] = (int16_t) ld_px<T>(org, (y + r) * st + x + c); }
   const int nsets = ((y & 127) == 0 || !(p.tools & 1)) ? 1 : 3;
-  build_refs<T>(p, fd, 0, x, y, w, h, L.cur_tile, nsets);
+  build_refs<T>(p, fd, 0, x, y, w, h, uni(L.cur_tile), nsets);
   if (threadIdx.x < 4) {
     const int s = threadIdx.x;           // dc per set (filtered set never used for DC)
     if (s != 1 && (s == 0 || nsets == 3)) L.dc_val[s] = dc_value(L.refs[s][0], L.refs[s][1], w, h, s == 0 ? 0 : s == 2 ? 1 : 3);
   }
   __syncthreads();
+  if (VVCX_STAMP && threadIdx.x == 0) L.prof[14] += (unsigned long long) (STAMP() - ts);
 }
 __device__ inline int luma_set(int mrl, int filt) { return mrl == 0 ? (filt ? 1 : 0) : (mrl == 1 ? 2 : 3); }
 
 // OP_STAGE_A: SATD-stage cost of every candidate in L.cand[op_a .. op_b) (EL/IntraSearch.cpp:489-682), one wave per candidate
 __device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
 {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int w = L.nw, h = L.nh, P = w * h, bd = p.bit_depth;
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int w = uni(L.nw), h = uni(L.nh), P = w * h, bd = p.bit_depth;
   int16_t *pred = slot_rec(scratch, P, wave, 0);
   int16_t *scr = (int16_t *) L.tmp[wave];
-  for (int c = L.op_a + wave; c < L.op_b; c += NW) {
-    const int mode = L.cand[c].mode, mrl = L.cand[c].mrl;
+  const int c_end = uni(L.op_b);
+  for (int c = uni(L.op_a) + wave; c < c_end; c += NW) {
+    const int mode = uni(L.cand[c].mode), mrl = uni(L.cand[c].mrl);
     Ipa ip; init_pred_params(w, h, 1, mode, mrl, ip);
     const int set = luma_set(mrl, ip.ref_filter);
     const int16_t *top = L.refs[set][0], *left = L.refs[set][1];
     const int dcv = L.dc_val[luma_set(mrl, 0)];
+    const long long ta = STAMP();
     for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; pred[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
     wave_sync();
+    const long long tb = STAMP();
     unsigned long long sad, satd;
     wave_sad_satd(L.org, pred, w, h, scr, lane, sad, satd);
+    if (VVCX_STAMP && threadIdx.x == 0) { const long long tc = STAMP(); L.prof[15] += (unsigned long long) (tb - ta); L.prof[11] += (unsigned long long) (tc - tb); }
     if (lane == 0) {
       const unsigned long long msh = sad * 2 < satd ? sad * 2 : satd;
-      // xFracModeBitsIntra 4263-4288 from the node's start contexts (every bin uses a distinct context)
-      Ctx *wc = &L.wctx[wave];
-      const int ids[5] = { VX_CTX_MultiRefLineIdx, VX_CTX_MultiRefLineIdx + 1, VX_CTX_IntraLumaMpmFlag, VX_CTX_IntraLumaPlanarFlag, VX_CTX_IntraLumaPlanarFlag + 1 };
-      for (int k = 0; k < 5; k++) { wc->s0[ids[k]] = L.cur.s0[ids[k]]; wc->s1[ids[k]] = L.cur.s1[ids[k]]; }
-      Cab cb; cb.c = wc; cb.bits = 0;
-      enc_intra_luma_pred_mode(cb, L.ny, mode, mrl);
-      const double a = (double) cb.bits * p.sqrt_lambda_fp;
+      const unsigned long long mbits = luma_mode_bits(L.cur, L.ny, mode, mrl);
+      const double a = (double) mbits * p.sqrt_lambda_fp;
       L.cand_cost[c] = (double) msh + a;
       L.cand_had[c] = (double) msh;
     }
@@ -885,13 +987,14 @@ __device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
 // OP_STAGE_B: full RD of L.rd[0..n_rd) (EL/IntraSearch.cpp:1158-1358 → xRecurIntraCodingLumaQT → xIntraCodingTUBlock)
 __device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
 {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int w = L.nw, h = L.nh, P = w * h, bd = p.bit_depth;
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int w = uni(L.nw), h = uni(L.nh), P = w * h, bd = p.bit_depth;
   if (lane == 0) L.wave_best[wave] = -1;
   double wbest = MAX_DOUBLE;
   int cur = 0;                                    // slot being written; the other one holds the wave's best so far
-  for (int c = wave; c < L.n_rd; c += NW) {
-    const int mode = L.rd[c].mode, mrl = L.rd[c].mrl;
+  const int n_rd = uni(L.n_rd);
+  for (int c = wave; c < n_rd; c += NW) {
+    const int mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
     int16_t *rec = slot_rec(scratch, P, wave, cur), *lev = slot_lev(scratch, P, wave, cur);
     Ipa ip; init_pred_params(w, h, 1, mode, mrl, ip);
     const int set = luma_set(mrl, ip.ref_filter);
@@ -913,18 +1016,25 @@ __device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
       cost = rd_cost(p, cb.bits, sse);
       L.rd_cost[c] = cost; L.rd_dist[c] = sse; L.rd_bits[c] = cb.bits; L.rd_cbf[c] = (uint8_t) cbf;
     }
-    cost = __shfl(cost, 0);
+    cost = uni_d(__shfl(cost, 0));
     if (cost < wbest) {
       wbest = cost;
       if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = cur; }
       cur ^= 1;
       // keep the end-of-candidate contexts of the wave's best: they are the CU's end contexts (same syntax as
       // cu_pred_data + cu_residual of xCheckRDCostIntra 2593-2619 for a luma-tree CU)
-      Ctx *keep = ctx_ptr(scratch, CTX_BEST, MAXD + wave, 0);
-      { uint32_t *d = (uint32_t *) keep; const uint32_t *s = (const uint32_t *) &L.wctx[wave]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
+      { uint32_t *d = (uint32_t *) &L.wpark[wave]; const uint32_t *s = (const uint32_t *) &L.wctx[wave]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     }
     wave_sync();
   }
+  __syncthreads();
+  // winner (strict <, list order ≙ EL/IntraSearch.cpp:1308) and its end contexts → wctx[0]; every thread computes the same
+  int best = 0; double bc = MAX_DOUBLE;
+  for (int c = 0; c < n_rd; c++) { const double v = L.rd_cost[c]; if (v < bc) { bc = v; best = c; } }
+  best = uni(best);
+  const int ww = best % NW;
+  if (threadIdx.x == 0) { L.win_idx = best; L.win_wave = ww; L.cu_bits = L.rd_bits[best]; }
+  ctx_copy_all(&L.wctx[0], &L.wpark[ww]);
   __syncthreads();
 }
 
@@ -933,12 +1043,12 @@ __device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
 template <typename T>
 __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
 {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int x = L.nx >> 1, y = L.ny >> 1, w = L.nw >> 1, h = L.nh >> 1, P = w * h, bd = p.bit_depth;
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int x = uni(L.nx) >> 1, y = uni(L.ny) >> 1, w = uni(L.nw) >> 1, h = uni(L.nh) >> 1, P = w * h, bd = p.bit_depth;
   for (int c = 1; c <= 2; c++) {
     const void *org = fd.org[c]; const int st = fd.stride[c];
     for (int i = threadIdx.x; i < P; i += NT) { const int r = i / w, cc = i - r * w; L.org[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
-    build_refs<T>(p, fd, c, x, y, w, h, L.cur_tile, 1);
+    build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
   }
   if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
   __syncthreads();
@@ -946,9 +1056,10 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
   double wbest = MAX_DOUBLE;
   int cur = 0;
   const int big = 2 * P > 1024;
-  for (int c = wave; c < L.n_rd; c += NW) {
-    const int cm = L.rd[c].mode;                      // chroma mode (70 = DM); final mode in .mrl field
-    const int fm = L.rd[c].mrl;
+  const int n_rd = uni(L.n_rd);
+  for (int c = wave; c < n_rd; c += NW) {
+    const int cm = uni(L.rd[c].mode);                 // chroma mode (70 = DM); final mode in .mrl field
+    const int fm = uni(L.rd[c].mrl);
     int16_t *recb = big ? (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + cur) * VXD_SLOT_ELEMS : &L.slot[wave][cur][0];
     int16_t *levb = recb + (big ? 4096 : 1024);
     { uint32_t *d = (uint32_t *) &L.wctx[wave]; const uint32_t *s = (const uint32_t *) &L.cur; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
@@ -982,9 +1093,29 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
       cost = rd_cost(p, cb.bits, dist);
       L.rd_cost[c] = cost; L.rd_dist[c] = dist; L.rd_cbf[c] = (uint8_t) ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 4 : 0));
     }
-    cost = __shfl(cost, 0);
+    cost = uni_d(__shfl(cost, 0));
     if (cost < wbest) { wbest = cost; if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = cur; } cur ^= 1; }
     wave_sync();
+  }
+  __syncthreads();
+  // winner; its CU-level bits are recomputed from the node's start contexts (EL/EncCu.cpp:2593-2619) by wave 0
+  int best = 0; double bc = MAX_DOUBLE;
+  for (int c = 0; c < n_rd; c++) { const double v = L.rd_cost[c]; if (v < bc) { bc = v; best = c; } }
+  best = uni(best);
+  const int ww = best % NW;
+  ctx_copy_all(&L.wctx[0], &L.cur);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int slot = L.wave_slot[ww];
+    const int16_t *levw = (big ? (const int16_t *) (scratch + VXD_OFF_SLOTS) + (ww * 2 + slot) * VXD_SLOT_ELEMS + 4096 : &L.slot[ww][slot][1024]);
+    const int cbfm = L.rd_cbf[best];
+    Cab cb; cb.c = &L.wctx[0]; cb.bits = 0;
+    enc_intra_chroma_pred_mode(cb, L.rd[best].mode);
+    enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
+    enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
+    if (cbfm & 2) residual_coding(cb, levw, w, h, 1);
+    if (cbfm & 4) residual_coding(cb, levw + P, w, h, 1);
+    L.win_idx = best; L.win_wave = ww; L.cu_bits = cb.bits;
   }
   __syncthreads();
 }
@@ -1034,6 +1165,7 @@ __device__ __noinline__ void op_save_intra(const VxParams &p, uint8_t *scratch, 
   VxUnit *su = (VxUnit *) (lvl + 2 * VXD_STORE_REC);
   const int ucw = (L.nw + 3) >> 2, uch = (L.nh + 3) >> 2;
   for (int i = threadIdx.x; i < ucw * uch; i += NT) su[(i / ucw) * 32 + (i % ucw)] = cu;
+  ctx_copy_all(ctx_ptr(scratch, CTX_BEST, d, 0), &L.wctx[0]);
   __threadfence_block();
   __syncthreads();
 }
@@ -1226,7 +1358,7 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
       }
     }
     case PH_A1_DONE: {                                  // EL/IntraSearch.cpp:489-623
-      const int numRd0 = VX_MODE_NUM_FAST_2D[(ilog2i(f.w) - 2) * 6 + (ilog2i(f.h) - 2)];
+      const int numRd0 = L.t.mode_num[(ilog2i(f.w) - 2) * 6 + (ilog2i(f.h) - 2)];
       S.numRd = numRd0; S.rdSize = 0;
       for (int c = 0; c < 35; c++) update_cand_list(L.cand[c], L.cand_cost[c], S.rdList, S.rdCost, S.rdSize, S.numRd);
       L.cnt[0] += (unsigned long long) L.n_cand;
@@ -1256,53 +1388,27 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
       f.phase = PH_B_DONE;
       post(OP_STAGE_B); return;
     }
-    case PH_B_DONE: {                                   // pick winner (strict <, list order), CU-level rate, xCheckBestMode
-      int best = -1; double bc = MAX_DOUBLE;
-      for (int c = 0; c < L.n_rd; c++) if (L.rd_cost[c] < bc) { bc = L.rd_cost[c]; best = c; }
+    case PH_B_DONE: {                                   // winner chosen by the operation; CU-level rate; xCheckBestMode
+      const int best = L.win_idx, ww = L.win_wave;
       L.cnt[1] += (unsigned long long) (ch ? 2 * L.n_rd : L.n_rd); L.cnt[2] += (unsigned long long) (ch ? 2 * L.n_rd * ((f.w >> 1) * (f.h >> 1)) : L.n_rd * f.w * f.h);
-      int ww = 0; for (int w2 = 0; w2 < NW; w2++) if (L.wave_best[w2] == best) ww = w2;
-      L.win_idx = best; L.win_wave = ww;
       L.op_a = L.wave_slot[ww];                         // slot of that wave holding the winner's reco / levels
       Sum &t = f.temp;
       t.dist = L.rd_dist[best];
-      Cab cb; cb.bits = 0;
       VxUnit &cu = L.cu;
-      if (!ch) {
-        cu.dir = L.rd[best].mode; cu.mrl = L.rd[best].mrl; cu.cbf = L.rd_cbf[best];
-        // luma CU: cu_pred_data + cu_residual == the stage-B syntax from the same start contexts
-        t.bits = L.rd_bits[best];
-        // end contexts of the winner were parked in scratch by its wave
-        const Ctx *keep = ctx_ptr(scratch, CTX_BEST, MAXD + ww, 0);
-        for (int i = 0; i < NCTX; i++) { L.wctx[0].s0[i] = keep->s0[i]; L.wctx[0].s1[i] = keep->s1[i]; }
-        cb.c = &L.wctx[0];
-      } else {
-        cu.dir = L.rd[best].mode; cu.mrl = 0; cu.cbf = L.rd_cbf[best];
-        // chroma CU: recompute from the start contexts (EL/EncCu.cpp:2593-2619)
-        for (int i = 0; i < NCTX; i++) { L.wctx[0].s0[i] = L.cur.s0[i]; L.wctx[0].s1[i] = L.cur.s1[i]; }
-        cb.c = &L.wctx[0];
-        const int P = (f.w >> 1) * (f.h >> 1);
-        const int big = 2 * P > 1024;
-        const int16_t *levb = (big ? (const int16_t *) (scratch + VXD_OFF_SLOTS) + (ww * 2 + L.op_a) * VXD_SLOT_ELEMS + 4096 : &L.slot[ww][L.op_a][1024]);
-        enc_intra_chroma_pred_mode(cb, cu.dir);
-        enc_bin(cb, (unsigned) !!(cu.cbf & 2), VX_CTX_QtCbf[1]);
-        enc_bin(cb, (unsigned) !!(cu.cbf & 4), VX_CTX_QtCbf[2] + !!(cu.cbf & 2));
-        if (cu.cbf & 2) residual_coding(cb, levb, f.w >> 1, f.h >> 1, 1);
-        if (cu.cbf & 4) residual_coding(cb, levb + P, f.w >> 1, f.h >> 1, 1);
-        t.bits = cb.bits;
-      }
-      cb.bits = 0;
+      cu.dir = L.rd[best].mode; cu.mrl = ch ? 0 : L.rd[best].mrl; cu.cbf = L.rd_cbf[best];
+      // cu_pred_data + cu_residual bits (EL/EncCu.cpp:2593-2619) and the CU's end contexts are left in cu_bits / wctx[0]
+      // by the operation (luma: identical to the stage-B syntax from the same start contexts)
+      t.bits = L.cu_bits;
+      Cab cb; cb.c = &L.wctx[0]; cb.bits = 0;
       enc_split_cu_mode(p, fd, cb, f, ch, tile, SPLIT_NONE);          // xEncodeDontSplit 5649-5662
       t.bits += cb.bits;
       t.cost = rd_cost(p, t.bits, t.dist);
       t.n_cu = 1; t.f_bt = t.l_bt = f.bt; t.f_cbf = cu.cbf != 0; t.f_w = t.l_w = (int16_t) (f.w >> sh); t.f_h = t.l_h = (int16_t) (f.h >> sh); t.max_qt = f.qt; t.valid = 1;
       if (use_mode_result(p, f, ch, ETM_INTRA, t)) {
         f.best = t; f.has_best = 1;
-        // ctxBest[d] ← wctx[0] (the CU's end contexts), store ← winner slot
-        Ctx *bs = ctx_ptr(scratch, CTX_BEST, d, 0);
-        for (int i = 0; i < NCTX; i++) { bs->s0[i] = L.wctx[0].s0[i]; bs->s1[i] = L.wctx[0].s1[i]; }
         f.phase = PH_ADVANCE;
         set_node(f, d);
-        post(OP_SAVE_INTRA); return;
+        post(OP_SAVE_INTRA); return;                    // store ← winner slot, ctxBest[d] ← wctx[0]
       }
       f.phase = PH_ADVANCE; break;
     }
@@ -1463,7 +1569,8 @@ __device__ void run_stream(const VxParams &p)
   uint8_t *scratch = p.scratch + (size_t) blockIdx.x * p.scratch_per_stream;
   Ctx *carry = (Ctx *) (p.stream_ctx + (size_t) (sd.frame * p.ntiles + sd.tile) * 2 * NCTX);
   const int tid = threadIdx.x;
-  if (tid == 0) { L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; }
+  if (tid == 0) { L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < 16; i++) L.prof[i] = 0; }
+  load_tables();
   ctx_copy_all(&L.cur, carry);
   __syncthreads();
   for (int t = 0; t < sd.n_tasks; t++) {
@@ -1482,13 +1589,25 @@ __device__ void run_stream(const VxParams &p)
       }
       if (ch == 1) ctx_copy_all(&L.cur, ctx_ptr(scratch, CTX_START, MAXD + NW, 0));     // EL/EncCu.cpp:521
       __syncthreads();
+      // NOTE: exactly one thread-0 section per iteration.  With two (`if (tid == 0)` at the head and at the tail)
+      // hipcc threads the "tid != 0" edges together and structurizes the result into an inner loop in which lanes
+      // 1..63 of wave 0 reach the next s_barrier while lane 0 is still parked outside it: the barrier then
+      // releases before the controller has run (observed: hang).  Keep thread-0 work in ONE block here.
+      int prev_op = 13; long long t_prev = STAMP();
       for (;;) {
-        if (tid == 0) control_step(p, fd, scratch);
+        if (tid == 0) {
+          const long long t0 = STAMP();
+          if (VVCX_STAMP) L.prof[prev_op] += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first)
+          control_step(p, fd, scratch);
+          t_prev = STAMP();
+          if (VVCX_STAMP) L.prof[0] += (unsigned long long) (t_prev - t0);
+        }
         __syncthreads();
-        const int op = L.op;
+        const int op = uni(L.op);
         if (op == OP_DONE) break;
+        prev_op = op;
         switch (op) {
-          case OP_LUMA_PREP: op_luma_prep<T>(p, fd); if (L.op_c) op_stage_a(p, scratch); break;
+          case OP_LUMA_PREP: op_luma_prep<T>(p, fd); if (uni(L.op_c)) op_stage_a(p, scratch); break;
           case OP_STAGE_A: op_stage_a(p, scratch); break;
           case OP_STAGE_B: op_stage_b(p, scratch); break;
           case OP_CHROMA_RD: op_chroma_rd<T>(p, fd, scratch); break;
@@ -1506,11 +1625,11 @@ __device__ void run_stream(const VxParams &p)
     // contexts back to the CTU start, then the estimator pass advances them (EL/EncCu.cpp:543, EL/EncSlice.cpp:1775-1776)
     ctx_copy_all(&L.cur, ctx_ptr(scratch, CTX_START, MAXD + NW, 0));
     __syncthreads();
-    if (tid == 0) { advance_ctx_ctu<T>(p, fd, sd.tile, ctu_x, ctu_y); p.results[sd.first_task + t] = res; }
+    if (tid == 0) { const long long t0 = STAMP(); advance_ctx_ctu<T>(p, fd, sd.tile, ctu_x, ctu_y); L.prof[12] += (unsigned long long) (STAMP() - t0); p.results[sd.first_task + t] = res; }
     __syncthreads();
   }
   ctx_copy_all(carry, &L.cur);
-  if (tid == 0) for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]);
+  if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); for (int i = 0; i < 16; i++) atomicAdd(&p.counters[4 + i], L.prof[i]); }
 }
 
 extern "C" __global__ void __launch_bounds__(NT) vvcx_compress_kernel_u8(VxParams p) { run_stream<uint8_t>(p); }

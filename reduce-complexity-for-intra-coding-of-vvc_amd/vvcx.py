@@ -62,6 +62,7 @@ def load_library(lib_path=None):
     L.vvcx_last_kernel_ms.restype = C.c_float
     L.vvcx_last_kernel_ms.argtypes = [C.c_void_p]
     L.vvcx_get_counters.argtypes = [C.c_void_p, C.c_void_p]
+    L.vvcx_get_profile.argtypes = [C.c_void_p, C.c_void_p]
     L.vvcx_last_error.restype = C.c_char_p
     L.vvcx_ctus_per_frame.argtypes = [C.c_void_p]
     _libs[path] = L
@@ -144,6 +145,11 @@ class VvcxEncoder:
 
     def last_kernel_ms(self):
         return float(self.L.vvcx_last_kernel_ms(self.h))
+
+    def profile(self):
+        c = np.zeros(16, np.uint64)
+        self._chk(self.L.vvcx_get_profile(self.h, c.ctypes.data))
+        return c
 
     def counters(self):
         c = np.zeros(4, np.uint64)

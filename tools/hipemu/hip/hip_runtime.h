@@ -67,6 +67,9 @@ inline void __threadfence() {}
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); }
 template <typename T> inline T __shfl_xor(T v, int mask) { return hipemu::shfl_idx(v, (int) ((hipemu::g_cur->tidx.x & 63) ^ (unsigned) mask)); }
 template <typename T> inline T __shfl(T v, int src) { return hipemu::shfl_idx(v, src); }
+inline long long clock64() { return 0; }
+inline long long wall_clock64() { return 0; }
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned) v); }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
 
