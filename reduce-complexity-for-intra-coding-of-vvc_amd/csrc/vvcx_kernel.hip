@@ -58,6 +58,7 @@ struct Frame {                     // one recursion level: partitioner level + C
   uint8_t impl_checked, impl_split, nmodes, did_h, did_v, did_q, do_th, do_tv;
   uint8_t qt_before_bt, max_qt_sub, has_best, cur_mode, cur_split, child, nparts, first;
   uint8_t modes[8];
+  uint8_t nb_ok, nbL_lh, nbL_qt, nbA_lw, nbA_qt;   // left / above CU of the node (bit0 left, bit1 above present)
   int16_t px[4], py[4], pw[4], ph[4];
   uint64_t ss;
   double max_cost;
@@ -224,34 +225,62 @@ __device__ int tmpl_abs_sum(const Cctx &c, const int16_t *coeff, int blk, int ba
   return imax(imin(sum - 5 * base, 31), 0);
 }
 // EL/CABACWriter.cpp residual_coding 3773-3883, last_sig_coeff 4102-4160, residual_coding_subblock 4164-4304
-// (regular residual, DepQuant off, sign hiding off).  Executed by ONE lane; coefficient tile stride = w.
-__device__ __noinline__ void residual_coding(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma)
+// (regular residual, DepQuant off, sign hiding off).  Coefficient tile stride = w.
+// Split in two: a pre-pass that builds the scan table (CL/Rom.cpp:87-370) and finds the last significant scan
+// position and the significant coefficient groups (3823-3835) — data parallel, done by all lanes of the calling wave
+// when PAR — and the context-coded part, which is a serial chain through the adaptive models (lane 0).
+struct RcPre { int last; unsigned long long sig_groups; };
+__device__ inline void diag_walk(int bw, int bh, int n, int &ox, int &oy)
+{
+  int line = 0, col = 0;
+  for (int i = 0; i < n; i++) {
+    if (col == bw - 1 || line == 0) { line += col + 1; col = 0; if (line >= bh) { col += line - (bh - 1); line = bh - 1; } }
+    else { col++; line--; }
+  }
+  ox = col; oy = line;
+}
+template <bool PAR>
+__device__ __noinline__ RcPre rc_prepass(const int16_t *coeff, int w, int h, uint16_t *scan, int lane)
+{
+  w = uni(w); h = uni(h);
+  int lcw, lch; cg_shape(w, h, lcw, lch);
+  const int lcg = lcw + lch, cw = 1 << lcw, chh = 1 << lch, cgSize = 1 << lcg;
+  const int zw = imin(32, w), zh = imin(32, h), wg = zw >> lcw, hg = zh >> lch, ngroups = wg * hg, nscan = zw * zh;
+  uint8_t *ix = L.scan_tab[threadIdx.x >> 6], *iy = ix + 16, *gxs = ix + 32, *gys = ix + 96;
+  const int l0 = PAR ? lane : 0, ls = PAR ? 64 : 1;
+  for (int n = l0; n < cgSize; n += ls) { int x, y; diag_walk(cw, chh, n, x, y); ix[n] = (uint8_t) x; iy[n] = (uint8_t) y; }
+  for (int n = l0; n < ngroups; n += ls) { int x, y; diag_walk(wg, hg, n, x, y); gxs[n] = (uint8_t) x; gys[n] = (uint8_t) y; }
+  if (PAR) wave_sync();
+  int last = -1; unsigned lo = 0, hi = 0;
+  for (int sp = l0; sp < nscan; sp += ls) {
+    const int g = sp >> lcg, i = sp & (cgSize - 1);
+    const int blk = ((int) gys[g] * chh + iy[i]) * w + (int) gxs[g] * cw + ix[i];
+    scan[sp] = (uint16_t) blk;
+    if (coeff[blk]) { last = sp; if (g < 32) lo |= 1u << g; else hi |= 1u << (g - 32); }
+  }
+  if (PAR) {
+    for (int m = 32; m >= 1; m >>= 1) { const int a = __shfl_xor(last, m); const unsigned b = __shfl_xor(lo, m), c = __shfl_xor(hi, m); last = imax(last, a); lo |= b; hi |= c; }
+    wave_sync();
+  }
+  RcPre r; r.last = last; r.sig_groups = ((unsigned long long) hi << 32) | lo;
+  return r;
+}
+__device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, const uint16_t *scan, RcPre pre)
 {
   Cctx c; c.w = w; c.h = h; c.ch = is_chroma; c.tmpl_diag = -1; c.tmpl_sum1 = -1;
   int lcw, lch; cg_shape(w, h, lcw, lch);
-  const int lcg = lcw + lch, cw = 1 << lcw, chh = 1 << lch;
+  const int lcg = lcw + lch, cgSize = 1 << lcg;
   const int zw = imin(32, w), zh = imin(32, h), wg = zw >> lcw, hg = zh >> lch;
-  const int ngroups = wg * hg, cgSize = 1 << lcg;
-  // inner scan of a coefficient group (<= 16 positions) and CG scan (<= 64 groups)
-  uint8_t *ix = L.scan_tab[threadIdx.x >> 6], *iy = ix + 16, *gxs = ix + 32, *gys = ix + 96;
-  { int line = 0, col = 0;
-    for (int n = 0; n < cgSize; n++) { ix[n] = (uint8_t) col; iy[n] = (uint8_t) line;
-      if (col == cw - 1 || line == 0) { line += col + 1; col = 0; if (line >= chh) { col += line - (chh - 1); line = chh - 1; } } else { col++; line--; } } }
-  { int line = 0, col = 0;
-    for (int n = 0; n < ngroups; n++) { gxs[n] = (uint8_t) col; gys[n] = (uint8_t) line;
-      if (col == wg - 1 || line == 0) { line += col + 1; col = 0; if (line >= hg) { col += line - (hg - 1); line = hg - 1; } } else { col++; line--; } } }
-#define BLK(sp) (((int) gys[(sp) >> lcg] * chh + iy[(sp) & (cgSize - 1)]) * w + (int) gxs[(sp) >> lcg] * cw + ix[(sp) & (cgSize - 1)])
-  const int nscan = zw * zh;
-  int scanPosLast = -1;
-  unsigned long long sigGroups = 0;      // by scan CG index
-  for (int sp = 0; sp < nscan; sp++) if (coeff[BLK(sp)]) { scanPosLast = sp; sigGroups |= 1ull << (sp >> lcg); }
+  const uint8_t *gxs = L.scan_tab[threadIdx.x >> 6] + 32, *gys = gxs + 64;
+  const int scanPosLast = pre.last;
+  const unsigned long long sigGroups = pre.sig_groups;
   if (scanPosLast < 0) return;
   const int l2w = ilog2i(w), l2h = ilog2i(h);
   int offx = 0, offy = 0, shx, shy;
   if (is_chroma) { shx = imin(2, w >> 3); shy = imin(2, h >> 3); }
   else { offx = L.t.last_prefix[l2w]; offy = L.t.last_prefix[l2h]; shx = (l2w + 1) >> 2; shy = (l2h + 1) >> 2; }
   {
-    const int blk = BLK(scanPosLast);
+    const int blk = scan[scanPosLast];
     const int posY = blk / w, posX = blk - posY * w;
     const int gx = L.t.group_idx[posX], gy = L.t.group_idx[posY];
     const int maxX = L.t.group_idx[zw - 1], maxY = L.t.group_idx[zh - 1];
@@ -282,7 +311,7 @@ __device__ __noinline__ void residual_coding(Cab &cb, const int16_t *coeff, int 
     const int inferSigPos = nextSigPos != scanPosLast ? (isNotFirst ? minSub : -1) : nextSigPos;
     int numNonZero = 0, remRegBins = regBins;
     for (; nextSigPos >= minSub && remRegBins >= 4; nextSigPos--) {
-      const int blk = BLK(nextSigPos);
+      const int blk = scan[nextSigPos];
       const int cf = coeff[blk];
       const unsigned sigFlag = cf != 0;
       if (numNonZero || nextSigPos != inferSigPos) { const int ctx = sig_ctx(c, coeff, blk); enc_bin(cb, sigFlag, ctx); remRegBins--; }
@@ -307,12 +336,12 @@ __device__ __noinline__ void residual_coding(Cab &cb, const int16_t *coeff, int 
     const int firstPosMode2 = nextSigPos;
     regBins = remRegBins;
     for (int sp = firstSigPos; sp > firstPosMode2; sp--) {
-      const int blk = BLK(sp);
+      const int blk = scan[sp];
       const unsigned a = (unsigned) iabs(coeff[blk]);
       if (a >= 4) enc_rem_abs(cb, (a - 4) >> 1, L.t.gorice_pars[tmpl_abs_sum(c, coeff, blk, 4)]);
     }
     for (int sp = firstPosMode2; sp >= minSub; sp--) {
-      const int blk = BLK(sp);
+      const int blk = scan[sp];
       const unsigned a = (unsigned) iabs(coeff[blk]);
       const int sumAll = tmpl_abs_sum(c, coeff, blk, 0);
       const unsigned rice = L.t.gorice_pars[sumAll], pos0 = L.t.gorice_pos0[sumAll];
@@ -321,7 +350,17 @@ __device__ __noinline__ void residual_coding(Cab &cb, const int16_t *coeff, int 
     }
     enc_ep(cb, numNonZero);
   }
-#undef BLK
+}
+// single-lane form (controller / estimator pass) and wave form (lane 0 owns cb)
+__device__ void residual_coding(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, uint16_t *scan)
+{
+  const RcPre pre = rc_prepass<false>(coeff, w, h, scan, 0);
+  rc_serial(cb, coeff, w, h, is_chroma, scan, pre);
+}
+__device__ void residual_coding_wave(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, uint16_t *scan, int lane)
+{
+  const RcPre pre = rc_prepass<true>(coeff, w, h, scan, lane);
+  if (lane == 0) rc_serial(cb, coeff, w, h, is_chroma, scan, pre);
 }
 
 // ------------------------------------------------------------------------------------------------ partitioner (thread 0)
@@ -384,13 +423,23 @@ __device__ const VxUnit *get_cu(const VxParams &p, const VxFrameDev &fd, int ch,
   const VxUnit *u = &fd.units[ch][(py >> ul) * p.uw + (px >> ul)];
   return u->tag == (uint16_t) (tile + 1) ? u : nullptr;
 }
+// the node's left / above neighbour CUs never change while the node is processed: fetch them once
+__device__ void fetch_neighbours(const VxParams &p, const VxFrameDev &fd, Frame &f, int ch, int tile)
+{
+  const int sh = ch ? 1 : 0;
+  const VxUnit *cuL = get_cu(p, fd, ch, (f.x >> sh) - 1, f.y >> sh, tile), *cuA = get_cu(p, fd, ch, f.x >> sh, (f.y >> sh) - 1, tile);
+  f.nb_ok = (uint8_t) ((cuL ? 1 : 0) | (cuA ? 2 : 0));
+  if (cuL) { f.nbL_lh = cuL->lh; f.nbL_qt = cuL->qt; }
+  if (cuA) { f.nbA_lw = cuA->lw; f.nbA_qt = cuA->qt; }
+}
 // DeriveCtx::CtxSplit (CL/ContextModelling.cpp:154-250) + CABACWriter::split_cu_mode (EL/CABACWriter.cpp:1010-1069)
 __device__ __noinline__ void enc_split_cu_mode(const VxParams &p, const VxFrameDev &fd, Cab &cb, Frame &f, int ch, int tile, int split)
 {
   int can[6]; can_split(p, f, ch, can);
   const int sh = ch ? 1 : 0;
-  const int bx = f.x >> sh, by = f.y >> sh, bw = f.w >> sh, bh = f.h >> sh;
-  const VxUnit *cuL = get_cu(p, fd, ch, bx - 1, by, tile), *cuA = get_cu(p, fd, ch, bx, by - 1, tile);
+  const int bw = f.w >> sh, bh = f.h >> sh;
+  struct Nb { int lh, lw, qt; } nl = { f.nbL_lh, 0, f.nbL_qt }, na = { 0, f.nbA_lw, f.nbA_qt };
+  const Nb *cuL = (f.nb_ok & 1) ? &nl : nullptr, *cuA = (f.nb_ok & 2) ? &na : nullptr;
   unsigned ctxSpl = 0;
   if (cuL) ctxSpl += ((1 << cuL->lh) < bh) ? 1 : 0;
   if (cuA) ctxSpl += ((1 << cuA->lw) < bw) ? 1 : 0;
@@ -982,6 +1031,28 @@ __device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
     wave_sync();
   }
   __syncthreads();
+  // updateCandList (CL/UnitTools.h:261-306) over a stream of candidates keeps the numRd cheapest with ties to the
+  // earlier-inserted one = a stable selection.  Done in parallel: every candidate computes its rank.
+  // Insertion order of the reference: 35 modes [0,35), then the +-1 refinements [n1, n2), then the MRL candidates [35, n1).
+  {
+    const int n1 = uni(L.n_cand), n2 = c_end, numRd = uni(L.S.numRd);
+    const int first_phase = uni(L.op_c);
+    const int n = first_phase ? 35 : n2;
+    const int c = threadIdx.x;
+    if (c < n) {
+      const double mine = L.cand_cost[c];
+      const int myseq = c < 35 ? c : (c < n1 ? 1000 + c : 500 + c);
+      int rank = 0;
+      for (int j = 0; j < n; j++) {
+        const double v = L.cand_cost[j];
+        const int sj = j < 35 ? j : (j < n1 ? 1000 + j : 500 + j);
+        rank += (v < mine) || (v == mine && sj < myseq);
+      }
+      if (rank < numRd) { L.S.rdList[rank] = L.cand[c]; L.S.rdCost[rank] = mine; }
+    }
+    if (c == 0) L.S.rdSize = imin(numRd, n);
+  }
+  __syncthreads();
 }
 
 // OP_STAGE_B: full RD of L.rd[0..n_rd) (EL/IntraSearch.cpp:1158-1358 → xRecurIntraCodingLumaQT → xIntraCodingTUBlock)
@@ -1008,11 +1079,13 @@ __device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
     { uint32_t *d = (uint32_t *) &L.wctx[wave]; const uint32_t *s = (const uint32_t *) &L.cur; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     wave_sync();
     double cost = 0;
+    Cab cb; cb.c = &L.wctx[wave]; cb.bits = 0;
     if (lane == 0) {
-      Cab cb; cb.c = &L.wctx[wave]; cb.bits = 0;
       enc_intra_luma_pred_mode(cb, L.ny, mode, mrl);
       enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[0]);
-      if (cbf) residual_coding(cb, lev, w, h, 0);
+    }
+    if (uni(cbf)) residual_coding_wave(cb, lev, w, h, 0, (uint16_t *) L.tmp[wave], lane);
+    if (lane == 0) {
       cost = rd_cost(p, cb.bits, sse);
       L.rd_cost[c] = cost; L.rd_dist[c] = sse; L.rd_bits[c] = cb.bits; L.rd_cbf[c] = (uint8_t) cbf;
     }
@@ -1075,23 +1148,27 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
       wave_code_block(L.org + k * P, rec, lev, L.tmp[wave], w, h, bd, p.qp_c[k], lane, sse, cbf);
       cbfs[k] = cbf;
       dist += (unsigned long long) (p.dist_weight[k] * (double) sse);             // CL/RdCost.cpp:405-408
-      if (lane == 0) {     // xGetIntraFracBitsQTChroma 2625-2692: contexts advance
+      {                    // xGetIntraFracBitsQTChroma 2625-2692: contexts advance
         Cab cb; cb.c = &L.wctx[wave]; cb.bits = 0;
-        enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[k + 1] + (k == 1 ? cbfs[0] : 0));
-        if (cbf) residual_coding(cb, lev, w, h, 1);
+        if (lane == 0) enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[k + 1] + (k == 1 ? cbfs[0] : 0));
+        if (uni(cbf)) residual_coding_wave(cb, lev, w, h, 1, (uint16_t *) L.tmp[wave], lane);
       }
       wave_sync();
     }
     double cost = 0;
-    if (lane == 0) {       // 1611-1621: contexts not reset; xGetIntraFracBitsQT(chroma)
+    {                      // 1611-1621: contexts not reset; xGetIntraFracBitsQT(chroma)
       Cab cb; cb.c = &L.wctx[wave]; cb.bits = 0;
-      enc_intra_chroma_pred_mode(cb, cm);
-      enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]);
-      enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]);
-      if (cbfs[0]) residual_coding(cb, levb, w, h, 1);
-      if (cbfs[1]) residual_coding(cb, levb + P, w, h, 1);
-      cost = rd_cost(p, cb.bits, dist);
-      L.rd_cost[c] = cost; L.rd_dist[c] = dist; L.rd_cbf[c] = (uint8_t) ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 4 : 0));
+      if (lane == 0) {
+        enc_intra_chroma_pred_mode(cb, cm);
+        enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]);
+        enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]);
+      }
+      if (uni(cbfs[0])) residual_coding_wave(cb, levb, w, h, 1, (uint16_t *) L.tmp[wave], lane);
+      if (uni(cbfs[1])) residual_coding_wave(cb, levb + P, w, h, 1, (uint16_t *) L.tmp[wave], lane);
+      if (lane == 0) {
+        cost = rd_cost(p, cb.bits, dist);
+        L.rd_cost[c] = cost; L.rd_dist[c] = dist; L.rd_cbf[c] = (uint8_t) ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 4 : 0));
+      }
     }
     cost = uni_d(__shfl(cost, 0));
     if (cost < wbest) { wbest = cost; if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = cur; } cur ^= 1; }
@@ -1105,17 +1182,19 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
   const int ww = best % NW;
   ctx_copy_all(&L.wctx[0], &L.cur);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int slot = L.wave_slot[ww];
+  if (wave == 0) {
+    const int slot = uni(L.wave_slot[ww]);
     const int16_t *levw = (big ? (const int16_t *) (scratch + VXD_OFF_SLOTS) + (ww * 2 + slot) * VXD_SLOT_ELEMS + 4096 : &L.slot[ww][slot][1024]);
-    const int cbfm = L.rd_cbf[best];
+    const int cbfm = uni(L.rd_cbf[best]);
     Cab cb; cb.c = &L.wctx[0]; cb.bits = 0;
-    enc_intra_chroma_pred_mode(cb, L.rd[best].mode);
-    enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
-    enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
-    if (cbfm & 2) residual_coding(cb, levw, w, h, 1);
-    if (cbfm & 4) residual_coding(cb, levw + P, w, h, 1);
-    L.win_idx = best; L.win_wave = ww; L.cu_bits = cb.bits;
+    if (lane == 0) {
+      enc_intra_chroma_pred_mode(cb, L.rd[best].mode);
+      enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
+      enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
+    }
+    if (cbfm & 2) residual_coding_wave(cb, levw, w, h, 1, (uint16_t *) L.tmp[0], lane);
+    if (cbfm & 4) residual_coding_wave(cb, levw + P, w, h, 1, (uint16_t *) L.tmp[0], lane);
+    if (lane == 0) { L.win_idx = best; L.win_wave = ww; L.cu_bits = cb.bits; }
   }
   __syncthreads();
 }
@@ -1234,9 +1313,9 @@ __device__ int next_mode(const VxParams &p, Frame &f, int ch)
 }
 __device__ __noinline__ void init_cu_level(const VxParams &p, const VxFrameDev &fd, Frame &f, int ch, int tile)       // initCULevel 1203-1549
 {
-  const int sh = ch ? 1 : 0;
-  const VxUnit *cuL = get_cu(p, fd, ch, (f.x >> sh) - 1, f.y >> sh, tile), *cuA = get_cu(p, fd, ch, f.x >> sh, (f.y >> sh) - 1, tile);
-  f.qt_before_bt = (uint8_t) (((cuL && cuA && cuL->qt > f.qt && cuA->qt > f.qt) || (cuL && !cuA && cuL->qt > f.qt) || (!cuL && cuA && cuA->qt > f.qt)
+  fetch_neighbours(p, fd, f, ch, tile);
+  const int cuL = f.nb_ok & 1, cuA = f.nb_ok & 2, lq = f.nbL_qt, aq = f.nbA_qt;
+  f.qt_before_bt = (uint8_t) (((cuL && cuA && lq > f.qt && aq > f.qt) || (cuL && !cuA && lq > f.qt) || (!cuL && cuA && aq > f.qt)
                    || (!cuA && !cuL && f.w >= 32)) && (f.w > (p.min_qt[ch] << 1)));
   f.do_th = f.do_tv = 1; f.did_h = f.did_v = f.did_q = 0; f.max_qt_sub = 0; f.has_best = 0; f.nmodes = 0;
   if (!f.qt_before_bt) f.modes[f.nmodes++] = ETM_SPLIT_QT;
@@ -1315,6 +1394,7 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
           if ((f.y & 127) != 0 && (p.tools & 1))
             for (int r = 1; r < 3; r++) for (int k = 1; k < 6; k++) { L.cand[n].mode = (uint8_t) L.mpm[k]; L.cand[n].mrl = (uint8_t) (r == 1 ? 1 : 3); n++; }
           L.n_cand = n;
+          S.numRd = L.t.mode_num[(ilog2i(f.w) - 2) * 6 + (ilog2i(f.h) - 2)];
           f.phase = PH_A1_DONE;
           L.op_a = 0; L.op_b = n; L.op_c = 1; post(OP_LUMA_PREP); return;      // prep, then stage A on [0,n)
         } else {
@@ -1357,27 +1437,19 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
         post(OP_CLEAR_UNITS); return;          // tempCS->initStructData: nothing of this node is coded yet
       }
     }
-    case PH_A1_DONE: {                                  // EL/IntraSearch.cpp:489-623
-      const int numRd0 = L.t.mode_num[(ilog2i(f.w) - 2) * 6 + (ilog2i(f.h) - 2)];
-      S.numRd = numRd0; S.rdSize = 0;
-      for (int c = 0; c < 35; c++) update_cand_list(L.cand[c], L.cand_cost[c], S.rdList, S.rdCost, S.rdSize, S.numRd);
+    case PH_A1_DONE: {                                  // EL/IntraSearch.cpp:489-623; the top-numRd list was selected by the operation
       L.cnt[0] += (unsigned long long) L.n_cand;
       int n = L.n_cand; S.n_a2 = 0;
-      for (int i = 0; i < S.numRd; i++) {
+      for (int i = 0; i < S.numRd; i++) {                 // +-1 of the survivors, from a snapshot of the list (parentCandList 574)
         const int pm = S.rdList[i].mode;
         if (pm > (DC + 1) && pm < 66)
-          for (int s = -1; s <= 1; s += 2) { const int m = pm + s; if (!S.checked[m]) { S.checked[m] = 1; L.cand[n].mode = (uint8_t) m; L.cand[n].mrl = 0; n++; S.n_a2++; } }
+          for (int s2 = -1; s2 <= 1; s2 += 2) { const int m = pm + s2; if (!S.checked[m]) { S.checked[m] = 1; L.cand[n].mode = (uint8_t) m; L.cand[n].mrl = 0; n++; S.n_a2++; } }
       }
-      // NOTE: the reference derives the ±1 candidates from a snapshot of the list (parentCandList 574) ✓ (list not yet modified here)
       f.phase = PH_A2_DONE;
-      if (S.n_a2 > 0) { L.op_a = L.n_cand; L.op_b = n; L.op_c = 0; post(OP_STAGE_A); return; }
-      break;
+      L.op_a = L.n_cand; L.op_b = n; L.op_c = 0; post(OP_STAGE_A); return;     // evaluates [n1, n) (possibly empty) and makes the final selection
     }
-    case PH_A2_DONE: {                                  // 577-682 inserts, 777-802 MPM append, then stage B
-      const int n1 = L.n_cand;
-      for (int c = n1; c < n1 + S.n_a2; c++) update_cand_list(L.cand[c], L.cand_cost[c], S.rdList, S.rdCost, S.rdSize, S.numRd);
+    case PH_A2_DONE: {                                  // 777-802 MPM append, then stage B
       L.cnt[0] += (unsigned long long) S.n_a2;
-      for (int c = 35; c < n1; c++) update_cand_list(L.cand[c], L.cand_cost[c], S.rdList, S.rdCost, S.rdSize, S.numRd);
       for (int j = 0; j < L.mpm_n; j++) {
         int incl = 0;
         for (int i = 0; i < S.numRd; i++) incl |= (S.rdList[i].mode == L.mpm[j] && S.rdList[i].mrl == 0);
@@ -1492,6 +1564,7 @@ __device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, 
       const VxUnit *u = &fd.units[ch][(f.y >> 2) * p.uw + (f.x >> 2)];
       const int split = (int) ((u->ss >> (f.depth * 5)) & 31);
       f.impl_checked = 0;
+      fetch_neighbours(p, fd, f, ch, tile);
       enc_split_cu_mode(p, fd, cb, f, ch, tile, split);
       if (!split) {
         const int sh = ch ? 1 : 0, W = f.w >> sh, H = f.h >> sh;
@@ -1502,14 +1575,14 @@ __device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, 
           derive_mpms(Ld, Ad, L.mpm);
           enc_intra_luma_pred_mode(cb, f.y, u->dir, u->mrl);
           enc_bin(cb, u->cbf & 1, VX_CTX_QtCbf[0]);
-          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; residual_coding(cb, lv, W, H, 0); }
+          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; residual_coding(cb, lv, W, H, 0, (uint16_t *) L.tmp[1]); }
         } else {
           enc_intra_chroma_pred_mode(cb, u->dir);
           enc_bin(cb, (unsigned) !!(u->cbf & 2), VX_CTX_QtCbf[1]);
           enc_bin(cb, (unsigned) !!(u->cbf & 4), VX_CTX_QtCbf[2] + !!(u->cbf & 2));
           for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c)) {
             for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[c][((f.y >> 1) + yy) * fd.lstride[c] + (f.x >> 1) + xx];
-            residual_coding(cb, lv, W, H, 1);
+            residual_coding(cb, lv, W, H, 1, (uint16_t *) L.tmp[1]);
           }
         }
         top--; continue;
