@@ -3,8 +3,8 @@
 #pragma once
 #include <stdint.h>
 
-#define VXD_NT 256          // threads per workgroup = one CTU stream
-#define VXD_NW 4            // wavefronts (64 lanes) per workgroup
+#define VXD_NT 512          // threads per workgroup = one CTU stream
+#define VXD_NW 8            // wavefronts (64 lanes) per workgroup
 #define VXD_MAXD 14         // recursion levels kept in LDS
 #define VXD_NUM_CTX 386     // flat context array, same indexing as the reference's ContextSetCfg
 
@@ -59,4 +59,5 @@ struct VxParams {
 #define VXD_OFF_CTX     (VXD_OFF_STORE + VXD_MAXD * VXD_STORE_LEVEL)          // [MAXD + NW + 1][2] snapshots {start, best}: levels, per-wave parking, CTU start
 #define VXD_OFF_SLOTS   (VXD_OFF_CTX + (VXD_MAXD + VXD_NW + 1) * 2 * VXD_CTXSNAP) // big-block slots: [NW][2][2*4096] int16
 #define VXD_SLOT_ELEMS  (2 * 4096)
-#define VXD_SCRATCH_BYTES (VXD_OFF_SLOTS + VXD_NW * 2 * VXD_SLOT_ELEMS * 2)
+#define VXD_OFF_TMP     (VXD_OFF_SLOTS + VXD_NW * 2 * VXD_SLOT_ELEMS * 2)             // big-block transform scratch: [NW][2048] int32
+#define VXD_SCRATCH_BYTES (VXD_OFF_TMP + VXD_NW * 2048 * 4)

@@ -89,10 +89,11 @@ struct Lds {
   Ctx wctx[NW];                    // per-wave working copies
   Ctx wpark[NW];                   // end-of-candidate contexts of each wave's best full-RD candidate
   int16_t org[4096];               // node's original tile: luma w*h, or Cb | Cr (cw*ch each)
+  int acc[NW][4][2];               // small-block SATD stage: per packed candidate {SAD, SATD}
   uint8_t scan_tab[NW][160];       // per-wave scratch of residual_coding: CG inner scan x/y (16+16) and CG scan x/y (64+64)
   int16_t refs[4][2][140];         // luma: set 0 mrl0 unfiltered, 1 mrl0 filtered, 2 mrl1, 3 mrl3; chroma: set 0 Cb, 1 Cr. [0]=top [1]=left
-  int32_t tmp[NW][2048];           // per-wave transform scratch / Hadamard scratch
-  int16_t slot[NW][2][2048];       // per-wave candidate slots (T = being evaluated, B = wave best): rec | lev
+  int32_t tmp[NW][1024];           // per-wave transform / Hadamard / scan scratch (blocks needing more use HBM scratch)
+  int16_t slot[NW][2048];          // per-wave candidate slot 0: rec[1024] | lev[1024] (slot 1 and big blocks live in HBM scratch)
   uint8_t flags[72]; int8_t src_unit[72];
   Frame fr[MAXD];
   // posted operation
@@ -964,10 +965,14 @@ __device__ __noinline__ void wave_code_block(const int16_t *org, int16_t *rec, i
 }
 
 // ------------------------------------------------------------------------------------------------ parallel operations
-__device__ inline int16_t *slot_rec(uint8_t *scratch, int P, int wave, int which)
-{ return P <= 1024 ? &L.slot[wave][which][0] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS; }
-__device__ inline int16_t *slot_lev(uint8_t *scratch, int P, int wave, int which)
-{ return P <= 1024 ? &L.slot[wave][which][1024] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS + 4096; }
+// candidate slots: nrec = reconstruction samples held (w*h luma, 2*cw*ch chroma).  Slot 0 of blocks up to 1024 samples is
+// in LDS; slot 1 (only used when a wave evaluates more than one full-RD candidate) and bigger blocks are in HBM scratch.
+__device__ inline int16_t *slot_rec(uint8_t *scratch, int nrec, int wave, int which)
+{ return (nrec <= 1024 && which == 0) ? &L.slot[wave][0] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS; }
+__device__ inline int16_t *slot_lev(uint8_t *scratch, int nrec, int wave, int which)
+{ return (nrec <= 1024 && which == 0) ? &L.slot[wave][1024] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS + 4096; }
+__device__ inline int32_t *wave_tmp(uint8_t *scratch, int n_i32, int wave)
+{ return n_i32 <= 1024 ? L.tmp[wave] : (int32_t *) (scratch + VXD_OFF_TMP) + wave * 2048; }
 
 __device__ void ctx_copy_all(Ctx *dst, const Ctx *src)
 {
@@ -1000,14 +1005,80 @@ __device__ __noinline__ void op_luma_prep(const VxParams &p, const VxFrameDev &f
 }
 __device__ inline int luma_set(int mrl, int filt) { return mrl == 0 ? (filt ? 1 : 0) : (mrl == 1 ? 2 : 3); }
 
+// SATD stage for blocks of at most 32 samples (4x4, 8x4, 4x8): the block is exactly one Hadamard tile, so 64/P
+// candidates are packed into one wavefront (one lane per predicted sample of one candidate).
+template <int BW, int BH>
+__device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin, int c_end)
+{
+  constexpr int P = BW * BH, G = 64 / P;
+  const int sub = lane / P, pl = lane - sub * P;
+  const int py = pl / BW, px = pl - py * BW;
+  int16_t *pred = &L.slot[wave][0];
+  int16_t *scr = (int16_t *) L.tmp[wave];
+  const int bd = p.bit_depth;
+  for (int c0 = c_begin + wave * G; c0 < c_end; c0 += NW * G) {
+    const int c = c0 + sub;
+    const bool valid = c < c_end;
+    const int mode = valid ? L.cand[c].mode : 0, mrl = valid ? L.cand[c].mrl : 0;
+    Ipa ip; init_pred_params(BW, BH, 1, mode, mrl, ip);
+    const int set = luma_set(mrl, ip.ref_filter);
+    pred[lane] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], BW, BH, px, py, ip, mode, 1, bd, L.dc_val[luma_set(mrl, 0)]);
+    wave_sync();
+    int sad = 0;
+    if (lane < G * BH) {                                 // one row of one candidate per lane
+      const int sr = lane / BH, r = lane - sr * BH;
+      int v[BW];
+#pragma unroll
+      for (int i = 0; i < BW; i++) { v[i] = L.org[r * BW + i] - pred[sr * P + r * BW + i]; sad += iabs(v[i]); }
+      had1d<BW>(v);
+#pragma unroll
+      for (int i = 0; i < BW; i++) scr[sr * P + r * BW + i] = (int16_t) v[i];
+    }
+#pragma unroll
+    for (int m = 1; m < BH; m <<= 1) sad += __shfl_xor(sad, m);
+    wave_sync();
+    int s = 0;
+    if (lane < G * BW) {                                 // one column of one candidate per lane
+      const int sc = lane / BW, i = lane - sc * BW;
+      int v[BH];
+#pragma unroll
+      for (int r = 0; r < BH; r++) v[r] = scr[sc * P + r * BW + i];
+      had1d<BH>(v);
+#pragma unroll
+      for (int r = 0; r < BH; r++) s += iabs(v[r]);
+    }
+#pragma unroll
+    for (int m = 1; m < BW; m <<= 1) s += __shfl_xor(s, m);
+    if (lane < G * BH && (lane % BH) == 0) L.acc[wave][lane / BH][0] = sad;
+    if (lane < G * BW && (lane % BW) == 0)
+      L.acc[wave][lane / BW][1] = (BW == 4 && BH == 4) ? (s + 1) >> 1 : (int) ((double) s / 0x1.6a09e667f3bcdp+2 * 2);   // CL/RdCost.cpp:2209,2662,2741
+    wave_sync();
+    if (lane < G && c0 + lane < c_end) {
+      const int cc = c0 + lane;
+      const unsigned long long sd = (unsigned long long) (unsigned) L.acc[wave][lane][0], st = (unsigned long long) (unsigned) L.acc[wave][lane][1];
+      const unsigned long long msh = sd * 2 < st ? sd * 2 : st;
+      const unsigned long long mbits = luma_mode_bits(L.cur, L.ny, L.cand[cc].mode, L.cand[cc].mrl);
+      const double a = (double) mbits * p.sqrt_lambda_fp;
+      L.cand_cost[cc] = (double) msh + a;
+      L.cand_had[cc] = (double) msh;
+    }
+    wave_sync();
+  }
+}
+
 // OP_STAGE_A: SATD-stage cost of every candidate in L.cand[op_a .. op_b) (EL/IntraSearch.cpp:489-682), one wave per candidate
 __device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
 {
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int w = uni(L.nw), h = uni(L.nh), P = w * h, bd = p.bit_depth;
   int16_t *pred = slot_rec(scratch, P, wave, 0);
-  int16_t *scr = (int16_t *) L.tmp[wave];
+  int16_t *scr = (int16_t *) wave_tmp(scratch, P >> 1, wave);
   const int c_end = uni(L.op_b);
+  if (P <= 32) {
+    if (w == 4 && h == 4) stage_a_small<4, 4>(p, wave, lane, uni(L.op_a), c_end);
+    else if (w == 8) stage_a_small<8, 4>(p, wave, lane, uni(L.op_a), c_end);
+    else stage_a_small<4, 8>(p, wave, lane, uni(L.op_a), c_end);
+  } else
   for (int c = uni(L.op_a) + wave; c < c_end; c += NW) {
     const int mode = uni(L.cand[c].mode), mrl = uni(L.cand[c].mrl);
     Ipa ip; init_pred_params(w, h, 1, mode, mrl, ip);
@@ -1074,7 +1145,7 @@ __device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
     for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
     wave_sync();
     unsigned long long sse; int cbf;
-    wave_code_block(L.org, rec, lev, L.tmp[wave], w, h, bd, p.qp, lane, sse, cbf);
+    wave_code_block(L.org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp, lane, sse, cbf);
     // xGetIntraFracBitsQT: header + cbf + residual from the node's start contexts
     { uint32_t *d = (uint32_t *) &L.wctx[wave]; const uint32_t *s = (const uint32_t *) &L.cur; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     wave_sync();
@@ -1128,13 +1199,12 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
   if (lane == 0) L.wave_best[wave] = -1;
   double wbest = MAX_DOUBLE;
   int cur = 0;
-  const int big = 2 * P > 1024;
   const int n_rd = uni(L.n_rd);
   for (int c = wave; c < n_rd; c += NW) {
     const int cm = uni(L.rd[c].mode);                 // chroma mode (70 = DM); final mode in .mrl field
     const int fm = uni(L.rd[c].mrl);
-    int16_t *recb = big ? (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + cur) * VXD_SLOT_ELEMS : &L.slot[wave][cur][0];
-    int16_t *levb = recb + (big ? 4096 : 1024);
+    int16_t *recb = slot_rec(scratch, 2 * P, wave, cur);
+    int16_t *levb = slot_lev(scratch, 2 * P, wave, cur);
     { uint32_t *d = (uint32_t *) &L.wctx[wave]; const uint32_t *s = (const uint32_t *) &L.cur; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     wave_sync();
     unsigned long long dist = 0; int cbfs[2];
@@ -1145,7 +1215,7 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
       for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
       wave_sync();
       unsigned long long sse; int cbf;
-      wave_code_block(L.org + k * P, rec, lev, L.tmp[wave], w, h, bd, p.qp_c[k], lane, sse, cbf);
+      wave_code_block(L.org + k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_c[k], lane, sse, cbf);
       cbfs[k] = cbf;
       dist += (unsigned long long) (p.dist_weight[k] * (double) sse);             // CL/RdCost.cpp:405-408
       {                    // xGetIntraFracBitsQTChroma 2625-2692: contexts advance
@@ -1184,7 +1254,7 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
   __syncthreads();
   if (wave == 0) {
     const int slot = uni(L.wave_slot[ww]);
-    const int16_t *levw = (big ? (const int16_t *) (scratch + VXD_OFF_SLOTS) + (ww * 2 + slot) * VXD_SLOT_ELEMS + 4096 : &L.slot[ww][slot][1024]);
+    const int16_t *levw = slot_lev(scratch, 2 * P, ww, slot);
     const int cbfm = uni(L.rd_cbf[best]);
     Cab cb; cb.c = &L.wctx[0]; cb.bits = 0;
     if (lane == 0) {
@@ -1235,9 +1305,8 @@ __device__ __noinline__ void op_save_intra(const VxParams &p, uint8_t *scratch, 
   const int W = L.nw >> sh, H = L.nh >> sh, P = W * H;
   uint8_t *lvl = scratch + VXD_OFF_STORE + (size_t) d * VXD_STORE_LEVEL;
   const int wave = L.win_wave, which = L.op_a;
-  const int big = (ch ? 2 * P : P) > 1024;
-  const int16_t *rec = big ? (const int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS : &L.slot[wave][which][0];
-  const int16_t *lev = rec + (big ? 4096 : 1024);
+  const int16_t *rec = slot_rec(scratch, ch ? 2 * P : P, wave, which);
+  const int16_t *lev = slot_lev(scratch, ch ? 2 * P : P, wave, which);
   int16_t *srec = (int16_t *) lvl, *slev = (int16_t *) (lvl + VXD_STORE_REC);
   const int n = ch ? 2 * P : P;
   for (int i = threadIdx.x; i < n; i += NT) { srec[i] = rec[i]; slev[i] = lev[i]; }
@@ -1575,14 +1644,14 @@ __device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, 
           derive_mpms(Ld, Ad, L.mpm);
           enc_intra_luma_pred_mode(cb, f.y, u->dir, u->mrl);
           enc_bin(cb, u->cbf & 1, VX_CTX_QtCbf[0]);
-          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; residual_coding(cb, lv, W, H, 0, (uint16_t *) L.tmp[1]); }
+          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; residual_coding(cb, lv, W, H, 0, (uint16_t *) L.tmp[2]); }
         } else {
           enc_intra_chroma_pred_mode(cb, u->dir);
           enc_bin(cb, (unsigned) !!(u->cbf & 2), VX_CTX_QtCbf[1]);
           enc_bin(cb, (unsigned) !!(u->cbf & 4), VX_CTX_QtCbf[2] + !!(u->cbf & 2));
           for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c)) {
             for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[c][((f.y >> 1) + yy) * fd.lstride[c] + (f.x >> 1) + xx];
-            residual_coding(cb, lv, W, H, 1, (uint16_t *) L.tmp[1]);
+            residual_coding(cb, lv, W, H, 1, (uint16_t *) L.tmp[2]);
           }
         }
         top--; continue;
@@ -1620,7 +1689,7 @@ template <typename T>
 __device__ __noinline__ void advance_ctx_ctu(const VxParams &p, const VxFrameDev &fd, int tile, int ctu_x, int ctu_y)
 {
   Cab cb; cb.c = &L.cur; cb.bits = 0;
-  int16_t *lv = (int16_t *) L.tmp[0];
+  int16_t *lv = (int16_t *) &L.tmp[0][0];        // 8 KB = tmp[0] + tmp[1]; the scan table of the estimator pass uses tmp[2]
   // 128x128 root: implicit QT for both trees (no bins); luma / chroma sub-trees interleaved per 64x64 (867-908)
   for (int q = 0; q < 4; q++) {
     const int qx = ctu_x + ((q & 1) ? 64 : 0), qy = ctu_y + ((q >= 2) ? 64 : 0);
