@@ -115,9 +115,9 @@ int  vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus, int *n_c
 float vvcx_last_kernel_ms(const vvcx_handle *h);
 /* work counters of the last launch: [0] SATD-stage candidates, [1] full-RD TU evaluations, [2] RD pixels, [3] nodes */
 int  vvcx_get_counters(vvcx_handle *h, uint64_t out[4]);
-/* diagnostic: shader-clock ticks (summed over streams) of the last launch: [0] mode controller, [1..11] parallel
- * operation kinds, [12] estimator pass */
-int  vvcx_get_profile(vvcx_handle *h, uint64_t out[16]);
+/* diagnostic (only filled by a -DVVCX_STAMP=1 build): shader-clock ticks summed over streams of the last launch:
+ * [0] mode controller, [1..11] parallel operation kinds, [12] estimator pass, [16..27] controller phases, [30] steps */
+int  vvcx_get_profile(vvcx_handle *h, uint64_t out[48]);
 const char *vvcx_last_error(void);
 int  vvcx_ctus_per_frame(const vvcx_handle *h);
 

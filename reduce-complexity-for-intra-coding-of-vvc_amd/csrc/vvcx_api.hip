@@ -80,7 +80,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   if (hipMalloc((void **) &h->frames_d, sizeof(VxFrameDev) * F) != hipSuccess || hipMalloc((void **) &h->lev_d, h->lev_frame * 2 * F) != hipSuccess ||
       hipMalloc((void **) &h->units_d, h->units_frame * sizeof(VxUnit) * F) != hipSuccess ||
       hipMalloc((void **) &h->stream_ctx_d, (size_t) F * h->ntiles * 2 * VXD_NUM_CTX * 2) != hipSuccess ||
-      hipMalloc((void **) &h->counters_d, 20 * sizeof(unsigned long long)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
+      hipMalloc((void **) &h->counters_d, 52 * sizeof(unsigned long long)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
   hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
   *out = h;
   return VVCX_OK;
@@ -186,7 +186,7 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
   if (need > h->scratch_cap) { hipFree(h->scratch_d); h->scratch_d = nullptr; HIPCHK(hipMalloc((void **) &h->scratch_d, need)); h->scratch_cap = need; }
   HIPCHK(hipMemcpyAsync(h->streams_d, sd.data(), sizeof(VxStreamDesc) * (size_t) ns, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(h->task_ctu_d, task_ctu.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemsetAsync(h->counters_d, 0, 20 * sizeof(unsigned long long), stream));
+  HIPCHK(hipMemsetAsync(h->counters_d, 0, 52 * sizeof(unsigned long long), stream));
 
   VxParams p; memset(&p, 0, sizeof p);
   p.pic_w = h->cfg.pic_w; p.pic_h = h->cfg.pic_h; p.bit_depth = h->cfg.bit_depth; p.chroma = h->cfg.chroma; p.tools = h->cfg.tools;
@@ -269,11 +269,11 @@ extern "C" int vvcx_get_counters(vvcx_handle *h, uint64_t out[4])
 
 // diagnostic: shader-clock ticks summed over streams per controller/operation kind of the last launch
 // [0] controller, [op] parallel operation `op` (enum in vvcx_kernel.hip), [12] estimator pass
-extern "C" int vvcx_get_profile(vvcx_handle *h, uint64_t out[16])
+extern "C" int vvcx_get_profile(vvcx_handle *h, uint64_t out[48])
 {
   if (!h || !out) return fail(VVCX_ERR_ARG, "null argument");
-  unsigned long long c[20];
+  unsigned long long c[52];
   HIPCHK(hipMemcpy(c, h->counters_d, sizeof c, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 16; i++) out[i] = c[4 + i];
+  for (int i = 0; i < 48; i++) out[i] = c[4 + i];
   return VVCX_OK;
 }

@@ -59,6 +59,7 @@ struct Frame {                     // one recursion level: partitioner level + C
   uint8_t qt_before_bt, max_qt_sub, has_best, cur_mode, cur_split, child, nparts, first;
   uint8_t modes[8];
   uint8_t nb_ok, nbL_lh, nbL_qt, nbA_lw, nbA_qt;   // left / above CU of the node (bit0 left, bit1 above present)
+  uint8_t can_mask, ctx_spl, ctx_qt, ctx_hv;       // canSplit() bits {no,qt,bh,bv,th,tv} and split-flag context increments, fixed per node
   int16_t px[4], py[4], pw[4], ph[4];
   uint64_t ss;
   double max_cost;
@@ -89,6 +90,7 @@ struct Lds {
   Ctx wctx[NW];                    // per-wave working copies
   Ctx wpark[NW];                   // end-of-candidate contexts of each wave's best full-RD candidate
   int16_t org[4096];               // node's original tile: luma w*h, or Cb | Cr (cw*ch each)
+  uint16_t binbuf[NW][160]; int rc_nb[NW], rc_sub[NW], rc_reg[NW];   // residual_coding_wave: pending (ctx<<1|bin) list and hand-over state
   int acc[NW][4][2];               // small-block SATD stage: per packed candidate {SAD, SATD}
   uint8_t scan_tab[NW][160];       // per-wave scratch of residual_coding: CG inner scan x/y (16+16) and CG scan x/y (64+64)
   int16_t refs[4][2][140];         // luma: set 0 mrl0 unfiltered, 1 mrl0 filtered, 2 mrl1, 3 mrl3; chroma: set 0 Cb, 1 Cr. [0]=top [1]=left
@@ -112,7 +114,7 @@ struct Lds {
   int win_idx, win_wave;
   unsigned long long cu_bits;      // cu_pred_data + cu_residual bits of the winner (contexts left in wctx[0])
   unsigned long long cnt[4];
-  unsigned long long prof[16];    // shader-clock ticks per operation kind (diagnostic, see vvcx_get_profile)
+  unsigned long long prof[48];    // shader-clock ticks per operation kind (diagnostic, see vvcx_get_profile)
 };
 
 __shared__ Lds L;
@@ -358,10 +360,170 @@ __device__ void residual_coding(Cab &cb, const int16_t *coeff, int w, int h, int
   const RcPre pre = rc_prepass<false>(coeff, w, h, scan, 0);
   rc_serial(cb, coeff, w, h, is_chroma, scan, pre);
 }
+// Wave form of residual_coding.  Three kinds of work, separated:
+//  (1) data-parallel pre-pass (all lanes): scan table, last position, significant groups and, per scan position, the
+//      neighbourhood template of CL/ContextModelling.h:107-199 folded into {sig ctx offset, gtx/par ctx offset, abs-sum};
+//  (2) lane 0 walks the coefficient groups in coding order and *emits* the context-coded bins as (ctx, bin) pairs
+//      (no model access: which context a bin uses never depends on the adaptive state) and adds the bypass bits;
+//  (3) all lanes run the adaptive models: bins that use different contexts are independent chains, so lane l owns the
+//      contexts with (ctx & 63) == l and replays its own bins of the list in order (BinProbModel_Std::estFracBitsUpdate).
+__device__ __noinline__ void rc_meta_pass(const int16_t *coeff, int w, int h, int is_chroma, const uint16_t *scan, uint16_t *meta, int last, int lane)
+{
+  w = uni(w); h = uni(h); last = uni(last);
+  for (int sp = lane; sp <= last; sp += 64) {
+    const int blk = scan[sp];
+    const int posY = blk / w, posX = blk - posY * w;
+    const int16_t *p = coeff + blk;
+    const int diag = posX + posY;
+    int numPos = 0, sumAbs = 0, sumPlain = 0;
+#define UPD(v) { int a = iabs(v); sumAbs += imin(4 + (a & 1), a); numPos += !!a; sumPlain += a; }
+    if (posX < w - 1) { UPD(p[1]); if (posX < w - 2) UPD(p[2]); if (posY < h - 1) UPD(p[w + 1]); }
+    if (posY < h - 1) { UPD(p[w]); if (posY < h - 2) UPD(p[w << 1]); }
+#undef UPD
+    int sigofs = imin((sumAbs + 1) >> 1, 3) + (diag < 2 ? 4 : 0);
+    if (!is_chroma) sigofs += diag < 5 ? 4 : 0;
+    int goff = imin(sumAbs - numPos, 4) + 1;
+    goff += (!diag ? (is_chroma ? 5 : 15) : !is_chroma ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
+    meta[sp] = (uint16_t) (sigofs | (goff << 5) | (imin(sumPlain, 63) << 10));
+  }
+  wave_sync();
+}
+__device__ __noinline__ void rc_chain(Ctx *c, const uint16_t *bins, int nb, int lane, unsigned long long &bits)
+{
+  nb = uni(nb);
+  for (int k = 0; k < nb; k++) {
+    const unsigned e = bins[k];
+    const int ctx = (int) (e >> 1);
+    if ((ctx & 63) == lane) {
+      const unsigned bin = e & 1;
+      unsigned a = c->s0[ctx], b = c->s1[ctx];
+      bits += L.t.bin_frac[(((a + b) >> 8) << 1) + bin];
+      const int rate = L.t.ctx_rate[ctx];
+      const int r0 = 2 + ((rate >> 2) & 3), r1 = 3 + r0 + (rate & 3);
+      a -= (a >> r0) & 0x7FE0u; b -= (b >> r1) & 0x7FFEu;
+      if (bin) { a += (0x7fffu >> r0) & 0x7FE0u; b += (0x7fffu >> r1) & 0x7FFEu; }
+      c->s0[ctx] = (uint16_t) a; c->s1[ctx] = (uint16_t) b;
+    }
+  }
+}
+// lane 0: emit the bins of coefficient groups sub, sub-1, ... while they fit the buffer; returns the next group to do
+__device__ __noinline__ void rc_emit(Cab &cb, const int16_t *coeff, int w, int h, int ch, const uint16_t *scan, const uint16_t *meta,
+                                     int scanPosLast, unsigned long long sigGroups, unsigned long long &sigPos, int first_call)
+{
+  const int wv = threadIdx.x >> 6;
+  uint16_t *bb = L.binbuf[wv];
+  int nb = 0;
+#define EMIT(bin_, ctx_) bb[nb++] = (uint16_t) (((ctx_) << 1) | (bin_))
+  int lcw, lch; cg_shape(w, h, lcw, lch);
+  const int lcg = lcw + lch, cgSize = 1 << lcg;
+  const int zw = imin(32, w), zh = imin(32, h), wg = zw >> lcw, hg = zh >> lch;
+  const uint8_t *gxs = L.scan_tab[wv] + 32, *gys = gxs + 64;
+  int sub = L.rc_sub[wv], regBins = L.rc_reg[wv];
+  if (first_call) {                                  // last_sig_coeff (4102-4160)
+    const int l2w = ilog2i(w), l2h = ilog2i(h);
+    int offx = 0, offy = 0, shx, shy;
+    if (ch) { shx = imin(2, w >> 3); shy = imin(2, h >> 3); }
+    else { offx = L.t.last_prefix[l2w]; offy = L.t.last_prefix[l2h]; shx = (l2w + 1) >> 2; shy = (l2h + 1) >> 2; }
+    const int blk = scan[scanPosLast];
+    const int posY = blk / w, posX = blk - posY * w;
+    const int gx = L.t.group_idx[posX], gy = L.t.group_idx[posY];
+    const int maxX = L.t.group_idx[zw - 1], maxY = L.t.group_idx[zh - 1];
+    int k;
+    for (k = 0; k < gx; k++) EMIT(1, VX_CTX_LastX[ch] + offx + (k >> shx));
+    if (gx < maxX) EMIT(0, VX_CTX_LastX[ch] + offx + (k >> shx));
+    for (k = 0; k < gy; k++) EMIT(1, VX_CTX_LastY[ch] + offy + (k >> shy));
+    if (gy < maxY) EMIT(0, VX_CTX_LastY[ch] + offy + (k >> shy));
+    if (gx > 3) enc_ep(cb, (gx - 2) >> 1);
+    if (gy > 3) enc_ep(cb, (gy - 2) >> 1);
+    regBins = (zw * zh * 28) >> 4;
+    sub = scanPosLast >> lcg;
+  }
+  const int sigBase = VX_CTX_SigFlag[ch], g1Base = VX_CTX_GtxFlag[ch + 2], g2Base = VX_CTX_GtxFlag[ch], parBase = VX_CTX_ParFlag[ch];
+  for (; sub >= 0 && nb + 4 * cgSize + 1 <= 160; sub--) {
+    const int cgX = gxs[sub], cgY = gys[sub], cgPos = cgY * wg + cgX;
+    const int minSub = sub << lcg, maxSub = minSub + cgSize - 1;
+    if ((sigGroups >> sub) & 1) sigPos |= 1ull << cgPos;
+    const int sigRight = (cgX + 1) < wg ? (int) ((sigPos >> (cgPos + 1)) & 1) : 0;
+    const int sigLower = (cgY + 1) < hg ? (int) ((sigPos >> (cgPos + wg)) & 1) : 0;
+    const int sigGroupCtx = VX_CTX_SigCoeffGroup[ch] + (sigRight | sigLower);
+    const int isLast = (scanPosLast >> lcg) == sub, isNotFirst = sub != 0;
+    const int firstSigPos = isLast ? scanPosLast : maxSub;
+    int nextSigPos = firstSigPos;
+    if (!isLast && isNotFirst) {
+      if ((sigPos >> cgPos) & 1) EMIT(1, sigGroupCtx);
+      else { EMIT(0, sigGroupCtx); continue; }
+    }
+    const int inferSigPos = nextSigPos != scanPosLast ? (isNotFirst ? minSub : -1) : nextSigPos;
+    int numNonZero = 0, remRegBins = regBins;
+    for (; nextSigPos >= minSub && remRegBins >= 4; nextSigPos--) {
+      const int cf = coeff[scan[nextSigPos]];
+      const unsigned m = meta[nextSigPos];
+      const unsigned sigFlag = cf != 0;
+      if (numNonZero || nextSigPos != inferSigPos) { EMIT(sigFlag, sigBase + (int) (m & 31)); remRegBins--; }
+      if (sigFlag) {
+        const int off = nextSigPos == scanPosLast ? 0 : (int) ((m >> 5) & 31);     // m_tmplCpDiag == -1 only for the very first coefficient
+        numNonZero++;
+        int rem = iabs(cf) - 1;
+        const unsigned gt1 = !!rem;
+        EMIT(gt1, g1Base + off); remRegBins--;
+        if (gt1) {
+          rem -= 1;
+          EMIT(rem & 1, parBase + off); rem >>= 1; remRegBins--;
+          EMIT(!!rem, g2Base + off); remRegBins--;
+        }
+      }
+    }
+    const int firstPosMode2 = nextSigPos;
+    regBins = remRegBins;
+    for (int sp = firstSigPos; sp > firstPosMode2; sp--) {
+      const unsigned a = (unsigned) iabs(coeff[scan[sp]]);
+      if (a >= 4) { const int sum = (int) (meta[sp] >> 10); enc_rem_abs(cb, (a - 4) >> 1, L.t.gorice_pars[imax(imin(sum - 20, 31), 0)]); }
+    }
+    for (int sp = firstPosMode2; sp >= minSub; sp--) {
+      const unsigned a = (unsigned) iabs(coeff[scan[sp]]);
+      const int sumAll = imin((int) (meta[sp] >> 10), 31);
+      const unsigned rice = L.t.gorice_pars[sumAll], pos0 = L.t.gorice_pos0[sumAll];
+      enc_rem_abs(cb, a == 0 ? pos0 : a <= pos0 ? a - 1 : a, rice);
+      if (a) numNonZero++;
+    }
+    enc_ep(cb, numNonZero);
+  }
+#undef EMIT
+  L.rc_nb[wv] = nb; L.rc_sub[wv] = sub; L.rc_reg[wv] = regBins;
+}
+// scan: uint16[<=1024] followed by meta: uint16[<=1024] (one 4 KB per-wave scratch)
 __device__ void residual_coding_wave(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, uint16_t *scan, int lane)
 {
+  const long long q0 = STAMP();
   const RcPre pre = rc_prepass<true>(coeff, w, h, scan, lane);
-  if (lane == 0) rc_serial(cb, coeff, w, h, is_chroma, scan, pre);
+  const int last = uni(pre.last);
+  if (last < 0) return;
+  uint16_t *meta = scan + 1024;
+  const long long q1 = STAMP();
+  rc_meta_pass(coeff, w, h, is_chroma, scan, meta, last, lane);
+  const long long q2 = STAMP();
+  long long qe = 0, qc = 0;
+  const int wv = uni(threadIdx.x >> 6);
+  unsigned long long sigPos = 0, mybits = 0;
+  int first = 1, sub = 0;
+  do {
+    const long long e0 = STAMP();
+    if (lane == 0) rc_emit(cb, coeff, w, h, is_chroma, scan, meta, last, pre.sig_groups, sigPos, first);
+    first = 0;
+    wave_sync();
+    const long long e1 = STAMP();
+    const int nb = uni(L.rc_nb[wv]);
+    sub = uni(L.rc_sub[wv]);
+    rc_chain(cb.c, L.binbuf[wv], nb, lane, mybits);
+    wave_sync();
+    qe += e1 - e0; qc += STAMP() - e1;
+  } while (sub >= 0);
+  const long long q3 = STAMP();
+  unsigned lo = (unsigned) mybits, hi = (unsigned) (mybits >> 32);      // per-TU totals fit 32 bits per lane; keep 64 for safety
+  unsigned long long tot = mybits;
+  for (int m = 32; m >= 1; m >>= 1) { const unsigned a = __shfl_xor(lo, m), b = __shfl_xor(hi, m); tot += ((unsigned long long) b << 32) | a; lo = (unsigned) tot; hi = (unsigned) (tot >> 32); }
+  if (lane == 0) cb.bits += tot;
+  if (VVCX_STAMP && threadIdx.x == 0) { L.prof[32] += (unsigned long long) (q1 - q0); L.prof[33] += (unsigned long long) (q2 - q1); L.prof[34] += (unsigned long long) qe; L.prof[35] += (unsigned long long) qc; L.prof[36] += (unsigned long long) (STAMP() - q3); L.prof[37] += 1; }
 }
 
 // ------------------------------------------------------------------------------------------------ partitioner (thread 0)
@@ -414,7 +576,7 @@ __device__ __noinline__ void can_split(const VxParams &p, Frame &f, int ch, int 
   if (f.w > 64 || f.h > 64) can[5] = 0;
   if (ch == 1 && cw * chh <= 32) can[5] = 0;
 }
-__device__ int can_do(const VxParams &p, Frame &f, int ch, int split) { int c[6]; can_split(p, f, ch, c); return c[split]; }
+__device__ inline int can_do(const VxParams &p, Frame &f, int ch, int split) { return (f.can_mask >> split) & 1; }
 
 // neighbour CU lookup (cs.getCU / getCURestricted → "coded in the current path and same tile")
 __device__ const VxUnit *get_cu(const VxParams &p, const VxFrameDev &fd, int ch, int px, int py, int tile)
@@ -424,54 +586,62 @@ __device__ const VxUnit *get_cu(const VxParams &p, const VxFrameDev &fd, int ch,
   const VxUnit *u = &fd.units[ch][(py >> ul) * p.uw + (px >> ul)];
   return u->tag == (uint16_t) (tile + 1) ? u : nullptr;
 }
-// the node's left / above neighbour CUs never change while the node is processed: fetch them once
-__device__ void fetch_neighbours(const VxParams &p, const VxFrameDev &fd, Frame &f, int ch, int tile)
+// Everything about a node that is fixed while it is processed — its left / above neighbour CUs, the canSplit() result
+// (CL/UnitPartitioner.cpp:379-466) and the split-flag context increments of DeriveCtx::CtxSplit
+// (CL/ContextModelling.cpp:154-250) — is derived once when the node is entered.
+__device__ __noinline__ void prepare_node(const VxParams &p, const VxFrameDev &fd, Frame &f, int ch, int tile)
 {
   const int sh = ch ? 1 : 0;
   const VxUnit *cuL = get_cu(p, fd, ch, (f.x >> sh) - 1, f.y >> sh, tile), *cuA = get_cu(p, fd, ch, f.x >> sh, (f.y >> sh) - 1, tile);
   f.nb_ok = (uint8_t) ((cuL ? 1 : 0) | (cuA ? 2 : 0));
-  if (cuL) { f.nbL_lh = cuL->lh; f.nbL_qt = cuL->qt; }
-  if (cuA) { f.nbA_lw = cuA->lw; f.nbA_qt = cuA->qt; }
-}
-// DeriveCtx::CtxSplit (CL/ContextModelling.cpp:154-250) + CABACWriter::split_cu_mode (EL/CABACWriter.cpp:1010-1069)
-__device__ __noinline__ void enc_split_cu_mode(const VxParams &p, const VxFrameDev &fd, Cab &cb, Frame &f, int ch, int tile, int split)
-{
+  int lh = 0, lq = 0, aw = 0, aq = 0;
+  if (cuL) { lh = cuL->lh; lq = cuL->qt; }
+  if (cuA) { aw = cuA->lw; aq = cuA->qt; }
+  f.nbL_lh = (uint8_t) lh; f.nbL_qt = (uint8_t) lq; f.nbA_lw = (uint8_t) aw; f.nbA_qt = (uint8_t) aq;
+  f.impl_checked = 0;
   int can[6]; can_split(p, f, ch, can);
-  const int sh = ch ? 1 : 0;
+  int mask = 0;
+  for (int i = 0; i < 6; i++) mask |= can[i] << i;
+  f.can_mask = (uint8_t) mask;
   const int bw = f.w >> sh, bh = f.h >> sh;
-  struct Nb { int lh, lw, qt; } nl = { f.nbL_lh, 0, f.nbL_qt }, na = { 0, f.nbA_lw, f.nbA_qt };
-  const Nb *cuL = (f.nb_ok & 1) ? &nl : nullptr, *cuA = (f.nb_ok & 2) ? &na : nullptr;
   unsigned ctxSpl = 0;
-  if (cuL) ctxSpl += ((1 << cuL->lh) < bh) ? 1 : 0;
-  if (cuA) ctxSpl += ((1 << cuA->lw) < bw) ? 1 : 0;
+  if (cuL) ctxSpl += ((1 << lh) < bh) ? 1 : 0;
+  if (cuA) ctxSpl += ((1 << aw) < bw) ? 1 : 0;
   unsigned numSplit = 0;
   if (can[1]) numSplit += 2;
   for (int i = 2; i < 6; i++) if (can[i]) numSplit += 1;
   if (numSplit > 0) numSplit--;
   ctxSpl += 3 * (numSplit >> 1);
-  unsigned ctxQt = (cuL && cuL->qt > f.qt) ? 1 : 0;
-  ctxQt += (cuA && cuA->qt > f.qt) ? 1 : 0;
+  unsigned ctxQt = (cuL && lq > f.qt) ? 1 : 0;
+  ctxQt += (cuA && aq > f.qt) ? 1 : 0;
   ctxQt += f.qt < 2 ? 0 : 3;
   unsigned ctxHv = 0;
   const unsigned numHor = (unsigned) (can[2] + can[4]), numVer = (unsigned) (can[3] + can[5]);
   if (numVer == numHor) {
-    const unsigned wAbove = cuA ? (1u << cuA->lw) : 1, hLeft = cuL ? (1u << cuL->lh) : 1;
+    const unsigned wAbove = cuA ? (1u << aw) : 1, hLeft = cuL ? (1u << lh) : 1;
     const unsigned depAbove = (unsigned) bw / wAbove, depLeft = (unsigned) bh / hLeft;
     if (depAbove == depLeft || !cuL || !cuA) ctxHv = 0; else if (depAbove < depLeft) ctxHv = 1; else ctxHv = 2;
   } else if (numVer < numHor) ctxHv = 3; else ctxHv = 4;
+  f.ctx_spl = (uint8_t) ctxSpl; f.ctx_qt = (uint8_t) ctxQt; f.ctx_hv = (uint8_t) ctxHv;
+}
+// CABACWriter::split_cu_mode (EL/CABACWriter.cpp:1010-1069)
+__device__ void enc_split_cu_mode(const VxParams &p, const VxFrameDev &fd, Cab &cb, Frame &f, int ch, int tile, int split)
+{
+  const int m = f.can_mask;
+  const int canNo = m & 1, canQt = (m >> 1) & 1, canBh = (m >> 2) & 1, canBv = (m >> 3) & 1, canTh = (m >> 4) & 1, canTv = (m >> 5) & 1;
   const unsigned ctxH12 = f.mt <= 1 ? 1 : 0, ctxV12 = f.mt <= 1 ? 3 : 2;
-  const int canSplit = can[1] || can[2] || can[3] || can[4] || can[5];
+  const int canSplit = canQt || canBh || canBv || canTh || canTv;
   const int isNo = split == SPLIT_NONE;
-  if (can[0] && canSplit) enc_bin(cb, !isNo, VX_CTX_SplitFlag + (int) ctxSpl);
+  if (canNo && canSplit) enc_bin(cb, !isNo, VX_CTX_SplitFlag + f.ctx_spl);
   if (isNo) return;
-  const int canBtt = can[2] || can[3] || can[4] || can[5];
+  const int canBtt = canBh || canBv || canTh || canTv;
   const int isQt = split == SPLIT_QT;
-  if (can[1] && canBtt) enc_bin(cb, (unsigned) isQt, VX_CTX_SplitQtFlag + (int) ctxQt);
+  if (canQt && canBtt) enc_bin(cb, (unsigned) isQt, VX_CTX_SplitQtFlag + f.ctx_qt);
   if (isQt) return;
-  const int canHor = can[2] || can[4], canVer = can[3] || can[5];
+  const int canHor = canBh || canTh, canVer = canBv || canTv;
   const int isVer = split == SPLIT_BV || split == SPLIT_TV;
-  if (canVer && canHor) enc_bin(cb, (unsigned) isVer, VX_CTX_SplitHvFlag + (int) ctxHv);
-  const int can14 = isVer ? can[5] : can[4], can12 = isVer ? can[3] : can[2];
+  if (canVer && canHor) enc_bin(cb, (unsigned) isVer, VX_CTX_SplitHvFlag + f.ctx_hv);
+  const int can14 = isVer ? canTv : canTh, can12 = isVer ? canBv : canBh;
   const int is12 = isVer ? (split == SPLIT_BV) : (split == SPLIT_BH);
   if (can12 && can14) enc_bin(cb, (unsigned) is12, VX_CTX_Split12Flag + (int) (isVer ? ctxV12 : ctxH12));
 }
@@ -1142,10 +1312,13 @@ __device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
     const int set = luma_set(mrl, ip.ref_filter);
     const int16_t *top = L.refs[set][0], *left = L.refs[set][1];
     const int dcv = L.dc_val[luma_set(mrl, 0)];
+    const long long tb0 = STAMP();
     for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
     wave_sync();
+    const long long tb1 = STAMP();
     unsigned long long sse; int cbf;
     wave_code_block(L.org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp, lane, sse, cbf);
+    const long long tb2 = STAMP();
     // xGetIntraFracBitsQT: header + cbf + residual from the node's start contexts
     { uint32_t *d = (uint32_t *) &L.wctx[wave]; const uint32_t *s = (const uint32_t *) &L.cur; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     wave_sync();
@@ -1160,6 +1333,7 @@ __device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
       cost = rd_cost(p, cb.bits, sse);
       L.rd_cost[c] = cost; L.rd_dist[c] = sse; L.rd_bits[c] = cb.bits; L.rd_cbf[c] = (uint8_t) cbf;
     }
+    if (VVCX_STAMP && threadIdx.x == 0) { const long long tb3 = STAMP(); L.prof[28] += (unsigned long long) (tb1 - tb0); L.prof[29] += (unsigned long long) (tb2 - tb1); L.prof[31] += (unsigned long long) (tb3 - tb2); }
     cost = uni_d(__shfl(cost, 0));
     if (cost < wbest) {
       wbest = cost;
@@ -1382,7 +1556,7 @@ __device__ int next_mode(const VxParams &p, Frame &f, int ch)
 }
 __device__ __noinline__ void init_cu_level(const VxParams &p, const VxFrameDev &fd, Frame &f, int ch, int tile)       // initCULevel 1203-1549
 {
-  fetch_neighbours(p, fd, f, ch, tile);
+  prepare_node(p, fd, f, ch, tile);
   const int cuL = f.nb_ok & 1, cuA = f.nb_ok & 2, lq = f.nbL_qt, aq = f.nbA_qt;
   f.qt_before_bt = (uint8_t) (((cuL && cuA && lq > f.qt && aq > f.qt) || (cuL && !cuA && lq > f.qt) || (!cuL && cuA && aq > f.qt)
                    || (!cuA && !cuL && f.w >= 32)) && (f.w > (p.min_qt[ch] << 1)));
@@ -1433,6 +1607,10 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
     if (L.d < 0) { post(OP_DONE); return; }
     Frame &f = L.fr[L.d];
     const int d = L.d;
+#if VVCX_STAMP
+    const long long tph = STAMP(); const int phs = f.phase;
+    struct PhStamp { long long t; int ph; __device__ ~PhStamp() { L.prof[16 + ph] += (unsigned long long) (STAMP() - t); L.prof[30] += 1; } } phstamp = { tph, phs };
+#endif
     switch (f.phase) {
     case PH_ENTER: {                                    // xCompressCU entry (EL/EncCu.cpp:727-1286)
       L.cnt[3]++;
@@ -1632,8 +1810,7 @@ __device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, 
     if (f.phase == 0) {
       const VxUnit *u = &fd.units[ch][(f.y >> 2) * p.uw + (f.x >> 2)];
       const int split = (int) ((u->ss >> (f.depth * 5)) & 31);
-      f.impl_checked = 0;
-      fetch_neighbours(p, fd, f, ch, tile);
+      prepare_node(p, fd, f, ch, tile);
       enc_split_cu_mode(p, fd, cb, f, ch, tile, split);
       if (!split) {
         const int sh = ch ? 1 : 0, W = f.w >> sh, H = f.h >> sh;
@@ -1711,7 +1888,7 @@ __device__ void run_stream(const VxParams &p)
   uint8_t *scratch = p.scratch + (size_t) blockIdx.x * p.scratch_per_stream;
   Ctx *carry = (Ctx *) (p.stream_ctx + (size_t) (sd.frame * p.ntiles + sd.tile) * 2 * NCTX);
   const int tid = threadIdx.x;
-  if (tid == 0) { L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < 16; i++) L.prof[i] = 0; }
+  if (tid == 0) { L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < 48; i++) L.prof[i] = 0; }
   load_tables();
   ctx_copy_all(&L.cur, carry);
   __syncthreads();
@@ -1771,7 +1948,7 @@ __device__ void run_stream(const VxParams &p)
     __syncthreads();
   }
   ctx_copy_all(carry, &L.cur);
-  if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); for (int i = 0; i < 16; i++) atomicAdd(&p.counters[4 + i], L.prof[i]); }
+  if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); for (int i = 0; i < 48; i++) atomicAdd(&p.counters[4 + i], L.prof[i]); }
 }
 
 extern "C" __global__ void __launch_bounds__(NT) vvcx_compress_kernel_u8(VxParams p) { run_stream<uint8_t>(p); }

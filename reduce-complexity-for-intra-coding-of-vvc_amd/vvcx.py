@@ -147,7 +147,7 @@ class VvcxEncoder:
         return float(self.L.vvcx_last_kernel_ms(self.h))
 
     def profile(self):
-        c = np.zeros(16, np.uint64)
+        c = np.zeros(48, np.uint64)
         self._chk(self.L.vvcx_get_profile(self.h, c.ctypes.data))
         return c
 

@@ -15,4 +15,8 @@ print("ctus",tc*tr,"time",dt,"kernel ms",enc.last_kernel_ms(),"CTU/s",tc*tr/dt)
 pr=enc.profile().astype(float); tot=pr[:11].sum()+pr[12]
 names=["ctrl","-","LUMA_PREP+A1","STAGE_A2","STAGE_B","CHROMA_RD","SAVE_INTRA","SAVE_PIC","RESTORE_PIC","CLEAR_UNITS","CTX_COPY","(A satd w0)","est_pass","-","(prep only)","(A pred w0)"]
 for i,n in enumerate(names): print("%-14s %6.2f%%  %.3e"%(n,100*pr[i]/tot,pr[i]))
-print("counters",enc.counters())
+phn=["ENTER","RUN","A1_DONE","A2_DONE","B_DONE","INTRA_SAVED","CHILD","CHILD_RET","SPLIT_SAVED","ADVANCE","EXIT","EXIT2"]
+for i,n in enumerate(phn): print("  ph %-12s %.3e"%(n,pr[16+i]))
+print("B wave0: pred %.3e code_block %.3e rate %.3e"%(pr[28],pr[29],pr[31]))
+print("rc wave0: prepass %.3e meta %.3e emit %.3e chain %.3e reduce %.3e calls %d"%(pr[32],pr[33],pr[34],pr[35],pr[36],pr[37]))
+print("steps",pr[30],"counters",enc.counters())
