@@ -26,6 +26,21 @@ B_CTU_8BIT = 49152          # 2 x 1.5 x 128 x 128 x 1 byte  
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch from the newest committed PMC summary of this exact workload (hardware counters cannot be
+    read from inside the process; tools/gpu_profile_round.sh collects FETCH_SIZE / WRITE_SIZE in separate rocprofv3
+    --pmc passes and tools/rocpd_summary.py applies the gfx950 correction).  None if no summary matches."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(p))
+        except Exception:
+            continue
+        if d.get("workload") == workload and "hbm_traffic_bytes_per_launch" in d:
+            return d["hbm_traffic_bytes_per_launch"], os.path.relpath(p, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,8 +81,8 @@ def main():
     enc = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, chroma=True, max_frames=args.frames, device=dev)
     enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
     frames = []
-    for f in range(args.frames):
-        planes = pkg.synth_frame(W, H, f, 8, 1000 + rank * 100 + f)
+    for poc in pkg.frames_of_rank(args.frames * world, rank, world):      # weak scaling: args.frames per rank
+        planes = pkg.synth_frame(W, H, poc, 8, 1000 + poc)
         org = [torch.from_numpy(p).cuda() for p in planes]
         rec = [torch.zeros_like(t) for t in org]
         frames.append((org, rec))
@@ -79,26 +94,8 @@ def main():
         res = enc.compress_bound_frames()
         return res, enc.last_kernel_ms()
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    res = None
-    for _ in range(args.steps):
-        res, ms = step()
-        kernel_ms.append(ms)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, outs = pkg.timed_steps(step, args.steps, args.warmup, world, device_sync=torch.cuda.synchronize, device="cuda")
+    kernel_ms = [ms for _, ms in outs]
     counters = enc.counters()
 
     if rank == 0:
@@ -106,16 +103,18 @@ def main():
         value = total_ctus / elapsed
         avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
         achieved = ctus_per_step * B_CTU_8BIT / avg_kernel_s / 1e9
+        workload = ("%dx%d 8-bit 4:2:0 All-Intra QP%d full RDO, %d frame(s)/step/GPU, %dx%d uniform tiles = %d CTU streams per frame"
+                    % (W, H, args.qp, args.frames, tc, tr, tc * tr))
+        traffic, traffic_src = pmc_traffic(workload)
         out = {
             "metric": "CTUs/sec (All-Intra, QP32)", "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16/int32 samples+coefficients, fp64 RD cost", "data": "synthetic",
-            "config": {"workload": "%dx%d 8-bit 4:2:0 All-Intra QP%d full RDO, %d frame(s)/step/GPU, %dx%d uniform tiles = %d CTU streams per frame"
-                                   % (W, H, args.qp, args.frames, tc, tr, tc * tr),
+            "config": {"workload": workload,
                        "tools": "P0: 67 intra modes + PDPC + MRL, DCT-II, plain quant, dual tree; MIP/ISP/LFNST/MTS/TS/CCLM/JCCR/LMCS/DepQuant/RDOQ/CU-reuse not built yet",
                        "ctus_per_step": ctus_per_step, "parallelism": "1 workgroup per CTU stream, frames sharded over ranks"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "vvcx_compress_kernel_u8", "kernel_ms": 1e3 * avg_kernel_s,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "vvcx_compress_kernel_u8", "kernel_ms": 1e3 * avg_kernel_s,
                          "algorithmic_bytes_per_launch": ctus_per_step * B_CTU_8BIT},
             "work": {"satd_candidates_per_launch": int(counters[0]), "rd_tu_evaluations_per_launch": int(counters[1]),
                      "rd_pixels_per_launch": int(counters[2]), "nodes_per_launch": int(counters[3]),
