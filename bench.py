@@ -49,8 +49,10 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--qp", type=int, default=32)
-    ap.add_argument("--frames", type=int, default=1, help="frames per step and rank")
+    ap.add_argument("--frames", type=str, default="auto",
+                    help="frames per step and rank; auto = enough frames for ~4 full waves of resident CTU streams")
     ap.add_argument("--tiles", type=str, default="auto", help="CxR uniform tile grid; auto = one tile per CTU")
+    ap.add_argument("--lib", type=str, default=None, help="alternative build of the HIP library (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ctus", type=int, default=12)
     args = ap.parse_args()
@@ -78,7 +80,13 @@ def main():
     else:
         tc, tr = map(int, args.tiles.lower().split("x"))
     sp = pkg.slice_params(args.qp)
-    enc = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, chroma=True, max_frames=args.frames, device=dev)
+    if args.frames == "auto":
+        probe = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, device=dev, lib_path=args.lib)
+        args.frames = max(1, (4 * probe.resident_streams()) // (tc * tr))
+        probe.close()
+    else:
+        args.frames = int(args.frames)
+    enc = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, chroma=True, max_frames=args.frames, device=dev, lib_path=args.lib)
     enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
     frames = []
     for poc in pkg.frames_of_rank(args.frames * world, rank, world):      # weak scaling: args.frames per rank
@@ -111,7 +119,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16/int32 samples+coefficients, fp64 RD cost", "data": "synthetic",
             "config": {"workload": workload,
-                       "tools": "P0: 67 intra modes + PDPC + MRL, DCT-II, plain quant, dual tree; MIP/ISP/LFNST/MTS/TS/CCLM/JCCR/LMCS/DepQuant/RDOQ/CU-reuse not built yet",
+                       "tools": "P0: 67 intra modes + PDPC + MRL, DCT-II, plain quant, dual tree, CU-result reuse (REUSE_CU_RESULTS); MIP/ISP/LFNST/MTS/TS/CCLM/JCCR/LMCS/DepQuant/RDOQ not built yet",
                        "ctus_per_step": ctus_per_step, "parallelism": "1 workgroup per CTU stream, frames sharded over ranks"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "vvcx_compress_kernel_u8", "kernel_ms": 1e3 * avg_kernel_s,

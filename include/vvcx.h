@@ -120,6 +120,9 @@ int  vvcx_get_counters(vvcx_handle *h, uint64_t out[4]);
 int  vvcx_get_profile(vvcx_handle *h, uint64_t out[48]);
 const char *vvcx_last_error(void);
 int  vvcx_ctus_per_frame(const vvcx_handle *h);
+/* number of CTU streams the device runs concurrently (CUs x resident workgroups per CU); batches with at least this
+ * many (frame, tile) streams fill the GPU.  ≙ the worker-thread count a frame-parallel host loop would size for */
+int  vvcx_resident_streams(const vvcx_handle *h);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ static int imin(int a, int b) { return a < b ? a : b; }
 static int imax(int a, int b) { return a > b ? a : b; }
 
 enum { SPLIT_NONE = 0, SPLIT_QT = 1, SPLIT_BH = 2, SPLIT_BV = 3, SPLIT_TH = 4, SPLIT_TV = 5 };   /* PartSplit values, CL/UnitPartitioner.h:56-65 */
-enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V };
+enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V, ETM_RECO_CACHED };
 
 typedef struct { int x, y, w, h; } area_t;   /* luma samples (UnitArea::Y) */
 
@@ -56,6 +56,13 @@ typedef struct {       /* what the mode controller reads from a CodingStructure 
   int max_qt;
 } cs_sum;
 
+/* BestEncodingInfo (EL/EncModeCtrl.h:456-475) reduced to what an intra CU needs; one entry per (position in CTU in
+ * 4-sample units, log2 w, log2 h) like m_bestEncInfo[x][y][wIdx][hIdx] (EL/EncModeCtrl.cpp:706-760).  The reference
+ * keeps entries across CTUs and rejects stale ones by comparing poc and absolute area (987-1024); clearing at every
+ * CTU start is equivalent.  lev: w*h luma levels, or Cb then Cr (cw*ch each). */
+typedef struct { uint8_t valid, ch, dir, mrl, cbf, depth; uint64_t ss; int16_t *lev; } cache_ent;
+#define CACHE_ENTRIES (32 * 32 * 6 * 6)
+
 #define MAX_DEPTH 20
 typedef struct {       /* per recursion level: saved best reconstruction of the node */
   int16_t *rec[3], *lev[3]; unit_t *units;
@@ -71,7 +78,8 @@ struct orc_enc {
   orc_cabac cabac;
   store_t store[MAX_DEPTH];
   double sqrt_lambda_fp;              /* sqrtLambdaForFirstPass */
-  uint64_t cnt_satd, cnt_rd, cnt_rdpix, cnt_nodes;
+  uint64_t cnt_satd, cnt_rd, cnt_rdpix, cnt_nodes, cnt_reuse;
+  cache_ent *cache; int ctu_is_last;
   /* scratch */
   int16_t *ref_unf, *ref_flt, *pred, *resi, *tmp_rec[2], *tmp_lev[2], *best_rec[2], *best_lev[2];
   int *coef;
@@ -80,7 +88,7 @@ struct orc_enc {
 /* ------------------------------------------------------------------------------------------------ */
 orc_enc *orc_create(const orc_cfg *cfg)
 {
-  if (cfg->tools & ~(uint32_t) ORC_TOOL_MRL) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (P0 = MRL only)", cfg->tools); return 0; }
+  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (P0 = MRL, CU reuse)", cfg->tools); return 0; }
   if (!cfg->dual_tree || cfg->ctu_size != 128) { snprintf(g_err, sizeof g_err, "oracle: only DualITree=1, CTUSize=128"); return 0; }
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7)) { snprintf(g_err, sizeof g_err, "oracle: picture size must be a multiple of 8 (EncAppCfg.cpp:2709)"); return 0; }
   orc_enc *e = (orc_enc *) calloc(1, sizeof *e);
@@ -99,6 +107,7 @@ orc_enc *orc_create(const orc_cfg *cfg)
     for (int c = 0; c < 3; c++) { e->store[d].rec[c] = (int16_t *) malloc(128 * 128 * 2); e->store[d].lev[c] = (int16_t *) malloc(128 * 128 * 2); }
     e->store[d].units = (unit_t *) malloc(32 * 32 * sizeof(unit_t));
   }
+  e->cache = (cache_ent *) calloc(CACHE_ENTRIES, sizeof(cache_ent));
   e->ref_unf = (int16_t *) malloc(2 * 300 * 300); e->ref_flt = (int16_t *) malloc(2 * 300 * 300);
   e->pred = (int16_t *) malloc(128 * 128 * 2); e->resi = (int16_t *) malloc(128 * 128 * 2); e->coef = (int *) malloc(128 * 128 * 4);
   for (int k = 0; k < 2; k++) { e->tmp_rec[k] = (int16_t *) malloc(128 * 128 * 2); e->tmp_lev[k] = (int16_t *) malloc(128 * 128 * 2); e->best_rec[k] = (int16_t *) malloc(128 * 128 * 2); e->best_lev[k] = (int16_t *) malloc(128 * 128 * 2); }
@@ -110,7 +119,8 @@ void orc_destroy(orc_enc *e)
   for (int c = 0; c < 3; c++) { free(e->org[c]); free(e->rec[c]); free(e->lev[c]); }
   for (int k = 0; k < 2; k++) { free(e->um[k]); free(e->avail[k]); free(e->tmp_rec[k]); free(e->tmp_lev[k]); free(e->best_rec[k]); free(e->best_lev[k]); }
   for (int d = 0; d < MAX_DEPTH; d++) { for (int c = 0; c < 3; c++) { free(e->store[d].rec[c]); free(e->store[d].lev[c]); } free(e->store[d].units); }
-  free(e->ctu_tile); free(e->ref_unf); free(e->ref_flt); free(e->pred); free(e->resi); free(e->coef); free(e);
+  for (int i = 0; i < CACHE_ENTRIES; i++) free(e->cache[i].lev);
+  free(e->cache); free(e->ctu_tile); free(e->ref_unf); free(e->ref_flt); free(e->pred); free(e->resi); free(e->coef); free(e);
 }
 int orc_set_slice(orc_enc *e, const orc_slice *s)
 {
@@ -662,7 +672,42 @@ typedef struct {            /* ComprCUCtx (EL/EncModeCtrl.h:182-249), intra-rele
   int min_depth, max_depth;
   int did_horz, did_vert, did_quad, do_trih, do_triv, qt_before_bt, max_qt_sub_depth;
   cs_sum *best;             /* bestCS (NULL until a mode result was accepted) */
+  int reusing, d;           /* IS_REUSING_CU; recursion level (index of the node's store) */
 } cu_ctx;
+
+/* ---- BestEncInfoCache (EL/EncModeCtrl.cpp:663-1110), REUSE_CU_RESULTS ---- */
+static cache_ent *cache_entry(orc_enc *e, area_t a)
+{
+  return &e->cache[((((a.y & 127) >> 2) * 32 + ((a.x & 127) >> 2)) * 6 + (ilog2(a.w) - 2)) * 6 + (ilog2(a.h) - 2)];
+}
+/* isValid (987-1024) with isTheSameNbHood (664-703): an entry of the same area and channel type, reached along another
+ * split path, is reusable iff the CU sits at the origin of the last common ancestor of the two paths.  poc, QP, tree
+ * and mode type are constant here; currQgEnable() is true only at CTU level (CL/UnitPartitioner.cpp:369, CuQpDeltaSubdiv 0). */
+static int cache_is_valid(orc_enc *e, const partitioner *P)
+{
+  if (!(e->cfg.tools & ORC_TOOL_CU_REUSE) || P->n == 1) return 0;
+  const cache_ent *c = cache_entry(e, P->cur);
+  if (!c->valid || c->ch != P->ch) return 0;
+  int i = 1;
+  for (; i < P->n; i++) {
+    const int dpt = i - 1, s = dpt >= c->depth ? SPLIT_NONE : (int) ((c->ss >> (5 * dpt)) & 31);   /* CU::getSplitAtDepth, CL/UnitTools.cpp:251 */
+    if (P->st[i].split != s) break;
+  }
+  const area_t anc = P->st[i - 1].parts[P->st[i - 1].idx];
+  return anc.x == P->cur.x && anc.y == P->cur.y;
+}
+/* setFromCs (939-985): called from tryMode(ETM_POST_DONT_SPLIT) when bestCS is a single unsplit CU; its data lives in store[d] */
+static void cache_set_from_cs(orc_enc *e, const partitioner *P, int d)
+{
+  if (!(e->cfg.tools & ORC_TOOL_CU_REUSE)) return;
+  const area_t a = P->cur; const int ch = P->ch;
+  cache_ent *c = cache_entry(e, a);
+  const unit_t *u = &e->store[d].units[0];
+  c->valid = 1; c->ch = (uint8_t) ch; c->dir = u->dir; c->mrl = u->mrl; c->cbf = u->cbf; c->depth = u->depth; c->ss = u->split_series;
+  if (!c->lev) c->lev = (int16_t *) malloc((size_t) a.w * a.h * 2);
+  if (!ch) memcpy(c->lev, e->store[d].lev[0], (size_t) a.w * a.h * 2);
+  else { const size_t n = (size_t) (a.w >> 1) * (a.h >> 1); memcpy(c->lev, e->store[d].lev[1], n * 2); memcpy(c->lev + n, e->store[d].lev[2], n * 2); }
+}
 
 static int mode_to_split(int m) { return m == ETM_SPLIT_QT ? SPLIT_QT : m == ETM_SPLIT_BT_H ? SPLIT_BH : m == ETM_SPLIT_BT_V ? SPLIT_BV : m == ETM_SPLIT_TT_H ? SPLIT_TH : m == ETM_SPLIT_TT_V ? SPLIT_TV : SPLIT_NONE; }
 
@@ -673,6 +718,10 @@ static int try_mode(orc_enc *e, partitioner *P, cu_ctx *C, int mode)
   if (impl != SPLIT_NONE && mode != ETM_SPLIT_QT) return mode_to_split(mode) == impl;
   else if (impl != SPLIT_NONE) return part_can(e, P, SPLIT_QT);
   const area_t a = P->cur;
+  if (C->reusing) {                               /* 1585-1598 */
+    if (mode == ETM_RECO_CACHED) return 1;
+    if (mode == ETM_INTRA) return 0;
+  }
   if (C->min_depth > P->qt_depth && part_can(e, P, SPLIT_QT)) return mode == ETM_SPLIT_QT;
   else if (mode == ETM_SPLIT_QT && C->max_depth <= P->qt_depth) return 0;
   if (mode == ETM_INTRA) {
@@ -680,7 +729,10 @@ static int try_mode(orc_enc *e, partitioner *P, cu_ctx *C, int mode)
     if (a.w > 64 || a.h > 64) return 0;           /* dual tree (1647) */
     return 1;
   }
-  if (mode == ETM_POST_DONT_SPLIT) return 0;      /* bookkeeping only (2005-2067) */
+  if (mode == ETM_POST_DONT_SPLIT) {              /* bookkeeping only (2005-2067) */
+    if (C->best && !C->best->is_split) cache_set_from_cs(e, P, C->d);
+    return 0;
+  }
   const int split = mode_to_split(mode);
   if (!part_can(e, P, split)) {
     if (split == SPLIT_BH) C->did_horz = 0;
@@ -722,9 +774,10 @@ static int next_mode(orc_enc *e, partitioner *P, cu_ctx *C)
   return C->nmodes > 0;
 }
 /* initCULevel (1203-1549) */
-static void init_cu_level(orc_enc *e, partitioner *P, cu_ctx *C)
+static void init_cu_level(orc_enc *e, partitioner *P, cu_ctx *C, int d)
 {
   memset(C, 0, sizeof *C);
+  C->d = d;
   const int ch = P->ch, sh = ch ? 1 : 0;
   C->min_depth = 0; C->max_depth = 7 - ilog2(e->cfg.min_qt[ch]);     /* plain QTBTPartitioner: no adaptive depth (EL/EncCu.cpp:472) */
   const area_t a = P->cur;
@@ -740,6 +793,8 @@ static void init_cu_level(orc_enc *e, partitioner *P, cu_ctx *C)
   if (part_can(e, P, SPLIT_BH)) { C->modes[C->nmodes++] = ETM_SPLIT_BT_H; C->did_horz = 1; }
   if (C->qt_before_bt) C->modes[C->nmodes++] = ETM_SPLIT_QT;
   C->modes[C->nmodes++] = ETM_POST_DONT_SPLIT;
+  C->reusing = cache_is_valid(e, P);               /* 1438-1444 */
+  if (C->reusing) C->modes[C->nmodes++] = ETM_RECO_CACHED;
   C->modes[C->nmodes++] = ETM_INTRA;
   if (!try_mode(e, P, C, C->modes[C->nmodes - 1])) next_mode(e, P, C);
 }
@@ -757,7 +812,47 @@ static int use_mode_result(orc_enc *e, partitioner *P, cu_ctx *C, int mode, cons
 static void compress_cu(orc_enc *e, partitioner *P, int d, double maxCostAllowed, cs_sum *best);
 
 /* xCheckRDCostIntra (EL/EncCu.cpp:2402-2777), single pass (no LFNST/MTS loops) */
-static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs_sum *best, orc_cabac *ctxStart, orc_cabac *ctxBest)
+/* reconstruct one block from given levels: prediction in e->pred; DecCu::xIntraRecBlk (DL/DecCu.cpp:199-414) */
+static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int h, const int16_t *lev, int cbf, int16_t *rec_out)
+{
+  const int st = e->stride[comp], bd = e->cfg.bit_depth, mx = (1 << bd) - 1;
+  const int16_t *org = e->org[comp] + y * st + x;
+  const int qp = comp ? e->sl.qp_c[comp - 1] : e->sl.qp;
+  if (cbf) { orc_dequant(lev, w, h, bd, qp, e->coef); orc_inv_2d(e->coef, w, h, bd, e->resi, w); }
+  else memset(e->resi, 0, (size_t) w * h * 2);
+  for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) { int v = e->pred[j * w + i] + e->resi[j * w + i]; rec_out[j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
+  uint64_t dd = orc_sse(org, st, rec_out, w, w, h);
+  if (comp) dd = (uint64_t) (e->sl.dist_weight[comp - 1] * (double) dd);
+  return dd;
+}
+/* xReuseCachedResult (EL/EncCu.cpp:5665-5771): cached mode + levels re-reconstructed against the current neighbourhood */
+static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *out_mrl, int *out_cbf)
+{
+  const cache_ent *c = cache_entry(e, a);
+  const int bd = e->cfg.bit_depth;
+  uint64_t dist = 0;
+  e->cnt_reuse++;
+  if (!ch) {
+    orc_ipa ip; orc_init_pred_params(a.w, a.h, 1, c->dir, c->mrl, &ip);
+    build_refs(e, 0, a.x, a.y, a.w, a.h, c->mrl, ip.ref_filter);
+    orc_pred_intra(e->ref_unf, e->ref_flt, a.w, a.h, 1, c->dir, c->mrl, bd, e->pred, a.w);
+    dist = recon_from_levels(e, 0, a.x, a.y, a.w, a.h, c->lev, c->cbf & 1, e->best_rec[0]);
+    memcpy(e->best_lev[0], c->lev, (size_t) a.w * a.h * 2);
+  } else {
+    const int cx = a.x >> 1, cy = a.y >> 1, cw = a.w >> 1, chh = a.h >> 1;
+    const int fm = c->dir == ORC_DM_CHROMA ? colocated_luma_mode(e, a) : c->dir;
+    for (int k = 1; k <= 2; k++) {
+      build_refs(e, k, cx, cy, cw, chh, 0, 0);
+      orc_pred_intra(e->ref_unf, e->ref_flt, cw, chh, 0, fm, 0, bd, e->pred, cw);
+      dist += recon_from_levels(e, k, cx, cy, cw, chh, c->lev + (size_t) (k - 1) * cw * chh, (c->cbf >> k) & 1, e->best_rec[k - 1]);
+      memcpy(e->best_lev[k - 1], c->lev + (size_t) (k - 1) * cw * chh, (size_t) cw * chh * 2);
+    }
+  }
+  *out_dir = c->dir; *out_mrl = c->mrl; *out_cbf = c->cbf;
+  return dist;
+}
+
+static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs_sum *best, orc_cabac *ctxStart, orc_cabac *ctxBest, int reuse)
 {
   const area_t a = P->cur; const int ch = P->ch, sh = ch ? 1 : 0;
   cs_sum t; memset(&t, 0, sizeof t);
@@ -766,7 +861,8 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
   cu.qt_depth = (uint8_t) P->qt_depth; cu.mt_depth = (uint8_t) P->mt_depth; cu.bt_depth = (uint8_t) P->bt_depth; cu.depth = (uint8_t) P->depth;
   cu.split_series = part_split_series(P);
   int dir = 0, mrl = 0, cbf = 0;
-  if (!ch) t.dist = est_intra_pred_luma(e, a, &dir, &mrl, &cbf), cbf = cbf ? 1 : 0;
+  if (reuse) t.dist = reuse_cached(e, a, ch, &dir, &mrl, &cbf);
+  else if (!ch) t.dist = est_intra_pred_luma(e, a, &dir, &mrl, &cbf), cbf = cbf ? 1 : 0;
   else t.dist = est_intra_pred_chroma(e, a, &dir, &cbf);
   cu.dir = (uint8_t) dir; cu.mrl = (uint8_t) mrl; cu.cbf = (uint8_t) cbf;
   /* CU-level rate from the node's start contexts (2593-2620) */
@@ -781,6 +877,12 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
     orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 4), ORC_CTX_QtCbf[2] + !!(cbf & 2));
     if (cbf & 2) orc_residual_coding(&e->cabac, e->best_lev[0], a.w >> 1, a.h >> 1, 1);
     if (cbf & 4) orc_residual_coding(&e->cabac, e->best_lev[1], a.w >> 1, a.h >> 1, 1);
+    /* the reuse path prices the CU with CABACWriter::coding_unit, whose end_of_ctu (EL/CABACWriter.cpp:2118-2141) adds the
+     * terminating bin after the last chroma CU of a CTU that does not end the slice */
+    if (reuse && !e->ctu_is_last) {
+      const int endX = a.x + a.w, endY = a.y + a.h;
+      if (((endX & 127) == 0 || endX == e->wl) && ((endY & 127) == 0 || endY == e->hl)) e->cabac.bits += 0x10c;   /* estFracBitsTrm(0), CL/Contexts.h:129 */
+    }
   }
   t.bits = e->cabac.bits;
   t.cost = rd_cost(e, t.bits, t.dist);
@@ -855,7 +957,7 @@ static void compress_cu(orc_enc *e, partitioner *P, int d, double maxCostAllowed
   cu_ctx C;
   const area_t a = P->cur; const int ch = P->ch;
   e->cnt_nodes++;
-  init_cu_level(e, P, &C);
+  init_cu_level(e, P, &C, d);
   orc_cabac ctxStart, ctxBest;
   orc_ctx_copy(&ctxStart, &e->cabac); orc_ctx_copy(&ctxBest, &e->cabac);
   memset(best, 0, sizeof *best); best->cost = ORC_MAX_DOUBLE;
@@ -864,7 +966,8 @@ static void compress_cu(orc_enc *e, partitioner *P, int d, double maxCostAllowed
   do {
     const int mode = C.modes[C.nmodes - 1];
     const cs_sum *before = C.best; const double costBefore = best->cost;
-    if (mode == ETM_INTRA) check_rd_cost_intra(e, P, d, &C, best, &ctxStart, &ctxBest);
+    if (mode == ETM_INTRA) check_rd_cost_intra(e, P, d, &C, best, &ctxStart, &ctxBest, 0);
+    else if (mode == ETM_RECO_CACHED) check_rd_cost_intra(e, P, d, &C, best, &ctxStart, &ctxBest, 1);
     else check_mode_split(e, P, d, &C, mode, maxCostAllowed, best, &ctxStart, &ctxBest);
     lastWasBest = (C.best != before) || (best->cost != costBefore);
   } while (next_mode(e, P, &C));
@@ -927,6 +1030,8 @@ static void advance_ctx_ctu(orc_enc *e, area_t ctu)
 static void compress_ctu(orc_enc *e, int rx, int ry, orc_ctu_result *res)
 {
   const area_t ctu = { rx << 7, ry << 7, 128, 128 };
+  for (int i = 0; i < CACHE_ENTRIES; i++) e->cache[i].valid = 0;
+  e->ctu_is_last = ry * e->ctus_w + rx == e->ctus_w * e->ctus_h - 1;
   orc_cabac ctuStart; orc_ctx_copy(&ctuStart, &e->cabac);
   partitioner P; cs_sum best;
   part_init_ctu(&P, ctu, 0);

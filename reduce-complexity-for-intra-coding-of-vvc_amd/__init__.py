@@ -1,4 +1,4 @@
 """MI355X-native VVC intra CU-partition RDO path.  Host-side Python mirror of include/vvcx.h."""
-from .vvcx import VvcxEncoder, VvcxError, load_library, TOOL_MRL  # noqa: F401
+from .vvcx import VvcxEncoder, VvcxError, load_library, TOOL_MRL, TOOL_CU_REUSE, TOOLS_DEFAULT  # noqa: F401
 from .synth import synth_frame, slice_params  # noqa: F401
 from .sharding import frames_of_rank, timed_steps, gather_ctu_results, max_over_ranks  # noqa: F401

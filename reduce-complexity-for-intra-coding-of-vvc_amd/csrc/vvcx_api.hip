@@ -43,7 +43,7 @@ struct vvcx_handle {
   size_t lev_plane[3], lev_frame, units_plane, units_frame;
 };
 
-static const uint32_t kBuiltTools = VVCX_TOOL_MRL;
+static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_CU_REUSE;
 
 extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
 {
@@ -81,7 +81,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
       hipMalloc((void **) &h->units_d, h->units_frame * sizeof(VxUnit) * F) != hipSuccess ||
       hipMalloc((void **) &h->stream_ctx_d, (size_t) F * h->ntiles * 2 * VXD_NUM_CTX * 2) != hipSuccess ||
       hipMalloc((void **) &h->counters_d, 52 * sizeof(unsigned long long)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
-  hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
+  (void) hipEventCreate(&h->ev0); (void) hipEventCreate(&h->ev1);
   *out = h;
   return VVCX_OK;
 }
@@ -89,9 +89,9 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
 extern "C" void vvcx_destroy(vvcx_handle *h)
 {
   if (!h) return;
-  hipFree(h->frames_d); hipFree(h->lev_d); hipFree(h->units_d); hipFree(h->stream_ctx_d); hipFree(h->scratch_d);
-  hipFree(h->streams_d); hipFree(h->task_ctu_d); hipFree(h->results_d); hipFree(h->counters_d);
-  hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+  (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d);
+  (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
+  (void) hipEventDestroy(h->ev0); (void) hipEventDestroy(h->ev1);
   delete h;
 }
 
@@ -148,6 +148,16 @@ extern "C" int vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n)
 
 extern "C" int vvcx_ctus_per_frame(const vvcx_handle *h) { return h ? h->ctus_w * h->ctus_h : 0; }
 
+extern "C" int vvcx_resident_streams(const vvcx_handle *h)
+{
+  if (!h) return 0;
+  int cus = 0, per_cu = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess) return 0;
+  const void *k = h->cfg.bit_depth == 8 ? (const void *) vvcx_compress_kernel_u8 : (const void *) vvcx_compress_kernel_u16;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, VXD_NT, 0) != hipSuccess) return 0;
+  return cus * per_cu;
+}
+
 extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int n, vvcx_ctu_result *out, void *hip_stream)
 {
   if (!h || !tasks || !out || n < 0) return fail(VVCX_ERR_ARG, "bad argument");
@@ -177,13 +187,14 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
     sd.push_back(d);
   }
   const int ns = (int) sd.size();
-  if (ns > h->stream_cap) { hipFree(h->streams_d); h->streams_d = nullptr; HIPCHK(hipMalloc((void **) &h->streams_d, sizeof(VxStreamDesc) * (size_t) ns)); h->stream_cap = ns; }
+  if (ns > h->stream_cap) { (void) hipFree(h->streams_d); h->streams_d = nullptr; HIPCHK(hipMalloc((void **) &h->streams_d, sizeof(VxStreamDesc) * (size_t) ns)); h->stream_cap = ns; }
   if (n > h->task_cap) {
-    hipFree(h->task_ctu_d); hipFree(h->results_d); h->task_ctu_d = nullptr; h->results_d = nullptr;
+    (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); h->task_ctu_d = nullptr; h->results_d = nullptr;
     HIPCHK(hipMalloc((void **) &h->task_ctu_d, sizeof(int32_t) * (size_t) n)); HIPCHK(hipMalloc((void **) &h->results_d, sizeof(VxCtuRes) * (size_t) n)); h->task_cap = n;
   }
-  const size_t need = (size_t) ns * VXD_SCRATCH_BYTES;
-  if (need > h->scratch_cap) { hipFree(h->scratch_d); h->scratch_d = nullptr; HIPCHK(hipMalloc((void **) &h->scratch_d, need)); h->scratch_cap = need; }
+  const size_t per_stream = (h->cfg.tools & VVCX_TOOL_CU_REUSE) ? (size_t) VXD_SCRATCH_BYTES : (size_t) VXD_OFF_CACHE;   // the CU cache only when used
+  const size_t need = (size_t) ns * per_stream;
+  if (need > h->scratch_cap) { (void) hipFree(h->scratch_d); h->scratch_d = nullptr; HIPCHK(hipMalloc((void **) &h->scratch_d, need)); h->scratch_cap = need; }
   HIPCHK(hipMemcpyAsync(h->streams_d, sd.data(), sizeof(VxStreamDesc) * (size_t) ns, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(h->task_ctu_d, task_ctu.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemsetAsync(h->counters_d, 0, 52 * sizeof(unsigned long long), stream));
@@ -196,7 +207,7 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
   p.dist_scale = (double) (1 << 15) / h->sl.lambda;                       // CL/RdCost.cpp:79
   p.sqrt_lambda_fp = sqrt(h->sl.lambda) * (1.0 / (double) (1 << 15));     // EL/IntraSearch.cpp:297
   p.frames = h->frames_d; p.streams = h->streams_d; p.task_ctu = h->task_ctu_d; p.results = h->results_d; p.stream_ctx = h->stream_ctx_d;
-  p.scratch = h->scratch_d; p.scratch_per_stream = VXD_SCRATCH_BYTES; p.counters = h->counters_d; p.ntiles = h->ntiles;
+  p.scratch = h->scratch_d; p.scratch_per_stream = per_stream; p.counters = h->counters_d; p.ntiles = h->ntiles;
 
   HIPCHK(hipEventRecord(h->ev0, stream));
   if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_compress_kernel_u8, dim3((unsigned) ns), dim3(VXD_NT), 0, stream, p);

@@ -3,8 +3,10 @@
 #pragma once
 #include <stdint.h>
 
-#define VXD_NT 512          // threads per workgroup = one CTU stream
-#define VXD_NW 8            // wavefronts (64 lanes) per workgroup
+#ifndef VXD_NW
+#define VXD_NW 4            // wavefronts (64 lanes) per workgroup = one CTU stream; 4 keeps LDS < 80 KB so two streams share a CU
+#endif
+#define VXD_NT (VXD_NW * 64) // threads per workgroup
 #define VXD_MAXD 14         // recursion levels kept in LDS
 #define VXD_NUM_CTX 386     // flat context array, same indexing as the reference's ContextSetCfg
 
@@ -60,4 +62,12 @@ struct VxParams {
 #define VXD_OFF_SLOTS   (VXD_OFF_CTX + (VXD_MAXD + VXD_NW + 1) * 2 * VXD_CTXSNAP) // big-block slots: [NW][2][2*4096] int16
 #define VXD_SLOT_ELEMS  (2 * 4096)
 #define VXD_OFF_TMP     (VXD_OFF_SLOTS + VXD_NW * 2 * VXD_SLOT_ELEMS * 2)             // big-block transform scratch: [NW][2048] int32
-#define VXD_SCRATCH_BYTES (VXD_OFF_TMP + VXD_NW * 2048 * 4)
+// CU-result cache of the current CTU (BestEncInfoCache, EL/EncModeCtrl.cpp:663-1110): one entry per (position in CTU in
+// 4-sample units, log2 w, log2 h <= 6) and a level pool with one slot per (size, position aligned to max(4, size/2)):
+// sum over sizes of size * 128 / max(4, size/2) = 1152 per dimension.
+struct VxCacheEnt { uint64_t ss; uint8_t kind /* 0 empty, 1 luma tree, 2 chroma tree */, dir, mrl, cbf, depth, pad[3]; };
+#define VXD_CACHE_ENTRIES (32 * 32 * 5 * 5)
+#define VXD_CACHE_DIM   1152
+#define VXD_OFF_CACHE   ((VXD_OFF_TMP + VXD_NW * 2048 * 4 + 255) & ~255)
+#define VXD_OFF_CACHE_LEV (VXD_OFF_CACHE + VXD_CACHE_ENTRIES * (int) sizeof(VxCacheEnt))
+#define VXD_SCRATCH_BYTES (VXD_OFF_CACHE_LEV + VXD_CACHE_DIM * VXD_CACHE_DIM * 2)

@@ -37,10 +37,11 @@
 #endif
 
 enum { SPLIT_NONE = 0, SPLIT_QT = 1, SPLIT_BH = 2, SPLIT_BV = 3, SPLIT_TH = 4, SPLIT_TV = 5 };
-enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V };
+enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V, ETM_RECO_CACHED };
+#define TOOL_CU_REUSE (1u << 11)
 enum { PLANAR = 0, DC = 1, HOR = 18, DIA = 34, VER = 50, VDIA = 66, DM_CHROMA = 70 };
 enum { OP_NONE, OP_DONE, OP_LUMA_PREP, OP_STAGE_A, OP_STAGE_B, OP_CHROMA_RD, OP_SAVE_INTRA, OP_SAVE_PIC, OP_RESTORE_PIC,
-       OP_CLEAR_UNITS, OP_CTX_COPY };
+       OP_CLEAR_UNITS, OP_CTX_COPY, OP_REUSE };
 enum { PH_ENTER, PH_RUN, PH_A1_DONE, PH_A2_DONE, PH_B_DONE, PH_INTRA_SAVED, PH_CHILD, PH_CHILD_RET, PH_SPLIT_SAVED, PH_ADVANCE, PH_EXIT, PH_EXIT2 };
 enum { CTX_CUR = 0, CTX_START = 1, CTX_BEST = 2, CTX_WAVE = 3 };   // OP_CTX_COPY endpoints
 
@@ -60,6 +61,7 @@ struct Frame {                     // one recursion level: partitioner level + C
   uint8_t modes[8];
   uint8_t nb_ok, nbL_lh, nbL_qt, nbA_lw, nbA_qt;   // left / above CU of the node (bit0 left, bit1 above present)
   uint8_t can_mask, ctx_spl, ctx_qt, ctx_hv;       // canSplit() bits {no,qt,bh,bv,th,tv} and split-flag context increments, fixed per node
+  uint8_t reusing, r_dir, r_mrl, r_cbf;            // IS_REUSING_CU and the cached CU's mode data (BestEncInfoCache)
   int16_t px[4], py[4], pw[4], ph[4];
   uint64_t ss;
   double max_cost;
@@ -1052,17 +1054,18 @@ __device__ void load_tables()
 // residual (org - pred) → DCT-II (TrQuant::xT 835-915) → plain quant (Quant::quant 994-1089) → levels;
 // if any level: dequant (423-549) → inverse DCT-II (xIT 917-992) → reco = clip(pred + resi) written over pred.
 // Returns SSE(org, reco) and abs-sum via out params.  rec/lev tiles have stride w.
+// given >= 0: the levels in lev are taken as coded (cbf = given): only the decoder half runs (DecCu::xIntraRecBlk, DL/DecCu.cpp:199-414).
 __device__ __noinline__ void wave_code_block(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp,
-                                int lane, unsigned long long &sse_out, int &cbf_out)
+                                int lane, unsigned long long &sse_out, int &cbf_out, int given = -1)
 {
-  w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp);
+  w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given);
   const int P = w * h, lw = ilog2i(w), lh = ilog2i(h);
   const int zw = imin(w, 32), zh = imin(h, 32);
   const int8_t *Mw = dct2_matrix(w), *Mh = dct2_matrix(h);
   const int shift1 = lw + bd + 6 - 15, shift2 = lh + 6;
   const int rnd1 = shift1 > 0 ? 1 << (shift1 - 1) : 0, rnd2 = 1 << (shift2 - 1);
   // stage 1 (horizontal): tmp[k*h + j] = (sum_i Mw[k][i] * resi[j][i] + rnd) >> shift1, k < zw
-  for (int o = lane; o < zw * h; o += 64) {
+  if (given < 0) for (int o = lane; o < zw * h; o += 64) {
     const int k = o / h, j = o - k * h;
     int s = 0;
     for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + i] - rec[j * w + i]);
@@ -1076,9 +1079,9 @@ __device__ __noinline__ void wave_code_block(const int16_t *org, int16_t *rec, i
   const int qbits = 14 + qp / 6 + tr_shift;
   const long long qadd = (long long) 171 << (qbits - 9);
   // stage 2 (vertical) + quant: coef[m*w + k], m < zh, k < zw
-  if (w > 32 || h > 32) { for (int o = lane; o < P; o += 64) lev[o] = 0; wave_sync(); }
+  if (given < 0 && (w > 32 || h > 32)) { for (int o = lane; o < P; o += 64) lev[o] = 0; wave_sync(); }
   int abs_sum = 0;
-  for (int o = lane; o < zw * zh; o += 64) {
+  if (given < 0) for (int o = lane; o < zw * zh; o += 64) {
     const int m = o / zw, k = o - m * zw;
     int s = 0;
     for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
@@ -1090,7 +1093,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org, int16_t *rec, i
     q = q < -32768 ? -32768 : q > 32767 ? 32767 : q;
     lev[m * w + k] = (int16_t) q;
   }
-  abs_sum = uni(wave_sum_i32(abs_sum));
+  abs_sum = given < 0 ? uni(wave_sum_i32(abs_sum)) : given;
   wave_sync();
   unsigned long long sse = 0;
   if (abs_sum > 0) {
@@ -1443,6 +1446,111 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
   __syncthreads();
 }
 
+// ---- CU-result cache (BestEncInfoCache, EL/EncModeCtrl.cpp:663-1110): entry index and level-pool offset of a node, -1 if the
+// node cannot be cached (sizes above 64 are never intra coded; origins are multiples of max(4, size/2) by construction of QT/BT/TT)
+__device__ int cache_slot(int x, int y, int w, int h, int &lev_off)
+{
+  const int lw = ilog2i(w), lh = ilog2i(h);
+  if (lw > 6 || lh > 6) return -1;
+  const int ax = imax(4, w >> 1), ay = imax(4, h >> 1), rx = x & 127, ry = y & 127;
+  if ((rx & (ax - 1)) | (ry & (ay - 1))) return -1;
+  const int npx = 128 / ax, segW = w * npx;
+  const int cumW = lw == 2 ? 0 : 128 + (lw - 3) * 256, cumH = lh == 2 ? 0 : 128 + (lh - 3) * 256;
+  lev_off = cumW * VXD_CACHE_DIM + segW * cumH + ((ry / ay) * npx + rx / ax) * w * h;
+  return (((ry >> 2) * 32 + (rx >> 2)) * 5 + (lw - 2)) * 5 + (lh - 2);
+}
+// isValid (987-1024) + isTheSameNbHood (664-703): thread 0, at node entry.  Frame i of the stack was produced by split
+// fr[i].last_split of frame i-1, so the partitioner stack is the frame stack.
+__device__ int cache_is_valid(const VxParams &p, uint8_t *scratch, Frame *fr, int d, int ch)
+{
+  Frame &f = fr[d];
+  if (!(p.tools & TOOL_CU_REUSE) || d == 0) return 0;
+  int lo;
+  const int e = cache_slot(f.x, f.y, f.w, f.h, lo);
+  if (e < 0) return 0;
+  const VxCacheEnt c = ((const VxCacheEnt *) (scratch + VXD_OFF_CACHE))[e];
+  if (c.kind != ch + 1) return 0;
+  int i = 1;
+  for (; i <= d; i++) {
+    const int dpt = i - 1, s = dpt >= c.depth ? SPLIT_NONE : (int) ((c.ss >> (5 * dpt)) & 31);
+    if (fr[i].last_split != s) break;
+  }
+  if (fr[i - 1].x != f.x || fr[i - 1].y != f.y) return 0;
+  f.r_dir = c.dir; f.r_mrl = c.mrl; f.r_cbf = c.cbf;
+  return 1;
+}
+
+// OP_REUSE: xReuseCachedResult (EL/EncCu.cpp:5665-5771).  The cached mode and levels of the node are reconstructed against the
+// current neighbourhood (DecCu::xReconIntraQT), distortion and CU bits are recomputed from the node's start contexts.  Results are
+// left where stage B / the chroma search leave theirs (candidate 0, wave 0, slot 0), so the controller continues at PH_B_DONE.
+template <typename T>
+__device__ __noinline__ void op_reuse(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
+{
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int ch = uni(L.tree_ch), bd = p.bit_depth;
+  const int sh = ch ? 1 : 0;
+  const int x = uni(L.nx) >> sh, y = uni(L.ny) >> sh, w = uni(L.nw) >> sh, h = uni(L.nh) >> sh, P = w * h, n = ch ? 2 * P : P;
+  if (!ch) op_luma_prep<T>(p, fd);
+  else {
+    for (int c = 1; c <= 2; c++) {
+      const void *org = fd.org[c]; const int st = fd.stride[c];
+      for (int i = threadIdx.x; i < P; i += NT) { const int r = i / w, cc = i - r * w; L.org[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
+      build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
+    }
+    if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
+  }
+  int16_t *recb = slot_rec(scratch, n, 0, 0), *levb = slot_lev(scratch, n, 0, 0);
+  {
+    int lo;
+    cache_slot(uni(L.nx), uni(L.ny), uni(L.nw), uni(L.nh), lo);
+    const int16_t *cl = (const int16_t *) (scratch + VXD_OFF_CACHE_LEV) + uni(lo);
+    for (int i = threadIdx.x; i < n; i += NT) levb[i] = cl[i];
+  }
+  ctx_copy_all(&L.wctx[0], &L.cur);
+  __threadfence_block();
+  __syncthreads();
+  if (wave == 0) {
+    const int mode = uni(L.rd[0].mode), fm = uni(L.rd[0].mrl), cbfm = uni(L.rd_cbf[0]);
+    Cab cb; cb.c = &L.wctx[0]; cb.bits = 0;
+    unsigned long long dist = 0;
+    if (!ch) {
+      Ipa ip; init_pred_params(w, h, 1, mode, fm, ip);
+      const int set = luma_set(fm, ip.ref_filter);
+      const int dcv = L.dc_val[luma_set(fm, 0)];
+      for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; recb[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], w, h, px, py, ip, mode, 1, bd, dcv); }
+      wave_sync();
+      int cbf;
+      wave_code_block(L.org, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp, lane, dist, cbf, cbfm & 1);
+      if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, fm); enc_bin(cb, (unsigned) (cbfm & 1), VX_CTX_QtCbf[0]); }
+      if (cbfm & 1) residual_coding_wave(cb, levb, w, h, 0, (uint16_t *) L.tmp[0], lane);
+    } else {
+      Ipa ip; init_pred_params(w, h, 0, fm, 0, ip);
+      for (int k = 0; k < 2; k++) {
+        int16_t *rec = recb + k * P;
+        for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(L.refs[k][0], L.refs[k][1], w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
+        wave_sync();
+        unsigned long long sse; int cbf;
+        wave_code_block(L.org + k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1);
+        dist += (unsigned long long) (p.dist_weight[k] * (double) sse);
+      }
+      if (lane == 0) {
+        enc_intra_chroma_pred_mode(cb, mode);
+        enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
+        enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
+      }
+      if (cbfm & 2) residual_coding_wave(cb, levb, w, h, 1, (uint16_t *) L.tmp[0], lane);
+      if (cbfm & 4) residual_coding_wave(cb, levb + P, w, h, 1, (uint16_t *) L.tmp[0], lane);
+      // coding_unit() ends with end_of_ctu (EL/CABACWriter.cpp:2118-2141): terminating bin after the last chroma CU of a CTU
+      // that does not end the slice; estFracBitsTrm(0) = 0x10c (CL/Contexts.h:129)
+      const int endX = L.nx + L.nw, endY = L.ny + L.nh;
+      const int lastCtu = (L.ctu_x >> 7) == p.ctus_w - 1 && (L.ctu_y >> 7) == p.ctus_h - 1;
+      if (lane == 0 && !lastCtu && ((endX & 127) == 0 || endX == p.pic_w) && ((endY & 127) == 0 || endY == p.pic_h)) cb.bits += 0x10c;
+    }
+    if (lane == 0) { L.win_idx = 0; L.win_wave = 0; L.wave_slot[0] = 0; L.rd_dist[0] = dist; L.cu_bits = cb.bits; }
+  }
+  __syncthreads();
+}
+
 // area copies between the picture (planes + unit map) and the level store / candidate slots
 template <typename T>
 __device__ __noinline__ void op_save_pic(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch, int restore)
@@ -1484,6 +1592,18 @@ __device__ __noinline__ void op_save_intra(const VxParams &p, uint8_t *scratch, 
   int16_t *srec = (int16_t *) lvl, *slev = (int16_t *) (lvl + VXD_STORE_REC);
   const int n = ch ? 2 * P : P;
   for (int i = threadIdx.x; i < n; i += NT) { srec[i] = rec[i]; slev[i] = lev[i]; }
+  if (p.tools & TOOL_CU_REUSE) {                       // setFromCs (939-985): the unsplit result is what tryMode(POST_DONT_SPLIT) caches right after
+    int lo;
+    const int e = uni(cache_slot(L.nx, L.ny, L.nw, L.nh, lo));
+    if (e >= 0) {
+      int16_t *cl = (int16_t *) (scratch + VXD_OFF_CACHE_LEV) + lo;
+      for (int i = threadIdx.x; i < n; i += NT) cl[i] = lev[i];
+      if (threadIdx.x == 0) {
+        VxCacheEnt c; c.ss = cu.ss; c.kind = (uint8_t) (ch + 1); c.dir = cu.dir; c.mrl = cu.mrl; c.cbf = cu.cbf; c.depth = cu.depth; c.pad[0] = c.pad[1] = c.pad[2] = 0;
+        ((VxCacheEnt *) (scratch + VXD_OFF_CACHE))[e] = c;
+      }
+    }
+  }
   VxUnit *su = (VxUnit *) (lvl + 2 * VXD_STORE_REC);
   const int ucw = (L.nw + 3) >> 2, uch = (L.nh + 3) >> 2;
   for (int i = threadIdx.x; i < ucw * uch; i += NT) su[(i / ucw) * 32 + (i % ucw)] = cu;
@@ -1510,6 +1630,7 @@ __device__ __noinline__ int try_mode(const VxParams &p, Frame &f, int ch, int mo
   const int impl = implicit_split(p, f, ch);
   if (impl != SPLIT_NONE && mode != ETM_SPLIT_QT) return mode_to_split(mode) == impl;
   else if (impl != SPLIT_NONE) return can_do(p, f, ch, SPLIT_QT);
+  if (f.reusing) { if (mode == ETM_RECO_CACHED) return 1; if (mode == ETM_INTRA) return 0; }     // 1585-1598
   const int maxDepth = 7 - ilog2i(p.min_qt[ch]);
   if (mode == ETM_SPLIT_QT && maxDepth <= f.qt) return 0;
   if (mode == ETM_INTRA) { if (f.w * f.h > 4096) return 0; if (f.w > 64 || f.h > 64) return 0; return 1; }
@@ -1554,8 +1675,9 @@ __device__ int next_mode(const VxParams &p, Frame &f, int ch)
   while (f.nmodes > 0 && !try_mode(p, f, ch, f.modes[f.nmodes - 1])) f.nmodes--;
   return f.nmodes > 0;
 }
-__device__ __noinline__ void init_cu_level(const VxParams &p, const VxFrameDev &fd, Frame &f, int ch, int tile)       // initCULevel 1203-1549
+__device__ __noinline__ void init_cu_level(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch, int d, int ch, int tile)       // initCULevel 1203-1549
 {
+  Frame &f = L.fr[d];
   prepare_node(p, fd, f, ch, tile);
   const int cuL = f.nb_ok & 1, cuA = f.nb_ok & 2, lq = f.nbL_qt, aq = f.nbA_qt;
   f.qt_before_bt = (uint8_t) (((cuL && cuA && lq > f.qt && aq > f.qt) || (cuL && !cuA && lq > f.qt) || (!cuL && cuA && aq > f.qt)
@@ -1568,6 +1690,8 @@ __device__ __noinline__ void init_cu_level(const VxParams &p, const VxFrameDev &
   if (can_do(p, f, ch, SPLIT_BH)) { f.modes[f.nmodes++] = ETM_SPLIT_BT_H; f.did_h = 1; }
   if (f.qt_before_bt) f.modes[f.nmodes++] = ETM_SPLIT_QT;
   f.modes[f.nmodes++] = ETM_POST_DONT_SPLIT;
+  f.reusing = (uint8_t) cache_is_valid(p, scratch, L.fr, d, ch);        // 1438-1444
+  if (f.reusing) f.modes[f.nmodes++] = ETM_RECO_CACHED;
   f.modes[f.nmodes++] = ETM_INTRA;
   if (!try_mode(p, f, ch, f.modes[f.nmodes - 1])) next_mode(p, f, ch);
 }
@@ -1614,7 +1738,7 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
     switch (f.phase) {
     case PH_ENTER: {                                    // xCompressCU entry (EL/EncCu.cpp:727-1286)
       L.cnt[3]++;
-      init_cu_level(p, fd, f, ch, tile);
+      init_cu_level(p, fd, scratch, d, ch, tile);
       f.best.cost = MAX_DOUBLE; f.best.dist = 0; f.best.bits = 0; f.best.valid = 0;
       if (f.nmodes == 0) { f.phase = PH_EXIT2; break; }
       f.phase = PH_RUN;
@@ -1624,11 +1748,26 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
       const int mode = f.modes[f.nmodes - 1];
       f.cur_mode = (uint8_t) mode;
       set_node(f, d);
-      if (mode == ETM_INTRA) {
+      if (mode == ETM_INTRA || mode == ETM_RECO_CACHED) {
         // CU record (partitioner.setCUData, EL/EncCu.cpp:2478-2496)
         VxUnit &cu = L.cu;
         cu.ss = f.ss; cu.x = (int16_t) (f.x >> sh); cu.y = (int16_t) (f.y >> sh); cu.lw = (uint8_t) ilog2i(f.w >> sh); cu.lh = (uint8_t) ilog2i(f.h >> sh);
         cu.qt = f.qt; cu.mt = f.mt; cu.bt = f.bt; cu.depth = f.depth; cu.dir = 0; cu.mrl = 0; cu.cbf = 0; cu.pad = 0; cu.tag = (uint16_t) (tile + 1);
+        if (mode == ETM_RECO_CACHED) {                  // xReuseCachedResult (EL/EncCu.cpp:5665-5771)
+          L.rd[0].mode = f.r_dir; L.rd[0].mrl = f.r_mrl; L.rd_cbf[0] = f.r_cbf; L.n_rd = 0;
+          if (!ch) {                                    // MPM list for intra_luma_pred_modes
+            int Ld = PLANAR, Ad = PLANAR;
+            const VxUnit *uL = get_cu(p, fd, 0, f.x - 1, f.y + f.h - 1, tile); if (uL) Ld = uL->dir;
+            const VxUnit *uA = get_cu(p, fd, 0, f.x + f.w - 1, f.y - 1, tile); if (uA && ((f.y - 1) >> 7) == (f.y >> 7)) Ad = uA->dir;
+            derive_mpms(Ld, Ad, L.mpm);
+          }
+          if (ch) {
+            const int cx = f.x + (f.w >> 1), cy = f.y + (f.h >> 1);
+            L.rd[0].mrl = (uint8_t) (f.r_dir == DM_CHROMA ? fd.units[0][(cy >> 2) * p.uw + (cx >> 2)].dir : f.r_dir);    // final mode
+          }
+          f.phase = PH_B_DONE;
+          post(OP_REUSE); return;
+        }
         if (!ch) {
           // MPM list of the node (PU::getIntraMPMs neighbours, CL/UnitTools.cpp:516-532)
           int Ld = PLANAR, Ad = PLANAR;
@@ -1897,11 +2036,16 @@ __device__ void run_stream(const VxParams &p)
     const int ctu_x = (addr % p.ctus_w) << 7, ctu_y = (addr / p.ctus_w) << 7;
     // contexts at CTU start → snapshot slot (MAXD-1) "start"
     ctx_copy_all(ctx_ptr(scratch, CTX_START, MAXD + NW, 0), &L.cur);
+    if (p.tools & TOOL_CU_REUSE) {                       // entries of an earlier CTU can never match (987-1024: poc / absolute area): drop them
+      uint64_t *ce = (uint64_t *) (scratch + VXD_OFF_CACHE);   // sizeof(VxCacheEnt) == 16
+      for (int i = tid; i < 2 * VXD_CACHE_ENTRIES; i += NT) ce[i] = 0;
+      __threadfence_block();
+    }
     __syncthreads();
     VxCtuRes res; res.dist = 0; res.bits = 0; res.cost = 0; res.n_cu = 0; res.pad = 0;
     for (int ch = 0; ch < (p.chroma ? 2 : 1); ch++) {
       if (tid == 0) {
-        L.tree_ch = ch; L.d = 0;
+        L.tree_ch = ch; L.d = 0; L.ctu_x = ctu_x; L.ctu_y = ctu_y;
         Frame &f = L.fr[0];
         f.x = (int16_t) ctu_x; f.y = (int16_t) ctu_y; f.w = 128; f.h = 128; f.depth = 0; f.qt = 0; f.bt = 0; f.mt = 0; f.impl_bt = 0;
         f.last_split = 0; f.part_idx = 0; f.impl_checked = 0; f.ss = 0; f.max_cost = MAX_DOUBLE; f.phase = PH_ENTER;
@@ -1935,6 +2079,7 @@ __device__ void run_stream(const VxParams &p)
           case OP_RESTORE_PIC: ctx_copy_all(ctx_ptr(scratch, L.op_a, L.op_c, 0), ctx_ptr(scratch, L.op_b, L.op_c, 0)); op_save_pic<T>(p, fd, scratch, 1); break;
           case OP_CLEAR_UNITS: op_clear_units(p, fd); break;
           case OP_CTX_COPY: ctx_copy_all(ctx_ptr(scratch, L.op_a, L.op_c, 0), ctx_ptr(scratch, L.op_b, L.op_c, 0)); __threadfence_block(); break;
+          case OP_REUSE: op_reuse<T>(p, fd, scratch); break;
         }
         __syncthreads();
       }

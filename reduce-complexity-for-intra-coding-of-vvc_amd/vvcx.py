@@ -11,6 +11,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libvvcx.so")
 TOOL_MRL = 1
+TOOL_CU_REUSE = 1 << 11      # BestEncInfoCache, REUSE_CU_RESULTS (CL/TypeDef.h:291) - on in the reference build
+TOOLS_DEFAULT = TOOL_MRL | TOOL_CU_REUSE
 
 
 class VvcxError(RuntimeError):
@@ -65,6 +67,7 @@ def load_library(lib_path=None):
     L.vvcx_get_profile.argtypes = [C.c_void_p, C.c_void_p]
     L.vvcx_last_error.restype = C.c_char_p
     L.vvcx_ctus_per_frame.argtypes = [C.c_void_p]
+    L.vvcx_resident_streams.argtypes = [C.c_void_p]
     _libs[path] = L
     return L
 
@@ -72,7 +75,7 @@ def load_library(lib_path=None):
 class VvcxEncoder:
     """≙ one EncCu instance (EL/EncCu.h:80-230): create/init → per-slice set-up → compressCtu calls → destroy."""
 
-    def __init__(self, width, height, bit_depth=8, tile_cols=1, tile_rows=1, chroma=True, tools=TOOL_MRL,
+    def __init__(self, width, height, bit_depth=8, tile_cols=1, tile_rows=1, chroma=True, tools=TOOLS_DEFAULT,
                  max_frames=1, device=0, lib_path=None):
         self.L = load_library(lib_path)
         c = _Cfg()
@@ -88,6 +91,9 @@ class VvcxEncoder:
         self._chk(self.L.vvcx_create(C.byref(c), C.byref(self.h)))
         self.ctus_per_frame = self.L.vvcx_ctus_per_frame(self.h)
         self.n_frames = 0
+
+    def resident_streams(self):
+        return int(self.L.vvcx_resident_streams(self.h))
 
     def _chk(self, rc):
         if rc != 0:

@@ -66,9 +66,11 @@ def lib():
 
 
 TOOL_MRL = 1
+TOOL_CU_REUSE = 1 << 11
+TOOLS_DEFAULT = TOOL_MRL | TOOL_CU_REUSE
 
 
-def default_cfg(w, h, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOL_MRL):
+def default_cfg(w, h, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOLS_DEFAULT):
     c = OrcCfg()
     c.pic_w, c.pic_h, c.bit_depth, c.ctu_size = w, h, bit_depth, 128
     c.min_qt[0], c.min_qt[1] = 8, 4
@@ -88,10 +90,10 @@ def make_slice(sp):
     return s
 
 
-def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1):
+def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOLS_DEFAULT):
     """Run the oracle on one frame; returns (ctu results, cu table, reco planes, counters)."""
     L = lib()
-    cfg = default_cfg(w, h, bit_depth, tile_cols, tile_rows, chroma)
+    cfg = default_cfg(w, h, bit_depth, tile_cols, tile_rows, chroma, tools)
     e = L.orc_create(C.byref(cfg))
     if not e:
         raise RuntimeError(L.orc_last_error().decode())

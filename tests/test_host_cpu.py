@@ -64,18 +64,19 @@ def test_missing_extension_fails_loudly(tmp_path):
         pkg.load_library(str(tmp_path / "nope.so"))
 
 
-@pytest.mark.parametrize("w,h,chroma,tiles", [(32, 32, 1, (1, 1)), (40, 24, 1, (1, 1))])
-def test_device_code_on_cpu_emulator_matches_oracle(emu_so, w, h, chroma, tiles):
+@pytest.mark.parametrize("w,h,chroma,tiles,tools", [(32, 32, 1, (1, 1), pkg.TOOLS_DEFAULT), (40, 24, 1, (1, 1), pkg.TOOLS_DEFAULT),
+                                                   (32, 32, 1, (1, 1), pkg.TOOL_MRL)])
+def test_device_code_on_cpu_emulator_matches_oracle(emu_so, w, h, chroma, tiles, tools):
     planes = pkg.synth_frame(w, h, 0, 8, 7)
     sp = pkg.slice_params(32)
-    enc = pkg.VvcxEncoder(w, h, 8, tile_cols=tiles[0], tile_rows=tiles[1], chroma=bool(chroma), lib_path=emu_so)
+    enc = pkg.VvcxEncoder(w, h, 8, tile_cols=tiles[0], tile_rows=tiles[1], chroma=bool(chroma), tools=tools, lib_path=emu_so)
     enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
     org = [np.ascontiguousarray(p) for p in planes]
     rec = [np.zeros_like(p) for p in planes]
     enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
     res = enc.compress_bound_frames()[0]
     cus = enc.get_cus(0)
-    ores, ocus, oreco, ocnt = O.compress_frame(planes, w, h, sp, chroma=chroma, tile_cols=tiles[0], tile_rows=tiles[1])
+    ores, ocus, oreco, ocnt = O.compress_frame(planes, w, h, sp, chroma=chroma, tile_cols=tiles[0], tile_rows=tiles[1], tools=tools)
     for k in ores.dtype.names:
         assert np.array_equal(ores[k], res[k]), k
     assert len(cus) == len(ocus) and all(np.array_equal(cus[k], ocus[k]) for k in cus.dtype.names)

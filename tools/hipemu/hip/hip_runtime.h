@@ -78,6 +78,9 @@ typedef int hipError_t; typedef void *hipStream_t; typedef void *hipEvent_t;
 enum { hipSuccess = 0 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 inline hipError_t hipSetDevice(int) { return 0; }
+enum { hipDeviceAttributeMultiprocessorCount = 0 };
+inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 1; return 0; }
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *v, const void *, int, size_t) { *v = 1; return 0; }
 inline hipError_t hipMalloc(void **p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipFree(void *p) { free(p); return 0; }
 inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return 0; }
