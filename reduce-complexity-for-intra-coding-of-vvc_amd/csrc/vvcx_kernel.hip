@@ -84,17 +84,18 @@ struct Tables {                    // constant tables staged once per workgroup 
   uint8_t  last_prefix[8], mode_shift[8];
   uint8_t  ctx_rate[NCTX + 2], gorice_pars[32], gorice_pos0[96], group_idx[64], mode_num[36], intra_thr[8];
   int8_t   dct[4 + 16 + 64 + 256 + 1024 + 4096];
+  uint8_t  cg_scan[52], grp_scan[228];   // diagonal scans (CL/Rom.cpp:87-131) as x | y << 4: inside a coefficient group {4x4, 2x2, 8x2, 2x8}; of the groups, per (log2 wg, log2 hg)
 };
 
+#define RC_LIST 320
 struct Lds {
   Tables t;
   Ctx cur;                         // the estimator's contexts
   Ctx wctx[NW];                    // per-wave working copies
   Ctx wpark[NW];                   // end-of-candidate contexts of each wave's best full-RD candidate
   int16_t org[4096];               // node's original tile: luma w*h, or Cb | Cr (cw*ch each)
-  uint16_t binbuf[NW][160]; int rc_nb[NW], rc_sub[NW], rc_reg[NW];   // residual_coding_wave: pending (ctx<<1|bin) list and hand-over state
+  uint16_t binbuf[NW][RC_LIST]; uint8_t binsort[NW][RC_LIST];        // residual_coding_wave: pending (ctx<<1|bin) list; bins grouped by context
   int acc[NW][4][2];               // small-block SATD stage: per packed candidate {SAD, SATD}
-  uint8_t scan_tab[NW][160];       // per-wave scratch of residual_coding: CG inner scan x/y (16+16) and CG scan x/y (64+64)
   int16_t refs[4][2][140];         // luma: set 0 mrl0 unfiltered, 1 mrl0 filtered, 2 mrl1, 3 mrl3; chroma: set 0 Cb, 1 Cr. [0]=top [1]=left
   int32_t tmp[NW][1024];           // per-wave transform / Hadamard / scan scratch (blocks needing more use HBM scratch)
   int16_t slot[NW][2048];          // per-wave candidate slot 0: rec[1024] | lev[1024] (slot 1 and big blocks live in HBM scratch)
@@ -137,20 +138,43 @@ __device__ inline double uni_d(double v)
   u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]); u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
   return u.d;
 }
+__device__ inline double lane0_d(double v)               // lane 0's value on every lane, as a scalar
+{
+  union { double d; int i[2]; } u; u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], 0); u.i[1] = __builtin_amdgcn_readlane(u.i[1], 0);
+  return u.d;
+}
 __device__ inline void wave_sync()
 {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   __builtin_amdgcn_wave_barrier();
 }
-__device__ inline unsigned long long wave_sum_u64(unsigned long long v)
-{
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
-}
+// wave-wide sums with DPP row operations (6 VALU instructions instead of 6 dependent ds_bpermute round trips): quad swaps,
+// row rotates, then row_bcast:15 / row_bcast:31 accumulate the rows into lane 63; the total comes back as a scalar.
 __device__ inline int wave_sum_i32(int v)
 {
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      // quad_perm:[1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      // quad_perm:[2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true);     // row_ror:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);     // row_ror:8: every lane holds its row's sum
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);     // row_bcast:15 into rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);     // row_bcast:31 into rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// sum over aligned groups of N (2..16) consecutive lanes, result on every lane of the group
+template <int N> __device__ inline int seg_sum(int v)
+{
+  if (N >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);     // quad_perm:[1,0,3,2]
+  if (N >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);     // quad_perm:[2,3,0,1]
+  if (N >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);    // row_half_mirror: the other quad of the 8
+  if (N >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror: the other half of the 16
   return v;
+}
+__device__ inline unsigned long long wave_sum_u64(unsigned long long v)      // per-lane values below 2^62; 24-bit limbs cannot overflow
+{
+  const unsigned long long a = (unsigned) wave_sum_i32((int) (v & 0xFFFFFFu)), b = (unsigned) wave_sum_i32((int) ((v >> 24) & 0xFFFFFFu)),
+                           c = (unsigned) wave_sum_i32((int) (v >> 48));
+  return a + (b << 24) + (c << 48);
 }
 __device__ inline double rd_cost(const VxParams &p, uint64_t bits, uint64_t dist)
 {
@@ -234,7 +258,7 @@ __device__ int tmpl_abs_sum(const Cctx &c, const int16_t *coeff, int blk, int ba
 // Split in two: a pre-pass that builds the scan table (CL/Rom.cpp:87-370) and finds the last significant scan
 // position and the significant coefficient groups (3823-3835) — data parallel, done by all lanes of the calling wave
 // when PAR — and the context-coded part, which is a serial chain through the adaptive models (lane 0).
-struct RcPre { int last; unsigned long long sig_groups; };
+struct RcPre { int last; unsigned long long sig_groups, sig_raster; };   // significant groups by scan index / by raster position
 __device__ inline void diag_walk(int bw, int bh, int n, int &ox, int &oy)
 {
   int line = 0, col = 0;
@@ -244,30 +268,59 @@ __device__ inline void diag_walk(int bw, int bh, int n, int &ox, int &oy)
   }
   ox = col; oy = line;
 }
-template <bool PAR>
-__device__ __noinline__ RcPre rc_prepass(const int16_t *coeff, int w, int h, uint16_t *scan, int lane)
+// scan geometry of a transform block: coefficient group shape (g_log2SbbSize), the two diagonal-scan tables and the mapping
+// scan position -> raster offset (CL/Rom.cpp:133-370, zero-out region 32x32)
+struct ScanGeo { const uint8_t *cg, *grp; int lcw, lch, lcg, w, wg, hg, nscan; };
+__device__ inline ScanGeo scan_geo(int w, int h)
+{
+  ScanGeo g; cg_shape(w, h, g.lcw, g.lch);
+  g.lcg = g.lcw + g.lch; g.w = w;
+  const int zw = imin(32, w), zh = imin(32, h);
+  g.wg = zw >> g.lcw; g.hg = zh >> g.lch; g.nscan = zw * zh;
+  g.cg = L.t.cg_scan + (g.lcw == 2 ? 0 : g.lcw == 3 ? 20 : g.lch == 3 ? 36 : 16);
+  const int a = ilog2i(g.wg), b = ilog2i(g.hg);
+  g.grp = L.t.grp_scan + 15 * ((1 << a) - 1) + (1 << a) * ((1 << b) - 1);
+  return g;
+}
+__device__ inline int scan_blk(const ScanGeo &g, int sp)
+{
+  const unsigned gi = g.grp[sp >> g.lcg], ci = g.cg[sp & ((1 << g.lcg) - 1)];
+  return (int) ((((gi >> 4) << g.lch) + (ci >> 4)) * g.w + ((gi & 15) << g.lcw) + (ci & 15));
+}
+// single-lane pre-pass: scan table, last significant scan position, significant groups (3823-3835)
+__device__ __noinline__ RcPre rc_prepass_serial(const int16_t *coeff, int w, int h, uint16_t *scan)
+{
+  const ScanGeo g = scan_geo(w, h);
+  int last = -1; unsigned long long sig = 0;
+  for (int sp = 0; sp < g.nscan; sp++) {
+    const int blk = scan_blk(g, sp);
+    scan[sp] = (uint16_t) blk;
+    if (coeff[blk]) { last = sp; sig |= 1ull << (sp >> g.lcg); }
+  }
+  RcPre r; r.last = last; r.sig_groups = sig; r.sig_raster = 0;
+  return r;
+}
+// wave pre-pass: 64 scan positions per step, last position and group significance from the ballot of "coefficient != 0"
+__device__ __noinline__ RcPre rc_prepass_wave(const int16_t *coeff, int w, int h, int lane)
 {
   w = uni(w); h = uni(h);
-  int lcw, lch; cg_shape(w, h, lcw, lch);
-  const int lcg = lcw + lch, cw = 1 << lcw, chh = 1 << lch, cgSize = 1 << lcg;
-  const int zw = imin(32, w), zh = imin(32, h), wg = zw >> lcw, hg = zh >> lch, ngroups = wg * hg, nscan = zw * zh;
-  uint8_t *ix = L.scan_tab[threadIdx.x >> 6], *iy = ix + 16, *gxs = ix + 32, *gys = ix + 96;
-  const int l0 = PAR ? lane : 0, ls = PAR ? 64 : 1;
-  for (int n = l0; n < cgSize; n += ls) { int x, y; diag_walk(cw, chh, n, x, y); ix[n] = (uint8_t) x; iy[n] = (uint8_t) y; }
-  for (int n = l0; n < ngroups; n += ls) { int x, y; diag_walk(wg, hg, n, x, y); gxs[n] = (uint8_t) x; gys[n] = (uint8_t) y; }
-  if (PAR) wave_sync();
-  int last = -1; unsigned lo = 0, hi = 0;
-  for (int sp = l0; sp < nscan; sp += ls) {
-    const int g = sp >> lcg, i = sp & (cgSize - 1);
-    const int blk = ((int) gys[g] * chh + iy[i]) * w + (int) gxs[g] * cw + ix[i];
-    scan[sp] = (uint16_t) blk;
-    if (coeff[blk]) { last = sp; if (g < 32) lo |= 1u << g; else hi |= 1u << (g - 32); }
+  const ScanGeo g = scan_geo(w, h);
+  int last = -1; unsigned long long sig = 0;
+  const int gpi = 64 >> g.lcg;                           // groups per step
+  const unsigned long long gmask = (g.lcg == 4) ? 0xFFFFull : 0xFull;
+  for (int it = 0; it * 64 < g.nscan; it++) {
+    const int sp = it * 64 + lane;
+    const unsigned long long m = __ballot(sp < g.nscan && coeff[scan_blk(g, sp)] != 0);
+    if (m) {
+      last = it * 64 + 63 - __clzll((long long) m);
+      for (int q = 0; q < gpi; q++) if ((m >> (q << g.lcg)) & gmask) sig |= 1ull << (it * gpi + q);
+    }
   }
-  if (PAR) {
-    for (int m = 32; m >= 1; m >>= 1) { const int a = __shfl_xor(last, m); const unsigned b = __shfl_xor(lo, m), c = __shfl_xor(hi, m); last = imax(last, a); lo |= b; hi |= c; }
-    wave_sync();
-  }
-  RcPre r; r.last = last; r.sig_groups = ((unsigned long long) hi << 32) | lo;
+  // the same set by raster position of the group (for the sigGroup context, 4177-4181): one group per lane
+  int rlo = 0, rhi = 0;
+  if (lane < g.wg * g.hg && ((sig >> lane) & 1)) { const unsigned gi = g.grp[lane]; const int r = (int) (gi >> 4) * g.wg + (int) (gi & 15); if (r < 32) rlo = 1 << r; else rhi = 1 << (r - 32); }
+  RcPre r; r.last = last; r.sig_groups = sig;
+  r.sig_raster = ((unsigned long long) (unsigned) wave_sum_i32(rhi) << 32) | (unsigned) wave_sum_i32(rlo);
   return r;
 }
 __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, const uint16_t *scan, RcPre pre)
@@ -276,7 +329,7 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
   int lcw, lch; cg_shape(w, h, lcw, lch);
   const int lcg = lcw + lch, cgSize = 1 << lcg;
   const int zw = imin(32, w), zh = imin(32, h), wg = zw >> lcw, hg = zh >> lch;
-  const uint8_t *gxs = L.scan_tab[threadIdx.x >> 6] + 32, *gys = gxs + 64;
+  const ScanGeo geo = scan_geo(w, h);
   const int scanPosLast = pre.last;
   const unsigned long long sigGroups = pre.sig_groups;
   if (scanPosLast < 0) return;
@@ -300,7 +353,7 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
   int regBins = (zw * zh * 28) >> 4;
   unsigned long long sigPos = 0;         // m_sigCoeffGroupFlag by CG raster position
   for (int sub = scanPosLast >> lcg; sub >= 0; sub--) {
-    const int cgX = gxs[sub], cgY = gys[sub], cgPos = cgY * wg + cgX;
+    const int cgX = geo.grp[sub] & 15, cgY = geo.grp[sub] >> 4, cgPos = cgY * wg + cgX;
     const int minSub = sub << lcg, maxSub = minSub + cgSize - 1;
     if ((sigGroups >> sub) & 1) sigPos |= 1ull << cgPos;
     const int sigRight = (cgX + 1) < wg ? (int) ((sigPos >> (cgPos + 1)) & 1) : 0;
@@ -359,173 +412,199 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
 // single-lane form (controller / estimator pass) and wave form (lane 0 owns cb)
 __device__ void residual_coding(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, uint16_t *scan)
 {
-  const RcPre pre = rc_prepass<false>(coeff, w, h, scan, 0);
+  const RcPre pre = rc_prepass_serial(coeff, w, h, scan);
   rc_serial(cb, coeff, w, h, is_chroma, scan, pre);
 }
-// Wave form of residual_coding.  Three kinds of work, separated:
-//  (1) data-parallel pre-pass (all lanes): scan table, last position, significant groups and, per scan position, the
-//      neighbourhood template of CL/ContextModelling.h:107-199 folded into {sig ctx offset, gtx/par ctx offset, abs-sum};
-//  (2) lane 0 walks the coefficient groups in coding order and *emits* the context-coded bins as (ctx, bin) pairs
-//      (no model access: which context a bin uses never depends on the adaptive state) and adds the bypass bits;
-//  (3) all lanes run the adaptive models: bins that use different contexts are independent chains, so lane l owns the
-//      contexts with (ctx & 63) == l and replays its own bins of the list in order (BinProbModel_Std::estFracBitsUpdate).
-__device__ __noinline__ void rc_meta_pass(const int16_t *coeff, int w, int h, int is_chroma, const uint16_t *scan, uint16_t *meta, int last, int lane)
+// Wave form of residual_coding (same syntax as rc_serial, all 64 lanes working):
+//  (1) data-parallel pre-pass: scan table, last position, significant groups (by scan index and by raster position);
+//  (2) 64 scan positions at a time, one per lane in coding order: the lane derives its neighbourhood template
+//      (CL/ContextModelling.h:107-199), which of {sig, gt1, par, gt2} it codes and with which contexts, its position in the
+//      bin sequence (ballot prefix sums; the regular-bin budget is a prefix condition) and its bypass bit count.  Which context
+//      a bin uses never depends on the adaptive state, so the bins are *emitted* as (ctx, bin) pairs without touching a model;
+//  (3) the adaptive models: bins of different contexts are independent chains.  The list is grouped by context (ballot per
+//      distinct context), lane t then replays segment t in order (BinProbModel_Std::estFracBitsUpdate), all chains in parallel.
+__device__ inline int lane_prefix(unsigned long long m)       // set bits of m below this lane
 {
-  w = uni(w); h = uni(h); last = uni(last);
-  for (int sp = lane; sp <= last; sp += 64) {
-    const int blk = scan[sp];
-    const int posY = blk / w, posX = blk - posY * w;
-    const int16_t *p = coeff + blk;
-    const int diag = posX + posY;
-    int numPos = 0, sumAbs = 0, sumPlain = 0;
-#define UPD(v) { int a = iabs(v); sumAbs += imin(4 + (a & 1), a); numPos += !!a; sumPlain += a; }
-    if (posX < w - 1) { UPD(p[1]); if (posX < w - 2) UPD(p[2]); if (posY < h - 1) UPD(p[w + 1]); }
-    if (posY < h - 1) { UPD(p[w]); if (posY < h - 2) UPD(p[w << 1]); }
-#undef UPD
-    int sigofs = imin((sumAbs + 1) >> 1, 3) + (diag < 2 ? 4 : 0);
-    if (!is_chroma) sigofs += diag < 5 ? 4 : 0;
-    int goff = imin(sumAbs - numPos, 4) + 1;
-    goff += (!diag ? (is_chroma ? 5 : 15) : !is_chroma ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
-    meta[sp] = (uint16_t) (sigofs | (goff << 5) | (imin(sumPlain, 63) << 10));
-  }
-  wave_sync();
+  return (int) __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u));
 }
-__device__ __noinline__ void rc_chain(Ctx *c, const uint16_t *bins, int nb, int lane, unsigned long long &bits)
+__device__ inline int prefix3(int v, int &total)               // exclusive prefix sum over the wave of a value in 0..7
+{
+  const unsigned long long b0 = __ballot(v & 1), b1 = __ballot(v & 2), b2 = __ballot(v & 4);
+  total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+  return lane_prefix(b0) + 2 * lane_prefix(b1) + 4 * lane_prefix(b2);
+}
+__device__ inline int rem_abs_len(unsigned bins, unsigned rice)   // bit count of enc_rem_abs (EL/BinEncoder.cpp:444-472)
+{
+  const unsigned thr = 5u << rice;
+  if (bins < thr) return (int) ((bins >> rice) + 1 + rice);
+  const unsigned maxPrefix = 32 - 5 - 15;
+  unsigned prefix = 0, suffix, code = (bins >> rice) - 5;
+  if (code >= ((1u << maxPrefix) - 1)) { prefix = maxPrefix; suffix = 15; }
+  else { while (code > ((2u << prefix) - 2)) prefix++; suffix = prefix + rice + 1; }
+  return (int) (5 + prefix + suffix);
+}
+#define RC_MAXJ 5             // pending list holds at most RC_MAXJ * 64 bins
+__device__ __noinline__ void rc_chain(Ctx *c, const uint16_t *bb, uint8_t *sorted, int nb, int lane, unsigned long long &bits)
 {
   nb = uni(nb);
-  for (int k = 0; k < nb; k++) {
-    const unsigned e = bins[k];
-    const int ctx = (int) (e >> 1);
-    if ((ctx & 63) == lane) {
-      const unsigned bin = e & 1;
-      unsigned a = c->s0[ctx], b = c->s1[ctx];
-      bits += L.t.bin_frac[(((a + b) >> 8) << 1) + bin];
-      const int rate = L.t.ctx_rate[ctx];
-      const int r0 = 2 + ((rate >> 2) & 3), r1 = 3 + r0 + (rate & 3);
-      a -= (a >> r0) & 0x7FE0u; b -= (b >> r1) & 0x7FFEu;
-      if (bin) { a += (0x7fffu >> r0) & 0x7FE0u; b += (0x7fffu >> r1) & 0x7FFEu; }
-      c->s0[ctx] = (uint16_t) a; c->s1[ctx] = (uint16_t) b;
-    }
+  int ctxv[RC_MAXJ]; unsigned binv[RC_MAXJ]; unsigned long long rem[RC_MAXJ];
+#pragma unroll
+  for (int j = 0; j < RC_MAXJ; j++) {
+    const int k = lane + 64 * j;
+    const unsigned e = (j * 64 < nb && k < nb) ? bb[k] : 0xffffu;
+    ctxv[j] = e == 0xffffu ? -1 : (int) (e >> 1); binv[j] = e & 1;
+    rem[j] = j * 64 < nb ? __ballot(ctxv[j] >= 0) : 0ull;
   }
-}
-// lane 0: emit the bins of coefficient groups sub, sub-1, ... while they fit the buffer; returns the next group to do
-__device__ __noinline__ void rc_emit(Cab &cb, const int16_t *coeff, int w, int h, int ch, const uint16_t *scan, const uint16_t *meta,
-                                     int scanPosLast, unsigned long long sigGroups, unsigned long long &sigPos, int first_call)
-{
-  const int wv = threadIdx.x >> 6;
-  uint16_t *bb = L.binbuf[wv];
-  int nb = 0;
-#define EMIT(bin_, ctx_) bb[nb++] = (uint16_t) (((ctx_) << 1) | (bin_))
-  int lcw, lch; cg_shape(w, h, lcw, lch);
-  const int lcg = lcw + lch, cgSize = 1 << lcg;
-  const int zw = imin(32, w), zh = imin(32, h), wg = zw >> lcw, hg = zh >> lch;
-  const uint8_t *gxs = L.scan_tab[wv] + 32, *gys = gxs + 64;
-  int sub = L.rc_sub[wv], regBins = L.rc_reg[wv];
-  if (first_call) {                                  // last_sig_coeff (4102-4160)
-    const int l2w = ilog2i(w), l2h = ilog2i(h);
-    int offx = 0, offy = 0, shx, shy;
-    if (ch) { shx = imin(2, w >> 3); shy = imin(2, h >> 3); }
-    else { offx = L.t.last_prefix[l2w]; offy = L.t.last_prefix[l2h]; shx = (l2w + 1) >> 2; shy = (l2h + 1) >> 2; }
-    const int blk = scan[scanPosLast];
-    const int posY = blk / w, posX = blk - posY * w;
-    const int gx = L.t.group_idx[posX], gy = L.t.group_idx[posY];
-    const int maxX = L.t.group_idx[zw - 1], maxY = L.t.group_idx[zh - 1];
-    int k;
-    for (k = 0; k < gx; k++) EMIT(1, VX_CTX_LastX[ch] + offx + (k >> shx));
-    if (gx < maxX) EMIT(0, VX_CTX_LastX[ch] + offx + (k >> shx));
-    for (k = 0; k < gy; k++) EMIT(1, VX_CTX_LastY[ch] + offy + (k >> shy));
-    if (gy < maxY) EMIT(0, VX_CTX_LastY[ch] + offy + (k >> shy));
-    if (gx > 3) enc_ep(cb, (gx - 2) >> 1);
-    if (gy > 3) enc_ep(cb, (gy - 2) >> 1);
-    regBins = (zw * zh * 28) >> 4;
-    sub = scanPosLast >> lcg;
-  }
-  const int sigBase = VX_CTX_SigFlag[ch], g1Base = VX_CTX_GtxFlag[ch + 2], g2Base = VX_CTX_GtxFlag[ch], parBase = VX_CTX_ParFlag[ch];
-  for (; sub >= 0 && nb + 4 * cgSize + 1 <= 160; sub--) {
-    const int cgX = gxs[sub], cgY = gys[sub], cgPos = cgY * wg + cgX;
-    const int minSub = sub << lcg, maxSub = minSub + cgSize - 1;
-    if ((sigGroups >> sub) & 1) sigPos |= 1ull << cgPos;
-    const int sigRight = (cgX + 1) < wg ? (int) ((sigPos >> (cgPos + 1)) & 1) : 0;
-    const int sigLower = (cgY + 1) < hg ? (int) ((sigPos >> (cgPos + wg)) & 1) : 0;
-    const int sigGroupCtx = VX_CTX_SigCoeffGroup[ch] + (sigRight | sigLower);
-    const int isLast = (scanPosLast >> lcg) == sub, isNotFirst = sub != 0;
-    const int firstSigPos = isLast ? scanPosLast : maxSub;
-    int nextSigPos = firstSigPos;
-    if (!isLast && isNotFirst) {
-      if ((sigPos >> cgPos) & 1) EMIT(1, sigGroupCtx);
-      else { EMIT(0, sigGroupCtx); continue; }
-    }
-    const int inferSigPos = nextSigPos != scanPosLast ? (isNotFirst ? minSub : -1) : nextSigPos;
-    int numNonZero = 0, remRegBins = regBins;
-    for (; nextSigPos >= minSub && remRegBins >= 4; nextSigPos--) {
-      const int cf = coeff[scan[nextSigPos]];
-      const unsigned m = meta[nextSigPos];
-      const unsigned sigFlag = cf != 0;
-      if (numNonZero || nextSigPos != inferSigPos) { EMIT(sigFlag, sigBase + (int) (m & 31)); remRegBins--; }
-      if (sigFlag) {
-        const int off = nextSigPos == scanPosLast ? 0 : (int) ((m >> 5) & 31);     // m_tmplCpDiag == -1 only for the very first coefficient
-        numNonZero++;
-        int rem = iabs(cf) - 1;
-        const unsigned gt1 = !!rem;
-        EMIT(gt1, g1Base + off); remRegBins--;
-        if (gt1) {
-          rem -= 1;
-          EMIT(rem & 1, parBase + off); rem >>= 1; remRegBins--;
-          EMIT(!!rem, g2Base + off); remRegBins--;
-        }
+  int segpos = 0;
+  for (;;) {
+    int nseg = 0, myctx = 0, mystart = 0, mylen = 0;
+    for (;;) {                                           // group the pending bins by context, first occurrence first
+      int v = -1;
+#pragma unroll
+      for (int j = 0; j < RC_MAXJ; j++) if (v < 0 && rem[j]) v = __builtin_amdgcn_readlane(ctxv[j], __ffsll(rem[j]) - 1);
+      if (v < 0) break;
+      const int start = segpos;
+#pragma unroll
+      for (int j = 0; j < RC_MAXJ; j++) if (rem[j]) {
+        const unsigned long long m = __ballot(ctxv[j] == v);
+        if (ctxv[j] == v) sorted[segpos + lane_prefix(m)] = (uint8_t) binv[j];
+        segpos += __popcll(m); rem[j] &= ~m;
       }
+      if (lane == nseg) { myctx = v; mystart = start; mylen = segpos - start; }
+      if (++nseg == 64) break;
     }
-    const int firstPosMode2 = nextSigPos;
-    regBins = remRegBins;
-    for (int sp = firstSigPos; sp > firstPosMode2; sp--) {
-      const unsigned a = (unsigned) iabs(coeff[scan[sp]]);
-      if (a >= 4) { const int sum = (int) (meta[sp] >> 10); enc_rem_abs(cb, (a - 4) >> 1, L.t.gorice_pars[imax(imin(sum - 20, 31), 0)]); }
+    if (nseg == 0) break;
+    wave_sync();
+    if (lane < nseg) {
+      unsigned a = c->s0[myctx], b = c->s1[myctx];
+      const int rate = L.t.ctx_rate[myctx];
+      const int r0 = 2 + ((rate >> 2) & 3), r1 = 3 + r0 + (rate & 3);
+      const unsigned i0 = (0x7fffu >> r0) & 0x7FE0u, i1 = (0x7fffu >> r1) & 0x7FFEu;
+      unsigned acc = 0;
+      for (int k = 0; k < mylen; k++) {
+        const unsigned bin = sorted[mystart + k];
+        acc += L.t.bin_frac[(((a + b) >> 8) << 1) + bin];
+        a -= (a >> r0) & 0x7FE0u; b -= (b >> r1) & 0x7FFEu;
+        if (bin) { a += i0; b += i1; }
+      }
+      c->s0[myctx] = (uint16_t) a; c->s1[myctx] = (uint16_t) b;
+      bits += acc;
     }
-    for (int sp = firstPosMode2; sp >= minSub; sp--) {
-      const unsigned a = (unsigned) iabs(coeff[scan[sp]]);
-      const int sumAll = imin((int) (meta[sp] >> 10), 31);
-      const unsigned rice = L.t.gorice_pars[sumAll], pos0 = L.t.gorice_pos0[sumAll];
-      enc_rem_abs(cb, a == 0 ? pos0 : a <= pos0 ? a - 1 : a, rice);
-      if (a) numNonZero++;
-    }
-    enc_ep(cb, numNonZero);
+    wave_sync();
+    if (nseg < 64) break;
   }
-#undef EMIT
-  L.rc_nb[wv] = nb; L.rc_sub[wv] = sub; L.rc_reg[wv] = regBins;
 }
-// scan: uint16[<=1024] followed by meta: uint16[<=1024] (one 4 KB per-wave scratch)
 __device__ void residual_coding_wave(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, uint16_t *scan, int lane)
 {
   const long long q0 = STAMP();
-  const RcPre pre = rc_prepass<true>(coeff, w, h, scan, lane);
+  const RcPre pre = rc_prepass_wave(coeff, w, h, lane);
   const int last = uni(pre.last);
   if (last < 0) return;
-  uint16_t *meta = scan + 1024;
+  w = uni(w); h = uni(h); is_chroma = uni(is_chroma);
+  const ScanGeo geo = scan_geo(w, h);
   const long long q1 = STAMP();
-  rc_meta_pass(coeff, w, h, is_chroma, scan, meta, last, lane);
-  const long long q2 = STAMP();
   long long qe = 0, qc = 0;
   const int wv = uni(threadIdx.x >> 6);
-  unsigned long long sigPos = 0, mybits = 0;
-  int first = 1, sub = 0;
-  do {
+  uint16_t *bb = L.binbuf[wv]; uint8_t *sorted = L.binsort[wv];
+  const int lcg = geo.lcg, cgSize = 1 << lcg;
+  const int zw = imin(32, w), zh = imin(32, h), wg = geo.wg, hg = geo.hg;
+  const unsigned long long sigGroups = pre.sig_groups, sigRaster = pre.sig_raster;
+  unsigned long long mybits = 0;
+  int nb;
+  {                                                    // last_sig_coeff (4102-4160): one bin per lane
+    const int l2w = ilog2i(w), l2h = ilog2i(h);
+    int offx = 0, offy = 0, shx, shy;
+    if (is_chroma) { shx = imin(2, w >> 3); shy = imin(2, h >> 3); }
+    else { offx = L.t.last_prefix[l2w]; offy = L.t.last_prefix[l2h]; shx = (l2w + 1) >> 2; shy = (l2h + 1) >> 2; }
+    const int blk = scan_blk(geo, last);
+    const int posY = blk / w, posX = blk - posY * w;
+    const int gx = uni(L.t.group_idx[posX]), gy = uni(L.t.group_idx[posY]);
+    const int maxX = L.t.group_idx[zw - 1], maxY = L.t.group_idx[zh - 1];
+    const int nX = gx + (gx < maxX), nY = gy + (gy < maxY);
+    if (lane < nX) bb[lane] = (uint16_t) (((VX_CTX_LastX[is_chroma] + offx + (lane >> shx)) << 1) | (lane < gx));
+    if (lane < nY) bb[nX + lane] = (uint16_t) (((VX_CTX_LastY[is_chroma] + offy + (lane >> shy)) << 1) | (lane < gy));
+    if (lane == 0) mybits += (unsigned long long) ((gx > 3 ? (gx - 2) >> 1 : 0) + (gy > 3 ? (gy - 2) >> 1 : 0)) << 15;
+    nb = nX + nY;
+  }
+  const int sigBase = VX_CTX_SigFlag[is_chroma], g1Base = VX_CTX_GtxFlag[is_chroma + 2], g2Base = VX_CTX_GtxFlag[is_chroma], parBase = VX_CTX_ParFlag[is_chroma];
+  const int grpBase = VX_CTX_SigCoeffGroup[is_chroma];
+  int regBins = (zw * zh * 28) >> 4;
+  const int lastCG = last >> lcg;
+  const unsigned long long ltMask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int c = last >> 6; c >= 0; c--) {
     const long long e0 = STAMP();
-    if (lane == 0) rc_emit(cb, coeff, w, h, is_chroma, scan, meta, last, pre.sig_groups, sigPos, first);
-    first = 0;
+    const int sp = c * 64 + 63 - lane;
+    const bool active = sp <= last;
+    const int sub = sp >> lcg, inCG = (cgSize - 1) - (sp & (cgSize - 1));      // inCG 0 = first position of its group in coding order
+    const bool isLastCG = sub == lastCG, notFirst = sub != 0;
+    const bool coded = active && (isLastCG || !notFirst || ((sigGroups >> sub) & 1));
+    int cf = 0, sigofs = 0, goff = 0, sumPlain = 0;
+    if (coded) {
+      const int blk = scan_blk(geo, sp);
+      const int posY = blk / w, posX = blk - posY * w;
+      const int16_t *pc = coeff + blk;
+      cf = pc[0];
+      const int diag = posX + posY;
+      int numPos = 0, sumAbs = 0;
+#define UPD(v) { int a_ = iabs(v); sumAbs += imin(4 + (a_ & 1), a_); numPos += !!a_; sumPlain += a_; }
+      if (posX < w - 1) { UPD(pc[1]); if (posX < w - 2) UPD(pc[2]); if (posY < h - 1) UPD(pc[w + 1]); }
+      if (posY < h - 1) { UPD(pc[w]); if (posY < h - 2) UPD(pc[w << 1]); }
+#undef UPD
+      sigofs = imin((sumAbs + 1) >> 1, 3) + (diag < 2 ? 4 : 0);
+      if (!is_chroma) sigofs += diag < 5 ? 4 : 0;
+      goff = imin(sumAbs - numPos, 4) + 1;
+      goff += (!diag ? (is_chroma ? 5 : 15) : !is_chroma ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
+      if (sp == last) goff = 0;                          // m_tmplCpDiag == -1 only for the very first coefficient
+    }
+    const int a = iabs(cf);
+    const unsigned long long nz = __ballot(coded && a != 0);
+    const int cgStart = lane - inCG;
+    const unsigned long long cgLt = ltMask & ~(cgStart <= 0 ? 0ull : (~0ull >> (64 - cgStart)));
+    const bool nzBefore = (nz & cgLt) != 0;
+    const int infer = isLastCG ? last : (notFirst ? (sub << lcg) : -1);
+    const bool sigCoded = coded && (nzBefore || sp != infer);
+    const int nbins = coded ? ((sigCoded ? 1 : 0) + (a ? (a > 1 ? 3 : 1) : 0)) : 0;
+    int tot;
+    const int before = prefix3(nbins, tot);
+    const bool ctxMode = coded && (regBins - before >= 4);          // the budget test of 4187 is a prefix condition
+    const int eff = ctxMode ? nbins : 0;
+    int used; prefix3(eff, used);
+    const bool gflag = active && inCG == 0 && !isLastCG && notFirst;
+    int o = nb + prefix3(eff + (gflag ? 1 : 0), tot);
+    if (gflag) {
+      const int cgX = geo.grp[sub] & 15, cgY = geo.grp[sub] >> 4, cgPos = cgY * wg + cgX;
+      const int sigRight = (cgX + 1) < wg ? (int) ((sigRaster >> (cgPos + 1)) & 1) : 0;
+      const int sigLower = (cgY + 1) < hg ? (int) ((sigRaster >> (cgPos + wg)) & 1) : 0;
+      bb[o++] = (uint16_t) (((grpBase + (sigRight | sigLower)) << 1) | (int) ((sigGroups >> sub) & 1));
+    }
+    int ep = (coded && a) ? 1 : 0;                        // sign
+    if (ctxMode) {
+      if (sigCoded) bb[o++] = (uint16_t) (((sigBase + sigofs) << 1) | (a != 0));
+      if (a) {
+        bb[o++] = (uint16_t) (((g1Base + goff) << 1) | (a > 1));
+        if (a > 1) {
+          bb[o++] = (uint16_t) (((parBase + goff) << 1) | ((a - 2) & 1));
+          bb[o++] = (uint16_t) (((g2Base + goff) << 1) | (((a - 2) >> 1) != 0));
+          if (a >= 4) ep += rem_abs_len((unsigned) (a - 4) >> 1, L.t.gorice_pars[imax(imin(sumPlain - 20, 31), 0)]);
+        }
+      }
+    } else if (coded) {
+      const int sumAll = imin(sumPlain, 31);
+      const unsigned rice = L.t.gorice_pars[sumAll], pos0 = L.t.gorice_pos0[sumAll];
+      ep += rem_abs_len(a == 0 ? pos0 : (unsigned) a <= pos0 ? (unsigned) a - 1 : (unsigned) a, rice);
+    }
+    mybits += (unsigned long long) ep << 15;
+    regBins -= used; nb += tot;
     wave_sync();
     const long long e1 = STAMP();
-    const int nb = uni(L.rc_nb[wv]);
-    sub = uni(L.rc_sub[wv]);
-    rc_chain(cb.c, L.binbuf[wv], nb, lane, mybits);
-    wave_sync();
+    rc_chain(cb.c, bb, sorted, nb, lane, mybits);
+    nb = 0;
     qe += e1 - e0; qc += STAMP() - e1;
-  } while (sub >= 0);
+  }
   const long long q3 = STAMP();
-  unsigned lo = (unsigned) mybits, hi = (unsigned) (mybits >> 32);      // per-TU totals fit 32 bits per lane; keep 64 for safety
-  unsigned long long tot = mybits;
-  for (int m = 32; m >= 1; m >>= 1) { const unsigned a = __shfl_xor(lo, m), b = __shfl_xor(hi, m); tot += ((unsigned long long) b << 32) | a; lo = (unsigned) tot; hi = (unsigned) (tot >> 32); }
+  const unsigned long long tot = wave_sum_u64(mybits);
   if (lane == 0) cb.bits += tot;
-  if (VVCX_STAMP && threadIdx.x == 0) { L.prof[32] += (unsigned long long) (q1 - q0); L.prof[33] += (unsigned long long) (q2 - q1); L.prof[34] += (unsigned long long) qe; L.prof[35] += (unsigned long long) qc; L.prof[36] += (unsigned long long) (STAMP() - q3); L.prof[37] += 1; }
+  if (VVCX_STAMP && threadIdx.x == 0) { L.prof[32] += (unsigned long long) (q1 - q0); L.prof[34] += (unsigned long long) qe; L.prof[35] += (unsigned long long) qc; L.prof[36] += (unsigned long long) (STAMP() - q3); L.prof[37] += 1; }
 }
 
 // ------------------------------------------------------------------------------------------------ partitioner (thread 0)
@@ -991,8 +1070,7 @@ __device__ inline void sad_satd_tiles(const int16_t *org, const int16_t *pred, i
 #pragma unroll
       for (int r = 0; r < BH; r++) s += iabs(v[r]);
     }
-#pragma unroll
-    for (int m = 1; m < BW; m <<= 1) s += __shfl_xor(s, m);       // tile total on every lane of the group
+    s = seg_sum<BW>(s);                                           // tile total on every lane of the group
     if (q < ncols && (lane & (BW - 1)) == 0) {
       int n;
       if (BW == 2) n = s;                                 // CL/RdCost.cpp:2110-2115
@@ -1021,10 +1099,9 @@ __device__ __noinline__ void wave_sad_satd(const int16_t *org, const int16_t *pr
     case 404:  sad_satd_tiles<4, 4>(org, pred, w, P, scr, lane, a, b); break;
     default:   sad_satd_tiles<2, 2>(org, pred, w, P, scr, lane, a, b); break;
   }
-  // both sums fit 32 bits (<= 4096 * 1023 * 16): two independent 32-bit butterflies
-  for (int m = 32; m >= 1; m >>= 1) { const int ta = __shfl_xor(a, m), tb = __shfl_xor(b, m); a += ta; b += tb; }
-  sad_out = (unsigned long long) (unsigned) a;
-  satd_out = (unsigned long long) (unsigned) b;
+  // both sums fit 32 bits (<= 4096 * 1023 * 16)
+  sad_out = (unsigned long long) (unsigned) wave_sum_i32(a);
+  satd_out = (unsigned long long) (unsigned) wave_sum_i32(b);
 }
 
 // ------------------------------------------------------------------------------------------------ transform + quant (one wave)
@@ -1044,6 +1121,17 @@ __device__ void load_tables()
   if (tid < 64) L.t.group_idx[tid] = VX_GROUP_IDX[tid];
   if (tid < 36) L.t.mode_num[tid] = VX_MODE_NUM_FAST_2D[tid];
   if (tid < 8) { L.t.intra_thr[tid] = INTRA_FILTER_THR[tid]; L.t.last_prefix[tid] = LAST_PREFIX_CTX[tid]; L.t.mode_shift[tid] = MODE_SHIFT[tid]; }
+  if (tid < 52) {
+    const int t = tid < 16 ? 0 : tid < 20 ? 1 : tid < 36 ? 2 : 3, n = tid - (t == 0 ? 0 : t == 1 ? 16 : t == 2 ? 20 : 36);
+    int x, y; diag_walk(t == 0 ? 4 : t == 2 ? 8 : 2, t == 0 ? 4 : t == 3 ? 8 : 2, n, x, y);
+    L.t.cg_scan[tid] = (uint8_t) (x | (y << 4));
+  }
+  for (int i = tid; i < 225; i += NT) {
+    int a = 0, b = 0, off = 0;                           // table of (lwg = a, lhg = b) starts at 15 (2^a - 1) + 2^a (2^b - 1)
+    for (int aa = 0; aa < 4; aa++) for (int bb = 0; bb < 4; bb++) { const int o = 15 * ((1 << aa) - 1) + (1 << aa) * ((1 << bb) - 1); if (o <= i) { a = aa; b = bb; off = o; } }
+    int x, y; diag_walk(1 << a, 1 << b, i - off, x, y);
+    L.t.grp_scan[i] = (uint8_t) (x | (y << 4));
+  }
   for (int i = tid; i < 4; i += NT) L.t.dct[i] = VX_DCT2_2[i];
   for (int i = tid; i < 16; i += NT) L.t.dct[4 + i] = VX_DCT2_4[i];
   for (int i = tid; i < 64; i += NT) L.t.dct[20 + i] = VX_DCT2_8[i];
@@ -1189,7 +1277,11 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
   int16_t *pred = &L.slot[wave][0];
   int16_t *scr = (int16_t *) L.tmp[wave];
   const int bd = p.bit_depth;
-  for (int c0 = c_begin + wave * G; c0 < c_end; c0 += NW * G) {
+  // mode bits of all candidates of this wave up front, one candidate per lane: lane l serves step l / G, slot l % G
+  unsigned long long mbits = 0;
+  { const int cc = c_begin + wave * G + (lane / G) * (NW * G) + (lane % G); if (cc < c_end) mbits = luma_mode_bits(L.cur, L.ny, L.cand[cc].mode, L.cand[cc].mrl); }
+  int step = 0;
+  for (int c0 = c_begin + wave * G; c0 < c_end; c0 += NW * G, step++) {
     const int c = c0 + sub;
     const bool valid = c < c_end;
     const int mode = valid ? L.cand[c].mode : 0, mrl = valid ? L.cand[c].mrl : 0;
@@ -1207,8 +1299,7 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
 #pragma unroll
       for (int i = 0; i < BW; i++) scr[sr * P + r * BW + i] = (int16_t) v[i];
     }
-#pragma unroll
-    for (int m = 1; m < BH; m <<= 1) sad += __shfl_xor(sad, m);
+    sad = seg_sum<BH>(sad);
     wave_sync();
     int s = 0;
     if (lane < G * BW) {                                 // one column of one candidate per lane
@@ -1220,17 +1311,15 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
 #pragma unroll
       for (int r = 0; r < BH; r++) s += iabs(v[r]);
     }
-#pragma unroll
-    for (int m = 1; m < BW; m <<= 1) s += __shfl_xor(s, m);
+    s = seg_sum<BW>(s);
     if (lane < G * BH && (lane % BH) == 0) L.acc[wave][lane / BH][0] = sad;
     if (lane < G * BW && (lane % BW) == 0)
       L.acc[wave][lane / BW][1] = (BW == 4 && BH == 4) ? (s + 1) >> 1 : (int) ((double) s / 0x1.6a09e667f3bcdp+2 * 2);   // CL/RdCost.cpp:2209,2662,2741
     wave_sync();
-    if (lane < G && c0 + lane < c_end) {
-      const int cc = c0 + lane;
-      const unsigned long long sd = (unsigned long long) (unsigned) L.acc[wave][lane][0], st = (unsigned long long) (unsigned) L.acc[wave][lane][1];
+    if (lane / G == step && c0 + lane % G < c_end) {
+      const int q = lane % G, cc = c0 + q;
+      const unsigned long long sd = (unsigned long long) (unsigned) L.acc[wave][q][0], st = (unsigned long long) (unsigned) L.acc[wave][q][1];
       const unsigned long long msh = sd * 2 < st ? sd * 2 : st;
-      const unsigned long long mbits = luma_mode_bits(L.cur, L.ny, L.cand[cc].mode, L.cand[cc].mrl);
       const double a = (double) mbits * p.sqrt_lambda_fp;
       L.cand_cost[cc] = (double) msh + a;
       L.cand_had[cc] = (double) msh;
@@ -1251,8 +1340,11 @@ __device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
     if (w == 4 && h == 4) stage_a_small<4, 4>(p, wave, lane, uni(L.op_a), c_end);
     else if (w == 8) stage_a_small<8, 4>(p, wave, lane, uni(L.op_a), c_end);
     else stage_a_small<4, 8>(p, wave, lane, uni(L.op_a), c_end);
-  } else
-  for (int c = uni(L.op_a) + wave; c < c_end; c += NW) {
+  } else {
+  unsigned long long mbits = 0;                         // mode bits of this wave's candidates up front, lane j serves step j
+  { const int cc = uni(L.op_a) + wave + lane * NW; if (cc < c_end) mbits = luma_mode_bits(L.cur, L.ny, L.cand[cc].mode, L.cand[cc].mrl); }
+  int step = 0;
+  for (int c = uni(L.op_a) + wave; c < c_end; c += NW, step++) {
     const int mode = uni(L.cand[c].mode), mrl = uni(L.cand[c].mrl);
     Ipa ip; init_pred_params(w, h, 1, mode, mrl, ip);
     const int set = luma_set(mrl, ip.ref_filter);
@@ -1265,14 +1357,14 @@ __device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
     unsigned long long sad, satd;
     wave_sad_satd(L.org, pred, w, h, scr, lane, sad, satd);
     if (VVCX_STAMP && threadIdx.x == 0) { const long long tc = STAMP(); L.prof[15] += (unsigned long long) (tb - ta); L.prof[11] += (unsigned long long) (tc - tb); }
-    if (lane == 0) {
+    if (lane == step) {
       const unsigned long long msh = sad * 2 < satd ? sad * 2 : satd;
-      const unsigned long long mbits = luma_mode_bits(L.cur, L.ny, mode, mrl);
       const double a = (double) mbits * p.sqrt_lambda_fp;
       L.cand_cost[c] = (double) msh + a;
       L.cand_had[c] = (double) msh;
     }
     wave_sync();
+  }
   }
   __syncthreads();
   // updateCandList (CL/UnitTools.h:261-306) over a stream of candidates keeps the numRd cheapest with ties to the
@@ -1337,7 +1429,7 @@ __device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
       L.rd_cost[c] = cost; L.rd_dist[c] = sse; L.rd_bits[c] = cb.bits; L.rd_cbf[c] = (uint8_t) cbf;
     }
     if (VVCX_STAMP && threadIdx.x == 0) { const long long tb3 = STAMP(); L.prof[28] += (unsigned long long) (tb1 - tb0); L.prof[29] += (unsigned long long) (tb2 - tb1); L.prof[31] += (unsigned long long) (tb3 - tb2); }
-    cost = uni_d(__shfl(cost, 0));
+    cost = lane0_d(cost);
     if (cost < wbest) {
       wbest = cost;
       if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = cur; }
@@ -1417,7 +1509,7 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
         L.rd_cost[c] = cost; L.rd_dist[c] = dist; L.rd_cbf[c] = (uint8_t) ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 4 : 0));
       }
     }
-    cost = uni_d(__shfl(cost, 0));
+    cost = lane0_d(cost);
     if (cost < wbest) { wbest = cost; if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = cur; } cur ^= 1; }
     wave_sync();
   }
@@ -2096,5 +2188,5 @@ __device__ void run_stream(const VxParams &p)
   if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); for (int i = 0; i < 48; i++) atomicAdd(&p.counters[4 + i], L.prof[i]); }
 }
 
-extern "C" __global__ void __launch_bounds__(NT) vvcx_compress_kernel_u8(VxParams p) { run_stream<uint8_t>(p); }
-extern "C" __global__ void __launch_bounds__(NT) vvcx_compress_kernel_u16(VxParams p) { run_stream<uint16_t>(p); }
+extern "C" __global__ void __launch_bounds__(NT, 2) vvcx_compress_kernel_u8(VxParams p) { run_stream<uint8_t>(p); }
+extern "C" __global__ void __launch_bounds__(NT, 2) vvcx_compress_kernel_u16(VxParams p) { run_stream<uint16_t>(p); }

@@ -70,6 +70,38 @@ template <typename T> inline T __shfl(T v, int src) { return hipemu::shfl_idx(v,
 inline long long clock64() { return 0; }
 inline long long wall_clock64() { return 0; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+inline unsigned long long __ballot(int pred)
+{
+  hipemu::Block &b = *hipemu::g_block; const unsigned w = hipemu::g_cur->tidx.x >> 6, l = hipemu::g_cur->tidx.x & 63;
+  unsigned nw = b.n - w * 64; if (nw > 64) nw = 64;
+  b.wslot[w][l] = pred ? 1 : 0; hipemu::wave_barrier();
+  unsigned long long m = 0; for (unsigned i = 0; i < nw; i++) m |= (unsigned long long) (b.wslot[w][i] & 1) << i;
+  hipemu::wave_barrier();
+  return m;
+}
+inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned m, unsigned base) { const unsigned l = hipemu::g_cur->tidx.x & 63; return base + (unsigned) __builtin_popcount(m & (l >= 32 ? 0xffffffffu : ((1u << l) - 1))); }
+inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned m, unsigned base) { const unsigned l = hipemu::g_cur->tidx.x & 63; return base + (unsigned) __builtin_popcount(m & (l <= 32 ? 0u : ((1u << (l - 32)) - 1))); }
+inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu::shfl_idx(v, lane); }
+// DPP controls used by the kernel's wave reductions: quad_perm (0x00-0xFF), row_ror (0x121-0x12F), row_bcast15/31 (0x142/0x143)
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+  hipemu::Block &b = *hipemu::g_block; const unsigned w = hipemu::g_cur->tidx.x >> 6, l = hipemu::g_cur->tidx.x & 63;
+  b.wslot[w][l] = (uint64_t) (uint32_t) src; hipemu::wave_barrier();
+  int sl = -1;
+  if (ctrl <= 0xFF) sl = (int) ((l & ~3u) | ((unsigned) (ctrl >> (2 * (l & 3))) & 3));
+  else if (ctrl >= 0x121 && ctrl <= 0x12F) sl = (int) ((l & ~15u) | ((l - (unsigned) (ctrl & 15)) & 15));
+  else if (ctrl == 0x140) sl = (int) ((l & ~15u) | (15 - (l & 15)));          // row_mirror
+  else if (ctrl == 0x141) sl = (int) ((l & ~7u) | (7 - (l & 7)));             // row_half_mirror
+  else if (ctrl == 0x142) sl = (l >> 4) >= 1 ? (int) (((l >> 4) - 1) * 16 + 15) : -1;
+  else if (ctrl == 0x143) sl = (l >> 4) >= 2 ? 31 : -1;
+  const bool en = ((row_mask >> (l >> 4)) & 1) && ((bank_mask >> ((l >> 2) & 3)) & 1);
+  const int r = !en ? old : (sl >= 0 ? (int) (uint32_t) b.wslot[w][sl] : (bound_ctrl ? 0 : old));
+  hipemu::wave_barrier();
+  return r;
+}
+inline int __clzll(long long v) { return v == 0 ? 64 : __builtin_clzll((unsigned long long) v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long) v); }
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned) v); }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
 
