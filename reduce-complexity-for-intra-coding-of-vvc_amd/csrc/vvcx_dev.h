@@ -59,7 +59,7 @@ struct VxParams {
 #define VXD_CTXSNAP     (2 * VXD_NUM_CTX * 2)                                 // s0 + s1
 #define VXD_OFF_STORE   0
 #define VXD_OFF_CTX     (VXD_OFF_STORE + VXD_MAXD * VXD_STORE_LEVEL)          // [MAXD + NW + 1][2] snapshots {start, best}: levels, per-wave parking, CTU start
-#define VXD_OFF_SLOTS   (VXD_OFF_CTX + (VXD_MAXD + VXD_NW + 1) * 2 * VXD_CTXSNAP) // big-block slots: [NW][2][2*4096] int16
+#define VXD_OFF_SLOTS   ((VXD_OFF_CTX + (VXD_MAXD + VXD_NW + 1) * 2 * VXD_CTXSNAP + 255) & ~255) // big-block slots: [NW][2][2*4096] int16
 #define VXD_SLOT_ELEMS  (2 * 4096)
 #define VXD_OFF_TMP     (VXD_OFF_SLOTS + VXD_NW * 2 * VXD_SLOT_ELEMS * 2)             // big-block transform scratch: [NW][2048] int32
 // CU-result cache of the current CTU (BestEncInfoCache, EL/EncModeCtrl.cpp:663-1110): one entry per (position in CTU in

@@ -46,7 +46,8 @@ enum { PH_ENTER, PH_RUN, PH_A1_DONE, PH_A2_DONE, PH_B_DONE, PH_INTRA_SAVED, PH_C
 enum { CTX_CUR = 0, CTX_START = 1, CTX_BEST = 2, CTX_WAVE = 3 };   // OP_CTX_COPY endpoints
 
 struct Ctx { uint16_t s0[NCTX], s1[NCTX]; };
-struct Cab { Ctx *c; uint64_t bits; };
+struct Cab { int ci; uint64_t bits; };   // ci: index into L.ctxs (the estimator a syntax function writes to); an index, not a pointer, so that
+                                          // every model access is an LDS instruction and not a generic-address one
 
 struct Sum {                       // what the mode controller reads from a CodingStructure
   double cost; uint64_t dist, bits;
@@ -88,17 +89,18 @@ struct Tables {                    // constant tables staged once per workgroup 
 };
 
 #define RC_LIST 320
+#define CI_CUR 0
+#define CI_W(w) (1 + (w))
+#define CI_PARK(w) (1 + NW + (w))
 struct Lds {
   Tables t;
-  Ctx cur;                         // the estimator's contexts
-  Ctx wctx[NW];                    // per-wave working copies
-  Ctx wpark[NW];                   // end-of-candidate contexts of each wave's best full-RD candidate
-  int16_t org[4096];               // node's original tile: luma w*h, or Cb | Cr (cw*ch each)
-  uint16_t binbuf[NW][RC_LIST]; uint8_t binsort[NW][RC_LIST];        // residual_coding_wave: pending (ctx<<1|bin) list; bins grouped by context
+  Ctx ctxs[1 + 2 * NW];            // [0] the estimator's contexts, [1 + w] per-wave working copy, [1 + NW + w] end-of-candidate contexts of wave w's best
+  alignas(16) int16_t org[4096];   // node's original tile: luma w*h, or Cb | Cr (cw*ch each)
+  uint16_t binbuf[NW][RC_LIST]; uint8_t binsort[NW][RC_LIST + 8];        // residual_coding_wave: pending (ctx<<1|bin) list; bins grouped by context
   int acc[NW][4][2];               // small-block SATD stage: per packed candidate {SAD, SATD}
   int16_t refs[4][2][140];         // luma: set 0 mrl0 unfiltered, 1 mrl0 filtered, 2 mrl1, 3 mrl3; chroma: set 0 Cb, 1 Cr. [0]=top [1]=left
-  int32_t tmp[NW][1024];           // per-wave transform / Hadamard / scan scratch (blocks needing more use HBM scratch)
-  int16_t slot[NW][2048];          // per-wave candidate slot 0: rec[1024] | lev[1024] (slot 1 and big blocks live in HBM scratch)
+  alignas(16) int32_t tmp[NW][1024];           // per-wave transform / Hadamard / scan scratch (blocks needing more use HBM scratch)
+  alignas(16) int16_t slot[NW][2048];          // per-wave candidate slot 0: rec[1024] | lev[1024] (slot 1 and big blocks live in HBM scratch)
   uint8_t flags[72]; int8_t src_unit[72];
   Frame fr[MAXD];
   // posted operation
@@ -189,7 +191,7 @@ template <typename T> __device__ inline void st_px(void *plane, int idx, int v) 
 // BinProbModel_Std + BitEstimator (CL/Contexts.h:86-155, EL/BinEncoder.h:238-303)
 __device__ inline void enc_bin(Cab &cb, unsigned bin, int ctx)
 {
-  Ctx *c = cb.c;
+  Ctx *c = &L.ctxs[cb.ci];
   const unsigned st = (unsigned) (c->s0[ctx] + c->s1[ctx]) >> 8;
   cb.bits += L.t.bin_frac[st * 2 + bin];
   const int rate = L.t.ctx_rate[ctx];
@@ -301,9 +303,14 @@ __device__ __noinline__ RcPre rc_prepass_serial(const int16_t *coeff, int w, int
   return r;
 }
 // wave pre-pass: 64 scan positions per step, last position and group significance from the ballot of "coefficient != 0"
-__device__ __noinline__ RcPre rc_prepass_wave(const int16_t *coeff, int w, int h, int lane)
+// SMALL: the levels are the calling wave's LDS slot (L.slot[wave] + 1024 + lev_off); else coeff_g (HBM).  The LDS pointer is formed
+// from L inside the function: a pointer handed through a call is a generic one and every access through it a flat_ instruction
+// (longer path to LDS, and its completion can only be awaited with vmcnt(0) + lgkmcnt(0)).
+template <bool SMALL>
+__device__ __noinline__ RcPre rc_prepass_wave(int lev_off, const int16_t *coeff_g, int w, int h, int lane)
 {
   w = uni(w); h = uni(h);
+  const int16_t *coeff = SMALL ? L.slot[uni(threadIdx.x >> 6)] + 1024 + uni(lev_off) : coeff_g;
   const ScanGeo g = scan_geo(w, h);
   int last = -1; unsigned long long sig = 0;
   const int gpi = 64 >> g.lcg;                           // groups per step
@@ -444,9 +451,10 @@ __device__ inline int rem_abs_len(unsigned bins, unsigned rice)   // bit count o
   return (int) (5 + prefix + suffix);
 }
 #define RC_MAXJ 5             // pending list holds at most RC_MAXJ * 64 bins
-__device__ __noinline__ void rc_chain(Ctx *c, const uint16_t *bb, uint8_t *sorted, int nb, int lane, unsigned long long &bits)
+__device__ __noinline__ void rc_chain(int ci, int wv, int nb, int lane, unsigned long long &bits)
 {
-  nb = uni(nb);
+  nb = uni(nb); ci = uni(ci); wv = uni(wv);
+  Ctx *c = &L.ctxs[ci]; const uint16_t *bb = L.binbuf[wv]; uint8_t *sorted = L.binsort[wv];
   int ctxv[RC_MAXJ]; unsigned binv[RC_MAXJ]; unsigned long long rem[RC_MAXJ];
 #pragma unroll
   for (int j = 0; j < RC_MAXJ; j++) {
@@ -480,24 +488,30 @@ __device__ __noinline__ void rc_chain(Ctx *c, const uint16_t *bb, uint8_t *sorte
       const int rate = L.t.ctx_rate[myctx];
       const int r0 = 2 + ((rate >> 2) & 3), r1 = 3 + r0 + (rate & 3);
       const unsigned i0 = (0x7fffu >> r0) & 0x7FE0u, i1 = (0x7fffu >> r1) & 0x7FFEu;
-      unsigned acc = 0;
+      // the only loop-carried chain is the state update: the next bin is fetched one step ahead and the fractional-bit
+      // lookup of a step is consumed one step later, so no LDS latency sits on it
+      unsigned acc = 0, pend = 0, nxt = sorted[mystart];
       for (int k = 0; k < mylen; k++) {
-        const unsigned bin = sorted[mystart + k];
-        acc += L.t.bin_frac[(((a + b) >> 8) << 1) + bin];
+        const unsigned bin = nxt;
+        nxt = sorted[mystart + k + 1];
+        acc += pend;
+        pend = L.t.bin_frac[(((a + b) >> 8) << 1) + bin];
         a -= (a >> r0) & 0x7FE0u; b -= (b >> r1) & 0x7FFEu;
         if (bin) { a += i0; b += i1; }
       }
       c->s0[myctx] = (uint16_t) a; c->s1[myctx] = (uint16_t) b;
-      bits += acc;
+      bits += acc + pend;
     }
     wave_sync();
     if (nseg < 64) break;
   }
 }
-__device__ void residual_coding_wave(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, uint16_t *scan, int lane)
+template <bool SMALL>
+__device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const int16_t *coeff_g, int w, int h, int is_chroma, int lane)
 {
   const long long q0 = STAMP();
-  const RcPre pre = rc_prepass_wave(coeff, w, h, lane);
+  const int16_t *coeff = SMALL ? L.slot[uni(threadIdx.x >> 6)] + 1024 + uni(lev_off) : coeff_g;
+  const RcPre pre = rc_prepass_wave<SMALL>(lev_off, coeff_g, w, h, lane);
   const int last = uni(pre.last);
   if (last < 0) return;
   w = uni(w); h = uni(h); is_chroma = uni(is_chroma);
@@ -597,7 +611,7 @@ __device__ void residual_coding_wave(Cab &cb, const int16_t *coeff, int w, int h
     regBins -= used; nb += tot;
     wave_sync();
     const long long e1 = STAMP();
-    rc_chain(cb.c, bb, sorted, nb, lane, mybits);
+    rc_chain(cb.ci, wv, nb, lane, mybits);
     nb = 0;
     qe += e1 - e0; qc += STAMP() - e1;
   }
@@ -625,8 +639,9 @@ __device__ int implicit_split(const VxParams &p, Frame &f, int ch)      // CL/Un
   f.impl_checked = 1; f.impl_split = (uint8_t) split;
   return split;
 }
-__device__ __noinline__ void can_split(const VxParams &p, Frame &f, int ch, int can[6])   // CL/UnitPartitioner.cpp:379-466
+__device__ __noinline__ void can_split(const VxParams &p, int d_, int ch, int can[6])   // CL/UnitPartitioner.cpp:379-466
 {
+  Frame &f = L.fr[d_];                  // frames are addressed by level so that the accesses are LDS instructions, not generic-address ones
   const int impl = implicit_split(p, f, ch);
   const int maxBTD = p.max_bt_depth[ch] + f.impl_bt;
   const int maxBt = p.max_bt_size[ch], minBt = 4, maxTt = p.max_tt_size[ch], minTt = 4, minQt = p.min_qt[ch];
@@ -670,17 +685,22 @@ __device__ const VxUnit *get_cu(const VxParams &p, const VxFrameDev &fd, int ch,
 // Everything about a node that is fixed while it is processed — its left / above neighbour CUs, the canSplit() result
 // (CL/UnitPartitioner.cpp:379-466) and the split-flag context increments of DeriveCtx::CtxSplit
 // (CL/ContextModelling.cpp:154-250) — is derived once when the node is entered.
-__device__ __noinline__ void prepare_node(const VxParams &p, const VxFrameDev &fd, Frame &f, int ch, int tile)
+__device__ __noinline__ void prepare_node(const VxParams &p, const VxFrameDev &fd, int d_, int ch, int tile)
 {
+  Frame &f = L.fr[d_];
   const int sh = ch ? 1 : 0;
-  const VxUnit *cuL = get_cu(p, fd, ch, (f.x >> sh) - 1, f.y >> sh, tile), *cuA = get_cu(p, fd, ch, f.x >> sh, (f.y >> sh) - 1, tile);
+  // left and above CU records fetched together (one HBM/L2 round trip instead of dependent ones); x - 1 / y - 1 of an
+  // in-picture node can only fall off the left / top edge
+  const int ul = ch ? 1 : 2, xL = (f.x >> sh) - 1, yL = f.y >> sh, xA = f.x >> sh, yA = (f.y >> sh) - 1;
+  const VxUnit uL = fd.units[ch][(yL >> ul) * p.uw + (imax(xL, 0) >> ul)], uA = fd.units[ch][(imax(yA, 0) >> ul) * p.uw + (xA >> ul)];
+  const bool cuL = xL >= 0 && uL.tag == (uint16_t) (tile + 1), cuA = yA >= 0 && uA.tag == (uint16_t) (tile + 1);
   f.nb_ok = (uint8_t) ((cuL ? 1 : 0) | (cuA ? 2 : 0));
   int lh = 0, lq = 0, aw = 0, aq = 0;
-  if (cuL) { lh = cuL->lh; lq = cuL->qt; }
-  if (cuA) { aw = cuA->lw; aq = cuA->qt; }
+  if (cuL) { lh = uL.lh; lq = uL.qt; }
+  if (cuA) { aw = uA.lw; aq = uA.qt; }
   f.nbL_lh = (uint8_t) lh; f.nbL_qt = (uint8_t) lq; f.nbA_lw = (uint8_t) aw; f.nbA_qt = (uint8_t) aq;
   f.impl_checked = 0;
-  int can[6]; can_split(p, f, ch, can);
+  int can[6]; can_split(p, d_, ch, can);
   int mask = 0;
   for (int i = 0; i < 6; i++) mask |= can[i] << i;
   f.can_mask = (uint8_t) mask;
@@ -1040,6 +1060,25 @@ __device__ void satd_tile_shape(int w, int h, int &bw, int &bh)       // CL/RdCo
 }
 // SAD and SATD (xGetHADs) of org vs pred, both w*h tiles with stride w, by one wavefront; scratch >= w*h int16.
 // Templated on the Hadamard tile shape so that the per-lane row/column vectors stay in registers.
+// BW consecutive int16 as one LDS/global vector access (rows of Hadamard tiles are BW-aligned in 16-byte aligned tiles)
+typedef short vs4 __attribute__((vector_size(8)));
+typedef short vs8 __attribute__((vector_size(16)));
+template <int BW> __device__ inline void row_diff(const int16_t *o, const int16_t *q, int *v)
+{
+  if constexpr (BW == 4) { const vs4 a = *(const vs4 *) o, b = *(const vs4 *) q; for (int i = 0; i < 4; i++) v[i] = a[i] - b[i]; }
+  else if constexpr (BW >= 8) {
+#pragma unroll
+    for (int k = 0; k < BW; k += 8) { const vs8 a = *(const vs8 *) (o + k), b = *(const vs8 *) (q + k); for (int i = 0; i < 8; i++) v[k + i] = a[i] - b[i]; }
+  } else { for (int i = 0; i < BW; i++) v[i] = o[i] - q[i]; }
+}
+template <int BW> __device__ inline void row_store(int16_t *d, const int *v)
+{
+  if constexpr (BW == 4) { vs4 a; for (int i = 0; i < 4; i++) a[i] = (short) v[i]; *(vs4 *) d = a; }
+  else if constexpr (BW >= 8) {
+#pragma unroll
+    for (int k = 0; k < BW; k += 8) { vs8 a; for (int i = 0; i < 8; i++) a[i] = (short) v[k + i]; *(vs8 *) (d + k) = a; }
+  } else { for (int i = 0; i < BW; i++) d[i] = (int16_t) v[i]; }
+}
 template <int BW, int BH>
 __device__ inline void sad_satd_tiles(const int16_t *org, const int16_t *pred, int w, int P, int16_t *scr, int lane, int &sad_out, int &satd_out)
 {
@@ -1049,11 +1088,11 @@ __device__ inline void sad_satd_tiles(const int16_t *org, const int16_t *pred, i
     const int t = s / BH, r = s - t * BH, tx = t % tilesX, ty = t / tilesX;
     const int base = (ty * BH + r) * w + tx * BW;
     int v[BW];
+    row_diff<BW>(org + base, pred + base, v);
 #pragma unroll
-    for (int i = 0; i < BW; i++) { v[i] = org[base + i] - pred[base + i]; sad += iabs(v[i]); }
+    for (int i = 0; i < BW; i++) sad += iabs(v[i]);
     had1d<BW>(v);
-#pragma unroll
-    for (int i = 0; i < BW; i++) scr[t * tsz + r * BW + i] = (int16_t) v[i];
+    row_store<BW>(scr + t * tsz + r * BW, v);
   }
   wave_sync();
   int satd = 0;
@@ -1083,10 +1122,14 @@ __device__ inline void sad_satd_tiles(const int16_t *org, const int16_t *pred, i
   wave_sync();
   sad_out = sad; satd_out = satd;
 }
-__device__ __noinline__ void wave_sad_satd(const int16_t *org, const int16_t *pred, int w, int h, int16_t *scr, int lane,
+template <bool SMALL>
+__device__ __noinline__ void wave_sad_satd(const int16_t *pred_g, int16_t *scr_g, int w, int h, int lane,
                               unsigned long long &sad_out, unsigned long long &satd_out)
 {
   w = uni(w); h = uni(h);
+  const int wave_ = uni(threadIdx.x >> 6);
+  const int16_t *org = L.org, *pred = SMALL ? L.slot[wave_] : pred_g;
+  int16_t *scr = SMALL ? (int16_t *) L.tmp[wave_] : scr_g;
   const int P = w * h;
   int bw, bh; satd_tile_shape(w, h, bw, bh);
   int a = 0, b = 0;
@@ -1143,10 +1186,16 @@ __device__ void load_tables()
 // if any level: dequant (423-549) → inverse DCT-II (xIT 917-992) → reco = clip(pred + resi) written over pred.
 // Returns SSE(org, reco) and abs-sum via out params.  rec/lev tiles have stride w.
 // given >= 0: the levels in lev are taken as coded (cbf = given): only the decoder half runs (DecCu::xIntraRecBlk, DL/DecCu.cpp:199-414).
-__device__ __noinline__ void wave_code_block(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp,
+// SMALL: rec / lev / tmp are the calling wave's LDS buffers (L.slot[wave] + buf_off, + 1024, L.tmp[wave]); else the _g pointers.
+template <bool SMALL>
+__device__ __noinline__ void wave_code_block(int org_off, int buf_off, int16_t *rec_g, int16_t *lev_g, int32_t *tmp_g, int w, int h, int bd, int qp,
                                 int lane, unsigned long long &sse_out, int &cbf_out, int given = -1)
 {
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given);
+  const int wave_ = uni(threadIdx.x >> 6);
+  const int16_t *org = L.org + uni(org_off);
+  int16_t *rec = SMALL ? L.slot[wave_] + uni(buf_off) : rec_g, *lev = SMALL ? L.slot[wave_] + 1024 + uni(buf_off) : lev_g;
+  int32_t *tmp = SMALL ? L.tmp[wave_] : tmp_g;
   const int P = w * h, lw = ilog2i(w), lh = ilog2i(h);
   const int zw = imin(w, 32), zh = imin(h, 32);
   const int8_t *Mw = dct2_matrix(w), *Mh = dct2_matrix(h);
@@ -1242,8 +1291,8 @@ __device__ void ctx_copy_all(Ctx *dst, const Ctx *src)
 }
 __device__ Ctx *ctx_ptr(uint8_t *scratch, int which, int d, int wave)
 {
-  if (which == CTX_CUR) return &L.cur;
-  if (which == CTX_WAVE) return &L.wctx[wave];
+  if (which == CTX_CUR) return &L.ctxs[CI_CUR];
+  if (which == CTX_WAVE) return &L.ctxs[CI_W(wave)];
   return (Ctx *) (scratch + VXD_OFF_CTX + (size_t) (d * 2 + (which == CTX_BEST ? 1 : 0)) * VXD_CTXSNAP);
 }
 
@@ -1279,7 +1328,7 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
   const int bd = p.bit_depth;
   // mode bits of all candidates of this wave up front, one candidate per lane: lane l serves step l / G, slot l % G
   unsigned long long mbits = 0;
-  { const int cc = c_begin + wave * G + (lane / G) * (NW * G) + (lane % G); if (cc < c_end) mbits = luma_mode_bits(L.cur, L.ny, L.cand[cc].mode, L.cand[cc].mrl); }
+  { const int cc = c_begin + wave * G + (lane / G) * (NW * G) + (lane % G); if (cc < c_end) mbits = luma_mode_bits(L.ctxs[CI_CUR], L.ny, L.cand[cc].mode, L.cand[cc].mrl); }
   int step = 0;
   for (int c0 = c_begin + wave * G; c0 < c_end; c0 += NW * G, step++) {
     const int c = c0 + sub;
@@ -1293,11 +1342,11 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
     if (lane < G * BH) {                                 // one row of one candidate per lane
       const int sr = lane / BH, r = lane - sr * BH;
       int v[BW];
+      row_diff<BW>(L.org + r * BW, pred + sr * P + r * BW, v);
 #pragma unroll
-      for (int i = 0; i < BW; i++) { v[i] = L.org[r * BW + i] - pred[sr * P + r * BW + i]; sad += iabs(v[i]); }
+      for (int i = 0; i < BW; i++) sad += iabs(v[i]);
       had1d<BW>(v);
-#pragma unroll
-      for (int i = 0; i < BW; i++) scr[sr * P + r * BW + i] = (int16_t) v[i];
+      row_store<BW>(scr + sr * P + r * BW, v);
     }
     sad = seg_sum<BH>(sad);
     wave_sync();
@@ -1328,21 +1377,16 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
   }
 }
 
-// OP_STAGE_A: SATD-stage cost of every candidate in L.cand[op_a .. op_b) (EL/IntraSearch.cpp:489-682), one wave per candidate
-__device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
+// SATD-stage loop of one wave over its candidates (blocks of more than 32 samples).  SMALL: prediction and Hadamard scratch in the
+// wave's LDS buffers, else in HBM scratch.
+template <bool SMALL>
+__device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h, int c_end)
 {
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int w = uni(L.nw), h = uni(L.nh), P = w * h, bd = p.bit_depth;
-  int16_t *pred = slot_rec(scratch, P, wave, 0);
-  int16_t *scr = (int16_t *) wave_tmp(scratch, P >> 1, wave);
-  const int c_end = uni(L.op_b);
-  if (P <= 32) {
-    if (w == 4 && h == 4) stage_a_small<4, 4>(p, wave, lane, uni(L.op_a), c_end);
-    else if (w == 8) stage_a_small<8, 4>(p, wave, lane, uni(L.op_a), c_end);
-    else stage_a_small<4, 8>(p, wave, lane, uni(L.op_a), c_end);
-  } else {
+  const int P = w * h, bd = p.bit_depth;
+  int16_t *pred = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, 0);
+  int16_t *scr = SMALL ? (int16_t *) L.tmp[wave] : (int16_t *) wave_tmp(scratch, P >> 1, wave);
   unsigned long long mbits = 0;                         // mode bits of this wave's candidates up front, lane j serves step j
-  { const int cc = uni(L.op_a) + wave + lane * NW; if (cc < c_end) mbits = luma_mode_bits(L.cur, L.ny, L.cand[cc].mode, L.cand[cc].mrl); }
+  { const int cc = uni(L.op_a) + wave + lane * NW; if (cc < c_end) mbits = luma_mode_bits(L.ctxs[CI_CUR], L.ny, L.cand[cc].mode, L.cand[cc].mrl); }
   int step = 0;
   for (int c = uni(L.op_a) + wave; c < c_end; c += NW, step++) {
     const int mode = uni(L.cand[c].mode), mrl = uni(L.cand[c].mrl);
@@ -1355,7 +1399,7 @@ __device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
     wave_sync();
     const long long tb = STAMP();
     unsigned long long sad, satd;
-    wave_sad_satd(L.org, pred, w, h, scr, lane, sad, satd);
+    wave_sad_satd<SMALL>(pred, scr, w, h, lane, sad, satd);
     if (VVCX_STAMP && threadIdx.x == 0) { const long long tc = STAMP(); L.prof[15] += (unsigned long long) (tb - ta); L.prof[11] += (unsigned long long) (tc - tb); }
     if (lane == step) {
       const unsigned long long msh = sad * 2 < satd ? sad * 2 : satd;
@@ -1365,7 +1409,19 @@ __device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
     }
     wave_sync();
   }
-  }
+}
+// OP_STAGE_A: SATD-stage cost of every candidate in L.cand[op_a .. op_b) (EL/IntraSearch.cpp:489-682), one wave per candidate
+__device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
+{
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int w = uni(L.nw), h = uni(L.nh), P = w * h;
+  const int c_end = uni(L.op_b);
+  if (P <= 32) {
+    if (w == 4 && h == 4) stage_a_small<4, 4>(p, wave, lane, uni(L.op_a), c_end);
+    else if (w == 8) stage_a_small<8, 4>(p, wave, lane, uni(L.op_a), c_end);
+    else stage_a_small<4, 8>(p, wave, lane, uni(L.op_a), c_end);
+  } else if (P <= 1024) stage_a_loop<true>(p, scratch, wave, lane, w, h, c_end);
+  else stage_a_loop<false>(p, scratch, wave, lane, w, h, c_end);
   __syncthreads();
   // updateCandList (CL/UnitTools.h:261-306) over a stream of candidates keeps the numRd cheapest with ties to the
   // earlier-inserted one = a stable selection.  Done in parallel: every candidate computes its rank.
@@ -1391,18 +1447,21 @@ __device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
   __syncthreads();
 }
 
+// Candidate buffers.  Blocks of at most 1024 samples (SMALL) are evaluated in the wave's LDS buffers; a candidate that becomes the
+// wave's best is parked in the wave's HBM slot 1 (a streaming copy), so the next candidate again runs out of LDS.  Bigger blocks
+// alternate between the wave's two HBM slots.
 // OP_STAGE_B: full RD of L.rd[0..n_rd) (EL/IntraSearch.cpp:1158-1358 → xRecurIntraCodingLumaQT → xIntraCodingTUBlock)
-__device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
+template <bool SMALL>
+__device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h)
 {
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int w = uni(L.nw), h = uni(L.nh), P = w * h, bd = p.bit_depth;
+  const int P = w * h, bd = p.bit_depth;
   if (lane == 0) L.wave_best[wave] = -1;
   double wbest = MAX_DOUBLE;
-  int cur = 0;                                    // slot being written; the other one holds the wave's best so far
+  int cur = 0;                                    // !SMALL: slot being written; the other one holds the wave's best so far
   const int n_rd = uni(L.n_rd);
   for (int c = wave; c < n_rd; c += NW) {
     const int mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
-    int16_t *rec = slot_rec(scratch, P, wave, cur), *lev = slot_lev(scratch, P, wave, cur);
+    int16_t *rec = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.slot[wave] + 1024 : slot_lev(scratch, P, wave, cur);
     Ipa ip; init_pred_params(w, h, 1, mode, mrl, ip);
     const int set = luma_set(mrl, ip.ref_filter);
     const int16_t *top = L.refs[set][0], *left = L.refs[set][1];
@@ -1412,18 +1471,18 @@ __device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
     wave_sync();
     const long long tb1 = STAMP();
     unsigned long long sse; int cbf;
-    wave_code_block(L.org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp, lane, sse, cbf);
+    wave_code_block<SMALL>(0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp, lane, sse, cbf);
     const long long tb2 = STAMP();
     // xGetIntraFracBitsQT: header + cbf + residual from the node's start contexts
-    { uint32_t *d = (uint32_t *) &L.wctx[wave]; const uint32_t *s = (const uint32_t *) &L.cur; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
+    { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     wave_sync();
     double cost = 0;
-    Cab cb; cb.c = &L.wctx[wave]; cb.bits = 0;
+    Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
     if (lane == 0) {
       enc_intra_luma_pred_mode(cb, L.ny, mode, mrl);
       enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[0]);
     }
-    if (uni(cbf)) residual_coding_wave(cb, lev, w, h, 0, (uint16_t *) L.tmp[wave], lane);
+    if (uni(cbf)) residual_coding_wave<SMALL>(cb, 0, lev, w, h, 0, lane);
     if (lane == 0) {
       cost = rd_cost(p, cb.bits, sse);
       L.rd_cost[c] = cost; L.rd_dist[c] = sse; L.rd_bits[c] = cb.bits; L.rd_cbf[c] = (uint8_t) cbf;
@@ -1432,39 +1491,40 @@ __device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
     cost = lane0_d(cost);
     if (cost < wbest) {
       wbest = cost;
-      if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = cur; }
-      cur ^= 1;
+      if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = SMALL ? 1 : cur; }
+      if (SMALL) { int16_t *pr = slot_rec(scratch, P, wave, 1), *pl = slot_lev(scratch, P, wave, 1); for (int i = lane; i < P; i += 64) { pr[i] = rec[i]; pl[i] = lev[i]; } }
+      else cur ^= 1;
       // keep the end-of-candidate contexts of the wave's best: they are the CU's end contexts (same syntax as
       // cu_pred_data + cu_residual of xCheckRDCostIntra 2593-2619 for a luma-tree CU)
-      { uint32_t *d = (uint32_t *) &L.wpark[wave]; const uint32_t *s = (const uint32_t *) &L.wctx[wave]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
+      { uint32_t *d = (uint32_t *) &L.ctxs[CI_PARK(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_W(wave)]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     }
     wave_sync();
   }
+}
+__device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
+{
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int w = uni(L.nw), h = uni(L.nh);
+  if (w * h <= 1024) stage_b_loop<true>(p, scratch, wave, lane, w, h); else stage_b_loop<false>(p, scratch, wave, lane, w, h);
+  __threadfence_block();
   __syncthreads();
   // winner (strict <, list order ≙ EL/IntraSearch.cpp:1308) and its end contexts → wctx[0]; every thread computes the same
+  const int n_rd = uni(L.n_rd);
   int best = 0; double bc = MAX_DOUBLE;
   for (int c = 0; c < n_rd; c++) { const double v = L.rd_cost[c]; if (v < bc) { bc = v; best = c; } }
   best = uni(best);
   const int ww = best % NW;
   if (threadIdx.x == 0) { L.win_idx = best; L.win_wave = ww; L.cu_bits = L.rd_bits[best]; }
-  ctx_copy_all(&L.wctx[0], &L.wpark[ww]);
+  ctx_copy_all(&L.ctxs[CI_W(0)], &L.ctxs[CI_PARK(ww)]);
   __syncthreads();
 }
 
 // OP_CHROMA_RD: estIntraPredChromaQT 1382-1686 + xRecurIntraChromaCodingQT 3779-4207 (CCLM / JointCbCr off):
 // one wave per chroma mode, Cb then Cr; winner kept per wave like stage B.
-template <typename T>
-__device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
+template <bool SMALL>
+__device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h)
 {
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int x = uni(L.nx) >> 1, y = uni(L.ny) >> 1, w = uni(L.nw) >> 1, h = uni(L.nh) >> 1, P = w * h, bd = p.bit_depth;
-  for (int c = 1; c <= 2; c++) {
-    const void *org = fd.org[c]; const int st = fd.stride[c];
-    for (int i = threadIdx.x; i < P; i += NT) { const int r = i / w, cc = i - r * w; L.org[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
-    build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
-  }
-  if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
-  __syncthreads();
+  const int P = w * h, bd = p.bit_depth;
   if (lane == 0) L.wave_best[wave] = -1;
   double wbest = MAX_DOUBLE;
   int cur = 0;
@@ -1472,9 +1532,9 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
   for (int c = wave; c < n_rd; c += NW) {
     const int cm = uni(L.rd[c].mode);                 // chroma mode (70 = DM); final mode in .mrl field
     const int fm = uni(L.rd[c].mrl);
-    int16_t *recb = slot_rec(scratch, 2 * P, wave, cur);
-    int16_t *levb = slot_lev(scratch, 2 * P, wave, cur);
-    { uint32_t *d = (uint32_t *) &L.wctx[wave]; const uint32_t *s = (const uint32_t *) &L.cur; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
+    int16_t *recb = SMALL ? L.slot[wave] : slot_rec(scratch, 2 * P, wave, cur);
+    int16_t *levb = SMALL ? L.slot[wave] + 1024 : slot_lev(scratch, 2 * P, wave, cur);
+    { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     wave_sync();
     unsigned long long dist = 0; int cbfs[2];
     Ipa ip; init_pred_params(w, h, 0, fm, 0, ip);
@@ -1484,55 +1544,76 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
       for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
       wave_sync();
       unsigned long long sse; int cbf;
-      wave_code_block(L.org + k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_c[k], lane, sse, cbf);
+      wave_code_block<SMALL>(k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_c[k], lane, sse, cbf);
       cbfs[k] = cbf;
       dist += (unsigned long long) (p.dist_weight[k] * (double) sse);             // CL/RdCost.cpp:405-408
       {                    // xGetIntraFracBitsQTChroma 2625-2692: contexts advance
-        Cab cb; cb.c = &L.wctx[wave]; cb.bits = 0;
+        Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
         if (lane == 0) enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[k + 1] + (k == 1 ? cbfs[0] : 0));
-        if (uni(cbf)) residual_coding_wave(cb, lev, w, h, 1, (uint16_t *) L.tmp[wave], lane);
+        if (uni(cbf)) residual_coding_wave<SMALL>(cb, k * P, lev, w, h, 1, lane);
       }
       wave_sync();
     }
     double cost = 0;
     {                      // 1611-1621: contexts not reset; xGetIntraFracBitsQT(chroma)
-      Cab cb; cb.c = &L.wctx[wave]; cb.bits = 0;
+      Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
       if (lane == 0) {
         enc_intra_chroma_pred_mode(cb, cm);
         enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]);
         enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]);
       }
-      if (uni(cbfs[0])) residual_coding_wave(cb, levb, w, h, 1, (uint16_t *) L.tmp[wave], lane);
-      if (uni(cbfs[1])) residual_coding_wave(cb, levb + P, w, h, 1, (uint16_t *) L.tmp[wave], lane);
+      if (uni(cbfs[0])) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane);
+      if (uni(cbfs[1])) residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane);
       if (lane == 0) {
         cost = rd_cost(p, cb.bits, dist);
         L.rd_cost[c] = cost; L.rd_dist[c] = dist; L.rd_cbf[c] = (uint8_t) ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 4 : 0));
       }
     }
     cost = lane0_d(cost);
-    if (cost < wbest) { wbest = cost; if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = cur; } cur ^= 1; }
+    if (cost < wbest) {
+      wbest = cost;
+      if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = SMALL ? 1 : cur; }
+      if (SMALL) { int16_t *pr = slot_rec(scratch, 2 * P, wave, 1), *pl = slot_lev(scratch, 2 * P, wave, 1); for (int i = lane; i < 2 * P; i += 64) { pr[i] = recb[i]; pl[i] = levb[i]; } }
+      else cur ^= 1;
+    }
     wave_sync();
   }
+}
+template <typename T>
+__device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
+{
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int x = uni(L.nx) >> 1, y = uni(L.ny) >> 1, w = uni(L.nw) >> 1, h = uni(L.nh) >> 1, P = w * h;
+  for (int c = 1; c <= 2; c++) {
+    const void *org = fd.org[c]; const int st = fd.stride[c];
+    for (int i = threadIdx.x; i < P; i += NT) { const int r = i / w, cc = i - r * w; L.org[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
+    build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
+  }
+  if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
+  __syncthreads();
+  if (2 * P <= 1024) chroma_rd_loop<true>(p, scratch, wave, lane, w, h); else chroma_rd_loop<false>(p, scratch, wave, lane, w, h);
+  __threadfence_block();
   __syncthreads();
   // winner; its CU-level bits are recomputed from the node's start contexts (EL/EncCu.cpp:2593-2619) by wave 0
+  const int n_rd = uni(L.n_rd);
   int best = 0; double bc = MAX_DOUBLE;
   for (int c = 0; c < n_rd; c++) { const double v = L.rd_cost[c]; if (v < bc) { bc = v; best = c; } }
   best = uni(best);
   const int ww = best % NW;
-  ctx_copy_all(&L.wctx[0], &L.cur);
+  ctx_copy_all(&L.ctxs[CI_W(0)], &L.ctxs[CI_CUR]);
   __syncthreads();
   if (wave == 0) {
     const int slot = uni(L.wave_slot[ww]);
-    const int16_t *levw = slot_lev(scratch, 2 * P, ww, slot);
+    const int16_t *levw = slot_lev(scratch, 2 * P, ww, slot);       // HBM (parked or big block)
     const int cbfm = uni(L.rd_cbf[best]);
-    Cab cb; cb.c = &L.wctx[0]; cb.bits = 0;
+    Cab cb; cb.ci = CI_W(0); cb.bits = 0;
     if (lane == 0) {
       enc_intra_chroma_pred_mode(cb, L.rd[best].mode);
       enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
       enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
     }
-    if (cbfm & 2) residual_coding_wave(cb, levw, w, h, 1, (uint16_t *) L.tmp[0], lane);
-    if (cbfm & 4) residual_coding_wave(cb, levw + P, w, h, 1, (uint16_t *) L.tmp[0], lane);
+    if (cbfm & 2) residual_coding_wave<false>(cb, 0, levw, w, h, 1, lane);
+    if (cbfm & 4) residual_coding_wave<false>(cb, 0, levw + P, w, h, 1, lane);
     if (lane == 0) { L.win_idx = best; L.win_wave = ww; L.cu_bits = cb.bits; }
   }
   __syncthreads();
@@ -1572,6 +1653,50 @@ __device__ int cache_is_valid(const VxParams &p, uint8_t *scratch, Frame *fr, in
   return 1;
 }
 
+// wave 0 of OP_REUSE: prediction, reconstruction from the cached levels, distortion and CU bits of the cached CU
+template <bool SMALL>
+__device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch, int w, int h)
+{
+  const int P = w * h, n = ch ? 2 * P : P, bd = p.bit_depth;
+  int16_t *recb = SMALL ? L.slot[0] : slot_rec(scratch, n, 0, 0), *levb = SMALL ? L.slot[0] + 1024 : slot_lev(scratch, n, 0, 0);
+  const int mode = uni(L.rd[0].mode), fm = uni(L.rd[0].mrl), cbfm = uni(L.rd_cbf[0]);
+  Cab cb; cb.ci = CI_W(0); cb.bits = 0;
+  unsigned long long dist = 0;
+  if (!ch) {
+    Ipa ip; init_pred_params(w, h, 1, mode, fm, ip);
+    const int set = luma_set(fm, ip.ref_filter);
+    const int dcv = L.dc_val[luma_set(fm, 0)];
+    for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; recb[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], w, h, px, py, ip, mode, 1, bd, dcv); }
+    wave_sync();
+    int cbf;
+    wave_code_block<SMALL>(0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp, lane, dist, cbf, cbfm & 1);
+    if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, fm); enc_bin(cb, (unsigned) (cbfm & 1), VX_CTX_QtCbf[0]); }
+    if (cbfm & 1) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 0, lane);
+  } else {
+    Ipa ip; init_pred_params(w, h, 0, fm, 0, ip);
+    for (int k = 0; k < 2; k++) {
+      int16_t *rec = recb + k * P;
+      for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(L.refs[k][0], L.refs[k][1], w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
+      wave_sync();
+      unsigned long long sse; int cbf;
+      wave_code_block<SMALL>(k * P, k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1);
+      dist += (unsigned long long) (p.dist_weight[k] * (double) sse);
+    }
+    if (lane == 0) {
+      enc_intra_chroma_pred_mode(cb, mode);
+      enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
+      enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
+    }
+    if (cbfm & 2) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane);
+    if (cbfm & 4) residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane);
+    // coding_unit() ends with end_of_ctu (EL/CABACWriter.cpp:2118-2141): terminating bin after the last chroma CU of a CTU
+    // that does not end the slice; estFracBitsTrm(0) = 0x10c (CL/Contexts.h:129)
+    const int endX = L.nx + L.nw, endY = L.ny + L.nh;
+    const int lastCtu = (L.ctu_x >> 7) == p.ctus_w - 1 && (L.ctu_y >> 7) == p.ctus_h - 1;
+    if (lane == 0 && !lastCtu && ((endX & 127) == 0 || endX == p.pic_w) && ((endY & 127) == 0 || endY == p.pic_h)) cb.bits += 0x10c;
+  }
+  if (lane == 0) { L.win_idx = 0; L.win_wave = 0; L.wave_slot[0] = 0; L.rd_dist[0] = dist; L.cu_bits = cb.bits; }
+}
 // OP_REUSE: xReuseCachedResult (EL/EncCu.cpp:5665-5771).  The cached mode and levels of the node are reconstructed against the
 // current neighbourhood (DecCu::xReconIntraQT), distortion and CU bits are recomputed from the node's start contexts.  Results are
 // left where stage B / the chroma search leave theirs (candidate 0, wave 0, slot 0), so the controller continues at PH_B_DONE.
@@ -1591,55 +1716,17 @@ __device__ __noinline__ void op_reuse(const VxParams &p, const VxFrameDev &fd, u
     }
     if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
   }
-  int16_t *recb = slot_rec(scratch, n, 0, 0), *levb = slot_lev(scratch, n, 0, 0);
+  int16_t *levb = slot_lev(scratch, n, 0, 0);
   {
     int lo;
     cache_slot(uni(L.nx), uni(L.ny), uni(L.nw), uni(L.nh), lo);
     const int16_t *cl = (const int16_t *) (scratch + VXD_OFF_CACHE_LEV) + uni(lo);
     for (int i = threadIdx.x; i < n; i += NT) levb[i] = cl[i];
   }
-  ctx_copy_all(&L.wctx[0], &L.cur);
+  ctx_copy_all(&L.ctxs[CI_W(0)], &L.ctxs[CI_CUR]);
   __threadfence_block();
   __syncthreads();
-  if (wave == 0) {
-    const int mode = uni(L.rd[0].mode), fm = uni(L.rd[0].mrl), cbfm = uni(L.rd_cbf[0]);
-    Cab cb; cb.c = &L.wctx[0]; cb.bits = 0;
-    unsigned long long dist = 0;
-    if (!ch) {
-      Ipa ip; init_pred_params(w, h, 1, mode, fm, ip);
-      const int set = luma_set(fm, ip.ref_filter);
-      const int dcv = L.dc_val[luma_set(fm, 0)];
-      for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; recb[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], w, h, px, py, ip, mode, 1, bd, dcv); }
-      wave_sync();
-      int cbf;
-      wave_code_block(L.org, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp, lane, dist, cbf, cbfm & 1);
-      if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, fm); enc_bin(cb, (unsigned) (cbfm & 1), VX_CTX_QtCbf[0]); }
-      if (cbfm & 1) residual_coding_wave(cb, levb, w, h, 0, (uint16_t *) L.tmp[0], lane);
-    } else {
-      Ipa ip; init_pred_params(w, h, 0, fm, 0, ip);
-      for (int k = 0; k < 2; k++) {
-        int16_t *rec = recb + k * P;
-        for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(L.refs[k][0], L.refs[k][1], w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
-        wave_sync();
-        unsigned long long sse; int cbf;
-        wave_code_block(L.org + k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1);
-        dist += (unsigned long long) (p.dist_weight[k] * (double) sse);
-      }
-      if (lane == 0) {
-        enc_intra_chroma_pred_mode(cb, mode);
-        enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
-        enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
-      }
-      if (cbfm & 2) residual_coding_wave(cb, levb, w, h, 1, (uint16_t *) L.tmp[0], lane);
-      if (cbfm & 4) residual_coding_wave(cb, levb + P, w, h, 1, (uint16_t *) L.tmp[0], lane);
-      // coding_unit() ends with end_of_ctu (EL/CABACWriter.cpp:2118-2141): terminating bin after the last chroma CU of a CTU
-      // that does not end the slice; estFracBitsTrm(0) = 0x10c (CL/Contexts.h:129)
-      const int endX = L.nx + L.nw, endY = L.ny + L.nh;
-      const int lastCtu = (L.ctu_x >> 7) == p.ctus_w - 1 && (L.ctu_y >> 7) == p.ctus_h - 1;
-      if (lane == 0 && !lastCtu && ((endX & 127) == 0 || endX == p.pic_w) && ((endY & 127) == 0 || endY == p.pic_h)) cb.bits += 0x10c;
-    }
-    if (lane == 0) { L.win_idx = 0; L.win_wave = 0; L.wave_slot[0] = 0; L.rd_dist[0] = dist; L.cu_bits = cb.bits; }
-  }
+  if (wave == 0) { if (n <= 1024) reuse_eval<true>(p, scratch, lane, ch, w, h); else reuse_eval<false>(p, scratch, lane, ch, w, h); }
   __syncthreads();
 }
 
@@ -1699,7 +1786,7 @@ __device__ __noinline__ void op_save_intra(const VxParams &p, uint8_t *scratch, 
   VxUnit *su = (VxUnit *) (lvl + 2 * VXD_STORE_REC);
   const int ucw = (L.nw + 3) >> 2, uch = (L.nh + 3) >> 2;
   for (int i = threadIdx.x; i < ucw * uch; i += NT) su[(i / ucw) * 32 + (i % ucw)] = cu;
-  ctx_copy_all(ctx_ptr(scratch, CTX_BEST, d, 0), &L.wctx[0]);
+  ctx_copy_all(ctx_ptr(scratch, CTX_BEST, d, 0), &L.ctxs[CI_W(0)]);
   __threadfence_block();
   __syncthreads();
 }
@@ -1717,8 +1804,9 @@ __device__ __noinline__ void op_clear_units(const VxParams &p, const VxFrameDev 
 __device__ inline int mode_to_split(int m) { return m == ETM_SPLIT_QT ? SPLIT_QT : m == ETM_SPLIT_BT_H ? SPLIT_BH : m == ETM_SPLIT_BT_V ? SPLIT_BV : m == ETM_SPLIT_TT_H ? SPLIT_TH : m == ETM_SPLIT_TT_V ? SPLIT_TV : SPLIT_NONE; }
 
 // EncModeCtrlMTnoRQT::tryMode (EL/EncModeCtrl.cpp:1557-2068), I-slice subset
-__device__ __noinline__ int try_mode(const VxParams &p, Frame &f, int ch, int mode)
+__device__ __noinline__ int try_mode(const VxParams &p, int d_, int ch, int mode)
 {
+  Frame &f = L.fr[d_];
   const int impl = implicit_split(p, f, ch);
   if (impl != SPLIT_NONE && mode != ETM_SPLIT_QT) return mode_to_split(mode) == impl;
   else if (impl != SPLIT_NONE) return can_do(p, f, ch, SPLIT_QT);
@@ -1761,16 +1849,17 @@ __device__ __noinline__ int try_mode(const VxParams &p, Frame &f, int ch, int mo
   if (split == SPLIT_QT) f.did_q = 1;
   return 1;
 }
-__device__ int next_mode(const VxParams &p, Frame &f, int ch)
+__device__ int next_mode(const VxParams &p, int d_, int ch)
 {
+  Frame &f = L.fr[d_];
   f.nmodes--;
-  while (f.nmodes > 0 && !try_mode(p, f, ch, f.modes[f.nmodes - 1])) f.nmodes--;
+  while (f.nmodes > 0 && !try_mode(p, d_, ch, f.modes[f.nmodes - 1])) f.nmodes--;
   return f.nmodes > 0;
 }
 __device__ __noinline__ void init_cu_level(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch, int d, int ch, int tile)       // initCULevel 1203-1549
 {
   Frame &f = L.fr[d];
-  prepare_node(p, fd, f, ch, tile);
+  prepare_node(p, fd, d, ch, tile);
   const int cuL = f.nb_ok & 1, cuA = f.nb_ok & 2, lq = f.nbL_qt, aq = f.nbA_qt;
   f.qt_before_bt = (uint8_t) (((cuL && cuA && lq > f.qt && aq > f.qt) || (cuL && !cuA && lq > f.qt) || (!cuL && cuA && aq > f.qt)
                    || (!cuA && !cuL && f.w >= 32)) && (f.w > (p.min_qt[ch] << 1)));
@@ -1785,7 +1874,7 @@ __device__ __noinline__ void init_cu_level(const VxParams &p, const VxFrameDev &
   f.reusing = (uint8_t) cache_is_valid(p, scratch, L.fr, d, ch);        // 1438-1444
   if (f.reusing) f.modes[f.nmodes++] = ETM_RECO_CACHED;
   f.modes[f.nmodes++] = ETM_INTRA;
-  if (!try_mode(p, f, ch, f.modes[f.nmodes - 1])) next_mode(p, f, ch);
+  if (!try_mode(p, d, ch, f.modes[f.nmodes - 1])) next_mode(p, d, ch);
 }
 __device__ int use_mode_result(const VxParams &p, Frame &f, int ch, int mode, const Sum &t)       // useModeResult 2089-2200
 {
@@ -1892,9 +1981,9 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
       const int split = mode_to_split(mode);
       f.cur_split = (uint8_t) split;
       {
-        Cab cb; cb.c = &L.wctx[0]; cb.bits = 0;
+        Cab cb; cb.ci = CI_W(0); cb.bits = 0;
         const int ids0 = VX_CTX_SplitFlag;           // split contexts occupy [SplitFlag, Split12Flag+4)
-        for (int k = ids0; k < VX_CTX_Split12Flag + 4; k++) { L.wctx[0].s0[k] = L.cur.s0[k]; L.wctx[0].s1[k] = L.cur.s1[k]; }
+        for (int k = ids0; k < VX_CTX_Split12Flag + 4; k++) { L.ctxs[CI_W(0)].s0[k] = L.ctxs[CI_CUR].s0[k]; L.ctxs[CI_W(0)].s1[k] = L.ctxs[CI_CUR].s1[k]; }
         enc_split_cu_mode(p, fd, cb, f, ch, tile, split);
         const double factor = p.qp > 30 ? 1.1 : 1.075;
         const double cost = rd_cost(p, (uint64_t) ((double) cb.bits + ((double) f.best.bits / factor)), (uint64_t) ((double) f.best.dist / factor));
@@ -1949,7 +2038,7 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
       // cu_pred_data + cu_residual bits (EL/EncCu.cpp:2593-2619) and the CU's end contexts are left in cu_bits / wctx[0]
       // by the operation (luma: identical to the stage-B syntax from the same start contexts)
       t.bits = L.cu_bits;
-      Cab cb; cb.c = &L.wctx[0]; cb.bits = 0;
+      Cab cb; cb.ci = CI_W(0); cb.bits = 0;
       enc_split_cu_mode(p, fd, cb, f, ch, tile, SPLIT_NONE);          // xEncodeDontSplit 5649-5662
       t.bits += cb.bits;
       t.cost = rd_cost(p, t.bits, t.dist);
@@ -1968,7 +2057,7 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
         Sum &t = f.temp;
         f.impl_checked = 0;
         const int enforceQT = implicit_split(p, f, ch) == SPLIT_QT;
-        if (!enforceQT) { Cab cb; cb.c = &L.cur; cb.bits = 0; enc_split_cu_mode(p, fd, cb, f, ch, tile, f.cur_split); t.bits += cb.bits; }
+        if (!enforceQT) { Cab cb; cb.ci = CI_CUR; cb.bits = 0; enc_split_cu_mode(p, fd, cb, f, ch, tile, f.cur_split); t.bits += cb.bits; }
         t.cost = rd_cost(p, t.bits, t.dist); t.valid = 1;
         if (use_mode_result(p, f, ch, f.cur_mode, t)) {
           f.best = t; f.has_best = 1;
@@ -2014,7 +2103,7 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
     case PH_SPLIT_SAVED: { f.phase = PH_ADVANCE; set_node(f, d); post(OP_SAVE_PIC); return; }
     case PH_INTRA_SAVED: { f.phase = PH_ADVANCE; break; }
     case PH_ADVANCE: {                                  // ctx ← start (xCheckBestMode 721), next mode
-      if (next_mode(p, f, ch)) f.phase = PH_RUN; else f.phase = PH_EXIT;
+      if (next_mode(p, d, ch)) f.phase = PH_RUN; else f.phase = PH_EXIT;
       L.op_a = CTX_CUR; L.op_b = CTX_START; L.op_c = d; post(OP_CTX_COPY); return;
     }
     case PH_EXIT: {                                     // EL/EncCu.cpp:1533-1583
@@ -2029,10 +2118,11 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
 }
 
 // final estimator pass over the coded CTU (CABACWriter::coding_tree_unit 254-309 / coding_tree 474-984): advances
-// L.cur for the next CTU of the stream.  Thread 0 only.
+// L.ctxs[CI_CUR] for the next CTU of the stream.  Thread 0 only.
 template <typename T>
-__device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, Cab &cb, int ch, int tile, Frame *st, int d, int16_t *lv)
+__device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, Cab &cb, int ch, int tile, Frame *st_, int d, int16_t *lv)
 {
+  Frame *st = L.fr; (void) st_;
   // iterative pre-order walk with an explicit stack of frames st[d..]
   int top = d;
   st[top].child = 0; st[top].phase = 0;
@@ -2041,7 +2131,7 @@ __device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, 
     if (f.phase == 0) {
       const VxUnit *u = &fd.units[ch][(f.y >> 2) * p.uw + (f.x >> 2)];
       const int split = (int) ((u->ss >> (f.depth * 5)) & 31);
-      prepare_node(p, fd, f, ch, tile);
+      prepare_node(p, fd, top, ch, tile);                  // st is L.fr
       enc_split_cu_mode(p, fd, cb, f, ch, tile, split);
       if (!split) {
         const int sh = ch ? 1 : 0, W = f.w >> sh, H = f.h >> sh;
@@ -2096,7 +2186,7 @@ __device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, 
 template <typename T>
 __device__ __noinline__ void advance_ctx_ctu(const VxParams &p, const VxFrameDev &fd, int tile, int ctu_x, int ctu_y)
 {
-  Cab cb; cb.c = &L.cur; cb.bits = 0;
+  Cab cb; cb.ci = CI_CUR; cb.bits = 0;
   int16_t *lv = (int16_t *) &L.tmp[0][0];        // 8 KB = tmp[0] + tmp[1]; the scan table of the estimator pass uses tmp[2]
   // 128x128 root: implicit QT for both trees (no bins); luma / chroma sub-trees interleaved per 64x64 (867-908)
   for (int q = 0; q < 4; q++) {
@@ -2121,13 +2211,13 @@ __device__ void run_stream(const VxParams &p)
   const int tid = threadIdx.x;
   if (tid == 0) { L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < 48; i++) L.prof[i] = 0; }
   load_tables();
-  ctx_copy_all(&L.cur, carry);
+  ctx_copy_all(&L.ctxs[CI_CUR], carry);
   __syncthreads();
   for (int t = 0; t < sd.n_tasks; t++) {
     const int addr = p.task_ctu[sd.first_task + t];
     const int ctu_x = (addr % p.ctus_w) << 7, ctu_y = (addr / p.ctus_w) << 7;
     // contexts at CTU start → snapshot slot (MAXD-1) "start"
-    ctx_copy_all(ctx_ptr(scratch, CTX_START, MAXD + NW, 0), &L.cur);
+    ctx_copy_all(ctx_ptr(scratch, CTX_START, MAXD + NW, 0), &L.ctxs[CI_CUR]);
     if (p.tools & TOOL_CU_REUSE) {                       // entries of an earlier CTU can never match (987-1024: poc / absolute area): drop them
       uint64_t *ce = (uint64_t *) (scratch + VXD_OFF_CACHE);   // sizeof(VxCacheEnt) == 16
       for (int i = tid; i < 2 * VXD_CACHE_ENTRIES; i += NT) ce[i] = 0;
@@ -2142,7 +2232,7 @@ __device__ void run_stream(const VxParams &p)
         f.x = (int16_t) ctu_x; f.y = (int16_t) ctu_y; f.w = 128; f.h = 128; f.depth = 0; f.qt = 0; f.bt = 0; f.mt = 0; f.impl_bt = 0;
         f.last_split = 0; f.part_idx = 0; f.impl_checked = 0; f.ss = 0; f.max_cost = MAX_DOUBLE; f.phase = PH_ENTER;
       }
-      if (ch == 1) ctx_copy_all(&L.cur, ctx_ptr(scratch, CTX_START, MAXD + NW, 0));     // EL/EncCu.cpp:521
+      if (ch == 1) ctx_copy_all(&L.ctxs[CI_CUR], ctx_ptr(scratch, CTX_START, MAXD + NW, 0));     // EL/EncCu.cpp:521
       __syncthreads();
       // NOTE: exactly one thread-0 section per iteration.  With two (`if (tid == 0)` at the head and at the tail)
       // hipcc threads the "tid != 0" edges together and structurizes the result into an inner loop in which lanes
@@ -2179,12 +2269,12 @@ __device__ void run_stream(const VxParams &p)
       __syncthreads();
     }
     // contexts back to the CTU start, then the estimator pass advances them (EL/EncCu.cpp:543, EL/EncSlice.cpp:1775-1776)
-    ctx_copy_all(&L.cur, ctx_ptr(scratch, CTX_START, MAXD + NW, 0));
+    ctx_copy_all(&L.ctxs[CI_CUR], ctx_ptr(scratch, CTX_START, MAXD + NW, 0));
     __syncthreads();
     if (tid == 0) { const long long t0 = STAMP(); advance_ctx_ctu<T>(p, fd, sd.tile, ctu_x, ctu_y); L.prof[12] += (unsigned long long) (STAMP() - t0); p.results[sd.first_task + t] = res; }
     __syncthreads();
   }
-  ctx_copy_all(carry, &L.cur);
+  ctx_copy_all(carry, &L.ctxs[CI_CUR]);
   if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); for (int i = 0; i < 48; i++) atomicAdd(&p.counters[4 + i], L.prof[i]); }
 }
 
