@@ -7,6 +7,12 @@
 #define VXD_NW 4            // wavefronts (64 lanes) per workgroup = one CTU stream; 4 keeps LDS < 80 KB so two streams share a CU
 #endif
 #define VXD_NT (VXD_NW * 64) // threads per workgroup
+#ifndef VXD_BUF
+#define VXD_BUF 256          // samples of a node (luma w*h, chroma 2*cw*ch) up to which its candidates are evaluated in LDS buffers
+#endif
+#ifndef VXD_WPE
+#define VXD_WPE 4            // waves per SIMD the register budget is sized for = CTU streams per CU (one wave of each stream per SIMD)
+#endif
 #define VXD_MAXD 14         // recursion levels kept in LDS
 #define VXD_NUM_CTX 386     // flat context array, same indexing as the reference's ContextSetCfg
 
@@ -68,6 +74,7 @@ struct VxParams {
 struct VxCacheEnt { uint64_t ss; uint8_t kind /* 0 empty, 1 luma tree, 2 chroma tree */, dir, mrl, cbf, depth, pad[3]; };
 #define VXD_CACHE_ENTRIES (32 * 32 * 5 * 5)
 #define VXD_CACHE_DIM   1152
-#define VXD_OFF_CACHE   ((VXD_OFF_TMP + VXD_NW * 2048 * 4 + 255) & ~255)
+#define VXD_OFF_ORG     (VXD_OFF_TMP + VXD_NW * 2048 * 4)                             // original tile of a node too big for LDS: 4096 int16
+#define VXD_OFF_CACHE   ((VXD_OFF_ORG + 4096 * 2 + 255) & ~255)
 #define VXD_OFF_CACHE_LEV (VXD_OFF_CACHE + VXD_CACHE_ENTRIES * (int) sizeof(VxCacheEnt))
 #define VXD_SCRATCH_BYTES (VXD_OFF_CACHE_LEV + VXD_CACHE_DIM * VXD_CACHE_DIM * 2)

@@ -23,6 +23,7 @@
 #define NT VXD_NT
 #define NW VXD_NW
 #define MAXD VXD_MAXD
+#define BUF VXD_BUF
 #define NCTX VXD_NUM_CTX
 #define MAX_DOUBLE 1.7e+308
 #ifndef VVCX_STAMP
@@ -91,16 +92,15 @@ struct Tables {                    // constant tables staged once per workgroup 
 #define RC_LIST 320
 #define CI_CUR 0
 #define CI_W(w) (1 + (w))
-#define CI_PARK(w) (1 + NW + (w))
 struct Lds {
   Tables t;
-  Ctx ctxs[1 + 2 * NW];            // [0] the estimator's contexts, [1 + w] per-wave working copy, [1 + NW + w] end-of-candidate contexts of wave w's best
-  alignas(16) int16_t org[4096];   // node's original tile: luma w*h, or Cb | Cr (cw*ch each)
+  Ctx ctxs[1 + NW];                // [0] the estimator's contexts, [1 + w] per-wave working copy (a wave's best end-of-candidate contexts are parked in HBM)
+  alignas(16) int16_t org[BUF];    // node's original tile: luma w*h, or Cb | Cr (cw*ch each); bigger nodes keep it in HBM scratch (VXD_OFF_ORG)
   uint16_t binbuf[NW][RC_LIST]; uint8_t binsort[NW][RC_LIST + 8];        // residual_coding_wave: pending (ctx<<1|bin) list; bins grouped by context
   int acc[NW][4][2];               // small-block SATD stage: per packed candidate {SAD, SATD}
   int16_t refs[4][2][140];         // luma: set 0 mrl0 unfiltered, 1 mrl0 filtered, 2 mrl1, 3 mrl3; chroma: set 0 Cb, 1 Cr. [0]=top [1]=left
-  alignas(16) int32_t tmp[NW][1024];           // per-wave transform / Hadamard / scan scratch (blocks needing more use HBM scratch)
-  alignas(16) int16_t slot[NW][2048];          // per-wave candidate slot 0: rec[1024] | lev[1024] (slot 1 and big blocks live in HBM scratch)
+  alignas(16) int32_t tmp[NW][BUF];           // per-wave transform / Hadamard / scan scratch (blocks needing more use HBM scratch)
+  alignas(16) int16_t slot[NW][2 * BUF];       // per-wave candidate buffers: rec[BUF] | lev[BUF] (parked winners and big blocks live in HBM scratch)
   uint8_t flags[72]; int8_t src_unit[72];
   Frame fr[MAXD];
   // posted operation
@@ -310,7 +310,7 @@ template <bool SMALL>
 __device__ __noinline__ RcPre rc_prepass_wave(int lev_off, const int16_t *coeff_g, int w, int h, int lane)
 {
   w = uni(w); h = uni(h);
-  const int16_t *coeff = SMALL ? L.slot[uni(threadIdx.x >> 6)] + 1024 + uni(lev_off) : coeff_g;
+  const int16_t *coeff = SMALL ? L.slot[uni(threadIdx.x >> 6)] + BUF + uni(lev_off) : coeff_g;
   const ScanGeo g = scan_geo(w, h);
   int last = -1; unsigned long long sig = 0;
   const int gpi = 64 >> g.lcg;                           // groups per step
@@ -510,7 +510,7 @@ template <bool SMALL>
 __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const int16_t *coeff_g, int w, int h, int is_chroma, int lane)
 {
   const long long q0 = STAMP();
-  const int16_t *coeff = SMALL ? L.slot[uni(threadIdx.x >> 6)] + 1024 + uni(lev_off) : coeff_g;
+  const int16_t *coeff = SMALL ? L.slot[uni(threadIdx.x >> 6)] + BUF + uni(lev_off) : coeff_g;
   const RcPre pre = rc_prepass_wave<SMALL>(lev_off, coeff_g, w, h, lane);
   const int last = uni(pre.last);
   if (last < 0) return;
@@ -1123,12 +1123,12 @@ __device__ inline void sad_satd_tiles(const int16_t *org, const int16_t *pred, i
   sad_out = sad; satd_out = satd;
 }
 template <bool SMALL>
-__device__ __noinline__ void wave_sad_satd(const int16_t *pred_g, int16_t *scr_g, int w, int h, int lane,
+__device__ __noinline__ void wave_sad_satd(const int16_t *org_g, const int16_t *pred_g, int16_t *scr_g, int w, int h, int lane,
                               unsigned long long &sad_out, unsigned long long &satd_out)
 {
   w = uni(w); h = uni(h);
   const int wave_ = uni(threadIdx.x >> 6);
-  const int16_t *org = L.org, *pred = SMALL ? L.slot[wave_] : pred_g;
+  const int16_t *org = SMALL ? L.org : org_g, *pred = SMALL ? L.slot[wave_] : pred_g;
   int16_t *scr = SMALL ? (int16_t *) L.tmp[wave_] : scr_g;
   const int P = w * h;
   int bw, bh; satd_tile_shape(w, h, bw, bh);
@@ -1188,13 +1188,13 @@ __device__ void load_tables()
 // given >= 0: the levels in lev are taken as coded (cbf = given): only the decoder half runs (DecCu::xIntraRecBlk, DL/DecCu.cpp:199-414).
 // SMALL: rec / lev / tmp are the calling wave's LDS buffers (L.slot[wave] + buf_off, + 1024, L.tmp[wave]); else the _g pointers.
 template <bool SMALL>
-__device__ __noinline__ void wave_code_block(int org_off, int buf_off, int16_t *rec_g, int16_t *lev_g, int32_t *tmp_g, int w, int h, int bd, int qp,
+__device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, int buf_off, int16_t *rec_g, int16_t *lev_g, int32_t *tmp_g, int w, int h, int bd, int qp,
                                 int lane, unsigned long long &sse_out, int &cbf_out, int given = -1)
 {
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given);
   const int wave_ = uni(threadIdx.x >> 6);
-  const int16_t *org = L.org + uni(org_off);
-  int16_t *rec = SMALL ? L.slot[wave_] + uni(buf_off) : rec_g, *lev = SMALL ? L.slot[wave_] + 1024 + uni(buf_off) : lev_g;
+  const int16_t *org = (SMALL ? L.org : org_g) + uni(org_off);
+  int16_t *rec = SMALL ? L.slot[wave_] + uni(buf_off) : rec_g, *lev = SMALL ? L.slot[wave_] + BUF + uni(buf_off) : lev_g;
   int32_t *tmp = SMALL ? L.tmp[wave_] : tmp_g;
   const int P = w * h, lw = ilog2i(w), lh = ilog2i(h);
   const int zw = imin(w, 32), zh = imin(h, 32);
@@ -1277,12 +1277,14 @@ __device__ __noinline__ void wave_code_block(int org_off, int buf_off, int16_t *
 // ------------------------------------------------------------------------------------------------ parallel operations
 // candidate slots: nrec = reconstruction samples held (w*h luma, 2*cw*ch chroma).  Slot 0 of blocks up to 1024 samples is
 // in LDS; slot 1 (only used when a wave evaluates more than one full-RD candidate) and bigger blocks are in HBM scratch.
+// original tile of the node: LDS for nodes of at most BUF samples, else the stream's HBM scratch
+__device__ inline int16_t *org_tile(uint8_t *scratch, int nrec) { return nrec <= BUF ? L.org : (int16_t *) (scratch + VXD_OFF_ORG); }
 __device__ inline int16_t *slot_rec(uint8_t *scratch, int nrec, int wave, int which)
-{ return (nrec <= 1024 && which == 0) ? &L.slot[wave][0] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS; }
+{ return (nrec <= BUF && which == 0) ? &L.slot[wave][0] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS; }
 __device__ inline int16_t *slot_lev(uint8_t *scratch, int nrec, int wave, int which)
-{ return (nrec <= 1024 && which == 0) ? &L.slot[wave][1024] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS + 4096; }
+{ return (nrec <= BUF && which == 0) ? &L.slot[wave][BUF] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS + 4096; }
 __device__ inline int32_t *wave_tmp(uint8_t *scratch, int n_i32, int wave)
-{ return n_i32 <= 1024 ? L.tmp[wave] : (int32_t *) (scratch + VXD_OFF_TMP) + wave * 2048; }
+{ return n_i32 <= BUF ? L.tmp[wave] : (int32_t *) (scratch + VXD_OFF_TMP) + wave * 2048; }
 
 __device__ void ctx_copy_all(Ctx *dst, const Ctx *src)
 {
@@ -1303,7 +1305,8 @@ __device__ __noinline__ void op_luma_prep(const VxParams &p, const VxFrameDev &f
   const int x = uni(L.nx), y = uni(L.ny), w = uni(L.nw), h = uni(L.nh);
   const long long ts = STAMP();
   const void *org = fd.org[0]; const int st = fd.stride[0];
-  for (int i = threadIdx.x; i < w * h; i += NT) { const int r = i / w, c = i - r * w; L.org[i] = (int16_t) ld_px<T>(org, (y + r) * st + x + c); }
+  int16_t *ot = org_tile(p.scratch + (size_t) blockIdx.x * p.scratch_per_stream, w * h);
+  for (int i = threadIdx.x; i < w * h; i += NT) { const int r = i / w, c = i - r * w; ot[i] = (int16_t) ld_px<T>(org, (y + r) * st + x + c); }
   const int nsets = ((y & 127) == 0 || !(p.tools & 1)) ? 1 : 3;
   build_refs<T>(p, fd, 0, x, y, w, h, uni(L.cur_tile), nsets);
   if (threadIdx.x < 4) {
@@ -1399,7 +1402,7 @@ __device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     wave_sync();
     const long long tb = STAMP();
     unsigned long long sad, satd;
-    wave_sad_satd<SMALL>(pred, scr, w, h, lane, sad, satd);
+    wave_sad_satd<SMALL>(org_tile(scratch, P), pred, scr, w, h, lane, sad, satd);
     if (VVCX_STAMP && threadIdx.x == 0) { const long long tc = STAMP(); L.prof[15] += (unsigned long long) (tb - ta); L.prof[11] += (unsigned long long) (tc - tb); }
     if (lane == step) {
       const unsigned long long msh = sad * 2 < satd ? sad * 2 : satd;
@@ -1420,7 +1423,7 @@ __device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
     if (w == 4 && h == 4) stage_a_small<4, 4>(p, wave, lane, uni(L.op_a), c_end);
     else if (w == 8) stage_a_small<8, 4>(p, wave, lane, uni(L.op_a), c_end);
     else stage_a_small<4, 8>(p, wave, lane, uni(L.op_a), c_end);
-  } else if (P <= 1024) stage_a_loop<true>(p, scratch, wave, lane, w, h, c_end);
+  } else if (P <= BUF) stage_a_loop<true>(p, scratch, wave, lane, w, h, c_end);
   else stage_a_loop<false>(p, scratch, wave, lane, w, h, c_end);
   __syncthreads();
   // updateCandList (CL/UnitTools.h:261-306) over a stream of candidates keeps the numRd cheapest with ties to the
@@ -1461,7 +1464,7 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
   const int n_rd = uni(L.n_rd);
   for (int c = wave; c < n_rd; c += NW) {
     const int mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
-    int16_t *rec = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.slot[wave] + 1024 : slot_lev(scratch, P, wave, cur);
+    int16_t *rec = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.slot[wave] + BUF : slot_lev(scratch, P, wave, cur);
     Ipa ip; init_pred_params(w, h, 1, mode, mrl, ip);
     const int set = luma_set(mrl, ip.ref_filter);
     const int16_t *top = L.refs[set][0], *left = L.refs[set][1];
@@ -1471,7 +1474,7 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     wave_sync();
     const long long tb1 = STAMP();
     unsigned long long sse; int cbf;
-    wave_code_block<SMALL>(0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp, lane, sse, cbf);
+    wave_code_block<SMALL>(org_tile(scratch, P), 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp, lane, sse, cbf);
     const long long tb2 = STAMP();
     // xGetIntraFracBitsQT: header + cbf + residual from the node's start contexts
     { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
@@ -1496,7 +1499,7 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
       else cur ^= 1;
       // keep the end-of-candidate contexts of the wave's best: they are the CU's end contexts (same syntax as
       // cu_pred_data + cu_residual of xCheckRDCostIntra 2593-2619 for a luma-tree CU)
-      { uint32_t *d = (uint32_t *) &L.ctxs[CI_PARK(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_W(wave)]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
+      { uint32_t *d = (uint32_t *) ctx_ptr(scratch, CTX_START, MAXD + wave, 0); const uint32_t *s = (const uint32_t *) &L.ctxs[CI_W(wave)]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     }
     wave_sync();
   }
@@ -1505,7 +1508,7 @@ __device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
 {
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int w = uni(L.nw), h = uni(L.nh);
-  if (w * h <= 1024) stage_b_loop<true>(p, scratch, wave, lane, w, h); else stage_b_loop<false>(p, scratch, wave, lane, w, h);
+  if (w * h <= BUF) stage_b_loop<true>(p, scratch, wave, lane, w, h); else stage_b_loop<false>(p, scratch, wave, lane, w, h);
   __threadfence_block();
   __syncthreads();
   // winner (strict <, list order ≙ EL/IntraSearch.cpp:1308) and its end contexts → wctx[0]; every thread computes the same
@@ -1515,7 +1518,7 @@ __device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
   best = uni(best);
   const int ww = best % NW;
   if (threadIdx.x == 0) { L.win_idx = best; L.win_wave = ww; L.cu_bits = L.rd_bits[best]; }
-  ctx_copy_all(&L.ctxs[CI_W(0)], &L.ctxs[CI_PARK(ww)]);
+  ctx_copy_all(&L.ctxs[CI_W(0)], ctx_ptr(scratch, CTX_START, MAXD + ww, 0));
   __syncthreads();
 }
 
@@ -1533,7 +1536,7 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
     const int cm = uni(L.rd[c].mode);                 // chroma mode (70 = DM); final mode in .mrl field
     const int fm = uni(L.rd[c].mrl);
     int16_t *recb = SMALL ? L.slot[wave] : slot_rec(scratch, 2 * P, wave, cur);
-    int16_t *levb = SMALL ? L.slot[wave] + 1024 : slot_lev(scratch, 2 * P, wave, cur);
+    int16_t *levb = SMALL ? L.slot[wave] + BUF : slot_lev(scratch, 2 * P, wave, cur);
     { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     wave_sync();
     unsigned long long dist = 0; int cbfs[2];
@@ -1544,7 +1547,7 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
       for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
       wave_sync();
       unsigned long long sse; int cbf;
-      wave_code_block<SMALL>(k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_c[k], lane, sse, cbf);
+      wave_code_block<SMALL>(org_tile(scratch, 2 * P), k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_c[k], lane, sse, cbf);
       cbfs[k] = cbf;
       dist += (unsigned long long) (p.dist_weight[k] * (double) sse);             // CL/RdCost.cpp:405-408
       {                    // xGetIntraFracBitsQTChroma 2625-2692: contexts advance
@@ -1586,12 +1589,13 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
   const int x = uni(L.nx) >> 1, y = uni(L.ny) >> 1, w = uni(L.nw) >> 1, h = uni(L.nh) >> 1, P = w * h;
   for (int c = 1; c <= 2; c++) {
     const void *org = fd.org[c]; const int st = fd.stride[c];
-    for (int i = threadIdx.x; i < P; i += NT) { const int r = i / w, cc = i - r * w; L.org[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
+    int16_t *ot = org_tile(scratch, 2 * P);
+    for (int i = threadIdx.x; i < P; i += NT) { const int r = i / w, cc = i - r * w; ot[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
     build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
   }
   if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
   __syncthreads();
-  if (2 * P <= 1024) chroma_rd_loop<true>(p, scratch, wave, lane, w, h); else chroma_rd_loop<false>(p, scratch, wave, lane, w, h);
+  if (2 * P <= BUF) chroma_rd_loop<true>(p, scratch, wave, lane, w, h); else chroma_rd_loop<false>(p, scratch, wave, lane, w, h);
   __threadfence_block();
   __syncthreads();
   // winner; its CU-level bits are recomputed from the node's start contexts (EL/EncCu.cpp:2593-2619) by wave 0
@@ -1658,7 +1662,7 @@ template <bool SMALL>
 __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch, int w, int h)
 {
   const int P = w * h, n = ch ? 2 * P : P, bd = p.bit_depth;
-  int16_t *recb = SMALL ? L.slot[0] : slot_rec(scratch, n, 0, 0), *levb = SMALL ? L.slot[0] + 1024 : slot_lev(scratch, n, 0, 0);
+  int16_t *recb = SMALL ? L.slot[0] : slot_rec(scratch, n, 0, 0), *levb = SMALL ? L.slot[0] + BUF : slot_lev(scratch, n, 0, 0);
   const int mode = uni(L.rd[0].mode), fm = uni(L.rd[0].mrl), cbfm = uni(L.rd_cbf[0]);
   Cab cb; cb.ci = CI_W(0); cb.bits = 0;
   unsigned long long dist = 0;
@@ -1669,7 +1673,7 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
     for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; recb[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], w, h, px, py, ip, mode, 1, bd, dcv); }
     wave_sync();
     int cbf;
-    wave_code_block<SMALL>(0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp, lane, dist, cbf, cbfm & 1);
+    wave_code_block<SMALL>(org_tile(scratch, n), 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp, lane, dist, cbf, cbfm & 1);
     if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, fm); enc_bin(cb, (unsigned) (cbfm & 1), VX_CTX_QtCbf[0]); }
     if (cbfm & 1) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 0, lane);
   } else {
@@ -1679,7 +1683,7 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
       for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(L.refs[k][0], L.refs[k][1], w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
       wave_sync();
       unsigned long long sse; int cbf;
-      wave_code_block<SMALL>(k * P, k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1);
+      wave_code_block<SMALL>(org_tile(scratch, n), k * P, k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1);
       dist += (unsigned long long) (p.dist_weight[k] * (double) sse);
     }
     if (lane == 0) {
@@ -1711,7 +1715,8 @@ __device__ __noinline__ void op_reuse(const VxParams &p, const VxFrameDev &fd, u
   else {
     for (int c = 1; c <= 2; c++) {
       const void *org = fd.org[c]; const int st = fd.stride[c];
-      for (int i = threadIdx.x; i < P; i += NT) { const int r = i / w, cc = i - r * w; L.org[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
+      int16_t *ot = org_tile(scratch, 2 * P);
+    for (int i = threadIdx.x; i < P; i += NT) { const int r = i / w, cc = i - r * w; ot[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
       build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
     }
     if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
@@ -1726,7 +1731,7 @@ __device__ __noinline__ void op_reuse(const VxParams &p, const VxFrameDev &fd, u
   ctx_copy_all(&L.ctxs[CI_W(0)], &L.ctxs[CI_CUR]);
   __threadfence_block();
   __syncthreads();
-  if (wave == 0) { if (n <= 1024) reuse_eval<true>(p, scratch, lane, ch, w, h); else reuse_eval<false>(p, scratch, lane, ch, w, h); }
+  if (wave == 0) { if (n <= BUF) reuse_eval<true>(p, scratch, lane, ch, w, h); else reuse_eval<false>(p, scratch, lane, ch, w, h); }
   __syncthreads();
 }
 
@@ -2142,14 +2147,14 @@ __device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, 
           derive_mpms(Ld, Ad, L.mpm);
           enc_intra_luma_pred_mode(cb, f.y, u->dir, u->mrl);
           enc_bin(cb, u->cbf & 1, VX_CTX_QtCbf[0]);
-          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; residual_coding(cb, lv, W, H, 0, (uint16_t *) L.tmp[2]); }
+          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; residual_coding(cb, lv, W, H, 0, (uint16_t *) (lv + 4096)); }
         } else {
           enc_intra_chroma_pred_mode(cb, u->dir);
           enc_bin(cb, (unsigned) !!(u->cbf & 2), VX_CTX_QtCbf[1]);
           enc_bin(cb, (unsigned) !!(u->cbf & 4), VX_CTX_QtCbf[2] + !!(u->cbf & 2));
           for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c)) {
             for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[c][((f.y >> 1) + yy) * fd.lstride[c] + (f.x >> 1) + xx];
-            residual_coding(cb, lv, W, H, 1, (uint16_t *) L.tmp[2]);
+            residual_coding(cb, lv, W, H, 1, (uint16_t *) (lv + 4096));
           }
         }
         top--; continue;
@@ -2187,7 +2192,8 @@ template <typename T>
 __device__ __noinline__ void advance_ctx_ctu(const VxParams &p, const VxFrameDev &fd, int tile, int ctu_x, int ctu_y)
 {
   Cab cb; cb.ci = CI_CUR; cb.bits = 0;
-  int16_t *lv = (int16_t *) &L.tmp[0][0];        // 8 KB = tmp[0] + tmp[1]; the scan table of the estimator pass uses tmp[2]
+  uint8_t *scratch_ = p.scratch + (size_t) blockIdx.x * p.scratch_per_stream;
+  int16_t *lv = (int16_t *) (scratch_ + VXD_OFF_SLOTS);      // level tile (up to 64x64) and scan table of the estimator pass: wave 0's big-block scratch
   // 128x128 root: implicit QT for both trees (no bins); luma / chroma sub-trees interleaved per 64x64 (867-908)
   for (int q = 0; q < 4; q++) {
     const int qx = ctu_x + ((q & 1) ? 64 : 0), qy = ctu_y + ((q >= 2) ? 64 : 0);
@@ -2242,7 +2248,10 @@ __device__ void run_stream(const VxParams &p)
       for (;;) {
         if (tid == 0) {
           const long long t0 = STAMP();
-          if (VVCX_STAMP) L.prof[prev_op] += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first)
+          if (VVCX_STAMP) {
+            L.prof[prev_op] += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first)
+            if (prev_op >= OP_LUMA_PREP && prev_op <= OP_CHROMA_RD) L.prof[38 + imin(9, imax(0, ilog2i(L.nw * L.nh) - 4))] += (unsigned long long) (t0 - t_prev);   // by node size
+          }
           control_step(p, fd, scratch);
           t_prev = STAMP();
           if (VVCX_STAMP) L.prof[0] += (unsigned long long) (t_prev - t0);
@@ -2278,5 +2287,5 @@ __device__ void run_stream(const VxParams &p)
   if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); for (int i = 0; i < 48; i++) atomicAdd(&p.counters[4 + i], L.prof[i]); }
 }
 
-extern "C" __global__ void __launch_bounds__(NT, 2) vvcx_compress_kernel_u8(VxParams p) { run_stream<uint8_t>(p); }
-extern "C" __global__ void __launch_bounds__(NT, 2) vvcx_compress_kernel_u16(VxParams p) { run_stream<uint16_t>(p); }
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_kernel_u8(VxParams p) { run_stream<uint8_t>(p); }
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_kernel_u16(VxParams p) { run_stream<uint16_t>(p); }

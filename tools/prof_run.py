@@ -20,3 +20,4 @@ for i,n in enumerate(phn): print("  ph %-12s %.3e"%(n,pr[16+i]))
 print("B wave0: pred %.3e code_block %.3e rate %.3e"%(pr[28],pr[29],pr[31]))
 print("rc wave0: prepass %.3e meta %.3e emit %.3e chain %.3e reduce %.3e calls %d"%(pr[32],pr[33],pr[34],pr[35],pr[36],pr[37]))
 print("steps",pr[30],"counters",enc.counters())
+print("search ops by luma node area (16,32,...,4096+):", ["%.2e" % v for v in pr[38:48]])
