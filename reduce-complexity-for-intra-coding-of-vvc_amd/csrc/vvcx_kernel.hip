@@ -129,6 +129,9 @@ __device__ inline int ilog2i(int v) { return 31 - __clz(v); }
 __device__ inline int imin(int a, int b) { return a < b ? a : b; }
 __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 __device__ inline int iabs(int a) { return a < 0 ? -a : a; }
+// i / d where d is usually a power of two (block and node dimensions; only clipped node areas at the picture edge are not): ld = log2 d or -1
+__device__ inline int pow2_log(int d) { return (d & (d - 1)) == 0 ? 31 - __clz(d) : -1; }
+__device__ inline int fast_div(int i, int d, int ld) { return ld >= 0 ? i >> ld : i / d; }
 // Values that are uniform across the workgroup / wavefront at run time but that the compiler sees in VGPRs
 // (LDS loads, threadIdx-derived wave index, arguments of non-inlined functions) are moved to SGPRs before they
 // steer any control flow that contains a barrier, a wave barrier or a shuffle: the structurizer may otherwise
@@ -233,7 +236,7 @@ __device__ inline void enc_rem_abs(Cab &cb, unsigned bins, unsigned rice)       
 struct Cctx { int w, h, ch, tmpl_diag, tmpl_sum1; };
 __device__ int sig_ctx(Cctx &c, const int16_t *coeff, int blk)      // CL/ContextModelling.h:107-156 (state 0)
 {
-  const int W = c.w, H = c.h, posY = blk / W, posX = blk - posY * W;
+  const int W = c.w, H = c.h, posY = blk >> ilog2i(W), posX = blk & (W - 1);
   const int16_t *p = coeff + blk;
   const int diag = posX + posY;
   int numPos = 0, sumAbs = 0;
@@ -248,7 +251,7 @@ __device__ int sig_ctx(Cctx &c, const int16_t *coeff, int blk)      // CL/Contex
 }
 __device__ int tmpl_abs_sum(const Cctx &c, const int16_t *coeff, int blk, int base)
 {
-  const int W = c.w, H = c.h, posY = blk / W, posX = blk - posY * W;
+  const int W = c.w, H = c.h, posY = blk >> ilog2i(W), posX = blk & (W - 1);
   const int16_t *p = coeff + blk;
   int sum = 0;
   if (posX < W - 1) { sum += iabs(p[1]); if (posX < W - 2) sum += iabs(p[2]); if (posY < H - 1) sum += iabs(p[W + 1]); }
@@ -346,7 +349,7 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
   else { offx = L.t.last_prefix[l2w]; offy = L.t.last_prefix[l2h]; shx = (l2w + 1) >> 2; shy = (l2h + 1) >> 2; }
   {
     const int blk = scan[scanPosLast];
-    const int posY = blk / w, posX = blk - posY * w;
+    const int posY = blk >> ilog2i(w), posX = blk & (w - 1);
     const int gx = L.t.group_idx[posX], gy = L.t.group_idx[posY];
     const int maxX = L.t.group_idx[zw - 1], maxY = L.t.group_idx[zh - 1];
     int k;
@@ -531,7 +534,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
     if (is_chroma) { shx = imin(2, w >> 3); shy = imin(2, h >> 3); }
     else { offx = L.t.last_prefix[l2w]; offy = L.t.last_prefix[l2h]; shx = (l2w + 1) >> 2; shy = (l2h + 1) >> 2; }
     const int blk = scan_blk(geo, last);
-    const int posY = blk / w, posX = blk - posY * w;
+    const int posY = blk >> ilog2i(w), posX = blk & (w - 1);
     const int gx = uni(L.t.group_idx[posX]), gy = uni(L.t.group_idx[posY]);
     const int maxX = L.t.group_idx[zw - 1], maxY = L.t.group_idx[zh - 1];
     const int nX = gx + (gx < maxX), nY = gy + (gy < maxY);
@@ -555,7 +558,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
     int cf = 0, sigofs = 0, goff = 0, sumPlain = 0;
     if (coded) {
       const int blk = scan_blk(geo, sp);
-      const int posY = blk / w, posX = blk - posY * w;
+      const int posY = blk >> ilog2i(w), posX = blk & (w - 1);
       const int16_t *pc = coeff + blk;
       cf = pc[0];
       const int diag = posX + posY;
@@ -963,8 +966,8 @@ __device__ __noinline__ void build_refs(const VxParams &p, const VxFrameDev &fd,
   const int unit = ch ? 2 : 4, ul = ch ? 1 : 2;
   const int W = ch ? p.pic_w >> 1 : p.pic_w, H = ch ? p.pic_h >> 1 : p.pic_h;
   const int predW = 2 * w, predH = 2 * h;
-  const int totalAbove = predW / unit, totalLeft = predH / unit, totalUnits = totalAbove + totalLeft + 1;
-  const int numAbove = w / unit, numLeft = h / unit;
+  const int totalAbove = predW >> ul, totalLeft = predH >> ul, totalUnits = totalAbove + totalLeft + 1;
+  const int numAbove = w >> ul, numLeft = h >> ul;
   if (tid < totalUnits) {
     int ux, uy;                         // a sample position inside the unit
     if (tid < totalLeft) { ux = x - 1; uy = y + (totalLeft - 1 - tid) * unit; }
@@ -1001,8 +1004,8 @@ __device__ __noinline__ void build_refs(const VxParams &p, const VxFrameDev &fd,
       if (i < nLeft) { isTop = 0; idx = nLeft - i; } else if (i == nLeft) { isTop = 0; idx = 0; } else { isTop = 1; idx = i - nLeft; }
       int u;
       if (idx <= mrl) u = totalLeft;
-      else if (isTop) u = totalLeft + 1 + (idx - 1 - mrl) / unit;
-      else u = totalLeft - 1 - (idx - 1 - mrl) / unit;
+      else if (isTop) u = totalLeft + 1 + ((idx - 1 - mrl) >> ul);
+      else u = totalLeft - 1 - ((idx - 1 - mrl) >> ul);
       int sx, sy, val;
       const int su = L.src_unit[u];
       if (su == -1) val = dcv;
@@ -1085,7 +1088,7 @@ __device__ inline void sad_satd_tiles(const int16_t *org, const int16_t *pred, i
   const int tilesX = w / BW, tsz = BW * BH;
   int sad = 0;
   for (int s = lane; s < P / BW; s += 64) {            // one row segment of a tile per lane
-    const int t = s / BH, r = s - t * BH, tx = t % tilesX, ty = t / tilesX;
+    const int t = s / BH, r = s - t * BH, tx = t & (tilesX - 1), ty = t >> ilog2i(tilesX);      // tilesX is a power of two
     const int base = (ty * BH + r) * w + tx * BW;
     int v[BW];
     row_diff<BW>(org + base, pred + base, v);
@@ -1197,13 +1200,13 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   int16_t *rec = SMALL ? L.slot[wave_] + uni(buf_off) : rec_g, *lev = SMALL ? L.slot[wave_] + BUF + uni(buf_off) : lev_g;
   int32_t *tmp = SMALL ? L.tmp[wave_] : tmp_g;
   const int P = w * h, lw = ilog2i(w), lh = ilog2i(h);
-  const int zw = imin(w, 32), zh = imin(h, 32);
+  const int zw = imin(w, 32), zh = imin(h, 32), lzw = imin(lw, 5);
   const int8_t *Mw = dct2_matrix(w), *Mh = dct2_matrix(h);
   const int shift1 = lw + bd + 6 - 15, shift2 = lh + 6;
   const int rnd1 = shift1 > 0 ? 1 << (shift1 - 1) : 0, rnd2 = 1 << (shift2 - 1);
   // stage 1 (horizontal): tmp[k*h + j] = (sum_i Mw[k][i] * resi[j][i] + rnd) >> shift1, k < zw
   if (given < 0) for (int o = lane; o < zw * h; o += 64) {
-    const int k = o / h, j = o - k * h;
+    const int k = o >> lh, j = o & (h - 1);
     int s = 0;
     for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + i] - rec[j * w + i]);
     tmp[o] = (s + rnd1) >> shift1;
@@ -1219,7 +1222,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   if (given < 0 && (w > 32 || h > 32)) { for (int o = lane; o < P; o += 64) lev[o] = 0; wave_sync(); }
   int abs_sum = 0;
   if (given < 0) for (int o = lane; o < zw * zh; o += 64) {
-    const int m = o / zw, k = o - m * zw;
+    const int m = o >> lzw, k = o & (zw - 1);
     int s = 0;
     for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
     const int c = (s + rnd2) >> shift2;
@@ -1240,7 +1243,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     const int in_min = -(1 << (tbd - 1)), in_max = (1 << (tbd - 1)) - 1;
     // inverse stage 1 (vertical): t[j*h + i] = clip((sum_k Mh[k][i] * deq(lev[k*w + j]) + 64) >> 7), j < zw
     for (int o = lane; o < zw * h; o += 64) {
-      const int j = o / h, i = o - j * h;
+      const int j = o >> lh, i = o & (h - 1);
       int s = 0;
       for (int k = 0; k < zh; k++) {
         int q = lev[k * w + j]; q = q < in_min ? in_min : q > in_max ? in_max : q;
@@ -1255,7 +1258,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     const int ishift2 = (6 + 15 - 1) - bd, irnd2 = 1 << (ishift2 - 1);
     const int mx = (1 << bd) - 1;
     for (int o = lane; o < P; o += 64) {
-      const int j2 = o / w, i2 = o - j2 * w;
+      const int j2 = o >> lw, i2 = o & (w - 1);
       int s = 0;
       for (int k = 0; k < zw; k++) s += Mw[k * w + i2] * tmp[k * h + j2];
       int r = (s + irnd2) >> ishift2;
@@ -1306,7 +1309,7 @@ __device__ __noinline__ void op_luma_prep(const VxParams &p, const VxFrameDev &f
   const long long ts = STAMP();
   const void *org = fd.org[0]; const int st = fd.stride[0];
   int16_t *ot = org_tile(p.scratch + (size_t) blockIdx.x * p.scratch_per_stream, w * h);
-  for (int i = threadIdx.x; i < w * h; i += NT) { const int r = i / w, c = i - r * w; ot[i] = (int16_t) ld_px<T>(org, (y + r) * st + x + c); }
+  for (int i = threadIdx.x; i < w * h; i += NT) { const int r = i >> ilog2i(w), c = i & (w - 1); ot[i] = (int16_t) ld_px<T>(org, (y + r) * st + x + c); }
   const int nsets = ((y & 127) == 0 || !(p.tools & 1)) ? 1 : 3;
   build_refs<T>(p, fd, 0, x, y, w, h, uni(L.cur_tile), nsets);
   if (threadIdx.x < 4) {
@@ -1398,7 +1401,7 @@ __device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     const int16_t *top = L.refs[set][0], *left = L.refs[set][1];
     const int dcv = L.dc_val[luma_set(mrl, 0)];
     const long long ta = STAMP();
-    for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; pred[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
+    for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); pred[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
     wave_sync();
     const long long tb = STAMP();
     unsigned long long sad, satd;
@@ -1470,7 +1473,7 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     const int16_t *top = L.refs[set][0], *left = L.refs[set][1];
     const int dcv = L.dc_val[luma_set(mrl, 0)];
     const long long tb0 = STAMP();
-    for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
+    for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
     wave_sync();
     const long long tb1 = STAMP();
     unsigned long long sse; int cbf;
@@ -1544,7 +1547,7 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
     for (int k = 0; k < 2; k++) {
       int16_t *rec = recb + k * P, *lev = levb + k * P;
       const int16_t *top = L.refs[k][0], *left = L.refs[k][1];
-      for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
+      for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
       wave_sync();
       unsigned long long sse; int cbf;
       wave_code_block<SMALL>(org_tile(scratch, 2 * P), k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_c[k], lane, sse, cbf);
@@ -1590,7 +1593,7 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
   for (int c = 1; c <= 2; c++) {
     const void *org = fd.org[c]; const int st = fd.stride[c];
     int16_t *ot = org_tile(scratch, 2 * P);
-    for (int i = threadIdx.x; i < P; i += NT) { const int r = i / w, cc = i - r * w; ot[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
+    for (int i = threadIdx.x; i < P; i += NT) { const int r = i >> ilog2i(w), cc = i & (w - 1); ot[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
     build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
   }
   if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
@@ -1631,9 +1634,9 @@ __device__ int cache_slot(int x, int y, int w, int h, int &lev_off)
   if (lw > 6 || lh > 6) return -1;
   const int ax = imax(4, w >> 1), ay = imax(4, h >> 1), rx = x & 127, ry = y & 127;
   if ((rx & (ax - 1)) | (ry & (ay - 1))) return -1;
-  const int npx = 128 / ax, segW = w * npx;
+  const int lax = ilog2i(ax), lay = ilog2i(ay), npx = 128 >> lax, segW = w * npx;
   const int cumW = lw == 2 ? 0 : 128 + (lw - 3) * 256, cumH = lh == 2 ? 0 : 128 + (lh - 3) * 256;
-  lev_off = cumW * VXD_CACHE_DIM + segW * cumH + ((ry / ay) * npx + rx / ax) * w * h;
+  lev_off = cumW * VXD_CACHE_DIM + segW * cumH + ((ry >> lay) * npx + (rx >> lax)) * w * h;
   return (((ry >> 2) * 32 + (rx >> 2)) * 5 + (lw - 2)) * 5 + (lh - 2);
 }
 // isValid (987-1024) + isTheSameNbHood (664-703): thread 0, at node entry.  Frame i of the stack was produced by split
@@ -1670,7 +1673,7 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
     Ipa ip; init_pred_params(w, h, 1, mode, fm, ip);
     const int set = luma_set(fm, ip.ref_filter);
     const int dcv = L.dc_val[luma_set(fm, 0)];
-    for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; recb[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], w, h, px, py, ip, mode, 1, bd, dcv); }
+    for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); recb[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], w, h, px, py, ip, mode, 1, bd, dcv); }
     wave_sync();
     int cbf;
     wave_code_block<SMALL>(org_tile(scratch, n), 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp, lane, dist, cbf, cbfm & 1);
@@ -1680,7 +1683,7 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
     Ipa ip; init_pred_params(w, h, 0, fm, 0, ip);
     for (int k = 0; k < 2; k++) {
       int16_t *rec = recb + k * P;
-      for (int i = lane; i < P; i += 64) { const int py = i / w, px = i - py * w; rec[i] = (int16_t) pred_sample(L.refs[k][0], L.refs[k][1], w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
+      for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(L.refs[k][0], L.refs[k][1], w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
       wave_sync();
       unsigned long long sse; int cbf;
       wave_code_block<SMALL>(org_tile(scratch, n), k * P, k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1);
@@ -1716,7 +1719,7 @@ __device__ __noinline__ void op_reuse(const VxParams &p, const VxFrameDev &fd, u
     for (int c = 1; c <= 2; c++) {
       const void *org = fd.org[c]; const int st = fd.stride[c];
       int16_t *ot = org_tile(scratch, 2 * P);
-    for (int i = threadIdx.x; i < P; i += NT) { const int r = i / w, cc = i - r * w; ot[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
+    for (int i = threadIdx.x; i < P; i += NT) { const int r = i >> ilog2i(w), cc = i & (w - 1); ot[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
       build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
     }
     if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
@@ -1748,16 +1751,18 @@ __device__ __noinline__ void op_save_pic(const VxParams &p, const VxFrameDev &fd
     const int comp = ch ? k + 1 : 0;
     int16_t *srec = (int16_t *) lvl + k * (Wn * (L.nh >> sh)), *slev = (int16_t *) (lvl + VXD_STORE_REC) + k * (Wn * (L.nh >> sh));
     void *rec = fd.rec[comp]; int16_t *lev = fd.lev[comp]; const int st = fd.stride[comp], ls = fd.lstride[comp];
+    const int lcw = pow2_log(cw);
     for (int i = threadIdx.x; i < cw * chh; i += NT) {
-      const int r = i / cw, c = i - r * cw;
+      const int r = fast_div(i, cw, lcw), c = i - r * cw;
       if (restore) { st_px<T>(rec, (Y0 + r) * st + X0 + c, srec[r * Wn + c]); lev[(Y0 + r) * ls + X0 + c] = slev[r * Wn + c]; }
       else { srec[r * Wn + c] = (int16_t) ld_px<T>(rec, (Y0 + r) * st + X0 + c); slev[r * Wn + c] = lev[(Y0 + r) * ls + X0 + c]; }
     }
   }
   VxUnit *su = (VxUnit *) (lvl + 2 * VXD_STORE_REC);
   const int ux0 = L.nx >> 2, uy0 = L.ny >> 2, ucw = ((x1 + 3) >> 2) - ux0, uch = ((y1 + 3) >> 2) - uy0;
+  const int lucw = pow2_log(ucw);
   for (int i = threadIdx.x; i < ucw * uch; i += NT) {
-    const int r = i / ucw, c = i - r * ucw;
+    const int r = fast_div(i, ucw, lucw), c = i - r * ucw;
     if (restore) fd.units[ch][(uy0 + r) * p.uw + ux0 + c] = su[r * 32 + c];
     else su[r * 32 + c] = fd.units[ch][(uy0 + r) * p.uw + ux0 + c];
   }
@@ -1790,7 +1795,7 @@ __device__ __noinline__ void op_save_intra(const VxParams &p, uint8_t *scratch, 
   }
   VxUnit *su = (VxUnit *) (lvl + 2 * VXD_STORE_REC);
   const int ucw = (L.nw + 3) >> 2, uch = (L.nh + 3) >> 2;
-  for (int i = threadIdx.x; i < ucw * uch; i += NT) su[(i / ucw) * 32 + (i % ucw)] = cu;
+  for (int i = threadIdx.x; i < ucw * uch; i += NT) { const int r = i >> ilog2i(ucw); su[r * 32 + (i & (ucw - 1))] = cu; }      // unclipped node: power of two
   ctx_copy_all(ctx_ptr(scratch, CTX_BEST, d, 0), &L.ctxs[CI_W(0)]);
   __threadfence_block();
   __syncthreads();
@@ -1800,7 +1805,8 @@ __device__ __noinline__ void op_clear_units(const VxParams &p, const VxFrameDev 
   const int ch = L.tree_ch;
   const int x1 = imin(L.nx + L.nw, p.pic_w), y1 = imin(L.ny + L.nh, p.pic_h);
   const int ux0 = L.nx >> 2, uy0 = L.ny >> 2, ucw = ((x1 + 3) >> 2) - ux0, uch = ((y1 + 3) >> 2) - uy0;
-  for (int i = threadIdx.x; i < ucw * uch; i += NT) fd.units[ch][(uy0 + i / ucw) * p.uw + ux0 + (i % ucw)].tag = 0;
+  const int lucw = pow2_log(ucw);
+  for (int i = threadIdx.x; i < ucw * uch; i += NT) { const int r = fast_div(i, ucw, lucw); fd.units[ch][(uy0 + r) * p.uw + ux0 + (i - r * ucw)].tag = 0; }
   __threadfence_block();
   __syncthreads();
 }
