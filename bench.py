@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — CTUs/sec of the intra CU-partition RDO hot path on MI355X (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch: one 1920x1080 8-bit 4:2:0 All-Intra frame (135 CTUs of
-128x128) at QP 32, full RDO (no early termination) with the tool subset built so far (see config.tools).
-The frame is cut into a uniform 15x9 tile grid so that every CTU is an independent stream (one workgroup per
-stream); original planes are resident in HBM before the timed region.  With --gpus N every rank
-encodes its own frame per step (weak scaling, no data-path collective; frames are independent in All-Intra).
+A "step" = one pass of the hot path over one batch of 1920x1080 8-bit 4:2:0 All-Intra frames (135 CTUs of 128x128
+each) at QP 32, full RDO (no early termination) with the tool subset built so far (see config.tools).  Every frame is
+cut into a uniform 15x9 tile grid so that every CTU is an independent stream (one workgroup per stream, SURVEY.md
+§8e); the batch holds enough frames for ~4 full waves of resident streams (30 frames on a 256-CU part, --frames to
+override); original planes are resident in HBM before the timed region.  With --gpus N every rank encodes its own
+frames per step (weak scaling, no data-path collective; frames are independent in All-Intra).
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against HBM bandwidth with the
 algorithmic bytes of SURVEY.md §8d (49 152 B per 8-bit CTU); `cpu_baseline` times the CPU oracle (a port of the
