@@ -124,6 +124,27 @@ int  vvcx_ctus_per_frame(const vvcx_handle *h);
  * many (frame, tile) streams fill the GPU.  ≙ the worker-thread count a frame-parallel host loop would size for */
 int  vvcx_resident_streams(const vvcx_handle *h);
 
+
+/* ---- leaf operators: the device functions of the path, individually callable.  They stand where the
+ * reference has its run-time seams — RdCost::m_afpDistortFunc[DF_*] (CL/RdCost.h:60,104) — and its CommonLib entry points
+ * IntraPrediction::initIntraPatternChType + predIntraAng (CL/IntraPrediction.cpp:304,1064), BinProbModel_Std
+ * (CL/Contexts.h:86-155), RdCost::calcRdCost (CL/RdCost.cpp:63), the scan tables (CL/Rom.cpp:133-370).  Test and
+ * diagnostic entry points: all pointers are HOST memory, the work runs on the device the handle / call selects. */
+/* SAD, SATD (RdCost::xGetHADs tiling and normalisation) and SSE of n pairs of w x h blocks stored back to back; out[n][3] */
+int  vvcx_distortion_batch(const int16_t *a, const int16_t *b, int w, int h, int n, uint64_t *out, int device);
+/* intra prediction of n blocks of one picture: reco = planar 4:2:0 samples of the handle's size and bit depth (uint8 / uint16),
+ * coded[2] = one byte per 4x4 luma unit (uw x uh, 1 = already reconstructed) for the luma and the chroma tree.
+ * x, y, w, h in samples of the component; mode 0..66, mrl 0/1/3 (luma).  pred: concatenated w*h tiles */
+typedef struct { int32_t comp, x, y, w, h, mode, mrl; } vvcx_pred_case;
+int  vvcx_intra_pred_batch(vvcx_handle *h, const void *const reco[3], const uint8_t *const coded[2], const vvcx_pred_case *cases, int n, int16_t *pred);
+/* CtxStore initialisation of an I slice (CL/Contexts.cpp:135-151) and the estimator's model update over a bin string */
+int  vvcx_ctx_init(int qp, uint16_t s0[386], uint16_t s1[386]);
+int  vvcx_cabac_code_bins(uint16_t *s0, uint16_t *s1, int ctx, const uint8_t *bins, int nbins, uint64_t *frac_bits, int device);
+/* RdCost::calcRdCost for n (fracBits, dist) pairs at one lambda */
+int  vvcx_rd_cost_batch(double lambda, const uint64_t *frac_bits, const uint64_t *dist, int n, double *cost, int device);
+/* coefficient scan (diagonal, grouped) of a w x h block: idx[min(w,32) * min(h,32)] raster offsets in scan order */
+int  vvcx_scan_order(int w, int h, uint16_t *idx, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,12 @@
 
 extern "C" __global__ void vvcx_compress_kernel_u8(VxParams p);
 extern "C" __global__ void vvcx_compress_kernel_u16(VxParams p);
+extern "C" __global__ void vvcx_leaf_dist_kernel(const int16_t *a, const int16_t *b, int w, int h, int16_t *scr, unsigned long long *out);
+extern "C" __global__ void vvcx_leaf_pred_kernel_u8(VxParams p, const VxLeafPred *cases, int16_t *out, const int *out_off);
+extern "C" __global__ void vvcx_leaf_pred_kernel_u16(VxParams p, const VxLeafPred *cases, int16_t *out, const int *out_off);
+extern "C" __global__ void vvcx_leaf_cabac_kernel(uint16_t *io, int ctx, const uint8_t *bins, int nbins, unsigned long long *bits);
+extern "C" __global__ void vvcx_leaf_rdcost_kernel(VxParams p, const unsigned long long *bits, const unsigned long long *dist, int n, double *cost);
+extern "C" __global__ void vvcx_leaf_scan_kernel(int w, int h, uint16_t *idx);
 
 static thread_local char g_err[512];
 extern "C" const char *vvcx_last_error(void) { return g_err; }
@@ -286,5 +292,122 @@ extern "C" int vvcx_get_profile(vvcx_handle *h, uint64_t out[48])
   unsigned long long c[52];
   HIPCHK(hipMemcpy(c, h->counters_d, sizeof c, hipMemcpyDeviceToHost));
   for (int i = 0; i < 48; i++) out[i] = c[4 + i];
+  return VVCX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ leaf operators
+namespace {
+struct DevBuf {                         // device allocation released on scope exit
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void) hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+  template <typename T> T *as() { return (T *) p; }
+};
+bool pow2_block(int w, int h) { return w >= 2 && h >= 2 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)); }
+}
+
+extern "C" int vvcx_distortion_batch(const int16_t *a, const int16_t *b, int w, int h, int n, uint64_t *out, int device)
+{
+  if (!a || !b || !out || n < 0 || !pow2_block(w, h)) return fail(VVCX_ERR_ARG, "bad argument");
+  if (n == 0) return VVCX_OK;
+  HIPCHK(hipSetDevice(device));
+  const size_t bytes = (size_t) n * w * h * 2;
+  DevBuf da, db, ds, dout;
+  HIPCHK(da.alloc(bytes)); HIPCHK(db.alloc(bytes)); HIPCHK(ds.alloc(bytes)); HIPCHK(dout.alloc((size_t) n * 3 * 8));
+  HIPCHK(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(vvcx_leaf_dist_kernel, dim3((unsigned) n), dim3(VXD_NT), 0, 0, da.as<int16_t>(), db.as<int16_t>(), w, h, ds.as<int16_t>(), dout.as<unsigned long long>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, dout.p, (size_t) n * 3 * 8, hipMemcpyDeviceToHost));
+  return VVCX_OK;
+}
+
+extern "C" int vvcx_intra_pred_batch(vvcx_handle *h, const void *const reco[3], const uint8_t *const coded[2], const vvcx_pred_case *cases, int n, int16_t *pred)
+{
+  if (!h || !reco || !coded || !cases || !pred || n < 0) return fail(VVCX_ERR_ARG, "bad argument");
+  if (n == 0) return VVCX_OK;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int bps = h->cfg.bit_depth == 8 ? 1 : 2, W = h->cfg.pic_w, H = h->cfg.pic_h;
+  std::vector<int> off((size_t) n); size_t total = 0;
+  for (int i = 0; i < n; i++) {
+    const vvcx_pred_case &c = cases[i];
+    const int cw = c.comp ? W >> 1 : W, chh = c.comp ? H >> 1 : H;
+    if (c.comp < 0 || c.comp > 2 || !pow2_block(c.w, c.h) || c.x < 0 || c.y < 0 || c.x + c.w > cw || c.y + c.h > chh || c.mode < 0 || c.mode > 66 ||
+        (c.mrl != 0 && (c.comp != 0 || (c.mrl != 1 && c.mrl != 3)))) return fail(VVCX_ERR_ARG, "bad prediction case %d", i);
+    off[(size_t) i] = (int) total; total += (size_t) c.w * c.h;
+  }
+  DevBuf dplane[3], dunits, dframe, dcases, doff, dpred;
+  VxFrameDev fd; memset(&fd, 0, sizeof fd);
+  for (int c = 0; c < 3; c++) {
+    const size_t pw = c ? W >> 1 : W, ph = c ? H >> 1 : H;
+    if (!reco[c]) return fail(VVCX_ERR_ARG, "plane %d is null", c);
+    HIPCHK(dplane[c].alloc(pw * ph * bps)); HIPCHK(hipMemcpy(dplane[c].p, reco[c], pw * ph * bps, hipMemcpyHostToDevice));
+    fd.org[c] = dplane[c].p; fd.rec[c] = dplane[c].p; fd.stride[c] = (int32_t) pw;
+  }
+  const size_t nu = (size_t) h->uw * h->uh;
+  std::vector<VxUnit> units(2 * nu); memset(units.data(), 0, units.size() * sizeof(VxUnit));
+  for (int t = 0; t < 2; t++) { if (!coded[t]) return fail(VVCX_ERR_ARG, "coded map %d is null", t); for (size_t i = 0; i < nu; i++) units[(size_t) t * nu + i].tag = coded[t][i] ? 1 : 0; }
+  HIPCHK(dunits.alloc(units.size() * sizeof(VxUnit))); HIPCHK(hipMemcpy(dunits.p, units.data(), units.size() * sizeof(VxUnit), hipMemcpyHostToDevice));
+  fd.units[0] = dunits.as<VxUnit>(); fd.units[1] = dunits.as<VxUnit>() + nu;
+  HIPCHK(dframe.alloc(sizeof fd)); HIPCHK(hipMemcpy(dframe.p, &fd, sizeof fd, hipMemcpyHostToDevice));
+  HIPCHK(dcases.alloc((size_t) n * sizeof(VxLeafPred))); HIPCHK(hipMemcpy(dcases.p, cases, (size_t) n * sizeof(VxLeafPred), hipMemcpyHostToDevice));
+  HIPCHK(doff.alloc((size_t) n * 4)); HIPCHK(hipMemcpy(doff.p, off.data(), (size_t) n * 4, hipMemcpyHostToDevice));
+  HIPCHK(dpred.alloc(total * 2));
+  VxParams p; memset(&p, 0, sizeof p);
+  p.pic_w = W; p.pic_h = H; p.bit_depth = h->cfg.bit_depth; p.tools = h->cfg.tools; p.uw = h->uw; p.uh = h->uh; p.frames = dframe.as<VxFrameDev>();
+  if (bps == 1) hipLaunchKernelGGL(vvcx_leaf_pred_kernel_u8, dim3((unsigned) n), dim3(VXD_NT), 0, 0, p, dcases.as<VxLeafPred>(), dpred.as<int16_t>(), doff.as<int>());
+  else hipLaunchKernelGGL(vvcx_leaf_pred_kernel_u16, dim3((unsigned) n), dim3(VXD_NT), 0, 0, p, dcases.as<VxLeafPred>(), dpred.as<int16_t>(), doff.as<int>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(pred, dpred.p, total * 2, hipMemcpyDeviceToHost));
+  return VVCX_OK;
+}
+
+extern "C" int vvcx_ctx_init(int qp, uint16_t *s0, uint16_t *s1)
+{
+  if (!s0 || !s1) return fail(VVCX_ERR_ARG, "null argument");
+  ctx_init_islice(qp, s0, s1);
+  return VVCX_OK;
+}
+
+extern "C" int vvcx_cabac_code_bins(uint16_t *s0, uint16_t *s1, int ctx, const uint8_t *bins, int nbins, uint64_t *frac_bits, int device)
+{
+  if (!s0 || !s1 || !bins || !frac_bits || nbins < 0 || ctx < 0 || ctx >= VXD_NUM_CTX) return fail(VVCX_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  DevBuf dio, dbins, dbits;
+  uint16_t io[2] = { *s0, *s1 };
+  HIPCHK(dio.alloc(4)); HIPCHK(dbins.alloc((size_t) nbins)); HIPCHK(dbits.alloc(8));
+  HIPCHK(hipMemcpy(dio.p, io, 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dbins.p, bins, (size_t) nbins, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(vvcx_leaf_cabac_kernel, dim3(1), dim3(VXD_NT), 0, 0, dio.as<uint16_t>(), ctx, dbins.as<uint8_t>(), nbins, dbits.as<unsigned long long>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(io, dio.p, 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(frac_bits, dbits.p, 8, hipMemcpyDeviceToHost));
+  *s0 = io[0]; *s1 = io[1];
+  return VVCX_OK;
+}
+
+extern "C" int vvcx_rd_cost_batch(double lambda, const uint64_t *frac_bits, const uint64_t *dist, int n, double *cost, int device)
+{
+  if (!(lambda > 0.0) || !frac_bits || !dist || !cost || n < 0) return fail(VVCX_ERR_ARG, "bad argument");
+  if (n == 0) return VVCX_OK;
+  HIPCHK(hipSetDevice(device));
+  DevBuf db, dd, dc;
+  HIPCHK(db.alloc((size_t) n * 8)); HIPCHK(dd.alloc((size_t) n * 8)); HIPCHK(dc.alloc((size_t) n * 8));
+  HIPCHK(hipMemcpy(db.p, frac_bits, (size_t) n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dd.p, dist, (size_t) n * 8, hipMemcpyHostToDevice));
+  VxParams p; memset(&p, 0, sizeof p);
+  p.lambda = lambda; p.dist_scale = (double) (1 << 15) / lambda;
+  hipLaunchKernelGGL(vvcx_leaf_rdcost_kernel, dim3((unsigned) ((n + VXD_NT - 1) / VXD_NT)), dim3(VXD_NT), 0, 0, p, db.as<unsigned long long>(), dd.as<unsigned long long>(), n, dc.as<double>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(cost, dc.p, (size_t) n * 8, hipMemcpyDeviceToHost));
+  return VVCX_OK;
+}
+
+extern "C" int vvcx_scan_order(int w, int h, uint16_t *idx, int device)
+{
+  if (!idx || !pow2_block(w, h)) return fail(VVCX_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  const int n = (w < 32 ? w : 32) * (h < 32 ? h : 32);
+  DevBuf d; HIPCHK(d.alloc((size_t) n * 2));
+  hipLaunchKernelGGL(vvcx_leaf_scan_kernel, dim3(1), dim3(VXD_NT), 0, 0, w, h, d.as<uint16_t>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(idx, d.p, (size_t) n * 2, hipMemcpyDeviceToHost));
   return VVCX_OK;
 }

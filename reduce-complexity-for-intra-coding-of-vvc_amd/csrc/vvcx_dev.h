@@ -36,6 +36,8 @@ struct VxFrameDev {         // one bound picture
   VxUnit     *units[2];     // luma-tree / chroma-tree maps, uw x uh
 };
 
+struct VxLeafPred { int32_t comp, x, y, w, h, mode, mrl; };      // same layout as vvcx_pred_case
+
 struct VxStreamDesc { int32_t frame, tile, first_task, n_tasks; };
 
 struct VxCtuRes { uint64_t dist, bits; double cost; int32_t n_cu, pad; };

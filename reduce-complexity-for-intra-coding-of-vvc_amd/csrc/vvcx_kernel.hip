@@ -85,7 +85,7 @@ struct Tables {                    // constant tables staged once per workgroup 
   int8_t   gauss[128], cubic[128];
   uint8_t  last_prefix[8], mode_shift[8];
   uint8_t  ctx_rate[NCTX + 2], gorice_pars[32], gorice_pos0[96], group_idx[64], mode_num[36], intra_thr[8];
-  int8_t   dct[4 + 16 + 64 + 256 + 1024 + 4096];
+  int8_t   dct[4 + 16 + 64 + 256 + 1024 + (BUF >= 256 ? 4096 : 0)];   // DCT-II 2..32, and 64 when a 64-wide block can be LDS resident (64x4 = 256 samples)
   uint8_t  cg_scan[52], grp_scan[228];   // diagonal scans (CL/Rom.cpp:87-131) as x | y << 4: inside a coefficient group {4x4, 2x2, 8x2, 2x8}; of the groups, per (log2 wg, log2 hg)
 };
 
@@ -1151,8 +1151,11 @@ __device__ __noinline__ void wave_sad_satd(const int16_t *org_g, const int16_t *
 }
 
 // ------------------------------------------------------------------------------------------------ transform + quant (one wave)
-__device__ inline const int8_t *dct2_matrix(int n)
+template <bool SMALL> __device__ inline const int8_t *dct2_matrix(int n)
 {
+  if (!SMALL && BUF < 256) {                            // HBM path of a build without the 64-point matrix in LDS: constant tables
+    switch (n) { case 2: return VX_DCT2_2; case 4: return VX_DCT2_4; case 8: return VX_DCT2_8; case 16: return VX_DCT2_16; case 32: return VX_DCT2_32; default: return VX_DCT2_64; }
+  }
   switch (n) { case 2: return L.t.dct; case 4: return L.t.dct + 4; case 8: return L.t.dct + 20; case 16: return L.t.dct + 84; case 32: return L.t.dct + 340; default: return L.t.dct + 1364; }
 }
 __device__ void load_tables()
@@ -1183,7 +1186,7 @@ __device__ void load_tables()
   for (int i = tid; i < 64; i += NT) L.t.dct[20 + i] = VX_DCT2_8[i];
   for (int i = tid; i < 256; i += NT) L.t.dct[84 + i] = VX_DCT2_16[i];
   for (int i = tid; i < 1024; i += NT) L.t.dct[340 + i] = VX_DCT2_32[i];
-  for (int i = tid; i < 4096; i += NT) L.t.dct[1364 + i] = VX_DCT2_64[i];
+  if (BUF >= 256) for (int i = tid; i < 4096; i += NT) L.t.dct[1364 + i] = VX_DCT2_64[i];
 }
 // residual (org - pred) → DCT-II (TrQuant::xT 835-915) → plain quant (Quant::quant 994-1089) → levels;
 // if any level: dequant (423-549) → inverse DCT-II (xIT 917-992) → reco = clip(pred + resi) written over pred.
@@ -1201,7 +1204,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   int32_t *tmp = SMALL ? L.tmp[wave_] : tmp_g;
   const int P = w * h, lw = ilog2i(w), lh = ilog2i(h);
   const int zw = imin(w, 32), zh = imin(h, 32), lzw = imin(lw, 5);
-  const int8_t *Mw = dct2_matrix(w), *Mh = dct2_matrix(h);
+  const int8_t *Mw = dct2_matrix<SMALL>(w), *Mh = dct2_matrix<SMALL>(h);
   const int shift1 = lw + bd + 6 - 15, shift2 = lh + 6;
   const int rnd1 = shift1 > 0 ? 1 << (shift1 - 1) : 0, rnd2 = 1 << (shift2 - 1);
   // stage 1 (horizontal): tmp[k*h + j] = (sum_i Mw[k][i] * resi[j][i] + rnd) >> shift1, k < zw
@@ -2291,6 +2294,70 @@ __device__ void run_stream(const VxParams &p)
   }
   ctx_copy_all(carry, &L.ctxs[CI_CUR]);
   if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); for (int i = 0; i < 48; i++) atomicAdd(&p.counters[4 + i], L.prof[i]); }
+}
+
+// ------------------------------------------------------------------------------------------------ leaf operators
+// The device functions of the path behind the individually testable operators of include/vvcx.h (≙ the reference's
+// function-pointer seams).  One workgroup per item; same code the CTU kernel runs.
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_dist_kernel(const int16_t *a, const int16_t *b, int w, int h, int16_t *scr, unsigned long long *out)
+{
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, P = w * h;
+  if (wave != 0) return;
+  const int16_t *pa = a + (size_t) blockIdx.x * P, *pb = b + (size_t) blockIdx.x * P;
+  unsigned long long sad, satd;
+  wave_sad_satd<false>(pa, pb, scr + (size_t) blockIdx.x * P, w, h, lane, sad, satd);
+  unsigned long long sse = 0;
+  for (int i = lane; i < P; i += 64) { const int d = pa[i] - pb[i]; sse += (unsigned long long) (d * d); }
+  sse = wave_sum_u64(sse);
+  if (lane == 0) { out[blockIdx.x * 3 + 0] = sad; out[blockIdx.x * 3 + 1] = satd; out[blockIdx.x * 3 + 2] = sse; }
+}
+template <typename T>
+__device__ void leaf_pred(const VxParams &p, const VxLeafPred *cases, int16_t *out, const int *out_off)
+{
+  const VxFrameDev &fd = p.frames[0];
+  const VxLeafPred c = cases[blockIdx.x];
+  load_tables();
+  if (threadIdx.x == 0) { L.cur_tile = 0; L.nx = c.x; L.ny = c.y; L.nw = c.w; L.nh = c.h; }
+  __syncthreads();
+  const int luma = c.comp == 0;
+  build_refs<T>(p, fd, c.comp, c.x, c.y, c.w, c.h, 0, luma ? 3 : 1);
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int s = threadIdx.x;
+    if (luma ? s != 1 : s == c.comp - 1) L.dc_val[s] = dc_value(L.refs[s][0], L.refs[s][1], c.w, c.h, luma ? (s == 0 ? 0 : s == 2 ? 1 : 3) : 0);
+  }
+  __syncthreads();
+  Ipa ip; init_pred_params(c.w, c.h, luma, c.mode, c.mrl, ip);
+  const int set = luma ? luma_set(c.mrl, ip.ref_filter) : c.comp - 1;
+  const int dcv = L.dc_val[luma ? luma_set(c.mrl, 0) : c.comp - 1];
+  int16_t *o = out + out_off[blockIdx.x];
+  for (int i = threadIdx.x; i < c.w * c.h; i += NT) { const int py = i >> ilog2i(c.w), px = i & (c.w - 1); o[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], c.w, c.h, px, py, ip, c.mode, luma, p.bit_depth, dcv); }
+}
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_pred_kernel_u8(VxParams p, const VxLeafPred *cases, int16_t *out, const int *out_off) { leaf_pred<uint8_t>(p, cases, out, out_off); }
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_pred_kernel_u16(VxParams p, const VxLeafPred *cases, int16_t *out, const int *out_off) { leaf_pred<uint16_t>(p, cases, out, out_off); }
+// estimator model: bins on one context (BinProbModel_Std::estFracBitsUpdate); io = {s0, s1} in/out, bits out
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_cabac_kernel(uint16_t *io, int ctx, const uint8_t *bins, int nbins, unsigned long long *bits)
+{
+  load_tables();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    L.ctxs[CI_CUR].s0[ctx] = io[0]; L.ctxs[CI_CUR].s1[ctx] = io[1];
+    Cab cb; cb.ci = CI_CUR; cb.bits = 0;
+    for (int i = 0; i < nbins; i++) enc_bin(cb, bins[i], ctx);
+    io[0] = L.ctxs[CI_CUR].s0[ctx]; io[1] = L.ctxs[CI_CUR].s1[ctx]; bits[0] = cb.bits;
+  }
+}
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_rdcost_kernel(VxParams p, const unsigned long long *bits, const unsigned long long *dist, int n, double *cost)
+{
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i < n) cost[i] = rd_cost(p, bits[i], dist[i]);
+}
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_scan_kernel(int w, int h, uint16_t *idx)
+{
+  load_tables();
+  __syncthreads();
+  const ScanGeo g = scan_geo(w, h);
+  for (int sp = threadIdx.x; sp < g.nscan; sp += NT) idx[sp] = (uint16_t) scan_blk(g, sp);
 }
 
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_kernel_u8(VxParams p) { run_stream<uint8_t>(p); }

@@ -68,6 +68,12 @@ def load_library(lib_path=None):
     L.vvcx_last_error.restype = C.c_char_p
     L.vvcx_ctus_per_frame.argtypes = [C.c_void_p]
     L.vvcx_resident_streams.argtypes = [C.c_void_p]
+    L.vvcx_distortion_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.vvcx_intra_pred_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p]
+    L.vvcx_ctx_init.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    L.vvcx_cabac_code_bins.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.vvcx_rd_cost_batch.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.vvcx_scan_order.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
     _libs[path] = L
     return L
 
@@ -94,6 +100,21 @@ class VvcxEncoder:
 
     def resident_streams(self):
         return int(self.L.vvcx_resident_streams(self.h))
+
+    def intra_pred_batch(self, reco, coded, cases):
+        """reco: 3 host planes (uint8 / uint16) of the picture; coded: 2 uint8 maps [uh, uw] (luma tree, chroma tree);
+        cases: structured array PRED_CASE_DTYPE -> list of int16 [h, w] predictions"""
+        reco = [np.ascontiguousarray(p) for p in reco]
+        coded = [np.ascontiguousarray(c, np.uint8) for c in coded]
+        cases = np.ascontiguousarray(cases, PRED_CASE_DTYPE)
+        total = int((cases["w"].astype(np.int64) * cases["h"]).sum())
+        pred = np.zeros(total, np.int16)
+        rp = (C.c_void_p * 3)(*[p.ctypes.data for p in reco]); cp = (C.c_void_p * 2)(*[c.ctypes.data for c in coded])
+        self._chk(self.L.vvcx_intra_pred_batch(self.h, rp, cp, cases.ctypes.data, len(cases), pred.ctypes.data))
+        out, off = [], 0
+        for c in cases:
+            out.append(pred[off:off + c["w"] * c["h"]].reshape(c["h"], c["w"])); off += int(c["w"]) * int(c["h"])
+        return out
 
     def _chk(self, rc):
         if rc != 0:
@@ -161,3 +182,51 @@ class VvcxEncoder:
         c = np.zeros(4, np.uint64)
         self._chk(self.L.vvcx_get_counters(self.h, c.ctypes.data))
         return c
+
+
+# ---- leaf operators (include/vvcx.h, "leaf operators"): host arrays in, host arrays out, work on the device
+PRED_CASE_DTYPE = np.dtype([("comp", "<i4"), ("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("mode", "<i4"), ("mrl", "<i4")])
+
+
+def _chk(L, rc):
+    if rc != 0:
+        raise VvcxError("vvcx error %d: %s" % (rc, L.vvcx_last_error().decode()))
+
+
+def distortion_batch(a, b, w, h, device=0, lib_path=None):
+    """a, b: int16 arrays of n*w*h samples (blocks back to back) -> uint64 [n, 3] = SAD, SATD, SSE"""
+    L = load_library(lib_path)
+    a = np.ascontiguousarray(a, np.int16).ravel(); b = np.ascontiguousarray(b, np.int16).ravel()
+    n = a.size // (w * h)
+    out = np.zeros((n, 3), np.uint64)
+    _chk(L, L.vvcx_distortion_batch(a.ctypes.data, b.ctypes.data, w, h, n, out.ctypes.data, device))
+    return out
+
+
+def ctx_init(qp, lib_path=None):
+    L = load_library(lib_path)
+    s0 = np.zeros(386, np.uint16); s1 = np.zeros(386, np.uint16)
+    _chk(L, L.vvcx_ctx_init(int(qp), s0.ctypes.data, s1.ctypes.data))
+    return s0, s1
+
+
+def cabac_code_bins(s0, s1, ctx, bins, device=0, lib_path=None):
+    """-> (frac_bits, s0', s1') after coding the bin string on context ctx"""
+    L = load_library(lib_path)
+    a = np.array([s0], np.uint16); b = np.array([s1], np.uint16); bins = np.ascontiguousarray(bins, np.uint8); bits = np.zeros(1, np.uint64)
+    _chk(L, L.vvcx_cabac_code_bins(a.ctypes.data, b.ctypes.data, int(ctx), bins.ctypes.data, len(bins), bits.ctypes.data, device))
+    return int(bits[0]), int(a[0]), int(b[0])
+
+
+def rd_cost_batch(lam, frac_bits, dist, device=0, lib_path=None):
+    L = load_library(lib_path)
+    fb = np.ascontiguousarray(frac_bits, np.uint64); d = np.ascontiguousarray(dist, np.uint64); out = np.zeros(len(fb), np.float64)
+    _chk(L, L.vvcx_rd_cost_batch(float(lam), fb.ctypes.data, d.ctypes.data, len(fb), out.ctypes.data, device))
+    return out
+
+
+def scan_order(w, h, device=0, lib_path=None):
+    L = load_library(lib_path)
+    idx = np.zeros(min(w, 32) * min(h, 32), np.uint16)
+    _chk(L, L.vvcx_scan_order(w, h, idx.ctypes.data, device))
+    return idx

@@ -1,0 +1,109 @@
+"""Leaf operators of the C-ABI (include/vvcx.h) against the golden vectors produced by the REAL reference code
+(tests/golden/make_golden.py → oracle/_ref/libvtmref.so): the device functions of the path are pinned directly to the
+reference, not only to the oracle.  GPU tests run every vector; the CPU tests run a slice of them through the CPU
+debug emulation of the same sources."""
+import importlib
+import os
+import subprocess
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKGNAME = "reduce-complexity-for-intra-coding-of-vvc_amd"
+pkg = importlib.import_module(PKGNAME)
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def emu_so():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, PKGNAME, "csrc"), "emu"])
+    return os.path.join(ROOT, "tools", "hipemu", "build", "libvvcx_emu.so")
+
+
+def _distortion(lib, limit):
+    g = np.load(os.path.join(G, "dist.npz"))
+    off, n = 0, 0
+    for (w, h, bd, had, sad, sse) in g["rows"][:limit]:
+        k = int(w * h)
+        a, b = g["a"][off:off + k], g["b"][off:off + k]; off += k
+        got = pkg.distortion_batch(a, b, int(w), int(h), lib_path=lib)[0]
+        assert (int(got[0]), int(got[1]), int(got[2])) == (int(sad), int(had), int(sse)), (w, h, bd)
+        n += 1
+    return n
+
+
+def _cabac(lib, limit):
+    g = np.load(os.path.join(G, "cabac.npz"))
+    for i, qp in enumerate(g["qps"]):
+        s0, s1 = pkg.ctx_init(int(qp), lib_path=lib)
+        assert np.array_equal(s0, g["s0"][i]) and np.array_equal(s1, g["s1"][i])
+    for (ctx, qi, bits, e0, e1), bins in list(zip(g["seq_meta"], g["seq_bins"]))[:limit]:
+        got = pkg.cabac_code_bins(int(g["s0"][qi, ctx]), int(g["s1"][qi, ctx]), int(ctx), bins, lib_path=lib)
+        assert got == (int(bits), int(e0), int(e1)), ctx
+    rd = g["rd"]
+    for lam in np.unique(rd[:, 0]):
+        rows = rd[rd[:, 0] == lam]
+        cost = pkg.rd_cost_batch(lam, rows[:, 1].astype(np.uint64), rows[:, 2].astype(np.uint64), lib_path=lib)
+        assert np.array_equal(cost, rows[:, 3])                 # identical doubles: two roundings, no FMA (CL/RdCost.cpp:63-74)
+
+
+def _scan(lib, keys=None):
+    g = np.load(os.path.join(G, "scan.npz"))
+    for key in (keys or g.files):
+        w, h = map(int, key[1:].split("x"))
+        idx = pkg.scan_order(w, h, lib_path=lib)
+        assert np.array_equal(idx, g[key][:len(idx)]), key
+
+
+def _intra(lib, limit):
+    g = np.load(os.path.join(G, "intra.npz"))
+    meta, off, n = g["case_meta"], 0, 0
+    offs = []
+    for m in meta:
+        ei, bd, comp, x, y, w, h, dirm, mrl, force = map(int, m)
+        cw, chh = (w, h) if comp == 0 else (w // 2, h // 2)
+        offs.append((off, cw * chh)); off += cw * chh
+    by_env = {}
+    for i, m in enumerate(meta[:limit] if limit else meta):
+        by_env.setdefault((int(m[0]), int(m[1])), []).append(i)
+    for (ei, bd), idxs in by_env.items():
+        reco = [g["env%d_reco%d" % (ei, c)] for c in range(3)]
+        H, W = reco[0].shape
+        dt = np.uint8 if bd == 8 else np.uint16
+        coded = np.repeat(np.repeat(g["env%d_coded" % ei], 2, axis=0), 2, axis=1).astype(np.uint8)     # 8x8 luma → 4x4 units
+        enc = pkg.VvcxEncoder(W, H, bd, lib_path=lib)
+        cases = np.zeros(len(idxs), pkg.PRED_CASE_DTYPE)
+        for k, i in enumerate(idxs):
+            _, _, comp, x, y, w, h, dirm, mrl, force = map(int, meta[i])
+            sh = 1 if comp else 0
+            cases[k] = (comp, x >> sh, y >> sh, w >> sh, h >> sh, dirm, mrl)
+        preds = enc.intra_pred_batch([p.astype(dt) for p in reco], [coded, coded], cases)
+        enc.close()
+        for k, i in enumerate(idxs):
+            o, sz = offs[i]
+            assert np.array_equal(preds[k].ravel(), g["case_pred"][o:o + sz]), ("pred", tuple(meta[i]))
+            n += 1
+    return n
+
+
+@pytest.mark.gpu
+def test_gpu_distortion_matches_reference():
+    assert _distortion(None, None) == 180
+
+
+@pytest.mark.gpu
+def test_gpu_cabac_model_rdcost_and_scan_match_reference():
+    _cabac(None, None)
+    _scan(None)
+
+
+@pytest.mark.gpu
+def test_gpu_intra_prediction_matches_reference():
+    assert _intra(None, None) > 1000
+
+
+def test_emulated_leaf_operators_match_reference(emu_so):
+    assert _distortion(emu_so, 24) == 24
+    _cabac(emu_so, 6)
+    _scan(emu_so, ["s4x4", "s8x8", "s16x4", "s32x32"])
+    assert _intra(emu_so, 40) == 40
