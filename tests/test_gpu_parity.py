@@ -120,3 +120,10 @@ def test_size_independent_properties_1080p_row():
     mse = np.mean((planes[0].astype(np.float64) - reco[0].astype(np.float64)) ** 2)
     assert 28.0 < 10 * np.log10(255.0 ** 2 / mse) < 45.0
     assert all(np.array_equal(a[0][0][k], b[0][0][k]) for k in res.dtype.names) and np.array_equal(a[0][2][0], b[0][2][0])
+
+
+def test_full_1080p_frame_matches_oracle():
+    """BASELINE.json's configuration itself: one 1920x1080 frame, QP 32, 15x9 tiles (135 CTU streams, bottom CTU row cut
+    at 56 luma rows → implicit splits), bit-exact against the oracle (≈1 min of oracle time on one host core)."""
+    W, H = 1920, 1080
+    _check([pkg.synth_frame(W, H, 0, 8, 1000)], W, H, pkg.slice_params(32), tile_cols=15, tile_rows=9)
