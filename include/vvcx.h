@@ -142,6 +142,11 @@ int  vvcx_ctx_init(int qp, uint16_t s0[386], uint16_t s1[386]);
 int  vvcx_cabac_code_bins(uint16_t *s0, uint16_t *s1, int ctx, const uint8_t *bins, int nbins, uint64_t *frac_bits, int device);
 /* RdCost::calcRdCost for n (fracBits, dist) pairs at one lambda */
 int  vvcx_rd_cost_batch(double lambda, const uint64_t *frac_bits, const uint64_t *dist, int n, double *cost, int device);
+/* the core of IntraSearch::xIntraCodingTUBlock (EL/IntraSearch.cpp:2852-3168) for n blocks: residual org - pred → TrQuant::transformNxN
+ * (DCT-II, plain Quant::quant) → levels; if any: invTransformNxN → rec = clip(pred + residual'); SSE(org, rec).  qp is the QP QpParam
+ * hands to the quantiser (slice QP + QpBDOffset, chroma after the mapping table) */
+int  vvcx_transform_quant_batch(const int16_t *org, const int16_t *pred, int w, int h, int bit_depth, int qp, int n,
+                                int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device);
 /* coefficient scan (diagonal, grouped) of a w x h block: idx[min(w,32) * min(h,32)] raster offsets in scan order */
 int  vvcx_scan_order(int w, int h, uint16_t *idx, int device);
 

@@ -441,7 +441,7 @@ static uint64_t code_tu_block(orc_enc *e, int comp, int x, int y, int w, int h, 
 {
   const int st = e->stride[comp], bd = e->cfg.bit_depth;
   const int16_t *org = e->org[comp] + y * st + x;
-  const int qp = comp ? e->sl.qp_c[comp - 1] : e->sl.qp;
+  const int qp = (comp ? e->sl.qp_c[comp - 1] : e->sl.qp) + 6 * (e->cfg.bit_depth - 8);    /* QpParam: + QpBDOffset (CL/Quant.cpp:68-106) */
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) e->resi[j * w + i] = (int16_t) (org[j * st + i] - e->pred[j * w + i]);
   orc_fwd_2d(e->resi, w, w, h, bd, e->coef);
   const int abs_sum = orc_quant(e->coef, w, h, bd, qp, lev_out);
@@ -817,7 +817,7 @@ static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int
 {
   const int st = e->stride[comp], bd = e->cfg.bit_depth, mx = (1 << bd) - 1;
   const int16_t *org = e->org[comp] + y * st + x;
-  const int qp = comp ? e->sl.qp_c[comp - 1] : e->sl.qp;
+  const int qp = (comp ? e->sl.qp_c[comp - 1] : e->sl.qp) + 6 * (e->cfg.bit_depth - 8);    /* QpParam: + QpBDOffset (CL/Quant.cpp:68-106) */
   if (cbf) { orc_dequant(lev, w, h, bd, qp, e->coef); orc_inv_2d(e->coef, w, h, bd, e->resi, w); }
   else memset(e->resi, 0, (size_t) w * h * 2);
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) { int v = e->pred[j * w + i] + e->resi[j * w + i]; rec_out[j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }

@@ -22,6 +22,7 @@ extern "C" __global__ void vvcx_leaf_pred_kernel_u16(VxParams p, const VxLeafPre
 extern "C" __global__ void vvcx_leaf_cabac_kernel(uint16_t *io, int ctx, const uint8_t *bins, int nbins, unsigned long long *bits);
 extern "C" __global__ void vvcx_leaf_rdcost_kernel(VxParams p, const unsigned long long *bits, const unsigned long long *dist, int n, double *cost);
 extern "C" __global__ void vvcx_leaf_scan_kernel(int w, int h, uint16_t *idx);
+extern "C" __global__ void vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp, unsigned long long *out);
 
 static thread_local char g_err[512];
 extern "C" const char *vvcx_last_error(void) { return g_err; }
@@ -210,6 +211,7 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
   for (int k = 0; k < 2; k++) { p.min_qt[k] = h->cfg.min_qt[k]; p.max_bt_depth[k] = h->cfg.max_bt_depth[k]; p.max_bt_size[k] = h->cfg.max_bt_size[k]; p.max_tt_size[k] = h->cfg.max_tt_size[k]; p.qp_c[k] = h->sl.qp_c[k]; p.dist_weight[k] = h->sl.dist_weight[k]; }
   p.ctus_w = h->ctus_w; p.ctus_h = h->ctus_h; p.uw = h->uw; p.uh = h->uh; p.qp = h->sl.qp;
   p.lambda = h->sl.lambda;
+  { const int bdo = 6 * (h->cfg.bit_depth - 8); p.qp_tr = h->sl.qp + bdo; p.qp_tr_c[0] = h->sl.qp_c[0] + bdo; p.qp_tr_c[1] = h->sl.qp_c[1] + bdo; }
   p.dist_scale = (double) (1 << 15) / h->sl.lambda;                       // CL/RdCost.cpp:79
   p.sqrt_lambda_fp = sqrt(h->sl.lambda) * (1.0 / (double) (1 << 15));     // EL/IntraSearch.cpp:297
   p.frames = h->frames_d; p.streams = h->streams_d; p.task_ctu = h->task_ctu_d; p.results = h->results_d; p.stream_ctx = h->stream_ctx_d;
@@ -409,5 +411,25 @@ extern "C" int vvcx_scan_order(int w, int h, uint16_t *idx, int device)
   hipLaunchKernelGGL(vvcx_leaf_scan_kernel, dim3(1), dim3(VXD_NT), 0, 0, w, h, d.as<uint16_t>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(idx, d.p, (size_t) n * 2, hipMemcpyDeviceToHost));
+  return VVCX_OK;
+}
+
+extern "C" int vvcx_transform_quant_batch(const int16_t *org, const int16_t *pred, int w, int h, int bit_depth, int qp, int n,
+                                          int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device)
+{
+  if (!org || !pred || !lev || !rec || !sse || !cbf || n < 0 || !pow2_block(w, h) || (bit_depth != 8 && bit_depth != 10) || qp < 0 || qp > 75) return fail(VVCX_ERR_ARG, "bad argument");
+  if (n == 0) return VVCX_OK;
+  HIPCHK(hipSetDevice(device));
+  const size_t bytes = (size_t) n * w * h * 2;
+  DevBuf dorg, drec, dlev, dtmp, dout;
+  HIPCHK(dorg.alloc(bytes)); HIPCHK(drec.alloc(bytes)); HIPCHK(dlev.alloc(bytes)); HIPCHK(dtmp.alloc((size_t) n * 2048 * 4)); HIPCHK(dout.alloc((size_t) n * 16));
+  HIPCHK(hipMemcpy(dorg.p, org, bytes, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(drec.p, pred, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(vvcx_leaf_trq_kernel, dim3((unsigned) n), dim3(VXD_NT), 0, 0, dorg.as<int16_t>(), drec.as<int16_t>(), dlev.as<int16_t>(), dtmp.as<int32_t>(), w, h, bit_depth, qp,
+                     dout.as<unsigned long long>());
+  HIPCHK(hipGetLastError());
+  std::vector<unsigned long long> o((size_t) n * 2);
+  HIPCHK(hipMemcpy(lev, dlev.p, bytes, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(rec, drec.p, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(o.data(), dout.p, (size_t) n * 16, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) { sse[i] = o[(size_t) i * 2]; cbf[i] = (uint8_t) o[(size_t) i * 2 + 1]; }
   return VVCX_OK;
 }

@@ -47,7 +47,8 @@ struct VxParams {
   uint32_t tools;
   int32_t min_qt[2], max_bt_depth[2], max_bt_size[2], max_tt_size[2];
   int32_t ctus_w, ctus_h, uw, uh;
-  int32_t qp, qp_c[2];
+  int32_t qp, qp_c[2];               // slice QP, mapped chroma QPs
+  int32_t qp_tr, qp_tr_c[2];         // + QpBDOffset: what QpParam hands to quantisation (CL/Quant.cpp:68-106)
   double  lambda, dist_scale, sqrt_lambda_fp, dist_weight[2];
   const VxFrameDev   *frames;
   const VxStreamDesc *streams;

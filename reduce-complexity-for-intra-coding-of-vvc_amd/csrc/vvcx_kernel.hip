@@ -1480,7 +1480,7 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     wave_sync();
     const long long tb1 = STAMP();
     unsigned long long sse; int cbf;
-    wave_code_block<SMALL>(org_tile(scratch, P), 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp, lane, sse, cbf);
+    wave_code_block<SMALL>(org_tile(scratch, P), 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf);
     const long long tb2 = STAMP();
     // xGetIntraFracBitsQT: header + cbf + residual from the node's start contexts
     { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
@@ -1553,7 +1553,7 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
       for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
       wave_sync();
       unsigned long long sse; int cbf;
-      wave_code_block<SMALL>(org_tile(scratch, 2 * P), k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_c[k], lane, sse, cbf);
+      wave_code_block<SMALL>(org_tile(scratch, 2 * P), k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[k], lane, sse, cbf);
       cbfs[k] = cbf;
       dist += (unsigned long long) (p.dist_weight[k] * (double) sse);             // CL/RdCost.cpp:405-408
       {                    // xGetIntraFracBitsQTChroma 2625-2692: contexts advance
@@ -1679,7 +1679,7 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
     for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); recb[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], w, h, px, py, ip, mode, 1, bd, dcv); }
     wave_sync();
     int cbf;
-    wave_code_block<SMALL>(org_tile(scratch, n), 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp, lane, dist, cbf, cbfm & 1);
+    wave_code_block<SMALL>(org_tile(scratch, n), 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr, lane, dist, cbf, cbfm & 1);
     if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, fm); enc_bin(cb, (unsigned) (cbfm & 1), VX_CTX_QtCbf[0]); }
     if (cbfm & 1) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 0, lane);
   } else {
@@ -1689,7 +1689,7 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
       for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(L.refs[k][0], L.refs[k][1], w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
       wave_sync();
       unsigned long long sse; int cbf;
-      wave_code_block<SMALL>(org_tile(scratch, n), k * P, k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1);
+      wave_code_block<SMALL>(org_tile(scratch, n), k * P, k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1);
       dist += (unsigned long long) (p.dist_weight[k] * (double) sse);
     }
     if (lane == 0) {
@@ -2310,6 +2310,18 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_dist_kernel(
   for (int i = lane; i < P; i += 64) { const int d = pa[i] - pb[i]; sse += (unsigned long long) (d * d); }
   sse = wave_sum_u64(sse);
   if (lane == 0) { out[blockIdx.x * 3 + 0] = sad; out[blockIdx.x * 3 + 1] = satd; out[blockIdx.x * 3 + 2] = sse; }
+}
+// T → Q → Q⁻¹ → T⁻¹ → reco → SSE of one block per workgroup (the core of xIntraCodingTUBlock): rec holds the prediction on entry
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp,
+                                                                               unsigned long long *out)
+{
+  load_tables();
+  __syncthreads();
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, P = w * h;
+  if (wave != 0) return;
+  unsigned long long sse; int cbf;
+  wave_code_block<false>(org + (size_t) blockIdx.x * P, 0, 0, rec + (size_t) blockIdx.x * P, lev + (size_t) blockIdx.x * P, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, lane, sse, cbf);
+  if (lane == 0) { out[blockIdx.x * 2] = sse; out[blockIdx.x * 2 + 1] = (unsigned long long) cbf; }
 }
 template <typename T>
 __device__ void leaf_pred(const VxParams &p, const VxLeafPred *cases, int16_t *out, const int *out_off)

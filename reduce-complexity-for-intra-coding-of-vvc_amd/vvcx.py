@@ -74,6 +74,7 @@ def load_library(lib_path=None):
     L.vvcx_cabac_code_bins.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.vvcx_rd_cost_batch.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.vvcx_scan_order.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.vvcx_transform_quant_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     _libs[path] = L
     return L
 
@@ -230,3 +231,13 @@ def scan_order(w, h, device=0, lib_path=None):
     idx = np.zeros(min(w, 32) * min(h, 32), np.uint16)
     _chk(L, L.vvcx_scan_order(w, h, idx.ctypes.data, device))
     return idx
+
+
+def transform_quant_batch(org, pred, w, h, bit_depth, qp, device=0, lib_path=None):
+    """n blocks back to back -> (levels int16 [n, h, w], reconstruction int16 [n, h, w], sse uint64 [n], cbf uint8 [n])"""
+    L = load_library(lib_path)
+    org = np.ascontiguousarray(org, np.int16).ravel(); pred = np.ascontiguousarray(pred, np.int16).ravel()
+    n = org.size // (w * h)
+    lev = np.zeros(org.size, np.int16); rec = np.zeros(org.size, np.int16); sse = np.zeros(n, np.uint64); cbf = np.zeros(n, np.uint8)
+    _chk(L, L.vvcx_transform_quant_batch(org.ctypes.data, pred.ctypes.data, w, h, bit_depth, qp, n, lev.ctypes.data, rec.ctypes.data, sse.ctypes.data, cbf.ctypes.data, device))
+    return lev.reshape(n, h, w), rec.reshape(n, h, w), sse, cbf

@@ -23,6 +23,7 @@ R.ref_env_reset.argtypes = [C.c_void_p]
 R.ref_env_set_reco.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
 R.ref_env_add_cu.argtypes = [C.c_void_p] + [C.c_int] * 8
 R.ref_env_pred.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p]
+R.ref_env_tr_quant.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4
 R.ref_env_partition.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 
 rng = np.random.default_rng(20261003)
@@ -260,6 +261,31 @@ def gen_partition():
     print("partition cases", len(rows))
 
 
+def gen_trquant():
+    """One luma transform block through the reference's TrQuant::transformNxN (xT + plain Quant::quant) and
+    invTransformNxN (dequant + xIT): residual in, levels and reconstructed residual out, for every block shape."""
+    meta, resi_all, lev_all, out_all = [], [], [], []
+    for bd, qp in ((8, 22), (8, 37), (10, 32)):
+        env = R.ref_env_create(192, 192, bd)
+        for w in (4, 8, 16, 32, 64):
+            for h in (4, 8, 16, 32, 64):
+                R.ref_env_reset(env)
+                amp = (1 << bd) // 4
+                yy, xx = np.mgrid[0:h, 0:w]
+                resi = rng.normal(0, amp / 6, (h, w)) + (amp / 3) * np.sin(xx / 5.0 + rng.uniform(0, 3)) * np.cos(yy / 7.0)
+                resi = np.ascontiguousarray(np.clip(resi.round(), -(1 << bd) + 1, (1 << bd) - 1).astype(np.int16))
+                lev = np.zeros(w * h, np.int32); ro = np.zeros(w * h, np.int16); a = C.c_int()
+                assert R.ref_env_tr_quant(env, 0, 0, w, h, qp, P(resi), P(lev), P(ro), C.byref(a)) == 0
+                meta.append((bd, qp, w, h, a.value))
+                resi_all.append(resi.ravel()); lev_all.append(lev.astype(np.int16)); out_all.append(ro)
+    np.savez_compressed(os.path.join(HERE, "trquant.npz"), meta=np.array(meta, np.int32), resi=np.concatenate(resi_all),
+                        lev=np.concatenate(lev_all), resi_out=np.concatenate(out_all))
+    print("trquant cases", len(meta))
+
+
 if __name__ == "__main__":
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition()
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "trquant":
+        gen_trquant(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant()
     print("done")

@@ -86,6 +86,32 @@ def _intra(lib, limit):
     return n
 
 
+def _trquant(lib, limit):
+    g = np.load(os.path.join(G, "trquant.npz"))
+    off, n = 0, 0
+    for (bd, qp, w, h, abs_sum) in g["meta"]:
+        k = int(w * h)
+        resi = g["resi"][off:off + k].astype(np.int32); lev_e = g["lev"][off:off + k]; out_e = g["resi_out"][off:off + k].astype(np.int32); off += k
+        if limit and n >= limit:
+            break
+        if limit and k > 256:
+            continue
+        mid, mx = 1 << (int(bd) - 1), (1 << int(bd)) - 1
+        org = (mid + resi).astype(np.int16); pred = np.full(k, mid, np.int16)
+        lev, rec, sse, cbf = pkg.transform_quant_batch(org, pred, int(w), int(h), int(bd), int(qp) + 6 * (int(bd) - 8), lib_path=lib)
+        rec_e = np.clip(mid + out_e, 0, mx) if abs_sum > 0 else np.full(k, mid)
+        assert np.array_equal(lev.ravel(), lev_e) and int(cbf[0]) == int(abs_sum > 0), ("levels", bd, qp, w, h)
+        assert np.array_equal(rec.ravel().astype(np.int32), rec_e), ("rec", bd, qp, w, h)
+        assert int(sse[0]) == int(((org.astype(np.int64) - rec_e) ** 2).sum())
+        n += 1
+    return n
+
+
+@pytest.mark.gpu
+def test_gpu_transform_quant_matches_reference():
+    assert _trquant(None, None) == 75
+
+
 @pytest.mark.gpu
 def test_gpu_distortion_matches_reference():
     assert _distortion(None, None) == 180
@@ -107,3 +133,4 @@ def test_emulated_leaf_operators_match_reference(emu_so):
     _cabac(emu_so, 6)
     _scan(emu_so, ["s4x4", "s8x8", "s16x4", "s32x32"])
     assert _intra(emu_so, 40) == 40
+    assert _trquant(emu_so, 8) == 8

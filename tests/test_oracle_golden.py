@@ -124,3 +124,23 @@ def test_partitioner_and_split_contexts():
         assert np.array_equal(can, can_e), ("can", r[:20], can, can_e)
         assert impl.value == impl_ref
         assert np.array_equal(ctx.astype(np.int32), ctx_e), ("ctx", r[:20], ctx, ctx_e)
+
+
+def test_transform_quant_round_trip():
+    """2-D DCT-II + plain quantiser + dequantiser + inverse, every luma block shape, against TrQuant::transformNxN /
+    invTransformNxN of the reference.  The leaf functions take the QP QpParam would hand them (slice QP + QpBDOffset)."""
+    L = O.lib()
+    g = np.load(os.path.join(G, "trquant.npz"))
+    off = 0
+    for (bd, qp, w, h, abs_sum) in g["meta"]:
+        k = int(w * h)
+        resi = np.ascontiguousarray(g["resi"][off:off + k]); lev_e = g["lev"][off:off + k]; out_e = g["resi_out"][off:off + k]; off += k
+        q = int(qp) + 6 * (int(bd) - 8)
+        coef = np.zeros(k, np.int32); lev = np.zeros(k, np.int16)
+        L.orc_fwd_2d(P(resi), int(w), int(w), int(h), int(bd), P(coef))
+        assert L.orc_quant(P(coef), int(w), int(h), int(bd), q, P(lev)) == abs_sum, ("abs_sum", bd, qp, w, h)
+        assert np.array_equal(lev, lev_e), ("levels", bd, qp, w, h)
+        if abs_sum > 0:
+            dq = np.zeros(k, np.int32); out = np.zeros(k, np.int16)
+            L.orc_dequant(P(lev), int(w), int(h), int(bd), q, P(dq)); L.orc_inv_2d(P(dq), int(w), int(h), int(bd), P(out), int(w))
+            assert np.array_equal(out, out_e), ("resi", bd, qp, w, h)
