@@ -606,3 +606,24 @@ int orc_scan_order(int w, int h, uint16_t *idx)
     for (int i = 0; i < cw * ch; i++) idx[n++] = (uint16_t) ((gy[g] * ch + iy[i]) * w + gx[g] * cw + ix[i]);
   return n;
 }
+
+/* test hook: the arithmetic coder over a sequence of operations from the I-slice contexts at qp (see ref_arith_encode in
+ * ref_harness.cpp): ops[i] = {kind, a, b}: 0 = context bin (ctx a, bin b); 1 = b bypass bins of value a; 2 = terminating bin a */
+int orc_arith_encode(int qp, const int32_t *ops, int nops, uint8_t *out, int cap)
+{
+  orc_cabac c; memset(&c, 0, sizeof c);
+  orc_arith aw; memset(&aw, 0, sizeof aw);
+  aw.out = out; aw.cap = (size_t) cap;
+  orc_ctx_init(qp, c.s0, c.s1);
+  orc_arith_start(&aw);
+  c.aw = &aw;
+  for (int i = 0; i < nops; i++) {
+    const int32_t *o = ops + 3 * i;
+    if (o[0] == 0) orc_enc_bin(&c, (unsigned) o[2], o[1]);
+    else if (o[0] == 1) orc_enc_bins_ep(&c, (uint32_t) o[1], o[2]);
+    else orc_arith_trm(&aw, (unsigned) o[1]);
+  }
+  orc_arith_finish(&aw);
+  orc_bs_write(&aw, 1, 1); while (aw.bit_n) orc_bs_write(&aw, 0, 1);
+  return aw.n > aw.cap ? -1 : (int) aw.n;
+}

@@ -75,12 +75,18 @@ static int tmpl_abs_sum(const cctx_t *c, const int16_t *coeff, int blk, int base
 static void enc_rem_abs(orc_cabac *cb, unsigned bins, unsigned rice)
 {
   const unsigned thr = 5u << rice;
-  if (bins < thr) { orc_enc_ep(cb, (int) ((bins >> rice) + 1 + rice)); return; }
+  if (bins < thr) {                                   /* unary prefix, then rice bits (EL/BinEncoder.cpp:222-229) */
+    const unsigned length = (bins >> rice) + 1;
+    orc_enc_bins_ep(cb, (1u << length) - 2, (int) length);
+    orc_enc_bins_ep(cb, bins & ((1u << rice) - 1), (int) rice);
+    return;
+  }
   const unsigned maxPrefix = 32 - 5 - 15;
   unsigned prefix = 0, suffix, code = (bins >> rice) - 5;
   if (code >= ((1u << maxPrefix) - 1)) { prefix = maxPrefix; suffix = 15; }
   else { while (code > ((2u << prefix) - 2)) prefix++; suffix = prefix + rice + 1; }
-  orc_enc_ep(cb, (int) (5 + prefix + suffix));
+  orc_enc_bins_ep(cb, (1u << (prefix + 5)) - 1, (int) (prefix + 5));                                           /* 248-252 */
+  orc_enc_bins_ep(cb, ((code - ((1u << prefix) - 1)) << rice) | (bins & ((1u << rice) - 1)), (int) suffix);
 }
 
 void orc_residual_coding(orc_cabac *cb, const int16_t *coeff, int w, int h, int is_chroma)
@@ -117,8 +123,8 @@ void orc_residual_coding(orc_cabac *cb, const int16_t *coeff, int w, int h, int 
     if (gx < maxX) orc_enc_bin(cb, 0, ORC_CTX_LastX[c.ch] + c.last_off_x + (k >> c.last_sh_x));
     for (k = 0; k < gy; k++) orc_enc_bin(cb, 1, ORC_CTX_LastY[c.ch] + c.last_off_y + (k >> c.last_sh_y));
     if (gy < maxY) orc_enc_bin(cb, 0, ORC_CTX_LastY[c.ch] + c.last_off_y + (k >> c.last_sh_y));
-    if (gx > 3) orc_enc_ep(cb, (gx - 2) >> 1);
-    if (gy > 3) orc_enc_ep(cb, (gy - 2) >> 1);
+    if (gx > 3) orc_enc_bins_ep(cb, (uint32_t) (posX - ORC_MIN_IN_GROUP[gx]), (gx - 2) >> 1);
+    if (gy > 3) orc_enc_bins_ep(cb, (uint32_t) (posY - ORC_MIN_IN_GROUP[gy]), (gy - 2) >> 1);
   }
   /* regular-bin budget (3859-3860): TbAreaAfterCoefZeroOut * 28 >> 4 */
   c.reg_bins = (imin(32, w) * imin(32, h) * 28) >> 4;
@@ -143,6 +149,7 @@ void orc_residual_coding(orc_cabac *cb, const int16_t *coeff, int w, int h, int 
     uint8_t ctxOffset[16];
     const int inferSigPos = nextSigPos != scanPosLast ? (isNotFirst ? minSub : -1) : nextSigPos;
     int numNonZero = 0, remRegBins = c.reg_bins;
+    uint32_t signPattern = 0;
     for (; nextSigPos >= minSub && remRegBins >= 4; nextSigPos--) {
       const int blk = c.scan[nextSigPos];
       const int cf = coeff[blk];
@@ -156,6 +163,7 @@ void orc_residual_coding(orc_cabac *cb, const int16_t *coeff, int w, int h, int 
         const int off = ctx_offset_abs(&c);
         ctxOffset[nextSigPos - minSub] = (uint8_t) off;
         numNonZero++;
+        signPattern = (signPattern << 1) | (cf < 0);     /* 4218-4219: no shift before the very first coefficient, where it is 0 anyway */
         int rem = abs(cf) - 1;
         const unsigned gt1 = !!rem;
         orc_enc_bin(cb, gt1, ORC_CTX_GtxFlag[c.ch + 2] + off);     /* greater1CtxIdAbs = m_gtxFlagCtxSet[1] */
@@ -189,16 +197,16 @@ void orc_residual_coding(orc_cabac *cb, const int16_t *coeff, int w, int h, int 
       const unsigned rice = ORC_GORICE_PARS[sumAll], pos0 = ORC_GORICE_POS0[sumAll];
       const unsigned rem = absLevel == 0 ? pos0 : absLevel <= pos0 ? absLevel - 1 : absLevel;
       enc_rem_abs(cb, rem, rice);
-      if (absLevel) numNonZero++;
+      if (absLevel) { numNonZero++; signPattern = (signPattern << 1) | (coeff[blk] < 0); }
     }
     (void) ctxOffset;
-    orc_enc_ep(cb, numNonZero);    /* sign bits (4297-4303), no sign hiding */
+    orc_enc_bins_ep(cb, signPattern, numNonZero);    /* sign bits (4297-4303), no sign hiding */
   }
 }
 
 uint64_t orc_residual_bits(uint16_t *s0, uint16_t *s1, const int16_t *level, int w, int h, int is_chroma)
 {
-  orc_cabac c;
+  orc_cabac c; c.aw = 0;
   memcpy(c.s0, s0, sizeof c.s0); memcpy(c.s1, s1, sizeof c.s1); c.bits = 0;
   orc_residual_coding(&c, level, w, h, is_chroma);
   memcpy(s0, c.s0, sizeof c.s0); memcpy(s1, c.s1, sizeof c.s1);

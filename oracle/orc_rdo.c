@@ -397,17 +397,17 @@ static void enc_intra_luma_pred_mode(orc_enc *e, int x, int y, int w, int h, int
   if (!mrl) orc_enc_bin(c, mpm_idx < 6, ORC_CTX_IntraLumaMpmFlag);
   if (mpm_idx < 6) {
     if (mrl == 0) orc_enc_bin(c, mpm_idx > 0, ORC_CTX_IntraLumaPlanarFlag + 1);   /* ctx 1: ispMode == NOT_INTRA_SUBPARTITIONS */
-    if (mpm_idx) orc_enc_ep(c, 1);
-    if (mpm_idx > 1) orc_enc_ep(c, 1);
-    if (mpm_idx > 2) orc_enc_ep(c, 1);
-    if (mpm_idx > 3) orc_enc_ep(c, 1);
+    if (mpm_idx) orc_enc_bins_ep(c, mpm_idx > 1, 1);
+    if (mpm_idx > 1) orc_enc_bins_ep(c, mpm_idx > 2, 1);
+    if (mpm_idx > 2) orc_enc_bins_ep(c, mpm_idx > 3, 1);
+    if (mpm_idx > 3) orc_enc_bins_ep(c, mpm_idx > 4, 1);
   } else {
     /* std::sort + rank, then xWriteTruncBinCode(ipred, 61): thresh 5, val 32, b 29 → 5 bits if < 3 else 6 */
     unsigned s[6]; memcpy(s, mpm, sizeof s);
     for (int i = 1; i < 6; i++) { unsigned v = s[i]; int j = i - 1; while (j >= 0 && s[j] > v) { s[j + 1] = s[j]; j--; } s[j + 1] = v; }
     unsigned m = (unsigned) dir;
     for (int i = 5; i >= 0; i--) if (m > s[i]) m--;
-    orc_enc_ep(c, m < 3 ? 5 : 6);
+    if (m < 3) orc_enc_bins_ep(c, m, 5); else orc_enc_bins_ep(c, m + 3, 6);          /* xWriteTruncBinCode 1553-1561 */
   }
 }
 /* PU::getCoLocatedIntraLumaMode (CL/UnitTools.cpp:949-960) + getIntraChromaCandModes (840-873) */
@@ -429,7 +429,10 @@ static void enc_intra_chroma_pred_mode(orc_enc *e, area_t a, int dir)
   const int isDM = dir == ORC_DM_CHROMA;
   orc_enc_bin(c, isDM ? 0 : 1, ORC_CTX_IntraChromaPredMode);
   if (isDM) return;
-  orc_enc_ep(c, 2);
+  int list[8]; chroma_cand_modes(e, a, list);
+  int cand = 0;
+  for (; cand < 4; cand++) if (list[cand] == dir) break;
+  orc_enc_bins_ep(c, (uint32_t) cand, 2);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1075,6 +1078,46 @@ int orc_compress_frame(orc_enc *e, orc_ctu_result *res, orc_cu *cus, int max_cus
     }
   *n_cus = n;
   return n > max_cus ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * slice_data() payload of the coded picture: the final CTU syntax of every tile through the arithmetic coder
+ * (EncSlice::encodeSlice, EL/EncSlice.cpp:1884-2006; CABACWriter::coding_tree_unit 254-322; end_of_ctu 2118-2141;
+ * end_of_slice = terminating bin 1 + finish; OutputBitstream::writeByteAlignment).  Call after orc_compress_frame.
+ * sizes[t] receives the byte count of tile t's sub-stream; returns the total or -1 if buf is too small.
+ * ---------------------------------------------------------------------------------------------- */
+long orc_write_tiles(orc_enc *e, uint8_t *buf, long cap, int *sizes)
+{
+  const int ntiles = e->cfg.tile_cols * e->cfg.tile_rows;
+  long total = 0;
+  int last_rx = 0, last_ry = 0;                    /* last CTU of the slice in tile-scan order */
+  for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++) if (e->ctu_tile[ry * e->ctus_w + rx] == ntiles - 1) { last_rx = rx; last_ry = ry; }
+  for (int t = 0; t < ntiles; t++) {
+    orc_arith aw; memset(&aw, 0, sizeof aw);
+    aw.out = buf + total; aw.cap = (size_t) (cap - total);
+    e->cur_tile = t;
+    orc_ctx_init(e->sl.qp, e->cabac.s0, e->cabac.s1);
+    orc_arith_start(&aw);
+    e->cabac.aw = &aw;
+    for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++) {
+      if (e->ctu_tile[ry * e->ctus_w + rx] != t) continue;
+      const area_t ctu = { rx << 7, ry << 7, 128, 128 };
+      advance_ctx_ctu(e, ctu);
+      if (!(rx == last_rx && ry == last_ry)) orc_arith_trm(&aw, 0);     /* end_of_ctu: not the last CTU of the slice */
+    }
+    orc_arith_trm(&aw, 1); orc_arith_finish(&aw);                        /* end_of_slice (brick) */
+    orc_bs_write(&aw, 1, 1); while (aw.bit_n) orc_bs_write(&aw, 0, 1);   /* writeByteAlignment */
+    e->cabac.aw = 0;
+    if (aw.n > aw.cap) return -1;
+    sizes[t] = (int) aw.n; total += (long) aw.n;
+  }
+  return total;
+}
+/* quantised levels of the coded picture, plane layout (stride = plane width) */
+int orc_get_levels(orc_enc *e, int16_t *const lev[3])
+{
+  for (int c = 0; c < 3; c++) memcpy(lev[c], e->lev[c], (size_t) (c ? e->wc * e->hc : e->wl * e->hl) * 2);
+  return 0;
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -93,6 +93,9 @@ int      orc_compress_frame(orc_enc *e, orc_ctu_result *res /* [n_ctus] */, orc_
 int      orc_get_reco(orc_enc *e, void *const reco[3], const int stride[3], int bytes_per_sample);
 const char *orc_last_error(void);
 /* work counters for the bench's diagnostic model */
+int      orc_arith_encode(int qp, const int32_t *ops, int nops, uint8_t *out, int cap);
+long     orc_write_tiles(orc_enc *e, uint8_t *buf, long cap, int *sizes);   /* slice_data payload per tile (after orc_compress_frame) */
+int      orc_get_levels(orc_enc *e, int16_t *const lev[3]);
 void     orc_get_counters(orc_enc *e, uint64_t out[4]); /* satd candidates, rd candidates, rd pixels, nodes */
 
 /* ---------------- leaf operators (individually testable; used by the golden-vector tests) -------- */

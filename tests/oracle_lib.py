@@ -119,3 +119,31 @@ def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chro
         return res, cus[:n.value].copy(), reco, cnt
     finally:
         L.orc_destroy(e)
+
+
+def write_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOLS_DEFAULT):
+    """Oracle: compress one frame, then its slice_data payload.  Returns (payload bytes, per-tile sizes, cu table, level planes)."""
+    L = lib()
+    L.orc_write_tiles.restype = C.c_long
+    L.orc_write_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+    L.orc_get_levels.argtypes = [C.c_void_p, C.c_void_p]
+    cfg = default_cfg(w, h, bit_depth, tile_cols, tile_rows, chroma, tools)
+    e = L.orc_create(C.byref(cfg))
+    if not e:
+        raise RuntimeError(L.orc_last_error().decode())
+    try:
+        sl = make_slice(sp)
+        L.orc_set_slice(e, C.byref(sl))
+        planes = [np.ascontiguousarray(p) for p in planes]
+        L.orc_load_frame(e, (C.c_void_p * 3)(*[p.ctypes.data for p in planes]), (C.c_int * 3)(*[p.shape[1] for p in planes]), planes[0].dtype.itemsize)
+        nctu = ((w + 127) // 128) * ((h + 127) // 128)
+        res = np.zeros(nctu, CTU_DTYPE); cus = np.zeros(nctu * 2048, CU_DTYPE); n = C.c_int()
+        assert L.orc_compress_frame(e, res.ctypes.data, cus.ctypes.data, len(cus), C.byref(n)) == 0
+        buf = np.zeros(w * h * 4 + 4096, np.uint8); sizes = np.zeros(tile_cols * tile_rows, np.int32)
+        tot = L.orc_write_tiles(e, buf.ctypes.data, len(buf), sizes.ctypes.data)
+        assert tot >= 0
+        lev = [np.zeros((h >> (1 if c else 0), w >> (1 if c else 0)), np.int16) for c in range(3)]
+        L.orc_get_levels(e, (C.c_void_p * 3)(*[l.ctypes.data for l in lev]))
+        return buf[:tot].copy(), sizes, cus[:n.value].copy(), lev
+    finally:
+        L.orc_destroy(e)

@@ -144,3 +144,25 @@ def test_transform_quant_round_trip():
             dq = np.zeros(k, np.int32); out = np.zeros(k, np.int16)
             L.orc_dequant(P(lev), int(w), int(h), int(bd), q, P(dq)); L.orc_inv_2d(P(dq), int(w), int(h), int(bd), P(out), int(w))
             assert np.array_equal(out, out_e), ("resi", bd, qp, w, h)
+
+
+def test_arithmetic_coder_and_slice_data_payload():
+    """BinEncoder_Std on random operation strings; and the slice_data payloads of six pictures: byte-identical to the
+    ones the reference DECODER parsed back into the oracle's CUs and levels when the fixture was generated."""
+    import importlib
+    pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+    L = O.lib()
+    g = np.load(os.path.join(G, "bitstream.npz"))
+    o_off = b_off = 0
+    for (qp, n, nbytes) in g["arith_meta"]:
+        ops = np.ascontiguousarray(g["arith_ops"][o_off:o_off + 3 * n]); o_off += 3 * int(n)
+        exp = g["arith_bytes"][b_off:b_off + nbytes]; b_off += int(nbytes)
+        out = np.zeros(int(nbytes) + 16, np.uint8)
+        assert L.orc_arith_encode(int(qp), P(ops), int(n), P(out), len(out)) == nbytes
+        assert np.array_equal(out[:nbytes], exp)
+    off = 0
+    for (W, H, qp, tc, tr, bd, seed, nbytes), sizes in zip(g["pic_meta"], g["pic_sizes"]):
+        exp = g["pic_bytes"][off:off + nbytes]; off += int(nbytes)
+        payload, sz, _, _ = O.write_frame(pkg.synth_frame(int(W), int(H), 0, int(bd), int(seed)), int(W), int(H), pkg.slice_params(int(qp), bit_depth=int(bd)),
+                                          bit_depth=int(bd), tile_cols=int(tc), tile_rows=int(tr))
+        assert np.array_equal(sz, sizes[:len(sz)]) and np.array_equal(payload, exp), (W, H, qp, tc, tr, bd)
