@@ -48,6 +48,7 @@ typedef struct {
   int32_t chroma;                /* 1 = code the chroma tree too (4:2:0) */
   int32_t max_frames;            /* frames resident per batch */
   int32_t device;                /* HIP device ordinal */
+  int32_t emit_payload;          /* 1 = also arithmetic-code the final CTU syntax: slice_data() payload per tile (vvcx_get_payload) */
 } vvcx_cfg;
 
 /* ≙ per-slice state pushed by EncSlice before the CTU loop: setUpLambda (EL/EncSlice.cpp:107-149),
@@ -111,6 +112,10 @@ int  vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out /* [n_frame
 /* final CU table of one bound frame (CTU raster order; per CTU luma CUs then chroma CUs, by origin).
  * ≙ walking cs.cus after the CTU loop; same fields D_BLOCK_STATISTICS_CODED traces */
 int  vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus, int *n_cus);
+/* slice_data() payload of one completely coded tile of a bound frame: the bytes EncSlice::encodeSlice would hand to the NAL writer
+ * for that brick (CABACWriter::coding_tree_unit per CTU, end_of_ctu / end_of_slice terminating bins, byte alignment;
+ * EL/EncSlice.cpp:1884-2006).  Requires cfg.emit_payload.  buf is host memory */
+int  vvcx_get_payload(vvcx_handle *h, int frame, int tile, uint8_t *buf, int cap, int *nbytes);
 /* device time of the last compress launch, measured with HIP events on the launch stream (ms) */
 float vvcx_last_kernel_ms(const vvcx_handle *h);
 /* work counters of the last launch: [0] SATD-stage candidates, [1] full-RD TU evaluations, [2] RD pixels, [3] nodes */

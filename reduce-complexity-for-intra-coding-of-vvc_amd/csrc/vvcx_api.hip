@@ -46,10 +46,13 @@ struct vvcx_handle {
   uint8_t *scratch_d; size_t scratch_cap;
   VxStreamDesc *streams_d; int32_t *task_ctu_d; VxCtuRes *results_d; int task_cap, stream_cap;
   unsigned long long *counters_d;
+  // optional slice_data writer: payload bytes per (frame, tile), byte ranges, persistent arithmetic-coder state
+  uint8_t *payload_d; uint64_t *payload_off_d; uint32_t *payload_cap_d; void *arith_d; std::vector<uint64_t> payload_off; std::vector<uint32_t> payload_cap;
   hipEvent_t ev0, ev1; float last_ms;
   size_t lev_plane[3], lev_frame, units_plane, units_frame;
 };
 
+#define VVCX_PAYLOAD_BYTES_PER_CTU 32768u
 static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_CU_REUSE;
 
 extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
@@ -82,12 +85,24 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   h->lev_frame = h->lev_plane[0] + 2 * h->lev_plane[1];
   h->units_plane = (size_t) h->uw * h->uh; h->units_frame = 2 * h->units_plane;
   h->frames_d = nullptr; h->lev_d = nullptr; h->units_d = nullptr; h->stream_ctx_d = nullptr; h->scratch_d = nullptr; h->scratch_cap = 0;
+  h->payload_d = nullptr; h->payload_off_d = nullptr; h->payload_cap_d = nullptr; h->arith_d = nullptr;
   h->streams_d = nullptr; h->task_ctu_d = nullptr; h->results_d = nullptr; h->task_cap = 0; h->stream_cap = 0; h->counters_d = nullptr;
   const int F = cfg->max_frames;
   if (hipMalloc((void **) &h->frames_d, sizeof(VxFrameDev) * F) != hipSuccess || hipMalloc((void **) &h->lev_d, h->lev_frame * 2 * F) != hipSuccess ||
       hipMalloc((void **) &h->units_d, h->units_frame * sizeof(VxUnit) * F) != hipSuccess ||
       hipMalloc((void **) &h->stream_ctx_d, (size_t) F * h->ntiles * 2 * VXD_NUM_CTX * 2) != hipSuccess ||
       hipMalloc((void **) &h->counters_d, 52 * sizeof(unsigned long long)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
+  if (cfg->emit_payload) {                       // VVCX_PAYLOAD_BYTES_PER_CTU per CTU: a CTU of 8-bit video at QP >= 17 stays far below (raw samples are 24 KB)
+    const size_t nstream = (size_t) F * h->ntiles;
+    h->payload_off.resize(nstream); h->payload_cap.resize(nstream);
+    uint64_t off = 0;
+    for (size_t s2 = 0; s2 < nstream; s2++) { const uint32_t cap = (uint32_t) h->tile_ctus[s2 % h->ntiles].size() * VVCX_PAYLOAD_BYTES_PER_CTU; h->payload_off[s2] = off; h->payload_cap[s2] = cap; off += cap; }
+    if (hipMalloc((void **) &h->payload_d, off) != hipSuccess || hipMalloc((void **) &h->payload_off_d, nstream * 8) != hipSuccess ||
+        hipMalloc((void **) &h->payload_cap_d, nstream * 4) != hipSuccess || hipMalloc(&h->arith_d, nstream * 32) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
+    (void) hipMemcpy(h->payload_off_d, h->payload_off.data(), nstream * 8, hipMemcpyHostToDevice);
+    (void) hipMemcpy(h->payload_cap_d, h->payload_cap.data(), nstream * 4, hipMemcpyHostToDevice);
+    (void) hipMemset(h->arith_d, 0, nstream * 32);
+  }
   (void) hipEventCreate(&h->ev0); (void) hipEventCreate(&h->ev1);
   *out = h;
   return VVCX_OK;
@@ -97,6 +112,7 @@ extern "C" void vvcx_destroy(vvcx_handle *h)
 {
   if (!h) return;
   (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d);
+  (void) hipFree(h->payload_d); (void) hipFree(h->payload_off_d); (void) hipFree(h->payload_cap_d); (void) hipFree(h->arith_d);
   (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
   (void) hipEventDestroy(h->ev0); (void) hipEventDestroy(h->ev1);
   delete h;
@@ -184,6 +200,7 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
     if (by_stream[s].empty()) continue;
     const int tile = (int) (s % h->ntiles);
     VxStreamDesc d; d.frame = (int) (s / h->ntiles); d.tile = tile; d.first_task = (int) task_ctu.size(); d.n_tasks = (int) by_stream[s].size();
+    d.done_before = h->next_idx[s]; d.tile_ctus = (int) h->tile_ctus[(size_t) tile].size();
     for (int i : by_stream[s]) {
       const std::vector<int> &order = h->tile_ctus[(size_t) tile];
       if (new_next[s] >= (int) order.size() || order[(size_t) new_next[s]] != tasks[i].ctu_rs_addr)
@@ -215,6 +232,7 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
   p.dist_scale = (double) (1 << 15) / h->sl.lambda;                       // CL/RdCost.cpp:79
   p.sqrt_lambda_fp = sqrt(h->sl.lambda) * (1.0 / (double) (1 << 15));     // EL/IntraSearch.cpp:297
   p.frames = h->frames_d; p.streams = h->streams_d; p.task_ctu = h->task_ctu_d; p.results = h->results_d; p.stream_ctx = h->stream_ctx_d;
+  p.payload = h->payload_d; p.payload_off = h->payload_off_d; p.payload_cap = h->payload_cap_d; p.arith_state = h->arith_d;
   p.scratch = h->scratch_d; p.scratch_per_stream = per_stream; p.counters = h->counters_d; p.ntiles = h->ntiles;
 
   HIPCHK(hipEventRecord(h->ev0, stream));
@@ -431,5 +449,22 @@ extern "C" int vvcx_transform_quant_batch(const int16_t *org, const int16_t *pre
   HIPCHK(hipMemcpy(lev, dlev.p, bytes, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(rec, drec.p, bytes, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(o.data(), dout.p, (size_t) n * 16, hipMemcpyDeviceToHost));
   for (int i = 0; i < n; i++) { sse[i] = o[(size_t) i * 2]; cbf[i] = (uint8_t) o[(size_t) i * 2 + 1]; }
+  return VVCX_OK;
+}
+
+// slice_data() payload of one tile of a bound frame (≙ the sub-stream EncSlice::encodeSlice hands to the NAL writer, EL/EncSlice.cpp:1884-2006)
+extern "C" int vvcx_get_payload(vvcx_handle *h, int frame, int tile, uint8_t *buf, int cap, int *nbytes)
+{
+  if (!h || !buf || !nbytes || frame < 0 || frame >= h->n_frames || tile < 0 || tile >= h->ntiles) return fail(VVCX_ERR_ARG, "bad argument");
+  if (!h->payload_d) return fail(VVCX_ERR_STATE, "handle was created without emit_payload");
+  const size_t s = (size_t) frame * h->ntiles + tile;
+  if (h->next_idx[s] != (int) h->tile_ctus[(size_t) tile].size()) return fail(VVCX_ERR_STATE, "tile %d of frame %d is not completely coded yet", tile, frame);
+  uint32_t st[8];
+  HIPCHK(hipMemcpy(st, (const uint8_t *) h->arith_d + s * 32, 32, hipMemcpyDeviceToHost));
+  const uint32_t n = st[7];                        // Arith::n
+  if (n > h->payload_cap[s]) return fail(VVCX_ERR_STATE, "payload of tile %d exceeds the %u bytes reserved", tile, h->payload_cap[s]);
+  *nbytes = (int) n;
+  if ((int) n > cap) return fail(VVCX_ERR_ARG, "buffer too small: %u bytes needed", n);
+  HIPCHK(hipMemcpy(buf, h->payload_d + h->payload_off[s], n, hipMemcpyDeviceToHost));
   return VVCX_OK;
 }

@@ -38,7 +38,7 @@ struct VxFrameDev {         // one bound picture
 
 struct VxLeafPred { int32_t comp, x, y, w, h, mode, mrl; };      // same layout as vvcx_pred_case
 
-struct VxStreamDesc { int32_t frame, tile, first_task, n_tasks; };
+struct VxStreamDesc { int32_t frame, tile, first_task, n_tasks, done_before /* CTUs of the tile coded by earlier launches */, tile_ctus; };
 
 struct VxCtuRes { uint64_t dist, bits; double cost; int32_t n_cu, pad; };
 
@@ -59,6 +59,11 @@ struct VxParams {
   uint64_t            scratch_per_stream;
   unsigned long long *counters;      // 4 global work counters
   int32_t             ntiles;
+  // slice_data writer (optional): per (frame, tile) byte range of the payload buffer and the persistent coder state (32 B each)
+  uint8_t            *payload;
+  const uint64_t     *payload_off;
+  const uint32_t     *payload_cap;
+  void               *arith_state;
 };
 
 // per-stream scratch layout (bytes)

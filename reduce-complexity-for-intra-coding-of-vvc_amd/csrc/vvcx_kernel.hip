@@ -71,6 +71,8 @@ struct Frame {                     // one recursion level: partitioner level + C
 };
 
 struct Cand { uint8_t mode, mrl; };
+// BinEncoderBase state + OutputBitstream position (EL/BinEncoder.cpp:106-371); persists in HBM between launches of a stream
+struct Arith { uint32_t low, range, buffered_byte; int32_t bits_left, num_buffered; uint32_t bit_acc; int32_t bit_n; uint32_t n; };
 
 struct CtlState {            // controller-private working set (touched by thread 0 only)
   Cand rdList[80]; double rdCost[80]; int rdSize, numRd;
@@ -119,6 +121,7 @@ struct Lds {
   int win_idx, win_wave;
   unsigned long long cu_bits;      // cu_pred_data + cu_residual bits of the winner (contexts left in wctx[0])
   unsigned long long cnt[4];
+  Arith aw; uint8_t *aw_out; uint32_t aw_cap; int colm;      // bitstream pass: arithmetic coder, its output (HBM) and capacity; co-located luma mode of the chroma node
   unsigned long long prof[48];    // shader-clock ticks per operation kind (diagnostic, see vvcx_get_profile)
 };
 
@@ -192,11 +195,90 @@ template <typename T> __device__ inline void st_px(void *plane, int idx, int v) 
 
 // ------------------------------------------------------------------------------------------------ CABAC estimator
 // BinProbModel_Std + BitEstimator (CL/Contexts.h:86-155, EL/BinEncoder.h:238-303)
+// OutputBitstream::write (MSB first) / BinEncoderBase::writeOut, encodeBinsEP, encodeBinTrm, finish: thread 0, bitstream pass only
+__device__ inline void bs_write(uint32_t v, int nbits)
+{
+  for (int i = nbits - 1; i >= 0; i--) {
+    L.aw.bit_acc = (L.aw.bit_acc << 1) | ((v >> i) & 1); L.aw.bit_n++;
+    if (L.aw.bit_n == 8) { if (L.aw.n < L.aw_cap) L.aw_out[L.aw.n] = (uint8_t) L.aw.bit_acc; L.aw.n++; L.aw.bit_acc = 0; L.aw.bit_n = 0; }
+  }
+}
+__device__ __noinline__ void arith_write_out()
+{
+  Arith &a = L.aw;
+  const uint32_t lead = a.low >> (24 - a.bits_left);
+  a.bits_left += 8;
+  a.low &= 0xffffffffu >> a.bits_left;
+  if (lead == 0xff) a.num_buffered++;
+  else if (a.num_buffered > 0) {
+    const uint32_t carry = lead >> 8;
+    uint32_t byte = a.buffered_byte + carry;
+    a.buffered_byte = lead & 0xff;
+    bs_write(byte, 8);
+    byte = (0xff + carry) & 0xff;
+    while (a.num_buffered > 1) { bs_write(byte, 8); a.num_buffered--; }
+  } else { a.num_buffered = 1; a.buffered_byte = lead; }
+}
+__device__ inline void arith_start() { Arith &a = L.aw; a.low = 0; a.range = 510; a.buffered_byte = 0xff; a.num_buffered = 0; a.bits_left = 23; a.bit_acc = 0; a.bit_n = 0; a.n = 0; }
+__device__ __noinline__ void arith_bins_ep(uint32_t bins, int n)
+{
+  Arith &a = L.aw;
+  while (n > 8) {
+    n -= 8;
+    const uint32_t pattern = bins >> n;
+    a.low <<= 8; a.low += a.range * pattern; bins -= pattern << n; a.bits_left -= 8;
+    if (a.bits_left < 12) arith_write_out();
+  }
+  a.low <<= n; a.low += a.range * bins; a.bits_left -= n;
+  if (a.bits_left < 12) arith_write_out();
+}
+__device__ __noinline__ void arith_trm(unsigned bin)
+{
+  Arith &a = L.aw;
+  a.range -= 2;
+  if (bin) { a.low += a.range; a.low <<= 7; a.range = 2 << 7; a.bits_left -= 7; }
+  else if (a.range >= 256) return;
+  else { a.low <<= 1; a.range <<= 1; a.bits_left--; }
+  if (a.bits_left < 12) arith_write_out();
+}
+__device__ __noinline__ void arith_finish()
+{
+  Arith &a = L.aw;
+  if (a.low >> (32 - a.bits_left)) {
+    bs_write(a.buffered_byte + 1, 8);
+    while (a.num_buffered > 1) { bs_write(0x00, 8); a.num_buffered--; }
+    a.low -= 1u << (32 - a.bits_left);
+  } else {
+    if (a.num_buffered > 0) bs_write(a.buffered_byte, 8);
+    while (a.num_buffered > 1) { bs_write(0xff, 8); a.num_buffered--; }
+  }
+  bs_write(a.low >> 8, 24 - a.bits_left);
+  bs_write(1, 1); while (a.bit_n) bs_write(0, 1);       // OutputBitstream::writeByteAlignment
+}
+__device__ __noinline__ void arith_bin(unsigned bin, unsigned st)      // TBinEncoder::encodeBin 378-420 with the state before its update
+{
+  Arith &a = L.aw;
+  unsigned q = st & 0xff; const unsigned mps = q >> 7;
+  if (q & 0x80) q ^= 0xff;
+  const uint32_t lps = (((q >> 2) * (a.range >> 5)) >> 1) + 4;
+  a.range -= lps;
+  if (bin != mps) {
+    const int nb = lps >= 128 ? 1 : lps >= 64 ? 2 : lps >= 32 ? 3 : lps >= 16 ? 4 : lps >= 8 ? 5 : 6;      // m_RenormTable_32[lps >> 3] (CL/Contexts.cpp:45-55)
+    a.bits_left -= nb; a.low += a.range; a.low <<= nb; a.range = lps << nb;
+    if (a.bits_left < 12) arith_write_out();
+  } else if (a.range < 256) {
+    a.bits_left -= 1; a.low <<= 1; a.range <<= 1;
+    if (a.bits_left < 12) arith_write_out();
+  }
+}
+// WR: also drive the arithmetic coder L.aw (bitstream pass only; a template so that the estimator's copies contain no call)
+template <bool WR = false>
 __device__ inline void enc_bin(Cab &cb, unsigned bin, int ctx)
 {
   Ctx *c = &L.ctxs[cb.ci];
   const unsigned st = (unsigned) (c->s0[ctx] + c->s1[ctx]) >> 8;
   cb.bits += L.t.bin_frac[st * 2 + bin];
+  if (WR) arith_bin(bin, st);
   const int rate = L.t.ctx_rate[ctx];
   const int r0 = 2 + ((rate >> 2) & 3), r1 = 3 + r0 + (rate & 3);
   unsigned a = c->s0[ctx], b = c->s1[ctx];
@@ -204,7 +286,9 @@ __device__ inline void enc_bin(Cab &cb, unsigned bin, int ctx)
   if (bin) { a += (0x7fffu >> r0) & 0x7FE0u; b += (0x7fffu >> r1) & 0x7FFEu; }
   c->s0[ctx] = (uint16_t) a; c->s1[ctx] = (uint16_t) b;
 }
-__device__ inline void enc_ep(Cab &cb, int n) { cb.bits += (uint64_t) n << 15; }
+// n bypass bins of the given value, MSB first (the estimator only needs n)
+template <bool WR = false>
+__device__ inline void enc_ep(Cab &cb, uint32_t value, int n) { cb.bits += (uint64_t) n << 15; if (WR && n > 0) arith_bins_ep(value, n); }
 
 __device__ void cg_shape(int w, int h, int &lcw, int &lch)     // g_log2SbbSize, CL/Rom.cpp:250-261
 {
@@ -223,15 +307,17 @@ __device__ void diag_pos(int bw, int bh, int n, int &ox, int &oy)
   }
   ox = col; oy = line;
 }
+template <bool WR = false>
 __device__ inline void enc_rem_abs(Cab &cb, unsigned bins, unsigned rice)       // EL/BinEncoder.cpp:444-472
 {
   const unsigned thr = 5u << rice;
-  if (bins < thr) { enc_ep(cb, (int) ((bins >> rice) + 1 + rice)); return; }
+  if (bins < thr) { const unsigned len = (bins >> rice) + 1; enc_ep<WR>(cb, (1u << len) - 2, (int) len); enc_ep<WR>(cb, bins & ((1u << rice) - 1), (int) rice); return; }
   const unsigned maxPrefix = 32 - 5 - 15;
   unsigned prefix = 0, suffix, code = (bins >> rice) - 5;
   if (code >= ((1u << maxPrefix) - 1)) { prefix = maxPrefix; suffix = 15; }
   else { while (code > ((2u << prefix) - 2)) prefix++; suffix = prefix + rice + 1; }
-  enc_ep(cb, (int) (5 + prefix + suffix));
+  enc_ep<WR>(cb, (1u << (prefix + 5)) - 1, (int) (prefix + 5));
+  enc_ep<WR>(cb, ((code - ((1u << prefix) - 1)) << rice) | (bins & ((1u << rice) - 1)), (int) suffix);
 }
 struct Cctx { int w, h, ch, tmpl_diag, tmpl_sum1; };
 __device__ int sig_ctx(Cctx &c, const int16_t *coeff, int blk)      // CL/ContextModelling.h:107-156 (state 0)
@@ -333,6 +419,7 @@ __device__ __noinline__ RcPre rc_prepass_wave(int lev_off, const int16_t *coeff_
   r.sig_raster = ((unsigned long long) (unsigned) wave_sum_i32(rhi) << 32) | (unsigned) wave_sum_i32(rlo);
   return r;
 }
+template <bool WR = false>
 __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, const uint16_t *scan, RcPre pre)
 {
   Cctx c; c.w = w; c.h = h; c.ch = is_chroma; c.tmpl_diag = -1; c.tmpl_sum1 = -1;
@@ -353,12 +440,12 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
     const int gx = L.t.group_idx[posX], gy = L.t.group_idx[posY];
     const int maxX = L.t.group_idx[zw - 1], maxY = L.t.group_idx[zh - 1];
     int k;
-    for (k = 0; k < gx; k++) enc_bin(cb, 1, VX_CTX_LastX[c.ch] + offx + (k >> shx));
-    if (gx < maxX) enc_bin(cb, 0, VX_CTX_LastX[c.ch] + offx + (k >> shx));
-    for (k = 0; k < gy; k++) enc_bin(cb, 1, VX_CTX_LastY[c.ch] + offy + (k >> shy));
-    if (gy < maxY) enc_bin(cb, 0, VX_CTX_LastY[c.ch] + offy + (k >> shy));
-    if (gx > 3) enc_ep(cb, (gx - 2) >> 1);
-    if (gy > 3) enc_ep(cb, (gy - 2) >> 1);
+    for (k = 0; k < gx; k++) enc_bin<WR>(cb, 1, VX_CTX_LastX[c.ch] + offx + (k >> shx));
+    if (gx < maxX) enc_bin<WR>(cb, 0, VX_CTX_LastX[c.ch] + offx + (k >> shx));
+    for (k = 0; k < gy; k++) enc_bin<WR>(cb, 1, VX_CTX_LastY[c.ch] + offy + (k >> shy));
+    if (gy < maxY) enc_bin<WR>(cb, 0, VX_CTX_LastY[c.ch] + offy + (k >> shy));
+    if (gx > 3) enc_ep<WR>(cb, (uint32_t) (posX - VX_MIN_IN_GROUP[gx]), (gx - 2) >> 1);
+    if (gy > 3) enc_ep<WR>(cb, (uint32_t) (posY - VX_MIN_IN_GROUP[gy]), (gy - 2) >> 1);
   }
   int regBins = (zw * zh * 28) >> 4;
   unsigned long long sigPos = 0;         // m_sigCoeffGroupFlag by CG raster position
@@ -373,16 +460,17 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
     const int firstSigPos = isLast ? scanPosLast : maxSub;
     int nextSigPos = firstSigPos;
     if (!isLast && isNotFirst) {
-      if ((sigPos >> cgPos) & 1) enc_bin(cb, 1, sigGroupCtx);
-      else { enc_bin(cb, 0, sigGroupCtx); continue; }
+      if ((sigPos >> cgPos) & 1) enc_bin<WR>(cb, 1, sigGroupCtx);
+      else { enc_bin<WR>(cb, 0, sigGroupCtx); continue; }
     }
     const int inferSigPos = nextSigPos != scanPosLast ? (isNotFirst ? minSub : -1) : nextSigPos;
     int numNonZero = 0, remRegBins = regBins;
+    uint32_t signPattern = 0;
     for (; nextSigPos >= minSub && remRegBins >= 4; nextSigPos--) {
       const int blk = scan[nextSigPos];
       const int cf = coeff[blk];
       const unsigned sigFlag = cf != 0;
-      if (numNonZero || nextSigPos != inferSigPos) { const int ctx = sig_ctx(c, coeff, blk); enc_bin(cb, sigFlag, ctx); remRegBins--; }
+      if (numNonZero || nextSigPos != inferSigPos) { const int ctx = sig_ctx(c, coeff, blk); enc_bin<WR>(cb, sigFlag, ctx); remRegBins--; }
       else if (nextSigPos != scanPosLast) sig_ctx(c, coeff, blk);
       if (sigFlag) {
         int off = 0;                       // ctxOffsetAbs (158-167)
@@ -391,13 +479,14 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
           off += (!c.tmpl_diag ? (c.ch == 0 ? 15 : 5) : c.ch == 0 ? (c.tmpl_diag < 3 ? 10 : (c.tmpl_diag < 10 ? 5 : 0)) : 0);
         }
         numNonZero++;
+        signPattern = (signPattern << 1) | (cf < 0);
         int rem = iabs(cf) - 1;
         const unsigned gt1 = !!rem;
-        enc_bin(cb, gt1, VX_CTX_GtxFlag[c.ch + 2] + off); remRegBins--;
+        enc_bin<WR>(cb, gt1, VX_CTX_GtxFlag[c.ch + 2] + off); remRegBins--;
         if (gt1) {
           rem -= 1;
-          enc_bin(cb, rem & 1, VX_CTX_ParFlag[c.ch] + off); rem >>= 1; remRegBins--;
-          enc_bin(cb, !!rem, VX_CTX_GtxFlag[c.ch] + off); remRegBins--;
+          enc_bin<WR>(cb, rem & 1, VX_CTX_ParFlag[c.ch] + off); rem >>= 1; remRegBins--;
+          enc_bin<WR>(cb, !!rem, VX_CTX_GtxFlag[c.ch] + off); remRegBins--;
         }
       }
     }
@@ -406,24 +495,25 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
     for (int sp = firstSigPos; sp > firstPosMode2; sp--) {
       const int blk = scan[sp];
       const unsigned a = (unsigned) iabs(coeff[blk]);
-      if (a >= 4) enc_rem_abs(cb, (a - 4) >> 1, L.t.gorice_pars[tmpl_abs_sum(c, coeff, blk, 4)]);
+      if (a >= 4) enc_rem_abs<WR>(cb, (a - 4) >> 1, L.t.gorice_pars[tmpl_abs_sum(c, coeff, blk, 4)]);
     }
     for (int sp = firstPosMode2; sp >= minSub; sp--) {
       const int blk = scan[sp];
       const unsigned a = (unsigned) iabs(coeff[blk]);
       const int sumAll = tmpl_abs_sum(c, coeff, blk, 0);
       const unsigned rice = L.t.gorice_pars[sumAll], pos0 = L.t.gorice_pos0[sumAll];
-      enc_rem_abs(cb, a == 0 ? pos0 : a <= pos0 ? a - 1 : a, rice);
-      if (a) numNonZero++;
+      enc_rem_abs<WR>(cb, a == 0 ? pos0 : a <= pos0 ? a - 1 : a, rice);
+      if (a) { numNonZero++; signPattern = (signPattern << 1) | (coeff[blk] < 0); }
     }
-    enc_ep(cb, numNonZero);
+    enc_ep<WR>(cb, signPattern, numNonZero);
   }
 }
 // single-lane form (controller / estimator pass) and wave form (lane 0 owns cb)
+template <bool WR = false>
 __device__ void residual_coding(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, uint16_t *scan)
 {
   const RcPre pre = rc_prepass_serial(coeff, w, h, scan);
-  rc_serial(cb, coeff, w, h, is_chroma, scan, pre);
+  rc_serial<WR>(cb, coeff, w, h, is_chroma, scan, pre);
 }
 // Wave form of residual_coding (same syntax as rc_serial, all 64 lanes working):
 //  (1) data-parallel pre-pass: scan table, last position, significant groups (by scan index and by raster position);
@@ -729,6 +819,7 @@ __device__ __noinline__ void prepare_node(const VxParams &p, const VxFrameDev &f
   f.ctx_spl = (uint8_t) ctxSpl; f.ctx_qt = (uint8_t) ctxQt; f.ctx_hv = (uint8_t) ctxHv;
 }
 // CABACWriter::split_cu_mode (EL/CABACWriter.cpp:1010-1069)
+template <bool WR = false>
 __device__ void enc_split_cu_mode(const VxParams &p, const VxFrameDev &fd, Cab &cb, Frame &f, int ch, int tile, int split)
 {
   const int m = f.can_mask;
@@ -736,18 +827,18 @@ __device__ void enc_split_cu_mode(const VxParams &p, const VxFrameDev &fd, Cab &
   const unsigned ctxH12 = f.mt <= 1 ? 1 : 0, ctxV12 = f.mt <= 1 ? 3 : 2;
   const int canSplit = canQt || canBh || canBv || canTh || canTv;
   const int isNo = split == SPLIT_NONE;
-  if (canNo && canSplit) enc_bin(cb, !isNo, VX_CTX_SplitFlag + f.ctx_spl);
+  if (canNo && canSplit) enc_bin<WR>(cb, !isNo, VX_CTX_SplitFlag + f.ctx_spl);
   if (isNo) return;
   const int canBtt = canBh || canBv || canTh || canTv;
   const int isQt = split == SPLIT_QT;
-  if (canQt && canBtt) enc_bin(cb, (unsigned) isQt, VX_CTX_SplitQtFlag + f.ctx_qt);
+  if (canQt && canBtt) enc_bin<WR>(cb, (unsigned) isQt, VX_CTX_SplitQtFlag + f.ctx_qt);
   if (isQt) return;
   const int canHor = canBh || canTh, canVer = canBv || canTv;
   const int isVer = split == SPLIT_BV || split == SPLIT_TV;
-  if (canVer && canHor) enc_bin(cb, (unsigned) isVer, VX_CTX_SplitHvFlag + f.ctx_hv);
+  if (canVer && canHor) enc_bin<WR>(cb, (unsigned) isVer, VX_CTX_SplitHvFlag + f.ctx_hv);
   const int can14 = isVer ? canTv : canTh, can12 = isVer ? canBv : canBh;
   const int is12 = isVer ? (split == SPLIT_BV) : (split == SPLIT_BH);
-  if (can12 && can14) enc_bin(cb, (unsigned) is12, VX_CTX_Split12Flag + (int) (isVer ? ctxV12 : ctxH12));
+  if (can12 && can14) enc_bin<WR>(cb, (unsigned) is12, VX_CTX_Split12Flag + (int) (isVer ? ctxV12 : ctxH12));
 }
 
 // PU::getIntraMPMs (CL/UnitTools.cpp:508-640)
@@ -774,22 +865,23 @@ __device__ void derive_mpms(int Ld, int Ad, unsigned mpm[6])
   for (int i = 1; i < 6; i++) { unsigned v = L.mpm_sorted[i]; int j = i - 1; while (j >= 0 && L.mpm_sorted[j] > v) { L.mpm_sorted[j + 1] = L.mpm_sorted[j]; j--; } L.mpm_sorted[j + 1] = v; }
 }
 // CABACWriter::intra_luma_pred_mode 1762-1845 + extend_ref_line 1566-1591 (MIP/ISP off); MPMs from L.mpm
+template <bool WR = false>
 __device__ void enc_intra_luma_pred_mode(Cab &cb, int y, int dir, int mrl)
 {
   if ((y & 127) != 0) {
-    enc_bin(cb, mrl != 0, VX_CTX_MultiRefLineIdx + 0);
-    if (mrl != 0) enc_bin(cb, mrl != 1, VX_CTX_MultiRefLineIdx + 1);
+    enc_bin<WR>(cb, mrl != 0, VX_CTX_MultiRefLineIdx + 0);
+    if (mrl != 0) enc_bin<WR>(cb, mrl != 1, VX_CTX_MultiRefLineIdx + 1);
   }
   int mpm_idx = 6;
   for (int i = 0; i < 6; i++) if ((unsigned) dir == L.mpm[i]) { mpm_idx = i; break; }
-  if (!mrl) enc_bin(cb, mpm_idx < 6, VX_CTX_IntraLumaMpmFlag);
+  if (!mrl) enc_bin<WR>(cb, mpm_idx < 6, VX_CTX_IntraLumaMpmFlag);
   if (mpm_idx < 6) {
-    if (mrl == 0) enc_bin(cb, mpm_idx > 0, VX_CTX_IntraLumaPlanarFlag + 1);
-    enc_ep(cb, imin(mpm_idx, 4));
+    if (mrl == 0) enc_bin<WR>(cb, mpm_idx > 0, VX_CTX_IntraLumaPlanarFlag + 1);
+    if (mpm_idx) { const int nb = imin(mpm_idx, 4); enc_ep<WR>(cb, mpm_idx < 5 ? (1u << nb) - 2 : 15u, nb); }      // truncated unary, bypass (1791-1806)
   } else {
     unsigned m = (unsigned) dir;
     for (int i = 5; i >= 0; i--) if (m > L.mpm_sorted[i]) m--;
-    enc_ep(cb, m < 3 ? 5 : 6);                   // xWriteTruncBinCode(m, 61)
+    if (m < 3) enc_ep<WR>(cb, m, 5); else enc_ep<WR>(cb, m + 3, 6);       // xWriteTruncBinCode(m, 61) 1528-1566
   }
 }
 // xFracModeBitsIntra (EL/IntraSearch.cpp:4263-4288) from the node's start contexts.  Every context-coded bin of
@@ -816,11 +908,17 @@ __device__ unsigned long long luma_mode_bits(const Ctx &c, int y, int dir, int m
   }
   return bits;
 }
-__device__ void enc_intra_chroma_pred_mode(Cab &cb, int dir)      // 1891-1933, CCLM off
+template <bool WR = false>
+__device__ void enc_intra_chroma_pred_mode(Cab &cb, int dir, int lm)      // 1891-1933, CCLM off; lm = co-located luma mode (candidate list 840-873)
 {
   const int isDM = dir == DM_CHROMA;
-  enc_bin(cb, isDM ? 0 : 1, VX_CTX_IntraChromaPredMode);
-  if (!isDM) enc_ep(cb, 2);
+  enc_bin<WR>(cb, isDM ? 0 : 1, VX_CTX_IntraChromaPredMode);
+  if (isDM) return;
+  int list[4] = { PLANAR, VER, HOR, DC };
+  for (int i = 0; i < 4; i++) if (lm == list[i]) { list[i] = VDIA; break; }
+  int cand = 0;
+  for (; cand < 3; cand++) if (list[cand] == dir) break;
+  enc_ep<WR>(cb, (uint32_t) cand, 2);
 }
 
 // ------------------------------------------------------------------------------------------------ intra prediction
@@ -1567,7 +1665,7 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
     {                      // 1611-1621: contexts not reset; xGetIntraFracBitsQT(chroma)
       Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
       if (lane == 0) {
-        enc_intra_chroma_pred_mode(cb, cm);
+        enc_intra_chroma_pred_mode(cb, cm, L.colm);
         enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]);
         enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]);
       }
@@ -1618,7 +1716,7 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &f
     const int cbfm = uni(L.rd_cbf[best]);
     Cab cb; cb.ci = CI_W(0); cb.bits = 0;
     if (lane == 0) {
-      enc_intra_chroma_pred_mode(cb, L.rd[best].mode);
+      enc_intra_chroma_pred_mode(cb, L.rd[best].mode, L.colm);
       enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
       enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
     }
@@ -1693,7 +1791,7 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
       dist += (unsigned long long) (p.dist_weight[k] * (double) sse);
     }
     if (lane == 0) {
-      enc_intra_chroma_pred_mode(cb, mode);
+      enc_intra_chroma_pred_mode(cb, mode, L.colm);
       enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
       enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
     }
@@ -1918,7 +2016,7 @@ __device__ void post(int op) { L.op = op; }
 __device__ void set_node(const Frame &f, int d) { L.nx = f.x; L.ny = f.y; L.nw = f.w; L.nh = f.h; L.nd = d; }
 
 // one controller step: runs until a parallel operation is posted (returns) or the CTU tree is finished (posts OP_DONE)
-__device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
+__device__ __attribute__((always_inline)) inline void control_step(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
 {
   CtlState &S = L.S;
   const int ch = L.tree_ch, tile = L.cur_tile, sh = ch ? 1 : 0;
@@ -1958,7 +2056,8 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
           }
           if (ch) {
             const int cx = f.x + (f.w >> 1), cy = f.y + (f.h >> 1);
-            L.rd[0].mrl = (uint8_t) (f.r_dir == DM_CHROMA ? fd.units[0][(cy >> 2) * p.uw + (cx >> 2)].dir : f.r_dir);    // final mode
+            L.colm = fd.units[0][(cy >> 2) * p.uw + (cx >> 2)].dir;
+            L.rd[0].mrl = (uint8_t) (f.r_dir == DM_CHROMA ? L.colm : f.r_dir);    // final mode
           }
           f.phase = PH_B_DONE;
           post(OP_REUSE); return;
@@ -1982,6 +2081,7 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
           // chroma candidate modes (PU::getIntraChromaCandModes, CL/UnitTools.cpp:840-873), LM modes disabled
           const int cx = f.x + (f.w >> 1), cy = f.y + (f.h >> 1);
           const int lm = fd.units[0][(cy >> 2) * p.uw + (cx >> 2)].dir;      // getCoLocatedIntraLumaMode 949-960
+          L.colm = lm;
           int list[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };
           for (int i = 0; i < 4; i++) if (lm == list[i]) { list[i] = VDIA; break; }
           for (int i = 0; i < 5; i++) { L.rd[i].mode = (uint8_t) list[i]; L.rd[i].mrl = (uint8_t) (list[i] == DM_CHROMA ? lm : list[i]); }
@@ -2133,7 +2233,7 @@ __device__ __noinline__ void control_step(const VxParams &p, const VxFrameDev &f
 
 // final estimator pass over the coded CTU (CABACWriter::coding_tree_unit 254-309 / coding_tree 474-984): advances
 // L.ctxs[CI_CUR] for the next CTU of the stream.  Thread 0 only.
-template <typename T>
+template <typename T, bool WR>
 __device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, Cab &cb, int ch, int tile, Frame *st_, int d, int16_t *lv)
 {
   Frame *st = L.fr; (void) st_;
@@ -2146,7 +2246,7 @@ __device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, 
       const VxUnit *u = &fd.units[ch][(f.y >> 2) * p.uw + (f.x >> 2)];
       const int split = (int) ((u->ss >> (f.depth * 5)) & 31);
       prepare_node(p, fd, top, ch, tile);                  // st is L.fr
-      enc_split_cu_mode(p, fd, cb, f, ch, tile, split);
+      enc_split_cu_mode<WR>(p, fd, cb, f, ch, tile, split);
       if (!split) {
         const int sh = ch ? 1 : 0, W = f.w >> sh, H = f.h >> sh;
         if (!ch) {
@@ -2154,16 +2254,16 @@ __device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, 
           const VxUnit *uL = get_cu(p, fd, 0, f.x - 1, f.y + f.h - 1, tile); if (uL) Ld = uL->dir;
           const VxUnit *uA = get_cu(p, fd, 0, f.x + f.w - 1, f.y - 1, tile); if (uA && ((f.y - 1) >> 7) == (f.y >> 7)) Ad = uA->dir;
           derive_mpms(Ld, Ad, L.mpm);
-          enc_intra_luma_pred_mode(cb, f.y, u->dir, u->mrl);
-          enc_bin(cb, u->cbf & 1, VX_CTX_QtCbf[0]);
-          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; residual_coding(cb, lv, W, H, 0, (uint16_t *) (lv + 4096)); }
+          enc_intra_luma_pred_mode<WR>(cb, f.y, u->dir, u->mrl);
+          enc_bin<WR>(cb, u->cbf & 1, VX_CTX_QtCbf[0]);
+          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; residual_coding<WR>(cb, lv, W, H, 0, (uint16_t *) (lv + 4096)); }
         } else {
-          enc_intra_chroma_pred_mode(cb, u->dir);
-          enc_bin(cb, (unsigned) !!(u->cbf & 2), VX_CTX_QtCbf[1]);
-          enc_bin(cb, (unsigned) !!(u->cbf & 4), VX_CTX_QtCbf[2] + !!(u->cbf & 2));
+          enc_intra_chroma_pred_mode<WR>(cb, u->dir, fd.units[0][((f.y + (f.h >> 1)) >> 2) * p.uw + ((f.x + (f.w >> 1)) >> 2)].dir);
+          enc_bin<WR>(cb, (unsigned) !!(u->cbf & 2), VX_CTX_QtCbf[1]);
+          enc_bin<WR>(cb, (unsigned) !!(u->cbf & 4), VX_CTX_QtCbf[2] + !!(u->cbf & 2));
           for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c)) {
             for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[c][((f.y >> 1) + yy) * fd.lstride[c] + (f.x >> 1) + xx];
-            residual_coding(cb, lv, W, H, 1, (uint16_t *) (lv + 4096));
+            residual_coding<WR>(cb, lv, W, H, 1, (uint16_t *) (lv + 4096));
           }
         }
         top--; continue;
@@ -2210,9 +2310,67 @@ __device__ __noinline__ void advance_ctx_ctu(const VxParams &p, const VxFrameDev
     for (int ch = 0; ch < (p.chroma ? 2 : 1); ch++) {
       Frame &f = L.fr[1];
       f.x = (int16_t) qx; f.y = (int16_t) qy; f.w = 64; f.h = 64; f.depth = 1; f.qt = 1; f.bt = 0; f.mt = 0; f.impl_bt = 0; f.last_split = SPLIT_QT; f.part_idx = (uint8_t) q;
-      walk_tree<T>(p, fd, cb, ch, tile, L.fr, 1, lv);
+      if (p.payload) walk_tree<T, true>(p, fd, cb, ch, tile, L.fr, 1, lv);     // CABACWriter::coding_tree_unit on the real coder
+      else walk_tree<T, false>(p, fd, cb, ch, tile, L.fr, 1, lv);
     }
   }
+}
+
+// slice_data writer of a (frame, tile) stream, thread 0.  Kept out of line so that the stream loop's register budget is not touched.
+// (plain ints, not the descriptor by reference: taking its address would move it - and every later use of it in the stream loop - to scratch memory)
+__device__ __noinline__ void writer_begin(const VxParams &p, int sidx, int done_before)      // resume where the last launch stopped
+{
+  L.aw_out = p.payload + p.payload_off[sidx]; L.aw_cap = p.payload_cap[sidx];
+  if (done_before == 0) arith_start(); else L.aw = ((const Arith *) p.arith_state)[sidx];
+}
+__device__ __noinline__ void writer_end_of_ctu(int lastOfTile, int lastTile)   // end_of_ctu (EL/CABACWriter.cpp:2118-2141), end of the brick (EL/EncSlice.cpp:1975-1990)
+{
+  if (!(lastOfTile && lastTile)) arith_trm(0);
+  if (lastOfTile) { arith_trm(1); arith_finish(); }
+}
+__device__ __noinline__ void writer_suspend(const VxParams &p, int sidx) { ((Arith *) p.arith_state)[sidx] = L.aw; }
+
+// The search of one tree of one CTU: thread 0 steps the mode controller, everybody executes the operation it posts.
+// Its own function: what is live across these calls (p, fd, scratch) fits the callee-saved registers; inlined into the
+// stream loop, the loop's bookkeeping was spilled to scratch around every operation.
+template <typename T>
+__device__ __noinline__ void run_tree(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
+{
+  const int tid = threadIdx.x;
+  // NOTE: exactly one thread-0 section per iteration.  With two (`if (tid == 0)` at the head and at the tail)
+  // hipcc threads the "tid != 0" edges together and structurizes the result into an inner loop in which lanes
+  // 1..63 of wave 0 reach the next s_barrier while lane 0 is still parked outside it: the barrier then
+  // releases before the controller has run (observed: hang).  Keep thread-0 work in ONE block here.
+  int prev_op = 13; long long t_prev = STAMP();
+  for (;;) {
+    if (tid == 0) {
+      const long long t0 = STAMP();
+      if (VVCX_STAMP) {
+        L.prof[prev_op] += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first)
+        if (prev_op >= OP_LUMA_PREP && prev_op <= OP_CHROMA_RD) L.prof[38 + imin(9, imax(0, ilog2i(L.nw * L.nh) - 4))] += (unsigned long long) (t0 - t_prev);   // by node size
+      }
+      control_step(p, fd, scratch);
+      t_prev = STAMP();
+      if (VVCX_STAMP) L.prof[0] += (unsigned long long) (t_prev - t0);
+    }
+    __syncthreads();
+    const int op = uni(L.op);
+    if (op == OP_DONE) break;
+    prev_op = op;
+    switch (op) {
+      case OP_LUMA_PREP: op_luma_prep<T>(p, fd); if (uni(L.op_c)) op_stage_a(p, scratch); break;
+      case OP_STAGE_A: op_stage_a(p, scratch); break;
+      case OP_STAGE_B: op_stage_b(p, scratch); break;
+      case OP_CHROMA_RD: op_chroma_rd<T>(p, fd, scratch); break;
+      case OP_SAVE_INTRA: op_save_intra(p, scratch, L.cu); break;
+      case OP_SAVE_PIC: op_save_pic<T>(p, fd, scratch, 0); break;
+      case OP_RESTORE_PIC: ctx_copy_all(ctx_ptr(scratch, L.op_a, L.op_c, 0), ctx_ptr(scratch, L.op_b, L.op_c, 0)); op_save_pic<T>(p, fd, scratch, 1); break;
+      case OP_CLEAR_UNITS: op_clear_units(p, fd); break;
+      case OP_CTX_COPY: ctx_copy_all(ctx_ptr(scratch, L.op_a, L.op_c, 0), ctx_ptr(scratch, L.op_b, L.op_c, 0)); __threadfence_block(); break;
+      case OP_REUSE: op_reuse<T>(p, fd, scratch); break;
+    }
+    __syncthreads();
+}
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
@@ -2224,7 +2382,10 @@ __device__ void run_stream(const VxParams &p)
   uint8_t *scratch = p.scratch + (size_t) blockIdx.x * p.scratch_per_stream;
   Ctx *carry = (Ctx *) (p.stream_ctx + (size_t) (sd.frame * p.ntiles + sd.tile) * 2 * NCTX);
   const int tid = threadIdx.x;
-  if (tid == 0) { L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < 48; i++) L.prof[i] = 0; }
+  if (tid == 0) {
+    L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < 48; i++) L.prof[i] = 0;
+    if (p.payload) writer_begin(p, sd.frame * p.ntiles + sd.tile, sd.done_before);
+  }
   load_tables();
   ctx_copy_all(&L.ctxs[CI_CUR], carry);
   __syncthreads();
@@ -2249,50 +2410,23 @@ __device__ void run_stream(const VxParams &p)
       }
       if (ch == 1) ctx_copy_all(&L.ctxs[CI_CUR], ctx_ptr(scratch, CTX_START, MAXD + NW, 0));     // EL/EncCu.cpp:521
       __syncthreads();
-      // NOTE: exactly one thread-0 section per iteration.  With two (`if (tid == 0)` at the head and at the tail)
-      // hipcc threads the "tid != 0" edges together and structurizes the result into an inner loop in which lanes
-      // 1..63 of wave 0 reach the next s_barrier while lane 0 is still parked outside it: the barrier then
-      // releases before the controller has run (observed: hang).  Keep thread-0 work in ONE block here.
-      int prev_op = 13; long long t_prev = STAMP();
-      for (;;) {
-        if (tid == 0) {
-          const long long t0 = STAMP();
-          if (VVCX_STAMP) {
-            L.prof[prev_op] += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first)
-            if (prev_op >= OP_LUMA_PREP && prev_op <= OP_CHROMA_RD) L.prof[38 + imin(9, imax(0, ilog2i(L.nw * L.nh) - 4))] += (unsigned long long) (t0 - t_prev);   // by node size
-          }
-          control_step(p, fd, scratch);
-          t_prev = STAMP();
-          if (VVCX_STAMP) L.prof[0] += (unsigned long long) (t_prev - t0);
-        }
-        __syncthreads();
-        const int op = uni(L.op);
-        if (op == OP_DONE) break;
-        prev_op = op;
-        switch (op) {
-          case OP_LUMA_PREP: op_luma_prep<T>(p, fd); if (uni(L.op_c)) op_stage_a(p, scratch); break;
-          case OP_STAGE_A: op_stage_a(p, scratch); break;
-          case OP_STAGE_B: op_stage_b(p, scratch); break;
-          case OP_CHROMA_RD: op_chroma_rd<T>(p, fd, scratch); break;
-          case OP_SAVE_INTRA: op_save_intra(p, scratch, L.cu); break;
-          case OP_SAVE_PIC: op_save_pic<T>(p, fd, scratch, 0); break;
-          case OP_RESTORE_PIC: ctx_copy_all(ctx_ptr(scratch, L.op_a, L.op_c, 0), ctx_ptr(scratch, L.op_b, L.op_c, 0)); op_save_pic<T>(p, fd, scratch, 1); break;
-          case OP_CLEAR_UNITS: op_clear_units(p, fd); break;
-          case OP_CTX_COPY: ctx_copy_all(ctx_ptr(scratch, L.op_a, L.op_c, 0), ctx_ptr(scratch, L.op_b, L.op_c, 0)); __threadfence_block(); break;
-          case OP_REUSE: op_reuse<T>(p, fd, scratch); break;
-        }
-        __syncthreads();
-      }
+      run_tree<T>(p, fd, scratch);
       if (tid == 0) { const Sum &b = L.fr[0].best; res.dist += b.dist; res.bits += b.bits; res.cost += b.cost; res.n_cu += b.n_cu; }
       __syncthreads();
     }
     // contexts back to the CTU start, then the estimator pass advances them (EL/EncCu.cpp:543, EL/EncSlice.cpp:1775-1776)
     ctx_copy_all(&L.ctxs[CI_CUR], ctx_ptr(scratch, CTX_START, MAXD + NW, 0));
     __syncthreads();
-    if (tid == 0) { const long long t0 = STAMP(); advance_ctx_ctu<T>(p, fd, sd.tile, ctu_x, ctu_y); L.prof[12] += (unsigned long long) (STAMP() - t0); p.results[sd.first_task + t] = res; }
+    if (tid == 0) {
+      const long long t0 = STAMP();
+      advance_ctx_ctu<T>(p, fd, sd.tile, ctu_x, ctu_y);
+      if (p.payload) writer_end_of_ctu(sd.done_before + t + 1 == sd.tile_ctus, sd.tile == p.ntiles - 1);
+      L.prof[12] += (unsigned long long) (STAMP() - t0); p.results[sd.first_task + t] = res;
+    }
     __syncthreads();
   }
   ctx_copy_all(carry, &L.ctxs[CI_CUR]);
+  if (tid == 0 && p.payload) writer_suspend(p, sd.frame * p.ntiles + sd.tile);
   if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); for (int i = 0; i < 48; i++) atomicAdd(&p.counters[4 + i], L.prof[i]); }
 }
 

@@ -23,7 +23,7 @@ class _Cfg(C.Structure):
     _fields_ = [("pic_w", C.c_int32), ("pic_h", C.c_int32), ("bit_depth", C.c_int32), ("ctu_size", C.c_int32),
                 ("min_qt", C.c_int32 * 2), ("max_bt_depth", C.c_int32 * 2), ("max_bt_size", C.c_int32 * 2),
                 ("max_tt_size", C.c_int32 * 2), ("dual_tree", C.c_int32), ("tile_cols", C.c_int32), ("tile_rows", C.c_int32),
-                ("tools", C.c_uint32), ("chroma", C.c_int32), ("max_frames", C.c_int32), ("device", C.c_int32)]
+                ("tools", C.c_uint32), ("chroma", C.c_int32), ("max_frames", C.c_int32), ("device", C.c_int32), ("emit_payload", C.c_int32)]
 
 
 class _Slice(C.Structure):
@@ -67,14 +67,24 @@ def load_library(lib_path=None):
     L.vvcx_get_profile.argtypes = [C.c_void_p, C.c_void_p]
     L.vvcx_last_error.restype = C.c_char_p
     L.vvcx_ctus_per_frame.argtypes = [C.c_void_p]
-    L.vvcx_resident_streams.argtypes = [C.c_void_p]
-    L.vvcx_distortion_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
-    L.vvcx_intra_pred_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p]
-    L.vvcx_ctx_init.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
-    L.vvcx_cabac_code_bins.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-    L.vvcx_rd_cost_batch.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-    L.vvcx_scan_order.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
-    L.vvcx_transform_quant_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    if hasattr(L, "vvcx_resident_streams"):
+        L.vvcx_resident_streams.argtypes = [C.c_void_p]
+    if hasattr(L, "vvcx_get_payload"):
+        L.vvcx_get_payload.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    if hasattr(L, "vvcx_distortion_batch"):
+        L.vvcx_distortion_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    if hasattr(L, "vvcx_intra_pred_batch"):
+        L.vvcx_intra_pred_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p]
+    if hasattr(L, "vvcx_ctx_init"):
+        L.vvcx_ctx_init.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    if hasattr(L, "vvcx_cabac_code_bins"):
+        L.vvcx_cabac_code_bins.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    if hasattr(L, "vvcx_rd_cost_batch"):
+        L.vvcx_rd_cost_batch.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    if hasattr(L, "vvcx_scan_order"):
+        L.vvcx_scan_order.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
+    if hasattr(L, "vvcx_transform_quant_batch"):
+        L.vvcx_transform_quant_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     _libs[path] = L
     return L
 
@@ -83,7 +93,7 @@ class VvcxEncoder:
     """≙ one EncCu instance (EL/EncCu.h:80-230): create/init → per-slice set-up → compressCtu calls → destroy."""
 
     def __init__(self, width, height, bit_depth=8, tile_cols=1, tile_rows=1, chroma=True, tools=TOOLS_DEFAULT,
-                 max_frames=1, device=0, lib_path=None):
+                 max_frames=1, device=0, lib_path=None, emit_payload=False):
         self.L = load_library(lib_path)
         c = _Cfg()
         c.pic_w, c.pic_h, c.bit_depth, c.ctu_size = width, height, bit_depth, 128
@@ -93,11 +103,19 @@ class VvcxEncoder:
         c.max_tt_size[0], c.max_tt_size[1] = 32, 32
         c.dual_tree, c.tile_cols, c.tile_rows, c.tools = 1, tile_cols, tile_rows, tools
         c.chroma, c.max_frames, c.device = int(chroma), max_frames, device
+        c.emit_payload = int(emit_payload)
         self.cfg = c
         self.h = C.c_void_p()
         self._chk(self.L.vvcx_create(C.byref(c), C.byref(self.h)))
         self.ctus_per_frame = self.L.vvcx_ctus_per_frame(self.h)
         self.n_frames = 0
+
+    def get_payload(self, frame, tile):
+        """slice_data() bytes of one coded tile (needs emit_payload=True)"""
+        cap = 1 << 22
+        buf = np.zeros(cap, np.uint8); n = C.c_int()
+        self._chk(self.L.vvcx_get_payload(self.h, frame, tile, buf.ctypes.data, cap, C.byref(n)))
+        return buf[:n.value].copy()
 
     def resident_streams(self):
         return int(self.L.vvcx_resident_streams(self.h))

@@ -127,3 +127,31 @@ def test_full_1080p_frame_matches_oracle():
     at 56 luma rows → implicit splits), bit-exact against the oracle (≈1 min of oracle time on one host core)."""
     W, H = 1920, 1080
     _check([pkg.synth_frame(W, H, 0, 8, 1000)], W, H, pkg.slice_params(32), tile_cols=15, tile_rows=9)
+
+
+def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted():
+    """Device writer (arithmetic coding of the final CTU syntax in the estimator pass) against tests/golden/bitstream.npz: payloads
+    that the reference's CABACReader parsed back into the coded CUs and levels when the fixture was generated."""
+    import os
+    import torch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bitstream.npz"))
+    off = 0
+    for (W, H, qp, tc, tr, bd, seed, nbytes), sizes in zip(g["pic_meta"], g["pic_sizes"]):
+        exp = g["pic_bytes"][off:off + nbytes]; off += int(nbytes)
+        W, H, bd = int(W), int(H), int(bd)
+        sp = pkg.slice_params(int(qp), bit_depth=bd)
+        planes = pkg.synth_frame(W, H, 0, bd, int(seed))
+        enc = pkg.VvcxEncoder(W, H, bd, tile_cols=int(tc), tile_rows=int(tr), emit_payload=True)
+        enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+        conv = [p if p.dtype == np.uint8 else p.view(np.int16) for p in planes]
+        org = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in conv]
+        rec = [torch.zeros_like(t) for t in org]
+        enc.bind_frames([([t.data_ptr() for t in org], [t.data_ptr() for t in rec], [t.shape[1] for t in org])])
+        if (W, H) == (256, 128):                           # CTU by CTU: the coder state persists between launches
+            enc.compress_ctus([(0, 0)]); enc.compress_ctus([(0, 1)])
+        else:
+            enc.compress_bound_frames()
+        got = np.concatenate([enc.get_payload(0, t) for t in range(int(tc) * int(tr))])
+        assert [len(enc.get_payload(0, t)) for t in range(int(tc) * int(tr))] == list(sizes[:int(tc) * int(tr)])
+        assert np.array_equal(got, exp), (W, H, qp, tc, tr, bd)
+        enc.close()

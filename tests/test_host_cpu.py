@@ -83,3 +83,20 @@ def test_device_code_on_cpu_emulator_matches_oracle(emu_so, w, h, chroma, tiles,
     assert all(np.array_equal(rec[c], oreco[c]) for c in range(3))
     assert np.array_equal(enc.counters(), ocnt)
     enc.close()
+
+
+def test_emulated_slice_data_writer_matches_oracle(emu_so):
+    """The device's bitstream pass (same sources on the CPU debug emulation) against the oracle's payload, whose format is pinned
+    through the reference decoder (tests/golden/make_golden.py bitstream)."""
+    w, h = 40, 24
+    planes = pkg.synth_frame(w, h, 0, 8, 7)
+    sp = pkg.slice_params(27)
+    payload, sizes, _, _ = O.write_frame(planes, w, h, sp)
+    enc = pkg.VvcxEncoder(w, h, 8, lib_path=emu_so, emit_payload=True)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    org = [np.ascontiguousarray(p) for p in planes]
+    rec = [np.zeros_like(p) for p in planes]
+    enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
+    enc.compress_bound_frames()
+    assert np.array_equal(enc.get_payload(0, 0), payload)
+    enc.close()
