@@ -121,6 +121,8 @@ struct Lds {
   int win_idx, win_wave;
   unsigned long long cu_bits;      // cu_pred_data + cu_residual bits of the winner (contexts left in wctx[0])
   unsigned long long cnt[4];
+  VxParams par; VxFrameDev fdv;     // launch parameters and the stream's picture record: read from here inside the out-of-line functions (a reference
+                                    // parameter to them is a generic pointer into the kernarg copy in scratch / into HBM: flat loads with full waits)
   Arith aw; uint8_t *aw_out; uint32_t aw_cap; int colm;      // bitstream pass: arithmetic coder, its output (HBM) and capacity; co-located luma mode of the chroma node
   unsigned long long prof[48];    // shader-clock ticks per operation kind (diagnostic, see vvcx_get_profile)
 };
@@ -732,8 +734,9 @@ __device__ int implicit_split(const VxParams &p, Frame &f, int ch)      // CL/Un
   f.impl_checked = 1; f.impl_split = (uint8_t) split;
   return split;
 }
-__device__ __noinline__ void can_split(const VxParams &p, int d_, int ch, int can[6])   // CL/UnitPartitioner.cpp:379-466
+__device__ __noinline__ void can_split(const VxParams &p_, int d_, int ch, int can[6])   // CL/UnitPartitioner.cpp:379-466
 {
+  const VxParams &p = L.par; (void) p_;
   Frame &f = L.fr[d_];                  // frames are addressed by level so that the accesses are LDS instructions, not generic-address ones
   const int impl = implicit_split(p, f, ch);
   const int maxBTD = p.max_bt_depth[ch] + f.impl_bt;
@@ -778,8 +781,9 @@ __device__ const VxUnit *get_cu(const VxParams &p, const VxFrameDev &fd, int ch,
 // Everything about a node that is fixed while it is processed — its left / above neighbour CUs, the canSplit() result
 // (CL/UnitPartitioner.cpp:379-466) and the split-flag context increments of DeriveCtx::CtxSplit
 // (CL/ContextModelling.cpp:154-250) — is derived once when the node is entered.
-__device__ __noinline__ void prepare_node(const VxParams &p, const VxFrameDev &fd, int d_, int ch, int tile)
+__device__ __noinline__ void prepare_node(const VxParams &p_, const VxFrameDev &fd_, int d_, int ch, int tile)
 {
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   Frame &f = L.fr[d_];
   const int sh = ch ? 1 : 0;
   // left and above CU records fetched together (one HBM/L2 round trip instead of dependent ones); x - 1 / y - 1 of an
@@ -1056,8 +1060,9 @@ __device__ int dc_value(const int16_t *top, const int16_t *left, int w, int h, i
 // the last sample of the nearest preceding available unit in scan order (bottom-left → top-right), or the
 // first sample of the first available unit when nothing precedes.  set layout: refs[set][0]=top, [1]=left.
 template <typename T>
-__device__ __noinline__ void build_refs(const VxParams &p, const VxFrameDev &fd, int comp, int x, int y, int w, int h, int tile, int nsets)
+__device__ __noinline__ void build_refs(const VxParams &p_, const VxFrameDev &fd_, int comp, int x, int y, int w, int h, int tile, int nsets)
 {
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int tid = threadIdx.x;
   comp = uni(comp); x = uni(x); y = uni(y); w = uni(w); h = uni(h); tile = uni(tile); nsets = uni(nsets);
   const int ch = comp ? 1 : 0;
@@ -1404,8 +1409,9 @@ __device__ Ctx *ctx_ptr(uint8_t *scratch, int which, int d, int wave)
 
 // OP_LUMA_PREP: stage the node's original luma tile and its reference samples (mrl 0,1,3) in LDS
 template <typename T>
-__device__ __noinline__ void op_luma_prep(const VxParams &p, const VxFrameDev &fd)
+__device__ __noinline__ void op_luma_prep(const VxParams &p_, const VxFrameDev &fd_)
 {
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int x = uni(L.nx), y = uni(L.ny), w = uni(L.nw), h = uni(L.nh);
   const long long ts = STAMP();
   const void *org = fd.org[0]; const int st = fd.stride[0];
@@ -1518,8 +1524,9 @@ __device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int 
   }
 }
 // OP_STAGE_A: SATD-stage cost of every candidate in L.cand[op_a .. op_b) (EL/IntraSearch.cpp:489-682), one wave per candidate
-__device__ __noinline__ void op_stage_a(const VxParams &p, uint8_t *scratch)
+__device__ __noinline__ void op_stage_a(const VxParams &p_, uint8_t *scratch)
 {
+  const VxParams &p = L.par; (void) p_;
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int w = uni(L.nw), h = uni(L.nh), P = w * h;
   const int c_end = uni(L.op_b);
@@ -1608,8 +1615,9 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     wave_sync();
   }
 }
-__device__ __noinline__ void op_stage_b(const VxParams &p, uint8_t *scratch)
+__device__ __noinline__ void op_stage_b(const VxParams &p_, uint8_t *scratch)
 {
+  const VxParams &p = L.par; (void) p_;
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int w = uni(L.nw), h = uni(L.nh);
   if (w * h <= BUF) stage_b_loop<true>(p, scratch, wave, lane, w, h); else stage_b_loop<false>(p, scratch, wave, lane, w, h);
@@ -1687,8 +1695,9 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
   }
 }
 template <typename T>
-__device__ __noinline__ void op_chroma_rd(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
+__device__ __noinline__ void op_chroma_rd(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int x = uni(L.nx) >> 1, y = uni(L.ny) >> 1, w = uni(L.nw) >> 1, h = uni(L.nh) >> 1, P = w * h;
   for (int c = 1; c <= 2; c++) {
@@ -1809,8 +1818,9 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
 // current neighbourhood (DecCu::xReconIntraQT), distortion and CU bits are recomputed from the node's start contexts.  Results are
 // left where stage B / the chroma search leave theirs (candidate 0, wave 0, slot 0), so the controller continues at PH_B_DONE.
 template <typename T>
-__device__ __noinline__ void op_reuse(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
+__device__ __noinline__ void op_reuse(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int ch = uni(L.tree_ch), bd = p.bit_depth;
   const int sh = ch ? 1 : 0;
@@ -1841,8 +1851,9 @@ __device__ __noinline__ void op_reuse(const VxParams &p, const VxFrameDev &fd, u
 
 // area copies between the picture (planes + unit map) and the level store / candidate slots
 template <typename T>
-__device__ __noinline__ void op_save_pic(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch, int restore)
+__device__ __noinline__ void op_save_pic(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch, int restore)
 {
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int ch = L.tree_ch, d = L.nd;
   const int x1 = imin(L.nx + L.nw, p.pic_w), y1 = imin(L.ny + L.nh, p.pic_h);
   uint8_t *lvl = scratch + VXD_OFF_STORE + (size_t) d * VXD_STORE_LEVEL;
@@ -1871,8 +1882,9 @@ __device__ __noinline__ void op_save_pic(const VxParams &p, const VxFrameDev &fd
   __syncthreads();
 }
 // winner of the intra check (slot B of wave L.win_wave) + its CU record → level store
-__device__ __noinline__ void op_save_intra(const VxParams &p, uint8_t *scratch, const VxUnit &cu)
+__device__ __noinline__ void op_save_intra(const VxParams &p_, uint8_t *scratch, const VxUnit &cu)
 {
+  const VxParams &p = L.par; (void) p_;
   const int ch = L.tree_ch, d = L.nd, sh = ch ? 1 : 0;
   const int W = L.nw >> sh, H = L.nh >> sh, P = W * H;
   uint8_t *lvl = scratch + VXD_OFF_STORE + (size_t) d * VXD_STORE_LEVEL;
@@ -1901,8 +1913,9 @@ __device__ __noinline__ void op_save_intra(const VxParams &p, uint8_t *scratch, 
   __threadfence_block();
   __syncthreads();
 }
-__device__ __noinline__ void op_clear_units(const VxParams &p, const VxFrameDev &fd)
+__device__ __noinline__ void op_clear_units(const VxParams &p_, const VxFrameDev &fd_)
 {
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int ch = L.tree_ch;
   const int x1 = imin(L.nx + L.nw, p.pic_w), y1 = imin(L.ny + L.nh, p.pic_h);
   const int ux0 = L.nx >> 2, uy0 = L.ny >> 2, ucw = ((x1 + 3) >> 2) - ux0, uch = ((y1 + 3) >> 2) - uy0;
@@ -1916,8 +1929,9 @@ __device__ __noinline__ void op_clear_units(const VxParams &p, const VxFrameDev 
 __device__ inline int mode_to_split(int m) { return m == ETM_SPLIT_QT ? SPLIT_QT : m == ETM_SPLIT_BT_H ? SPLIT_BH : m == ETM_SPLIT_BT_V ? SPLIT_BV : m == ETM_SPLIT_TT_H ? SPLIT_TH : m == ETM_SPLIT_TT_V ? SPLIT_TV : SPLIT_NONE; }
 
 // EncModeCtrlMTnoRQT::tryMode (EL/EncModeCtrl.cpp:1557-2068), I-slice subset
-__device__ __noinline__ int try_mode(const VxParams &p, int d_, int ch, int mode)
+__device__ __noinline__ int try_mode(const VxParams &p_, int d_, int ch, int mode)
 {
+  const VxParams &p = L.par; (void) p_;
   Frame &f = L.fr[d_];
   const int impl = implicit_split(p, f, ch);
   if (impl != SPLIT_NONE && mode != ETM_SPLIT_QT) return mode_to_split(mode) == impl;
@@ -1968,8 +1982,9 @@ __device__ int next_mode(const VxParams &p, int d_, int ch)
   while (f.nmodes > 0 && !try_mode(p, d_, ch, f.modes[f.nmodes - 1])) f.nmodes--;
   return f.nmodes > 0;
 }
-__device__ __noinline__ void init_cu_level(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch, int d, int ch, int tile)       // initCULevel 1203-1549
+__device__ __noinline__ void init_cu_level(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch, int d, int ch, int tile)       // initCULevel 1203-1549
 {
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   Frame &f = L.fr[d];
   prepare_node(p, fd, d, ch, tile);
   const int cuL = f.nb_ok & 1, cuA = f.nb_ok & 2, lq = f.nbL_qt, aq = f.nbA_qt;
@@ -2234,8 +2249,9 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
 // final estimator pass over the coded CTU (CABACWriter::coding_tree_unit 254-309 / coding_tree 474-984): advances
 // L.ctxs[CI_CUR] for the next CTU of the stream.  Thread 0 only.
 template <typename T, bool WR>
-__device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, Cab &cb, int ch, int tile, Frame *st_, int d, int16_t *lv)
+__device__ __noinline__ void walk_tree(const VxParams &p_, const VxFrameDev &fd_, Cab &cb, int ch, int tile, Frame *st_, int d, int16_t *lv)
 {
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   Frame *st = L.fr; (void) st_;
   // iterative pre-order walk with an explicit stack of frames st[d..]
   int top = d;
@@ -2298,8 +2314,9 @@ __device__ __noinline__ void walk_tree(const VxParams &p, const VxFrameDev &fd, 
   }
 }
 template <typename T>
-__device__ __noinline__ void advance_ctx_ctu(const VxParams &p, const VxFrameDev &fd, int tile, int ctu_x, int ctu_y)
+__device__ __noinline__ void advance_ctx_ctu(const VxParams &p_, const VxFrameDev &fd_, int tile, int ctu_x, int ctu_y)
 {
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   Cab cb; cb.ci = CI_CUR; cb.bits = 0;
   uint8_t *scratch_ = p.scratch + (size_t) blockIdx.x * p.scratch_per_stream;
   int16_t *lv = (int16_t *) (scratch_ + VXD_OFF_SLOTS);      // level tile (up to 64x64) and scan table of the estimator pass: wave 0's big-block scratch
@@ -2334,8 +2351,9 @@ __device__ __noinline__ void writer_suspend(const VxParams &p, int sidx) { ((Ari
 // Its own function: what is live across these calls (p, fd, scratch) fits the callee-saved registers; inlined into the
 // stream loop, the loop's bookkeeping was spilled to scratch around every operation.
 template <typename T>
-__device__ __noinline__ void run_tree(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
+__device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int tid = threadIdx.x;
   // NOTE: exactly one thread-0 section per iteration.  With two (`if (tid == 0)` at the head and at the tail)
   // hipcc threads the "tid != 0" edges together and structurizes the result into an inner loop in which lanes
@@ -2370,7 +2388,7 @@ __device__ __noinline__ void run_tree(const VxParams &p, const VxFrameDev &fd, u
       case OP_REUSE: op_reuse<T>(p, fd, scratch); break;
     }
     __syncthreads();
-}
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
@@ -2378,6 +2396,7 @@ template <typename T>
 __device__ void run_stream(const VxParams &p)
 {
   const VxStreamDesc sd = p.streams[blockIdx.x];
+  if (threadIdx.x == 0) { L.par = p; L.fdv = p.frames[sd.frame]; }
   const VxFrameDev &fd = p.frames[sd.frame];
   uint8_t *scratch = p.scratch + (size_t) blockIdx.x * p.scratch_per_stream;
   Ctx *carry = (Ctx *) (p.stream_ctx + (size_t) (sd.frame * p.ntiles + sd.tile) * 2 * NCTX);
@@ -2462,6 +2481,7 @@ __device__ void leaf_pred(const VxParams &p, const VxLeafPred *cases, int16_t *o
 {
   const VxFrameDev &fd = p.frames[0];
   const VxLeafPred c = cases[blockIdx.x];
+  if (threadIdx.x == 0) { L.par = p; L.fdv = p.frames[0]; }
   load_tables();
   if (threadIdx.x == 0) { L.cur_tile = 0; L.nx = c.x; L.ny = c.y; L.nw = c.w; L.nh = c.h; }
   __syncthreads();
