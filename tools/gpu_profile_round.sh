@@ -1,7 +1,7 @@
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01c
+O=$R/gpurun_out/r01d
 mkdir -p $O
 cd $R
 timeout -k 10 300 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1
