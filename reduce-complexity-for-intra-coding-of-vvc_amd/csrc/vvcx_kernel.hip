@@ -64,6 +64,7 @@ struct Frame {                     // one recursion level: partitioner level + C
   uint8_t nb_ok, nbL_lh, nbL_qt, nbA_lw, nbA_qt;   // left / above CU of the node (bit0 left, bit1 above present)
   uint8_t can_mask, ctx_spl, ctx_qt, ctx_hv;       // canSplit() bits {no,qt,bh,bv,th,tv} and split-flag context increments, fixed per node
   uint8_t reusing, r_dir, r_mrl, r_cbf;            // IS_REUSING_CU and the cached CU's mode data (BestEncInfoCache)
+  uint8_t ctx_dirty;                               // the estimator's contexts differ from the node's start snapshot (a split was carried out)
   int16_t px[4], py[4], pw[4], ph[4];
   uint64_t ss;
   double max_cost;
@@ -107,6 +108,7 @@ struct Lds {
   Frame fr[MAXD];
   // posted operation
   int op, op_a, op_b, op_c, op_d, op_ch;
+  int pre_copy_d;                  // >= 0: before the posted operation, snapshot the estimator's contexts as the start contexts of level pre_copy_d
   int nx, ny, nw, nh, nd;          // node of the posted op (luma coordinates) and its level
   // candidates
   Cand cand[64]; double cand_cost[64]; double cand_had[64]; int n_cand;
@@ -2049,8 +2051,9 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
       init_cu_level(p, fd, scratch, d, ch, tile);
       f.best.cost = MAX_DOUBLE; f.best.dist = 0; f.best.bits = 0; f.best.valid = 0;
       if (f.nmodes == 0) { f.phase = PH_EXIT2; break; }
-      f.phase = PH_RUN;
-      L.op_a = CTX_START; L.op_b = CTX_CUR; L.op_c = d; post(OP_CTX_COPY); return;     // m_CurrCtx->start = ctx
+      f.phase = PH_RUN; f.ctx_dirty = 0;
+      L.pre_copy_d = d;                                   // m_CurrCtx->start = ctx: done by the dispatch that runs the node's first operation
+      break;
     }
     case PH_RUN: {
       const int mode = f.modes[f.nmodes - 1];
@@ -2128,7 +2131,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
           case SPLIT_TH: f.nparts = 3; for (int i = 0; i < 3; i++) { f.px[i] = (int16_t) x; f.pw[i] = (int16_t) w; } f.ph[0] = f.ph[2] = (int16_t) (h >> 2); f.ph[1] = (int16_t) (h >> 1); f.py[0] = (int16_t) y; f.py[1] = (int16_t) (y + (h >> 2)); f.py[2] = (int16_t) (y + (h >> 2) + (h >> 1)); break;
           default:       f.nparts = 3; for (int i = 0; i < 3; i++) { f.py[i] = (int16_t) y; f.ph[i] = (int16_t) h; } f.pw[0] = f.pw[2] = (int16_t) (w >> 2); f.pw[1] = (int16_t) (w >> 1); f.px[0] = (int16_t) x; f.px[1] = (int16_t) (x + (w >> 2)); f.px[2] = (int16_t) (x + (w >> 2) + (w >> 1)); break;
         }
-        f.child = 0; f.first = 1;
+        f.child = 0; f.first = 1; f.ctx_dirty = 1;
         f.phase = PH_CHILD;
         post(OP_CLEAR_UNITS); return;          // tempCS->initStructData: nothing of this node is coded yet
       }
@@ -2233,6 +2236,8 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
     case PH_INTRA_SAVED: { f.phase = PH_ADVANCE; break; }
     case PH_ADVANCE: {                                  // ctx ← start (xCheckBestMode 721), next mode
       if (next_mode(p, d, ch)) f.phase = PH_RUN; else f.phase = PH_EXIT;
+      if (!f.ctx_dirty) break;                            // intra / pruned split: the estimator still holds the start contexts
+      f.ctx_dirty = 0;
       L.op_a = CTX_CUR; L.op_b = CTX_START; L.op_c = d; post(OP_CTX_COPY); return;
     }
     case PH_EXIT: {                                     // EL/EncCu.cpp:1533-1583
@@ -2367,12 +2372,14 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
         L.prof[prev_op] += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first)
         if (prev_op >= OP_LUMA_PREP && prev_op <= OP_CHROMA_RD) L.prof[38 + imin(9, imax(0, ilog2i(L.nw * L.nh) - 4))] += (unsigned long long) (t0 - t_prev);   // by node size
       }
+      L.pre_copy_d = -1;
       control_step(p, fd, scratch);
       t_prev = STAMP();
       if (VVCX_STAMP) L.prof[0] += (unsigned long long) (t_prev - t0);
     }
     __syncthreads();
     const int op = uni(L.op);
+    { const int pd = uni(L.pre_copy_d); if (pd >= 0) ctx_copy_all(ctx_ptr(scratch, CTX_START, pd, 0), &L.ctxs[CI_CUR]); }      // reads only; every operation leaves L.ctxs[CI_CUR] alone until its own barrier
     if (op == OP_DONE) break;
     prev_op = op;
     switch (op) {
