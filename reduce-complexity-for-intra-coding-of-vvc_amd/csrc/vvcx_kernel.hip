@@ -112,6 +112,7 @@ struct Lds {
   int nx, ny, nw, nh, nd;          // node of the posted op (luma coordinates) and its level
   // candidates
   Cand cand[64]; double cand_cost[64]; double cand_had[64]; int n_cand;
+  uint2 cand_ipa[64];              // prediction parameters of each SATD-stage candidate (initPredIntraParams), packed, derived once per operation
   Cand rd[16]; double rd_cost[16]; uint64_t rd_dist[16]; uint64_t rd_bits[16]; uint8_t rd_cbf[16]; int n_rd;
   int wave_best[NW], wave_slot[NW]; // candidate index of each wave's best and the slot that holds it
   CtlState S; VxUnit cu;           // controller working set; CU record of the intra candidate being evaluated
@@ -975,6 +976,18 @@ __device__ void init_pred_params(int w, int h, int is_luma, int mode, int mrl, I
     if (diff > L.t.intra_thr[log2Size]) { const int is_int = (absAng & 0x1F) == 0; p.ref_filter = is_int; p.interp = !is_int; }
   }
 }
+__device__ inline uint2 ipa_pack(const Ipa &p)
+{
+  uint2 r;
+  r.x = (unsigned) p.pred_mode | ((unsigned) p.is_ver << 8) | ((unsigned) p.mrl << 9) | ((unsigned) p.ref_filter << 11) | ((unsigned) p.interp << 12) | ((unsigned) p.pdpc << 13) | ((unsigned) (p.ang_scale + 1) << 14);
+  r.y = ((unsigned) p.angle & 0xffffu) | ((unsigned) p.inv_angle << 16);
+  return r;
+}
+__device__ inline void ipa_unpack(uint2 r, Ipa &p)
+{
+  p.pred_mode = (int) (r.x & 255); p.is_ver = (int) ((r.x >> 8) & 1); p.mrl = (int) ((r.x >> 9) & 3); p.ref_filter = (int) ((r.x >> 11) & 1); p.interp = (int) ((r.x >> 12) & 1);
+  p.pdpc = (int) ((r.x >> 13) & 1); p.ang_scale = (int) ((r.x >> 14) & 7) - 1; p.angle = (int) (int16_t) (r.y & 0xffffu); p.inv_angle = (int) (r.y >> 16);
+}
 __device__ inline int clip_bd(int v, int bd) { const int mx = (1 << bd) - 1; return v < 0 ? 0 : v > mx ? mx : v; }
 
 // one predicted sample.  top[i] = pSrc.at(i,0), left[i] = pSrc.at(0,i) of the (un)filtered reference
@@ -1449,7 +1462,7 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
     const int c = c0 + sub;
     const bool valid = c < c_end;
     const int mode = valid ? L.cand[c].mode : 0, mrl = valid ? L.cand[c].mrl : 0;
-    Ipa ip; init_pred_params(BW, BH, 1, mode, mrl, ip);
+    Ipa ip; ipa_unpack(L.cand_ipa[valid ? c : 0], ip);
     const int set = luma_set(mrl, ip.ref_filter);
     pred[lane] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], BW, BH, px, py, ip, mode, 1, bd, L.dc_val[luma_set(mrl, 0)]);
     wave_sync();
@@ -1505,7 +1518,7 @@ __device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int 
   int step = 0;
   for (int c = uni(L.op_a) + wave; c < c_end; c += NW, step++) {
     const int mode = uni(L.cand[c].mode), mrl = uni(L.cand[c].mrl);
-    Ipa ip; init_pred_params(w, h, 1, mode, mrl, ip);
+    Ipa ip; { uint2 pk = L.cand_ipa[c]; pk.x = (unsigned) uni((int) pk.x); pk.y = (unsigned) uni((int) pk.y); ipa_unpack(pk, ip); }
     const int set = luma_set(mrl, ip.ref_filter);
     const int16_t *top = L.refs[set][0], *left = L.refs[set][1];
     const int dcv = L.dc_val[luma_set(mrl, 0)];
@@ -1532,6 +1545,8 @@ __device__ __noinline__ void op_stage_a(const VxParams &p_, uint8_t *scratch)
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int w = uni(L.nw), h = uni(L.nh), P = w * h;
   const int c_end = uni(L.op_b);
+  { const int c = uni(L.op_a) + (int) threadIdx.x; if (c < c_end) { Ipa ip; init_pred_params(w, h, 1, L.cand[c].mode, L.cand[c].mrl, ip); L.cand_ipa[c] = ipa_pack(ip); } }
+  __syncthreads();
   if (P <= 32) {
     if (w == 4 && h == 4) stage_a_small<4, 4>(p, wave, lane, uni(L.op_a), c_end);
     else if (w == 8) stage_a_small<8, 4>(p, wave, lane, uni(L.op_a), c_end);

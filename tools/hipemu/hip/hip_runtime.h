@@ -22,6 +22,7 @@
 #define __noinline__ __attribute__((noinline))
 #define __forceinline__ inline
 
+struct uint2 { unsigned x, y; };
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 
 namespace hipemu {
