@@ -114,6 +114,11 @@ void orc_init_pred_params(int w, int h, int is_luma, int mode, int mrl, orc_ipa 
 void orc_cg_shape(int w, int h, int *lcw, int *lch);
 void orc_satd_tile_shape(int w, int h, int *bw, int *bh);
 const int8_t *orc_tr_matrix(int tr, int n);
+/* CCLM (orc_leaf.c) */
+void orc_cclm_luma(const int16_t *recY, int strideY, const uint8_t *avail, int avail_stride, int tag, int pic_wc, int pic_hc,
+                   int cx, int cy, int cw, int ch, int mdlm, int info[4], int16_t *tmp, int tstride);
+void orc_cclm_params(const int16_t *tmp, int tstride, const int16_t *ref, int cw, int ch, int mode, const int info[4], int bit_depth, int *pa, int *pb, int *pshift);
+void orc_pred_cclm(const int16_t *tmp, int tstride, int a, int b, int shift, int bit_depth, int cw, int ch, int16_t *pred, int pstride);
 /* residual_coding on the estimator (orc_rate.c) */
 void orc_residual_coding(orc_cabac *c, const int16_t *level, int w, int h, int is_chroma);
 

@@ -607,6 +607,143 @@ int orc_scan_order(int w, int h, uint16_t *idx)
   return n;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * CCLM (CL/IntraPrediction.cpp): 4:2:0, sps_cclm_colocated_chroma_flag = 0.
+ * orc_cclm_luma      = xGetLumaRecPixels 1665-1930: down-sampled reconstructed luma of the chroma block plus, where
+ *                      available, one row above / one column left (extended by the available above-right / below-left
+ *                      units when mdlm).  tmp origin = tmp[tstride + 1]; info = {leftAvail, aboveAvail, availLeftBelowUnits,
+ *                      availAboveRightUnits}; availability on the chroma tree (isLeft/Above/BelowLeft/AboveRightAvailable 1524-1663).
+ * orc_cclm_params    = xGetLMParameters 1931-2150 (ref = the block's unfiltered chroma reference samples, layout of
+ *                      orc_fill_ref_samples with mrl 0).
+ * orc_pred_cclm      = predIntraChromaLM 400-420 (linearTransform with clipping).
+ * ---------------------------------------------------------------------------------------------- */
+void orc_cclm_luma(const int16_t *recY, int strideY, const uint8_t *avail, int avail_stride, int tag, int pic_wc, int pic_hc,
+                   int cx, int cy, int cw, int ch, int mdlm, int info[4], int16_t *tmp, int tstride)
+{
+  const int unit = 2;                                    /* chroma samples per 4x4 luma unit */
+  const int aboveUnits = cw / unit, leftUnits = ch / unit;
+  const int totalAbove = (2 * cw + unit - 1) / unit, totalLeft = (2 * ch + unit - 1) / unit;
+  const int aboveRightUnits = totalAbove - aboveUnits, leftBelowUnits = totalLeft - leftUnits;
+  int n = 0;
+  for (int dy = 0; dy < leftUnits * unit; dy += unit) { if (!unit_avail(avail, avail_stride, 1, pic_wc, pic_hc, cx - 1, cy + dy, tag)) break; n++; }
+  const int leftAvail = n == leftUnits;
+  n = 0;
+  for (int dx = 0; dx < aboveUnits * unit; dx += unit) { if (!unit_avail(avail, avail_stride, 1, pic_wc, pic_hc, cx + dx, cy - 1, tag)) break; n++; }
+  const int aboveAvail = n == aboveUnits;
+  int availLB = 0, availAR = 0;
+  if (leftAvail) for (int dy = 0; dy < leftBelowUnits * unit; dy += unit) { if (!unit_avail(avail, avail_stride, 1, pic_wc, pic_hc, cx - 1, cy + ch - 1 + unit + dy, tag)) break; availLB++; }
+  if (aboveAvail) for (int dx = 0; dx < aboveRightUnits * unit; dx += unit) { if (!unit_avail(avail, avail_stride, 1, pic_wc, pic_hc, cx + cw - 1 + unit + dx, cy - 1, tag)) break; availAR++; }
+  info[0] = leftAvail; info[1] = aboveAvail; info[2] = availLB; info[3] = availAR;
+  const int16_t *src0 = recY + (size_t) (2 * cy) * strideY + 2 * cx;
+  const int S = strideY, S2 = 2 * strideY;
+  int16_t *dst0 = tmp + tstride + 1;
+  const int firstRowOfCtu = (cy & 63) == 0;
+  if (aboveAvail) {
+    int16_t *d = dst0 - tstride;
+    const int added = mdlm ? availAR * unit : 0;
+    for (int i = 0; i < cw + added; i++) {
+      if (firstRowOfCtu) {
+        const int16_t *q = src0 - S;
+        if (i == 0 && !leftAvail) d[i] = q[2 * i];
+        else d[i] = (int16_t) ((q[2 * i] * 2 + q[2 * i - 1] + q[2 * i + 1] + 2) >> 2);
+      } else {
+        const int16_t *q = src0 - S2;
+        if (i == 0 && !leftAvail) d[i] = (int16_t) ((q[2 * i] + q[2 * i + S] + 1) >> 1);
+        else d[i] = (int16_t) ((q[2 * i] * 2 + q[2 * i - 1] + q[2 * i + 1] + q[2 * i + S] * 2 + q[2 * i - 1 + S] + q[2 * i + 1 + S] + 4) >> 3);
+      }
+    }
+  }
+  if (leftAvail) {
+    int16_t *d = dst0 - 1;
+    const int16_t *q = src0 - 3;
+    const int added = mdlm ? availLB * unit : 0;
+    for (int j = 0; j < ch + added; j++) {
+      d[0] = (int16_t) ((q[1] * 2 + q[0] + q[2] + q[1 + S] * 2 + q[S] + q[2 + S] + 4) >> 3);
+      q += S2; d += tstride;
+    }
+  }
+  for (int j = 0; j < ch; j++) {
+    const int16_t *q = src0 + (size_t) j * S2; int16_t *d = dst0 + (size_t) j * tstride;
+    for (int i = 0; i < cw; i++) {
+      if (i == 0 && !leftAvail) d[i] = (int16_t) ((q[2 * i] + q[2 * i + S] + 1) >> 1);
+      else d[i] = (int16_t) ((q[2 * i] * 2 + q[2 * i + 1] + q[2 * i - 1] + q[2 * i + S] * 2 + q[2 * i + 1 + S] + q[2 * i - 1 + S] + 4) >> 3);
+    }
+  }
+}
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+static int floor_log2(unsigned v) { int r = 0; while (v > 1) { v >>= 1; r++; } return r; }
+void orc_cclm_params(const int16_t *tmp, int tstride, const int16_t *ref, int cw, int ch, int mode, const int info[4], int bit_depth, int *pa, int *pb, int *pshift)
+{
+  const int unit = 2;
+  int leftAvail = info[0], aboveAvail = info[1], availLB = info[2], availAR = info[3];
+  const int availAbove = aboveAvail ? cw / unit : 0, availLeft = leftAvail ? ch / unit : 0;
+  const int16_t *src0 = tmp + tstride + 1;
+  const int rstride = 2 * cw + 1;                       /* chroma reference buffer: top[i] = ref[i], left[i] = ref[i * rstride] */
+  int actualTop = 0, actualLeft = 0;
+  if (mode == 69) { leftAvail = 0; if (availAR > ch / unit) availAR = ch / unit; actualTop = unit * (availAbove + availAR); }           /* MDLM_T */
+  else if (mode == 68) { aboveAvail = 0; if (availLB > cw / unit) availLB = cw / unit; actualLeft = unit * (availLeft + availLB); }      /* MDLM_L */
+  else { actualTop = cw; actualLeft = ch; }
+  const int aboveIs4 = leftAvail ? 0 : 1, leftIs4 = aboveAvail ? 0 : 1;
+  const int startT = actualTop >> (2 + aboveIs4), stepT = imax(1, actualTop >> (1 + aboveIs4));
+  const int startL = actualLeft >> (2 + leftIs4), stepL = imax(1, actualLeft >> (1 + leftIs4));
+  int selL[4] = { 0, 0, 0, 0 }, selC[4] = { 0, 0, 0, 0 };
+  int cntT = 0, cntL = 0, cnt = 0;
+  if (aboveAvail) {
+    cntT = imin(actualTop, (1 + aboveIs4) << 1);
+    for (int pos = startT; cnt < cntT; pos += stepT, cnt++) { selL[cnt] = src0[-tstride + pos]; selC[cnt] = ref[1 + pos]; }
+  }
+  if (leftAvail) {
+    cntL = imin(actualLeft, (1 + leftIs4) << 1);
+    int pos = startL;
+    for (int k = 0; k < cntL; pos += stepL, k++) { selL[k + cntT] = src0[pos * tstride - 1]; selC[k + cntT] = ref[(1 + pos) * rstride]; }
+  }
+  cnt = cntL + cntT;
+  if (cnt == 2) {
+    selL[3] = selL[0]; selC[3] = selC[0]; selL[2] = selL[1]; selC[2] = selC[1];
+    selL[0] = selL[1]; selC[0] = selC[1]; selL[1] = selL[3]; selC[1] = selC[3];
+  }
+  int minG[2] = { 0, 2 }, maxG[2] = { 1, 3 };
+  int *tmin = minG, *tmax = maxG;
+#define SWAPI(a_, b_) { int t_ = (a_); (a_) = (b_); (b_) = t_; }
+  if (selL[tmin[0]] > selL[tmin[1]]) SWAPI(tmin[0], tmin[1]);
+  if (selL[tmax[0]] > selL[tmax[1]]) SWAPI(tmax[0], tmax[1]);
+  if (selL[tmin[0]] > selL[tmax[1]]) { int *t_ = tmin; tmin = tmax; tmax = t_; }
+  if (selL[tmin[1]] > selL[tmax[0]]) SWAPI(tmin[1], tmax[0]);
+#undef SWAPI
+  const int minL = (selL[tmin[0]] + selL[tmin[1]] + 1) >> 1, minC = (selC[tmin[0]] + selC[tmin[1]] + 1) >> 1;
+  const int maxL = (selL[tmax[0]] + selL[tmax[1]] + 1) >> 1, maxC = (selC[tmax[0]] + selC[tmax[1]] + 1) >> 1;
+  int a, b, shift;
+  if (leftAvail || aboveAvail) {
+    const int diff = maxL - minL;
+    if (diff > 0) {
+      static const uint8_t DivSigTable[16] = { 0, 7, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1, 1, 1, 0 };
+      const int diffC = maxC - minC;
+      int x = floor_log2((unsigned) diff);
+      const int normDiff = ((diff << 4) >> x) & 15;
+      const int v = DivSigTable[normDiff] | 8;
+      x += normDiff != 0;
+      const int y = floor_log2((unsigned) abs(diffC)) + 1;     /* floorLog2(0) = -1 in the reference: see below */
+      const int yy = diffC == 0 ? 0 : y;
+      const int add = (1 << yy) >> 1;
+      a = (diffC * v + add) >> yy;
+      shift = 3 + x - yy;
+      if (shift < 1) { shift = 1; a = a == 0 ? 0 : a < 0 ? -15 : 15; }
+      b = minC - ((a * minL) >> shift);
+    } else { a = 0; b = minC; shift = 0; }
+  } else { a = 0; b = 1 << (bit_depth - 1); shift = 0; }
+  *pa = a; *pb = b; *pshift = shift;
+}
+void orc_pred_cclm(const int16_t *tmp, int tstride, int a, int b, int shift, int bit_depth, int cw, int ch, int16_t *pred, int pstride)
+{
+  const int16_t *src0 = tmp + tstride + 1;
+  const int mx = (1 << bit_depth) - 1;
+  for (int j = 0; j < ch; j++) for (int i = 0; i < cw; i++) {
+    int v = ((a * src0[j * tstride + i]) >> shift) + b;           /* AreaBuf::linearTransform, CL/Buffer.cpp:699 */
+    pred[j * pstride + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v);
+  }
+}
+
 /* test hook: the arithmetic coder over a sequence of operations from the I-slice contexts at qp (see ref_arith_encode in
  * ref_harness.cpp): ops[i] = {kind, a, b}: 0 = context bin (ctx a, bin b); 1 = b bypass bins of value a; 2 = terminating bin a */
 int orc_arith_encode(int qp, const int32_t *ops, int nops, uint8_t *out, int cap)

@@ -88,7 +88,7 @@ struct orc_enc {
 /* ------------------------------------------------------------------------------------------------ */
 orc_enc *orc_create(const orc_cfg *cfg)
 {
-  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (P0 = MRL, CU reuse)", cfg->tools); return 0; }
+  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, CU reuse, CCLM)", cfg->tools); return 0; }
   if (!cfg->dual_tree || cfg->ctu_size != 128) { snprintf(g_err, sizeof g_err, "oracle: only DualITree=1, CTUSize=128"); return 0; }
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7)) { snprintf(g_err, sizeof g_err, "oracle: picture size must be a multiple of 8 (EncAppCfg.cpp:2709)"); return 0; }
   orc_enc *e = (orc_enc *) calloc(1, sizeof *e);
@@ -422,10 +422,33 @@ static void chroma_cand_modes(const orc_enc *e, area_t a, int list[8])
   const int lm = colocated_luma_mode(e, a);
   for (int i = 0; i < 4; i++) if (lm == list[i]) { list[i] = ORC_VDIA; break; }
 }
-/* CABACWriter::intra_chroma_pred_mode (1891-1933), CCLM off */
-static void enc_intra_chroma_pred_mode(orc_enc *e, area_t a, int dir)
+/* CodingUnit::checkCCLMAllowed (CL/Unit.cpp:375-449) for a chroma-tree CU of a dual-tree I slice, CTU 128: decided by the splits of
+ * the 64x64 chroma node (depths 1, 2 of the CU's split series) and of the co-located 64x64 luma node */
+static int cclm_allowed(const orc_enc *e, area_t a, uint64_t ss, int depth)
+{
+  if (!(e->cfg.tools & ORC_TOOL_CCLM)) return 0;
+  const int s1 = depth > 1 ? (int) ((ss >> 5) & 31) : SPLIT_NONE, s2 = depth > 2 ? (int) ((ss >> 10) & 31) : SPLIT_NONE;
+  int allow = s1 == SPLIT_QT || (s1 == SPLIT_BH && s2 == SPLIT_BV) || s1 == SPLIT_NONE || (s1 == SPLIT_BH && s2 == SPLIT_NONE);
+  if (allow) {
+    const unit_t *u = &e->um[0][(a.y >> 2) * e->uw + (a.x >> 2)];      /* colLumaCu at the CU's luma position */
+    if (u->lw < 6 || u->lh < 6) { const int l1 = u->depth > 1 ? (int) ((u->split_series >> 5) & 31) : SPLIT_NONE; if (l1 != SPLIT_QT) allow = 0; }
+  }
+  return allow;
+}
+/* CABACWriter::intra_chroma_pred_mode (1891-1933) + intra_chroma_lmc_mode (1864-1888) */
+static void enc_intra_chroma_pred_mode(orc_enc *e, area_t a, int dir, int lm_ok)
 {
   orc_cabac *c = &e->cabac;
+  if (lm_ok) {
+    const int isLM = dir >= 67 && dir <= 69;
+    orc_enc_bin(c, (unsigned) isLM, ORC_CTX_CclmModeFlag);
+    if (isLM) {
+      const int symbol = dir - 67;
+      orc_enc_bin(c, symbol == 0 ? 0 : 1, ORC_CTX_IntraChromaPredMode);
+      if (symbol > 0) orc_enc_bins_ep(c, (uint32_t) (symbol - 1), 1);
+      return;
+    }
+  }
   const int isDM = dir == ORC_DM_CHROMA;
   orc_enc_bin(c, isDM ? 0 : 1, ORC_CTX_IntraChromaPredMode);
   if (isDM) return;
@@ -590,23 +613,67 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
 
 /* estIntraPredChromaQT (1382-1686) + xRecurIntraChromaCodingQT (3779-4207), CCLM/JCCR off.
  * a in luma samples.  Winner left in best_rec[0..1]/best_lev[0..1] (Cb,Cr; stride cw). */
-static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int *out_dir, int *out_cbf)
+#define CCLM_TSTRIDE 130
+/* prediction of one chroma component into e->pred (stride cw): regular mode fm, or CCLM mode (67..69) from the down-sampled luma in tmp */
+static void pred_chroma_comp(orc_enc *e, int c, int cx, int cy, int cw, int chh, int fm, const int16_t *tmp, const int info[4])
 {
-  const int cx = a.x >> 1, cy = a.y >> 1, cw = a.w >> 1, chh = a.h >> 1, bd = e->cfg.bit_depth;
+  const int bd = e->cfg.bit_depth;
+  build_refs(e, c, cx, cy, cw, chh, 0, 0);
+  if (fm >= 67 && fm <= 69) {
+    int a_, b_, sh_;
+    orc_cclm_params(tmp, CCLM_TSTRIDE, e->ref_unf, cw, chh, fm, info, bd, &a_, &b_, &sh_);
+    orc_pred_cclm(tmp, CCLM_TSTRIDE, a_, b_, sh_, bd, cw, chh, e->pred, cw);
+  } else orc_pred_intra(e->ref_unf, e->ref_flt, cw, chh, 0, fm, 0, bd, e->pred, cw);
+}
+static void cclm_luma(orc_enc *e, int cx, int cy, int cw, int chh, int mdlm, int16_t *tmp, int info[4])
+{
+  orc_cclm_luma(e->rec[0], e->stride[0], e->avail[1], e->uw, e->cur_tile + 1, e->wc, e->hc, cx, cy, cw, chh, mdlm, info, tmp, CCLM_TSTRIDE);
+}
+static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int lm_ok, int *out_dir, int *out_cbf)
+{
+  const int cx = a.x >> 1, cy = a.y >> 1, cw = a.w >> 1, chh = a.h >> 1;
   orc_cabac ctxStart; orc_ctx_copy(&ctxStart, &e->cabac);
   int cand[8]; chroma_cand_modes(e, a, cand);
   double bestCost = ORC_MAX_DOUBLE; uint64_t bestDist = 0; int bestMode = 0, bestCbf = 0;
   int16_t *rec2[2], *lev2[2];
   rec2[0] = e->tmp_rec[0]; rec2[1] = e->tmp_rec[1]; lev2[0] = e->tmp_lev[0]; lev2[1] = e->tmp_lev[1];
+  static int16_t tmpLM[CCLM_TSTRIDE * CCLM_TSTRIDE], tmpMD[CCLM_TSTRIDE * CCLM_TSTRIDE];
+  int infoLM[4] = { 0, 0, 0, 0 }, infoMD[4] = { 0, 0, 0, 0 };
+  uint8_t enabled[71]; memset(enabled, 1, sizeof enabled);
+  if (lm_ok) {
+    /* SATD pre-selection (1479-1582): regular modes except planar and the two MDLM modes are ranked by SATD(Cb) + SATD(Cr); the exchange
+     * sort below is the reference's (not stable); the two last entries are dropped from the RD loop */
+    cclm_luma(e, cx, cy, cw, chh, 0, tmpLM, infoLM); cclm_luma(e, cx, cy, cw, chh, 1, tmpMD, infoMD);
+    int list[8]; int64_t cost[8];
+    for (int i = 0; i < 8; i++) { list[i] = 0; cost[i] = 0; }
+    for (int idx = 0; idx <= 6; idx++) {
+      const int mode = cand[idx];
+      list[idx] = mode;
+      if (mode == 67 || mode == ORC_PLANAR || mode == ORC_DM_CHROMA) continue;
+      int64_t sad = 0;
+      for (int c = 1; c <= 2; c++) {
+        pred_chroma_comp(e, c, cx, cy, cw, chh, mode, tmpMD, infoMD);
+        sad += (int64_t) orc_satd(e->org[c] + cy * e->stride[c] + cx, e->stride[c], e->pred, cw, cw, chh);
+        e->cnt_satd++;
+      }
+      cost[idx] = sad;
+    }
+    for (int i = 0; i <= 6; i++) for (int j = i + 1; j <= 6; j++) if (cost[j] < cost[i]) {
+      const int tm = list[i]; list[i] = list[j]; list[j] = tm;
+      const int64_t tc = cost[i]; cost[i] = cost[j]; cost[j] = tc;
+    }
+    enabled[list[6]] = 0; enabled[list[5]] = 0;
+  }
   for (int k = 0; k < 8; k++) {
     const int cm = cand[k];
-    if (cm >= 67 && cm <= 69) continue;                       /* LM modes not enabled (1588-1591) */
+    const int isLM = cm >= 67 && cm <= 69;
+    if (isLM && !lm_ok) continue;                              /* 1588-1591 */
+    if (lm_ok && !enabled[cm]) continue;                       /* 1592-1595 */
     orc_ctx_copy(&e->cabac, &ctxStart);
     const int fm = cm == ORC_DM_CHROMA ? colocated_luma_mode(e, a) : cm;   /* PU::getFinalIntraMode 921 */
     int cbf[2]; uint64_t dist = 0;
     for (int c = 1; c <= 2; c++) {
-      build_refs(e, c, cx, cy, cw, chh, 0, 0);
-      orc_pred_intra(e->ref_unf, e->ref_flt, cw, chh, 0, fm, 0, bd, e->pred, cw);
+      pred_chroma_comp(e, c, cx, cy, cw, chh, fm, cm == 67 ? tmpLM : tmpMD, cm == 67 ? infoLM : infoMD);
       dist += code_tu_block(e, c, cx, cy, cw, chh, rec2[c - 1], lev2[c - 1], &cbf[c - 1]);
       /* xGetIntraFracBitsQTChroma (2625-2692): contexts advance, bits only feed per-component costs */
       orc_enc_bin(&e->cabac, (unsigned) cbf[c - 1], ORC_CTX_QtCbf[c] + (c == 2 ? cbf[0] : 0));
@@ -614,7 +681,7 @@ static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int *out_dir, int *o
     }
     /* 1611-1621: contexts are NOT reset (transform skip off); xGetIntraFracBitsQT(chroma) */
     e->cabac.bits = 0;
-    enc_intra_chroma_pred_mode(e, a, cm);
+    enc_intra_chroma_pred_mode(e, a, cm, lm_ok);
     orc_enc_bin(&e->cabac, (unsigned) cbf[0], ORC_CTX_QtCbf[1] + 0);
     orc_enc_bin(&e->cabac, (unsigned) cbf[1], ORC_CTX_QtCbf[2] + cbf[0]);
     if (cbf[0]) orc_residual_coding(&e->cabac, lev2[0], cw, chh, 1);
@@ -844,9 +911,10 @@ static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *ou
   } else {
     const int cx = a.x >> 1, cy = a.y >> 1, cw = a.w >> 1, chh = a.h >> 1;
     const int fm = c->dir == ORC_DM_CHROMA ? colocated_luma_mode(e, a) : c->dir;
+    static int16_t tmpC[CCLM_TSTRIDE * CCLM_TSTRIDE]; int infoC[4] = { 0, 0, 0, 0 };
+    if (fm >= 67 && fm <= 69) cclm_luma(e, cx, cy, cw, chh, fm != 67, tmpC, infoC);
     for (int k = 1; k <= 2; k++) {
-      build_refs(e, k, cx, cy, cw, chh, 0, 0);
-      orc_pred_intra(e->ref_unf, e->ref_flt, cw, chh, 0, fm, 0, bd, e->pred, cw);
+      pred_chroma_comp(e, k, cx, cy, cw, chh, fm, tmpC, infoC);
       dist += recon_from_levels(e, k, cx, cy, cw, chh, c->lev + (size_t) (k - 1) * cw * chh, (c->cbf >> k) & 1, e->best_rec[k - 1]);
       memcpy(e->best_lev[k - 1], c->lev + (size_t) (k - 1) * cw * chh, (size_t) cw * chh * 2);
     }
@@ -866,7 +934,7 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
   int dir = 0, mrl = 0, cbf = 0;
   if (reuse) t.dist = reuse_cached(e, a, ch, &dir, &mrl, &cbf);
   else if (!ch) t.dist = est_intra_pred_luma(e, a, &dir, &mrl, &cbf), cbf = cbf ? 1 : 0;
-  else t.dist = est_intra_pred_chroma(e, a, &dir, &cbf);
+  else t.dist = est_intra_pred_chroma(e, a, cclm_allowed(e, a, cu.split_series, cu.depth), &dir, &cbf);
   cu.dir = (uint8_t) dir; cu.mrl = (uint8_t) mrl; cu.cbf = (uint8_t) cbf;
   /* CU-level rate from the node's start contexts (2593-2620) */
   e->cabac.bits = 0;
@@ -875,7 +943,7 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
     orc_enc_bin(&e->cabac, (unsigned) (cbf & 1), ORC_CTX_QtCbf[0]);
     if (cbf & 1) orc_residual_coding(&e->cabac, e->best_lev[0], a.w, a.h, 0);
   } else {
-    enc_intra_chroma_pred_mode(e, a, dir);
+    enc_intra_chroma_pred_mode(e, a, dir, cclm_allowed(e, a, cu.split_series, cu.depth));
     orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 2), ORC_CTX_QtCbf[1]);
     orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 4), ORC_CTX_QtCbf[2] + !!(cbf & 2));
     if (cbf & 2) orc_residual_coding(&e->cabac, e->best_lev[0], a.w >> 1, a.h >> 1, 1);
@@ -1004,7 +1072,7 @@ static void walk_tree(orc_enc *e, partitioner *P)
     orc_enc_bin(&e->cabac, u->cbf & 1, ORC_CTX_QtCbf[0]);
     if (u->cbf & 1) { for (int y = 0; y < H; y++) memcpy(lv + y * W, e->lev[0] + (a.y + y) * e->stride[0] + a.x, (size_t) W * 2); orc_residual_coding(&e->cabac, lv, W, H, 0); }
   } else {
-    enc_intra_chroma_pred_mode(e, a, u->dir);
+    enc_intra_chroma_pred_mode(e, a, u->dir, cclm_allowed(e, a, u->split_series, u->depth));
     orc_enc_bin(&e->cabac, !!(u->cbf & 2), ORC_CTX_QtCbf[1]);
     orc_enc_bin(&e->cabac, !!(u->cbf & 4), ORC_CTX_QtCbf[2] + !!(u->cbf & 2));
     for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c)) {

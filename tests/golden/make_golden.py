@@ -283,6 +283,66 @@ def gen_trquant():
     print("trquant cases", len(meta))
 
 
+def gen_cclm():
+    """CCLM prediction (xGetLumaRecPixels + xGetLMParameters + predIntraChromaLM) for LM / MDLM_L / MDLM_T over random partial
+    reconstructions, real availability logic of the chroma tree."""
+    r2 = np.random.default_rng(20261004)
+    W = H = 192
+    envs, meta, preds = [], [], []
+    for bd in (8, 10):
+        env = R.ref_env_create(W, H, bd)
+        for trial in range(10):
+            reco = []
+            for c in range(3):
+                hh, ww = H >> (c > 0), W >> (c > 0)
+                base = ((np.arange(ww)[None, :] * int(r2.integers(1, 5)) + np.arange(hh)[:, None] * int(r2.integers(1, 5))) % (1 << bd))
+                noise = r2.integers(0, 1 << bd, (hh, ww)) * (r2.random((hh, ww)) < 0.15)
+                reco.append(np.clip(np.where(noise > 0, noise, base), 0, (1 << bd) - 1).astype(np.int16))
+            for c in range(3):
+                R.ref_env_set_reco(env, c, P(reco[c]), reco[c].shape[1])
+            lw = int(r2.choice([8, 16, 32, 64])); lh = int(r2.choice([8, 16, 32, 64]))
+            x = int(r2.integers(0, (W - lw) // lw + 1)) * lw
+            y = int(r2.integers(0, (H - lh) // lh + 1)) * lh
+            if trial % 4 == 0:
+                x = 0
+            if trial % 3 == 0:
+                y = 128 if trial % 2 else 0
+            coded = np.zeros((H // 8, W // 8), np.uint8)
+            mode = trial % 4
+            for by in range(H // 8):
+                for bx in range(W // 8):
+                    px, py = bx * 8, by * 8
+                    if px < x + lw and px + 8 > x and py < y + lh and py + 8 > y:
+                        continue
+                    if mode == 0:
+                        c_ = (py < y) or (py < y + lh and px < x)
+                    elif mode == 1:
+                        c_ = (py + 8 <= y) or (px + 8 <= x and py < y + 2 * lh)
+                    elif mode == 2:
+                        c_ = r2.random() < 0.7 and ((py < y + 2 * lh and px < x) or py < y)
+                    else:
+                        c_ = (py < y) or (px < x)
+                    coded[by, bx] = c_
+            envs.append((bd, [r.copy() for r in reco], coded.copy()))
+            for comp in (1, 2):
+                for dirm in (67, 68, 69):
+                    R.ref_env_reset(env)
+                    for by in range(H // 8):
+                        for bx in range(W // 8):
+                            if coded[by, bx]:
+                                R.ref_env_add_cu(env, 1, bx * 8, by * 8, 8, 8, 0, 3, 1)
+                    pred = np.zeros((lw // 2) * (lh // 2), np.int16); mpm = np.zeros(6, np.uint32)
+                    assert R.ref_env_pred(env, comp, x, y, lw, lh, dirm, 0, 0, P(pred), P(mpm)) == 0
+                    meta.append((len(envs) - 1, bd, comp, x, y, lw, lh, dirm)); preds.append(pred)
+    out = {"n_env": np.array(len(envs)), "case_meta": np.array(meta, np.int32), "case_pred": np.concatenate(preds)}
+    for i, (bd, reco, coded) in enumerate(envs):
+        for c in range(3):
+            out["env%d_reco%d" % (i, c)] = reco[c]
+        out["env%d_coded" % i] = coded
+    np.savez_compressed(os.path.join(HERE, "cclm.npz"), **out)
+    print("cclm cases", len(meta))
+
+
 def gen_bitstream():
     """(1) The reference's arithmetic coder (BinEncoder_Std) on random operation sequences.  (2) For several pictures: the
     oracle's slice_data payload per tile, accepted here only after the reference DECODER (CABACReader + BinDecoder) has
@@ -352,6 +412,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "trquant":
         gen_trquant(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream":
-        gen_bitstream(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream()
+        gen_bitstream(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cclm":
+        gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm()
     print("done")

@@ -166,3 +166,27 @@ def test_arithmetic_coder_and_slice_data_payload():
         payload, sz, _, _ = O.write_frame(pkg.synth_frame(int(W), int(H), 0, int(bd), int(seed)), int(W), int(H), pkg.slice_params(int(qp), bit_depth=int(bd)),
                                           bit_depth=int(bd), tile_cols=int(tc), tile_rows=int(tr))
         assert np.array_equal(sz, sizes[:len(sz)]) and np.array_equal(payload, exp), (W, H, qp, tc, tr, bd)
+
+
+def test_cclm_prediction():
+    """LM / MDLM_L / MDLM_T chroma prediction against IntraPrediction::xGetLumaRecPixels + xGetLMParameters + predIntraChromaLM."""
+    L = O.lib()
+    g = np.load(os.path.join(G, "cclm.npz"))
+    off = 0
+    for (ei, bd, comp, x, y, w, h, mode) in g["case_meta"]:
+        reco = [np.ascontiguousarray(g["env%d_reco%d" % (ei, c)]) for c in range(3)]
+        H, W = reco[0].shape
+        avail = _avail_map(g["env%d_coded" % ei], W, H)
+        cx, cy, cw, chh = int(x) // 2, int(y) // 2, int(w) // 2, int(h) // 2
+        exp = g["case_pred"][off:off + cw * chh]; off += cw * chh
+        ref = np.zeros(4 * 300 * 300, np.int16)
+        plane = reco[comp]
+        L.orc_fill_ref_samples(P(plane), plane.shape[1], plane.shape[1], plane.shape[0], P(avail), avail.shape[1], 1, 1, cx, cy, cw, chh, 0, int(bd), P(ref))
+        tstride = 2 * 64 + 2
+        tmp = np.zeros(tstride * (2 * 64 + 2), np.int16); info = np.zeros(4, np.int32)
+        L.orc_cclm_luma(P(reco[0]), W, P(avail), avail.shape[1], 1, W // 2, H // 2, cx, cy, cw, chh, int(mode != 67), P(info), P(tmp), tstride)
+        a = C.c_int(); b = C.c_int(); sh = C.c_int()
+        L.orc_cclm_params(P(tmp), tstride, P(ref), cw, chh, int(mode), P(info), int(bd), C.byref(a), C.byref(b), C.byref(sh))
+        pred = np.zeros(cw * chh, np.int16)
+        L.orc_pred_cclm(P(tmp), tstride, a.value, b.value, sh.value, int(bd), cw, chh, P(pred), cw)
+        assert np.array_equal(pred, exp), ("cclm", ei, comp, x, y, w, h, mode, a.value, b.value, sh.value, info)
