@@ -979,7 +979,8 @@ __device__ void init_pred_params(int w, int h, int is_luma, int mode, int mrl, I
 __device__ inline uint2 ipa_pack(const Ipa &p)
 {
   uint2 r;
-  r.x = (unsigned) p.pred_mode | ((unsigned) p.is_ver << 8) | ((unsigned) p.mrl << 9) | ((unsigned) p.ref_filter << 11) | ((unsigned) p.interp << 12) | ((unsigned) p.pdpc << 13) | ((unsigned) (p.ang_scale + 1) << 14);
+  // pred_mode can be negative after the wide-angle remap: mask it
+  r.x = ((unsigned) p.pred_mode & 255u) | ((unsigned) p.is_ver << 8) | ((unsigned) p.mrl << 9) | ((unsigned) p.ref_filter << 11) | ((unsigned) p.interp << 12) | ((unsigned) p.pdpc << 13) | ((unsigned) (p.ang_scale + 1) << 14);
   r.y = ((unsigned) p.angle & 0xffffu) | ((unsigned) p.inv_angle << 16);
   return r;
 }
