@@ -53,7 +53,7 @@ struct vvcx_handle {
 };
 
 #define VVCX_PAYLOAD_BYTES_PER_CTU 32768u
-static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_CU_REUSE;
+static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM;
 
 extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
 {

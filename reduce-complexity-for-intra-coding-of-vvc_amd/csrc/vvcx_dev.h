@@ -83,6 +83,7 @@ struct VxCacheEnt { uint64_t ss; uint8_t kind /* 0 empty, 1 luma tree, 2 chroma 
 #define VXD_CACHE_ENTRIES (32 * 32 * 5 * 5)
 #define VXD_CACHE_DIM   1152
 #define VXD_OFF_ORG     (VXD_OFF_TMP + VXD_NW * 2048 * 4)                             // original tile of a node too big for LDS: 4096 int16
-#define VXD_OFF_CACHE   ((VXD_OFF_ORG + 4096 * 2 + 255) & ~255)
+#define VXD_OFF_LM      (VXD_OFF_ORG + 4096 * 2)                                      // CCLM down-sampled luma of a big chroma node: in[1024] | top[64] | left[64] int16
+#define VXD_OFF_CACHE   ((VXD_OFF_LM + (1024 + 128) * 2 + 255) & ~255)
 #define VXD_OFF_CACHE_LEV (VXD_OFF_CACHE + VXD_CACHE_ENTRIES * (int) sizeof(VxCacheEnt))
 #define VXD_SCRATCH_BYTES (VXD_OFF_CACHE_LEV + VXD_CACHE_DIM * VXD_CACHE_DIM * 2)

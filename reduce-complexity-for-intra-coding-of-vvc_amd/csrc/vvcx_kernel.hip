@@ -40,6 +40,8 @@
 enum { SPLIT_NONE = 0, SPLIT_QT = 1, SPLIT_BH = 2, SPLIT_BV = 3, SPLIT_TH = 4, SPLIT_TV = 5 };
 enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V, ETM_RECO_CACHED };
 #define TOOL_CU_REUSE (1u << 11)
+#define TOOL_CCLM (1u << 8)
+enum { LM_CHROMA = 67, MDLM_L = 68, MDLM_T = 69 };
 enum { PLANAR = 0, DC = 1, HOR = 18, DIA = 34, VER = 50, VDIA = 66, DM_CHROMA = 70 };
 enum { OP_NONE, OP_DONE, OP_LUMA_PREP, OP_STAGE_A, OP_STAGE_B, OP_CHROMA_RD, OP_SAVE_INTRA, OP_SAVE_PIC, OP_RESTORE_PIC,
        OP_CLEAR_UNITS, OP_CTX_COPY, OP_REUSE };
@@ -126,6 +128,8 @@ struct Lds {
   unsigned long long cnt[4];
   VxParams par; VxFrameDev fdv;     // launch parameters and the stream's picture record: read from here inside the out-of-line functions (a reference
                                     // parameter to them is a generic pointer into the kernarg copy in scratch / into HBM: flat loads with full waits)
+  // CCLM: down-sampled luma of the chroma node (nodes of at most BUF chroma samples; bigger ones in HBM scratch), availability and line parameters
+  alignas(16) int16_t lm_in[BUF / 2]; int16_t lm_top[64], lm_left[64]; int lm_info[4], lm_ok, lm_nsatd; int lm_par[2][3][3]; int64_t lm_cost[8];
   Arith aw; uint8_t *aw_out; uint32_t aw_cap; int colm;      // bitstream pass: arithmetic coder, its output (HBM) and capacity; co-located luma mode of the chroma node
   unsigned long long prof[48];    // shader-clock ticks per operation kind (diagnostic, see vvcx_get_profile)
 };
@@ -915,16 +919,28 @@ __device__ unsigned long long luma_mode_bits(const Ctx &c, int y, int dir, int m
   }
   return bits;
 }
+// CABACWriter::intra_chroma_pred_mode 1891-1933 + intra_chroma_lmc_mode 1864-1888; lm = co-located luma mode (candidate list
+// CL/UnitTools.cpp:840-873), lm_ok = CodingUnit::checkCCLMAllowed
 template <bool WR = false>
-__device__ void enc_intra_chroma_pred_mode(Cab &cb, int dir, int lm)      // 1891-1933, CCLM off; lm = co-located luma mode (candidate list 840-873)
+__device__ void enc_intra_chroma_pred_mode(Cab &cb, int dir, int lm, int lm_ok)
 {
+  if (lm_ok) {
+    const int isLM = dir >= LM_CHROMA && dir <= MDLM_T;
+    enc_bin<WR>(cb, (unsigned) isLM, VX_CTX_CclmModeFlag);
+    if (isLM) {
+      const int symbol = dir - LM_CHROMA;
+      enc_bin<WR>(cb, symbol == 0 ? 0 : 1, VX_CTX_IntraChromaPredMode);
+      if (symbol > 0) enc_ep<WR>(cb, (uint32_t) (symbol - 1), 1);
+      return;
+    }
+  }
   const int isDM = dir == DM_CHROMA;
   enc_bin<WR>(cb, isDM ? 0 : 1, VX_CTX_IntraChromaPredMode);
   if (isDM) return;
   int list[4] = { PLANAR, VER, HOR, DC };
   for (int i = 0; i < 4; i++) if (lm == list[i]) { list[i] = VDIA; break; }
   int cand = 0;
-  for (; cand < 3; cand++) if (list[cand] == dir) break;
+  for (; cand < 4; cand++) if (list[cand] == dir) break;      // 4 for a cached LM mode reused where CCLM is not allowed: the reference codes that value too
   enc_ep<WR>(cb, (uint32_t) cand, 2);
 }
 
@@ -1160,6 +1176,131 @@ __device__ __noinline__ void build_refs(const VxParams &p_, const VxFrameDev &fd
   }
 }
 
+// ------------------------------------------------------------------------------------------------ CCLM (all threads unless noted)
+// CodingUnit::checkCCLMAllowed (CL/Unit.cpp:375-449) for a chroma-tree CU of a dual-tree I slice with CTU 128: the splits of the 64x64
+// chroma node (depths 1, 2 of the CU's split series) and of the co-located 64x64 luma node decide
+__device__ int cclm_allowed(const VxParams &p, const VxFrameDev &fd, int x, int y, uint64_t ss, int depth)
+{
+  if (!(p.tools & TOOL_CCLM)) return 0;
+  const int s1 = depth > 1 ? (int) ((ss >> 5) & 31) : SPLIT_NONE, s2 = depth > 2 ? (int) ((ss >> 10) & 31) : SPLIT_NONE;
+  int allow = s1 == SPLIT_QT || (s1 == SPLIT_BH && s2 == SPLIT_BV) || s1 == SPLIT_NONE || (s1 == SPLIT_BH && s2 == SPLIT_NONE);
+  if (allow) {
+    const VxUnit u = fd.units[0][(y >> 2) * p.uw + (x >> 2)];        // colLumaCu at the CU's luma position
+    if (u.lw < 6 || u.lh < 6) { const int l1 = u.depth > 1 ? (int) ((u.ss >> 5) & 31) : SPLIT_NONE; if (l1 != SPLIT_QT) allow = 0; }
+  }
+  return allow;
+}
+__device__ inline int16_t *lm_in_buf(uint8_t *scratch, int nrec) { return nrec <= BUF ? L.lm_in : (int16_t *) (scratch + VXD_OFF_LM); }
+// xGetLMParameters 1931-2150 for component k (0 Cb, 1 Cr) and mode; one thread
+__device__ void cclm_params(const int16_t *in, int cw, int chh, int k, int mode, int bd, int out[3])
+{
+  int leftAvail = L.lm_info[0], aboveAvail = L.lm_info[1], availLB = L.lm_info[2], availAR = L.lm_info[3];
+  const int availAbove = aboveAvail ? cw >> 1 : 0, availLeft = leftAvail ? chh >> 1 : 0;
+  const int16_t *top = L.refs[k][0], *left = L.refs[k][1];
+  int actualTop = 0, actualLeft = 0;
+  if (mode == MDLM_T) { leftAvail = 0; availAR = imin(availAR, chh >> 1); actualTop = 2 * (availAbove + availAR); }
+  else if (mode == MDLM_L) { aboveAvail = 0; availLB = imin(availLB, cw >> 1); actualLeft = 2 * (availLeft + availLB); }
+  else { actualTop = cw; actualLeft = chh; }
+  const int aboveIs4 = leftAvail ? 0 : 1, leftIs4 = aboveAvail ? 0 : 1;
+  const int startT = actualTop >> (2 + aboveIs4), stepT = imax(1, actualTop >> (1 + aboveIs4));
+  const int startL = actualLeft >> (2 + leftIs4), stepL = imax(1, actualLeft >> (1 + leftIs4));
+  int selL[4] = { 0, 0, 0, 0 }, selC[4] = { 0, 0, 0, 0 };
+  int cntT = 0, cntL = 0;
+  if (aboveAvail) { cntT = imin(actualTop, (1 + aboveIs4) << 1); for (int c = 0, pos = startT; c < cntT; pos += stepT, c++) { selL[c] = L.lm_top[pos]; selC[c] = top[1 + pos]; } }
+  if (leftAvail) { cntL = imin(actualLeft, (1 + leftIs4) << 1); for (int c = 0, pos = startL; c < cntL; pos += stepL, c++) { selL[c + cntT] = L.lm_left[pos]; selC[c + cntT] = left[1 + pos]; } }
+  if (cntL + cntT == 2) {
+    selL[3] = selL[0]; selC[3] = selC[0]; selL[2] = selL[1]; selC[2] = selC[1];
+    selL[0] = selL[1]; selC[0] = selC[1]; selL[1] = selL[3]; selC[1] = selC[3];
+  }
+  int mn0 = 0, mn1 = 2, mx0 = 1, mx1 = 3;            // minGrpIdx / maxGrpIdx with the reference's four compare-and-swap steps
+  if (selL[mn0] > selL[mn1]) { const int t = mn0; mn0 = mn1; mn1 = t; }
+  if (selL[mx0] > selL[mx1]) { const int t = mx0; mx0 = mx1; mx1 = t; }
+  if (selL[mn0] > selL[mx1]) { int t = mn0; mn0 = mx0; mx0 = t; t = mn1; mn1 = mx1; mx1 = t; }
+  if (selL[mn1] > selL[mx0]) { const int t = mn1; mn1 = mx0; mx0 = t; }
+  const int minL = (selL[mn0] + selL[mn1] + 1) >> 1, minC = (selC[mn0] + selC[mn1] + 1) >> 1;
+  const int maxL = (selL[mx0] + selL[mx1] + 1) >> 1, maxC = (selC[mx0] + selC[mx1] + 1) >> 1;
+  int a, b, shift;
+  if (leftAvail || aboveAvail) {
+    const int diff = maxL - minL;
+    if (diff > 0) {
+      const int diffC = maxC - minC;
+      int x = ilog2i(diff);
+      const int normDiff = ((diff << 4) >> x) & 15;
+      const int v = (int) ((0x0765544332211110ull >> (4 * (15 - normDiff))) & 15) | 8;      // DivSigTable {0,7,6,5,5,4,4,3,3,2,2,1,1,1,1,0}
+      x += normDiff != 0;
+      const int yy = diffC == 0 ? 0 : ilog2i(iabs(diffC)) + 1;
+      const int add = (1 << yy) >> 1;
+      a = (diffC * v + add) >> yy;
+      shift = 3 + x - yy;
+      if (shift < 1) { shift = 1; a = a == 0 ? 0 : a < 0 ? -15 : 15; }
+      b = minC - ((a * minL) >> shift);
+    } else { a = 0; b = minC; shift = 0; }
+  } else { a = 0; b = 1 << (bd - 1); shift = 0; }
+  out[0] = a; out[1] = b; out[2] = shift;
+  (void) in;
+}
+// xGetLumaRecPixels 1665-1930 (4:2:0, sps_cclm_colocated_chroma_flag 0) + the parameters of the three LM modes for both components.
+// Call after build_refs of the chroma node: L.flags then hold the availability (stopping at the first missing unit of each segment)
+// of its reference units, which are the units CCLM asks about.  One buffer serves LM and MDLM: the extension only adds entries.
+template <typename T>
+__device__ void cclm_prepare(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch, int cx, int cy, int cw, int chh)
+{
+  const int tid = threadIdx.x, P = cw * chh;
+  const int totalLeft = chh, numLeft = chh >> 1, totalAbove = cw, numAbove = cw >> 1;       // units of 2 chroma samples
+  if (tid == 0) {
+    const int leftAvail = L.flags[totalLeft - numLeft], aboveAvail = L.flags[totalLeft + numAbove];
+    int lb = 0, ar = 0;
+    if (leftAvail) for (int i = numLeft; i < totalLeft && L.flags[totalLeft - 1 - i]; i++) lb++;
+    if (aboveAvail) for (int i = numAbove; i < totalAbove && L.flags[totalLeft + 1 + i]; i++) ar++;
+    L.lm_info[0] = leftAvail; L.lm_info[1] = aboveAvail; L.lm_info[2] = lb; L.lm_info[3] = ar;
+  }
+  __syncthreads();
+  const int leftAvail = uni(L.lm_info[0]), aboveAvail = uni(L.lm_info[1]);
+  const int nTop = aboveAvail ? cw + 2 * uni(L.lm_info[3]) : 0, nLeft = leftAvail ? chh + 2 * uni(L.lm_info[2]) : 0;
+  const void *rec = fd.rec[0]; const int S = fd.stride[0];
+  const int base = (2 * cy) * S + 2 * cx;
+  const int firstRowOfCtu = (cy & 63) == 0;
+  int16_t *in = lm_in_buf(scratch, 2 * P);
+#define LY(dx_, dy_) ld_px<T>(rec, base + (dy_) * S + (dx_))
+  for (int e = tid; e < P + nTop + nLeft; e += NT) {
+    if (e < P) {
+      const int j = e >> ilog2i(cw), i = e & (cw - 1);
+      int v;
+      if (i == 0 && !leftAvail) v = (LY(0, 2 * j) + LY(0, 2 * j + 1) + 1) >> 1;
+      else v = (LY(2 * i, 2 * j) * 2 + LY(2 * i + 1, 2 * j) + LY(2 * i - 1, 2 * j) + LY(2 * i, 2 * j + 1) * 2 + LY(2 * i + 1, 2 * j + 1) + LY(2 * i - 1, 2 * j + 1) + 4) >> 3;
+      in[e] = (int16_t) v;
+    } else if (e < P + nTop) {
+      const int i = e - P;
+      int v;
+      if (firstRowOfCtu) v = (i == 0 && !leftAvail) ? LY(0, -1) : (LY(2 * i, -1) * 2 + LY(2 * i - 1, -1) + LY(2 * i + 1, -1) + 2) >> 2;
+      else v = (i == 0 && !leftAvail) ? (LY(0, -2) + LY(0, -1) + 1) >> 1
+                                      : (LY(2 * i, -2) * 2 + LY(2 * i - 1, -2) + LY(2 * i + 1, -2) + LY(2 * i, -1) * 2 + LY(2 * i - 1, -1) + LY(2 * i + 1, -1) + 4) >> 3;
+      L.lm_top[i] = (int16_t) v;
+    } else {
+      const int j = e - P - nTop;
+      L.lm_left[j] = (int16_t) ((LY(-2, 2 * j) * 2 + LY(-3, 2 * j) + LY(-1, 2 * j) + LY(-2, 2 * j + 1) * 2 + LY(-3, 2 * j + 1) + LY(-1, 2 * j + 1) + 4) >> 3);
+    }
+  }
+#undef LY
+  __threadfence_block();
+  __syncthreads();
+  if (tid < 6) { int o[3]; cclm_params(in, cw, chh, tid / 3, LM_CHROMA + tid % 3, p.bit_depth, o); L.lm_par[tid / 3][tid % 3][0] = o[0]; L.lm_par[tid / 3][tid % 3][1] = o[1]; L.lm_par[tid / 3][tid % 3][2] = o[2]; }
+  __syncthreads();
+}
+// one wave: prediction of chroma component k with final mode fm into dst (w*h, stride w)
+__device__ inline void chroma_pred_wave(int16_t *dst, const int16_t *lm_in, int k, int fm, int w, int h, int bd, int lane)
+{
+  const int P = w * h;
+  if (fm >= LM_CHROMA && fm <= MDLM_T) {                  // predIntraChromaLM 400-420: linearTransform with clipping
+    const int a = L.lm_par[k][fm - LM_CHROMA][0], b = L.lm_par[k][fm - LM_CHROMA][1], sh = L.lm_par[k][fm - LM_CHROMA][2];
+    for (int i = lane; i < P; i += 64) dst[i] = (int16_t) clip_bd(((a * lm_in[i]) >> sh) + b, bd);
+  } else {
+    Ipa ip; init_pred_params(w, h, 0, fm, 0, ip);
+    const int16_t *top = L.refs[k][0], *left = L.refs[k][1];
+    for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); dst[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ distortion (one wave)
 template <int N> __device__ inline void had1d(int *v)
 {
@@ -1246,11 +1387,11 @@ __device__ inline void sad_satd_tiles(const int16_t *org, const int16_t *pred, i
 }
 template <bool SMALL>
 __device__ __noinline__ void wave_sad_satd(const int16_t *org_g, const int16_t *pred_g, int16_t *scr_g, int w, int h, int lane,
-                              unsigned long long &sad_out, unsigned long long &satd_out)
+                              unsigned long long &sad_out, unsigned long long &satd_out, int org_off = 0, int pred_off = 0)
 {
-  w = uni(w); h = uni(h);
+  w = uni(w); h = uni(h); org_off = uni(org_off); pred_off = uni(pred_off);       // offsets: second component of a chroma pair
   const int wave_ = uni(threadIdx.x >> 6);
-  const int16_t *org = SMALL ? L.org : org_g, *pred = SMALL ? L.slot[wave_] : pred_g;
+  const int16_t *org = (SMALL ? L.org : org_g) + org_off, *pred = (SMALL ? L.slot[wave_] : pred_g) + pred_off;
   int16_t *scr = SMALL ? (int16_t *) L.tmp[wave_] : scr_g;
   const int P = w * h;
   int bw, bh; satd_tile_shape(w, h, bw, bh);
@@ -1658,6 +1799,41 @@ template <bool SMALL>
 __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h)
 {
   const int P = w * h, bd = p.bit_depth;
+  const int16_t *lmin = lm_in_buf(scratch, 2 * P);
+  if (uni(L.lm_ok)) {
+    // SATD pre-selection (1479-1582): the first seven candidates except LM, planar (and DM, which is the eighth) are ranked by
+    // SATD(Cb) + SATD(Cr); the reference's exchange sort (not stable) then drops the two last entries from the RD loop
+    for (int idx = wave; idx < 7; idx += NW) {
+      const int mode = uni(L.rd[idx].mode);
+      long long sum = 0;
+      if (mode != LM_CHROMA && mode != PLANAR) {
+        int16_t *pred = SMALL ? L.slot[wave] : slot_rec(scratch, 2 * P, wave, 0);
+        for (int k = 0; k < 2; k++) {
+          chroma_pred_wave(pred, lmin, k, mode, w, h, bd, lane);
+          wave_sync();
+          unsigned long long sad, satd;
+          wave_sad_satd<SMALL>(org_tile(scratch, 2 * P), pred, SMALL ? (int16_t *) L.tmp[wave] : (int16_t *) wave_tmp(scratch, P >> 1, wave), w, h, lane, sad, satd, k * P, 0);
+          sum += (long long) satd;
+          wave_sync();
+        }
+      }
+      if (lane == 0) L.lm_cost[idx] = sum;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int list[7]; long long cost[7]; int ns = 0;
+      for (int i = 0; i < 7; i++) { list[i] = L.rd[i].mode; cost[i] = L.lm_cost[i]; ns += list[i] != LM_CHROMA && list[i] != PLANAR; }
+      for (int i = 0; i < 7; i++) for (int j = i + 1; j < 7; j++) if (cost[j] < cost[i]) {
+        const int tm = list[i]; list[i] = list[j]; list[j] = tm;
+        const long long tc = cost[i]; cost[i] = cost[j]; cost[j] = tc;
+      }
+      int n = 0;
+      for (int i = 0; i < 8; i++) { const int m = L.rd[i].mode; if (m == list[5] || m == list[6]) continue; L.rd[n] = L.rd[i]; n++; }
+      L.n_rd = n; L.lm_nsatd = 2 * ns;
+    }
+    __syncthreads();
+  }
   if (lane == 0) L.wave_best[wave] = -1;
   double wbest = MAX_DOUBLE;
   int cur = 0;
@@ -1670,11 +1846,9 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
     { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     wave_sync();
     unsigned long long dist = 0; int cbfs[2];
-    Ipa ip; init_pred_params(w, h, 0, fm, 0, ip);
     for (int k = 0; k < 2; k++) {
       int16_t *rec = recb + k * P, *lev = levb + k * P;
-      const int16_t *top = L.refs[k][0], *left = L.refs[k][1];
-      for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
+      chroma_pred_wave(rec, lmin, k, fm, w, h, bd, lane);
       wave_sync();
       unsigned long long sse; int cbf;
       wave_code_block<SMALL>(org_tile(scratch, 2 * P), k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[k], lane, sse, cbf);
@@ -1691,7 +1865,7 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
     {                      // 1611-1621: contexts not reset; xGetIntraFracBitsQT(chroma)
       Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
       if (lane == 0) {
-        enc_intra_chroma_pred_mode(cb, cm, L.colm);
+        enc_intra_chroma_pred_mode(cb, cm, L.colm, L.lm_ok);
         enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]);
         enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]);
       }
@@ -1725,6 +1899,7 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p_, const VxFrameDev &
     build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
   }
   if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
+  if (uni(L.lm_ok)) cclm_prepare<T>(p, fd, scratch, x, y, w, h);
   __syncthreads();
   if (2 * P <= BUF) chroma_rd_loop<true>(p, scratch, wave, lane, w, h); else chroma_rd_loop<false>(p, scratch, wave, lane, w, h);
   __threadfence_block();
@@ -1743,7 +1918,7 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p_, const VxFrameDev &
     const int cbfm = uni(L.rd_cbf[best]);
     Cab cb; cb.ci = CI_W(0); cb.bits = 0;
     if (lane == 0) {
-      enc_intra_chroma_pred_mode(cb, L.rd[best].mode, L.colm);
+      enc_intra_chroma_pred_mode(cb, L.rd[best].mode, L.colm, L.lm_ok);
       enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
       enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
     }
@@ -1808,17 +1983,16 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
     if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, fm); enc_bin(cb, (unsigned) (cbfm & 1), VX_CTX_QtCbf[0]); }
     if (cbfm & 1) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 0, lane);
   } else {
-    Ipa ip; init_pred_params(w, h, 0, fm, 0, ip);
     for (int k = 0; k < 2; k++) {
       int16_t *rec = recb + k * P;
-      for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(L.refs[k][0], L.refs[k][1], w, h, px, py, ip, fm, 0, bd, L.dc_val[k]); }
+      chroma_pred_wave(rec, lm_in_buf(scratch, n), k, fm, w, h, bd, lane);
       wave_sync();
       unsigned long long sse; int cbf;
       wave_code_block<SMALL>(org_tile(scratch, n), k * P, k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1);
       dist += (unsigned long long) (p.dist_weight[k] * (double) sse);
     }
     if (lane == 0) {
-      enc_intra_chroma_pred_mode(cb, mode, L.colm);
+      enc_intra_chroma_pred_mode(cb, mode, L.colm, L.lm_ok);
       enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
       enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
     }
@@ -1852,6 +2026,7 @@ __device__ __noinline__ void op_reuse(const VxParams &p_, const VxFrameDev &fd_,
       build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
     }
     if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
+    { const int fm = uni(L.rd[0].mrl); if (fm >= LM_CHROMA && fm <= MDLM_T) cclm_prepare<T>(p, fd, scratch, x, y, w, h); }
   }
   int16_t *levb = slot_lev(scratch, n, 0, 0);
   {
@@ -2092,6 +2267,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
             const int cx = f.x + (f.w >> 1), cy = f.y + (f.h >> 1);
             L.colm = fd.units[0][(cy >> 2) * p.uw + (cx >> 2)].dir;
             L.rd[0].mrl = (uint8_t) (f.r_dir == DM_CHROMA ? L.colm : f.r_dir);    // final mode
+            L.lm_ok = cclm_allowed(p, fd, f.x, f.y, f.ss, f.depth); L.lm_nsatd = 0;
           }
           f.phase = PH_B_DONE;
           post(OP_REUSE); return;
@@ -2116,10 +2292,15 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
           const int cx = f.x + (f.w >> 1), cy = f.y + (f.h >> 1);
           const int lm = fd.units[0][(cy >> 2) * p.uw + (cx >> 2)].dir;      // getCoLocatedIntraLumaMode 949-960
           L.colm = lm;
-          int list[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };
+          int list[8] = { PLANAR, VER, HOR, DC, LM_CHROMA, MDLM_L, MDLM_T, DM_CHROMA };
           for (int i = 0; i < 4; i++) if (lm == list[i]) { list[i] = VDIA; break; }
-          for (int i = 0; i < 5; i++) { L.rd[i].mode = (uint8_t) list[i]; L.rd[i].mrl = (uint8_t) (list[i] == DM_CHROMA ? lm : list[i]); }
-          L.n_rd = 5;
+          L.lm_ok = cclm_allowed(p, fd, f.x, f.y, f.ss, f.depth); L.lm_nsatd = 0;
+          int n = 0;
+          for (int i = 0; i < 8; i++) {
+            if (!L.lm_ok && list[i] >= LM_CHROMA && list[i] <= MDLM_T) continue;      // EL/IntraSearch.cpp:1588-1591
+            L.rd[n].mode = (uint8_t) list[i]; L.rd[n].mrl = (uint8_t) (list[i] == DM_CHROMA ? lm : list[i]); n++;
+          }
+          L.n_rd = n;
           f.phase = PH_B_DONE;
           post(OP_CHROMA_RD); return;
         }
@@ -2177,6 +2358,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
     }
     case PH_B_DONE: {                                   // winner chosen by the operation; CU-level rate; xCheckBestMode
       const int best = L.win_idx, ww = L.win_wave;
+      if (ch) L.cnt[0] += (unsigned long long) L.lm_nsatd;
       L.cnt[1] += (unsigned long long) (ch ? 2 * L.n_rd : L.n_rd); L.cnt[2] += (unsigned long long) (ch ? 2 * L.n_rd * ((f.w >> 1) * (f.h >> 1)) : L.n_rd * f.w * f.h);
       L.op_a = L.wave_slot[ww];                         // slot of that wave holding the winner's reco / levels
       Sum &t = f.temp;
@@ -2295,7 +2477,7 @@ __device__ __noinline__ void walk_tree(const VxParams &p_, const VxFrameDev &fd_
           enc_bin<WR>(cb, u->cbf & 1, VX_CTX_QtCbf[0]);
           if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; residual_coding<WR>(cb, lv, W, H, 0, (uint16_t *) (lv + 4096)); }
         } else {
-          enc_intra_chroma_pred_mode<WR>(cb, u->dir, fd.units[0][((f.y + (f.h >> 1)) >> 2) * p.uw + ((f.x + (f.w >> 1)) >> 2)].dir);
+          enc_intra_chroma_pred_mode<WR>(cb, u->dir, fd.units[0][((f.y + (f.h >> 1)) >> 2) * p.uw + ((f.x + (f.w >> 1)) >> 2)].dir, cclm_allowed(p, fd, f.x, f.y, u->ss, u->depth));
           enc_bin<WR>(cb, (unsigned) !!(u->cbf & 2), VX_CTX_QtCbf[1]);
           enc_bin<WR>(cb, (unsigned) !!(u->cbf & 4), VX_CTX_QtCbf[2] + !!(u->cbf & 2));
           for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c)) {

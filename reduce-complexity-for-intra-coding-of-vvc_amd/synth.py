@@ -1,8 +1,10 @@
-"""Seeded synthetic YUV 4:2:0 generator — a pure function of (W, H, frame, bitdepth, seed)."""
+"""Seeded synthetic YUV 4:2:0 generator — a pure function of (W, H, frame, bitdepth, seed, chroma_texture)."""
 import numpy as np
 
 
-def synth_frame(width, height, frame=0, bit_depth=8, seed=1234):
+def synth_frame(width, height, frame=0, bit_depth=8, seed=1234, chroma_texture=0.0):
+    """chroma_texture > 0 adds that fraction of the (2x2 averaged) luma texture to Cb and minus half of it to Cr: natural video has
+    such cross-component correlation and the LM chroma modes (CCLM) only win on pictures that have it."""
     s = 1 if bit_depth == 8 else 4
     mid, a1, a2 = (128, 60, 40) if bit_depth == 8 else (512, 240, 160)
     mx = (1 << bit_depth) - 1
@@ -12,6 +14,10 @@ def synth_frame(width, height, frame=0, bit_depth=8, seed=1234):
     yc, xc = np.mgrid[0:height // 2, 0:width // 2]
     U = mid + 20 * s * np.sin(xc / 50.0) + rng.normal(0, 2 * s, (height // 2, width // 2))
     V = mid + 20 * s * np.cos(yc / 40.0) + rng.normal(0, 2 * s, (height // 2, width // 2))
+    if chroma_texture:
+        Yd = (Y[0:height // 2 * 2:2, 0:width // 2 * 2:2] + Y[1:height // 2 * 2:2, 0:width // 2 * 2:2] + Y[0:height // 2 * 2:2, 1:width // 2 * 2:2] + Y[1:height // 2 * 2:2, 1:width // 2 * 2:2]) / 4.0 - mid
+        U = U + chroma_texture * Yd
+        V = V - 0.5 * chroma_texture * Yd
     dt = np.uint8 if bit_depth == 8 else np.uint16
     return [np.clip(np.rint(p), 0, mx).astype(dt) for p in (Y, U, V)]
 

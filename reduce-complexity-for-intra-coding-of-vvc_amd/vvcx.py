@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libvvcx.so")
 TOOL_MRL = 1
 TOOL_CU_REUSE = 1 << 11      # BestEncInfoCache, REUSE_CU_RESULTS (CL/TypeDef.h:291) - on in the reference build
+TOOL_CCLM = 1 << 8           # LM / MDLM chroma modes (cfg LMChroma 1, on in the reference's intra configuration)
 TOOLS_DEFAULT = TOOL_MRL | TOOL_CU_REUSE
 
 

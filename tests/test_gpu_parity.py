@@ -61,6 +61,18 @@ def test_one_ctu_without_cu_reuse():
     _check([pkg.synth_frame(128, 128, 0, 8, 7)], 128, 128, pkg.slice_params(32), tools=pkg.TOOL_MRL)
 
 
+@pytest.mark.parametrize("case", [(128, 128, 32, 8, 1, 1, 7), (200, 136, 27, 8, 1, 1, 1234), (256, 256, 37, 8, 2, 2, 5), (128, 128, 32, 10, 1, 1, 3)])
+def test_lm_chroma_modes(case):
+    # CCLM on (tools 0x901) on pictures whose chroma follows the luma texture, where LM / MDLM_L / MDLM_T win most chroma CUs
+    W, H, qp, bd, tc, tr, seed = case
+    _check([pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=0.6)], W, H, pkg.slice_params(qp, bit_depth=bd), bit_depth=bd, tile_cols=tc, tile_rows=tr,
+           tools=pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM)
+
+
+def test_lm_chroma_modes_without_cu_reuse():
+    _check([pkg.synth_frame(128, 128, 0, 8, 9, chroma_texture=0.4)], 128, 128, pkg.slice_params(27), tools=pkg.TOOL_MRL | pkg.TOOL_CCLM)
+
+
 def test_picture_boundary_implicit_splits():
     # 200x136: partial CTUs on the right and at the bottom → implicit QT/BT splits (CL/UnitPartitioner.cpp:530-581)
     _check([pkg.synth_frame(200, 136, 0, 8, 1234)], 200, 136, pkg.slice_params(32))
@@ -129,19 +141,22 @@ def test_full_1080p_frame_matches_oracle():
     _check([pkg.synth_frame(W, H, 0, 8, 1000)], W, H, pkg.slice_params(32), tile_cols=15, tile_rows=9)
 
 
-def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted():
+@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz"])
+def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fixture):
     """Device writer (arithmetic coding of the final CTU syntax in the estimator pass) against tests/golden/bitstream.npz: payloads
     that the reference's CABACReader parsed back into the coded CUs and levels when the fixture was generated."""
     import os
     import torch
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bitstream.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
+    tools = int(g["tools"][0]) if "tools" in g else pkg.TOOLS_DEFAULT
+    texture = float(g["chroma_texture"][0]) if "chroma_texture" in g else 0.0
     off = 0
     for (W, H, qp, tc, tr, bd, seed, nbytes), sizes in zip(g["pic_meta"], g["pic_sizes"]):
         exp = g["pic_bytes"][off:off + nbytes]; off += int(nbytes)
         W, H, bd = int(W), int(H), int(bd)
         sp = pkg.slice_params(int(qp), bit_depth=bd)
-        planes = pkg.synth_frame(W, H, 0, bd, int(seed))
-        enc = pkg.VvcxEncoder(W, H, bd, tile_cols=int(tc), tile_rows=int(tr), emit_payload=True)
+        planes = pkg.synth_frame(W, H, 0, bd, int(seed), chroma_texture=texture)
+        enc = pkg.VvcxEncoder(W, H, bd, tile_cols=int(tc), tile_rows=int(tr), emit_payload=True, tools=tools)
         enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
         conv = [p if p.dtype == np.uint8 else p.view(np.int16) for p in planes]
         org = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in conv]

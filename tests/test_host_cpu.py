@@ -65,9 +65,9 @@ def test_missing_extension_fails_loudly(tmp_path):
 
 
 @pytest.mark.parametrize("w,h,chroma,tiles,tools", [(32, 32, 1, (1, 1), pkg.TOOLS_DEFAULT), (40, 24, 1, (1, 1), pkg.TOOLS_DEFAULT),
-                                                   (32, 32, 1, (1, 1), pkg.TOOL_MRL)])
+                                                   (32, 32, 1, (1, 1), pkg.TOOL_MRL), (40, 24, 1, (1, 1), pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM)])
 def test_device_code_on_cpu_emulator_matches_oracle(emu_so, w, h, chroma, tiles, tools):
-    planes = pkg.synth_frame(w, h, 0, 8, 7)
+    planes = pkg.synth_frame(w, h, 0, 8, 7, chroma_texture=0.6 if tools & pkg.TOOL_CCLM else 0.0)
     sp = pkg.slice_params(32)
     enc = pkg.VvcxEncoder(w, h, 8, tile_cols=tiles[0], tile_rows=tiles[1], chroma=bool(chroma), tools=tools, lib_path=emu_so)
     enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
@@ -85,14 +85,15 @@ def test_device_code_on_cpu_emulator_matches_oracle(emu_so, w, h, chroma, tiles,
     enc.close()
 
 
-def test_emulated_slice_data_writer_matches_oracle(emu_so):
+@pytest.mark.parametrize("tools", [pkg.TOOLS_DEFAULT, pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM])
+def test_emulated_slice_data_writer_matches_oracle(emu_so, tools):
     """The device's bitstream pass (same sources on the CPU debug emulation) against the oracle's payload, whose format is pinned
     through the reference decoder (tests/golden/make_golden.py bitstream)."""
     w, h = 40, 24
-    planes = pkg.synth_frame(w, h, 0, 8, 7)
+    planes = pkg.synth_frame(w, h, 0, 8, 7, chroma_texture=0.6 if tools & pkg.TOOL_CCLM else 0.0)
     sp = pkg.slice_params(27)
-    payload, sizes, _, _ = O.write_frame(planes, w, h, sp)
-    enc = pkg.VvcxEncoder(w, h, 8, lib_path=emu_so, emit_payload=True)
+    payload, sizes, _, _ = O.write_frame(planes, w, h, sp, tools=tools)
+    enc = pkg.VvcxEncoder(w, h, 8, lib_path=emu_so, emit_payload=True, tools=tools)
     enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
     org = [np.ascontiguousarray(p) for p in planes]
     rec = [np.zeros_like(p) for p in planes]
