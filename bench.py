@@ -54,6 +54,12 @@ def main():
                     help="frames per step and rank; auto = enough frames for ~4 full waves of resident CTU streams")
     ap.add_argument("--tiles", type=str, default="auto", help="CxR uniform tile grid; auto = one tile per CTU")
     ap.add_argument("--lib", type=str, default=None, help="alternative build of the HIP library (experiments only)")
+    ap.add_argument("--tools", type=lambda v: int(v, 0), default=0x901,
+                    help="VVCX_TOOL_* bits; default MRL | CCLM | CU reuse = every tool of the reference's intra cfg that is built so far")
+    ap.add_argument("--classifier", action="store_true",
+                    help="BASELINE config 3 flavour: the fork's FAST_ALGORITHM with the shipped forest (forests/partition_qp32.npz) on the device")
+    ap.add_argument("--chroma-texture", type=float, default=0.5,
+                    help="fraction of the luma texture mixed into the synthetic chroma planes (0 = smooth chroma)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ctus", type=int, default=12)
     args = ap.parse_args()
@@ -81,17 +87,21 @@ def main():
     else:
         tc, tr = map(int, args.tiles.lower().split("x"))
     sp = pkg.slice_params(args.qp)
+    forest = None
+    if args.classifier:
+        args.tools |= pkg.TOOL_FAST
+        forest = pkg.load_forest(os.path.join(ROOT, "reduce-complexity-for-intra-coding-of-vvc_amd", "forests", "partition_qp32.npz"))
     if args.frames == "auto":
-        probe = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, device=dev, lib_path=args.lib)
+        probe = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, device=dev, lib_path=args.lib, tools=args.tools, forest=forest)
         args.frames = max(1, (4 * probe.resident_streams()) // (tc * tr))
         probe.close()
     else:
         args.frames = int(args.frames)
-    enc = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, chroma=True, max_frames=args.frames, device=dev, lib_path=args.lib)
+    enc = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, chroma=True, max_frames=args.frames, device=dev, lib_path=args.lib, tools=args.tools, forest=forest)
     enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
     frames = []
     for poc in pkg.frames_of_rank(args.frames * world, rank, world):      # weak scaling: args.frames per rank
-        planes = pkg.synth_frame(W, H, poc, 8, 1000 + poc)
+        planes = pkg.synth_frame(W, H, poc, 8, 1000 + poc, chroma_texture=args.chroma_texture)
         org = [torch.from_numpy(p).cuda() for p in planes]
         rec = [torch.zeros_like(t) for t in org]
         frames.append((org, rec))
@@ -112,15 +122,18 @@ def main():
         value = total_ctus / elapsed
         avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
         achieved = ctus_per_step * B_CTU_8BIT / avg_kernel_s / 1e9
-        workload = ("%dx%d 8-bit 4:2:0 All-Intra QP%d full RDO, %d frame(s)/step/GPU, %dx%d uniform tiles = %d CTU streams per frame"
-                    % (W, H, args.qp, args.frames, tc, tr, tc * tr))
+        workload = ("%dx%d 8-bit 4:2:0 All-Intra QP%d full RDO, tools 0x%x, chroma texture %.2f, %d frame(s)/step/GPU, %dx%d uniform tiles = %d CTU streams per frame"
+                    % (W, H, args.qp, args.tools, args.chroma_texture, args.frames, tc, tr, tc * tr))
         traffic, traffic_src = pmc_traffic(workload)
         out = {
             "metric": "CTUs/sec (All-Intra, QP32)", "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16/int32 samples+coefficients, fp64 RD cost", "data": "synthetic",
             "config": {"workload": workload,
-                       "tools": "P0: 67 intra modes + PDPC + MRL, DCT-II, plain quant, dual tree, CU-result reuse (REUSE_CU_RESULTS); MIP/ISP/LFNST/MTS/TS/CCLM/JCCR/LMCS/DepQuant/RDOQ not built yet",
+                       "tools": "67 intra modes + PDPC" + (" + MRL" if args.tools & 1 else "") + (" + CCLM (LM, MDLM_L, MDLM_T)" if args.tools & 0x100 else "")
+                                + ", DCT-II, plain quant, dual tree" + (", CU-result reuse (REUSE_CU_RESULTS)" if args.tools & 0x800 else "")
+                                + (", FAST_ALGORITHM partition classifier (shipped forest)" if args.tools & 0x1000 else "")
+                                + "; MIP/ISP/LFNST/MTS/TS/JCCR/LMCS/DepQuant/RDOQ of the reference's cfg not built yet",
                        "ctus_per_step": ctus_per_step, "parallelism": "1 workgroup per CTU stream, frames sharded over ranks"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "vvcx_compress_kernel_u8", "kernel_ms": 1e3 * avg_kernel_s,
@@ -135,10 +148,10 @@ def main():
             cw = min(ctus_w, 4)
             chh = max(1, n // cw)
             sw, sh = min(W, cw * 128), min(H, chh * 128)
-            planes = pkg.synth_frame(W, H, 0, 8, 1000)
+            planes = pkg.synth_frame(W, H, 0, 8, 1000, chroma_texture=args.chroma_texture)
             crop = [planes[0][:sh, :sw], planes[1][:sh // 2, :sw // 2], planes[2][:sh // 2, :sw // 2]]
             t1 = time.perf_counter()
-            O.compress_frame(crop, sw, sh, sp, tile_cols=(sw + 127) // 128, tile_rows=(sh + 127) // 128)
+            O.compress_frame(crop, sw, sh, sp, tile_cols=(sw + 127) // 128, tile_rows=(sh + 127) // 128, tools=args.tools, forest=forest)
             dt = time.perf_counter() - t1
             nct = ((sw + 127) // 128) * ((sh + 127) // 128)
             out["cpu_baseline"] = {"value": nct / dt, "unit": "CTU/s", "cores": 1, "kind": "port",

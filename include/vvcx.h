@@ -30,7 +30,8 @@ typedef enum {
 enum {
   VVCX_TOOL_MRL = 1 << 0, VVCX_TOOL_MIP = 1 << 1, VVCX_TOOL_ISP = 1 << 2, VVCX_TOOL_LFNST = 1 << 3, VVCX_TOOL_MTS = 1 << 4,
   VVCX_TOOL_TS = 1 << 5, VVCX_TOOL_DEPQUANT = 1 << 6, VVCX_TOOL_RDOQ = 1 << 7, VVCX_TOOL_CCLM = 1 << 8,
-  VVCX_TOOL_JCCR = 1 << 9, VVCX_TOOL_LMCS = 1 << 10, VVCX_TOOL_CU_REUSE = 1 << 11
+  VVCX_TOOL_JCCR = 1 << 9, VVCX_TOOL_LMCS = 1 << 10, VVCX_TOOL_CU_REUSE = 1 << 11,
+  VVCX_TOOL_FAST = 1 << 12      /* the fork's FAST_ALGORITHM (CL/TypeDef.h:54-56): features + forest pick the one partition mode of a luma node */
 };
 
 /* ≙ the EncCfg/SPS fields EncCu::create/init read (EL/EncCu.cpp:167-236, CL/Slice.h PreCalcValues 2229-2275) */
@@ -98,6 +99,13 @@ int  vvcx_create(const vvcx_cfg *cfg, vvcx_handle **h);
 void vvcx_destroy(vvcx_handle *h);
 /* ≙ EncSlice::setUpLambda + slice QP (EL/EncSlice.cpp:107-149, 1568-1572) */
 int  vvcx_set_slice(vvcx_handle *h, const vvcx_slice *s);
+/* ≙ the model the fork's classifier asks at every qualifying luma node: Py_Initialize + joblib.load("Partition_32.pkl").predict(x)
+ * per call (EL/EncCu.cpp:1140-1166, BIN/TEST.py:7-25), replaced by one upload of the forest's flattened sklearn tree arrays (host
+ * pointers): root[n_trees]; feature / left / right [n_nodes] (children -1 at leaves, children after their parent); threshold[n_nodes]
+ * (go left when float(x[feature]) <= threshold); value[n_nodes][n_classes] class distributions; classes[n_classes] = label of each
+ * column (0 do not split, 1 QT, 2 BT_H, 3 BT_V, 4 TT_H, 5 TT_V).  Needed before the first CTU when VVCX_TOOL_FAST is set. */
+int  vvcx_set_forest(vvcx_handle *h, int n_trees, int n_nodes, int n_classes, const int32_t *root, const int32_t *feature, const double *threshold,
+                     const int32_t *left, const int32_t *right, const double *value, const int32_t *classes);
 /* bind n pictures (device pointers) as the current batch and reset every CTU stream to its tile start
  * (≙ Picture::finalInit + the context reset of EL/EncSlice.cpp:1640-1647) */
 int  vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n);
@@ -154,6 +162,8 @@ int  vvcx_transform_quant_batch(const int16_t *org, const int16_t *pred, int w, 
                                 int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device);
 /* coefficient scan (diagonal, grouped) of a w x h block: idx[min(w,32) * min(h,32)] raster offsets in scan order */
 int  vvcx_scan_order(int w, int h, uint16_t *idx, int device);
+/* ≙ BIN/TEST.py GetPartition(C0..C25, 2): the forest of vvcx_set_forest on n rows of 26 int32 features (host pointers) → class per row */
+int  vvcx_forest_predict_batch(vvcx_handle *h, const int32_t *rows, int n, int32_t *out);
 
 #ifdef __cplusplus
 }

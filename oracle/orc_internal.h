@@ -119,6 +119,12 @@ void orc_cclm_luma(const int16_t *recY, int strideY, const uint8_t *avail, int a
                    int cx, int cy, int cw, int ch, int mdlm, int info[4], int16_t *tmp, int tstride);
 void orc_cclm_params(const int16_t *tmp, int tstride, const int16_t *ref, int cw, int ch, int mode, const int info[4], int bit_depth, int *pa, int *pb, int *pshift);
 void orc_pred_cclm(const int16_t *tmp, int tstride, int a, int b, int shift, int bit_depth, int cw, int ch, int16_t *pred, int pstride);
+/* FAST_ALGORITHM restatement (orc_fast.c) */
+typedef struct { int n_trees, n_nodes, n_classes; int32_t *root, *feature, *left, *right; double *threshold, *value; int32_t classes[8]; } orc_forest;
+int  orc_fast_region_var(const int16_t *p, int stride, int w, int h);
+void orc_fast_block_features(const int16_t *org, int stride, int w, int h, int feat[26]);
+void orc_fast_context_features(const int nb[][3], int n, int feat[26]);
+int  orc_forest_predict(const orc_forest *f, const int feat[26]);
 /* residual_coding on the estimator (orc_rate.c) */
 void orc_residual_coding(orc_cabac *c, const int16_t *level, int w, int h, int is_chroma);
 

@@ -80,6 +80,7 @@ struct orc_enc {
   double sqrt_lambda_fp;              /* sqrtLambdaForFirstPass */
   uint64_t cnt_satd, cnt_rd, cnt_rdpix, cnt_nodes, cnt_reuse;
   cache_ent *cache; int ctu_is_last;
+  orc_forest forest; int32_t *dump; int dump_cap, dump_n; uint64_t cnt_fast;
   /* scratch */
   int16_t *ref_unf, *ref_flt, *pred, *resi, *tmp_rec[2], *tmp_lev[2], *best_rec[2], *best_lev[2];
   int *coef;
@@ -88,7 +89,7 @@ struct orc_enc {
 /* ------------------------------------------------------------------------------------------------ */
 orc_enc *orc_create(const orc_cfg *cfg)
 {
-  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, CU reuse, CCLM)", cfg->tools); return 0; }
+  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, CU reuse, CCLM, FAST)", cfg->tools); return 0; }
   if (!cfg->dual_tree || cfg->ctu_size != 128) { snprintf(g_err, sizeof g_err, "oracle: only DualITree=1, CTUSize=128"); return 0; }
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7)) { snprintf(g_err, sizeof g_err, "oracle: picture size must be a multiple of 8 (EncAppCfg.cpp:2709)"); return 0; }
   orc_enc *e = (orc_enc *) calloc(1, sizeof *e);
@@ -120,7 +121,33 @@ void orc_destroy(orc_enc *e)
   for (int k = 0; k < 2; k++) { free(e->um[k]); free(e->avail[k]); free(e->tmp_rec[k]); free(e->tmp_lev[k]); free(e->best_rec[k]); free(e->best_lev[k]); }
   for (int d = 0; d < MAX_DEPTH; d++) { for (int c = 0; c < 3; c++) { free(e->store[d].rec[c]); free(e->store[d].lev[c]); } free(e->store[d].units); }
   for (int i = 0; i < CACHE_ENTRIES; i++) free(e->cache[i].lev);
+  free(e->forest.root); free(e->forest.feature); free(e->forest.left); free(e->forest.right); free(e->forest.threshold); free(e->forest.value);
   free(e->cache); free(e->ctu_tile); free(e->ref_unf); free(e->ref_flt); free(e->pred); free(e->resi); free(e->coef); free(e);
+}
+static void *dup_mem(const void *p, size_t n) { void *d = malloc(n ? n : 1); memcpy(d, p, n); return d; }
+int orc_set_forest(orc_enc *e, int n_trees, int n_nodes, int n_classes, const int32_t *root, const int32_t *feature, const double *threshold,
+                   const int32_t *left, const int32_t *right, const double *value, const int32_t *classes)
+{
+  if (n_trees < 1 || n_nodes < n_trees || n_classes < 1 || n_classes > 8) { snprintf(g_err, sizeof g_err, "oracle: bad forest shape"); return -1; }
+  for (int i = 0; i < n_nodes; i++)
+    if (left[i] >= 0 && (left[i] >= n_nodes || right[i] < 0 || right[i] >= n_nodes || feature[i] < 0 || feature[i] >= 26)) { snprintf(g_err, sizeof g_err, "oracle: forest node %d out of range", i); return -1; }
+  orc_forest *f = &e->forest;
+  free(f->root); free(f->feature); free(f->left); free(f->right); free(f->threshold); free(f->value);
+  f->n_trees = n_trees; f->n_nodes = n_nodes; f->n_classes = n_classes;
+  f->root = (int32_t *) dup_mem(root, (size_t) n_trees * 4); f->feature = (int32_t *) dup_mem(feature, (size_t) n_nodes * 4);
+  f->left = (int32_t *) dup_mem(left, (size_t) n_nodes * 4); f->right = (int32_t *) dup_mem(right, (size_t) n_nodes * 4);
+  f->threshold = (double *) dup_mem(threshold, (size_t) n_nodes * 8); f->value = (double *) dup_mem(value, (size_t) n_nodes * n_classes * 8);
+  for (int c = 0; c < n_classes; c++) f->classes[c] = classes[c];
+  return 0;
+}
+int orc_set_training_dump(orc_enc *e, int32_t *rows, int cap_rows) { e->dump = rows; e->dump_cap = cap_rows; e->dump_n = 0; return 0; }
+int orc_training_rows(const orc_enc *e) { return e->dump_n; }
+int orc_fast_features(const int16_t *org, int stride, int w, int h, int feat[26]) { memset(feat, 0, 26 * sizeof(int)); orc_fast_block_features(org, stride, w, h, feat); return 0; }
+int orc_forest_predict_rows(orc_enc *e, const int32_t *rows, int n, int32_t *out)
+{
+  if (!e->forest.n_trees) return -1;
+  for (int i = 0; i < n; i++) { int f[26]; for (int k = 0; k < 26; k++) f[k] = rows[i * 26 + k]; out[i] = orc_forest_predict(&e->forest, f); }
+  return 0;
 }
 int orc_set_slice(orc_enc *e, const orc_slice *s)
 {
@@ -881,6 +908,58 @@ static int use_mode_result(orc_enc *e, partitioner *P, cu_ctx *C, int mode, cons
 
 static void compress_cu(orc_enc *e, partitioner *P, int d, double maxCostAllowed, cs_sum *best);
 
+/* The fork's addition to xCompressCU (EL/EncCu.cpp:816-1217), luma tree only: features of the node and of its coded neighbour CUs,
+ * forest prediction, then the mode stack is replaced by the one predicted mode if the mode controller accepts it and — for the "fuzzy"
+ * and "complex" classes — it is not "do not split" (1195-1216, ChangeTestMode EL/EncModeCtrl.cpp:56-93).  The reference hard-codes its
+ * 416x240 test sequence as the picture size (833-834); the picture's own size is used here.  Neighbours are looked up with the
+ * tile-restricted get_cu so that tiles stay independent streams (the reference's unrestricted getCU also sees CUs of tiles coded
+ * earlier; identical for one tile).  Returns the row written to the training dump, or -1. */
+static int nb_info(const orc_enc *e, const unit_t *u, int out[3])
+{
+  out[0] = orc_fast_region_var(e->org[0] + u->y * e->stride[0] + u->x, e->stride[0], 1 << u->lw, 1 << u->lh);   /* get_context 137-163 */
+  out[1] = u->qt_depth; out[2] = u->mt_depth;
+  return 1;
+}
+static int fast_partition(orc_enc *e, partitioner *P, cu_ctx *C)
+{
+  const area_t a = P->cur;
+  const int x = a.x, y = a.y, w = imin(a.w, e->wl - a.x), h = imin(a.h, e->hl - a.y);     /* currCsArea is clipped to the picture (810) */
+  if (!(a.h < 128 && x + a.w <= e->wl && y + a.h <= e->hl)) return -1;                    /* 836 */
+  if (P->mt_depth == 3 || (h == 4 && w == 4)) return -1;                                  /* 838-846 */
+  int nb[5][3], n = 0;
+  const unit_t *cuL = get_cu(e, 0, x - 1, y), *cuU = get_cu(e, 0, x, y - 1), *cuLU = get_cu(e, 0, x - 1, y - 1);
+  if (cuL) {
+    n += nb_info(e, cuL, nb[n]);
+    const unit_t *cuLD = get_cu(e, 0, x - 1, y + (1 << cuL->lh) + 1);
+    if (cuLD && cuLD->y <= y + h) n += nb_info(e, cuLD, nb[n]);
+  }
+  if (cuU) {
+    n += nb_info(e, cuU, nb[n]);
+    const unit_t *cuRU = get_cu(e, 0, x + (1 << cuU->lw) + 1, y - 1);
+    if (cuRU && cuRU->x < x + w) n += nb_info(e, cuRU, nb[n]);
+  }
+  if (cuLU && !((cuLU->y + (1 << cuLU->lh)) > y || (cuLU->x + (1 << cuLU->lw)) > x)) n += nb_info(e, cuLU, nb[n]);
+  if (n < 3) return -1;                                                                   /* 933 */
+  int feat[27];
+  feat[0] = h; feat[1] = w; feat[2] = P->qt_depth; feat[3] = P->mt_depth;
+  orc_fast_block_features(e->org[0] + y * e->stride[0] + x, e->stride[0], w, h, feat);
+  orc_fast_context_features(nb, n, feat);
+  feat[26] = feat[10] < feat[13] ? 0 : feat[10] > feat[12] ? 2 : 1;                       /* simple / complex / fuzzy (1127-1138) */
+  e->cnt_fast++;
+  int row = -1;
+  if (e->dump && e->dump_n < e->dump_cap) { row = e->dump_n++; for (int k = 0; k < 27; k++) e->dump[row * 28 + k] = feat[k]; e->dump[row * 28 + 27] = -1; }
+  if (e->cfg.tools & ORC_TOOL_FAST) {
+    const int res = orc_forest_predict(&e->forest, feat);
+    if (res >= 0 && res <= 5) {
+      static const int mode_of[6] = { ETM_INTRA, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V };
+      int valid = try_mode(e, P, C, mode_of[res]);                                        /* tryModeMaster 1199 */
+      if (feat[26] >= 1 && res == 0) valid = 0;
+      if (valid) { C->modes[0] = mode_of[res]; C->nmodes = 1; }
+    }
+  }
+  return row;
+}
+
 /* xCheckRDCostIntra (EL/EncCu.cpp:2402-2777), single pass (no LFNST/MTS loops) */
 /* reconstruct one block from given levels: prediction in e->pred; DecCu::xIntraRecBlk (DL/DecCu.cpp:199-414) */
 static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int h, const int16_t *lev, int cbf, int16_t *rec_out)
@@ -988,7 +1067,7 @@ static void check_mode_split(orc_enc *e, partitioner *P, int d, cu_ctx *C, int m
   const double cost = rd_cost(e, (uint64_t) ((double) splitBits + ((double) best->bits / factor)), (uint64_t) ((double) best->dist / factor));
   if (cost > best->cost) return;                 /* xCheckBestMode with empty tempCS: nothing */
   cs_sum t; memset(&t, 0, sizeof t);
-  t.is_split = 1;
+  t.is_split = split;                                /* PartSplit code (1..5): also the training label */
   part_split(e, P, split);
   set_units(e, ch, a, 0, 0);                     /* tempCS->initStructData: nothing of this node is coded yet */
   int first = 1;
@@ -1029,6 +1108,8 @@ static void compress_cu(orc_enc *e, partitioner *P, int d, double maxCostAllowed
   const area_t a = P->cur; const int ch = P->ch;
   e->cnt_nodes++;
   init_cu_level(e, P, &C, d);
+  int dump_row = -1;
+  if (!ch && ((e->cfg.tools & ORC_TOOL_FAST) || e->dump)) dump_row = fast_partition(e, P, &C);
   orc_cabac ctxStart, ctxBest;
   orc_ctx_copy(&ctxStart, &e->cabac); orc_ctx_copy(&ctxBest, &e->cabac);
   memset(best, 0, sizeof *best); best->cost = ORC_MAX_DOUBLE;
@@ -1043,6 +1124,7 @@ static void compress_cu(orc_enc *e, partitioner *P, int d, double maxCostAllowed
     lastWasBest = (C.best != before) || (best->cost != costBefore);
   } while (next_mode(e, P, &C));
   (void) lastWasBest;
+  if (dump_row >= 0) e->dump[dump_row * 28 + 27] = best->cost == ORC_MAX_DOUBLE ? -1 : best->is_split;
   if (best->cost == ORC_MAX_DOUBLE) return;
   orc_ctx_copy(&e->cabac, &ctxBest);
   /* picture ← bestCS reco (1581-1582); CU info of the winner becomes visible to later nodes */
@@ -1120,6 +1202,7 @@ static void compress_ctu(orc_enc *e, int rx, int ry, orc_ctu_result *res)
 
 int orc_compress_frame(orc_enc *e, orc_ctu_result *res, orc_cu *cus, int max_cus, int *n_cus)
 {
+  if ((e->cfg.tools & ORC_TOOL_FAST) && !e->forest.n_trees) { snprintf(g_err, sizeof g_err, "oracle: ORC_TOOL_FAST needs orc_set_forest first"); return -1; }
   const int ntiles = e->cfg.tile_cols * e->cfg.tile_rows;
   for (int t = 0; t < ntiles; t++) {
     e->cur_tile = t;

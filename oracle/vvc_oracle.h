@@ -39,7 +39,8 @@ enum {
   ORC_TOOL_MRL   = 1 << 0,  /* multi-reference-line (compile-time always on in the reference) */
   ORC_TOOL_MIP   = 1 << 1, ORC_TOOL_ISP = 1 << 2, ORC_TOOL_LFNST = 1 << 3, ORC_TOOL_MTS = 1 << 4,
   ORC_TOOL_TS    = 1 << 5, ORC_TOOL_DEPQUANT = 1 << 6, ORC_TOOL_RDOQ = 1 << 7, ORC_TOOL_CCLM = 1 << 8,
-  ORC_TOOL_JCCR  = 1 << 9, ORC_TOOL_LMCS = 1 << 10, ORC_TOOL_CU_REUSE = 1 << 11
+  ORC_TOOL_JCCR  = 1 << 9, ORC_TOOL_LMCS = 1 << 10, ORC_TOOL_CU_REUSE = 1 << 11,
+  ORC_TOOL_FAST  = 1 << 12  /* the fork's FAST_ALGORITHM: features + forest decide the one partition mode a luma node tries (needs orc_set_forest) */
 };
 
 typedef struct {
@@ -96,6 +97,16 @@ const char *orc_last_error(void);
 int      orc_arith_encode(int qp, const int32_t *ops, int nops, uint8_t *out, int cap);
 long     orc_write_tiles(orc_enc *e, uint8_t *buf, long cap, int *sizes);   /* slice_data payload per tile (after orc_compress_frame) */
 int      orc_get_levels(orc_enc *e, int16_t *const lev[3]);
+/* FAST_ALGORITHM (orc_fast.c): the flattened random forest (sklearn tree_ arrays; value = n_nodes x n_classes leaf distributions;
+ * classes = label of each column, 0 no split, 1 QT, 2 BT_H, 3 BT_V, 4 TT_H, 5 TT_V like BIN/TEST.py's return value) */
+int      orc_set_forest(orc_enc *e, int n_trees, int n_nodes, int n_classes, const int32_t *root, const int32_t *feature, const double *threshold,
+                        const int32_t *left, const int32_t *right, const double *value, const int32_t *classes);
+/* counterpart of GET_TRAINING_SET: every luma node that qualifies for the classifier appends 28 ints to rows: the 26 features, the
+ * complexity class (0 simple, 1 fuzzy, 2 complex) and the partition the search chose there (0..5).  Returns rows written so far. */
+int      orc_set_training_dump(orc_enc *e, int32_t *rows, int cap_rows);
+int      orc_training_rows(const orc_enc *e);
+int      orc_fast_features(const int16_t *org, int stride, int w, int h, int feat[26]);   /* test hook: block features 4..11, 21..25 */
+int      orc_forest_predict_rows(orc_enc *e, const int32_t *rows, int n, int32_t *out);   /* test hook: forest on n rows of 26 ints */
 void     orc_get_counters(orc_enc *e, uint64_t out[4]); /* satd candidates, rd candidates, rd pixels, nodes */
 
 /* ---------------- leaf operators (individually testable; used by the golden-vector tests) -------- */

@@ -22,6 +22,7 @@ extern "C" __global__ void vvcx_leaf_pred_kernel_u16(VxParams p, const VxLeafPre
 extern "C" __global__ void vvcx_leaf_cabac_kernel(uint16_t *io, int ctx, const uint8_t *bins, int nbins, unsigned long long *bits);
 extern "C" __global__ void vvcx_leaf_rdcost_kernel(VxParams p, const unsigned long long *bits, const unsigned long long *dist, int n, double *cost);
 extern "C" __global__ void vvcx_leaf_scan_kernel(int w, int h, uint16_t *idx);
+extern "C" __global__ void vvcx_leaf_forest_kernel(VxParams p, const int32_t *rows, int n, int32_t *out);
 extern "C" __global__ void vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp, unsigned long long *out);
 
 static thread_local char g_err[512];
@@ -48,12 +49,14 @@ struct vvcx_handle {
   unsigned long long *counters_d;
   // optional slice_data writer: payload bytes per (frame, tile), byte ranges, persistent arithmetic-coder state
   uint8_t *payload_d; uint64_t *payload_off_d; uint32_t *payload_cap_d; void *arith_d; std::vector<uint64_t> payload_off; std::vector<uint32_t> payload_cap;
+  // FAST_ALGORITHM forest (vvcx_set_forest)
+  VxForestNode *f_node_d; double *f_value_d; int32_t *f_root_d; int f_ntrees, f_nclasses; int32_t f_classes[8];
   hipEvent_t ev0, ev1; float last_ms;
   size_t lev_plane[3], lev_frame, units_plane, units_frame;
 };
 
 #define VVCX_PAYLOAD_BYTES_PER_CTU 32768u
-static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM;
+static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST;
 
 extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
 {
@@ -114,8 +117,39 @@ extern "C" void vvcx_destroy(vvcx_handle *h)
   (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d);
   (void) hipFree(h->payload_d); (void) hipFree(h->payload_off_d); (void) hipFree(h->payload_cap_d); (void) hipFree(h->arith_d);
   (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
+  (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d);
   (void) hipEventDestroy(h->ev0); (void) hipEventDestroy(h->ev1);
   delete h;
+}
+
+// The partition forest of the FAST_ALGORITHM path (the reference: joblib.load("Partition_32.pkl").predict, BIN/TEST.py:21-25), as
+// flattened sklearn tree arrays; validated here so that the device walk cannot leave the arrays or loop.
+extern "C" int vvcx_set_forest(vvcx_handle *h, int n_trees, int n_nodes, int n_classes, const int32_t *root, const int32_t *feature, const double *threshold,
+                               const int32_t *left, const int32_t *right, const double *value, const int32_t *classes)
+{
+  if (!h || !root || !feature || !threshold || !left || !right || !value || !classes) return fail(VVCX_ERR_ARG, "null argument");
+  if (n_trees < 1 || n_nodes < n_trees || n_classes < 1 || n_classes > 8) return fail(VVCX_ERR_ARG, "forest shape");
+  std::vector<VxForestNode> nodes((size_t) n_nodes);
+  for (int i = 0; i < n_nodes; i++) {
+    if (left[i] >= 0) {
+      // children of sklearn trees always follow their parent in the node array: a walk therefore ends
+      if (left[i] <= i || right[i] <= i || left[i] >= n_nodes || right[i] >= n_nodes || feature[i] < 0 || feature[i] >= 26) return fail(VVCX_ERR_ARG, "forest node %d: child or feature index out of range", i);
+    }
+    nodes[(size_t) i].thr = threshold[i]; nodes[(size_t) i].left = left[i] >= 0 ? left[i] : -1; nodes[(size_t) i].right = right[i]; nodes[(size_t) i].feature = left[i] >= 0 ? feature[i] : 0; nodes[(size_t) i].pad = 0;
+  }
+  for (int t = 0; t < n_trees; t++) if (root[t] < 0 || root[t] >= n_nodes) return fail(VVCX_ERR_ARG, "forest root %d out of range", t);
+  for (int c = 0; c < n_classes; c++) if (classes[c] < 0 || classes[c] > 5) return fail(VVCX_ERR_ARG, "forest class label %d", classes[c]);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d); h->f_node_d = nullptr; h->f_value_d = nullptr; h->f_root_d = nullptr; h->f_ntrees = 0;
+  HIPCHK(hipMalloc((void **) &h->f_node_d, sizeof(VxForestNode) * (size_t) n_nodes));
+  HIPCHK(hipMalloc((void **) &h->f_value_d, sizeof(double) * (size_t) n_nodes * (size_t) n_classes));
+  HIPCHK(hipMalloc((void **) &h->f_root_d, sizeof(int32_t) * (size_t) n_trees));
+  HIPCHK(hipMemcpy(h->f_node_d, nodes.data(), sizeof(VxForestNode) * (size_t) n_nodes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->f_value_d, value, sizeof(double) * (size_t) n_nodes * (size_t) n_classes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->f_root_d, root, sizeof(int32_t) * (size_t) n_trees, hipMemcpyHostToDevice));
+  h->f_ntrees = n_trees; h->f_nclasses = n_classes;
+  for (int c = 0; c < 8; c++) h->f_classes[c] = c < n_classes ? classes[c] : 0;
+  return VVCX_OK;
 }
 
 extern "C" int vvcx_set_slice(vvcx_handle *h, const vvcx_slice *s)
@@ -183,6 +217,7 @@ extern "C" int vvcx_resident_streams(const vvcx_handle *h)
 
 extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int n, vvcx_ctu_result *out, void *hip_stream)
 {
+  if (h && (h->cfg.tools & VVCX_TOOL_FAST) && !h->f_ntrees) return fail(VVCX_ERR_STATE, "VVCX_TOOL_FAST needs vvcx_set_forest before the first CTU");
   if (!h || !tasks || !out || n < 0) return fail(VVCX_ERR_ARG, "bad argument");
   if (h->n_frames == 0) return fail(VVCX_ERR_STATE, "no frames bound");
   if (n == 0) return VVCX_OK;
@@ -234,6 +269,8 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
   p.frames = h->frames_d; p.streams = h->streams_d; p.task_ctu = h->task_ctu_d; p.results = h->results_d; p.stream_ctx = h->stream_ctx_d;
   p.payload = h->payload_d; p.payload_off = h->payload_off_d; p.payload_cap = h->payload_cap_d; p.arith_state = h->arith_d;
   p.scratch = h->scratch_d; p.scratch_per_stream = per_stream; p.counters = h->counters_d; p.ntiles = h->ntiles;
+  p.f_node = h->f_node_d; p.f_value = h->f_value_d; p.f_root = h->f_root_d; p.f_ntrees = h->f_ntrees; p.f_nclasses = h->f_nclasses;
+  for (int c = 0; c < 8; c++) p.f_classes[c] = h->f_classes[c];
 
   HIPCHK(hipEventRecord(h->ev0, stream));
   if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_compress_kernel_u8, dim3((unsigned) ns), dim3(VXD_NT), 0, stream, p);
@@ -429,6 +466,24 @@ extern "C" int vvcx_scan_order(int w, int h, uint16_t *idx, int device)
   hipLaunchKernelGGL(vvcx_leaf_scan_kernel, dim3(1), dim3(VXD_NT), 0, 0, w, h, d.as<uint16_t>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(idx, d.p, (size_t) n * 2, hipMemcpyDeviceToHost));
+  return VVCX_OK;
+}
+
+// ≙ GetPartition(C0..C25, 2) of BIN/TEST.py for n feature rows (26 int32 each, host pointers): the forest set with vvcx_set_forest
+extern "C" int vvcx_forest_predict_batch(vvcx_handle *h, const int32_t *rows, int n, int32_t *out)
+{
+  if (!h || !rows || !out || n < 0) return fail(VVCX_ERR_ARG, "bad argument");
+  if (!h->f_ntrees) return fail(VVCX_ERR_STATE, "vvcx_set_forest first");
+  if (n == 0) return VVCX_OK;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  DevBuf dr, dout; HIPCHK(dr.alloc((size_t) n * 26 * 4)); HIPCHK(dout.alloc((size_t) n * 4));
+  HIPCHK(hipMemcpy(dr.p, rows, (size_t) n * 26 * 4, hipMemcpyHostToDevice));
+  VxParams p; memset(&p, 0, sizeof p);
+  p.f_node = h->f_node_d; p.f_value = h->f_value_d; p.f_root = h->f_root_d; p.f_ntrees = h->f_ntrees; p.f_nclasses = h->f_nclasses;
+  for (int c = 0; c < 8; c++) p.f_classes[c] = h->f_classes[c];
+  hipLaunchKernelGGL(vvcx_leaf_forest_kernel, dim3((unsigned) ((n + VXD_NT - 1) / VXD_NT)), dim3(VXD_NT), 0, 0, p, dr.as<int32_t>(), n, dout.as<int32_t>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, dout.p, (size_t) n * 4, hipMemcpyDeviceToHost));
   return VVCX_OK;
 }
 

@@ -42,6 +42,8 @@ struct VxStreamDesc { int32_t frame, tile, first_task, n_tasks, done_before /* C
 
 struct VxCtuRes { uint64_t dist, bits; double cost; int32_t n_cu, pad; };
 
+struct VxForestNode { double thr; int32_t left, right, feature, pad; };     // left < 0: leaf
+
 struct VxParams {
   int32_t pic_w, pic_h, bit_depth, chroma;
   uint32_t tools;
@@ -64,6 +66,12 @@ struct VxParams {
   const uint64_t     *payload_off;
   const uint32_t     *payload_cap;
   void               *arith_state;
+  // FAST_ALGORITHM partition forest (optional): flattened sklearn trees, see include/vvcx.h vvcx_set_forest
+  const VxForestNode *f_node;
+  const double       *f_value;       // [n_nodes][f_nclasses] leaf distributions
+  const int32_t      *f_root;        // [f_ntrees]
+  int32_t             f_ntrees, f_nclasses;
+  int32_t             f_classes[8];
 };
 
 // per-stream scratch layout (bytes)

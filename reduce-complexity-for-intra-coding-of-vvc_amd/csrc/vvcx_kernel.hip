@@ -41,11 +41,12 @@ enum { SPLIT_NONE = 0, SPLIT_QT = 1, SPLIT_BH = 2, SPLIT_BV = 3, SPLIT_TH = 4, S
 enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V, ETM_RECO_CACHED };
 #define TOOL_CU_REUSE (1u << 11)
 #define TOOL_CCLM (1u << 8)
+#define TOOL_FAST (1u << 12)
 enum { LM_CHROMA = 67, MDLM_L = 68, MDLM_T = 69 };
 enum { PLANAR = 0, DC = 1, HOR = 18, DIA = 34, VER = 50, VDIA = 66, DM_CHROMA = 70 };
 enum { OP_NONE, OP_DONE, OP_LUMA_PREP, OP_STAGE_A, OP_STAGE_B, OP_CHROMA_RD, OP_SAVE_INTRA, OP_SAVE_PIC, OP_RESTORE_PIC,
-       OP_CLEAR_UNITS, OP_CTX_COPY, OP_REUSE };
-enum { PH_ENTER, PH_RUN, PH_A1_DONE, PH_A2_DONE, PH_B_DONE, PH_INTRA_SAVED, PH_CHILD, PH_CHILD_RET, PH_SPLIT_SAVED, PH_ADVANCE, PH_EXIT, PH_EXIT2 };
+       OP_CLEAR_UNITS, OP_CTX_COPY, OP_REUSE, OP_FAST };
+enum { PH_ENTER, PH_FAST_DONE, PH_RUN, PH_A1_DONE, PH_A2_DONE, PH_B_DONE, PH_INTRA_SAVED, PH_CHILD, PH_CHILD_RET, PH_SPLIT_SAVED, PH_ADVANCE, PH_EXIT, PH_EXIT2 };
 enum { CTX_CUR = 0, CTX_START = 1, CTX_BEST = 2, CTX_WAVE = 3 };   // OP_CTX_COPY endpoints
 
 struct Ctx { uint16_t s0[NCTX], s1[NCTX]; };
@@ -130,6 +131,7 @@ struct Lds {
                                     // parameter to them is a generic pointer into the kernarg copy in scratch / into HBM: flat loads with full waits)
   // CCLM: down-sampled luma of the chroma node (nodes of at most BUF chroma samples; bigger ones in HBM scratch), availability and line parameters
   alignas(16) int16_t lm_in[BUF / 2]; int16_t lm_top[64], lm_left[64]; int lm_info[4], lm_ok, lm_nsatd; int lm_par[2][3][3]; int64_t lm_cost[8];
+  int16_t fa_nb[5][4]; int fa_n, fa_res, fa_feat[27];      // FAST_ALGORITHM: neighbour CUs {x, y, w, h} of the node, forest answer, features
   Arith aw; uint8_t *aw_out; uint32_t aw_cap; int colm;      // bitstream pass: arithmetic coder, its output (HBM) and capacity; co-located luma mode of the chroma node
   unsigned long long prof[48];    // shader-clock ticks per operation kind (diagnostic, see vvcx_get_profile)
 };
@@ -2042,6 +2044,159 @@ __device__ __noinline__ void op_reuse(const VxParams &p_, const VxFrameDev &fd_,
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------ FAST_ALGORITHM (the fork's classifier path)
+// OP_FAST: the 26 features of a luma node (EL/EncCu.cpp:863-1123; OpenCV semantics as stated in oracle/orc_fast.c) and the random
+// forest's answer (BIN/TEST.py GetPartition).  Samples are staged once as 8-bit values in the LDS candidate slots (free at node
+// entry); each wave takes whole cells of the node's 4x4 grid, whose sums give every sub-block variance the features need.
+struct FaScratch {                 // overlays L.tmp
+  int cell[16][2];                 // Σ, Σ² of the samples of one grid cell
+  int wsum[NW][8];                 // per wave: Σ MADP, Σ MADP², Σ of the four saturated gradients, max quarter sum
+  int nbs[5][2];                   // Σ, Σ² over the original samples of each neighbour CU
+  int leaf[NT];                    // forest: leaf reached in tree t of the current chunk
+};
+__device__ inline int sat8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+__device__ inline int wave_max_i32(int v) { for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o > v ? o : v; } return v; }
+// cv::meanStdDev then stddev * stddev, truncated like the reference's int(var)
+__device__ inline int var_int(long long s, long long sq, int n)
+{
+  const double scale = 1.0 / (double) n, mean = (double) s * scale;
+  double var = (double) sq * scale - mean * mean;
+  if (var < 0) var = 0;
+  const double sd = sqrt(var);
+  return (int) (sd * sd);
+}
+template <typename T>
+__device__ __noinline__ void op_fast(const VxParams &p_, const VxFrameDev &fd_)
+{
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
+  const int tid = threadIdx.x, wave = uni(tid >> 6), lane = tid & 63;
+  const int x = uni(L.nx), y = uni(L.ny), w = uni(L.nw), h = uni(L.nh), P = w * h, lw = ilog2i(w);
+  uint8_t *px = (uint8_t *) &L.slot[0][0];
+  FaScratch &fa = *(FaScratch *) &L.tmp[0][0];
+  const void *org = fd.org[0]; const int st = fd.stride[0];
+  for (int i = tid; i < P; i += NT) px[i] = (uint8_t) sat8(ld_px<T>(org, (y + (i >> lw)) * st + x + (i & (w - 1))));
+  __threadfence_block();
+  __syncthreads();
+  {
+    int ms = 0, msq = 0, g0 = 0, g1 = 0, g2 = 0, g3 = 0, gmax = 0;
+    const int cw = w >> 2, chh = h >> 2, cp = cw * chh, lcw = ilog2i(cw);
+    for (int c = wave; c < 16; c += NW) {
+      const int cx0 = (c & 3) * cw, cy0 = (c >> 2) * chh;
+      int s = 0, sq = 0;
+      for (int k = lane; k < cp; k += 64) {
+        const int i = cx0 + (k & (cw - 1)), j = cy0 + (k >> lcw);
+        // 3x3 neighbourhood: v[] with reflect-101 coordinates for the gradient kernels, in[] = inside the block for MADP (73-134)
+        int v[9]; int sum = 0, n = 0;
+        for (int dj = -1; dj <= 1; dj++) for (int di = -1; di <= 1; di++) {
+          int xx = i + di, yy = j + dj;
+          const int inside = xx >= 0 && yy >= 0 && xx < w && yy < h;
+          if (xx < 0) xx = -xx;
+          if (xx >= w) xx = 2 * w - 2 - xx;
+          if (yy < 0) yy = -yy;
+          if (yy >= h) yy = 2 * h - 2 - yy;
+          v[(dj + 1) * 3 + di + 1] = px[yy * w + xx];
+          if (inside && (di | dj)) { n++; }
+        }
+        const int ctr = v[4];
+        for (int dj = -1; dj <= 1; dj++) for (int di = -1; di <= 1; di++) {
+          const int xx = i + di, yy = j + dj;
+          if ((di | dj) && xx >= 0 && yy >= 0 && xx < w && yy < h) sum += iabs(v[(dj + 1) * 3 + di + 1] - ctr);
+        }
+        const int m = n == 8 ? sum >> 3 : n == 5 ? sum / 5 : sum / 3;
+        ms += m; msq += m * m;
+        s += ctr; sq += ctr * ctr;
+        // kernels 997-1013: H {-1 0 1; -2 0 2; -1 0 1}, V {1 2 1; 0 0 0; -1 -2 -1}, 45 {0 1 2; -1 0 1; -2 -1 0}, 135 {2 1 0; 1 0 -1; 0 -1 -2}
+        const int a0 = sat8(-v[0] + v[2] - 2 * v[3] + 2 * v[5] - v[6] + v[8]);
+        const int a1 = sat8(v[0] + 2 * v[1] + v[2] - v[6] - 2 * v[7] - v[8]);
+        const int a2 = sat8(v[1] + 2 * v[2] - v[3] + v[5] - 2 * v[6] - v[7]);
+        const int a3 = sat8(2 * v[0] + v[1] + v[3] - v[5] - v[7] - 2 * v[8]);
+        g0 += a0; g1 += a1; g2 += a2; g3 += a3;
+        float t = (float) a0 * 0.25f + (float) a1 * 0.25f;                // Gra_H / 4 + Gra_V / 4 + ... on 8-bit matrices (1027)
+        int q = sat8((int) rintf(t));
+        t = (float) q + (float) a2 * 0.25f; q = sat8((int) rintf(t));
+        t = (float) q + (float) a3 * 0.25f; q = sat8((int) rintf(t));
+        gmax = q > gmax ? q : gmax;
+      }
+      s = wave_sum_i32(s); sq = wave_sum_i32(sq);
+      if (lane == 0) { fa.cell[c][0] = s; fa.cell[c][1] = sq; }
+    }
+    ms = wave_sum_i32(ms); msq = wave_sum_i32(msq); g0 = wave_sum_i32(g0); g1 = wave_sum_i32(g1); g2 = wave_sum_i32(g2); g3 = wave_sum_i32(g3);
+    gmax = wave_max_i32(gmax);
+    if (lane == 0) { int *o = fa.wsum[wave]; o[0] = ms; o[1] = msq; o[2] = g0; o[3] = g1; o[4] = g2; o[5] = g3; o[6] = gmax; }
+  }
+  {                                   // get_context 137-163: variance of the original samples of each neighbour CU
+    const int nn = uni(L.fa_n);
+    for (int k = wave; k < nn; k += NW) {
+      const int nx = uni(L.fa_nb[k][0]), ny = uni(L.fa_nb[k][1]), nw = uni(L.fa_nb[k][2]), nh = uni(L.fa_nb[k][3]), lnw = ilog2i(nw);
+      int s = 0, sq = 0;
+      for (int i = lane; i < nw * nh; i += 64) { const int v = sat8(ld_px<T>(org, (ny + (i >> lnw)) * st + nx + (i & (nw - 1)))); s += v; sq += v * v; }
+      s = wave_sum_i32(s); sq = wave_sum_i32(sq);
+      if (lane == 0) { fa.nbs[k][0] = s; fa.nbs[k][1] = sq; }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {
+    int *feat = L.fa_feat;
+    long long ms = 0, msq = 0, gs[4] = { 0, 0, 0, 0 }; int gmax = 0;
+    for (int k = 0; k < NW; k++) { ms += fa.wsum[k][0]; msq += fa.wsum[k][1]; for (int q = 0; q < 4; q++) gs[q] += fa.wsum[k][2 + q]; gmax = imax(gmax, fa.wsum[k][6]); }
+    const double G_H = (double) gs[0] / P, G_V = (double) gs[1] / P, G_45 = (double) gs[2] / P, G_135 = (double) gs[3] / P;
+    const double Gra = (G_H + G_V + G_45 + G_135) / 4;
+    feat[4] = (int) G_H; feat[5] = (int) G_V; feat[6] = (int) G_45; feat[7] = (int) G_135; feat[8] = (int) Gra; feat[9] = gmax;
+    // region (cx0..cx1, cy0..cy1) of the cell grid
+#define REGV(cx0_, cx1_, cy0_, cy1_) ([&]() { long long s_ = 0, q_ = 0; for (int cy_ = (cy0_); cy_ < (cy1_); cy_++) for (int cx_ = (cx0_); cx_ < (cx1_); cx_++) { s_ += fa.cell[cy_ * 4 + cx_][0]; q_ += fa.cell[cy_ * 4 + cx_][1]; } \
+                                        return var_int(s_, q_, ((cx1_) - (cx0_)) * ((cy1_) - (cy0_)) * (P >> 4)); }())
+    feat[10] = REGV(0, 4, 0, 4);
+    feat[11] = var_int(ms, msq, P);
+    { const int B1 = REGV(0, 4, 0, 2), B2 = REGV(0, 4, 2, 4), m = (B1 + B2) / 2; feat[21] = ((B1 - m) * (B1 - m) + (B2 - m) * (B2 - m)) / 2; }
+    { const int B1 = REGV(0, 2, 0, 4), B2 = REGV(2, 4, 0, 4), m = (B1 + B2) / 2; feat[22] = ((B1 - m) * (B1 - m) + (B2 - m) * (B2 - m)) / 2; }
+    { const int T1 = REGV(0, 4, 0, 1), T2 = REGV(0, 4, 1, 3), T3 = REGV(0, 4, 3, 4), m = (T1 + T2 + T3) / 3; feat[23] = ((T1 - m) * (T1 - m) + (T2 - m) * (T2 - m) + (T3 - m) * (T3 - m)) / 3; }
+    { const int T1 = REGV(0, 1, 0, 4), T2 = REGV(1, 3, 0, 4), T3 = REGV(3, 4, 0, 4), m = (T1 + T2 + T3) / 3; feat[24] = ((T1 - m) * (T1 - m) + (T2 - m) * (T2 - m) + (T3 - m) * (T3 - m)) / 3; }
+    { const int Q1 = REGV(0, 2, 0, 2), Q2 = REGV(2, 4, 0, 2), Q3 = REGV(0, 2, 2, 4), Q4 = REGV(2, 4, 2, 4), m = (Q1 + Q2 + Q3 + Q4) / 4;
+      feat[25] = ((Q1 - m) * (Q1 - m) + (Q2 - m) * (Q2 - m) + (Q3 - m) * (Q3 - m) + (Q4 - m) * (Q4 - m)) / 4; }
+#undef REGV
+    // neighbour statistics 943-983: variance features 12..14 (the depth features 15..20 were filled by the controller)
+    const int nn = L.fa_n;
+    int vmx = 0, vmn = 0, vsum = 0;
+    for (int k = 0; k < nn; k++) {
+      const int v = var_int(fa.nbs[k][0], fa.nbs[k][1], L.fa_nb[k][2] * L.fa_nb[k][3]);
+      if (k == 0 || v > vmx) vmx = v;
+      if (k == 0 || v < vmn) vmn = v;
+      vsum += v;
+    }
+    feat[12] = vmx; feat[13] = vmn; feat[14] = vsum / nn;
+    feat[26] = feat[10] < feat[13] ? 0 : feat[10] > feat[12] ? 2 : 1;          // simple / complex / fuzzy (1127-1138)
+  }
+  __threadfence_block();
+  __syncthreads();
+  // forest: one thread per tree walks to its leaf; thread 0 adds the leaf distributions in tree order (sklearn's predict_proba order)
+  double acc[8];
+  if (tid == 0) for (int c = 0; c < 8; c++) acc[c] = 0;
+  const int nt = p.f_ntrees, nc = p.f_nclasses;
+  for (int t0 = 0; t0 < nt; t0 += NT) {
+    const int t = t0 + tid;
+    if (t < nt) {
+      int n = p.f_root[t];
+      for (;;) {
+        const VxForestNode nd = p.f_node[n];
+        if (nd.left < 0) break;
+        n = ((double) (float) L.fa_feat[nd.feature] <= nd.thr) ? nd.left : nd.right;
+      }
+      fa.leaf[tid] = n;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) for (int k = 0; k < imin(NT, nt - t0); k++) { const double *v = p.f_value + (size_t) fa.leaf[k] * nc; for (int c = 0; c < nc; c++) acc[c] += v[c]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int best = 0;
+    for (int c = 1; c < nc; c++) if (acc[c] > acc[best]) best = c;
+    L.fa_res = p.f_classes[best];
+  }
+  __syncthreads();
+}
+
 // area copies between the picture (planes + unit map) and the level store / candidate slots
 template <typename T>
 __device__ __noinline__ void op_save_pic(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch, int restore)
@@ -2087,7 +2242,7 @@ __device__ __noinline__ void op_save_intra(const VxParams &p_, uint8_t *scratch,
   int16_t *srec = (int16_t *) lvl, *slev = (int16_t *) (lvl + VXD_STORE_REC);
   const int n = ch ? 2 * P : P;
   for (int i = threadIdx.x; i < n; i += NT) { srec[i] = rec[i]; slev[i] = lev[i]; }
-  if (p.tools & TOOL_CU_REUSE) {                       // setFromCs (939-985): the unsplit result is what tryMode(POST_DONT_SPLIT) caches right after
+  if ((p.tools & TOOL_CU_REUSE) && uni(L.op_c)) {      // setFromCs (939-985): the unsplit result is what tryMode(POST_DONT_SPLIT) caches right after
     int lo;
     const int e = uni(cache_slot(L.nx, L.ny, L.nw, L.nh, lo));
     if (e >= 0) {
@@ -2220,6 +2375,39 @@ __device__ void update_cand_list(Cand m, double cost, Cand *list, double *costs,
   }
 }
 
+// The fork's gate and neighbour lookups (EL/EncCu.cpp:836-933), thread 0: the node qualifies when it lies inside the picture, is smaller
+// than the CTU, is not 4x4, has mtDepth < 3 and at least three of the left / left-below / above / above-right / above-left CUs exist.
+// Neighbours come from the tile-restricted map (tiles stay independent streams; the reference's getCU is unrestricted).
+__device__ __noinline__ int fast_candidates(const VxParams &p_, const VxFrameDev &fd_, const Frame &f, int tile)
+{
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
+  const int x = f.x, y = f.y, w = f.w, h = f.h;
+  if (!(h < 128 && x + w <= p.pic_w && y + h <= p.pic_h)) return 0;
+  if (f.mt == 3 || (w == 4 && h == 4)) return 0;
+  int n = 0; int qmx = 0, qmn = 0, qs = 0, mmx = 0, mmn = 0, msum = 0;
+#define FA_ADD(u_) { L.fa_nb[n][0] = (u_)->x; L.fa_nb[n][1] = (u_)->y; L.fa_nb[n][2] = (int16_t) (1 << (u_)->lw); L.fa_nb[n][3] = (int16_t) (1 << (u_)->lh); \
+                     const int q_ = (u_)->qt, m_ = (u_)->mt; if (!n || q_ > qmx) qmx = q_; if (!n || q_ < qmn) qmn = q_; qs += q_; \
+                     if (!n || m_ > mmx) mmx = m_; if (!n || m_ < mmn) mmn = m_; msum += m_; n++; }
+  const VxUnit *cuL = get_cu(p, fd, 0, x - 1, y, tile), *cuU = get_cu(p, fd, 0, x, y - 1, tile), *cuLU = get_cu(p, fd, 0, x - 1, y - 1, tile);
+  if (cuL) {
+    FA_ADD(cuL);
+    const VxUnit *cuLD = get_cu(p, fd, 0, x - 1, y + (1 << cuL->lh) + 1, tile);
+    if (cuLD && cuLD->y <= y + h) FA_ADD(cuLD);
+  }
+  if (cuU) {
+    FA_ADD(cuU);
+    const VxUnit *cuRU = get_cu(p, fd, 0, x + (1 << cuU->lw) + 1, y - 1, tile);
+    if (cuRU && cuRU->x < x + w) FA_ADD(cuRU);
+  }
+  if (cuLU && !((cuLU->y + (1 << cuLU->lh)) > y || (cuLU->x + (1 << cuLU->lw)) > x)) FA_ADD(cuLU);
+#undef FA_ADD
+  if (n < 3) return 0;
+  L.fa_n = n;
+  int *feat = L.fa_feat;
+  feat[0] = h; feat[1] = w; feat[2] = f.qt; feat[3] = f.mt;
+  feat[15] = qmx; feat[16] = qmn; feat[17] = qs / n; feat[18] = mmx; feat[19] = mmn; feat[20] = msum / n;
+  return 1;
+}
 __device__ void post(int op) { L.op = op; }
 __device__ void set_node(const Frame &f, int d) { L.nx = f.x; L.ny = f.y; L.nw = f.w; L.nh = f.h; L.nd = d; }
 
@@ -2244,6 +2432,18 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
       if (f.nmodes == 0) { f.phase = PH_EXIT2; break; }
       f.phase = PH_RUN; f.ctx_dirty = 0;
       L.pre_copy_d = d;                                   // m_CurrCtx->start = ctx: done by the dispatch that runs the node's first operation
+      if ((p.tools & TOOL_FAST) && !ch && fast_candidates(p, fd, f, tile)) { f.phase = PH_FAST_DONE; set_node(f, d); post(OP_FAST); return; }
+      break;
+    }
+    case PH_FAST_DONE: {                                // EL/EncCu.cpp:1126-1217: replace the mode stack by the predicted mode if the controller accepts it
+      const int res = L.fa_res;
+      if (res >= 0 && res <= 5) {
+        const int mode = res == 0 ? ETM_INTRA : res == 1 ? ETM_SPLIT_QT : res == 2 ? ETM_SPLIT_BT_H : res == 3 ? ETM_SPLIT_BT_V : res == 4 ? ETM_SPLIT_TT_H : ETM_SPLIT_TT_V;
+        int valid = try_mode(p, d, ch, mode);                                             // tryModeMaster 1199
+        if (L.fa_feat[26] >= 1 && res == 0) valid = 0;
+        if (valid) { f.modes[0] = (uint8_t) mode; f.nmodes = 1; }                         // ChangeTestMode (EL/EncModeCtrl.cpp:56-93)
+      }
+      f.phase = PH_RUN;
       break;
     }
     case PH_RUN: {
@@ -2377,6 +2577,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         f.best = t; f.has_best = 1;
         f.phase = PH_ADVANCE;
         set_node(f, d);
+        L.op_c = f.nmodes > 1;                          // ETM_POST_DONT_SPLIT still on the stack (not a single predicted mode): its setFromCs caches this result
         post(OP_SAVE_INTRA); return;                    // store ← winner slot, ctxBest[d] ← wctx[0]
       }
       f.phase = PH_ADVANCE; break;
@@ -2591,6 +2792,7 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
       case OP_CLEAR_UNITS: op_clear_units(p, fd); break;
       case OP_CTX_COPY: ctx_copy_all(ctx_ptr(scratch, L.op_a, L.op_c, 0), ctx_ptr(scratch, L.op_b, L.op_c, 0)); __threadfence_block(); break;
       case OP_REUSE: op_reuse<T>(p, fd, scratch); break;
+      case OP_FAST: op_fast<T>(p, fd); break;
     }
     __syncthreads();
   }
@@ -2729,6 +2931,26 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_scan_kernel(
   __syncthreads();
   const ScanGeo g = scan_geo(w, h);
   for (int sp = threadIdx.x; sp < g.nscan; sp += NT) idx[sp] = (uint16_t) scan_blk(g, sp);
+}
+
+// forest inference on its own: one thread per feature row, trees in order (the sum order of OP_FAST and of sklearn's predict_proba)
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_forest_kernel(VxParams p, const int32_t *rows, int n, int32_t *out)
+{
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  double acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  for (int t = 0; t < p.f_ntrees; t++) {
+    int nd = p.f_root[t];
+    for (;;) {
+      const VxForestNode q = p.f_node[nd];
+      if (q.left < 0) break;
+      nd = ((double) (float) rows[i * 26 + q.feature] <= q.thr) ? q.left : q.right;
+    }
+    for (int c = 0; c < p.f_nclasses; c++) acc[c] += p.f_value[(size_t) nd * p.f_nclasses + c];
+  }
+  int best = 0;
+  for (int c = 1; c < p.f_nclasses; c++) if (acc[c] > acc[best]) best = c;
+  out[i] = p.f_classes[best];
 }
 
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_kernel_u8(VxParams p) { run_stream<uint8_t>(p); }

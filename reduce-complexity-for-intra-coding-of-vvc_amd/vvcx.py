@@ -13,6 +13,7 @@ DEFAULT_LIB = os.path.join(HERE, "libvvcx.so")
 TOOL_MRL = 1
 TOOL_CU_REUSE = 1 << 11      # BestEncInfoCache, REUSE_CU_RESULTS (CL/TypeDef.h:291) - on in the reference build
 TOOL_CCLM = 1 << 8           # LM / MDLM chroma modes (cfg LMChroma 1, on in the reference's intra configuration)
+TOOL_FAST = 1 << 12          # the fork's FAST_ALGORITHM: features + random forest pick the one partition mode of a luma node
 TOOLS_DEFAULT = TOOL_MRL | TOOL_CU_REUSE
 
 
@@ -70,6 +71,10 @@ def load_library(lib_path=None):
     L.vvcx_ctus_per_frame.argtypes = [C.c_void_p]
     if hasattr(L, "vvcx_resident_streams"):
         L.vvcx_resident_streams.argtypes = [C.c_void_p]
+    if hasattr(L, "vvcx_set_forest"):
+        L.vvcx_set_forest.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
+    if hasattr(L, "vvcx_forest_predict_batch"):
+        L.vvcx_forest_predict_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     if hasattr(L, "vvcx_get_payload"):
         L.vvcx_get_payload.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     if hasattr(L, "vvcx_distortion_batch"):
@@ -94,7 +99,7 @@ class VvcxEncoder:
     """≙ one EncCu instance (EL/EncCu.h:80-230): create/init → per-slice set-up → compressCtu calls → destroy."""
 
     def __init__(self, width, height, bit_depth=8, tile_cols=1, tile_rows=1, chroma=True, tools=TOOLS_DEFAULT,
-                 max_frames=1, device=0, lib_path=None, emit_payload=False):
+                 max_frames=1, device=0, lib_path=None, emit_payload=False, forest=None):
         self.L = load_library(lib_path)
         c = _Cfg()
         c.pic_w, c.pic_h, c.bit_depth, c.ctu_size = width, height, bit_depth, 128
@@ -110,6 +115,23 @@ class VvcxEncoder:
         self._chk(self.L.vvcx_create(C.byref(c), C.byref(self.h)))
         self.ctus_per_frame = self.L.vvcx_ctus_per_frame(self.h)
         self.n_frames = 0
+        if forest is not None:
+            self.set_forest(forest)
+
+    def set_forest(self, forest):
+        """forest: dict of flattened sklearn tree arrays (forest.py: load_forest / forest_from_sklearn); needed with TOOL_FAST"""
+        from .forest import check_forest
+        check_forest(forest)
+        self._chk(self.L.vvcx_set_forest(self.h, len(forest["root"]), len(forest["feature"]), len(forest["classes"]), forest["root"].ctypes.data,
+                                         forest["feature"].ctypes.data, forest["threshold"].ctypes.data, forest["left"].ctypes.data,
+                                         forest["right"].ctypes.data, forest["value"].ctypes.data, forest["classes"].ctypes.data))
+
+    def forest_predict(self, rows):
+        """the forest's class for each row of 26 int32 features (≙ BIN/TEST.py GetPartition)"""
+        rows = np.ascontiguousarray(rows, np.int32).reshape(-1, 26)
+        out = np.zeros(len(rows), np.int32)
+        self._chk(self.L.vvcx_forest_predict_batch(self.h, rows.ctypes.data, len(rows), out.ctypes.data))
+        return out
 
     def get_payload(self, frame, tile):
         """slice_data() bytes of one coded tile (needs emit_payload=True)"""

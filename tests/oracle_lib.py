@@ -90,8 +90,20 @@ def make_slice(sp):
     return s
 
 
-def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOLS_DEFAULT):
-    """Run the oracle on one frame; returns (ctu results, cu table, reco planes, counters)."""
+TOOL_FAST = 1 << 12
+
+
+def set_forest(L, e, forest):
+    L.orc_set_forest.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
+    rc = L.orc_set_forest(e, len(forest["root"]), len(forest["feature"]), len(forest["classes"]), forest["root"].ctypes.data, forest["feature"].ctypes.data,
+                          forest["threshold"].ctypes.data, forest["left"].ctypes.data, forest["right"].ctypes.data, forest["value"].ctypes.data, forest["classes"].ctypes.data)
+    if rc != 0:
+        raise RuntimeError(L.orc_last_error().decode())
+
+
+def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOLS_DEFAULT, forest=None, training_rows=None):
+    """Run the oracle on one frame; returns (ctu results, cu table, reco planes, counters).  forest: flattened random forest for
+    TOOL_FAST; training_rows: a list that receives the (n, 28) int32 array of the classifier's training rows of this frame."""
     L = lib()
     cfg = default_cfg(w, h, bit_depth, tile_cols, tile_rows, chroma, tools)
     e = L.orc_create(C.byref(cfg))
@@ -100,6 +112,13 @@ def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chro
     try:
         sl = make_slice(sp)
         L.orc_set_slice(e, C.byref(sl))
+        if forest is not None:
+            set_forest(L, e, forest)
+        dump = None
+        if training_rows is not None:
+            dump = np.zeros((((w + 127) // 128) * ((h + 127) // 128) * 6000, 28), np.int32)
+            L.orc_set_training_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            L.orc_set_training_dump(e, dump.ctypes.data, len(dump))
         bps = planes[0].dtype.itemsize
         planes = [np.ascontiguousarray(p) for p in planes]
         ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
@@ -116,6 +135,9 @@ def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chro
         L.orc_get_reco(e, rptrs, strides, bps)
         cnt = np.zeros(4, np.uint64)
         L.orc_get_counters(e, cnt.ctypes.data)
+        if dump is not None:
+            L.orc_training_rows.argtypes = [C.c_void_p]
+            training_rows.append(dump[:L.orc_training_rows(e)].copy())
         return res, cus[:n.value].copy(), reco, cnt
     finally:
         L.orc_destroy(e)

@@ -8,6 +8,7 @@ import pytest
 import oracle_lib as O
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda a: a.ctypes.data_as(C.c_void_p)
 
 
@@ -204,3 +205,37 @@ def test_cclm_prediction():
         pred = np.zeros(cw * chh, np.int16)
         L.orc_pred_cclm(P(tmp), tstride, a.value, b.value, sh.value, int(bd), cw, chh, P(pred), cw)
         assert np.array_equal(pred, exp), ("cclm", ei, comp, x, y, w, h, mode, a.value, b.value, sh.value, info)
+
+
+def test_partition_forest_matches_sklearn_and_classifier_shrinks_the_search():
+    """FAST_ALGORITHM (parity with the reference unpinned: no OpenCV, no Partition_32.pkl).  (1) The oracle's forest
+    inference on the shipped forest gives sklearn's own predict() of the same forest (tests/golden/forest.npz, written by
+    tools/train_partition_forest.py in the development container).  (2) With the classifier on, the search visits fewer nodes and
+    still yields a complete partition; the training dump labels are partition codes."""
+    import importlib
+    import ctypes as C
+    pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+    forest = pkg.load_forest(os.path.join(ROOT, "reduce-complexity-for-intra-coding-of-vvc_amd", "forests", "partition_qp32.npz"))
+    g = np.load(os.path.join(G, "forest.npz"))
+    L = O.lib()
+    cfg = O.default_cfg(128, 128)
+    e = L.orc_create(C.byref(cfg))
+    O.set_forest(L, e, forest)
+    rows = np.ascontiguousarray(g["rows"], np.int32); out = np.zeros(len(rows), np.int32)
+    L.orc_forest_predict_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    assert L.orc_forest_predict_rows(e, rows.ctypes.data, len(rows), out.ctypes.data) == 0
+    L.orc_destroy(e)
+    assert np.array_equal(out, g["sklearn_predict"]) and len(np.unique(out)) >= 4
+    W, H = 128, 128
+    planes = pkg.synth_frame(W, H, 0, 8, 7, chroma_texture=0.5); sp = pkg.slice_params(32)
+    dump = []
+    full = O.compress_frame(planes, W, H, sp, training_rows=dump)
+    fast = O.compress_frame(planes, W, H, sp, tools=O.TOOLS_DEFAULT | O.TOOL_FAST, forest=forest)
+    assert fast[3][3] < full[3][3] and fast[0]["cost"][0] >= full[0]["cost"][0]          # fewer nodes, never a better RD cost than the full search
+    cover = np.zeros((H, W), np.int32)
+    for c in fast[1][fast[1]["ch_type"] == 0]:
+        cover[c["y"]:c["y"] + c["h"], c["x"]:c["x"] + c["w"]] += 1
+    assert (cover == 1).all()
+    r = dump[0]
+    assert len(r) > 100 and ((r[:, 27] >= 0) & (r[:, 27] <= 5)).all() and ((r[:, 26] >= 0) & (r[:, 26] <= 2)).all()
+    assert (r[:, 0] <= 64).all() and (r[:, 1] <= 64).all() and (r[:, 3] < 3).all() and not ((r[:, 0] == 4) & (r[:, 1] == 4)).any()
