@@ -2,8 +2,9 @@
 
 Every picture of an All-Intra sequence is independent (IntraPeriod 1, BIN/encoder_intra.cfg) and so is every tile
 of a picture (contexts and neighbour availability reset at tile starts, EL/EncSlice.cpp:1640-1647), so ranks get
-disjoint frames and there is NO data-path collective.  The only exchanges are control-plane: a barrier around the
-timed region, MAX of the elapsed time, and (optionally) gathering the per-CTU summaries on rank 0.
+disjoint frames and there is NO collective inside the search.  The exchanges are: a barrier around the timed region, MAX
+of the elapsed time, (optionally) the per-CTU summaries on rank 0, and the one data-path step the job has - the final
+gather of every rank's slice_data bytes on rank 0 (gather_payloads; RCCL when the process group is "nccl").
 """
 import time
 
@@ -64,4 +65,48 @@ def gather_ctu_results(local, world):
     merged = {}
     for part in bucket:
         merged.update(part)
+    return merged
+
+
+def _gather_var(t, world, device):
+    """variable-length 1-D tensors of every rank on rank 0: all_gather of the lengths, then one gather of the padded tensors"""
+    import torch
+    d = _dist(world)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    d.all_gather(sizes, n)
+    sizes = [int(x.item()) for x in sizes]
+    cap = max(1, max(sizes))
+    pad = torch.zeros(cap, dtype=t.dtype, device=device)
+    pad[:t.numel()] = t.to(device)
+    bucket = [torch.zeros(cap, dtype=t.dtype, device=device) for _ in range(world)] if d.get_rank() == 0 else None
+    d.gather(pad, bucket, dst=0)
+    if bucket is None:
+        return None
+    return [b[:k].cpu() for b, k in zip(bucket, sizes)]
+
+
+def gather_payloads(local, world, device="cpu"):
+    """Final bitstream gather: local = {poc: [bytes of tile 0, tile 1, ...]} (numpy uint8 arrays) of this rank's frames; rank 0
+    gets {poc: [tile payloads]} of the whole job, other ranks None.  Two tensor collectives (an index of int64 triples and the
+    bytes) over the job's process group - RCCL over xGMI for backend "nccl" with device="cuda", gloo in the CPU tests."""
+    import numpy as np
+    import torch
+    if _dist(world) is None:
+        return {poc: [np.asarray(b, np.uint8) for b in tiles] for poc, tiles in local.items()}
+    index, chunks = [], []
+    for poc in sorted(local):
+        for t, b in enumerate(local[poc]):
+            index += [poc, t, len(b)]
+            chunks.append(np.asarray(b, np.uint8))
+    blob = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+    idx = _gather_var(torch.tensor(index, dtype=torch.int64), world, device)
+    data = _gather_var(torch.from_numpy(blob), world, device)
+    if idx is None:
+        return None
+    merged = {}
+    for ix, dat in zip(idx, data):
+        ix = ix.numpy().reshape(-1, 3); dat = dat.numpy(); off = 0
+        for poc, t, n in ix:
+            merged.setdefault(int(poc), []).append(dat[off:off + int(n)].copy()); off += int(n)
     return merged

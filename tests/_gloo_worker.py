@@ -19,7 +19,7 @@ def main():
     W = H = 32
     sp = pkg.slice_params(32)
     mine = pkg.frames_of_rank(n_frames, rank, world)
-    enc = pkg.VvcxEncoder(W, H, 8, max_frames=max(1, len(mine)), lib_path=emu_so)
+    enc = pkg.VvcxEncoder(W, H, 8, max_frames=max(1, len(mine)), lib_path=emu_so, emit_payload=True)
     enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
     org = [[np.ascontiguousarray(p) for p in pkg.synth_frame(W, H, poc, 8, 1000 + poc)] for poc in mine]
     rec = [[np.zeros_like(p) for p in f] for f in org]
@@ -38,12 +38,15 @@ def main():
 
     elapsed, outs = pkg.timed_steps(step, 1, 0, world)
     merged = pkg.gather_ctu_results(local, world)
+    streams = pkg.gather_payloads({poc: [enc.get_payload(i, 0)] for i, poc in enumerate(mine)}, world)     # the final bitstream gather
     if rank == 0:
         import oracle_lib as O
-        ok = sorted(merged) == list(range(n_frames))
+        ok = sorted(merged) == list(range(n_frames)) and sorted(streams) == list(range(n_frames))
         for poc, res in merged.items():
-            ores = O.compress_frame(pkg.synth_frame(W, H, poc, 8, 1000 + poc), W, H, sp)[0]
+            planes = pkg.synth_frame(W, H, poc, 8, 1000 + poc)
+            ores = O.compress_frame(planes, W, H, sp)[0]
             ok = ok and all(np.array_equal(ores[k], res[k]) for k in ores.dtype.names)
+            ok = ok and np.array_equal(streams[poc][0], O.write_frame(planes, W, H, sp)[0])
         json.dump({"ok": bool(ok), "frames": sorted(int(k) for k in merged), "elapsed": elapsed, "world": world}, open(out_path, "w"))
     dist.destroy_process_group()
 
