@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--bit-depth", type=int, default=8, choices=(8, 10), help="10: uint16 planes (BASELINE configs 4 and 5), algorithmic bytes double")
     ap.add_argument("--frames", type=str, default="auto",
                     help="frames per step and rank; auto = enough frames for ~4 full waves of resident CTU streams")
     ap.add_argument("--tiles", type=str, default="auto", help="CxR uniform tile grid; auto = one tile per CTU")
@@ -86,23 +87,25 @@ def main():
         tc, tr = ctus_w, ctus_h
     else:
         tc, tr = map(int, args.tiles.lower().split("x"))
-    sp = pkg.slice_params(args.qp)
+    sp = pkg.slice_params(args.qp, bit_depth=args.bit_depth)
+    bd = args.bit_depth
+    b_ctu = B_CTU_8BIT * (2 if bd == 10 else 1)
     forest = None
     if args.classifier:
         args.tools |= pkg.TOOL_FAST
         forest = pkg.load_forest(os.path.join(ROOT, "reduce-complexity-for-intra-coding-of-vvc_amd", "forests", "partition_qp32.npz"))
     if args.frames == "auto":
-        probe = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, device=dev, lib_path=args.lib, tools=args.tools, forest=forest)
+        probe = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, device=dev, lib_path=args.lib, tools=args.tools, forest=forest)
         args.frames = max(1, (4 * probe.resident_streams()) // (tc * tr))
         probe.close()
     else:
         args.frames = int(args.frames)
-    enc = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, chroma=True, max_frames=args.frames, device=dev, lib_path=args.lib, tools=args.tools, forest=forest)
+    enc = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, chroma=True, max_frames=args.frames, device=dev, lib_path=args.lib, tools=args.tools, forest=forest)
     enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
     frames = []
     for poc in pkg.frames_of_rank(args.frames * world, rank, world):      # weak scaling: args.frames per rank
-        planes = pkg.synth_frame(W, H, poc, 8, 1000 + poc, chroma_texture=args.chroma_texture)
-        org = [torch.from_numpy(p).cuda() for p in planes]
+        planes = pkg.synth_frame(W, H, poc, bd, 1000 + poc, chroma_texture=args.chroma_texture)
+        org = [torch.from_numpy(p if bd == 8 else p.view(np.int16)).cuda() for p in planes]      # 16-bit containers: same bits, a dtype torch can hold
         rec = [torch.zeros_like(t) for t in org]
         frames.append((org, rec))
     bind = [([t.data_ptr() for t in o], [t.data_ptr() for t in r], [t.shape[1] for t in o]) for o, r in frames]
@@ -121,9 +124,9 @@ def main():
         total_ctus = ctus_per_step * args.steps * world
         value = total_ctus / elapsed
         avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
-        achieved = ctus_per_step * B_CTU_8BIT / avg_kernel_s / 1e9
-        workload = ("%dx%d 8-bit 4:2:0 All-Intra QP%d full RDO, tools 0x%x, chroma texture %.2f, %d frame(s)/step/GPU, %dx%d uniform tiles = %d CTU streams per frame"
-                    % (W, H, args.qp, args.tools, args.chroma_texture, args.frames, tc, tr, tc * tr))
+        achieved = ctus_per_step * b_ctu / avg_kernel_s / 1e9
+        workload = ("%dx%d %d-bit 4:2:0 All-Intra QP%d full RDO, tools 0x%x, chroma texture %.2f, %d frame(s)/step/GPU, %dx%d uniform tiles = %d CTU streams per frame"
+                    % (W, H, bd, args.qp, args.tools, args.chroma_texture, args.frames, tc, tr, tc * tr))
         traffic, traffic_src = pmc_traffic(workload)
         out = {
             "metric": "CTUs/sec (All-Intra, QP32)", "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps,
@@ -136,8 +139,8 @@ def main():
                                 + "; MIP/ISP/LFNST/MTS/TS/JCCR/LMCS/DepQuant/RDOQ of the reference's cfg not built yet",
                        "ctus_per_step": ctus_per_step, "parallelism": "1 workgroup per CTU stream, frames sharded over ranks"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "vvcx_compress_kernel_u8", "kernel_ms": 1e3 * avg_kernel_s,
-                         "algorithmic_bytes_per_launch": ctus_per_step * B_CTU_8BIT},
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "vvcx_compress_kernel_u8" if bd == 8 else "vvcx_compress_kernel_u16", "kernel_ms": 1e3 * avg_kernel_s,
+                         "algorithmic_bytes_per_launch": ctus_per_step * b_ctu},
             "work": {"satd_candidates_per_launch": int(counters[0]), "rd_tu_evaluations_per_launch": int(counters[1]),
                      "rd_pixels_per_launch": int(counters[2]), "nodes_per_launch": int(counters[3]),
                      "rd_pixels_per_s": float(counters[2]) / avg_kernel_s},
@@ -148,10 +151,10 @@ def main():
             cw = min(ctus_w, 4)
             chh = max(1, n // cw)
             sw, sh = min(W, cw * 128), min(H, chh * 128)
-            planes = pkg.synth_frame(W, H, 0, 8, 1000, chroma_texture=args.chroma_texture)
+            planes = pkg.synth_frame(W, H, 0, bd, 1000, chroma_texture=args.chroma_texture)
             crop = [planes[0][:sh, :sw], planes[1][:sh // 2, :sw // 2], planes[2][:sh // 2, :sw // 2]]
             t1 = time.perf_counter()
-            O.compress_frame(crop, sw, sh, sp, tile_cols=(sw + 127) // 128, tile_rows=(sh + 127) // 128, tools=args.tools, forest=forest)
+            O.compress_frame(crop, sw, sh, sp, tile_cols=(sw + 127) // 128, tile_rows=(sh + 127) // 128, tools=args.tools, forest=forest, bit_depth=bd)
             dt = time.perf_counter() - t1
             nct = ((sw + 127) // 128) * ((sh + 127) // 128)
             out["cpu_baseline"] = {"value": nct / dt, "unit": "CTU/s", "cores": 1, "kind": "port",

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""BASELINE config 3: classifier on the device at QP {22, 27, 32, 37} against the full search (the anchor) on the same synthetic
+frames: bits (real slice_data bytes of the device's arithmetic coder), PSNR, kernel time, and the Bjontegaard delta rate.
+
+  python tools/bd_rate.py [--frames 8] [--width 1920 --height 1080] [--out profiles/r01e_bdrate.json]      (needs a GPU)
+
+The anchor is this library's full RDO search with the same tool subset (bit-exact with the CPU oracle), not a VTM binary: the
+reference encoder cannot be built in this image."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def bd_rate(r_anchor, p_anchor, r_test, p_test):
+    """Bjontegaard delta rate (VCEG-M33): cubic fit of log10(rate) over PSNR, integrated over the common PSNR interval; percent."""
+    la, lt = np.log10(r_anchor), np.log10(r_test)
+    ca, ct = np.polyfit(p_anchor, la, 3), np.polyfit(p_test, lt, 3)
+    lo, hi = max(min(p_anchor), min(p_test)), min(max(p_anchor), max(p_test))
+    ia, it = np.polyint(ca), np.polyint(ct)
+    avg = ((np.polyval(it, hi) - np.polyval(it, lo)) - (np.polyval(ia, hi) - np.polyval(ia, lo))) / (hi - lo)
+    return float((10.0 ** avg - 1.0) * 100.0)
+
+
+def encode(pkg, torch, W, H, frames, qp, tools, forest, tc, tr):
+    sp = pkg.slice_params(qp)
+    enc = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, tools=tools, max_frames=len(frames), emit_payload=True, forest=forest)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    dev = []
+    for planes in frames:
+        org = [torch.from_numpy(p).cuda() for p in planes]
+        dev.append((org, [torch.zeros_like(t) for t in org]))
+    enc.bind_frames([([t.data_ptr() for t in o], [t.data_ptr() for t in r], [t.shape[1] for t in o]) for o, r in dev])
+    enc.compress_bound_frames()
+    ms = enc.last_kernel_ms()
+    nbytes = sum(len(enc.get_payload(f, t)) for f in range(len(frames)) for t in range(tc * tr))
+    sse = [0.0, 0.0, 0.0]; npx = [0, 0, 0]
+    for planes, (o, r) in zip(frames, dev):
+        for c in range(3):
+            d = o[c].to(torch.float64) - r[c].to(torch.float64)
+            sse[c] += float((d * d).sum().item()); npx[c] += d.numel()
+    psnr = [10 * np.log10(255.0 ** 2 / (sse[c] / npx[c])) for c in range(3)]
+    cnt = [int(v) for v in enc.counters()]
+    enc.close()
+    return dict(qp=qp, bits=8 * nbytes, psnr_y=psnr[0], psnr_u=psnr[1], psnr_v=psnr[2], psnr_yuv=(6 * psnr[0] + psnr[1] + psnr[2]) / 8, kernel_ms=ms, nodes=cnt[3])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--chroma-texture", type=float, default=0.5)
+    ap.add_argument("--out", type=str, default=None)
+    args = ap.parse_args()
+    import torch
+    pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+    W, H = args.width, args.height
+    tc, tr = (W + 127) // 128, (H + 127) // 128
+    frames = [pkg.synth_frame(W, H, poc, 8, 1000 + poc, chroma_texture=args.chroma_texture) for poc in range(args.frames)]
+    base = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM
+    rows = {"anchor": [], "classifier": []}
+    for qp in (22, 27, 32, 37):
+        forest = pkg.load_forest(os.path.join(ROOT, "reduce-complexity-for-intra-coding-of-vvc_amd", "forests", "partition_qp%d.npz" % qp))
+        rows["anchor"].append(encode(pkg, torch, W, H, frames, qp, base, None, tc, tr))
+        rows["classifier"].append(encode(pkg, torch, W, H, frames, qp, base | pkg.TOOL_FAST, forest, tc, tr))
+        a, t = rows["anchor"][-1], rows["classifier"][-1]
+        print("QP %d: anchor %d bits %.2f dB %.0f ms | classifier %d bits %.2f dB %.0f ms (x%.2f)" % (qp, a["bits"], a["psnr_y"], a["kernel_ms"], t["bits"], t["psnr_y"], t["kernel_ms"], a["kernel_ms"] / t["kernel_ms"]), flush=True)
+    ra = [r["bits"] for r in rows["anchor"]]; rt = [r["bits"] for r in rows["classifier"]]
+    out = {"workload": "%dx%d 8-bit 4:2:0, %d synthetic frames, chroma texture %.2f, one tile per CTU, tools 0x%x vs 0x%x" % (W, H, args.frames, args.chroma_texture, base, base | pkg.TOOL_FAST),
+           "bd_rate_y_percent": bd_rate(ra, [r["psnr_y"] for r in rows["anchor"]], rt, [r["psnr_y"] for r in rows["classifier"]]),
+           "bd_rate_yuv_percent": bd_rate(ra, [r["psnr_yuv"] for r in rows["anchor"]], rt, [r["psnr_yuv"] for r in rows["classifier"]]),
+           "kernel_time_saving_percent": 100.0 * (1.0 - sum(r["kernel_ms"] for r in rows["classifier"]) / sum(r["kernel_ms"] for r in rows["anchor"])),
+           "ctus_per_s": {k: [args.frames * tc * tr / (r["kernel_ms"] / 1e3) for r in v] for k, v in rows.items()},
+           "points": rows}
+    print(json.dumps({k: out[k] for k in ("bd_rate_y_percent", "bd_rate_yuv_percent", "kernel_time_saving_percent", "ctus_per_s")}))
+    if args.out:
+        json.dump(out, open(os.path.join(ROOT, args.out) if not os.path.isabs(args.out) else args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
