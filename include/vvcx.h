@@ -88,6 +88,7 @@ typedef struct {
   uint8_t  intra_dir;            /* luma mode 0..66; chroma mode (70 = DM) */
   uint8_t  mrl_idx;              /* multiRefIdx */
   uint8_t  cbf;                  /* bit0 Y, bit1 Cb, bit2 Cr */
+  uint8_t  mts_idx;              /* tu.mtsIdx of the luma TU: 0 DCT2xDCT2, 2..5 explicit MTS (VVCX_TOOL_MTS) */
   uint64_t split_series;         /* CU::splitSeries, 5 bits per depth */
 } vvcx_cu;
 

@@ -127,5 +127,6 @@ void orc_fast_context_features(const int nb[][3], int n, int feat[26]);
 int  orc_forest_predict(const orc_forest *f, const int feat[26]);
 /* residual_coding on the estimator (orc_rate.c) */
 void orc_residual_coding(orc_cabac *c, const int16_t *level, int w, int h, int is_chroma);
+void orc_residual_coding_mts(orc_cabac *c, const int16_t *level, int w, int h, int is_chroma, int mts_idx);
 
 #endif

@@ -66,29 +66,65 @@ void orc_inv_1d(int tr, int n, const int *src, int *dst, int shift, int line, in
 static int ilog2(int v) { int r = 0; while (v > 1) { v >>= 1; r++; } return r; }
 
 /* CL/TrQuant.cpp:835-915 xT, DCT2/DCT2, no LFNST: zero-out above 32 (853-854), shifts 892-893 */
-void orc_fwd_2d(const int16_t *resi, int stride, int w, int h, int bit_depth, int *coef)
+/* explicit MTS (getTrTypes 817-830): mts_idx 0 DCT2xDCT2; 2..5: horizontal = (idx-2)&1 ? DCT8 : DST7, vertical = (idx-2)>>1 ? DCT8 : DST7
+ * (orc_fwd_1d numbering: 0 DCT2, 1 DCT8, 2 DST7) */
+static void mts_types(int mts_idx, int *trh, int *trv)
 {
+  if (mts_idx < 2) { *trh = *trv = 0; return; }
+  *trh = ((mts_idx - 2) & 1) ? 1 : 2; *trv = ((mts_idx - 2) >> 1) ? 1 : 2;
+}
+void orc_fwd_2d_mts(const int16_t *resi, int stride, int w, int h, int bit_depth, int mts_idx, int *coef)
+{
+  int trh, trv; mts_types(mts_idx, &trh, &trv);
   int *block = (int *) malloc(sizeof(int) * w * h * 2), *tmp = block + w * h;
   for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) block[y * w + x] = resi[y * stride + x];
-  const int skipW = w > 32 ? w - 32 : 0, skipH = h > 32 ? h - 32 : 0;
+  const int skipW = (trh != 0 && w == 32) ? 16 : w > 32 ? w - 32 : 0, skipH = (trv != 0 && h == 32) ? 16 : h > 32 ? h - 32 : 0;   /* 853-854 */
   const int shift1 = ilog2(w) + bit_depth + 6 - 15;
   const int shift2 = ilog2(h) + 6;
-  orc_fwd_1d(0, w, block, tmp, shift1, h, 0, skipW);
-  orc_fwd_1d(0, h, tmp, coef, shift2, w, skipW, skipH);
+  orc_fwd_1d(trh, w, block, tmp, shift1, h, 0, skipW);
+  orc_fwd_1d(trv, h, tmp, coef, shift2, w, skipW, skipH);
   free(block);
 }
+void orc_fwd_2d(const int16_t *resi, int stride, int w, int h, int bit_depth, int *coef) { orc_fwd_2d_mts(resi, stride, w, h, bit_depth, 0, coef); }
 
 /* CL/TrQuant.cpp:917-992 xIT */
-void orc_inv_2d(const int *coef, int w, int h, int bit_depth, int16_t *resi, int stride)
+void orc_inv_2d_mts(const int *coef, int w, int h, int bit_depth, int mts_idx, int16_t *resi, int stride)
 {
+  int trh, trv; mts_types(mts_idx, &trh, &trv);
   int *tmp = (int *) malloc(sizeof(int) * w * h * 2), *block = tmp + w * h;
-  const int skipW = w > 32 ? w - 32 : 0, skipH = h > 32 ? h - 32 : 0;
+  const int skipW = (trh != 0 && w == 32) ? 16 : w > 32 ? w - 32 : 0, skipH = (trv != 0 && h == 32) ? 16 : h > 32 ? h - 32 : 0;
   const int cmin = -(1 << 15), cmax = (1 << 15) - 1;
   const int shift1 = 6 + 1, shift2 = (6 + 15 - 1) - bit_depth;
-  orc_inv_1d(0, h, coef, tmp, shift1, w, skipW, skipH, cmin, cmax);
-  orc_inv_1d(0, w, tmp, block, shift2, h, 0, skipW, cmin, cmax);
+  orc_inv_1d(trv, h, coef, tmp, shift1, w, skipW, skipH, cmin, cmax);
+  orc_inv_1d(trh, w, tmp, block, shift2, h, 0, skipW, cmin, cmax);
   for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) resi[y * stride + x] = (int16_t) block[y * w + x];
   free(tmp);
+}
+void orc_inv_2d(const int *coef, int w, int h, int bit_depth, int16_t *resi, int stride) { orc_inv_2d_mts(coef, w, h, bit_depth, 0, resi, stride); }
+
+/* TrQuant::transformNxN, pruning overload (CL/TrQuant.cpp:1049-1124) for the candidate list {DCT2, 2, 3, 4, 5} (no transform skip):
+ * sum |coeff| per transform; an entry stays when its sum <= fac * sum(DCT2) — list position 1 is compared against sum(DCT2) itself, the
+ * reference's transform-skip threshold applied by position — and no more than max_cand + 1 entries are kept, in list order. */
+void orc_mts_prune(const int16_t *resi, int stride, int w, int h, int bit_depth, int max_cand, int test[5])
+{
+  static const double facBB[5] = { 1.2, 1.3, 1.3, 1.4, 1.5 };
+  static const int idx_of[5] = { 0, 2, 3, 4, 5 };
+  int *coef = (int *) malloc(sizeof(int) * w * h);
+  int sums[5];
+  for (int k = 0; k < 5; k++) {
+    orc_fwd_2d_mts(resi, stride, w, h, bit_depth, idx_of[k], coef);
+    int sa = 0;
+    for (int i = 0; i < w * h; i++) sa += coef[i] < 0 ? -coef[i] : coef[i];
+    sums[k] = sa;
+  }
+  free(coef);
+  const double fac = facBB[ilog2(w > h ? w : h) - 2];
+  const double thr = fac * sums[0], thrTS = sums[0];
+  int numTests = 0;
+  for (int k = 0; k < 5; k++) {
+    const int t = (double) sums[k] <= (k == 1 ? thrTS : thr) && numTests <= max_cand;
+    test[k] = t; numTests += t;
+  }
 }
 
 /* CL/Quant.cpp:994-1089 Quant::quant without scaling lists / sign hiding; I-slice rounding 171<<(qbits-9).

@@ -89,8 +89,15 @@ static void enc_rem_abs(orc_cabac *cb, unsigned bins, unsigned rice)
   orc_enc_bins_ep(cb, ((code - ((1u << prefix) - 1)) << rice) | (bins & ((1u << rice) - 1)), (int) suffix);
 }
 
-void orc_residual_coding(orc_cabac *cb, const int16_t *coeff, int w, int h, int is_chroma)
+void orc_residual_coding(orc_cabac *cb, const int16_t *coeff, int w, int h, int is_chroma) { orc_residual_coding_mts(cb, coeff, w, h, is_chroma, -1); }
+/* mts_idx: -1 = no MTS syntax for this block (TU::isMTSAllowed false); otherwise tu.mtsIdx (0 DCT2, 2..5) */
+void orc_residual_coding_mts(orc_cabac *cb, const int16_t *coeff, int w, int h, int is_chroma, int mts_idx)
 {
+  if (mts_idx >= 0) {                 /* mts_coding (3885-3941), transform skip not allowed, JVET_O0294 context assignment */
+    orc_enc_bin(cb, mts_idx != 0, ORC_CTX_MTSIndex + 0);
+    if (mts_idx) for (int i = 0; i < 3; i++) { const int sym = mts_idx > i + 2; orc_enc_bin(cb, (unsigned) sym, ORC_CTX_MTSIndex + 7 + i); if (!sym) break; }
+  }
+  const int zo = mts_idx > 1;         /* 32-point DST-VII / DCT-VIII keep 16 coefficients (getTbAreaAfterCoefZeroOut, CL/Unit.cpp:872-890) */
   cctx_t c; memset(&c, 0, sizeof c);
   c.w = w; c.h = h; c.ch = is_chroma;
   orc_cg_shape(w, h, &c.lcw, &c.lch); c.lcg = c.lcw + c.lch;
@@ -127,7 +134,7 @@ void orc_residual_coding(orc_cabac *cb, const int16_t *coeff, int w, int h, int 
     if (gy > 3) orc_enc_bins_ep(cb, (uint32_t) (posY - ORC_MIN_IN_GROUP[gy]), (gy - 2) >> 1);
   }
   /* regular-bin budget (3859-3860): TbAreaAfterCoefZeroOut * 28 >> 4 */
-  c.reg_bins = (imin(32, w) * imin(32, h) * 28) >> 4;
+  c.reg_bins = ((zo && w == 32 ? 16 : imin(32, w)) * (zo && h == 32 ? 16 : imin(32, h)) * 28) >> 4;
 
   const int cgSize = 1 << c.lcg;
   for (int sub = scanPosLast >> c.lcg; sub >= 0; sub--) {
@@ -138,6 +145,7 @@ void orc_residual_coding(orc_cabac *cb, const int16_t *coeff, int w, int h, int 
     const int sigRight = (cgPosX + 1) < c.wg ? c.sig_group[cgPos + 1] : 0;
     const int sigLower = (cgPosY + 1) < c.hg ? c.sig_group[cgPos + c.wg] : 0;
     const int sigGroupCtx = ORC_CTX_SigCoeffGroup[c.ch] + (sigRight | sigLower);
+    if (zo && ((h == 32 && cgPosY >= (16 >> c.lch)) || (w == 32 && cgPosX >= (16 >> c.lcw)))) continue;   /* 3866-3877: sub-blocks of the zeroed area are not coded */
     /* residual_coding_subblock (4164-4304) */
     const int isLast = (scanPosLast >> c.lcg) == sub, isNotFirst = sub != 0;
     const int firstSigPos = isLast ? scanPosLast : maxSub;

@@ -33,7 +33,7 @@ enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_B
 typedef struct { int x, y, w, h; } area_t;   /* luma samples (UnitArea::Y) */
 
 typedef struct {       /* per 4x4-luma-unit record of the CU covering it, one map per channel type */
-  uint8_t valid, tile, qt_depth, mt_depth, bt_depth, depth, dir, mrl, cbf, lw, lh;
+  uint8_t valid, tile, qt_depth, mt_depth, bt_depth, depth, dir, mrl, cbf, lw, lh, mts;
   int16_t x, y;        /* CU origin in channel samples */
   uint64_t split_series;
 } unit_t;
@@ -60,7 +60,7 @@ typedef struct {       /* what the mode controller reads from a CodingStructure 
  * 4-sample units, log2 w, log2 h) like m_bestEncInfo[x][y][wIdx][hIdx] (EL/EncModeCtrl.cpp:706-760).  The reference
  * keeps entries across CTUs and rejects stale ones by comparing poc and absolute area (987-1024); clearing at every
  * CTU start is equivalent.  lev: w*h luma levels, or Cb then Cr (cw*ch each). */
-typedef struct { uint8_t valid, ch, dir, mrl, cbf, depth; uint64_t ss; int16_t *lev; } cache_ent;
+typedef struct { uint8_t valid, ch, dir, mrl, cbf, depth, mts; uint64_t ss; int16_t *lev; } cache_ent;
 #define CACHE_ENTRIES (32 * 32 * 6 * 6)
 
 #define MAX_DEPTH 20
@@ -82,14 +82,14 @@ struct orc_enc {
   cache_ent *cache; int ctu_is_last;
   orc_forest forest; int32_t *dump; int dump_cap, dump_n; uint64_t cnt_fast;
   /* scratch */
-  int16_t *ref_unf, *ref_flt, *pred, *resi, *tmp_rec[2], *tmp_lev[2], *best_rec[2], *best_lev[2];
+  int16_t *ref_unf, *ref_flt, *pred, *resi, *resi_org, *tmp_rec[2], *tmp_lev[2], *best_rec[2], *best_lev[2];
   int *coef;
 };
 
 /* ------------------------------------------------------------------------------------------------ */
 orc_enc *orc_create(const orc_cfg *cfg)
 {
-  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, CU reuse, CCLM, FAST)", cfg->tools); return 0; }
+  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MTS, CU reuse, CCLM, FAST)", cfg->tools); return 0; }
   if (!cfg->dual_tree || cfg->ctu_size != 128) { snprintf(g_err, sizeof g_err, "oracle: only DualITree=1, CTUSize=128"); return 0; }
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7)) { snprintf(g_err, sizeof g_err, "oracle: picture size must be a multiple of 8 (EncAppCfg.cpp:2709)"); return 0; }
   orc_enc *e = (orc_enc *) calloc(1, sizeof *e);
@@ -110,7 +110,7 @@ orc_enc *orc_create(const orc_cfg *cfg)
   }
   e->cache = (cache_ent *) calloc(CACHE_ENTRIES, sizeof(cache_ent));
   e->ref_unf = (int16_t *) malloc(2 * 300 * 300); e->ref_flt = (int16_t *) malloc(2 * 300 * 300);
-  e->pred = (int16_t *) malloc(128 * 128 * 2); e->resi = (int16_t *) malloc(128 * 128 * 2); e->coef = (int *) malloc(128 * 128 * 4);
+  e->pred = (int16_t *) malloc(128 * 128 * 2); e->resi = (int16_t *) malloc(128 * 128 * 2); e->resi_org = (int16_t *) malloc(128 * 128 * 2); e->coef = (int *) malloc(128 * 128 * 4);
   for (int k = 0; k < 2; k++) { e->tmp_rec[k] = (int16_t *) malloc(128 * 128 * 2); e->tmp_lev[k] = (int16_t *) malloc(128 * 128 * 2); e->best_rec[k] = (int16_t *) malloc(128 * 128 * 2); e->best_lev[k] = (int16_t *) malloc(128 * 128 * 2); }
   return e;
 }
@@ -122,7 +122,7 @@ void orc_destroy(orc_enc *e)
   for (int d = 0; d < MAX_DEPTH; d++) { for (int c = 0; c < 3; c++) { free(e->store[d].rec[c]); free(e->store[d].lev[c]); } free(e->store[d].units); }
   for (int i = 0; i < CACHE_ENTRIES; i++) free(e->cache[i].lev);
   free(e->forest.root); free(e->forest.feature); free(e->forest.left); free(e->forest.right); free(e->forest.threshold); free(e->forest.value);
-  free(e->cache); free(e->ctu_tile); free(e->ref_unf); free(e->ref_flt); free(e->pred); free(e->resi); free(e->coef); free(e);
+  free(e->cache); free(e->ctu_tile); free(e->ref_unf); free(e->ref_flt); free(e->pred); free(e->resi); free(e->resi_org); free(e->coef); free(e);
 }
 static void *dup_mem(const void *p, size_t n) { void *d = malloc(n ? n : 1); memcpy(d, p, n); return d; }
 int orc_set_forest(orc_enc *e, int n_trees, int n_nodes, int n_classes, const int32_t *root, const int32_t *feature, const double *threshold,
@@ -490,15 +490,18 @@ static void enc_intra_chroma_pred_mode(orc_enc *e, area_t a, int dir, int lm_ok)
  * (EL/IntraSearch.cpp:2852-3168, CL/TrQuant.cpp:1127-1235)
  * comp: 0 Y 1 Cb 2 Cr; x,y,w,h in component samples; writes rec_out / lev_out tiles (stride w)
  * ---------------------------------------------------------------------------------------------- */
-static uint64_t code_tu_block(orc_enc *e, int comp, int x, int y, int w, int h, int16_t *rec_out, int16_t *lev_out, int *cbf)
+static uint64_t code_tu_block_mts(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int16_t *rec_out, int16_t *lev_out, int *cbf);
+static uint64_t code_tu_block(orc_enc *e, int comp, int x, int y, int w, int h, int16_t *rec_out, int16_t *lev_out, int *cbf) { return code_tu_block_mts(e, comp, x, y, w, h, 0, rec_out, lev_out, cbf); }
+static uint64_t code_tu_block_mts(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int16_t *rec_out, int16_t *lev_out, int *cbf)
 {
   const int st = e->stride[comp], bd = e->cfg.bit_depth;
   const int16_t *org = e->org[comp] + y * st + x;
   const int qp = (comp ? e->sl.qp_c[comp - 1] : e->sl.qp) + 6 * (e->cfg.bit_depth - 8);    /* QpParam: + QpBDOffset (CL/Quant.cpp:68-106) */
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) e->resi[j * w + i] = (int16_t) (org[j * st + i] - e->pred[j * w + i]);
-  orc_fwd_2d(e->resi, w, w, h, bd, e->coef);
+  if (!comp) memcpy(e->resi_org, e->resi, (size_t) w * h * 2);      /* the MTS pruning works on the prediction residual */
+  orc_fwd_2d_mts(e->resi, w, w, h, bd, mts_idx, e->coef);
   const int abs_sum = orc_quant(e->coef, w, h, bd, qp, lev_out);
-  if (abs_sum > 0) { orc_dequant(lev_out, w, h, bd, qp, e->coef); orc_inv_2d(e->coef, w, h, bd, e->resi, w); }
+  if (abs_sum > 0) { orc_dequant(lev_out, w, h, bd, qp, e->coef); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
   else memset(e->resi, 0, (size_t) w * h * 2);
   const int mx = (1 << bd) - 1;
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) { int v = e->pred[j * w + i] + e->resi[j * w + i]; rec_out[j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
@@ -538,7 +541,9 @@ static void update_cand_list(minfo m, double cost, minfo *list, double *costs, i
  * estIntraPredLumaQT (EL/IntraSearch.cpp:289-1380), P0 subset.  Leaves the winner's reco/levels in
  * e->best_rec[0]/best_lev[0] (stride w).  Returns dist; *dir,*mrl,*cbf the winner.
  * ---------------------------------------------------------------------------------------------- */
-static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out_mrl, int *out_cbf)
+/* TU::isMTSAllowed (CL/UnitTools.cpp:4549-4565) for an intra luma TU without ISP / BDPCM: explicit intra MTS on, both sides <= 32 */
+static int mts_allowed(const orc_enc *e, int w, int h) { return (e->cfg.tools & ORC_TOOL_MTS) && w <= 32 && h <= 32; }
+static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts)
 {
   const int x = a.x, y = a.y, w = a.w, h = a.h, bd = e->cfg.bit_depth;
   orc_cabac ctxStart; orc_ctx_copy(&ctxStart, &e->cabac);
@@ -612,7 +617,7 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
   }
 
   /* stage B: full RD (1158-1358) */
-  double bestCost = ORC_MAX_DOUBLE; uint64_t bestDist = 0; int bestDir = 0, bestMrl = 0, bestCbf = 0;
+  double bestCost = ORC_MAX_DOUBLE; uint64_t bestDist = 0; int bestDir = 0, bestMrl = 0, bestCbf = 0, bestMts = 0;
   for (int m = 0; m < numRd; m++) {
     const int dir = rdList[m].mode, mrl = rdList[m].mrl;
     orc_ctx_copy(&e->cabac, &ctxStart);
@@ -620,21 +625,42 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
     orc_ipa ip; orc_init_pred_params(w, h, 1, dir, mrl, &ip);
     build_refs(e, 0, x, y, w, h, mrl, ip.ref_filter);
     orc_pred_intra(e->ref_unf, e->ref_flt, w, h, 1, dir, mrl, bd, e->pred, w);
-    int cbf;
-    const uint64_t dist = code_tu_block(e, 0, x, y, w, h, e->tmp_rec[0], e->tmp_lev[0], &cbf);
-    /* xGetIntraFracBitsQT(luma): header + cbf + coefficients */
-    e->cabac.bits = 0;
-    enc_intra_luma_pred_mode(e, x, y, w, h, dir, mrl);
-    orc_enc_bin(&e->cabac, (unsigned) cbf, ORC_CTX_QtCbf[0] + 0);
-    if (cbf) orc_residual_coding(&e->cabac, e->tmp_lev[0], w, h, 0);
-    const double cost = rd_cost(e, e->cabac.bits, dist);
-    if (cost < bestCost) {
-      bestCost = cost; bestDist = dist; bestDir = dir; bestMrl = mrl; bestCbf = cbf;
+    /* xRecurIntraCodingLumaQT 3340-3640 without LFNST / transform skip: transform candidates {DCT2} or, where TU::isMTSAllowed,
+     * {DCT2, 2, 3, 4, 5} pruned by TrQuant::transformNxN (1049-1124) on the first (DCT2) pass; every further candidate starts from the
+     * start contexts; the loop ends after DCT2 when its cbf is 0; an MTS candidate with cbf 0 is forbidden (cost MAX) */
+    const int mtsAllowed = mts_allowed(e, w, h);
+    int test[5] = { 1, 0, 0, 0, 0 };
+    static const int idx_of[5] = { 0, 2, 3, 4, 5 };
+    double modeCost = ORC_MAX_DOUBLE; uint64_t modeDist = 0; int modeCbf = 0, modeMts = 0, cbfDCT2 = 1;
+    for (int k = 0; k < (mtsAllowed ? 5 : 1); k++) {
+      if (!cbfDCT2) break;
+      if (!test[k]) continue;
+      if (k) orc_ctx_copy(&e->cabac, &ctxStart);
+      int cbf;
+      const uint64_t dist = code_tu_block_mts(e, 0, x, y, w, h, idx_of[k], e->tmp_rec[1], e->tmp_lev[1], &cbf);
+      if (k == 0 && mtsAllowed) orc_mts_prune(e->resi_org, w, w, h, bd, 3 /* MTSIntraMaxCand, BIN/encoder_intra.cfg */, test);
+      double cost = ORC_MAX_DOUBLE;
+      if (!(k && !cbf)) {
+        /* xGetIntraFracBitsQT(luma): header + cbf + [mts_idx +] coefficients */
+        e->cabac.bits = 0;
+        enc_intra_luma_pred_mode(e, x, y, w, h, dir, mrl);
+        orc_enc_bin(&e->cabac, (unsigned) cbf, ORC_CTX_QtCbf[0] + 0);
+        if (cbf) orc_residual_coding_mts(&e->cabac, e->tmp_lev[1], w, h, 0, mtsAllowed ? idx_of[k] : -1);
+        cost = rd_cost(e, e->cabac.bits, dist);
+      }
+      if (cost < modeCost) {
+        modeCost = cost; modeDist = dist; modeCbf = cbf; modeMts = idx_of[k];
+        if (k == 0) cbfDCT2 = cbf;
+        memcpy(e->tmp_rec[0], e->tmp_rec[1], (size_t) w * h * 2); memcpy(e->tmp_lev[0], e->tmp_lev[1], (size_t) w * h * 2);
+      }
+    }
+    if (modeCost < bestCost) {
+      bestCost = modeCost; bestDist = modeDist; bestDir = dir; bestMrl = mrl; bestCbf = modeCbf; bestMts = modeMts;
       memcpy(e->best_rec[0], e->tmp_rec[0], (size_t) w * h * 2); memcpy(e->best_lev[0], e->tmp_lev[0], (size_t) w * h * 2);
     }
   }
   orc_ctx_copy(&e->cabac, &ctxStart);
-  *out_dir = bestDir; *out_mrl = bestMrl; *out_cbf = bestCbf;
+  *out_dir = bestDir; *out_mrl = bestMrl; *out_cbf = bestCbf; *out_mts = bestMts;
   return bestDist;
 }
 
@@ -800,7 +826,7 @@ static void cache_set_from_cs(orc_enc *e, const partitioner *P, int d)
   const area_t a = P->cur; const int ch = P->ch;
   cache_ent *c = cache_entry(e, a);
   const unit_t *u = &e->store[d].units[0];
-  c->valid = 1; c->ch = (uint8_t) ch; c->dir = u->dir; c->mrl = u->mrl; c->cbf = u->cbf; c->depth = u->depth; c->ss = u->split_series;
+  c->valid = 1; c->ch = (uint8_t) ch; c->dir = u->dir; c->mrl = u->mrl; c->cbf = u->cbf; c->depth = u->depth; c->mts = u->mts; c->ss = u->split_series;
   if (!c->lev) c->lev = (int16_t *) malloc((size_t) a.w * a.h * 2);
   if (!ch) memcpy(c->lev, e->store[d].lev[0], (size_t) a.w * a.h * 2);
   else { const size_t n = (size_t) (a.w >> 1) * (a.h >> 1); memcpy(c->lev, e->store[d].lev[1], n * 2); memcpy(c->lev + n, e->store[d].lev[2], n * 2); }
@@ -962,12 +988,12 @@ static int fast_partition(orc_enc *e, partitioner *P, cu_ctx *C)
 
 /* xCheckRDCostIntra (EL/EncCu.cpp:2402-2777), single pass (no LFNST/MTS loops) */
 /* reconstruct one block from given levels: prediction in e->pred; DecCu::xIntraRecBlk (DL/DecCu.cpp:199-414) */
-static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int h, const int16_t *lev, int cbf, int16_t *rec_out)
+static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int h, const int16_t *lev, int cbf, int mts_idx, int16_t *rec_out)
 {
   const int st = e->stride[comp], bd = e->cfg.bit_depth, mx = (1 << bd) - 1;
   const int16_t *org = e->org[comp] + y * st + x;
   const int qp = (comp ? e->sl.qp_c[comp - 1] : e->sl.qp) + 6 * (e->cfg.bit_depth - 8);    /* QpParam: + QpBDOffset (CL/Quant.cpp:68-106) */
-  if (cbf) { orc_dequant(lev, w, h, bd, qp, e->coef); orc_inv_2d(e->coef, w, h, bd, e->resi, w); }
+  if (cbf) { orc_dequant(lev, w, h, bd, qp, e->coef); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
   else memset(e->resi, 0, (size_t) w * h * 2);
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) { int v = e->pred[j * w + i] + e->resi[j * w + i]; rec_out[j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
   uint64_t dd = orc_sse(org, st, rec_out, w, w, h);
@@ -975,7 +1001,7 @@ static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int
   return dd;
 }
 /* xReuseCachedResult (EL/EncCu.cpp:5665-5771): cached mode + levels re-reconstructed against the current neighbourhood */
-static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *out_mrl, int *out_cbf)
+static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts)
 {
   const cache_ent *c = cache_entry(e, a);
   const int bd = e->cfg.bit_depth;
@@ -985,7 +1011,7 @@ static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *ou
     orc_ipa ip; orc_init_pred_params(a.w, a.h, 1, c->dir, c->mrl, &ip);
     build_refs(e, 0, a.x, a.y, a.w, a.h, c->mrl, ip.ref_filter);
     orc_pred_intra(e->ref_unf, e->ref_flt, a.w, a.h, 1, c->dir, c->mrl, bd, e->pred, a.w);
-    dist = recon_from_levels(e, 0, a.x, a.y, a.w, a.h, c->lev, c->cbf & 1, e->best_rec[0]);
+    dist = recon_from_levels(e, 0, a.x, a.y, a.w, a.h, c->lev, c->cbf & 1, c->mts, e->best_rec[0]);
     memcpy(e->best_lev[0], c->lev, (size_t) a.w * a.h * 2);
   } else {
     const int cx = a.x >> 1, cy = a.y >> 1, cw = a.w >> 1, chh = a.h >> 1;
@@ -994,11 +1020,11 @@ static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *ou
     if (fm >= 67 && fm <= 69) cclm_luma(e, cx, cy, cw, chh, fm != 67, tmpC, infoC);
     for (int k = 1; k <= 2; k++) {
       pred_chroma_comp(e, k, cx, cy, cw, chh, fm, tmpC, infoC);
-      dist += recon_from_levels(e, k, cx, cy, cw, chh, c->lev + (size_t) (k - 1) * cw * chh, (c->cbf >> k) & 1, e->best_rec[k - 1]);
+      dist += recon_from_levels(e, k, cx, cy, cw, chh, c->lev + (size_t) (k - 1) * cw * chh, (c->cbf >> k) & 1, 0, e->best_rec[k - 1]);
       memcpy(e->best_lev[k - 1], c->lev + (size_t) (k - 1) * cw * chh, (size_t) cw * chh * 2);
     }
   }
-  *out_dir = c->dir; *out_mrl = c->mrl; *out_cbf = c->cbf;
+  *out_dir = c->dir; *out_mrl = c->mrl; *out_cbf = c->cbf; *out_mts = c->mts;
   return dist;
 }
 
@@ -1010,17 +1036,17 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
   cu.x = (int16_t) (a.x >> sh); cu.y = (int16_t) (a.y >> sh); cu.lw = (uint8_t) ilog2(a.w >> sh); cu.lh = (uint8_t) ilog2(a.h >> sh);
   cu.qt_depth = (uint8_t) P->qt_depth; cu.mt_depth = (uint8_t) P->mt_depth; cu.bt_depth = (uint8_t) P->bt_depth; cu.depth = (uint8_t) P->depth;
   cu.split_series = part_split_series(P);
-  int dir = 0, mrl = 0, cbf = 0;
-  if (reuse) t.dist = reuse_cached(e, a, ch, &dir, &mrl, &cbf);
-  else if (!ch) t.dist = est_intra_pred_luma(e, a, &dir, &mrl, &cbf), cbf = cbf ? 1 : 0;
+  int dir = 0, mrl = 0, cbf = 0, mts = 0;
+  if (reuse) t.dist = reuse_cached(e, a, ch, &dir, &mrl, &cbf, &mts);
+  else if (!ch) t.dist = est_intra_pred_luma(e, a, &dir, &mrl, &cbf, &mts), cbf = cbf ? 1 : 0;
   else t.dist = est_intra_pred_chroma(e, a, cclm_allowed(e, a, cu.split_series, cu.depth), &dir, &cbf);
-  cu.dir = (uint8_t) dir; cu.mrl = (uint8_t) mrl; cu.cbf = (uint8_t) cbf;
+  cu.dir = (uint8_t) dir; cu.mrl = (uint8_t) mrl; cu.cbf = (uint8_t) cbf; cu.mts = (uint8_t) mts;
   /* CU-level rate from the node's start contexts (2593-2620) */
   e->cabac.bits = 0;
   if (!ch) {
     enc_intra_luma_pred_mode(e, a.x, a.y, a.w, a.h, dir, mrl);
     orc_enc_bin(&e->cabac, (unsigned) (cbf & 1), ORC_CTX_QtCbf[0]);
-    if (cbf & 1) orc_residual_coding(&e->cabac, e->best_lev[0], a.w, a.h, 0);
+    if (cbf & 1) orc_residual_coding_mts(&e->cabac, e->best_lev[0], a.w, a.h, 0, mts_allowed(e, a.w, a.h) ? mts : -1);
   } else {
     enc_intra_chroma_pred_mode(e, a, dir, cclm_allowed(e, a, cu.split_series, cu.depth));
     orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 2), ORC_CTX_QtCbf[1]);
@@ -1152,7 +1178,7 @@ static void walk_tree(orc_enc *e, partitioner *P)
   if (!ch) {
     enc_intra_luma_pred_mode(e, a.x, a.y, a.w, a.h, u->dir, u->mrl);
     orc_enc_bin(&e->cabac, u->cbf & 1, ORC_CTX_QtCbf[0]);
-    if (u->cbf & 1) { for (int y = 0; y < H; y++) memcpy(lv + y * W, e->lev[0] + (a.y + y) * e->stride[0] + a.x, (size_t) W * 2); orc_residual_coding(&e->cabac, lv, W, H, 0); }
+    if (u->cbf & 1) { for (int y = 0; y < H; y++) memcpy(lv + y * W, e->lev[0] + (a.y + y) * e->stride[0] + a.x, (size_t) W * 2); orc_residual_coding_mts(&e->cabac, lv, W, H, 0, mts_allowed(e, W, H) ? u->mts : -1); }
   } else {
     enc_intra_chroma_pred_mode(e, a, u->dir, cclm_allowed(e, a, u->split_series, u->depth));
     orc_enc_bin(&e->cabac, !!(u->cbf & 2), ORC_CTX_QtCbf[1]);
@@ -1222,7 +1248,7 @@ int orc_compress_frame(orc_enc *e, orc_ctu_result *res, orc_cu *cus, int max_cus
           orc_cu *o = &cus[n];
           o->x = u->x; o->y = u->y; o->w = (int16_t) (1 << u->lw); o->h = (int16_t) (1 << u->lh); o->ch_type = (uint8_t) ch;
           o->qt_depth = u->qt_depth; o->bt_depth = u->bt_depth; o->mt_depth = u->mt_depth; o->depth = u->depth;
-          o->intra_dir = u->dir; o->mrl_idx = u->mrl; o->cbf = u->cbf; o->split_series = u->split_series;
+          o->intra_dir = u->dir; o->mrl_idx = u->mrl; o->cbf = u->cbf; o->mts_idx = u->mts; o->split_series = u->split_series;
         }
         n++;
       }

@@ -72,6 +72,7 @@ typedef struct {
   uint8_t  intra_dir;      /* luma mode, or chroma mode (70 = DM) */
   uint8_t  mrl_idx;        /* multiRefIdx 0/1/3 */
   uint8_t  cbf;            /* bit0 Y, bit1 Cb, bit2 Cr */
+  uint8_t  mts_idx;        /* luma TU: 0 DCT2xDCT2, 2..5 explicit MTS (tu.mtsIdx) */
   uint64_t split_series;
 } orc_cu;
 
@@ -116,6 +117,11 @@ void orc_inv_1d(int tr, int n, const int *src, int *dst, int shift, int line, in
 /* CL/TrQuant.cpp:835-992 (xT / xIT), DCT2 both directions */
 void orc_fwd_2d(const int16_t *resi, int stride, int w, int h, int bit_depth, int *coef);
 void orc_inv_2d(const int *coef, int w, int h, int bit_depth, int16_t *resi, int stride);
+/* the same with an explicit-MTS index (0 DCT2, 2 DST7xDST7, 3 DCT8 hor, 4 DCT8 ver, 5 DCT8xDCT8; getTrTypes 817-830); 32-point MTS keeps 16 */
+void orc_fwd_2d_mts(const int16_t *resi, int stride, int w, int h, int bit_depth, int mts_idx, int *coef);
+void orc_inv_2d_mts(const int *coef, int w, int h, int bit_depth, int mts_idx, int16_t *resi, int stride);
+/* CL/TrQuant.cpp:1049-1124: which of {DCT2, mts 2, 3, 4, 5} stay in the RD loop of a luma TU */
+void orc_mts_prune(const int16_t *resi, int stride, int w, int h, int bit_depth, int max_cand, int test[5]);
 /* CL/Quant.cpp:994-1089 (plain quant, I-slice offset 171) and 423-549 (dequant) */
 int  orc_quant(const int *coef, int w, int h, int bit_depth, int qp, int16_t *level);
 void orc_dequant(const int16_t *level, int w, int h, int bit_depth, int qp, int *coef);

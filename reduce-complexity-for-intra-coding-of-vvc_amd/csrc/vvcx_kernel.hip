@@ -2422,7 +2422,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
     const int d = L.d;
 #if VVCX_STAMP
     const long long tph = STAMP(); const int phs = f.phase;
-    struct PhStamp { long long t; int ph; __device__ ~PhStamp() { L.prof[16 + ph] += (unsigned long long) (STAMP() - t); L.prof[30] += 1; } } phstamp = { tph, phs };
+    struct PhStamp { long long t; int ph; __device__ ~PhStamp() { if (ph < 12) L.prof[16 + ph] += (unsigned long long) (STAMP() - t); L.prof[30] += 1; } } phstamp = { tph, phs };
 #endif
     switch (f.phase) {
     case PH_ENTER: {                                    // xCompressCU entry (EL/EncCu.cpp:727-1286)

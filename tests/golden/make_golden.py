@@ -283,6 +283,37 @@ def gen_trquant():
     print("trquant cases", len(meta))
 
 
+def gen_trquant_mts():
+    """Explicit MTS through the reference's TrQuant: (1) transformNxN / invTransformNxN with tu.mtsIdx 2..5 (DST-VII / DCT-VIII pairs,
+    32-point zero-out) for every luma shape up to 32; (2) the candidate pruning overload (CL/TrQuant.cpp:1049-1124) on the list
+    {DCT2, 2, 3, 4, 5} with MTSIntraMaxCand 3."""
+    R.ref_env_tr_quant_mts.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 4
+    R.ref_env_mts_prune.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 2
+    g = np.random.default_rng(20260)
+    meta, resi_all, lev_all, out_all, prune = [], [], [], [], []
+    for bd, qp in ((8, 27), (10, 32)):
+        env = R.ref_env_create(192, 192, bd)
+        for w in (4, 8, 16, 32):
+            for h in (4, 8, 16, 32):
+                amp = (1 << bd) // 4
+                yy, xx = np.mgrid[0:h, 0:w]
+                resi = g.normal(0, amp / 8, (h, w)) + (amp / 3) * (xx / w) * g.uniform(-1, 1) + (amp / 3) * (yy / h) * g.uniform(-1, 1)
+                resi = np.ascontiguousarray(np.clip(resi.round(), -(1 << bd) + 1, (1 << bd) - 1).astype(np.int16))
+                for mts in (2, 3, 4, 5):
+                    R.ref_env_reset(env)
+                    lev = np.zeros(w * h, np.int32); ro = np.zeros(w * h, np.int16); a = C.c_int()
+                    assert R.ref_env_tr_quant_mts(env, 0, 0, w, h, qp, mts, P(resi), P(lev), P(ro), C.byref(a)) == 0
+                    meta.append((bd, qp, w, h, mts, a.value))
+                    resi_all.append(resi.ravel()); lev_all.append(lev.astype(np.int16)); out_all.append(ro)
+                R.ref_env_reset(env)
+                t = np.zeros(5, np.int32)
+                assert R.ref_env_mts_prune(env, 0, 0, w, h, qp, 3, P(resi), P(t)) == 0
+                prune.append(t)
+    np.savez_compressed(os.path.join(HERE, "trquant_mts.npz"), meta=np.array(meta, np.int32), resi=np.concatenate(resi_all),
+                        lev=np.concatenate(lev_all), resi_out=np.concatenate(out_all), prune=np.stack(prune))
+    print("mts trquant cases", len(meta), "prune keep histogram", np.stack(prune).sum(axis=0))
+
+
 def gen_cclm():
     """CCLM prediction (xGetLumaRecPixels + xGetLMParameters + predIntraChromaLM) for LM / MDLM_L / MDLM_T over random partial
     reconstructions, real availability logic of the chroma tree."""
@@ -391,6 +422,14 @@ def gen_bitstream_cclm():
     np.savez_compressed(os.path.join(HERE, "bitstream_cclm.npz"), **out)
 
 
+def gen_bitstream_mts():
+    """Decoder round trip with explicit MTS on as well (tools 0x911, sps MTS + IntraMTS): mts_idx bins, the skipped sub-blocks of
+    32-point MTS blocks and the DST-VII / DCT-VIII choice per luma TU are parsed back by the reference's CABACReader."""
+    R.ref_env_set_tools.argtypes = [C.c_void_p, C.c_uint]
+    out = _pictures(((128, 128, 27, 1, 1, 8, 7), (200, 136, 22, 1, 1, 8, 1234), (256, 256, 32, 2, 2, 8, 5), (128, 128, 27, 1, 1, 10, 3)), 0x911, 0.5)
+    np.savez_compressed(os.path.join(HERE, "bitstream_mts.npz"), **out)
+
+
 def _pictures(cases, tools, texture):
     import importlib, sys
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -407,7 +446,7 @@ def _pictures(cases, tools, texture):
         planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture)
         payload, sizes, cus, lev = O.write_frame(planes, W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools)
         env = R.ref_env_create(W, H, bd); R.ref_env_set_tiles(env, tc, tr)
-        if tools & 0x100:
+        if tools & 0x110:
             R.ref_env_set_tools(env, tools)
         R.ref_env_reset(env)
         cw, chh = (W + 127) // 128, (H + 127) // 128
@@ -421,14 +460,15 @@ def _pictures(cases, tools, texture):
         nd = R.ref_dec_get_cus(env, P(rows), P(ss), len(rows)); assert nd == len(cus)
         dec = {(int(r[0]), int(r[1]), int(r[2])): (tuple(int(v) for v in r[3:]), int(s)) for r, s in zip(rows[:nd], ss[:nd])}
         for c in cus:
-            exp = ((int(c["w"]), int(c["h"]), int(c["qt_depth"]), int(c["bt_depth"]), int(c["mt_depth"]), int(c["depth"]), int(c["intra_dir"]), int(c["mrl_idx"]), int(c["cbf"])), int(c["split_series"]))
+            exp = ((int(c["w"]), int(c["h"]), int(c["qt_depth"]), int(c["bt_depth"]), int(c["mt_depth"]), int(c["depth"]), int(c["intra_dir"]), int(c["mrl_idx"]), int(c["cbf"]) | (int(c["mts_idx"]) << 8)), int(c["split_series"]))
             assert dec[(int(c["ch_type"]), int(c["x"]), int(c["y"]))] == exp, "decoded CU differs"
         for comp in range(3):
             d = np.zeros_like(lev[comp]); R.ref_dec_get_levels(env, comp, P(d), d.shape[1])
             assert np.array_equal(d, lev[comp]), "decoded levels differ"
         pic_meta.append((W, H, qp, tc, tr, bd, seed, len(payload))); pic_bytes.append(payload); pic_sizes.append(np.pad(sizes, (0, 16 - len(sizes))))
         nlm = int(sum(1 for c in cus if c["ch_type"] == 1 and 67 <= c["intra_dir"] <= 69))
-        print("picture", W, H, qp, tc, tr, bd, "payload", len(payload), "bytes, decoded by the reference:", nd, "CUs,", nlm, "with an LM chroma mode")
+        nmts = int(sum(1 for c in cus if c["ch_type"] == 0 and c["mts_idx"] > 1))
+        print("picture", W, H, qp, tc, tr, bd, "payload", len(payload), "bytes, decoded by the reference:", nd, "CUs,", nlm, "with an LM chroma mode,", nmts, "with an MTS transform")
     out["pic_meta"] = np.array(pic_meta, np.int32); out["pic_bytes"] = np.concatenate(pic_bytes); out["pic_sizes"] = np.stack(pic_sizes).astype(np.int32)
     out["tools"] = np.array([tools], np.int32); out["chroma_texture"] = np.array([texture], np.float64)
     return out
@@ -440,9 +480,13 @@ if __name__ == "__main__":
         gen_trquant(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream":
         gen_bitstream(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bitstream_mts":
+        gen_bitstream_mts(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "trquant_mts":
+        gen_trquant_mts(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream_cclm":
         gen_bitstream_cclm(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts()
     print("done")

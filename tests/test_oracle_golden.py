@@ -239,3 +239,35 @@ def test_partition_forest_matches_sklearn_and_classifier_shrinks_the_search():
     r = dump[0]
     assert len(r) > 100 and ((r[:, 27] >= 0) & (r[:, 27] <= 5)).all() and ((r[:, 26] >= 0) & (r[:, 26] <= 2)).all()
     assert (r[:, 0] <= 64).all() and (r[:, 1] <= 64).all() and (r[:, 3] < 3).all() and not ((r[:, 0] == 4) & (r[:, 1] == 4)).any()
+
+
+def test_mts_transforms_and_candidate_pruning():
+    """Explicit MTS: DST-VII / DCT-VIII pairs (mts_idx 2..5) through transform + plain quantiser + dequantiser + inverse, and the
+    sum-of-absolute-coefficients candidate pruning, against TrQuant of the reference (tests/golden/make_golden.py trquant_mts)."""
+    L = O.lib()
+    g = np.load(os.path.join(G, "trquant_mts.npz"))
+    off = 0; pi = 0
+    for k, (bd, qp, w, h, mts, asum) in enumerate(g["meta"]):
+        n = int(w) * int(h)
+        resi = np.ascontiguousarray(g["resi"][off:off + n]); lev_e = g["lev"][off:off + n]; out_e = g["resi_out"][off:off + n]; off += n
+        qpe = int(qp) + 6 * (int(bd) - 8)
+        coef = np.zeros(n, np.int32); lev = np.zeros(n, np.int16); out = np.zeros(n, np.int16)
+        L.orc_fwd_2d_mts(P(resi), int(w), int(w), int(h), int(bd), int(mts), P(coef))
+        a = L.orc_quant(P(coef), int(w), int(h), int(bd), qpe, P(lev))
+        assert a == asum and np.array_equal(lev, lev_e), (bd, qp, w, h, mts)
+        if a:
+            L.orc_dequant(P(lev), int(w), int(h), int(bd), qpe, P(coef))
+            L.orc_inv_2d_mts(P(coef), int(w), int(h), int(bd), int(mts), P(out), int(w))
+            assert np.array_equal(out, out_e), (bd, qp, w, h, mts)
+        if mts == 2:
+            t = np.zeros(5, np.int32)
+            L.orc_mts_prune(P(resi), int(w), int(w), int(h), int(bd), 3, P(t))
+            assert np.array_equal(t, g["prune"][pi]), (bd, w, h, t, g["prune"][pi]); pi += 1
+    assert pi == len(g["prune"])
+
+
+def test_slice_data_payload_with_explicit_mts():
+    """tools 0x911 (MRL, MTS, CCLM, CU reuse): the reference's CABACReader parsed mts_idx, the sub-block skipping of 32-point MTS
+    blocks and every level of these payloads back (tests/golden/make_golden.py bitstream_mts)."""
+    import importlib
+    _check_pictures(np.load(os.path.join(G, "bitstream_mts.npz")), importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd"))
