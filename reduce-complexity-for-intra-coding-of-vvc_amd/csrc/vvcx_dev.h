@@ -23,7 +23,7 @@ struct VxUnit {
   int16_t  x, y;            // CU origin, samples of this channel type
   uint8_t  lw, lh;          // log2 size, samples of this channel type
   uint8_t  qt, mt, bt, depth;
-  uint8_t  dir, mrl, cbf, pad;
+  uint8_t  dir, mrl, cbf, mts;  // mts: tu.mtsIdx of the luma TU (0 DCT2, 2..5)
   uint16_t tag;             // 0 = not coded in the current path; else tile index + 1
 };
 
@@ -87,7 +87,7 @@ struct VxParams {
 // CU-result cache of the current CTU (BestEncInfoCache, EL/EncModeCtrl.cpp:663-1110): one entry per (position in CTU in
 // 4-sample units, log2 w, log2 h <= 6) and a level pool with one slot per (size, position aligned to max(4, size/2)):
 // sum over sizes of size * 128 / max(4, size/2) = 1152 per dimension.
-struct VxCacheEnt { uint64_t ss; uint8_t kind /* 0 empty, 1 luma tree, 2 chroma tree */, dir, mrl, cbf, depth, pad[3]; };
+struct VxCacheEnt { uint64_t ss; uint8_t kind /* 0 empty, 1 luma tree, 2 chroma tree */, dir, mrl, cbf, depth, mts, pad[2]; };
 #define VXD_CACHE_ENTRIES (32 * 32 * 5 * 5)
 #define VXD_CACHE_DIM   1152
 #define VXD_OFF_ORG     (VXD_OFF_TMP + VXD_NW * 2048 * 4)                             // original tile of a node too big for LDS: 4096 int16

@@ -40,6 +40,7 @@
 enum { SPLIT_NONE = 0, SPLIT_QT = 1, SPLIT_BH = 2, SPLIT_BV = 3, SPLIT_TH = 4, SPLIT_TV = 5 };
 enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V, ETM_RECO_CACHED };
 #define TOOL_CU_REUSE (1u << 11)
+#define TOOL_MTS (1u << 4)
 #define TOOL_CCLM (1u << 8)
 #define TOOL_FAST (1u << 12)
 enum { LM_CHROMA = 67, MDLM_L = 68, MDLM_T = 69 };
@@ -66,7 +67,7 @@ struct Frame {                     // one recursion level: partitioner level + C
   uint8_t modes[8];
   uint8_t nb_ok, nbL_lh, nbL_qt, nbA_lw, nbA_qt;   // left / above CU of the node (bit0 left, bit1 above present)
   uint8_t can_mask, ctx_spl, ctx_qt, ctx_hv;       // canSplit() bits {no,qt,bh,bv,th,tv} and split-flag context increments, fixed per node
-  uint8_t reusing, r_dir, r_mrl, r_cbf;            // IS_REUSING_CU and the cached CU's mode data (BestEncInfoCache)
+  uint8_t reusing, r_dir, r_mrl, r_cbf, r_mts;     // IS_REUSING_CU and the cached CU's mode data (BestEncInfoCache)
   uint8_t ctx_dirty;                               // the estimator's contexts differ from the node's start snapshot (a split was carried out)
   int16_t px[4], py[4], pw[4], ph[4];
   uint64_t ss;
@@ -91,6 +92,7 @@ struct Tables {                    // constant tables staged once per workgroup 
   int8_t   gauss[128], cubic[128];
   uint8_t  last_prefix[8], mode_shift[8];
   uint8_t  ctx_rate[NCTX + 2], gorice_pars[32], gorice_pos0[96], group_idx[64], mode_num[36], intra_thr[8];
+  int8_t   dst7[16 + 64 + 256 + 1024];   // DST-VII 4..32 (explicit MTS); DCT-VIII[k][i] = (-1)^k DST-VII[k][n-1-i] is read from the same rows
   int8_t   dct[4 + 16 + 64 + 256 + 1024 + (BUF >= 256 ? 4096 : 0)];   // DCT-II 2..32, and 64 when a 64-wide block can be LDS resident (64x4 = 256 samples)
   uint8_t  cg_scan[52], grp_scan[228];   // diagonal scans (CL/Rom.cpp:87-131) as x | y << 4: inside a coefficient group {4x4, 2x2, 8x2, 2x8}; of the groups, per (log2 wg, log2 hg)
 };
@@ -116,7 +118,7 @@ struct Lds {
   // candidates
   Cand cand[64]; double cand_cost[64]; double cand_had[64]; int n_cand;
   uint2 cand_ipa[64];              // prediction parameters of each SATD-stage candidate (initPredIntraParams), packed, derived once per operation
-  Cand rd[16]; double rd_cost[16]; uint64_t rd_dist[16]; uint64_t rd_bits[16]; uint8_t rd_cbf[16]; int n_rd;
+  Cand rd[16]; double rd_cost[16]; uint64_t rd_dist[16]; uint64_t rd_bits[16]; uint8_t rd_cbf[16]; uint8_t rd_mts[16]; int mts_evals[NW]; int n_rd;
   int wave_best[NW], wave_slot[NW]; // candidate index of each wave's best and the slot that holds it
   CtlState S; VxUnit cu;           // controller working set; CU record of the intra candidate being evaluated
   unsigned mpm[6], mpm_sorted[6]; int mpm_n;
@@ -431,7 +433,7 @@ __device__ __noinline__ RcPre rc_prepass_wave(int lev_off, const int16_t *coeff_
   return r;
 }
 template <bool WR = false>
-__device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, const uint16_t *scan, RcPre pre)
+__device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, const uint16_t *scan, RcPre pre, int zo = 0)
 {
   Cctx c; c.w = w; c.h = h; c.ch = is_chroma; c.tmpl_diag = -1; c.tmpl_sum1 = -1;
   int lcw, lch; cg_shape(w, h, lcw, lch);
@@ -458,7 +460,7 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
     if (gx > 3) enc_ep<WR>(cb, (uint32_t) (posX - VX_MIN_IN_GROUP[gx]), (gx - 2) >> 1);
     if (gy > 3) enc_ep<WR>(cb, (uint32_t) (posY - VX_MIN_IN_GROUP[gy]), (gy - 2) >> 1);
   }
-  int regBins = (zw * zh * 28) >> 4;
+  int regBins = (((zo && w == 32) ? 16 : zw) * ((zo && h == 32) ? 16 : zh) * 28) >> 4;      // getTbAreaAfterCoefZeroOut (CL/Unit.cpp:872-890)
   unsigned long long sigPos = 0;         // m_sigCoeffGroupFlag by CG raster position
   for (int sub = scanPosLast >> lcg; sub >= 0; sub--) {
     const int cgX = geo.grp[sub] & 15, cgY = geo.grp[sub] >> 4, cgPos = cgY * wg + cgX;
@@ -467,6 +469,7 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
     const int sigRight = (cgX + 1) < wg ? (int) ((sigPos >> (cgPos + 1)) & 1) : 0;
     const int sigLower = (cgY + 1) < hg ? (int) ((sigPos >> (cgPos + wg)) & 1) : 0;
     const int sigGroupCtx = VX_CTX_SigCoeffGroup[c.ch] + (sigRight | sigLower);
+    if (zo && ((h == 32 && cgY >= (16 >> lch)) || (w == 32 && cgX >= (16 >> lcw)))) continue;       // 3866-3877: groups of the zeroed area of a 32-point MTS block
     const int isLast = (scanPosLast >> lcg) == sub, isNotFirst = sub != 0;
     const int firstSigPos = isLast ? scanPosLast : maxSub;
     int nextSigPos = firstSigPos;
@@ -521,10 +524,10 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
 }
 // single-lane form (controller / estimator pass) and wave form (lane 0 owns cb)
 template <bool WR = false>
-__device__ void residual_coding(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, uint16_t *scan)
+__device__ void residual_coding(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, uint16_t *scan, int zo = 0)
 {
   const RcPre pre = rc_prepass_serial(coeff, w, h, scan);
-  rc_serial<WR>(cb, coeff, w, h, is_chroma, scan, pre);
+  rc_serial<WR>(cb, coeff, w, h, is_chroma, scan, pre, zo);
 }
 // Wave form of residual_coding (same syntax as rc_serial, all 64 lanes working):
 //  (1) data-parallel pre-pass: scan table, last position, significant groups (by scan index and by raster position);
@@ -611,8 +614,9 @@ __device__ __noinline__ void rc_chain(int ci, int wv, int nb, int lane, unsigned
   }
 }
 template <bool SMALL>
-__device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const int16_t *coeff_g, int w, int h, int is_chroma, int lane)
+__device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const int16_t *coeff_g, int w, int h, int is_chroma, int lane, int zo = 0)
 {
+  zo = uni(zo);
   const long long q0 = STAMP();
   const int16_t *coeff = SMALL ? L.slot[uni(threadIdx.x >> 6)] + BUF + uni(lev_off) : coeff_g;
   const RcPre pre = rc_prepass_wave<SMALL>(lev_off, coeff_g, w, h, lane);
@@ -646,7 +650,8 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
   }
   const int sigBase = VX_CTX_SigFlag[is_chroma], g1Base = VX_CTX_GtxFlag[is_chroma + 2], g2Base = VX_CTX_GtxFlag[is_chroma], parBase = VX_CTX_ParFlag[is_chroma];
   const int grpBase = VX_CTX_SigCoeffGroup[is_chroma];
-  int regBins = (zw * zh * 28) >> 4;
+  int regBins = (((zo && w == 32) ? 16 : zw) * ((zo && h == 32) ? 16 : zh) * 28) >> 4;
+  const int zoX = (zo && w == 32) ? (16 >> geo.lcw) : 64, zoY = (zo && h == 32) ? (16 >> geo.lch) : 64;     // first group column / row of the zeroed area
   const int lastCG = last >> lcg;
   const unsigned long long ltMask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   for (int c = last >> 6; c >= 0; c--) {
@@ -687,7 +692,8 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
     const bool ctxMode = coded && (regBins - before >= 4);          // the budget test of 4187 is a prefix condition
     const int eff = ctxMode ? nbins : 0;
     int used; prefix3(eff, used);
-    const bool gflag = active && inCG == 0 && !isLastCG && notFirst;
+    bool gflag = active && inCG == 0 && !isLastCG && notFirst;
+    if (zo) gflag = gflag && (int) (geo.grp[sub] & 15) < zoX && (int) (geo.grp[sub] >> 4) < zoY;
     int o = nb + prefix3(eff + (gflag ? 1 : 0), tot);
     if (gflag) {
       const int cgX = geo.grp[sub] & 15, cgY = geo.grp[sub] >> 4, cgPos = cgY * wg + cgX;
@@ -1443,6 +1449,10 @@ __device__ void load_tables()
     int x, y; diag_walk(1 << a, 1 << b, i - off, x, y);
     L.t.grp_scan[i] = (uint8_t) (x | (y << 4));
   }
+  for (int i = tid; i < 16; i += NT) L.t.dst7[i] = VX_DST7_4[i];
+  for (int i = tid; i < 64; i += NT) L.t.dst7[16 + i] = VX_DST7_8[i];
+  for (int i = tid; i < 256; i += NT) L.t.dst7[80 + i] = VX_DST7_16[i];
+  for (int i = tid; i < 1024; i += NT) L.t.dst7[336 + i] = VX_DST7_32[i];
   for (int i = tid; i < 4; i += NT) L.t.dct[i] = VX_DCT2_2[i];
   for (int i = tid; i < 16; i += NT) L.t.dct[4 + i] = VX_DCT2_4[i];
   for (int i = tid; i < 64; i += NT) L.t.dct[20 + i] = VX_DCT2_8[i];
@@ -1541,6 +1551,149 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   sse_out = wave_sum_u64(sse);
   cbf_out = abs_sum > 0;
 }
+
+// ---- explicit MTS (TrQuant::getTrTypes 817-830): mts_idx 2..5 → (horizontal, vertical) ∈ {DST-VII, DCT-VIII}; tr: 0 DCT2, 1 DCT8, 2 DST7
+__device__ inline void mts_types(int mts, int &trh, int &trv)
+{
+  if (mts < 2) { trh = trv = 0; return; }
+  trh = ((mts - 2) & 1) ? 1 : 2; trv = ((mts - 2) >> 1) ? 1 : 2;
+}
+template <bool SMALL> __device__ inline const int8_t *tr_matrix(int tr, int n)
+{
+  if (tr == 0) return dct2_matrix<SMALL>(n);
+  return n == 4 ? L.t.dst7 : n == 8 ? L.t.dst7 + 16 : n == 16 ? L.t.dst7 + 80 : L.t.dst7 + 336;
+}
+__device__ inline int tr_coef(const int8_t *M, int n, int tr, int k, int i)
+{
+  if (tr == 1) { const int v = M[k * n + (n - 1 - i)]; return (k & 1) ? -v : v; }
+  return M[k * n + i];
+}
+// forward 2-D transform of (org - pred) with the transform pair of mts and the sum of |coefficient| (the measure TrQuant::transformNxN
+// 1049-1124 prunes the MTS candidates with); pred is the calling wave's candidate buffer (SMALL) or pred_g
+template <bool SMALL>
+__device__ __noinline__ int wave_fwd_sumabs(const int16_t *org_g, const int16_t *pred_g, int32_t *tmp_g, int w, int h, int bd, int mts, int lane)
+{
+  w = uni(w); h = uni(h); bd = uni(bd); mts = uni(mts);
+  const int wave_ = uni(threadIdx.x >> 6);
+  const int16_t *org = SMALL ? L.org : org_g, *pred = SMALL ? L.slot[wave_] : pred_g;
+  int32_t *tmp = SMALL ? L.tmp[wave_] : tmp_g;
+  int trh, trv; mts_types(mts, trh, trv);
+  const int lw = ilog2i(w), lh = ilog2i(h);
+  const int zw = (trh && w == 32) ? 16 : imin(w, 32), zh = (trv && h == 32) ? 16 : imin(h, 32), lzw = ilog2i(zw);
+  const int8_t *Mw = tr_matrix<SMALL>(trh, w), *Mh = tr_matrix<SMALL>(trv, h);
+  const int shift1 = lw + bd + 6 - 15, shift2 = lh + 6;
+  const int rnd1 = shift1 > 0 ? 1 << (shift1 - 1) : 0, rnd2 = 1 << (shift2 - 1);
+  for (int o = lane; o < zw * h; o += 64) {
+    const int k = o >> lh, j = o & (h - 1);
+    int s = 0;
+    for (int i = 0; i < w; i++) s += tr_coef(Mw, w, trh, k, i) * (org[j * w + i] - pred[j * w + i]);
+    tmp[o] = (s + rnd1) >> shift1;
+  }
+  wave_sync();
+  int sa = 0;
+  for (int o = lane; o < zw * zh; o += 64) {
+    const int m = o >> lzw, k = o & (zw - 1);
+    int s = 0;
+    for (int j = 0; j < h; j++) s += tr_coef(Mh, h, trv, m, j) * tmp[k * h + j];
+    sa += iabs((s + rnd2) >> shift2);
+  }
+  sa = wave_sum_i32(sa);
+  wave_sync();
+  return sa;
+}
+// wave_code_block with an explicit-MTS transform pair (mts 2..5; blocks up to 32x32): same steps, DST-VII / DCT-VIII matrices, and the
+// 32-point transforms keep 16 coefficients (TrQuant::xT 853-854, xIT 935-936)
+template <bool SMALL>
+__device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *rec_g, int16_t *lev_g, int32_t *tmp_g, int w, int h, int bd, int qp, int mts,
+                                                 int lane, unsigned long long &sse_out, int &cbf_out, int given = -1)
+{
+  w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given); mts = uni(mts);
+  const int wave_ = uni(threadIdx.x >> 6);
+  const int16_t *org = SMALL ? L.org : org_g;
+  int16_t *rec = SMALL ? L.slot[wave_] : rec_g, *lev = SMALL ? L.slot[wave_] + BUF : lev_g;
+  int32_t *tmp = SMALL ? L.tmp[wave_] : tmp_g;
+  int trh, trv; mts_types(mts, trh, trv);
+  const int P = w * h, lw = ilog2i(w), lh = ilog2i(h);
+  const int zw = (trh && w == 32) ? 16 : w, zh = (trv && h == 32) ? 16 : h, lzw = ilog2i(zw);
+  const int8_t *Mw = tr_matrix<SMALL>(trh, w), *Mh = tr_matrix<SMALL>(trv, h);
+  const int shift1 = lw + bd + 6 - 15, shift2 = lh + 6;
+  const int rnd1 = shift1 > 0 ? 1 << (shift1 - 1) : 0, rnd2 = 1 << (shift2 - 1);
+  if (given < 0) for (int o = lane; o < zw * h; o += 64) {
+    const int k = o >> lh, j = o & (h - 1);
+    int s = 0;
+    for (int i = 0; i < w; i++) s += tr_coef(Mw, w, trh, k, i) * (org[j * w + i] - rec[j * w + i]);
+    tmp[o] = (s + rnd1) >> shift1;
+  }
+  wave_sync();
+  const int need_sqrt = (lw + lh) & 1;
+  const int qscale = L.t.qscale[need_sqrt * 6 + qp % 6];
+  const int tr_shift = 15 - bd - ((lw + lh) >> 1) + (need_sqrt ? -1 : 0);
+  const int qbits = 14 + qp / 6 + tr_shift;
+  const long long qadd = (long long) 171 << (qbits - 9);
+  if (given < 0 && (zw < w || zh < h)) { for (int o = lane; o < P; o += 64) lev[o] = 0; wave_sync(); }
+  int abs_sum = 0;
+  if (given < 0) for (int o = lane; o < zw * zh; o += 64) {
+    const int m = o >> lzw, k = o & (zw - 1);
+    int s = 0;
+    for (int j = 0; j < h; j++) s += tr_coef(Mh, h, trv, m, j) * tmp[k * h + j];
+    const int c = (s + rnd2) >> shift2;
+    const long long t = (long long) iabs(c) * qscale;
+    int q = (int) ((t + qadd) >> qbits);
+    abs_sum += q;
+    if (c < 0) q = -q;
+    q = q < -32768 ? -32768 : q > 32767 ? 32767 : q;
+    lev[m * w + k] = (int16_t) q;
+  }
+  abs_sum = given < 0 ? uni(wave_sum_i32(abs_sum)) : given;
+  wave_sync();
+  unsigned long long sse = 0;
+  if (abs_sum > 0) {
+    const int iscale = L.t.iqscale[need_sqrt * 6 + qp % 6];
+    const int right_shift = 6 - (tr_shift + qp / 6);
+    int tbd = 32 + right_shift - 7; if (tbd > 16) tbd = 16;
+    const int in_min = -(1 << (tbd - 1)), in_max = (1 << (tbd - 1)) - 1;
+    for (int o = lane; o < zw * h; o += 64) {
+      const int j = o >> lh, i = o & (h - 1);
+      int s = 0;
+      for (int k = 0; k < zh; k++) {
+        int q = lev[k * w + j]; q = q < in_min ? in_min : q > in_max ? in_max : q;
+        int v = right_shift > 0 ? (q * iscale + (1 << (right_shift - 1))) >> right_shift : (q * iscale) << (-right_shift);
+        v = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+        s += tr_coef(Mh, h, trv, k, i) * v;
+      }
+      int v = (s + 64) >> 7;
+      tmp[o] = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+    }
+    wave_sync();
+    const int ishift2 = (6 + 15 - 1) - bd, irnd2 = 1 << (ishift2 - 1);
+    const int mx = (1 << bd) - 1;
+    for (int o = lane; o < P; o += 64) {
+      const int j2 = o >> lw, i2 = o & (w - 1);
+      int s = 0;
+      for (int k = 0; k < zw; k++) s += tr_coef(Mw, w, trh, k, i2) * tmp[k * h + j2];
+      int r = (s + irnd2) >> ishift2;
+      r = r < -32768 ? -32768 : r > 32767 ? 32767 : r;
+      int v = rec[o] + (int) (int16_t) r;
+      v = v < 0 ? 0 : v > mx ? mx : v;
+      rec[o] = (int16_t) v;
+      const int d = org[o] - v;
+      sse += (unsigned long long) (d * d);
+    }
+  } else {
+    for (int o = lane; o < P; o += 64) { const int d = org[o] - rec[o]; sse += (unsigned long long) (d * d); }
+  }
+  wave_sync();
+  sse_out = wave_sum_u64(sse);
+  cbf_out = abs_sum > 0;
+}
+// CABACWriter::mts_coding 3885-3941 for a TU where MTS is allowed and transform skip is not (JVET_O0294 contexts); lane 0 / thread 0
+template <bool WR = false>
+__device__ inline void enc_mts_idx(Cab &cb, int mts)
+{
+  enc_bin<WR>(cb, (unsigned) (mts != 0), VX_CTX_MTSIndex + 0);
+  if (mts) for (int i = 0; i < 3; i++) { const unsigned sym = mts > i + 2; enc_bin<WR>(cb, sym, VX_CTX_MTSIndex + 7 + i); if (!sym) break; }
+}
+__device__ inline int mts_allowed(const VxParams &p, int w, int h) { return (p.tools & TOOL_MTS) && w <= 32 && h <= 32; }     // TU::isMTSAllowed, CL/UnitTools.cpp:4549-4565
 
 // ------------------------------------------------------------------------------------------------ parallel operations
 // candidate slots: nrec = reconstruction samples held (w*h luma, 2*cw*ch chroma).  Slot 0 of blocks up to 1024 samples is
@@ -1726,17 +1879,19 @@ __device__ __noinline__ void op_stage_a(const VxParams &p_, uint8_t *scratch)
 // wave's best is parked in the wave's HBM slot 1 (a streaming copy), so the next candidate again runs out of LDS.  Bigger blocks
 // alternate between the wave's two HBM slots.
 // OP_STAGE_B: full RD of L.rd[0..n_rd) (EL/IntraSearch.cpp:1158-1358 → xRecurIntraCodingLumaQT → xIntraCodingTUBlock)
-template <bool SMALL>
+template <bool SMALL, bool MTS>
 __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h)
 {
   const int P = w * h, bd = p.bit_depth;
   if (lane == 0) L.wave_best[wave] = -1;
   double wbest = MAX_DOUBLE;
   int cur = 0;                                    // !SMALL: slot being written; the other one holds the wave's best so far
+  int nmts = 0;                                   // MTS transform candidates this wave evaluated (work counter)
   const int n_rd = uni(L.n_rd);
   for (int c = wave; c < n_rd; c += NW) {
     const int mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
     int16_t *rec = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.slot[wave] + BUF : slot_lev(scratch, P, wave, cur);
+    if (lane == 0) L.rd_cost[c] = MAX_DOUBLE;
     Ipa ip; init_pred_params(w, h, 1, mode, mrl, ip);
     const int set = luma_set(mrl, ip.ref_filter);
     const int16_t *top = L.refs[set][0], *left = L.refs[set][1];
@@ -1745,8 +1900,36 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
     wave_sync();
     const long long tb1 = STAMP();
+    // transform candidates of the TU (xRecurIntraCodingLumaQT 3340-3640 without LFNST / transform skip): DCT2 alone, or where MTS is
+    // allowed {DCT2, 2, 3, 4, 5} pruned by the sum of absolute coefficients (TrQuant::transformNxN 1049-1124, MTSIntraMaxCand 3).
+    // Every (mode, transform) pair is offered to the wave's best like a candidate of its own: the result is the two-level minimum.
+    const int mtsOk = MTS && mts_allowed(p, w, h);        // MTS = false: the loop below is the single DCT-II pass
+    unsigned test = 1;
+    if (mtsOk) {
+      int sums[5];
+      for (int k = 0; k < 5; k++) sums[k] = wave_fwd_sumabs<SMALL>(org_tile(scratch, P), rec, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, k ? k + 1 : 0, lane);
+      const int ls = imax(ilog2i(w), ilog2i(h)) - 2;
+      const double fac = ls == 0 ? 1.2 : ls <= 2 ? 1.3 : ls == 3 ? 1.4 : 1.5;
+      const double thr = fac * (double) sums[0], thrTS = (double) sums[0];
+      int numTests = 0; test = 0;
+      for (int k = 0; k < 5; k++) { const int t = (double) sums[k] <= (k == 1 ? thrTS : thr) && numTests <= 3; test |= (unsigned) t << k; numTests += t; }
+    }
+    double mbest = MAX_DOUBLE; int cbfDCT2 = 1;
+    for (int k = 0; k < (MTS && mtsOk ? 5 : 1); k++) {
+    if (!cbfDCT2) break;
+    if (!((test >> k) & 1)) continue;
+    const int mts = k ? k + 1 : 0;
+    if (k) {                                             // the previous transform candidate turned the prediction into its reconstruction
+      rec = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, cur); lev = SMALL ? L.slot[wave] + BUF : slot_lev(scratch, P, wave, cur);
+      for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
+      wave_sync();
+    }
     unsigned long long sse; int cbf;
-    wave_code_block<SMALL>(org_tile(scratch, P), 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf);
+    if (k == 0) wave_code_block<SMALL>(org_tile(scratch, P), 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf);
+    else wave_code_block_mts<SMALL>(org_tile(scratch, P), rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, mts, lane, sse, cbf);
+    if (k) nmts++;
+    if (k == 0) cbfDCT2 = uni(cbf);
+    if (k && !uni(cbf)) continue;                        // an MTS index is not coded for a zero block: forbidden (cost MAX_DOUBLE)
     const long long tb2 = STAMP();
     // xGetIntraFracBitsQT: header + cbf + residual from the node's start contexts
     { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
@@ -1756,14 +1939,16 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     if (lane == 0) {
       enc_intra_luma_pred_mode(cb, L.ny, mode, mrl);
       enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[0]);
+      if (cbf && mtsOk) enc_mts_idx(cb, mts);
     }
-    if (uni(cbf)) residual_coding_wave<SMALL>(cb, 0, lev, w, h, 0, lane);
-    if (lane == 0) {
-      cost = rd_cost(p, cb.bits, sse);
-      L.rd_cost[c] = cost; L.rd_dist[c] = sse; L.rd_bits[c] = cb.bits; L.rd_cbf[c] = (uint8_t) cbf;
-    }
+    if (uni(cbf)) residual_coding_wave<SMALL>(cb, 0, lev, w, h, 0, lane, mts > 1);
+    if (lane == 0) cost = rd_cost(p, cb.bits, sse);
     if (VVCX_STAMP && threadIdx.x == 0) { const long long tb3 = STAMP(); L.prof[28] += (unsigned long long) (tb1 - tb0); L.prof[29] += (unsigned long long) (tb2 - tb1); L.prof[31] += (unsigned long long) (tb3 - tb2); }
     cost = lane0_d(cost);
+    if (cost < mbest) {
+      mbest = cost;
+      if (lane == 0) { L.rd_cost[c] = cost; L.rd_dist[c] = sse; L.rd_bits[c] = cb.bits; L.rd_cbf[c] = (uint8_t) cbf; L.rd_mts[c] = (uint8_t) mts; }
+    }
     if (cost < wbest) {
       wbest = cost;
       if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = SMALL ? 1 : cur; }
@@ -1774,14 +1959,19 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
       { uint32_t *d = (uint32_t *) ctx_ptr(scratch, CTX_START, MAXD + wave, 0); const uint32_t *s = (const uint32_t *) &L.ctxs[CI_W(wave)]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     }
     wave_sync();
+    }
   }
+  if (lane == 0) L.mts_evals[wave] = nmts;
 }
+// out of line: the MTS variant must not weigh on the register allocation of the DCT-II-only loop inlined into op_stage_b
+template <bool SMALL> __device__ __noinline__ void stage_b_loop_mts(const VxParams &p_, uint8_t *scratch, int wave, int lane, int w, int h) { stage_b_loop<SMALL, true>(L.par, scratch, wave, lane, w, h); (void) p_; }
 __device__ __noinline__ void op_stage_b(const VxParams &p_, uint8_t *scratch)
 {
   const VxParams &p = L.par; (void) p_;
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int w = uni(L.nw), h = uni(L.nh);
-  if (w * h <= BUF) stage_b_loop<true>(p, scratch, wave, lane, w, h); else stage_b_loop<false>(p, scratch, wave, lane, w, h);
+  if (uni(p.tools & TOOL_MTS)) { if (w * h <= BUF) stage_b_loop_mts<true>(p, scratch, wave, lane, w, h); else stage_b_loop_mts<false>(p, scratch, wave, lane, w, h); }
+  else if (w * h <= BUF) stage_b_loop<true, false>(p, scratch, wave, lane, w, h); else stage_b_loop<false, false>(p, scratch, wave, lane, w, h);
   __threadfence_block();
   __syncthreads();
   // winner (strict <, list order ≙ EL/IntraSearch.cpp:1308) and its end contexts → wctx[0]; every thread computes the same
@@ -1961,7 +2151,7 @@ __device__ int cache_is_valid(const VxParams &p, uint8_t *scratch, Frame *fr, in
     if (fr[i].last_split != s) break;
   }
   if (fr[i - 1].x != f.x || fr[i - 1].y != f.y) return 0;
-  f.r_dir = c.dir; f.r_mrl = c.mrl; f.r_cbf = c.cbf;
+  f.r_dir = c.dir; f.r_mrl = c.mrl; f.r_cbf = c.cbf; f.r_mts = c.mts;
   return 1;
 }
 
@@ -1981,9 +2171,11 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
     for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); recb[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], w, h, px, py, ip, mode, 1, bd, dcv); }
     wave_sync();
     int cbf;
-    wave_code_block<SMALL>(org_tile(scratch, n), 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr, lane, dist, cbf, cbfm & 1);
-    if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, fm); enc_bin(cb, (unsigned) (cbfm & 1), VX_CTX_QtCbf[0]); }
-    if (cbfm & 1) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 0, lane);
+    const int mts = uni(L.rd_mts[0]);
+    if (mts > 1) wave_code_block_mts<SMALL>(org_tile(scratch, n), recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr, mts, lane, dist, cbf, cbfm & 1);
+    else wave_code_block<SMALL>(org_tile(scratch, n), 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr, lane, dist, cbf, cbfm & 1);
+    if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, fm); enc_bin(cb, (unsigned) (cbfm & 1), VX_CTX_QtCbf[0]); if ((cbfm & 1) && mts_allowed(p, w, h)) enc_mts_idx(cb, mts); }
+    if (cbfm & 1) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 0, lane, mts > 1);
   } else {
     for (int k = 0; k < 2; k++) {
       int16_t *rec = recb + k * P;
@@ -2249,7 +2441,7 @@ __device__ __noinline__ void op_save_intra(const VxParams &p_, uint8_t *scratch,
       int16_t *cl = (int16_t *) (scratch + VXD_OFF_CACHE_LEV) + lo;
       for (int i = threadIdx.x; i < n; i += NT) cl[i] = lev[i];
       if (threadIdx.x == 0) {
-        VxCacheEnt c; c.ss = cu.ss; c.kind = (uint8_t) (ch + 1); c.dir = cu.dir; c.mrl = cu.mrl; c.cbf = cu.cbf; c.depth = cu.depth; c.pad[0] = c.pad[1] = c.pad[2] = 0;
+        VxCacheEnt c; c.ss = cu.ss; c.kind = (uint8_t) (ch + 1); c.dir = cu.dir; c.mrl = cu.mrl; c.cbf = cu.cbf; c.depth = cu.depth; c.mts = cu.mts; c.pad[0] = c.pad[1] = 0;
         ((VxCacheEnt *) (scratch + VXD_OFF_CACHE))[e] = c;
       }
     }
@@ -2454,9 +2646,9 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         // CU record (partitioner.setCUData, EL/EncCu.cpp:2478-2496)
         VxUnit &cu = L.cu;
         cu.ss = f.ss; cu.x = (int16_t) (f.x >> sh); cu.y = (int16_t) (f.y >> sh); cu.lw = (uint8_t) ilog2i(f.w >> sh); cu.lh = (uint8_t) ilog2i(f.h >> sh);
-        cu.qt = f.qt; cu.mt = f.mt; cu.bt = f.bt; cu.depth = f.depth; cu.dir = 0; cu.mrl = 0; cu.cbf = 0; cu.pad = 0; cu.tag = (uint16_t) (tile + 1);
+        cu.qt = f.qt; cu.mt = f.mt; cu.bt = f.bt; cu.depth = f.depth; cu.dir = 0; cu.mrl = 0; cu.cbf = 0; cu.mts = 0; cu.tag = (uint16_t) (tile + 1);
         if (mode == ETM_RECO_CACHED) {                  // xReuseCachedResult (EL/EncCu.cpp:5665-5771)
-          L.rd[0].mode = f.r_dir; L.rd[0].mrl = f.r_mrl; L.rd_cbf[0] = f.r_cbf; L.n_rd = 0;
+          L.rd[0].mode = f.r_dir; L.rd[0].mrl = f.r_mrl; L.rd_cbf[0] = f.r_cbf; L.rd_mts[0] = ch ? 0 : f.r_mts; L.n_rd = 0;
           if (!ch) {                                    // MPM list for intra_luma_pred_modes
             int Ld = PLANAR, Ad = PLANAR;
             const VxUnit *uL = get_cu(p, fd, 0, f.x - 1, f.y + f.h - 1, tile); if (uL) Ld = uL->dir;
@@ -2559,12 +2751,13 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
     case PH_B_DONE: {                                   // winner chosen by the operation; CU-level rate; xCheckBestMode
       const int best = L.win_idx, ww = L.win_wave;
       if (ch) L.cnt[0] += (unsigned long long) L.lm_nsatd;
+      if (!ch && L.n_rd) { int ex = 0; for (int k = 0; k < NW; k++) ex += L.mts_evals[k]; L.cnt[1] += (unsigned long long) ex; L.cnt[2] += (unsigned long long) (ex * f.w * f.h); }      // transform candidates beyond DCT2
       L.cnt[1] += (unsigned long long) (ch ? 2 * L.n_rd : L.n_rd); L.cnt[2] += (unsigned long long) (ch ? 2 * L.n_rd * ((f.w >> 1) * (f.h >> 1)) : L.n_rd * f.w * f.h);
       L.op_a = L.wave_slot[ww];                         // slot of that wave holding the winner's reco / levels
       Sum &t = f.temp;
       t.dist = L.rd_dist[best];
       VxUnit &cu = L.cu;
-      cu.dir = L.rd[best].mode; cu.mrl = ch ? 0 : L.rd[best].mrl; cu.cbf = L.rd_cbf[best];
+      cu.dir = L.rd[best].mode; cu.mrl = ch ? 0 : L.rd[best].mrl; cu.cbf = L.rd_cbf[best]; cu.mts = ch ? 0 : L.rd_mts[best];
       // cu_pred_data + cu_residual bits (EL/EncCu.cpp:2593-2619) and the CU's end contexts are left in cu_bits / wctx[0]
       // by the operation (luma: identical to the stage-B syntax from the same start contexts)
       t.bits = L.cu_bits;
@@ -2676,7 +2869,7 @@ __device__ __noinline__ void walk_tree(const VxParams &p_, const VxFrameDev &fd_
           derive_mpms(Ld, Ad, L.mpm);
           enc_intra_luma_pred_mode<WR>(cb, f.y, u->dir, u->mrl);
           enc_bin<WR>(cb, u->cbf & 1, VX_CTX_QtCbf[0]);
-          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; residual_coding<WR>(cb, lv, W, H, 0, (uint16_t *) (lv + 4096)); }
+          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; if (mts_allowed(p, W, H)) enc_mts_idx<WR>(cb, u->mts); residual_coding<WR>(cb, lv, W, H, 0, (uint16_t *) (lv + 4096), u->mts > 1); }
         } else {
           enc_intra_chroma_pred_mode<WR>(cb, u->dir, fd.units[0][((f.y + (f.h >> 1)) >> 2) * p.uw + ((f.x + (f.w >> 1)) >> 2)].dir, cclm_allowed(p, fd, f.x, f.y, u->ss, u->depth));
           enc_bin<WR>(cb, (unsigned) !!(u->cbf & 2), VX_CTX_QtCbf[1]);

@@ -11,6 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libvvcx.so")
 TOOL_MRL = 1
+TOOL_MTS = 1 << 4            # explicit intra MTS (cfg MTS 1, MTSIntraMaxCand 3): DST-VII / DCT-VIII pairs for luma TUs up to 32x32
 TOOL_CU_REUSE = 1 << 11      # BestEncInfoCache, REUSE_CU_RESULTS (CL/TypeDef.h:291) - on in the reference build
 TOOL_CCLM = 1 << 8           # LM / MDLM chroma modes (cfg LMChroma 1, on in the reference's intra configuration)
 TOOL_FAST = 1 << 12          # the fork's FAST_ALGORITHM: features + random forest pick the one partition mode of a luma node

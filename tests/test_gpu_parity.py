@@ -79,6 +79,21 @@ def test_lm_chroma_modes_without_cu_reuse():
     _check([pkg.synth_frame(128, 128, 0, 8, 9, chroma_texture=0.4)], 128, 128, pkg.slice_params(27), tools=pkg.TOOL_MRL | pkg.TOOL_CCLM)
 
 
+MTS = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS
+
+
+@pytest.mark.parametrize("case", [(128, 128, 27, 8, 1, 1, 7), (200, 136, 22, 8, 1, 1, 1234), (256, 256, 32, 8, 2, 2, 5), (128, 128, 27, 10, 1, 1, 3)])
+def test_explicit_mts(case):
+    # tools 0x911: DST-VII / DCT-VIII candidates per luma TU up to 32x32 (pruned by the sum of absolute coefficients), mts_idx syntax, 32-point zero-out
+    W, H, qp, bd, tc, tr, seed = case
+    _check([pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=0.5)], W, H, pkg.slice_params(qp, bit_depth=bd), bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=MTS)
+
+
+def test_explicit_mts_without_cu_reuse_and_with_classifier():
+    _check([pkg.synth_frame(128, 128, 0, 8, 11, chroma_texture=0.5)], 128, 128, pkg.slice_params(32), tools=pkg.TOOL_MRL | pkg.TOOL_MTS)
+    _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=0.5)], 256, 128, pkg.slice_params(27), tools=MTS | pkg.TOOL_FAST)
+
+
 FAST = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_FAST
 
 
@@ -165,7 +180,7 @@ def test_full_1080p_frame_matches_oracle():
     _check([pkg.synth_frame(W, H, 0, 8, 1000)], W, H, pkg.slice_params(32), tile_cols=15, tile_rows=9)
 
 
-@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz"])
+@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz"])
 def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fixture):
     """Device writer (arithmetic coding of the final CTU syntax in the estimator pass) against tests/golden/bitstream.npz: payloads
     that the reference's CABACReader parsed back into the coded CUs and levels when the fixture was generated."""
