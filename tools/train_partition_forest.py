@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def rows_of(pkg, O, W, H, qp, seed, texture):
     out = []
-    O.compress_frame(pkg.synth_frame(W, H, seed % 5, 8, seed, chroma_texture=texture), W, H, pkg.slice_params(qp), chroma=0, tools=O.TOOLS_DEFAULT, training_rows=out)
+    O.compress_frame(pkg.synth_frame(W, H, seed % 5, 8, seed, chroma_texture=texture), W, H, pkg.slice_params(qp), chroma=0, tools=O.TOOLS_DEFAULT | (1 << 4), training_rows=out)      # luma tree with every built luma tool: MRL, MTS, CU reuse
     r = out[0]
     return r[r[:, 27] >= 0]
 
