@@ -1465,10 +1465,11 @@ __device__ void load_tables()
 // Returns SSE(org, reco) and abs-sum via out params.  rec/lev tiles have stride w.
 // given >= 0: the levels in lev are taken as coded (cbf = given): only the decoder half runs (DecCu::xIntraRecBlk, DL/DecCu.cpp:199-414).
 // SMALL: rec / lev / tmp are the calling wave's LDS buffers (L.slot[wave] + buf_off, + 1024, L.tmp[wave]); else the _g pointers.
-template <bool SMALL>
+template <bool SMALL, bool SUMABS = false>
 __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, int buf_off, int16_t *rec_g, int16_t *lev_g, int32_t *tmp_g, int w, int h, int bd, int qp,
-                                int lane, unsigned long long &sse_out, int &cbf_out, int given = -1)
+                                int lane, unsigned long long &sse_out, int &cbf_out, int given = -1, int *sumabs_out = nullptr)
 {
+  int coef_sum = 0;                                     // SUMABS: sum of |DCT-II coefficient| for the MTS pruning (TrQuant::transformNxN 1049-1124)
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given);
   const int wave_ = uni(threadIdx.x >> 6);
   const int16_t *org = (SMALL ? L.org : org_g) + uni(org_off);
@@ -1501,6 +1502,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     int s = 0;
     for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
     const int c = (s + rnd2) >> shift2;
+    if (SUMABS) coef_sum += iabs(c);
     const long long t = (long long) iabs(c) * qscale;
     int q = (int) ((t + qadd) >> qbits);
     abs_sum += q;
@@ -1509,6 +1511,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     lev[m * w + k] = (int16_t) q;
   }
   abs_sum = given < 0 ? uni(wave_sum_i32(abs_sum)) : given;
+  if (SUMABS) *sumabs_out = wave_sum_i32(coef_sum);
   wave_sync();
   unsigned long long sse = 0;
   if (abs_sum > 0) {
@@ -1586,7 +1589,9 @@ __device__ __noinline__ int wave_fwd_sumabs(const int16_t *org_g, const int16_t 
   for (int o = lane; o < zw * h; o += 64) {
     const int k = o >> lh, j = o & (h - 1);
     int s = 0;
-    for (int i = 0; i < w; i++) s += tr_coef(Mw, w, trh, k, i) * (org[j * w + i] - pred[j * w + i]);
+    // DCT-VIII[k][i] = (-1)^k DST-VII[k][n-1-i]: the DST-VII row applied to the reversed input, sign by the parity of k
+    if (trh == 1) { for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + w - 1 - i] - pred[j * w + w - 1 - i]); if (k & 1) s = -s; }
+    else for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + i] - pred[j * w + i]);
     tmp[o] = (s + rnd1) >> shift1;
   }
   wave_sync();
@@ -1594,7 +1599,8 @@ __device__ __noinline__ int wave_fwd_sumabs(const int16_t *org_g, const int16_t 
   for (int o = lane; o < zw * zh; o += 64) {
     const int m = o >> lzw, k = o & (zw - 1);
     int s = 0;
-    for (int j = 0; j < h; j++) s += tr_coef(Mh, h, trv, m, j) * tmp[k * h + j];
+    if (trv == 1) { for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + h - 1 - j]; if (m & 1) s = -s; }
+    else for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
     sa += iabs((s + rnd2) >> shift2);
   }
   sa = wave_sum_i32(sa);
@@ -1621,7 +1627,9 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
   if (given < 0) for (int o = lane; o < zw * h; o += 64) {
     const int k = o >> lh, j = o & (h - 1);
     int s = 0;
-    for (int i = 0; i < w; i++) s += tr_coef(Mw, w, trh, k, i) * (org[j * w + i] - rec[j * w + i]);
+    // DCT-VIII[k][i] = (-1)^k DST-VII[k][n-1-i]: the DST-VII row applied to the reversed input, sign by the parity of k
+    if (trh == 1) { for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + w - 1 - i] - rec[j * w + w - 1 - i]); if (k & 1) s = -s; }
+    else for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + i] - rec[j * w + i]);
     tmp[o] = (s + rnd1) >> shift1;
   }
   wave_sync();
@@ -1635,7 +1643,8 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
   if (given < 0) for (int o = lane; o < zw * zh; o += 64) {
     const int m = o >> lzw, k = o & (zw - 1);
     int s = 0;
-    for (int j = 0; j < h; j++) s += tr_coef(Mh, h, trv, m, j) * tmp[k * h + j];
+    if (trv == 1) { for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + h - 1 - j]; if (m & 1) s = -s; }
+    else for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
     const int c = (s + rnd2) >> shift2;
     const long long t = (long long) iabs(c) * qscale;
     int q = (int) ((t + qadd) >> qbits);
@@ -1659,7 +1668,7 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
         int q = lev[k * w + j]; q = q < in_min ? in_min : q > in_max ? in_max : q;
         int v = right_shift > 0 ? (q * iscale + (1 << (right_shift - 1))) >> right_shift : (q * iscale) << (-right_shift);
         v = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
-        s += tr_coef(Mh, h, trv, k, i) * v;
+        s += (trv == 1 ? ((k & 1) ? -Mh[k * h + h - 1 - i] : Mh[k * h + h - 1 - i]) : Mh[k * h + i]) * v;
       }
       int v = (s + 64) >> 7;
       tmp[o] = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
@@ -1670,7 +1679,8 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
     for (int o = lane; o < P; o += 64) {
       const int j2 = o >> lw, i2 = o & (w - 1);
       int s = 0;
-      for (int k = 0; k < zw; k++) s += tr_coef(Mw, w, trh, k, i2) * tmp[k * h + j2];
+      if (trh == 1) for (int k = 0; k < zw; k++) { const int v = Mw[k * w + w - 1 - i2] * tmp[k * h + j2]; s += (k & 1) ? -v : v; }
+      else for (int k = 0; k < zw; k++) s += Mw[k * w + i2] * tmp[k * h + j2];
       int r = (s + irnd2) >> ishift2;
       r = r < -32768 ? -32768 : r > 32767 ? 32767 : r;
       int v = rec[o] + (int) (int16_t) r;
@@ -1904,16 +1914,7 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     // allowed {DCT2, 2, 3, 4, 5} pruned by the sum of absolute coefficients (TrQuant::transformNxN 1049-1124, MTSIntraMaxCand 3).
     // Every (mode, transform) pair is offered to the wave's best like a candidate of its own: the result is the two-level minimum.
     const int mtsOk = MTS && mts_allowed(p, w, h);        // MTS = false: the loop below is the single DCT-II pass
-    unsigned test = 1;
-    if (mtsOk) {
-      int sums[5];
-      for (int k = 0; k < 5; k++) sums[k] = wave_fwd_sumabs<SMALL>(org_tile(scratch, P), rec, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, k ? k + 1 : 0, lane);
-      const int ls = imax(ilog2i(w), ilog2i(h)) - 2;
-      const double fac = ls == 0 ? 1.2 : ls <= 2 ? 1.3 : ls == 3 ? 1.4 : 1.5;
-      const double thr = fac * (double) sums[0], thrTS = (double) sums[0];
-      int numTests = 0; test = 0;
-      for (int k = 0; k < 5; k++) { const int t = (double) sums[k] <= (k == 1 ? thrTS : thr) && numTests <= 3; test |= (unsigned) t << k; numTests += t; }
-    }
+    unsigned test = 1; int sum0 = 0;
     double mbest = MAX_DOUBLE; int cbfDCT2 = 1;
     for (int k = 0; k < (MTS && mtsOk ? 5 : 1); k++) {
     if (!cbfDCT2) break;
@@ -1924,11 +1925,25 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
       for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
       wave_sync();
     }
+    if (MTS && k == 1) {
+      // the pruning of the candidate list (the reference runs it inside the DCT-II pass; its outcome is only read when that pass left
+      // a non-zero block, so it is computed here, after the pass, from the restored prediction; the DCT-II sum came with the pass)
+      int sums[5]; sums[0] = sum0;
+      for (int q = 1; q < 5; q++) sums[q] = wave_fwd_sumabs<SMALL>(org_tile(scratch, P), rec, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, q + 1, lane);
+      const int ls = imax(ilog2i(w), ilog2i(h)) - 2;
+      const double fac = ls == 0 ? 1.2 : ls <= 2 ? 1.3 : ls == 3 ? 1.4 : 1.5;
+      const double thr = fac * (double) sums[0], thrTS = (double) sums[0];
+      int numTests = 0; test = 0;
+      for (int q = 0; q < 5; q++) { const int t = (double) sums[q] <= (q == 1 ? thrTS : thr) && numTests <= 3; test |= (unsigned) t << q; numTests += t; }
+      test = uni((int) test);
+      if (!((test >> 1) & 1)) continue;
+    }
     unsigned long long sse; int cbf;
-    if (k == 0) wave_code_block<SMALL>(org_tile(scratch, P), 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf);
+    if (k == 0 && !(MTS && mtsOk)) wave_code_block<SMALL>(org_tile(scratch, P), 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf);
+    else if (k == 0) wave_code_block<SMALL, true>(org_tile(scratch, P), 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf, -1, &sum0);
     else wave_code_block_mts<SMALL>(org_tile(scratch, P), rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, mts, lane, sse, cbf);
     if (k) nmts++;
-    if (k == 0) cbfDCT2 = uni(cbf);
+    if (k == 0) { cbfDCT2 = uni(cbf); if (MTS && mtsOk) test = 0x1f; }      // k = 1 is entered to run the pruning
     if (k && !uni(cbf)) continue;                        // an MTS index is not coded for a zero block: forbidden (cost MAX_DOUBLE)
     const long long tb2 = STAMP();
     // xGetIntraFracBitsQT: header + cbf + residual from the node's start contexts
