@@ -92,8 +92,8 @@ struct Tables {                    // constant tables staged once per workgroup 
   int8_t   gauss[128], cubic[128];
   uint8_t  last_prefix[8], mode_shift[8];
   uint8_t  ctx_rate[NCTX + 2], gorice_pars[32], gorice_pos0[96], group_idx[64], mode_num[36], intra_thr[8];
-  int8_t   dst7[16 + 64 + 256 + 1024];   // DST-VII 4..32 (explicit MTS); DCT-VIII[k][i] = (-1)^k DST-VII[k][n-1-i] is read from the same rows
-  int8_t   dct[4 + 16 + 64 + 256 + 1024 + (BUF >= 256 ? 4096 : 0)];   // DCT-II 2..32, and 64 when a 64-wide block can be LDS resident (64x4 = 256 samples)
+  alignas(16) int8_t dst7[16 + 64 + 256 + 1024];   // DST-VII 4..32 (explicit MTS); DCT-VIII[k][i] = (-1)^k DST-VII[k][n-1-i] is read from the same rows
+  alignas(16) int8_t dct[4 + 16 + 64 + 256 + 1024 + (BUF >= 256 ? 4096 : 0)];   // DCT-II 2..32, and 64 when a 64-wide block can be LDS resident (64x4 = 256 samples)
   uint8_t  cg_scan[52], grp_scan[228];   // diagonal scans (CL/Rom.cpp:87-131) as x | y << 4: inside a coefficient group {4x4, 2x2, 8x2, 2x8}; of the groups, per (log2 wg, log2 hg)
 };
 
@@ -1419,6 +1419,25 @@ __device__ __noinline__ void wave_sad_satd(const int16_t *org_g, const int16_t *
 }
 
 // ------------------------------------------------------------------------------------------------ transform + quant (one wave)
+// four matrix coefficients (int8, one 32-bit load) times four int16 samples (one 64-bit load) / four int32 values (one 128-bit load):
+// rows of the matrices and of the sample tiles start at multiples of their length (>= 4 elements) in 16-byte aligned buffers
+struct alignas(16) I32x4 { int x, y, z, w; };
+__device__ inline int dot4_s16(uint32_t m, uint2 d)
+{
+  return (int) (int8_t) m * (int) (int16_t) d.x + (int) (int8_t) (m >> 8) * (int) (int16_t) (d.x >> 16) + (int) (int8_t) (m >> 16) * (int) (int16_t) d.y + (int) (int8_t) (m >> 24) * (int) (int16_t) (d.y >> 16);
+}
+__device__ inline int dot4_resi(uint32_t m, uint2 a, uint2 b)     // coefficients times (a - b), element-wise int16
+{
+  return (int) (int8_t) m * ((int) (int16_t) a.x - (int) (int16_t) b.x) + (int) (int8_t) (m >> 8) * ((int) (int16_t) (a.x >> 16) - (int) (int16_t) (b.x >> 16))
+       + (int) (int8_t) (m >> 16) * ((int) (int16_t) a.y - (int) (int16_t) b.y) + (int) (int8_t) (m >> 24) * ((int) (int16_t) (a.y >> 16) - (int) (int16_t) (b.y >> 16));
+}
+__device__ inline int dot4_s32(uint32_t m, I32x4 d)
+{
+  return (int) (int8_t) m * d.x + (int) (int8_t) (m >> 8) * d.y + (int) (int8_t) (m >> 16) * d.z + (int) (int8_t) (m >> 24) * d.w;
+}
+// the same with the four data elements taken in reverse order (DCT-VIII rows are DST-VII rows on the reversed input)
+__device__ inline uint2 rev4_s16(uint2 d) { uint2 r; r.x = (d.y >> 16) | (d.y << 16); r.y = (d.x >> 16) | (d.x << 16); return r; }
+__device__ inline I32x4 rev4_s32(I32x4 d) { I32x4 r; r.x = d.w; r.y = d.z; r.z = d.y; r.w = d.x; return r; }
 template <bool SMALL> __device__ inline const int8_t *dct2_matrix(int n)
 {
   if (!SMALL && BUF < 256) {                            // HBM path of a build without the 64-point matrix in LDS: constant tables
@@ -1484,7 +1503,8 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   if (given < 0) for (int o = lane; o < zw * h; o += 64) {
     const int k = o >> lh, j = o & (h - 1);
     int s = 0;
-    for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + i] - rec[j * w + i]);
+    if (w >= 4) for (int i = 0; i < w; i += 4) s += dot4_resi(*(const uint32_t *) (Mw + k * w + i), *(const uint2 *) (org + j * w + i), *(const uint2 *) (rec + j * w + i));
+    else for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + i] - rec[j * w + i]);
     tmp[o] = (s + rnd1) >> shift1;
   }
   wave_sync();
@@ -1500,7 +1520,8 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   if (given < 0) for (int o = lane; o < zw * zh; o += 64) {
     const int m = o >> lzw, k = o & (zw - 1);
     int s = 0;
-    for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
+    if (h >= 4) for (int j = 0; j < h; j += 4) s += dot4_s32(*(const uint32_t *) (Mh + m * h + j), *(const I32x4 *) (tmp + k * h + j));
+    else for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
     const int c = (s + rnd2) >> shift2;
     if (SUMABS) coef_sum += iabs(c);
     const long long t = (long long) iabs(c) * qscale;
@@ -1519,18 +1540,23 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     const int right_shift = 6 - (tr_shift + qp / 6);
     int tbd = 32 + right_shift - 7; if (tbd > 16) tbd = 16;
     const int in_min = -(1 << (tbd - 1)), in_max = (1 << (tbd - 1)) - 1;
-    // inverse stage 1 (vertical): t[j*h + i] = clip((sum_k Mh[k][i] * deq(lev[k*w + j]) + 64) >> 7), j < zw
+    // dequantised coefficients once (they are clipped to 16 bits, Quant::dequant 423-549): deq[m*zw + k], int16 at the start of tmp,
+    // followed by the (16-bit clipped) output of the vertical stage: zw*zh + zw*h int16 <= the zw*h int32 the forward pass used
+    int16_t *deq = (int16_t *) tmp, *tcol = deq + zw * zh;
+    for (int o = lane; o < zw * zh; o += 64) {
+      const int m = o >> lzw, k = o & (zw - 1);
+      int q = lev[m * w + k]; q = q < in_min ? in_min : q > in_max ? in_max : q;
+      int v = right_shift > 0 ? (q * iscale + (1 << (right_shift - 1))) >> right_shift : (q * iscale) << (-right_shift);
+      deq[o] = (int16_t) (v < -32768 ? -32768 : v > 32767 ? 32767 : v);
+    }
+    wave_sync();
+    // inverse stage 1 (vertical): t[j*h + i] = clip((sum_k Mh[k][i] * deq[k][j] + 64) >> 7), j < zw
     for (int o = lane; o < zw * h; o += 64) {
       const int j = o >> lh, i = o & (h - 1);
       int s = 0;
-      for (int k = 0; k < zh; k++) {
-        int q = lev[k * w + j]; q = q < in_min ? in_min : q > in_max ? in_max : q;
-        int v = right_shift > 0 ? (q * iscale + (1 << (right_shift - 1))) >> right_shift : (q * iscale) << (-right_shift);
-        v = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
-        s += Mh[k * h + i] * v;
-      }
+      for (int k = 0; k < zh; k++) s += Mh[k * h + i] * deq[(k << lzw) + j];
       int v = (s + 64) >> 7;
-      tmp[o] = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+      tcol[o] = (int16_t) (v < -32768 ? -32768 : v > 32767 ? 32767 : v);
     }
     wave_sync();
     const int ishift2 = (6 + 15 - 1) - bd, irnd2 = 1 << (ishift2 - 1);
@@ -1538,7 +1564,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     for (int o = lane; o < P; o += 64) {
       const int j2 = o >> lw, i2 = o & (w - 1);
       int s = 0;
-      for (int k = 0; k < zw; k++) s += Mw[k * w + i2] * tmp[k * h + j2];
+      for (int k = 0; k < zw; k++) s += Mw[k * w + i2] * tcol[k * h + j2];
       int r = (s + irnd2) >> ishift2;
       r = r < -32768 ? -32768 : r > 32767 ? 32767 : r;
       int v = rec[o] + (int) (int16_t) r;
@@ -1590,8 +1616,8 @@ __device__ __noinline__ int wave_fwd_sumabs(const int16_t *org_g, const int16_t 
     const int k = o >> lh, j = o & (h - 1);
     int s = 0;
     // DCT-VIII[k][i] = (-1)^k DST-VII[k][n-1-i]: the DST-VII row applied to the reversed input, sign by the parity of k
-    if (trh == 1) { for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + w - 1 - i] - pred[j * w + w - 1 - i]); if (k & 1) s = -s; }
-    else for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + i] - pred[j * w + i]);
+    if (trh == 1) { for (int i = 0; i < w; i += 4) s += dot4_resi(*(const uint32_t *) (Mw + k * w + i), rev4_s16(*(const uint2 *) (org + j * w + w - 4 - i)), rev4_s16(*(const uint2 *) (pred + j * w + w - 4 - i))); if (k & 1) s = -s; }
+    else for (int i = 0; i < w; i += 4) s += dot4_resi(*(const uint32_t *) (Mw + k * w + i), *(const uint2 *) (org + j * w + i), *(const uint2 *) (pred + j * w + i));
     tmp[o] = (s + rnd1) >> shift1;
   }
   wave_sync();
@@ -1599,8 +1625,8 @@ __device__ __noinline__ int wave_fwd_sumabs(const int16_t *org_g, const int16_t 
   for (int o = lane; o < zw * zh; o += 64) {
     const int m = o >> lzw, k = o & (zw - 1);
     int s = 0;
-    if (trv == 1) { for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + h - 1 - j]; if (m & 1) s = -s; }
-    else for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
+    if (trv == 1) { for (int j = 0; j < h; j += 4) s += dot4_s32(*(const uint32_t *) (Mh + m * h + j), rev4_s32(*(const I32x4 *) (tmp + k * h + h - 4 - j))); if (m & 1) s = -s; }
+    else for (int j = 0; j < h; j += 4) s += dot4_s32(*(const uint32_t *) (Mh + m * h + j), *(const I32x4 *) (tmp + k * h + j));
     sa += iabs((s + rnd2) >> shift2);
   }
   sa = wave_sum_i32(sa);
@@ -1628,8 +1654,8 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
     const int k = o >> lh, j = o & (h - 1);
     int s = 0;
     // DCT-VIII[k][i] = (-1)^k DST-VII[k][n-1-i]: the DST-VII row applied to the reversed input, sign by the parity of k
-    if (trh == 1) { for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + w - 1 - i] - rec[j * w + w - 1 - i]); if (k & 1) s = -s; }
-    else for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + i] - rec[j * w + i]);
+    if (trh == 1) { for (int i = 0; i < w; i += 4) s += dot4_resi(*(const uint32_t *) (Mw + k * w + i), rev4_s16(*(const uint2 *) (org + j * w + w - 4 - i)), rev4_s16(*(const uint2 *) (rec + j * w + w - 4 - i))); if (k & 1) s = -s; }
+    else for (int i = 0; i < w; i += 4) s += dot4_resi(*(const uint32_t *) (Mw + k * w + i), *(const uint2 *) (org + j * w + i), *(const uint2 *) (rec + j * w + i));
     tmp[o] = (s + rnd1) >> shift1;
   }
   wave_sync();
@@ -1643,8 +1669,8 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
   if (given < 0) for (int o = lane; o < zw * zh; o += 64) {
     const int m = o >> lzw, k = o & (zw - 1);
     int s = 0;
-    if (trv == 1) { for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + h - 1 - j]; if (m & 1) s = -s; }
-    else for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
+    if (trv == 1) { for (int j = 0; j < h; j += 4) s += dot4_s32(*(const uint32_t *) (Mh + m * h + j), rev4_s32(*(const I32x4 *) (tmp + k * h + h - 4 - j))); if (m & 1) s = -s; }
+    else for (int j = 0; j < h; j += 4) s += dot4_s32(*(const uint32_t *) (Mh + m * h + j), *(const I32x4 *) (tmp + k * h + j));
     const int c = (s + rnd2) >> shift2;
     const long long t = (long long) iabs(c) * qscale;
     int q = (int) ((t + qadd) >> qbits);
@@ -1661,17 +1687,21 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
     const int right_shift = 6 - (tr_shift + qp / 6);
     int tbd = 32 + right_shift - 7; if (tbd > 16) tbd = 16;
     const int in_min = -(1 << (tbd - 1)), in_max = (1 << (tbd - 1)) - 1;
+    int16_t *deq = (int16_t *) tmp, *tcol = deq + zw * zh;       // as in wave_code_block: coefficients dequantised once, 16-bit intermediate
+    for (int o = lane; o < zw * zh; o += 64) {
+      const int m = o >> lzw, k = o & (zw - 1);
+      int q = lev[m * w + k]; q = q < in_min ? in_min : q > in_max ? in_max : q;
+      int v = right_shift > 0 ? (q * iscale + (1 << (right_shift - 1))) >> right_shift : (q * iscale) << (-right_shift);
+      deq[o] = (int16_t) (v < -32768 ? -32768 : v > 32767 ? 32767 : v);
+    }
+    wave_sync();
     for (int o = lane; o < zw * h; o += 64) {
       const int j = o >> lh, i = o & (h - 1);
       int s = 0;
-      for (int k = 0; k < zh; k++) {
-        int q = lev[k * w + j]; q = q < in_min ? in_min : q > in_max ? in_max : q;
-        int v = right_shift > 0 ? (q * iscale + (1 << (right_shift - 1))) >> right_shift : (q * iscale) << (-right_shift);
-        v = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
-        s += (trv == 1 ? ((k & 1) ? -Mh[k * h + h - 1 - i] : Mh[k * h + h - 1 - i]) : Mh[k * h + i]) * v;
-      }
+      if (trv == 1) for (int k = 0; k < zh; k++) { const int v = Mh[k * h + h - 1 - i] * deq[(k << lzw) + j]; s += (k & 1) ? -v : v; }
+      else for (int k = 0; k < zh; k++) s += Mh[k * h + i] * deq[(k << lzw) + j];
       int v = (s + 64) >> 7;
-      tmp[o] = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+      tcol[o] = (int16_t) (v < -32768 ? -32768 : v > 32767 ? 32767 : v);
     }
     wave_sync();
     const int ishift2 = (6 + 15 - 1) - bd, irnd2 = 1 << (ishift2 - 1);
@@ -1679,8 +1709,8 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
     for (int o = lane; o < P; o += 64) {
       const int j2 = o >> lw, i2 = o & (w - 1);
       int s = 0;
-      if (trh == 1) for (int k = 0; k < zw; k++) { const int v = Mw[k * w + w - 1 - i2] * tmp[k * h + j2]; s += (k & 1) ? -v : v; }
-      else for (int k = 0; k < zw; k++) s += Mw[k * w + i2] * tmp[k * h + j2];
+      if (trh == 1) for (int k = 0; k < zw; k++) { const int v = Mw[k * w + w - 1 - i2] * tcol[k * h + j2]; s += (k & 1) ? -v : v; }
+      else for (int k = 0; k < zw; k++) s += Mw[k * w + i2] * tcol[k * h + j2];
       int r = (s + irnd2) >> ishift2;
       r = r < -32768 ? -32768 : r > 32767 ? 32767 : r;
       int v = rec[o] + (int) (int16_t) r;
