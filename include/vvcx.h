@@ -100,6 +100,23 @@ int  vvcx_create(const vvcx_cfg *cfg, vvcx_handle **h);
 void vvcx_destroy(vvcx_handle *h);
 /* ≙ EncSlice::setUpLambda + slice QP (EL/EncSlice.cpp:107-149, 1568-1572) */
 int  vvcx_set_slice(vvcx_handle *h, const vvcx_slice *s);
+/* ---- slice-level inputs: what the reference derives before the CTU loop, as pure host functions ---- */
+typedef struct {
+  int32_t qp;                    /* slice QP (cfg QP) */
+  int32_t bit_depth;             /* 8 or 10 */
+  int32_t n_pts;                 /* chroma QP mapping pivots: cfg QpInValCb / QpOutValCb (SameCQPTablesForAllChroma 1), 1..8 */
+  int32_t qp_in[8], qp_out[8];   /* BIN/encoder_intra.cfg:86-87: "2 31 43" -> "2 32 41" */
+  int32_t cb_qp_offset, cr_qp_offset;   /* cfg CbQpOffset / CrQpOffset */
+  int32_t gop_size;              /* cfg GOPSize (1 for All-Intra): lambda scale 1 - clip(0, 0.5, 0.05 * (GOPSize - 1)) */
+  int32_t dep_quant;             /* cfg DepQuant: lambda * 2^(0.25/3) */
+} vvcx_slice_cfg;
+/* ≙ ChromaQpMappingTable::derivedChromaQPMappingTables (CL/Slice.cpp:1540-1581): table[q + 6*(bit_depth-8)] = mapped chroma QP of
+ * luma-scale QP q, q = -6*(bit_depth-8) .. 63 */
+int  vvcx_chroma_qp_table(int bit_depth, int n_pts, const int32_t *qp_in, const int32_t *qp_out, int32_t *table);
+/* ≙ EncSlice::calculateLambda for an I slice (EL/EncSlice.cpp:752-845: QPFactor 0.57 * scale, 2^((QP + 6*(bd-8) - 12)/3), DepQuant factor)
+ * + the chroma QPs QpParam uses (CL/Quant.cpp:68-106) + EncSlice::setUpLambda's distortion weights 2^((QP - QPc)/3) (107-149) */
+int  vvcx_derive_slice(const vvcx_slice_cfg *cfg, vvcx_slice *out);
+
 /* ≙ the model the fork's classifier asks at every qualifying luma node: Py_Initialize + joblib.load("Partition_32.pkl").predict(x)
  * per call (EL/EncCu.cpp:1140-1166, BIN/TEST.py:7-25), replaced by one upload of the forest's flattened sklearn tree arrays (host
  * pointers): root[n_trees]; feature / left / right [n_nodes] (children -1 at leaves, children after their parent); threshold[n_nodes]

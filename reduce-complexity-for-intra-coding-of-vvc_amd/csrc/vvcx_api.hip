@@ -122,6 +122,49 @@ extern "C" void vvcx_destroy(vvcx_handle *h)
   delete h;
 }
 
+// ---- slice-level inputs (host only)
+extern "C" int vvcx_chroma_qp_table(int bit_depth, int n_pts, const int32_t *qp_in, const int32_t *qp_out, int32_t *table)
+{
+  if (!qp_in || !qp_out || !table || n_pts < 1 || n_pts > 8 || (bit_depth != 8 && bit_depth != 10)) return fail(VVCX_ERR_ARG, "bad argument");
+  const int off = 6 * (bit_depth - 8), maxQp = 63;
+  for (int j = 0; j < n_pts; j++) {
+    if (qp_in[j] < -off || qp_in[j] > maxQp || qp_out[j] < -off || qp_out[j] > maxQp || (j && qp_in[j] <= qp_in[j - 1])) return fail(VVCX_ERR_ARG, "chroma QP pivot %d out of range or not increasing", j);
+  }
+  auto clipq = [&](int v) { return v < -off ? -off : v > maxQp ? maxQp : v; };
+  int32_t *t = table + off;                           // t[q], q = -off .. 63
+  t[qp_in[0]] = qp_out[0];
+  for (int k = qp_in[0] - 1; k >= -off; k--) t[k] = clipq(t[k + 1] - 1);
+  for (int j = 0; j + 1 < n_pts; j++) {
+    const int dIn = qp_in[j + 1] - qp_in[j], dOut = qp_out[j + 1] - qp_out[j], sh = (dIn + 1) >> 1;      // deltaQpInValMinus1 + 1 = dIn
+    for (int k = qp_in[j] + 1, m = 1; k <= qp_in[j + 1]; k++, m++) t[k] = t[qp_in[j]] + (dOut * m + sh) / dIn;
+  }
+  for (int k = qp_in[n_pts - 1] + 1; k <= maxQp; k++) t[k] = clipq(t[k - 1] + 1);
+  return VVCX_OK;
+}
+extern "C" int vvcx_derive_slice(const vvcx_slice_cfg *c, vvcx_slice *out)
+{
+  if (!c || !out) return fail(VVCX_ERR_ARG, "null argument");
+  const int off = 6 * (c->bit_depth - 8);
+  if (c->qp < -off || c->qp > 63 || c->gop_size < 1) return fail(VVCX_ERR_ARG, "qp / gop_size");
+  int32_t table[64 + 12];
+  const int rc = vvcx_chroma_qp_table(c->bit_depth, c->n_pts, c->qp_in, c->qp_out, table);
+  if (rc) return rc;
+  memset(out, 0, sizeof *out);
+  out->qp = c->qp;
+  double scale = 0.05 * (double) (c->gop_size - 1); scale = scale < 0.0 ? 0.0 : scale > 0.5 ? 0.5 : scale;
+  out->lambda = 0.57 * (1.0 - scale) * pow(2.0, ((double) c->qp + (double) off - 12.0) / 3.0);
+  if (c->dep_quant) out->lambda *= pow(2.0, 0.25 / 3.0);
+  const int offs[2] = { c->cb_qp_offset, c->cr_qp_offset };
+  for (int k = 0; k < 2; k++) {
+    const int mapped = table[c->qp + off];                                    // getMappedChromaQpValue(compID, qp), JVET_O0650
+    int q = mapped + offs[k]; q = q < -off ? -off : q > 63 ? 63 : q;           // QpParam (CL/Quant.cpp:95-97): map, add the offset, clip
+    out->qp_c[k] = q;
+    out->dist_weight[k] = pow(2.0, ((double) c->qp - (double) (mapped + offs[k])) / 3.0);      // setUpLambda 120-126: unclipped
+    if (c->dep_quant) out->dist_weight[k] *= (c->gop_size >= 8 ? pow(2.0, 0.1 / 3.0) : pow(2.0, 0.2 / 3.0));      // 127-130 (LFNST off)
+  }
+  return VVCX_OK;
+}
+
 // The partition forest of the FAST_ALGORITHM path (the reference: joblib.load("Partition_32.pkl").predict, BIN/TEST.py:21-25), as
 // flattened sklearn tree arrays; validated here so that the device walk cannot leave the arrays or loop.
 extern "C" int vvcx_set_forest(vvcx_handle *h, int n_trees, int n_nodes, int n_classes, const int32_t *root, const int32_t *feature, const double *threshold,

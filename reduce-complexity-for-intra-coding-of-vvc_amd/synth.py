@@ -22,25 +22,34 @@ def synth_frame(width, height, frame=0, bit_depth=8, seed=1234, chroma_texture=0
     return [np.clip(np.rint(p), 0, mx).astype(dt) for p in (Y, U, V)]
 
 
+def chroma_qp_table(bit_depth=8, qp_in=(2, 31, 43), qp_out=(2, 32, 41)):
+    """ChromaQpMappingTable::derivedChromaQPMappingTables (CL/Slice.cpp:1540-1581) for the cfg's pivots (BIN/encoder_intra.cfg:86-87);
+    returns {q: mapped chroma QP} for q = -6*(bit_depth-8) .. 63 (same algorithm as vvcx_chroma_qp_table, pinned by tests/golden/chroma_qp.npz)."""
+    off = 6 * (bit_depth - 8)
+    clip = lambda v: max(-off, min(63, v))
+    t = {qp_in[0]: qp_out[0]}
+    for k in range(qp_in[0] - 1, -off - 1, -1):
+        t[k] = clip(t[k + 1] - 1)
+    for j in range(len(qp_in) - 1):
+        d_in, d_out = qp_in[j + 1] - qp_in[j], qp_out[j + 1] - qp_out[j]
+        sh = (d_in + 1) >> 1
+        for m, k in enumerate(range(qp_in[j] + 1, qp_in[j + 1] + 1), 1):
+            v = d_out * m + sh
+            t[k] = t[qp_in[j]] + (v // d_in if v >= 0 else -((-v) // d_in))        # C integer division truncates towards zero
+    for k in range(qp_in[-1] + 1, 64):
+        t[k] = clip(t[k - 1] + 1)
+    return t
+
+
 def slice_params(qp, bit_depth=8, dep_quant=False):
-    """Slice-level inputs the hot path consumes (the caller's job in the reference):
-    lambda per EL/EncSlice.cpp:754-845 for an I slice (QPFactor 0.57, GOP size 1), chroma QP through the
-    cfg's mapping table (BIN/encoder_intra.cfg:94-95, identity below 31 here approximated by the VVC
-    default table for 4:2:0), distortion weights per EL/EncSlice.cpp:121-137."""
+    """Slice-level inputs the hot path consumes (the caller's job in the reference; same values as vvcx_derive_slice):
+    lambda per EL/EncSlice.cpp:752-845 for an I slice (QPFactor 0.57, GOP size 1), chroma QP through the cfg's mapping table
+    (QpInValCb "2 31 43" -> QpOutValCb "2 32 41", CbQpOffset / CrQpOffset 0), distortion weights per EL/EncSlice.cpp:107-137."""
     lam = 0.57 * 2.0 ** ((qp + 6 * (bit_depth - 8) - 12) / 3.0)
     if dep_quant:
         lam *= 2.0 ** (0.25 / 3.0)
-    # chroma QP mapping table of the cfg: QpInValCb "17 22 34 42", QpOutValCb "17 23 35 39" is the VTM6 CTC
-    # default; this fork's cfg gives points (2->2?, 31->32, 43->41).  Piecewise-linear through (31,32),(43,41).
-    def map_qp(q):
-        pts_in, pts_out = [31, 43], [32, 41]
-        if q <= pts_in[0]:
-            return q + (pts_out[0] - pts_in[0])
-        if q >= pts_in[-1]:
-            return q + (pts_out[-1] - pts_in[-1])
-        num = (pts_out[1] - pts_out[0]) * (q - pts_in[0])
-        den = pts_in[1] - pts_in[0]
-        return pts_out[0] + (num + den // 2) // den
-    qpc = map_qp(qp)
+    qpc = chroma_qp_table(bit_depth)[qp]
     w = 2.0 ** ((qp - qpc) / 3.0)
+    if dep_quant:
+        w *= 2.0 ** (0.2 / 3.0)
     return dict(qp=qp, qp_c=(qpc, qpc), lam=lam, dist_weight=(w, w))

@@ -96,6 +96,35 @@ def load_library(lib_path=None):
     return L
 
 
+class _SliceCfg(C.Structure):
+    _fields_ = [("qp", C.c_int32), ("bit_depth", C.c_int32), ("n_pts", C.c_int32), ("qp_in", C.c_int32 * 8), ("qp_out", C.c_int32 * 8),
+                ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32), ("gop_size", C.c_int32), ("dep_quant", C.c_int32)]
+
+
+def chroma_qp_table(bit_depth=8, qp_in=(2, 31, 43), qp_out=(2, 32, 41), lib_path=None):
+    """vvcx_chroma_qp_table: mapped chroma QP for q = -6*(bit_depth-8) .. 63 (host function of the library)"""
+    L = load_library(lib_path)
+    a = np.asarray(qp_in, np.int32); b = np.asarray(qp_out, np.int32); t = np.zeros(64 + 6 * (bit_depth - 8), np.int32)
+    L.vvcx_chroma_qp_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    if L.vvcx_chroma_qp_table(bit_depth, len(a), a.ctypes.data, b.ctypes.data, t.ctypes.data) != 0:
+        raise VvcxError(L.vvcx_last_error().decode())
+    return t
+
+
+def derive_slice(qp, bit_depth=8, qp_in=(2, 31, 43), qp_out=(2, 32, 41), cb_qp_offset=0, cr_qp_offset=0, gop_size=1, dep_quant=False, lib_path=None):
+    """vvcx_derive_slice: the slice-level inputs (lambda, chroma QPs, distortion weights) in the form set_slice takes"""
+    L = load_library(lib_path)
+    c = _SliceCfg(); c.qp, c.bit_depth, c.n_pts = qp, bit_depth, len(qp_in)
+    for i, (a, b) in enumerate(zip(qp_in, qp_out)):
+        c.qp_in[i], c.qp_out[i] = a, b
+    c.cb_qp_offset, c.cr_qp_offset, c.gop_size, c.dep_quant = cb_qp_offset, cr_qp_offset, gop_size, int(dep_quant)
+    out = _Slice()
+    L.vvcx_derive_slice.argtypes = [C.POINTER(_SliceCfg), C.POINTER(_Slice)]
+    if L.vvcx_derive_slice(C.byref(c), C.byref(out)) != 0:
+        raise VvcxError(L.vvcx_last_error().decode())
+    return dict(qp=out.qp, qp_c=(out.qp_c[0], out.qp_c[1]), lam=out.lam, dist_weight=(out.dist_weight[0], out.dist_weight[1]))
+
+
 class VvcxEncoder:
     """≙ one EncCu instance (EL/EncCu.h:80-230): create/init → per-slice set-up → compressCtu calls → destroy."""
 

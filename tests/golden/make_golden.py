@@ -314,6 +314,20 @@ def gen_trquant_mts():
     print("mts trquant cases", len(meta), "prune keep histogram", np.stack(prune).sum(axis=0))
 
 
+def gen_chroma_qp():
+    """ChromaQpMappingTable (CL/Slice.cpp:1529-1581) for pivot sets given the way the cfg gives them: the reference cfg's, the VTM
+    default, a single identity point and a four-point set; 8 and 10 bit."""
+    R.ref_chroma_qp_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    meta, pts, tabs = [], [], []
+    for bd in (8, 10):
+        for qin, qout in (((2, 31, 43), (2, 32, 41)), ((17, 22, 34, 42), (17, 23, 35, 39)), ((0,), (0,)), ((9, 23, 33, 42), (9, 24, 33, 37))):
+            a = np.array(qin, np.int32); b = np.array(qout, np.int32); t = np.zeros(64 + 6 * (bd - 8), np.int32)
+            assert R.ref_chroma_qp_table(bd, len(a), P(a), P(b), P(t)) == 0
+            meta.append((bd, len(a), len(t))); pts.append(np.pad(a, (0, 8 - len(a)))); pts.append(np.pad(b, (0, 8 - len(b)))); tabs.append(t)
+    np.savez_compressed(os.path.join(HERE, "chroma_qp.npz"), meta=np.array(meta, np.int32), pts=np.stack(pts), tables=np.concatenate(tabs))
+    print("chroma qp tables", len(meta))
+
+
 def gen_cclm():
     """CCLM prediction (xGetLumaRecPixels + xGetLMParameters + predIntraChromaLM) for LM / MDLM_L / MDLM_T over random partial
     reconstructions, real availability logic of the chroma tree."""
@@ -480,6 +494,8 @@ if __name__ == "__main__":
         gen_trquant(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream":
         gen_bitstream(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "chroma_qp":
+        gen_chroma_qp(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream_mts":
         gen_bitstream_mts(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "trquant_mts":
@@ -488,5 +504,5 @@ if __name__ == "__main__":
         gen_bitstream_cclm(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_chroma_qp()
     print("done")
