@@ -209,3 +209,21 @@ def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fix
         assert [len(enc.get_payload(0, t)) for t in range(int(tc) * int(tr))] == list(sizes[:int(tc) * int(tr)])
         assert np.array_equal(got, exp), (W, H, qp, tc, tr, bd)
         enc.close()
+
+
+def test_seeded_sweep_over_sizes_qps_tools_and_tiles():
+    """A wider net for rare paths (cached LM mode reused where CCLM is not allowed, 32-point MTS zero-out, big nodes on the HBM path,
+    boundary CTUs in both directions, classifier with tiles): twelve seeded configurations, each bit-exact against the oracle."""
+    rng = np.random.default_rng(20261003)
+    sizes = [(128, 128), (192, 128), (136, 200), (256, 192), (320, 136), (264, 264)]
+    tool_sets = [pkg.TOOLS_DEFAULT, pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM, MTS, MTS | pkg.TOOL_FAST, pkg.TOOL_MRL | pkg.TOOL_MTS | pkg.TOOL_CCLM, pkg.TOOL_CCLM]
+    for i in range(12):
+        W, H = sizes[int(rng.integers(len(sizes)))]
+        qp = int(rng.choice([20, 24, 27, 30, 32, 35, 39, 42]))
+        bd = 10 if i % 5 == 4 else 8
+        tools = tool_sets[i % len(tool_sets)]
+        ctw, cth = (W + 127) // 128, (H + 127) // 128
+        tc, tr = int(rng.integers(1, ctw + 1)), int(rng.integers(1, cth + 1))
+        tex = float(rng.choice([0.0, 0.3, 0.7]))
+        planes = pkg.synth_frame(W, H, int(rng.integers(0, 4)), bd, int(rng.integers(1, 1 << 20)), chroma_texture=tex)
+        _check([planes], W, H, pkg.slice_params(qp, bit_depth=bd), bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools)
