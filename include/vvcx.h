@@ -138,6 +138,9 @@ int  vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out /* [n_frame
 /* final CU table of one bound frame (CTU raster order; per CTU luma CUs then chroma CUs, by origin).
  * ≙ walking cs.cus after the CTU loop; same fields D_BLOCK_STATISTICS_CODED traces */
 int  vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus, int *n_cus);
+/* ≙ tu.getCoeffs(compID) of the final TUs: the quantised levels of component comp (0 Y, 1 Cb, 2 Cr) at their sample positions, copied to
+ * a host plane (what a caller needs to rebuild cs.tus for the reference's own CABACWriter instead of taking vvcx_get_payload) */
+int  vvcx_get_levels(vvcx_handle *h, int frame, int comp, int16_t *plane, int stride);
 /* slice_data() payload of one completely coded tile of a bound frame: the bytes EncSlice::encodeSlice would hand to the NAL writer
  * for that brick (CABACWriter::coding_tree_unit per CTU, end_of_ctu / end_of_slice terminating bins, byte alignment;
  * EL/EncSlice.cpp:1884-2006).  Requires cfg.emit_payload.  buf is host memory */

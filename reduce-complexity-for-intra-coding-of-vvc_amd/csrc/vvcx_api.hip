@@ -349,6 +349,20 @@ extern "C" int vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out, 
   return VVCX_OK;
 }
 
+// quantised levels of one component of a coded picture at their sample positions (≙ tu.getCoeffs(compID) of the final TUs), host plane
+extern "C" int vvcx_get_levels(vvcx_handle *h, int frame, int comp, int16_t *plane, int stride)
+{
+  if (!h || !plane || frame < 0 || frame >= h->n_frames || comp < 0 || comp > 2) return fail(VVCX_ERR_ARG, "bad argument");
+  const int w = comp ? h->cfg.pic_w >> 1 : h->cfg.pic_w, hh = comp ? h->cfg.pic_h >> 1 : h->cfg.pic_h;
+  if (stride < w) return fail(VVCX_ERR_ARG, "stride smaller than the plane width");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int16_t *src = h->lev_d + (size_t) frame * h->lev_frame + (comp == 0 ? 0 : comp == 1 ? h->lev_plane[0] : h->lev_plane[0] + h->lev_plane[1]);
+  std::vector<int16_t> tmp((size_t) w * hh);
+  HIPCHK(hipMemcpy(tmp.data(), src, tmp.size() * 2, hipMemcpyDeviceToHost));
+  for (int y = 0; y < hh; y++) memcpy(plane + (size_t) y * stride, tmp.data() + (size_t) y * w, (size_t) w * 2);
+  return VVCX_OK;
+}
+
 extern "C" int vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus, int *n_cus)
 {
   if (!h || !n_cus || frame < 0 || frame >= h->n_frames) return fail(VVCX_ERR_ARG, "bad argument");

@@ -156,6 +156,17 @@ class VvcxEncoder:
                                          forest["feature"].ctypes.data, forest["threshold"].ctypes.data, forest["left"].ctypes.data,
                                          forest["right"].ctypes.data, forest["value"].ctypes.data, forest["classes"].ctypes.data))
 
+    def get_levels(self, frame):
+        """quantised levels of the coded picture: three int16 planes (Y, Cb, Cr)"""
+        out = []
+        self.L.vvcx_get_levels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        for c in range(3):
+            w, h = (self.cfg.pic_w, self.cfg.pic_h) if c == 0 else (self.cfg.pic_w >> 1, self.cfg.pic_h >> 1)
+            a = np.zeros((h, w), np.int16)
+            self._chk(self.L.vvcx_get_levels(self.h, frame, c, a.ctypes.data, w))
+            out.append(a)
+        return out
+
     def forest_predict(self, rows):
         """the forest's class for each row of 26 int32 features (≙ BIN/TEST.py GetPartition)"""
         rows = np.ascontiguousarray(rows, np.int32).reshape(-1, 26)

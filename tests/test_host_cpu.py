@@ -101,6 +101,8 @@ def test_emulated_slice_data_writer_matches_oracle(emu_so, tools):
     enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
     enc.compress_bound_frames()
     assert np.array_equal(enc.get_payload(0, 0), payload)
+    _, _, _, olev = O.write_frame(planes, w, h, sp, tools=tools)
+    assert all(np.array_equal(a, b) for a, b in zip(enc.get_levels(0), olev))          # vvcx_get_levels: the coded levels, plane layout
     enc.close()
 
 
