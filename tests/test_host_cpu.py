@@ -158,3 +158,20 @@ def test_slice_level_inputs_match_the_reference_mapping_table(emu_so):
             assert a["qp_c"] == b["qp_c"] and a["lam"] == b["lam"] and a["dist_weight"] == b["dist_weight"], (bd, qp, a, b)
     with pytest.raises(pkg.VvcxError):
         vv.chroma_qp_table(8, (31, 20), (32, 21), lib_path=emu_so)          # pivots must increase
+
+
+def test_cpp_caller_of_the_c_abi(emu_so, tmp_path):
+    """examples/encode_intra.cpp — a C++ program that uses nothing but include/vvcx.h (derive slice, bind, compress, CUs, payload) — built
+    with g++ against the emulation build of the library: its slice data must be the oracle's, frame by frame."""
+    exe = str(tmp_path / "encode_intra")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "encode_intra.cpp"), "-o", exe,
+                           "-L", os.path.dirname(emu_so), "-lvvcx_emu", "-ldl", "-Wl,-rpath," + os.path.dirname(emu_so)])
+    w, h, qp = 40, 24, 32
+    frames = [pkg.synth_frame(w, h, f, 8, 1000 + f, chroma_texture=0.5) for f in range(2)]
+    yuv = tmp_path / "in.yuv"
+    yuv.write_bytes(b"".join(p.tobytes() for f in frames for p in f))
+    out = subprocess.run([exe, str(yuv), str(w), str(h), "2", str(qp), str(tmp_path / "out.bin"), "--host-memory"], capture_output=True, text=True, check=True).stdout
+    assert out.count("frame ") == 2
+    tools = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS
+    exp = b"".join(O.write_frame(f, w, h, pkg.slice_params(qp), tools=tools)[0].tobytes() for f in frames)
+    assert (tmp_path / "out.bin").read_bytes() == exp
