@@ -125,6 +125,9 @@ int  orc_fast_region_var(const int16_t *p, int stride, int w, int h);
 void orc_fast_block_features(const int16_t *org, int stride, int w, int h, int feat[26]);
 void orc_fast_context_features(const int nb[][3], int n, int feat[26]);
 int  orc_forest_predict(const orc_forest *f, const int feat[26]);
+/* deblocking filter (orc_deblock.c) */
+void orc_deblock_luma_segment(int16_t *s, int o, int step, int sizeP, int sizeQ, int ctuTop, int qp, int bd, int beta_off2, int tc_off2);
+void orc_deblock_chroma_segment(int16_t *s, int o, int step, int sizeP, int sizeQ, int ctuTop, int qp, int bd, int beta_off2, int tc_off2);
 /* residual_coding on the estimator (orc_rate.c) */
 void orc_residual_coding(orc_cabac *c, const int16_t *level, int w, int h, int is_chroma);
 void orc_residual_coding_mts(orc_cabac *c, const int16_t *level, int w, int h, int is_chroma, int mts_idx);

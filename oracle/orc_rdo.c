@@ -1337,3 +1337,46 @@ int orc_test_mpm(int pic_w, int pic_h, const int *nb, int n_nb, int x, int y, in
   orc_destroy(e);
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * deblocking of the coded picture (LoopFilter::loopFilterPic, CL/LoopFilter.cpp:153-262): every CU has one TU, so the filtered edges are
+ * the left and top edges of the CUs of each tree; all vertical edges first, then all horizontal ones; boundary strength 2 everywhere.
+ * Luma edges lie on the 4x4 grid, chroma edges on the 8x8 chroma-sample grid (1217-1227); every CU has the slice QP.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_deblock_frame(orc_enc *e, int beta_offset_div2, int tc_offset_div2)
+{
+  const int bd = e->cfg.bit_depth, qp = e->sl.qp;
+  for (int dir = 0; dir < 2; dir++) {                 /* 0: vertical edges, 1: horizontal edges */
+    for (int uy = 0; uy < e->uh; uy++) for (int ux = 0; ux < e->uw; ux++) {
+      const unit_t *u = &e->um[0][uy * e->uw + ux];
+      const int x = ux << 2, y = uy << 2, st = e->stride[0];
+      if (!u->valid) continue;
+      if (dir == 0 && u->x == x && x > 0) {
+        const unit_t *p = &e->um[0][uy * e->uw + ux - 1];
+        orc_deblock_luma_segment(e->rec[0] + y * st + x, 1, st, 1 << p->lw, 1 << u->lw, 0, qp, bd, beta_offset_div2, tc_offset_div2);
+      }
+      if (dir == 1 && u->y == y && y > 0) {
+        const unit_t *p = &e->um[0][(uy - 1) * e->uw + ux];
+        orc_deblock_luma_segment(e->rec[0] + y * st + x, st, 1, 1 << p->lh, 1 << u->lh, (y & 127) == 0, qp, bd, beta_offset_div2, tc_offset_div2);
+      }
+    }
+    if (!e->cfg.chroma) continue;
+    for (int uy = 0; uy < e->uh; uy++) for (int ux = 0; ux < e->uw; ux++) {
+      const unit_t *u = &e->um[1][uy * e->uw + ux];
+      const int cx = ux << 1, cy = uy << 1;          /* chroma samples of this unit: 2x2 */
+      if (!u->valid) continue;
+      for (int k = 0; k < 2; k++) {
+        const int st = e->stride[k + 1], qpc = e->sl.qp_c[k] < 0 ? 0 : e->sl.qp_c[k] > 63 ? 63 : e->sl.qp_c[k];
+        if (dir == 0 && u->x == cx && cx > 0 && (cx & 7) == 0) {
+          const unit_t *p = &e->um[1][uy * e->uw + ux - 1];
+          orc_deblock_chroma_segment(e->rec[k + 1] + cy * st + cx, 1, st, 1 << p->lw, 1 << u->lw, 0, qpc, bd, beta_offset_div2, tc_offset_div2);
+        }
+        if (dir == 1 && u->y == cy && cy > 0 && (cy & 7) == 0) {
+          const unit_t *p = &e->um[1][(uy - 1) * e->uw + ux];
+          orc_deblock_chroma_segment(e->rec[k + 1] + cy * st + cx, st, 1, 1 << p->lh, 1 << u->lh, (cy & 63) == 0, qpc, bd, beta_offset_div2, tc_offset_div2);
+        }
+      }
+    }
+  }
+  return 0;
+}

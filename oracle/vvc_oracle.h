@@ -108,6 +108,8 @@ int      orc_set_training_dump(orc_enc *e, int32_t *rows, int cap_rows);
 int      orc_training_rows(const orc_enc *e);
 int      orc_fast_features(const int16_t *org, int stride, int w, int h, int feat[26]);   /* test hook: block features 4..11, 21..25 */
 int      orc_forest_predict_rows(orc_enc *e, const int32_t *rows, int n, int32_t *out);   /* test hook: forest on n rows of 26 ints */
+/* deblocking filter on the coded picture (CL/LoopFilter.cpp; after orc_compress_frame, before orc_get_reco): cfg LoopFilterBetaOffset_div2 / TcOffset_div2 */
+int      orc_deblock_frame(orc_enc *e, int beta_offset_div2, int tc_offset_div2);
 void     orc_get_counters(orc_enc *e, uint64_t out[4]); /* satd candidates, rd candidates, rd pixels, nodes */
 
 /* ---------------- leaf operators (individually testable; used by the golden-vector tests) -------- */

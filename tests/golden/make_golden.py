@@ -328,6 +328,31 @@ def gen_chroma_qp():
     print("chroma qp tables", len(meta))
 
 
+def gen_deblock():
+    """The reference's LoopFilter::loopFilterPic on pictures coded by the oracle (CU table + reconstruction before the filter): the
+    fixture keeps the filtered planes; the test recomputes the oracle's compress + deblock and must land on the same samples."""
+    import importlib, sys
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+    R.ref_env_deblock.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    meta, planes_all = [], []
+    for (W, H, qp, bd, seed, tools) in ((128, 128, 32, 8, 7, 0x911), (256, 256, 37, 8, 5, 0x911), (200, 136, 22, 8, 1234, 0x901), (256, 128, 42, 10, 3, 0x911), (384, 256, 27, 8, 21, 0x801)):
+        pl = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=0.5); sp = pkg.slice_params(qp, bit_depth=bd)
+        _, cus, pre, _ = O.compress_frame(pl, W, H, sp, bit_depth=bd, tools=tools)
+        env = R.ref_env_create(W, H, bd); R.ref_env_reset(env)
+        for c in range(3):
+            a = np.ascontiguousarray(pre[c].astype(np.int16)); R.ref_env_set_reco(env, c, P(a), a.shape[1])
+        rows = np.array([[c["ch_type"]] + [int(c[k]) * (2 if c["ch_type"] else 1) for k in ("x", "y", "w", "h")] for c in cus], np.int32)
+        outs = [np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)]
+        assert R.ref_env_deblock(env, P(rows), len(rows), qp, 0, 0, P(outs[0]), P(outs[1]), P(outs[2])) == 0
+        changed = [int((outs[c] != pre[c]).sum()) for c in range(3)]
+        assert min(changed) > 0
+        meta.append((W, H, qp, bd, seed, tools)); planes_all += [o.ravel() for o in outs]
+        print("deblock", W, H, qp, bd, "samples changed by the reference filter:", changed)
+    np.savez_compressed(os.path.join(HERE, "deblock.npz"), meta=np.array(meta, np.int32), planes=np.concatenate(planes_all))
+
+
 def gen_cclm():
     """CCLM prediction (xGetLumaRecPixels + xGetLMParameters + predIntraChromaLM) for LM / MDLM_L / MDLM_T over random partial
     reconstructions, real availability logic of the chroma tree."""
@@ -494,6 +519,8 @@ if __name__ == "__main__":
         gen_trquant(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream":
         gen_bitstream(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "deblock":
+        gen_deblock(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "chroma_qp":
         gen_chroma_qp(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream_mts":
@@ -504,5 +531,5 @@ if __name__ == "__main__":
         gen_bitstream_cclm(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_chroma_qp()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_chroma_qp(); gen_deblock()
     print("done")

@@ -101,7 +101,7 @@ def set_forest(L, e, forest):
         raise RuntimeError(L.orc_last_error().decode())
 
 
-def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOLS_DEFAULT, forest=None, training_rows=None):
+def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOLS_DEFAULT, forest=None, training_rows=None, deblock=False):
     """Run the oracle on one frame; returns (ctu results, cu table, reco planes, counters).  forest: flattened random forest for
     TOOL_FAST; training_rows: a list that receives the (n, 28) int32 array of the classifier's training rows of this frame."""
     L = lib()
@@ -130,6 +130,9 @@ def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chro
         n = C.c_int()
         rc = L.orc_compress_frame(e, res.ctypes.data, cus.ctypes.data, len(cus), C.byref(n))
         assert rc == 0
+        if deblock:                                   # in-loop deblocking of the coded picture (cfg offsets 0)
+            L.orc_deblock_frame.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            assert L.orc_deblock_frame(e, 0, 0) == 0
         reco = [np.zeros_like(p) for p in planes]
         rptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in reco])
         L.orc_get_reco(e, rptrs, strides, bps)
