@@ -145,6 +145,15 @@ def main():
                      "rd_pixels_per_launch": int(counters[2]), "nodes_per_launch": int(counters[3]),
                      "rd_pixels_per_s": float(counters[2]) / avg_kernel_s},
         }
+        # secondary kernel (not part of the timed step): in-loop deblocking of the pictures just coded, an HBM-bound pass
+        try:
+            db_ms = min(enc.deblock_bound_frames() for _ in range(1))
+            db_bytes = args.frames * (W * H * 3 // 2) * (2 if bd == 10 else 1) * 2          # every sample read once and written once
+            out["deblock"] = {"kernel": "vvcx_deblock_kernel_u8" if bd == 8 else "vvcx_deblock_kernel_u16", "launches": 2, "ms": db_ms, "frames": args.frames,
+                              "algorithmic_bytes": db_bytes, "achieved_GBps": db_bytes / (db_ms / 1e3) / 1e9 if db_ms > 0 else None, "frac_of_hbm_peak": db_bytes / (db_ms / 1e3) / 1e9 / HBM_PEAK_GBS if db_ms > 0 else None,
+                              "note": "deblocks the pictures of the last step once (a second call would filter filtered samples)"}
+        except Exception as ex:                                   # an older --lib build without the kernel
+            out["deblock"] = {"error": str(ex)}
         if not args.no_cpu_baseline and world == 1:
             import oracle_lib as O
             n = max(1, min(args.cpu_sample_ctus, ctus_w * ctus_h))

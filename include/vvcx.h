@@ -141,6 +141,11 @@ int  vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus, int *n_c
 /* ≙ tu.getCoeffs(compID) of the final TUs: the quantised levels of component comp (0 Y, 1 Cb, 2 Cr) at their sample positions, copied to
  * a host plane (what a caller needs to rebuild cs.tus for the reference's own CABACWriter instead of taking vvcx_get_payload) */
 int  vvcx_get_levels(vvcx_handle *h, int frame, int comp, int16_t *plane, int stride);
+/* ≙ LoopFilter::loopFilterPic (CL/LoopFilter.cpp:153; called from EncGOP after the slices of a picture are compressed): in-loop deblocking
+ * of every bound picture, in place on its reconstruction planes; offsets = cfg LoopFilterBetaOffset_div2 / LoopFilterTcOffset_div2.
+ * Every CTU of the pictures must have been compressed.  SAO and ALF, which follow in the reference, are not built. */
+int  vvcx_deblock_bound_frames(vvcx_handle *h, int beta_offset_div2, int tc_offset_div2, void *hip_stream);
+float vvcx_last_deblock_ms(const vvcx_handle *h);
 /* slice_data() payload of one completely coded tile of a bound frame: the bytes EncSlice::encodeSlice would hand to the NAL writer
  * for that brick (CABACWriter::coding_tree_unit per CTU, end_of_ctu / end_of_slice terminating bins, byte alignment;
  * EL/EncSlice.cpp:1884-2006).  Requires cfg.emit_payload.  buf is host memory */

@@ -23,6 +23,8 @@ extern "C" __global__ void vvcx_leaf_cabac_kernel(uint16_t *io, int ctx, const u
 extern "C" __global__ void vvcx_leaf_rdcost_kernel(VxParams p, const unsigned long long *bits, const unsigned long long *dist, int n, double *cost);
 extern "C" __global__ void vvcx_leaf_scan_kernel(int w, int h, uint16_t *idx);
 extern "C" __global__ void vvcx_leaf_forest_kernel(VxParams p, const int32_t *rows, int n, int32_t *out);
+extern "C" __global__ void vvcx_deblock_kernel_u8(VxDeblockParams p);
+extern "C" __global__ void vvcx_deblock_kernel_u16(VxDeblockParams p);
 extern "C" __global__ void vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp, unsigned long long *out);
 
 static thread_local char g_err[512];
@@ -51,7 +53,7 @@ struct vvcx_handle {
   uint8_t *payload_d; uint64_t *payload_off_d; uint32_t *payload_cap_d; void *arith_d; std::vector<uint64_t> payload_off; std::vector<uint32_t> payload_cap;
   // FAST_ALGORITHM forest (vvcx_set_forest)
   VxForestNode *f_node_d; double *f_value_d; int32_t *f_root_d; int f_ntrees, f_nclasses; int32_t f_classes[8];
-  hipEvent_t ev0, ev1; float last_ms;
+  hipEvent_t ev0, ev1; float last_ms, last_deblock_ms;
   size_t lev_plane[3], lev_frame, units_plane, units_frame;
 };
 
@@ -348,6 +350,35 @@ extern "C" int vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out, 
   for (size_t k = 0; k < tasks.size(); k++) out[dst[k]] = tmp[k];
   return VVCX_OK;
 }
+
+// ≙ LoopFilter::loopFilterPic (CL/LoopFilter.cpp:153) on every bound picture, in place on the reconstruction planes the search wrote:
+// one launch for all vertical edges, one for all horizontal edges (vvcx_deblock.hip).  Every CTU of the pictures must have been coded.
+extern "C" int vvcx_deblock_bound_frames(vvcx_handle *h, int beta_offset_div2, int tc_offset_div2, void *hip_stream)
+{
+  if (!h) return fail(VVCX_ERR_ARG, "null handle");
+  if (!h->n_frames || !h->have_slice) return fail(VVCX_ERR_STATE, "no bound frames / slice");
+  for (size_t i = 0; i < h->next_idx.size(); i++)
+    if (h->next_idx[i] != (int) h->tile_ctus[i % (size_t) h->ntiles].size()) return fail(VVCX_ERR_STATE, "deblocking needs every CTU of the bound pictures coded (frame %d tile %d is not)", (int) (i / (size_t) h->ntiles), (int) (i % (size_t) h->ntiles));
+  if (beta_offset_div2 < -6 || beta_offset_div2 > 6 || tc_offset_div2 < -6 || tc_offset_div2 > 6) return fail(VVCX_ERR_ARG, "deblocking offsets outside -6..6");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  hipStream_t stream = (hipStream_t) hip_stream;
+  VxDeblockParams p; memset(&p, 0, sizeof p);
+  p.frames = h->frames_d; p.uw = h->uw; p.uh = h->uh; p.bit_depth = h->cfg.bit_depth; p.chroma = h->cfg.chroma;
+  p.qp = h->sl.qp; p.qp_c[0] = h->sl.qp_c[0]; p.qp_c[1] = h->sl.qp_c[1]; p.beta_off2 = beta_offset_div2; p.tc_off2 = tc_offset_div2;
+  const dim3 grid((unsigned) ((2 * h->uw * h->uh + 255) / 256), (unsigned) h->n_frames);
+  HIPCHK(hipEventRecord(h->ev0, stream));
+  for (int dir = 0; dir < 2; dir++) {
+    p.dir = dir;
+    if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_deblock_kernel_u8, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(vvcx_deblock_kernel_u16, grid, dim3(256), 0, stream, p);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipEventRecord(h->ev1, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  HIPCHK(hipEventElapsedTime(&h->last_deblock_ms, h->ev0, h->ev1));
+  return VVCX_OK;
+}
+extern "C" float vvcx_last_deblock_ms(const vvcx_handle *h) { return h ? h->last_deblock_ms : 0.f; }
 
 // quantised levels of one component of a coded picture at their sample positions (≙ tu.getCoeffs(compID) of the final TUs), host plane
 extern "C" int vvcx_get_levels(vvcx_handle *h, int frame, int comp, int16_t *plane, int stride)

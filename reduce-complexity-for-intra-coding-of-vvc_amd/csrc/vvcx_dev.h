@@ -74,6 +74,13 @@ struct VxParams {
   int32_t             f_classes[8];
 };
 
+struct VxDeblockParams {     // vvcx_deblock.hip
+  const VxFrameDev *frames;
+  int32_t uw, uh, bit_depth, chroma;
+  int32_t qp, qp_c[2];       // every CU carries the slice QP; mapped chroma QPs (+ offsets)
+  int32_t beta_off2, tc_off2, dir;      // cfg LoopFilterBetaOffset_div2 / LoopFilterTcOffset_div2; 0 = vertical edges, 1 = horizontal edges
+};
+
 // per-stream scratch layout (bytes)
 #define VXD_STORE_REC   (128 * 128 * 2)
 #define VXD_STORE_UNITS (32 * 32 * (int) sizeof(VxUnit))

@@ -156,6 +156,14 @@ class VvcxEncoder:
                                          forest["feature"].ctypes.data, forest["threshold"].ctypes.data, forest["left"].ctypes.data,
                                          forest["right"].ctypes.data, forest["value"].ctypes.data, forest["classes"].ctypes.data))
 
+    def deblock_bound_frames(self, beta_offset_div2=0, tc_offset_div2=0):
+        """in-loop deblocking of every bound (completely coded) picture, in place on the reconstruction planes; returns the kernel time in ms"""
+        self.L.vvcx_deblock_bound_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.L.vvcx_last_deblock_ms.restype = C.c_float
+        self.L.vvcx_last_deblock_ms.argtypes = [C.c_void_p]
+        self._chk(self.L.vvcx_deblock_bound_frames(self.h, beta_offset_div2, tc_offset_div2, None))
+        return float(self.L.vvcx_last_deblock_ms(self.h))
+
     def get_levels(self, frame):
         """quantised levels of the coded picture: three int16 planes (Y, Cb, Cr)"""
         out = []

@@ -227,3 +227,31 @@ def test_seeded_sweep_over_sizes_qps_tools_and_tiles():
         tex = float(rng.choice([0.0, 0.3, 0.7]))
         planes = pkg.synth_frame(W, H, int(rng.integers(0, 4)), bd, int(rng.integers(1, 1 << 20)), chroma_texture=tex)
         _check([planes], W, H, pkg.slice_params(qp, bit_depth=bd), bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools)
+
+
+@pytest.mark.parametrize("case", [(128, 128, 32, 8, 1, 1, 7, MTS), (256, 256, 37, 8, 2, 2, 5, MTS), (200, 136, 22, 8, 1, 1, 1234, pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM),
+                                  (256, 128, 42, 10, 1, 1, 3, MTS), (384, 256, 27, 8, 3, 2, 21, pkg.TOOLS_DEFAULT)])
+def test_deblocking_filter(case):
+    """vvcx_deblock_bound_frames against the oracle's deblocking (itself equal to the reference's LoopFilter output on these very
+    pictures: tests/golden/deblock.npz holds the first, second, fourth and fifth without tiles), two frames per call."""
+    import torch
+    W, H, qp, bd, tc, tr, seed, tools = case
+    sp = pkg.slice_params(qp, bit_depth=bd)
+    frames = [pkg.synth_frame(W, H, f, bd, seed + f, chroma_texture=0.5) for f in range(2)]
+    enc = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, tools=tools, max_frames=2)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    dev = []
+    for planes in frames:
+        org = [torch.from_numpy(np.ascontiguousarray(p if p.dtype == np.uint8 else p.view(np.int16))).cuda() for p in planes]
+        dev.append((org, [torch.zeros_like(t) for t in org]))
+    enc.bind_frames([([t.data_ptr() for t in o], [t.data_ptr() for t in r], [t.shape[1] for t in o]) for o, r in dev])
+    enc.compress_bound_frames()
+    ms = enc.deblock_bound_frames()
+    assert ms > 0
+    for planes, (o, r) in zip(frames, dev):
+        oreco = O.compress_frame(planes, W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools, deblock=True)[2]
+        for c in range(3):
+            got = r[c].cpu().numpy()
+            got = got if got.dtype == np.uint8 else got.view(np.uint16)
+            assert np.array_equal(got, oreco[c]), (case, c)
+    enc.close()

@@ -175,3 +175,27 @@ def test_cpp_caller_of_the_c_abi(emu_so, tmp_path):
     tools = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS
     exp = b"".join(O.write_frame(f, w, h, pkg.slice_params(qp), tools=tools)[0].tobytes() for f in frames)
     assert (tmp_path / "out.bin").read_bytes() == exp
+
+
+@pytest.mark.parametrize("case", [(64, 48, 32, (1, 1)), (72, 40, 37, (1, 1))])
+def test_deblocking_kernel_on_cpu_emulator_matches_oracle(emu_so, case):
+    """vvcx_deblock_bound_frames (the sources of vvcx_deblock.hip on the emulator) after a complete search, against the oracle's
+    deblocking, which tests/golden/deblock.npz pins to the reference's LoopFilter."""
+    w, h, qp, tiles = case
+    tools = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM
+    planes = pkg.synth_frame(w, h, 0, 8, 7, chroma_texture=0.5)
+    sp = pkg.slice_params(qp)
+    enc = pkg.VvcxEncoder(w, h, 8, tile_cols=tiles[0], tile_rows=tiles[1], tools=tools, lib_path=emu_so)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    org = [np.ascontiguousarray(p) for p in planes]
+    rec = [np.zeros_like(p) for p in planes]
+    enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
+    with pytest.raises(pkg.VvcxError):
+        enc.deblock_bound_frames()                    # nothing coded yet
+    enc.compress_bound_frames()
+    before = [r.copy() for r in rec]
+    enc.deblock_bound_frames()
+    oreco = O.compress_frame(planes, w, h, sp, tools=tools, tile_cols=tiles[0], tile_rows=tiles[1], deblock=True)[2]
+    assert all(np.array_equal(rec[c], oreco[c]) for c in range(3))
+    assert any((before[c] != rec[c]).any() for c in range(3))
+    enc.close()
