@@ -26,14 +26,21 @@ def main():
                            "from kernels where name like 'vvcx%' order by start"):
             f.write('"%s",%d,%d,%d,%d,%d,%d,%d,%d,%d,%d\n' % r)
     pmc = {}
+    pmc_db = {}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         p = os.path.join(src, sub, "p_results.db")
         if not os.path.exists(p):
             continue
         d = sqlite3.connect(p)
-        for name, val in d.execute("select counter_name, avg(value) from counters_collection where kernel_name like 'vvcx%' group by counter_name"):
+        for name, val in d.execute("select counter_name, avg(value) from counters_collection where kernel_name like 'vvcx_compress%' group by counter_name"):
             pmc[name] = val
+        for name, val in d.execute("select counter_name, avg(value) from counters_collection where kernel_name like 'vvcx_deblock%' group by counter_name"):
+            pmc_db[name] = val
     out = {"kernel": "vvcx_compress_kernel_u8", "per_launch_avg": pmc}
+    if pmc_db:
+        out["deblock_kernel_per_launch_avg"] = pmc_db
+        if "FETCH_SIZE" in pmc_db and "WRITE_SIZE" in pmc_db:
+            out["deblock_hbm_traffic_bytes_per_launch"] = int(pmc_db["FETCH_SIZE"] * 1024 * 2 + pmc_db["WRITE_SIZE"] * 1024)
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         out["hbm_traffic_bytes_per_launch"] = int(pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024)
         out["note"] = ("FETCH_SIZE/WRITE_SIZE in KiB from separate --pmc passes; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); "
