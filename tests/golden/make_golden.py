@@ -504,6 +504,13 @@ def _pictures(cases, tools, texture):
         for comp in range(3):
             d = np.zeros_like(lev[comp]); R.ref_dec_get_levels(env, comp, P(d), d.shape[1])
             assert np.array_equal(d, lev[comp]), "decoded levels differ"
+        # the reference decoder's reconstruction of the parsed picture (DecCu) must be the oracle's reconstruction, sample for sample
+        oreco = O.compress_frame(planes, W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools)[2]
+        R.ref_dec_reconstruct.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        dec = [np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)]
+        assert R.ref_dec_reconstruct(env, P(dec[0]), P(dec[1]), P(dec[2])) == 0
+        for comp in range(3):
+            assert np.array_equal(dec[comp], oreco[comp].astype(np.int16)), ("reference decoder reconstruction differs", comp, int((dec[comp] != oreco[comp]).sum()))
         pic_meta.append((W, H, qp, tc, tr, bd, seed, len(payload))); pic_bytes.append(payload); pic_sizes.append(np.pad(sizes, (0, 16 - len(sizes))))
         nlm = int(sum(1 for c in cus if c["ch_type"] == 1 and 67 <= c["intra_dir"] <= 69))
         nmts = int(sum(1 for c in cus if c["ch_type"] == 0 and c["mts_idx"] > 1))
