@@ -119,6 +119,7 @@ struct Lds {
   Cand cand[64]; double cand_cost[64]; double cand_had[64]; int n_cand;
   uint2 cand_ipa[64];              // prediction parameters of each SATD-stage candidate (initPredIntraParams), packed, derived once per operation
   Cand rd[16]; double rd_cost[16]; uint64_t rd_dist[16]; uint64_t rd_bits[16]; uint8_t rd_cbf[16]; uint8_t rd_mts[16]; int mts_evals[NW]; int n_rd;
+  int do_save;                      // after_intra_op: the controller accepted the intra result
   int wave_best[NW], wave_slot[NW]; // candidate index of each wave's best and the slot that holds it
   CtlState S; VxUnit cu;           // controller working set; CU record of the intra candidate being evaluated
   unsigned mpm[6], mpm_sorted[6]; int mpm_n;
@@ -2647,6 +2648,39 @@ __device__ __noinline__ int fast_candidates(const VxParams &p_, const VxFrameDev
 }
 __device__ void post(int op) { L.op = op; }
 __device__ void set_node(const Frame &f, int d) { L.nx = f.x; L.ny = f.y; L.nw = f.w; L.nh = f.h; L.nd = d; }
+// xCheckRDCostIntra's tail for the node on top of the frame stack (thread 0): winner chosen by the operation; CU-level rate; xCheckBestMode.
+// Returns 1 when the result becomes the node's best and has to be saved (OP_SAVE_INTRA / the fused tail of the operation).
+__device__ __noinline__ int ctrl_b_done(const VxParams &p_, const VxFrameDev &fd_)
+{
+  const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
+  const int ch = L.tree_ch, tile = L.cur_tile, sh = ch ? 1 : 0, d = L.d;
+  Frame &f = L.fr[d];
+      const int best = L.win_idx, ww = L.win_wave;
+      if (ch) L.cnt[0] += (unsigned long long) L.lm_nsatd;
+      if (!ch && L.n_rd) { int ex = 0; for (int k = 0; k < NW; k++) ex += L.mts_evals[k]; L.cnt[1] += (unsigned long long) ex; L.cnt[2] += (unsigned long long) (ex * f.w * f.h); }      // transform candidates beyond DCT2
+      L.cnt[1] += (unsigned long long) (ch ? 2 * L.n_rd : L.n_rd); L.cnt[2] += (unsigned long long) (ch ? 2 * L.n_rd * ((f.w >> 1) * (f.h >> 1)) : L.n_rd * f.w * f.h);
+      L.op_a = L.wave_slot[ww];                         // slot of that wave holding the winner's reco / levels
+      Sum &t = f.temp;
+      t.dist = L.rd_dist[best];
+      VxUnit &cu = L.cu;
+      cu.dir = L.rd[best].mode; cu.mrl = ch ? 0 : L.rd[best].mrl; cu.cbf = L.rd_cbf[best]; cu.mts = ch ? 0 : L.rd_mts[best];
+      // cu_pred_data + cu_residual bits (EL/EncCu.cpp:2593-2619) and the CU's end contexts are left in cu_bits / wctx[0]
+      // by the operation (luma: identical to the stage-B syntax from the same start contexts)
+      t.bits = L.cu_bits;
+      Cab cb; cb.ci = CI_W(0); cb.bits = 0;
+      enc_split_cu_mode(p, fd, cb, f, ch, tile, SPLIT_NONE);          // xEncodeDontSplit 5649-5662
+      t.bits += cb.bits;
+      t.cost = rd_cost(p, t.bits, t.dist);
+      t.n_cu = 1; t.f_bt = t.l_bt = f.bt; t.f_cbf = cu.cbf != 0; t.f_w = t.l_w = (int16_t) (f.w >> sh); t.f_h = t.l_h = (int16_t) (f.h >> sh); t.max_qt = f.qt; t.valid = 1;
+      f.phase = PH_ADVANCE;
+      if (use_mode_result(p, f, ch, ETM_INTRA, t)) {
+        f.best = t; f.has_best = 1;
+        set_node(f, d);
+        L.op_c = f.nmodes > 1;                          // ETM_POST_DONT_SPLIT still on the stack (not a single predicted mode): its setFromCs caches this result
+        return 1;                                       // store ← winner slot, ctxBest[d] ← wctx[0]
+      }
+      return 0;
+}
 
 // one controller step: runs until a parallel operation is posted (returns) or the CTU tree is finished (posts OP_DONE)
 __device__ __attribute__((always_inline)) inline void control_step(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
@@ -2793,32 +2827,9 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
       f.phase = PH_B_DONE;
       post(OP_STAGE_B); return;
     }
-    case PH_B_DONE: {                                   // winner chosen by the operation; CU-level rate; xCheckBestMode
-      const int best = L.win_idx, ww = L.win_wave;
-      if (ch) L.cnt[0] += (unsigned long long) L.lm_nsatd;
-      if (!ch && L.n_rd) { int ex = 0; for (int k = 0; k < NW; k++) ex += L.mts_evals[k]; L.cnt[1] += (unsigned long long) ex; L.cnt[2] += (unsigned long long) (ex * f.w * f.h); }      // transform candidates beyond DCT2
-      L.cnt[1] += (unsigned long long) (ch ? 2 * L.n_rd : L.n_rd); L.cnt[2] += (unsigned long long) (ch ? 2 * L.n_rd * ((f.w >> 1) * (f.h >> 1)) : L.n_rd * f.w * f.h);
-      L.op_a = L.wave_slot[ww];                         // slot of that wave holding the winner's reco / levels
-      Sum &t = f.temp;
-      t.dist = L.rd_dist[best];
-      VxUnit &cu = L.cu;
-      cu.dir = L.rd[best].mode; cu.mrl = ch ? 0 : L.rd[best].mrl; cu.cbf = L.rd_cbf[best]; cu.mts = ch ? 0 : L.rd_mts[best];
-      // cu_pred_data + cu_residual bits (EL/EncCu.cpp:2593-2619) and the CU's end contexts are left in cu_bits / wctx[0]
-      // by the operation (luma: identical to the stage-B syntax from the same start contexts)
-      t.bits = L.cu_bits;
-      Cab cb; cb.ci = CI_W(0); cb.bits = 0;
-      enc_split_cu_mode(p, fd, cb, f, ch, tile, SPLIT_NONE);          // xEncodeDontSplit 5649-5662
-      t.bits += cb.bits;
-      t.cost = rd_cost(p, t.bits, t.dist);
-      t.n_cu = 1; t.f_bt = t.l_bt = f.bt; t.f_cbf = cu.cbf != 0; t.f_w = t.l_w = (int16_t) (f.w >> sh); t.f_h = t.l_h = (int16_t) (f.h >> sh); t.max_qt = f.qt; t.valid = 1;
-      if (use_mode_result(p, f, ch, ETM_INTRA, t)) {
-        f.best = t; f.has_best = 1;
-        f.phase = PH_ADVANCE;
-        set_node(f, d);
-        L.op_c = f.nmodes > 1;                          // ETM_POST_DONT_SPLIT still on the stack (not a single predicted mode): its setFromCs caches this result
-        post(OP_SAVE_INTRA); return;                    // store ← winner slot, ctxBest[d] ← wctx[0]
-      }
-      f.phase = PH_ADVANCE; break;
+    case PH_B_DONE: {                                   // only reached when an operation was dispatched without the fused tail (see after_intra_op)
+      if (ctrl_b_done(p, fd)) { post(OP_SAVE_INTRA); return; }
+      break;
     }
     case PH_CHILD: {                                    // children loop of xCheckModeSplit (2065-2177)
       if (f.child >= f.nparts) {
@@ -2992,6 +3003,17 @@ __device__ __noinline__ void writer_suspend(const VxParams &p, int sidx) { ((Ari
 // The search of one tree of one CTU: thread 0 steps the mode controller, everybody executes the operation it posts.
 // Its own function: what is live across these calls (p, fd, scratch) fits the callee-saved registers; inlined into the
 // stream loop, the loop's bookkeeping was spilled to scratch around every operation.
+// Tail of the operations that evaluate the intra mode of a node (stage B, chroma RD, cached-result reuse): the controller's decision and,
+// when the result is accepted, the save that used to be a dispatch of its own (one controller round trip per evaluated node less).
+// Out of line: run_tree's barrier loop must contain exactly one thread-0 section of its own (see there).
+__device__ __noinline__ void after_intra_op(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
+{
+  if (threadIdx.x == 0) L.do_save = ctrl_b_done(p_, fd_);
+  __threadfence_block();
+  __syncthreads();
+  if (uni(L.do_save)) op_save_intra(p_, scratch, L.cu);
+}
+
 template <typename T>
 __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
@@ -3022,14 +3044,14 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
     switch (op) {
       case OP_LUMA_PREP: op_luma_prep<T>(p, fd); if (uni(L.op_c)) op_stage_a(p, scratch); break;
       case OP_STAGE_A: op_stage_a(p, scratch); break;
-      case OP_STAGE_B: op_stage_b(p, scratch); break;
-      case OP_CHROMA_RD: op_chroma_rd<T>(p, fd, scratch); break;
+      case OP_STAGE_B: op_stage_b(p, scratch); after_intra_op(p, fd, scratch); break;
+      case OP_CHROMA_RD: op_chroma_rd<T>(p, fd, scratch); after_intra_op(p, fd, scratch); break;
       case OP_SAVE_INTRA: op_save_intra(p, scratch, L.cu); break;
       case OP_SAVE_PIC: op_save_pic<T>(p, fd, scratch, 0); break;
       case OP_RESTORE_PIC: ctx_copy_all(ctx_ptr(scratch, L.op_a, L.op_c, 0), ctx_ptr(scratch, L.op_b, L.op_c, 0)); op_save_pic<T>(p, fd, scratch, 1); break;
       case OP_CLEAR_UNITS: op_clear_units(p, fd); break;
       case OP_CTX_COPY: ctx_copy_all(ctx_ptr(scratch, L.op_a, L.op_c, 0), ctx_ptr(scratch, L.op_b, L.op_c, 0)); __threadfence_block(); break;
-      case OP_REUSE: op_reuse<T>(p, fd, scratch); break;
+      case OP_REUSE: op_reuse<T>(p, fd, scratch); after_intra_op(p, fd, scratch); break;
       case OP_FAST: op_fast<T>(p, fd); break;
     }
     __syncthreads();

@@ -255,3 +255,36 @@ def test_deblocking_filter(case):
             got = got if got.dtype == np.uint8 else got.view(np.uint16)
             assert np.array_equal(got, oreco[c]), (case, c)
     enc.close()
+
+
+def test_size_independent_properties_4k_ten_bit():
+    """BASELINE config 4's picture size (3840x2160, 10 bit, one tile per CTU = 510 streams): every luma and chroma sample covered by exactly
+    one CU of its tree, plausible PSNR, payload present for every tile, and two runs identical (CTU results, reconstruction, slice data)."""
+    import torch
+    W, H, bd = 3840, 2160, 10
+    planes = pkg.synth_frame(W, H, 0, bd, 4242, chroma_texture=0.5)
+    sp = pkg.slice_params(37, bit_depth=bd)
+    tc, tr = (W + 127) // 128, (H + 127) // 128
+    outs = []
+    for _ in range(2):
+        enc = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, tools=MTS, emit_payload=True)
+        enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+        org = [torch.from_numpy(np.ascontiguousarray(p.view(np.int16))).cuda() for p in planes]
+        rec = [torch.zeros_like(t) for t in org]
+        enc.bind_frames([([t.data_ptr() for t in org], [t.data_ptr() for t in rec], [t.shape[1] for t in org])])
+        res = enc.compress_bound_frames()
+        cus = enc.get_cus(0)
+        pay = [enc.get_payload(0, t) for t in (0, tc * tr // 2, tc * tr - 1)]
+        outs.append((res, cus, [r.cpu().numpy().view(np.uint16) for r in rec], pay))
+        enc.close()
+    res, cus, reco, pay = outs[0]
+    for ch, (w, h) in enumerate(((W, H), (W // 2, H // 2))):
+        cover = np.zeros((h, w), np.int16)
+        for c in cus[cus["ch_type"] == ch]:
+            cover[c["y"]:c["y"] + c["h"], c["x"]:c["x"] + c["w"]] += 1
+        assert (cover == 1).all()
+    mse = np.mean((planes[0].astype(np.float64) - reco[0].astype(np.float64)) ** 2)
+    assert 28.0 < 10 * np.log10(1023.0 ** 2 / mse) < 50.0
+    assert all(len(b) > 0 for b in pay)
+    assert all(np.array_equal(outs[0][0][k], outs[1][0][k]) for k in res.dtype.names)
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0][2], outs[1][2])) and all(np.array_equal(a, b) for a, b in zip(outs[0][3], outs[1][3]))
