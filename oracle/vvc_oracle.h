@@ -144,6 +144,10 @@ void orc_fill_ref_samples(const int16_t *reco, int stride, int pic_w, int pic_h,
 void orc_filter_ref_samples(const int16_t *ref_unf, int16_t *ref_flt, int w, int h, int mrl);
 void orc_pred_intra(const int16_t *ref_unf, const int16_t *ref_flt, int w, int h, int is_luma, int mode, int mrl,
                     int bit_depth, int16_t *pred, int pred_stride);
+/* CL/MatrixIntraPrediction.cpp (JVET_O0925 form): matrix-based intra prediction of a w x h luma block from its unfiltered line-0 reference
+ * samples top[w] / left[h]; mode 0 .. orc_mip_num_modes(w, h) - 1 (the upper half of the modes uses the transposed input) */
+int  orc_mip_num_modes(int w, int h);
+void orc_pred_mip(const int16_t *top, const int16_t *left, int w, int h, int mode, int bit_depth, int16_t *pred);
 /* CL/UnitTools.cpp:508-640 */
 void orc_get_mpms(int left_dir, int above_dir, unsigned mpm[6]);
 /* scan order (CL/Rom.cpp:87-370): fills idx[] with raster positions in coding order, returns count */

@@ -353,6 +353,29 @@ def gen_deblock():
     np.savez_compressed(os.path.join(HERE, "deblock.npz"), meta=np.array(meta, np.int32), planes=np.concatenate(planes_all))
 
 
+def gen_mip():
+    """Matrix-based intra prediction (MatrixIntraPrediction::prepareInputForPred + predBlock of the reference) for every block shape MIP
+    allows and every mode, from random reference samples."""
+    R.ref_mip_pred.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    g = np.random.default_rng(925)
+    meta, refs, preds = [], [], []
+    for bd in (8, 10):
+        for w in (4, 8, 16, 32, 64):
+            for h in (4, 8, 16, 32, 64):
+                if w > 4 * h or h > 4 * w:
+                    continue
+                nm = 35 if (w == 4 and h == 4) else 19 if (w <= 8 and h <= 8) else 11
+                base = g.integers(0, 1 << bd)
+                top = np.clip(base + np.cumsum(g.integers(-12, 13, w)) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(np.int16)
+                left = np.clip(base + np.cumsum(g.integers(-12, 13, h)) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(np.int16)
+                for mode in range(nm):
+                    out = np.zeros(w * h, np.int16)
+                    assert R.ref_mip_pred(w, h, bd, mode, P(top), P(left), P(out)) == 0
+                    meta.append((bd, w, h, mode)); refs.append(np.concatenate([top, left])); preds.append(out)
+    np.savez_compressed(os.path.join(HERE, "mip.npz"), meta=np.array(meta, np.int32), refs=np.concatenate(refs), preds=np.concatenate(preds))
+    print("mip cases", len(meta))
+
+
 def gen_cclm():
     """CCLM prediction (xGetLumaRecPixels + xGetLMParameters + predIntraChromaLM) for LM / MDLM_L / MDLM_T over random partial
     reconstructions, real availability logic of the chroma tree."""
@@ -526,6 +549,8 @@ if __name__ == "__main__":
         gen_trquant(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream":
         gen_bitstream(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mip":
+        gen_mip(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "deblock":
         gen_deblock(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "chroma_qp":
@@ -538,5 +563,5 @@ if __name__ == "__main__":
         gen_bitstream_cclm(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_chroma_qp(); gen_deblock()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_chroma_qp(); gen_deblock(); gen_mip()
     print("done")

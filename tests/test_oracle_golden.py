@@ -287,3 +287,19 @@ def test_deblocking_filter_against_the_reference_loop_filter():
         for c in range(3):
             n = reco[c].size
             assert np.array_equal(reco[c].astype(np.int16).ravel(), g["planes"][off:off + n]), (W, H, qp, bd, c); off += n
+
+
+def test_matrix_based_intra_prediction():
+    """MIP (prediction only): orc_pred_mip against MatrixIntraPrediction of the reference for every allowed block shape,
+    every mode (plain and transposed), 8 and 10 bit (tests/golden/make_golden.py mip)."""
+    L = O.lib()
+    g = np.load(os.path.join(G, "mip.npz"))
+    ro = po = 0
+    for (bd, w, h, mode) in g["meta"]:
+        w, h = int(w), int(h)
+        top = np.ascontiguousarray(g["refs"][ro:ro + w]); left = np.ascontiguousarray(g["refs"][ro + w:ro + w + h]); ro += w + h
+        exp = g["preds"][po:po + w * h]; po += w * h
+        out = np.zeros(w * h, np.int16)
+        L.orc_pred_mip(P(top), P(left), w, h, int(mode), int(bd), P(out))
+        assert np.array_equal(out, exp), (bd, w, h, mode)
+    assert L.orc_mip_num_modes(4, 4) == 35 and L.orc_mip_num_modes(8, 4) == 19 and L.orc_mip_num_modes(16, 4) == 11 and L.orc_mip_num_modes(32, 4) == 0
