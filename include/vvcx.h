@@ -189,6 +189,10 @@ int  vvcx_transform_quant_batch(const int16_t *org, const int16_t *pred, int w, 
 /* coefficient scan (diagonal, grouped) of a w x h block: idx[min(w,32) * min(h,32)] raster offsets in scan order */
 int  vvcx_scan_order(int w, int h, uint16_t *idx, int device);
 /* ≙ BIN/TEST.py GetPartition(C0..C25, 2): the forest of vvcx_set_forest on n rows of 26 int32 features (host pointers) → class per row */
+/* ≙ IntraPrediction::initIntraMip + predIntraMip (CL/IntraPrediction.cpp:2152-2205; MatrixIntraPrediction, JVET_O0925 form) for n luma
+ * blocks: cases = n x {w, h, mode, bit_depth}; refs = per case top[w] | left[h] (unfiltered line-0 reference samples); pred = per case w*h.
+ * The search does not call it yet (VVCX_TOOL_MIP is still refused). */
+int  vvcx_mip_pred_batch(const int32_t *cases, int n, const int16_t *refs, int n_refs, int16_t *pred, int n_pred, int device);
 int  vvcx_forest_predict_batch(vvcx_handle *h, const int32_t *rows, int n, int32_t *out);
 
 #ifdef __cplusplus

@@ -23,6 +23,8 @@ extern "C" __global__ void vvcx_leaf_cabac_kernel(uint16_t *io, int ctx, const u
 extern "C" __global__ void vvcx_leaf_rdcost_kernel(VxParams p, const unsigned long long *bits, const unsigned long long *dist, int n, double *cost);
 extern "C" __global__ void vvcx_leaf_scan_kernel(int w, int h, uint16_t *idx);
 extern "C" __global__ void vvcx_leaf_forest_kernel(VxParams p, const int32_t *rows, int n, int32_t *out);
+struct VxMipCase { int32_t w, h, mode, bit_depth, ref_off, pred_off; };
+extern "C" __global__ void vvcx_leaf_mip_kernel(const VxMipCase *cases, const int16_t *refs, int16_t *preds);
 extern "C" __global__ void vvcx_deblock_kernel_u8(VxDeblockParams p);
 extern "C" __global__ void vvcx_deblock_kernel_u16(VxDeblockParams p);
 extern "C" __global__ void vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp, unsigned long long *out);
@@ -554,6 +556,33 @@ extern "C" int vvcx_scan_order(int w, int h, uint16_t *idx, int device)
   hipLaunchKernelGGL(vvcx_leaf_scan_kernel, dim3(1), dim3(VXD_NT), 0, 0, w, h, d.as<uint16_t>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(idx, d.p, (size_t) n * 2, hipMemcpyDeviceToHost));
+  return VVCX_OK;
+}
+
+// ≙ IntraPrediction::initIntraMip + predIntraMip (CL/IntraPrediction.cpp:2152-2205) for n blocks: case i = {w, h, mode, bit_depth}, its
+// unfiltered line-0 reference samples top[w] | left[h] at refs + ref_off[i], prediction (w*h, stride w) to pred + pred_off[i]; host pointers
+extern "C" int vvcx_mip_pred_batch(const int32_t *cases, int n, const int16_t *refs, int n_refs, int16_t *pred, int n_pred, int device)
+{
+  if (!cases || !refs || !pred || n < 0) return fail(VVCX_ERR_ARG, "bad argument");
+  std::vector<VxMipCase> cs((size_t) n);
+  int ro = 0, po = 0;
+  for (int i = 0; i < n; i++) {
+    const int w = cases[4 * i], h = cases[4 * i + 1], mode = cases[4 * i + 2], bd = cases[4 * i + 3];
+    const bool shape = pow2_block(w, h) && w <= 64 && h <= 64 && w <= 4 * h && h <= 4 * w;
+    const int nm = !shape ? 0 : (w == 4 && h == 4) ? 35 : (w <= 8 && h <= 8) ? 19 : 11;
+    if (!shape || mode < 0 || mode >= nm || (bd != 8 && bd != 10)) return fail(VVCX_ERR_ARG, "MIP case %d: block %dx%d mode %d bit depth %d", i, w, h, mode, bd);
+    cs[(size_t) i] = { w, h, mode, bd, ro, po };
+    ro += w + h; po += w * h;
+  }
+  if (ro > n_refs || po > n_pred) return fail(VVCX_ERR_ARG, "reference / prediction buffers too small");
+  if (n == 0) return VVCX_OK;
+  HIPCHK(hipSetDevice(device));
+  DevBuf dc, dr, dp; HIPCHK(dc.alloc(sizeof(VxMipCase) * (size_t) n)); HIPCHK(dr.alloc((size_t) ro * 2)); HIPCHK(dp.alloc((size_t) po * 2));
+  HIPCHK(hipMemcpy(dc.p, cs.data(), sizeof(VxMipCase) * (size_t) n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dr.p, refs, (size_t) ro * 2, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(vvcx_leaf_mip_kernel, dim3((unsigned) n), dim3(64), 0, 0, dc.as<VxMipCase>(), dr.as<int16_t>(), dp.as<int16_t>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(pred, dp.p, (size_t) po * 2, hipMemcpyDeviceToHost));
   return VVCX_OK;
 }
 

@@ -96,6 +96,17 @@ def load_library(lib_path=None):
     return L
 
 
+def mip_pred_batch(cases, refs, lib_path=None, device=0):
+    """vvcx_mip_pred_batch: cases (n, 4) int32 {w, h, mode, bit_depth}; refs int16 (top | left per case); returns the concatenated predictions"""
+    L = load_library(lib_path)
+    cases = np.ascontiguousarray(cases, np.int32).reshape(-1, 4); refs = np.ascontiguousarray(refs, np.int16)
+    out = np.zeros(int((cases[:, 0] * cases[:, 1]).sum()), np.int16)
+    L.vvcx_mip_pred_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    if L.vvcx_mip_pred_batch(cases.ctypes.data, len(cases), refs.ctypes.data, len(refs), out.ctypes.data, len(out), device) != 0:
+        raise VvcxError(L.vvcx_last_error().decode())
+    return out
+
+
 class _SliceCfg(C.Structure):
     _fields_ = [("qp", C.c_int32), ("bit_depth", C.c_int32), ("n_pts", C.c_int32), ("qp_in", C.c_int32 * 8), ("qp_out", C.c_int32 * 8),
                 ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32), ("gop_size", C.c_int32), ("dep_quant", C.c_int32)]
