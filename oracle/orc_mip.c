@@ -63,9 +63,9 @@ void orc_pred_mip(const int16_t *top, const int16_t *left, int w, int h, int mod
   const int transpose = mode > numModes / 2;
   const int idx = transpose ? mode - numModes / 2 : mode;
   const uint8_t *matrix; int shiftM, offsetM;
-  if (w == 4 && h == 4) { matrix = &ORC_MIP_MATRIX_4x4[idx][0][0]; shiftM = ORC_MIP_SHIFT_4x4[idx]; offsetM = ORC_MIP_OFFSET_4x4[idx]; }
-  else if (small) { matrix = &ORC_MIP_MATRIX_8x8[idx][0][0]; shiftM = ORC_MIP_SHIFT_8x8[idx]; offsetM = ORC_MIP_OFFSET_8x8[idx]; }
-  else { matrix = &ORC_MIP_MATRIX_16x16[idx][0][0]; shiftM = ORC_MIP_SHIFT_16x16[idx]; offsetM = ORC_MIP_OFFSET_16x16[idx]; }
+  if (w == 4 && h == 4) { matrix = ORC_MIP_MATRIX_4x4 + idx * ORC_MIP_ROWS_4x4 * ORC_MIP_COLS_4x4; shiftM = ORC_MIP_SHIFT_4x4[idx]; offsetM = ORC_MIP_OFFSET_4x4[idx]; }
+  else if (small) { matrix = ORC_MIP_MATRIX_8x8 + idx * ORC_MIP_ROWS_8x8 * ORC_MIP_COLS_8x8; shiftM = ORC_MIP_SHIFT_8x8[idx]; offsetM = ORC_MIP_OFFSET_8x8[idx]; }
+  else { matrix = ORC_MIP_MATRIX_16x16 + idx * ORC_MIP_ROWS_16x16 * ORC_MIP_COLS_16x16; shiftM = ORC_MIP_SHIFT_16x16[idx]; offsetM = ORC_MIP_OFFSET_16x16[idx]; }
   int leaveHor = w == 4 && h >= 16, leaveVer = h == 4 && w >= 16;
   if (transpose) { const int t = leaveHor; leaveHor = leaveVer; leaveVer = t; }
   const int needUp = upH > 1 || upV > 1;

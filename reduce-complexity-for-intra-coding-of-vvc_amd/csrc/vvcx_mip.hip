@@ -43,9 +43,9 @@ __device__ void mip_reduced_pred(const int16_t *top, const int16_t *left, const 
   for (int i = 1; i < inSize; i++) in[i] -= inOff;
   in[0] = g.small ? inOff - (1 << (bd - 1)) : 0;
   const uint8_t *matrix; int shiftM, offsetM, cols;
-  if (g.w == 4 && g.h == 4) { matrix = &VX_MIP_MATRIX_4x4[idx][0][0]; shiftM = VX_MIP_SHIFT_4x4[idx]; offsetM = VX_MIP_OFFSET_4x4[idx]; cols = 4; }
-  else if (g.small) { matrix = &VX_MIP_MATRIX_8x8[idx][0][0]; shiftM = VX_MIP_SHIFT_8x8[idx]; offsetM = VX_MIP_OFFSET_8x8[idx]; cols = 8; }
-  else { matrix = &VX_MIP_MATRIX_16x16[idx][0][0]; shiftM = VX_MIP_SHIFT_16x16[idx]; offsetM = VX_MIP_OFFSET_16x16[idx]; cols = 7; }
+  if (g.w == 4 && g.h == 4) { matrix = VX_MIP_MATRIX_4x4 + idx * 16 * 4; shiftM = VX_MIP_SHIFT_4x4[idx]; offsetM = VX_MIP_OFFSET_4x4[idx]; cols = 4; }
+  else if (g.small) { matrix = VX_MIP_MATRIX_8x8 + idx * 16 * 8; shiftM = VX_MIP_SHIFT_8x8[idx]; offsetM = VX_MIP_OFFSET_8x8[idx]; cols = 8; }
+  else { matrix = VX_MIP_MATRIX_16x16 + idx * 64 * 7; shiftM = VX_MIP_SHIFT_16x16[idx]; offsetM = VX_MIP_OFFSET_16x16[idx]; cols = 7; }
   int leaveHor = g.w == 4 && g.h >= 16, leaveVer = g.h == 4 && g.w >= 16;
   if (transpose) { const int t = leaveHor; leaveHor = leaveVer; leaveVer = t; }
   const int iw = transpose ? g.rph : g.rpw, ih = transpose ? g.rpw : g.rph;            // the matrix stage's own output grid
