@@ -89,7 +89,7 @@ struct orc_enc {
 /* ------------------------------------------------------------------------------------------------ */
 orc_enc *orc_create(const orc_cfg *cfg)
 {
-  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MTS, CU reuse, CCLM, FAST)", cfg->tools); return 0; }
+  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, MTS, CU reuse, CCLM, FAST)", cfg->tools); return 0; }
   if (!cfg->dual_tree || cfg->ctu_size != 128) { snprintf(g_err, sizeof g_err, "oracle: only DualITree=1, CTUSize=128"); return 0; }
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7)) { snprintf(g_err, sizeof g_err, "oracle: picture size must be a multiple of 8 (EncAppCfg.cpp:2709)"); return 0; }
   orc_enc *e = (orc_enc *) calloc(1, sizeof *e);
@@ -398,21 +398,45 @@ static void enc_split_cu_mode(orc_enc *e, partitioner *P, int split)
 
 /* PU::getIntraMPMs neighbour lookup (CL/UnitTools.cpp:516-532): left PU at bottom-left, above PU at
  * top-right and only inside the same CTU */
+/* a MIP CU (cu.mipFlag) is carried as bit 7 of the unit's mrl field (MIP forces multiRefIdx 0) with the MIP mode in dir; every reader of a
+ * neighbour's luma mode goes through PU::getIntraDirLuma (CL/UnitTools.cpp:786-800), which is PLANAR for a MIP block */
+#define MIP_FLAG 0x80
+static int unit_luma_dir(const unit_t *u) { return (u->mrl & MIP_FLAG) ? ORC_PLANAR : u->dir; }
+static int mpm_neighbours(const orc_enc *e, int x, int y, int w, int h, int *L, int *A)
+{
+  *L = ORC_PLANAR; *A = ORC_PLANAR;
+  const unit_t *uL = get_cu(e, 0, x - 1, y + h - 1);
+  if (uL) *L = unit_luma_dir(uL);
+  const unit_t *uA = get_cu(e, 0, x + w - 1, y - 1);
+  if (uA && ((y - 1) >> 7) == (y >> 7)) *A = unit_luma_dir(uA);
+  return *L == *A ? 1 : 2;
+}
 static void get_mpms(const orc_enc *e, int x, int y, int w, int h, unsigned mpm[6])
 {
-  int L = ORC_PLANAR, A = ORC_PLANAR;
-  const unit_t *uL = get_cu(e, 0, x - 1, y + h - 1);
-  if (uL) L = uL->dir;
-  const unit_t *uA = get_cu(e, 0, x + w - 1, y - 1);
-  if (uA && ((y - 1) >> 7) == (y >> 7)) A = uA->dir;
+  int L, A; mpm_neighbours(e, x, y, w, h, &L, &A);
   orc_get_mpms(L, A, mpm);
 }
+/* mip_flag is present (EL/CABACWriter.cpp:4741-4767): SPS MIP on, both sides <= MaxTbSize (64), and mipModesAvailable: getNumModesMip
+ * (CL/UnitTools.cpp:4688-4708) is 0 for blocks beyond 4:1 */
+static int mip_signalled(const orc_enc *e, int w, int h) { return (e->cfg.tools & ORC_TOOL_MIP) && w <= 64 && h <= 64 && orc_mip_num_modes(w, h) > 0; }
 
 /* CABACWriter::intra_luma_pred_mode (1762-1845) with extend_ref_line (1566-1591); mip_flag / isp_mode
- * write nothing when the tools are off in the SPS */
+ * write nothing when the tools are off in the SPS.  mrl carries MIP_FLAG for a MIP CU (dir = MIP mode) */
 static void enc_intra_luma_pred_mode(orc_enc *e, int x, int y, int w, int h, int dir, int mrl)
 {
   orc_cabac *c = &e->cabac;
+  if (mip_signalled(e, w, h)) {
+    /* DeriveCtx::CtxMipFlag (CL/ContextModelling.cpp:555-569); mip_pred_mode 4781-4787 = xWriteTruncBinCode(mode, numModes) 1519-1564 */
+    const unit_t *uL = get_cu(e, 0, x - 1, y), *uA = get_cu(e, 0, x, y - 1);
+    unsigned ctx = (unsigned) ((uL && (uL->mrl & MIP_FLAG)) + (uA && (uA->mrl & MIP_FLAG)));
+    if (w > 2 * h || h > 2 * w) ctx = 3;
+    orc_enc_bin(c, (mrl & MIP_FLAG) != 0, ORC_CTX_MipFlag + (int) ctx);
+    if (mrl & MIP_FLAG) {
+      const int n = orc_mip_num_modes(w, h), thresh = ilog2(n), val = 1 << thresh, b = n - val;
+      if (dir < val - b) orc_enc_bins_ep(c, (uint32_t) dir, thresh); else orc_enc_bins_ep(c, (uint32_t) (dir + val - b), thresh + 1);
+      return;
+    }
+  }
   const int firstLine = (y & 127) == 0;
   if (!firstLine) {
     orc_enc_bin(c, mrl != 0, ORC_CTX_MultiRefLineIdx + 0);
@@ -441,7 +465,7 @@ static void enc_intra_luma_pred_mode(orc_enc *e, int x, int y, int w, int h, int
 static int colocated_luma_mode(const orc_enc *e, area_t a)
 {
   const int px = a.x + (a.w >> 1), py = a.y + (a.h >> 1);
-  return e->um[0][(py >> 2) * e->uw + (px >> 2)].dir;
+  return unit_luma_dir(&e->um[0][(py >> 2) * e->uw + (px >> 2)]);
 }
 static void chroma_cand_modes(const orc_enc *e, area_t a, int list[8])
 {
@@ -537,6 +561,55 @@ static void update_cand_list(minfo m, double cost, minfo *list, double *costs, i
   }
 }
 
+/* luma prediction of one candidate into e->pred (stride w): xIntraCodingTUBlock's initIntraPatternChType + predIntraAng, or for a MIP
+ * candidate initIntraMip + predIntraMip from the unfiltered line-0 references (CL/IntraPrediction.cpp:2152-2186) */
+static void mip_from_refs(orc_enc *e, int w, int h, int mode)
+{
+  int16_t top[64], left[64]; const int rs = 2 * w + 1;
+  for (int i = 0; i < w; i++) top[i] = e->ref_unf[1 + i];
+  for (int j = 0; j < h; j++) left[j] = e->ref_unf[(1 + j) * rs];
+  orc_pred_mip(top, left, w, h, mode, e->cfg.bit_depth, e->pred);
+}
+static void pred_luma_cand(orc_enc *e, int x, int y, int w, int h, int dir, int mrl)
+{
+  if (mrl & MIP_FLAG) { build_refs(e, 0, x, y, w, h, 0, 0); mip_from_refs(e, w, h, dir); return; }
+  orc_ipa ip; orc_init_pred_params(w, h, 1, dir, mrl, &ip);
+  build_refs(e, 0, x, y, w, h, mrl, ip.ref_filter);
+  orc_pred_intra(e->ref_unf, e->ref_flt, w, h, 1, dir, mrl, e->cfg.bit_depth, e->pred, w);
+}
+/* IntraSearch::reduceHadCandList (EL/IntraSearch.cpp:4331-4406, JVET_O0925 form, FastMIP 1): at most 3 regular candidates, MIP candidates
+ * up to half the list or within thresholdHadCost of the best, always one MIP; for blocks above 8x8 the best of MIP modes {3,4,5} (each in its
+ * better orientation) is appended when absent */
+static void reduce_had_cand_list(minfo *list, double *costs, int *size, int *numRd, double thr, const double *mipCost, int w, int h)
+{
+  const int maxPerType = *numRd >> 1;
+  minfo tl[80]; double tc[80]; int tn = 0;
+  const double minCost = costs[0];
+  int keepOneMip = *size > *numRd, numConv = 0, numMip = 0;
+  for (int idx = 0; idx < *size - (keepOneMip ? 0 : 1); idx++) {
+    int add;
+    if (!(list[idx].mrl & MIP_FLAG)) { add = numConv < 3; numConv += add; }
+    else { add = numMip < maxPerType || costs[idx] < thr * minCost || keepOneMip; keepOneMip = 0; numMip += add; }
+    if (add) { tl[tn] = list[idx]; tc[tn] = costs[idx]; tn++; }
+  }
+  if (w > 8 && h > 8) {
+    const int transpOff = orc_mip_num_modes(w, h) / 2;
+    minfo sm[3]; double sc[3]; int sn = 0;
+    for (int mode = 3; mode <= 5; mode++) {
+      const int cand = mode + (mipCost[mode + transpOff] < mipCost[mode] ? transpOff : 0);
+      update_cand_list((minfo) { cand, MIP_FLAG }, mipCost[cand], sm, sc, &sn, 3);
+    }
+    const int n0 = tn;
+    for (int idx = 0; idx < 3; idx++) {
+      int incl = 0;
+      for (int k = 0; k < n0; k++) incl |= tl[k].mode == sm[idx].mode && tl[k].mrl == sm[idx].mrl;
+      if (!incl) { tl[tn] = sm[idx]; tc[tn] = 0; tn++; break; /* fastMip */ }
+    }
+  }
+  memcpy(list, tl, sizeof(minfo) * (size_t) tn); memcpy(costs, tc, sizeof(double) * (size_t) tn);
+  *size = tn; *numRd = tn;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * estIntraPredLumaQT (EL/IntraSearch.cpp:289-1380), P0 subset.  Leaves the winner's reco/levels in
  * e->best_rec[0]/best_lev[0] (stride w).  Returns dist; *dir,*mrl,*cbf the winner.
@@ -551,6 +624,11 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
   int numRd = ORC_MODE_NUM_FAST_2D[(ilog2(w) - 2) * 6 + (ilog2(h) - 2)];
   minfo rdList[80]; double rdCost[80]; int rdSize = 0;
   minfo hadList[8]; double hadCost[8]; int hadSize = 0;
+  /* 404-418 with FastMIP 1 (BIN/encoder_intra.cfg): MIP is searched unless the block is more than 2:1; 469-477: the regular list is kept
+   * longer while MIP candidates compete for it */
+  const int testMip = mip_signalled(e, w, h) && !(w > 2 * h || h > 2 * w);
+  if (testMip) numRd += imax(numRd, ilog2(imin(w, h)) - 1);
+  const int numHad = testMip ? 6 : 3;
   uint8_t checked[ORC_NUM_LUMA_MODE]; memset(checked, 0, sizeof checked);
   const int firstLine = (y & 127) == 0;
   const int numRefPasses = (firstLine || !(e->cfg.tools & ORC_TOOL_MRL)) ? 1 : 3;
@@ -558,7 +636,7 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
   /* stage A: SATD pre-selection (483-682).  initIntraPatternChType(cu, Y, forceRefFilter=true) */
   build_refs(e, 0, x, y, w, h, 0, 1);
 #define SATD_COST(mode_, mrl_, cost_out, had_out) do { \
-    orc_pred_intra(e->ref_unf, e->ref_flt, w, h, 1, (mode_), (mrl_), bd, e->pred, w); \
+    if ((mrl_) & MIP_FLAG) mip_from_refs(e, w, h, (mode_)); else orc_pred_intra(e->ref_unf, e->ref_flt, w, h, 1, (mode_), (mrl_), bd, e->pred, w); \
     const uint64_t sad_ = orc_sad(org, e->stride[0], e->pred, w, w, h), satd_ = orc_satd(org, e->stride[0], e->pred, w, w, h); \
     const uint64_t msh_ = sad_ * 2 < satd_ ? sad_ * 2 : satd_; \
     orc_ctx_copy(&e->cabac, &ctxStart); e->cabac.bits = 0; \
@@ -569,7 +647,7 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
     checked[mode] = 1;
     double cost, had; SATD_COST(mode, 0, cost, had);
     update_cand_list((minfo) { mode, 0 }, cost, rdList, rdCost, &rdSize, numRd);
-    update_cand_list((minfo) { mode, 0 }, had, hadList, hadCost, &hadSize, 3);
+    update_cand_list((minfo) { mode, 0 }, had, hadList, hadCost, &hadSize, numHad);
   }
   {
     minfo parent[80]; memcpy(parent, rdList, sizeof(minfo) * (size_t) numRd);
@@ -581,7 +659,7 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
           if (!checked[mode]) {
             double cost, had; SATD_COST(mode, 0, cost, had);
             update_cand_list((minfo) { mode, 0 }, cost, rdList, rdCost, &rdSize, numRd);
-            update_cand_list((minfo) { mode, 0 }, had, hadList, hadCost, &hadSize, 3);
+            update_cand_list((minfo) { mode, 0 }, had, hadList, hadCost, &hadSize, numHad);
             checked[mode] = 1;
           }
         }
@@ -596,24 +674,43 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
       for (int k = 1; k < 6; k++) {
         double cost, had; SATD_COST((int) mpm[k], mrl, cost, had);
         update_cand_list((minfo) { (int) mpm[k], mrl }, cost, rdList, rdCost, &rdSize, numRd);
-        update_cand_list((minfo) { (int) mpm[k], mrl }, had, hadList, hadCost, &hadSize, 3);
+        update_cand_list((minfo) { (int) mpm[k], mrl }, had, hadList, hadCost, &hadSize, numHad);
       }
     }
+  }
+  if (testMip) {
+    /* 703-748: every MIP mode by SATD into the same list (one entry longer), then reduceHadCandList */
+    double mipCost[35];
+    build_refs(e, 0, x, y, w, h, 0, 0);
+    const int nMip = orc_mip_num_modes(w, h);
+    for (int mode = 0; mode < nMip; mode++) {
+      double cost, had; SATD_COST(mode, MIP_FLAG, cost, had);
+      mipCost[mode] = cost;
+      update_cand_list((minfo) { mode, MIP_FLAG }, cost, rdList, rdCost, &rdSize, numRd + 1);
+      update_cand_list((minfo) { mode, MIP_FLAG }, 0.8 * had, hadList, hadCost, &hadSize, numHad);
+    }
+    reduce_had_cand_list(rdList, rdCost, &rdSize, &numRd, 1.0 + 1.4 / sqrt((double) (w * h)), mipCost, w, h);
   }
 #undef SATD_COST
   {
     /* EL/IntraSearch.cpp:784-802: numCand = PU::getIntraMPMs(...) (1 if left==above dir else 2) */
     unsigned mpm[6];
-    int L = ORC_PLANAR, A = ORC_PLANAR;
-    const unit_t *uL = get_cu(e, 0, x - 1, y + h - 1); if (uL) L = uL->dir;
-    const unit_t *uA = get_cu(e, 0, x + w - 1, y - 1); if (uA && ((y - 1) >> 7) == (y >> 7)) A = uA->dir;
+    int L, A;
+    const int numCand = mpm_neighbours(e, x, y, w, h, &L, &A);
     orc_get_mpms(L, A, mpm);
-    const int numCand = (L == A) ? 1 : 2;
     for (int j = 0; j < numCand; j++) {
       int incl = 0;
       for (int i = 0; i < numRd; i++) incl |= (rdList[i].mode == (int) mpm[j] && rdList[i].mrl == 0);
       if (!incl) { rdList[numRd] = (minfo) { (int) mpm[j], 0 }; rdCost[numRd] = 0; numRd++; }
     }
+  }
+
+  if (testMip) {
+    /* 1097-1122: regular candidates first, MIP candidates after them, each group in list order */
+    minfo t[80]; int n = 0;
+    for (int i = 0; i < numRd; i++) if (!(rdList[i].mrl & MIP_FLAG)) t[n++] = rdList[i];
+    for (int i = 0; i < numRd; i++) if (rdList[i].mrl & MIP_FLAG) t[n++] = rdList[i];
+    memcpy(rdList, t, sizeof(minfo) * (size_t) numRd);
   }
 
   /* stage B: full RD (1158-1358) */
@@ -622,9 +719,7 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
     const int dir = rdList[m].mode, mrl = rdList[m].mrl;
     orc_ctx_copy(&e->cabac, &ctxStart);
     /* xIntraCodingTUBlock: initIntraPatternChType without forced filter */
-    orc_ipa ip; orc_init_pred_params(w, h, 1, dir, mrl, &ip);
-    build_refs(e, 0, x, y, w, h, mrl, ip.ref_filter);
-    orc_pred_intra(e->ref_unf, e->ref_flt, w, h, 1, dir, mrl, bd, e->pred, w);
+    pred_luma_cand(e, x, y, w, h, dir, mrl);
     /* xRecurIntraCodingLumaQT 3340-3640 without LFNST / transform skip: transform candidates {DCT2} or, where TU::isMTSAllowed,
      * {DCT2, 2, 3, 4, 5} pruned by TrQuant::transformNxN (1049-1124) on the first (DCT2) pass; every further candidate starts from the
      * start contexts; the loop ends after DCT2 when its cbf is 0; an MTS candidate with cbf 0 is forbidden (cost MAX) */
@@ -1004,13 +1099,10 @@ static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int
 static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts)
 {
   const cache_ent *c = cache_entry(e, a);
-  const int bd = e->cfg.bit_depth;
   uint64_t dist = 0;
   e->cnt_reuse++;
   if (!ch) {
-    orc_ipa ip; orc_init_pred_params(a.w, a.h, 1, c->dir, c->mrl, &ip);
-    build_refs(e, 0, a.x, a.y, a.w, a.h, c->mrl, ip.ref_filter);
-    orc_pred_intra(e->ref_unf, e->ref_flt, a.w, a.h, 1, c->dir, c->mrl, bd, e->pred, a.w);
+    pred_luma_cand(e, a.x, a.y, a.w, a.h, c->dir, c->mrl);
     dist = recon_from_levels(e, 0, a.x, a.y, a.w, a.h, c->lev, c->cbf & 1, c->mts, e->best_rec[0]);
     memcpy(e->best_lev[0], c->lev, (size_t) a.w * a.h * 2);
   } else {
@@ -1248,7 +1340,7 @@ int orc_compress_frame(orc_enc *e, orc_ctu_result *res, orc_cu *cus, int max_cus
           orc_cu *o = &cus[n];
           o->x = u->x; o->y = u->y; o->w = (int16_t) (1 << u->lw); o->h = (int16_t) (1 << u->lh); o->ch_type = (uint8_t) ch;
           o->qt_depth = u->qt_depth; o->bt_depth = u->bt_depth; o->mt_depth = u->mt_depth; o->depth = u->depth;
-          o->intra_dir = u->dir; o->mrl_idx = u->mrl; o->cbf = u->cbf; o->mts_idx = u->mts; o->split_series = u->split_series;
+          o->intra_dir = u->dir; o->mrl_idx = ch ? u->mrl : (u->mrl & ~MIP_FLAG); o->mip_flag = !ch && (u->mrl & MIP_FLAG) ? 1 : 0; o->cbf = u->cbf; o->mts_idx = u->mts; o->split_series = u->split_series;
         }
         n++;
       }

@@ -484,6 +484,15 @@ def gen_bitstream_cclm():
     np.savez_compressed(os.path.join(HERE, "bitstream_cclm.npz"), **out)
 
 
+def gen_bitstream_mip():
+    """Decoder round trip with matrix-based intra prediction searched as well (tools 0x913, sps MIP 1): mip_flag with its neighbour context,
+    the truncated-binary MIP mode, PLANAR as the mode a MIP block shows to MPM lists and chroma DM, and the MIP prediction itself are parsed
+    and reconstructed by the reference's CABACReader / DecCu.  Oracle only so far: the device refuses VVCX_TOOL_MIP."""
+    R.ref_env_set_tools.argtypes = [C.c_void_p, C.c_uint]
+    out = _pictures(((128, 128, 27, 1, 1, 8, 7), (200, 136, 22, 1, 1, 8, 1234), (256, 256, 32, 2, 2, 8, 5), (128, 128, 37, 1, 1, 10, 3)), 0x913, 0.5)
+    np.savez_compressed(os.path.join(HERE, "bitstream_mip.npz"), **out)
+
+
 def gen_bitstream_mts():
     """Decoder round trip with explicit MTS on as well (tools 0x911, sps MTS + IntraMTS): mts_idx bins, the skipped sub-blocks of
     32-point MTS blocks and the DST-VII / DCT-VIII choice per luma TU are parsed back by the reference's CABACReader."""
@@ -508,7 +517,7 @@ def _pictures(cases, tools, texture):
         planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture)
         payload, sizes, cus, lev = O.write_frame(planes, W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools)
         env = R.ref_env_create(W, H, bd); R.ref_env_set_tiles(env, tc, tr)
-        if tools & 0x110:
+        if tools & 0x112:
             R.ref_env_set_tools(env, tools)
         R.ref_env_reset(env)
         cw, chh = (W + 127) // 128, (H + 127) // 128
@@ -522,7 +531,7 @@ def _pictures(cases, tools, texture):
         nd = R.ref_dec_get_cus(env, P(rows), P(ss), len(rows)); assert nd == len(cus)
         dec = {(int(r[0]), int(r[1]), int(r[2])): (tuple(int(v) for v in r[3:]), int(s)) for r, s in zip(rows[:nd], ss[:nd])}
         for c in cus:
-            exp = ((int(c["w"]), int(c["h"]), int(c["qt_depth"]), int(c["bt_depth"]), int(c["mt_depth"]), int(c["depth"]), int(c["intra_dir"]), int(c["mrl_idx"]), int(c["cbf"]) | (int(c["mts_idx"]) << 8)), int(c["split_series"]))
+            exp = ((int(c["w"]), int(c["h"]), int(c["qt_depth"]), int(c["bt_depth"]), int(c["mt_depth"]), int(c["depth"]), int(c["intra_dir"]), int(c["mrl_idx"]) | (int(c["mip_flag"]) << 7), int(c["cbf"]) | (int(c["mts_idx"]) << 8)), int(c["split_series"]))
             assert dec[(int(c["ch_type"]), int(c["x"]), int(c["y"]))] == exp, "decoded CU differs"
         for comp in range(3):
             d = np.zeros_like(lev[comp]); R.ref_dec_get_levels(env, comp, P(d), d.shape[1])
@@ -537,7 +546,7 @@ def _pictures(cases, tools, texture):
         pic_meta.append((W, H, qp, tc, tr, bd, seed, len(payload))); pic_bytes.append(payload); pic_sizes.append(np.pad(sizes, (0, 16 - len(sizes))))
         nlm = int(sum(1 for c in cus if c["ch_type"] == 1 and 67 <= c["intra_dir"] <= 69))
         nmts = int(sum(1 for c in cus if c["ch_type"] == 0 and c["mts_idx"] > 1))
-        print("picture", W, H, qp, tc, tr, bd, "payload", len(payload), "bytes, decoded by the reference:", nd, "CUs,", nlm, "with an LM chroma mode,", nmts, "with an MTS transform")
+        print("picture", W, H, qp, tc, tr, bd, "payload", len(payload), "bytes, decoded by the reference:", nd, "CUs,", nlm, "with an LM chroma mode,", nmts, "with an MTS transform,", int(np.count_nonzero(cus["mip_flag"])), "MIP")
     out["pic_meta"] = np.array(pic_meta, np.int32); out["pic_bytes"] = np.concatenate(pic_bytes); out["pic_sizes"] = np.stack(pic_sizes).astype(np.int32)
     out["tools"] = np.array([tools], np.int32); out["chroma_texture"] = np.array([texture], np.float64)
     return out
@@ -555,6 +564,8 @@ if __name__ == "__main__":
         gen_deblock(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "chroma_qp":
         gen_chroma_qp(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bitstream_mip":
+        gen_bitstream_mip(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream_mts":
         gen_bitstream_mts(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "trquant_mts":
@@ -563,5 +574,5 @@ if __name__ == "__main__":
         gen_bitstream_cclm(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_chroma_qp(); gen_deblock(); gen_mip()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip()
     print("done")
