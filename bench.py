@@ -55,8 +55,8 @@ def main():
                     help="frames per step and rank; auto = enough frames for ~4 full waves of resident CTU streams")
     ap.add_argument("--tiles", type=str, default="auto", help="CxR uniform tile grid; auto = one tile per CTU")
     ap.add_argument("--lib", type=str, default=None, help="alternative build of the HIP library (experiments only)")
-    ap.add_argument("--tools", type=lambda v: int(v, 0), default=0x911,
-                    help="VVCX_TOOL_* bits; default MRL | MTS | CCLM | CU reuse = every tool of the reference's intra cfg that is built so far")
+    ap.add_argument("--tools", type=lambda v: int(v, 0), default=0x913,
+                    help="VVCX_TOOL_* bits; default MRL | MIP | MTS | CCLM | CU reuse = every tool of the reference's intra cfg that is built so far")
     ap.add_argument("--classifier", action="store_true",
                     help="BASELINE config 3 flavour: the fork's FAST_ALGORITHM with the shipped forest (forests/partition_qp32.npz) on the device")
     ap.add_argument("--chroma-texture", type=float, default=0.5,
@@ -133,10 +133,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16/int32 samples+coefficients, fp64 RD cost", "data": "synthetic",
             "config": {"workload": workload,
-                       "tools": "67 intra modes + PDPC" + (" + MRL" if args.tools & 1 else "") + (" + CCLM (LM, MDLM_L, MDLM_T)" if args.tools & 0x100 else "")
+                       "tools": "67 intra modes + PDPC" + (" + MRL" if args.tools & 1 else "") + (" + MIP search (FastMIP 1)" if args.tools & 2 else "") + (" + CCLM (LM, MDLM_L, MDLM_T)" if args.tools & 0x100 else "")
                                 + (", DCT-II + explicit MTS (DST-VII/DCT-VIII, MTSIntraMaxCand 3)" if args.tools & 0x10 else ", DCT-II") + ", plain quant, dual tree" + (", CU-result reuse (REUSE_CU_RESULTS)" if args.tools & 0x800 else "")
                                 + (", FAST_ALGORITHM partition classifier (shipped forest)" if args.tools & 0x1000 else "")
-                                + "; MIP/ISP/LFNST/TS/JCCR/LMCS/DepQuant/RDOQ of the reference's cfg not built yet",
+                                + "; ISP/LFNST/TS/JCCR/LMCS/DepQuant/RDOQ of the reference's cfg not built yet",
                        "ctus_per_step": ctus_per_step, "parallelism": "1 workgroup per CTU stream, frames sharded over ranks"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "vvcx_compress_kernel_u8" if bd == 8 else "vvcx_compress_kernel_u16", "kernel_ms": 1e3 * avg_kernel_s,

@@ -89,6 +89,7 @@ typedef struct {
   uint8_t  mrl_idx;              /* multiRefIdx */
   uint8_t  cbf;                  /* bit0 Y, bit1 Cb, bit2 Cr */
   uint8_t  mts_idx;              /* tu.mtsIdx of the luma TU: 0 DCT2xDCT2, 2..5 explicit MTS (VVCX_TOOL_MTS) */
+  uint8_t  mip_flag;             /* cu.mipFlag of a luma CU (VVCX_TOOL_MIP): intra_dir is then the MIP mode, mrl_idx 0 */
   uint64_t split_series;         /* CU::splitSeries, 5 bits per depth */
 } vvcx_cu;
 
@@ -191,7 +192,7 @@ int  vvcx_scan_order(int w, int h, uint16_t *idx, int device);
 /* ≙ BIN/TEST.py GetPartition(C0..C25, 2): the forest of vvcx_set_forest on n rows of 26 int32 features (host pointers) → class per row */
 /* ≙ IntraPrediction::initIntraMip + predIntraMip (CL/IntraPrediction.cpp:2152-2205; MatrixIntraPrediction, JVET_O0925 form) for n luma
  * blocks: cases = n x {w, h, mode, bit_depth}; refs = per case top[w] | left[h] (unfiltered line-0 reference samples); pred = per case w*h.
- * The search does not call it yet (VVCX_TOOL_MIP is still refused). */
+ * The search uses the same device functions for its MIP candidates (VVCX_TOOL_MIP); this entry point exposes them for the parity test. */
 int  vvcx_mip_pred_batch(const int32_t *cases, int n, const int16_t *refs, int n_refs, int16_t *pred, int n_pred, int device);
 int  vvcx_forest_predict_batch(vvcx_handle *h, const int32_t *rows, int n, int32_t *out);
 

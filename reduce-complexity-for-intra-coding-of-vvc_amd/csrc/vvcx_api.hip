@@ -60,7 +60,7 @@ struct vvcx_handle {
 };
 
 #define VVCX_PAYLOAD_BYTES_PER_CTU 32768u
-static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_MTS | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST;
+static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_MTS | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST;
 
 extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
 {
@@ -411,7 +411,7 @@ extern "C" int vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus
         if (cus && n < max_cus) {
           vvcx_cu &o = cus[n];
           o.x = u.x; o.y = u.y; o.w = (int16_t) (1 << u.lw); o.h = (int16_t) (1 << u.lh); o.ch_type = (uint8_t) ch;
-          o.qt_depth = u.qt; o.bt_depth = u.bt; o.mt_depth = u.mt; o.depth = u.depth; o.intra_dir = u.dir; o.mrl_idx = u.mrl; o.cbf = u.cbf; o.mts_idx = u.mts; o.split_series = u.ss;
+          o.qt_depth = u.qt; o.bt_depth = u.bt; o.mt_depth = u.mt; o.depth = u.depth; o.intra_dir = u.dir; o.mrl_idx = u.mrl & 0x7f; o.mip_flag = u.mrl >> 7; o.cbf = u.cbf; o.mts_idx = u.mts; o.split_series = u.ss;
         }
         n++;
       }

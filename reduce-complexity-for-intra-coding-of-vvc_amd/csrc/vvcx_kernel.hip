@@ -19,6 +19,7 @@
 #define VX_QUAL static __device__ const
 #include "vvcx_tables.h"
 #include "vvcx_dev.h"
+#include "vvcx_mip_dev.h"
 
 #define NT VXD_NT
 #define NW VXD_NW
@@ -40,6 +41,8 @@
 enum { SPLIT_NONE = 0, SPLIT_QT = 1, SPLIT_BH = 2, SPLIT_BV = 3, SPLIT_TH = 4, SPLIT_TV = 5 };
 enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V, ETM_RECO_CACHED };
 #define TOOL_CU_REUSE (1u << 11)
+#define TOOL_MIP (1u << 1)
+#define MIPF 0x80                  // a MIP CU: bit 7 of the unit's / candidate's mrl field (MIP forces multiRefIdx 0), the MIP mode in dir / mode
 #define TOOL_MTS (1u << 4)
 #define TOOL_CCLM (1u << 8)
 #define TOOL_FAST (1u << 12)
@@ -47,7 +50,7 @@ enum { LM_CHROMA = 67, MDLM_L = 68, MDLM_T = 69 };
 enum { PLANAR = 0, DC = 1, HOR = 18, DIA = 34, VER = 50, VDIA = 66, DM_CHROMA = 70 };
 enum { OP_NONE, OP_DONE, OP_LUMA_PREP, OP_STAGE_A, OP_STAGE_B, OP_CHROMA_RD, OP_SAVE_INTRA, OP_SAVE_PIC, OP_RESTORE_PIC,
        OP_CLEAR_UNITS, OP_CTX_COPY, OP_REUSE, OP_FAST };
-enum { PH_ENTER, PH_FAST_DONE, PH_RUN, PH_A1_DONE, PH_A2_DONE, PH_B_DONE, PH_INTRA_SAVED, PH_CHILD, PH_CHILD_RET, PH_SPLIT_SAVED, PH_ADVANCE, PH_EXIT, PH_EXIT2 };
+enum { PH_ENTER, PH_FAST_DONE, PH_RUN, PH_A1_DONE, PH_A2_DONE, PH_B_DONE, PH_INTRA_SAVED, PH_CHILD, PH_CHILD_RET, PH_SPLIT_SAVED, PH_ADVANCE, PH_EXIT, PH_EXIT2, PH_A3_DONE };
 enum { CTX_CUR = 0, CTX_START = 1, CTX_BEST = 2, CTX_WAVE = 3 };   // OP_CTX_COPY endpoints
 
 struct Ctx { uint16_t s0[NCTX], s1[NCTX]; };
@@ -123,6 +126,7 @@ struct Lds {
   int wave_best[NW], wave_slot[NW]; // candidate index of each wave's best and the slot that holds it
   CtlState S; VxUnit cu;           // controller working set; CU record of the intra candidate being evaluated
   unsigned mpm[6], mpm_sorted[6]; int mpm_n;
+  int16_t mip_n, mip_ctx;          // MIP modes of the node (0: no mip_flag) and the context of its mip_flag (3: more than 2:1, not searched)
   int dc_val[4];
   int cur_tile, frame, ctu_x, ctu_y, tree_ch;
   int d;                           // current recursion level
@@ -862,6 +866,22 @@ __device__ void enc_split_cu_mode(const VxParams &p, const VxFrameDev &fd, Cab &
 }
 
 // PU::getIntraMPMs (CL/UnitTools.cpp:508-640)
+// luma mode a unit shows to its neighbours' MPM lists and to the chroma DM (PU::getIntraDirLuma, CL/UnitTools.cpp:786-800): PLANAR for MIP
+__device__ inline int unit_ldir(const VxUnit &u) { return (u.mrl & MIPF) ? PLANAR : u.dir; }
+// neighbours of a luma node: the modes for its MPM list (PU::getIntraMPMs, CL/UnitTools.cpp:516-532) and, with MIP on, the number of MIP modes
+// (getNumModesMip 4688-4708; 0 = no mip_flag, also above MaxTbSize) and the context of its mip_flag (DeriveCtx::CtxMipFlag, CL/ContextModelling.cpp:555-569)
+__device__ __noinline__ void luma_neighbours(const VxParams &p, const VxFrameDev &fd, int x, int y, int w, int h, int tile, int &Ld, int &Ad)
+{
+  Ld = PLANAR; Ad = PLANAR;
+  const VxUnit *uL = get_cu(p, fd, 0, x - 1, y + h - 1, tile); if (uL) Ld = unit_ldir(*uL);
+  const VxUnit *uA = get_cu(p, fd, 0, x + w - 1, y - 1, tile); if (uA && ((y - 1) >> 7) == (y >> 7)) Ad = unit_ldir(*uA);
+  L.mip_n = 0; L.mip_ctx = 0;
+  if ((p.tools & TOOL_MIP) && w <= 64 && h <= 64) {
+    L.mip_n = (int16_t) mip_num_modes(w, h);
+    const VxUnit *a = get_cu(p, fd, 0, x - 1, y, tile), *b = get_cu(p, fd, 0, x, y - 1, tile);
+    L.mip_ctx = (int16_t) ((w > 2 * h || h > 2 * w) ? 3 : ((a && (a->mrl & MIPF)) ? 1 : 0) + ((b && (b->mrl & MIPF)) ? 1 : 0));
+  }
+}
 __device__ void derive_mpms(int Ld, int Ad, unsigned mpm[6])
 {
   const int offset = 61, mod = 64;
@@ -884,10 +904,19 @@ __device__ void derive_mpms(int Ld, int Ad, unsigned mpm[6])
   for (int i = 0; i < 6; i++) L.mpm_sorted[i] = mpm[i];
   for (int i = 1; i < 6; i++) { unsigned v = L.mpm_sorted[i]; int j = i - 1; while (j >= 0 && L.mpm_sorted[j] > v) { L.mpm_sorted[j + 1] = L.mpm_sorted[j]; j--; } L.mpm_sorted[j + 1] = v; }
 }
-// CABACWriter::intra_luma_pred_mode 1762-1845 + extend_ref_line 1566-1591 (MIP/ISP off); MPMs from L.mpm
+// CABACWriter::intra_luma_pred_mode 1762-1845 + extend_ref_line 1566-1591 (ISP off); MPMs from L.mpm; mip_flag 4741-4767 with the node's
+// context (DeriveCtx::CtxMipFlag) and mip_pred_mode 4781-4787 = xWriteTruncBinCode(mode, numModes) from L.mip_n / L.mip_ctx
 template <bool WR = false>
 __device__ void enc_intra_luma_pred_mode(Cab &cb, int y, int dir, int mrl)
 {
+  if (L.mip_n) {
+    enc_bin<WR>(cb, (unsigned) (mrl >> 7), VX_CTX_MipFlag + L.mip_ctx);
+    if (mrl & MIPF) {
+      const int n = L.mip_n, th = ilog2i(n), val = 1 << th, b = n - val;
+      if (dir < val - b) enc_ep<WR>(cb, (unsigned) dir, th); else enc_ep<WR>(cb, (unsigned) (dir + val - b), th + 1);
+      return;
+    }
+  }
   if ((y & 127) != 0) {
     enc_bin<WR>(cb, mrl != 0, VX_CTX_MultiRefLineIdx + 0);
     if (mrl != 0) enc_bin<WR>(cb, mrl != 1, VX_CTX_MultiRefLineIdx + 1);
@@ -911,6 +940,10 @@ __device__ inline unsigned frac_bits_of(const Ctx &c, int ctx, unsigned bin)
 __device__ unsigned long long luma_mode_bits(const Ctx &c, int y, int dir, int mrl)
 {
   unsigned long long bits = 0;
+  if (L.mip_n) {
+    bits += frac_bits_of(c, VX_CTX_MipFlag + L.mip_ctx, (unsigned) (mrl >> 7));
+    if (mrl & MIPF) { const int n = L.mip_n, th = ilog2i(n), val = 1 << th, b = n - val; return bits + ((unsigned long long) (dir < val - b ? th : th + 1) << 15); }
+  }
   if ((y & 127) != 0) {
     bits += frac_bits_of(c, VX_CTX_MultiRefLineIdx, mrl != 0);
     if (mrl != 0) bits += frac_bits_of(c, VX_CTX_MultiRefLineIdx + 1, mrl != 1);
@@ -1843,6 +1876,41 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
   }
 }
 
+// MIP prediction of the node by one wave into dst[0 .. w*h) from the unfiltered line-0 references (initIntraMip + predIntraMip,
+// CL/IntraPrediction.cpp:2152-2186); the reduced boundary and the matrix outputs pass through the wave's LDS scratch
+__device__ __noinline__ void wave_pred_mip(int16_t *dst, int w, int h, int mode, int bd, int wave, int lane)
+{
+  w = uni(w); h = uni(h); mode = uni(mode); wave = uni(wave);
+  int *sh = (int *) L.tmp[wave], *red = sh + 16;
+  const MipGeo g = mip_geo(w, h);
+  const int16_t *top = L.refs[0][0] + 1, *left = L.refs[0][1] + 1;
+  mip_reduced_pred(top, left, g, mode, bd, lane, sh, red);
+  wave_sync();
+  for (int i = lane; i < w * h; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); dst[i] = (int16_t) mip_sample(red, top, left, g, px, py); }
+  wave_sync();
+}
+// SATD-stage costs of the MIP candidates L.cand[0 .. c_end) (EL/IntraSearch.cpp:703-745), one wave per candidate, every block size
+template <bool SMALL>
+__device__ __noinline__ void stage_a_mip(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h, int c_end)
+{
+  const int P = w * h, bd = p.bit_depth;
+  int16_t *pred = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, 0);
+  int16_t *scr = SMALL ? (int16_t *) L.tmp[wave] : (int16_t *) wave_tmp(scratch, P >> 1, wave);
+  for (int c = wave; c < c_end; c += NW) {
+    const int mode = uni(L.cand[c].mode);
+    wave_pred_mip(pred, w, h, mode, bd, wave, lane);
+    unsigned long long sad, satd;
+    wave_sad_satd<SMALL>(org_tile(scratch, P), pred, scr, w, h, lane, sad, satd);
+    if (lane == 0) {
+      const unsigned long long msh = sad * 2 < satd ? sad * 2 : satd;
+      const unsigned long long mbits = luma_mode_bits(L.ctxs[CI_CUR], L.ny, mode, MIPF);
+      const double a = (double) mbits * p.sqrt_lambda_fp;
+      L.cand_cost[c] = (double) msh + a;
+      L.cand_had[c] = (double) msh;
+    }
+    wave_sync();
+  }
+}
 // SATD-stage loop of one wave over its candidates (blocks of more than 32 samples).  SMALL: prediction and Hadamard scratch in the
 // wave's LDS buffers, else in HBM scratch.
 template <bool SMALL>
@@ -1883,6 +1951,11 @@ __device__ __noinline__ void op_stage_a(const VxParams &p_, uint8_t *scratch)
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int w = uni(L.nw), h = uni(L.nh), P = w * h;
   const int c_end = uni(L.op_b);
+  if (uni(L.op_c) == 2) {                                  // the MIP candidates: costs only, the control step merges them into the list
+    if (P <= BUF) stage_a_mip<true>(p, scratch, wave, lane, w, h, c_end); else stage_a_mip<false>(p, scratch, wave, lane, w, h, c_end);
+    __syncthreads();
+    return;
+  }
   { const int c = uni(L.op_a) + (int) threadIdx.x; if (c < c_end) { Ipa ip; init_pred_params(w, h, 1, L.cand[c].mode, L.cand[c].mrl, ip); L.cand_ipa[c] = ipa_pack(ip); } }
   __syncthreads();
   if (P <= 32) {
@@ -1933,12 +2006,14 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     const int mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
     int16_t *rec = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.slot[wave] + BUF : slot_lev(scratch, P, wave, cur);
     if (lane == 0) L.rd_cost[c] = MAX_DOUBLE;
-    Ipa ip; init_pred_params(w, h, 1, mode, mrl, ip);
-    const int set = luma_set(mrl, ip.ref_filter);
+    const int mip = mrl & MIPF;                           // a MIP candidate: mode is the MIP mode, no reference line / filter choice
+    Ipa ip; init_pred_params(w, h, 1, mip ? 0 : mode, mip ? 0 : mrl, ip);
+    const int set = luma_set(mip ? 0 : mrl, ip.ref_filter);
     const int16_t *top = L.refs[set][0], *left = L.refs[set][1];
-    const int dcv = L.dc_val[luma_set(mrl, 0)];
+    const int dcv = L.dc_val[luma_set(mip ? 0 : mrl, 0)];
     const long long tb0 = STAMP();
-    for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
+    if (mip) wave_pred_mip(rec, w, h, mode, bd, wave, lane);
+    else for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
     wave_sync();
     const long long tb1 = STAMP();
     // transform candidates of the TU (xRecurIntraCodingLumaQT 3340-3640 without LFNST / transform skip): DCT2 alone, or where MTS is
@@ -1953,7 +2028,8 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     const int mts = k ? k + 1 : 0;
     if (k) {                                             // the previous transform candidate turned the prediction into its reconstruction
       rec = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, cur); lev = SMALL ? L.slot[wave] + BUF : slot_lev(scratch, P, wave, cur);
-      for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
+      if (mip) wave_pred_mip(rec, w, h, mode, bd, wave, lane);
+      else for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
       wave_sync();
     }
     if (MTS && k == 1) {
@@ -2211,10 +2287,13 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
   Cab cb; cb.ci = CI_W(0); cb.bits = 0;
   unsigned long long dist = 0;
   if (!ch) {
-    Ipa ip; init_pred_params(w, h, 1, mode, fm, ip);
-    const int set = luma_set(fm, ip.ref_filter);
-    const int dcv = L.dc_val[luma_set(fm, 0)];
-    for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); recb[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], w, h, px, py, ip, mode, 1, bd, dcv); }
+    if (fm & MIPF) wave_pred_mip(recb, w, h, mode, bd, 0, lane);
+    else {
+      Ipa ip; init_pred_params(w, h, 1, mode, fm, ip);
+      const int set = luma_set(fm, ip.ref_filter);
+      const int dcv = L.dc_val[luma_set(fm, 0)];
+      for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); recb[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], w, h, px, py, ip, mode, 1, bd, dcv); }
+    }
     wave_sync();
     int cbf;
     const int mts = uni(L.rd_mts[0]);
@@ -2650,6 +2729,51 @@ __device__ void post(int op) { L.op = op; }
 __device__ void set_node(const Frame &f, int d) { L.nx = f.x; L.ny = f.y; L.nw = f.w; L.nh = f.h; L.nd = d; }
 // xCheckRDCostIntra's tail for the node on top of the frame stack (thread 0): winner chosen by the operation; CU-level rate; xCheckBestMode.
 // Returns 1 when the result becomes the node's best and has to be saved (OP_SAVE_INTRA / the fused tail of the operation).
+// thread 0 after the MIP candidates' SATD operation (EL/IntraSearch.cpp:733-748): every MIP mode into the list (one entry longer), then
+// IntraSearch::reduceHadCandList (4331-4406, JVET_O0925 form, FastMIP 1): at most 3 regular candidates, MIP candidates up to half the list or within
+// thresholdHadCost of the best, always one MIP; above 8x8 the best of MIP modes {3,4,5} (each in its better orientation) is appended when absent
+__device__ __noinline__ void ctrl_mip_merge(int w, int h)
+{
+  CtlState &S = L.S;
+  const int nMip = L.mip_n;
+  L.cnt[0] += (unsigned long long) nMip;
+  for (int m = 0; m < nMip; m++) update_cand_list(L.cand[m], L.cand_cost[m], S.rdList, S.rdCost, S.rdSize, S.numRd + 1);
+  // thresholdHadCost = 1 + 1.4 / sqrt(w * h) (747): w * h = 2^k, so the root is 2^(k/2), times the correctly rounded sqrt(2) for odd k — exact scaling, no device sqrt
+  const int k2 = ilog2i(w) + ilog2i(h);
+  const double root = (k2 & 1) ? 0x1.6a09e667f3bcdp+0 * (double) (1 << (k2 >> 1)) : (double) (1 << (k2 >> 1));
+  const double thr = 1.0 + 1.4 / root;
+  const int maxPerType = S.numRd >> 1, size = S.rdSize;
+  const double minCost = S.rdCost[0];
+  int keepOneMip = size > S.numRd, numConv = 0, numMip = 0, tn = 0;
+  for (int idx = 0; idx < size - (keepOneMip ? 0 : 1); idx++) {
+    int add;
+    if (!(S.rdList[idx].mrl & MIPF)) { add = numConv < 3; numConv += add; }
+    else { add = numMip < maxPerType || S.rdCost[idx] < thr * minCost || keepOneMip; keepOneMip = 0; numMip += add; }
+    if (add) { S.rdList[tn] = S.rdList[idx]; S.rdCost[tn] = S.rdCost[idx]; tn++; }
+  }
+  if (w > 8 && h > 8) {
+    // MIP modes 3, 4, 5, each in its cheaper orientation, in ascending SATD-stage cost (updateCandList into an empty list of 3 = a stable
+    // sort: an equal cost stays behind the earlier mode); scalars only, no private arrays in this thread-0 function
+    const int transpOff = nMip / 2;
+    int m0 = 3 + (L.cand_cost[3 + transpOff] < L.cand_cost[3] ? transpOff : 0);
+    int m1 = 4 + (L.cand_cost[4 + transpOff] < L.cand_cost[4] ? transpOff : 0);
+    int m2 = 5 + (L.cand_cost[5 + transpOff] < L.cand_cost[5] ? transpOff : 0);
+    double k0 = L.cand_cost[m0], k1 = L.cand_cost[m1], k2 = L.cand_cost[m2];
+    if (k1 < k0) { const int tm = m0; m0 = m1; m1 = tm; const double tk = k0; k0 = k1; k1 = tk; }
+    if (k2 < k1) {
+      { const int tm = m1; m1 = m2; m2 = tm; const double tk = k1; k1 = k2; k2 = tk; }
+      if (k1 < k0) { const int tm = m0; m0 = m1; m1 = tm; const double tk = k0; k0 = k1; k1 = tk; }
+    }
+    const int n0 = tn;
+    for (int idx = 0; idx < 3; idx++) {
+      const int mm = idx == 0 ? m0 : idx == 1 ? m1 : m2;
+      int incl = 0;
+      for (int k = 0; k < n0; k++) incl |= S.rdList[k].mode == mm && S.rdList[k].mrl == MIPF;
+      if (!incl) { S.rdList[tn].mode = (uint8_t) mm; S.rdList[tn].mrl = MIPF; S.rdCost[tn] = 0; tn++; break; }      // fastMip: one
+    }
+  }
+  S.rdSize = tn; S.numRd = tn;
+}
 __device__ __noinline__ int ctrl_b_done(const VxParams &p_, const VxFrameDev &fd_)
 {
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
@@ -2729,14 +2853,12 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         if (mode == ETM_RECO_CACHED) {                  // xReuseCachedResult (EL/EncCu.cpp:5665-5771)
           L.rd[0].mode = f.r_dir; L.rd[0].mrl = f.r_mrl; L.rd_cbf[0] = f.r_cbf; L.rd_mts[0] = ch ? 0 : f.r_mts; L.n_rd = 0;
           if (!ch) {                                    // MPM list for intra_luma_pred_modes
-            int Ld = PLANAR, Ad = PLANAR;
-            const VxUnit *uL = get_cu(p, fd, 0, f.x - 1, f.y + f.h - 1, tile); if (uL) Ld = uL->dir;
-            const VxUnit *uA = get_cu(p, fd, 0, f.x + f.w - 1, f.y - 1, tile); if (uA && ((f.y - 1) >> 7) == (f.y >> 7)) Ad = uA->dir;
+            int Ld, Ad; luma_neighbours(p, fd, f.x, f.y, f.w, f.h, tile, Ld, Ad);
             derive_mpms(Ld, Ad, L.mpm);
           }
           if (ch) {
             const int cx = f.x + (f.w >> 1), cy = f.y + (f.h >> 1);
-            L.colm = fd.units[0][(cy >> 2) * p.uw + (cx >> 2)].dir;
+            L.colm = unit_ldir(fd.units[0][(cy >> 2) * p.uw + (cx >> 2)]);
             L.rd[0].mrl = (uint8_t) (f.r_dir == DM_CHROMA ? L.colm : f.r_dir);    // final mode
             L.lm_ok = cclm_allowed(p, fd, f.x, f.y, f.ss, f.depth); L.lm_nsatd = 0;
           }
@@ -2745,9 +2867,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         }
         if (!ch) {
           // MPM list of the node (PU::getIntraMPMs neighbours, CL/UnitTools.cpp:516-532)
-          int Ld = PLANAR, Ad = PLANAR;
-          const VxUnit *uL = get_cu(p, fd, 0, f.x - 1, f.y + f.h - 1, tile); if (uL) Ld = uL->dir;
-          const VxUnit *uA = get_cu(p, fd, 0, f.x + f.w - 1, f.y - 1, tile); if (uA && ((f.y - 1) >> 7) == (f.y >> 7)) Ad = uA->dir;
+          int Ld, Ad; luma_neighbours(p, fd, f.x, f.y, f.w, f.h, tile, Ld, Ad);
           derive_mpms(Ld, Ad, L.mpm); L.mpm_n = (Ld == Ad) ? 1 : 2;
           // stage A candidate list, phase 1: 35 even modes + MRL MPM candidates (costs are order independent)
           int n = 0;
@@ -2756,12 +2876,15 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
             for (int r = 1; r < 3; r++) for (int k = 1; k < 6; k++) { L.cand[n].mode = (uint8_t) L.mpm[k]; L.cand[n].mrl = (uint8_t) (r == 1 ? 1 : 3); n++; }
           L.n_cand = n;
           S.numRd = L.t.mode_num[(ilog2i(f.w) - 2) * 6 + (ilog2i(f.h) - 2)];
+          // EL/IntraSearch.cpp:404-418,469-477 with FastMIP 1: MIP is searched unless the block is more than 2:1 (mip_ctx 3); the regular list is
+          // kept longer while the MIP candidates compete for it
+          if (L.mip_n && L.mip_ctx != 3) S.numRd += imax(S.numRd, ilog2i(imin(f.w, f.h)) - 1);
           f.phase = PH_A1_DONE;
           L.op_a = 0; L.op_b = n; L.op_c = 1; post(OP_LUMA_PREP); return;      // prep, then stage A on [0,n)
         } else {
           // chroma candidate modes (PU::getIntraChromaCandModes, CL/UnitTools.cpp:840-873), LM modes disabled
           const int cx = f.x + (f.w >> 1), cy = f.y + (f.h >> 1);
-          const int lm = fd.units[0][(cy >> 2) * p.uw + (cx >> 2)].dir;      // getCoLocatedIntraLumaMode 949-960
+          const int lm = unit_ldir(fd.units[0][(cy >> 2) * p.uw + (cx >> 2)]);      // getCoLocatedIntraLumaMode 949-960
           L.colm = lm;
           int list[8] = { PLANAR, VER, HOR, DC, LM_CHROMA, MDLM_L, MDLM_T, DM_CHROMA };
           for (int i = 0; i < 4; i++) if (lm == list[i]) { list[i] = VDIA; break; }
@@ -2815,13 +2938,27 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
       f.phase = PH_A2_DONE;
       L.op_a = L.n_cand; L.op_b = n; L.op_c = 0; post(OP_STAGE_A); return;     // evaluates [n1, n) (possibly empty) and makes the final selection
     }
-    case PH_A2_DONE: {                                  // 777-802 MPM append, then stage B
-      L.cnt[0] += (unsigned long long) S.n_a2;
+    case PH_A2_DONE:
+    case PH_A3_DONE: {                                  // [703-748 MIP candidates,] 777-802 MPM append, then stage B
+      const int testMip = L.mip_n && L.mip_ctx != 3;
+      if (f.phase == PH_A2_DONE) {
+        L.cnt[0] += (unsigned long long) S.n_a2;
+        if (testMip) {                                  // every MIP mode by SATD; the regular candidates are in the list, their buffer is free
+          for (int m = 0; m < L.mip_n; m++) { L.cand[m].mode = (uint8_t) m; L.cand[m].mrl = MIPF; }
+          f.phase = PH_A3_DONE;
+          L.op_a = 0; L.op_b = L.mip_n; L.op_c = 2; post(OP_STAGE_A); return;
+        }
+      } else ctrl_mip_merge(f.w, f.h);
       for (int j = 0; j < L.mpm_n; j++) {
         int incl = 0;
         for (int i = 0; i < S.numRd; i++) incl |= (S.rdList[i].mode == L.mpm[j] && S.rdList[i].mrl == 0);
         if (!incl) { S.rdList[S.numRd].mode = (uint8_t) L.mpm[j]; S.rdList[S.numRd].mrl = 0; S.rdCost[S.numRd] = 0; S.numRd++; }
       }
+      if (testMip) {                                    // 1097-1122: regular candidates first, MIP candidates after them, each group in list order
+        int n = 0;
+        for (int i = 0; i < S.numRd; i++) if (!(S.rdList[i].mrl & MIPF)) L.rd[n++] = S.rdList[i];
+        for (int i = 0; i < S.numRd; i++) if (S.rdList[i].mrl & MIPF) L.rd[n++] = S.rdList[i];
+      } else
       for (int i = 0; i < S.numRd; i++) L.rd[i] = S.rdList[i];
       L.n_rd = S.numRd;
       f.phase = PH_B_DONE;
@@ -2919,15 +3056,13 @@ __device__ __noinline__ void walk_tree(const VxParams &p_, const VxFrameDev &fd_
       if (!split) {
         const int sh = ch ? 1 : 0, W = f.w >> sh, H = f.h >> sh;
         if (!ch) {
-          int Ld = PLANAR, Ad = PLANAR;
-          const VxUnit *uL = get_cu(p, fd, 0, f.x - 1, f.y + f.h - 1, tile); if (uL) Ld = uL->dir;
-          const VxUnit *uA = get_cu(p, fd, 0, f.x + f.w - 1, f.y - 1, tile); if (uA && ((f.y - 1) >> 7) == (f.y >> 7)) Ad = uA->dir;
+          int Ld, Ad; luma_neighbours(p, fd, f.x, f.y, f.w, f.h, tile, Ld, Ad);
           derive_mpms(Ld, Ad, L.mpm);
           enc_intra_luma_pred_mode<WR>(cb, f.y, u->dir, u->mrl);
           enc_bin<WR>(cb, u->cbf & 1, VX_CTX_QtCbf[0]);
           if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; if (mts_allowed(p, W, H)) enc_mts_idx<WR>(cb, u->mts); residual_coding<WR>(cb, lv, W, H, 0, (uint16_t *) (lv + 4096), u->mts > 1); }
         } else {
-          enc_intra_chroma_pred_mode<WR>(cb, u->dir, fd.units[0][((f.y + (f.h >> 1)) >> 2) * p.uw + ((f.x + (f.w >> 1)) >> 2)].dir, cclm_allowed(p, fd, f.x, f.y, u->ss, u->depth));
+          enc_intra_chroma_pred_mode<WR>(cb, u->dir, unit_ldir(fd.units[0][((f.y + (f.h >> 1)) >> 2) * p.uw + ((f.x + (f.w >> 1)) >> 2)]), cclm_allowed(p, fd, f.x, f.y, u->ss, u->depth));
           enc_bin<WR>(cb, (unsigned) !!(u->cbf & 2), VX_CTX_QtCbf[1]);
           enc_bin<WR>(cb, (unsigned) !!(u->cbf & 4), VX_CTX_QtCbf[2] + !!(u->cbf & 2));
           for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c)) {

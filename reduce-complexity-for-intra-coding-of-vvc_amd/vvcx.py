@@ -11,6 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libvvcx.so")
 TOOL_MRL = 1
+TOOL_MIP = 1 << 1            # matrix-based intra prediction searched (cfg MIP 1, FastMIP 1): mip_flag / MIP mode per luma CU
 TOOL_MTS = 1 << 4            # explicit intra MTS (cfg MTS 1, MTSIntraMaxCand 3): DST-VII / DCT-VIII pairs for luma TUs up to 32x32
 TOOL_CU_REUSE = 1 << 11      # BestEncInfoCache, REUSE_CU_RESULTS (CL/TypeDef.h:291) - on in the reference build
 TOOL_CCLM = 1 << 8           # LM / MDLM chroma modes (cfg LMChroma 1, on in the reference's intra configuration)
@@ -44,7 +45,7 @@ class _Task(C.Structure):
 CTU_DTYPE = np.dtype([("dist", "<u8"), ("frac_bits", "<u8"), ("cost", "<f8"), ("n_cu", "<i4")], align=True)
 CU_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("ch_type", "u1"), ("qt_depth", "u1"),
                      ("bt_depth", "u1"), ("mt_depth", "u1"), ("depth", "u1"), ("intra_dir", "u1"), ("mrl_idx", "u1"),
-                     ("cbf", "u1"), ("mts_idx", "u1"), ("split_series", "<u8")], align=True)
+                     ("cbf", "u1"), ("mts_idx", "u1"), ("mip_flag", "u1"), ("split_series", "<u8")], align=True)
 
 _libs = {}
 

@@ -94,6 +94,22 @@ def test_explicit_mts_without_cu_reuse_and_with_classifier():
     _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=0.5)], 256, 128, pkg.slice_params(27), tools=MTS | pkg.TOOL_FAST)
 
 
+MIP = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS | pkg.TOOL_MIP
+
+
+@pytest.mark.parametrize("case", [(128, 128, 27, 8, 1, 1, 7), (200, 136, 22, 8, 1, 1, 1234), (256, 256, 32, 8, 2, 2, 5), (128, 128, 37, 10, 1, 1, 3), (256, 128, 32, 8, 2, 1, 6)])
+def test_matrix_intra_prediction_search(case):
+    # tools 0x913: the MIP candidates of the SATD stage (every MIP mode, reduceHadCandList), of the RD stage and of the CU cache; mip_flag with
+    # its neighbour context and the truncated-binary MIP mode; PLANAR as the mode a MIP block shows to MPM lists and the chroma DM
+    W, H, qp, bd, tc, tr, seed = case
+    _check([pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=0.5)], W, H, pkg.slice_params(qp, bit_depth=bd), bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=MIP)
+
+
+def test_matrix_intra_prediction_alone_without_cu_reuse_and_with_classifier():
+    _check([pkg.synth_frame(128, 128, 0, 8, 11)], 128, 128, pkg.slice_params(32), tools=pkg.TOOL_MRL | pkg.TOOL_MIP)
+    _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=0.5)], 256, 128, pkg.slice_params(27), tools=MIP | pkg.TOOL_FAST)
+
+
 FAST = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_FAST
 
 
@@ -180,7 +196,7 @@ def test_full_1080p_frame_matches_oracle():
     _check([pkg.synth_frame(W, H, 0, 8, 1000)], W, H, pkg.slice_params(32), tile_cols=15, tile_rows=9)
 
 
-@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz"])
+@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz"])
 def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fixture):
     """Device writer (arithmetic coding of the final CTU syntax in the estimator pass) against tests/golden/bitstream.npz: payloads
     that the reference's CABACReader parsed back into the coded CUs and levels when the fixture was generated."""

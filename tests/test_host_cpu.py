@@ -52,7 +52,7 @@ def test_host_argument_checks(emu_so):
     with pytest.raises(pkg.VvcxError):
         pkg.VvcxEncoder(130, 128, 8, lib_path=emu_so)            # not a multiple of 8
     with pytest.raises(pkg.VvcxError):
-        pkg.VvcxEncoder(128, 128, 8, tools=1 | 2, lib_path=emu_so)  # MIP not built yet: refuse, never ignore
+        pkg.VvcxEncoder(128, 128, 8, tools=1 | 4, lib_path=emu_so)  # ISP not built yet: refuse, never ignore
     enc = pkg.VvcxEncoder(128, 128, 8, lib_path=emu_so)
     with pytest.raises(pkg.VvcxError):
         enc.bind_frames([([1, 1, 1], [1, 1, 1], [128, 64, 64])])  # slice not set
@@ -66,7 +66,9 @@ def test_missing_extension_fails_loudly(tmp_path):
 
 @pytest.mark.parametrize("w,h,chroma,tiles,tools", [(32, 32, 1, (1, 1), pkg.TOOLS_DEFAULT), (40, 24, 1, (1, 1), pkg.TOOLS_DEFAULT),
                                                    (32, 32, 1, (1, 1), pkg.TOOL_MRL), (40, 24, 1, (1, 1), pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM),
-                                                   (40, 24, 1, (1, 1), pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS)])
+                                                   (40, 24, 1, (1, 1), pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS),
+                                                   (40, 24, 1, (1, 1), pkg.TOOLS_DEFAULT | pkg.TOOL_MIP),
+                                                   (32, 32, 1, (1, 1), pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS | pkg.TOOL_MIP)])
 def test_device_code_on_cpu_emulator_matches_oracle(emu_so, w, h, chroma, tiles, tools):
     planes = pkg.synth_frame(w, h, 0, 8, 7, chroma_texture=0.6 if tools & pkg.TOOL_CCLM else 0.0)
     sp = pkg.slice_params(32)
@@ -86,7 +88,8 @@ def test_device_code_on_cpu_emulator_matches_oracle(emu_so, w, h, chroma, tiles,
     enc.close()
 
 
-@pytest.mark.parametrize("tools", [pkg.TOOLS_DEFAULT, pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM, pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS])
+@pytest.mark.parametrize("tools", [pkg.TOOLS_DEFAULT, pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM, pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS,
+                                   pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS | pkg.TOOL_MIP])
 def test_emulated_slice_data_writer_matches_oracle(emu_so, tools):
     """The device's bitstream pass (same sources on the CPU debug emulation) against the oracle's payload, whose format is pinned
     through the reference decoder (tests/golden/make_golden.py bitstream)."""
