@@ -18,6 +18,7 @@ typedef struct {
   uint16_t s0[ORC_NUM_CTX], s1[ORC_NUM_CTX];
   uint64_t bits;
   orc_arith *aw;
+  int dq;                  /* slice dep_quant_enabled_flag: residual_coding runs the quantiser state machine */
 } orc_cabac;
 
 static inline void orc_bs_write(orc_arith *a, uint32_t v, int nbits)           /* OutputBitstream::write, MSB first */

@@ -3,7 +3,8 @@
  * Restates EL/CABACWriter.cpp residual_coding (3773-3883), last_sig_coeff (4102-4160),
  * residual_coding_subblock (4164-4304), CL/ContextModelling.h CoeffCodingContext (50-200) and
  * CL/ContextModelling.cpp:40-134, EL/BinEncoder.cpp:444-485 encodeRemAbsEP.
- * Scope: regular (non transform-skip) residuals, DepQuant off (state stays 0), sign hiding off.
+ * Scope: regular (non transform-skip) residuals, sign hiding off; with cb->dq the dependent-quantisation state machine (stateTransTable
+ * 32040, 3857-3858) selects the sig_coeff_flag context set and the bypass-mode zero position per coefficient, carried across sub-blocks.
  */
 #include "orc_internal.h"
 #include <stdlib.h>
@@ -35,8 +36,8 @@ static void cg_diag(int bw, int bh, uint8_t *xs, uint8_t *ys)
   }
 }
 
-/* sigCtxIdAbs (CL/ContextModelling.h:107-156), state = 0 */
-static int sig_ctx(cctx_t *c, const int16_t *coeff, int blk)
+/* sigCtxIdAbs (CL/ContextModelling.h:107-156) */
+static int sig_ctx(cctx_t *c, const int16_t *coeff, int blk, int state)
 {
   const int W = c->w, H = c->h, posY = blk / W, posX = blk - posY * W;
   const int16_t *p = coeff + blk;
@@ -49,7 +50,7 @@ static int sig_ctx(cctx_t *c, const int16_t *coeff, int blk)
   int ofs = imin((sumAbs + 1) >> 1, 3) + (diag < 2 ? 4 : 0);
   if (c->ch == 0) ofs += diag < 5 ? 4 : 0;
   c->tmpl_diag = diag; c->tmpl_sum1 = sumAbs - numPos;
-  return ORC_CTX_SigFlag[c->ch] + ofs;      /* m_sigFlagCtxSet[max(0,state-1)] with state 0 */
+  return ORC_CTX_SigFlag[c->ch + 2 * imax(0, state - 1)] + ofs;      /* m_sigFlagCtxSet[max(0,state-1)] */
 }
 /* ctxOffsetAbs (158-167) */
 static int ctx_offset_abs(const cctx_t *c)
@@ -137,6 +138,7 @@ void orc_residual_coding_mts(orc_cabac *cb, const int16_t *coeff, int w, int h, 
   c.reg_bins = ((zo && w == 32 ? 16 : imin(32, w)) * (zo && h == 32 ? 16 : imin(32, h)) * 28) >> 4;
 
   const int cgSize = 1 << c.lcg;
+  const int stateTab = cb->dq ? 32040 : 0; int state = 0;
   for (int sub = scanPosLast >> c.lcg; sub >= 0; sub--) {
     /* initSubblock (CL/ContextModelling.cpp:114-134) */
     const int cgPosX = c.cgx[sub], cgPosY = c.cgy[sub], cgPos = cgPosY * c.wg + cgPosX;
@@ -163,10 +165,10 @@ void orc_residual_coding_mts(orc_cabac *cb, const int16_t *coeff, int w, int h, 
       const int cf = coeff[blk];
       const unsigned sigFlag = cf != 0;
       if (numNonZero || nextSigPos != inferSigPos) {
-        const int ctx = sig_ctx(&c, coeff, blk);
+        const int ctx = sig_ctx(&c, coeff, blk, state);
         orc_enc_bin(cb, sigFlag, ctx);
         remRegBins--;
-      } else if (nextSigPos != scanPosLast) sig_ctx(&c, coeff, blk);
+      } else if (nextSigPos != scanPosLast) sig_ctx(&c, coeff, blk, state);
       if (sigFlag) {
         const int off = ctx_offset_abs(&c);
         ctxOffset[nextSigPos - minSub] = (uint8_t) off;
@@ -185,6 +187,7 @@ void orc_residual_coding_mts(orc_cabac *cb, const int16_t *coeff, int w, int h, 
           remRegBins--;
         }
       }
+      state = (stateTab >> ((state << 2) + ((cf & 1) << 1))) & 3;      /* 4247 */
     }
     const int firstPosMode2 = nextSigPos;
     c.reg_bins = remRegBins;
@@ -197,14 +200,15 @@ void orc_residual_coding_mts(orc_cabac *cb, const int16_t *coeff, int w, int h, 
         enc_rem_abs(cb, (absLevel - 4) >> 1, ORC_GORICE_PARS[sumAll]);
       }
     }
-    /* 3rd pass: bypass-coded positions (4275-4294), state 0 */
+    /* 3rd pass: bypass-coded positions (4275-4294) */
     for (int sp = firstPosMode2; sp >= minSub; sp--) {
       const int blk = c.scan[sp];
       const unsigned absLevel = (unsigned) abs(coeff[blk]);
       const int sumAll = tmpl_abs_sum(&c, coeff, blk, 0);
-      const unsigned rice = ORC_GORICE_PARS[sumAll], pos0 = ORC_GORICE_POS0[sumAll];
+      const unsigned rice = ORC_GORICE_PARS[sumAll], pos0 = ORC_GORICE_POS0[imax(0, state - 1) * 32 + sumAll];
       const unsigned rem = absLevel == 0 ? pos0 : absLevel <= pos0 ? absLevel - 1 : absLevel;
       enc_rem_abs(cb, rem, rice);
+      state = (stateTab >> ((state << 2) + ((absLevel & 1) << 1))) & 3;
       if (absLevel) { numNonZero++; signPattern = (signPattern << 1) | (coeff[blk] < 0); }
     }
     (void) ctxOffset;
@@ -214,9 +218,18 @@ void orc_residual_coding_mts(orc_cabac *cb, const int16_t *coeff, int w, int h, 
 
 uint64_t orc_residual_bits(uint16_t *s0, uint16_t *s1, const int16_t *level, int w, int h, int is_chroma)
 {
-  orc_cabac c; c.aw = 0;
+  orc_cabac c; c.aw = 0; c.dq = 0;
   memcpy(c.s0, s0, sizeof c.s0); memcpy(c.s1, s1, sizeof c.s1); c.bits = 0;
   orc_residual_coding(&c, level, w, h, is_chroma);
+  memcpy(s0, c.s0, sizeof c.s0); memcpy(s1, c.s1, sizeof c.s1);
+  return c.bits;
+}
+/* the same with the dependent-quantisation state machine (slice dep_quant_enabled_flag) */
+uint64_t orc_residual_bits_dq(uint16_t *s0, uint16_t *s1, const int16_t *level, int w, int h, int is_chroma, int mts_idx)
+{
+  orc_cabac c; c.aw = 0; c.dq = 1;
+  memcpy(c.s0, s0, sizeof c.s0); memcpy(c.s1, s1, sizeof c.s1); c.bits = 0;
+  orc_residual_coding_mts(&c, level, w, h, is_chroma, mts_idx);
   memcpy(s0, c.s0, sizeof c.s0); memcpy(s1, c.s1, sizeof c.s1);
   return c.bits;
 }

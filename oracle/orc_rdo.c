@@ -80,6 +80,7 @@ struct orc_enc {
   double sqrt_lambda_fp;              /* sqrtLambdaForFirstPass */
   uint64_t cnt_satd, cnt_rd, cnt_rdpix, cnt_nodes, cnt_reuse;
   cache_ent *cache; int ctu_is_last;
+  int tu_cbf_cb;                      /* tu.cbf[Cb] while Cr is quantised (context of its cbf in DepQuant's rate tables) */
   orc_forest forest; int32_t *dump; int dump_cap, dump_n; uint64_t cnt_fast;
   /* scratch */
   int16_t *ref_unf, *ref_flt, *pred, *resi, *resi_org, *tmp_rec[2], *tmp_lev[2], *best_rec[2], *best_lev[2];
@@ -89,11 +90,12 @@ struct orc_enc {
 /* ------------------------------------------------------------------------------------------------ */
 orc_enc *orc_create(const orc_cfg *cfg)
 {
-  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, MTS, CU reuse, CCLM, FAST)", cfg->tools); return 0; }
+  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, MTS, DepQuant, CU reuse, CCLM, FAST)", cfg->tools); return 0; }
   if (!cfg->dual_tree || cfg->ctu_size != 128) { snprintf(g_err, sizeof g_err, "oracle: only DualITree=1, CTUSize=128"); return 0; }
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7)) { snprintf(g_err, sizeof g_err, "oracle: picture size must be a multiple of 8 (EncAppCfg.cpp:2709)"); return 0; }
   orc_enc *e = (orc_enc *) calloc(1, sizeof *e);
   e->cfg = *cfg;
+  e->cabac.dq = (cfg->tools & ORC_TOOL_DEPQUANT) ? 1 : 0;
   e->wl = cfg->pic_w; e->hl = cfg->pic_h; e->wc = e->wl >> 1; e->hc = e->hl >> 1;
   for (int c = 0; c < 3; c++) {
     const int w = c ? e->wc : e->wl, h = c ? e->hc : e->hl;
@@ -515,6 +517,8 @@ static void enc_intra_chroma_pred_mode(orc_enc *e, area_t a, int dir, int lm_ok)
  * comp: 0 Y 1 Cb 2 Cr; x,y,w,h in component samples; writes rec_out / lev_out tiles (stride w)
  * ---------------------------------------------------------------------------------------------- */
 static uint64_t code_tu_block_mts(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int16_t *rec_out, int16_t *lev_out, int *cbf);
+/* lambda the quantiser sees for a component (RDOQ_CHROMA_LAMBDA: EL/EncSlice.cpp:107-149 setLambdas, EL/IntraSearch.cpp:2889 selectLambda) */
+static double quant_lambda(const orc_enc *e, int comp) { return comp ? e->sl.lambda / e->sl.dist_weight[comp - 1] : e->sl.lambda; }
 static uint64_t code_tu_block(orc_enc *e, int comp, int x, int y, int w, int h, int16_t *rec_out, int16_t *lev_out, int *cbf) { return code_tu_block_mts(e, comp, x, y, w, h, 0, rec_out, lev_out, cbf); }
 static uint64_t code_tu_block_mts(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int16_t *rec_out, int16_t *lev_out, int *cbf)
 {
@@ -524,9 +528,17 @@ static uint64_t code_tu_block_mts(orc_enc *e, int comp, int x, int y, int w, int
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) e->resi[j * w + i] = (int16_t) (org[j * st + i] - e->pred[j * w + i]);
   if (!comp) memcpy(e->resi_org, e->resi, (size_t) w * h * 2);      /* the MTS pruning works on the prediction residual */
   orc_fwd_2d_mts(e->resi, w, w, h, bd, mts_idx, e->coef);
-  const int abs_sum = orc_quant(e->coef, w, h, bd, qp, lev_out);
-  if (abs_sum > 0) { orc_dequant(lev_out, w, h, bd, qp, e->coef); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
-  else memset(e->resi, 0, (size_t) w * h * 2);
+  int abs_sum;
+  if (e->cfg.tools & ORC_TOOL_DEPQUANT) {
+    /* DepQuant::quant (CL/DepQuant.cpp:1755-1781) with the estimator's live contexts (EL/IntraSearch.cpp:2968,3024) and the quantiser's lambda of the
+     * component: TrQuant::selectLambda (2889) = lambda / distortion weight for chroma (EL/EncSlice.cpp:107-149) */
+    abs_sum = orc_depquant(e->cabac.s0, e->cabac.s1, e->coef, w, h, comp, ORC_CTX_QtCbf[comp] + (comp == 2 ? e->tu_cbf_cb : 0), bd, qp, quant_lambda(e, comp), mts_idx > 1, 0, lev_out);
+    if (abs_sum > 0) { orc_dequant_dq(lev_out, w, h, bd, qp, e->coef); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
+  } else {
+    abs_sum = orc_quant(e->coef, w, h, bd, qp, lev_out);
+    if (abs_sum > 0) { orc_dequant(lev_out, w, h, bd, qp, e->coef); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
+  }
+  if (abs_sum <= 0) memset(e->resi, 0, (size_t) w * h * 2);
   const int mx = (1 << bd) - 1;
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) { int v = e->pred[j * w + i] + e->resi[j * w + i]; rec_out[j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
   *cbf = abs_sum > 0;
@@ -822,6 +834,7 @@ static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int lm_ok, int *out_
     int cbf[2]; uint64_t dist = 0;
     for (int c = 1; c <= 2; c++) {
       pred_chroma_comp(e, c, cx, cy, cw, chh, fm, cm == 67 ? tmpLM : tmpMD, cm == 67 ? infoLM : infoMD);
+      e->tu_cbf_cb = c == 2 ? cbf[0] : 0;
       dist += code_tu_block(e, c, cx, cy, cw, chh, rec2[c - 1], lev2[c - 1], &cbf[c - 1]);
       /* xGetIntraFracBitsQTChroma (2625-2692): contexts advance, bits only feed per-component costs */
       orc_enc_bin(&e->cabac, (unsigned) cbf[c - 1], ORC_CTX_QtCbf[c] + (c == 2 ? cbf[0] : 0));
@@ -1088,7 +1101,7 @@ static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int
   const int st = e->stride[comp], bd = e->cfg.bit_depth, mx = (1 << bd) - 1;
   const int16_t *org = e->org[comp] + y * st + x;
   const int qp = (comp ? e->sl.qp_c[comp - 1] : e->sl.qp) + 6 * (e->cfg.bit_depth - 8);    /* QpParam: + QpBDOffset (CL/Quant.cpp:68-106) */
-  if (cbf) { orc_dequant(lev, w, h, bd, qp, e->coef); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
+  if (cbf) { if (e->cfg.tools & ORC_TOOL_DEPQUANT) orc_dequant_dq(lev, w, h, bd, qp, e->coef); else orc_dequant(lev, w, h, bd, qp, e->coef); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
   else memset(e->resi, 0, (size_t) w * h * 2);
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) { int v = e->pred[j * w + i] + e->resi[j * w + i]; rec_out[j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
   uint64_t dd = orc_sse(org, st, rec_out, w, w, h);

@@ -128,6 +128,13 @@ void orc_mts_prune(const int16_t *resi, int stride, int w, int h, int bit_depth,
 /* CL/Quant.cpp:994-1089 (plain quant, I-slice offset 171) and 423-549 (dequant) */
 int  orc_quant(const int *coef, int w, int h, int bit_depth, int qp, int16_t *level);
 void orc_dequant(const int16_t *level, int w, int h, int bit_depth, int qp, int *coef);
+/* CL/DepQuant.cpp: dependent quantisation of one block from the estimator's contexts (s0, s1) at the time of the call; comp 0 Y / 1 Cb / 2 Cr;
+ * cbf_ctx = flat context index of the block's cbf flag (-1: inferred); qp as for orc_quant; lambda = the quantiser's lambda for the component;
+ * zo = explicit MTS (mts_idx > 1); lfnst = cu.lfnstIdx.  Returns absSum.  orc_dequant_dq: Quantizer::dequantBlock (741-810). */
+int  orc_depquant(const uint16_t *s0, const uint16_t *s1, const int *coef, int w, int h, int comp, int cbf_ctx, int bit_depth, int qp, double lambda,
+                  int zo, int lfnst, int16_t *level);
+void orc_dequant_dq(const int16_t *level, int w, int h, int bit_depth, int qp, int *coef);
+void orc_depquant_consts(int w, int h, int bit_depth, int qp, double lambda, int64_t out[9]);   /* Quantizer::initQuantBlock 694-739 */
 /* CL/RdCost.cpp xGetSAD / xGetHADs / xGetSSE */
 uint64_t orc_sad(const int16_t *a, int sa, const int16_t *b, int sb, int w, int h);
 uint64_t orc_satd(const int16_t *a, int sa, const int16_t *b, int sb, int w, int h);

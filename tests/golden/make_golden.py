@@ -314,6 +314,53 @@ def gen_trquant_mts():
     print("mts trquant cases", len(meta), "prune keep histogram", np.stack(prune).sum(axis=0))
 
 
+def gen_depquant():
+    """Dependent quantisation through the reference: TrQuant::transformNxN with the slice's dep_quant flag on (DepQuant::quant →
+    DQIntern::DepQuant::quant, CL/DepQuant.cpp:1592-1735) and invTransformNxN (Quantizer::dequantBlock 741-810), for luma blocks of every
+    shape (DCT-II and explicit MTS pairs), Cb and Cr blocks (Cr with both values of tu.cbf[Cb]), sparse to dense residuals (the dense ones
+    exhaust the regular-bin budget), context models that have been adapted by random bins."""
+    R.ref_env_depquant.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_double, C.c_int] + [C.c_void_p] * 7
+    R.ref_ctx_init.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 3
+    g = np.random.default_rng(20262)
+    nctx = R.ref_ctx_count()
+    meta, lam_all, ctx_all, resi_all, lev_all, out_all = [], [], [], [], [], []
+    luma_shapes = [(w, h) for w in (4, 8, 16, 32, 64) for h in (4, 8, 16, 32, 64)]
+    chroma_shapes = [(2, 8), (8, 2), (2, 16), (16, 2), (4, 4), (4, 8), (8, 4), (8, 8), (4, 16), (16, 16), (32, 8), (32, 32)]
+    for gi, (bd, qp) in enumerate(((8, 22), (8, 32), (8, 37), (10, 32), (10, 24))):
+        env = R.ref_env_create(192, 192, bd)
+        s0 = np.zeros(nctx, np.uint16); s1 = np.zeros(nctx, np.uint16); rate = np.zeros(nctx, np.uint8)
+        R.ref_ctx_init(qp, 2, P(s0), P(s1), P(rate))
+        for i in range(nctx):                      # adapt every model by a short random bin string (as a search in progress would have)
+            n = int(g.integers(0, 24)); bins = (g.random(n) < g.random()).astype(np.uint8)
+            a = s0[i:i + 1].copy(); b = s1[i:i + 1].copy()
+            if n: R.ref_ctx_code_bins(P(a), P(b), int(rate[i]), P(bins), n)
+            s0[i] = a[0]; s1[i] = b[0]
+        ctx_all.append(np.stack([s0, s1]))
+        lam0 = 0.57 * 2.0 ** ((qp + 6 * (bd - 8) - 12) / 3.0) * 2.0 ** (0.25 / 3.0)
+        cases = [(0, w, h, m) for (w, h) in luma_shapes for m in ((0,) if max(w, h) > 32 else (0, 2 + int(g.integers(0, 4))))]
+        cases += [(c, w, h, 0) for (w, h) in chroma_shapes for c in (1, 2)]
+        for (comp, w, h, mts) in cases:
+            for dens in range(2 if w * h <= 256 else 1):
+                R.ref_env_reset(env)
+                amp = (1 << bd) // 4
+                yy, xx = np.mgrid[0:h, 0:w]
+                sig = (amp / 10, amp / 2.5)[dens] if w * h <= 256 else amp / 8
+                resi = g.normal(0, sig, (h, w)) + (amp / 3) * np.sin(xx / 5.0 + g.uniform(0, 3)) * np.cos(yy / 7.0) * g.uniform(0, 1)
+                resi = np.ascontiguousarray(np.clip(resi.round(), -(1 << bd) + 1, (1 << bd) - 1).astype(np.int16))
+                cbf_cb = int(g.integers(0, 2)) if comp == 2 else 0
+                lam = lam0 * (1.0 if comp == 0 else float(g.choice([0.8, 1.0, 1.3])))
+                lev = np.zeros(w * h, np.int32); ro = np.zeros(w * h, np.int16); a = C.c_int(); qu = C.c_int()
+                cw, chh = (w, h) if comp == 0 else (2 * w, 2 * h)
+                assert R.ref_env_depquant(env, comp, 0, 0, cw, chh, qp, mts, lam, cbf_cb, P(s0), P(s1), P(resi), P(lev), P(ro), C.byref(a), C.byref(qu)) == 0
+                assert np.abs(lev).max() < 32768
+                meta.append((bd, qp, comp, w, h, mts, cbf_cb, qu.value, a.value, gi)); lam_all.append(lam)
+                resi_all.append(resi.ravel()); lev_all.append(lev.astype(np.int16)); out_all.append(ro)
+    np.savez_compressed(os.path.join(HERE, "depquant.npz"), meta=np.array(meta, np.int32), lam=np.array(lam_all, np.float64), ctx=np.stack(ctx_all),
+                        resi=np.concatenate(resi_all), lev=np.concatenate(lev_all), resi_out=np.concatenate(out_all))
+    m = np.array(meta)
+    print("depquant cases", len(meta), "non-zero", int((m[:, 8] > 0).sum()), "max abs level", int(np.abs(np.concatenate(lev_all)).max()))
+
+
 def gen_chroma_qp():
     """ChromaQpMappingTable (CL/Slice.cpp:1529-1581) for pivot sets given the way the cfg gives them: the reference cfg's, the VTM
     default, a single identity point and a four-point set; 8 and 10 bit."""
@@ -501,6 +548,15 @@ def gen_bitstream_mts():
     np.savez_compressed(os.path.join(HERE, "bitstream_mts.npz"), **out)
 
 
+def gen_bitstream_dq():
+    """Decoder round trip with dependent quantisation on as well (tools 0x953, slice dep_quant_enabled_flag 1): the state-driven sig_coeff_flag
+    context sets and bypass zero positions are parsed back by the reference's CABACReader, and DecCu dequantises with the reference's
+    Quantizer::dequantBlock state machine: every level and every reconstructed sample must equal the oracle's."""
+    R.ref_env_set_tools.argtypes = [C.c_void_p, C.c_uint]
+    out = _pictures(((128, 128, 27, 1, 1, 8, 7), (200, 136, 22, 1, 1, 8, 1234), (256, 256, 32, 2, 2, 8, 5), (128, 128, 37, 1, 1, 10, 3)), 0x953, 0.5)
+    np.savez_compressed(os.path.join(HERE, "bitstream_dq.npz"), **out)
+
+
 def _pictures(cases, tools, texture):
     import importlib, sys
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -513,11 +569,11 @@ def _pictures(cases, tools, texture):
     out = {}
     pic_meta, pic_bytes, pic_sizes = [], [], []
     for (W, H, qp, tc, tr, bd, seed) in cases:
-        sp = pkg.slice_params(qp, bit_depth=bd)
+        sp = pkg.slice_params(qp, bit_depth=bd, dep_quant=bool(tools & 0x40))
         planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture)
         payload, sizes, cus, lev = O.write_frame(planes, W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools)
         env = R.ref_env_create(W, H, bd); R.ref_env_set_tiles(env, tc, tr)
-        if tools & 0x112:
+        if tools & 0x152:
             R.ref_env_set_tools(env, tools)
         R.ref_env_reset(env)
         cw, chh = (W + 127) // 128, (H + 127) // 128
@@ -572,7 +628,11 @@ if __name__ == "__main__":
         gen_trquant_mts(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream_cclm":
         gen_bitstream_cclm(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bitstream_dq":
+        gen_bitstream_dq(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "depquant":
+        gen_depquant(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq()
     print("done")
