@@ -87,7 +87,7 @@ def main():
         tc, tr = ctus_w, ctus_h
     else:
         tc, tr = map(int, args.tiles.lower().split("x"))
-    sp = pkg.slice_params(args.qp, bit_depth=args.bit_depth)
+    sp = pkg.slice_params(args.qp, bit_depth=args.bit_depth, dep_quant=bool(args.tools & 0x40))
     bd = args.bit_depth
     b_ctu = B_CTU_8BIT * (2 if bd == 10 else 1)
     forest = None

@@ -187,6 +187,11 @@ int  vvcx_rd_cost_batch(double lambda, const uint64_t *frac_bits, const uint64_t
  * hands to the quantiser (slice QP + QpBDOffset, chroma after the mapping table) */
 int  vvcx_transform_quant_batch(const int16_t *org, const int16_t *pred, int w, int h, int bit_depth, int qp, int n,
                                 int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device);
+/* the same block pipeline with the dependent quantiser (≙ DepQuant::quant / dequant, CL/DepQuant.cpp:1755-1810, with the slice's dep_quant_enabled_flag on):
+ * comp 0 Y / 1 Cb / 2 Cr; mts_idx 0 or 2..5 (luma, up to 32x32); cbf_cb = tu.cbf[Cb] when Cr is quantised; lambda = the quantiser's lambda of the
+ * component (TrQuant::selectLambda); s0 / s1 = the two states of each of the 386 context models the rate terms are read from */
+int  vvcx_depquant_batch(const int16_t *org, const int16_t *pred, int w, int h, int bit_depth, int qp, int comp, int mts_idx, int cbf_cb, double lambda,
+                         const uint16_t *s0, const uint16_t *s1, int n, int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device);
 /* coefficient scan (diagonal, grouped) of a w x h block: idx[min(w,32) * min(h,32)] raster offsets in scan order */
 int  vvcx_scan_order(int w, int h, uint16_t *idx, int device);
 /* ≙ BIN/TEST.py GetPartition(C0..C25, 2): the forest of vvcx_set_forest on n rows of 26 int32 features (host pointers) → class per row */

@@ -27,6 +27,7 @@ struct VxMipCase { int32_t w, h, mode, bit_depth, ref_off, pred_off; };
 extern "C" __global__ void vvcx_leaf_mip_kernel(const VxMipCase *cases, const int16_t *refs, int16_t *preds);
 extern "C" __global__ void vvcx_deblock_kernel_u8(VxDeblockParams p);
 extern "C" __global__ void vvcx_deblock_kernel_u16(VxDeblockParams p);
+extern "C" __global__ void vvcx_leaf_dq_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int qp, int comp, int mts, int cbf_cb, unsigned long long *out);
 extern "C" __global__ void vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp, unsigned long long *out);
 
 static thread_local char g_err[512];
@@ -55,12 +56,39 @@ struct vvcx_handle {
   uint8_t *payload_d; uint64_t *payload_off_d; uint32_t *payload_cap_d; void *arith_d; std::vector<uint64_t> payload_off; std::vector<uint32_t> payload_cap;
   // FAST_ALGORITHM forest (vvcx_set_forest)
   VxForestNode *f_node_d; double *f_value_d; int32_t *f_root_d; int f_ntrees, f_nclasses; int32_t f_classes[8];
+  VxDqConst *dq_d;                              // dependent-quantiser constants per (component, log2 w + log2 h)
   hipEvent_t ev0, ev1; float last_ms, last_deblock_ms;
   size_t lev_plane[3], lev_frame, units_plane, units_frame;
 };
 
 #define VVCX_PAYLOAD_BYTES_PER_CTU 32768u
-static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_MTS | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST;
+static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_MTS | VVCX_TOOL_DEPQUANT | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST;
+
+// Quantizer::initQuantBlock (CL/DepQuant.cpp:694-739) for blocks with log2 w + log2 h = lsum: the quantiser's shift / scale / thresholds and the fixed-point
+// distortion normalisation, which the reference derives in fp64 from lambda.  qp: what QpParam hands over (with QpBDOffset).
+static VxDqConst dq_consts_of(int lsum, int bit_depth, int qp, double lambda)
+{
+  VxDqConst c; memset(&c, 0, sizeof c);
+  const int sq = lsum & 1, qpDQ = qp + 1, per = qpDQ / 6, rem = qpDQ - 6 * per;
+  const int nomShift = 15 - bit_depth - (lsum >> 1), trShift = nomShift + (sq ? -1 : 0);
+  const int qshift = 14 - 1 + per + trShift;
+  const int64_t qscale = VX_QUANT_SCALES[sq * 6 + rem];
+  const int invShift = 6 + 1 - per - trShift;
+  int qIdxBD = 32 + invShift - 6 - 1; if (qIdxBD > 16) qIdxBD = 16;
+  const int nomDShift = 15 - 2 * nomShift + qshift + (sq ? 1 : 0);
+  const double qScale2 = (double) (qscale * qscale);
+  const double nomDistFactor = nomDShift < 0 ? 1.0 / ((double) ((int64_t) 1 << (-nomDShift)) * qScale2 * lambda) : (double) ((int64_t) 1 << nomDShift) / (qScale2 * lambda);
+  const int64_t pow2dfShift = (int64_t) (nomDistFactor * qScale2) + 1;
+  int dfShift = (pow2dfShift & (pow2dfShift - 1)) ? 1 : 0;                   // ceil_log2 (680-693)
+  for (uint64_t x = (uint64_t) pow2dfShift; x > 1; x >>= 1) dfShift++;
+  const int dshift = 62 + qshift - 2 * 15 - dfShift;
+  c.qshift = qshift; c.qadd = -(((int64_t) 3 << qshift) >> 1); c.qscale = qscale; c.max_qidx = (1 << (qIdxBD - 1)) - 4;
+  c.thres = (int32_t) ((int64_t) 4 << qshift);
+  c.dshift = dshift; c.dadd = ((int64_t) 1 << dshift) >> 1;
+  c.dstep = (int64_t) (nomDistFactor * (double) ((int64_t) 1 << (dshift + qshift)) + .5);
+  c.dorg = (int64_t) (nomDistFactor * (double) ((int64_t) 1 << (dshift + 1)) + .5);
+  return c;
+}
 
 extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
 {
@@ -94,11 +122,13 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   h->frames_d = nullptr; h->lev_d = nullptr; h->units_d = nullptr; h->stream_ctx_d = nullptr; h->scratch_d = nullptr; h->scratch_cap = 0;
   h->payload_d = nullptr; h->payload_off_d = nullptr; h->payload_cap_d = nullptr; h->arith_d = nullptr;
   h->streams_d = nullptr; h->task_ctu_d = nullptr; h->results_d = nullptr; h->task_cap = 0; h->stream_cap = 0; h->counters_d = nullptr;
+  h->dq_d = nullptr;
   const int F = cfg->max_frames;
   if (hipMalloc((void **) &h->frames_d, sizeof(VxFrameDev) * F) != hipSuccess || hipMalloc((void **) &h->lev_d, h->lev_frame * 2 * F) != hipSuccess ||
       hipMalloc((void **) &h->units_d, h->units_frame * sizeof(VxUnit) * F) != hipSuccess ||
       hipMalloc((void **) &h->stream_ctx_d, (size_t) F * h->ntiles * 2 * VXD_NUM_CTX * 2) != hipSuccess ||
-      hipMalloc((void **) &h->counters_d, 52 * sizeof(unsigned long long)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
+      hipMalloc((void **) &h->counters_d, 52 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void **) &h->dq_d, 48 * sizeof(VxDqConst)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
   if (cfg->emit_payload) {                       // VVCX_PAYLOAD_BYTES_PER_CTU per CTU: a CTU of 8-bit video at QP >= 17 stays far below (raw samples are 24 KB)
     const size_t nstream = (size_t) F * h->ntiles;
     h->payload_off.resize(nstream); h->payload_cap.resize(nstream);
@@ -121,7 +151,7 @@ extern "C" void vvcx_destroy(vvcx_handle *h)
   (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d);
   (void) hipFree(h->payload_d); (void) hipFree(h->payload_off_d); (void) hipFree(h->payload_cap_d); (void) hipFree(h->arith_d);
   (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
-  (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d);
+  (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d); (void) hipFree(h->dq_d);
   (void) hipEventDestroy(h->ev0); (void) hipEventDestroy(h->ev1);
   delete h;
 }
@@ -318,6 +348,17 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
   p.scratch = h->scratch_d; p.scratch_per_stream = per_stream; p.counters = h->counters_d; p.ntiles = h->ntiles;
   p.f_node = h->f_node_d; p.f_value = h->f_value_d; p.f_root = h->f_root_d; p.f_ntrees = h->f_ntrees; p.f_nclasses = h->f_nclasses;
   for (int c = 0; c < 8; c++) p.f_classes[c] = h->f_classes[c];
+  if (h->cfg.tools & VVCX_TOOL_DEPQUANT) {
+    // the quantiser's lambda of a component: TrQuant::setLambdas / selectLambda (EL/EncSlice.cpp:107-149, EL/IntraSearch.cpp:2889) = lambda / distortion weight for chroma
+    VxDqConst tab[48]; memset(tab, 0, sizeof tab);
+    for (int comp = 0; comp < 3; comp++) {
+      const double lam = comp ? h->sl.lambda / h->sl.dist_weight[comp - 1] : h->sl.lambda;
+      const int qp = comp ? p.qp_tr_c[comp - 1] : p.qp_tr;
+      for (int lsum = 2; lsum <= 12; lsum++) tab[comp * 16 + lsum] = dq_consts_of(lsum, h->cfg.bit_depth, qp, lam);
+    }
+    HIPCHK(hipMemcpyAsync(h->dq_d, tab, sizeof tab, hipMemcpyHostToDevice, stream));
+    p.dq_consts = h->dq_d;
+  }
 
   HIPCHK(hipEventRecord(h->ev0, stream));
   if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_compress_kernel_u8, dim3((unsigned) ns), dim3(VXD_NT), 0, stream, p);
@@ -616,6 +657,34 @@ extern "C" int vvcx_transform_quant_batch(const int16_t *org, const int16_t *pre
   HIPCHK(hipMemcpy(dorg.p, org, bytes, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(drec.p, pred, bytes, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(vvcx_leaf_trq_kernel, dim3((unsigned) n), dim3(VXD_NT), 0, 0, dorg.as<int16_t>(), drec.as<int16_t>(), dlev.as<int16_t>(), dtmp.as<int32_t>(), w, h, bit_depth, qp,
                      dout.as<unsigned long long>());
+  HIPCHK(hipGetLastError());
+  std::vector<unsigned long long> o((size_t) n * 2);
+  HIPCHK(hipMemcpy(lev, dlev.p, bytes, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(rec, drec.p, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(o.data(), dout.p, (size_t) n * 16, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) { sse[i] = o[(size_t) i * 2]; cbf[i] = (uint8_t) o[(size_t) i * 2 + 1]; }
+  return VVCX_OK;
+}
+
+extern "C" int vvcx_depquant_batch(const int16_t *org, const int16_t *pred, int w, int h, int bit_depth, int qp, int comp, int mts_idx, int cbf_cb, double lambda,
+                                   const uint16_t *s0, const uint16_t *s1, int n, int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device)
+{
+  if (!org || !pred || !lev || !rec || !sse || !cbf || !s0 || !s1 || n < 0 || !pow2_block(w, h) || (bit_depth != 8 && bit_depth != 10) || qp < 0 || qp > 75 || comp < 0 || comp > 2 ||
+      !(lambda > 0.0) || (mts_idx != 0 && (mts_idx < 2 || mts_idx > 5 || comp != 0 || w > 32 || h > 32 || w < 4 || h < 4))) return fail(VVCX_ERR_ARG, "bad argument");
+  if (n == 0) return VVCX_OK;
+  HIPCHK(hipSetDevice(device));
+  const size_t bytes = (size_t) n * w * h * 2;
+  DevBuf dorg, drec, dlev, dtmp, dout, dctx, dtab, dscr;
+  HIPCHK(dorg.alloc(bytes)); HIPCHK(drec.alloc(bytes)); HIPCHK(dlev.alloc(bytes)); HIPCHK(dtmp.alloc((size_t) n * 2048 * 4)); HIPCHK(dout.alloc((size_t) n * 16));
+  HIPCHK(dctx.alloc(2 * VXD_NUM_CTX * 2)); HIPCHK(dtab.alloc(48 * sizeof(VxDqConst))); HIPCHK(dscr.alloc((size_t) n * VXD_OFF_CACHE));
+  HIPCHK(hipMemcpy(dorg.p, org, bytes, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(drec.p, pred, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dctx.p, s0, VXD_NUM_CTX * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dctx.as<uint16_t>() + VXD_NUM_CTX, s1, VXD_NUM_CTX * 2, hipMemcpyHostToDevice));
+  VxDqConst tab[48]; memset(tab, 0, sizeof tab);
+  for (int lsum = 2; lsum <= 12; lsum++) tab[comp * 16 + lsum] = dq_consts_of(lsum, bit_depth, qp, lambda);
+  HIPCHK(hipMemcpy(dtab.p, tab, sizeof tab, hipMemcpyHostToDevice));
+  VxParams p; memset(&p, 0, sizeof p);
+  p.bit_depth = bit_depth; p.tools = VVCX_TOOL_DEPQUANT | VVCX_TOOL_MTS; p.dq_consts = dtab.as<VxDqConst>(); p.scratch = dscr.as<uint8_t>(); p.scratch_per_stream = VXD_OFF_CACHE;
+  hipLaunchKernelGGL(vvcx_leaf_dq_kernel, dim3((unsigned) n), dim3(VXD_NT), 0, 0, p, dctx.as<uint16_t>(), dorg.as<int16_t>(), drec.as<int16_t>(), dlev.as<int16_t>(), dtmp.as<int32_t>(),
+                     w, h, qp, comp, mts_idx, cbf_cb, dout.as<unsigned long long>());
   HIPCHK(hipGetLastError());
   std::vector<unsigned long long> o((size_t) n * 2);
   HIPCHK(hipMemcpy(lev, dlev.p, bytes, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(rec, drec.p, bytes, hipMemcpyDeviceToHost));

@@ -44,6 +44,10 @@ struct VxCtuRes { uint64_t dist, bits; double cost; int32_t n_cu, pad; };
 
 struct VxForestNode { double thr; int32_t left, right, feature, pad; };     // left < 0: leaf
 
+// per-block constants of the dependent quantiser (Quantizer::initQuantBlock, CL/DepQuant.cpp:694-739; fp64 on the host), one entry per
+// (component, log2 w + log2 h): index comp * 16 + log2 w + log2 h
+struct VxDqConst { int32_t qshift, max_qidx, thres, dshift; int64_t qadd, qscale, dadd, dstep, dorg; };
+
 struct VxParams {
   int32_t pic_w, pic_h, bit_depth, chroma;
   uint32_t tools;
@@ -72,6 +76,7 @@ struct VxParams {
   const int32_t      *f_root;        // [f_ntrees]
   int32_t             f_ntrees, f_nclasses;
   int32_t             f_classes[8];
+  const VxDqConst    *dq_consts;     // [3 * 16] (VVCX_TOOL_DEPQUANT)
 };
 
 struct VxDeblockParams {     // vvcx_deblock.hip
@@ -99,6 +104,9 @@ struct VxCacheEnt { uint64_t ss; uint8_t kind /* 0 empty, 1 luma tree, 2 chroma 
 #define VXD_CACHE_DIM   1152
 #define VXD_OFF_ORG     (VXD_OFF_TMP + VXD_NW * 2048 * 4)                             // original tile of a node too big for LDS: 4096 int16
 #define VXD_OFF_LM      (VXD_OFF_ORG + 4096 * 2)                                      // CCLM down-sampled luma of a big chroma node: in[1024] | top[64] | left[64] int16
-#define VXD_OFF_CACHE   ((VXD_OFF_LM + (1024 + 128) * 2 + 255) & ~255)
+// dependent quantisation of blocks too big for LDS: per wave decisions (2 KB), path nodes of up to 64 coefficient groups (4 KB + 512 B), last-position offsets
+#define VXD_DQ_WAVE     8192
+#define VXD_OFF_DQ      ((VXD_OFF_LM + (1024 + 128) * 2 + 255) & ~255)
+#define VXD_OFF_CACHE   ((VXD_OFF_DQ + VXD_NW * VXD_DQ_WAVE + 255) & ~255)
 #define VXD_OFF_CACHE_LEV (VXD_OFF_CACHE + VXD_CACHE_ENTRIES * (int) sizeof(VxCacheEnt))
 #define VXD_SCRATCH_BYTES (VXD_OFF_CACHE_LEV + VXD_CACHE_DIM * VXD_CACHE_DIM * 2)

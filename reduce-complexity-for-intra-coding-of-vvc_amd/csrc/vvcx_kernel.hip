@@ -44,6 +44,7 @@ enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_B
 #define TOOL_MIP (1u << 1)
 #define MIPF 0x80                  // a MIP CU: bit 7 of the unit's / candidate's mrl field (MIP forces multiRefIdx 0), the MIP mode in dir / mode
 #define TOOL_MTS (1u << 4)
+#define TOOL_DEPQUANT (1u << 6)
 #define TOOL_CCLM (1u << 8)
 #define TOOL_FAST (1u << 12)
 enum { LM_CHROMA = 67, MDLM_L = 68, MDLM_T = 69 };
@@ -96,18 +97,23 @@ struct Tables {                    // constant tables staged once per workgroup 
   uint8_t  last_prefix[8], mode_shift[8];
   uint8_t  ctx_rate[NCTX + 2], gorice_pars[32], gorice_pos0[96], group_idx[64], mode_num[36], intra_thr[8];
   alignas(16) int8_t dst7[16 + 64 + 256 + 1024];   // DST-VII 4..32 (explicit MTS); DCT-VIII[k][i] = (-1)^k DST-VII[k][n-1-i] is read from the same rows
-  alignas(16) int8_t dct[4 + 16 + 64 + 256 + 1024 + (BUF >= 256 ? 4096 : 0)];   // DCT-II 2..32, and 64 when a 64-wide block can be LDS resident (64x4 = 256 samples)
+  alignas(16) int8_t dct[4 + 16 + 64 + 256 + 1024];   // DCT-II 2..32 (the 64-point matrix is only used by 64x64 luma nodes, which never are LDS resident: read from constant memory)
   uint8_t  cg_scan[52], grp_scan[228];   // diagonal scans (CL/Rom.cpp:87-131) as x | y << 4: inside a coefficient group {4x4, 2x2, 8x2, 2x8}; of the groups, per (log2 wg, log2 hg)
+  uint8_t  cg_inv[52], grp_inv[228];     // their inverses: raster position (y * width + x) -> scan index, same table offsets
 };
 
 #define RC_LIST 320
+// per-wave scratch that the rate estimator (pending bin list) and the dependent quantiser (decisions, path nodes) use at different times
+struct WaveRc { uint16_t binbuf[RC_LIST]; uint8_t binsort[RC_LIST + 8]; };
+struct WaveDq { uint16_t trel[BUF]; uint8_t hlev[BUF / 16][4][16]; int8_t hpar[BUF / 16][4]; uint8_t hflag[BUF / 16][4]; int lastb[32]; };
+union WaveScratch { WaveRc rc; WaveDq dq; };
 #define CI_CUR 0
 #define CI_W(w) (1 + (w))
 struct Lds {
   Tables t;
   Ctx ctxs[1 + NW];                // [0] the estimator's contexts, [1 + w] per-wave working copy (a wave's best end-of-candidate contexts are parked in HBM)
   alignas(16) int16_t org[BUF];    // node's original tile: luma w*h, or Cb | Cr (cw*ch each); bigger nodes keep it in HBM scratch (VXD_OFF_ORG)
-  uint16_t binbuf[NW][RC_LIST]; uint8_t binsort[NW][RC_LIST + 8];        // residual_coding_wave: pending (ctx<<1|bin) list; bins grouped by context
+  alignas(16) WaveScratch ws[NW];  // residual_coding_wave: pending (ctx<<1|bin) list, bins grouped by context; wave_depquant: decisions and path nodes
   int acc[NW][4][2];               // small-block SATD stage: per packed candidate {SAD, SATD}
   int16_t refs[4][2][140];         // luma: set 0 mrl0 unfiltered, 1 mrl0 filtered, 2 mrl1, 3 mrl3; chroma: set 0 Cb, 1 Cr. [0]=top [1]=left
   alignas(16) int32_t tmp[NW][BUF];           // per-wave transform / Hadamard / scan scratch (blocks needing more use HBM scratch)
@@ -466,6 +472,7 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
     if (gy > 3) enc_ep<WR>(cb, (uint32_t) (posY - VX_MIN_IN_GROUP[gy]), (gy - 2) >> 1);
   }
   int regBins = (((zo && w == 32) ? 16 : zw) * ((zo && h == 32) ? 16 : zh) * 28) >> 4;      // getTbAreaAfterCoefZeroOut (CL/Unit.cpp:872-890)
+  const int stateTab = (L.par.tools & TOOL_DEPQUANT) ? 32040 : 0; int state = 0;            // 3857-3858
   unsigned long long sigPos = 0;         // m_sigCoeffGroupFlag by CG raster position
   for (int sub = scanPosLast >> lcg; sub >= 0; sub--) {
     const int cgX = geo.grp[sub] & 15, cgY = geo.grp[sub] >> 4, cgPos = cgY * wg + cgX;
@@ -489,7 +496,7 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
       const int blk = scan[nextSigPos];
       const int cf = coeff[blk];
       const unsigned sigFlag = cf != 0;
-      if (numNonZero || nextSigPos != inferSigPos) { const int ctx = sig_ctx(c, coeff, blk); enc_bin<WR>(cb, sigFlag, ctx); remRegBins--; }
+      if (numNonZero || nextSigPos != inferSigPos) { const int ctx = sig_ctx(c, coeff, blk) + VX_CTX_SigFlag[c.ch + 2 * imax(0, state - 1)] - VX_CTX_SigFlag[c.ch]; enc_bin<WR>(cb, sigFlag, ctx); remRegBins--; }
       else if (nextSigPos != scanPosLast) sig_ctx(c, coeff, blk);
       if (sigFlag) {
         int off = 0;                       // ctxOffsetAbs (158-167)
@@ -508,6 +515,7 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
           enc_bin<WR>(cb, !!rem, VX_CTX_GtxFlag[c.ch] + off); remRegBins--;
         }
       }
+      state = (stateTab >> ((state << 2) + ((cf & 1) << 1))) & 3;
     }
     const int firstPosMode2 = nextSigPos;
     regBins = remRegBins;
@@ -520,8 +528,9 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
       const int blk = scan[sp];
       const unsigned a = (unsigned) iabs(coeff[blk]);
       const int sumAll = tmpl_abs_sum(c, coeff, blk, 0);
-      const unsigned rice = L.t.gorice_pars[sumAll], pos0 = L.t.gorice_pos0[sumAll];
+      const unsigned rice = L.t.gorice_pars[sumAll], pos0 = L.t.gorice_pos0[imax(0, state - 1) * 32 + sumAll];
       enc_rem_abs<WR>(cb, a == 0 ? pos0 : a <= pos0 ? a - 1 : a, rice);
+      state = (stateTab >> ((state << 2) + ((a & 1) << 1))) & 3;
       if (a) { numNonZero++; signPattern = (signPattern << 1) | (coeff[blk] < 0); }
     }
     enc_ep<WR>(cb, signPattern, numNonZero);
@@ -566,7 +575,7 @@ __device__ inline int rem_abs_len(unsigned bins, unsigned rice)   // bit count o
 __device__ __noinline__ void rc_chain(int ci, int wv, int nb, int lane, unsigned long long &bits)
 {
   nb = uni(nb); ci = uni(ci); wv = uni(wv);
-  Ctx *c = &L.ctxs[ci]; const uint16_t *bb = L.binbuf[wv]; uint8_t *sorted = L.binsort[wv];
+  Ctx *c = &L.ctxs[ci]; const uint16_t *bb = L.ws[wv].rc.binbuf; uint8_t *sorted = L.ws[wv].rc.binsort;
   int ctxv[RC_MAXJ]; unsigned binv[RC_MAXJ]; unsigned long long rem[RC_MAXJ];
 #pragma unroll
   for (int j = 0; j < RC_MAXJ; j++) {
@@ -622,6 +631,8 @@ template <bool SMALL>
 __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const int16_t *coeff_g, int w, int h, int is_chroma, int lane, int zo = 0)
 {
   zo = uni(zo);
+  const int dq = uni((int) (L.par.tools & TOOL_DEPQUANT)) != 0;       // dep_quant_enabled_flag: the quantiser state picks the sig_coeff_flag context set and the bypass zero position
+  int dqx = 0, dqy = 0;                                                 // state bits in front of lane 0 of the current 64 positions (see wave_dequant_dq)
   const long long q0 = STAMP();
   const int16_t *coeff = SMALL ? L.slot[uni(threadIdx.x >> 6)] + BUF + uni(lev_off) : coeff_g;
   const RcPre pre = rc_prepass_wave<SMALL>(lev_off, coeff_g, w, h, lane);
@@ -632,7 +643,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
   const long long q1 = STAMP();
   long long qe = 0, qc = 0;
   const int wv = uni(threadIdx.x >> 6);
-  uint16_t *bb = L.binbuf[wv]; uint8_t *sorted = L.binsort[wv];
+  uint16_t *bb = L.ws[wv].rc.binbuf; uint8_t *sorted = L.ws[wv].rc.binsort;
   const int lcg = geo.lcg, cgSize = 1 << lcg;
   const int zw = imin(32, w), zh = imin(32, h), wg = geo.wg, hg = geo.hg;
   const unsigned long long sigGroups = pre.sig_groups, sigRaster = pre.sig_raster;
@@ -685,6 +696,15 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
       if (sp == last) goff = 0;                          // m_tmplCpDiag == -1 only for the very first coefficient
     }
     const int a = iabs(cf);
+    int qstate = 0;
+    if (dq) {
+      const unsigned long long Pm = __ballot(a & 1);
+      const unsigned long long EVEN = 0x5555555555555555ull, ODD = 0xAAAAAAAAAAAAAAAAull;
+      const int odd = lane & 1;
+      const int xs = (odd ? dqy : dqx) ^ (__popcll(Pm & ltMask & (odd ? EVEN : ODD)) & 1), ys = (odd ? dqx : dqy) ^ (__popcll(Pm & ltMask & (odd ? ODD : EVEN)) & 1);
+      qstate = (xs << 1) | ys;
+      dqx ^= __popcll(Pm & ODD) & 1; dqy ^= __popcll(Pm & EVEN) & 1;
+    }
     const unsigned long long nz = __ballot(coded && a != 0);
     const int cgStart = lane - inCG;
     const unsigned long long cgLt = ltMask & ~(cgStart <= 0 ? 0ull : (~0ull >> (64 - cgStart)));
@@ -708,7 +728,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
     }
     int ep = (coded && a) ? 1 : 0;                        // sign
     if (ctxMode) {
-      if (sigCoded) bb[o++] = (uint16_t) (((sigBase + sigofs) << 1) | (a != 0));
+      if (sigCoded) bb[o++] = (uint16_t) (((VX_CTX_SigFlag[is_chroma + 2 * imax(0, qstate - 1)] + sigofs) << 1) | (a != 0));
       if (a) {
         bb[o++] = (uint16_t) (((g1Base + goff) << 1) | (a > 1));
         if (a > 1) {
@@ -719,7 +739,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
       }
     } else if (coded) {
       const int sumAll = imin(sumPlain, 31);
-      const unsigned rice = L.t.gorice_pars[sumAll], pos0 = L.t.gorice_pos0[sumAll];
+      const unsigned rice = L.t.gorice_pars[sumAll], pos0 = L.t.gorice_pos0[imax(0, qstate - 1) * 32 + sumAll];
       ep += rem_abs_len(a == 0 ? pos0 : (unsigned) a <= pos0 ? (unsigned) a - 1 : (unsigned) a, rice);
     }
     mybits += (unsigned long long) ep << 15;
@@ -735,6 +755,8 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
   if (lane == 0) cb.bits += tot;
   if (VVCX_STAMP && threadIdx.x == 0) { L.prof[32] += (unsigned long long) (q1 - q0); L.prof[34] += (unsigned long long) qe; L.prof[35] += (unsigned long long) qc; L.prof[36] += (unsigned long long) (STAMP() - q3); L.prof[37] += 1; }
 }
+
+#include "vvcx_depquant_dev.h"
 
 // ------------------------------------------------------------------------------------------------ partitioner (thread 0)
 __device__ int implicit_split(const VxParams &p, Frame &f, int ch)      // CL/UnitPartitioner.cpp:530-581
@@ -1474,10 +1496,7 @@ __device__ inline uint2 rev4_s16(uint2 d) { uint2 r; r.x = (d.y >> 16) | (d.y <<
 __device__ inline I32x4 rev4_s32(I32x4 d) { I32x4 r; r.x = d.w; r.y = d.z; r.z = d.y; r.w = d.x; return r; }
 template <bool SMALL> __device__ inline const int8_t *dct2_matrix(int n)
 {
-  if (!SMALL && BUF < 256) {                            // HBM path of a build without the 64-point matrix in LDS: constant tables
-    switch (n) { case 2: return VX_DCT2_2; case 4: return VX_DCT2_4; case 8: return VX_DCT2_8; case 16: return VX_DCT2_16; case 32: return VX_DCT2_32; default: return VX_DCT2_64; }
-  }
-  switch (n) { case 2: return L.t.dct; case 4: return L.t.dct + 4; case 8: return L.t.dct + 20; case 16: return L.t.dct + 84; case 32: return L.t.dct + 340; default: return L.t.dct + 1364; }
+  switch (n) { case 2: return L.t.dct; case 4: return L.t.dct + 4; case 8: return L.t.dct + 20; case 16: return L.t.dct + 84; case 32: return L.t.dct + 340; default: return VX_DCT2_64; }
 }
 __device__ void load_tables()
 {
@@ -1495,12 +1514,14 @@ __device__ void load_tables()
     const int t = tid < 16 ? 0 : tid < 20 ? 1 : tid < 36 ? 2 : 3, n = tid - (t == 0 ? 0 : t == 1 ? 16 : t == 2 ? 20 : 36);
     int x, y; diag_walk(t == 0 ? 4 : t == 2 ? 8 : 2, t == 0 ? 4 : t == 3 ? 8 : 2, n, x, y);
     L.t.cg_scan[tid] = (uint8_t) (x | (y << 4));
+    L.t.cg_inv[(t == 0 ? 0 : t == 1 ? 16 : t == 2 ? 20 : 36) + y * (t == 0 ? 4 : t == 2 ? 8 : 2) + x] = (uint8_t) n;
   }
   for (int i = tid; i < 225; i += NT) {
     int a = 0, b = 0, off = 0;                           // table of (lwg = a, lhg = b) starts at 15 (2^a - 1) + 2^a (2^b - 1)
     for (int aa = 0; aa < 4; aa++) for (int bb = 0; bb < 4; bb++) { const int o = 15 * ((1 << aa) - 1) + (1 << aa) * ((1 << bb) - 1); if (o <= i) { a = aa; b = bb; off = o; } }
     int x, y; diag_walk(1 << a, 1 << b, i - off, x, y);
     L.t.grp_scan[i] = (uint8_t) (x | (y << 4));
+    L.t.grp_inv[off + y * (1 << a) + x] = (uint8_t) (i - off);
   }
   for (int i = tid; i < 16; i += NT) L.t.dst7[i] = VX_DST7_4[i];
   for (int i = tid; i < 64; i += NT) L.t.dst7[16 + i] = VX_DST7_8[i];
@@ -1511,19 +1532,21 @@ __device__ void load_tables()
   for (int i = tid; i < 64; i += NT) L.t.dct[20 + i] = VX_DCT2_8[i];
   for (int i = tid; i < 256; i += NT) L.t.dct[84 + i] = VX_DCT2_16[i];
   for (int i = tid; i < 1024; i += NT) L.t.dct[340 + i] = VX_DCT2_32[i];
-  if (BUF >= 256) for (int i = tid; i < 4096; i += NT) L.t.dct[1364 + i] = VX_DCT2_64[i];
 }
 // residual (org - pred) → DCT-II (TrQuant::xT 835-915) → plain quant (Quant::quant 994-1089) → levels;
 // if any level: dequant (423-549) → inverse DCT-II (xIT 917-992) → reco = clip(pred + resi) written over pred.
 // Returns SSE(org, reco) and abs-sum via out params.  rec/lev tiles have stride w.
 // given >= 0: the levels in lev are taken as coded (cbf = given): only the decoder half runs (DecCu::xIntraRecBlk, DL/DecCu.cpp:199-414).
 // SMALL: rec / lev / tmp are the calling wave's LDS buffers (L.slot[wave] + buf_off, + 1024, L.tmp[wave]); else the _g pointers.
+// With VVCX_TOOL_DEPQUANT the quantiser is the trellis of wave_depquant (comp: 0 Y / 1 Cb / 2 Cr, ci: the context set its rate terms are read from =
+// the estimator's contexts at this point of the search, cbf_cb: tu.cbf[Cb] when Cr is quantised) and the dequantiser its state machine.
 template <bool SMALL, bool SUMABS = false>
 __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, int buf_off, int16_t *rec_g, int16_t *lev_g, int32_t *tmp_g, int w, int h, int bd, int qp,
-                                int lane, unsigned long long &sse_out, int &cbf_out, int given = -1, int *sumabs_out = nullptr)
+                                int lane, unsigned long long &sse_out, int &cbf_out, int given = -1, int *sumabs_out = nullptr, int comp = 0, int ci = 0, int cbf_cb = 0)
 {
   int coef_sum = 0;                                     // SUMABS: sum of |DCT-II coefficient| for the MTS pruning (TrQuant::transformNxN 1049-1124)
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given);
+  const int dq = uni((int) (L.par.tools & TOOL_DEPQUANT)) != 0;
   const int wave_ = uni(threadIdx.x >> 6);
   const int16_t *org = (SMALL ? L.org : org_g) + uni(org_off);
   int16_t *rec = SMALL ? L.slot[wave_] + uni(buf_off) : rec_g, *lev = SMALL ? L.slot[wave_] + BUF + uni(buf_off) : lev_g;
@@ -1558,6 +1581,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     else for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
     const int c = (s + rnd2) >> shift2;
     if (SUMABS) coef_sum += iabs(c);
+    if (dq) { lev[m * w + k] = (int16_t) c; continue; }       // the trellis works on the coefficients (15 bits + sign by construction of the transform shifts)
     const long long t = (long long) iabs(c) * qscale;
     int q = (int) ((t + qadd) >> qbits);
     abs_sum += q;
@@ -1565,7 +1589,10 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     q = q < -32768 ? -32768 : q > 32767 ? 32767 : q;
     lev[m * w + k] = (int16_t) q;
   }
-  abs_sum = given < 0 ? uni(wave_sum_i32(abs_sum)) : given;
+  if (dq && given < 0) {
+    wave_sync();
+    abs_sum = wave_depquant<SMALL>(lev, buf_off, L.par.scratch + (size_t) blockIdx.x * L.par.scratch_per_stream, ci, w, h, comp, VX_CTX_QtCbf[comp] + (comp == 2 ? cbf_cb : 0), 0, 0, lane);
+  } else abs_sum = given < 0 ? uni(wave_sum_i32(abs_sum)) : given;
   if (SUMABS) *sumabs_out = wave_sum_i32(coef_sum);
   wave_sync();
   unsigned long long sse = 0;
@@ -1577,6 +1604,8 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     // dequantised coefficients once (they are clipped to 16 bits, Quant::dequant 423-549): deq[m*zw + k], int16 at the start of tmp,
     // followed by the (16-bit clipped) output of the vertical stage: zw*zh + zw*h int16 <= the zw*h int32 the forward pass used
     int16_t *deq = (int16_t *) tmp, *tcol = deq + zw * zh;
+    if (dq) wave_dequant_dq(lev, deq, w, h, zw, zh, bd, qp, lane);
+    else {
     for (int o = lane; o < zw * zh; o += 64) {
       const int m = o >> lzw, k = o & (zw - 1);
       int q = lev[m * w + k]; q = q < in_min ? in_min : q > in_max ? in_max : q;
@@ -1584,6 +1613,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
       deq[o] = (int16_t) (v < -32768 ? -32768 : v > 32767 ? 32767 : v);
     }
     wave_sync();
+    }
     // inverse stage 1 (vertical): t[j*h + i] = clip((sum_k Mh[k][i] * deq[k][j] + 64) >> 7), j < zw
     for (int o = lane; o < zw * h; o += 64) {
       const int j = o >> lh, i = o & (h - 1);
@@ -1674,6 +1704,7 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
                                                  int lane, unsigned long long &sse_out, int &cbf_out, int given = -1)
 {
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given); mts = uni(mts);
+  const int dq = uni((int) (L.par.tools & TOOL_DEPQUANT)) != 0;        // luma only: the rate terms come from the node's start contexts (CI_CUR)
   const int wave_ = uni(threadIdx.x >> 6);
   const int16_t *org = SMALL ? L.org : org_g;
   int16_t *rec = SMALL ? L.slot[wave_] : rec_g, *lev = SMALL ? L.slot[wave_] + BUF : lev_g;
@@ -1706,6 +1737,7 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
     if (trv == 1) { for (int j = 0; j < h; j += 4) s += dot4_s32(*(const uint32_t *) (Mh + m * h + j), rev4_s32(*(const I32x4 *) (tmp + k * h + h - 4 - j))); if (m & 1) s = -s; }
     else for (int j = 0; j < h; j += 4) s += dot4_s32(*(const uint32_t *) (Mh + m * h + j), *(const I32x4 *) (tmp + k * h + j));
     const int c = (s + rnd2) >> shift2;
+    if (dq) { lev[m * w + k] = (int16_t) c; continue; }
     const long long t = (long long) iabs(c) * qscale;
     int q = (int) ((t + qadd) >> qbits);
     abs_sum += q;
@@ -1713,7 +1745,10 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
     q = q < -32768 ? -32768 : q > 32767 ? 32767 : q;
     lev[m * w + k] = (int16_t) q;
   }
-  abs_sum = given < 0 ? uni(wave_sum_i32(abs_sum)) : given;
+  if (dq && given < 0) {
+    wave_sync();
+    abs_sum = wave_depquant<SMALL>(lev, 0, L.par.scratch + (size_t) blockIdx.x * L.par.scratch_per_stream, CI_CUR, w, h, 0, VX_CTX_QtCbf[0], 1, 0, lane);
+  } else abs_sum = given < 0 ? uni(wave_sum_i32(abs_sum)) : given;
   wave_sync();
   unsigned long long sse = 0;
   if (abs_sum > 0) {
@@ -1722,6 +1757,8 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
     int tbd = 32 + right_shift - 7; if (tbd > 16) tbd = 16;
     const int in_min = -(1 << (tbd - 1)), in_max = (1 << (tbd - 1)) - 1;
     int16_t *deq = (int16_t *) tmp, *tcol = deq + zw * zh;       // as in wave_code_block: coefficients dequantised once, 16-bit intermediate
+    if (dq) wave_dequant_dq(lev, deq, w, h, zw, zh, bd, qp, lane);
+    else {
     for (int o = lane; o < zw * zh; o += 64) {
       const int m = o >> lzw, k = o & (zw - 1);
       int q = lev[m * w + k]; q = q < in_min ? in_min : q > in_max ? in_max : q;
@@ -1729,6 +1766,7 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
       deq[o] = (int16_t) (v < -32768 ? -32768 : v > 32767 ? 32767 : v);
     }
     wave_sync();
+    }
     for (int o = lane; o < zw * h; o += 64) {
       const int j = o >> lh, i = o & (h - 1);
       int s = 0;
@@ -2165,7 +2203,7 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
       chroma_pred_wave(rec, lmin, k, fm, w, h, bd, lane);
       wave_sync();
       unsigned long long sse; int cbf;
-      wave_code_block<SMALL>(org_tile(scratch, 2 * P), k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[k], lane, sse, cbf);
+      wave_code_block<SMALL>(org_tile(scratch, 2 * P), k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[k], lane, sse, cbf, -1, nullptr, k + 1, CI_W(wave), k == 1 ? cbfs[0] : 0);
       cbfs[k] = cbf;
       dist += (unsigned long long) (p.dist_weight[k] * (double) sse);             // CL/RdCost.cpp:405-408
       {                    // xGetIntraFracBitsQTChroma 2625-2692: contexts advance
@@ -3276,6 +3314,30 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_trq_kernel(c
   if (wave != 0) return;
   unsigned long long sse; int cbf;
   wave_code_block<false>(org + (size_t) blockIdx.x * P, 0, 0, rec + (size_t) blockIdx.x * P, lev + (size_t) blockIdx.x * P, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, lane, sse, cbf);
+  if (lane == 0) { out[blockIdx.x * 2] = sse; out[blockIdx.x * 2 + 1] = (unsigned long long) cbf; }
+}
+// the same with the dependent quantiser (wave_depquant + wave_dequant_dq) from given context models: p carries tools, dq_consts and a scratch area
+// (VXD_OFF_CACHE bytes per block); blocks of at most BUF samples run the LDS-resident form the search uses for them, bigger ones the HBM form
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_dq_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp,
+                                                                              int w, int h, int qp, int comp, int mts, int cbf_cb, unsigned long long *out)
+{
+  if (threadIdx.x == 0) L.par = p;
+  load_tables();
+  for (int i = threadIdx.x; i < NCTX; i += NT) { L.ctxs[CI_CUR].s0[i] = ctx[i]; L.ctxs[CI_CUR].s1[i] = ctx[NCTX + i]; }
+  __syncthreads();
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, P = w * h, bd = p.bit_depth;
+  if (wave != 0) return;
+  const size_t b = (size_t) blockIdx.x * P;
+  unsigned long long sse; int cbf;
+  if (P <= BUF) {
+    for (int i = lane; i < P; i += 64) { L.org[i] = org[b + i]; L.slot[0][i] = rec[b + i]; }
+    wave_sync();
+    if (mts > 1) wave_code_block_mts<true>(nullptr, nullptr, nullptr, nullptr, w, h, bd, qp, mts, lane, sse, cbf);
+    else wave_code_block<true>(nullptr, 0, 0, nullptr, nullptr, nullptr, w, h, bd, qp, lane, sse, cbf, -1, nullptr, comp, CI_CUR, cbf_cb);
+    wave_sync();
+    for (int i = lane; i < P; i += 64) { rec[b + i] = L.slot[0][i]; lev[b + i] = L.slot[0][BUF + i]; }
+  } else if (mts > 1) wave_code_block_mts<false>(org + b, rec + b, lev + b, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, mts, lane, sse, cbf);
+  else wave_code_block<false>(org + b, 0, 0, rec + b, lev + b, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, lane, sse, cbf, -1, nullptr, comp, CI_CUR, cbf_cb);
   if (lane == 0) { out[blockIdx.x * 2] = sse; out[blockIdx.x * 2 + 1] = (unsigned long long) cbf; }
 }
 template <typename T>

@@ -13,6 +13,7 @@ DEFAULT_LIB = os.path.join(HERE, "libvvcx.so")
 TOOL_MRL = 1
 TOOL_MIP = 1 << 1            # matrix-based intra prediction searched (cfg MIP 1, FastMIP 1): mip_flag / MIP mode per luma CU
 TOOL_MTS = 1 << 4            # explicit intra MTS (cfg MTS 1, MTSIntraMaxCand 3): DST-VII / DCT-VIII pairs for luma TUs up to 32x32
+TOOL_DEPQUANT = 1 << 6       # dependent quantisation (cfg DepQuant 1): trellis quantiser, state-driven residual syntax and dequantiser
 TOOL_CU_REUSE = 1 << 11      # BestEncInfoCache, REUSE_CU_RESULTS (CL/TypeDef.h:291) - on in the reference build
 TOOL_CCLM = 1 << 8           # LM / MDLM chroma modes (cfg LMChroma 1, on in the reference's intra configuration)
 TOOL_FAST = 1 << 12          # the fork's FAST_ALGORITHM: features + random forest pick the one partition mode of a luma node
@@ -342,4 +343,17 @@ def transform_quant_batch(org, pred, w, h, bit_depth, qp, device=0, lib_path=Non
     n = org.size // (w * h)
     lev = np.zeros(org.size, np.int16); rec = np.zeros(org.size, np.int16); sse = np.zeros(n, np.uint64); cbf = np.zeros(n, np.uint8)
     _chk(L, L.vvcx_transform_quant_batch(org.ctypes.data, pred.ctypes.data, w, h, bit_depth, qp, n, lev.ctypes.data, rec.ctypes.data, sse.ctypes.data, cbf.ctypes.data, device))
+    return lev.reshape(n, h, w), rec.reshape(n, h, w), sse, cbf
+
+
+def depquant_batch(org, pred, w, h, bit_depth, qp, comp, mts_idx, cbf_cb, lam, s0, s1, device=0, lib_path=None):
+    """vvcx_depquant_batch: n blocks back to back through transform + dependent quantiser + its dequantiser + inverse transform"""
+    L = load_library(lib_path)
+    org = np.ascontiguousarray(org, np.int16).ravel(); pred = np.ascontiguousarray(pred, np.int16).ravel()
+    s0 = np.ascontiguousarray(s0, np.uint16); s1 = np.ascontiguousarray(s1, np.uint16)
+    n = org.size // (w * h)
+    lev = np.zeros(org.size, np.int16); rec = np.zeros(org.size, np.int16); sse = np.zeros(n, np.uint64); cbf = np.zeros(n, np.uint8)
+    L.vvcx_depquant_batch.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_double, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int]
+    _chk(L, L.vvcx_depquant_batch(org.ctypes.data, pred.ctypes.data, w, h, bit_depth, qp, comp, mts_idx, cbf_cb, lam, s0.ctypes.data, s1.ctypes.data, n,
+                                  lev.ctypes.data, rec.ctypes.data, sse.ctypes.data, cbf.ctypes.data, device))
     return lev.reshape(n, h, w), rec.reshape(n, h, w), sse, cbf

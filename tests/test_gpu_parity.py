@@ -110,6 +110,23 @@ def test_matrix_intra_prediction_alone_without_cu_reuse_and_with_classifier():
     _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=0.5)], 256, 128, pkg.slice_params(27), tools=MIP | pkg.TOOL_FAST)
 
 
+DQ = MIP | pkg.TOOL_DEPQUANT
+
+
+@pytest.mark.parametrize("case", [(128, 128, 27, 8, 1, 1, 7), (200, 136, 22, 8, 1, 1, 1234), (256, 256, 32, 8, 2, 2, 5), (128, 128, 37, 10, 1, 1, 3), (256, 128, 32, 8, 2, 1, 6)])
+def test_dependent_quantisation_in_the_search(case):
+    # tools 0x953: every block quantised by the trellis (wave_depquant: rate terms from the live contexts, lambda of the component), the state-driven
+    # sig_coeff_flag contexts / bypass zero positions in the rate estimator and in the final pass, the state-machine dequantiser; slice lambda and
+    # chroma weights as EncSlice derives them with DepQuant on
+    W, H, qp, bd, tc, tr, seed = case
+    _check([pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=0.5)], W, H, pkg.slice_params(qp, bit_depth=bd, dep_quant=True), bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=DQ)
+
+
+def test_dependent_quantisation_without_cu_reuse_low_qp_and_with_classifier():
+    _check([pkg.synth_frame(128, 128, 0, 8, 11, chroma_texture=0.3)], 128, 128, pkg.slice_params(17, dep_quant=True), tools=pkg.TOOL_MRL | pkg.TOOL_MTS | pkg.TOOL_CCLM | pkg.TOOL_DEPQUANT)
+    _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=0.5)], 256, 128, pkg.slice_params(27, dep_quant=True), tools=DQ | pkg.TOOL_FAST)
+
+
 FAST = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_FAST
 
 
@@ -196,7 +213,7 @@ def test_full_1080p_frame_matches_oracle():
     _check([pkg.synth_frame(W, H, 0, 8, 1000)], W, H, pkg.slice_params(32), tile_cols=15, tile_rows=9)
 
 
-@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz"])
+@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz", "bitstream_dq.npz"])
 def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fixture):
     """Device writer (arithmetic coding of the final CTU syntax in the estimator pass) against tests/golden/bitstream.npz: payloads
     that the reference's CABACReader parsed back into the coded CUs and levels when the fixture was generated."""
@@ -209,7 +226,7 @@ def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fix
     for (W, H, qp, tc, tr, bd, seed, nbytes), sizes in zip(g["pic_meta"], g["pic_sizes"]):
         exp = g["pic_bytes"][off:off + nbytes]; off += int(nbytes)
         W, H, bd = int(W), int(H), int(bd)
-        sp = pkg.slice_params(int(qp), bit_depth=bd)
+        sp = pkg.slice_params(int(qp), bit_depth=bd, dep_quant=bool(tools & pkg.TOOL_DEPQUANT))
         planes = pkg.synth_frame(W, H, 0, bd, int(seed), chroma_texture=texture)
         enc = pkg.VvcxEncoder(W, H, bd, tile_cols=int(tc), tile_rows=int(tr), emit_payload=True, tools=tools)
         enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])

@@ -107,6 +107,32 @@ def _trquant(lib, limit):
     return n
 
 
+def _depquant(lib, limit):
+    """vvcx_depquant_batch (the search's wave_depquant + wave_dequant_dq) against the reference's DepQuant vectors (tests/golden/depquant.npz)"""
+    from test_oracle_golden import _depquant_cases
+    n = 0
+    for c in _depquant_cases():
+        w, h, bd = c["w"], c["h"], c["bd"]
+        if limit and (n >= limit or w * h > 64):
+            continue
+        mid, mx = 1 << (bd - 1), (1 << bd) - 1
+        resi = c["resi"].astype(np.int32)
+        org = (mid + resi).astype(np.int16); pred = np.full(w * h, mid, np.int16)
+        lev, rec, sse, cbf = pkg.depquant_batch(org, pred, w, h, bd, c["qp_used"], c["comp"], c["mts"], c["cbf_cb"], c["lam"], c["ctx"][0], c["ctx"][1], lib_path=lib)
+        key = (bd, c["qp"], c["comp"], w, h, c["mts"])
+        assert np.array_equal(lev.ravel(), c["lev"]) and int(cbf[0]) == int(c["asum"] > 0), ("levels", key)
+        rec_e = np.clip(mid + c["out"].astype(np.int32), 0, mx) if c["asum"] > 0 else np.full(w * h, mid)
+        assert np.array_equal(rec.ravel().astype(np.int32), rec_e), ("rec", key)
+        assert int(sse[0]) == int(((org.astype(np.int64) - rec_e) ** 2).sum())
+        n += 1
+    return n
+
+
+@pytest.mark.gpu
+def test_gpu_dependent_quantisation_matches_reference():
+    assert _depquant(None, None) == 575
+
+
 @pytest.mark.gpu
 def test_gpu_transform_quant_matches_reference():
     assert _trquant(None, None) == 75
@@ -134,6 +160,7 @@ def test_emulated_leaf_operators_match_reference(emu_so):
     _scan(emu_so, ["s4x4", "s8x8", "s16x4", "s32x32"])
     assert _intra(emu_so, 40) == 40
     assert _trquant(emu_so, 8) == 8
+    assert _depquant(emu_so, 12) == 12
 
 
 @pytest.mark.gpu
