@@ -107,6 +107,16 @@ struct VxCacheEnt { uint64_t ss; uint8_t kind /* 0 empty, 1 luma tree, 2 chroma 
 // dependent quantisation of blocks too big for LDS: per wave decisions (2 KB), path nodes of up to 64 coefficient groups (4 KB + 512 B), last-position offsets
 #define VXD_DQ_WAVE     8192
 #define VXD_OFF_DQ      ((VXD_OFF_LM + (1024 + 128) * 2 + 255) & ~255)
-#define VXD_OFF_CACHE   ((VXD_OFF_DQ + VXD_NW * VXD_DQ_WAVE + 255) & ~255)
+// candidate pool of the batched full-RD stage (dependent quantisation): the predictions of the node's candidates, their transform coefficients / levels, the
+// path nodes of the batched trellis and one result record per (candidate, transform) item
+#define VXD_POOL_ELEMS      32768                                                      // int16 elements of the prediction pool and of the coefficient pool
+#define VXD_POOL_NODE_BYTES (128 * 1024)
+#define VXD_POOL_ITEMS      64
+struct VxRbItem { double cost; uint64_t dist, bits; int32_t cbf, sum0, test, wave; };   // 40 bytes
+#define VXD_OFF_POOL    ((VXD_OFF_DQ + VXD_NW * VXD_DQ_WAVE + 255) & ~255)
+#define VXD_OFF_POOL_COEF  (VXD_OFF_POOL + VXD_POOL_ELEMS * 2)
+#define VXD_OFF_POOL_NODES (VXD_OFF_POOL_COEF + VXD_POOL_ELEMS * 2)
+#define VXD_OFF_POOL_REC   (VXD_OFF_POOL_NODES + VXD_POOL_NODE_BYTES)
+#define VXD_OFF_CACHE   ((VXD_OFF_POOL_REC + 2 * VXD_POOL_ITEMS * (int) sizeof(VxRbItem) + 255) & ~255)
 #define VXD_OFF_CACHE_LEV (VXD_OFF_CACHE + VXD_CACHE_ENTRIES * (int) sizeof(VxCacheEnt))
 #define VXD_SCRATCH_BYTES (VXD_OFF_CACHE_LEV + VXD_CACHE_DIM * VXD_CACHE_DIM * 2)

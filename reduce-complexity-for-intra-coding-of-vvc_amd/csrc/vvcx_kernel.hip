@@ -105,20 +105,24 @@ struct Tables {                    // constant tables staged once per workgroup 
 #define RC_LIST 320
 // per-wave scratch that the rate estimator (pending bin list) and the dependent quantiser (decisions, path nodes) use at different times
 struct WaveRc { uint16_t binbuf[RC_LIST]; uint8_t binsort[RC_LIST + 8]; };
-struct WaveDq { uint16_t trel[BUF]; uint8_t hlev[BUF / 16][4][16]; int8_t hpar[BUF / 16][4]; uint8_t hflag[BUF / 16][4]; int lastb[32]; };
+struct WaveDq { int lastb[16][20]; uint16_t trel[256]; };      // last-position offsets per item; decisions (they continue into tmp / slot behind)
 union WaveScratch { WaveRc rc; WaveDq dq; };
+struct WaveMem {
+  WaveScratch ws;
+  alignas(16) int32_t tmp[BUF];                // transform / Hadamard / scan scratch (blocks needing more use HBM scratch)
+  alignas(16) int16_t slot[2 * BUF];           // candidate buffers: rec[BUF] | lev[BUF] (parked winners and big blocks live in HBM scratch)
+};
 #define CI_CUR 0
 #define CI_W(w) (1 + (w))
 struct Lds {
   Tables t;
   Ctx ctxs[1 + NW];                // [0] the estimator's contexts, [1 + w] per-wave working copy (a wave's best end-of-candidate contexts are parked in HBM)
   alignas(16) int16_t org[BUF];    // node's original tile: luma w*h, or Cb | Cr (cw*ch each); bigger nodes keep it in HBM scratch (VXD_OFF_ORG)
-  alignas(16) WaveScratch ws[NW];  // residual_coding_wave: pending (ctx<<1|bin) list, bins grouped by context; wave_depquant: decisions and path nodes
+  alignas(16) WaveMem wm[NW];      // per wave: rate-estimator / quantiser scratch, transform scratch, candidate buffers (contiguous: the batched trellis uses all of it)
   int acc[NW][4][2];               // small-block SATD stage: per packed candidate {SAD, SATD}
   int16_t refs[4][2][140];         // luma: set 0 mrl0 unfiltered, 1 mrl0 filtered, 2 mrl1, 3 mrl3; chroma: set 0 Cb, 1 Cr. [0]=top [1]=left
-  alignas(16) int32_t tmp[NW][BUF];           // per-wave transform / Hadamard / scan scratch (blocks needing more use HBM scratch)
-  alignas(16) int16_t slot[NW][2 * BUF];       // per-wave candidate buffers: rec[BUF] | lev[BUF] (parked winners and big blocks live in HBM scratch)
   uint8_t flags[72]; int8_t src_unit[72];
+  int dq_abs[64 + NW];             // wave_depquant_batch: absSum per item of a batch ([64 + wave]: a wave's own single block)
   Frame fr[MAXD];
   // posted operation
   int op, op_a, op_b, op_c, op_d, op_ch;
@@ -130,6 +134,8 @@ struct Lds {
   Cand rd[16]; double rd_cost[16]; uint64_t rd_dist[16]; uint64_t rd_bits[16]; uint8_t rd_cbf[16]; uint8_t rd_mts[16]; int mts_evals[NW]; int n_rd;
   int do_save;                      // after_intra_op: the controller accepted the intra result
   int wave_best[NW], wave_slot[NW]; // candidate index of each wave's best and the slot that holds it
+  uint8_t rd_wave[16];              // which wave evaluated (and parked) the best (mode, transform) pair of each candidate
+  uint8_t rb_pairs[VXD_POOL_ITEMS]; int rb_nb;   // batched full-RD stage: the (candidate << 3 | MTS pair) items of the current chunk
   CtlState S; VxUnit cu;           // controller working set; CU record of the intra candidate being evaluated
   unsigned mpm[6], mpm_sorted[6]; int mpm_n;
   int16_t mip_n, mip_ctx;          // MIP modes of the node (0: no mip_flag) and the context of its mip_flag (3: more than 2:1, not searched)
@@ -416,14 +422,14 @@ __device__ __noinline__ RcPre rc_prepass_serial(const int16_t *coeff, int w, int
   return r;
 }
 // wave pre-pass: 64 scan positions per step, last position and group significance from the ballot of "coefficient != 0"
-// SMALL: the levels are the calling wave's LDS slot (L.slot[wave] + 1024 + lev_off); else coeff_g (HBM).  The LDS pointer is formed
+// SMALL: the levels are the calling wave's LDS slot (L.wm[wave].slot + 1024 + lev_off); else coeff_g (HBM).  The LDS pointer is formed
 // from L inside the function: a pointer handed through a call is a generic one and every access through it a flat_ instruction
 // (longer path to LDS, and its completion can only be awaited with vmcnt(0) + lgkmcnt(0)).
 template <bool SMALL>
 __device__ __noinline__ RcPre rc_prepass_wave(int lev_off, const int16_t *coeff_g, int w, int h, int lane)
 {
   w = uni(w); h = uni(h);
-  const int16_t *coeff = SMALL ? L.slot[uni(threadIdx.x >> 6)] + BUF + uni(lev_off) : coeff_g;
+  const int16_t *coeff = SMALL ? L.wm[uni(threadIdx.x >> 6)].slot + BUF + uni(lev_off) : coeff_g;
   const ScanGeo g = scan_geo(w, h);
   int last = -1; unsigned long long sig = 0;
   const int gpi = 64 >> g.lcg;                           // groups per step
@@ -575,7 +581,7 @@ __device__ inline int rem_abs_len(unsigned bins, unsigned rice)   // bit count o
 __device__ __noinline__ void rc_chain(int ci, int wv, int nb, int lane, unsigned long long &bits)
 {
   nb = uni(nb); ci = uni(ci); wv = uni(wv);
-  Ctx *c = &L.ctxs[ci]; const uint16_t *bb = L.ws[wv].rc.binbuf; uint8_t *sorted = L.ws[wv].rc.binsort;
+  Ctx *c = &L.ctxs[ci]; const uint16_t *bb = L.wm[wv].ws.rc.binbuf; uint8_t *sorted = L.wm[wv].ws.rc.binsort;
   int ctxv[RC_MAXJ]; unsigned binv[RC_MAXJ]; unsigned long long rem[RC_MAXJ];
 #pragma unroll
   for (int j = 0; j < RC_MAXJ; j++) {
@@ -634,7 +640,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
   const int dq = uni((int) (L.par.tools & TOOL_DEPQUANT)) != 0;       // dep_quant_enabled_flag: the quantiser state picks the sig_coeff_flag context set and the bypass zero position
   int dqx = 0, dqy = 0;                                                 // state bits in front of lane 0 of the current 64 positions (see wave_dequant_dq)
   const long long q0 = STAMP();
-  const int16_t *coeff = SMALL ? L.slot[uni(threadIdx.x >> 6)] + BUF + uni(lev_off) : coeff_g;
+  const int16_t *coeff = SMALL ? L.wm[uni(threadIdx.x >> 6)].slot + BUF + uni(lev_off) : coeff_g;
   const RcPre pre = rc_prepass_wave<SMALL>(lev_off, coeff_g, w, h, lane);
   const int last = uni(pre.last);
   if (last < 0) return;
@@ -643,7 +649,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
   const long long q1 = STAMP();
   long long qe = 0, qc = 0;
   const int wv = uni(threadIdx.x >> 6);
-  uint16_t *bb = L.ws[wv].rc.binbuf; uint8_t *sorted = L.ws[wv].rc.binsort;
+  uint16_t *bb = L.wm[wv].ws.rc.binbuf; uint8_t *sorted = L.wm[wv].ws.rc.binsort;
   const int lcg = geo.lcg, cgSize = 1 << lcg;
   const int zw = imin(32, w), zh = imin(32, h), wg = geo.wg, hg = geo.hg;
   const unsigned long long sigGroups = pre.sig_groups, sigRaster = pre.sig_raster;
@@ -1455,8 +1461,8 @@ __device__ __noinline__ void wave_sad_satd(const int16_t *org_g, const int16_t *
 {
   w = uni(w); h = uni(h); org_off = uni(org_off); pred_off = uni(pred_off);       // offsets: second component of a chroma pair
   const int wave_ = uni(threadIdx.x >> 6);
-  const int16_t *org = (SMALL ? L.org : org_g) + org_off, *pred = (SMALL ? L.slot[wave_] : pred_g) + pred_off;
-  int16_t *scr = SMALL ? (int16_t *) L.tmp[wave_] : scr_g;
+  const int16_t *org = (SMALL ? L.org : org_g) + org_off, *pred = (SMALL ? L.wm[wave_].slot : pred_g) + pred_off;
+  int16_t *scr = SMALL ? (int16_t *) L.wm[wave_].tmp : scr_g;
   const int P = w * h;
   int bw, bh; satd_tile_shape(w, h, bw, bh);
   int a = 0, b = 0;
@@ -1537,7 +1543,7 @@ __device__ void load_tables()
 // if any level: dequant (423-549) → inverse DCT-II (xIT 917-992) → reco = clip(pred + resi) written over pred.
 // Returns SSE(org, reco) and abs-sum via out params.  rec/lev tiles have stride w.
 // given >= 0: the levels in lev are taken as coded (cbf = given): only the decoder half runs (DecCu::xIntraRecBlk, DL/DecCu.cpp:199-414).
-// SMALL: rec / lev / tmp are the calling wave's LDS buffers (L.slot[wave] + buf_off, + 1024, L.tmp[wave]); else the _g pointers.
+// SMALL: rec / lev / tmp are the calling wave's LDS buffers (L.wm[wave].slot + buf_off, + 1024, L.wm[wave].tmp); else the _g pointers.
 // With VVCX_TOOL_DEPQUANT the quantiser is the trellis of wave_depquant (comp: 0 Y / 1 Cb / 2 Cr, ci: the context set its rate terms are read from =
 // the estimator's contexts at this point of the search, cbf_cb: tu.cbf[Cb] when Cr is quantised) and the dequantiser its state machine.
 template <bool SMALL, bool SUMABS = false>
@@ -1549,8 +1555,8 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   const int dq = uni((int) (L.par.tools & TOOL_DEPQUANT)) != 0;
   const int wave_ = uni(threadIdx.x >> 6);
   const int16_t *org = (SMALL ? L.org : org_g) + uni(org_off);
-  int16_t *rec = SMALL ? L.slot[wave_] + uni(buf_off) : rec_g, *lev = SMALL ? L.slot[wave_] + BUF + uni(buf_off) : lev_g;
-  int32_t *tmp = SMALL ? L.tmp[wave_] : tmp_g;
+  int16_t *rec = SMALL ? L.wm[wave_].slot + uni(buf_off) : rec_g, *lev = SMALL ? L.wm[wave_].slot + BUF + uni(buf_off) : lev_g;
+  int32_t *tmp = SMALL ? L.wm[wave_].tmp : tmp_g;
   const int P = w * h, lw = ilog2i(w), lh = ilog2i(h);
   const int zw = imin(w, 32), zh = imin(h, 32), lzw = imin(lw, 5);
   const int8_t *Mw = dct2_matrix<SMALL>(w), *Mh = dct2_matrix<SMALL>(h);
@@ -1588,6 +1594,12 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     if (c < 0) q = -q;
     q = q < -32768 ? -32768 : q > 32767 ? 32767 : q;
     lev[m * w + k] = (int16_t) q;
+  }
+  if (given == -2) {                                    // forward half only (batched full-RD stage): the coefficients stay in lev for the trellis of the batch
+    if (SUMABS) *sumabs_out = wave_sum_i32(coef_sum);
+    wave_sync();
+    sse_out = 0; cbf_out = 0;
+    return;
   }
   if (dq && given < 0) {
     wave_sync();
@@ -1668,8 +1680,8 @@ __device__ __noinline__ int wave_fwd_sumabs(const int16_t *org_g, const int16_t 
 {
   w = uni(w); h = uni(h); bd = uni(bd); mts = uni(mts);
   const int wave_ = uni(threadIdx.x >> 6);
-  const int16_t *org = SMALL ? L.org : org_g, *pred = SMALL ? L.slot[wave_] : pred_g;
-  int32_t *tmp = SMALL ? L.tmp[wave_] : tmp_g;
+  const int16_t *org = SMALL ? L.org : org_g, *pred = SMALL ? L.wm[wave_].slot : pred_g;
+  int32_t *tmp = SMALL ? L.wm[wave_].tmp : tmp_g;
   int trh, trv; mts_types(mts, trh, trv);
   const int lw = ilog2i(w), lh = ilog2i(h);
   const int zw = (trh && w == 32) ? 16 : imin(w, 32), zh = (trv && h == 32) ? 16 : imin(h, 32), lzw = ilog2i(zw);
@@ -1707,8 +1719,8 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
   const int dq = uni((int) (L.par.tools & TOOL_DEPQUANT)) != 0;        // luma only: the rate terms come from the node's start contexts (CI_CUR)
   const int wave_ = uni(threadIdx.x >> 6);
   const int16_t *org = SMALL ? L.org : org_g;
-  int16_t *rec = SMALL ? L.slot[wave_] : rec_g, *lev = SMALL ? L.slot[wave_] + BUF : lev_g;
-  int32_t *tmp = SMALL ? L.tmp[wave_] : tmp_g;
+  int16_t *rec = SMALL ? L.wm[wave_].slot : rec_g, *lev = SMALL ? L.wm[wave_].slot + BUF : lev_g;
+  int32_t *tmp = SMALL ? L.wm[wave_].tmp : tmp_g;
   int trh, trv; mts_types(mts, trh, trv);
   const int P = w * h, lw = ilog2i(w), lh = ilog2i(h);
   const int zw = (trh && w == 32) ? 16 : w, zh = (trv && h == 32) ? 16 : h, lzw = ilog2i(zw);
@@ -1745,6 +1757,7 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
     q = q < -32768 ? -32768 : q > 32767 ? 32767 : q;
     lev[m * w + k] = (int16_t) q;
   }
+  if (given == -2) { wave_sync(); sse_out = 0; cbf_out = 0; return; }      // forward half only (batched full-RD stage)
   if (dq && given < 0) {
     wave_sync();
     abs_sum = wave_depquant<SMALL>(lev, 0, L.par.scratch + (size_t) blockIdx.x * L.par.scratch_per_stream, CI_CUR, w, h, 0, VX_CTX_QtCbf[0], 1, 0, lane);
@@ -1813,11 +1826,11 @@ __device__ inline int mts_allowed(const VxParams &p, int w, int h) { return (p.t
 // original tile of the node: LDS for nodes of at most BUF samples, else the stream's HBM scratch
 __device__ inline int16_t *org_tile(uint8_t *scratch, int nrec) { return nrec <= BUF ? L.org : (int16_t *) (scratch + VXD_OFF_ORG); }
 __device__ inline int16_t *slot_rec(uint8_t *scratch, int nrec, int wave, int which)
-{ return (nrec <= BUF && which == 0) ? &L.slot[wave][0] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS; }
+{ return (nrec <= BUF && which == 0) ? &L.wm[wave].slot[0] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS; }
 __device__ inline int16_t *slot_lev(uint8_t *scratch, int nrec, int wave, int which)
-{ return (nrec <= BUF && which == 0) ? &L.slot[wave][BUF] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS + 4096; }
+{ return (nrec <= BUF && which == 0) ? &L.wm[wave].slot[BUF] : (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS + 4096; }
 __device__ inline int32_t *wave_tmp(uint8_t *scratch, int n_i32, int wave)
-{ return n_i32 <= BUF ? L.tmp[wave] : (int32_t *) (scratch + VXD_OFF_TMP) + wave * 2048; }
+{ return n_i32 <= BUF ? L.wm[wave].tmp : (int32_t *) (scratch + VXD_OFF_TMP) + wave * 2048; }
 
 __device__ void ctx_copy_all(Ctx *dst, const Ctx *src)
 {
@@ -1860,8 +1873,8 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
   constexpr int P = BW * BH, G = 64 / P;
   const int sub = lane / P, pl = lane - sub * P;
   const int py = pl / BW, px = pl - py * BW;
-  int16_t *pred = &L.slot[wave][0];
-  int16_t *scr = (int16_t *) L.tmp[wave];
+  int16_t *pred = &L.wm[wave].slot[0];
+  int16_t *scr = (int16_t *) L.wm[wave].tmp;
   const int bd = p.bit_depth;
   // mode bits of all candidates of this wave up front, one candidate per lane: lane l serves step l / G, slot l % G
   unsigned long long mbits = 0;
@@ -1919,7 +1932,7 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
 __device__ __noinline__ void wave_pred_mip(int16_t *dst, int w, int h, int mode, int bd, int wave, int lane)
 {
   w = uni(w); h = uni(h); mode = uni(mode); wave = uni(wave);
-  int *sh = (int *) L.tmp[wave], *red = sh + 16;
+  int *sh = (int *) L.wm[wave].tmp, *red = sh + 16;
   const MipGeo g = mip_geo(w, h);
   const int16_t *top = L.refs[0][0] + 1, *left = L.refs[0][1] + 1;
   mip_reduced_pred(top, left, g, mode, bd, lane, sh, red);
@@ -1932,8 +1945,8 @@ template <bool SMALL>
 __device__ __noinline__ void stage_a_mip(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h, int c_end)
 {
   const int P = w * h, bd = p.bit_depth;
-  int16_t *pred = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, 0);
-  int16_t *scr = SMALL ? (int16_t *) L.tmp[wave] : (int16_t *) wave_tmp(scratch, P >> 1, wave);
+  int16_t *pred = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, 0);
+  int16_t *scr = SMALL ? (int16_t *) L.wm[wave].tmp : (int16_t *) wave_tmp(scratch, P >> 1, wave);
   for (int c = wave; c < c_end; c += NW) {
     const int mode = uni(L.cand[c].mode);
     wave_pred_mip(pred, w, h, mode, bd, wave, lane);
@@ -1955,8 +1968,8 @@ template <bool SMALL>
 __device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h, int c_end)
 {
   const int P = w * h, bd = p.bit_depth;
-  int16_t *pred = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, 0);
-  int16_t *scr = SMALL ? (int16_t *) L.tmp[wave] : (int16_t *) wave_tmp(scratch, P >> 1, wave);
+  int16_t *pred = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, 0);
+  int16_t *scr = SMALL ? (int16_t *) L.wm[wave].tmp : (int16_t *) wave_tmp(scratch, P >> 1, wave);
   unsigned long long mbits = 0;                         // mode bits of this wave's candidates up front, lane j serves step j
   { const int cc = uni(L.op_a) + wave + lane * NW; if (cc < c_end) mbits = luma_mode_bits(L.ctxs[CI_CUR], L.ny, L.cand[cc].mode, L.cand[cc].mrl); }
   int step = 0;
@@ -2042,7 +2055,7 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
   const int n_rd = uni(L.n_rd);
   for (int c = wave; c < n_rd; c += NW) {
     const int mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
-    int16_t *rec = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.slot[wave] + BUF : slot_lev(scratch, P, wave, cur);
+    int16_t *rec = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, P, wave, cur);
     if (lane == 0) L.rd_cost[c] = MAX_DOUBLE;
     const int mip = mrl & MIPF;                           // a MIP candidate: mode is the MIP mode, no reference line / filter choice
     Ipa ip; init_pred_params(w, h, 1, mip ? 0 : mode, mip ? 0 : mrl, ip);
@@ -2065,7 +2078,7 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     if (!((test >> k) & 1)) continue;
     const int mts = k ? k + 1 : 0;
     if (k) {                                             // the previous transform candidate turned the prediction into its reconstruction
-      rec = SMALL ? L.slot[wave] : slot_rec(scratch, P, wave, cur); lev = SMALL ? L.slot[wave] + BUF : slot_lev(scratch, P, wave, cur);
+      rec = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur); lev = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, P, wave, cur);
       if (mip) wave_pred_mip(rec, w, h, mode, bd, wave, lane);
       else for (int i = lane; i < P; i += 64) { const int py = i >> ilog2i(w), px = i & (w - 1); rec[i] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
       wave_sync();
@@ -2107,7 +2120,7 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     cost = lane0_d(cost);
     if (cost < mbest) {
       mbest = cost;
-      if (lane == 0) { L.rd_cost[c] = cost; L.rd_dist[c] = sse; L.rd_bits[c] = cb.bits; L.rd_cbf[c] = (uint8_t) cbf; L.rd_mts[c] = (uint8_t) mts; }
+      if (lane == 0) { L.rd_cost[c] = cost; L.rd_dist[c] = sse; L.rd_bits[c] = cb.bits; L.rd_cbf[c] = (uint8_t) cbf; L.rd_mts[c] = (uint8_t) mts; L.rd_wave[c] = (uint8_t) wave; }
     }
     if (cost < wbest) {
       wbest = cost;
@@ -2125,12 +2138,180 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
 }
 // out of line: the MTS variant must not weigh on the register allocation of the DCT-II-only loop inlined into op_stage_b
 template <bool SMALL> __device__ __noinline__ void stage_b_loop_mts(const VxParams &p_, uint8_t *scratch, int wave, int lane, int w, int h) { stage_b_loop<SMALL, true>(L.par, scratch, wave, lane, w, h); (void) p_; }
+// ---- full-RD stage with the dependent quantiser: the trellis of a block is serial and four lanes wide, so the candidates of the node are taken through the
+// stage together, in rounds (all threads; every wave meets the same barriers):
+//   A1  per candidate (one wave each): prediction, forward DCT-II -> coefficient pool (HBM scratch), prediction -> prediction pool
+//   A2  the trellis of up to 16 candidates per wavefront side by side (wave_depquant_batch)
+//   A3  per candidate: dequantise, inverse transform, reconstruction, SSE, rate; MTS pruning of a candidate whose DCT-II block is non-zero
+//   B1-B3 the same for the (candidate, explicit MTS pair) items that survived the pruning.
+// A wave keeps the best (cost, candidate, transform) item it evaluated parked like stage_b_loop does: the winner of the reference's two nested strict-<
+// loops is the lexicographic minimum of (cost, list position, transform order), which is the minimum of one of the waves.
+template <bool SMALL>
+__device__ void dq_trellis_phase(uint8_t *scratch, int n, int P, int total, int w, int h, int zo, int wave, int lane)
+{
+  int16_t *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF); uint8_t *poolNodes = scratch + VXD_OFF_POOL_NODES;
+  const int ipw = imin(16, (int) sizeof(WaveMem) / (80 + 2 * total));          // items one wave can hold decisions for
+  for (int i0 = wave * ipw; i0 < n; i0 += NW * ipw)
+    wave_depquant_batch(imin(ipw, n - i0), poolCoef + (size_t) i0 * P, P, poolNodes + (size_t) i0 * 4 * total, 4 * total, (uint8_t *) &L.wm[wave], i0,
+                        CI_CUR, 0, VX_CTX_QtCbf[0], 0u, w, h, 0, zo, 0, lane);
+}
+template <bool SMALL>
+__device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane, int w, int h)
+{
+  const VxParams &p = L.par;
+  const int P = w * h, bd = p.bit_depth, total = imin(32, w) * imin(32, h);
+  const int mtsOk = mts_allowed(p, w, h);
+  int16_t *poolPred = (int16_t *) (scratch + VXD_OFF_POOL), *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF);
+  VxRbItem *recA = (VxRbItem *) (scratch + VXD_OFF_POOL_REC), *recB = recA + VXD_POOL_ITEMS;
+  const int capItems = imin(VXD_POOL_ITEMS, imin(VXD_POOL_ELEMS / P, VXD_POOL_NODE_BYTES / (4 * total)));
+  const int capCand = imin(16, mtsOk ? imax(1, capItems / 3) : capItems);
+  const int n_rd = uni(L.n_rd);
+  if (lane == 0) L.wave_best[wave] = -1;
+  double wbest = MAX_DOUBLE; int wkey = 1 << 30;         // the wave's best item so far: cost, and candidate * 8 + transform order as the tie break
+  int cur = 0, nmts = 0;
+  const int16_t *org = org_tile(scratch, P);
+  for (int c0 = 0; c0 < n_rd; c0 += capCand) {
+    const int nA = imin(capCand, n_rd - c0);
+    // ---- A1
+    for (int i = wave; i < nA; i += NW) {
+      const int c = c0 + i, mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl), mip = mrl & MIPF;
+      int16_t *rec = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, P, wave, cur);
+      if (mip) wave_pred_mip(rec, w, h, mode, bd, wave, lane);
+      else {
+        Ipa ip; init_pred_params(w, h, 1, mode, mrl, ip);
+        const int set = luma_set(mrl, ip.ref_filter), dcv = L.dc_val[luma_set(mrl, 0)];
+        const int16_t *top = L.refs[set][0], *left = L.refs[set][1];
+        for (int e = lane; e < P; e += 64) { const int py = e >> ilog2i(w), px = e & (w - 1); rec[e] = (int16_t) pred_sample(top, left, w, h, px, py, ip, mode, 1, bd, dcv); }
+      }
+      wave_sync();
+      for (int e = lane; e < P; e += 64) poolPred[(size_t) i * P + e] = rec[e];
+      unsigned long long sse; int cbf, sum0 = 0;
+      wave_code_block<SMALL, true>(org, 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf, -2, &sum0);
+      for (int e = lane; e < P; e += 64) poolCoef[(size_t) i * P + e] = lev[e];
+      if (lane == 0) { recA[i].sum0 = sum0; recA[i].test = 0; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, 0, wave, lane);
+    __threadfence_block();
+    __syncthreads();
+    // ---- A3
+    for (int i = wave; i < nA; i += NW) {
+      const int c = c0 + i, mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
+      int16_t *rec = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, P, wave, cur);
+      for (int e = lane; e < P; e += 64) { rec[e] = poolPred[(size_t) i * P + e]; lev[e] = poolCoef[(size_t) i * P + e]; }
+      wave_sync();
+      const int cbf = uni(L.dq_abs[i]) > 0;
+      unsigned long long sse; int cbf2;
+      wave_code_block<SMALL>(org, 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf2, cbf);
+      { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s[e]; }
+      wave_sync();
+      double cost = 0;
+      Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
+      if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, mrl); enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[0]); if (cbf && mtsOk) enc_mts_idx(cb, 0); }
+      if (cbf) residual_coding_wave<SMALL>(cb, 0, lev, w, h, 0, lane, 0);
+      if (lane == 0) { cost = rd_cost(p, cb.bits, sse); recA[i].cost = cost; recA[i].dist = sse; recA[i].bits = cb.bits; recA[i].cbf = cbf; recA[i].wave = wave; }
+      cost = lane0_d(cost);
+      if (cost < wbest || (cost == wbest && c * 8 < wkey)) {
+        wbest = cost; wkey = c * 8;
+        if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = SMALL ? 1 : cur; }
+        if (SMALL) { int16_t *pr = slot_rec(scratch, P, wave, 1), *pl = slot_lev(scratch, P, wave, 1); for (int e = lane; e < P; e += 64) { pr[e] = rec[e]; pl[e] = lev[e]; } }
+        else cur ^= 1;
+        { uint32_t *d = (uint32_t *) ctx_ptr(scratch, CTX_START, MAXD + wave, 0); const uint32_t *s = (const uint32_t *) &L.ctxs[CI_W(wave)]; for (int e = lane; e < NCTX; e += 64) d[e] = s[e]; }
+      }
+      wave_sync();
+      if (mtsOk && cbf) {                                  // TrQuant::transformNxN 1049-1124: which of the explicit MTS pairs stay, by their sums of absolute coefficients
+        int16_t *pr = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur);
+        for (int e = lane; e < P; e += 64) pr[e] = poolPred[(size_t) i * P + e];
+        wave_sync();
+        int sums[5]; sums[0] = recA[i].sum0;
+        for (int q = 1; q < 5; q++) sums[q] = wave_fwd_sumabs<SMALL>(org, pr, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, q + 1, lane);
+        const int ls = imax(ilog2i(w), ilog2i(h)) - 2;
+        const double fac = ls == 0 ? 1.2 : ls <= 2 ? 1.3 : ls == 3 ? 1.4 : 1.5;
+        const double thr = fac * (double) sums[0], thrTS = (double) sums[0];
+        int numTests = 0; unsigned test = 0;
+        for (int q = 0; q < 5; q++) { const int t = (double) sums[q] <= (q == 1 ? thrTS : thr) && numTests <= 3; test |= (unsigned) t << q; numTests += t; }
+        if (lane == 0) recA[i].test = (int) (test & 0x1e);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- the (candidate, MTS pair) items of this chunk, candidate by candidate in transform order; every thread builds the same list
+    uint8_t *pi_ = L.rb_pairs;
+    if (threadIdx.x == 0) {
+      int n = 0;
+      for (int i = 0; i < nA; i++) { const int t = recA[i].test; for (int k = 1; k < 5; k++) if (((t >> k) & 1) && n < VXD_POOL_ITEMS) pi_[n++] = (uint8_t) ((i << 3) | k); }
+      L.rb_nb = n;
+    }
+    __syncthreads();
+    const int nB = uni(L.rb_nb);
+    if (nB) {
+      // ---- B1
+      for (int j = wave; j < nB; j += NW) {
+        const int i = uni((int) pi_[j] >> 3), k = uni((int) pi_[j] & 7);
+        int16_t *rec = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, P, wave, cur);
+        for (int e = lane; e < P; e += 64) rec[e] = poolPred[(size_t) i * P + e];
+        wave_sync();
+        unsigned long long sse; int cbf;
+        wave_code_block_mts<SMALL>(org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, k + 1, lane, sse, cbf, -2);
+        for (int e = lane; e < P; e += 64) poolCoef[(size_t) j * P + e] = lev[e];
+      }
+      __threadfence_block();
+      __syncthreads();
+      dq_trellis_phase<SMALL>(scratch, nB, P, total, w, h, 1, wave, lane);
+      __threadfence_block();
+      __syncthreads();
+      // ---- B3
+      for (int j = wave; j < nB; j += NW) {
+        const int i = uni((int) pi_[j] >> 3), k = uni((int) pi_[j] & 7);
+        const int c = c0 + i, mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl), mts = k + 1;
+        nmts++;
+        const int cbf = uni(L.dq_abs[j]) > 0;
+        if (lane == 0) { recB[j].cost = MAX_DOUBLE; recB[j].cbf = cbf; recB[j].wave = wave; }
+        if (!cbf) continue;                                 // an MTS index is not coded for a zero block: forbidden
+        int16_t *rec = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, P, wave, cur);
+        for (int e = lane; e < P; e += 64) { rec[e] = poolPred[(size_t) i * P + e]; lev[e] = poolCoef[(size_t) j * P + e]; }
+        wave_sync();
+        unsigned long long sse; int cbf2;
+        wave_code_block_mts<SMALL>(org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, mts, lane, sse, cbf2, 1);
+        { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s[e]; }
+        wave_sync();
+        double cost = 0;
+        Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
+        if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, mrl); enc_bin(cb, 1u, VX_CTX_QtCbf[0]); enc_mts_idx(cb, mts); }
+        residual_coding_wave<SMALL>(cb, 0, lev, w, h, 0, lane, 1);
+        if (lane == 0) { cost = rd_cost(p, cb.bits, sse); recB[j].cost = cost; recB[j].dist = sse; recB[j].bits = cb.bits; }
+        cost = lane0_d(cost);
+        if (cost < wbest || (cost == wbest && c * 8 + k < wkey)) {
+          wbest = cost; wkey = c * 8 + k;
+          if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = SMALL ? 1 : cur; }
+          if (SMALL) { int16_t *pr = slot_rec(scratch, P, wave, 1), *pl = slot_lev(scratch, P, wave, 1); for (int e = lane; e < P; e += 64) { pr[e] = rec[e]; pl[e] = lev[e]; } }
+          else cur ^= 1;
+          { uint32_t *d = (uint32_t *) ctx_ptr(scratch, CTX_START, MAXD + wave, 0); const uint32_t *s = (const uint32_t *) &L.ctxs[CI_W(wave)]; for (int e = lane; e < NCTX; e += 64) d[e] = s[e]; }
+        }
+        wave_sync();
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    // ---- per candidate: DCT-II, then its MTS items in transform order, strict < (xRecurIntraCodingLumaQT 3579-3616)
+    if ((int) threadIdx.x < nA) {
+      const int i = threadIdx.x, c = c0 + i;
+      double bc = recA[i].cost; uint64_t bd_ = recA[i].dist, bb = recA[i].bits; int bcbf = recA[i].cbf, bm = 0, bw = recA[i].wave;
+      for (int j = 0; j < nB; j++) if ((pi_[j] >> 3) == i) { const double v = recB[j].cost; if (v < bc) { bc = v; bd_ = recB[j].dist; bb = recB[j].bits; bcbf = 1; bm = (pi_[j] & 7) + 1; bw = recB[j].wave; } }
+      L.rd_cost[c] = bc; L.rd_dist[c] = bd_; L.rd_bits[c] = bb; L.rd_cbf[c] = (uint8_t) bcbf; L.rd_mts[c] = (uint8_t) bm; L.rd_wave[c] = (uint8_t) bw;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) L.mts_evals[wave] = nmts;
+}
 __device__ __noinline__ void op_stage_b(const VxParams &p_, uint8_t *scratch)
 {
   const VxParams &p = L.par; (void) p_;
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int w = uni(L.nw), h = uni(L.nh);
-  if (uni(p.tools & TOOL_MTS)) { if (w * h <= BUF) stage_b_loop_mts<true>(p, scratch, wave, lane, w, h); else stage_b_loop_mts<false>(p, scratch, wave, lane, w, h); }
+  if (uni(p.tools & TOOL_DEPQUANT)) { if (w * h <= BUF) stage_b_rounds<true>(scratch, wave, lane, w, h); else stage_b_rounds<false>(scratch, wave, lane, w, h); }
+  else if (uni(p.tools & TOOL_MTS)) { if (w * h <= BUF) stage_b_loop_mts<true>(p, scratch, wave, lane, w, h); else stage_b_loop_mts<false>(p, scratch, wave, lane, w, h); }
   else if (w * h <= BUF) stage_b_loop<true, false>(p, scratch, wave, lane, w, h); else stage_b_loop<false, false>(p, scratch, wave, lane, w, h);
   __threadfence_block();
   __syncthreads();
@@ -2139,7 +2320,7 @@ __device__ __noinline__ void op_stage_b(const VxParams &p_, uint8_t *scratch)
   int best = 0; double bc = MAX_DOUBLE;
   for (int c = 0; c < n_rd; c++) { const double v = L.rd_cost[c]; if (v < bc) { bc = v; best = c; } }
   best = uni(best);
-  const int ww = best % NW;
+  const int ww = uni((int) L.rd_wave[best]);
   if (threadIdx.x == 0) { L.win_idx = best; L.win_wave = ww; L.cu_bits = L.rd_bits[best]; }
   ctx_copy_all(&L.ctxs[CI_W(0)], ctx_ptr(scratch, CTX_START, MAXD + ww, 0));
   __syncthreads();
@@ -2159,12 +2340,12 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
       const int mode = uni(L.rd[idx].mode);
       long long sum = 0;
       if (mode != LM_CHROMA && mode != PLANAR) {
-        int16_t *pred = SMALL ? L.slot[wave] : slot_rec(scratch, 2 * P, wave, 0);
+        int16_t *pred = SMALL ? L.wm[wave].slot : slot_rec(scratch, 2 * P, wave, 0);
         for (int k = 0; k < 2; k++) {
           chroma_pred_wave(pred, lmin, k, mode, w, h, bd, lane);
           wave_sync();
           unsigned long long sad, satd;
-          wave_sad_satd<SMALL>(org_tile(scratch, 2 * P), pred, SMALL ? (int16_t *) L.tmp[wave] : (int16_t *) wave_tmp(scratch, P >> 1, wave), w, h, lane, sad, satd, k * P, 0);
+          wave_sad_satd<SMALL>(org_tile(scratch, 2 * P), pred, SMALL ? (int16_t *) L.wm[wave].tmp : (int16_t *) wave_tmp(scratch, P >> 1, wave), w, h, lane, sad, satd, k * P, 0);
           sum += (long long) satd;
           wave_sync();
         }
@@ -2193,8 +2374,8 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
   for (int c = wave; c < n_rd; c += NW) {
     const int cm = uni(L.rd[c].mode);                 // chroma mode (70 = DM); final mode in .mrl field
     const int fm = uni(L.rd[c].mrl);
-    int16_t *recb = SMALL ? L.slot[wave] : slot_rec(scratch, 2 * P, wave, cur);
-    int16_t *levb = SMALL ? L.slot[wave] + BUF : slot_lev(scratch, 2 * P, wave, cur);
+    int16_t *recb = SMALL ? L.wm[wave].slot : slot_rec(scratch, 2 * P, wave, cur);
+    int16_t *levb = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, 2 * P, wave, cur);
     { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int i = lane; i < NCTX; i += 64) d[i] = s[i]; }
     wave_sync();
     unsigned long long dist = 0; int cbfs[2];
@@ -2320,7 +2501,7 @@ template <bool SMALL>
 __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch, int w, int h)
 {
   const int P = w * h, n = ch ? 2 * P : P, bd = p.bit_depth;
-  int16_t *recb = SMALL ? L.slot[0] : slot_rec(scratch, n, 0, 0), *levb = SMALL ? L.slot[0] + BUF : slot_lev(scratch, n, 0, 0);
+  int16_t *recb = SMALL ? L.wm[0].slot : slot_rec(scratch, n, 0, 0), *levb = SMALL ? L.wm[0].slot + BUF : slot_lev(scratch, n, 0, 0);
   const int mode = uni(L.rd[0].mode), fm = uni(L.rd[0].mrl), cbfm = uni(L.rd_cbf[0]);
   Cab cb; cb.ci = CI_W(0); cb.bits = 0;
   unsigned long long dist = 0;
@@ -2426,8 +2607,8 @@ __device__ __noinline__ void op_fast(const VxParams &p_, const VxFrameDev &fd_)
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int tid = threadIdx.x, wave = uni(tid >> 6), lane = tid & 63;
   const int x = uni(L.nx), y = uni(L.ny), w = uni(L.nw), h = uni(L.nh), P = w * h, lw = ilog2i(w);
-  uint8_t *px = (uint8_t *) &L.slot[0][0];
-  FaScratch &fa = *(FaScratch *) &L.tmp[0][0];
+  uint8_t *px = (uint8_t *) &L.wm[0];                                   // 4096 bytes of the (idle) per-wave buffers, the scratch behind them
+  FaScratch &fa = *(FaScratch *) ((uint8_t *) &L.wm[0] + 4096);
   const void *org = fd.org[0]; const int st = fd.stride[0];
   for (int i = tid; i < P; i += NT) px[i] = (uint8_t) sat8(ld_px<T>(org, (y + (i >> lw)) * st + x + (i & (w - 1))));
   __threadfence_block();
@@ -3330,12 +3511,12 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_dq_kernel(Vx
   const size_t b = (size_t) blockIdx.x * P;
   unsigned long long sse; int cbf;
   if (P <= BUF) {
-    for (int i = lane; i < P; i += 64) { L.org[i] = org[b + i]; L.slot[0][i] = rec[b + i]; }
+    for (int i = lane; i < P; i += 64) { L.org[i] = org[b + i]; L.wm[0].slot[i] = rec[b + i]; }
     wave_sync();
     if (mts > 1) wave_code_block_mts<true>(nullptr, nullptr, nullptr, nullptr, w, h, bd, qp, mts, lane, sse, cbf);
     else wave_code_block<true>(nullptr, 0, 0, nullptr, nullptr, nullptr, w, h, bd, qp, lane, sse, cbf, -1, nullptr, comp, CI_CUR, cbf_cb);
     wave_sync();
-    for (int i = lane; i < P; i += 64) { rec[b + i] = L.slot[0][i]; lev[b + i] = L.slot[0][BUF + i]; }
+    for (int i = lane; i < P; i += 64) { rec[b + i] = L.wm[0].slot[i]; lev[b + i] = L.wm[0].slot[BUF + i]; }
   } else if (mts > 1) wave_code_block_mts<false>(org + b, rec + b, lev + b, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, mts, lane, sse, cbf);
   else wave_code_block<false>(org + b, 0, 0, rec + b, lev + b, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, lane, sse, cbf, -1, nullptr, comp, CI_CUR, cbf_cb);
   if (lane == 0) { out[blockIdx.x * 2] = sse; out[blockIdx.x * 2 + 1] = (unsigned long long) cbf; }
