@@ -19,7 +19,10 @@
 //     coefficient when the winning path is walked back.
 #pragma once
 
-struct DqS { long long cost; int pk, rem; unsigned long long anc; unsigned lev[4]; unsigned tm[8]; };
+// 16 bytes / 16 half-words kept as scalar members (arrays indexed with a run-time value would be placed in scratch memory by the compiler)
+struct U4 { unsigned a, b, c, d; };
+struct U8 { unsigned a, b, c, d, e, f, g, h; };
+struct DqS { long long cost; int pk, rem; unsigned long long anc; U4 lev; U8 tm; };
 // pk: [0,5) non-zero levels of the path in the current group, [5,8) hist + 1 (state id of the path at the last group change), [8,10) Rice parameter,
 // [10,16) zero position of the bypass mode, [16,18) sig_coeff_group context + 1 (0: no bits), [18,22) sig_coeff_flag context increment,
 // [22,27) context increment of the gt1 / par / gt2 set
@@ -35,24 +38,42 @@ struct DqS { long long cost; int pk, rem; unsigned long long anc; unsigned lev[4
 #define DQ_GTXI(p) (((p) >> 22) & 31)
 __device__ inline int dq_put(int p, int sh, int nbits, int v) { const int m = ((1 << nbits) - 1) << sh; return (p & ~m) | ((v << sh) & m); }
 
-__device__ inline unsigned dq_get_b(const unsigned *a, int i) { const unsigned w = i < 8 ? (i < 4 ? a[0] : a[1]) : (i < 12 ? a[2] : a[3]); return (w >> ((i & 3) << 3)) & 255u; }
-__device__ inline void dq_set_b(unsigned *a, int i, unsigned v)
+// (the register barrier keeps the compiler from folding the selects into one load with a computed address, which would pin the struct in scratch memory)
+#ifndef VX_REG_BARRIER
+#define VX_REG_BARRIER(x) asm volatile("" : "+v"(x))
+#endif
+__device__ inline unsigned dq_get_b(const U4 &v, int i)
 {
-  const unsigned sh = (unsigned) (i & 3) << 3, m = ~(255u << sh); const int wi = i >> 2;
-#pragma unroll
-  for (int j = 0; j < 4; j++) if (wi == j) a[j] = (a[j] & m) | (v << sh);
+  unsigned a = v.a, b = v.b, c = v.c, d = v.d;
+  VX_REG_BARRIER(a); VX_REG_BARRIER(b); VX_REG_BARRIER(c); VX_REG_BARRIER(d);
+  const unsigned w = i < 8 ? (i < 4 ? a : b) : (i < 12 ? c : d);
+  return (w >> ((i & 3) << 3)) & 255u;
 }
-__device__ inline unsigned dq_get_h(const unsigned *a, int i)
+__device__ inline void dq_set_b(U4 &v, int i, unsigned x)
+{
+  const unsigned sh = (unsigned) (i & 3) << 3, m = ~(255u << sh), y = x << sh; const int wi = i >> 2;
+  v.a = wi == 0 ? (v.a & m) | y : v.a; v.b = wi == 1 ? (v.b & m) | y : v.b; v.c = wi == 2 ? (v.c & m) | y : v.c; v.d = wi == 3 ? (v.d & m) | y : v.d;
+}
+__device__ inline unsigned dq_get_h(const U8 &v, int i)
 {
   const int wi = i >> 1;
-  const unsigned w = wi < 4 ? (wi < 2 ? (wi == 0 ? a[0] : a[1]) : (wi == 2 ? a[2] : a[3])) : (wi < 6 ? (wi == 4 ? a[4] : a[5]) : (wi == 6 ? a[6] : a[7]));
+  unsigned a = v.a, b = v.b, c = v.c, d = v.d, e = v.e, f = v.f, g = v.g, h = v.h;
+  VX_REG_BARRIER(a); VX_REG_BARRIER(b); VX_REG_BARRIER(c); VX_REG_BARRIER(d); VX_REG_BARRIER(e); VX_REG_BARRIER(f); VX_REG_BARRIER(g); VX_REG_BARRIER(h);
+  const unsigned w = wi < 4 ? (wi < 2 ? (wi == 0 ? a : b) : (wi == 2 ? c : d)) : (wi < 6 ? (wi == 4 ? e : f) : (wi == 6 ? g : h));
   return (w >> ((i & 1) << 4)) & 0xffffu;
 }
-__device__ inline void dq_set_h(unsigned *a, int i, unsigned v)
+__device__ inline void dq_set_h(U8 &v, int i, unsigned x)
 {
-  const unsigned sh = (unsigned) (i & 1) << 4, m = ~(0xffffu << sh); const int wi = i >> 1;
-#pragma unroll
-  for (int j = 0; j < 8; j++) if (wi == j) a[j] = (a[j] & m) | (v << sh);
+  const unsigned sh = (unsigned) (i & 1) << 4, m = ~(0xffffu << sh), y = x << sh; const int wi = i >> 1;
+  v.a = wi == 0 ? (v.a & m) | y : v.a; v.b = wi == 1 ? (v.b & m) | y : v.b; v.c = wi == 2 ? (v.c & m) | y : v.c; v.d = wi == 3 ? (v.d & m) | y : v.d;
+  v.e = wi == 4 ? (v.e & m) | y : v.e; v.f = wi == 5 ? (v.f & m) | y : v.f; v.g = wi == 6 ? (v.g & m) | y : v.g; v.h = wi == 7 ? (v.h & m) | y : v.h;
+}
+__device__ inline U4 dq_shfl_u4(const U4 &v, int src) { U4 r; r.a = (unsigned) __shfl((int) v.a, src); r.b = (unsigned) __shfl((int) v.b, src); r.c = (unsigned) __shfl((int) v.c, src); r.d = (unsigned) __shfl((int) v.d, src); return r; }
+__device__ inline U8 dq_shfl_u8(const U8 &v, int src)
+{
+  U8 r; r.a = (unsigned) __shfl((int) v.a, src); r.b = (unsigned) __shfl((int) v.b, src); r.c = (unsigned) __shfl((int) v.c, src); r.d = (unsigned) __shfl((int) v.d, src);
+  r.e = (unsigned) __shfl((int) v.e, src); r.f = (unsigned) __shfl((int) v.f, src); r.g = (unsigned) __shfl((int) v.g, src); r.h = (unsigned) __shfl((int) v.h, src);
+  return r;
 }
 template <int CTRL> __device__ inline long long dq_quad_i64(long long v)
 {
@@ -171,15 +192,15 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   }
   wave_sync();
   const int regFull = (imin(32, effW) * imin(32, effH) * 28) >> 4;
-  DqS cur, prv, skp;
+  // The sub-block entry role (skp) is only ever read for its cost, counters and ancestors; when its object comes back into the rotation, what it still
+  // holds of levels / template sums is overwritten before an existing path reads it.  It is therefore kept as those members only.
+  struct DqK { long long cost; int pk, rem; unsigned long long anc; };
+  DqS cur, prv; DqK skp;
   {
     DqS s0; s0.cost = 0x7fffffffffffffffll >> 1; s0.rem = 4; s0.anc = 0;
     s0.pk = dq_put(0, 5, 3, 0);                             // hist -1, everything else 0 (sbbc -1: no bits)
-#pragma unroll
-    for (int i = 0; i < 4; i++) s0.lev[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) s0.tm[i] = 0;
-    cur = s0; prv = s0; skp = s0;
+    s0.lev = U4{ 0, 0, 0, 0 }; s0.tm = U8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+    cur = s0; prv = s0; skp.cost = s0.cost; skp.pk = s0.pk; skp.rem = s0.rem; skp.anc = 0;
   }
   long long decCost = 0x7fffffffffffffffll >> 2;
   int cnext = valid ? (int) cf[scan_blk(geo, top)] : 0;       // coefficient of the position about to be processed (fetched one position ahead)
@@ -261,34 +282,25 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
     if (eos || !zeroed) {
       // parent state (a previous state of the quad) — every lane shuffles, the lanes whose decision has no such parent discard the result
       const int srcLane = qbase + ((prevId >= 0 && prevId < 4) ? prevId : k);
-      DqS P;
+      struct { int pk, rem; unsigned long long anc; U4 lev; } P;
       P.pk = __shfl(prv.pk, srcLane); P.rem = __shfl(prv.rem, srcLane); P.anc = (unsigned long long) dq_shfl_i64((long long) prv.anc, srcLane);
-#pragma unroll
-      for (int i = 0; i < 4; i++) P.lev[i] = (unsigned) __shfl((int) prv.lev[i], srcLane);
-      if (!eos) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) P.tm[i] = (unsigned) __shfl((int) prv.tm[i], srcLane);
-      }
+      P.lev = dq_shfl_u4(prv.lev, srcLane);
       const bool alive = act && prevId > -2, fromPrev = prevId >= 0 && prevId < 4;
       if (act) cur.cost = dc;
       if (!eos) {                                           // State::updateState 1109-1273
+        // the template sums travel with the path; a lane without a parent in the quad starts from zeros (a path that does not exist never reads them)
+        { const U8 v = dq_shfl_u8(prv.tm, srcLane); if (alive) cur.tm = fromPrev ? v : U8{ 0, 0, 0, 0, 0, 0, 0, 0 }; }
         if (alive) {
           int pk = cur.pk;
           if (fromPrev) {
             pk = dq_put(pk, 0, 5, DQ_NUMSIG(P.pk) + (dlev != 0)); pk = dq_put(pk, 5, 3, DQ_HIST(P.pk) + 1); pk = dq_put(pk, 16, 2, DQ_SBBC(P.pk) + 1); pk = dq_put(pk, 8, 2, DQ_RPAR(P.pk));
             cur.rem = P.rem - 1; cur.anc = P.anc;
             if (cur.rem >= 4) cur.rem -= dlev < 2 ? dlev : 3;
-#pragma unroll
-            for (int i = 0; i < 4; i++) cur.lev[i] = P.lev[i];
-#pragma unroll
-            for (int i = 0; i < 8; i++) cur.tm[i] = P.tm[i];
+            cur.lev = P.lev;
           } else {
             pk = dq_put(pk, 0, 5, 1); pk = dq_put(pk, 5, 3, 0); cur.anc = 0;
             cur.rem = regFull - (dlev < 2 ? dlev : 3);
-#pragma unroll
-            for (int i = 0; i < 4; i++) cur.lev[i] = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) cur.tm[i] = 0;
+            cur.lev = U4{ 0, 0, 0, 0 };
           }
           dq_set_b(cur.lev, inside, (unsigned) imin(255, dlev));
           // template of the next position: its neighbours inside the group (m_scanId2NbInfoSbb) on top of the sums over those outside
@@ -313,14 +325,14 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
         }
       } else {                                              // State::updateStateEOS 1275-1315 + CommonCtx::update 1317-1398
         const int g = sp >> lcg;
-        int pk = cur.pk; int numSig, pRem; unsigned long long pAnc; unsigned lv[4];
-        if (prevId >= 4) { numSig = 0; pRem = skp.rem; pAnc = skp.anc; lv[0] = lv[1] = lv[2] = lv[3] = 0; }
-        else if (fromPrev) { numSig = DQ_NUMSIG(P.pk) + (dlev != 0); pRem = P.rem; pAnc = P.anc; lv[0] = P.lev[0]; lv[1] = P.lev[1]; lv[2] = P.lev[2]; lv[3] = P.lev[3]; }
-        else { numSig = 1; pRem = regFull; pAnc = 0; lv[0] = lv[1] = lv[2] = lv[3] = 0; }
+        int pk = cur.pk; int numSig, pRem; unsigned long long pAnc; U4 lv = { 0, 0, 0, 0 };
+        if (prevId >= 4) { numSig = 0; pRem = skp.rem; pAnc = skp.anc; }
+        else if (fromPrev) { numSig = DQ_NUMSIG(P.pk) + (dlev != 0); pRem = P.rem; pAnc = P.anc; lv = P.lev; }
+        else { numSig = 1; pRem = regFull; pAnc = 0; }
         dq_set_b(lv, 0, (unsigned) imin(255, imax(dlev, 0)));
         // the path as it leaves this group: field 0 = this state and the group's significance, the older groups one field up
         const unsigned long long anc = (pAnc << 4) | (unsigned long long) (unsigned) (k + 1) | ((numSig != 0) ? 8ull : 0ull);
-        if (alive) { uint32_t *hl = (uint32_t *) (nd + (size_t) (g * 4 + k) * 16); hl[0] = lv[0]; hl[1] = lv[1]; hl[2] = lv[2]; hl[3] = lv[3]; }
+        if (alive) { uint32_t *hl = (uint32_t *) (nd + (size_t) (g * 4 + k) * 16); hl[0] = lv.a; hl[1] = lv.b; hl[2] = lv.c; hl[3] = lv.d; }
         wave_sync();
         // the groups right of, below and diagonally below the next group: their distance in group-scan order picks the ancestor field
         const unsigned ng = geo.grp[g - 1]; const int nsx = (int) (ng & 15), nsy = (int) (ng >> 4);
@@ -330,13 +342,13 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
         const unsigned fD = gD >= 0 ? (unsigned) (anc >> (4 * (gD - g))) & 15u : 0u;
         const int sigN = ((fR & 8u) || (fB & 8u)) ? 1 : 0;
         // the three nodes (16 level bytes each) whose levels the next group's templates look at
-        unsigned nR[4] = { 0, 0, 0, 0 }, nB[4] = { 0, 0, 0, 0 }, nD[4] = { 0, 0, 0, 0 };
+        U4 nR = { 0, 0, 0, 0 }, nB = { 0, 0, 0, 0 }, nD = { 0, 0, 0, 0 };
         if (alive) {
-          if (fR & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gR * 4 + (int) (fR & 7u) - 1) * 16); nR[0] = p_[0]; nR[1] = p_[1]; nR[2] = p_[2]; nR[3] = p_[3]; }
-          if (fB & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gB * 4 + (int) (fB & 7u) - 1) * 16); nB[0] = p_[0]; nB[1] = p_[1]; nB[2] = p_[2]; nB[3] = p_[3]; }
-          if (fD & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gD * 4 + (int) (fD & 7u) - 1) * 16); nD[0] = p_[0]; nD[1] = p_[1]; nD[2] = p_[2]; nD[3] = p_[3]; }
+          if (fR & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gR * 4 + (int) (fR & 7u) - 1) * 16); nR.a = p_[0]; nR.b = p_[1]; nR.c = p_[2]; nR.d = p_[3]; }
+          if (fB & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gB * 4 + (int) (fB & 7u) - 1) * 16); nB.a = p_[0]; nB.b = p_[1]; nB.c = p_[2]; nB.d = p_[3]; }
+          if (fD & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gD * 4 + (int) (fD & 7u) - 1) * 16); nD.a = p_[0]; nD.b = p_[1]; nD.c = p_[2]; nD.d = p_[3]; }
         }
-        unsigned tmn[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        U8 tmn = { 0, 0, 0, 0, 0, 0, 0, 0 };
         for (int id = 0; id < gs; id++) {
           const int pb = scan_blk(geo, ((g - 1) << lcg) + id), px = pb & (w - 1), py = pb >> lw;
           int sumAbs = 0, sumAbs1 = 0, sumNum = 0, any = 0;
@@ -356,10 +368,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
         if (alive) {
           pk = dq_put(pk, 0, 5, 0); pk = dq_put(pk, 8, 2, 0); pk = dq_put(pk, 5, 3, k + 1); pk = dq_put(pk, 16, 2, sigN + 1);
           cur.rem = pRem; cur.anc = anc;
-#pragma unroll
-          for (int i = 0; i < 4; i++) cur.lev[i] = 0;
-#pragma unroll
-          for (int i = 0; i < 8; i++) cur.tm[i] = tmn[i];
+          cur.lev = U4{ 0, 0, 0, 0 }; cur.tm = tmn;
           const int t = (int) dq_get_h(cur.tm, nin);
           const int sumAbs1 = (t >> 3) & 31, sumNum = t & 7;
           pk = dq_put(pk, 18, 4, dq_sig_off(ch, diagN) + imin((sumAbs1 + 1) >> 1, 3)); pk = dq_put(pk, 22, 5, dq_gtx_off(ch, diagN) + imin(sumAbs1 - sumNum, 4));
@@ -367,7 +376,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
         }
       }
     }
-    if (spt == 1) { const DqS t = prv; prv = skp; skp = t; }
+    if (spt == 1) { const DqK t = skp; skp.cost = prv.cost; skp.pk = prv.pk; skp.rem = prv.rem; skp.anc = prv.anc; prv.cost = t.cost; prv.pk = t.pk; prv.rem = t.rem; prv.anc = t.anc; }
   }
   // ---- best final state and back-tracking (1709-1730), lane 0 of every quad for its item
   int prev = -2; long long minCost = 0;
@@ -408,7 +417,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
 template <bool SMALL>
 __device__ inline int wave_depquant(int16_t *cf_g, int buf_off, uint8_t *scratch, int ci, int w, int h, int comp, int cbf_ctx, int zo, int lfnst, int lane)
 {
-  const int wave_ = uni(threadIdx.x >> 6);
+  const int wave_ = uni(VTX >> 6);
   int16_t *cf = SMALL ? L.wm[wave_].slot + BUF + uni(buf_off) : cf_g;
   wave_depquant_batch(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, (uint8_t *) &L.wm[wave_].ws, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane);
   return uni(L.dq_abs[64 + wave_]);

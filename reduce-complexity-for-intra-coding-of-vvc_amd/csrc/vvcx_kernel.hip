@@ -22,6 +22,10 @@
 #include "vvcx_mip_dev.h"
 
 #define NT VXD_NT
+// Virtual thread index: the workgroup's wavefronts are rotated by a per-stream amount, so that the serial parts of a stream (the mode controller on thread 0,
+// the batched trellis on wave 0) do not all land on the same SIMD of a CU when its four resident streams run them (wave w of a workgroup sits on SIMD w).
+// Lanes keep their place inside the wavefront; every wave index in this file is the virtual one.
+#define VTX ((threadIdx.x + ((((unsigned) blockIdx.x * 0x9E3779B1u) >> 30) << 6)) & (unsigned) (VXD_NT - 1))
 #define NW VXD_NW
 #define MAXD VXD_MAXD
 #define BUF VXD_BUF
@@ -429,7 +433,7 @@ template <bool SMALL>
 __device__ __noinline__ RcPre rc_prepass_wave(int lev_off, const int16_t *coeff_g, int w, int h, int lane)
 {
   w = uni(w); h = uni(h);
-  const int16_t *coeff = SMALL ? L.wm[uni(threadIdx.x >> 6)].slot + BUF + uni(lev_off) : coeff_g;
+  const int16_t *coeff = SMALL ? L.wm[uni(VTX >> 6)].slot + BUF + uni(lev_off) : coeff_g;
   const ScanGeo g = scan_geo(w, h);
   int last = -1; unsigned long long sig = 0;
   const int gpi = 64 >> g.lcg;                           // groups per step
@@ -640,7 +644,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
   const int dq = uni((int) (L.par.tools & TOOL_DEPQUANT)) != 0;       // dep_quant_enabled_flag: the quantiser state picks the sig_coeff_flag context set and the bypass zero position
   int dqx = 0, dqy = 0;                                                 // state bits in front of lane 0 of the current 64 positions (see wave_dequant_dq)
   const long long q0 = STAMP();
-  const int16_t *coeff = SMALL ? L.wm[uni(threadIdx.x >> 6)].slot + BUF + uni(lev_off) : coeff_g;
+  const int16_t *coeff = SMALL ? L.wm[uni(VTX >> 6)].slot + BUF + uni(lev_off) : coeff_g;
   const RcPre pre = rc_prepass_wave<SMALL>(lev_off, coeff_g, w, h, lane);
   const int last = uni(pre.last);
   if (last < 0) return;
@@ -648,7 +652,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
   const ScanGeo geo = scan_geo(w, h);
   const long long q1 = STAMP();
   long long qe = 0, qc = 0;
-  const int wv = uni(threadIdx.x >> 6);
+  const int wv = uni(VTX >> 6);
   uint16_t *bb = L.wm[wv].ws.rc.binbuf; uint8_t *sorted = L.wm[wv].ws.rc.binsort;
   const int lcg = geo.lcg, cgSize = 1 << lcg;
   const int zw = imin(32, w), zh = imin(32, h), wg = geo.wg, hg = geo.hg;
@@ -759,7 +763,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
   const long long q3 = STAMP();
   const unsigned long long tot = wave_sum_u64(mybits);
   if (lane == 0) cb.bits += tot;
-  if (VVCX_STAMP && threadIdx.x == 0) { L.prof[32] += (unsigned long long) (q1 - q0); L.prof[34] += (unsigned long long) qe; L.prof[35] += (unsigned long long) qc; L.prof[36] += (unsigned long long) (STAMP() - q3); L.prof[37] += 1; }
+  if (VVCX_STAMP && VTX == 0) { L.prof[32] += (unsigned long long) (q1 - q0); L.prof[34] += (unsigned long long) qe; L.prof[35] += (unsigned long long) qc; L.prof[36] += (unsigned long long) (STAMP() - q3); L.prof[37] += 1; }
 }
 
 #include "vvcx_depquant_dev.h"
@@ -1165,7 +1169,7 @@ template <typename T>
 __device__ __noinline__ void build_refs(const VxParams &p_, const VxFrameDev &fd_, int comp, int x, int y, int w, int h, int tile, int nsets)
 {
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
-  const int tid = threadIdx.x;
+  const int tid = VTX;
   comp = uni(comp); x = uni(x); y = uni(y); w = uni(w); h = uni(h); tile = uni(tile); nsets = uni(nsets);
   const int ch = comp ? 1 : 0;
   const int unit = ch ? 2 : 4, ul = ch ? 1 : 2;
@@ -1315,7 +1319,7 @@ __device__ void cclm_params(const int16_t *in, int cw, int chh, int k, int mode,
 template <typename T>
 __device__ void cclm_prepare(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch, int cx, int cy, int cw, int chh)
 {
-  const int tid = threadIdx.x, P = cw * chh;
+  const int tid = VTX, P = cw * chh;
   const int totalLeft = chh, numLeft = chh >> 1, totalAbove = cw, numAbove = cw >> 1;       // units of 2 chroma samples
   if (tid == 0) {
     const int leftAvail = L.flags[totalLeft - numLeft], aboveAvail = L.flags[totalLeft + numAbove];
@@ -1460,7 +1464,7 @@ __device__ __noinline__ void wave_sad_satd(const int16_t *org_g, const int16_t *
                               unsigned long long &sad_out, unsigned long long &satd_out, int org_off = 0, int pred_off = 0)
 {
   w = uni(w); h = uni(h); org_off = uni(org_off); pred_off = uni(pred_off);       // offsets: second component of a chroma pair
-  const int wave_ = uni(threadIdx.x >> 6);
+  const int wave_ = uni(VTX >> 6);
   const int16_t *org = (SMALL ? L.org : org_g) + org_off, *pred = (SMALL ? L.wm[wave_].slot : pred_g) + pred_off;
   int16_t *scr = SMALL ? (int16_t *) L.wm[wave_].tmp : scr_g;
   const int P = w * h;
@@ -1506,7 +1510,7 @@ template <bool SMALL> __device__ inline const int8_t *dct2_matrix(int n)
 }
 __device__ void load_tables()
 {
-  const int tid = threadIdx.x;
+  const int tid = VTX;
   for (int i = tid; i < 512; i += NT) L.t.bin_frac[i] = VX_BIN_FRAC_BITS[i];
   for (int i = tid; i < NCTX; i += NT) L.t.ctx_rate[i] = VX_CTX_RATE[i];
   if (tid < 12) { L.t.qscale[tid] = VX_QUANT_SCALES[tid]; L.t.iqscale[tid] = VX_INV_QUANT_SCALES[tid]; }
@@ -1553,7 +1557,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   int coef_sum = 0;                                     // SUMABS: sum of |DCT-II coefficient| for the MTS pruning (TrQuant::transformNxN 1049-1124)
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given);
   const int dq = uni((int) (L.par.tools & TOOL_DEPQUANT)) != 0;
-  const int wave_ = uni(threadIdx.x >> 6);
+  const int wave_ = uni(VTX >> 6);
   const int16_t *org = (SMALL ? L.org : org_g) + uni(org_off);
   int16_t *rec = SMALL ? L.wm[wave_].slot + uni(buf_off) : rec_g, *lev = SMALL ? L.wm[wave_].slot + BUF + uni(buf_off) : lev_g;
   int32_t *tmp = SMALL ? L.wm[wave_].tmp : tmp_g;
@@ -1679,7 +1683,7 @@ template <bool SMALL>
 __device__ __noinline__ int wave_fwd_sumabs(const int16_t *org_g, const int16_t *pred_g, int32_t *tmp_g, int w, int h, int bd, int mts, int lane)
 {
   w = uni(w); h = uni(h); bd = uni(bd); mts = uni(mts);
-  const int wave_ = uni(threadIdx.x >> 6);
+  const int wave_ = uni(VTX >> 6);
   const int16_t *org = SMALL ? L.org : org_g, *pred = SMALL ? L.wm[wave_].slot : pred_g;
   int32_t *tmp = SMALL ? L.wm[wave_].tmp : tmp_g;
   int trh, trv; mts_types(mts, trh, trv);
@@ -1717,7 +1721,7 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
 {
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given); mts = uni(mts);
   const int dq = uni((int) (L.par.tools & TOOL_DEPQUANT)) != 0;        // luma only: the rate terms come from the node's start contexts (CI_CUR)
-  const int wave_ = uni(threadIdx.x >> 6);
+  const int wave_ = uni(VTX >> 6);
   const int16_t *org = SMALL ? L.org : org_g;
   int16_t *rec = SMALL ? L.wm[wave_].slot : rec_g, *lev = SMALL ? L.wm[wave_].slot + BUF : lev_g;
   int32_t *tmp = SMALL ? L.wm[wave_].tmp : tmp_g;
@@ -1835,7 +1839,7 @@ __device__ inline int32_t *wave_tmp(uint8_t *scratch, int n_i32, int wave)
 __device__ void ctx_copy_all(Ctx *dst, const Ctx *src)
 {
   uint32_t *d = (uint32_t *) dst; const uint32_t *s = (const uint32_t *) src;
-  for (int i = threadIdx.x; i < NCTX; i += NT) d[i] = s[i];       // s0 and s1 are 2*NCTX uint16 = NCTX uint32
+  for (int i = VTX; i < NCTX; i += NT) d[i] = s[i];       // s0 and s1 are 2*NCTX uint16 = NCTX uint32
 }
 __device__ Ctx *ctx_ptr(uint8_t *scratch, int which, int d, int wave)
 {
@@ -1853,15 +1857,15 @@ __device__ __noinline__ void op_luma_prep(const VxParams &p_, const VxFrameDev &
   const long long ts = STAMP();
   const void *org = fd.org[0]; const int st = fd.stride[0];
   int16_t *ot = org_tile(p.scratch + (size_t) blockIdx.x * p.scratch_per_stream, w * h);
-  for (int i = threadIdx.x; i < w * h; i += NT) { const int r = i >> ilog2i(w), c = i & (w - 1); ot[i] = (int16_t) ld_px<T>(org, (y + r) * st + x + c); }
+  for (int i = VTX; i < w * h; i += NT) { const int r = i >> ilog2i(w), c = i & (w - 1); ot[i] = (int16_t) ld_px<T>(org, (y + r) * st + x + c); }
   const int nsets = ((y & 127) == 0 || !(p.tools & 1)) ? 1 : 3;
   build_refs<T>(p, fd, 0, x, y, w, h, uni(L.cur_tile), nsets);
-  if (threadIdx.x < 4) {
-    const int s = threadIdx.x;           // dc per set (filtered set never used for DC)
+  if (VTX < 4) {
+    const int s = VTX;           // dc per set (filtered set never used for DC)
     if (s != 1 && (s == 0 || nsets == 3)) L.dc_val[s] = dc_value(L.refs[s][0], L.refs[s][1], w, h, s == 0 ? 0 : s == 2 ? 1 : 3);
   }
   __syncthreads();
-  if (VVCX_STAMP && threadIdx.x == 0) L.prof[14] += (unsigned long long) (STAMP() - ts);
+  if (VVCX_STAMP && VTX == 0) L.prof[14] += (unsigned long long) (STAMP() - ts);
 }
 __device__ inline int luma_set(int mrl, int filt) { return mrl == 0 ? (filt ? 1 : 0) : (mrl == 1 ? 2 : 3); }
 
@@ -1985,7 +1989,7 @@ __device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     const long long tb = STAMP();
     unsigned long long sad, satd;
     wave_sad_satd<SMALL>(org_tile(scratch, P), pred, scr, w, h, lane, sad, satd);
-    if (VVCX_STAMP && threadIdx.x == 0) { const long long tc = STAMP(); L.prof[15] += (unsigned long long) (tb - ta); L.prof[11] += (unsigned long long) (tc - tb); }
+    if (VVCX_STAMP && VTX == 0) { const long long tc = STAMP(); L.prof[15] += (unsigned long long) (tb - ta); L.prof[11] += (unsigned long long) (tc - tb); }
     if (lane == step) {
       const unsigned long long msh = sad * 2 < satd ? sad * 2 : satd;
       const double a = (double) mbits * p.sqrt_lambda_fp;
@@ -1999,7 +2003,7 @@ __device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int 
 __device__ __noinline__ void op_stage_a(const VxParams &p_, uint8_t *scratch)
 {
   const VxParams &p = L.par; (void) p_;
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wave = uni(VTX >> 6), lane = VTX & 63;
   const int w = uni(L.nw), h = uni(L.nh), P = w * h;
   const int c_end = uni(L.op_b);
   if (uni(L.op_c) == 2) {                                  // the MIP candidates: costs only, the control step merges them into the list
@@ -2007,7 +2011,7 @@ __device__ __noinline__ void op_stage_a(const VxParams &p_, uint8_t *scratch)
     __syncthreads();
     return;
   }
-  { const int c = uni(L.op_a) + (int) threadIdx.x; if (c < c_end) { Ipa ip; init_pred_params(w, h, 1, L.cand[c].mode, L.cand[c].mrl, ip); L.cand_ipa[c] = ipa_pack(ip); } }
+  { const int c = uni(L.op_a) + (int) VTX; if (c < c_end) { Ipa ip; init_pred_params(w, h, 1, L.cand[c].mode, L.cand[c].mrl, ip); L.cand_ipa[c] = ipa_pack(ip); } }
   __syncthreads();
   if (P <= 32) {
     if (w == 4 && h == 4) stage_a_small<4, 4>(p, wave, lane, uni(L.op_a), c_end);
@@ -2023,7 +2027,7 @@ __device__ __noinline__ void op_stage_a(const VxParams &p_, uint8_t *scratch)
     const int n1 = uni(L.n_cand), n2 = c_end, numRd = uni(L.S.numRd);
     const int first_phase = uni(L.op_c);
     const int n = first_phase ? 35 : n2;
-    const int c = threadIdx.x;
+    const int c = VTX;
     if (c < n) {
       const double mine = L.cand_cost[c];
       const int myseq = c < 35 ? c : (c < n1 ? 1000 + c : 500 + c);
@@ -2116,7 +2120,7 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     }
     if (uni(cbf)) residual_coding_wave<SMALL>(cb, 0, lev, w, h, 0, lane, mts > 1);
     if (lane == 0) cost = rd_cost(p, cb.bits, sse);
-    if (VVCX_STAMP && threadIdx.x == 0) { const long long tb3 = STAMP(); L.prof[28] += (unsigned long long) (tb1 - tb0); L.prof[29] += (unsigned long long) (tb2 - tb1); L.prof[31] += (unsigned long long) (tb3 - tb2); }
+    if (VVCX_STAMP && VTX == 0) { const long long tb3 = STAMP(); L.prof[28] += (unsigned long long) (tb1 - tb0); L.prof[29] += (unsigned long long) (tb2 - tb1); L.prof[31] += (unsigned long long) (tb3 - tb2); }
     cost = lane0_d(cost);
     if (cost < mbest) {
       mbest = cost;
@@ -2172,6 +2176,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
   const int16_t *org = org_tile(scratch, P);
   for (int c0 = 0; c0 < n_rd; c0 += capCand) {
     const int nA = imin(capCand, n_rd - c0);
+    const long long q0 = STAMP();
     // ---- A1
     for (int i = wave; i < nA; i += NW) {
       const int c = c0 + i, mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl), mip = mrl & MIPF;
@@ -2192,9 +2197,11 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
     }
     __threadfence_block();
     __syncthreads();
+    const long long q1 = STAMP();
     dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, 0, wave, lane);
     __threadfence_block();
     __syncthreads();
+    const long long q2 = STAMP();
     // ---- A3
     for (int i = wave; i < nA; i += NW) {
       const int c = c0 + i, mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
@@ -2237,8 +2244,9 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
     __threadfence_block();
     __syncthreads();
     // ---- the (candidate, MTS pair) items of this chunk, candidate by candidate in transform order; every thread builds the same list
+    const long long q3 = STAMP();
     uint8_t *pi_ = L.rb_pairs;
-    if (threadIdx.x == 0) {
+    if (VTX == 0) {
       int n = 0;
       for (int i = 0; i < nA; i++) { const int t = recA[i].test; for (int k = 1; k < 5; k++) if (((t >> k) & 1) && n < VXD_POOL_ITEMS) pi_[n++] = (uint8_t) ((i << 3) | k); }
       L.rb_nb = n;
@@ -2258,9 +2266,11 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       }
       __threadfence_block();
       __syncthreads();
+      const long long q4 = STAMP();
       dq_trellis_phase<SMALL>(scratch, nB, P, total, w, h, 1, wave, lane);
       __threadfence_block();
       __syncthreads();
+      if (VVCX_STAMP && VTX == 0) { L.prof[42] += (unsigned long long) (q4 - q3); L.prof[43] += (unsigned long long) (STAMP() - q4); L.prof[46] += (unsigned long long) nB; }
       // ---- B3
       for (int j = wave; j < nB; j += NW) {
         const int i = uni((int) pi_[j] >> 3), k = uni((int) pi_[j] & 7);
@@ -2294,9 +2304,10 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       __threadfence_block();
       __syncthreads();
     }
+    if (VVCX_STAMP && VTX == 0) { L.prof[38] += (unsigned long long) (q1 - q0); L.prof[39] += (unsigned long long) (q2 - q1); L.prof[40] += (unsigned long long) (q3 - q2); L.prof[41] += (unsigned long long) (STAMP() - q3); L.prof[44] += 1; L.prof[45] += (unsigned long long) nA; }
     // ---- per candidate: DCT-II, then its MTS items in transform order, strict < (xRecurIntraCodingLumaQT 3579-3616)
-    if ((int) threadIdx.x < nA) {
-      const int i = threadIdx.x, c = c0 + i;
+    if ((int) VTX < nA) {
+      const int i = VTX, c = c0 + i;
       double bc = recA[i].cost; uint64_t bd_ = recA[i].dist, bb = recA[i].bits; int bcbf = recA[i].cbf, bm = 0, bw = recA[i].wave;
       for (int j = 0; j < nB; j++) if ((pi_[j] >> 3) == i) { const double v = recB[j].cost; if (v < bc) { bc = v; bd_ = recB[j].dist; bb = recB[j].bits; bcbf = 1; bm = (pi_[j] & 7) + 1; bw = recB[j].wave; } }
       L.rd_cost[c] = bc; L.rd_dist[c] = bd_; L.rd_bits[c] = bb; L.rd_cbf[c] = (uint8_t) bcbf; L.rd_mts[c] = (uint8_t) bm; L.rd_wave[c] = (uint8_t) bw;
@@ -2308,7 +2319,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
 __device__ __noinline__ void op_stage_b(const VxParams &p_, uint8_t *scratch)
 {
   const VxParams &p = L.par; (void) p_;
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wave = uni(VTX >> 6), lane = VTX & 63;
   const int w = uni(L.nw), h = uni(L.nh);
   if (uni(p.tools & TOOL_DEPQUANT)) { if (w * h <= BUF) stage_b_rounds<true>(scratch, wave, lane, w, h); else stage_b_rounds<false>(scratch, wave, lane, w, h); }
   else if (uni(p.tools & TOOL_MTS)) { if (w * h <= BUF) stage_b_loop_mts<true>(p, scratch, wave, lane, w, h); else stage_b_loop_mts<false>(p, scratch, wave, lane, w, h); }
@@ -2321,11 +2332,12 @@ __device__ __noinline__ void op_stage_b(const VxParams &p_, uint8_t *scratch)
   for (int c = 0; c < n_rd; c++) { const double v = L.rd_cost[c]; if (v < bc) { bc = v; best = c; } }
   best = uni(best);
   const int ww = uni((int) L.rd_wave[best]);
-  if (threadIdx.x == 0) { L.win_idx = best; L.win_wave = ww; L.cu_bits = L.rd_bits[best]; }
+  if (VTX == 0) { L.win_idx = best; L.win_wave = ww; L.cu_bits = L.rd_bits[best]; }
   ctx_copy_all(&L.ctxs[CI_W(0)], ctx_ptr(scratch, CTX_START, MAXD + ww, 0));
   __syncthreads();
 }
 
+template <bool SMALL> __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int lane, int w, int h);
 // OP_CHROMA_RD: estIntraPredChromaQT 1382-1686 + xRecurIntraChromaCodingQT 3779-4207 (CCLM / JointCbCr off):
 // one wave per chroma mode, Cb then Cr; winner kept per wave like stage B.
 template <bool SMALL>
@@ -2354,7 +2366,7 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
     }
     __threadfence_block();
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (VTX == 0) {
       int list[7]; long long cost[7]; int ns = 0;
       for (int i = 0; i < 7; i++) { list[i] = L.rd[i].mode; cost[i] = L.lm_cost[i]; ns += list[i] != LM_CHROMA && list[i] != PLANAR; }
       for (int i = 0; i < 7; i++) for (int j = i + 1; j < 7; j++) if (cost[j] < cost[i]) {
@@ -2367,6 +2379,7 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
     }
     __syncthreads();
   }
+  if (uni((int) (p.tools & TOOL_DEPQUANT))) { chroma_rd_rounds<SMALL>(scratch, wave, lane, w, h); return; }      // the trellis quantiser: candidates in rounds
   if (lane == 0) L.wave_best[wave] = -1;
   double wbest = MAX_DOUBLE;
   int cur = 0;
@@ -2419,19 +2432,129 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
     wave_sync();
   }
 }
+// The RD loop of the chroma search with the dependent quantiser, in rounds like stage_b_rounds (all threads; the SATD pre-selection has run):
+//   C1  per mode (one wave each): Cb and Cr prediction -> prediction pool, forward DCT-II of both -> coefficient pool
+//   C2  the Cb trellises of all modes side by side (they all start from the node's contexts)
+//   C3  four modes at a time, one per wave: Cb reconstruction and rate (the wave's contexts advance), then the Cr trellises of the four modes in one wavefront
+//       (each from its wave's contexts and with its own tu.cbf[Cb]), then Cr reconstruction, rate and the mode's cost.
+template <bool SMALL>
+__device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int lane, int w, int h)
+{
+  const VxParams &p = L.par;
+  const int P = w * h, bd = p.bit_depth, total = imin(32, w) * imin(32, h);
+  const int16_t *lmin = lm_in_buf(scratch, 2 * P);
+  const int16_t *org = org_tile(scratch, 2 * P);
+  int16_t *poolPred = (int16_t *) (scratch + VXD_OFF_POOL), *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF); uint8_t *poolNodes = scratch + VXD_OFF_POOL_NODES;
+  if (lane == 0) L.wave_best[wave] = -1;
+  double wbest = MAX_DOUBLE;
+  int cur = 0;
+  const int n_rd = uni(L.n_rd);
+  // ---- C1
+  for (int c = wave; c < n_rd; c += NW) {
+    const int fm = uni(L.rd[c].mrl);
+    int16_t *recb = SMALL ? L.wm[wave].slot : slot_rec(scratch, 2 * P, wave, cur), *levb = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, 2 * P, wave, cur);
+    for (int k = 0; k < 2; k++) {
+      int16_t *rec = recb + k * P, *lev = levb + k * P;
+      chroma_pred_wave(rec, lmin, k, fm, w, h, bd, lane);
+      wave_sync();
+      for (int e = lane; e < P; e += 64) poolPred[(size_t) (2 * c + k) * P + e] = rec[e];
+      unsigned long long sse; int cbf;
+      wave_code_block<SMALL>(org, k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[k], lane, sse, cbf, -2, nullptr, k + 1, CI_CUR, 0);
+      for (int e = lane; e < P; e += 64) poolCoef[(size_t) (2 * c + k) * P + e] = lev[e];
+      wave_sync();
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- C2: items 0, 2, 4, ... of the pool (stride 2P)
+  {
+    const int ipw = imin(16, (int) sizeof(WaveMem) / (80 + 2 * total));
+    for (int i0 = wave * ipw; i0 < n_rd; i0 += NW * ipw)
+      wave_depquant_batch(imin(ipw, n_rd - i0), poolCoef + (size_t) (2 * i0) * P, 2 * P, poolNodes + (size_t) (2 * i0) * 4 * total, 8 * total, (uint8_t *) &L.wm[wave], i0,
+                          CI_CUR, 0, VX_CTX_QtCbf[1], 0u, w, h, 1, 0, 0, lane);
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- C3
+  const bool crBatch = 4 * (80 + 2 * total) <= (int) (sizeof(WaveScratch) + sizeof(int32_t) * BUF);      // four Cr trellises fit wave 0's rate-estimator scratch + tmp
+  for (int c0 = 0; c0 < n_rd; c0 += NW) {
+    const int c = c0 + wave; const bool have = c < n_rd;
+    const int cm = have ? uni(L.rd[c].mode) : 0;
+    int16_t *recb = SMALL ? L.wm[wave].slot : slot_rec(scratch, 2 * P, wave, cur), *levb = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, 2 * P, wave, cur);
+    unsigned long long dist = 0; int cbfs[2] = { 0, 0 };
+    if (have) {
+      { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s_ = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s_[e]; }
+      for (int e = lane; e < P; e += 64) { recb[e] = poolPred[(size_t) (2 * c) * P + e]; levb[e] = poolCoef[(size_t) (2 * c) * P + e]; }
+      wave_sync();
+      cbfs[0] = uni(L.dq_abs[c]) > 0;
+      unsigned long long sse; int cbf2;
+      wave_code_block<SMALL>(org, 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[0], lane, sse, cbf2, cbfs[0], nullptr, 1, CI_W(wave), 0);
+      dist += (unsigned long long) (p.dist_weight[0] * (double) sse);
+      { Cab cb; cb.ci = CI_W(wave); cb.bits = 0; if (lane == 0) enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]); if (cbfs[0]) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane); }
+      wave_sync();
+      if (lane == 0) L.rb_pairs[wave] = (uint8_t) cbfs[0];
+    }
+    __threadfence_block();
+    __syncthreads();
+    {                                                       // Cr trellises of the modes c0 .. c0 + 3
+      const int n4 = imin(NW, n_rd - c0);
+      unsigned mask = 0; for (int i = 0; i < n4; i++) mask |= (unsigned) L.rb_pairs[i] << i;
+      if (crBatch) { if (wave == 0) wave_depquant_batch(n4, poolCoef + (size_t) (2 * c0 + 1) * P, 2 * P, poolNodes + (size_t) (2 * c0 + 1) * 4 * total, 8 * total, (uint8_t *) &L.wm[0].ws, c0,
+                                                        CI_W(0), 1, VX_CTX_QtCbf[2], mask, w, h, 2, 0, 0, lane); }
+      else if (have) wave_depquant_batch(1, poolCoef + (size_t) (2 * c + 1) * P, 0, poolNodes + (size_t) (2 * c + 1) * 4 * total, 0, (uint8_t *) &L.wm[wave].ws, c,
+                                         CI_W(wave), 0, VX_CTX_QtCbf[2], (unsigned) cbfs[0], w, h, 2, 0, 0, lane);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (have) {
+      int16_t *rec = recb + P, *lev = levb + P;
+      for (int e = lane; e < P; e += 64) { rec[e] = poolPred[(size_t) (2 * c + 1) * P + e]; lev[e] = poolCoef[(size_t) (2 * c + 1) * P + e]; }
+      wave_sync();
+      cbfs[1] = uni(L.dq_abs[c]) > 0;
+      unsigned long long sse; int cbf2;
+      wave_code_block<SMALL>(org, P, P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[1], lane, sse, cbf2, cbfs[1], nullptr, 2, CI_W(wave), cbfs[0]);
+      dist += (unsigned long long) (p.dist_weight[1] * (double) sse);
+      { Cab cb; cb.ci = CI_W(wave); cb.bits = 0; if (lane == 0) enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]); if (cbfs[1]) residual_coding_wave<SMALL>(cb, P, lev, w, h, 1, lane); }
+      wave_sync();
+      double cost = 0;
+      {                    // 1611-1621: contexts not reset; xGetIntraFracBitsQT(chroma)
+        Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
+        if (lane == 0) {
+          enc_intra_chroma_pred_mode(cb, cm, L.colm, L.lm_ok);
+          enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]);
+          enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]);
+        }
+        if (cbfs[0]) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane);
+        if (cbfs[1]) residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane);
+        if (lane == 0) {
+          cost = rd_cost(p, cb.bits, dist);
+          L.rd_cost[c] = cost; L.rd_dist[c] = dist; L.rd_cbf[c] = (uint8_t) ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 4 : 0));
+        }
+      }
+      cost = lane0_d(cost);
+      if (cost < wbest) {
+        wbest = cost;
+        if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = SMALL ? 1 : cur; }
+        if (SMALL) { int16_t *pr = slot_rec(scratch, 2 * P, wave, 1), *pl = slot_lev(scratch, 2 * P, wave, 1); for (int e = lane; e < 2 * P; e += 64) { pr[e] = recb[e]; pl[e] = levb[e]; } }
+        else cur ^= 1;
+      }
+      wave_sync();
+    }
+  }
+}
 template <typename T>
 __device__ __noinline__ void op_chroma_rd(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wave = uni(VTX >> 6), lane = VTX & 63;
   const int x = uni(L.nx) >> 1, y = uni(L.ny) >> 1, w = uni(L.nw) >> 1, h = uni(L.nh) >> 1, P = w * h;
   for (int c = 1; c <= 2; c++) {
     const void *org = fd.org[c]; const int st = fd.stride[c];
     int16_t *ot = org_tile(scratch, 2 * P);
-    for (int i = threadIdx.x; i < P; i += NT) { const int r = i >> ilog2i(w), cc = i & (w - 1); ot[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
+    for (int i = VTX; i < P; i += NT) { const int r = i >> ilog2i(w), cc = i & (w - 1); ot[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
     build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
   }
-  if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
+  if (VTX < 2) L.dc_val[VTX] = dc_value(L.refs[VTX][0], L.refs[VTX][1], w, h, 0);
   if (uni(L.lm_ok)) cclm_prepare<T>(p, fd, scratch, x, y, w, h);
   __syncthreads();
   if (2 * P <= BUF) chroma_rd_loop<true>(p, scratch, wave, lane, w, h); else chroma_rd_loop<false>(p, scratch, wave, lane, w, h);
@@ -2551,7 +2674,7 @@ template <typename T>
 __device__ __noinline__ void op_reuse(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wave = uni(VTX >> 6), lane = VTX & 63;
   const int ch = uni(L.tree_ch), bd = p.bit_depth;
   const int sh = ch ? 1 : 0;
   const int x = uni(L.nx) >> sh, y = uni(L.ny) >> sh, w = uni(L.nw) >> sh, h = uni(L.nh) >> sh, P = w * h, n = ch ? 2 * P : P;
@@ -2560,10 +2683,10 @@ __device__ __noinline__ void op_reuse(const VxParams &p_, const VxFrameDev &fd_,
     for (int c = 1; c <= 2; c++) {
       const void *org = fd.org[c]; const int st = fd.stride[c];
       int16_t *ot = org_tile(scratch, 2 * P);
-    for (int i = threadIdx.x; i < P; i += NT) { const int r = i >> ilog2i(w), cc = i & (w - 1); ot[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
+    for (int i = VTX; i < P; i += NT) { const int r = i >> ilog2i(w), cc = i & (w - 1); ot[(c - 1) * P + i] = (int16_t) ld_px<T>(org, (y + r) * st + x + cc); }
       build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
     }
-    if (threadIdx.x < 2) L.dc_val[threadIdx.x] = dc_value(L.refs[threadIdx.x][0], L.refs[threadIdx.x][1], w, h, 0);
+    if (VTX < 2) L.dc_val[VTX] = dc_value(L.refs[VTX][0], L.refs[VTX][1], w, h, 0);
     { const int fm = uni(L.rd[0].mrl); if (fm >= LM_CHROMA && fm <= MDLM_T) cclm_prepare<T>(p, fd, scratch, x, y, w, h); }
   }
   int16_t *levb = slot_lev(scratch, n, 0, 0);
@@ -2571,7 +2694,7 @@ __device__ __noinline__ void op_reuse(const VxParams &p_, const VxFrameDev &fd_,
     int lo;
     cache_slot(uni(L.nx), uni(L.ny), uni(L.nw), uni(L.nh), lo);
     const int16_t *cl = (const int16_t *) (scratch + VXD_OFF_CACHE_LEV) + uni(lo);
-    for (int i = threadIdx.x; i < n; i += NT) levb[i] = cl[i];
+    for (int i = VTX; i < n; i += NT) levb[i] = cl[i];
   }
   ctx_copy_all(&L.ctxs[CI_W(0)], &L.ctxs[CI_CUR]);
   __threadfence_block();
@@ -2605,7 +2728,7 @@ template <typename T>
 __device__ __noinline__ void op_fast(const VxParams &p_, const VxFrameDev &fd_)
 {
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
-  const int tid = threadIdx.x, wave = uni(tid >> 6), lane = tid & 63;
+  const int tid = VTX, wave = uni(tid >> 6), lane = tid & 63;
   const int x = uni(L.nx), y = uni(L.ny), w = uni(L.nw), h = uni(L.nh), P = w * h, lw = ilog2i(w);
   uint8_t *px = (uint8_t *) &L.wm[0];                                   // 4096 bytes of the (idle) per-wave buffers, the scratch behind them
   FaScratch &fa = *(FaScratch *) ((uint8_t *) &L.wm[0] + 4096);
@@ -2748,7 +2871,7 @@ __device__ __noinline__ void op_save_pic(const VxParams &p_, const VxFrameDev &f
     int16_t *srec = (int16_t *) lvl + k * (Wn * (L.nh >> sh)), *slev = (int16_t *) (lvl + VXD_STORE_REC) + k * (Wn * (L.nh >> sh));
     void *rec = fd.rec[comp]; int16_t *lev = fd.lev[comp]; const int st = fd.stride[comp], ls = fd.lstride[comp];
     const int lcw = pow2_log(cw);
-    for (int i = threadIdx.x; i < cw * chh; i += NT) {
+    for (int i = VTX; i < cw * chh; i += NT) {
       const int r = fast_div(i, cw, lcw), c = i - r * cw;
       if (restore) { st_px<T>(rec, (Y0 + r) * st + X0 + c, srec[r * Wn + c]); lev[(Y0 + r) * ls + X0 + c] = slev[r * Wn + c]; }
       else { srec[r * Wn + c] = (int16_t) ld_px<T>(rec, (Y0 + r) * st + X0 + c); slev[r * Wn + c] = lev[(Y0 + r) * ls + X0 + c]; }
@@ -2757,7 +2880,7 @@ __device__ __noinline__ void op_save_pic(const VxParams &p_, const VxFrameDev &f
   VxUnit *su = (VxUnit *) (lvl + 2 * VXD_STORE_REC);
   const int ux0 = L.nx >> 2, uy0 = L.ny >> 2, ucw = ((x1 + 3) >> 2) - ux0, uch = ((y1 + 3) >> 2) - uy0;
   const int lucw = pow2_log(ucw);
-  for (int i = threadIdx.x; i < ucw * uch; i += NT) {
+  for (int i = VTX; i < ucw * uch; i += NT) {
     const int r = fast_div(i, ucw, lucw), c = i - r * ucw;
     if (restore) fd.units[ch][(uy0 + r) * p.uw + ux0 + c] = su[r * 32 + c];
     else su[r * 32 + c] = fd.units[ch][(uy0 + r) * p.uw + ux0 + c];
@@ -2777,14 +2900,14 @@ __device__ __noinline__ void op_save_intra(const VxParams &p_, uint8_t *scratch,
   const int16_t *lev = slot_lev(scratch, ch ? 2 * P : P, wave, which);
   int16_t *srec = (int16_t *) lvl, *slev = (int16_t *) (lvl + VXD_STORE_REC);
   const int n = ch ? 2 * P : P;
-  for (int i = threadIdx.x; i < n; i += NT) { srec[i] = rec[i]; slev[i] = lev[i]; }
+  for (int i = VTX; i < n; i += NT) { srec[i] = rec[i]; slev[i] = lev[i]; }
   if ((p.tools & TOOL_CU_REUSE) && uni(L.op_c)) {      // setFromCs (939-985): the unsplit result is what tryMode(POST_DONT_SPLIT) caches right after
     int lo;
     const int e = uni(cache_slot(L.nx, L.ny, L.nw, L.nh, lo));
     if (e >= 0) {
       int16_t *cl = (int16_t *) (scratch + VXD_OFF_CACHE_LEV) + lo;
-      for (int i = threadIdx.x; i < n; i += NT) cl[i] = lev[i];
-      if (threadIdx.x == 0) {
+      for (int i = VTX; i < n; i += NT) cl[i] = lev[i];
+      if (VTX == 0) {
         VxCacheEnt c; c.ss = cu.ss; c.kind = (uint8_t) (ch + 1); c.dir = cu.dir; c.mrl = cu.mrl; c.cbf = cu.cbf; c.depth = cu.depth; c.mts = cu.mts; c.pad[0] = c.pad[1] = 0;
         ((VxCacheEnt *) (scratch + VXD_OFF_CACHE))[e] = c;
       }
@@ -2792,7 +2915,7 @@ __device__ __noinline__ void op_save_intra(const VxParams &p_, uint8_t *scratch,
   }
   VxUnit *su = (VxUnit *) (lvl + 2 * VXD_STORE_REC);
   const int ucw = (L.nw + 3) >> 2, uch = (L.nh + 3) >> 2;
-  for (int i = threadIdx.x; i < ucw * uch; i += NT) { const int r = i >> ilog2i(ucw); su[r * 32 + (i & (ucw - 1))] = cu; }      // unclipped node: power of two
+  for (int i = VTX; i < ucw * uch; i += NT) { const int r = i >> ilog2i(ucw); su[r * 32 + (i & (ucw - 1))] = cu; }      // unclipped node: power of two
   ctx_copy_all(ctx_ptr(scratch, CTX_BEST, d, 0), &L.ctxs[CI_W(0)]);
   __threadfence_block();
   __syncthreads();
@@ -2804,7 +2927,7 @@ __device__ __noinline__ void op_clear_units(const VxParams &p_, const VxFrameDev
   const int x1 = imin(L.nx + L.nw, p.pic_w), y1 = imin(L.ny + L.nh, p.pic_h);
   const int ux0 = L.nx >> 2, uy0 = L.ny >> 2, ucw = ((x1 + 3) >> 2) - ux0, uch = ((y1 + 3) >> 2) - uy0;
   const int lucw = pow2_log(ucw);
-  for (int i = threadIdx.x; i < ucw * uch; i += NT) { const int r = fast_div(i, ucw, lucw); fd.units[ch][(uy0 + r) * p.uw + ux0 + (i - r * ucw)].tag = 0; }
+  for (int i = VTX; i < ucw * uch; i += NT) { const int r = fast_div(i, ucw, lucw); fd.units[ch][(uy0 + r) * p.uw + ux0 + (i - r * ucw)].tag = 0; }
   __threadfence_block();
   __syncthreads();
 }
@@ -3362,7 +3485,7 @@ __device__ __noinline__ void writer_suspend(const VxParams &p, int sidx) { ((Ari
 // Out of line: run_tree's barrier loop must contain exactly one thread-0 section of its own (see there).
 __device__ __noinline__ void after_intra_op(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
-  if (threadIdx.x == 0) L.do_save = ctrl_b_done(p_, fd_);
+  if (VTX == 0) L.do_save = ctrl_b_done(p_, fd_);
   __threadfence_block();
   __syncthreads();
   if (uni(L.do_save)) op_save_intra(p_, scratch, L.cu);
@@ -3372,7 +3495,7 @@ template <typename T>
 __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
-  const int tid = threadIdx.x;
+  const int tid = VTX;
   // NOTE: exactly one thread-0 section per iteration.  With two (`if (tid == 0)` at the head and at the tail)
   // hipcc threads the "tid != 0" edges together and structurizes the result into an inner loop in which lanes
   // 1..63 of wave 0 reach the next s_barrier while lane 0 is still parked outside it: the barrier then
@@ -3383,7 +3506,9 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
       const long long t0 = STAMP();
       if (VVCX_STAMP) {
         L.prof[prev_op] += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first)
+#ifndef VVCX_STAMP_ROUNDS
         if (prev_op >= OP_LUMA_PREP && prev_op <= OP_CHROMA_RD) L.prof[38 + imin(9, imax(0, ilog2i(L.nw * L.nh) - 4))] += (unsigned long long) (t0 - t_prev);   // by node size
+#endif
       }
       L.pre_copy_d = -1;
       control_step(p, fd, scratch);
@@ -3417,11 +3542,11 @@ template <typename T>
 __device__ void run_stream(const VxParams &p)
 {
   const VxStreamDesc sd = p.streams[blockIdx.x];
-  if (threadIdx.x == 0) { L.par = p; L.fdv = p.frames[sd.frame]; }
+  if (VTX == 0) { L.par = p; L.fdv = p.frames[sd.frame]; }
   const VxFrameDev &fd = p.frames[sd.frame];
   uint8_t *scratch = p.scratch + (size_t) blockIdx.x * p.scratch_per_stream;
   Ctx *carry = (Ctx *) (p.stream_ctx + (size_t) (sd.frame * p.ntiles + sd.tile) * 2 * NCTX);
-  const int tid = threadIdx.x;
+  const int tid = VTX;
   if (tid == 0) {
     L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < 48; i++) L.prof[i] = 0;
     if (p.payload) writer_begin(p, sd.frame * p.ntiles + sd.tile, sd.done_before);
@@ -3475,7 +3600,7 @@ __device__ void run_stream(const VxParams &p)
 // function-pointer seams).  One workgroup per item; same code the CTU kernel runs.
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_dist_kernel(const int16_t *a, const int16_t *b, int w, int h, int16_t *scr, unsigned long long *out)
 {
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, P = w * h;
+  const int wave = uni(VTX >> 6), lane = VTX & 63, P = w * h;
   if (wave != 0) return;
   const int16_t *pa = a + (size_t) blockIdx.x * P, *pb = b + (size_t) blockIdx.x * P;
   unsigned long long sad, satd;
@@ -3491,7 +3616,7 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_trq_kernel(c
 {
   load_tables();
   __syncthreads();
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, P = w * h;
+  const int wave = uni(VTX >> 6), lane = VTX & 63, P = w * h;
   if (wave != 0) return;
   unsigned long long sse; int cbf;
   wave_code_block<false>(org + (size_t) blockIdx.x * P, 0, 0, rec + (size_t) blockIdx.x * P, lev + (size_t) blockIdx.x * P, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, lane, sse, cbf);
@@ -3502,11 +3627,11 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_trq_kernel(c
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_dq_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp,
                                                                               int w, int h, int qp, int comp, int mts, int cbf_cb, unsigned long long *out)
 {
-  if (threadIdx.x == 0) L.par = p;
+  if (VTX == 0) L.par = p;
   load_tables();
-  for (int i = threadIdx.x; i < NCTX; i += NT) { L.ctxs[CI_CUR].s0[i] = ctx[i]; L.ctxs[CI_CUR].s1[i] = ctx[NCTX + i]; }
+  for (int i = VTX; i < NCTX; i += NT) { L.ctxs[CI_CUR].s0[i] = ctx[i]; L.ctxs[CI_CUR].s1[i] = ctx[NCTX + i]; }
   __syncthreads();
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, P = w * h, bd = p.bit_depth;
+  const int wave = uni(VTX >> 6), lane = VTX & 63, P = w * h, bd = p.bit_depth;
   if (wave != 0) return;
   const size_t b = (size_t) blockIdx.x * P;
   unsigned long long sse; int cbf;
@@ -3526,15 +3651,15 @@ __device__ void leaf_pred(const VxParams &p, const VxLeafPred *cases, int16_t *o
 {
   const VxFrameDev &fd = p.frames[0];
   const VxLeafPred c = cases[blockIdx.x];
-  if (threadIdx.x == 0) { L.par = p; L.fdv = p.frames[0]; }
+  if (VTX == 0) { L.par = p; L.fdv = p.frames[0]; }
   load_tables();
-  if (threadIdx.x == 0) { L.cur_tile = 0; L.nx = c.x; L.ny = c.y; L.nw = c.w; L.nh = c.h; }
+  if (VTX == 0) { L.cur_tile = 0; L.nx = c.x; L.ny = c.y; L.nw = c.w; L.nh = c.h; }
   __syncthreads();
   const int luma = c.comp == 0;
   build_refs<T>(p, fd, c.comp, c.x, c.y, c.w, c.h, 0, luma ? 3 : 1);
   __syncthreads();
-  if (threadIdx.x < 4) {
-    const int s = threadIdx.x;
+  if (VTX < 4) {
+    const int s = VTX;
     if (luma ? s != 1 : s == c.comp - 1) L.dc_val[s] = dc_value(L.refs[s][0], L.refs[s][1], c.w, c.h, luma ? (s == 0 ? 0 : s == 2 ? 1 : 3) : 0);
   }
   __syncthreads();
@@ -3542,7 +3667,7 @@ __device__ void leaf_pred(const VxParams &p, const VxLeafPred *cases, int16_t *o
   const int set = luma ? luma_set(c.mrl, ip.ref_filter) : c.comp - 1;
   const int dcv = L.dc_val[luma ? luma_set(c.mrl, 0) : c.comp - 1];
   int16_t *o = out + out_off[blockIdx.x];
-  for (int i = threadIdx.x; i < c.w * c.h; i += NT) { const int py = i >> ilog2i(c.w), px = i & (c.w - 1); o[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], c.w, c.h, px, py, ip, c.mode, luma, p.bit_depth, dcv); }
+  for (int i = VTX; i < c.w * c.h; i += NT) { const int py = i >> ilog2i(c.w), px = i & (c.w - 1); o[i] = (int16_t) pred_sample(L.refs[set][0], L.refs[set][1], c.w, c.h, px, py, ip, c.mode, luma, p.bit_depth, dcv); }
 }
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_pred_kernel_u8(VxParams p, const VxLeafPred *cases, int16_t *out, const int *out_off) { leaf_pred<uint8_t>(p, cases, out, out_off); }
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_pred_kernel_u16(VxParams p, const VxLeafPred *cases, int16_t *out, const int *out_off) { leaf_pred<uint16_t>(p, cases, out, out_off); }
@@ -3551,7 +3676,7 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_cabac_kernel
 {
   load_tables();
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (VTX == 0) {
     L.ctxs[CI_CUR].s0[ctx] = io[0]; L.ctxs[CI_CUR].s1[ctx] = io[1];
     Cab cb; cb.ci = CI_CUR; cb.bits = 0;
     for (int i = 0; i < nbins; i++) enc_bin(cb, bins[i], ctx);
@@ -3560,7 +3685,7 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_cabac_kernel
 }
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_rdcost_kernel(VxParams p, const unsigned long long *bits, const unsigned long long *dist, int n, double *cost)
 {
-  const int i = blockIdx.x * NT + threadIdx.x;
+  const int i = blockIdx.x * NT + VTX;
   if (i < n) cost[i] = rd_cost(p, bits[i], dist[i]);
 }
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_scan_kernel(int w, int h, uint16_t *idx)
@@ -3568,13 +3693,13 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_scan_kernel(
   load_tables();
   __syncthreads();
   const ScanGeo g = scan_geo(w, h);
-  for (int sp = threadIdx.x; sp < g.nscan; sp += NT) idx[sp] = (uint16_t) scan_blk(g, sp);
+  for (int sp = VTX; sp < g.nscan; sp += NT) idx[sp] = (uint16_t) scan_blk(g, sp);
 }
 
 // forest inference on its own: one thread per feature row, trees in order (the sum order of OP_FAST and of sklearn's predict_proba)
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_forest_kernel(VxParams p, const int32_t *rows, int n, int32_t *out)
 {
-  const int i = blockIdx.x * NT + threadIdx.x;
+  const int i = blockIdx.x * NT + VTX;
   if (i >= n) return;
   double acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   for (int t = 0; t < p.f_ntrees; t++) {

@@ -22,6 +22,7 @@
 #define __launch_bounds__(...)
 #define __noinline__ __attribute__((noinline))
 #define __forceinline__ inline
+#define VX_REG_BARRIER(x) ((void) 0)      // device builds: an empty asm that keeps a value in a register (see csrc/vvcx_depquant_dev.h)
 
 struct uint2 { unsigned x, y; };
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };

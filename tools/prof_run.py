@@ -2,8 +2,8 @@ import sys, importlib, numpy as np, torch, time
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
 W,H=int(sys.argv[1]),int(sys.argv[2]); tc,tr=(W+127)//128,(H+127)//128
-sp=pkg.slice_params(32)
 import os
+sp=pkg.slice_params(32, dep_quant=bool(int(os.environ.get("VVCX_TOOLS","0x913"),0)&0x40))
 TOOLS=int(os.environ.get("VVCX_TOOLS","0x913"),0); TEX=float(os.environ.get("VVCX_TEX","0.5"))
 forest=pkg.load_forest("reduce-complexity-for-intra-coding-of-vvc_amd/forests/partition_qp32.npz") if TOOLS&0x1000 else None
 enc=pkg.VvcxEncoder(W,H,8,tile_cols=tc,tile_rows=tr,lib_path=os.environ.get("VVCX_LIB"),tools=TOOLS,forest=forest)
@@ -23,3 +23,5 @@ print("B wave0: pred %.3e code_block %.3e rate %.3e"%(pr[28],pr[29],pr[31]))
 print("rc wave0: prepass %.3e meta %.3e emit %.3e chain %.3e reduce %.3e calls %d"%(pr[32],pr[33],pr[34],pr[35],pr[36],pr[37]))
 print("steps",pr[30],"counters",enc.counters())
 print("search ops by luma node area (16,32,...,4096+):", ["%.2e" % v for v in pr[38:48]])
+if TOOLS & 0x40:
+    print("rounds (thread 0 clocks): A1 %.3e  A2 trellis %.3e  A3 %.3e  B total %.3e (B1 %.3e, B2 trellis %.3e)  chunks %d  cands %d  mts items %d" % (pr[38], pr[39], pr[40], pr[41], pr[42], pr[43], pr[44], pr[45], pr[46]))
