@@ -203,17 +203,43 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
     cur = s0; prv = s0; skp.cost = s0.cost; skp.pk = s0.pk; skp.rem = s0.rem; skp.anc = 0;
   }
   long long decCost = 0x7fffffffffffffffll >> 2;
-  int cnext = valid ? (int) cf[scan_blk(geo, top)] : 0;       // coefficient of the position about to be processed (fetched one position ahead)
-  for (int sp = top; sp >= 0; sp--) {
-    const int blk = scan_blk(geo, sp), x = blk & (w - 1), y = blk >> lw;
-    const int inside = sp & (gs - 1), eos = inside == 0;
-    int spt = 0;
-    if (inside == gs - 1 && sp > gs && sp < total - 1) spt = 1; else if (eos && sp > 0 && sp < total - gs) spt = 2;
-    const int zeroed = zeroOut && (x >= effW || y >= effH);
+  // What depends only on the scan position (the same for every item) is prepared for 64 positions at a time, one per lane, and read back with v_readlane:
+  //   pgA: raster offset [0,12), position inside its group [12,16), kind of position [16,18), zeroed by the MTS zero-out [18], last-position group
+  //        indices of x [19,23) and y [23,27)
+  //   pgB (about the position coded next): position inside its group [0,4), context offsets of its sig flag [4,8) and gt1/par/gt2 set [8,13), number of
+  //        template neighbours inside its group [13,16), raster offset [16,28);  pgC: those neighbours' places inside the group, 4 bits each
+  int cnext = 0;
+  for (int top64 = top; top64 >= 0; top64 -= 64) {
+  int pgA = 0, pgB = 0, pgC = 0;
+  {
+    const int sp = top64 - lane;
+    if (sp >= 0) {
+      const int blk = scan_blk(geo, sp), x = blk & (w - 1), y = blk >> lw, inside = sp & (gs - 1);
+      int spt = 0;
+      if (inside == gs - 1 && sp > gs && sp < total - 1) spt = 1; else if (inside == 0 && sp > 0 && sp < total - gs) spt = 2;
+      pgA = blk | (inside << 12) | (spt << 16) | ((zeroOut && (x >= effW || y >= effH)) ? 1 << 18 : 0) | ((int) L.t.group_idx[x] << 19) | ((int) L.t.group_idx[y] << 23);
+      if (sp > 0) {
+        const int nb = scan_blk(geo, sp - 1), xn = nb & (w - 1), yn = nb >> lw, diag = xn + yn;
+        int cnt = 0;
+#pragma unroll
+        for (int n = 0; n < 5; n++) {
+          const int xx = xn + (n == 0 ? 1 : n == 1 ? 2 : n == 2 ? 1 : 0), yy = yn + (n == 2 ? 1 : n == 3 ? 1 : n == 4 ? 2 : 0);
+          if (xx < nzw && yy < nzh && (xx >> lcw) == (xn >> lcw) && (yy >> lch) == (yn >> lch)) { pgC |= (int) cg_inv[((yy & ((1 << lch) - 1)) << lcw) | (xx & ((1 << lcw) - 1))] << (4 * cnt); cnt++; }
+        }
+        pgB = ((sp - 1) & (gs - 1)) | (dq_sig_off(ch, diag) << 4) | (dq_gtx_off(ch, diag) << 8) | (cnt << 13) | (nb << 16);
+      }
+    }
+  }
+  if (top64 == top) cnext = valid ? (int) cf[__builtin_amdgcn_readlane(pgA, 0) & 4095] : 0;       // coefficient of the position about to be processed (fetched one position ahead)
+  const int nchunk = imin(64, top64 + 1);
+  for (int it = 0; it < nchunk; it++) {
+    const int sp = top64 - it;
+    const int gA = __builtin_amdgcn_readlane(pgA, it), gB = __builtin_amdgcn_readlane(pgB, it), nbl = __builtin_amdgcn_readlane(pgC, it);
+    const int inside = (gA >> 12) & 15, eos = inside == 0, spt = (gA >> 16) & 3, zeroed = (gA >> 18) & 1;
+    const int nin = gB & 15, sigOffN = (gB >> 4) & 15, gtxOffN = (gB >> 8) & 31, nbCnt = (gB >> 13) & 7;
     const bool act = valid && sp <= first;                   // the item's trellis has started
     const int absC = iabs(cnext);
-    const int nextBlk = sp > 0 ? scan_blk(geo, sp - 1) : 0;
-    if (valid && sp > 0) cnext = cf[nextBlk];
+    if (valid && sp > 0) cnext = cf[(gB >> 16) & 4095];
     { const DqS t = prv; prv = cur; cur = t; }
     // ---- decision of target state k (xDecide 1455-1517)
     long long dc = 0x7fffffffffffffffll >> 2; int dsrc = 0, dnz = 0, dlev = -1;          // dsrc: 0 none, 1 start, 2 from the "A/zero" source state, 3 from the "B" source state, 4 sub-block skipped
@@ -263,7 +289,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
       }
       if (!(k & 1)) {                                       // checkRdCostStart 1032-1050 into decisions 0 (candidate 0) and 2 (candidate 2)
         const int stS = DQ_STEP(k), levS = DQ_LEV(stS);
-        const long long c = dq_dd(q, scaledOrg, qIdx0, stS) + (long long) (lastb[L.t.group_idx[x]] + lastb[10 + L.t.group_idx[y]]) + dq_lev_bits(R, 0, 0, levS);
+        const long long c = dq_dd(q, scaledOrg, qIdx0, stS) + (long long) (lastb[(gA >> 19) & 15] + lastb[10 + ((gA >> 23) & 15)]) + dq_lev_bits(R, 0, 0, levS);
         if (c < dc) { dc = c; dsrc = 1; dnz = 1; dlev = levS; }
       }
 #undef DQ_STEP
@@ -278,7 +304,6 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
     if (sp == 0) break;
     // ---- state update (xDecideAndUpdate 1527-1588)
     const int prevId = dsrc == 2 ? ((k & 1) ? (k == 1 ? 2 : 3) : (k == 0 ? 0 : 1)) : dsrc == 3 ? ((k & 1) ? (k == 1 ? 3 : 2) : (k == 0 ? 1 : 0)) : dsrc == 4 ? 4 + k : dsrc == 1 ? -1 : -2;
-    const int xn = nextBlk & (w - 1), yn = nextBlk >> lw, nin = (sp - 1) & (gs - 1), diagN = xn + yn;
     if (eos || !zeroed) {
       // parent state (a previous state of the quad) — every lane shuffles, the lanes whose decision has no such parent discard the result
       const int srcLane = qbase + ((prevId >= 0 && prevId < 4) ? prevId : k);
@@ -307,15 +332,12 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
           const int t = (int) dq_get_h(cur.tm, nin);
           int sumAbs = t >> 8, sumAbs1 = (t >> 3) & 31, sumNum = t & 7;
 #pragma unroll
-          for (int n = 0; n < 5; n++) {
-            const int xx = xn + (n == 0 ? 1 : n == 1 ? 2 : n == 2 ? 1 : 0), yy = yn + (n == 2 ? 1 : n == 3 ? 1 : n == 4 ? 2 : 0);
-            if (xx < nzw && yy < nzh && (xx >> lcw) == (xn >> lcw) && (yy >> lch) == (yn >> lch)) {
-              const int a = (int) dq_get_b(cur.lev, cg_inv[((yy & ((1 << lch) - 1)) << lcw) | (xx & ((1 << lcw) - 1))]);
-              sumAbs += a; sumAbs1 += imin(4 + (a & 1), a); sumNum += a != 0;
-            }
+          for (int n = 0; n < 5; n++) if (n < nbCnt) {
+            const int a = (int) dq_get_b(cur.lev, (nbl >> (4 * n)) & 15);
+            sumAbs += a; sumAbs1 += imin(4 + (a & 1), a); sumNum += a != 0;
           }
           if (cur.rem >= 4) {
-            pk = dq_put(pk, 18, 4, dq_sig_off(ch, diagN) + imin((sumAbs1 + 1) >> 1, 3)); pk = dq_put(pk, 22, 5, dq_gtx_off(ch, diagN) + imin(sumAbs1 - sumNum, 4));
+            pk = dq_put(pk, 18, 4, sigOffN + imin((sumAbs1 + 1) >> 1, 3)); pk = dq_put(pk, 22, 5, gtxOffN + imin(sumAbs1 - sumNum, 4));
             pk = dq_put(pk, 8, 2, L.t.gorice_pars[imax(imin(31, sumAbs - 20), 0)]);
           } else {
             sumAbs = imin(31, sumAbs);
@@ -371,14 +393,14 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
           cur.lev = U4{ 0, 0, 0, 0 }; cur.tm = tmn;
           const int t = (int) dq_get_h(cur.tm, nin);
           const int sumAbs1 = (t >> 3) & 31, sumNum = t & 7;
-          pk = dq_put(pk, 18, 4, dq_sig_off(ch, diagN) + imin((sumAbs1 + 1) >> 1, 3)); pk = dq_put(pk, 22, 5, dq_gtx_off(ch, diagN) + imin(sumAbs1 - sumNum, 4));
+          pk = dq_put(pk, 18, 4, sigOffN + imin((sumAbs1 + 1) >> 1, 3)); pk = dq_put(pk, 22, 5, gtxOffN + imin(sumAbs1 - sumNum, 4));
           cur.pk = pk;
         }
       }
     }
     if (spt == 1) { const DqK t = skp; skp.cost = prv.cost; skp.pk = prv.pk; skp.rem = prv.rem; skp.anc = prv.anc; prv.cost = t.cost; prv.pk = t.pk; prv.rem = t.rem; prv.anc = t.anc; }
   }
-  // ---- best final state and back-tracking (1709-1730), lane 0 of every quad for its item
+  }  // ---- best final state and back-tracking (1709-1730), lane 0 of every quad for its item
   int prev = -2; long long minCost = 0;
 #pragma unroll
   for (int s = 0; s < 4; s++) { const long long c = dq_shfl_i64(decCost, qbase + s); if (c < minCost) { prev = s; minCost = c; } }
