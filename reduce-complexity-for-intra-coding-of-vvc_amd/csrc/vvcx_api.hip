@@ -37,6 +37,12 @@ static int fail(int code, const char *fmt, ...)
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
   return code;
 }
+// every entry point works on the handle's device and leaves the caller's current device as it found it
+struct DevGuard {
+  int prev; bool ok;
+  explicit DevGuard(int dev) : prev(-1), ok(false) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; ok = hipSetDevice(dev) == hipSuccess; }
+  ~DevGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(VVCX_ERR_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
 
 struct vvcx_handle {
@@ -114,7 +120,8 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
     h->ctu_tile[(size_t) ry * h->ctus_w + rx] = t;
     h->tile_ctus[(size_t) t].push_back(ry * h->ctus_w + rx);
   }
-  if (hipSetDevice(cfg->device) != hipSuccess) { delete h; return fail(VVCX_ERR_DEVICE, "hipSetDevice(%d) failed", cfg->device); }
+  DevGuard guard(cfg->device);
+  if (!guard.ok) { delete h; return fail(VVCX_ERR_DEVICE, "hipSetDevice(%d) failed", cfg->device); }
   const int wc = cfg->pic_w >> 1, hc = cfg->pic_h >> 1;
   h->lev_plane[0] = (size_t) cfg->pic_w * cfg->pic_h; h->lev_plane[1] = h->lev_plane[2] = (size_t) wc * hc;
   h->lev_frame = h->lev_plane[0] + 2 * h->lev_plane[1];
@@ -127,7 +134,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   if (hipMalloc((void **) &h->frames_d, sizeof(VxFrameDev) * F) != hipSuccess || hipMalloc((void **) &h->lev_d, h->lev_frame * 2 * F) != hipSuccess ||
       hipMalloc((void **) &h->units_d, h->units_frame * sizeof(VxUnit) * F) != hipSuccess ||
       hipMalloc((void **) &h->stream_ctx_d, (size_t) F * h->ntiles * 2 * VXD_NUM_CTX * 2) != hipSuccess ||
-      hipMalloc((void **) &h->counters_d, 52 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void **) &h->counters_d, 56 * sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc((void **) &h->dq_d, 48 * sizeof(VxDqConst)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
   if (cfg->emit_payload) {                       // VVCX_PAYLOAD_BYTES_PER_CTU per CTU: a CTU of 8-bit video at QP >= 17 stays far below (raw samples are 24 KB)
     const size_t nstream = (size_t) F * h->ntiles;
@@ -232,7 +239,7 @@ extern "C" int vvcx_set_forest(vvcx_handle *h, int n_trees, int n_nodes, int n_c
 extern "C" int vvcx_set_slice(vvcx_handle *h, const vvcx_slice *s)
 {
   if (!h || !s) return fail(VVCX_ERR_ARG, "null argument");
-  if (!(s->lambda > 0.0) || s->qp < 0 || s->qp > 63) return fail(VVCX_ERR_ARG, "bad slice parameters");
+  if (!(s->lambda > 0.0) || s->qp < -6 * (h->cfg.bit_depth - 8) || s->qp > 63) return fail(VVCX_ERR_ARG, "bad slice parameters (QP range -QpBDOffset..63, like vvcx_derive_slice)");
   h->sl = *s; h->have_slice = true;
   return VVCX_OK;
 }
@@ -254,6 +261,7 @@ static void ctx_init_islice(int qp, uint16_t *s0, uint16_t *s1)
 extern "C" int vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n)
 {
   if (!h || !frames) return fail(VVCX_ERR_ARG, "null argument");
+  DevGuard guard(h->cfg.device);
   if (n < 1 || n > h->cfg.max_frames) return fail(VVCX_ERR_ARG, "n_frames %d outside 1..%d", n, h->cfg.max_frames);
   if (!h->have_slice) return fail(VVCX_ERR_STATE, "vvcx_set_slice must precede vvcx_bind_frames");
   h->frames_h.resize((size_t) n);
@@ -263,6 +271,8 @@ extern "C" int vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n)
       if (!frames[f].org[c] || !frames[f].reco[c]) return fail(VVCX_ERR_ARG, "frame %d plane %d is null", f, c);
       d.org[c] = frames[f].org[c]; d.rec[c] = frames[f].reco[c]; d.stride[c] = frames[f].stride[c];
       if (d.stride[c] < (c ? h->cfg.pic_w >> 1 : h->cfg.pic_w)) return fail(VVCX_ERR_ARG, "frame %d plane %d stride too small", f, c);
+      const size_t bps = h->cfg.bit_depth == 8 ? 1 : 2;   // the deblocking kernel loads four samples at a time: strides and bases must keep that alignment
+      if ((d.stride[c] & 3) || (((uintptr_t) d.org[c] | (uintptr_t) d.rec[c]) & (4 * bps - 1))) return fail(VVCX_ERR_ARG, "frame %d plane %d: base address / stride not aligned to 4 samples", f, c);
     }
     int16_t *lev = h->lev_d + (size_t) f * h->lev_frame;
     d.lev[0] = lev; d.lev[1] = lev + h->lev_plane[0]; d.lev[2] = lev + h->lev_plane[0] + h->lev_plane[1];
@@ -285,6 +295,7 @@ extern "C" int vvcx_ctus_per_frame(const vvcx_handle *h) { return h ? h->ctus_w 
 extern "C" int vvcx_resident_streams(const vvcx_handle *h)
 {
   if (!h) return 0;
+  DevGuard guard(h->cfg.device);
   int cus = 0, per_cu = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess) return 0;
   const void *k = h->cfg.bit_depth == 8 ? (const void *) vvcx_compress_kernel_u8 : (const void *) vvcx_compress_kernel_u16;
@@ -295,9 +306,10 @@ extern "C" int vvcx_resident_streams(const vvcx_handle *h)
 extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int n, vvcx_ctu_result *out, void *hip_stream)
 {
   if (h && (h->cfg.tools & VVCX_TOOL_FAST) && !h->f_ntrees) return fail(VVCX_ERR_STATE, "VVCX_TOOL_FAST needs vvcx_set_forest before the first CTU");
+  if (h && n == 0) return VVCX_OK;                      // nothing left to code (e.g. compress_bound_frames after the last CTU): not an error
   if (!h || !tasks || !out || n < 0) return fail(VVCX_ERR_ARG, "bad argument");
   if (h->n_frames == 0) return fail(VVCX_ERR_STATE, "no frames bound");
-  if (n == 0) return VVCX_OK;
+  DevGuard guard(h->cfg.device);
   hipStream_t stream = (hipStream_t) hip_stream;
   const int nctu = h->ctus_w * h->ctus_h;
   // group tasks by stream, keeping their order; validate that every stream continues in tile raster order
@@ -329,11 +341,18 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
     HIPCHK(hipMalloc((void **) &h->task_ctu_d, sizeof(int32_t) * (size_t) n)); HIPCHK(hipMalloc((void **) &h->results_d, sizeof(VxCtuRes) * (size_t) n)); h->task_cap = n;
   }
   const size_t per_stream = (h->cfg.tools & VVCX_TOOL_CU_REUSE) ? (size_t) VXD_SCRATCH_BYTES : (size_t) VXD_OFF_CACHE;   // the CU cache only when used
-  const size_t need = (size_t) ns * per_stream;
-  if (need > h->scratch_cap) { (void) hipFree(h->scratch_d); h->scratch_d = nullptr; HIPCHK(hipMalloc((void **) &h->scratch_d, need)); h->scratch_cap = need; }
+  // one workgroup per resident stream slot (they take the streams from a queue): scratch is per slot
+  int resident = vvcx_resident_streams(h);
+  if (resident < 1) resident = 1;
+  const int grid = ns < resident ? ns : resident;
+  const size_t need = (size_t) grid * per_stream;
+  if (need > h->scratch_cap) {
+    (void) hipFree(h->scratch_d); h->scratch_d = nullptr; HIPCHK(hipMalloc((void **) &h->scratch_d, need)); h->scratch_cap = need;
+    HIPCHK(hipMemsetAsync(h->scratch_d, 0, need, stream));       // CU-cache entries and generation counters start empty
+  }
   HIPCHK(hipMemcpyAsync(h->streams_d, sd.data(), sizeof(VxStreamDesc) * (size_t) ns, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(h->task_ctu_d, task_ctu.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemsetAsync(h->counters_d, 0, 52 * sizeof(unsigned long long), stream));
+  HIPCHK(hipMemsetAsync(h->counters_d, 0, 56 * sizeof(unsigned long long), stream));
 
   VxParams p; memset(&p, 0, sizeof p);
   p.pic_w = h->cfg.pic_w; p.pic_h = h->cfg.pic_h; p.bit_depth = h->cfg.bit_depth; p.chroma = h->cfg.chroma; p.tools = h->cfg.tools;
@@ -348,6 +367,7 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
   p.scratch = h->scratch_d; p.scratch_per_stream = per_stream; p.counters = h->counters_d; p.ntiles = h->ntiles;
   p.f_node = h->f_node_d; p.f_value = h->f_value_d; p.f_root = h->f_root_d; p.f_ntrees = h->f_ntrees; p.f_nclasses = h->f_nclasses;
   for (int c = 0; c < 8; c++) p.f_classes[c] = h->f_classes[c];
+  p.n_streams = ns;
   if (h->cfg.tools & VVCX_TOOL_DEPQUANT) {
     // the quantiser's lambda of a component: TrQuant::setLambdas / selectLambda (EL/EncSlice.cpp:107-149, EL/IntraSearch.cpp:2889) = lambda / distortion weight for chroma
     VxDqConst tab[48]; memset(tab, 0, sizeof tab);
@@ -361,8 +381,8 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
   }
 
   HIPCHK(hipEventRecord(h->ev0, stream));
-  if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_compress_kernel_u8, dim3((unsigned) ns), dim3(VXD_NT), 0, stream, p);
-  else hipLaunchKernelGGL(vvcx_compress_kernel_u16, dim3((unsigned) ns), dim3(VXD_NT), 0, stream, p);
+  if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_compress_kernel_u8, dim3((unsigned) grid), dim3(VXD_NT), 0, stream, p);
+  else hipLaunchKernelGGL(vvcx_compress_kernel_u16, dim3((unsigned) grid), dim3(VXD_NT), 0, stream, p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, stream));
   std::vector<VxCtuRes> res((size_t) n);
@@ -440,6 +460,7 @@ extern "C" int vvcx_get_levels(vvcx_handle *h, int frame, int comp, int16_t *pla
 extern "C" int vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus, int *n_cus)
 {
   if (!h || !n_cus || frame < 0 || frame >= h->n_frames) return fail(VVCX_ERR_ARG, "bad argument");
+  DevGuard guard(h->cfg.device);
   std::vector<VxUnit> um(h->units_frame);
   HIPCHK(hipMemcpy(um.data(), h->units_d + (size_t) frame * h->units_frame, h->units_frame * sizeof(VxUnit), hipMemcpyDeviceToHost));
   int n = 0;
@@ -466,6 +487,7 @@ extern "C" float vvcx_last_kernel_ms(const vvcx_handle *h) { return h ? h->last_
 extern "C" int vvcx_get_counters(vvcx_handle *h, uint64_t out[4])
 {
   if (!h || !out) return fail(VVCX_ERR_ARG, "null argument");
+  DevGuard guard(h->cfg.device);
   unsigned long long c[4];
   HIPCHK(hipMemcpy(c, h->counters_d, sizeof c, hipMemcpyDeviceToHost));
   for (int i = 0; i < 4; i++) out[i] = c[i];
@@ -477,6 +499,7 @@ extern "C" int vvcx_get_counters(vvcx_handle *h, uint64_t out[4])
 extern "C" int vvcx_get_profile(vvcx_handle *h, uint64_t out[48])
 {
   if (!h || !out) return fail(VVCX_ERR_ARG, "null argument");
+  DevGuard guard(h->cfg.device);
   unsigned long long c[52];
   HIPCHK(hipMemcpy(c, h->counters_d, sizeof c, hipMemcpyDeviceToHost));
   for (int i = 0; i < 48; i++) out[i] = c[4 + i];
@@ -698,6 +721,7 @@ extern "C" int vvcx_get_payload(vvcx_handle *h, int frame, int tile, uint8_t *bu
 {
   if (!h || !buf || !nbytes || frame < 0 || frame >= h->n_frames || tile < 0 || tile >= h->ntiles) return fail(VVCX_ERR_ARG, "bad argument");
   if (!h->payload_d) return fail(VVCX_ERR_STATE, "handle was created without emit_payload");
+  DevGuard guard(h->cfg.device);
   const size_t s = (size_t) frame * h->ntiles + tile;
   if (h->next_idx[s] != (int) h->tile_ctus[(size_t) tile].size()) return fail(VVCX_ERR_STATE, "tile %d of frame %d is not completely coded yet", tile, frame);
   uint32_t st[8];

@@ -230,7 +230,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
       }
     }
   }
-  if (top64 == top) cnext = valid ? (int) cf[__builtin_amdgcn_readlane(pgA, 0) & 4095] : 0;       // coefficient of the position about to be processed (fetched one position ahead)
+  if (top64 == top) { const int b0 = __builtin_amdgcn_readlane(pgA, 0) & 4095; cnext = valid ? (int) cf[b0] : 0; }       // coefficient of the position about to be processed (fetched one position ahead)
   const int nchunk = imin(64, top64 + 1);
   for (int it = 0; it < nchunk; it++) {
     const int sp = top64 - it;
@@ -400,7 +400,8 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
     }
     if (spt == 1) { const DqK t = skp; skp.cost = prv.cost; skp.pk = prv.pk; skp.rem = prv.rem; skp.anc = prv.anc; prv.cost = t.cost; prv.pk = t.pk; prv.rem = t.rem; prv.anc = t.anc; }
   }
-  }  // ---- best final state and back-tracking (1709-1730), lane 0 of every quad for its item
+  }
+  // ---- best final state and back-tracking (1709-1730), lane 0 of every quad for its item
   int prev = -2; long long minCost = 0;
 #pragma unroll
   for (int s = 0; s < 4; s++) { const long long c = dq_shfl_i64(decCost, qbase + s); if (c < minCost) { prev = s; minCost = c; } }

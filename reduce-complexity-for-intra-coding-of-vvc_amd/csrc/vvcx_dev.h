@@ -61,7 +61,7 @@ struct VxParams {
   const int32_t      *task_ctu;      // CTU raster address per task
   VxCtuRes           *results;       // per task
   uint16_t           *stream_ctx;    // per (frame*ntiles+tile): 2*VXD_NUM_CTX states carried CTU -> CTU
-  uint8_t            *scratch;       // per launched stream
+  uint8_t            *scratch;       // per workgroup of the launch (= per resident stream slot)
   uint64_t            scratch_per_stream;
   unsigned long long *counters;      // 4 global work counters
   int32_t             ntiles;
@@ -77,6 +77,7 @@ struct VxParams {
   int32_t             f_ntrees, f_nclasses;
   int32_t             f_classes[8];
   const VxDqConst    *dq_consts;     // [3 * 16] (VVCX_TOOL_DEPQUANT)
+  int32_t             n_streams;     // stream descriptors of the launch: the workgroups (at most one per resident slot) take them from a queue (counters[52])
 };
 
 struct VxDeblockParams {     // vvcx_deblock.hip
@@ -99,7 +100,7 @@ struct VxDeblockParams {     // vvcx_deblock.hip
 // CU-result cache of the current CTU (BestEncInfoCache, EL/EncModeCtrl.cpp:663-1110): one entry per (position in CTU in
 // 4-sample units, log2 w, log2 h <= 6) and a level pool with one slot per (size, position aligned to max(4, size/2)):
 // sum over sizes of size * 128 / max(4, size/2) = 1152 per dimension.
-struct VxCacheEnt { uint64_t ss; uint8_t kind /* 0 empty, 1 luma tree, 2 chroma tree */, dir, mrl, cbf, depth, mts, pad[2]; };
+struct VxCacheEnt { uint64_t ss; uint8_t kind /* 0 empty, 1 luma tree, 2 chroma tree */, dir, mrl, cbf, depth, mts; uint16_t gen /* CTU generation of the scratch slot the entry belongs to */; };
 #define VXD_CACHE_ENTRIES (32 * 32 * 5 * 5)
 #define VXD_CACHE_DIM   1152
 #define VXD_OFF_ORG     (VXD_OFF_TMP + VXD_NW * 2048 * 4)                             // original tile of a node too big for LDS: 4096 int16
@@ -119,4 +120,5 @@ struct VxRbItem { double cost; uint64_t dist, bits; int32_t cbf, sum0, test, wav
 #define VXD_OFF_POOL_REC   (VXD_OFF_POOL_NODES + VXD_POOL_NODE_BYTES)
 #define VXD_OFF_CACHE   ((VXD_OFF_POOL_REC + 2 * VXD_POOL_ITEMS * (int) sizeof(VxRbItem) + 255) & ~255)
 #define VXD_OFF_CACHE_LEV (VXD_OFF_CACHE + VXD_CACHE_ENTRIES * (int) sizeof(VxCacheEnt))
-#define VXD_SCRATCH_BYTES (VXD_OFF_CACHE_LEV + VXD_CACHE_DIM * VXD_CACHE_DIM * 2)
+#define VXD_OFF_META    (VXD_OFF_CACHE_LEV + VXD_CACHE_DIM * VXD_CACHE_DIM * 2)      // uint32: CTU generations this scratch slot has seen (validates CU-cache entries)
+#define VXD_SCRATCH_BYTES (VXD_OFF_META + 256)

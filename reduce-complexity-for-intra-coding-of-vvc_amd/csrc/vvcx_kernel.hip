@@ -126,6 +126,7 @@ struct Lds {
   int acc[NW][4][2];               // small-block SATD stage: per packed candidate {SAD, SATD}
   int16_t refs[4][2][140];         // luma: set 0 mrl0 unfiltered, 1 mrl0 filtered, 2 mrl1, 3 mrl3; chroma: set 0 Cb, 1 Cr. [0]=top [1]=left
   uint8_t flags[72]; int8_t src_unit[72];
+  int cache_gen, cur_stream;       // CTU generation of this scratch slot (CU-result cache validity); stream descriptor the workgroup is running
   int dq_abs[64 + NW];             // wave_depquant_batch: absSum per item of a batch ([64 + wave]: a wave's own single block)
   Frame fr[MAXD];
   // posted operation
@@ -2608,7 +2609,7 @@ __device__ int cache_is_valid(const VxParams &p, uint8_t *scratch, Frame *fr, in
   const int e = cache_slot(f.x, f.y, f.w, f.h, lo);
   if (e < 0) return 0;
   const VxCacheEnt c = ((const VxCacheEnt *) (scratch + VXD_OFF_CACHE))[e];
-  if (c.kind != ch + 1) return 0;
+  if (c.kind != ch + 1 || c.gen != (uint16_t) L.cache_gen) return 0;      // entries of earlier CTUs carry another generation
   int i = 1;
   for (; i <= d; i++) {
     const int dpt = i - 1, s = dpt >= c.depth ? SPLIT_NONE : (int) ((c.ss >> (5 * dpt)) & 31);
@@ -2908,7 +2909,7 @@ __device__ __noinline__ void op_save_intra(const VxParams &p_, uint8_t *scratch,
       int16_t *cl = (int16_t *) (scratch + VXD_OFF_CACHE_LEV) + lo;
       for (int i = VTX; i < n; i += NT) cl[i] = lev[i];
       if (VTX == 0) {
-        VxCacheEnt c; c.ss = cu.ss; c.kind = (uint8_t) (ch + 1); c.dir = cu.dir; c.mrl = cu.mrl; c.cbf = cu.cbf; c.depth = cu.depth; c.mts = cu.mts; c.pad[0] = c.pad[1] = 0;
+        VxCacheEnt c; c.ss = cu.ss; c.kind = (uint8_t) (ch + 1); c.dir = cu.dir; c.mrl = cu.mrl; c.cbf = cu.cbf; c.depth = cu.depth; c.mts = cu.mts; c.gen = (uint16_t) L.cache_gen;
         ((VxCacheEnt *) (scratch + VXD_OFF_CACHE))[e] = c;
       }
     }
@@ -3539,9 +3540,9 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
 
 // ------------------------------------------------------------------------------------------------ kernel
 template <typename T>
-__device__ void run_stream(const VxParams &p)
+__device__ void run_stream(const VxParams &p, int stream_idx)
 {
-  const VxStreamDesc sd = p.streams[blockIdx.x];
+  const VxStreamDesc sd = p.streams[stream_idx];
   if (VTX == 0) { L.par = p; L.fdv = p.frames[sd.frame]; }
   const VxFrameDev &fd = p.frames[sd.frame];
   uint8_t *scratch = p.scratch + (size_t) blockIdx.x * p.scratch_per_stream;
@@ -3550,6 +3551,7 @@ __device__ void run_stream(const VxParams &p)
   if (tid == 0) {
     L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < 48; i++) L.prof[i] = 0;
     if (p.payload) writer_begin(p, sd.frame * p.ntiles + sd.tile, sd.done_before);
+    if (p.tools & TOOL_CU_REUSE) L.cache_gen = (int) *(const uint32_t *) (scratch + VXD_OFF_META);
   }
   load_tables();
   ctx_copy_all(&L.ctxs[CI_CUR], carry);
@@ -3559,10 +3561,15 @@ __device__ void run_stream(const VxParams &p)
     const int ctu_x = (addr % p.ctus_w) << 7, ctu_y = (addr / p.ctus_w) << 7;
     // contexts at CTU start → snapshot slot (MAXD-1) "start"
     ctx_copy_all(ctx_ptr(scratch, CTX_START, MAXD + NW, 0), &L.ctxs[CI_CUR]);
-    if (p.tools & TOOL_CU_REUSE) {                       // entries of an earlier CTU can never match (987-1024: poc / absolute area): drop them
-      uint64_t *ce = (uint64_t *) (scratch + VXD_OFF_CACHE);   // sizeof(VxCacheEnt) == 16
-      for (int i = tid; i < 2 * VXD_CACHE_ENTRIES; i += NT) ce[i] = 0;
-      __threadfence_block();
+    if (p.tools & TOOL_CU_REUSE) {                       // entries of an earlier CTU can never match (987-1024: poc / absolute area): a new generation drops them
+      const int g = uni(L.cache_gen) + 1;
+      if ((g & 0xffff) == 0) {                             // the 16-bit tag wraps: clear the entries once
+        uint64_t *ce = (uint64_t *) (scratch + VXD_OFF_CACHE);   // sizeof(VxCacheEnt) == 16
+        for (int i = tid; i < 2 * VXD_CACHE_ENTRIES; i += NT) ce[i] = 0;
+        __threadfence_block();
+      }
+      __syncthreads();
+      if (tid == 0) L.cache_gen = (g & 0xffff) == 0 ? g + 1 : g;
     }
     __syncthreads();
     VxCtuRes res; res.dist = 0; res.bits = 0; res.cost = 0; res.n_cu = 0; res.pad = 0;
@@ -3591,6 +3598,7 @@ __device__ void run_stream(const VxParams &p)
     __syncthreads();
   }
   ctx_copy_all(carry, &L.ctxs[CI_CUR]);
+  if (tid == 0 && (p.tools & TOOL_CU_REUSE)) *(uint32_t *) (scratch + VXD_OFF_META) = (uint32_t) L.cache_gen;
   if (tid == 0 && p.payload) writer_suspend(p, sd.frame * p.ntiles + sd.tile);
   if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); for (int i = 0; i < 48; i++) atomicAdd(&p.counters[4 + i], L.prof[i]); }
 }
@@ -3614,6 +3622,7 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_dist_kernel(
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp,
                                                                                unsigned long long *out)
 {
+  if (VTX == 0) L.par.tools = 0;                           // the plain quantiser (LDS is not cleared between launches)
   load_tables();
   __syncthreads();
   const int wave = uni(VTX >> 6), lane = VTX & 63, P = w * h;
@@ -3716,5 +3725,19 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_forest_kerne
   out[i] = p.f_classes[best];
 }
 
-extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_kernel_u8(VxParams p) { run_stream<uint8_t>(p); }
-extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_kernel_u16(VxParams p) { run_stream<uint16_t>(p); }
+// One workgroup per resident stream slot: it takes stream descriptors from the launch's queue until the queue is empty (every workgroup reaches the exit),
+// so the scratch of a launch is sized by the slots, not by the streams.
+template <typename T>
+__device__ void run_streams(const VxParams &p)
+{
+  for (;;) {
+    __syncthreads();
+    if (VTX == 0) L.cur_stream = (int) atomicAdd(&p.counters[52], 1ull);
+    __syncthreads();
+    const int s = uni(L.cur_stream);
+    if (s >= p.n_streams) break;
+    run_stream<T>(p, s);
+  }
+}
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_kernel_u8(VxParams p) { run_streams<uint8_t>(p); }
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_kernel_u16(VxParams p) { run_streams<uint16_t>(p); }

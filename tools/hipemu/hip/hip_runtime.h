@@ -113,6 +113,7 @@ typedef int hipError_t; typedef void *hipStream_t; typedef void *hipEvent_t;
 enum { hipSuccess = 0 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
 enum { hipDeviceAttributeMultiprocessorCount = 0 };
 inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 1; return 0; }
 inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *v, const void *, int, size_t) { *v = 1; return 0; }
