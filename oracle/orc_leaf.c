@@ -150,6 +150,108 @@ int orc_quant(const int *coef, int w, int h, int bit_depth, int qp, int16_t *lev
   return abs_sum;
 }
 
+/* Quant::quant for a block of a CU with lfnstIdx > 0 (CL/Quant.cpp:1054-1058, JVET_O0094): the level buffer is cleared and only the first
+ * max_coefs buffer positions (8 for 4x4 / 8x8 blocks, else 16 -- buffer order, as the reference indexes them) are quantised */
+int orc_quant_lfnst(const int *coef, int w, int h, int bit_depth, int qp, int16_t *level)
+{
+  const int lw = ilog2(w), lh = ilog2(h);
+  const int need_sqrt = (lw + lh) & 1;
+  const int scale = ORC_QUANT_SCALES[need_sqrt * 6 + qp % 6];
+  const int tr_shift = 15 - bit_depth - ((lw + lh) >> 1) + (need_sqrt ? -1 : 0);
+  const int qbits = 14 + qp / 6 + tr_shift;
+  const int64_t add = (int64_t) 171 << (qbits - 9);
+  const int max_coefs = ((w == 4 && h == 4) || (w == 8 && h == 8)) ? 8 : 16;
+  int abs_sum = 0;
+  memset(level, 0, (size_t) w * h * sizeof(int16_t));
+  for (int i = 0; i < max_coefs; i++) {
+    const int c = coef[i];
+    const int64_t t = (int64_t) (c < 0 ? -c : c) * scale;
+    int q = (int) ((t + add) >> qbits);
+    abs_sum += q;
+    if (c < 0) q = -q;
+    q = q < -32768 ? -32768 : q > 32767 ? 32767 : q;
+    level[i] = (int16_t) q;
+  }
+  return abs_sum;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * LFNST (CL/TrQuant.cpp:241-560; kernels CL/RomLFNST.cpp as data in orc_lfnst_tables.h)
+ * orc_lfnst_mode   = PU::getWideAngIntraMode (CL/UnitTools.cpp:963-989) + TrQuant::getLFNSTIntraMode (293-311): the index into the
+ *                    mode -> kernel-set table and (>= 0x100) the transpose flag of getTransposeFlag (312-317); dir is the block's final
+ *                    intra mode (planar for MIP, the co-located luma mode for DM / CCLM), w x h the transform block
+ * orc_lfnst_keep   = the zero-out of the primary transform for lfnstIdx > 0 (xT 855-868): only the top-left 4x4 (one side 4) or 8x8 stays
+ * orc_fwd_lfnst    = xFwdLfnst 437-560, orc_inv_lfnst = xInvLfnst 319-436 on a w x h coefficient block (stride w)
+ * ---------------------------------------------------------------------------------------------- */
+#include "orc_lfnst_tables.h"
+int orc_lfnst_mode(int dir, int w, int h)
+{
+  int pm = dir;
+  if (dir >= 2) {
+    static const int modeShift[6] = { 0, 6, 10, 12, 14, 15 };
+    const int lw = ilog2(w), lh = ilog2(h), ds = lw > lh ? lw - lh : lh - lw;
+    if (w > h && dir < 2 + modeShift[ds]) pm += 65;
+    else if (h > w && pm > 66 - modeShift[ds]) pm -= 67;
+  }
+  const int ext = pm < 0 ? pm + 14 + 67 : pm >= 67 ? pm + 14 : pm;
+  const int transpose = (ext >= 67 && ext >= 67 + 14) || (ext < 67 && ext > 34);
+  return ext | (transpose ? 0x100 : 0);
+}
+void orc_lfnst_keep(int *coef, int w, int h)
+{
+  int kw = w, kh = h;
+  if ((w == 4 && h > 4) || (w > 4 && h == 4)) { kw = 4; kh = 4; }
+  else if (w >= 8 && h >= 8) { kw = 8; kh = 8; }
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) if (x >= kw || y >= kh) coef[y * w + x] = 0;
+}
+/* place of the k-th entry of the diagonal scan of the top-left 8x8 (4x4 groups) / 4x4 region */
+static int lfnst_scan_pos(int k, int w)
+{
+  static const uint8_t d4[16][2] = { {0,0},{0,1},{1,0},{0,2},{1,1},{2,0},{0,3},{1,2},{2,1},{3,0},{1,3},{2,2},{3,1},{2,3},{3,2},{3,3} };
+  static const uint8_t g[4][2] = { {0,0},{0,1},{1,0},{1,1} };
+  const int grp = k >> 4, in = k & 15;
+  return (g[grp][1] * 4 + d4[in][1]) * w + g[grp][0] * 4 + d4[in][0];
+}
+/* index inside the (possibly transposed) kernel input / output vector of the region sample (x, y) */
+static int lfnst_vec_pos(int x, int y, int sb, int transpose)
+{
+  if (transpose) { const int t = x; x = y; y = t; }
+  return sb == 4 ? y * 4 + x : (y < 4 ? y * 8 + x : 32 + (y - 4) * 4 + x);
+}
+void orc_fwd_lfnst(int *coef, int w, int h, int mode, int lfnst_idx)
+{
+  if (!lfnst_idx || w < 4 || h < 4) return;
+  const int sb = (w >= 8 && h >= 8) ? 8 : 4, trSize = sb == 8 ? 48 : 16;
+  const int nOut = ((w == 4 && h == 4) || (w == 8 && h == 8)) ? 8 : 16;
+  const int transpose = (mode >> 8) & 1, set = ORC_LFNST_LUT[mode & 255];
+  const int8_t *M = sb == 8 ? ORC_LFNST_8x8 + ((set * 2 + lfnst_idx - 1) * 16) * 48 : ORC_LFNST_4x4 + ((set * 2 + lfnst_idx - 1) * 16) * 16;
+  int in[48], out[48];
+  for (int y = 0; y < sb; y++) for (int x = 0; x < sb; x++) if (sb == 4 || x < 4 || y < 4) in[lfnst_vec_pos(x, y, sb, transpose)] = coef[y * w + x];
+  for (int j = 0; j < trSize; j++) {
+    int c = 0;
+    if (j < nOut) { for (int i = 0; i < trSize; i++) c += in[i] * M[j * trSize + i]; c = (c + 64) >> 7; }
+    out[j] = c;
+  }
+  for (int k = 0; k < trSize; k++) coef[lfnst_scan_pos(k, w)] = out[k];
+}
+void orc_inv_lfnst(int *coef, int w, int h, int mode, int lfnst_idx)
+{
+  if (!lfnst_idx || w < 4 || h < 4) return;
+  const int sb = (w >= 8 && h >= 8) ? 8 : 4, trSize = sb == 8 ? 48 : 16;
+  const int nIn = ((w == 4 && h == 4) || (w == 8 && h == 8)) ? 8 : 16;
+  const int transpose = (mode >> 8) & 1, set = ORC_LFNST_LUT[mode & 255];
+  const int8_t *M = sb == 8 ? ORC_LFNST_8x8 + ((set * 2 + lfnst_idx - 1) * 16) * 48 : ORC_LFNST_4x4 + ((set * 2 + lfnst_idx - 1) * 16) * 16;
+  int in[16], out[48];
+  for (int k = 0; k < 16; k++) in[k] = coef[lfnst_scan_pos(k, w)];
+  for (int j = 0; j < trSize; j++) {
+    int r = 0;
+    for (int i = 0; i < nIn; i++) r += in[i] * M[i * trSize + j];
+    r = (r + 64) >> 7;
+    out[j] = r < -32768 ? -32768 : r > 32767 ? 32767 : r;
+  }
+  for (int y = 0; y < sb; y++) for (int x = 0; x < sb; x++) if (sb == 4 || x < 4 || y < 4) coef[y * w + x] = out[lfnst_vec_pos(x, y, sb, transpose)];
+}
+
 /* CL/Quant.cpp:423-549 Quant::dequant, flat scaling */
 void orc_dequant(const int16_t *level, int w, int h, int bit_depth, int qp, int *coef)
 {
@@ -799,4 +901,25 @@ int orc_arith_encode(int qp, const int32_t *ops, int nops, uint8_t *out, int cap
   orc_arith_finish(&aw);
   orc_bs_write(&aw, 1, 1); while (aw.bit_n) orc_bs_write(&aw, 0, 1);
   return aw.n > aw.cap ? -1 : (int) aw.n;
+}
+
+/* one block of a CU with lfnstIdx through TrQuant::transformNxN / invTransformNxN (CL/TrQuant.cpp:1127-1235, 563-610): primary transform with the
+ * LFNST zero-out, xFwdLfnst, the quantiser, then dequantisation, xInvLfnst and the inverse transform.  Returns absSum (resi_out only when > 0). */
+int orc_trquant_lfnst(const uint16_t *s0, const uint16_t *s1, const int16_t *resi, int w, int h, int comp, int cbf_cb, int bit_depth, int qp, double lambda,
+                      int dep_quant, int dir, int lfnst_idx, int16_t *level, int16_t *resi_out)
+{
+  int *coef = (int *) malloc(sizeof(int) * (size_t) w * h);
+  const int mode = orc_lfnst_mode(dir, w, h);
+  orc_fwd_2d_mts(resi, w, w, h, bit_depth, 0, coef);
+  if (lfnst_idx) { orc_lfnst_keep(coef, w, h); orc_fwd_lfnst(coef, w, h, mode, lfnst_idx); }
+  int abs_sum;
+  if (dep_quant) abs_sum = orc_depquant(s0, s1, coef, w, h, comp, ORC_CTX_QtCbf[comp] + (comp == 2 ? cbf_cb : 0), bit_depth, qp, lambda, 0, lfnst_idx, level);
+  else abs_sum = lfnst_idx ? orc_quant_lfnst(coef, w, h, bit_depth, qp, level) : orc_quant(coef, w, h, bit_depth, qp, level);
+  if (abs_sum > 0) {
+    if (dep_quant) orc_dequant_dq(level, w, h, bit_depth, qp, coef); else orc_dequant(level, w, h, bit_depth, qp, coef);
+    orc_inv_lfnst(coef, w, h, mode, lfnst_idx);
+    orc_inv_2d_mts(coef, w, h, bit_depth, 0, resi_out, w);
+  }
+  free(coef);
+  return abs_sum;
 }

@@ -128,6 +128,15 @@ void orc_mts_prune(const int16_t *resi, int stride, int w, int h, int bit_depth,
 /* CL/Quant.cpp:994-1089 (plain quant, I-slice offset 171) and 423-549 (dequant) */
 int  orc_quant(const int *coef, int w, int h, int bit_depth, int qp, int16_t *level);
 void orc_dequant(const int16_t *level, int w, int h, int bit_depth, int qp, int *coef);
+/* LFNST (CL/TrQuant.cpp:241-560): see orc_leaf.c.  mode = orc_lfnst_mode(final intra mode, block w, h) */
+int  orc_quant_lfnst(const int *coef, int w, int h, int bit_depth, int qp, int16_t *level);
+int  orc_lfnst_mode(int dir, int w, int h);
+void orc_lfnst_keep(int *coef, int w, int h);
+void orc_fwd_lfnst(int *coef, int w, int h, int mode, int lfnst_idx);
+void orc_inv_lfnst(int *coef, int w, int h, int mode, int lfnst_idx);
+/* transform + quantisation + reconstruction residual of one block with LFNST: the path of code_tu_block (test entry point) */
+int  orc_trquant_lfnst(const uint16_t *s0, const uint16_t *s1, const int16_t *resi, int w, int h, int comp, int cbf_cb, int bit_depth, int qp, double lambda,
+                       int dep_quant, int dir, int lfnst_idx, int16_t *level, int16_t *resi_out);
 /* CL/DepQuant.cpp: dependent quantisation of one block from the estimator's contexts (s0, s1) at the time of the call; comp 0 Y / 1 Cb / 2 Cr;
  * cbf_ctx = flat context index of the block's cbf flag (-1: inferred); qp as for orc_quant; lambda = the quantiser's lambda for the component;
  * zo = explicit MTS (mts_idx > 1); lfnst = cu.lfnstIdx.  Returns absSum.  orc_dequant_dq: Quantizer::dequantBlock (741-810). */

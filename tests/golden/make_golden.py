@@ -361,6 +361,61 @@ def gen_depquant():
     print("depquant cases", len(meta), "non-zero", int((m[:, 8] > 0).sum()), "max abs level", int(np.abs(np.concatenate(lev_all)).max()))
 
 
+def gen_lfnst():
+    """LFNST through the reference: TrQuant::transformNxN / invTransformNxN of blocks of a CU with lfnstIdx 1 / 2 (and 0 as the control) --
+    the zero-out of the primary transform (xT 855-868), xFwdLfnst / xInvLfnst (CL/TrQuant.cpp:319-560) with the kernel set and transposition
+    derived from the intra mode after the wide-angle mapping, followed by DepQuant (first tested position 7 / 15) or the plain quantiser (its
+    8 / 16 first buffer positions).  Luma blocks of every shape with every intra mode class, MIP CUs (planar set), Cb / Cr blocks."""
+    R.ref_env_trquant_lfnst.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_double, C.c_int] + [C.c_void_p] * 7
+    R.ref_ctx_init.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 3
+    g = np.random.default_rng(20263)
+    nctx = R.ref_ctx_count()
+    meta, lam_all, ctx_all, resi_all, lev_all, out_all = [], [], [], [], [], []
+    luma_shapes = [(w, h) for w in (4, 8, 16, 32, 64) for h in (4, 8, 16, 32, 64)]
+    chroma_shapes = [(4, 4), (4, 8), (8, 4), (8, 8), (4, 16), (16, 4), (16, 16), (32, 8), (8, 32), (32, 32)]
+    for gi, (bd, qp) in enumerate(((8, 27), (8, 37), (10, 32))):
+        env = R.ref_env_create(192, 192, bd)
+        s0 = np.zeros(nctx, np.uint16); s1 = np.zeros(nctx, np.uint16); rate = np.zeros(nctx, np.uint8)
+        R.ref_ctx_init(qp, 2, P(s0), P(s1), P(rate))
+        for i in range(nctx):
+            n = int(g.integers(0, 24)); bins = (g.random(n) < g.random()).astype(np.uint8)
+            a = s0[i:i + 1].copy(); b = s1[i:i + 1].copy()
+            if n: R.ref_ctx_code_bins(P(a), P(b), int(rate[i]), P(bins), n)
+            s0[i] = a[0]; s1[i] = b[0]
+        ctx_all.append(np.stack([s0, s1]))
+        lam0 = 0.57 * 2.0 ** ((qp + 6 * (bd - 8) - 12) / 3.0) * 2.0 ** (0.25 / 3.0)
+        cases = []
+        for (w, h) in luma_shapes:
+            dirs = [0, 1, 2, 18, 34, 35, 50, 66] + [int(x) for x in g.integers(2, 67, 4)]
+            for k, d in enumerate(dirs):
+                cases.append((0, w, h, d, 0, 1 + (k & 1), int(k % 3 != 2)))
+            cases.append((0, w, h, int(g.integers(0, 6)), 1, 1 + int(g.integers(0, 2)), 1))      # MIP CU: planar set
+            cases.append((0, w, h, int(g.integers(0, 67)), 0, 0, int(g.integers(0, 2))))          # control
+        for (w, h) in chroma_shapes:
+            for c in (1, 2):
+                for d in (0, 1, int(g.integers(2, 67)), int(g.integers(2, 67))):
+                    cases.append((c, w, h, d, 0, 1 + int(g.integers(0, 2)), int(g.integers(0, 4) != 0)))
+        for (comp, w, h, d, mip, li, dq) in cases:
+            R.ref_env_reset(env)
+            amp = (1 << bd) // 4
+            yy, xx = np.mgrid[0:h, 0:w]
+            sig = amp / float(g.choice([20, 8, 3]))
+            resi = g.normal(0, sig, (h, w)) + (amp / 3) * np.sin(xx / 5.0 + g.uniform(0, 3)) * np.cos(yy / 7.0) * g.uniform(0, 1)
+            resi = np.ascontiguousarray(np.clip(resi.round(), -(1 << bd) + 1, (1 << bd) - 1).astype(np.int16))
+            cbf_cb = int(g.integers(0, 2)) if comp == 2 else 0
+            lam = lam0 * (1.0 if comp == 0 else float(g.choice([0.8, 1.0, 1.3])))
+            lev = np.zeros(w * h, np.int32); ro = np.zeros(w * h, np.int16); a = C.c_int(); qu = C.c_int()
+            cw, chh = (w, h) if comp == 0 else (2 * w, 2 * h)
+            assert R.ref_env_trquant_lfnst(env, comp, 0, 0, cw, chh, qp, li, d, mip, dq, lam, cbf_cb, P(s0), P(s1), P(resi), P(lev), P(ro), C.byref(a), C.byref(qu)) == 0
+            assert np.abs(lev).max() < 32768
+            meta.append((bd, qp, comp, w, h, d, mip, li, dq, cbf_cb, a.value, gi, qu.value)); lam_all.append(lam)
+            resi_all.append(resi.ravel()); lev_all.append(lev.astype(np.int16)); out_all.append(ro)
+    np.savez_compressed(os.path.join(HERE, "lfnst.npz"), meta=np.array(meta, np.int32), lam=np.array(lam_all, np.float64), ctx=np.stack(ctx_all),
+                        resi=np.concatenate(resi_all), lev=np.concatenate(lev_all), resi_out=np.concatenate(out_all))
+    m = np.array(meta)
+    print("lfnst cases", len(meta), "non-zero", int((m[:, 10] > 0).sum()))
+
+
 def gen_chroma_qp():
     """ChromaQpMappingTable (CL/Slice.cpp:1529-1581) for pivot sets given the way the cfg gives them: the reference cfg's, the VTM
     default, a single identity point and a four-point set; 8 and 10 bit."""
@@ -632,7 +687,9 @@ if __name__ == "__main__":
         gen_bitstream_dq(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "depquant":
         gen_depquant(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lfnst":
+        gen_lfnst(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst()
     print("done")

@@ -360,6 +360,39 @@ def test_dependent_quantisation_against_the_reference_trellis():
     assert nz > 400
 
 
+def _lfnst_cases():
+    g = np.load(os.path.join(G, "lfnst.npz"))
+    off = 0
+    for k, row in enumerate(g["meta"]):
+        bd, qp, comp, w, h, d, mip, li, dq, cbf_cb, asum, gi, qp_used = (int(v) for v in row)
+        n = w * h
+        yield dict(bd=bd, qp=qp, comp=comp, w=w, h=h, dir=d, mip=mip, lfnst=li, dq=dq, cbf_cb=cbf_cb, asum=asum, qp_used=qp_used, lam=float(g["lam"][k]), ctx=g["ctx"][gi],
+                   resi=np.ascontiguousarray(g["resi"][off:off + n]), lev=g["lev"][off:off + n], out=g["resi_out"][off:off + n])
+        off += n
+
+
+def test_lfnst_against_the_reference_transform_path():
+    """LFNST (CL/TrQuant.cpp:241-560): levels, absSum and the reconstructed residual of 1290 blocks == the reference's TrQuant::transformNxN /
+    invTransformNxN with cu.lfnstIdx 1 / 2 (kernel set and transposition from the intra mode after wide-angle mapping, planar set for MIP,
+    primary zero-out, DepQuant's first tested position or the plain quantiser's 8 / 16 buffer positions), luma of every shape and Cb / Cr."""
+    L = O.lib()
+    L.orc_trquant_lfnst.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_double] + [C.c_int] * 3 + [C.c_void_p] * 2
+    nz = 0
+    for c in _lfnst_cases():
+        w, h, n = c["w"], c["h"], c["w"] * c["h"]
+        lev = np.zeros(n, np.int16); out = np.zeros(n, np.int16)
+        s0 = np.ascontiguousarray(c["ctx"][0]); s1 = np.ascontiguousarray(c["ctx"][1])
+        d = 0 if c["mip"] else c["dir"]
+        a = L.orc_trquant_lfnst(P(s0), P(s1), P(c["resi"]), w, h, c["comp"], c["cbf_cb"], c["bd"], c["qp_used"], c["lam"], c["dq"], d, c["lfnst"], P(lev), P(out))
+        key = (c["bd"], c["qp"], c["comp"], w, h, c["dir"], c["mip"], c["lfnst"], c["dq"])
+        assert a == c["asum"], ("absSum", key, a, c["asum"])
+        assert np.array_equal(lev, c["lev"]), ("levels", key)
+        if a:
+            nz += 1
+            assert np.array_equal(out, c["out"]), ("resi", key)
+    assert nz > 900
+
+
 def test_slice_data_payload_with_dependent_quantisation():
     """tools 0x953 (+ DepQuant): payloads the reference's CABACReader parsed back with dep_quant_enabled_flag on (state-driven contexts) and whose
     DecCu reconstruction - Quantizer::dequantBlock's state machine included - was the oracle's (tests/golden/make_golden.py bitstream_dq)."""
