@@ -19,6 +19,7 @@ typedef struct {
   uint64_t bits;
   orc_arith *aw;
   int dq;                  /* slice dep_quant_enabled_flag: residual_coding runs the quantiser state machine */
+  int last_scan_pos;       /* scanPosLast of the block coded last */
 } orc_cabac;
 
 static inline void orc_bs_write(orc_arith *a, uint32_t v, int nbits)           /* OutputBitstream::write, MSB first */

@@ -119,13 +119,15 @@ void orc_residual_coding_mts(orc_cabac *cb, const int16_t *coeff, int w, int h, 
   uint8_t sigGroupFlags[64] = { 0 };
   for (int sp = 0; sp < c.nscan; sp++) if (coeff[c.scan[sp]]) { scanPosLast = sp; sigGroupFlags[sp >> c.lcg] = 1; }
   if (scanPosLast < 0) return;   /* reference CHECKs; callers only come here with cbf = 1 */
+  cb->last_scan_pos = scanPosLast;         /* read by the CU-level LFNST signalling (3837-3850) */
 
   /* last_sig_coeff (4102-4160) */
   {
     const int blk = c.scan[scanPosLast];
     int posY = blk / w, posX = blk - posY * w;
     const int gx = ORC_GROUP_IDX[posX], gy = ORC_GROUP_IDX[posY];
-    const int maxX = ORC_GROUP_IDX[imin(32, w) - 1], maxY = ORC_GROUP_IDX[imin(32, h) - 1];
+    /* 4115-4126: with an explicit MTS pair a 32-point side only codes positions below 16 */
+    const int maxX = ORC_GROUP_IDX[(zo && w == 32 ? 16 : imin(32, w)) - 1], maxY = ORC_GROUP_IDX[(zo && h == 32 ? 16 : imin(32, h)) - 1];
     int k;
     for (k = 0; k < gx; k++) orc_enc_bin(cb, 1, ORC_CTX_LastX[c.ch] + c.last_off_x + (k >> c.last_sh_x));
     if (gx < maxX) orc_enc_bin(cb, 0, ORC_CTX_LastX[c.ch] + c.last_off_x + (k >> c.last_sh_x));

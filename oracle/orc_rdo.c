@@ -33,7 +33,7 @@ enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_B
 typedef struct { int x, y, w, h; } area_t;   /* luma samples (UnitArea::Y) */
 
 typedef struct {       /* per 4x4-luma-unit record of the CU covering it, one map per channel type */
-  uint8_t valid, tile, qt_depth, mt_depth, bt_depth, depth, dir, mrl, cbf, lw, lh, mts;
+  uint8_t valid, tile, qt_depth, mt_depth, bt_depth, depth, dir, mrl, cbf, lw, lh, mts, lfnst;
   int16_t x, y;        /* CU origin in channel samples */
   uint64_t split_series;
 } unit_t;
@@ -60,7 +60,7 @@ typedef struct {       /* what the mode controller reads from a CodingStructure 
  * 4-sample units, log2 w, log2 h) like m_bestEncInfo[x][y][wIdx][hIdx] (EL/EncModeCtrl.cpp:706-760).  The reference
  * keeps entries across CTUs and rejects stale ones by comparing poc and absolute area (987-1024); clearing at every
  * CTU start is equivalent.  lev: w*h luma levels, or Cb then Cr (cw*ch each). */
-typedef struct { uint8_t valid, ch, dir, mrl, cbf, depth, mts; uint64_t ss; int16_t *lev; } cache_ent;
+typedef struct { uint8_t valid, ch, dir, mrl, cbf, depth, mts, lfnst; uint64_t ss; int16_t *lev; } cache_ent;
 #define CACHE_ENTRIES (32 * 32 * 6 * 6)
 
 #define MAX_DEPTH 20
@@ -90,7 +90,10 @@ struct orc_enc {
 /* ------------------------------------------------------------------------------------------------ */
 orc_enc *orc_create(const orc_cfg *cfg)
 {
-  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, MTS, DepQuant, CU reuse, CCLM, FAST)", cfg->tools); return 0; }
+  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, LFNST, MTS, DepQuant, CU reuse, CCLM, FAST)", cfg->tools); return 0; }
+  /* the plain quantiser's LFNST branch (CL/Quant.cpp:1054-1058) keeps buffer positions the decoder's LFNST conditions reject: the reference only
+   * ever runs LFNST over DepQuant / RDOQ */
+  if ((cfg->tools & ORC_TOOL_LFNST) && !(cfg->tools & ORC_TOOL_DEPQUANT)) { snprintf(g_err, sizeof g_err, "oracle: LFNST needs DepQuant (tool set 0x%x)", cfg->tools); return 0; }
   if (!cfg->dual_tree || cfg->ctu_size != 128) { snprintf(g_err, sizeof g_err, "oracle: only DualITree=1, CTUSize=128"); return 0; }
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7)) { snprintf(g_err, sizeof g_err, "oracle: picture size must be a multiple of 8 (EncAppCfg.cpp:2709)"); return 0; }
   orc_enc *e = (orc_enc *) calloc(1, sizeof *e);
@@ -516,27 +519,32 @@ static void enc_intra_chroma_pred_mode(orc_enc *e, area_t a, int dir, int lm_ok)
  * (EL/IntraSearch.cpp:2852-3168, CL/TrQuant.cpp:1127-1235)
  * comp: 0 Y 1 Cb 2 Cr; x,y,w,h in component samples; writes rec_out / lev_out tiles (stride w)
  * ---------------------------------------------------------------------------------------------- */
-static uint64_t code_tu_block_mts(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int16_t *rec_out, int16_t *lev_out, int *cbf);
+static uint64_t code_tu_block_ex(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int lfnst_idx, int lfnst_dir, int16_t *rec_out, int16_t *lev_out, int *cbf);
 /* lambda the quantiser sees for a component (RDOQ_CHROMA_LAMBDA: EL/EncSlice.cpp:107-149 setLambdas, EL/IntraSearch.cpp:2889 selectLambda) */
 static double quant_lambda(const orc_enc *e, int comp) { return comp ? e->sl.lambda / e->sl.dist_weight[comp - 1] : e->sl.lambda; }
-static uint64_t code_tu_block(orc_enc *e, int comp, int x, int y, int w, int h, int16_t *rec_out, int16_t *lev_out, int *cbf) { return code_tu_block_mts(e, comp, x, y, w, h, 0, rec_out, lev_out, cbf); }
-static uint64_t code_tu_block_mts(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int16_t *rec_out, int16_t *lev_out, int *cbf)
+static uint64_t code_tu_block(orc_enc *e, int comp, int x, int y, int w, int h, int16_t *rec_out, int16_t *lev_out, int *cbf) { return code_tu_block_ex(e, comp, x, y, w, h, 0, 0, 0, rec_out, lev_out, cbf); }
+static uint64_t code_tu_block_mts(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int16_t *rec_out, int16_t *lev_out, int *cbf) { return code_tu_block_ex(e, comp, x, y, w, h, mts_idx, 0, 0, rec_out, lev_out, cbf); }
+/* lfnst_idx: cu.lfnstIdx (applies to blocks of at least 4x4, CL/TrQuant.cpp:444); lfnst_dir: the block's final intra mode for the kernel choice
+ * (planar for a MIP CU, the co-located luma mode for DM / CCLM chroma, CL/TrQuant.cpp:449-463) */
+static uint64_t code_tu_block_ex(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int lfnst_idx, int lfnst_dir, int16_t *rec_out, int16_t *lev_out, int *cbf)
 {
   const int st = e->stride[comp], bd = e->cfg.bit_depth;
   const int16_t *org = e->org[comp] + y * st + x;
   const int qp = (comp ? e->sl.qp_c[comp - 1] : e->sl.qp) + 6 * (e->cfg.bit_depth - 8);    /* QpParam: + QpBDOffset (CL/Quant.cpp:68-106) */
+  const int lf = (lfnst_idx && w >= 4 && h >= 4) ? lfnst_idx : 0, lmode = lf ? orc_lfnst_mode(lfnst_dir, w, h) : 0;
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) e->resi[j * w + i] = (int16_t) (org[j * st + i] - e->pred[j * w + i]);
   if (!comp) memcpy(e->resi_org, e->resi, (size_t) w * h * 2);      /* the MTS pruning works on the prediction residual */
   orc_fwd_2d_mts(e->resi, w, w, h, bd, mts_idx, e->coef);
+  if (lf) { orc_lfnst_keep(e->coef, w, h); orc_fwd_lfnst(e->coef, w, h, lmode, lf); }       /* xT's zero-out 855-868, xFwdLfnst 1220-1223 */
   int abs_sum;
   if (e->cfg.tools & ORC_TOOL_DEPQUANT) {
     /* DepQuant::quant (CL/DepQuant.cpp:1755-1781) with the estimator's live contexts (EL/IntraSearch.cpp:2968,3024) and the quantiser's lambda of the
      * component: TrQuant::selectLambda (2889) = lambda / distortion weight for chroma (EL/EncSlice.cpp:107-149) */
-    abs_sum = orc_depquant(e->cabac.s0, e->cabac.s1, e->coef, w, h, comp, ORC_CTX_QtCbf[comp] + (comp == 2 ? e->tu_cbf_cb : 0), bd, qp, quant_lambda(e, comp), mts_idx > 1, 0, lev_out);
-    if (abs_sum > 0) { orc_dequant_dq(lev_out, w, h, bd, qp, e->coef); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
+    abs_sum = orc_depquant(e->cabac.s0, e->cabac.s1, e->coef, w, h, comp, ORC_CTX_QtCbf[comp] + (comp == 2 ? e->tu_cbf_cb : 0), bd, qp, quant_lambda(e, comp), mts_idx > 1, lf, lev_out);
+    if (abs_sum > 0) { orc_dequant_dq(lev_out, w, h, bd, qp, e->coef); orc_inv_lfnst(e->coef, w, h, lmode, lf); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
   } else {
-    abs_sum = orc_quant(e->coef, w, h, bd, qp, lev_out);
-    if (abs_sum > 0) { orc_dequant(lev_out, w, h, bd, qp, e->coef); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
+    abs_sum = lf ? orc_quant_lfnst(e->coef, w, h, bd, qp, lev_out) : orc_quant(e->coef, w, h, bd, qp, lev_out);
+    if (abs_sum > 0) { orc_dequant(lev_out, w, h, bd, qp, e->coef); orc_inv_lfnst(e->coef, w, h, lmode, lf); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
   }
   if (abs_sum <= 0) memset(e->resi, 0, (size_t) w * h * 2);
   const int mx = (1 << bd) - 1;
@@ -628,22 +636,40 @@ static void reduce_had_cand_list(minfo *list, double *costs, int *size, int *num
  * ---------------------------------------------------------------------------------------------- */
 /* TU::isMTSAllowed (CL/UnitTools.cpp:4549-4565) for an intra luma TU without ISP / BDPCM: explicit intra MTS on, both sides <= 32 */
 static int mts_allowed(const orc_enc *e, int w, int h) { return (e->cfg.tools & ORC_TOOL_MTS) && w <= 32 && h <= 32; }
-static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts)
+/* What IntraSearch keeps between the passes of one xCheckRDCostIntra call when LFNST is on (m_uiSavedRdModeListLFNST ... 534-566, m_savedRdModeList /
+ * m_modeCostStore / m_bestModeCostStore 884-916, 1262-1290) and the parameters of a pass (cu.lfnstIdx, cu.mtsFlag, the MTS index range = the
+ * transform group, moreProbMTSIdxFirst) */
+typedef struct {
+  int lfnst, mts_flag, tr_grp;                       /* pass: cu.lfnstIdx, cu.mtsFlag, mtsFirstCheckId = mtsLastCheckId = trGrpIdx (moreProbMTSIdxFirst = trGrpIdx > 0) */
+  int lfnst_num, lfnst_size; minfo lfnst_list[80]; double lfnst_cost[80];
+  int rd_num[3]; minfo rd_list[3][80]; double mode_cost[3][80], best_cost[3]; int best_valid[3];
+} luma_passes;
+static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, luma_passes *ps, int *valid, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts)
 {
   const int x = a.x, y = a.y, w = a.w, h = a.h, bd = e->cfg.bit_depth;
   orc_cabac ctxStart; orc_ctx_copy(&ctxStart, &e->cabac);
   const int16_t *org = e->org[0] + y * e->stride[0] + x;
-  int numRd = ORC_MODE_NUM_FAST_2D[(ilog2(w) - 2) * 6 + (ilog2(h) - 2)];
+  const int lfnstOn = (e->cfg.tools & ORC_TOOL_LFNST) != 0, lfnstIdx = lfnstOn ? ps->lfnst : 0, mtsFlag = lfnstOn ? ps->mts_flag : 0;
+  const int useMip = (e->cfg.tools & ORC_TOOL_MIP) != 0;
+  const int numTab = ORC_MODE_NUM_FAST_2D[(ilog2(w) - 2) * 6 + (ilog2(h) - 2)];
+  int numRd = numTab;
   minfo rdList[80]; double rdCost[80]; int rdSize = 0;
   minfo hadList[8]; double hadCost[8]; int hadSize = 0;
-  /* 404-418 with FastMIP 1 (BIN/encoder_intra.cfg): MIP is searched unless the block is more than 2:1; 469-477: the regular list is kept
-   * longer while MIP candidates compete for it */
-  const int testMip = mip_signalled(e, w, h) && !(w > 2 * h || h > 2 * w);
-  if (testMip) numRd += imax(numRd, ilog2(imin(w, h)) - 1);
-  const int numHad = testMip ? 6 : 3;
+  /* 330-341: 0 no MTS for this CU, 1 the DCT-II pass of a CU that also gets MTS passes, 2 an MTS pass (LFNST on: MTS is a CU-level pass) */
+  int mtsUsage = 0;
+  if (w <= 32 && h <= 32 && (e->cfg.tools & ORC_TOOL_MTS)) mtsUsage = (lfnstOn && mtsFlag == 1) ? 2 : 1;
+  const int lfnstLoad = lfnstOn && lfnstIdx != 0; int lfnstSave = lfnstOn && lfnstIdx == 0 && mtsFlag == 0;       /* 314-317 */
+  /* 404-418 (JVET_O0925): MIP is searched wherever it can be signalled; with LFNST only for blocks of at least 16x16; 469-477: the regular list is
+   * kept longer while MIP candidates compete for it */
+  const int lfnstWithMip = w >= 16 && h >= 16;
+  const int testMip = mip_signalled(e, w, h) && (lfnstIdx == 0 || lfnstWithMip);
   uint8_t checked[ORC_NUM_LUMA_MODE]; memset(checked, 0, sizeof checked);
   const int firstLine = (y & 127) == 0;
   const int numRefPasses = (firstLine || !(e->cfg.tools & ORC_TOOL_MRL)) ? 1 : 3;
+  int idxOf[80];                                     /* rdModeIdxList 1097-1122: place of a stage-B candidate in the list before the MIP re-ordering */
+  if (mtsUsage != 2) {
+  if (testMip) numRd += imax(numRd, ilog2(imin(w, h)) - 1);
+  const int numHad = testMip ? 6 : 3;
 
   /* stage A: SATD pre-selection (483-682).  initIntraPatternChType(cu, Y, forceRefFilter=true) */
   build_refs(e, 0, x, y, w, h, 0, 1);
@@ -654,13 +680,20 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
     orc_ctx_copy(&e->cabac, &ctxStart); e->cabac.bits = 0; \
     enc_intra_luma_pred_mode(e, x, y, w, h, (mode_), (mrl_)); \
     (cost_out) = (double) msh_ + (double) e->cabac.bits * e->sqrt_lambda_fp; (had_out) = (double) msh_; e->cnt_satd++; } while (0)
-  for (int mode = 0; mode < ORC_NUM_LUMA_MODE; mode++) {
-    if (mode > ORC_DC && (mode & 1)) continue;
-    checked[mode] = 1;
-    double cost, had; SATD_COST(mode, 0, cost, had);
-    update_cand_list((minfo) { mode, 0 }, cost, rdList, rdCost, &rdSize, numRd);
-    update_cand_list((minfo) { mode, 0 }, had, hadList, hadCost, &hadSize, numHad);
+#define LFNST_SAVE(n_) do { ps->lfnst_num = (n_); ps->lfnst_size = rdSize; memcpy(ps->lfnst_list, rdList, sizeof(minfo) * (size_t) rdSize); memcpy(ps->lfnst_cost, rdCost, sizeof(double) * (size_t) rdSize); lfnstSave = 0; } while (0)
+#define LFNST_LOAD() do { numRd = ps->lfnst_num; rdSize = imin(ps->lfnst_size, ps->lfnst_num); memcpy(rdList, ps->lfnst_list, sizeof(minfo) * (size_t) rdSize); memcpy(rdCost, ps->lfnst_cost, sizeof(double) * (size_t) rdSize); } while (0)
+  if (!lfnstLoad) {
+    for (int mode = 0; mode < ORC_NUM_LUMA_MODE; mode++) {
+      if (mode > ORC_DC && (mode & 1)) continue;
+      checked[mode] = 1;
+      double cost, had; SATD_COST(mode, 0, cost, had);
+      update_cand_list((minfo) { mode, 0 }, cost, rdList, rdCost, &rdSize, numRd);
+      update_cand_list((minfo) { mode, 0 }, had, hadList, hadCost, &hadSize, numHad);
+    }
+    if (!useMip && lfnstSave) LFNST_SAVE(numRd);             /* 534-546 */
   }
+  if (!useMip && lfnstLoad) LFNST_LOAD();                    /* 547-566 */
+  if (!(useMip && lfnstLoad)) {                              /* 568-: the rest of the SATD stage; an LFNST pass with MIP on restores the list instead (763-775) */
   {
     minfo parent[80]; memcpy(parent, rdList, sizeof(minfo) * (size_t) numRd);
     for (int i = 0; i < numRd; i++) {
@@ -690,6 +723,9 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
       }
     }
   }
+  if (lfnstSave && testMip && !lfnstWithMip) {               /* 681-698: the LFNST passes of this CU run without MIP: keep the regular list for them */
+    LFNST_SAVE(numTab); ps->lfnst_size = imin(ps->lfnst_size, numTab);
+  }
   if (testMip) {
     /* 703-748: every MIP mode by SATD into the same list (one entry longer), then reduceHadCandList */
     double mipCost[35];
@@ -703,6 +739,8 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
     }
     reduce_had_cand_list(rdList, rdCost, &rdSize, &numRd, 1.0 + 1.4 / sqrt((double) (w * h)), mipCost, w, h);
   }
+  if (useMip && lfnstSave) LFNST_SAVE(numRd);                /* 750-761 */
+  } else LFNST_LOAD();
 #undef SATD_COST
   {
     /* EL/IntraSearch.cpp:784-802: numCand = PU::getIntraMPMs(...) (1 if left==above dir else 2) */
@@ -716,29 +754,59 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
       if (!incl) { rdList[numRd] = (minfo) { (int) mpm[j], 0 }; rdCost[numRd] = 0; numRd++; }
     }
   }
+  if (lfnstOn && mtsUsage == 1) { ps->rd_num[lfnstIdx] = numRd; memcpy(ps->rd_list[lfnstIdx], rdList, sizeof(minfo) * (size_t) numRd); }      /* 884-889 */
+  } else {
+    /* 891-916: an MTS pass re-tests the DCT-II pass's candidates whose cost stayed within the threshold of its best one (FastLFNST 1) */
+    numRd = 0;
+    if (ps->best_valid[lfnstIdx]) {
+      const double thr = 1.0 + ((lfnstIdx > 0) ? 0.1 : 1.0) * (1.4 / sqrt((double) (w * h)));
+      for (int i = 0; i < ps->rd_num[lfnstIdx]; i++) if (ps->mode_cost[lfnstIdx][i] <= thr * ps->best_cost[lfnstIdx]) rdList[numRd++] = ps->rd_list[lfnstIdx][i];
+    } else { numRd = ps->rd_num[lfnstIdx]; memcpy(rdList, ps->rd_list[lfnstIdx], sizeof(minfo) * (size_t) numRd); }
+  }
 
+  for (int i = 0; i < 80; i++) idxOf[i] = i;
   if (testMip) {
     /* 1097-1122: regular candidates first, MIP candidates after them, each group in list order */
     minfo t[80]; int n = 0;
-    for (int i = 0; i < numRd; i++) if (!(rdList[i].mrl & MIP_FLAG)) t[n++] = rdList[i];
-    for (int i = 0; i < numRd; i++) if (rdList[i].mrl & MIP_FLAG) t[n++] = rdList[i];
+    for (int i = 0; i < numRd; i++) if (!(rdList[i].mrl & MIP_FLAG)) { idxOf[n] = i; t[n++] = rdList[i]; }
+    for (int i = 0; i < numRd; i++) if (rdList[i].mrl & MIP_FLAG) { idxOf[n] = i; t[n++] = rdList[i]; }
     memcpy(rdList, t, sizeof(minfo) * (size_t) numRd);
+  } else {
+    /* 1123-1141: MIP candidates leave the list */
+    int n = 0;
+    for (int i = 0; i < numRd; i++) if (!(rdList[i].mrl & MIP_FLAG)) rdList[n++] = rdList[i];
+    numRd = n;
   }
 
   /* stage B: full RD (1158-1358) */
-  double bestCost = ORC_MAX_DOUBLE; uint64_t bestDist = 0; int bestDir = 0, bestMrl = 0, bestCbf = 0, bestMts = 0;
+  double bestCost = ORC_MAX_DOUBLE; uint64_t bestDist = 0; int bestDir = 0, bestMrl = 0, bestCbf = 0, bestMts = 0, any = 0;
   for (int m = 0; m < numRd; m++) {
     const int dir = rdList[m].mode, mrl = rdList[m].mrl;
     orc_ctx_copy(&e->cabac, &ctxStart);
     /* xIntraCodingTUBlock: initIntraPatternChType without forced filter */
     pred_luma_cand(e, x, y, w, h, dir, mrl);
+    const int mtsAllowed = mts_allowed(e, w, h);
+    double modeCost = ORC_MAX_DOUBLE; uint64_t modeDist = 0; int modeCbf = 0, modeMts = 0;
+    if (lfnstOn) {
+      /* xRecurIntraCodingLumaQT 3340-3640 with LFNST on (no transform skip): one transform per pass -- DCT-II, or for an MTS pass the pair picked
+       * by the transform group: DST7/DST7 in group 0, then (3474-3498, moreProbMTSIdxFirst) the pair the intra mode makes more likely */
+      int mtsIdx = 0;
+      if (mtsFlag) mtsIdx = ps->tr_grp == 0 ? 2 : ps->tr_grp == 1 ? (dir < 34 ? 4 : 3) : ps->tr_grp == 2 ? (dir < 34 ? 3 : 4) : 5;
+      int cbf;
+      const uint64_t dist = code_tu_block_ex(e, 0, x, y, w, h, mtsIdx, lfnstIdx, (mrl & MIP_FLAG) ? ORC_PLANAR : dir, e->tmp_rec[0], e->tmp_lev[0], &cbf);
+      e->cabac.bits = 0;
+      enc_intra_luma_pred_mode(e, x, y, w, h, dir, mrl);
+      orc_enc_bin(&e->cabac, (unsigned) cbf, ORC_CTX_QtCbf[0] + 0);
+      if (cbf) orc_residual_coding_mts(&e->cabac, e->tmp_lev[0], w, h, 0, mtsAllowed ? mtsIdx : -1);
+      modeCost = rd_cost(e, e->cabac.bits, dist); modeDist = dist; modeCbf = cbf; modeMts = mtsIdx;
+      if (mtsUsage == 1) ps->mode_cost[lfnstIdx][idxOf[m]] = modeCost;                       /* 1262-1265 */
+    } else {
     /* xRecurIntraCodingLumaQT 3340-3640 without LFNST / transform skip: transform candidates {DCT2} or, where TU::isMTSAllowed,
      * {DCT2, 2, 3, 4, 5} pruned by TrQuant::transformNxN (1049-1124) on the first (DCT2) pass; every further candidate starts from the
      * start contexts; the loop ends after DCT2 when its cbf is 0; an MTS candidate with cbf 0 is forbidden (cost MAX) */
-    const int mtsAllowed = mts_allowed(e, w, h);
     int test[5] = { 1, 0, 0, 0, 0 };
     static const int idx_of[5] = { 0, 2, 3, 4, 5 };
-    double modeCost = ORC_MAX_DOUBLE; uint64_t modeDist = 0; int modeCbf = 0, modeMts = 0, cbfDCT2 = 1;
+    int cbfDCT2 = 1;
     for (int k = 0; k < (mtsAllowed ? 5 : 1); k++) {
       if (!cbfDCT2) break;
       if (!test[k]) continue;
@@ -761,15 +829,21 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, int *out_dir, int *out
         memcpy(e->tmp_rec[0], e->tmp_rec[1], (size_t) w * h * 2); memcpy(e->tmp_lev[0], e->tmp_lev[1], (size_t) w * h * 2);
       }
     }
+    }
+    any = 1;
     if (modeCost < bestCost) {
       bestCost = modeCost; bestDist = modeDist; bestDir = dir; bestMrl = mrl; bestCbf = modeCbf; bestMts = modeMts;
       memcpy(e->best_rec[0], e->tmp_rec[0], (size_t) w * h * 2); memcpy(e->best_lev[0], e->tmp_lev[0], (size_t) w * h * 2);
+      if (lfnstOn && mtsUsage == 1) { ps->best_cost[lfnstIdx] = bestCost; ps->best_valid[lfnstIdx] = 1; }     /* 1283-1287 */
     }
   }
   orc_ctx_copy(&e->cabac, &ctxStart);
+  *valid = any;
   *out_dir = bestDir; *out_mrl = bestMrl; *out_cbf = bestCbf; *out_mts = bestMts;
   return bestDist;
 }
+#undef LFNST_SAVE
+#undef LFNST_LOAD
 
 /* estIntraPredChromaQT (1382-1686) + xRecurIntraChromaCodingQT (3779-4207), CCLM/JCCR off.
  * a in luma samples.  Winner left in best_rec[0..1]/best_lev[0..1] (Cb,Cr; stride cw). */
@@ -789,7 +863,7 @@ static void cclm_luma(orc_enc *e, int cx, int cy, int cw, int chh, int mdlm, int
 {
   orc_cclm_luma(e->rec[0], e->stride[0], e->avail[1], e->uw, e->cur_tile + 1, e->wc, e->hc, cx, cy, cw, chh, mdlm, info, tmp, CCLM_TSTRIDE);
 }
-static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int lm_ok, int *out_dir, int *out_cbf)
+static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int lm_ok, int lfnst_idx, int *out_dir, int *out_cbf)
 {
   const int cx = a.x >> 1, cy = a.y >> 1, cw = a.w >> 1, chh = a.h >> 1;
   orc_cabac ctxStart; orc_ctx_copy(&ctxStart, &e->cabac);
@@ -835,7 +909,8 @@ static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int lm_ok, int *out_
     for (int c = 1; c <= 2; c++) {
       pred_chroma_comp(e, c, cx, cy, cw, chh, fm, cm == 67 ? tmpLM : tmpMD, cm == 67 ? infoLM : infoMD);
       e->tu_cbf_cb = c == 2 ? cbf[0] : 0;
-      dist += code_tu_block(e, c, cx, cy, cw, chh, rec2[c - 1], lev2[c - 1], &cbf[c - 1]);
+      /* LFNST kernel choice: DM through the final mode, CCLM through the co-located luma mode (CL/TrQuant.cpp:449-457) */
+      dist += code_tu_block_ex(e, c, cx, cy, cw, chh, 0, lfnst_idx, isLM ? colocated_luma_mode(e, a) : fm, rec2[c - 1], lev2[c - 1], &cbf[c - 1]);
       /* xGetIntraFracBitsQTChroma (2625-2692): contexts advance, bits only feed per-component costs */
       orc_enc_bin(&e->cabac, (unsigned) cbf[c - 1], ORC_CTX_QtCbf[c] + (c == 2 ? cbf[0] : 0));
       if (cbf[c - 1]) orc_residual_coding(&e->cabac, lev2[c - 1], cw, chh, 1);
@@ -934,7 +1009,7 @@ static void cache_set_from_cs(orc_enc *e, const partitioner *P, int d)
   const area_t a = P->cur; const int ch = P->ch;
   cache_ent *c = cache_entry(e, a);
   const unit_t *u = &e->store[d].units[0];
-  c->valid = 1; c->ch = (uint8_t) ch; c->dir = u->dir; c->mrl = u->mrl; c->cbf = u->cbf; c->depth = u->depth; c->mts = u->mts; c->ss = u->split_series;
+  c->valid = 1; c->ch = (uint8_t) ch; c->dir = u->dir; c->mrl = u->mrl; c->cbf = u->cbf; c->depth = u->depth; c->mts = u->mts; c->lfnst = u->lfnst; c->ss = u->split_series;
   if (!c->lev) c->lev = (int16_t *) malloc((size_t) a.w * a.h * 2);
   if (!ch) memcpy(c->lev, e->store[d].lev[0], (size_t) a.w * a.h * 2);
   else { const size_t n = (size_t) (a.w >> 1) * (a.h >> 1); memcpy(c->lev, e->store[d].lev[1], n * 2); memcpy(c->lev + n, e->store[d].lev[2], n * 2); }
@@ -1096,12 +1171,13 @@ static int fast_partition(orc_enc *e, partitioner *P, cu_ctx *C)
 
 /* xCheckRDCostIntra (EL/EncCu.cpp:2402-2777), single pass (no LFNST/MTS loops) */
 /* reconstruct one block from given levels: prediction in e->pred; DecCu::xIntraRecBlk (DL/DecCu.cpp:199-414) */
-static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int h, const int16_t *lev, int cbf, int mts_idx, int16_t *rec_out)
+static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int h, const int16_t *lev, int cbf, int mts_idx, int lfnst_idx, int lfnst_dir, int16_t *rec_out)
 {
+  const int lf = (lfnst_idx && w >= 4 && h >= 4) ? lfnst_idx : 0, lmode = lf ? orc_lfnst_mode(lfnst_dir, w, h) : 0;
   const int st = e->stride[comp], bd = e->cfg.bit_depth, mx = (1 << bd) - 1;
   const int16_t *org = e->org[comp] + y * st + x;
   const int qp = (comp ? e->sl.qp_c[comp - 1] : e->sl.qp) + 6 * (e->cfg.bit_depth - 8);    /* QpParam: + QpBDOffset (CL/Quant.cpp:68-106) */
-  if (cbf) { if (e->cfg.tools & ORC_TOOL_DEPQUANT) orc_dequant_dq(lev, w, h, bd, qp, e->coef); else orc_dequant(lev, w, h, bd, qp, e->coef); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
+  if (cbf) { if (e->cfg.tools & ORC_TOOL_DEPQUANT) orc_dequant_dq(lev, w, h, bd, qp, e->coef); else orc_dequant(lev, w, h, bd, qp, e->coef); orc_inv_lfnst(e->coef, w, h, lmode, lf); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
   else memset(e->resi, 0, (size_t) w * h * 2);
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) { int v = e->pred[j * w + i] + e->resi[j * w + i]; rec_out[j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
   uint64_t dd = orc_sse(org, st, rec_out, w, w, h);
@@ -1109,14 +1185,14 @@ static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int
   return dd;
 }
 /* xReuseCachedResult (EL/EncCu.cpp:5665-5771): cached mode + levels re-reconstructed against the current neighbourhood */
-static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts)
+static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts, int *out_lfnst)
 {
   const cache_ent *c = cache_entry(e, a);
   uint64_t dist = 0;
   e->cnt_reuse++;
   if (!ch) {
     pred_luma_cand(e, a.x, a.y, a.w, a.h, c->dir, c->mrl);
-    dist = recon_from_levels(e, 0, a.x, a.y, a.w, a.h, c->lev, c->cbf & 1, c->mts, e->best_rec[0]);
+    dist = recon_from_levels(e, 0, a.x, a.y, a.w, a.h, c->lev, c->cbf & 1, c->mts, c->lfnst, (c->mrl & MIP_FLAG) ? ORC_PLANAR : c->dir, e->best_rec[0]);
     memcpy(e->best_lev[0], c->lev, (size_t) a.w * a.h * 2);
   } else {
     const int cx = a.x >> 1, cy = a.y >> 1, cw = a.w >> 1, chh = a.h >> 1;
@@ -1125,63 +1201,123 @@ static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *ou
     if (fm >= 67 && fm <= 69) cclm_luma(e, cx, cy, cw, chh, fm != 67, tmpC, infoC);
     for (int k = 1; k <= 2; k++) {
       pred_chroma_comp(e, k, cx, cy, cw, chh, fm, tmpC, infoC);
-      dist += recon_from_levels(e, k, cx, cy, cw, chh, c->lev + (size_t) (k - 1) * cw * chh, (c->cbf >> k) & 1, 0, e->best_rec[k - 1]);
+      dist += recon_from_levels(e, k, cx, cy, cw, chh, c->lev + (size_t) (k - 1) * cw * chh, (c->cbf >> k) & 1, 0, c->lfnst, (fm >= 67 && fm <= 69) ? colocated_luma_mode(e, a) : fm, e->best_rec[k - 1]);
       memcpy(e->best_lev[k - 1], c->lev + (size_t) (k - 1) * cw * chh, (size_t) cw * chh * 2);
     }
   }
-  *out_dir = c->dir; *out_mrl = c->mrl; *out_cbf = c->cbf; *out_mts = c->mts;
+  *out_dir = c->dir; *out_mrl = c->mrl; *out_cbf = c->cbf; *out_mts = c->mts; *out_lfnst = c->lfnst;
   return dist;
+}
+
+/* CU-level syntax of one intra CU on the estimator / writer: cu_pred_data + cu_residual (EL/CABACWriter.cpp:1456-1530, 2002-2052): prediction
+ * mode, cbf flags, residual_coding per block and -- LFNST on -- residual_lfnst_mode (3989-4100): the index is present when the CU may use LFNST
+ * (not a MIP CU below 16x16, chroma blocks of at least 4x4, at most 64x64 luma), some block's last position is not DC (lfnstLastScanPos 3844-3850),
+ * no block has a coefficient beyond the LFNST region (violatesLfnstConstrained 3837-3842) and the luma transform is DCT-II.
+ * lev0 / lev1: luma levels, or Cb / Cr levels (stride = block width).  *lfnst_last receives cuCtx.lfnstLastScanPos. */
+static void enc_cu_syntax(orc_enc *e, int ch, area_t a, int dir, int mrl, int cbf, int mts, int lfnst, int lm_ok, const int16_t *lev0, const int16_t *lev1, int *lfnst_last)
+{
+  int lastPos = 0, violates = 0;
+  const int W = a.w >> (ch ? 1 : 0), H = a.h >> (ch ? 1 : 0);
+  const int maxPos = ((W == 4 && H == 4) || (W == 8 && H == 8)) ? 7 : 15;
+  if (!ch) {
+    enc_intra_luma_pred_mode(e, a.x, a.y, a.w, a.h, dir, mrl);
+    orc_enc_bin(&e->cabac, (unsigned) (cbf & 1), ORC_CTX_QtCbf[0]);
+    if (cbf & 1) { orc_residual_coding_mts(&e->cabac, lev0, a.w, a.h, 0, mts_allowed(e, a.w, a.h) ? mts : -1); lastPos |= e->cabac.last_scan_pos >= 1; violates |= e->cabac.last_scan_pos > maxPos; }
+  } else {
+    enc_intra_chroma_pred_mode(e, a, dir, lm_ok);
+    orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 2), ORC_CTX_QtCbf[1]);
+    orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 4), ORC_CTX_QtCbf[2] + !!(cbf & 2));
+    if (cbf & 2) { orc_residual_coding(&e->cabac, lev0, W, H, 1); if (W >= 4 && H >= 4) { lastPos |= e->cabac.last_scan_pos >= 1; violates |= e->cabac.last_scan_pos > maxPos; } }
+    if (cbf & 4) { orc_residual_coding(&e->cabac, lev1, W, H, 1); if (W >= 4 && H >= 4) { lastPos |= e->cabac.last_scan_pos >= 1; violates |= e->cabac.last_scan_pos > maxPos; } }
+  }
+  if (lfnst_last) *lfnst_last = lastPos;
+  if (!(e->cfg.tools & ORC_TOOL_LFNST)) return;
+  if (!ch && (mrl & MIP_FLAG) && !(a.w >= 16 && a.h >= 16)) return;
+  if (ch && imin(W, H) < 4) return;
+  if (a.w > 64 || a.h > 64) return;
+  const int nonDct2 = !ch && (cbf & 1) && mts != 0;
+  if (!lastPos || violates || nonDct2) return;
+  orc_enc_bin(&e->cabac, lfnst ? 1u : 0u, ORC_CTX_LFNSTIdx + 1);                    /* separate trees: context 1 (4077) */
+  if (lfnst) orc_enc_bins_ep(&e->cabac, (uint32_t) (lfnst - 1), 1);
 }
 
 static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs_sum *best, orc_cabac *ctxStart, orc_cabac *ctxBest, int reuse)
 {
   const area_t a = P->cur; const int ch = P->ch, sh = ch ? 1 : 0;
-  cs_sum t; memset(&t, 0, sizeof t);
   unit_t cu; memset(&cu, 0, sizeof cu);
   cu.x = (int16_t) (a.x >> sh); cu.y = (int16_t) (a.y >> sh); cu.lw = (uint8_t) ilog2(a.w >> sh); cu.lh = (uint8_t) ilog2(a.h >> sh);
   cu.qt_depth = (uint8_t) P->qt_depth; cu.mt_depth = (uint8_t) P->mt_depth; cu.bt_depth = (uint8_t) P->bt_depth; cu.depth = (uint8_t) P->depth;
   cu.split_series = part_split_series(P);
-  int dir = 0, mrl = 0, cbf = 0, mts = 0;
-  if (reuse) t.dist = reuse_cached(e, a, ch, &dir, &mrl, &cbf, &mts);
-  else if (!ch) t.dist = est_intra_pred_luma(e, a, &dir, &mrl, &cbf, &mts), cbf = cbf ? 1 : 0;
-  else t.dist = est_intra_pred_chroma(e, a, cclm_allowed(e, a, cu.split_series, cu.depth), &dir, &cbf);
-  cu.dir = (uint8_t) dir; cu.mrl = (uint8_t) mrl; cu.cbf = (uint8_t) cbf; cu.mts = (uint8_t) mts;
-  /* CU-level rate from the node's start contexts (2593-2620) */
-  e->cabac.bits = 0;
-  if (!ch) {
-    enc_intra_luma_pred_mode(e, a.x, a.y, a.w, a.h, dir, mrl);
-    orc_enc_bin(&e->cabac, (unsigned) (cbf & 1), ORC_CTX_QtCbf[0]);
-    if (cbf & 1) orc_residual_coding_mts(&e->cabac, e->best_lev[0], a.w, a.h, 0, mts_allowed(e, a.w, a.h) ? mts : -1);
-  } else {
-    enc_intra_chroma_pred_mode(e, a, dir, cclm_allowed(e, a, cu.split_series, cu.depth));
-    orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 2), ORC_CTX_QtCbf[1]);
-    orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 4), ORC_CTX_QtCbf[2] + !!(cbf & 2));
-    if (cbf & 2) orc_residual_coding(&e->cabac, e->best_lev[0], a.w >> 1, a.h >> 1, 1);
-    if (cbf & 4) orc_residual_coding(&e->cabac, e->best_lev[1], a.w >> 1, a.h >> 1, 1);
-    /* the reuse path prices the CU with CABACWriter::coding_unit, whose end_of_ctu (EL/CABACWriter.cpp:2118-2141) adds the
-     * terminating bin after the last chroma CU of a CTU that does not end the slice */
-    if (reuse && !e->ctu_is_last) {
-      const int endX = a.x + a.w, endY = a.y + a.h;
-      if (((endX & 127) == 0 || endX == e->wl) && ((endY & 127) == 0 || endY == e->hl)) e->cabac.bits += 0x10c;   /* estFracBitsTrm(0), CL/Contexts.h:129 */
+  const int lm_ok = ch ? cclm_allowed(e, a, cu.split_series, cu.depth) : 0;
+  /* the pass loop of xCheckRDCostIntra (2417-2777): transform groups x lfnstIdx x mtsFlag; without LFNST (or for a cached CU) a single pass */
+  const int lfnstOn = (e->cfg.tools & ORC_TOOL_LFNST) != 0 && !reuse;
+  const int considerMts = (e->cfg.tools & ORC_TOOL_MTS) && !ch && a.w <= 32 && a.h <= 32;                      /* 2409 */
+  const int maxLfnstIdx = ((ch && (a.w < 8 || a.h < 8)) || a.w > 64 || a.h > 64) ? 0 : 2;                   /* 2431-2436 */
+  double dct2Cost = ORC_MAX_DOUBLE, trGrpBestCost[4] = { ORC_MAX_DOUBLE, ORC_MAX_DOUBLE, ORC_MAX_DOUBLE, ORC_MAX_DOUBLE };
+  int bestSelFlag[4] = { 0, 0, 0, 0 }, trGrpCheck[4] = { 1, 1, 1, 1 }, bestMtsFlag = 0, bestLfnstIdx = 0;
+  int skipOtherLfnst = 0, startLfnstIdx = 0, endLfnstIdx = lfnstOn ? maxLfnstIdx : 0;
+  const int grpNumMax = lfnstOn ? 4 : 1;
+  static luma_passes ps; memset(ps.best_valid, 0, sizeof ps.best_valid);                                  /* invalidateBestModeCost 2451 */
+  for (int trGrp = 0; trGrp < grpNumMax; trGrp++) {
+    const int startMtsFlag = trGrp > 0, endMtsFlag = lfnstOn ? considerMts : 0;
+    if ((trGrp == 0 || considerMts) && trGrpCheck[trGrp]) {
+      for (int lfnstIdx = startLfnstIdx; lfnstIdx <= endLfnstIdx; lfnstIdx++) {
+        for (int mtsFlag = startMtsFlag; mtsFlag <= endMtsFlag; mtsFlag++) {
+          if (mtsFlag > 0 && lfnstIdx > 0) continue;                                                      /* JVET_O0368 2463-2466 */
+          cs_sum t; memset(&t, 0, sizeof t);
+          int dir = 0, mrl = 0, cbf = 0, mts = 0, lfnst = lfnstIdx, valid = 1;
+          if (reuse) t.dist = reuse_cached(e, a, ch, &dir, &mrl, &cbf, &mts, &lfnst);
+          else if (!ch) {
+            ps.lfnst = lfnstIdx; ps.mts_flag = mtsFlag; ps.tr_grp = trGrp;
+            t.dist = est_intra_pred_luma(e, a, &ps, &valid, &dir, &mrl, &cbf, &mts); cbf = cbf ? 1 : 0;
+            if (lfnstOn && !valid) continue;                                                              /* 2529-2532 */
+          } else t.dist = est_intra_pred_chroma(e, a, lm_ok, lfnstIdx, &dir, &cbf);
+          cu.dir = (uint8_t) dir; cu.mrl = (uint8_t) mrl; cu.cbf = (uint8_t) cbf; cu.mts = (uint8_t) mts; cu.lfnst = (uint8_t) lfnst;
+          /* CU-level rate from the node's start contexts (2593-2620) */
+          e->cabac.bits = 0;
+          int lfnstLast = 0;
+          enc_cu_syntax(e, ch, a, dir, mrl, cbf, mts, lfnst, lm_ok, e->best_lev[0], e->best_lev[1], &lfnstLast);
+          if (ch && reuse && !e->ctu_is_last) {
+            /* the reuse path prices the CU with CABACWriter::coding_unit, whose end_of_ctu (EL/CABACWriter.cpp:2118-2141) adds the
+             * terminating bin after the last chroma CU of a CTU that does not end the slice */
+            const int endX = a.x + a.w, endY = a.y + a.h;
+            if (((endX & 127) == 0 || endX == e->wl) && ((endY & 127) == 0 || endY == e->hl)) e->cabac.bits += 0x10c;   /* estFracBitsTrm(0), CL/Contexts.h:129 */
+          }
+          t.bits = e->cabac.bits;
+          t.cost = rd_cost(e, t.bits, t.dist);
+          /* xEncodeDontSplit (5649-5662) */
+          e->cabac.bits = 0;
+          enc_split_cu_mode(e, P, SPLIT_NONE);
+          t.bits += e->cabac.bits;
+          t.cost = rd_cost(e, t.bits, t.dist);
+          /* 2633-2645: an LFNST index that cannot be signalled (no block with a last position beyond DC) while there are coefficients */
+          if (!reuse && lfnstIdx && !lfnstLast && cbf) t.cost = ORC_MAX_DOUBLE;
+          if (mtsFlag == 0 && lfnstIdx == 0) dct2Cost = t.cost;
+          /* checkSkipOtherLfnst (EL/EncModeCtrl.cpp:2070-2087): the intra passes are the first modes of a node, so its condition always holds */
+          if (lfnstOn) skipOtherLfnst = !cbf;
+          t.n_cu = 1; t.is_split = 0;
+          t.f_bt = t.l_bt = P->bt_depth; t.f_depth = P->depth; t.f_mt = P->mt_depth; t.f_cbf = cbf != 0;
+          t.f_w = t.l_w = a.w >> sh; t.f_h = t.l_h = a.h >> sh; t.max_qt = P->qt_depth;
+          /* xCheckBestMode (677-724) */
+          if (use_mode_result(e, P, C, ETM_INTRA, &t)) {
+            *best = t; C->best = best;
+            store_save_intra(e, d, ch, a, &cu);
+            orc_ctx_copy(ctxBest, &e->cabac);
+            trGrpBestCost[trGrp] = best->cost; bestSelFlag[trGrp] = 1; bestMtsFlag = mtsFlag; bestLfnstIdx = lfnstIdx;      /* 2696-2701 */
+          }
+          orc_ctx_copy(&e->cabac, ctxStart);
+        }
+        if (skipOtherLfnst) { startLfnstIdx = lfnstIdx; endLfnstIdx = lfnstIdx; break; }               /* 2754-2759 */
+      }
+    }
+    if (lfnstOn && trGrp < 3) {                                                                            /* 2763-2773 */
+      trGrpCheck[trGrp + 1] = 0;
+      if (bestSelFlag[trGrp] && considerMts) {
+        const double ratio = dct2Cost / trGrpBestCost[trGrp];
+        trGrpCheck[trGrp + 1] = (bestMtsFlag != 0 || bestLfnstIdx != 0) && ratio < 1.001;
+      }
     }
   }
-  t.bits = e->cabac.bits;
-  t.cost = rd_cost(e, t.bits, t.dist);
-  /* xEncodeDontSplit (5649-5662) */
-  e->cabac.bits = 0;
-  enc_split_cu_mode(e, P, SPLIT_NONE);
-  t.bits += e->cabac.bits;
-  t.cost = rd_cost(e, t.bits, t.dist);
-  t.n_cu = 1; t.is_split = 0;
-  t.f_bt = t.l_bt = P->bt_depth; t.f_depth = P->depth; t.f_mt = P->mt_depth; t.f_cbf = cbf != 0;
-  t.f_w = t.l_w = a.w >> sh; t.f_h = t.l_h = a.h >> sh; t.max_qt = P->qt_depth;
-  /* xCheckBestMode (677-724) */
-  if (use_mode_result(e, P, C, ETM_INTRA, &t)) {
-    *best = t; C->best = best;
-    store_save_intra(e, d, ch, a, &cu);
-    orc_ctx_copy(ctxBest, &e->cabac);
-  }
-  orc_ctx_copy(&e->cabac, ctxStart);
 }
 
 /* xCheckModeSplit (EL/EncCu.cpp:1918-2399) */
@@ -1279,19 +1415,14 @@ static void walk_tree(orc_enc *e, partitioner *P)
   }
   /* coding_unit: cu_pred_data + cu_residual */
   const int W = a.w >> sh, H = a.h >> sh;
-  int16_t *lv = e->tmp_lev[0];
+  int16_t *lv = e->tmp_lev[0], *lv1 = e->tmp_lev[1];
   if (!ch) {
-    enc_intra_luma_pred_mode(e, a.x, a.y, a.w, a.h, u->dir, u->mrl);
-    orc_enc_bin(&e->cabac, u->cbf & 1, ORC_CTX_QtCbf[0]);
-    if (u->cbf & 1) { for (int y = 0; y < H; y++) memcpy(lv + y * W, e->lev[0] + (a.y + y) * e->stride[0] + a.x, (size_t) W * 2); orc_residual_coding_mts(&e->cabac, lv, W, H, 0, mts_allowed(e, W, H) ? u->mts : -1); }
+    if (u->cbf & 1) for (int y = 0; y < H; y++) memcpy(lv + y * W, e->lev[0] + (a.y + y) * e->stride[0] + a.x, (size_t) W * 2);
+    enc_cu_syntax(e, 0, a, u->dir, u->mrl, u->cbf, u->mts, u->lfnst, 0, lv, lv1, 0);
   } else {
-    enc_intra_chroma_pred_mode(e, a, u->dir, cclm_allowed(e, a, u->split_series, u->depth));
-    orc_enc_bin(&e->cabac, !!(u->cbf & 2), ORC_CTX_QtCbf[1]);
-    orc_enc_bin(&e->cabac, !!(u->cbf & 4), ORC_CTX_QtCbf[2] + !!(u->cbf & 2));
-    for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c)) {
-      for (int y = 0; y < H; y++) memcpy(lv + y * W, e->lev[c] + ((a.y >> 1) + y) * e->stride[c] + (a.x >> 1), (size_t) W * 2);
-      orc_residual_coding(&e->cabac, lv, W, H, 1);
-    }
+    for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c))
+      for (int y = 0; y < H; y++) memcpy((c == 1 ? lv : lv1) + y * W, e->lev[c] + ((a.y >> 1) + y) * e->stride[c] + (a.x >> 1), (size_t) W * 2);
+    enc_cu_syntax(e, 1, a, u->dir, u->mrl, u->cbf, u->mts, u->lfnst, cclm_allowed(e, a, u->split_series, u->depth), lv, lv1, 0);
   }
 }
 static void advance_ctx_ctu(orc_enc *e, area_t ctu)
@@ -1353,7 +1484,7 @@ int orc_compress_frame(orc_enc *e, orc_ctu_result *res, orc_cu *cus, int max_cus
           orc_cu *o = &cus[n];
           o->x = u->x; o->y = u->y; o->w = (int16_t) (1 << u->lw); o->h = (int16_t) (1 << u->lh); o->ch_type = (uint8_t) ch;
           o->qt_depth = u->qt_depth; o->bt_depth = u->bt_depth; o->mt_depth = u->mt_depth; o->depth = u->depth;
-          o->intra_dir = u->dir; o->mrl_idx = ch ? u->mrl : (u->mrl & ~MIP_FLAG); o->mip_flag = !ch && (u->mrl & MIP_FLAG) ? 1 : 0; o->cbf = u->cbf; o->mts_idx = u->mts; o->split_series = u->split_series;
+          o->intra_dir = u->dir; o->mrl_idx = ch ? u->mrl : (u->mrl & ~MIP_FLAG); o->mip_flag = !ch && (u->mrl & MIP_FLAG) ? 1 : 0; o->cbf = u->cbf; o->mts_idx = u->mts; o->lfnst_idx = u->lfnst; o->split_series = u->split_series;
         }
         n++;
       }

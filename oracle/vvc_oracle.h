@@ -73,7 +73,8 @@ typedef struct {
   uint8_t  mrl_idx;        /* multiRefIdx 0/1/3 */
   uint8_t  cbf;            /* bit0 Y, bit1 Cb, bit2 Cr */
   uint8_t  mts_idx;        /* luma TU: 0 DCT2xDCT2, 2..5 explicit MTS (tu.mtsIdx) */
-  uint8_t  mip_flag;       /* luma CU: cu.mipFlag; intra_dir is then the MIP mode (oracle only so far: the device refuses VVCX_TOOL_MIP) */
+  uint8_t  mip_flag;       /* luma CU: cu.mipFlag; intra_dir is then the MIP mode */
+  uint8_t  lfnst_idx;      /* cu.lfnstIdx (0..2) */
   uint64_t split_series;
 } orc_cu;
 

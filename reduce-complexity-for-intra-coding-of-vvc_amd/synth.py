@@ -2,15 +2,22 @@
 import numpy as np
 
 
-def synth_frame(width, height, frame=0, bit_depth=8, seed=1234, chroma_texture=0.0):
+def synth_frame(width, height, frame=0, bit_depth=8, seed=1234, chroma_texture=0.0, oriented=0.0):
     """chroma_texture > 0 adds that fraction of the (2x2 averaged) luma texture to Cb and minus half of it to Cr: natural video has
-    such cross-component correlation and the LM chroma modes (CCLM) only win on pictures that have it."""
+    such cross-component correlation and the LM chroma modes (CCLM) only win on pictures that have it.  oriented > 0 adds gratings of that
+    amplitude (8-bit scale) whose direction and period change from one 32x32 block to the next: directional detail is what the angular modes
+    predict and what the mode-dependent secondary transform (LFNST) compacts; white noise alone never selects it."""
     s = 1 if bit_depth == 8 else 4
     mid, a1, a2 = (128, 60, 40) if bit_depth == 8 else (512, 240, 160)
     mx = (1 << bit_depth) - 1
     rng = np.random.default_rng(seed)
     y, x = np.mgrid[0:height, 0:width]
     Y = mid + a1 * np.sin(x / 37.0) + a2 * np.cos(y / 23.0) + 30 * s * (((x // 32) + (y // 32) + frame) % 2) + rng.normal(0, 6 * s, (height, width))
+    if oriented:
+        bx, by = x // 32, y // 32
+        h1 = (bx * 73856093 ^ by * 19349663 ^ (seed * 83492791)) & 0xffff
+        theta = (h1 % 32) * (np.pi / 32.0); period = 2.5 + ((h1 >> 5) % 5)
+        Y = Y + oriented * s * np.sin((x * np.cos(theta) + y * np.sin(theta)) * (2 * np.pi / period))
     yc, xc = np.mgrid[0:height // 2, 0:width // 2]
     U = mid + 20 * s * np.sin(xc / 50.0) + rng.normal(0, 2 * s, (height // 2, width // 2))
     V = mid + 20 * s * np.cos(yc / 40.0) + rng.normal(0, 2 * s, (height // 2, width // 2))

@@ -612,7 +612,18 @@ def gen_bitstream_dq():
     np.savez_compressed(os.path.join(HERE, "bitstream_dq.npz"), **out)
 
 
-def _pictures(cases, tools, texture):
+def gen_bitstream_lfnst():
+    """Decoder round trip with LFNST on (tools 0x95b: + LFNST over MIP, MTS, DepQuant, CCLM): residual_lfnst_mode is parsed back by the reference's CABACReader where the last-position / zero-out conditions allow it, and DecCu
+    applies the inverse LFNST with the kernel set derived from the decoded modes (wide-angle mapping, planar for MIP, co-located luma mode for
+    CCLM / DM chroma): every lfnstIdx, level and reconstructed sample must equal the oracle's."""
+    R.ref_env_set_tools.argtypes = [C.c_void_p, C.c_uint]
+    out = _pictures(((128, 128, 37, 1, 1, 8, 9), (200, 136, 32, 1, 1, 8, 1234), (256, 128, 32, 2, 1, 8, 5), (128, 128, 32, 1, 1, 10, 3)), 0x95b, 0.5, oriented=40.0)
+    np.savez_compressed(os.path.join(HERE, "bitstream_lfnst.npz"), **out)
+    out = _pictures(((128, 128, 37, 1, 1, 8, 9), (136, 72, 27, 1, 1, 8, 5)), 0x85b, 1.5, oriented=40.0)      # no CCLM, strong chroma detail: LFNST on Cb / Cr
+    np.savez_compressed(os.path.join(HERE, "bitstream_lfnst_c.npz"), **out)
+
+
+def _pictures(cases, tools, texture, oriented=0.0):
     import importlib, sys
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -625,10 +636,10 @@ def _pictures(cases, tools, texture):
     pic_meta, pic_bytes, pic_sizes = [], [], []
     for (W, H, qp, tc, tr, bd, seed) in cases:
         sp = pkg.slice_params(qp, bit_depth=bd, dep_quant=bool(tools & 0x40))
-        planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture)
+        planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture, oriented=oriented)
         payload, sizes, cus, lev = O.write_frame(planes, W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools)
         env = R.ref_env_create(W, H, bd); R.ref_env_set_tiles(env, tc, tr)
-        if tools & 0x152:
+        if tools & 0x15a:
             R.ref_env_set_tools(env, tools)
         R.ref_env_reset(env)
         cw, chh = (W + 127) // 128, (H + 127) // 128
@@ -642,7 +653,7 @@ def _pictures(cases, tools, texture):
         nd = R.ref_dec_get_cus(env, P(rows), P(ss), len(rows)); assert nd == len(cus)
         dec = {(int(r[0]), int(r[1]), int(r[2])): (tuple(int(v) for v in r[3:]), int(s)) for r, s in zip(rows[:nd], ss[:nd])}
         for c in cus:
-            exp = ((int(c["w"]), int(c["h"]), int(c["qt_depth"]), int(c["bt_depth"]), int(c["mt_depth"]), int(c["depth"]), int(c["intra_dir"]), int(c["mrl_idx"]) | (int(c["mip_flag"]) << 7), int(c["cbf"]) | (int(c["mts_idx"]) << 8)), int(c["split_series"]))
+            exp = ((int(c["w"]), int(c["h"]), int(c["qt_depth"]), int(c["bt_depth"]), int(c["mt_depth"]), int(c["depth"]), int(c["intra_dir"]), int(c["mrl_idx"]) | (int(c["mip_flag"]) << 7), int(c["cbf"]) | (int(c["mts_idx"]) << 8) | (int(c["lfnst_idx"]) << 16)), int(c["split_series"]))
             assert dec[(int(c["ch_type"]), int(c["x"]), int(c["y"]))] == exp, "decoded CU differs"
         for comp in range(3):
             d = np.zeros_like(lev[comp]); R.ref_dec_get_levels(env, comp, P(d), d.shape[1])
@@ -657,9 +668,11 @@ def _pictures(cases, tools, texture):
         pic_meta.append((W, H, qp, tc, tr, bd, seed, len(payload))); pic_bytes.append(payload); pic_sizes.append(np.pad(sizes, (0, 16 - len(sizes))))
         nlm = int(sum(1 for c in cus if c["ch_type"] == 1 and 67 <= c["intra_dir"] <= 69))
         nmts = int(sum(1 for c in cus if c["ch_type"] == 0 and c["mts_idx"] > 1))
-        print("picture", W, H, qp, tc, tr, bd, "payload", len(payload), "bytes, decoded by the reference:", nd, "CUs,", nlm, "with an LM chroma mode,", nmts, "with an MTS transform,", int(np.count_nonzero(cus["mip_flag"])), "MIP")
+        print("picture", W, H, qp, tc, tr, bd, "payload", len(payload), "bytes, decoded by the reference:", nd, "CUs,", nlm, "with an LM chroma mode,", nmts, "with an MTS transform,", int(np.count_nonzero(cus["mip_flag"])), "MIP,", int(np.count_nonzero(cus["lfnst_idx"])), "LFNST")
     out["pic_meta"] = np.array(pic_meta, np.int32); out["pic_bytes"] = np.concatenate(pic_bytes); out["pic_sizes"] = np.stack(pic_sizes).astype(np.int32)
     out["tools"] = np.array([tools], np.int32); out["chroma_texture"] = np.array([texture], np.float64)
+    if oriented:
+        out["oriented"] = np.array([oriented], np.float64)
     return out
 
 
@@ -687,9 +700,11 @@ if __name__ == "__main__":
         gen_bitstream_dq(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "depquant":
         gen_depquant(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bitstream_lfnst":
+        gen_bitstream_lfnst(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lfnst":
         gen_lfnst(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst()
     print("done")

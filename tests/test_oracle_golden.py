@@ -167,10 +167,11 @@ def test_arithmetic_coder_and_slice_data_payload():
 def _check_pictures(g, pkg):
     tools = int(g["tools"][0]) if "tools" in g else O.TOOLS_DEFAULT
     texture = float(g["chroma_texture"][0]) if "chroma_texture" in g else 0.0
+    oriented = float(g["oriented"][0]) if "oriented" in g else 0.0
     off = 0
     for (W, H, qp, tc, tr, bd, seed, nbytes), sizes in zip(g["pic_meta"], g["pic_sizes"]):
         exp = g["pic_bytes"][off:off + nbytes]; off += int(nbytes)
-        planes = pkg.synth_frame(int(W), int(H), 0, int(bd), int(seed), chroma_texture=texture)
+        planes = pkg.synth_frame(int(W), int(H), 0, int(bd), int(seed), chroma_texture=texture, oriented=oriented)
         payload, sz, _, _ = O.write_frame(planes, int(W), int(H), pkg.slice_params(int(qp), bit_depth=int(bd), dep_quant=bool(tools & 0x40)),
                                           bit_depth=int(bd), tile_cols=int(tc), tile_rows=int(tr), tools=tools)
         assert np.array_equal(sz, sizes[:len(sz)]) and np.array_equal(payload, exp), (W, H, qp, tc, tr, bd)
@@ -191,14 +192,14 @@ def test_slice_data_payload_with_mip_search():
     assert int(g["tools"][0]) & O.TOOL_MIP
     pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
     _check_pictures(g, pkg)
-    # MIP really is chosen, only where the reference allows it, and a MIP CU never carries a reference line index
+    # MIP really is chosen, only where the reference allows it (up to 4:1 blocks: getNumModesMip, CL/UnitTools.cpp:4688-4707), and a MIP CU never carries a reference line index
     planes = pkg.synth_frame(128, 128, 0, 8, 7, chroma_texture=0.5)
     cus = O.write_frame(planes, 128, 128, pkg.slice_params(27), tools=int(g["tools"][0]))[2]
     mip = cus[(cus["ch_type"] == 0) & (cus["mip_flag"] == 1)]
     assert len(mip) > 0 and np.all(mip["mrl_idx"] == 0)
     for c in mip:
         w, h = int(c["w"]), int(c["h"])
-        assert w <= 2 * h and h <= 2 * w and int(c["intra_dir"]) < (35 if w == 4 and h == 4 else 19 if max(w, h) <= 8 else 11)
+        assert w <= 4 * h and h <= 4 * w and int(c["intra_dir"]) < (35 if w == 4 and h == 4 else 19 if max(w, h) <= 8 else 11)
     assert np.all(cus[cus["ch_type"] == 1]["mip_flag"] == 0)
 
 
@@ -391,6 +392,18 @@ def test_lfnst_against_the_reference_transform_path():
             nz += 1
             assert np.array_equal(out, c["out"]), ("resi", key)
     assert nz > 900
+
+
+def test_slice_data_payload_with_lfnst():
+    """tools 0x95b / 0x85b (+ LFNST): payloads the reference's CABACReader parsed back including residual_lfnst_mode, and whose DecCu reconstruction
+    (inverse LFNST with the kernel set derived from the decoded modes) was the oracle's, on pictures with directional detail where LFNST is
+    selected for luma and for chroma CUs (tests/golden/make_golden.py bitstream_lfnst)."""
+    import importlib
+    pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+    for name in ("bitstream_lfnst.npz", "bitstream_lfnst_c.npz"):
+        g = np.load(os.path.join(G, name))
+        assert int(g["tools"][0]) & 0x8
+        _check_pictures(g, pkg)
 
 
 def test_slice_data_payload_with_dependent_quantisation():
