@@ -68,7 +68,7 @@ struct vvcx_handle {
 };
 
 #define VVCX_PAYLOAD_BYTES_PER_CTU 32768u
-static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_MTS | VVCX_TOOL_DEPQUANT | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST;
+static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_LFNST | VVCX_TOOL_MTS | VVCX_TOOL_DEPQUANT | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST;
 
 // Quantizer::initQuantBlock (CL/DepQuant.cpp:694-739) for blocks with log2 w + log2 h = lsum: the quantiser's shift / scale / thresholds and the fixed-point
 // distortion normalisation, which the reference derives in fp64 from lambda.  qp: what QpParam hands over (with QpBDOffset).
@@ -100,6 +100,10 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
 {
   if (!cfg || !out) return fail(VVCX_ERR_ARG, "null argument");
   if (cfg->tools & ~kBuiltTools) return fail(VVCX_ERR_UNSUPPORTED, "tool set 0x%x not built yet (available: 0x%x)", cfg->tools, kBuiltTools);
+  // LFNST is built on top of the dependent quantiser (the reference's plain quantiser keeps positions its own decoder rejects with LFNST, CL/Quant.cpp:1054-1058)
+  // and on the search's MIP form of the saved mode lists (EL/IntraSearch.cpp:750-775)
+  if ((cfg->tools & VVCX_TOOL_LFNST) && (cfg->tools & (VVCX_TOOL_DEPQUANT | VVCX_TOOL_MIP)) != (VVCX_TOOL_DEPQUANT | VVCX_TOOL_MIP))
+    return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_LFNST needs VVCX_TOOL_DEPQUANT and VVCX_TOOL_MIP (tool set 0x%x)", cfg->tools);
   if (cfg->ctu_size != 128 || !cfg->dual_tree) return fail(VVCX_ERR_UNSUPPORTED, "only CTUSize 128 with DualITree 1");
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7) || cfg->pic_w <= 0 || cfg->pic_h <= 0) return fail(VVCX_ERR_ARG, "picture size must be a positive multiple of 8");
   if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return fail(VVCX_ERR_UNSUPPORTED, "bit depth %d", cfg->bit_depth);
@@ -473,7 +477,7 @@ extern "C" int vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus
         if (cus && n < max_cus) {
           vvcx_cu &o = cus[n];
           o.x = u.x; o.y = u.y; o.w = (int16_t) (1 << u.lw); o.h = (int16_t) (1 << u.lh); o.ch_type = (uint8_t) ch;
-          o.qt_depth = u.qt; o.bt_depth = u.bt; o.mt_depth = u.mt; o.depth = u.depth; o.intra_dir = u.dir; o.mrl_idx = u.mrl & 0x7f; o.mip_flag = u.mrl >> 7; o.cbf = u.cbf; o.mts_idx = u.mts; o.split_series = u.ss;
+          o.qt_depth = u.qt; o.bt_depth = u.bt; o.mt_depth = u.mt; o.depth = u.depth; o.intra_dir = u.dir; o.mrl_idx = u.mrl & 0x7f; o.mip_flag = u.mrl >> 7; o.cbf = u.cbf; o.mts_idx = u.mts & 7; o.lfnst_idx = u.mts >> 4; o.split_series = u.ss;
         }
         n++;
       }

@@ -46,6 +46,7 @@ enum { SPLIT_NONE = 0, SPLIT_QT = 1, SPLIT_BH = 2, SPLIT_BV = 3, SPLIT_TH = 4, S
 enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V, ETM_RECO_CACHED };
 #define TOOL_CU_REUSE (1u << 11)
 #define TOOL_MIP (1u << 1)
+#define TOOL_LFNST (1u << 3)
 #define MIPF 0x80                  // a MIP CU: bit 7 of the unit's / candidate's mrl field (MIP forces multiRefIdx 0), the MIP mode in dir / mode
 #define TOOL_MTS (1u << 4)
 #define TOOL_DEPQUANT (1u << 6)
@@ -55,7 +56,7 @@ enum { LM_CHROMA = 67, MDLM_L = 68, MDLM_T = 69 };
 enum { PLANAR = 0, DC = 1, HOR = 18, DIA = 34, VER = 50, VDIA = 66, DM_CHROMA = 70 };
 enum { OP_NONE, OP_DONE, OP_LUMA_PREP, OP_STAGE_A, OP_STAGE_B, OP_CHROMA_RD, OP_SAVE_INTRA, OP_SAVE_PIC, OP_RESTORE_PIC,
        OP_CLEAR_UNITS, OP_CTX_COPY, OP_REUSE, OP_FAST };
-enum { PH_ENTER, PH_FAST_DONE, PH_RUN, PH_A1_DONE, PH_A2_DONE, PH_B_DONE, PH_INTRA_SAVED, PH_CHILD, PH_CHILD_RET, PH_SPLIT_SAVED, PH_ADVANCE, PH_EXIT, PH_EXIT2, PH_A3_DONE };
+enum { PH_ENTER, PH_FAST_DONE, PH_RUN, PH_A1_DONE, PH_A2_DONE, PH_B_DONE, PH_INTRA_SAVED, PH_CHILD, PH_CHILD_RET, PH_SPLIT_SAVED, PH_ADVANCE, PH_EXIT, PH_EXIT2, PH_A3_DONE, PH_PASS, PH_NEXT_PASS };
 enum { CTX_CUR = 0, CTX_START = 1, CTX_BEST = 2, CTX_WAVE = 3 };   // OP_CTX_COPY endpoints
 
 struct Ctx { uint16_t s0[NCTX], s1[NCTX]; };
@@ -88,9 +89,16 @@ struct Cand { uint8_t mode, mrl; };
 struct Arith { uint32_t low, range, buffered_byte; int32_t bits_left, num_buffered; uint32_t bit_acc; int32_t bit_n; uint32_t n; };
 
 struct CtlState {            // controller-private working set (touched by thread 0 only)
-  Cand rdList[80]; double rdCost[80]; int rdSize, numRd;
+  Cand rdList[24]; double rdCost[24]; int rdSize, numRd;      // at most 3 + 4 (+ 1) candidates survive the SATD stage, + 2 MPMs
   uint8_t checked[67];
   int n_a2;
+  // LFNST: the pass loop of xCheckRDCostIntra (EL/EncCu.cpp:2417-2777: transform group x lfnstIdx x mtsFlag) of the node being intra coded, and what
+  // IntraSearch keeps between its passes: the SATD-stage list for the LFNST passes (m_uiSavedRdModeListLFNST, 534-566 / 681-698 / 750-775), the DCT-II
+  // pass's list with its full-RD costs for the MTS passes (m_savedRdModeList / m_modeCostStore / m_bestModeCostStore, 884-916, 1262-1290)
+  int8_t lfOn, grp, lf, mts, startLf, endLf, skipOther, bestMts, bestLf, considerMts, mtsUsage, testMip, lfSaved, bestValid0;
+  uint8_t grpCheck[4], bestSel[4], idxOf[16];
+  double dct2Cost, grpBest[4], modeCost[16], bestCost0;
+  int lfNum, lfSize, mtsNum; Cand lfList[16], mtsList[16];
 };
 
 struct Tables {                    // constant tables staged once per workgroup (LDS latency instead of global latency
@@ -143,7 +151,10 @@ struct Lds {
   uint8_t rb_pairs[VXD_POOL_ITEMS]; int rb_nb;   // batched full-RD stage: the (candidate << 3 | MTS pair) items of the current chunk
   CtlState S; VxUnit cu;           // controller working set; CU record of the intra candidate being evaluated
   unsigned mpm[6], mpm_sorted[6]; int mpm_n;
-  int16_t mip_n, mip_ctx;          // MIP modes of the node (0: no mip_flag) and the context of its mip_flag (3: more than 2:1, not searched)
+  int16_t mip_n, mip_ctx;          // MIP modes of the node (0: no mip_flag) and the context of its mip_flag (3: more than 2:1)
+  // LFNST: the pass of xCheckRDCostIntra being evaluated (cu.lfnstIdx, cu.mtsFlag, transform group); last scan position of the block a wave coded last;
+  // per stage-B / chroma candidate: bit 0 some block's last position is beyond DC, bit 1 some block has a coefficient outside the LFNST region
+  int8_t ps_lfnst, ps_mts, ps_grp, ps_pad; int rc_last[NW]; uint8_t rd_lfl[16];
   int dc_val[4];
   int cur_tile, frame, ctu_x, ctu_y, tree_ch;
   int d;                           // current recursion level
@@ -473,7 +484,7 @@ __device__ __noinline__ void rc_serial(Cab &cb, const int16_t *coeff, int w, int
     const int blk = scan[scanPosLast];
     const int posY = blk >> ilog2i(w), posX = blk & (w - 1);
     const int gx = L.t.group_idx[posX], gy = L.t.group_idx[posY];
-    const int maxX = L.t.group_idx[zw - 1], maxY = L.t.group_idx[zh - 1];
+    const int maxX = L.t.group_idx[((zo && w == 32) ? 16 : zw) - 1], maxY = L.t.group_idx[((zo && h == 32) ? 16 : zh) - 1];      // 4115-4126: a 32-point MTS side codes positions below 16
     int k;
     for (k = 0; k < gx; k++) enc_bin<WR>(cb, 1, VX_CTX_LastX[c.ch] + offx + (k >> shx));
     if (gx < maxX) enc_bin<WR>(cb, 0, VX_CTX_LastX[c.ch] + offx + (k >> shx));
@@ -552,6 +563,7 @@ template <bool WR = false>
 __device__ void residual_coding(Cab &cb, const int16_t *coeff, int w, int h, int is_chroma, uint16_t *scan, int zo = 0)
 {
   const RcPre pre = rc_prepass_serial(coeff, w, h, scan);
+  L.rc_last[0] = pre.last;                                 // thread 0 (estimator pass / writer): read by the CU-level LFNST signalling
   rc_serial<WR>(cb, coeff, w, h, is_chroma, scan, pre, zo);
 }
 // Wave form of residual_coding (same syntax as rc_serial, all 64 lanes working):
@@ -648,6 +660,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
   const int16_t *coeff = SMALL ? L.wm[uni(VTX >> 6)].slot + BUF + uni(lev_off) : coeff_g;
   const RcPre pre = rc_prepass_wave<SMALL>(lev_off, coeff_g, w, h, lane);
   const int last = uni(pre.last);
+  if (lane == 0) L.rc_last[uni(VTX >> 6)] = last;
   if (last < 0) return;
   w = uni(w); h = uni(h); is_chroma = uni(is_chroma);
   const ScanGeo geo = scan_geo(w, h);
@@ -668,7 +681,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
     const int blk = scan_blk(geo, last);
     const int posY = blk >> ilog2i(w), posX = blk & (w - 1);
     const int gx = uni(L.t.group_idx[posX]), gy = uni(L.t.group_idx[posY]);
-    const int maxX = L.t.group_idx[zw - 1], maxY = L.t.group_idx[zh - 1];
+    const int maxX = L.t.group_idx[((zo && w == 32) ? 16 : zw) - 1], maxY = L.t.group_idx[((zo && h == 32) ? 16 : zh) - 1];      // 4115-4126: a 32-point MTS side codes positions below 16
     const int nX = gx + (gx < maxX), nY = gy + (gy < maxY);
     if (lane < nX) bb[lane] = (uint16_t) (((VX_CTX_LastX[is_chroma] + offx + (lane >> shx)) << 1) | (lane < gx));
     if (lane < nY) bb[nX + lane] = (uint16_t) (((VX_CTX_LastY[is_chroma] + offy + (lane >> shy)) << 1) | (lane < gy));
@@ -768,6 +781,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
 }
 
 #include "vvcx_depquant_dev.h"
+#include "vvcx_lfnst_dev.h"
 
 // ------------------------------------------------------------------------------------------------ partitioner (thread 0)
 __device__ int implicit_split(const VxParams &p, Frame &f, int ch)      // CL/UnitPartitioner.cpp:530-581
@@ -1553,8 +1567,10 @@ __device__ void load_tables()
 // the estimator's contexts at this point of the search, cbf_cb: tu.cbf[Cb] when Cr is quantised) and the dequantiser its state machine.
 template <bool SMALL, bool SUMABS = false>
 __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, int buf_off, int16_t *rec_g, int16_t *lev_g, int32_t *tmp_g, int w, int h, int bd, int qp,
-                                int lane, unsigned long long &sse_out, int &cbf_out, int given = -1, int *sumabs_out = nullptr, int comp = 0, int ci = 0, int cbf_cb = 0)
+                                int lane, unsigned long long &sse_out, int &cbf_out, int given = -1, int *sumabs_out = nullptr, int comp = 0, int ci = 0, int cbf_cb = 0,
+                                int lf = 0, int lfmode = 0)
 {
+  // lf: cu.lfnstIdx for a block of at least 4x4 (0 otherwise), lfmode: lfnst_mode() of its final intra mode (dependent quantisation only)
   int coef_sum = 0;                                     // SUMABS: sum of |DCT-II coefficient| for the MTS pruning (TrQuant::transformNxN 1049-1124)
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given);
   const int dq = uni((int) (L.par.tools & TOOL_DEPQUANT)) != 0;
@@ -1564,11 +1580,14 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   int32_t *tmp = SMALL ? L.wm[wave_].tmp : tmp_g;
   const int P = w * h, lw = ilog2i(w), lh = ilog2i(h);
   const int zw = imin(w, 32), zh = imin(h, 32), lzw = imin(lw, 5);
+  lf = uni(lf); lfmode = uni(lfmode);
+  const int lfsb = (w >= 8 && h >= 8) ? 8 : 4;            // with LFNST only the top-left 4x4 / 8x8 of the primary coefficients is kept (xT 855-868)
+  const int fzw = lf ? lfsb : zw, fzh = lf ? lfsb : zh, lfzw = lf ? ilog2i(lfsb) : lzw;
   const int8_t *Mw = dct2_matrix<SMALL>(w), *Mh = dct2_matrix<SMALL>(h);
   const int shift1 = lw + bd + 6 - 15, shift2 = lh + 6;
   const int rnd1 = shift1 > 0 ? 1 << (shift1 - 1) : 0, rnd2 = 1 << (shift2 - 1);
   // stage 1 (horizontal): tmp[k*h + j] = (sum_i Mw[k][i] * resi[j][i] + rnd) >> shift1, k < zw
-  if (given < 0) for (int o = lane; o < zw * h; o += 64) {
+  if (given < 0) for (int o = lane; o < fzw * h; o += 64) {
     const int k = o >> lh, j = o & (h - 1);
     int s = 0;
     if (w >= 4) for (int i = 0; i < w; i += 4) s += dot4_resi(*(const uint32_t *) (Mw + k * w + i), *(const uint2 *) (org + j * w + i), *(const uint2 *) (rec + j * w + i));
@@ -1585,8 +1604,8 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   // stage 2 (vertical) + quant: coef[m*w + k], m < zh, k < zw
   if (given < 0 && (w > 32 || h > 32)) { for (int o = lane; o < P; o += 64) lev[o] = 0; wave_sync(); }
   int abs_sum = 0;
-  if (given < 0) for (int o = lane; o < zw * zh; o += 64) {
-    const int m = o >> lzw, k = o & (zw - 1);
+  if (given < 0) for (int o = lane; o < fzw * fzh; o += 64) {
+    const int m = o >> lfzw, k = o & (fzw - 1);
     int s = 0;
     if (h >= 4) for (int j = 0; j < h; j += 4) s += dot4_s32(*(const uint32_t *) (Mh + m * h + j), *(const I32x4 *) (tmp + k * h + j));
     else for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
@@ -1600,6 +1619,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     q = q < -32768 ? -32768 : q > 32767 ? 32767 : q;
     lev[m * w + k] = (int16_t) q;
   }
+  if (lf && given < 0) { wave_sync(); wave_lfnst_fwd(lev, w, w, h, lfmode, lf, (int32_t *) &L.wm[wave_].ws, lane); }      // xFwdLfnst (TrQuant::transformNxN 1220-1223)
   if (given == -2) {                                    // forward half only (batched full-RD stage): the coefficients stay in lev for the trellis of the batch
     if (SUMABS) *sumabs_out = wave_sum_i32(coef_sum);
     wave_sync();
@@ -1608,7 +1628,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   }
   if (dq && given < 0) {
     wave_sync();
-    abs_sum = wave_depquant<SMALL>(lev, buf_off, L.par.scratch + (size_t) blockIdx.x * L.par.scratch_per_stream, ci, w, h, comp, VX_CTX_QtCbf[comp] + (comp == 2 ? cbf_cb : 0), 0, 0, lane);
+    abs_sum = wave_depquant<SMALL>(lev, buf_off, L.par.scratch + (size_t) blockIdx.x * L.par.scratch_per_stream, ci, w, h, comp, VX_CTX_QtCbf[comp] + (comp == 2 ? cbf_cb : 0), 0, lf, lane);
   } else abs_sum = given < 0 ? uni(wave_sum_i32(abs_sum)) : given;
   if (SUMABS) *sumabs_out = wave_sum_i32(coef_sum);
   wave_sync();
@@ -1621,7 +1641,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     // dequantised coefficients once (they are clipped to 16 bits, Quant::dequant 423-549): deq[m*zw + k], int16 at the start of tmp,
     // followed by the (16-bit clipped) output of the vertical stage: zw*zh + zw*h int16 <= the zw*h int32 the forward pass used
     int16_t *deq = (int16_t *) tmp, *tcol = deq + zw * zh;
-    if (dq) wave_dequant_dq(lev, deq, w, h, zw, zh, bd, qp, lane);
+    if (dq) { wave_dequant_dq(lev, deq, w, h, zw, zh, bd, qp, lane); if (lf) wave_lfnst_inv(deq, zw, w, h, lfmode, lf, (int32_t *) &L.wm[wave_].ws, lane); }      // xInvLfnst (invTransformNxN 593-596)
     else {
     for (int o = lane; o < zw * zh; o += 64) {
       const int m = o >> lzw, k = o & (zw - 1);
@@ -1824,6 +1844,29 @@ __device__ inline void enc_mts_idx(Cab &cb, int mts)
   if (mts) for (int i = 0; i < 3; i++) { const unsigned sym = mts > i + 2; enc_bin<WR>(cb, sym, VX_CTX_MTSIndex + 7 + i); if (!sym) break; }
 }
 __device__ inline int mts_allowed(const VxParams &p, int w, int h) { return (p.tools & TOOL_MTS) && w <= 32 && h <= 32; }     // TU::isMTSAllowed, CL/UnitTools.cpp:4549-4565
+// the transform pair of an MTS pass (LFNST on: MTS is a CU-level pass, xRecurIntraCodingLumaQT 3474-3498): DST7/DST7 in transform group 0, then the pair the
+// intra mode makes more likely first (moreProbMTSIdxFirst), its mirror, DCT8/DCT8
+__device__ inline int pass_mts_idx(int grp, int dir) { return grp == 0 ? 2 : grp == 1 ? (dir < 34 ? 4 : 3) : grp == 2 ? (dir < 34 ? 3 : 4) : 5; }
+// cuCtx.lfnstLastScanPos / violatesLfnstConstrained of one coded block (CABACWriter::residual_coding 3837-3850): bit 0 / bit 1; last = its last scan position
+__device__ inline int lfnst_flags(int last, int w, int h)
+{
+  if (w < 4 || h < 4 || last < 0) return 0;
+  const int maxPos = ((w == 4 && h == 4) || (w == 8 && h == 8)) ? 7 : 15;
+  return (last >= 1 ? 1 : 0) | (last > maxPos ? 2 : 0);
+}
+// CABACWriter::residual_lfnst_mode (3989-4100) of a CU of a separate tree (context 1); w, h: the CU in luma samples; mip: cu.mipFlag (luma);
+// non_dct2: the luma block is coded with an explicit MTS pair; flags: OR of lfnst_flags over the CU's coded blocks.  lane 0 / thread 0
+template <bool WR = false>
+__device__ inline void enc_lfnst_idx(Cab &cb, int ch, int w, int h, int mip, int non_dct2, int flags, int lfnst)
+{
+  if (!(L.par.tools & TOOL_LFNST)) return;
+  if (!ch && mip && !(w >= 16 && h >= 16)) return;
+  if (ch && imin(w >> 1, h >> 1) < 4) return;
+  if (w > 64 || h > 64) return;
+  if (!(flags & 1) || (flags & 2) || non_dct2) return;
+  enc_bin<WR>(cb, lfnst ? 1u : 0u, VX_CTX_LFNSTIdx + 1);
+  if (lfnst) enc_ep<WR>(cb, (uint32_t) (lfnst - 1), 1);
+}
 
 // ------------------------------------------------------------------------------------------------ parallel operations
 // candidate slots: nrec = reconstruction samples held (w*h luma, 2*cw*ch chroma).  Slot 0 of blocks up to 1024 samples is
@@ -2152,13 +2195,13 @@ template <bool SMALL> __device__ __noinline__ void stage_b_loop_mts(const VxPara
 // A wave keeps the best (cost, candidate, transform) item it evaluated parked like stage_b_loop does: the winner of the reference's two nested strict-<
 // loops is the lexicographic minimum of (cost, list position, transform order), which is the minimum of one of the waves.
 template <bool SMALL>
-__device__ void dq_trellis_phase(uint8_t *scratch, int n, int P, int total, int w, int h, int zo, int wave, int lane)
+__device__ void dq_trellis_phase(uint8_t *scratch, int n, int P, int total, int w, int h, int zo, int wave, int lane, int lfnst = 0)
 {
   int16_t *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF); uint8_t *poolNodes = scratch + VXD_OFF_POOL_NODES;
   const int ipw = imin(16, (int) sizeof(WaveMem) / (80 + 2 * total));          // items one wave can hold decisions for
   for (int i0 = wave * ipw; i0 < n; i0 += NW * ipw)
     wave_depquant_batch(imin(ipw, n - i0), poolCoef + (size_t) i0 * P, P, poolNodes + (size_t) i0 * 4 * total, 4 * total, (uint8_t *) &L.wm[wave], i0,
-                        CI_CUR, 0, VX_CTX_QtCbf[0], 0u, w, h, 0, zo, 0, lane);
+                        CI_CUR, 0, VX_CTX_QtCbf[0], 0u, w, h, 0, zo, lfnst, lane);
 }
 template <bool SMALL>
 __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane, int w, int h)
@@ -2166,10 +2209,13 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
   const VxParams &p = L.par;
   const int P = w * h, bd = p.bit_depth, total = imin(32, w) * imin(32, h);
   const int mtsOk = mts_allowed(p, w, h);
+  // LFNST on: one transform per pass for every candidate (DCT-II with the pass's LFNST kernel, or the pass's MTS pair), no per-block MTS pruning
+  const int lfOn = uni((int) (p.tools & TOOL_LFNST)) != 0, psLf = lfOn ? uni((int) L.ps_lfnst) : 0, psMts = lfOn ? uni((int) L.ps_mts) : 0, psGrp = uni((int) L.ps_grp);
+  const int pruneOk = mtsOk && !lfOn;
   int16_t *poolPred = (int16_t *) (scratch + VXD_OFF_POOL), *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF);
   VxRbItem *recA = (VxRbItem *) (scratch + VXD_OFF_POOL_REC), *recB = recA + VXD_POOL_ITEMS;
   const int capItems = imin(VXD_POOL_ITEMS, imin(VXD_POOL_ELEMS / P, VXD_POOL_NODE_BYTES / (4 * total)));
-  const int capCand = imin(16, mtsOk ? imax(1, capItems / 3) : capItems);
+  const int capCand = imin(16, pruneOk ? imax(1, capItems / 3) : capItems);
   const int n_rd = uni(L.n_rd);
   if (lane == 0) L.wave_best[wave] = -1;
   double wbest = MAX_DOUBLE; int wkey = 1 << 30;         // the wave's best item so far: cost, and candidate * 8 + transform order as the tie break
@@ -2192,14 +2238,16 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       wave_sync();
       for (int e = lane; e < P; e += 64) poolPred[(size_t) i * P + e] = rec[e];
       unsigned long long sse; int cbf, sum0 = 0;
-      wave_code_block<SMALL, true>(org, 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf, -2, &sum0);
+      const int mtsC = psMts ? pass_mts_idx(psGrp, mode) : 0;
+      if (mtsC) wave_code_block_mts<SMALL>(org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, mtsC, lane, sse, cbf, -2);
+      else wave_code_block<SMALL, true>(org, 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf, -2, &sum0, 0, 0, 0, psLf, psLf ? lfnst_mode(mip ? PLANAR : mode, w, h) : 0);
       for (int e = lane; e < P; e += 64) poolCoef[(size_t) i * P + e] = lev[e];
       if (lane == 0) { recA[i].sum0 = sum0; recA[i].test = 0; }
     }
     __threadfence_block();
     __syncthreads();
     const long long q1 = STAMP();
-    dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, 0, wave, lane);
+    dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, psMts, wave, lane, psLf);
     __threadfence_block();
     __syncthreads();
     const long long q2 = STAMP();
@@ -2211,14 +2259,16 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       wave_sync();
       const int cbf = uni(L.dq_abs[i]) > 0;
       unsigned long long sse; int cbf2;
-      wave_code_block<SMALL>(org, 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf2, cbf);
+      const int mtsC = psMts ? pass_mts_idx(psGrp, mode) : 0;
+      if (mtsC) wave_code_block_mts<SMALL>(org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, mtsC, lane, sse, cbf2, cbf);
+      else wave_code_block<SMALL>(org, 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf2, cbf, nullptr, 0, 0, 0, psLf, psLf ? lfnst_mode((mrl & MIPF) ? PLANAR : mode, w, h) : 0);
       { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s[e]; }
       wave_sync();
       double cost = 0;
       Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
-      if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, mrl); enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[0]); if (cbf && mtsOk) enc_mts_idx(cb, 0); }
-      if (cbf) residual_coding_wave<SMALL>(cb, 0, lev, w, h, 0, lane, 0);
-      if (lane == 0) { cost = rd_cost(p, cb.bits, sse); recA[i].cost = cost; recA[i].dist = sse; recA[i].bits = cb.bits; recA[i].cbf = cbf; recA[i].wave = wave; }
+      if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, mrl); enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[0]); if (cbf && mtsOk) enc_mts_idx(cb, mtsC); }
+      if (cbf) residual_coding_wave<SMALL>(cb, 0, lev, w, h, 0, lane, mtsC > 1);
+      if (lane == 0) { cost = rd_cost(p, cb.bits, sse); recA[i].cost = cost; recA[i].dist = sse; recA[i].bits = cb.bits; recA[i].cbf = cbf; recA[i].wave = wave; if (lfOn) recA[i].sum0 = (mtsC << 8) | (cbf ? lfnst_flags(L.rc_last[wave], w, h) : 0); }
       cost = lane0_d(cost);
       if (cost < wbest || (cost == wbest && c * 8 < wkey)) {
         wbest = cost; wkey = c * 8;
@@ -2228,7 +2278,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
         { uint32_t *d = (uint32_t *) ctx_ptr(scratch, CTX_START, MAXD + wave, 0); const uint32_t *s = (const uint32_t *) &L.ctxs[CI_W(wave)]; for (int e = lane; e < NCTX; e += 64) d[e] = s[e]; }
       }
       wave_sync();
-      if (mtsOk && cbf) {                                  // TrQuant::transformNxN 1049-1124: which of the explicit MTS pairs stay, by their sums of absolute coefficients
+      if (pruneOk && cbf) {                                // TrQuant::transformNxN 1049-1124: which of the explicit MTS pairs stay, by their sums of absolute coefficients
         int16_t *pr = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur);
         for (int e = lane; e < P; e += 64) pr[e] = poolPred[(size_t) i * P + e];
         wave_sync();
@@ -2311,6 +2361,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       const int i = VTX, c = c0 + i;
       double bc = recA[i].cost; uint64_t bd_ = recA[i].dist, bb = recA[i].bits; int bcbf = recA[i].cbf, bm = 0, bw = recA[i].wave;
       for (int j = 0; j < nB; j++) if ((pi_[j] >> 3) == i) { const double v = recB[j].cost; if (v < bc) { bc = v; bd_ = recB[j].dist; bb = recB[j].bits; bcbf = 1; bm = (pi_[j] & 7) + 1; bw = recB[j].wave; } }
+      if (lfOn) { bm = recA[i].sum0 >> 8; L.rd_lfl[c] = (uint8_t) (recA[i].sum0 & 3); }
       L.rd_cost[c] = bc; L.rd_dist[c] = bd_; L.rd_bits[c] = bb; L.rd_cbf[c] = (uint8_t) bcbf; L.rd_mts[c] = (uint8_t) bm; L.rd_wave[c] = (uint8_t) bw;
     }
     __syncthreads();
@@ -2336,6 +2387,14 @@ __device__ __noinline__ void op_stage_b(const VxParams &p_, uint8_t *scratch)
   if (VTX == 0) { L.win_idx = best; L.win_wave = ww; L.cu_bits = L.rd_bits[best]; }
   ctx_copy_all(&L.ctxs[CI_W(0)], ctx_ptr(scratch, CTX_START, MAXD + ww, 0));
   __syncthreads();
+  if (uni(p.tools & TOOL_LFNST)) {                          // cu_residual ends with residual_lfnst_mode (EL/CABACWriter.cpp:2051)
+    if (VTX == 0) {
+      Cab cb; cb.ci = CI_W(0); cb.bits = 0;
+      enc_lfnst_idx(cb, 0, w, h, (L.rd[best].mrl & MIPF) != 0, L.rd_cbf[best] && L.rd_mts[best] != 0, L.rd_lfl[best], L.ps_lfnst);
+      L.cu_bits += cb.bits;
+    }
+    __syncthreads();
+  }
 }
 
 template <bool SMALL> __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int lane, int w, int h);
@@ -2450,9 +2509,12 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
   double wbest = MAX_DOUBLE;
   int cur = 0;
   const int n_rd = uni(L.n_rd);
+  // LFNST of the pass on both components of blocks of at least 4x4; kernel choice: the final mode, or the co-located luma mode for the LM modes (CL/TrQuant.cpp:449-457)
+  const int psLf = (uni((int) (p.tools & TOOL_LFNST)) && w >= 4 && h >= 4) ? uni((int) L.ps_lfnst) : 0;
+#define CHROMA_LFMODE(c_) (psLf ? lfnst_mode((uni((int) L.rd[c_].mode) >= LM_CHROMA && uni((int) L.rd[c_].mode) <= MDLM_T) ? uni(L.colm) : uni((int) L.rd[c_].mrl), w, h) : 0)
   // ---- C1
   for (int c = wave; c < n_rd; c += NW) {
-    const int fm = uni(L.rd[c].mrl);
+    const int fm = uni(L.rd[c].mrl), lfm = CHROMA_LFMODE(c);
     int16_t *recb = SMALL ? L.wm[wave].slot : slot_rec(scratch, 2 * P, wave, cur), *levb = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, 2 * P, wave, cur);
     for (int k = 0; k < 2; k++) {
       int16_t *rec = recb + k * P, *lev = levb + k * P;
@@ -2460,7 +2522,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
       wave_sync();
       for (int e = lane; e < P; e += 64) poolPred[(size_t) (2 * c + k) * P + e] = rec[e];
       unsigned long long sse; int cbf;
-      wave_code_block<SMALL>(org, k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[k], lane, sse, cbf, -2, nullptr, k + 1, CI_CUR, 0);
+      wave_code_block<SMALL>(org, k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[k], lane, sse, cbf, -2, nullptr, k + 1, CI_CUR, 0, psLf, lfm);
       for (int e = lane; e < P; e += 64) poolCoef[(size_t) (2 * c + k) * P + e] = lev[e];
       wave_sync();
     }
@@ -2472,7 +2534,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
     const int ipw = imin(16, (int) sizeof(WaveMem) / (80 + 2 * total));
     for (int i0 = wave * ipw; i0 < n_rd; i0 += NW * ipw)
       wave_depquant_batch(imin(ipw, n_rd - i0), poolCoef + (size_t) (2 * i0) * P, 2 * P, poolNodes + (size_t) (2 * i0) * 4 * total, 8 * total, (uint8_t *) &L.wm[wave], i0,
-                          CI_CUR, 0, VX_CTX_QtCbf[1], 0u, w, h, 1, 0, 0, lane);
+                          CI_CUR, 0, VX_CTX_QtCbf[1], 0u, w, h, 1, 0, psLf, lane);
   }
   __threadfence_block();
   __syncthreads();
@@ -2481,6 +2543,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
   for (int c0 = 0; c0 < n_rd; c0 += NW) {
     const int c = c0 + wave; const bool have = c < n_rd;
     const int cm = have ? uni(L.rd[c].mode) : 0;
+    const int lfm = have ? CHROMA_LFMODE(c) : 0;
     int16_t *recb = SMALL ? L.wm[wave].slot : slot_rec(scratch, 2 * P, wave, cur), *levb = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, 2 * P, wave, cur);
     unsigned long long dist = 0; int cbfs[2] = { 0, 0 };
     if (have) {
@@ -2489,7 +2552,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
       wave_sync();
       cbfs[0] = uni(L.dq_abs[c]) > 0;
       unsigned long long sse; int cbf2;
-      wave_code_block<SMALL>(org, 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[0], lane, sse, cbf2, cbfs[0], nullptr, 1, CI_W(wave), 0);
+      wave_code_block<SMALL>(org, 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[0], lane, sse, cbf2, cbfs[0], nullptr, 1, CI_W(wave), 0, psLf, lfm);
       dist += (unsigned long long) (p.dist_weight[0] * (double) sse);
       { Cab cb; cb.ci = CI_W(wave); cb.bits = 0; if (lane == 0) enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]); if (cbfs[0]) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane); }
       wave_sync();
@@ -2501,9 +2564,9 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
       const int n4 = imin(NW, n_rd - c0);
       unsigned mask = 0; for (int i = 0; i < n4; i++) mask |= (unsigned) L.rb_pairs[i] << i;
       if (crBatch) { if (wave == 0) wave_depquant_batch(n4, poolCoef + (size_t) (2 * c0 + 1) * P, 2 * P, poolNodes + (size_t) (2 * c0 + 1) * 4 * total, 8 * total, (uint8_t *) &L.wm[0].ws, c0,
-                                                        CI_W(0), 1, VX_CTX_QtCbf[2], mask, w, h, 2, 0, 0, lane); }
+                                                        CI_W(0), 1, VX_CTX_QtCbf[2], mask, w, h, 2, 0, psLf, lane); }
       else if (have) wave_depquant_batch(1, poolCoef + (size_t) (2 * c + 1) * P, 0, poolNodes + (size_t) (2 * c + 1) * 4 * total, 0, (uint8_t *) &L.wm[wave].ws, c,
-                                         CI_W(wave), 0, VX_CTX_QtCbf[2], (unsigned) cbfs[0], w, h, 2, 0, 0, lane);
+                                         CI_W(wave), 0, VX_CTX_QtCbf[2], (unsigned) cbfs[0], w, h, 2, 0, psLf, lane);
     }
     __threadfence_block();
     __syncthreads();
@@ -2513,7 +2576,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
       wave_sync();
       cbfs[1] = uni(L.dq_abs[c]) > 0;
       unsigned long long sse; int cbf2;
-      wave_code_block<SMALL>(org, P, P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[1], lane, sse, cbf2, cbfs[1], nullptr, 2, CI_W(wave), cbfs[0]);
+      wave_code_block<SMALL>(org, P, P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[1], lane, sse, cbf2, cbfs[1], nullptr, 2, CI_W(wave), cbfs[0], psLf, lfm);
       dist += (unsigned long long) (p.dist_weight[1] * (double) sse);
       { Cab cb; cb.ci = CI_W(wave); cb.bits = 0; if (lane == 0) enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]); if (cbfs[1]) residual_coding_wave<SMALL>(cb, P, lev, w, h, 1, lane); }
       wave_sync();
@@ -2525,11 +2588,12 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
           enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]);
           enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]);
         }
-        if (cbfs[0]) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane);
-        if (cbfs[1]) residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane);
+        int fl = 0;
+        if (cbfs[0]) { residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane); fl |= lfnst_flags(uni(L.rc_last[wave]), w, h); }
+        if (cbfs[1]) { residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane); fl |= lfnst_flags(uni(L.rc_last[wave]), w, h); }
         if (lane == 0) {
           cost = rd_cost(p, cb.bits, dist);
-          L.rd_cost[c] = cost; L.rd_dist[c] = dist; L.rd_cbf[c] = (uint8_t) ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 4 : 0));
+          L.rd_cost[c] = cost; L.rd_dist[c] = dist; L.rd_cbf[c] = (uint8_t) ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 4 : 0)); L.rd_lfl[c] = (uint8_t) fl;
         }
       }
       cost = lane0_d(cost);
@@ -2542,6 +2606,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
       wave_sync();
     }
   }
+#undef CHROMA_LFMODE
 }
 template <typename T>
 __device__ __noinline__ void op_chroma_rd(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
@@ -2581,7 +2646,7 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p_, const VxFrameDev &
     }
     if (cbfm & 2) residual_coding_wave<false>(cb, 0, levw, w, h, 1, lane);
     if (cbfm & 4) residual_coding_wave<false>(cb, 0, levw + P, w, h, 1, lane);
-    if (lane == 0) { L.win_idx = best; L.win_wave = ww; L.cu_bits = cb.bits; }
+    if (lane == 0) { enc_lfnst_idx(cb, 1, 2 * w, 2 * h, 0, 0, L.rd_lfl[best], L.ps_lfnst); L.win_idx = best; L.win_wave = ww; L.cu_bits = cb.bits; }
   }
   __syncthreads();
 }
@@ -2639,18 +2704,22 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
     }
     wave_sync();
     int cbf;
-    const int mts = uni(L.rd_mts[0]);
+    const int mts = uni(L.rd_mts[0]), lf = uni((int) L.ps_lfnst);
     if (mts > 1) wave_code_block_mts<SMALL>(org_tile(scratch, n), recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr, mts, lane, dist, cbf, cbfm & 1);
-    else wave_code_block<SMALL>(org_tile(scratch, n), 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr, lane, dist, cbf, cbfm & 1);
+    else wave_code_block<SMALL>(org_tile(scratch, n), 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr, lane, dist, cbf, cbfm & 1, nullptr, 0, 0, 0, lf, lf ? lfnst_mode((fm & MIPF) ? PLANAR : mode, w, h) : 0);
     if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, fm); enc_bin(cb, (unsigned) (cbfm & 1), VX_CTX_QtCbf[0]); if ((cbfm & 1) && mts_allowed(p, w, h)) enc_mts_idx(cb, mts); }
-    if (cbfm & 1) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 0, lane, mts > 1);
+    int fl = 0;
+    if (cbfm & 1) { residual_coding_wave<SMALL>(cb, 0, levb, w, h, 0, lane, mts > 1); fl = lfnst_flags(uni(L.rc_last[0]), w, h); }
+    if (lane == 0) enc_lfnst_idx(cb, 0, w, h, (fm & MIPF) != 0, (cbfm & 1) && mts != 0, fl, lf);
   } else {
+    const int lf = (w >= 4 && h >= 4) ? uni((int) L.ps_lfnst) : 0;
+    const int lfm = lf ? lfnst_mode((mode >= LM_CHROMA && mode <= MDLM_T) ? uni(L.colm) : fm, w, h) : 0;
     for (int k = 0; k < 2; k++) {
       int16_t *rec = recb + k * P;
       chroma_pred_wave(rec, lm_in_buf(scratch, n), k, fm, w, h, bd, lane);
       wave_sync();
       unsigned long long sse; int cbf;
-      wave_code_block<SMALL>(org_tile(scratch, n), k * P, k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1);
+      wave_code_block<SMALL>(org_tile(scratch, n), k * P, k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1, nullptr, k + 1, 0, 0, lf, lfm);
       dist += (unsigned long long) (p.dist_weight[k] * (double) sse);
     }
     if (lane == 0) {
@@ -2658,8 +2727,10 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
       enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
       enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
     }
-    if (cbfm & 2) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane);
-    if (cbfm & 4) residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane);
+    int fl = 0;
+    if (cbfm & 2) { residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane); fl |= lfnst_flags(uni(L.rc_last[0]), w, h); }
+    if (cbfm & 4) { residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane); fl |= lfnst_flags(uni(L.rc_last[0]), w, h); }
+    if (lane == 0) enc_lfnst_idx(cb, 1, 2 * w, 2 * h, 0, 0, fl, uni((int) L.ps_lfnst));
     // coding_unit() ends with end_of_ctu (EL/CABACWriter.cpp:2118-2141): terminating bin after the last chroma CU of a CTU
     // that does not end the slice; estFracBitsTrm(0) = 0x10c (CL/Contexts.h:129)
     const int endX = L.nx + L.nw, endY = L.ny + L.nh;
@@ -3117,6 +3188,56 @@ __device__ __noinline__ void ctrl_mip_merge(int w, int h)
   }
   S.rdSize = tn; S.numRd = tn;
 }
+// thread 0: the full-RD list of a luma pass is in S.rdList[0, numRd): MPM append (777-802) unless the list comes from the DCT-II pass (an MTS pass), the
+// MIP re-ordering (1097-1122) or removal of MIP candidates (1123-1141), then stage B
+__device__ __noinline__ void ctrl_post_stage_b(Frame &f, int append_mpm)
+{
+  CtlState &S = L.S;
+  if (append_mpm) {
+    for (int j = 0; j < L.mpm_n; j++) {
+      int incl = 0;
+      for (int i = 0; i < S.numRd; i++) incl |= (S.rdList[i].mode == L.mpm[j] && S.rdList[i].mrl == 0);
+      if (!incl) { S.rdList[S.numRd].mode = (uint8_t) L.mpm[j]; S.rdList[S.numRd].mrl = 0; S.rdCost[S.numRd] = 0; S.numRd++; }
+    }
+    if (S.lfOn && S.mtsUsage == 1 && S.lf == 0) { S.mtsNum = S.numRd; for (int i = 0; i < S.numRd; i++) S.mtsList[i] = S.rdList[i]; }      // 884-889 (only the list of lfnstIdx 0 is read again)
+  }
+  int n = 0;
+  if (S.testMip) {
+    for (int i = 0; i < S.numRd; i++) if (!(S.rdList[i].mrl & MIPF)) { S.idxOf[n] = (uint8_t) i; L.rd[n++] = S.rdList[i]; }
+    for (int i = 0; i < S.numRd; i++) if (S.rdList[i].mrl & MIPF) { S.idxOf[n] = (uint8_t) i; L.rd[n++] = S.rdList[i]; }
+  } else
+    for (int i = 0; i < S.numRd; i++) if (!(S.rdList[i].mrl & MIPF)) { S.idxOf[n] = (uint8_t) n; L.rd[n++] = S.rdList[i]; }
+  L.n_rd = n;
+  f.phase = PH_B_DONE;
+  post(OP_STAGE_B);
+}
+// thread 0: step the (transform group, lfnstIdx, mtsFlag) loops of xCheckRDCostIntra (2453-2775) after a pass; returns 0 when no pass is left
+__device__ __noinline__ int ctrl_next_pass()
+{
+  CtlState &S = L.S;
+  int g = S.grp, lf = S.lf, m = S.mts + 1;
+  for (;;) {
+    const int endM = S.considerMts;
+    if (m > endM) {                                        // the mtsFlag loop of this lfnstIdx is over
+      int endOfLf = 0;
+      if (S.skipOther) { S.startLf = (int8_t) lf; S.endLf = (int8_t) lf; endOfLf = 1; }      // 2754-2759
+      else { lf++; m = g > 0; if (lf > S.endLf) endOfLf = 1; }
+      while (endOfLf) {                                    // end of a transform group (2763-2773), on to the next one that is checked
+        if (g < 3) {
+          S.grpCheck[g + 1] = 0;
+          if (S.bestSel[g] && S.considerMts) S.grpCheck[g + 1] = (uint8_t) ((S.bestMts != 0 || S.bestLf != 0) && S.dct2Cost / S.grpBest[g] < 1.001);
+        }
+        g++;
+        if (g >= 4) return 0;
+        if (S.considerMts && S.grpCheck[g]) { lf = S.startLf; m = 1; endOfLf = lf > S.endLf; }
+      }
+      continue;
+    }
+    if (m > 0 && lf > 0) { m++; continue; }                // JVET_O0368: no LFNST with an MTS pair
+    S.grp = (int8_t) g; S.lf = (int8_t) lf; S.mts = (int8_t) m;
+    return 1;
+  }
+}
 __device__ __noinline__ int ctrl_b_done(const VxParams &p_, const VxFrameDev &fd_)
 {
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
@@ -3130,7 +3251,7 @@ __device__ __noinline__ int ctrl_b_done(const VxParams &p_, const VxFrameDev &fd
       Sum &t = f.temp;
       t.dist = L.rd_dist[best];
       VxUnit &cu = L.cu;
-      cu.dir = L.rd[best].mode; cu.mrl = ch ? 0 : L.rd[best].mrl; cu.cbf = L.rd_cbf[best]; cu.mts = ch ? 0 : L.rd_mts[best];
+      cu.dir = L.rd[best].mode; cu.mrl = ch ? 0 : L.rd[best].mrl; cu.cbf = L.rd_cbf[best]; cu.mts = (uint8_t) ((ch ? 0 : L.rd_mts[best]) | (L.ps_lfnst << 4));      // lfnstIdx rides in bits 4-5
       // cu_pred_data + cu_residual bits (EL/EncCu.cpp:2593-2619) and the CU's end contexts are left in cu_bits / wctx[0]
       // by the operation (luma: identical to the stage-B syntax from the same start contexts)
       t.bits = L.cu_bits;
@@ -3140,7 +3261,19 @@ __device__ __noinline__ int ctrl_b_done(const VxParams &p_, const VxFrameDev &fd
       t.cost = rd_cost(p, t.bits, t.dist);
       t.n_cu = 1; t.f_bt = t.l_bt = f.bt; t.f_cbf = cu.cbf != 0; t.f_w = t.l_w = (int16_t) (f.w >> sh); t.f_h = t.l_h = (int16_t) (f.h >> sh); t.max_qt = f.qt; t.valid = 1;
       f.phase = PH_ADVANCE;
+      CtlState &S = L.S;
+      if (S.lfOn) {                                     // a pass of the LFNST / MTS loop (2633-2760)
+        if (!ch && S.mtsUsage == 1 && S.lf == 0) {      // 1262-1290: the DCT-II pass's costs steer the candidate choice of the MTS passes
+          for (int c = 0; c < L.n_rd; c++) S.modeCost[S.idxOf[c]] = L.rd_cost[c];
+          S.bestCost0 = L.rd_cost[best]; S.bestValid0 = 1;
+        }
+        if (S.lf && !(L.rd_lfl[best] & 1) && cu.cbf) t.cost = MAX_DOUBLE;      // 2633-2645: an LFNST index that cannot be signalled
+        if (S.mts == 0 && S.lf == 0) S.dct2Cost = t.cost;
+        S.skipOther = (int8_t) !cu.cbf;                 // checkSkipOtherLfnst (EL/EncModeCtrl.cpp:2070-2087): the intra passes are a node's first modes, its condition always holds
+        f.phase = PH_NEXT_PASS;
+      }
       if (use_mode_result(p, f, ch, ETM_INTRA, t)) {
+        if (S.lfOn) { S.grpBest[S.grp] = t.cost; S.bestSel[S.grp] = 1; S.bestMts = S.mts; S.bestLf = S.lf; }      // 2696-2701
         f.best = t; f.has_best = 1;
         set_node(f, d);
         L.op_c = f.nmodes > 1;                          // ETM_POST_DONT_SPLIT still on the stack (not a single predicted mode): its setFromCs caches this result
@@ -3194,7 +3327,8 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         cu.ss = f.ss; cu.x = (int16_t) (f.x >> sh); cu.y = (int16_t) (f.y >> sh); cu.lw = (uint8_t) ilog2i(f.w >> sh); cu.lh = (uint8_t) ilog2i(f.h >> sh);
         cu.qt = f.qt; cu.mt = f.mt; cu.bt = f.bt; cu.depth = f.depth; cu.dir = 0; cu.mrl = 0; cu.cbf = 0; cu.mts = 0; cu.tag = (uint16_t) (tile + 1);
         if (mode == ETM_RECO_CACHED) {                  // xReuseCachedResult (EL/EncCu.cpp:5665-5771)
-          L.rd[0].mode = f.r_dir; L.rd[0].mrl = f.r_mrl; L.rd_cbf[0] = f.r_cbf; L.rd_mts[0] = ch ? 0 : f.r_mts; L.n_rd = 0;
+          L.rd[0].mode = f.r_dir; L.rd[0].mrl = f.r_mrl; L.rd_cbf[0] = f.r_cbf; L.rd_mts[0] = ch ? 0 : (f.r_mts & 7); L.n_rd = 0;
+          L.ps_lfnst = (int8_t) (f.r_mts >> 4); L.ps_mts = 0; L.ps_grp = 0; S.lfOn = 0;
           if (!ch) {                                    // MPM list for intra_luma_pred_modes
             int Ld, Ad; luma_neighbours(p, fd, f.x, f.y, f.w, f.h, tile, Ld, Ad);
             derive_mpms(Ld, Ad, L.mpm);
@@ -3208,39 +3342,15 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
           f.phase = PH_B_DONE;
           post(OP_REUSE); return;
         }
-        if (!ch) {
-          // MPM list of the node (PU::getIntraMPMs neighbours, CL/UnitTools.cpp:516-532)
-          int Ld, Ad; luma_neighbours(p, fd, f.x, f.y, f.w, f.h, tile, Ld, Ad);
-          derive_mpms(Ld, Ad, L.mpm); L.mpm_n = (Ld == Ad) ? 1 : 2;
-          // stage A candidate list, phase 1: 35 even modes + MRL MPM candidates (costs are order independent)
-          int n = 0;
-          for (int m = 0; m < 67; m++) { S.checked[m] = 0; if (m > DC && (m & 1)) continue; L.cand[n].mode = (uint8_t) m; L.cand[n].mrl = 0; n++; S.checked[m] = 1; }
-          if ((f.y & 127) != 0 && (p.tools & 1))
-            for (int r = 1; r < 3; r++) for (int k = 1; k < 6; k++) { L.cand[n].mode = (uint8_t) L.mpm[k]; L.cand[n].mrl = (uint8_t) (r == 1 ? 1 : 3); n++; }
-          L.n_cand = n;
-          S.numRd = L.t.mode_num[(ilog2i(f.w) - 2) * 6 + (ilog2i(f.h) - 2)];
-          // EL/IntraSearch.cpp:404-418,469-477 with FastMIP 1: MIP is searched unless the block is more than 2:1 (mip_ctx 3); the regular list is
-          // kept longer while the MIP candidates compete for it
-          if (L.mip_n && L.mip_ctx != 3) S.numRd += imax(S.numRd, ilog2i(imin(f.w, f.h)) - 1);
-          f.phase = PH_A1_DONE;
-          L.op_a = 0; L.op_b = n; L.op_c = 1; post(OP_LUMA_PREP); return;      // prep, then stage A on [0,n)
-        } else {
-          // chroma candidate modes (PU::getIntraChromaCandModes, CL/UnitTools.cpp:840-873), LM modes disabled
-          const int cx = f.x + (f.w >> 1), cy = f.y + (f.h >> 1);
-          const int lm = unit_ldir(fd.units[0][(cy >> 2) * p.uw + (cx >> 2)]);      // getCoLocatedIntraLumaMode 949-960
-          L.colm = lm;
-          int list[8] = { PLANAR, VER, HOR, DC, LM_CHROMA, MDLM_L, MDLM_T, DM_CHROMA };
-          for (int i = 0; i < 4; i++) if (lm == list[i]) { list[i] = VDIA; break; }
-          L.lm_ok = cclm_allowed(p, fd, f.x, f.y, f.ss, f.depth); L.lm_nsatd = 0;
-          int n = 0;
-          for (int i = 0; i < 8; i++) {
-            if (!L.lm_ok && list[i] >= LM_CHROMA && list[i] <= MDLM_T) continue;      // EL/IntraSearch.cpp:1588-1591
-            L.rd[n].mode = (uint8_t) list[i]; L.rd[n].mrl = (uint8_t) (list[i] == DM_CHROMA ? lm : list[i]); n++;
-          }
-          L.n_rd = n;
-          f.phase = PH_B_DONE;
-          post(OP_CHROMA_RD); return;
-        }
+        // the pass loop of xCheckRDCostIntra (2417-2452): without LFNST a single pass
+        S.lfOn = (int8_t) ((p.tools & TOOL_LFNST) != 0);
+        S.grp = 0; S.lf = 0; S.mts = 0; S.startLf = 0; S.skipOther = 0; S.bestMts = 0; S.bestLf = 0; S.bestValid0 = 0; S.lfSaved = 0;
+        S.endLf = (int8_t) ((!S.lfOn || (ch && (f.w < 8 || f.h < 8)) || f.w > 64 || f.h > 64) ? 0 : 2);                 // 2431-2449
+        S.considerMts = (int8_t) (S.lfOn && (p.tools & TOOL_MTS) && !ch && f.w <= 32 && f.h <= 32);                      // 2409 (as the MTS passes' loop bound)
+        S.dct2Cost = MAX_DOUBLE;
+        for (int i = 0; i < 4; i++) { S.grpCheck[i] = 1; S.bestSel[i] = 0; S.grpBest[i] = MAX_DOUBLE; }
+        f.phase = PH_PASS;
+        break;
       }
       if (mode == ETM_POST_DONT_SPLIT) { f.phase = PH_ADVANCE; break; }
       // ---- xCheckModeSplit (EL/EncCu.cpp:1918-2399)
@@ -3270,6 +3380,66 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         post(OP_CLEAR_UNITS); return;          // tempCS->initStructData: nothing of this node is coded yet
       }
     }
+    case PH_PASS: {                                     // one (lfnstIdx, mtsFlag) pass: estIntraPredLumaQT / estIntraPredChromaQT with cu.lfnstIdx, cu.mtsFlag set
+      L.ps_lfnst = S.lf; L.ps_mts = S.mts; L.ps_grp = S.grp;
+      set_node(f, d);
+      if (!ch) {
+        S.mtsUsage = (int8_t) ((f.w <= 32 && f.h <= 32 && (p.tools & TOOL_MTS)) ? ((S.lfOn && S.mts == 1) ? 2 : 1) : 0);           // 330-341
+        if (S.lf == 0 && S.mts == 0) {
+          // MPM list of the node (PU::getIntraMPMs neighbours, CL/UnitTools.cpp:516-532) and its number of MIP modes
+          int Ld, Ad; luma_neighbours(p, fd, f.x, f.y, f.w, f.h, tile, Ld, Ad);
+          derive_mpms(Ld, Ad, L.mpm); L.mpm_n = (Ld == Ad) ? 1 : 2;
+        }
+        S.testMip = (int8_t) (L.mip_n && (S.lf == 0 || (f.w >= 16 && f.h >= 16)));                                               // 404-418 (JVET_O0925) + allowLfnstWithMip
+        if (S.lf == 0 && S.mts == 0) {
+          // stage A candidate list, phase 1: 35 even modes + MRL MPM candidates (costs are order independent)
+          int n = 0;
+          for (int m = 0; m < 67; m++) { S.checked[m] = 0; if (m > DC && (m & 1)) continue; L.cand[n].mode = (uint8_t) m; L.cand[n].mrl = 0; n++; S.checked[m] = 1; }
+          if ((f.y & 127) != 0 && (p.tools & 1))
+            for (int r = 1; r < 3; r++) for (int k = 1; k < 6; k++) { L.cand[n].mode = (uint8_t) L.mpm[k]; L.cand[n].mrl = (uint8_t) (r == 1 ? 1 : 3); n++; }
+          L.n_cand = n;
+          S.numRd = L.t.mode_num[(ilog2i(f.w) - 2) * 6 + (ilog2i(f.h) - 2)];
+          // EL/IntraSearch.cpp:469-477: the regular list is kept longer while the MIP candidates compete for it
+          if (S.testMip) S.numRd += imax(S.numRd, ilog2i(imin(f.w, f.h)) - 1);
+          f.phase = PH_A1_DONE;
+          L.op_a = 0; L.op_b = n; L.op_c = 1; post(OP_LUMA_PREP); return;      // prep, then stage A on [0,n)
+        }
+        if (S.mtsUsage == 2) {                          // 891-916: an MTS pass re-tests the DCT-II pass's candidates whose cost stayed close to its best (FastLFNST 1)
+          S.numRd = 0;
+          if (S.bestValid0) {
+            const int k2 = ilog2i(f.w) + ilog2i(f.h);
+            const double root = (k2 & 1) ? 0x1.6a09e667f3bcdp+0 * (double) (1 << (k2 >> 1)) : (double) (1 << (k2 >> 1));
+            const double thr = 1.0 + 1.4 / root;
+            for (int i = 0; i < S.mtsNum; i++) if (S.modeCost[i] <= thr * S.bestCost0) S.rdList[S.numRd++] = S.mtsList[i];
+          } else { S.numRd = S.mtsNum; for (int i = 0; i < S.mtsNum; i++) S.rdList[i] = S.mtsList[i]; }
+          ctrl_post_stage_b(f, 0); return;
+        }
+        // an LFNST pass: the SATD-stage list of the first pass (763-775), then the MPMs again
+        S.numRd = S.lfNum; { const int n = imin(S.lfSize, S.lfNum); for (int i = 0; i < n; i++) { S.rdList[i] = S.lfList[i]; S.rdCost[i] = 0; } }
+        ctrl_post_stage_b(f, 1); return;
+      } else {
+        // chroma candidate modes (PU::getIntraChromaCandModes, CL/UnitTools.cpp:840-873), LM modes disabled
+        const int cx = f.x + (f.w >> 1), cy = f.y + (f.h >> 1);
+        const int lm = unit_ldir(fd.units[0][(cy >> 2) * p.uw + (cx >> 2)]);      // getCoLocatedIntraLumaMode 949-960
+        L.colm = lm;
+        int list[8] = { PLANAR, VER, HOR, DC, LM_CHROMA, MDLM_L, MDLM_T, DM_CHROMA };
+        for (int i = 0; i < 4; i++) if (lm == list[i]) { list[i] = VDIA; break; }
+        L.lm_ok = cclm_allowed(p, fd, f.x, f.y, f.ss, f.depth); L.lm_nsatd = 0;
+        int n = 0;
+        for (int i = 0; i < 8; i++) {
+          if (!L.lm_ok && list[i] >= LM_CHROMA && list[i] <= MDLM_T) continue;      // EL/IntraSearch.cpp:1588-1591
+          L.rd[n].mode = (uint8_t) list[i]; L.rd[n].mrl = (uint8_t) (list[i] == DM_CHROMA ? lm : list[i]); n++;
+        }
+        L.n_rd = n;
+        f.phase = PH_B_DONE;
+        post(OP_CHROMA_RD); return;
+      }
+    }
+    case PH_NEXT_PASS: {
+      if (ctrl_next_pass()) { VxUnit &cu = L.cu; cu.dir = 0; cu.mrl = 0; cu.cbf = 0; cu.mts = 0; f.phase = PH_PASS; }
+      else f.phase = PH_ADVANCE;
+      break;
+    }
     case PH_A1_DONE: {                                  // EL/IntraSearch.cpp:489-623; the top-numRd list was selected by the operation
       L.cnt[0] += (unsigned long long) L.n_cand;
       int n = L.n_cand; S.n_a2 = 0;
@@ -3283,29 +3453,26 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
     }
     case PH_A2_DONE:
     case PH_A3_DONE: {                                  // [703-748 MIP candidates,] 777-802 MPM append, then stage B
-      const int testMip = L.mip_n && L.mip_ctx != 3;
+      const int testMip = S.testMip;
       if (f.phase == PH_A2_DONE) {
         L.cnt[0] += (unsigned long long) S.n_a2;
+        if (S.lfOn && testMip && !(f.w >= 16 && f.h >= 16)) {      // 681-698: the LFNST passes of this CU run without MIP: keep the regular list for them
+          S.lfNum = L.t.mode_num[(ilog2i(f.w) - 2) * 6 + (ilog2i(f.h) - 2)]; S.lfSize = imin(S.rdSize, S.lfNum);
+          for (int i = 0; i < S.lfSize; i++) S.lfList[i] = S.rdList[i];
+          S.lfSaved = 1;
+        }
         if (testMip) {                                  // every MIP mode by SATD; the regular candidates are in the list, their buffer is free
           for (int m = 0; m < L.mip_n; m++) { L.cand[m].mode = (uint8_t) m; L.cand[m].mrl = MIPF; }
           f.phase = PH_A3_DONE;
           L.op_a = 0; L.op_b = L.mip_n; L.op_c = 2; post(OP_STAGE_A); return;
         }
       } else ctrl_mip_merge(f.w, f.h);
-      for (int j = 0; j < L.mpm_n; j++) {
-        int incl = 0;
-        for (int i = 0; i < S.numRd; i++) incl |= (S.rdList[i].mode == L.mpm[j] && S.rdList[i].mrl == 0);
-        if (!incl) { S.rdList[S.numRd].mode = (uint8_t) L.mpm[j]; S.rdList[S.numRd].mrl = 0; S.rdCost[S.numRd] = 0; S.numRd++; }
+      if (S.lfOn && !S.lfSaved) {                       // 750-761: the list the LFNST passes start from
+        S.lfNum = S.numRd; S.lfSize = imin(S.rdSize, 16);
+        for (int i = 0; i < S.lfSize; i++) S.lfList[i] = S.rdList[i];
+        S.lfSaved = 1;
       }
-      if (testMip) {                                    // 1097-1122: regular candidates first, MIP candidates after them, each group in list order
-        int n = 0;
-        for (int i = 0; i < S.numRd; i++) if (!(S.rdList[i].mrl & MIPF)) L.rd[n++] = S.rdList[i];
-        for (int i = 0; i < S.numRd; i++) if (S.rdList[i].mrl & MIPF) L.rd[n++] = S.rdList[i];
-      } else
-      for (int i = 0; i < S.numRd; i++) L.rd[i] = S.rdList[i];
-      L.n_rd = S.numRd;
-      f.phase = PH_B_DONE;
-      post(OP_STAGE_B); return;
+      ctrl_post_stage_b(f, 1); return;
     }
     case PH_B_DONE: {                                   // only reached when an operation was dispatched without the fused tail (see after_intra_op)
       if (ctrl_b_done(p, fd)) { post(OP_SAVE_INTRA); return; }
@@ -3403,15 +3570,20 @@ __device__ __noinline__ void walk_tree(const VxParams &p_, const VxFrameDev &fd_
           derive_mpms(Ld, Ad, L.mpm);
           enc_intra_luma_pred_mode<WR>(cb, f.y, u->dir, u->mrl);
           enc_bin<WR>(cb, u->cbf & 1, VX_CTX_QtCbf[0]);
-          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; if (mts_allowed(p, W, H)) enc_mts_idx<WR>(cb, u->mts); residual_coding<WR>(cb, lv, W, H, 0, (uint16_t *) (lv + 4096), u->mts > 1); }
+          int fl = 0;
+          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; if (mts_allowed(p, W, H)) enc_mts_idx<WR>(cb, u->mts & 7); residual_coding<WR>(cb, lv, W, H, 0, (uint16_t *) (lv + 4096), (u->mts & 7) > 1); fl = lfnst_flags(L.rc_last[0], W, H); }
+          enc_lfnst_idx<WR>(cb, 0, W, H, (u->mrl & MIPF) != 0, (u->cbf & 1) && (u->mts & 7) != 0, fl, u->mts >> 4);
         } else {
+          int fl = 0;
           enc_intra_chroma_pred_mode<WR>(cb, u->dir, unit_ldir(fd.units[0][((f.y + (f.h >> 1)) >> 2) * p.uw + ((f.x + (f.w >> 1)) >> 2)]), cclm_allowed(p, fd, f.x, f.y, u->ss, u->depth));
           enc_bin<WR>(cb, (unsigned) !!(u->cbf & 2), VX_CTX_QtCbf[1]);
           enc_bin<WR>(cb, (unsigned) !!(u->cbf & 4), VX_CTX_QtCbf[2] + !!(u->cbf & 2));
           for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c)) {
             for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[c][((f.y >> 1) + yy) * fd.lstride[c] + (f.x >> 1) + xx];
             residual_coding<WR>(cb, lv, W, H, 1, (uint16_t *) (lv + 4096));
+            fl |= lfnst_flags(L.rc_last[0], W, H);
           }
+          enc_lfnst_idx<WR>(cb, 1, f.w, f.h, 0, 0, fl, u->mts >> 4);
         }
         top--; continue;
       }

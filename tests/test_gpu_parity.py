@@ -127,6 +127,24 @@ def test_dependent_quantisation_without_cu_reuse_low_qp_and_with_classifier():
     _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=0.5)], 256, 128, pkg.slice_params(27, dep_quant=True), tools=DQ | pkg.TOOL_FAST)
 
 
+LF = DQ | pkg.TOOL_LFNST
+
+
+@pytest.mark.parametrize("case", [(128, 128, 37, 8, 1, 1, 9, 0.5), (200, 136, 32, 8, 1, 1, 1234, 0.5), (256, 128, 32, 8, 2, 1, 5, 1.5), (128, 128, 32, 10, 1, 1, 3, 0.5), (256, 256, 27, 8, 2, 2, 6, 0.8)])
+def test_lfnst_in_the_search(case):
+    # tools 0x95b: the (transform group, lfnstIdx, mtsFlag) pass loop of xCheckRDCostIntra for luma and chroma CUs, the saved SATD-stage / DCT-II lists
+    # between its passes, MTS as CU-level passes, forward / inverse LFNST with the primary zero-out around the trellis (first tested position 7 / 15),
+    # residual_lfnst_mode in the CU rate and in the final pass; pictures with directional detail, where LFNST is selected
+    W, H, qp, bd, tc, tr, seed, tex = case
+    _check([pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=tex, oriented=40.0)], W, H, pkg.slice_params(qp, bit_depth=bd, dep_quant=True), bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=LF)
+
+
+def test_lfnst_without_cclm_and_cu_reuse_and_with_classifier():
+    _check([pkg.synth_frame(128, 128, 0, 8, 9, chroma_texture=1.5, oriented=40.0)], 128, 128, pkg.slice_params(37, dep_quant=True), tools=0x85b & ~pkg.TOOL_CU_REUSE)
+    _check([pkg.synth_frame(136, 72, 0, 8, 5, chroma_texture=1.5, oriented=40.0)], 136, 72, pkg.slice_params(27, dep_quant=True), tools=0x85b)
+    _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=0.5, oriented=30.0)], 256, 128, pkg.slice_params(27, dep_quant=True), tools=LF | pkg.TOOL_FAST)
+
+
 FAST = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_FAST
 
 
@@ -213,7 +231,7 @@ def test_full_1080p_frame_matches_oracle():
     _check([pkg.synth_frame(W, H, 0, 8, 1000)], W, H, pkg.slice_params(32), tile_cols=15, tile_rows=9)
 
 
-@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz", "bitstream_dq.npz"])
+@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz", "bitstream_dq.npz", "bitstream_lfnst.npz", "bitstream_lfnst_c.npz"])
 def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fixture):
     """Device writer (arithmetic coding of the final CTU syntax in the estimator pass) against tests/golden/bitstream.npz: payloads
     that the reference's CABACReader parsed back into the coded CUs and levels when the fixture was generated."""
@@ -222,12 +240,13 @@ def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fix
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
     tools = int(g["tools"][0]) if "tools" in g else pkg.TOOLS_DEFAULT
     texture = float(g["chroma_texture"][0]) if "chroma_texture" in g else 0.0
+    oriented = float(g["oriented"][0]) if "oriented" in g else 0.0
     off = 0
     for (W, H, qp, tc, tr, bd, seed, nbytes), sizes in zip(g["pic_meta"], g["pic_sizes"]):
         exp = g["pic_bytes"][off:off + nbytes]; off += int(nbytes)
         W, H, bd = int(W), int(H), int(bd)
         sp = pkg.slice_params(int(qp), bit_depth=bd, dep_quant=bool(tools & pkg.TOOL_DEPQUANT))
-        planes = pkg.synth_frame(W, H, 0, bd, int(seed), chroma_texture=texture)
+        planes = pkg.synth_frame(W, H, 0, bd, int(seed), chroma_texture=texture, oriented=oriented)
         enc = pkg.VvcxEncoder(W, H, bd, tile_cols=int(tc), tile_rows=int(tr), emit_payload=True, tools=tools)
         enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
         conv = [p if p.dtype == np.uint8 else p.view(np.int16) for p in planes]
