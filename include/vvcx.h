@@ -193,6 +193,11 @@ int  vvcx_transform_quant_batch(const int16_t *org, const int16_t *pred, int w, 
  * component (TrQuant::selectLambda); s0 / s1 = the two states of each of the 386 context models the rate terms are read from */
 int  vvcx_depquant_batch(const int16_t *org, const int16_t *pred, int w, int h, int bit_depth, int qp, int comp, int mts_idx, int cbf_cb, double lambda,
                          const uint16_t *s0, const uint16_t *s1, int n, int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device);
+/* the same with the LFNST of a CU with lfnstIdx 1 / 2 between the (zeroed-out) DCT-II and the dependent quantiser and back (≙ TrQuant::xFwdLfnst / xInvLfnst,
+ * CL/TrQuant.cpp:319-560; blocks below 4x4 take none): intra_dir = the block's final intra mode (0..66; planar for a MIP CU, the co-located luma
+ * mode for DM / CCLM chroma), from which the kernel set and the transposition follow after the wide-angle mapping of the block shape */
+int  vvcx_lfnst_depquant_batch(const int16_t *org, const int16_t *pred, int w, int h, int bit_depth, int qp, int comp, int lfnst_idx, int intra_dir, int cbf_cb, double lambda,
+                               const uint16_t *s0, const uint16_t *s1, int n, int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device);
 /* coefficient scan (diagonal, grouped) of a w x h block: idx[min(w,32) * min(h,32)] raster offsets in scan order */
 int  vvcx_scan_order(int w, int h, uint16_t *idx, int device);
 /* ≙ BIN/TEST.py GetPartition(C0..C25, 2): the forest of vvcx_set_forest on n rows of 26 int32 features (host pointers) → class per row */

@@ -5,4 +5,4 @@ from .vvcx import derive_slice  # noqa: F401
 from .sharding import frames_of_rank, timed_steps, gather_ctu_results, gather_payloads, max_over_ranks  # noqa: F401
 from .vvcx import distortion_batch, ctx_init, cabac_code_bins, rd_cost_batch, scan_order, transform_quant_batch, PRED_CASE_DTYPE  # noqa: F401
 from .forest import forest_from_sklearn, save_forest, load_forest, check_forest  # noqa: F401
-from .vvcx import depquant_batch  # noqa: F401
+from .vvcx import depquant_batch, lfnst_depquant_batch  # noqa: F401

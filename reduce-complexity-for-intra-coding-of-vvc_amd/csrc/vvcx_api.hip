@@ -27,7 +27,7 @@ struct VxMipCase { int32_t w, h, mode, bit_depth, ref_off, pred_off; };
 extern "C" __global__ void vvcx_leaf_mip_kernel(const VxMipCase *cases, const int16_t *refs, int16_t *preds);
 extern "C" __global__ void vvcx_deblock_kernel_u8(VxDeblockParams p);
 extern "C" __global__ void vvcx_deblock_kernel_u16(VxDeblockParams p);
-extern "C" __global__ void vvcx_leaf_dq_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int qp, int comp, int mts, int cbf_cb, unsigned long long *out);
+extern "C" __global__ void vvcx_leaf_dq_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int qp, int comp, int mts, int cbf_cb, unsigned long long *out, int lf, int lfdir);
 extern "C" __global__ void vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp, unsigned long long *out);
 
 static thread_local char g_err[512];
@@ -692,8 +692,8 @@ extern "C" int vvcx_transform_quant_batch(const int16_t *org, const int16_t *pre
   return VVCX_OK;
 }
 
-extern "C" int vvcx_depquant_batch(const int16_t *org, const int16_t *pred, int w, int h, int bit_depth, int qp, int comp, int mts_idx, int cbf_cb, double lambda,
-                                   const uint16_t *s0, const uint16_t *s1, int n, int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device)
+static int depquant_batch_impl(const int16_t *org, const int16_t *pred, int w, int h, int bit_depth, int qp, int comp, int mts_idx, int cbf_cb, double lambda,
+                               const uint16_t *s0, const uint16_t *s1, int n, int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device, int lfnst_idx, int intra_dir)
 {
   if (!org || !pred || !lev || !rec || !sse || !cbf || !s0 || !s1 || n < 0 || !pow2_block(w, h) || (bit_depth != 8 && bit_depth != 10) || qp < 0 || qp > 75 || comp < 0 || comp > 2 ||
       !(lambda > 0.0) || (mts_idx != 0 && (mts_idx < 2 || mts_idx > 5 || comp != 0 || w > 32 || h > 32 || w < 4 || h < 4))) return fail(VVCX_ERR_ARG, "bad argument");
@@ -709,15 +709,27 @@ extern "C" int vvcx_depquant_batch(const int16_t *org, const int16_t *pred, int 
   for (int lsum = 2; lsum <= 12; lsum++) tab[comp * 16 + lsum] = dq_consts_of(lsum, bit_depth, qp, lambda);
   HIPCHK(hipMemcpy(dtab.p, tab, sizeof tab, hipMemcpyHostToDevice));
   VxParams p; memset(&p, 0, sizeof p);
-  p.bit_depth = bit_depth; p.tools = VVCX_TOOL_DEPQUANT | VVCX_TOOL_MTS; p.dq_consts = dtab.as<VxDqConst>(); p.scratch = dscr.as<uint8_t>(); p.scratch_per_stream = VXD_OFF_CACHE;
+  p.bit_depth = bit_depth; p.tools = VVCX_TOOL_DEPQUANT | VVCX_TOOL_MTS | (lfnst_idx ? VVCX_TOOL_LFNST : 0); p.dq_consts = dtab.as<VxDqConst>(); p.scratch = dscr.as<uint8_t>(); p.scratch_per_stream = VXD_OFF_CACHE;
   hipLaunchKernelGGL(vvcx_leaf_dq_kernel, dim3((unsigned) n), dim3(VXD_NT), 0, 0, p, dctx.as<uint16_t>(), dorg.as<int16_t>(), drec.as<int16_t>(), dlev.as<int16_t>(), dtmp.as<int32_t>(),
-                     w, h, qp, comp, mts_idx, cbf_cb, dout.as<unsigned long long>());
+                     w, h, qp, comp, mts_idx, cbf_cb, dout.as<unsigned long long>(), (w >= 4 && h >= 4) ? lfnst_idx : 0, intra_dir);
   HIPCHK(hipGetLastError());
   std::vector<unsigned long long> o((size_t) n * 2);
   HIPCHK(hipMemcpy(lev, dlev.p, bytes, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(rec, drec.p, bytes, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(o.data(), dout.p, (size_t) n * 16, hipMemcpyDeviceToHost));
   for (int i = 0; i < n; i++) { sse[i] = o[(size_t) i * 2]; cbf[i] = (uint8_t) o[(size_t) i * 2 + 1]; }
   return VVCX_OK;
+}
+
+extern "C" int vvcx_depquant_batch(const int16_t *org, const int16_t *pred, int w, int h, int bit_depth, int qp, int comp, int mts_idx, int cbf_cb, double lambda,
+                                   const uint16_t *s0, const uint16_t *s1, int n, int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device)
+{
+  return depquant_batch_impl(org, pred, w, h, bit_depth, qp, comp, mts_idx, cbf_cb, lambda, s0, s1, n, lev, rec, sse, cbf, device, 0, 0);
+}
+extern "C" int vvcx_lfnst_depquant_batch(const int16_t *org, const int16_t *pred, int w, int h, int bit_depth, int qp, int comp, int lfnst_idx, int intra_dir, int cbf_cb, double lambda,
+                                         const uint16_t *s0, const uint16_t *s1, int n, int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device)
+{
+  if (lfnst_idx < 0 || lfnst_idx > 2 || intra_dir < 0 || intra_dir > 66) return fail(VVCX_ERR_ARG, "bad argument");
+  return depquant_batch_impl(org, pred, w, h, bit_depth, qp, comp, 0, cbf_cb, lambda, s0, s1, n, lev, rec, sse, cbf, device, lfnst_idx, intra_dir);
 }
 
 // slice_data() payload of one tile of a bound frame (≙ the sub-stream EncSlice::encodeSlice hands to the NAL writer, EL/EncSlice.cpp:1884-2006)

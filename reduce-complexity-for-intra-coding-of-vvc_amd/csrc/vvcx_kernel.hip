@@ -3806,7 +3806,7 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_trq_kernel(c
 // the same with the dependent quantiser (wave_depquant + wave_dequant_dq) from given context models: p carries tools, dq_consts and a scratch area
 // (VXD_OFF_CACHE bytes per block); blocks of at most BUF samples run the LDS-resident form the search uses for them, bigger ones the HBM form
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_dq_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp,
-                                                                              int w, int h, int qp, int comp, int mts, int cbf_cb, unsigned long long *out)
+                                                                              int w, int h, int qp, int comp, int mts, int cbf_cb, unsigned long long *out, int lf, int lfdir)
 {
   if (VTX == 0) L.par = p;
   load_tables();
@@ -3820,11 +3820,11 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_dq_kernel(Vx
     for (int i = lane; i < P; i += 64) { L.org[i] = org[b + i]; L.wm[0].slot[i] = rec[b + i]; }
     wave_sync();
     if (mts > 1) wave_code_block_mts<true>(nullptr, nullptr, nullptr, nullptr, w, h, bd, qp, mts, lane, sse, cbf);
-    else wave_code_block<true>(nullptr, 0, 0, nullptr, nullptr, nullptr, w, h, bd, qp, lane, sse, cbf, -1, nullptr, comp, CI_CUR, cbf_cb);
+    else wave_code_block<true>(nullptr, 0, 0, nullptr, nullptr, nullptr, w, h, bd, qp, lane, sse, cbf, -1, nullptr, comp, CI_CUR, cbf_cb, lf, lf ? lfnst_mode(lfdir, w, h) : 0);
     wave_sync();
     for (int i = lane; i < P; i += 64) { rec[b + i] = L.wm[0].slot[i]; lev[b + i] = L.wm[0].slot[BUF + i]; }
   } else if (mts > 1) wave_code_block_mts<false>(org + b, rec + b, lev + b, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, mts, lane, sse, cbf);
-  else wave_code_block<false>(org + b, 0, 0, rec + b, lev + b, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, lane, sse, cbf, -1, nullptr, comp, CI_CUR, cbf_cb);
+  else wave_code_block<false>(org + b, 0, 0, rec + b, lev + b, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, lane, sse, cbf, -1, nullptr, comp, CI_CUR, cbf_cb, lf, lf ? lfnst_mode(lfdir, w, h) : 0);
   if (lane == 0) { out[blockIdx.x * 2] = sse; out[blockIdx.x * 2 + 1] = (unsigned long long) cbf; }
 }
 template <typename T>

@@ -128,9 +128,36 @@ def _depquant(lib, limit):
     return n
 
 
+def _lfnst(lib, limit):
+    """vvcx_lfnst_depquant_batch (wave_lfnst_fwd / wave_lfnst_inv around the trellis, as the search runs them) against the reference's LFNST vectors
+    (tests/golden/lfnst.npz; the DepQuant cases: the device runs LFNST only over the dependent quantiser)"""
+    from test_oracle_golden import _lfnst_cases
+    n = 0
+    for c in _lfnst_cases():
+        w, h, bd = c["w"], c["h"], c["bd"]
+        if not c["dq"] or (limit and (n >= limit or w * h > 64)):
+            continue
+        mid, mx = 1 << (bd - 1), (1 << bd) - 1
+        resi = c["resi"].astype(np.int32)
+        org = (mid + resi).astype(np.int16); pred = np.full(w * h, mid, np.int16)
+        d = 0 if c["mip"] else c["dir"]
+        lev, rec, sse, cbf = pkg.lfnst_depquant_batch(org, pred, w, h, bd, c["qp_used"], c["comp"], c["lfnst"], d, c["cbf_cb"], c["lam"], c["ctx"][0], c["ctx"][1], lib_path=lib)
+        key = (bd, c["qp"], c["comp"], w, h, c["dir"], c["mip"], c["lfnst"])
+        assert np.array_equal(lev.ravel(), c["lev"]) and int(cbf[0]) == int(c["asum"] > 0), ("levels", key)
+        rec_e = np.clip(mid + c["out"].astype(np.int32), 0, mx) if c["asum"] > 0 else np.full(w * h, mid)
+        assert np.array_equal(rec.ravel().astype(np.int32), rec_e), ("rec", key)
+        n += 1
+    return n
+
+
 @pytest.mark.gpu
 def test_gpu_dependent_quantisation_matches_reference():
     assert _depquant(None, None) == 575
+
+
+@pytest.mark.gpu
+def test_gpu_lfnst_matches_reference():
+    assert _lfnst(None, None) > 900
 
 
 @pytest.mark.gpu
@@ -161,6 +188,7 @@ def test_emulated_leaf_operators_match_reference(emu_so):
     assert _intra(emu_so, 40) == 40
     assert _trquant(emu_so, 8) == 8
     assert _depquant(emu_so, 12) == 12
+    assert _lfnst(emu_so, 16) == 16
 
 
 @pytest.mark.gpu
