@@ -9,8 +9,14 @@ override); original planes are resident in HBM before the timed region.  With --
 frames per step (weak scaling, no data-path collective; frames are independent in All-Intra).
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against HBM bandwidth with the
-algorithmic bytes of SURVEY.md §8d (49 152 B per 8-bit CTU); `cpu_baseline` times the CPU oracle (a port of the
-reference path, oracle/) on a bounded sample of the same workload on this host.
+algorithmic bytes of SURVEY.md §8d (49 152 B per 8-bit CTU) and adds the VALU issue fraction from the newest committed
+PMC summary (the kernel is instruction-issue bound, not HBM bound); `cpu_baseline` times the CPU oracle (a port of the
+reference path, oracle/) on a bounded sample of the same workload on this host and quotes the reference encoder's own
+measured rate (one core of the authoring container) beside it.
+
+`--gpus N` without a torchrun environment launches N ranks itself (before anything touches the GPU) and exits with
+their code.  With N > 1 every rank also emits its tiles' slice_data payloads and the final bitstream gather to rank 0
+(two RCCL collectives, sharding.gather_payloads) is timed after the steps (`gather` object).
 """
 import argparse
 import importlib
@@ -42,6 +48,27 @@ def pmc_traffic(workload):
     return None, None
 
 
+def pmc_valu(workload):
+    """VALU issue fraction of the dominant kernel from the same PMC summary: SQ_INSTS_VALU per launch x 4 cycles (one wave64 VALU instruction
+    occupies its SIMD for 4 cycles) / (kernel cycles x 1024 SIMDs).  None if no summary matches."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(p))
+        except Exception:
+            continue
+        pl = d.get("per_launch_avg", {})
+        if d.get("workload") == workload and "SQ_INSTS_VALU" in pl and "SQ_BUSY_CYCLES" in pl:
+            # SQ_BUSY_CYCLES is summed over the 32 shader engines' SQs x XCDs as collected; the launch duration of the same run is the robust denominator
+            ms = d.get("kernel_ms")
+            out = {"insts_valu_per_launch": pl["SQ_INSTS_VALU"], "wave_cycles_per_launch": pl.get("SQ_WAVE_CYCLES"), "wait_any_per_launch": pl.get("SQ_WAIT_ANY"),
+                   "source": os.path.relpath(p, ROOT)}
+            if ms:
+                out["issue_frac"] = pl["SQ_INSTS_VALU"] * 4.0 / (ms * 1e-3 * 2.4e9 * 1024)
+            return out
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,10 +80,11 @@ def main():
     ap.add_argument("--bit-depth", type=int, default=8, choices=(8, 10), help="10: uint16 planes (BASELINE configs 4 and 5), algorithmic bytes double")
     ap.add_argument("--frames", type=str, default="auto",
                     help="frames per step and rank; auto = enough frames for ~4 full waves of resident CTU streams")
-    ap.add_argument("--tiles", type=str, default="auto", help="CxR uniform tile grid; auto = one tile per CTU")
+    ap.add_argument("--tiles", type=str, default="auto",
+                    help="CxR uniform tile grid (1x1 = the reference cfg's single tile: one stream per frame; 4x2; ...); auto = one tile per CTU")
     ap.add_argument("--lib", type=str, default=None, help="alternative build of the HIP library (experiments only)")
-    ap.add_argument("--tools", type=lambda v: int(v, 0), default=0x913,
-                    help="VVCX_TOOL_* bits; default MRL | MIP | MTS | CCLM | CU reuse = every tool of the reference's intra cfg that is built so far")
+    ap.add_argument("--tools", type=lambda v: int(v, 0), default=0x95b,
+                    help="VVCX_TOOL_* bits; default MRL | MIP | LFNST | MTS | DepQuant | CCLM | CU reuse = every tool of the reference's intra cfg that is built so far")
     ap.add_argument("--classifier", action="store_true",
                     help="BASELINE config 3 flavour: the fork's FAST_ALGORITHM with the shipped forest (forests/partition_qp32.npz) on the device")
     ap.add_argument("--chroma-texture", type=float, default=0.5,
@@ -64,6 +92,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ctus", type=int, default=12)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # self-launch: one process per GPU, started before this process initialises anything on the GPU (no exec of an initialised process)
+        import subprocess
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import numpy as np
     import torch
@@ -100,7 +136,8 @@ def main():
         probe.close()
     else:
         args.frames = int(args.frames)
-    enc = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, chroma=True, max_frames=args.frames, device=dev, lib_path=args.lib, tools=args.tools, forest=forest)
+    emit = world > 1                                # the N-GPU job ends with the bitstream gather: its ranks run the slice_data writer too
+    enc = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, chroma=True, max_frames=args.frames, device=dev, lib_path=args.lib, tools=args.tools, forest=forest, emit_payload=emit)
     enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
     frames = []
     for poc in pkg.frames_of_rank(args.frames * world, rank, world):      # weak scaling: args.frames per rank
@@ -119,6 +156,19 @@ def main():
     elapsed, outs = pkg.timed_steps(step, args.steps, args.warmup, world, device_sync=torch.cuda.synchronize, device="cuda")
     kernel_ms = [ms for _, ms in outs]
     counters = enc.counters()
+    gather = None
+    if world > 1:
+        # the final bitstream gather (north_star: RCCL over xGMI only here): payloads of this rank's frames -> rank 0, timed on its own
+        mine = list(pkg.frames_of_rank(args.frames * world, rank, world))
+        local = {poc: [enc.get_payload(i, t) for t in range(tc * tr)] for i, poc in enumerate(mine)}
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        merged = pkg.gather_payloads(local, world, device="cuda")
+        torch.cuda.synchronize(); dist.barrier()
+        gms = 1e3 * pkg.max_over_ranks(time.perf_counter() - t0, world, "cuda")
+        if rank == 0:
+            gather = {"ms": gms, "bytes": int(sum(len(b) for tiles in merged.values() for b in tiles)), "frames": len(merged), "ranks_seen": world,
+                      "collectives": "all_gather(sizes) + gather(padded) for the index and for the bytes (RCCL)"}
 
     if rank == 0:
         total_ctus = ctus_per_step * args.steps * world
@@ -128,19 +178,26 @@ def main():
         workload = ("%dx%d %d-bit 4:2:0 All-Intra QP%d full RDO, tools 0x%x, chroma texture %.2f, %d frame(s)/step/GPU, %dx%d uniform tiles = %d CTU streams per frame"
                     % (W, H, bd, args.qp, args.tools, args.chroma_texture, args.frames, tc, tr, tc * tr))
         traffic, traffic_src = pmc_traffic(workload)
+        valu = pmc_valu(workload)
         out = {
             "metric": "CTUs/sec (All-Intra, QP32)", "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16/int32 samples+coefficients, fp64 RD cost", "data": "synthetic",
             "config": {"workload": workload,
                        "tools": "67 intra modes + PDPC" + (" + MRL" if args.tools & 1 else "") + (" + MIP search (FastMIP 1)" if args.tools & 2 else "") + (" + CCLM (LM, MDLM_L, MDLM_T)" if args.tools & 0x100 else "")
-                                + (", DCT-II + explicit MTS (DST-VII/DCT-VIII, MTSIntraMaxCand 3)" if args.tools & 0x10 else ", DCT-II") + ", plain quant, dual tree" + (", CU-result reuse (REUSE_CU_RESULTS)" if args.tools & 0x800 else "")
+                                + (", DCT-II + explicit MTS (DST-VII/DCT-VIII" + (", as CU-level passes" if args.tools & 8 else ", MTSIntraMaxCand 3") + ")" if args.tools & 0x10 else ", DCT-II")
+                                + (" + LFNST (lfnstIdx passes, FastLFNST 1)" if args.tools & 8 else "")
+                                + (", dependent quantisation (DepQuant 1)" if args.tools & 0x40 else ", plain quant") + ", dual tree" + (", CU-result reuse (REUSE_CU_RESULTS)" if args.tools & 0x800 else "")
                                 + (", FAST_ALGORITHM partition classifier (shipped forest)" if args.tools & 0x1000 else "")
-                                + "; ISP/LFNST/TS/JCCR/LMCS/DepQuant/RDOQ of the reference's cfg not built yet",
-                       "ctus_per_step": ctus_per_step, "parallelism": "1 workgroup per CTU stream, frames sharded over ranks"},
+                                + "; not built yet from the reference's cfg: ISP, transform skip / BDPCM (+ RDOQ-TS), JointCbCr, LMCS"
+                                + ("" if args.tools & 8 else ", LFNST") + ("" if args.tools & 0x40 else ", DepQuant")
+                                + "; leaf operators, syntax and reconstruction are pinned to the reference (CommonLib + decoder), the search decisions (EncCu / EncModeCtrl / IntraSearch restatement) are unpinned",
+                       "tiling": ("one tile per CTU (every CTU an independent stream; the reference's cfg codes one tile per picture)" if (tc, tr) == (ctus_w, ctus_h)
+                                  else "%dx%d uniform tiles" % (tc, tr)),
+                       "ctus_per_step": ctus_per_step, "parallelism": "1 workgroup per CTU stream over a work queue of resident slots, frames sharded over ranks"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "vvcx_compress_kernel_u8" if bd == 8 else "vvcx_compress_kernel_u16", "kernel_ms": 1e3 * avg_kernel_s,
-                         "algorithmic_bytes_per_launch": ctus_per_step * b_ctu},
+                         "algorithmic_bytes_per_launch": ctus_per_step * b_ctu, "valu": valu},
             "work": {"satd_candidates_per_launch": int(counters[0]), "rd_tu_evaluations_per_launch": int(counters[1]),
                      "rd_pixels_per_launch": int(counters[2]), "nodes_per_launch": int(counters[3]),
                      "rd_pixels_per_s": float(counters[2]) / avg_kernel_s},
@@ -167,7 +224,11 @@ def main():
             dt = time.perf_counter() - t1
             nct = ((sw + 127) // 128) * ((sh + 127) // 128)
             out["cpu_baseline"] = {"value": nct / dt, "unit": "CTU/s", "cores": 1, "kind": "port",
-                                   "sample": "top-left %dx%d crop (%d CTUs, one tile per CTU) of the same frame, same QP/tools, oracle/ built -O2 -mavx2, %.1f s" % (sw, sh, nct, dt)}
+                                   "sample": "top-left %dx%d crop (%d CTUs, one tile per CTU) of the same frame, same QP/tools, oracle/ built -O2 -mavx2, %.1f s" % (sw, sh, nct, dt),
+                                   "reference_encoder": {"value": 0.44, "unit": "CTU/s", "cores": 1,
+                                                         "note": "the reference's own EncoderApp (full encoder_intra.cfg, AVX2) on 416x240 QP32, measured once in the authoring container (BASELINE.md); not re-run here: its build needs OpenCV"}}
+        if gather:
+            out["gather"] = gather
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -45,6 +45,8 @@ def main():
         out["hbm_traffic_bytes_per_launch"] = int(pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024)
         out["note"] = ("FETCH_SIZE/WRITE_SIZE in KiB from separate --pmc passes; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); "
                        "the kernel's accesses are 1-2 B/lane rows, for which the guide gives no calibration, so treat as an upper estimate")
+    for r in c.execute("select average*1000 from top_kernels where name like 'vvcx_compress%'"):
+        out["kernel_ms"] = r[0] / 1e6                       # average launch duration of the --kernel-trace run (ms)
     bj = os.path.join(src, "bench.json")
     if os.path.exists(bj):
         line = [l for l in open(bj) if l.startswith("{")][-1]
