@@ -1462,11 +1462,15 @@ static void compress_ctu(orc_enc *e, int rx, int ry, orc_ctu_result *res)
   advance_ctx_ctu(e, ctu);
 }
 
-int orc_compress_frame(orc_enc *e, orc_ctu_result *res, orc_cu *cus, int max_cus, int *n_cus)
+int orc_compress_frame(orc_enc *e, orc_ctu_result *res, orc_cu *cus, int max_cus, int *n_cus) { return orc_compress_tiles(e, 0, e->cfg.tile_cols * e->cfg.tile_rows, res, cus, max_cus, n_cus); }
+/* the tiles [tile_first, tile_first + tile_count) only (tiles are independent streams: test runs spread them over processes); res rows and CU
+ * table entries of the other tiles' CTUs are left out */
+int orc_compress_tiles(orc_enc *e, int tile_first, int tile_count, orc_ctu_result *res, orc_cu *cus, int max_cus, int *n_cus)
 {
   if ((e->cfg.tools & ORC_TOOL_FAST) && !e->forest.n_trees) { snprintf(g_err, sizeof g_err, "oracle: ORC_TOOL_FAST needs orc_set_forest first"); return -1; }
   const int ntiles = e->cfg.tile_cols * e->cfg.tile_rows;
-  for (int t = 0; t < ntiles; t++) {
+  if (tile_first < 0 || tile_count < 0 || tile_first + tile_count > ntiles) { snprintf(g_err, sizeof g_err, "oracle: tile range"); return -1; }
+  for (int t = tile_first; t < tile_first + tile_count; t++) {
     e->cur_tile = t;
     orc_ctx_init(e->sl.qp, e->cabac.s0, e->cabac.s1);       /* contexts reset at tile start (EL/EncSlice.cpp:1640-1647) */
     for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++)
@@ -1476,7 +1480,8 @@ int orc_compress_frame(orc_enc *e, orc_ctu_result *res, orc_cu *cus, int max_cus
   int n = 0;
   for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++)
     for (int ch = 0; ch < (e->cfg.chroma ? 2 : 1); ch++) {
-      const int ul = ch ? 1 : 2;
+      const int ul = ch ? 1 : 2, tl = e->ctu_tile[ry * e->ctus_w + rx];
+      if (tl < tile_first || tl >= tile_first + tile_count) continue;
       for (int uy = ry * 32; uy < imin(ry * 32 + 32, e->uh); uy++) for (int ux = rx * 32; ux < imin(rx * 32 + 32, e->uw); ux++) {
         const unit_t *u = &e->um[ch][uy * e->uw + ux];
         if (!u->valid || (u->x >> ul) != ux || (u->y >> ul) != uy) continue;

@@ -94,6 +94,7 @@ int      orc_set_slice(orc_enc *e, const orc_slice *s);
 int      orc_load_frame(orc_enc *e, const void *const org[3], const int stride[3], int bytes_per_sample);
 /* compress every CTU of the loaded frame (tiles in raster order, CTUs in raster order inside a tile) */
 int      orc_compress_frame(orc_enc *e, orc_ctu_result *res /* [n_ctus] */, orc_cu *cus, int max_cus, int *n_cus);
+int      orc_compress_tiles(orc_enc *e, int tile_first, int tile_count, orc_ctu_result *res, orc_cu *cus, int max_cus, int *n_cus);   /* a range of tiles only (test runs spread tiles over processes) */
 int      orc_get_reco(orc_enc *e, void *const reco[3], const int stride[3], int bytes_per_sample);
 const char *orc_last_error(void);
 /* work counters for the bench's diagnostic model */

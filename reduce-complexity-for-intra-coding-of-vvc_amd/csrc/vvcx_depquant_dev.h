@@ -208,6 +208,10 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   //        indices of x [19,23) and y [23,27)
   //   pgB (about the position coded next): position inside its group [0,4), context offsets of its sig flag [4,8) and gt1/par/gt2 set [8,13), number of
   //        template neighbours inside its group [13,16), raster offset [16,28);  pgC: those neighbours' places inside the group, 4 bits each
+  // The coefficients of the tested positions are staged in the decision slots first (slot sp holds coefficient sp until the position's decisions replace
+  // it): one burst of independent loads per item instead of a dependent (HBM) load in every step of the serial loop
+  if (valid) for (int sp = k; sp <= first; sp += 4) trel[sp] = (uint16_t) cf[scan_blk(geo, sp)];
+  wave_sync();
   int cnext = 0;
   for (int top64 = top; top64 >= 0; top64 -= 64) {
   int pgA = 0, pgB = 0, pgC = 0;
@@ -230,7 +234,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
       }
     }
   }
-  if (top64 == top) { const int b0 = __builtin_amdgcn_readlane(pgA, 0) & 4095; cnext = valid ? (int) cf[b0] : 0; }       // coefficient of the position about to be processed (fetched one position ahead)
+  if (top64 == top) cnext = (valid && top <= first) ? (int) (int16_t) trel[top] : 0;       // coefficient of the position about to be processed (fetched one position ahead)
   const int nchunk = imin(64, top64 + 1);
   for (int it = 0; it < nchunk; it++) {
     const int sp = top64 - it;
@@ -239,7 +243,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
     const int nin = gB & 15, sigOffN = (gB >> 4) & 15, gtxOffN = (gB >> 8) & 31, nbCnt = (gB >> 13) & 7;
     const bool act = valid && sp <= first;                   // the item's trellis has started
     const int absC = iabs(cnext);
-    if (valid && sp > 0) cnext = cf[(gB >> 16) & 4095];
+    if (valid && sp > 0 && sp - 1 <= first) cnext = (int) (int16_t) trel[sp - 1];
     { const DqS t = prv; prv = cur; cur = t; }
     // ---- decision of target state k (xDecide 1455-1517)
     long long dc = 0x7fffffffffffffffll >> 2; int dsrc = 0, dnz = 0, dlev = -1;          // dsrc: 0 none, 1 start, 2 from the "A/zero" source state, 3 from the "B" source state, 4 sub-block skipped

@@ -102,9 +102,10 @@ def set_forest(L, e, forest):
         raise RuntimeError(L.orc_last_error().decode())
 
 
-def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOLS_DEFAULT, forest=None, training_rows=None, deblock=False):
+def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOLS_DEFAULT, forest=None, training_rows=None, deblock=False, tile_range=None):
     """Run the oracle on one frame; returns (ctu results, cu table, reco planes, counters).  forest: flattened random forest for
-    TOOL_FAST; training_rows: a list that receives the (n, 28) int32 array of the classifier's training rows of this frame."""
+    TOOL_FAST; training_rows: a list that receives the (n, 28) int32 array of the classifier's training rows of this frame.
+    tile_range = (first, count): only those tiles are coded (results of the others stay zero)."""
     L = lib()
     cfg = default_cfg(w, h, bit_depth, tile_cols, tile_rows, chroma, tools)
     e = L.orc_create(C.byref(cfg))
@@ -129,7 +130,11 @@ def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chro
         res = np.zeros(nctu, CTU_DTYPE)
         cus = np.zeros(nctu * 2048, CU_DTYPE)
         n = C.c_int()
-        rc = L.orc_compress_frame(e, res.ctypes.data, cus.ctypes.data, len(cus), C.byref(n))
+        if tile_range is None:
+            rc = L.orc_compress_frame(e, res.ctypes.data, cus.ctypes.data, len(cus), C.byref(n))
+        else:
+            L.orc_compress_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+            rc = L.orc_compress_tiles(e, int(tile_range[0]), int(tile_range[1]), res.ctypes.data, cus.ctypes.data, len(cus), C.byref(n))
         assert rc == 0
         if deblock:                                   # in-loop deblocking of the coded picture (cfg offsets 0)
             L.orc_deblock_frame.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -145,6 +150,50 @@ def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chro
         return res, cus[:n.value].copy(), reco, cnt
     finally:
         L.orc_destroy(e)
+
+
+def _tile_of_ctu(cw, chh, tc, tr):
+    col = [max(i for i in range(tc) if rx >= (i * cw) // tc) for rx in range(cw)]
+    row = [max(i for i in range(tr) if ry >= (i * chh) // tr) for ry in range(chh)]
+    return np.array([[row[ry] * tc + col[rx] for rx in range(cw)] for ry in range(chh)], np.int32)
+
+
+def _tiles_job(a):
+    planes, w, h, sp, kw, rng = a
+    return compress_frame(planes, w, h, sp, tile_range=rng, **kw)
+
+
+def compress_frame_parallel(planes, w, h, sp, workers=8, **kw):
+    """compress_frame with the picture's tiles spread over `workers` processes (tiles are independent streams, so the merged result is the
+    single-process one): used where the one-core oracle would take minutes (full pictures with the complete tool set)."""
+    import multiprocessing as mp
+    tc, tr = kw.get("tile_cols", 1), kw.get("tile_rows", 1)
+    nt = tc * tr
+    workers = max(1, min(workers, nt))
+    if workers == 1:
+        return compress_frame(planes, w, h, sp, **kw)
+    lib()                                               # build once, before forking
+    bounds = [(i * nt) // workers for i in range(workers + 1)]
+    jobs = [(planes, w, h, sp, kw, (bounds[i], bounds[i + 1] - bounds[i])) for i in range(workers) if bounds[i + 1] > bounds[i]]
+    with mp.get_context("fork").Pool(len(jobs)) as pool:
+        parts = pool.map(_tiles_job, jobs)
+    cw, chh = (w + 127) // 128, (h + 127) // 128
+    tmap = _tile_of_ctu(cw, chh, tc, tr)
+    res = np.zeros(cw * chh, CTU_DTYPE); reco = [np.zeros_like(np.asarray(p)) for p in planes]; cnt = np.zeros(4, np.uint64); cus = []
+    for (r, c, rec, k), (_, _, _, _, _, (t0, tn)) in zip(parts, jobs):
+        cnt += k
+        cus.append(c)
+        for ry in range(chh):
+            for rx in range(cw):
+                if t0 <= tmap[ry, rx] < t0 + tn:
+                    res[ry * cw + rx] = r[ry * cw + rx]
+                    for comp in range(3):
+                        s_ = 128 if comp == 0 else 64
+                        reco[comp][ry * s_:(ry + 1) * s_, rx * s_:(rx + 1) * s_] = rec[comp][ry * s_:(ry + 1) * s_, rx * s_:(rx + 1) * s_]
+    cus = np.concatenate(cus)
+    sh = np.where(cus["ch_type"] == 0, 7, 6)
+    key = ((cus["y"].astype(np.int64) >> sh) * cw + (cus["x"].astype(np.int64) >> sh)) * 2 + cus["ch_type"]
+    return res, cus[np.argsort(key, kind="stable")], reco, cnt
 
 
 def write_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOLS_DEFAULT):

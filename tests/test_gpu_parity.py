@@ -9,15 +9,15 @@ pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
 pytestmark = pytest.mark.gpu
 
 
-def _forest():
+def _forest(qp=32):
     import os
-    return pkg.load_forest(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reduce-complexity-for-intra-coding-of-vvc_amd", "forests", "partition_qp32.npz"))
+    return pkg.load_forest(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reduce-complexity-for-intra-coding-of-vvc_amd", "forests", "partition_qp%d.npz" % qp))
 
 
-def _run_gpu(frames, W, H, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=True, tools=pkg.TOOLS_DEFAULT):
+def _run_gpu(frames, W, H, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=True, tools=pkg.TOOLS_DEFAULT, forest_qp=32, workers=1):
     import torch
     enc = pkg.VvcxEncoder(W, H, bit_depth, tile_cols=tile_cols, tile_rows=tile_rows, chroma=chroma, tools=tools, max_frames=len(frames),
-                          forest=_forest() if tools & pkg.TOOL_FAST else None)
+                          forest=_forest(forest_qp) if tools & pkg.TOOL_FAST else None)
     enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
     dev = []
     for planes in frames:
@@ -44,7 +44,8 @@ def _check(frames, W, H, sp, **kw):
                tools=kw.get("tools", pkg.TOOLS_DEFAULT))
     ocnt_sum = np.zeros(4, np.uint64)
     for planes, (res, cus, reco) in zip(frames, got):
-        ores, ocus, oreco, ocnt = O.compress_frame(planes, W, H, sp, forest=_forest() if okw["tools"] & pkg.TOOL_FAST else None, **okw)
+        # workers > 1: the oracle's tiles spread over host processes (same result, tiles are independent streams)
+        ores, ocus, oreco, ocnt = O.compress_frame_parallel(planes, W, H, sp, workers=kw.get("workers", 1), forest=_forest(kw.get("forest_qp", 32)) if okw["tools"] & pkg.TOOL_FAST else None, **okw)
         ocnt_sum += ocnt
         for k in ores.dtype.names:
             assert np.array_equal(ores[k], res[k]), (k, ores[k], res[k])
@@ -225,10 +226,26 @@ def test_size_independent_properties_1080p_row():
 
 
 def test_full_1080p_frame_matches_oracle():
-    """BASELINE.json's configuration itself: one 1920x1080 frame, QP 32, 15x9 tiles (135 CTU streams, bottom CTU row cut
-    at 56 luma rows → implicit splits), bit-exact against the oracle (≈1 min of oracle time on one host core)."""
+    """BASELINE.json's configuration 2 with bench.py's tool set and synthetic picture: one 1920x1080 frame, QP 32, every built tool (0x95b),
+    15x9 tiles (135 CTU streams, bottom CTU row cut at 56 luma rows -> implicit splits), bit-exact against the oracle (whose tiles run on 12
+    host processes)."""
     W, H = 1920, 1080
-    _check([pkg.synth_frame(W, H, 0, 8, 1000)], W, H, pkg.slice_params(32), tile_cols=15, tile_rows=9)
+    _check([pkg.synth_frame(W, H, 0, 8, 1000, chroma_texture=0.5)], W, H, pkg.slice_params(32, dep_quant=True), tile_cols=15, tile_rows=9, tools=LF, workers=12)
+
+
+def test_baseline_config_1_picture_size_single_tile():
+    """BASELINE.json configuration 1's shape: 416x240, one frame, QP 32, the reference cfg's single tile (one stream: contexts and neighbours run
+    through all 8 CTUs, right and bottom CTUs cut by the picture edge), every built tool."""
+    W, H = 416, 240
+    _check([pkg.synth_frame(W, H, 0, 8, 1234, chroma_texture=0.5, oriented=20.0)], W, H, pkg.slice_params(32, dep_quant=True), tools=LF)
+
+
+@pytest.mark.parametrize("qp", [22, 27, 32, 37])
+def test_baseline_config_3_classifier_per_qp_forest_1080p_rows(qp):
+    """BASELINE.json configuration 3's flavour: the FAST_ALGORITHM classifier on the device with the forest shipped for each QP, every built tool,
+    on 1080p-wide pictures (two CTU rows of a 1920-wide frame, 30 CTU streams), bit-exact against the oracle."""
+    W, H = 1920, 256
+    _check([pkg.synth_frame(W, H, 0, 8, 2000 + qp, chroma_texture=0.5)], W, H, pkg.slice_params(qp, dep_quant=True), tile_cols=15, tile_rows=2, tools=LF | pkg.TOOL_FAST, forest_qp=qp, workers=12)
 
 
 @pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz", "bitstream_dq.npz", "bitstream_lfnst.npz", "bitstream_lfnst_c.npz"])
