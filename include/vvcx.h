@@ -91,6 +91,7 @@ typedef struct {
   uint8_t  mts_idx;              /* tu.mtsIdx of the luma TU: 0 DCT2xDCT2, 2..5 explicit MTS (VVCX_TOOL_MTS) */
   uint8_t  mip_flag;             /* cu.mipFlag of a luma CU (VVCX_TOOL_MIP): intra_dir is then the MIP mode, mrl_idx 0 */
   uint8_t  lfnst_idx;            /* cu.lfnstIdx of the CU (VVCX_TOOL_LFNST): 0 none, 1 / 2 the kernel of the set */
+  uint8_t  joint_cb_cr;          /* tu.jointCbCr of a chroma CU (VVCX_TOOL_JCCR): 0 separate residuals, 1..3 the cbf mask of the joint residual */
   uint64_t split_series;         /* CU::splitSeries, 5 bits per depth */
 } vvcx_cu;
 

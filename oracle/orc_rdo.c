@@ -33,7 +33,7 @@ enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_B
 typedef struct { int x, y, w, h; } area_t;   /* luma samples (UnitArea::Y) */
 
 typedef struct {       /* per 4x4-luma-unit record of the CU covering it, one map per channel type */
-  uint8_t valid, tile, qt_depth, mt_depth, bt_depth, depth, dir, mrl, cbf, lw, lh, mts, lfnst;
+  uint8_t valid, tile, qt_depth, mt_depth, bt_depth, depth, dir, mrl, cbf, lw, lh, mts, lfnst, jccr;
   int16_t x, y;        /* CU origin in channel samples */
   uint64_t split_series;
 } unit_t;
@@ -60,7 +60,7 @@ typedef struct {       /* what the mode controller reads from a CodingStructure 
  * 4-sample units, log2 w, log2 h) like m_bestEncInfo[x][y][wIdx][hIdx] (EL/EncModeCtrl.cpp:706-760).  The reference
  * keeps entries across CTUs and rejects stale ones by comparing poc and absolute area (987-1024); clearing at every
  * CTU start is equivalent.  lev: w*h luma levels, or Cb then Cr (cw*ch each). */
-typedef struct { uint8_t valid, ch, dir, mrl, cbf, depth, mts, lfnst; uint64_t ss; int16_t *lev; } cache_ent;
+typedef struct { uint8_t valid, ch, dir, mrl, cbf, depth, mts, lfnst, jccr; uint64_t ss; int16_t *lev; } cache_ent;
 #define CACHE_ENTRIES (32 * 32 * 6 * 6)
 
 #define MAX_DEPTH 20
@@ -81,6 +81,8 @@ struct orc_enc {
   uint64_t cnt_satd, cnt_rd, cnt_rdpix, cnt_nodes, cnt_reuse;
   cache_ent *cache; int ctu_is_last;
   int tu_cbf_cb;                      /* tu.cbf[Cb] while Cr is quantised (context of its cbf in DepQuant's rate tables) */
+  int jccr_sign;                      /* slice joint_cb_cr_sign_flag, from the picture's chroma planes (EL/EncSlice.cpp:1503-1538) */
+  int16_t *pred_c[2], *resi_c[2];     /* JointCbCr: predictions and residuals of the chroma block pair */
   orc_forest forest; int32_t *dump; int dump_cap, dump_n; uint64_t cnt_fast;
   /* scratch */
   int16_t *ref_unf, *ref_flt, *pred, *resi, *resi_org, *tmp_rec[2], *tmp_lev[2], *best_rec[2], *best_lev[2];
@@ -90,7 +92,7 @@ struct orc_enc {
 /* ------------------------------------------------------------------------------------------------ */
 orc_enc *orc_create(const orc_cfg *cfg)
 {
-  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, LFNST, MTS, DepQuant, CU reuse, CCLM, FAST)", cfg->tools); return 0; }
+  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST | ORC_TOOL_JCCR)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, LFNST, MTS, DepQuant, CCLM, JointCbCr, CU reuse, FAST)", cfg->tools); return 0; }
   /* the plain quantiser's LFNST branch (CL/Quant.cpp:1054-1058) keeps buffer positions the decoder's LFNST conditions reject: the reference only
    * ever runs LFNST over DepQuant / RDOQ */
   if ((cfg->tools & ORC_TOOL_LFNST) && !(cfg->tools & ORC_TOOL_DEPQUANT)) { snprintf(g_err, sizeof g_err, "oracle: LFNST needs DepQuant (tool set 0x%x)", cfg->tools); return 0; }
@@ -115,6 +117,7 @@ orc_enc *orc_create(const orc_cfg *cfg)
   }
   e->cache = (cache_ent *) calloc(CACHE_ENTRIES, sizeof(cache_ent));
   e->ref_unf = (int16_t *) malloc(2 * 300 * 300); e->ref_flt = (int16_t *) malloc(2 * 300 * 300);
+  for (int k = 0; k < 2; k++) { e->pred_c[k] = (int16_t *) malloc(64 * 64 * 2); e->resi_c[k] = (int16_t *) malloc(64 * 64 * 2); }
   e->pred = (int16_t *) malloc(128 * 128 * 2); e->resi = (int16_t *) malloc(128 * 128 * 2); e->resi_org = (int16_t *) malloc(128 * 128 * 2); e->coef = (int *) malloc(128 * 128 * 4);
   for (int k = 0; k < 2; k++) { e->tmp_rec[k] = (int16_t *) malloc(128 * 128 * 2); e->tmp_lev[k] = (int16_t *) malloc(128 * 128 * 2); e->best_rec[k] = (int16_t *) malloc(128 * 128 * 2); e->best_lev[k] = (int16_t *) malloc(128 * 128 * 2); }
   return e;
@@ -161,6 +164,19 @@ int orc_set_slice(orc_enc *e, const orc_slice *s)
   e->sqrt_lambda_fp = sqrt(s->lambda) * (1.0 / (double) (1 << 15));
   return 0;
 }
+/* setJointCbCrModes (EL/EncSlice.cpp:1503-1538): the sign of the inter-chroma transform from the correlation of the high-pass filtered Cb and Cr
+ * planes (interior samples); a slice-level input of the search, derived here from the loaded picture like the reference does before compressSlice */
+int orc_jccr_sign(const int16_t *cb, const int16_t *cr, int stride, int w, int h)
+{
+  int64_t sum = 0;
+  for (int y = 1; y < h - 1; y++) for (int x = 1; x < w - 1; x++) {
+    const int16_t *p = cb + y * stride + x, *q = cr + y * stride + x;
+    const int a = 12 * p[0] - 2 * (p[-1] + p[1] + p[-stride] + p[stride]) - (p[-1 - stride] + p[1 - stride] + p[-1 + stride] + p[1 + stride]);
+    const int b = 12 * q[0] - 2 * (q[-1] + q[1] + q[-stride] + q[stride]) - (q[-1 - stride] + q[1 - stride] + q[-1 + stride] + q[1 + stride]);
+    sum += (int64_t) a * b;
+  }
+  return sum < 0;
+}
 int orc_load_frame(orc_enc *e, const void *const org[3], const int stride[3], int bps)
 {
   for (int c = 0; c < 3; c++) {
@@ -170,6 +186,7 @@ int orc_load_frame(orc_enc *e, const void *const org[3], const int stride[3], in
     memset(e->rec[c], 0, (size_t) w * h * 2); memset(e->lev[c], 0, (size_t) w * h * 2);
   }
   for (int k = 0; k < 2; k++) { memset(e->um[k], 0, (size_t) e->uw * e->uh * sizeof(unit_t)); memset(e->avail[k], 0, (size_t) e->uw * e->uh); }
+  e->jccr_sign = orc_jccr_sign(e->org[1], e->org[2], e->stride[1], e->wc, e->hc);
   /* uniform tile grid (CL/Slice.cpp PPS uniform spacing): boundary i = i*N/T */
   for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++) {
     int tc = 0, tr = 0;
@@ -521,7 +538,13 @@ static void enc_intra_chroma_pred_mode(orc_enc *e, area_t a, int dir, int lm_ok)
  * ---------------------------------------------------------------------------------------------- */
 static uint64_t code_tu_block_ex(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int lfnst_idx, int lfnst_dir, int16_t *rec_out, int16_t *lev_out, int *cbf);
 /* lambda the quantiser sees for a component (RDOQ_CHROMA_LAMBDA: EL/EncSlice.cpp:107-149 setLambdas, EL/IntraSearch.cpp:2889 selectLambda) */
-static double quant_lambda(const orc_enc *e, int comp) { return comp ? e->sl.lambda / e->sl.dist_weight[comp - 1] : e->sl.lambda; }
+/* with JointCbCr on, every chroma block is quantised with 1.3 x that lambda above slice QP 18 (EL/IntraSearch.cpp:2937-2942) */
+static double quant_lambda(const orc_enc *e, int comp)
+{
+  if (!comp) return e->sl.lambda;
+  const double l = e->sl.lambda / e->sl.dist_weight[comp - 1];
+  return ((e->cfg.tools & ORC_TOOL_JCCR) && e->sl.qp > 18) ? 1.3 * l : l;
+}
 static uint64_t code_tu_block(orc_enc *e, int comp, int x, int y, int w, int h, int16_t *rec_out, int16_t *lev_out, int *cbf) { return code_tu_block_ex(e, comp, x, y, w, h, 0, 0, 0, rec_out, lev_out, cbf); }
 static uint64_t code_tu_block_mts(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int16_t *rec_out, int16_t *lev_out, int *cbf) { return code_tu_block_ex(e, comp, x, y, w, h, mts_idx, 0, 0, rec_out, lev_out, cbf); }
 /* lfnst_idx: cu.lfnstIdx (applies to blocks of at least 4x4, CL/TrQuant.cpp:444); lfnst_dir: the block's final intra mode for the kernel choice
@@ -863,12 +886,118 @@ static void cclm_luma(orc_enc *e, int cx, int cy, int cw, int chh, int mdlm, int
 {
   orc_cclm_luma(e->rec[0], e->stride[0], e->avail[1], e->uw, e->cur_tile + 1, e->wc, e->hc, cx, cy, cw, chh, mdlm, info, tmp, CCLM_TSTRIDE);
 }
-static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int lm_ok, int lfnst_idx, int *out_dir, int *out_cbf)
+/* JointCbCr (JVET_O0105 ICT).  g_ictModes (CL/Rom.cpp:613): signed mode of a cbf mask under the slice's sign flag */
+static int ict_mode(const orc_enc *e, int mask) { static const int m[4] = { 0, 3, 1, 2 }; return e->jccr_sign ? -m[mask] : m[mask]; }
+/* fwdTransformCbCr (CL/TrQuant.cpp:87-137): the joint residual of a mode (into c, n samples) and the distortion of representing both residuals by it */
+static int64_t ict_forward(const int16_t *cb, const int16_t *cr, int n, int mode, int16_t *c)
+{
+  int64_t d = 0;
+  for (int i = 0; i < n; i++) {
+    const int b = cb[i], r = cr[i]; int v, eb, er;
+    switch (mode) {
+      case  1: v = (4 * b + 2 * r) / 5; eb = b - v; er = r - (v >> 1); break;
+      case -1: v = (4 * b - 2 * r) / 5; eb = b - v; er = r - (-v >> 1); break;
+      case  2: v = (b + r) / 2; eb = b - v; er = r - v; break;
+      case -2: v = (b - r) / 2; eb = b - v; er = r + v; break;
+      case  3: v = (4 * r + 2 * b) / 5; eb = b - (v >> 1); er = r - v; break;
+      default: v = (4 * r - 2 * b) / 5; eb = b - (-v >> 1); er = r - v; break;
+    }
+    c[i] = (int16_t) v;
+    d += (int64_t) eb * eb + (int64_t) er * er;
+  }
+  return d;
+}
+/* TrQuant::selectICTCandidates for an intra CU (CL/TrQuant.cpp:701-743): up to two cbf masks whose joint representation is closest */
+static int ict_candidates(const orc_enc *e, const int16_t *cb, const int16_t *cr, int n, int masks[2], int16_t *tmp)
+{
+  int64_t d0 = 0, d1 = 0, pd[4];
+  for (int i = 0; i < n; i++) { d0 += (int64_t) cb[i] * cb[i]; d1 += (int64_t) cr[i] * cr[i]; }
+  for (int m = 1; m < 4; m++) pd[m] = ict_forward(cb, cr, n, ict_mode(e, m), tmp);
+  int64_t min1 = d0 < d1 ? d0 : d1, min2 = INT64_MAX; int m1 = 0, m2 = 0;
+  for (int m = 1; m < 4; m++) {
+    if (pd[m] < min1) { m2 = m1; min2 = min1; m1 = m; min1 = pd[m]; }
+    else if (pd[m] < min2) { m2 = m; min2 = pd[m]; }
+  }
+  int n_ = 0;
+  if (m1) masks[n_++] = m1;
+  if (m2 && ((min2 < (9 * min1) / 8) || (!m1 && min2 < (3 * min1) / 2))) masks[n_++] = m2;
+  return n_;
+}
+/* QpParam of a joint TU (CL/Quant.cpp:139-176): the coded component's QP, except for the modes +-2 (cbf mask 3), which use the JointCbCr QP: the mapping
+ * table's value (one table for all chroma, SameCQPTablesForAllChroma 1) + pps_joint_cbcr_qp_offset (CbCrQpOffset -1, APP/EncAppCfg.cpp:1082) */
+static int joint_qp(const orc_enc *e, int mask)
+{
+  const int bd = e->cfg.bit_depth, off = 6 * (bd - 8);
+  if (mask != 3) return e->sl.qp_c[(mask >> 1) ? 0 : 1] + off;
+  int qp = e->sl.qp_c[0] - 1; if (qp < -off) qp = -off; if (qp > 63) qp = 63;
+  return qp + off;
+}
+/* test hook: selectICTCandidates + the three joint residuals (joint[m - 1], n samples each) for a residual pair under a sign flag */
+int orc_test_ict(int sign, const int16_t *cb, const int16_t *cr, int n, int *masks, int16_t *joint)
+{
+  orc_enc e; memset(&e, 0, sizeof e); e.jccr_sign = sign;
+  for (int m = 1; m <= 3; m++) ict_forward(cb, cr, n, ict_mode(&e, m), joint + (size_t) (m - 1) * n);
+  int16_t *tmp = (int16_t *) malloc((size_t) n * 2);
+  const int k = ict_candidates(&e, cb, cr, n, masks, tmp);
+  free(tmp);
+  return k;
+}
+/* xIntraCodingTUBlock for a joint TU (EL/IntraSearch.cpp:2909-2934, 3050-3091): the joint residual is transformed and quantised as the Cb block (mask 2, 3)
+ * or the Cr block (mask 1) at the JointCbCr QP with the loosened lambda; both residuals come back through the inverse ICT.  Predictions in
+ * e->pred_c, residuals in e->resi_c.  Returns the distortion of both blocks or UINT64_MAX when the coded block turns out empty (the mask cannot be
+ * signalled); levels of the coded block in lev_out, reconstructions in rec_out[0..1]. */
+static uint64_t code_joint_block(orc_enc *e, int mask, int cx, int cy, int w, int h, int lfnst_idx, int lfnst_dir, int16_t *const rec_out[2], int16_t *lev_out)
+{
+  const int bd = e->cfg.bit_depth, n = w * h, mode = ict_mode(e, mask), comp = (mask >> 1) ? 1 : 2;
+  const int qp = joint_qp(e, mask);
+  const int lf = (lfnst_idx && w >= 4 && h >= 4) ? lfnst_idx : 0, lmode = lf ? orc_lfnst_mode(lfnst_dir, w, h) : 0;
+  ict_forward(e->resi_c[0], e->resi_c[1], n, mode, e->resi);
+  orc_fwd_2d_mts(e->resi, w, w, h, bd, 0, e->coef);
+  if (lf) { orc_lfnst_keep(e->coef, w, h); orc_fwd_lfnst(e->coef, w, h, lmode, lf); }
+  /* lambda: the Cb lambda (selectLambda(compID = Cb) 2889), loosened by 0.8 (modes +-1, +-3) or 0.5 (+-2), then the 1.3 of every chroma block */
+  const int am = mode < 0 ? -mode : mode;
+  double lam = (am == 1 || am == 3 ? 0.8 : 0.5) * (e->sl.lambda / e->sl.dist_weight[0]);
+  if (e->sl.qp > 18) lam = 1.3 * lam;
+  /* the other block's cbf is cleared first (3053-3058): Cr's cbf context sees tu.cbf[Cb] = 0 for mask 1 */
+  const int abs_sum = orc_depquant(e->cabac.s0, e->cabac.s1, e->coef, w, h, comp, ORC_CTX_QtCbf[comp], bd, qp, lam, 0, lf, lev_out);
+  e->cnt_rd++; e->cnt_rdpix += (uint64_t) n;
+  if (abs_sum <= 0) return UINT64_MAX;
+  orc_dequant_dq(lev_out, w, h, bd, qp, e->coef); orc_inv_lfnst(e->coef, w, h, lmode, lf); orc_inv_2d_mts(e->coef, w, h, bd, 0, e->resi, w);
+  const int mx = (1 << bd) - 1;
+  uint64_t dist = 0;
+  for (int k = 0; k < 2; k++) {
+    const int st = e->stride[k + 1]; const int16_t *org = e->org[k + 1] + cy * st + cx;
+    for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) {
+      const int c = e->resi[j * w + i]; int r;
+      /* invTransformCbCr (139-156): the coded block keeps its residual, the other one is derived */
+      if (comp == 1) r = k == 0 ? c : (am == 1 ? ((mode < 0 ? -c : c) >> 1) : (mode < 0 ? -c : c));
+      else r = k == 1 ? c : ((mode < 0 ? -c : c) >> 1);
+      const int v = e->pred_c[k][j * w + i] + r;
+      rec_out[k][j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v);
+    }
+    dist += (uint64_t) (e->sl.dist_weight[k] * (double) orc_sse(org, st, rec_out[k], w, w, h));
+  }
+  return dist;
+}
+/* chroma part of transform_unit (EL/CABACWriter.cpp:3560-3680): cbf_cb, cbf_cr, joint_cb_cr (JointCbCr on and some cbf set; context cbfMask - 1),
+ * residual_coding of Cb and of Cr (not coded when tu.jointCbCr == 3); lfl collects the LFNST conditions of the coded blocks */
+static void enc_chroma_tu(orc_enc *e, int W, int H, int cbf, int jccr, const int16_t *lev0, const int16_t *lev1, int *lastPos, int *violates)
+{
+  const int maxPos = ((W == 4 && H == 4) || (W == 8 && H == 8)) ? 7 : 15;
+  orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 2), ORC_CTX_QtCbf[1]);
+  orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 4), ORC_CTX_QtCbf[2] + !!(cbf & 2));
+  const int mask = ((cbf & 2) ? 2 : 0) | ((cbf & 4) ? 1 : 0);
+  if ((e->cfg.tools & ORC_TOOL_JCCR) && mask) orc_enc_bin(&e->cabac, jccr ? 1u : 0u, ORC_CTX_JointCbCrFlag + mask - 1);
+  if (cbf & 2) { orc_residual_coding(&e->cabac, lev0, W, H, 1); if (W >= 4 && H >= 4) { *lastPos |= e->cabac.last_scan_pos >= 1; *violates |= e->cabac.last_scan_pos > maxPos; } }
+  if ((cbf & 4) && jccr != 3) { orc_residual_coding(&e->cabac, lev1, W, H, 1); if (W >= 4 && H >= 4) { *lastPos |= e->cabac.last_scan_pos >= 1; *violates |= e->cabac.last_scan_pos > maxPos; } }
+}
+
+static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int lm_ok, int lfnst_idx, int *out_dir, int *out_cbf, int *out_jccr)
 {
   const int cx = a.x >> 1, cy = a.y >> 1, cw = a.w >> 1, chh = a.h >> 1;
   orc_cabac ctxStart; orc_ctx_copy(&ctxStart, &e->cabac);
   int cand[8]; chroma_cand_modes(e, a, cand);
-  double bestCost = ORC_MAX_DOUBLE; uint64_t bestDist = 0; int bestMode = 0, bestCbf = 0;
+  double bestCost = ORC_MAX_DOUBLE; uint64_t bestDist = 0; int bestMode = 0, bestCbf = 0, bestJccr = 0;
   int16_t *rec2[2], *lev2[2];
   rec2[0] = e->tmp_rec[0]; rec2[1] = e->tmp_rec[1]; lev2[0] = e->tmp_lev[0]; lev2[1] = e->tmp_lev[1];
   static int16_t tmpLM[CCLM_TSTRIDE * CCLM_TSTRIDE], tmpMD[CCLM_TSTRIDE * CCLM_TSTRIDE];
@@ -906,30 +1035,73 @@ static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int lm_ok, int lfnst
     orc_ctx_copy(&e->cabac, &ctxStart);
     const int fm = cm == ORC_DM_CHROMA ? colocated_luma_mode(e, a) : cm;   /* PU::getFinalIntraMode 921 */
     int cbf[2]; uint64_t dist = 0;
+    const int jccrOn = (e->cfg.tools & ORC_TOOL_JCCR) != 0;
+    const int lfDir = isLM ? colocated_luma_mode(e, a) : fm;      /* LFNST kernel choice: DM through the final mode, CCLM through the co-located luma mode (CL/TrQuant.cpp:449-457) */
+    double compCost[2] = { 0, 0 }; uint64_t compDist[2];
     for (int c = 1; c <= 2; c++) {
       pred_chroma_comp(e, c, cx, cy, cw, chh, fm, cm == 67 ? tmpLM : tmpMD, cm == 67 ? infoLM : infoMD);
+      if (jccrOn) {                                         /* 3823-3843: predictions and residuals of the pair for the joint candidates */
+        memcpy(e->pred_c[c - 1], e->pred, (size_t) cw * chh * 2);
+        const int st = e->stride[c]; const int16_t *org = e->org[c] + cy * st + cx;
+        for (int j = 0; j < chh; j++) for (int i = 0; i < cw; i++) e->resi_c[c - 1][j * cw + i] = (int16_t) (org[j * st + i] - e->pred[j * cw + i]);
+      }
       e->tu_cbf_cb = c == 2 ? cbf[0] : 0;
-      /* LFNST kernel choice: DM through the final mode, CCLM through the co-located luma mode (CL/TrQuant.cpp:449-457) */
-      dist += code_tu_block_ex(e, c, cx, cy, cw, chh, 0, lfnst_idx, isLM ? colocated_luma_mode(e, a) : fm, rec2[c - 1], lev2[c - 1], &cbf[c - 1]);
-      /* xGetIntraFracBitsQTChroma (2625-2692): contexts advance, bits only feed per-component costs */
+      compDist[c - 1] = code_tu_block_ex(e, c, cx, cy, cw, chh, 0, lfnst_idx, lfDir, rec2[c - 1], lev2[c - 1], &cbf[c - 1]);
+      dist += compDist[c - 1];
+      /* xGetIntraFracBitsQTChroma (2625-2692): cbf [+ the joint flag (0) behind Cr's cbf] + coefficients; the contexts advance */
+      e->cabac.bits = 0;
       orc_enc_bin(&e->cabac, (unsigned) cbf[c - 1], ORC_CTX_QtCbf[c] + (c == 2 ? cbf[0] : 0));
+      if (jccrOn && c == 2 && (cbf[0] || cbf[1])) orc_enc_bin(&e->cabac, 0, ORC_CTX_JointCbCrFlag + ((cbf[0] ? 2 : 0) | (cbf[1] ? 1 : 0)) - 1);
       if (cbf[c - 1]) orc_residual_coding(&e->cabac, lev2[c - 1], cw, chh, 1);
+      compCost[c - 1] = rd_cost(e, e->cabac.bits, compDist[c - 1]);
+    }
+    int jccr = 0, cbfMask = (cbf[0] ? 2 : 0) | (cbf[1] ? 1 : 0);
+    if (jccrOn && cbfMask) {
+      /* 4060-4150: joint candidates against the sum of the two separate costs; each starts from the TU's start contexts */
+      double bestCbCr = compCost[0] + compCost[1];
+      orc_cabac ctxSep; orc_ctx_copy(&ctxSep, &e->cabac);
+      int masks[2]; const int nm = ict_candidates(e, e->resi_c[0], e->resi_c[1], cw * chh, masks, e->resi);
+      static int16_t jrec[2][64 * 64], jlev[64 * 64], brec[2][64 * 64], blev[64 * 64];
+      int16_t *const jr[2] = { jrec[0], jrec[1] };
+      orc_cabac ctxJ; int haveJ = 0; uint64_t bestJDist = 0;
+      for (int q = 0; q < nm; q++) {
+        const int mask = masks[q];
+        orc_ctx_copy(&e->cabac, &ctxStart);
+        const uint64_t d = code_joint_block(e, mask, cx, cy, cw, chh, lfnst_idx, lfDir, jr, jlev);
+        if (d == UINT64_MAX) continue;
+        e->cabac.bits = 0;
+        orc_enc_bin(&e->cabac, (unsigned) (mask >> 1), ORC_CTX_QtCbf[1]);
+        orc_enc_bin(&e->cabac, (unsigned) (mask & 1), ORC_CTX_QtCbf[2] + (mask >> 1));
+        orc_enc_bin(&e->cabac, 1, ORC_CTX_JointCbCrFlag + mask - 1);
+        orc_residual_coding(&e->cabac, jlev, cw, chh, 1);
+        const double cj = rd_cost(e, e->cabac.bits, d);
+        if (cj < bestCbCr) {
+          bestCbCr = cj; bestJDist = d; jccr = mask; haveJ = 1;
+          memcpy(brec[0], jrec[0], (size_t) cw * chh * 2); memcpy(brec[1], jrec[1], (size_t) cw * chh * 2); memcpy(blev, jlev, (size_t) cw * chh * 2);
+          orc_ctx_copy(&ctxJ, &e->cabac);
+        }
+      }
+      if (haveJ) {
+        dist = bestJDist; cbf[0] = jccr >> 1; cbf[1] = jccr & 1;
+        memcpy(rec2[0], brec[0], (size_t) cw * chh * 2); memcpy(rec2[1], brec[1], (size_t) cw * chh * 2);
+        /* the coded block's levels sit with its component; the other block has none */
+        memset(lev2[0], 0, (size_t) cw * chh * 2); memset(lev2[1], 0, (size_t) cw * chh * 2);
+        memcpy((jccr >> 1) ? lev2[0] : lev2[1], blev, (size_t) cw * chh * 2);
+        orc_ctx_copy(&e->cabac, &ctxJ);
+      } else orc_ctx_copy(&e->cabac, &ctxSep);
     }
     /* 1611-1621: contexts are NOT reset (transform skip off); xGetIntraFracBitsQT(chroma) */
     e->cabac.bits = 0;
     enc_intra_chroma_pred_mode(e, a, cm, lm_ok);
-    orc_enc_bin(&e->cabac, (unsigned) cbf[0], ORC_CTX_QtCbf[1] + 0);
-    orc_enc_bin(&e->cabac, (unsigned) cbf[1], ORC_CTX_QtCbf[2] + cbf[0]);
-    if (cbf[0]) orc_residual_coding(&e->cabac, lev2[0], cw, chh, 1);
-    if (cbf[1]) orc_residual_coding(&e->cabac, lev2[1], cw, chh, 1);
+    { int lp = 0, vi = 0; enc_chroma_tu(e, cw, chh, (cbf[0] ? 2 : 0) | (cbf[1] ? 4 : 0), jccr, lev2[0], lev2[1], &lp, &vi); }
     const double cost = rd_cost(e, e->cabac.bits, dist);
     if (cost < bestCost) {
-      bestCost = cost; bestDist = dist; bestMode = cm; bestCbf = (cbf[0] ? 2 : 0) | (cbf[1] ? 4 : 0);
+      bestCost = cost; bestDist = dist; bestMode = cm; bestCbf = (cbf[0] ? 2 : 0) | (cbf[1] ? 4 : 0); bestJccr = jccr;
       for (int c = 0; c < 2; c++) { memcpy(e->best_rec[c], rec2[c], (size_t) cw * chh * 2); memcpy(e->best_lev[c], lev2[c], (size_t) cw * chh * 2); }
     }
   }
   orc_ctx_copy(&e->cabac, &ctxStart);
-  *out_dir = bestMode; *out_cbf = bestCbf;
+  *out_dir = bestMode; *out_cbf = bestCbf; *out_jccr = bestJccr;
   return bestDist;
 }
 
@@ -1009,7 +1181,7 @@ static void cache_set_from_cs(orc_enc *e, const partitioner *P, int d)
   const area_t a = P->cur; const int ch = P->ch;
   cache_ent *c = cache_entry(e, a);
   const unit_t *u = &e->store[d].units[0];
-  c->valid = 1; c->ch = (uint8_t) ch; c->dir = u->dir; c->mrl = u->mrl; c->cbf = u->cbf; c->depth = u->depth; c->mts = u->mts; c->lfnst = u->lfnst; c->ss = u->split_series;
+  c->valid = 1; c->ch = (uint8_t) ch; c->dir = u->dir; c->mrl = u->mrl; c->cbf = u->cbf; c->depth = u->depth; c->mts = u->mts; c->lfnst = u->lfnst; c->jccr = u->jccr; c->ss = u->split_series;
   if (!c->lev) c->lev = (int16_t *) malloc((size_t) a.w * a.h * 2);
   if (!ch) memcpy(c->lev, e->store[d].lev[0], (size_t) a.w * a.h * 2);
   else { const size_t n = (size_t) (a.w >> 1) * (a.h >> 1); memcpy(c->lev, e->store[d].lev[1], n * 2); memcpy(c->lev + n, e->store[d].lev[2], n * 2); }
@@ -1185,7 +1357,7 @@ static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int
   return dd;
 }
 /* xReuseCachedResult (EL/EncCu.cpp:5665-5771): cached mode + levels re-reconstructed against the current neighbourhood */
-static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts, int *out_lfnst)
+static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts, int *out_lfnst, int *out_jccr)
 {
   const cache_ent *c = cache_entry(e, a);
   uint64_t dist = 0;
@@ -1199,13 +1371,36 @@ static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *ou
     const int fm = c->dir == ORC_DM_CHROMA ? colocated_luma_mode(e, a) : c->dir;
     static int16_t tmpC[CCLM_TSTRIDE * CCLM_TSTRIDE]; int infoC[4] = { 0, 0, 0, 0 };
     if (fm >= 67 && fm <= 69) cclm_luma(e, cx, cy, cw, chh, fm != 67, tmpC, infoC);
+    const int lfDir = (fm >= 67 && fm <= 69) ? colocated_luma_mode(e, a) : fm;
+    if (c->jccr) {
+      /* DecCu::xIntraRecQT with a joint TU (DL/DecCu.cpp:330-414): the coded block's residual, the other one through the inverse ICT */
+      const int bd = e->cfg.bit_depth, mx = (1 << bd) - 1, mode = ict_mode(e, c->jccr), am = mode < 0 ? -mode : mode, comp = (c->jccr >> 1) ? 1 : 2;
+      const int qp = joint_qp(e, c->jccr);
+      const int16_t *lv = c->lev + (size_t) (comp - 1) * cw * chh;
+      const int lf = (c->lfnst && cw >= 4 && chh >= 4) ? c->lfnst : 0, lmode = lf ? orc_lfnst_mode(lfDir, cw, chh) : 0;
+      static int16_t jres[64 * 64];
+      orc_dequant_dq(lv, cw, chh, bd, qp, e->coef); orc_inv_lfnst(e->coef, cw, chh, lmode, lf); orc_inv_2d_mts(e->coef, cw, chh, bd, 0, jres, cw);
+      for (int k = 0; k < 2; k++) {
+        pred_chroma_comp(e, k + 1, cx, cy, cw, chh, fm, tmpC, infoC);
+        const int st = e->stride[k + 1]; const int16_t *org = e->org[k + 1] + cy * st + cx;
+        for (int j = 0; j < chh; j++) for (int i = 0; i < cw; i++) {
+          const int v0 = jres[j * cw + i]; int r;
+          if (comp == 1) r = k == 0 ? v0 : (am == 1 ? ((mode < 0 ? -v0 : v0) >> 1) : (mode < 0 ? -v0 : v0));
+          else r = k == 1 ? v0 : ((mode < 0 ? -v0 : v0) >> 1);
+          const int v = e->pred[j * cw + i] + r;
+          e->best_rec[k][j * cw + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v);
+        }
+        dist += (uint64_t) (e->sl.dist_weight[k] * (double) orc_sse(org, st, e->best_rec[k], cw, cw, chh));
+        memcpy(e->best_lev[k], c->lev + (size_t) k * cw * chh, (size_t) cw * chh * 2);
+      }
+    } else
     for (int k = 1; k <= 2; k++) {
       pred_chroma_comp(e, k, cx, cy, cw, chh, fm, tmpC, infoC);
-      dist += recon_from_levels(e, k, cx, cy, cw, chh, c->lev + (size_t) (k - 1) * cw * chh, (c->cbf >> k) & 1, 0, c->lfnst, (fm >= 67 && fm <= 69) ? colocated_luma_mode(e, a) : fm, e->best_rec[k - 1]);
+      dist += recon_from_levels(e, k, cx, cy, cw, chh, c->lev + (size_t) (k - 1) * cw * chh, (c->cbf >> k) & 1, 0, c->lfnst, lfDir, e->best_rec[k - 1]);
       memcpy(e->best_lev[k - 1], c->lev + (size_t) (k - 1) * cw * chh, (size_t) cw * chh * 2);
     }
   }
-  *out_dir = c->dir; *out_mrl = c->mrl; *out_cbf = c->cbf; *out_mts = c->mts; *out_lfnst = c->lfnst;
+  *out_dir = c->dir; *out_mrl = c->mrl; *out_cbf = c->cbf; *out_mts = c->mts; *out_lfnst = c->lfnst; *out_jccr = c->jccr;
   return dist;
 }
 
@@ -1214,7 +1409,7 @@ static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *ou
  * (not a MIP CU below 16x16, chroma blocks of at least 4x4, at most 64x64 luma), some block's last position is not DC (lfnstLastScanPos 3844-3850),
  * no block has a coefficient beyond the LFNST region (violatesLfnstConstrained 3837-3842) and the luma transform is DCT-II.
  * lev0 / lev1: luma levels, or Cb / Cr levels (stride = block width).  *lfnst_last receives cuCtx.lfnstLastScanPos. */
-static void enc_cu_syntax(orc_enc *e, int ch, area_t a, int dir, int mrl, int cbf, int mts, int lfnst, int lm_ok, const int16_t *lev0, const int16_t *lev1, int *lfnst_last)
+static void enc_cu_syntax(orc_enc *e, int ch, area_t a, int dir, int mrl, int cbf, int mts, int lfnst, int jccr, int lm_ok, const int16_t *lev0, const int16_t *lev1, int *lfnst_last)
 {
   int lastPos = 0, violates = 0;
   const int W = a.w >> (ch ? 1 : 0), H = a.h >> (ch ? 1 : 0);
@@ -1225,10 +1420,7 @@ static void enc_cu_syntax(orc_enc *e, int ch, area_t a, int dir, int mrl, int cb
     if (cbf & 1) { orc_residual_coding_mts(&e->cabac, lev0, a.w, a.h, 0, mts_allowed(e, a.w, a.h) ? mts : -1); lastPos |= e->cabac.last_scan_pos >= 1; violates |= e->cabac.last_scan_pos > maxPos; }
   } else {
     enc_intra_chroma_pred_mode(e, a, dir, lm_ok);
-    orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 2), ORC_CTX_QtCbf[1]);
-    orc_enc_bin(&e->cabac, (unsigned) !!(cbf & 4), ORC_CTX_QtCbf[2] + !!(cbf & 2));
-    if (cbf & 2) { orc_residual_coding(&e->cabac, lev0, W, H, 1); if (W >= 4 && H >= 4) { lastPos |= e->cabac.last_scan_pos >= 1; violates |= e->cabac.last_scan_pos > maxPos; } }
-    if (cbf & 4) { orc_residual_coding(&e->cabac, lev1, W, H, 1); if (W >= 4 && H >= 4) { lastPos |= e->cabac.last_scan_pos >= 1; violates |= e->cabac.last_scan_pos > maxPos; } }
+    enc_chroma_tu(e, W, H, cbf, jccr, lev0, lev1, &lastPos, &violates);
   }
   if (lfnst_last) *lfnst_last = lastPos;
   if (!(e->cfg.tools & ORC_TOOL_LFNST)) return;
@@ -1265,18 +1457,18 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
         for (int mtsFlag = startMtsFlag; mtsFlag <= endMtsFlag; mtsFlag++) {
           if (mtsFlag > 0 && lfnstIdx > 0) continue;                                                      /* JVET_O0368 2463-2466 */
           cs_sum t; memset(&t, 0, sizeof t);
-          int dir = 0, mrl = 0, cbf = 0, mts = 0, lfnst = lfnstIdx, valid = 1;
-          if (reuse) t.dist = reuse_cached(e, a, ch, &dir, &mrl, &cbf, &mts, &lfnst);
+          int dir = 0, mrl = 0, cbf = 0, mts = 0, lfnst = lfnstIdx, valid = 1, jccr = 0;
+          if (reuse) t.dist = reuse_cached(e, a, ch, &dir, &mrl, &cbf, &mts, &lfnst, &jccr);
           else if (!ch) {
             ps.lfnst = lfnstIdx; ps.mts_flag = mtsFlag; ps.tr_grp = trGrp;
             t.dist = est_intra_pred_luma(e, a, &ps, &valid, &dir, &mrl, &cbf, &mts); cbf = cbf ? 1 : 0;
             if (lfnstOn && !valid) continue;                                                              /* 2529-2532 */
-          } else t.dist = est_intra_pred_chroma(e, a, lm_ok, lfnstIdx, &dir, &cbf);
-          cu.dir = (uint8_t) dir; cu.mrl = (uint8_t) mrl; cu.cbf = (uint8_t) cbf; cu.mts = (uint8_t) mts; cu.lfnst = (uint8_t) lfnst;
+          } else t.dist = est_intra_pred_chroma(e, a, lm_ok, lfnstIdx, &dir, &cbf, &jccr);
+          cu.dir = (uint8_t) dir; cu.mrl = (uint8_t) mrl; cu.cbf = (uint8_t) cbf; cu.mts = (uint8_t) mts; cu.lfnst = (uint8_t) lfnst; cu.jccr = (uint8_t) jccr;
           /* CU-level rate from the node's start contexts (2593-2620) */
           e->cabac.bits = 0;
           int lfnstLast = 0;
-          enc_cu_syntax(e, ch, a, dir, mrl, cbf, mts, lfnst, lm_ok, e->best_lev[0], e->best_lev[1], &lfnstLast);
+          enc_cu_syntax(e, ch, a, dir, mrl, cbf, mts, lfnst, jccr, lm_ok, e->best_lev[0], e->best_lev[1], &lfnstLast);
           if (ch && reuse && !e->ctu_is_last) {
             /* the reuse path prices the CU with CABACWriter::coding_unit, whose end_of_ctu (EL/CABACWriter.cpp:2118-2141) adds the
              * terminating bin after the last chroma CU of a CTU that does not end the slice */
@@ -1418,11 +1610,11 @@ static void walk_tree(orc_enc *e, partitioner *P)
   int16_t *lv = e->tmp_lev[0], *lv1 = e->tmp_lev[1];
   if (!ch) {
     if (u->cbf & 1) for (int y = 0; y < H; y++) memcpy(lv + y * W, e->lev[0] + (a.y + y) * e->stride[0] + a.x, (size_t) W * 2);
-    enc_cu_syntax(e, 0, a, u->dir, u->mrl, u->cbf, u->mts, u->lfnst, 0, lv, lv1, 0);
+    enc_cu_syntax(e, 0, a, u->dir, u->mrl, u->cbf, u->mts, u->lfnst, 0, 0, lv, lv1, 0);
   } else {
     for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c))
       for (int y = 0; y < H; y++) memcpy((c == 1 ? lv : lv1) + y * W, e->lev[c] + ((a.y >> 1) + y) * e->stride[c] + (a.x >> 1), (size_t) W * 2);
-    enc_cu_syntax(e, 1, a, u->dir, u->mrl, u->cbf, u->mts, u->lfnst, cclm_allowed(e, a, u->split_series, u->depth), lv, lv1, 0);
+    enc_cu_syntax(e, 1, a, u->dir, u->mrl, u->cbf, u->mts, u->lfnst, u->jccr, cclm_allowed(e, a, u->split_series, u->depth), lv, lv1, 0);
   }
 }
 static void advance_ctx_ctu(orc_enc *e, area_t ctu)
@@ -1489,7 +1681,7 @@ int orc_compress_tiles(orc_enc *e, int tile_first, int tile_count, orc_ctu_resul
           orc_cu *o = &cus[n];
           o->x = u->x; o->y = u->y; o->w = (int16_t) (1 << u->lw); o->h = (int16_t) (1 << u->lh); o->ch_type = (uint8_t) ch;
           o->qt_depth = u->qt_depth; o->bt_depth = u->bt_depth; o->mt_depth = u->mt_depth; o->depth = u->depth;
-          o->intra_dir = u->dir; o->mrl_idx = ch ? u->mrl : (u->mrl & ~MIP_FLAG); o->mip_flag = !ch && (u->mrl & MIP_FLAG) ? 1 : 0; o->cbf = u->cbf; o->mts_idx = u->mts; o->lfnst_idx = u->lfnst; o->split_series = u->split_series;
+          o->intra_dir = u->dir; o->mrl_idx = ch ? u->mrl : (u->mrl & ~MIP_FLAG); o->mip_flag = !ch && (u->mrl & MIP_FLAG) ? 1 : 0; o->cbf = u->cbf; o->mts_idx = u->mts; o->lfnst_idx = u->lfnst; o->joint_cb_cr = u->jccr; o->split_series = u->split_series;
         }
         n++;
       }

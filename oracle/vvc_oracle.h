@@ -75,6 +75,7 @@ typedef struct {
   uint8_t  mts_idx;        /* luma TU: 0 DCT2xDCT2, 2..5 explicit MTS (tu.mtsIdx) */
   uint8_t  mip_flag;       /* luma CU: cu.mipFlag; intra_dir is then the MIP mode */
   uint8_t  lfnst_idx;      /* cu.lfnstIdx (0..2) */
+  uint8_t  joint_cb_cr;    /* chroma CU: tu.jointCbCr (0 separate, 1..3 = the cbf mask of the joint residual) */
   uint64_t split_series;
 } orc_cu;
 
@@ -95,6 +96,7 @@ int      orc_load_frame(orc_enc *e, const void *const org[3], const int stride[3
 /* compress every CTU of the loaded frame (tiles in raster order, CTUs in raster order inside a tile) */
 int      orc_compress_frame(orc_enc *e, orc_ctu_result *res /* [n_ctus] */, orc_cu *cus, int max_cus, int *n_cus);
 int      orc_compress_tiles(orc_enc *e, int tile_first, int tile_count, orc_ctu_result *res, orc_cu *cus, int max_cus, int *n_cus);   /* a range of tiles only (test runs spread tiles over processes) */
+int      orc_jccr_sign(const int16_t *cb, const int16_t *cr, int stride, int w, int h);
 int      orc_get_reco(orc_enc *e, void *const reco[3], const int stride[3], int bytes_per_sample);
 const char *orc_last_error(void);
 /* work counters for the bench's diagnostic model */

@@ -623,6 +623,38 @@ def gen_bitstream_lfnst():
     np.savez_compressed(os.path.join(HERE, "bitstream_lfnst_c.npz"), **out)
 
 
+def gen_ict():
+    """JointCbCr candidate choice: TrQuant::selectICTCandidates / fwdTransformICT on chroma residual pairs with every kind of correlation, both
+    sign flags: the cbf masks to test and the three joint residuals."""
+    R.ref_ict_candidates.argtypes = [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 4
+    g = np.random.default_rng(20264)
+    env = R.ref_env_create(192, 192, 8)
+    meta, cbs, crs, masks_all, joint_all = [], [], [], [], []
+    for (w, h) in ((2, 8), (4, 4), (8, 4), (8, 8), (16, 16), (4, 32), (32, 32)):
+        for corr in (-1.0, -0.5, 0.0, 0.5, 1.0, 2.0, -2.0):
+            for sign in (0, 1):
+                R.ref_env_reset(env)
+                base = g.normal(0, 20, (h, w))
+                cb = np.ascontiguousarray(np.clip((base * g.uniform(0.3, 1.5) + g.normal(0, 3, (h, w))).round(), -255, 255).astype(np.int16))
+                cr = np.ascontiguousarray(np.clip((corr * base + g.normal(0, 4, (h, w))).round(), -255, 255).astype(np.int16))
+                m = np.zeros(4, np.int32); j = np.zeros(3 * w * h, np.int16)
+                n = R.ref_ict_candidates(env, w, h, sign, P(cb), P(cr), P(m), P(j)); assert n >= 0
+                meta.append((w, h, sign, n)); cbs.append(cb.ravel()); crs.append(cr.ravel()); masks_all.append(m); joint_all.append(j)
+    np.savez_compressed(os.path.join(HERE, "ict.npz"), meta=np.array(meta, np.int32), cb=np.concatenate(cbs), cr=np.concatenate(crs), masks=np.stack(masks_all), joint=np.concatenate(joint_all))
+    print("ict cases", len(meta), "with candidates", int(sum(1 for r in meta if r[3] > 0)))
+
+
+def gen_bitstream_jccr():
+    """Decoder round trip with JointCbCr on (tools 0xb5b: every built tool; and 0x241: JointCbCr over DepQuant alone): joint_cb_cr flags and the
+    joint residual are parsed back by the reference's CABACReader, DecCu rebuilds both chroma residuals through the inverse ICT of the slice's
+    sign flag at the JointCbCr QP: every tu.jointCbCr, level and reconstructed sample must equal the oracle's."""
+    R.ref_env_set_tools.argtypes = [C.c_void_p, C.c_uint]
+    out = _pictures(((128, 128, 37, 1, 1, 8, 9), (200, 136, 32, 1, 1, 8, 1234), (256, 128, 27, 2, 1, 8, 5), (128, 128, 32, 1, 1, 10, 3)), 0xb5b, 1.0, oriented=30.0)
+    np.savez_compressed(os.path.join(HERE, "bitstream_jccr.npz"), **out)
+    out = _pictures(((128, 128, 32, 1, 1, 8, 11), (136, 72, 22, 1, 1, 8, 12)), 0xa41, 1.5)
+    np.savez_compressed(os.path.join(HERE, "bitstream_jccr_plain.npz"), **out)
+
+
 def _pictures(cases, tools, texture, oriented=0.0):
     import importlib, sys
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -639,8 +671,13 @@ def _pictures(cases, tools, texture, oriented=0.0):
         planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture, oriented=oriented)
         payload, sizes, cus, lev = O.write_frame(planes, W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools)
         env = R.ref_env_create(W, H, bd); R.ref_env_set_tiles(env, tc, tr)
-        if tools & 0x15a:
+        if tools & 0x35a:
             R.ref_env_set_tools(env, tools)
+        if tools & 0x200:
+            cb, cr = planes[1].astype(np.int16), planes[2].astype(np.int16)
+            O.lib().orc_jccr_sign.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+            R.ref_env_set_jccr_sign.argtypes = [C.c_void_p, C.c_int]
+            R.ref_env_set_jccr_sign(env, O.lib().orc_jccr_sign(P(np.ascontiguousarray(cb)), P(np.ascontiguousarray(cr)), cb.shape[1], cb.shape[1], cb.shape[0]))
         R.ref_env_reset(env)
         cw, chh = (W + 127) // 128, (H + 127) // 128
         tile_of = lambda rx, ry: max(i for i in range(tr) if ry >= (i * chh) // tr) * tc + max(i for i in range(tc) if rx >= (i * cw) // tc)
@@ -653,7 +690,7 @@ def _pictures(cases, tools, texture, oriented=0.0):
         nd = R.ref_dec_get_cus(env, P(rows), P(ss), len(rows)); assert nd == len(cus)
         dec = {(int(r[0]), int(r[1]), int(r[2])): (tuple(int(v) for v in r[3:]), int(s)) for r, s in zip(rows[:nd], ss[:nd])}
         for c in cus:
-            exp = ((int(c["w"]), int(c["h"]), int(c["qt_depth"]), int(c["bt_depth"]), int(c["mt_depth"]), int(c["depth"]), int(c["intra_dir"]), int(c["mrl_idx"]) | (int(c["mip_flag"]) << 7), int(c["cbf"]) | (int(c["mts_idx"]) << 8) | (int(c["lfnst_idx"]) << 16)), int(c["split_series"]))
+            exp = ((int(c["w"]), int(c["h"]), int(c["qt_depth"]), int(c["bt_depth"]), int(c["mt_depth"]), int(c["depth"]), int(c["intra_dir"]), int(c["mrl_idx"]) | (int(c["mip_flag"]) << 7), int(c["cbf"]) | (int(c["mts_idx"]) << 8) | (int(c["lfnst_idx"]) << 16) | (int(c["joint_cb_cr"]) << 20)), int(c["split_series"]))
             assert dec[(int(c["ch_type"]), int(c["x"]), int(c["y"]))] == exp, "decoded CU differs"
         for comp in range(3):
             d = np.zeros_like(lev[comp]); R.ref_dec_get_levels(env, comp, P(d), d.shape[1])
@@ -668,7 +705,7 @@ def _pictures(cases, tools, texture, oriented=0.0):
         pic_meta.append((W, H, qp, tc, tr, bd, seed, len(payload))); pic_bytes.append(payload); pic_sizes.append(np.pad(sizes, (0, 16 - len(sizes))))
         nlm = int(sum(1 for c in cus if c["ch_type"] == 1 and 67 <= c["intra_dir"] <= 69))
         nmts = int(sum(1 for c in cus if c["ch_type"] == 0 and c["mts_idx"] > 1))
-        print("picture", W, H, qp, tc, tr, bd, "payload", len(payload), "bytes, decoded by the reference:", nd, "CUs,", nlm, "with an LM chroma mode,", nmts, "with an MTS transform,", int(np.count_nonzero(cus["mip_flag"])), "MIP,", int(np.count_nonzero(cus["lfnst_idx"])), "LFNST")
+        print("picture", W, H, qp, tc, tr, bd, "payload", len(payload), "bytes, decoded by the reference:", nd, "CUs,", nlm, "with an LM chroma mode,", nmts, "with an MTS transform,", int(np.count_nonzero(cus["mip_flag"])), "MIP,", int(np.count_nonzero(cus["lfnst_idx"])), "LFNST,", int(np.count_nonzero(cus["joint_cb_cr"])), "JointCbCr")
     out["pic_meta"] = np.array(pic_meta, np.int32); out["pic_bytes"] = np.concatenate(pic_bytes); out["pic_sizes"] = np.stack(pic_sizes).astype(np.int32)
     out["tools"] = np.array([tools], np.int32); out["chroma_texture"] = np.array([texture], np.float64)
     if oriented:
@@ -700,11 +737,15 @@ if __name__ == "__main__":
         gen_bitstream_dq(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "depquant":
         gen_depquant(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ict":
+        gen_ict(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bitstream_jccr":
+        gen_bitstream_jccr(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream_lfnst":
         gen_bitstream_lfnst(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lfnst":
         gen_lfnst(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict()
     print("done")

@@ -394,6 +394,34 @@ def test_lfnst_against_the_reference_transform_path():
     assert nz > 900
 
 
+def test_joint_cbcr_candidates_against_the_reference():
+    """TrQuant::selectICTCandidates / fwdTransformICT (CL/TrQuant.cpp:87-137, 701-743): the cbf masks the search tests and the joint residual of every mask, for
+    residual pairs of every correlation under both sign flags."""
+    L = O.lib()
+    L.orc_test_ict.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    g = np.load(os.path.join(G, "ict.npz"))
+    off = joff = 0; some = 0
+    for (w, h, sign, n), exp in zip(g["meta"], g["masks"]):
+        k = int(w * h)
+        cb = np.ascontiguousarray(g["cb"][off:off + k]); cr = np.ascontiguousarray(g["cr"][off:off + k]); off += k
+        m = np.zeros(4, np.int32); j = np.zeros(3 * k, np.int16)
+        assert L.orc_test_ict(int(sign), P(cb), P(cr), k, P(m), P(j)) == n and np.array_equal(m[:n], exp[:n]), (w, h, sign)
+        assert np.array_equal(j, g["joint"][joff:joff + 3 * k]); joff += 3 * k
+        some += n > 0
+    assert some > 40
+
+
+def test_slice_data_payload_with_joint_cbcr():
+    """tools 0xb5b / 0xa41 (+ JointCbCr): payloads the reference's CABACReader parsed back including the joint_cb_cr flags, whose DecCu reconstruction (joint
+    residual at the component's / the JointCbCr QP, inverse ICT under the slice's sign flag) was the oracle's (tests/golden/make_golden.py bitstream_jccr)."""
+    import importlib
+    pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+    for name in ("bitstream_jccr.npz", "bitstream_jccr_plain.npz"):
+        g = np.load(os.path.join(G, name))
+        assert int(g["tools"][0]) & 0x200
+        _check_pictures(g, pkg)
+
+
 def test_slice_data_payload_with_lfnst():
     """tools 0x95b / 0x85b (+ LFNST): payloads the reference's CABACReader parsed back including residual_lfnst_mode, and whose DecCu reconstruction
     (inverse LFNST with the kernel set derived from the decoded modes) was the oracle's, on pictures with directional detail where LFNST is
