@@ -83,8 +83,8 @@ def main():
     ap.add_argument("--tiles", type=str, default="auto",
                     help="CxR uniform tile grid (1x1 = the reference cfg's single tile: one stream per frame; 4x2; ...); auto = one tile per CTU")
     ap.add_argument("--lib", type=str, default=None, help="alternative build of the HIP library (experiments only)")
-    ap.add_argument("--tools", type=lambda v: int(v, 0), default=0x95b,
-                    help="VVCX_TOOL_* bits; default MRL | MIP | LFNST | MTS | DepQuant | CCLM | CU reuse = every tool of the reference's intra cfg that is built so far")
+    ap.add_argument("--tools", type=lambda v: int(v, 0), default=0xb5b,
+                    help="VVCX_TOOL_* bits; default MRL | MIP | LFNST | MTS | DepQuant | CCLM | JointCbCr | CU reuse = every tool of the reference's intra cfg that is built so far")
     ap.add_argument("--classifier", action="store_true",
                     help="BASELINE config 3 flavour: the fork's FAST_ALGORITHM with the shipped forest (forests/partition_qp32.npz) on the device")
     ap.add_argument("--chroma-texture", type=float, default=0.5,
@@ -189,8 +189,9 @@ def main():
                                 + (" + LFNST (lfnstIdx passes, FastLFNST 1)" if args.tools & 8 else "")
                                 + (", dependent quantisation (DepQuant 1)" if args.tools & 0x40 else ", plain quant") + ", dual tree" + (", CU-result reuse (REUSE_CU_RESULTS)" if args.tools & 0x800 else "")
                                 + (", FAST_ALGORITHM partition classifier (shipped forest)" if args.tools & 0x1000 else "")
-                                + "; not built yet from the reference's cfg: ISP, transform skip / BDPCM (+ RDOQ-TS), JointCbCr, LMCS"
-                                + ("" if args.tools & 8 else ", LFNST") + ("" if args.tools & 0x40 else ", DepQuant")
+                                + (", JointCbCr" if args.tools & 0x200 else "")
+                                + "; not built yet from the reference's cfg: ISP, transform skip / BDPCM (+ RDOQ-TS), LMCS"
+                                + ("" if args.tools & 8 else ", LFNST off") + ("" if args.tools & 0x40 else ", DepQuant off") + ("" if args.tools & 0x200 else ", JointCbCr off")
                                 + "; leaf operators, syntax and reconstruction are pinned to the reference (CommonLib + decoder), the search decisions (EncCu / EncModeCtrl / IntraSearch restatement) are unpinned",
                        "tiling": ("one tile per CTU (every CTU an independent stream; the reference's cfg codes one tile per picture)" if (tc, tr) == (ctus_w, ctus_h)
                                   else "%dx%d uniform tiles" % (tc, tr)),

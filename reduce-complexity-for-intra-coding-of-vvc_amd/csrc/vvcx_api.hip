@@ -27,6 +27,8 @@ struct VxMipCase { int32_t w, h, mode, bit_depth, ref_off, pred_off; };
 extern "C" __global__ void vvcx_leaf_mip_kernel(const VxMipCase *cases, const int16_t *refs, int16_t *preds);
 extern "C" __global__ void vvcx_deblock_kernel_u8(VxDeblockParams p);
 extern "C" __global__ void vvcx_deblock_kernel_u16(VxDeblockParams p);
+extern "C" __global__ void vvcx_jccr_sign_kernel_u8(VxFrameDev *frames, int wc, int hc);
+extern "C" __global__ void vvcx_jccr_sign_kernel_u16(VxFrameDev *frames, int wc, int hc);
 extern "C" __global__ void vvcx_leaf_dq_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int qp, int comp, int mts, int cbf_cb, unsigned long long *out, int lf, int lfdir);
 extern "C" __global__ void vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp, unsigned long long *out);
 
@@ -68,7 +70,7 @@ struct vvcx_handle {
 };
 
 #define VVCX_PAYLOAD_BYTES_PER_CTU 32768u
-static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_LFNST | VVCX_TOOL_MTS | VVCX_TOOL_DEPQUANT | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST;
+static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_LFNST | VVCX_TOOL_MTS | VVCX_TOOL_JCCR | VVCX_TOOL_DEPQUANT | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST;
 
 // Quantizer::initQuantBlock (CL/DepQuant.cpp:694-739) for blocks with log2 w + log2 h = lsum: the quantiser's shift / scale / thresholds and the fixed-point
 // distortion normalisation, which the reference derives in fp64 from lambda.  qp: what QpParam hands over (with QpBDOffset).
@@ -104,6 +106,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   // and on the search's MIP form of the saved mode lists (EL/IntraSearch.cpp:750-775)
   if ((cfg->tools & VVCX_TOOL_LFNST) && (cfg->tools & (VVCX_TOOL_DEPQUANT | VVCX_TOOL_MIP)) != (VVCX_TOOL_DEPQUANT | VVCX_TOOL_MIP))
     return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_LFNST needs VVCX_TOOL_DEPQUANT and VVCX_TOOL_MIP (tool set 0x%x)", cfg->tools);
+  if ((cfg->tools & VVCX_TOOL_JCCR) && !(cfg->tools & VVCX_TOOL_DEPQUANT)) return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_JCCR needs VVCX_TOOL_DEPQUANT (tool set 0x%x)", cfg->tools);
   if (cfg->ctu_size != 128 || !cfg->dual_tree) return fail(VVCX_ERR_UNSUPPORTED, "only CTUSize 128 with DualITree 1");
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7) || cfg->pic_w <= 0 || cfg->pic_h <= 0) return fail(VVCX_ERR_ARG, "picture size must be a positive multiple of 8");
   if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return fail(VVCX_ERR_UNSUPPORTED, "bit depth %d", cfg->bit_depth);
@@ -139,7 +142,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
       hipMalloc((void **) &h->units_d, h->units_frame * sizeof(VxUnit) * F) != hipSuccess ||
       hipMalloc((void **) &h->stream_ctx_d, (size_t) F * h->ntiles * 2 * VXD_NUM_CTX * 2) != hipSuccess ||
       hipMalloc((void **) &h->counters_d, 56 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc((void **) &h->dq_d, 48 * sizeof(VxDqConst)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
+      hipMalloc((void **) &h->dq_d, 96 * sizeof(VxDqConst)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
   if (cfg->emit_payload) {                       // VVCX_PAYLOAD_BYTES_PER_CTU per CTU: a CTU of 8-bit video at QP >= 17 stays far below (raw samples are 24 KB)
     const size_t nstream = (size_t) F * h->ntiles;
     h->payload_off.resize(nstream); h->payload_cap.resize(nstream);
@@ -284,6 +287,11 @@ extern "C" int vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n)
     d.units[0] = h->units_d + (size_t) f * h->units_frame; d.units[1] = d.units[0] + h->units_plane;
   }
   HIPCHK(hipMemcpy(h->frames_d, h->frames_h.data(), sizeof(VxFrameDev) * (size_t) n, hipMemcpyHostToDevice));
+  if (h->cfg.tools & VVCX_TOOL_JCCR) {                    // the slice's joint_cb_cr_sign_flag from the bound picture (EL/EncSlice.cpp:1594-1597), left in its record
+    if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_jccr_sign_kernel_u8, dim3((unsigned) n), dim3(VXD_NT), 0, 0, h->frames_d, h->cfg.pic_w >> 1, h->cfg.pic_h >> 1);
+    else hipLaunchKernelGGL(vvcx_jccr_sign_kernel_u16, dim3((unsigned) n), dim3(VXD_NT), 0, 0, h->frames_d, h->cfg.pic_w >> 1, h->cfg.pic_h >> 1);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipMemset(h->units_d, 0, h->units_frame * sizeof(VxUnit) * (size_t) n));
   HIPCHK(hipMemset(h->lev_d, 0, h->lev_frame * 2 * (size_t) n));
   std::vector<uint16_t> ctx((size_t) n * h->ntiles * 2 * VXD_NUM_CTX);
@@ -363,7 +371,9 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
   for (int k = 0; k < 2; k++) { p.min_qt[k] = h->cfg.min_qt[k]; p.max_bt_depth[k] = h->cfg.max_bt_depth[k]; p.max_bt_size[k] = h->cfg.max_bt_size[k]; p.max_tt_size[k] = h->cfg.max_tt_size[k]; p.qp_c[k] = h->sl.qp_c[k]; p.dist_weight[k] = h->sl.dist_weight[k]; }
   p.ctus_w = h->ctus_w; p.ctus_h = h->ctus_h; p.uw = h->uw; p.uh = h->uh; p.qp = h->sl.qp;
   p.lambda = h->sl.lambda;
-  { const int bdo = 6 * (h->cfg.bit_depth - 8); p.qp_tr = h->sl.qp + bdo; p.qp_tr_c[0] = h->sl.qp_c[0] + bdo; p.qp_tr_c[1] = h->sl.qp_c[1] + bdo; }
+  { const int bdo = 6 * (h->cfg.bit_depth - 8); p.qp_tr = h->sl.qp + bdo; p.qp_tr_c[0] = h->sl.qp_c[0] + bdo; p.qp_tr_c[1] = h->sl.qp_c[1] + bdo;
+    // QpParam of the modes +-2: the mapping table's value (one table for all chroma) + pps_joint_cbcr_qp_offset (CbCrQpOffset -1, APP/EncAppCfg.cpp:1082)
+    int qj = h->sl.qp_c[0] - 1; qj = qj < -bdo ? -bdo : qj > 63 ? 63 : qj; p.qp_tr_j = qj + bdo; }
   p.dist_scale = (double) (1 << 15) / h->sl.lambda;                       // CL/RdCost.cpp:79
   p.sqrt_lambda_fp = sqrt(h->sl.lambda) * (1.0 / (double) (1 << 15));     // EL/IntraSearch.cpp:297
   p.frames = h->frames_d; p.streams = h->streams_d; p.task_ctu = h->task_ctu_d; p.results = h->results_d; p.stream_ctx = h->stream_ctx_d;
@@ -374,11 +384,19 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
   p.n_streams = ns;
   if (h->cfg.tools & VVCX_TOOL_DEPQUANT) {
     // the quantiser's lambda of a component: TrQuant::setLambdas / selectLambda (EL/EncSlice.cpp:107-149, EL/IntraSearch.cpp:2889) = lambda / distortion weight for chroma
-    VxDqConst tab[48]; memset(tab, 0, sizeof tab);
+    VxDqConst tab[96]; memset(tab, 0, sizeof tab);
+    const bool jccr = (h->cfg.tools & VVCX_TOOL_JCCR) != 0;
     for (int comp = 0; comp < 3; comp++) {
-      const double lam = comp ? h->sl.lambda / h->sl.dist_weight[comp - 1] : h->sl.lambda;
+      double lam = comp ? h->sl.lambda / h->sl.dist_weight[comp - 1] : h->sl.lambda;
+      if (comp && jccr && h->sl.qp > 18) lam = 1.3 * lam;          // EL/IntraSearch.cpp:2937-2942: every chroma block once JointCbCr is on
       const int qp = comp ? p.qp_tr_c[comp - 1] : p.qp_tr;
       for (int lsum = 2; lsum <= 12; lsum++) tab[comp * 16 + lsum] = dq_consts_of(lsum, h->cfg.bit_depth, qp, lam);
+    }
+    if (jccr) for (int mask = 1; mask <= 3; mask++) {              // joint blocks: the Cb lambda loosened by 0.8 (modes +-1, +-3) or 0.5 (+-2), QP of the coded component or the JointCbCr QP
+      double lam = (mask == 3 ? 0.5 : 0.8) * (h->sl.lambda / h->sl.dist_weight[0]);
+      if (h->sl.qp > 18) lam = 1.3 * lam;
+      const int qp = mask == 3 ? p.qp_tr_j : p.qp_tr_c[(mask >> 1) ? 0 : 1];
+      for (int lsum = 2; lsum <= 12; lsum++) tab[(2 + mask) * 16 + lsum] = dq_consts_of(lsum, h->cfg.bit_depth, qp, lam);
     }
     HIPCHK(hipMemcpyAsync(h->dq_d, tab, sizeof tab, hipMemcpyHostToDevice, stream));
     p.dq_consts = h->dq_d;
@@ -477,7 +495,7 @@ extern "C" int vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus
         if (cus && n < max_cus) {
           vvcx_cu &o = cus[n];
           o.x = u.x; o.y = u.y; o.w = (int16_t) (1 << u.lw); o.h = (int16_t) (1 << u.lh); o.ch_type = (uint8_t) ch;
-          o.qt_depth = u.qt; o.bt_depth = u.bt; o.mt_depth = u.mt; o.depth = u.depth; o.intra_dir = u.dir; o.mrl_idx = u.mrl & 0x7f; o.mip_flag = u.mrl >> 7; o.cbf = u.cbf; o.mts_idx = u.mts & 7; o.lfnst_idx = u.mts >> 4; o.split_series = u.ss;
+          o.qt_depth = u.qt; o.bt_depth = u.bt; o.mt_depth = u.mt; o.depth = u.depth; o.intra_dir = u.dir; o.mrl_idx = u.mrl & 0x7f; o.mip_flag = u.mrl >> 7; o.cbf = u.cbf; o.mts_idx = ch ? 0 : (u.mts & 7); o.joint_cb_cr = ch ? (u.mts & 7) : 0; o.lfnst_idx = u.mts >> 4; o.split_series = u.ss;
         }
         n++;
       }

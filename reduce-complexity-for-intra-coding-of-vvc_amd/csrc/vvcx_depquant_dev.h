@@ -119,11 +119,11 @@ __device__ inline int dq_gtx_off(int ch, int diag) { return ch ? (diag < 1 ? 6 :
 // cbf_ctx0 + bit i of cbf_mask (cbf_ctx0 < 0: inferred cbf); path nodes at nodes + i * node_stride bytes (HBM, 4 * positions bytes each); decisions
 // and last-position offsets in the LDS area wk (80 + 2 * positions bytes per item).  absSum of item i -> L.dq_abs[abs0 + i].
 __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, int cf_stride, uint8_t *nodes, int node_stride, uint8_t *wk, int abs0,
-                                                 int ci0, int ci_step, int cbf_ctx0, unsigned cbf_mask, int w, int h, int comp, int zo, int lfnst, int lane)
+                                                 int ci0, int ci_step, int cbf_ctx0, unsigned cbf_mask, int w, int h, int comp, int zo, int lfnst, int lane, int qidx = -1)
 {
   n_items = uni(n_items); w = uni(w); h = uni(h); comp = uni(comp); zo = uni(zo); lfnst = uni(lfnst); ci0 = uni(ci0); ci_step = uni(ci_step); cbf_ctx0 = uni(cbf_ctx0);
   const int ch = comp ? 1 : 0, lw = ilog2i(w), lh = ilog2i(h);
-  const VxDqConst q = L.par.dq_consts[comp * 16 + lw + lh];
+  const VxDqConst q = L.par.dq_consts[(uni(qidx) < 0 ? comp : uni(qidx)) * 16 + lw + lh];      // qidx: another row of the table (joint chroma blocks)
   const ScanGeo geo = scan_geo(w, h);
   const int lcw = geo.lcw, lch = geo.lch, lcg = geo.lcg, gs = 1 << lcg, total = geo.nscan;
   const int nzw = imin(32, w), nzh = imin(32, h), wsbb = geo.wg, hsbb = geo.hg;
@@ -442,11 +442,11 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
 // one block of the calling wave's own candidate: decisions in the wave's rate-estimator scratch and tmp (both free at that point of wave_code_block:
 // the transform's first stage has been consumed), path nodes in the wave's HBM area
 template <bool SMALL>
-__device__ inline int wave_depquant(int16_t *cf_g, int buf_off, uint8_t *scratch, int ci, int w, int h, int comp, int cbf_ctx, int zo, int lfnst, int lane)
+__device__ inline int wave_depquant(int16_t *cf_g, int buf_off, uint8_t *scratch, int ci, int w, int h, int comp, int cbf_ctx, int zo, int lfnst, int lane, int qidx = -1)
 {
   const int wave_ = uni(VTX >> 6);
   int16_t *cf = SMALL ? L.wm[wave_].slot + BUF + uni(buf_off) : cf_g;
-  wave_depquant_batch(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, (uint8_t *) &L.wm[wave_].ws, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane);
+  wave_depquant_batch(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, (uint8_t *) &L.wm[wave_].ws, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
   return uni(L.dq_abs[64 + wave_]);
 }
 

@@ -34,6 +34,8 @@ struct VxFrameDev {         // one bound picture
   int16_t    *lev[3];       // quantised levels, plane layout (owned by the handle)
   int32_t     lstride[3];
   VxUnit     *units[2];     // luma-tree / chroma-tree maps, uw x uh
+  int32_t     jccr_sign;    // slice joint_cb_cr_sign_flag of the picture (VVCX_TOOL_JCCR; written by vvcx_jccr_sign_kernel at bind time)
+  int32_t     pad_;
 };
 
 struct VxLeafPred { int32_t comp, x, y, w, h, mode, mrl; };      // same layout as vvcx_pred_case
@@ -55,6 +57,7 @@ struct VxParams {
   int32_t ctus_w, ctus_h, uw, uh;
   int32_t qp, qp_c[2];               // slice QP, mapped chroma QPs
   int32_t qp_tr, qp_tr_c[2];         // + QpBDOffset: what QpParam hands to quantisation (CL/Quant.cpp:68-106)
+  int32_t qp_tr_j;                   // the JointCbCr QP (joint blocks of cbf mask 3)
   double  lambda, dist_scale, sqrt_lambda_fp, dist_weight[2];
   const VxFrameDev   *frames;
   const VxStreamDesc *streams;
@@ -76,7 +79,7 @@ struct VxParams {
   const int32_t      *f_root;        // [f_ntrees]
   int32_t             f_ntrees, f_nclasses;
   int32_t             f_classes[8];
-  const VxDqConst    *dq_consts;     // [3 * 16] (VVCX_TOOL_DEPQUANT)
+  const VxDqConst    *dq_consts;     // [6 * 16] (VVCX_TOOL_DEPQUANT): Y, Cb, Cr, then the joint blocks of cbf masks 1, 2, 3 (VVCX_TOOL_JCCR)
   int32_t             n_streams;     // stream descriptors of the launch: the workgroups (at most one per resident slot) take them from a queue (counters[52])
 };
 
@@ -121,4 +124,6 @@ struct VxRbItem { double cost; uint64_t dist, bits; int32_t cbf, sum0, test, wav
 #define VXD_OFF_CACHE   ((VXD_OFF_POOL_REC + 2 * VXD_POOL_ITEMS * (int) sizeof(VxRbItem) + 255) & ~255)
 #define VXD_OFF_CACHE_LEV (VXD_OFF_CACHE + VXD_CACHE_ENTRIES * (int) sizeof(VxCacheEnt))
 #define VXD_OFF_META    (VXD_OFF_CACHE_LEV + VXD_CACHE_DIM * VXD_CACHE_DIM * 2)      // uint32: CTU generations this scratch slot has seen (validates CU-cache entries)
-#define VXD_SCRATCH_BYTES (VXD_OFF_META + 256)
+#define VXD_OFF_JCCR    (VXD_OFF_META + 256)                                          // JointCbCr: per wave joint residual | its reconstruction | levels | best pair of reconstructions | best levels (6 x 1024 int16)
+#define VXD_JCCR_WAVE   (6 * 1024 * 2)
+#define VXD_SCRATCH_BYTES (VXD_OFF_JCCR + VXD_NW * VXD_JCCR_WAVE)

@@ -51,6 +51,7 @@ enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_B
 #define TOOL_MTS (1u << 4)
 #define TOOL_DEPQUANT (1u << 6)
 #define TOOL_CCLM (1u << 8)
+#define TOOL_JCCR (1u << 9)
 #define TOOL_FAST (1u << 12)
 enum { LM_CHROMA = 67, MDLM_L = 68, MDLM_T = 69 };
 enum { PLANAR = 0, DC = 1, HOR = 18, DIA = 34, VER = 50, VDIA = 66, DM_CHROMA = 70 };
@@ -1568,8 +1569,9 @@ __device__ void load_tables()
 template <bool SMALL, bool SUMABS = false>
 __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, int buf_off, int16_t *rec_g, int16_t *lev_g, int32_t *tmp_g, int w, int h, int bd, int qp,
                                 int lane, unsigned long long &sse_out, int &cbf_out, int given = -1, int *sumabs_out = nullptr, int comp = 0, int ci = 0, int cbf_cb = 0,
-                                int lf = 0, int lfmode = 0)
+                                int lf = 0, int lfmode = 0, int raw = 0, int qidx = -1)
 {
+  // raw: the block is a bare residual (org = the residual, rec = zeros on entry): rec receives the reconstructed residual, unclipped (joint chroma blocks)
   // lf: cu.lfnstIdx for a block of at least 4x4 (0 otherwise), lfmode: lfnst_mode() of its final intra mode (dependent quantisation only)
   int coef_sum = 0;                                     // SUMABS: sum of |DCT-II coefficient| for the MTS pruning (TrQuant::transformNxN 1049-1124)
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given);
@@ -1628,7 +1630,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   }
   if (dq && given < 0) {
     wave_sync();
-    abs_sum = wave_depquant<SMALL>(lev, buf_off, L.par.scratch + (size_t) blockIdx.x * L.par.scratch_per_stream, ci, w, h, comp, VX_CTX_QtCbf[comp] + (comp == 2 ? cbf_cb : 0), 0, lf, lane);
+    abs_sum = wave_depquant<SMALL>(lev, buf_off, L.par.scratch + (size_t) blockIdx.x * L.par.scratch_per_stream, ci, w, h, comp, VX_CTX_QtCbf[comp] + (comp == 2 ? cbf_cb : 0), 0, lf, lane, qidx);
   } else abs_sum = given < 0 ? uni(wave_sum_i32(abs_sum)) : given;
   if (SUMABS) *sumabs_out = wave_sum_i32(coef_sum);
   wave_sync();
@@ -1668,6 +1670,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
       for (int k = 0; k < zw; k++) s += Mw[k * w + i2] * tcol[k * h + j2];
       int r = (s + irnd2) >> ishift2;
       r = r < -32768 ? -32768 : r > 32767 ? 32767 : r;
+      if (raw) { rec[o] = (int16_t) r; continue; }
       int v = rec[o] + (int) (int16_t) r;
       v = v < 0 ? 0 : v > mx ? mx : v;
       rec[o] = (int16_t) v;
@@ -2497,6 +2500,32 @@ __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, in
 //   C2  the Cb trellises of all modes side by side (they all start from the node's contexts)
 //   C3  four modes at a time, one per wave: Cb reconstruction and rate (the wave's contexts advance), then the Cr trellises of the four modes in one wavefront
 //       (each from its wave's contexts and with its own tu.cbf[Cb]), then Cr reconstruction, rate and the mode's cost.
+// ---- JointCbCr (JVET_O0105 inter-chroma transform).  g_ictModes (CL/Rom.cpp:613): signed mode of a cbf mask under the slice's sign flag
+__device__ inline int ict_mode(int sign, int mask) { const int m = mask == 1 ? 3 : mask == 2 ? 1 : 2; return sign ? -m : m; }
+// fwdTransformCbCr (CL/TrQuant.cpp:87-137): joint residual of one sample pair and the squared error of representing both residuals by it
+__device__ inline int ict_fwd(int b, int r, int mode, long long &err)
+{
+  int v, eb, er;
+  switch (mode) {
+    case  1: v = (4 * b + 2 * r) / 5; eb = b - v; er = r - (v >> 1); break;
+    case -1: v = (4 * b - 2 * r) / 5; eb = b - v; er = r - (-v >> 1); break;
+    case  2: v = (b + r) / 2; eb = b - v; er = r - v; break;
+    case -2: v = (b - r) / 2; eb = b - v; er = r + v; break;
+    case  3: v = (4 * r + 2 * b) / 5; eb = b - (v >> 1); er = r - v; break;
+    default: v = (4 * r - 2 * b) / 5; eb = b - (-v >> 1); er = r - v; break;
+  }
+  err += (long long) eb * eb + (long long) er * er;
+  return v;
+}
+// invTransformCbCr (139-156): residual of component k (0 Cb, 1 Cr) from the joint residual c of a block coded as Cb (modes +-1, +-2) or as Cr (+-3)
+__device__ inline int ict_inv(int c, int mode, int k)
+{
+  const int am = mode < 0 ? -mode : mode, sc = mode < 0 ? -c : c;
+  if (am == 3) return k == 1 ? c : (sc >> 1);
+  return k == 0 ? c : (am == 1 ? (sc >> 1) : sc);
+}
+__device__ inline long long wave_sum_i64(long long v) { return (long long) wave_sum_u64((unsigned long long) v); }
+
 template <bool SMALL>
 __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int lane, int w, int h)
 {
@@ -2511,6 +2540,8 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
   const int n_rd = uni(L.n_rd);
   // LFNST of the pass on both components of blocks of at least 4x4; kernel choice: the final mode, or the co-located luma mode for the LM modes (CL/TrQuant.cpp:449-457)
   const int psLf = (uni((int) (p.tools & TOOL_LFNST)) && w >= 4 && h >= 4) ? uni((int) L.ps_lfnst) : 0;
+  const int jccrOn = uni((int) (p.tools & TOOL_JCCR)) != 0;
+  int njoint = 0;
 #define CHROMA_LFMODE(c_) (psLf ? lfnst_mode((uni((int) L.rd[c_].mode) >= LM_CHROMA && uni((int) L.rd[c_].mode) <= MDLM_T) ? uni(L.colm) : uni((int) L.rd[c_].mrl), w, h) : 0)
   // ---- C1
   for (int c = wave; c < n_rd; c += NW) {
@@ -2546,6 +2577,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
     const int lfm = have ? CHROMA_LFMODE(c) : 0;
     int16_t *recb = SMALL ? L.wm[wave].slot : slot_rec(scratch, 2 * P, wave, cur), *levb = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, 2 * P, wave, cur);
     unsigned long long dist = 0; int cbfs[2] = { 0, 0 };
+    double compCost = 0; int jccr = 0;
     if (have) {
       { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s_ = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s_[e]; }
       for (int e = lane; e < P; e += 64) { recb[e] = poolPred[(size_t) (2 * c) * P + e]; levb[e] = poolCoef[(size_t) (2 * c) * P + e]; }
@@ -2554,7 +2586,8 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
       unsigned long long sse; int cbf2;
       wave_code_block<SMALL>(org, 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[0], lane, sse, cbf2, cbfs[0], nullptr, 1, CI_W(wave), 0, psLf, lfm);
       dist += (unsigned long long) (p.dist_weight[0] * (double) sse);
-      { Cab cb; cb.ci = CI_W(wave); cb.bits = 0; if (lane == 0) enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]); if (cbfs[0]) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane); }
+      { Cab cb; cb.ci = CI_W(wave); cb.bits = 0; if (lane == 0) enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]); if (cbfs[0]) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane);
+        double c0 = 0; if (lane == 0) c0 = rd_cost(p, cb.bits, dist); compCost = lane0_d(c0); }      // xGetIntraFracBitsQTChroma(Cb) 2625-2692
       wave_sync();
       if (lane == 0) L.rb_pairs[wave] = (uint8_t) cbfs[0];
     }
@@ -2577,9 +2610,92 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
       cbfs[1] = uni(L.dq_abs[c]) > 0;
       unsigned long long sse; int cbf2;
       wave_code_block<SMALL>(org, P, P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[1], lane, sse, cbf2, cbfs[1], nullptr, 2, CI_W(wave), cbfs[0], psLf, lfm);
-      dist += (unsigned long long) (p.dist_weight[1] * (double) sse);
-      { Cab cb; cb.ci = CI_W(wave); cb.bits = 0; if (lane == 0) enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]); if (cbfs[1]) residual_coding_wave<SMALL>(cb, P, lev, w, h, 1, lane); }
+      const unsigned long long distCr = (unsigned long long) (p.dist_weight[1] * (double) sse);
+      dist += distCr;
+      { Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
+        if (lane == 0) { enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]); if (jccrOn && (cbfs[0] | cbfs[1])) enc_bin(cb, 0u, VX_CTX_JointCbCrFlag + ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 1 : 0)) - 1); }
+        if (cbfs[1]) residual_coding_wave<SMALL>(cb, P, lev, w, h, 1, lane);
+        double c1 = 0; if (lane == 0) c1 = compCost + rd_cost(p, cb.bits, distCr); compCost = lane0_d(c1); }
       wave_sync();
+      if (jccrOn && (cbfs[0] | cbfs[1])) {
+        // xRecurIntraChromaCodingQT 4060-4150: up to two joint candidates (TrQuant::selectICTCandidates) against the sum of the two separate costs
+        int16_t *jb = (int16_t *) (scratch + VXD_OFF_JCCR + (size_t) wave * VXD_JCCR_WAVE);
+        int16_t *jres = jb, *jout = jb + 1024, *jlev = jb + 2048, *brec = jb + 3072, *blev = jb + 5120;
+        const int16_t *pCb = poolPred + (size_t) (2 * c) * P, *pCr = poolPred + (size_t) (2 * c + 1) * P;
+        const int sign = uni(L.fdv.jccr_sign);
+        long long d0 = 0, d1 = 0, e1 = 0, e2 = 0, e3 = 0;
+        for (int e = lane; e < P; e += 64) {
+          const int b = org[e] - pCb[e], r = org[P + e] - pCr[e];
+          d0 += (long long) b * b; d1 += (long long) r * r;
+          ict_fwd(b, r, ict_mode(sign, 1), e1); ict_fwd(b, r, ict_mode(sign, 2), e2); ict_fwd(b, r, ict_mode(sign, 3), e3);
+        }
+        d0 = wave_sum_i64(d0); d1 = wave_sum_i64(d1); e1 = wave_sum_i64(e1); e2 = wave_sum_i64(e2); e3 = wave_sum_i64(e3);
+        long long min1 = d0 < d1 ? d0 : d1, min2 = 0x7fffffffffffffffll; int m1 = 0, m2 = 0;
+        for (int m = 1; m < 4; m++) {
+          const long long pd = m == 1 ? e1 : m == 2 ? e2 : e3;
+          if (pd < min1) { m2 = m1; min2 = min1; m1 = m; min1 = pd; } else if (pd < min2) { m2 = m; min2 = pd; }
+        }
+        int masks[2], nm = 0;
+        if (m1) masks[nm++] = m1;
+        if (m2 && ((min2 < (9 * min1) / 8) || (!m1 && min2 < (3 * min1) / 2))) masks[nm++] = m2;
+        nm = uni(nm);
+        unsigned long long bestJDist = 0;
+        for (int q = 0; q < nm; q++) {
+          const int mask = uni(masks[q]), mode = ict_mode(sign, mask), comp = (mask >> 1) ? 1 : 2;
+          for (int e = lane; e < P; e += 64) { long long dm = 0; jres[e] = (int16_t) ict_fwd(org[e] - pCb[e], org[P + e] - pCr[e], mode, dm); jout[e] = 0; }
+          wave_sync();
+          njoint++;
+          unsigned long long sseJ; int cbfJ;
+          // the joint block: quantised as the Cb (masks 2, 3) / Cr (mask 1) block from the TU's start contexts, at the component's QP or (mask 3) the JointCbCr QP, loosened lambda (table rows 3..5)
+          wave_code_block<false>(jres, 0, 0, jout, jlev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, mask == 3 ? p.qp_tr_j : p.qp_tr_c[comp - 1], lane, sseJ, cbfJ, -1, nullptr, comp, CI_CUR, 0, psLf, lfm, 1, 2 + mask);
+          if (!cbfJ) continue;                              // the mask cannot be signalled with an empty block (3083-3087)
+          unsigned long long sCb = 0, sCr = 0;
+          const int mx = (1 << bd) - 1;
+          for (int e = lane; e < P; e += 64) {
+            const int cj = jout[e];
+            int vb = pCb[e] + ict_inv(cj, mode, 0), vr = pCr[e] + ict_inv(cj, mode, 1);
+            vb = vb < 0 ? 0 : vb > mx ? mx : vb; vr = vr < 0 ? 0 : vr > mx ? mx : vr;
+            jres[e] = (int16_t) vb; jout[e] = (int16_t) vr;          // the pair of reconstructions replaces the residuals
+            const int db = org[e] - vb, dr = org[P + e] - vr;
+            sCb += (unsigned long long) (db * db); sCr += (unsigned long long) (dr * dr);
+          }
+          sCb = wave_sum_u64(sCb); sCr = wave_sum_u64(sCr);
+          const unsigned long long dJ = (unsigned long long) (p.dist_weight[0] * (double) sCb) + (unsigned long long) (p.dist_weight[1] * (double) sCr);
+          { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s_ = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s_[e]; }
+          wave_sync();
+          Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
+          if (lane == 0) { enc_bin(cb, (unsigned) (mask >> 1), VX_CTX_QtCbf[1]); enc_bin(cb, (unsigned) (mask & 1), VX_CTX_QtCbf[2] + (mask >> 1)); enc_bin(cb, 1u, VX_CTX_JointCbCrFlag + mask - 1); }
+          residual_coding_wave<false>(cb, 0, jlev, w, h, 1, lane);
+          double cj = 0; if (lane == 0) cj = rd_cost(p, cb.bits, dJ);
+          cj = lane0_d(cj);
+          if (cj < compCost) {
+            compCost = cj; jccr = mask; bestJDist = dJ;
+            for (int e = lane; e < P; e += 64) { brec[e] = jres[e]; brec[P + e] = jout[e]; blev[e] = jlev[e]; }
+          }
+          wave_sync();
+        }
+        if (jccr) {                                         // the joint candidate replaces the separately coded pair
+          dist = bestJDist; cbfs[0] = jccr >> 1; cbfs[1] = jccr & 1;
+          for (int e = lane; e < P; e += 64) { recb[e] = brec[e]; recb[P + e] = brec[P + e]; levb[e] = (jccr >> 1) ? blev[e] : 0; levb[P + e] = (jccr >> 1) ? 0 : blev[e]; }
+        }
+        wave_sync();
+      }
+      if (jccrOn) {                                         // the contexts after the winning variant (4152-4170): replayed from the TU's start contexts
+        { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s_ = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s_[e]; }
+        wave_sync();
+        Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
+        const int msk = (cbfs[0] ? 2 : 0) | (cbfs[1] ? 1 : 0);
+        if (!jccr) {
+          if (lane == 0) enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]);
+          if (cbfs[0]) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane);
+          if (lane == 0) { enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]); if (msk) enc_bin(cb, 0u, VX_CTX_JointCbCrFlag + msk - 1); }
+          if (cbfs[1]) residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane);
+        } else {
+          if (lane == 0) { enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]); enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]); enc_bin(cb, 1u, VX_CTX_JointCbCrFlag + msk - 1); }
+          if (jccr >> 1) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane); else residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane);
+        }
+        wave_sync();
+      }
       double cost = 0;
       {                    // 1611-1621: contexts not reset; xGetIntraFracBitsQT(chroma)
         Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
@@ -2587,13 +2703,14 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
           enc_intra_chroma_pred_mode(cb, cm, L.colm, L.lm_ok);
           enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]);
           enc_bin(cb, (unsigned) cbfs[1], VX_CTX_QtCbf[2] + cbfs[0]);
+          if (jccrOn && (cbfs[0] | cbfs[1])) enc_bin(cb, jccr ? 1u : 0u, VX_CTX_JointCbCrFlag + ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 1 : 0)) - 1);
         }
         int fl = 0;
         if (cbfs[0]) { residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane); fl |= lfnst_flags(uni(L.rc_last[wave]), w, h); }
-        if (cbfs[1]) { residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane); fl |= lfnst_flags(uni(L.rc_last[wave]), w, h); }
+        if (cbfs[1] && jccr != 3) { residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane); fl |= lfnst_flags(uni(L.rc_last[wave]), w, h); }
         if (lane == 0) {
           cost = rd_cost(p, cb.bits, dist);
-          L.rd_cost[c] = cost; L.rd_dist[c] = dist; L.rd_cbf[c] = (uint8_t) ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 4 : 0)); L.rd_lfl[c] = (uint8_t) fl;
+          L.rd_cost[c] = cost; L.rd_dist[c] = dist; L.rd_cbf[c] = (uint8_t) ((cbfs[0] ? 2 : 0) | (cbfs[1] ? 4 : 0)); L.rd_lfl[c] = (uint8_t) fl; L.rd_mts[c] = (uint8_t) jccr;
         }
       }
       cost = lane0_d(cost);
@@ -2607,6 +2724,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
     }
   }
 #undef CHROMA_LFMODE
+  if (lane == 0) L.mts_evals[wave] = njoint;                  // joint blocks coded on top of the 2 per mode (work counters)
 }
 template <typename T>
 __device__ __noinline__ void op_chroma_rd(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
@@ -2637,15 +2755,16 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p_, const VxFrameDev &
   if (wave == 0) {
     const int slot = uni(L.wave_slot[ww]);
     const int16_t *levw = slot_lev(scratch, 2 * P, ww, slot);       // HBM (parked or big block)
-    const int cbfm = uni(L.rd_cbf[best]);
+    const int cbfm = uni(L.rd_cbf[best]), jm = (p.tools & TOOL_JCCR) ? uni((int) L.rd_mts[best]) : 0;
     Cab cb; cb.ci = CI_W(0); cb.bits = 0;
     if (lane == 0) {
       enc_intra_chroma_pred_mode(cb, L.rd[best].mode, L.colm, L.lm_ok);
       enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
       enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
+      if ((p.tools & TOOL_JCCR) && (cbfm & 6)) enc_bin(cb, jm ? 1u : 0u, VX_CTX_JointCbCrFlag + (((cbfm & 2) ? 2 : 0) | ((cbfm & 4) ? 1 : 0)) - 1);
     }
     if (cbfm & 2) residual_coding_wave<false>(cb, 0, levw, w, h, 1, lane);
-    if (cbfm & 4) residual_coding_wave<false>(cb, 0, levw + P, w, h, 1, lane);
+    if ((cbfm & 4) && jm != 3) residual_coding_wave<false>(cb, 0, levw + P, w, h, 1, lane);
     if (lane == 0) { enc_lfnst_idx(cb, 1, 2 * w, 2 * h, 0, 0, L.rd_lfl[best], L.ps_lfnst); L.win_idx = best; L.win_wave = ww; L.cu_bits = cb.bits; }
   }
   __syncthreads();
@@ -2714,6 +2833,27 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
   } else {
     const int lf = (w >= 4 && h >= 4) ? uni((int) L.ps_lfnst) : 0;
     const int lfm = lf ? lfnst_mode((mode >= LM_CHROMA && mode <= MDLM_T) ? uni(L.colm) : fm, w, h) : 0;
+    const int jm = (p.tools & TOOL_JCCR) ? uni((int) L.rd_mts[0]) : 0;
+    if (jm) {
+      // DecCu::xIntraRecQT of a joint TU (DL/DecCu.cpp:330-414): the coded block's residual at its QP, the other block through the inverse ICT
+      int16_t *jb = (int16_t *) (scratch + VXD_OFF_JCCR), *jout = jb + 1024, *jlev = jb + 2048;
+      const int mode = ict_mode(uni(L.fdv.jccr_sign), jm), comp = (jm >> 1) ? 1 : 2;
+      const int16_t *org = org_tile(scratch, n);
+      for (int e = lane; e < P; e += 64) { jout[e] = 0; jlev[e] = levb[(comp - 1) * P + e]; }
+      wave_sync();
+      unsigned long long sseJ; int cbfJ;
+      wave_code_block<false>(jout, 0, 0, jout, jlev, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, jm == 3 ? p.qp_tr_j : p.qp_tr_c[comp - 1], lane, sseJ, cbfJ, 1, nullptr, comp, 0, 0, lf, lfm, 1);
+      const int mx = (1 << bd) - 1;
+      for (int k = 0; k < 2; k++) {
+        int16_t *rec = recb + k * P;
+        chroma_pred_wave(rec, lm_in_buf(scratch, n), k, fm, w, h, bd, lane);
+        wave_sync();
+        unsigned long long sse = 0;
+        for (int e = lane; e < P; e += 64) { int v = rec[e] + ict_inv(jout[e], mode, k); v = v < 0 ? 0 : v > mx ? mx : v; rec[e] = (int16_t) v; const int d = org[k * P + e] - v; sse += (unsigned long long) (d * d); }
+        dist += (unsigned long long) (p.dist_weight[k] * (double) wave_sum_u64(sse));
+        wave_sync();
+      }
+    } else
     for (int k = 0; k < 2; k++) {
       int16_t *rec = recb + k * P;
       chroma_pred_wave(rec, lm_in_buf(scratch, n), k, fm, w, h, bd, lane);
@@ -2726,10 +2866,11 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
       enc_intra_chroma_pred_mode(cb, mode, L.colm, L.lm_ok);
       enc_bin(cb, (unsigned) !!(cbfm & 2), VX_CTX_QtCbf[1]);
       enc_bin(cb, (unsigned) !!(cbfm & 4), VX_CTX_QtCbf[2] + !!(cbfm & 2));
+      if ((p.tools & TOOL_JCCR) && (cbfm & 6)) enc_bin(cb, jm ? 1u : 0u, VX_CTX_JointCbCrFlag + (((cbfm & 2) ? 2 : 0) | ((cbfm & 4) ? 1 : 0)) - 1);
     }
     int fl = 0;
     if (cbfm & 2) { residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane); fl |= lfnst_flags(uni(L.rc_last[0]), w, h); }
-    if (cbfm & 4) { residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane); fl |= lfnst_flags(uni(L.rc_last[0]), w, h); }
+    if ((cbfm & 4) && jm != 3) { residual_coding_wave<SMALL>(cb, P, levb + P, w, h, 1, lane); fl |= lfnst_flags(uni(L.rc_last[0]), w, h); }
     if (lane == 0) enc_lfnst_idx(cb, 1, 2 * w, 2 * h, 0, 0, fl, uni((int) L.ps_lfnst));
     // coding_unit() ends with end_of_ctu (EL/CABACWriter.cpp:2118-2141): terminating bin after the last chroma CU of a CTU
     // that does not end the slice; estFracBitsTrm(0) = 0x10c (CL/Contexts.h:129)
@@ -3246,12 +3387,13 @@ __device__ __noinline__ int ctrl_b_done(const VxParams &p_, const VxFrameDev &fd
       const int best = L.win_idx, ww = L.win_wave;
       if (ch) L.cnt[0] += (unsigned long long) L.lm_nsatd;
       if (!ch && L.n_rd) { int ex = 0; for (int k = 0; k < NW; k++) ex += L.mts_evals[k]; L.cnt[1] += (unsigned long long) ex; L.cnt[2] += (unsigned long long) (ex * f.w * f.h); }      // transform candidates beyond DCT2
+      if (ch && L.n_rd && (p.tools & TOOL_JCCR)) { int ex = 0; for (int k = 0; k < NW; k++) ex += L.mts_evals[k]; L.cnt[1] += (unsigned long long) ex; L.cnt[2] += (unsigned long long) (ex * (f.w >> 1) * (f.h >> 1)); }      // joint chroma blocks
       L.cnt[1] += (unsigned long long) (ch ? 2 * L.n_rd : L.n_rd); L.cnt[2] += (unsigned long long) (ch ? 2 * L.n_rd * ((f.w >> 1) * (f.h >> 1)) : L.n_rd * f.w * f.h);
       L.op_a = L.wave_slot[ww];                         // slot of that wave holding the winner's reco / levels
       Sum &t = f.temp;
       t.dist = L.rd_dist[best];
       VxUnit &cu = L.cu;
-      cu.dir = L.rd[best].mode; cu.mrl = ch ? 0 : L.rd[best].mrl; cu.cbf = L.rd_cbf[best]; cu.mts = (uint8_t) ((ch ? 0 : L.rd_mts[best]) | (L.ps_lfnst << 4));      // lfnstIdx rides in bits 4-5
+      cu.dir = L.rd[best].mode; cu.mrl = ch ? 0 : L.rd[best].mrl; cu.cbf = L.rd_cbf[best]; cu.mts = (uint8_t) (((ch && !(p.tools & TOOL_JCCR)) ? 0 : L.rd_mts[best]) | (L.ps_lfnst << 4));      // luma: tu.mtsIdx, chroma: tu.jointCbCr; lfnstIdx rides in bits 4-5
       // cu_pred_data + cu_residual bits (EL/EncCu.cpp:2593-2619) and the CU's end contexts are left in cu_bits / wctx[0]
       // by the operation (luma: identical to the stage-B syntax from the same start contexts)
       t.bits = L.cu_bits;
@@ -3327,7 +3469,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         cu.ss = f.ss; cu.x = (int16_t) (f.x >> sh); cu.y = (int16_t) (f.y >> sh); cu.lw = (uint8_t) ilog2i(f.w >> sh); cu.lh = (uint8_t) ilog2i(f.h >> sh);
         cu.qt = f.qt; cu.mt = f.mt; cu.bt = f.bt; cu.depth = f.depth; cu.dir = 0; cu.mrl = 0; cu.cbf = 0; cu.mts = 0; cu.tag = (uint16_t) (tile + 1);
         if (mode == ETM_RECO_CACHED) {                  // xReuseCachedResult (EL/EncCu.cpp:5665-5771)
-          L.rd[0].mode = f.r_dir; L.rd[0].mrl = f.r_mrl; L.rd_cbf[0] = f.r_cbf; L.rd_mts[0] = ch ? 0 : (f.r_mts & 7); L.n_rd = 0;
+          L.rd[0].mode = f.r_dir; L.rd[0].mrl = f.r_mrl; L.rd_cbf[0] = f.r_cbf; L.rd_mts[0] = (uint8_t) (f.r_mts & 7); L.n_rd = 0;
           L.ps_lfnst = (int8_t) (f.r_mts >> 4); L.ps_mts = 0; L.ps_grp = 0; S.lfOn = 0;
           if (!ch) {                                    // MPM list for intra_luma_pred_modes
             int Ld, Ad; luma_neighbours(p, fd, f.x, f.y, f.w, f.h, tile, Ld, Ad);
@@ -3578,7 +3720,9 @@ __device__ __noinline__ void walk_tree(const VxParams &p_, const VxFrameDev &fd_
           enc_intra_chroma_pred_mode<WR>(cb, u->dir, unit_ldir(fd.units[0][((f.y + (f.h >> 1)) >> 2) * p.uw + ((f.x + (f.w >> 1)) >> 2)]), cclm_allowed(p, fd, f.x, f.y, u->ss, u->depth));
           enc_bin<WR>(cb, (unsigned) !!(u->cbf & 2), VX_CTX_QtCbf[1]);
           enc_bin<WR>(cb, (unsigned) !!(u->cbf & 4), VX_CTX_QtCbf[2] + !!(u->cbf & 2));
-          for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c)) {
+          const int jm = (p.tools & TOOL_JCCR) ? (u->mts & 7) : 0;
+          if ((p.tools & TOOL_JCCR) && (u->cbf & 6)) enc_bin<WR>(cb, jm ? 1u : 0u, VX_CTX_JointCbCrFlag + (((u->cbf & 2) ? 2 : 0) | ((u->cbf & 4) ? 1 : 0)) - 1);
+          for (int c = 1; c <= 2; c++) if ((u->cbf & (1 << c)) && !(c == 2 && jm == 3)) {
             for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[c][((f.y >> 1) + yy) * fd.lstride[c] + (f.x >> 1) + xx];
             residual_coding<WR>(cb, lv, W, H, 1, (uint16_t *) (lv + 4096));
             fl |= lfnst_flags(L.rc_last[0], W, H);
@@ -3913,3 +4057,28 @@ __device__ void run_streams(const VxParams &p)
 }
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_kernel_u8(VxParams p) { run_streams<uint8_t>(p); }
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_kernel_u16(VxParams p) { run_streams<uint16_t>(p); }
+
+// slice joint_cb_cr_sign_flag of a bound picture (setJointCbCrModes, EL/EncSlice.cpp:1503-1538): the sign of the correlation of the high-pass filtered Cb and
+// Cr planes over the interior samples; one workgroup per picture, launched when the pictures are bound
+template <typename T>
+__device__ void jccr_sign(VxFrameDev *frames, int wc, int hc)
+{
+  __shared__ long long part[NT];
+  VxFrameDev &fd = frames[blockIdx.x];
+  const T *cb = (const T *) fd.org[1], *cr = (const T *) fd.org[2];
+  const int sb = fd.stride[1], sr = fd.stride[2];
+  long long sum = 0;
+  const int iw = wc - 2, n = iw * (hc - 2);
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const int y = 1 + i / iw, x = 1 + i % iw;
+    const T *p = cb + y * sb + x, *q = cr + y * sr + x;
+    const int a = 12 * (int) p[0] - 2 * ((int) p[-1] + (int) p[1] + (int) p[-sb] + (int) p[sb]) - ((int) p[-1 - sb] + (int) p[1 - sb] + (int) p[-1 + sb] + (int) p[1 + sb]);
+    const int b = 12 * (int) q[0] - 2 * ((int) q[-1] + (int) q[1] + (int) q[-sr] + (int) q[sr]) - ((int) q[-1 - sr] + (int) q[1 - sr] + (int) q[-1 + sr] + (int) q[1 + sr]);
+    sum += (long long) a * b;
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) { long long t = 0; for (int i = 0; i < NT; i++) t += part[i]; fd.jccr_sign = t < 0; }
+}
+extern "C" __global__ void __launch_bounds__(NT) vvcx_jccr_sign_kernel_u8(VxFrameDev *frames, int wc, int hc) { jccr_sign<uint8_t>(frames, wc, hc); }
+extern "C" __global__ void __launch_bounds__(NT) vvcx_jccr_sign_kernel_u16(VxFrameDev *frames, int wc, int hc) { jccr_sign<uint16_t>(frames, wc, hc); }

@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libvvcx.so")
 TOOL_MRL = 1
 TOOL_LFNST = 1 << 3          # low-frequency non-separable transform: the lfnstIdx passes of the search, residual_lfnst_mode (needs DEPQUANT and MIP)
+TOOL_JCCR = 1 << 9           # JointCbCr: joint coding of the chroma residual pair (inter-chroma transform), joint_cb_cr flag (needs DEPQUANT)
 TOOL_MIP = 1 << 1            # matrix-based intra prediction searched (cfg MIP 1, FastMIP 1): mip_flag / MIP mode per luma CU
 TOOL_MTS = 1 << 4            # explicit intra MTS (cfg MTS 1, MTSIntraMaxCand 3): DST-VII / DCT-VIII pairs for luma TUs up to 32x32
 TOOL_DEPQUANT = 1 << 6       # dependent quantisation (cfg DepQuant 1): trellis quantiser, state-driven residual syntax and dequantiser

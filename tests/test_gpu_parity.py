@@ -146,6 +146,24 @@ def test_lfnst_without_cclm_and_cu_reuse_and_with_classifier():
     _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=0.5, oriented=30.0)], 256, 128, pkg.slice_params(27, dep_quant=True), tools=LF | pkg.TOOL_FAST)
 
 
+ALL = LF | pkg.TOOL_JCCR               # every tool built so far = bench.py's default tool set
+
+
+@pytest.mark.parametrize("case", [(128, 128, 37, 8, 1, 1, 9, 1.0), (200, 136, 32, 8, 1, 1, 1234, 1.0), (256, 128, 27, 8, 2, 1, 5, 1.5), (128, 128, 32, 10, 1, 1, 3, 1.0)])
+def test_joint_cbcr_in_the_search(case):
+    # tools 0xb5b: per chroma mode the joint candidates of TrQuant::selectICTCandidates against the separately coded pair (joint residual through the
+    # trellis at the component's / the JointCbCr QP with the loosened lambda, inverse ICT under the picture's sign flag, which the device derives when the
+    # pictures are bound), joint_cb_cr flag in every chroma rate, 1.3 x chroma lambda
+    W, H, qp, bd, tc, tr, seed, tex = case
+    _check([pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=tex, oriented=30.0)], W, H, pkg.slice_params(qp, bit_depth=bd, dep_quant=True), bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=ALL)
+
+
+def test_joint_cbcr_over_depquant_alone_and_with_classifier():
+    _check([pkg.synth_frame(128, 128, 0, 8, 11, chroma_texture=1.5)], 128, 128, pkg.slice_params(32, dep_quant=True), tools=0xa41)
+    _check([pkg.synth_frame(136, 72, 0, 8, 12, chroma_texture=1.5)], 136, 72, pkg.slice_params(22, dep_quant=True), tools=0xa41 & ~pkg.TOOL_CU_REUSE)
+    _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=1.0, oriented=30.0)], 256, 128, pkg.slice_params(27, dep_quant=True), tools=ALL | pkg.TOOL_FAST)
+
+
 FAST = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_FAST
 
 
@@ -226,18 +244,18 @@ def test_size_independent_properties_1080p_row():
 
 
 def test_full_1080p_frame_matches_oracle():
-    """BASELINE.json's configuration 2 with bench.py's tool set and synthetic picture: one 1920x1080 frame, QP 32, every built tool (0x95b),
+    """BASELINE.json's configuration 2 with bench.py's tool set and synthetic picture: one 1920x1080 frame, QP 32, every built tool (0xb5b),
     15x9 tiles (135 CTU streams, bottom CTU row cut at 56 luma rows -> implicit splits), bit-exact against the oracle (whose tiles run on 12
     host processes)."""
     W, H = 1920, 1080
-    _check([pkg.synth_frame(W, H, 0, 8, 1000, chroma_texture=0.5)], W, H, pkg.slice_params(32, dep_quant=True), tile_cols=15, tile_rows=9, tools=LF, workers=12)
+    _check([pkg.synth_frame(W, H, 0, 8, 1000, chroma_texture=0.5)], W, H, pkg.slice_params(32, dep_quant=True), tile_cols=15, tile_rows=9, tools=ALL, workers=12)
 
 
 def test_baseline_config_1_picture_size_single_tile():
     """BASELINE.json configuration 1's shape: 416x240, one frame, QP 32, the reference cfg's single tile (one stream: contexts and neighbours run
     through all 8 CTUs, right and bottom CTUs cut by the picture edge), every built tool."""
     W, H = 416, 240
-    _check([pkg.synth_frame(W, H, 0, 8, 1234, chroma_texture=0.5, oriented=20.0)], W, H, pkg.slice_params(32, dep_quant=True), tools=LF)
+    _check([pkg.synth_frame(W, H, 0, 8, 1234, chroma_texture=0.5, oriented=20.0)], W, H, pkg.slice_params(32, dep_quant=True), tools=ALL)
 
 
 @pytest.mark.parametrize("qp", [22, 27, 32, 37])
@@ -245,10 +263,10 @@ def test_baseline_config_3_classifier_per_qp_forest_1080p_rows(qp):
     """BASELINE.json configuration 3's flavour: the FAST_ALGORITHM classifier on the device with the forest shipped for each QP, every built tool,
     on 1080p-wide pictures (two CTU rows of a 1920-wide frame, 30 CTU streams), bit-exact against the oracle."""
     W, H = 1920, 256
-    _check([pkg.synth_frame(W, H, 0, 8, 2000 + qp, chroma_texture=0.5)], W, H, pkg.slice_params(qp, dep_quant=True), tile_cols=15, tile_rows=2, tools=LF | pkg.TOOL_FAST, forest_qp=qp, workers=12)
+    _check([pkg.synth_frame(W, H, 0, 8, 2000 + qp, chroma_texture=0.5)], W, H, pkg.slice_params(qp, dep_quant=True), tile_cols=15, tile_rows=2, tools=ALL | pkg.TOOL_FAST, forest_qp=qp, workers=12)
 
 
-@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz", "bitstream_dq.npz", "bitstream_lfnst.npz", "bitstream_lfnst_c.npz"])
+@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz", "bitstream_dq.npz", "bitstream_lfnst.npz", "bitstream_lfnst_c.npz", "bitstream_jccr.npz", "bitstream_jccr_plain.npz"])
 def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fixture):
     """Device writer (arithmetic coding of the final CTU syntax in the estimator pass) against tests/golden/bitstream.npz: payloads
     that the reference's CABACReader parsed back into the coded CUs and levels when the fixture was generated."""
