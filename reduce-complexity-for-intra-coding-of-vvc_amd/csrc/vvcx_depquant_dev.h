@@ -22,7 +22,7 @@
 // 16 bytes / 16 half-words kept as scalar members (arrays indexed with a run-time value would be placed in scratch memory by the compiler)
 struct U4 { unsigned a, b, c, d; };
 struct U8 { unsigned a, b, c, d, e, f, g, h; };
-struct DqS { long long cost; int pk, rem; unsigned long long anc; U4 lev; U8 tm; };
+struct DqS { long long cost; int pk, rem; unsigned long long anc; U4 lev; };      // the template sums of a path live in LDS rows, pk bits 27-29 name the row
 // pk: [0,5) non-zero levels of the path in the current group, [5,8) hist + 1 (state id of the path at the last group change), [8,10) Rice parameter,
 // [10,16) zero position of the bypass mode, [16,18) sig_coeff_group context + 1 (0: no bits), [18,22) sig_coeff_flag context increment,
 // [22,27) context increment of the gt1 / par / gt2 set
@@ -138,6 +138,9 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   uint8_t *nd = nodes + (size_t) it0 * node_stride;
   int *lastb = (int *) wk + it0 * 20;
   uint16_t *trel = (uint16_t *) (wk + n_items * 80) + it0 * total;
+  // template-sum rows of the item: one per state (written when the state enters a coefficient group) + a row of zeros, 16 sums each
+  uint16_t *tmrows = (uint16_t *) (wk + n_items * (80 + 2 * total)) + it0 * 80;
+  if (valid) for (int e = k; e < 80; e += 4) tmrows[e] = 0;
   const int ci = ci0 + it0 * ci_step;
   const int cbf_ctx = cbf_ctx0 < 0 ? -1 : cbf_ctx0 + (int) ((cbf_mask >> it0) & 1u);
   // ---- first tested position of every item (1630-1660): the last scan position whose coefficient exceeds the threshold
@@ -199,7 +202,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   {
     DqS s0; s0.cost = 0x7fffffffffffffffll >> 1; s0.rem = 4; s0.anc = 0;
     s0.pk = dq_put(0, 5, 3, 0);                             // hist -1, everything else 0 (sbbc -1: no bits)
-    s0.lev = U4{ 0, 0, 0, 0 }; s0.tm = U8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+    s0.lev = U4{ 0, 0, 0, 0 };
     cur = s0; prv = s0; skp.cost = s0.cost; skp.pk = s0.pk; skp.rem = s0.rem; skp.anc = 0;
   }
   long long decCost = 0x7fffffffffffffffll >> 2;
@@ -318,7 +321,6 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
       if (act) cur.cost = dc;
       if (!eos) {                                           // State::updateState 1109-1273
         // the template sums travel with the path; a lane without a parent in the quad starts from zeros (a path that does not exist never reads them)
-        { const U8 v = dq_shfl_u8(prv.tm, srcLane); if (alive) cur.tm = fromPrev ? v : U8{ 0, 0, 0, 0, 0, 0, 0, 0 }; }
         if (alive) {
           int pk = cur.pk;
           if (fromPrev) {
@@ -333,7 +335,10 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
           }
           dq_set_b(cur.lev, inside, (unsigned) imin(255, dlev));
           // template of the next position: its neighbours inside the group (m_scanId2NbInfoSbb) on top of the sums over those outside
-          const int t = (int) dq_get_h(cur.tm, nin);
+          // the sums over the neighbours outside the group travel with the path as the row its group entry state wrote; a path that starts here has none (row 4: zeros)
+          const int trow = fromPrev ? ((P.pk >> 27) & 7) : 4;
+          pk = dq_put(pk, 27, 3, trow);
+          const int t = (int) tmrows[trow * 16 + nin];
           int sumAbs = t >> 8, sumAbs1 = (t >> 3) & 31, sumNum = t & 7;
 #pragma unroll
           for (int n = 0; n < 5; n++) if (n < nbCnt) {
@@ -374,7 +379,6 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
           if (fB & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gB * 4 + (int) (fB & 7u) - 1) * 16); nB.a = p_[0]; nB.b = p_[1]; nB.c = p_[2]; nB.d = p_[3]; }
           if (fD & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gD * 4 + (int) (fD & 7u) - 1) * 16); nD.a = p_[0]; nD.b = p_[1]; nD.c = p_[2]; nD.d = p_[3]; }
         }
-        U8 tmn = { 0, 0, 0, 0, 0, 0, 0, 0 };
         for (int id = 0; id < gs; id++) {
           const int pb = scan_blk(geo, ((g - 1) << lcg) + id), px = pb & (w - 1), py = pb >> lw;
           int sumAbs = 0, sumAbs1 = 0, sumNum = 0, any = 0;
@@ -389,13 +393,14 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
               sumAbs += a; sumAbs1 += imin(4 + (a & 1), a); sumNum += a != 0;
             }
           }
-          if (any) dq_set_h(tmn, id, (unsigned) (sumNum + (sumAbs1 << 3) + (imin(127, sumAbs) << 8)));
+          if (alive) tmrows[k * 16 + id] = (uint16_t) (any ? (sumNum + (sumAbs1 << 3) + (imin(127, sumAbs) << 8)) : 0);      // row k: this state's entry into the next group
         }
         if (alive) {
           pk = dq_put(pk, 0, 5, 0); pk = dq_put(pk, 8, 2, 0); pk = dq_put(pk, 5, 3, k + 1); pk = dq_put(pk, 16, 2, sigN + 1);
           cur.rem = pRem; cur.anc = anc;
-          cur.lev = U4{ 0, 0, 0, 0 }; cur.tm = tmn;
-          const int t = (int) dq_get_h(cur.tm, nin);
+          cur.lev = U4{ 0, 0, 0, 0 };
+          pk = dq_put(pk, 27, 3, k);
+          const int t = (int) tmrows[k * 16 + nin];
           const int sumAbs1 = (t >> 3) & 31, sumNum = t & 7;
           pk = dq_put(pk, 18, 4, sigOffN + imin((sumAbs1 + 1) >> 1, 3)); pk = dq_put(pk, 22, 5, gtxOffN + imin(sumAbs1 - sumNum, 4));
           cur.pk = pk;

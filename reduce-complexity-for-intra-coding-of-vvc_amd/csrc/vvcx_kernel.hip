@@ -2201,7 +2201,7 @@ template <bool SMALL>
 __device__ void dq_trellis_phase(uint8_t *scratch, int n, int P, int total, int w, int h, int zo, int wave, int lane, int lfnst = 0)
 {
   int16_t *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF); uint8_t *poolNodes = scratch + VXD_OFF_POOL_NODES;
-  const int ipw = imin(16, (int) sizeof(WaveMem) / (80 + 2 * total));          // items one wave can hold decisions for
+  const int ipw = imin(16, (int) sizeof(WaveMem) / (240 + 2 * total));          // items one wave can hold decisions for
   for (int i0 = wave * ipw; i0 < n; i0 += NW * ipw)
     wave_depquant_batch(imin(ipw, n - i0), poolCoef + (size_t) i0 * P, P, poolNodes + (size_t) i0 * 4 * total, 4 * total, (uint8_t *) &L.wm[wave], i0,
                         CI_CUR, 0, VX_CTX_QtCbf[0], 0u, w, h, 0, zo, lfnst, lane);
@@ -2562,7 +2562,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
   __syncthreads();
   // ---- C2: items 0, 2, 4, ... of the pool (stride 2P)
   {
-    const int ipw = imin(16, (int) sizeof(WaveMem) / (80 + 2 * total));
+    const int ipw = imin(16, (int) sizeof(WaveMem) / (240 + 2 * total));
     for (int i0 = wave * ipw; i0 < n_rd; i0 += NW * ipw)
       wave_depquant_batch(imin(ipw, n_rd - i0), poolCoef + (size_t) (2 * i0) * P, 2 * P, poolNodes + (size_t) (2 * i0) * 4 * total, 8 * total, (uint8_t *) &L.wm[wave], i0,
                           CI_CUR, 0, VX_CTX_QtCbf[1], 0u, w, h, 1, 0, psLf, lane);
@@ -2570,7 +2570,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
   __threadfence_block();
   __syncthreads();
   // ---- C3
-  const bool crBatch = 4 * (80 + 2 * total) <= (int) (sizeof(WaveScratch) + sizeof(int32_t) * BUF);      // four Cr trellises fit wave 0's rate-estimator scratch + tmp
+  const bool crBatch = 4 * (240 + 2 * total) <= (int) (sizeof(WaveScratch) + sizeof(int32_t) * BUF);      // four Cr trellises fit wave 0's rate-estimator scratch + tmp
   for (int c0 = 0; c0 < n_rd; c0 += NW) {
     const int c = c0 + wave; const bool have = c < n_rd;
     const int cm = have ? uni(L.rd[c].mode) : 0;
