@@ -93,14 +93,26 @@ int main(int argc, char **argv)
     for (int c = 0; c < nctu; c++) { dist += res[(size_t) f * nctu + c].dist; bits += res[(size_t) f * nctu + c].frac_bits; cost += res[(size_t) f * nctu + c].cost; }
     int ncu = 0;
     check(vvcx_get_cus(h, f, cus.data(), (int) cus.size(), &ncu), "vvcx_get_cus");
+    // the TU records and their coefficients, as a caller rebuilding cs.tus would read them (INTEGRATION.md fetchCUs): count the coded coefficients per component
+    int ntu = 0; unsigned long long nz[3] = { 0, 0, 0 };
+    check(vvcx_get_tus(h, f, nullptr, 0, &ntu), "vvcx_get_tus");
+    std::vector<vvcx_tu> tus((size_t) ntu);
+    check(vvcx_get_tus(h, f, tus.data(), ntu, &ntu), "vvcx_get_tus");
+    for (int c = 0; c < 3; c++) {
+      const int pw = c ? W / 2 : W, ph = c ? H / 2 : H;
+      std::vector<int16_t> lev((size_t) pw * ph);
+      check(vvcx_get_levels(h, f, c, lev.data(), pw), "vvcx_get_levels");
+      for (const vvcx_tu &t : tus) if (t.coeff_offset[c] >= 0 && t.cbf[c])
+        for (int y = 0; y < t.h; y++) for (int x = 0; x < t.w; x++) nz[c] += lev[(size_t) t.coeff_offset[c] + (size_t) y * t.coeff_stride[c] + x] != 0;
+    }
     size_t bytes = 0;
     for (int t = 0; t < cfg.tile_cols * cfg.tile_rows; t++) {
       int n = 0;
       check(vvcx_get_payload(h, f, t, payload.data(), (int) payload.size(), &n), "vvcx_get_payload");
       fwrite(payload.data(), 1, (size_t) n, out); bytes += (size_t) n;
     }
-    printf("frame %d: %d CUs, distortion %llu, estimated bits %.1f, RD cost %.3f, slice data %zu bytes, kernel %.1f ms\n",
-           f, ncu, dist, (double) bits / 32768.0, cost, bytes, vvcx_last_kernel_ms(h));
+    printf("frame %d: %d CUs, %d TUs (%llu / %llu / %llu coded Y / Cb / Cr coefficients), distortion %llu, estimated bits %.1f, RD cost %.3f, slice data %zu bytes, kernel %.1f ms\n",
+           f, ncu, ntu, nz[0], nz[1], nz[2], dist, (double) bits / 32768.0, cost, bytes, vvcx_last_kernel_ms(h));
   }
   fclose(out);
   for (void *p : owned) dev.release(p);

@@ -95,6 +95,19 @@ typedef struct {
   uint64_t split_series;         /* CU::splitSeries, 5 bits per depth */
 } vvcx_cu;
 
+/* one transform unit ≙ TransformUnit (CL/Unit.h:412-470): area, depth, mtsIdx, cbf[], jointCbCr and where its coefficients are */
+typedef struct {
+  int32_t  cu_index;             /* index of its CU in vvcx_get_cus order */
+  int16_t  x, y, w, h;           /* like the CU: luma samples for ch_type 0, chroma samples for ch_type 1 */
+  uint8_t  ch_type, depth;       /* transform depth (0: the TU is the CU) */
+  uint8_t  mts_idx;              /* tu.mtsIdx (luma) */
+  uint8_t  joint_cb_cr;          /* tu.jointCbCr (chroma) */
+  uint8_t  cbf[3];               /* Y, Cb, Cr */
+  uint8_t  pad_;
+  int32_t  coeff_offset[3];      /* sample offset of the block's levels in the level plane of component c, -1 if absent */
+  int32_t  coeff_stride[3];
+} vvcx_tu;
+
 typedef struct vvcx_handle vvcx_handle;
 
 /* ≙ EncCu::create(EncCfg*) + init(EncLib*, const SPS&)  (EL/EncCu.h:167-171) */
@@ -141,6 +154,11 @@ int  vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out /* [n_frame
 /* final CU table of one bound frame (CTU raster order; per CTU luma CUs then chroma CUs, by origin).
  * ≙ walking cs.cus after the CTU loop; same fields D_BLOCK_STATISTICS_CODED traces */
 int  vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus, int *n_cus);
+/* The TU records of the same picture (≙ cs.tus; EL/EncSlice.cpp reads them through CodingStructure::traverseTUs when it writes the slice): one per CU here
+ * (every intra CU of a dual-tree I slice fits MaxTbSize 64), in vvcx_get_cus order.  coeff_offset[c] / coeff_stride[c] address the block's quantised levels
+ * inside the plane vvcx_get_levels(h, frame, c, ...) returns (-1: the TU has no block of component c); a joint chroma TU keeps its levels with the coded
+ * component (Cb for joint_cb_cr 2 / 3, Cr for 1).  tus may be NULL to query the count. */
+int  vvcx_get_tus(vvcx_handle *h, int frame, vvcx_tu *tus, int max_tus, int *n_tus);
 /* ≙ tu.getCoeffs(compID) of the final TUs: the quantised levels of component comp (0 Y, 1 Cb, 2 Cr) at their sample positions, copied to
  * a host plane (what a caller needs to rebuild cs.tus for the reference's own CABACWriter instead of taking vvcx_get_payload) */
 int  vvcx_get_levels(vvcx_handle *h, int frame, int comp, int16_t *plane, int stride);

@@ -504,6 +504,35 @@ extern "C" int vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus
   return (cus && n > max_cus) ? fail(VVCX_ERR_ARG, "CU table too small (%d > %d)", n, max_cus) : VVCX_OK;
 }
 
+// The transform units of the coded picture (cs.tus as the reference's encodeCtus / the bitstream writer walk them, CL/CodingStructure.h:216-241): in this
+// configuration every CU carries exactly one TU (MaxTbSize 64 = the largest intra CU of a dual-tree I slice), in the order of vvcx_get_cus.
+extern "C" int vvcx_get_tus(vvcx_handle *h, int frame, vvcx_tu *tus, int max_tus, int *n_tus)
+{
+  if (!h || !n_tus || frame < 0 || frame >= h->n_frames) return fail(VVCX_ERR_ARG, "bad argument");
+  int n = 0;
+  const int rc = vvcx_get_cus(h, frame, nullptr, 0, &n);
+  if (rc != VVCX_OK) return rc;
+  *n_tus = n;
+  if (!tus) return VVCX_OK;
+  if (n > max_tus) return fail(VVCX_ERR_ARG, "TU table too small (%d > %d)", n, max_tus);
+  std::vector<vvcx_cu> cus((size_t) n);
+  const int rc2 = vvcx_get_cus(h, frame, cus.data(), n, &n);
+  if (rc2 != VVCX_OK) return rc2;
+  const int wl = h->cfg.pic_w, wc = h->cfg.pic_w >> 1;
+  for (int i = 0; i < n; i++) {
+    const vvcx_cu &c = cus[(size_t) i]; vvcx_tu &t = tus[i];
+    memset(&t, 0, sizeof t);
+    t.cu_index = i; t.ch_type = c.ch_type; t.x = c.x; t.y = c.y; t.w = c.w; t.h = c.h; t.depth = 0;
+    t.mts_idx = c.mts_idx; t.joint_cb_cr = c.joint_cb_cr;
+    if (!c.ch_type) { t.cbf[0] = c.cbf & 1; t.coeff_offset[0] = (int32_t) c.y * wl + c.x; t.coeff_stride[0] = wl; t.coeff_offset[1] = t.coeff_offset[2] = -1; }
+    else {
+      t.cbf[1] = (c.cbf >> 1) & 1; t.cbf[2] = (c.cbf >> 2) & 1;
+      t.coeff_offset[0] = -1; t.coeff_offset[1] = t.coeff_offset[2] = (int32_t) c.y * wc + c.x; t.coeff_stride[1] = t.coeff_stride[2] = wc;
+    }
+  }
+  return VVCX_OK;
+}
+
 extern "C" float vvcx_last_kernel_ms(const vvcx_handle *h) { return h ? h->last_ms : 0.f; }
 
 extern "C" int vvcx_get_counters(vvcx_handle *h, uint64_t out[4])

@@ -45,6 +45,8 @@ class _Task(C.Structure):
     _fields_ = [("frame", C.c_int32), ("ctu_rs_addr", C.c_int32)]
 
 
+TU_DTYPE = np.dtype([("cu_index", "<i4"), ("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("ch_type", "u1"), ("depth", "u1"), ("mts_idx", "u1"),
+                     ("joint_cb_cr", "u1"), ("cbf", "u1", (3,)), ("pad_", "u1"), ("coeff_offset", "<i4", (3,)), ("coeff_stride", "<i4", (3,))], align=True)
 CTU_DTYPE = np.dtype([("dist", "<u8"), ("frac_bits", "<u8"), ("cost", "<f8"), ("n_cu", "<i4")], align=True)
 CU_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("ch_type", "u1"), ("qt_depth", "u1"),
                      ("bt_depth", "u1"), ("mt_depth", "u1"), ("depth", "u1"), ("intra_dir", "u1"), ("mrl_idx", "u1"),
@@ -68,6 +70,7 @@ def load_library(lib_path=None):
     L.vvcx_compress_ctus.argtypes = [C.c_void_p, C.POINTER(_Task), C.c_int, C.c_void_p, C.c_void_p]
     L.vvcx_compress_bound_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.vvcx_get_cus.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.vvcx_get_tus.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.vvcx_last_kernel_ms.restype = C.c_float
     L.vvcx_last_kernel_ms.argtypes = [C.c_void_p]
     L.vvcx_get_counters.argtypes = [C.c_void_p, C.c_void_p]
@@ -275,6 +278,13 @@ class VvcxEncoder:
         cus = np.zeros(self.ctus_per_frame * 2048, CU_DTYPE)
         self._chk(self.L.vvcx_get_cus(self.h, frame, cus.ctypes.data, len(cus), C.byref(n)))
         return cus[:n.value].copy()
+
+    def get_tus(self, frame):
+        n = C.c_int()
+        self._chk(self.L.vvcx_get_tus(self.h, frame, None, 0, C.byref(n)))
+        tus = np.zeros(max(1, n.value), TU_DTYPE)
+        self._chk(self.L.vvcx_get_tus(self.h, frame, tus.ctypes.data, len(tus), C.byref(n)))
+        return tus[:n.value].copy()
 
     def last_kernel_ms(self):
         return float(self.L.vvcx_last_kernel_ms(self.h))

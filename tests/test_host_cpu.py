@@ -239,3 +239,39 @@ def test_mip_leaf_operator_on_cpu_emulator(emu_so):
     assert np.array_equal(got, g["preds"])
     with pytest.raises(pkg.VvcxError):
         vv.mip_pred_batch(np.array([[32, 4, 0, 8]], np.int32), np.zeros(36, np.int16), lib_path=emu_so)        # 8:1 blocks have no MIP modes
+
+
+def test_tu_table_addresses_the_levels_of_every_cu(emu_so):
+    """vvcx_get_tus (≙ cs.tus): one TU per CU in CU order; cbf[c] set exactly when the addressed block of the level plane holds a non-zero level; a joint chroma
+    TU keeps its levels with the coded component."""
+    W, H = 64, 32
+    tools = pkg.TOOL_MRL | pkg.TOOL_MIP | pkg.TOOL_MTS | pkg.TOOL_CCLM | pkg.TOOL_DEPQUANT | pkg.TOOL_LFNST | pkg.TOOL_JCCR | pkg.TOOL_CU_REUSE
+    planes = pkg.synth_frame(W, H, 0, 8, 7, chroma_texture=1.0, oriented=30.0)
+    sp = pkg.slice_params(32, dep_quant=True)
+    enc = pkg.VvcxEncoder(W, H, 8, tools=tools, lib_path=emu_so)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    org = [np.ascontiguousarray(p) for p in planes]; rec = [np.zeros_like(p) for p in planes]
+    enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
+    enc.compress_bound_frames()
+    cus, tus, lev = enc.get_cus(0), enc.get_tus(0), enc.get_levels(0)
+    assert len(tus) == len(cus) and np.array_equal(tus["cu_index"], np.arange(len(cus)))
+    for c, t in zip(cus, tus):
+        assert (t["x"], t["y"], t["w"], t["h"], t["ch_type"]) == (c["x"], c["y"], c["w"], c["h"], c["ch_type"]) and t["mts_idx"] == c["mts_idx"] and t["joint_cb_cr"] == c["joint_cb_cr"]
+        for comp in range(3):
+            on_tree = (comp == 0) == (c["ch_type"] == 0)
+            assert (t["coeff_offset"][comp] >= 0) == on_tree
+            if not on_tree:
+                assert t["cbf"][comp] == 0
+                continue
+            st = int(t["coeff_stride"][comp]); off = int(t["coeff_offset"][comp])
+            blk = lev[comp].ravel()[off:off + (int(t["h"]) - 1) * st + int(t["w"])].reshape(-1)      # rows of the block start every `st` samples
+            rows = [lev[comp].ravel()[off + r * st: off + r * st + int(t["w"])] for r in range(int(t["h"]))]
+            nz = any(np.any(r) for r in rows)
+            coded = nz if not (comp == 2 and c["joint_cb_cr"] == 3) and not (comp == 1 and c["joint_cb_cr"] == 1) else None
+            if c["joint_cb_cr"] == 3 and comp == 2:
+                assert t["cbf"][2] == 1 and not nz            # cbf set, levels live with Cb
+            elif c["joint_cb_cr"] == 1 and comp == 1:
+                assert t["cbf"][1] == 0 and not nz
+            else:
+                assert bool(t["cbf"][comp]) == nz, (c, comp)
+    enc.close()
