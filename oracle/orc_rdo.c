@@ -933,6 +933,18 @@ static int joint_qp(const orc_enc *e, int mask)
   int qp = e->sl.qp_c[0] - 1; if (qp < -off) qp = -off; if (qp > 63) qp = 63;
   return qp + off;
 }
+/* test hooks for the decision helpers pinned against CommonLib: updateCandList on a sequence of insertions; per-shape constants of the luma search */
+int orc_test_update_cand_list(int n, const int *modes, const double *costs, int fastNum, int *out_modes, double *out_costs)
+{
+  minfo list[80]; double cl[80]; int size = 0;
+  for (int i = 0; i < n; i++) update_cand_list((minfo) { modes[i], 0 }, costs[i], list, cl, &size, fastNum);
+  for (int i = 0; i < size; i++) { out_modes[i] = list[i].mode; out_costs[i] = cl[i]; }
+  return size;
+}
+void orc_test_shape_constants(int w, int h, int *out)
+{
+  out[0] = orc_mip_num_modes(w, h); out[1] = w >= 16 && h >= 16; out[2] = ORC_MODE_NUM_FAST_2D[(ilog2(w) - 2) * 6 + (ilog2(h) - 2)]; out[3] = w <= 32 && h <= 32;
+}
 /* test hook: selectICTCandidates + the three joint residuals (joint[m - 1], n samples each) for a residual pair under a sign flag */
 int orc_test_ict(int sign, const int16_t *cb, const int16_t *cr, int n, int *masks, int16_t *joint)
 {

@@ -623,6 +623,29 @@ def gen_bitstream_lfnst():
     np.savez_compressed(os.path.join(HERE, "bitstream_lfnst_c.npz"), **out)
 
 
+def gen_decision_helpers():
+    """CommonLib pieces the decision level calls: updateCandList (CL/UnitTools.h:261-306) on random insertion sequences incl. ties and lists shorter / longer than
+    fastNum, and the per-shape constants of the luma search (getNumModesMip, allowLfnstWithMip, g_aucIntraModeNumFast_UseMPM_2D, the MTS size limit)."""
+    R.ref_update_cand_list.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    R.ref_shape_constants.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    g = np.random.default_rng(20265)
+    meta, modes_all, costs_all, om_all, oc_all = [], [], [], [], []
+    for k in range(120):
+        n = int(g.integers(1, 60)); fast = int(g.integers(1, 9))
+        modes = g.integers(0, 67, n).astype(np.int32)
+        costs = np.round(g.uniform(0, 50, n) * (4 if k % 3 else 1)) / (4 if k % 3 else 1)       # coarse values: plenty of ties
+        om = np.zeros(80, np.int32); oc = np.zeros(80, np.float64)
+        sz = R.ref_update_cand_list(n, P(modes), P(costs), fast, P(om), P(oc))
+        meta.append((n, fast, sz)); modes_all.append(modes); costs_all.append(costs); om_all.append(om[:sz].copy()); oc_all.append(oc[:sz].copy())
+    shapes = []
+    for w in (4, 8, 16, 32, 64):
+        for h in (4, 8, 16, 32, 64):
+            o = np.zeros(4, np.int32); R.ref_shape_constants(w, h, P(o)); shapes.append((w, h) + tuple(int(v) for v in o))
+    np.savez_compressed(os.path.join(HERE, "decision_helpers.npz"), meta=np.array(meta, np.int32), modes=np.concatenate(modes_all), costs=np.concatenate(costs_all),
+                        out_modes=np.concatenate(om_all), out_costs=np.concatenate(oc_all), shapes=np.array(shapes, np.int32))
+    print("decision helper cases", len(meta), "shapes", len(shapes))
+
+
 def gen_ict():
     """JointCbCr candidate choice: TrQuant::selectICTCandidates / fwdTransformICT on chroma residual pairs with every kind of correlation, both
     sign flags: the cbf masks to test and the three joint residuals."""
@@ -737,6 +760,8 @@ if __name__ == "__main__":
         gen_bitstream_dq(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "depquant":
         gen_depquant(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "decision_helpers":
+        gen_decision_helpers(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ict":
         gen_ict(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream_jccr":
@@ -747,5 +772,5 @@ if __name__ == "__main__":
         gen_lfnst(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict(); gen_decision_helpers()
     print("done")

@@ -394,6 +394,24 @@ def test_lfnst_against_the_reference_transform_path():
     assert nz > 900
 
 
+def test_decision_helpers_against_commonlib():
+    """updateCandList (CL/UnitTools.h:261-306) on 120 insertion sequences with ties, and the per-shape constants the luma search branches on (getNumModesMip,
+    allowLfnstWithMip, g_aucIntraModeNumFast_UseMPM_2D, the MTS size limit) for all 25 luma shapes."""
+    L = O.lib()
+    L.orc_test_update_cand_list.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_test_shape_constants.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    g = np.load(os.path.join(G, "decision_helpers.npz"))
+    off = ooff = 0
+    for (n, fast, sz) in g["meta"]:
+        modes = np.ascontiguousarray(g["modes"][off:off + n]); costs = np.ascontiguousarray(g["costs"][off:off + n]); off += int(n)
+        om = np.zeros(80, np.int32); oc = np.zeros(80, np.float64)
+        assert L.orc_test_update_cand_list(int(n), P(modes), P(costs), int(fast), P(om), P(oc)) == sz
+        assert np.array_equal(om[:sz], g["out_modes"][ooff:ooff + sz]) and np.array_equal(oc[:sz], g["out_costs"][ooff:ooff + sz]); ooff += int(sz)
+    for row in g["shapes"]:
+        o = np.zeros(4, np.int32); L.orc_test_shape_constants(int(row[0]), int(row[1]), P(o))
+        assert np.array_equal(o, row[2:]), row
+
+
 def test_joint_cbcr_candidates_against_the_reference():
     """TrQuant::selectICTCandidates / fwdTransformICT (CL/TrQuant.cpp:87-137, 701-743): the cbf masks the search tests and the joint residual of every mask, for
     residual pairs of every correlation under both sign flags."""
