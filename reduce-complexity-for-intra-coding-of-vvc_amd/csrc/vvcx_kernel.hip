@@ -100,6 +100,7 @@ struct CtlState {            // controller-private working set (touched by threa
   uint8_t grpCheck[4], bestSel[4], idxOf[16];
   double dct2Cost, grpBest[4], modeCost[16], bestCost0;
   int lfNum, lfSize, mtsNum; Cand lfList[16], mtsList[16];
+  uint8_t inv0[16], rdSrc[24];           // first pass: list place -> stage-B item; per list entry of an MTS pass: the first pass's item that carries its prepared DST-VII block
 };
 
 struct Tables {                    // constant tables staged once per workgroup (LDS latency instead of global latency
@@ -156,6 +157,8 @@ struct Lds {
   // LFNST: the pass of xCheckRDCostIntra being evaluated (cu.lfnstIdx, cu.mtsFlag, transform group); last scan position of the block a wave coded last;
   // per stage-B / chroma candidate: bit 0 some block's last position is beyond DC, bit 1 some block has a coefficient outside the LFNST region
   int8_t ps_lfnst, ps_mts, ps_grp, ps_pad; int rc_last[NW]; uint8_t rd_lfl[16];
+  // the DST-VII pass prepared by the DCT-II pass (stage_b_rounds): number of prepared items (0: none), item of each candidate of the running pass, absSum per item
+  int8_t spec_n; uint8_t rd_src[16]; int spec_abs[16];
   int dc_val[4];
   int cur_tile, frame, ctu_x, ctu_y, tree_ch;
   int d;                           // current recursion level
@@ -2198,12 +2201,13 @@ template <bool SMALL> __device__ __noinline__ void stage_b_loop_mts(const VxPara
 // A wave keeps the best (cost, candidate, transform) item it evaluated parked like stage_b_loop does: the winner of the reference's two nested strict-<
 // loops is the lexicographic minimum of (cost, list position, transform order), which is the minimum of one of the waves.
 template <bool SMALL>
-__device__ void dq_trellis_phase(uint8_t *scratch, int n, int P, int total, int w, int h, int zo, int wave, int lane, int lfnst = 0)
+__device__ void dq_trellis_phase(uint8_t *scratch, int n, int P, int total, int w, int h, int zo, int wave, int lane, int lfnst = 0, int item0 = 0, int abs0 = 0, int wave_shift = 0)
 {
-  int16_t *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF); uint8_t *poolNodes = scratch + VXD_OFF_POOL_NODES;
+  // items item0 .. item0 + n of the pool, absSum -> L.dq_abs[abs0 ..]; wave_shift rotates which wave takes the first chunk (two batches of one operation run side by side)
+  int16_t *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF) + (size_t) item0 * P; uint8_t *poolNodes = scratch + VXD_OFF_POOL_NODES + (size_t) item0 * 4 * total;
   const int ipw = imin(16, (int) sizeof(WaveMem) / (240 + 2 * total));          // items one wave can hold decisions for
-  for (int i0 = wave * ipw; i0 < n; i0 += NW * ipw)
-    wave_depquant_batch(imin(ipw, n - i0), poolCoef + (size_t) i0 * P, P, poolNodes + (size_t) i0 * 4 * total, 4 * total, (uint8_t *) &L.wm[wave], i0,
+  for (int i0 = ((wave + NW - wave_shift) & (NW - 1)) * ipw; i0 < n; i0 += NW * ipw)
+    wave_depquant_batch(imin(ipw, n - i0), poolCoef + (size_t) i0 * P, P, poolNodes + (size_t) i0 * 4 * total, 4 * total, (uint8_t *) &L.wm[wave], abs0 + i0,
                         CI_CUR, 0, VX_CTX_QtCbf[0], 0u, w, h, 0, zo, lfnst, lane);
 }
 template <bool SMALL>
@@ -2220,6 +2224,12 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
   const int capItems = imin(VXD_POOL_ITEMS, imin(VXD_POOL_ELEMS / P, VXD_POOL_NODE_BYTES / (4 * total)));
   const int capCand = imin(16, pruneOk ? imax(1, capItems / 3) : capItems);
   const int n_rd = uni(L.n_rd);
+  // LFNST on: the DCT-II pass of a node that also gets the DST-VII pass (transform group 0) prepares that pass - forward DST-VII of every candidate beside its
+  // DCT-II, the two trellis batches side by side on different waves (the serial chain is what a pass costs; the contexts both start from are the node's) - and
+  // the DST-VII pass, whose candidate list is a subset chosen from this pass's costs, only reconstructs and prices the blocks it needs
+  const int specGen = lfOn && !psLf && !psMts && mtsOk && 2 * n_rd <= capItems && n_rd <= 16;
+  const int specUse = lfOn && psMts && psGrp == 0 && uni((int) L.spec_n) > 0;
+  const int specN = uni((int) L.spec_n);
   if (lane == 0) L.wave_best[wave] = -1;
   double wbest = MAX_DOUBLE; int wkey = 1 << 30;         // the wave's best item so far: cost, and candidate * 8 + transform order as the tie break
   int cur = 0, nmts = 0;
@@ -2228,7 +2238,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
     const int nA = imin(capCand, n_rd - c0);
     const long long q0 = STAMP();
     // ---- A1
-    for (int i = wave; i < nA; i += NW) {
+    if (!specUse) for (int i = wave; i < nA; i += NW) {
       const int c = c0 + i, mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl), mip = mrl & MIPF;
       int16_t *rec = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, P, wave, cur);
       if (mip) wave_pred_mip(rec, w, h, mode, bd, wave, lane);
@@ -2246,21 +2256,29 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       else wave_code_block<SMALL, true>(org, 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf, -2, &sum0, 0, 0, 0, psLf, psLf ? lfnst_mode(mip ? PLANAR : mode, w, h) : 0);
       for (int e = lane; e < P; e += 64) poolCoef[(size_t) i * P + e] = lev[e];
       if (lane == 0) { recA[i].sum0 = sum0; recA[i].test = 0; }
+      if (specGen) {                                        // rec still holds the prediction (forward-only calls leave it alone)
+        wave_code_block_mts<SMALL>(org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, 2, lane, sse, cbf, -2);
+        for (int e = lane; e < P; e += 64) poolCoef[(size_t) (nA + i) * P + e] = lev[e];
+      }
     }
     __threadfence_block();
     __syncthreads();
     const long long q1 = STAMP();
-    dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, psMts, wave, lane, psLf);
+    if (!specUse) dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, psMts, wave, lane, psLf);
+    if (specGen) dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, 1, wave, lane, 0, nA, 32, 1);
     __threadfence_block();
     __syncthreads();
     const long long q2 = STAMP();
+    if (specGen) { if ((int) VTX < nA) L.spec_abs[VTX] = L.dq_abs[32 + VTX]; if (VTX == 0) L.spec_n = (int8_t) nA; }      // read by the DST-VII pass
+    else if (VTX == 0) L.spec_n = 0;                        // consumed (or not valid for what follows)
     // ---- A3
     for (int i = wave; i < nA; i += NW) {
       const int c = c0 + i, mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
       int16_t *rec = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, P, wave, cur);
-      for (int e = lane; e < P; e += 64) { rec[e] = poolPred[(size_t) i * P + e]; lev[e] = poolCoef[(size_t) i * P + e]; }
+      const int src = specUse ? uni((int) L.rd_src[c]) : i;          // a prepared DST-VII block sits behind the specN DCT-II blocks of the pass that made it
+      for (int e = lane; e < P; e += 64) { rec[e] = poolPred[(size_t) src * P + e]; lev[e] = poolCoef[(size_t) (specUse ? specN + src : i) * P + e]; }
       wave_sync();
-      const int cbf = uni(L.dq_abs[i]) > 0;
+      const int cbf = (specUse ? uni(L.spec_abs[src]) : uni(L.dq_abs[i])) > 0;
       unsigned long long sse; int cbf2;
       const int mtsC = psMts ? pass_mts_idx(psGrp, mode) : 0;
       if (mtsC) wave_code_block_mts<SMALL>(org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, mtsC, lane, sse, cbf2, cbf);
@@ -2271,7 +2289,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
       if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, mrl); enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[0]); if (cbf && mtsOk) enc_mts_idx(cb, mtsC); }
       if (cbf) residual_coding_wave<SMALL>(cb, 0, lev, w, h, 0, lane, mtsC > 1);
-      if (lane == 0) { cost = rd_cost(p, cb.bits, sse); recA[i].cost = cost; recA[i].dist = sse; recA[i].bits = cb.bits; recA[i].cbf = cbf; recA[i].wave = wave; if (lfOn) recA[i].sum0 = (mtsC << 8) | (cbf ? lfnst_flags(L.rc_last[wave], w, h) : 0); }
+      if (lane == 0) { cost = rd_cost(p, cb.bits, sse); recA[i].cost = cost; recA[i].dist = sse; recA[i].bits = cb.bits; recA[i].cbf = cbf; recA[i].wave = wave; if (lfOn) { recA[i].sum0 = (mtsC << 8) | (cbf ? lfnst_flags(L.rc_last[wave], w, h) : 0); recA[i].test = 0; } }
       cost = lane0_d(cost);
       if (cost < wbest || (cost == wbest && c * 8 < wkey)) {
         wbest = cost; wkey = c * 8;
@@ -3344,11 +3362,12 @@ __device__ __noinline__ void ctrl_post_stage_b(Frame &f, int append_mpm)
   }
   int n = 0;
   if (S.testMip) {
-    for (int i = 0; i < S.numRd; i++) if (!(S.rdList[i].mrl & MIPF)) { S.idxOf[n] = (uint8_t) i; L.rd[n++] = S.rdList[i]; }
-    for (int i = 0; i < S.numRd; i++) if (S.rdList[i].mrl & MIPF) { S.idxOf[n] = (uint8_t) i; L.rd[n++] = S.rdList[i]; }
+    for (int i = 0; i < S.numRd; i++) if (!(S.rdList[i].mrl & MIPF)) { S.idxOf[n] = (uint8_t) i; L.rd_src[n] = S.rdSrc[i]; L.rd[n++] = S.rdList[i]; }
+    for (int i = 0; i < S.numRd; i++) if (S.rdList[i].mrl & MIPF) { S.idxOf[n] = (uint8_t) i; L.rd_src[n] = S.rdSrc[i]; L.rd[n++] = S.rdList[i]; }
   } else
-    for (int i = 0; i < S.numRd; i++) if (!(S.rdList[i].mrl & MIPF)) { S.idxOf[n] = (uint8_t) n; L.rd[n++] = S.rdList[i]; }
+    for (int i = 0; i < S.numRd; i++) if (!(S.rdList[i].mrl & MIPF)) { S.idxOf[n] = (uint8_t) n; L.rd_src[n] = S.rdSrc[i]; L.rd[n++] = S.rdList[i]; }
   L.n_rd = n;
+  if (S.lf == 0 && S.mts == 0) for (int c = 0; c < n && c < 16; c++) S.inv0[S.idxOf[c]] = (uint8_t) c;      // where the first pass evaluates each place of its list
   f.phase = PH_B_DONE;
   post(OP_STAGE_B);
 }
@@ -3490,6 +3509,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         S.endLf = (int8_t) ((!S.lfOn || (ch && (f.w < 8 || f.h < 8)) || f.w > 64 || f.h > 64) ? 0 : 2);                 // 2431-2449
         S.considerMts = (int8_t) (S.lfOn && (p.tools & TOOL_MTS) && !ch && f.w <= 32 && f.h <= 32);                      // 2409 (as the MTS passes' loop bound)
         S.dct2Cost = MAX_DOUBLE;
+        L.spec_n = 0;
         for (int i = 0; i < 4; i++) { S.grpCheck[i] = 1; S.bestSel[i] = 0; S.grpBest[i] = MAX_DOUBLE; }
         f.phase = PH_PASS;
         break;
@@ -3552,8 +3572,8 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
             const int k2 = ilog2i(f.w) + ilog2i(f.h);
             const double root = (k2 & 1) ? 0x1.6a09e667f3bcdp+0 * (double) (1 << (k2 >> 1)) : (double) (1 << (k2 >> 1));
             const double thr = 1.0 + 1.4 / root;
-            for (int i = 0; i < S.mtsNum; i++) if (S.modeCost[i] <= thr * S.bestCost0) S.rdList[S.numRd++] = S.mtsList[i];
-          } else { S.numRd = S.mtsNum; for (int i = 0; i < S.mtsNum; i++) S.rdList[i] = S.mtsList[i]; }
+            for (int i = 0; i < S.mtsNum; i++) if (S.modeCost[i] <= thr * S.bestCost0) { S.rdSrc[S.numRd] = S.inv0[i]; S.rdList[S.numRd++] = S.mtsList[i]; }
+          } else { S.numRd = S.mtsNum; for (int i = 0; i < S.mtsNum; i++) { S.rdSrc[i] = S.inv0[i]; S.rdList[i] = S.mtsList[i]; } }
           ctrl_post_stage_b(f, 0); return;
         }
         // an LFNST pass: the SATD-stage list of the first pass (763-775), then the MPMs again

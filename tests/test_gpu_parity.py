@@ -344,17 +344,33 @@ def test_deblocking_filter(case):
     enc.close()
 
 
-def test_size_independent_properties_4k_ten_bit():
-    """BASELINE config 4's picture size (3840x2160, 10 bit, one tile per CTU = 510 streams): every luma and chroma sample covered by exactly
-    one CU of its tree, plausible PSNR, payload present for every tile, and two runs identical (CTU results, reconstruction, slice data)."""
+def _spot_check_tiles(planes, W, H, sp, bd, tc, tr, tools, res, tiles, forest_qp=32):
+    """bit-exact oracle check of a few one-CTU tiles of a big picture (each tile is an independent stream: the oracle codes only those, one process each)"""
+    import multiprocessing as mp
+    kw = dict(bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools, forest=_forest(forest_qp) if tools & pkg.TOOL_FAST else None)
+    O.lib()
+    with mp.get_context("fork").Pool(len(tiles)) as pool:
+        parts = pool.map(O._tiles_job, [(planes, W, H, sp, kw, (t, 1)) for t in tiles])
+    for t, (ores, _, _, _) in zip(tiles, parts):
+        for k in ores.dtype.names:
+            assert ores[k][t] == res[k][t], ("tile", t, k, ores[k][t], res[k][t])
+
+
+@pytest.mark.parametrize("cfg", [(3840, 2160, 32, False), (7680, 4320, 37, True)])
+def test_size_independent_properties_4k_and_8k_ten_bit(cfg):
+    """BASELINE config 4's picture (3840x2160, 10 bit, QP 32) and config 5's (7680x4320, 10 bit, QP 37, classifier on), every built tool, one tile per CTU
+    (510 / 2040 streams): every luma and chroma sample covered by exactly one CU of its tree, plausible PSNR, payload present, two runs identical (CTU
+    results, reconstruction, slice data), and six CTUs spread over the picture bit-exact against the oracle."""
     import torch
-    W, H, bd = 3840, 2160, 10
+    W, H, qp, fast = cfg
+    bd = 10
+    tools = ALL | (pkg.TOOL_FAST if fast else 0)
     planes = pkg.synth_frame(W, H, 0, bd, 4242, chroma_texture=0.5)
-    sp = pkg.slice_params(37, bit_depth=bd)
+    sp = pkg.slice_params(qp, bit_depth=bd, dep_quant=True)
     tc, tr = (W + 127) // 128, (H + 127) // 128
     outs = []
     for _ in range(2):
-        enc = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, tools=MTS, emit_payload=True)
+        enc = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, tools=tools, emit_payload=True, forest=_forest(qp) if fast else None)
         enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
         org = [torch.from_numpy(np.ascontiguousarray(p.view(np.int16))).cuda() for p in planes]
         rec = [torch.zeros_like(t) for t in org]
@@ -364,6 +380,7 @@ def test_size_independent_properties_4k_ten_bit():
         pay = [enc.get_payload(0, t) for t in (0, tc * tr // 2, tc * tr - 1)]
         outs.append((res, cus, [r.cpu().numpy().view(np.uint16) for r in rec], pay))
         enc.close()
+        del org, rec
     res, cus, reco, pay = outs[0]
     for ch, (w, h) in enumerate(((W, H), (W // 2, H // 2))):
         cover = np.zeros((h, w), np.int16)
@@ -375,3 +392,5 @@ def test_size_independent_properties_4k_ten_bit():
     assert all(len(b) > 0 for b in pay)
     assert all(np.array_equal(outs[0][0][k], outs[1][0][k]) for k in res.dtype.names)
     assert all(np.array_equal(a, b) for a, b in zip(outs[0][2], outs[1][2])) and all(np.array_equal(a, b) for a, b in zip(outs[0][3], outs[1][3]))
+    nt = tc * tr
+    _spot_check_tiles(planes, W, H, sp, bd, tc, tr, tools, outs[0][0][0], [0, tc - 1, nt // 3, nt // 2 + 3, nt - tc, nt - 1], forest_qp=qp)
