@@ -74,7 +74,8 @@ struct orc_enc {
   int16_t *org[3], *rec[3], *lev[3];  /* original, reconstruction, quantised levels (plane layout) */
   int stride[3];
   unit_t *um[2]; uint8_t *avail[2]; int uw, uh;
-  int ctus_w, ctus_h; int *ctu_tile; int cur_tile;
+  int ctus_w, ctus_h; int *ctu_tile; int cur_tile;       /* cur_tile: the tile's 8-bit tag (index mod 255; neighbouring tiles never share it below 255 tile columns), cur_tile_idx: its index */
+  int cur_tile_idx;
   orc_cabac cabac;
   store_t store[MAX_DEPTH];
   double sqrt_lambda_fp;              /* sqrtLambdaForFirstPass */
@@ -1676,7 +1677,7 @@ int orc_compress_tiles(orc_enc *e, int tile_first, int tile_count, orc_ctu_resul
   const int ntiles = e->cfg.tile_cols * e->cfg.tile_rows;
   if (tile_first < 0 || tile_count < 0 || tile_first + tile_count > ntiles) { snprintf(g_err, sizeof g_err, "oracle: tile range"); return -1; }
   for (int t = tile_first; t < tile_first + tile_count; t++) {
-    e->cur_tile = t;
+    e->cur_tile = t % 255; e->cur_tile_idx = t;
     orc_ctx_init(e->sl.qp, e->cabac.s0, e->cabac.s1);       /* contexts reset at tile start (EL/EncSlice.cpp:1640-1647) */
     for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++)
       if (e->ctu_tile[ry * e->ctus_w + rx] == t) compress_ctu(e, rx, ry, &res[ry * e->ctus_w + rx]);
@@ -1718,7 +1719,7 @@ long orc_write_tiles(orc_enc *e, uint8_t *buf, long cap, int *sizes)
   for (int t = 0; t < ntiles; t++) {
     orc_arith aw; memset(&aw, 0, sizeof aw);
     aw.out = buf + total; aw.cap = (size_t) (cap - total);
-    e->cur_tile = t;
+    e->cur_tile = t % 255; e->cur_tile_idx = t;
     orc_ctx_init(e->sl.qp, e->cabac.s0, e->cabac.s1);
     orc_arith_start(&aw);
     e->cabac.aw = &aw;
