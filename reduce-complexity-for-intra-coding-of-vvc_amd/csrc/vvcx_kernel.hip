@@ -3822,7 +3822,7 @@ __device__ __noinline__ void writer_suspend(const VxParams &p, int sidx) { ((Ari
 // Out of line: run_tree's barrier loop must contain exactly one thread-0 section of its own (see there).
 __device__ __noinline__ void after_intra_op(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
-  if (VTX == 0) L.do_save = ctrl_b_done(p_, fd_);
+  if (uni(VTX >> 6) == 0) { if ((VTX & 63) == 0) L.do_save = ctrl_b_done(p_, fd_); }      // wave-uniform entry, lane 0 inside (see run_tree)
   __threadfence_block();
   __syncthreads();
   if (uni(L.do_save)) op_save_intra(p_, scratch, L.cu);
@@ -3833,13 +3833,18 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
 {
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int tid = VTX;
-  // NOTE: exactly one thread-0 section per iteration.  With two (`if (tid == 0)` at the head and at the tail)
-  // hipcc threads the "tid != 0" edges together and structurizes the result into an inner loop in which lanes
-  // 1..63 of wave 0 reach the next s_barrier while lane 0 is still parked outside it: the barrier then
-  // releases before the controller has run (observed: hang).  Keep thread-0 work in ONE block here.
+  // NOTE on the shape of this loop.  Round 1 saw a hang with two `if (tid == 0)` sections per iteration (head and tail): hipcc threaded the "tid != 0" edges
+  // together and structurised the result into an inner loop in which lanes 1..63 of the controller's wave reached the next s_barrier while lane 0 was still
+  // parked outside it, so the barrier released before the controller had run.  The cause is that `tid == 0` is a divergent condition *of the wave that holds
+  // the controller*: a barrier behind it is reached by that wave under a partial exec mask whenever the structuriser decides to split the paths.  The loop is
+  // therefore written so that no barrier can sit behind a lane-divergent branch: the controller section is entered on a wave-uniform condition (the wave index
+  // in an SGPR) and lane 0 is picked *inside* it, in a region that contains no barrier and rejoins before the branch ends; after_intra_op does the same.
+  // tests/test_host_cpu.py::test_barrier_shape_of_the_operation_loop checks the built code object: run_tree reaches its barriers with exec restored.
+  const int ctl_wave = uni(VTX >> 6) == 0, ctl_lane = (VTX & 63) == 0;
+  (void) tid;
   int prev_op = 13; long long t_prev = STAMP();
   for (;;) {
-    if (tid == 0) {
+    if (ctl_wave) { if (ctl_lane) {
       const long long t0 = STAMP();
       if (VVCX_STAMP) {
         L.prof[prev_op] += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first)
@@ -3851,7 +3856,7 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
       control_step(p, fd, scratch);
       t_prev = STAMP();
       if (VVCX_STAMP) L.prof[0] += (unsigned long long) (t_prev - t0);
-    }
+    } }
     __syncthreads();
     const int op = uni(L.op);
     { const int pd = uni(L.pre_copy_d); if (pd >= 0) ctx_copy_all(ctx_ptr(scratch, CTX_START, pd, 0), &L.ctxs[CI_CUR]); }      // reads only; every operation leaves L.ctxs[CI_CUR] alone until its own barrier

@@ -6,6 +6,7 @@ import importlib
 import os
 import re
 import subprocess
+import tempfile
 import numpy as np
 import pytest
 import oracle_lib as O
@@ -275,3 +276,37 @@ def test_tu_table_addresses_the_levels_of_every_cu(emu_so):
             else:
                 assert bool(t["cbf"][comp]) == nz, (c, comp)
     enc.close()
+
+
+def test_barrier_shape_of_the_operation_loop(hip_lib):
+    """Guard against the round-1 hang (a workgroup barrier reached by the controller's wave under a partial exec mask, DESIGN.md §5 note 1): in the built gfx950
+    code object, every s_barrier of the operation loop (run_tree) and of its fused tail (after_intra_op) is reached with exec restored - the last instruction
+    that writes exec before the barrier is a restore (s_or_b64 exec, exec, saved), never a narrowing s_and_saveexec."""
+    import re
+    import shutil
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("llvm tools not installed")
+    tmp = tempfile.mkdtemp()
+    try:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "k.co")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, HIP_SO, os.path.join(tmp, "copy.so")])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co, "--unbundle"])
+        asm = subprocess.check_output([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", co]).decode().split("\n")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    checked = 0
+    for name in ("_Z8run_treeIhE", "_Z8run_treeItE", "_Z14after_intra_op"):
+        start = [i for i, l in enumerate(asm) if ("<" + name) in l and l.rstrip().endswith(">:")]
+        assert start, name
+        end = next(i for i in range(start[0] + 1, len(asm)) if re.match(r"^[0-9a-f]+ <.*>:", asm[i]))
+        body = [l.strip().split("//")[0].strip() for l in asm[start[0] + 1:end] if l.strip()]
+        bars = [i for i, t in enumerate(body) if t.startswith("s_barrier")]
+        assert bars, name
+        for b in bars:
+            for t in reversed(body[max(0, b - 60):b]):
+                if re.match(r"s_\S+\s+exec\b", t) or "saveexec" in t:
+                    assert t.startswith("s_or_b64 exec, exec") or t.startswith("s_mov_b64 exec"), (name, t)
+                    break
+            checked += 1
+    assert checked >= 5
