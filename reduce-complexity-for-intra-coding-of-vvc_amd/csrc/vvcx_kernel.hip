@@ -176,6 +176,9 @@ struct Lds {
 };
 
 __shared__ Lds L;
+#ifndef VX_POISON_LDS
+#define VX_POISON_LDS(obj) ((void) 0)
+#endif
 
 // ------------------------------------------------------------------------------------------------ utilities
 __device__ inline int ilog2i(int v) { return 31 - __clz(v); }
@@ -4071,6 +4074,9 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_forest_kerne
 template <typename T>
 __device__ void run_streams(const VxParams &p)
 {
+  // LDS keeps whatever the previous workgroup left: the CPU emulation build fills the object with a poison pattern here (VX_POISON_LDS is empty in the device build), so that a
+  // field read before its first write shows up in the CPU suite too and not only as a GPU-only difference in the work counters (round 1's "miscompile", round 2's L.mip_n)
+  VX_POISON_LDS(L);
   for (;;) {
     __syncthreads();
     if (VTX == 0) L.cur_stream = (int) atomicAdd(&p.counters[52], 1ull);

@@ -28,7 +28,7 @@ def bd_rate(r_anchor, p_anchor, r_test, p_test):
 
 
 def encode(pkg, torch, W, H, frames, qp, tools, forest, tc, tr):
-    sp = pkg.slice_params(qp)
+    sp = pkg.slice_params(qp, dep_quant=bool(tools & pkg.TOOL_DEPQUANT))
     enc = pkg.VvcxEncoder(W, H, 8, tile_cols=tc, tile_rows=tr, tools=tools, max_frames=len(frames), emit_payload=True, forest=forest)
     enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
     dev = []
@@ -63,7 +63,7 @@ def main():
     W, H = args.width, args.height
     tc, tr = (W + 127) // 128, (H + 127) // 128
     frames = [pkg.synth_frame(W, H, poc, 8, 1000 + poc, chroma_texture=args.chroma_texture) for poc in range(args.frames)]
-    base = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS | pkg.TOOL_MIP
+    base = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS | pkg.TOOL_MIP | pkg.TOOL_DEPQUANT | pkg.TOOL_LFNST | pkg.TOOL_JCCR      # every built tool = bench.py's default
     rows = {"anchor": [], "classifier": []}
     for qp in (22, 27, 32, 37):
         forest = pkg.load_forest(os.path.join(ROOT, "reduce-complexity-for-intra-coding-of-vvc_amd", "forests", "partition_qp%d.npz" % qp))

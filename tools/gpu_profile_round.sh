@@ -17,10 +17,10 @@ fi
 if [ "${PART:-2}" = "2" ]; then
 # the classifier config, BD-rate against the full search, and the 10-bit 4K configuration (single GPU share of BASELINE config 4)
 cd $R
-timeout -k 10 200 python bench.py --classifier > $O/bench_classifier.json 2> $O/bench_classifier.err
+timeout -k 10 300 python bench.py --classifier > $O/bench_classifier.json 2> $O/bench_classifier.err
 tail -c 400 $O/bench_classifier.json
-timeout -k 10 300 python tools/bd_rate.py --frames 8 --out gpurun_out/${ROUND_TAG:-r01e}/bdrate.json > $O/bdrate.log 2>&1
-tail -2 $O/bdrate.log
+[ -n "$SKIP_BDRATE" ] || timeout -k 10 300 python tools/bd_rate.py --frames 8 --out gpurun_out/${ROUND_TAG:-r01e}/bdrate.json > $O/bdrate.log 2>&1
+[ -n "$SKIP_BDRATE" ] || tail -2 $O/bdrate.log
 timeout -k 10 420 python bench.py --width 3840 --height 2160 --bit-depth 10 --steps 2 --warmup 1 > $O/bench_4k10.json 2> $O/bench_4k10.err
 tail -c 600 $O/bench_4k10.json
 fi

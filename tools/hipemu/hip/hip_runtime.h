@@ -23,6 +23,8 @@
 #define __noinline__ __attribute__((noinline))
 #define __forceinline__ inline
 #define VX_REG_BARRIER(x) ((void) 0)      // device builds: an empty asm that keeps a value in a register (see csrc/vvcx_depquant_dev.h)
+// workgroup-shared storage is not cleared between workgroups on the GPU: poison it at kernel entry so that reads of never-written fields misbehave here too
+#define VX_POISON_LDS(obj) do { if (hipemu::g_cur->tidx.x == 0) memset((void *) &(obj), 0xA5, sizeof(obj)); hipemu::syncthreads(); } while (0)
 
 struct uint2 { unsigned x, y; };
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
