@@ -149,6 +149,15 @@ int  vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n);
  * call stopped; different streams run concurrently, one workgroup per stream.  `out` is host memory [n].
  * `hip_stream` is a hipStream_t (NULL = default stream); the call returns after the work completed. */
 int  vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int n, vvcx_ctu_result *out, void *hip_stream);
+/* The same call in two halves, for a host that keeps working while the device searches (the reference's CTU loop is synchronous,
+ * EL/EncSlice.cpp:1560-1790; an encoder with frame threads would overlap picture N's search with picture N-1's write-out here).
+ * vvcx_submit_ctus validates and enqueues uploads, the launch and the copy of the results into pinned host memory on `hip_stream`
+ * and returns without waiting; vvcx_poll_ctus = 1 when done, 0 while running; vvcx_wait_ctus blocks, advances the streams'
+ * positions and fills out[n] (n = the submitted count).  One submission per handle may be outstanding; until it is collected
+ * every other entry point that touches the handle's device state returns VVCX_ERR_STATE. */
+int  vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int n, void *hip_stream);
+int  vvcx_poll_ctus(vvcx_handle *h);
+int  vvcx_wait_ctus(vvcx_handle *h, vvcx_ctu_result *out, int n);
 /* convenience: all CTUs of all bound frames in stream order (one launch) */
 int  vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out /* [n_frames * ctus_per_frame], host */, void *hip_stream);
 /* final CU table of one bound frame (CTU raster order; per CTU luma CUs then chroma CUs, by origin).

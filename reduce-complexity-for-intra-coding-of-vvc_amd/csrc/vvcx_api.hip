@@ -66,6 +66,9 @@ struct vvcx_handle {
   VxForestNode *f_node_d; double *f_value_d; int32_t *f_root_d; int f_ntrees, f_nclasses; int32_t f_classes[8];
   VxDqConst *dq_d;                              // dependent-quantiser constants per (component, log2 w + log2 h)
   hipEvent_t ev0, ev1; float last_ms, last_deblock_ms;
+  // a submitted, not yet collected launch (vvcx_submit_ctus .. vvcx_wait_ctus): staging the async copies read from / write to stays alive here
+  bool pending; hipStream_t pend_stream; int pend_n; VxCtuRes *pend_res; int pend_cap;
+  std::vector<VxStreamDesc> pend_sd; std::vector<int32_t> pend_task_ctu; std::vector<int> pend_src, pend_next; VxDqConst pend_dq[96];
   size_t lev_plane[3], lev_frame, units_plane, units_frame;
 };
 
@@ -97,6 +100,9 @@ static VxDqConst dq_consts_of(int lsum, int bit_depth, int qp, double lambda)
   c.dorg = (int64_t) (nomDistFactor * (double) ((int64_t) 1 << (dshift + 1)) + .5);
   return c;
 }
+
+// entry points that touch a handle's device state refuse to run between vvcx_submit_ctus and vvcx_wait_ctus
+#define NOT_PENDING(h) do { if ((h) && (h)->pending) return fail(VVCX_ERR_STATE, "a submitted launch is outstanding: call vvcx_wait_ctus first"); } while (0)
 
 extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
 {
@@ -166,6 +172,8 @@ extern "C" void vvcx_destroy(vvcx_handle *h)
   (void) hipFree(h->payload_d); (void) hipFree(h->payload_off_d); (void) hipFree(h->payload_cap_d); (void) hipFree(h->arith_d);
   (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
   (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d); (void) hipFree(h->dq_d);
+  if (h->pending) (void) hipStreamSynchronize(h->pend_stream);
+  (void) hipHostFree(h->pend_res);
   (void) hipEventDestroy(h->ev0); (void) hipEventDestroy(h->ev1);
   delete h;
 }
@@ -218,6 +226,7 @@ extern "C" int vvcx_derive_slice(const vvcx_slice_cfg *c, vvcx_slice *out)
 extern "C" int vvcx_set_forest(vvcx_handle *h, int n_trees, int n_nodes, int n_classes, const int32_t *root, const int32_t *feature, const double *threshold,
                                const int32_t *left, const int32_t *right, const double *value, const int32_t *classes)
 {
+  NOT_PENDING(h);
   if (!h || !root || !feature || !threshold || !left || !right || !value || !classes) return fail(VVCX_ERR_ARG, "null argument");
   if (n_trees < 1 || n_nodes < n_trees || n_classes < 1 || n_classes > 8) return fail(VVCX_ERR_ARG, "forest shape");
   std::vector<VxForestNode> nodes((size_t) n_nodes);
@@ -245,6 +254,7 @@ extern "C" int vvcx_set_forest(vvcx_handle *h, int n_trees, int n_nodes, int n_c
 
 extern "C" int vvcx_set_slice(vvcx_handle *h, const vvcx_slice *s)
 {
+  NOT_PENDING(h);
   if (!h || !s) return fail(VVCX_ERR_ARG, "null argument");
   if (!(s->lambda > 0.0) || s->qp < -6 * (h->cfg.bit_depth - 8) || s->qp > 63) return fail(VVCX_ERR_ARG, "bad slice parameters (QP range -QpBDOffset..63, like vvcx_derive_slice)");
   h->sl = *s; h->have_slice = true;
@@ -267,6 +277,7 @@ static void ctx_init_islice(int qp, uint16_t *s0, uint16_t *s1)
 
 extern "C" int vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n)
 {
+  NOT_PENDING(h);
   if (!h || !frames) return fail(VVCX_ERR_ARG, "null argument");
   DevGuard guard(h->cfg.device);
   if (n < 1 || n > h->cfg.max_frames) return fail(VVCX_ERR_ARG, "n_frames %d outside 1..%d", n, h->cfg.max_frames);
@@ -315,11 +326,13 @@ extern "C" int vvcx_resident_streams(const vvcx_handle *h)
   return cus * per_cu;
 }
 
-extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int n, vvcx_ctu_result *out, void *hip_stream)
+// The enqueue half: everything up to and including the device-to-host copy of the CTU results goes onto `hip_stream`; nothing waits.
+extern "C" int vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int n, void *hip_stream)
 {
+  NOT_PENDING(h);
   if (h && (h->cfg.tools & VVCX_TOOL_FAST) && !h->f_ntrees) return fail(VVCX_ERR_STATE, "VVCX_TOOL_FAST needs vvcx_set_forest before the first CTU");
-  if (h && n == 0) return VVCX_OK;                      // nothing left to code (e.g. compress_bound_frames after the last CTU): not an error
-  if (!h || !tasks || !out || n < 0) return fail(VVCX_ERR_ARG, "bad argument");
+  if (!h || (!tasks && n) || n < 0) return fail(VVCX_ERR_ARG, "bad argument");
+  if (n == 0) { h->pending = true; h->pend_n = 0; h->pend_stream = (hipStream_t) hip_stream; h->pend_src.clear(); h->pend_next = h->next_idx; return VVCX_OK; }   // nothing to code: an empty submission, not an error
   if (h->n_frames == 0) return fail(VVCX_ERR_STATE, "no frames bound");
   DevGuard guard(h->cfg.device);
   hipStream_t stream = (hipStream_t) hip_stream;
@@ -330,8 +343,9 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
     if (tasks[i].frame < 0 || tasks[i].frame >= h->n_frames || tasks[i].ctu_rs_addr < 0 || tasks[i].ctu_rs_addr >= nctu) return fail(VVCX_ERR_ARG, "task %d out of range", i);
     by_stream[(size_t) tasks[i].frame * h->ntiles + h->ctu_tile[(size_t) tasks[i].ctu_rs_addr]].push_back(i);
   }
-  std::vector<VxStreamDesc> sd; std::vector<int32_t> task_ctu; std::vector<int> task_src;
-  std::vector<int> new_next = h->next_idx;
+  std::vector<VxStreamDesc> &sd = h->pend_sd; std::vector<int32_t> &task_ctu = h->pend_task_ctu; std::vector<int> &task_src = h->pend_src;
+  sd.clear(); task_ctu.clear(); task_src.clear();
+  std::vector<int> &new_next = h->pend_next; new_next = h->next_idx;
   for (size_t s = 0; s < by_stream.size(); s++) {
     if (by_stream[s].empty()) continue;
     const int tile = (int) (s % h->ntiles);
@@ -384,7 +398,7 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
   p.n_streams = ns;
   if (h->cfg.tools & VVCX_TOOL_DEPQUANT) {
     // the quantiser's lambda of a component: TrQuant::setLambdas / selectLambda (EL/EncSlice.cpp:107-149, EL/IntraSearch.cpp:2889) = lambda / distortion weight for chroma
-    VxDqConst tab[96]; memset(tab, 0, sizeof tab);
+    VxDqConst *tab = h->pend_dq; memset(tab, 0, sizeof h->pend_dq);
     const bool jccr = (h->cfg.tools & VVCX_TOOL_JCCR) != 0;
     for (int comp = 0; comp < 3; comp++) {
       double lam = comp ? h->sl.lambda / h->sl.dist_weight[comp - 1] : h->sl.lambda;
@@ -398,7 +412,7 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
       const int qp = mask == 3 ? p.qp_tr_j : p.qp_tr_c[(mask >> 1) ? 0 : 1];
       for (int lsum = 2; lsum <= 12; lsum++) tab[(2 + mask) * 16 + lsum] = dq_consts_of(lsum, h->cfg.bit_depth, qp, lam);
     }
-    HIPCHK(hipMemcpyAsync(h->dq_d, tab, sizeof tab, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->dq_d, tab, sizeof h->pend_dq, hipMemcpyHostToDevice, stream));
     p.dq_consts = h->dq_d;
   }
 
@@ -407,21 +421,60 @@ extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, in
   else hipLaunchKernelGGL(vvcx_compress_kernel_u16, dim3((unsigned) grid), dim3(VXD_NT), 0, stream, p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, stream));
-  std::vector<VxCtuRes> res((size_t) n);
-  HIPCHK(hipMemcpyAsync(res.data(), h->results_d, sizeof(VxCtuRes) * (size_t) n, hipMemcpyDeviceToHost, stream));
-  HIPCHK(hipStreamSynchronize(stream));
+  if (n > h->pend_cap) {                               // pinned, so that the copy back does not block the caller
+    (void) hipHostFree(h->pend_res); h->pend_res = nullptr; h->pend_cap = 0;
+    HIPCHK(hipHostMalloc((void **) &h->pend_res, sizeof(VxCtuRes) * (size_t) n, 0)); h->pend_cap = n;
+  }
+  HIPCHK(hipMemcpyAsync(h->pend_res, h->results_d, sizeof(VxCtuRes) * (size_t) n, hipMemcpyDeviceToHost, stream));
+  h->pending = true; h->pend_stream = stream; h->pend_n = n;
+  return VVCX_OK;
+}
+
+// 1 once the submitted launch and its copy back have finished (vvcx_wait_ctus will not block), 0 while it runs, < 0 on error
+extern "C" int vvcx_poll_ctus(vvcx_handle *h)
+{
+  if (!h) return fail(VVCX_ERR_ARG, "null handle");
+  if (!h->pending) return fail(VVCX_ERR_STATE, "nothing submitted");
+  if (h->pend_n == 0) return 1;
+  DevGuard guard(h->cfg.device);
+  const hipError_t e = hipStreamQuery(h->pend_stream);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) return 0;
+  return fail(VVCX_ERR_DEVICE, "hipStreamQuery: %s", hipGetErrorString(e));
+}
+
+// The collecting half: waits for the stream, advances the streams' positions and hands the results over in task order.
+extern "C" int vvcx_wait_ctus(vvcx_handle *h, vvcx_ctu_result *out, int n)
+{
+  if (!h) return fail(VVCX_ERR_ARG, "null handle");
+  if (!h->pending) return fail(VVCX_ERR_STATE, "nothing submitted");
+  if (n != h->pend_n || (!out && n)) return fail(VVCX_ERR_ARG, "vvcx_wait_ctus: %d results asked, %d tasks submitted", n, h->pend_n);
+  h->pending = false;
+  if (n == 0) return VVCX_OK;
+  DevGuard guard(h->cfg.device);
+  HIPCHK(hipStreamSynchronize(h->pend_stream));
   HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
-  h->next_idx = new_next;
+  h->next_idx = h->pend_next;
+  const VxCtuRes *res = h->pend_res;
   for (int k = 0; k < n; k++) {
-    vvcx_ctu_result &o = out[task_src[(size_t) k]];
-    o.dist = res[(size_t) k].dist; o.frac_bits = res[(size_t) k].bits; o.cost = res[(size_t) k].cost; o.n_cu = res[(size_t) k].n_cu;
-    if (!(res[(size_t) k].cost < 1.7e+308)) return fail(VVCX_ERR_NO_ENCODING, "no possible encoding found for task %d (EL/EncCu.cpp:555-557)", task_src[(size_t) k]);
+    vvcx_ctu_result &o = out[h->pend_src[(size_t) k]];
+    o.dist = res[k].dist; o.frac_bits = res[k].bits; o.cost = res[k].cost; o.n_cu = res[k].n_cu;
+    if (!(res[k].cost < 1.7e+308)) return fail(VVCX_ERR_NO_ENCODING, "no possible encoding found for task %d (EL/EncCu.cpp:555-557)", h->pend_src[(size_t) k]);
   }
   return VVCX_OK;
 }
 
+extern "C" int vvcx_compress_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int n, vvcx_ctu_result *out, void *hip_stream)
+{
+  if (h && n == 0 && !h->pending) return (h->cfg.tools & VVCX_TOOL_FAST) && !h->f_ntrees ? fail(VVCX_ERR_STATE, "VVCX_TOOL_FAST needs vvcx_set_forest before the first CTU") : VVCX_OK;
+  if (!out) return fail(VVCX_ERR_ARG, "bad argument");
+  const int rc = vvcx_submit_ctus(h, tasks, n, hip_stream);
+  return rc != VVCX_OK ? rc : vvcx_wait_ctus(h, out, n);
+}
+
 extern "C" int vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out, void *hip_stream)
 {
+  NOT_PENDING(h);
   if (!h || !out) return fail(VVCX_ERR_ARG, "null argument");
   const int nctu = h->ctus_w * h->ctus_h;
   std::vector<vvcx_ctu_task> tasks; std::vector<int> dst;
@@ -440,6 +493,7 @@ extern "C" int vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out, 
 // one launch for all vertical edges, one for all horizontal edges (vvcx_deblock.hip).  Every CTU of the pictures must have been coded.
 extern "C" int vvcx_deblock_bound_frames(vvcx_handle *h, int beta_offset_div2, int tc_offset_div2, void *hip_stream)
 {
+  NOT_PENDING(h);
   if (!h) return fail(VVCX_ERR_ARG, "null handle");
   if (!h->n_frames || !h->have_slice) return fail(VVCX_ERR_STATE, "no bound frames / slice");
   for (size_t i = 0; i < h->next_idx.size(); i++)
@@ -468,6 +522,7 @@ extern "C" float vvcx_last_deblock_ms(const vvcx_handle *h) { return h ? h->last
 // quantised levels of one component of a coded picture at their sample positions (≙ tu.getCoeffs(compID) of the final TUs), host plane
 extern "C" int vvcx_get_levels(vvcx_handle *h, int frame, int comp, int16_t *plane, int stride)
 {
+  NOT_PENDING(h);
   if (!h || !plane || frame < 0 || frame >= h->n_frames || comp < 0 || comp > 2) return fail(VVCX_ERR_ARG, "bad argument");
   const int w = comp ? h->cfg.pic_w >> 1 : h->cfg.pic_w, hh = comp ? h->cfg.pic_h >> 1 : h->cfg.pic_h;
   if (stride < w) return fail(VVCX_ERR_ARG, "stride smaller than the plane width");
@@ -481,6 +536,7 @@ extern "C" int vvcx_get_levels(vvcx_handle *h, int frame, int comp, int16_t *pla
 
 extern "C" int vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus, int *n_cus)
 {
+  NOT_PENDING(h);
   if (!h || !n_cus || frame < 0 || frame >= h->n_frames) return fail(VVCX_ERR_ARG, "bad argument");
   DevGuard guard(h->cfg.device);
   std::vector<VxUnit> um(h->units_frame);
@@ -508,6 +564,7 @@ extern "C" int vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus
 // configuration every CU carries exactly one TU (MaxTbSize 64 = the largest intra CU of a dual-tree I slice), in the order of vvcx_get_cus.
 extern "C" int vvcx_get_tus(vvcx_handle *h, int frame, vvcx_tu *tus, int max_tus, int *n_tus)
 {
+  NOT_PENDING(h);
   if (!h || !n_tus || frame < 0 || frame >= h->n_frames) return fail(VVCX_ERR_ARG, "bad argument");
   int n = 0;
   const int rc = vvcx_get_cus(h, frame, nullptr, 0, &n);
@@ -537,6 +594,7 @@ extern "C" float vvcx_last_kernel_ms(const vvcx_handle *h) { return h ? h->last_
 
 extern "C" int vvcx_get_counters(vvcx_handle *h, uint64_t out[4])
 {
+  NOT_PENDING(h);
   if (!h || !out) return fail(VVCX_ERR_ARG, "null argument");
   DevGuard guard(h->cfg.device);
   unsigned long long c[4];
@@ -549,6 +607,7 @@ extern "C" int vvcx_get_counters(vvcx_handle *h, uint64_t out[4])
 // [0] controller, [op] parallel operation `op` (enum in vvcx_kernel.hip), [12] estimator pass
 extern "C" int vvcx_get_profile(vvcx_handle *h, uint64_t out[48])
 {
+  NOT_PENDING(h);
   if (!h || !out) return fail(VVCX_ERR_ARG, "null argument");
   DevGuard guard(h->cfg.device);
   unsigned long long c[52];
@@ -586,6 +645,7 @@ extern "C" int vvcx_distortion_batch(const int16_t *a, const int16_t *b, int w, 
 
 extern "C" int vvcx_intra_pred_batch(vvcx_handle *h, const void *const reco[3], const uint8_t *const coded[2], const vvcx_pred_case *cases, int n, int16_t *pred)
 {
+  NOT_PENDING(h);
   if (!h || !reco || !coded || !cases || !pred || n < 0) return fail(VVCX_ERR_ARG, "bad argument");
   if (n == 0) return VVCX_OK;
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -704,6 +764,7 @@ extern "C" int vvcx_mip_pred_batch(const int32_t *cases, int n, const int16_t *r
 // ≙ GetPartition(C0..C25, 2) of BIN/TEST.py for n feature rows (26 int32 each, host pointers): the forest set with vvcx_set_forest
 extern "C" int vvcx_forest_predict_batch(vvcx_handle *h, const int32_t *rows, int n, int32_t *out)
 {
+  NOT_PENDING(h);
   if (!h || !rows || !out || n < 0) return fail(VVCX_ERR_ARG, "bad argument");
   if (!h->f_ntrees) return fail(VVCX_ERR_STATE, "vvcx_set_forest first");
   if (n == 0) return VVCX_OK;
@@ -782,6 +843,7 @@ extern "C" int vvcx_lfnst_depquant_batch(const int16_t *org, const int16_t *pred
 // slice_data() payload of one tile of a bound frame (≙ the sub-stream EncSlice::encodeSlice hands to the NAL writer, EL/EncSlice.cpp:1884-2006)
 extern "C" int vvcx_get_payload(vvcx_handle *h, int frame, int tile, uint8_t *buf, int cap, int *nbytes)
 {
+  NOT_PENDING(h);
   if (!h || !buf || !nbytes || frame < 0 || frame >= h->n_frames || tile < 0 || tile >= h->ntiles) return fail(VVCX_ERR_ARG, "bad argument");
   if (!h->payload_d) return fail(VVCX_ERR_STATE, "handle was created without emit_payload");
   DevGuard guard(h->cfg.device);

@@ -69,6 +69,9 @@ def load_library(lib_path=None):
     L.vvcx_bind_frames.argtypes = [C.c_void_p, C.POINTER(_Frame), C.c_int]
     L.vvcx_compress_ctus.argtypes = [C.c_void_p, C.POINTER(_Task), C.c_int, C.c_void_p, C.c_void_p]
     L.vvcx_compress_bound_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vvcx_submit_ctus.argtypes = [C.c_void_p, C.POINTER(_Task), C.c_int, C.c_void_p]
+    L.vvcx_poll_ctus.argtypes = [C.c_void_p]
+    L.vvcx_wait_ctus.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.vvcx_get_cus.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.vvcx_get_tus.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.vvcx_last_kernel_ms.restype = C.c_float
@@ -266,6 +269,25 @@ class VvcxEncoder:
             t[i].frame, t[i].ctu_rs_addr = f, a
         out = np.zeros(len(tasks), CTU_DTYPE)
         self._chk(self.L.vvcx_compress_ctus(self.h, t, len(tasks), out.ctypes.data, stream))
+        return out
+
+    def submit_ctus(self, tasks, stream=None):
+        """Enqueue only (vvcx_submit_ctus): returns the number of tasks to hand to wait_ctus."""
+        t = (_Task * max(1, len(tasks)))()
+        for i, (f, a) in enumerate(tasks):
+            t[i].frame, t[i].ctu_rs_addr = f, a
+        self._chk(self.L.vvcx_submit_ctus(self.h, t, len(tasks), stream))
+        return len(tasks)
+
+    def poll_ctus(self):
+        r = self.L.vvcx_poll_ctus(self.h)
+        if r < 0:
+            self._chk(r)
+        return bool(r)
+
+    def wait_ctus(self, n):
+        out = np.zeros(n, CTU_DTYPE)
+        self._chk(self.L.vvcx_wait_ctus(self.h, out.ctypes.data, n))
         return out
 
     def compress_bound_frames(self, stream=None):

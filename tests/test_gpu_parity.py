@@ -394,3 +394,32 @@ def test_size_independent_properties_4k_and_8k_ten_bit(cfg):
     assert all(np.array_equal(a, b) for a, b in zip(outs[0][2], outs[1][2])) and all(np.array_equal(a, b) for a, b in zip(outs[0][3], outs[1][3]))
     nt = tc * tr
     _spot_check_tiles(planes, W, H, sp, bd, tc, tr, tools, outs[0][0][0], [0, tc - 1, nt // 3, nt // 2 + 3, nt - tc, nt - 1], forest_qp=qp)
+
+
+def test_two_handles_submitted_on_two_streams_equal_the_blocking_calls():
+    """vvcx_submit_ctus / vvcx_wait_ctus on caller streams: two encoders (two pictures, as an encoder with frame threads would hold) enqueue side by side, the
+    host is free in between, and each collects the results the blocking vvcx_compress_ctus gives."""
+    import torch
+    W, H, sp = 128, 128, pkg.slice_params(32)
+    pics = [pkg.synth_frame(W, H, f, 8, 11) for f in range(2)]
+    want = [_run_gpu([p], W, H, sp)[0][0] for p in pics]
+    encs, devs, streams = [], [], [torch.cuda.Stream(), torch.cuda.Stream()]
+    for planes in pics:
+        enc = pkg.VvcxEncoder(W, H, 8)
+        enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+        org = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes]
+        rec = [torch.zeros_like(t) for t in org]
+        enc.bind_frames([([t.data_ptr() for t in org], [t.data_ptr() for t in rec], [t.shape[1] for t in org])])
+        encs.append(enc); devs.append((org, rec))
+    torch.cuda.synchronize()
+    ns = [enc.submit_ctus([(0, 0)], stream=s.cuda_stream) for enc, s in zip(encs, streams)]
+    polled = [enc.poll_ctus() for enc in encs]                     # may be either; must not block or fail
+    assert all(p in (False, True) for p in polled)
+    for enc, n, (org, rec), (res, cus, reco) in zip(encs, ns, devs, want):
+        got = enc.wait_ctus(n)
+        for k in got.dtype.names:
+            assert np.array_equal(got[k], res[k]), k
+        gc = enc.get_cus(0)
+        assert all(np.array_equal(gc[k], cus[k]) for k in cus.dtype.names)
+        assert all(np.array_equal(r.cpu().numpy(), w) for r, w in zip(rec, reco))
+        enc.close()

@@ -278,6 +278,45 @@ def test_tu_table_addresses_the_levels_of_every_cu(emu_so):
     enc.close()
 
 
+def test_submit_and_wait_halves_equal_the_blocking_call(emu_so):
+    """vvcx_submit_ctus / vvcx_poll_ctus / vvcx_wait_ctus: the same results as vvcx_compress_ctus, one submission at a time, every other device entry point
+    refused while one is outstanding, the stream positions advanced only by the wait."""
+    W, H = 32, 16
+    planes = pkg.synth_frame(W, H, 0, 8, 3)
+    sp = pkg.slice_params(37)
+
+    def make():
+        enc = pkg.VvcxEncoder(W, H, 8, tools=pkg.TOOLS_DEFAULT, lib_path=emu_so)
+        enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+        org = [np.ascontiguousarray(p) for p in planes]; rec = [np.zeros_like(p) for p in planes]
+        enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
+        return enc, org, rec
+    a, _, rec_a = make()
+    want = a.compress_ctus([(0, 0)])
+    cus_a = a.get_cus(0)
+    b, _, rec_b = make()
+    with pytest.raises(pkg.VvcxError):
+        b.poll_ctus()                                              # nothing submitted
+    with pytest.raises(pkg.VvcxError):
+        b.wait_ctus(1)
+    n = b.submit_ctus([(0, 0)])
+    with pytest.raises(pkg.VvcxError):
+        b.submit_ctus([(0, 0)])                                    # one outstanding submission per handle
+    with pytest.raises(pkg.VvcxError):
+        b.get_cus(0)
+    with pytest.raises(pkg.VvcxError):
+        b.compress_bound_frames()
+    with pytest.raises(pkg.VvcxError):
+        b.wait_ctus(2)                                             # not the submitted count; the submission stays outstanding
+    assert b.poll_ctus() in (False, True)
+    got = b.wait_ctus(n)
+    assert np.array_equal(got, want) and np.array_equal(b.get_cus(0), cus_a) and all(np.array_equal(x, y) for x, y in zip(rec_a, rec_b))
+    with pytest.raises(pkg.VvcxError):
+        b.submit_ctus([(0, 0)])                                    # CTU 0 is done: the wait advanced the stream
+    assert b.submit_ctus([]) == 0 and b.poll_ctus() and len(b.wait_ctus(0)) == 0      # an empty submission is legal
+    a.close(); b.close()
+
+
 def test_barrier_shape_of_the_operation_loop(hip_lib):
     """Guard against the round-1 hang (a workgroup barrier reached by the controller's wave under a partial exec mask, DESIGN.md §5 note 1): in the built gfx950
     code object, every s_barrier of the operation loop (run_tree) and of its fused tail (after_intra_op) is reached with exec restored - the last instruction

@@ -126,6 +126,10 @@ inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+enum { hipErrorNotReady = 600 };
+inline hipError_t hipStreamQuery(hipStream_t) { return 0; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? 0 : 2; }
+inline hipError_t hipHostFree(void *p) { free(p); return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
