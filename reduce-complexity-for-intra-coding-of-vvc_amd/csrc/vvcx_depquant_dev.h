@@ -80,6 +80,12 @@ template <int CTRL> __device__ inline long long dq_quad_i64(long long v)
   const int lo = __builtin_amdgcn_update_dpp(0, (int) v, CTRL, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, (int) (v >> 32), CTRL, 0xF, 0xF, true);
   return (long long) (((unsigned long long) (unsigned) hi << 32) | (unsigned) lo);
 }
+// both permutations by every lane of the quad (a lane reads through them from lanes that take the other one), then the select
+__device__ inline int dq_parent(int v, bool fromA)
+{
+  const int a = __builtin_amdgcn_update_dpp(0, v, 0xD8, 0xF, 0xF, true), b = __builtin_amdgcn_update_dpp(0, v, 0x8D, 0xF, 0xF, true);
+  return fromA ? a : b;
+}
 __device__ inline long long dq_shfl_i64(long long v, int src)
 {
   const int lo = __shfl((int) v, src), hi = __shfl((int) (v >> 32), src);
@@ -117,7 +123,35 @@ __device__ inline int dq_gtx_off(int ch, int diag) { return ch ? (diag < 1 ? 6 :
 // n_items blocks (1..16) of w x h.  Item i (quad i of the wave): coefficients cf_base + i * cf_stride (int16 — the forward transforms keep 15 bits
 // + sign — raster order, stride w; LDS or HBM), replaced by its levels; rate terms from context set ci0 + i * ci_step with the cbf context
 // cbf_ctx0 + bit i of cbf_mask (cbf_ctx0 < 0: inferred cbf); path nodes at nodes + i * node_stride bytes (HBM, 4 * positions bytes each); decisions
-// and last-position offsets in the LDS area wk (80 + 2 * positions bytes per item).  absSum of item i -> L.dq_abs[abs0 + i].
+// and last-position offsets in the LDS area wk (240 + 2 * positions bytes per item).  absSum of item i -> L.dq_abs[abs0 + i].
+// TAB != 0 (only with ci_step == 0: all items price against the same models): the rate terms are tabulated as RateEstimator::initCtx does
+// (m_gtxFracBits per context and level class, m_sigFracBits, the group flag), so a rate in the serial loop is one LDS read instead of a chain of
+// model reads.  TAB 2: the tables of the node's models, built once per full-RD operation by the whole workgroup (dq_build_tables -> L.dq_tab);
+// TAB 1: built here behind the items' areas (DQ_TAB_BYTES more of wk), for a wave that quantises one block against its own models.
+#define DQ_TAB_BYTES (4 * DQ_TAB_INTS)
+#ifdef VVCX_STAMP_DQ
+#define DQ_T(n_) const long long n_ = clock64()
+#define DQ_U(n_) n_ = clock64()
+#else
+#define DQ_T(n_)
+#define DQ_U(n_)
+#endif
+// levTab[gtx context][0 | lev 1 | 2 | 3 | even >= 4 | odd >= 4] (without the Rice part), sigTab[state set][context][bin], sbbTab[context][bin]
+__device__ inline void dq_fill_tables(int *tab, int ci, int ch, int t, int nt)
+{
+  const int ngtx = ch ? 11 : 21, nsig = ch ? 8 : 12;
+  const int g1Base = VX_CTX_GtxFlag[2 + ch], g2Base = VX_CTX_GtxFlag[ch], parBase = VX_CTX_ParFlag[ch], sbbBase = VX_CTX_SigCoeffGroup[ch];
+  int *levTab = tab, *sigTab = tab + 21 * 6, *sbbTab = sigTab + 3 * 12 * 2;
+  for (int e = t; e < ngtx * 6; e += nt) {
+    const int g = e / 6, j = e - g * 6;
+    levTab[e] = j == 0 ? 0 : j == 1 ? dq_fb(ci, g1Base + g, 0) + (1 << 15) : dq_fb(ci, g1Base + g, 1) + (1 << 15) + dq_fb(ci, parBase + g, j & 1) + dq_fb(ci, g2Base + g, j >= 4);
+  }
+  for (int e = t; e < 3 * nsig * 2; e += nt) { const int st = e / (nsig * 2), r = e - st * nsig * 2; sigTab[st * 24 + r] = dq_fb(ci, VX_CTX_SigFlag[ch + 2 * st] + (r >> 1), r & 1); }
+  if (t < 4) sbbTab[t] = dq_fb(ci, sbbBase + (t >> 1), t & 1);
+}
+// all threads of the workgroup, at the start of a full-RD operation whose trellises price against the estimator's current models; a barrier follows
+__device__ inline void dq_build_tables(int ch) { dq_fill_tables(L.dq_tab, CI_CUR, ch, (int) VTX, NT); __syncthreads(); }
+template <int TAB>
 __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, int cf_stride, uint8_t *nodes, int node_stride, uint8_t *wk, int abs0,
                                                  int ci0, int ci_step, int cbf_ctx0, unsigned cbf_mask, int w, int h, int comp, int zo, int lfnst, int lane, int qidx = -1)
 {
@@ -133,6 +167,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   if (zo && comp == 0) { effH = h == 32 ? 16 : h; effW = w == 32 ? 16 : w; zeroOut = effH < h || effW < w; }
   const int item = lane >> 2, k = lane & 3, qbase = lane & ~3;
   const bool valid = item < n_items;
+  DQ_T(t0);
   const int it0 = valid ? item : 0;
   int16_t *cf = cf_base + it0 * cf_stride;
   uint8_t *nd = nodes + (size_t) it0 * node_stride;
@@ -167,6 +202,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
       top = imax(top, found);
     }
   }
+  DQ_T(t1);
   if (top < 0) {
     for (int i = 0; i < n_items; i++) { int16_t *c = cf_base + i * cf_stride; for (int sp = lane; sp < total; sp += 64) c[scan_blk(geo, sp)] = 0; }
     if (lane < n_items) L.dq_abs[abs0 + lane] = 0;
@@ -175,6 +211,19 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   }
   DqRate R; R.ci = ci; R.g1Base = VX_CTX_GtxFlag[2 + ch]; R.g2Base = VX_CTX_GtxFlag[ch]; R.parBase = VX_CTX_ParFlag[ch]; R.sbbBase = VX_CTX_SigCoeffGroup[ch];
   const int sigSet = VX_CTX_SigFlag[ch + 2 * imax(k - 1, 0)];          // the state's sig_coeff_flag context set (443-446)
+  int *tabBase = TAB == 2 ? L.dq_tab : (int *) (wk + n_items * (240 + 2 * total));
+  if (TAB == 1) dq_fill_tables(tabBase, ci, ch, lane, 64);
+  const int *levTab = tabBase, *sigTab = tabBase + 21 * 6, *sbbTab = sigTab + 3 * 12 * 2; const uint8_t *riceTab = L.t.rice_len;
+  const int *mySig = sigTab + imax(k - 1, 0) * 24;
+  // rate of a non-zero level / of the zero run code of the bypass mode / of a group flag, from the tables or from the models
+  auto levBits = [&](int gtx_i, int rpar, int lev) -> int {
+    if (!TAB) return (int) dq_lev_bits(R, gtx_i, rpar, lev);
+    const int b = levTab[gtx_i * 6 + (lev < 4 ? lev : 4 + (lev & 1))];
+    const int rb = (int) riceTab[rpar * 32 + imin(31, imax(0, lev - 4) >> 1)] << 15;
+    return lev >= 4 ? b + rb : b;
+  };
+  auto riceBits = [&](int rpar, unsigned v) -> int { return TAB ? (int) riceTab[rpar * 32 + (int) v] << 15 : dq_rice_bits(rpar, v); };
+  auto sbbBits = [&](int sbbc, int bin) -> int { return TAB ? sbbTab[sbbc * 2 + bin] : dq_fb(ci, R.sbbBase + sbbc, bin); };
   // ---- last-position offsets per group index (RateEstimator::xSetLastCoeffOffset 488-568): lane k of the quad takes the entries k, k + 4, ...
   if (valid) {
     const int cbfDelta = cbf_ctx >= 0 ? dq_fb(ci, cbf_ctx, 1) - dq_fb(ci, cbf_ctx, 0) : 0;
@@ -194,6 +243,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
     }
   }
   wave_sync();
+  DQ_T(t2);
   const int regFull = (imin(32, effW) * imin(32, effH) * 28) >> 4;
   // The sub-block entry role (skp) is only ever read for its cost, counters and ancestors; when its object comes back into the rotation, what it still
   // holds of levels / template sums is overwritten before an existing path reads it.  It is therefore kept as those members only.
@@ -215,7 +265,24 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   // it): one burst of independent loads per item instead of a dependent (HBM) load in every step of the serial loop
   if (valid) for (int sp = k; sp <= first; sp += 4) trel[sp] = (uint16_t) cf[scan_blk(geo, sp)];
   wave_sync();
+  // What a position of a coefficient group sees of the groups right of / below / diagonally below it depends only on the group shape: lane id holds, for
+  // position id of a group, 6 bits per template neighbour - which of the three groups (0: inside the group, 1 right, 2 below, 3 diagonal) and the
+  // neighbour's place in that group's level bytes
+  unsigned eosW = 0;
+  if (lane < gs) {
+    const int off = lcw == 2 ? 0 : lcw == 3 ? 20 : lch == 3 ? 36 : 16;
+    const int xy = L.t.cg_scan[off + lane], gx = xy & 15, gy = xy >> 4;
+#pragma unroll
+    for (int n = 0; n < 5; n++) {
+      const int xx = gx + (n == 0 ? 1 : n == 1 ? 2 : n == 2 ? 1 : 0), yy = gy + (n == 2 ? 1 : n == 3 ? 1 : n == 4 ? 2 : 0);
+      const int ox = (xx >> lcw) != 0, oy = (yy >> lch) != 0;
+      if (ox || oy) eosW |= (unsigned) ((ox ? (oy ? 3 : 1) : 2) | ((int) cg_inv[((yy & ((1 << lch) - 1)) << lcw) | (xx & ((1 << lcw) - 1))] << 2)) << (6 * n);
+    }
+  }
   int cnext = 0;
+#ifdef VVCX_STAMP_DQ
+  long long sA = 0, sB = 0, sC = 0, sE = 0, u1 = 0, u2 = 0, u3 = 0;
+#endif
   for (int top64 = top; top64 >= 0; top64 -= 64) {
   int pgA = 0, pgB = 0, pgC = 0;
   {
@@ -241,6 +308,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   const int nchunk = imin(64, top64 + 1);
   for (int it = 0; it < nchunk; it++) {
     const int sp = top64 - it;
+    DQ_T(u0); DQ_U(u1);
     const int gA = __builtin_amdgcn_readlane(pgA, it), gB = __builtin_amdgcn_readlane(pgB, it), nbl = __builtin_amdgcn_readlane(pgC, it);
     const int inside = (gA >> 12) & 15, eos = inside == 0, spt = (gA >> 16) & 3, zeroed = (gA >> 18) & 1;
     const int nin = gB & 15, sigOffN = (gB >> 4) & 15, gtxOffN = (gB >> 8) & 31, nbCnt = (gB >> 13) & 7;
@@ -251,7 +319,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
     // ---- decision of target state k (xDecide 1455-1517)
     long long dc = 0x7fffffffffffffffll >> 2; int dsrc = 0, dnz = 0, dlev = -1;          // dsrc: 0 none, 1 start, 2 from the "A/zero" source state, 3 from the "B" source state, 4 sub-block skipped
     if (zeroed) {
-      if (spt == 2) { dc = skp.cost + (DQ_SBBC(skp.pk) >= 0 ? dq_fb(ci, R.sbbBase + DQ_SBBC(skp.pk), 0) : 0); dsrc = 4; dlev = 0; }
+      if (spt == 2) { dc = skp.cost + (DQ_SBBC(skp.pk) >= 0 ? sbbBits(DQ_SBBC(skp.pk), 0) : 0); dsrc = 4; dlev = 0; }
     } else {
       const long long scaledOrg = (long long) absC * q.qscale;
       const int qIdx0 = dq_qidx0(q, scaledOrg);
@@ -265,19 +333,22 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
       {
         const int ppk = prv.pk, rpar = DQ_RPAR(ppk);
         if (prv.rem >= 4) {
-          cA += dq_lev_bits(R, DQ_GTXI(ppk), rpar, levA); cB += dq_lev_bits(R, DQ_GTXI(ppk), rpar, levB);
-          const int s0b = dq_fb(ci, sigSet + DQ_SIGI(ppk), 0), s1b = dq_fb(ci, sigSet + DQ_SIGI(ppk), 1);
+          cA += levBits(DQ_GTXI(ppk), rpar, levA); cB += levBits(DQ_GTXI(ppk), rpar, levB);
+          int s0b, s1b;
+          if (TAB) { const long long sb2 = *(const long long *) (mySig + 2 * DQ_SIGI(ppk)); s0b = (int) sb2; s1b = (int) (sb2 >> 32); }
+          else { s0b = dq_fb(ci, sigSet + DQ_SIGI(ppk), 0); s1b = dq_fb(ci, sigSet + DQ_SIGI(ppk), 1); }
           if (spt == 0) { cA += s1b; cB += s1b; cZ += s0b; }
-          else if (spt == 1) { const int sb = DQ_SBBC(ppk) >= 0 ? dq_fb(ci, R.sbbBase + DQ_SBBC(ppk), 1) : 0; cA += sb + s1b; cB += sb + s1b; cZ += sb + s0b; }
+          else if (spt == 1) { const int sb = DQ_SBBC(ppk) >= 0 ? sbbBits(DQ_SBBC(ppk), 1) : 0; cA += sb + s1b; cB += sb + s1b; cZ += sb + s0b; }
           else if (DQ_NUMSIG(ppk)) { cA += s1b; cB += s1b; cZ += s0b; }
           else cZ = 0x7fffffffffffffffll;                   // a group whose flag is coded as significant cannot end all-zero: no zero candidate
         } else {
           const int rz = DQ_RZERO(ppk);
-          cA += (1 << 15) + dq_rice_bits(rpar, (unsigned) (levA <= rz ? levA - 1 : (levA < 32 ? levA : 31)));
-          cB += (1 << 15) + dq_rice_bits(rpar, (unsigned) (levB <= rz ? levB - 1 : (levB < 32 ? levB : 31)));
-          cZ += dq_rice_bits(rpar, (unsigned) rz);
+          cA += (1 << 15) + riceBits(rpar, (unsigned) (levA <= rz ? levA - 1 : (levA < 32 ? levA : 31)));
+          cB += (1 << 15) + riceBits(rpar, (unsigned) (levB <= rz ? levB - 1 : (levB < 32 ? levB : 31)));
+          cZ += riceBits(rpar, (unsigned) imin(31, rz));
         }
       }
+      DQ_U(u1);
       // gather: target 0 <- {A, Z of state 0; B of state 1}, target 2 <- {B of 0; A, Z of 1}, target 1 <- {A, Z of 2; B of 3}, target 3 <- {B of 2; A, Z of 3}
       const long long azA = dq_quad_i64<0xD8>(cA), azZ = dq_quad_i64<0xD8>(cZ), bB = dq_quad_i64<0x8D>(cB);      // quad_perm [0,2,1,3] / [1,3,0,2]
       const int tLevA = DQ_LEV(DQ_STEP((k & 1) ? 3 : 0)), tLevB = DQ_LEV(DQ_STEP((k & 1) ? 1 : 2));
@@ -291,12 +362,12 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
         if (azZ < dc) { dc = azZ; dsrc = 2; dnz = 0; dlev = 0; }
       }
       if (spt == 2) {                                       // checkRdCostSkipSbb 1052-1061
-        const long long c = skp.cost + (DQ_SBBC(skp.pk) >= 0 ? dq_fb(ci, R.sbbBase + DQ_SBBC(skp.pk), 0) : 0);
+        const long long c = skp.cost + (DQ_SBBC(skp.pk) >= 0 ? sbbBits(DQ_SBBC(skp.pk), 0) : 0);
         if (c < dc) { dc = c; dsrc = 4; dnz = 0; dlev = 0; }
       }
       if (!(k & 1)) {                                       // checkRdCostStart 1032-1050 into decisions 0 (candidate 0) and 2 (candidate 2)
         const int stS = DQ_STEP(k), levS = DQ_LEV(stS);
-        const long long c = dq_dd(q, scaledOrg, qIdx0, stS) + (long long) (lastb[(gA >> 19) & 15] + lastb[10 + ((gA >> 23) & 15)]) + dq_lev_bits(R, 0, 0, levS);
+        const long long c = dq_dd(q, scaledOrg, qIdx0, stS) + (long long) (lastb[(gA >> 19) & 15] + lastb[10 + ((gA >> 23) & 15)]) + levBits(0, 0, levS);
         if (c < dc) { dc = c; dsrc = 1; dnz = 1; dlev = levS; }
       }
 #undef DQ_STEP
@@ -308,15 +379,22 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
       if (k == 0 && act) trel[sp] = (uint16_t) e;
     }
     if (act) decCost = dc;
+    DQ_U(u2);
     if (sp == 0) break;
     // ---- state update (xDecideAndUpdate 1527-1588)
     const int prevId = dsrc == 2 ? ((k & 1) ? (k == 1 ? 2 : 3) : (k == 0 ? 0 : 1)) : dsrc == 3 ? ((k & 1) ? (k == 1 ? 3 : 2) : (k == 0 ? 1 : 0)) : dsrc == 4 ? 4 + k : dsrc == 1 ? -1 : -2;
     if (eos || !zeroed) {
       // parent state (a previous state of the quad) — every lane shuffles, the lanes whose decision has no such parent discard the result
-      const int srcLane = qbase + ((prevId >= 0 && prevId < 4) ? prevId : k);
+      // (the "A/zero" source of target k is lane [0,2,1,3][k] of the quad, the "B" source lane [1,3,0,2][k]: two quad permutations and a select)
       struct { int pk, rem; unsigned long long anc; U4 lev; } P;
-      P.pk = __shfl(prv.pk, srcLane); P.rem = __shfl(prv.rem, srcLane); P.anc = (unsigned long long) dq_shfl_i64((long long) prv.anc, srcLane);
-      P.lev = dq_shfl_u4(prv.lev, srcLane);
+      {
+        const bool fromA = dsrc == 2;
+#define DQ_PARENT(x_) dq_parent((int) (x_), fromA)
+        P.pk = DQ_PARENT(prv.pk); P.rem = DQ_PARENT(prv.rem);
+        P.anc = (unsigned long long) (unsigned) DQ_PARENT((unsigned) prv.anc) | ((unsigned long long) (unsigned) DQ_PARENT((unsigned) (prv.anc >> 32)) << 32);
+        P.lev.a = (unsigned) DQ_PARENT(prv.lev.a); P.lev.b = (unsigned) DQ_PARENT(prv.lev.b); P.lev.c = (unsigned) DQ_PARENT(prv.lev.c); P.lev.d = (unsigned) DQ_PARENT(prv.lev.d);
+#undef DQ_PARENT
+      }
       const bool alive = act && prevId > -2, fromPrev = prevId >= 0 && prevId < 4;
       if (act) cur.cost = dc;
       if (!eos) {                                           // State::updateState 1109-1273
@@ -373,27 +451,26 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
         const unsigned fD = gD >= 0 ? (unsigned) (anc >> (4 * (gD - g))) & 15u : 0u;
         const int sigN = ((fR & 8u) || (fB & 8u)) ? 1 : 0;
         // the three nodes (16 level bytes each) whose levels the next group's templates look at
-        U4 nR = { 0, 0, 0, 0 }, nB = { 0, 0, 0, 0 }, nD = { 0, 0, 0, 0 };
+        // (a group beyond the block's edge - the coded 32 x 32 region's for bigger blocks - is an all-zero node: it adds nothing to the sums)
+        typedef unsigned dq_v16u __attribute__((vector_size(64)));
+        dq_v16u nv = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // [4..8) right, [8..12) below, [12..16) diagonal
         if (alive) {
-          if (fR & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gR * 4 + (int) (fR & 7u) - 1) * 16); nR.a = p_[0]; nR.b = p_[1]; nR.c = p_[2]; nR.d = p_[3]; }
-          if (fB & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gB * 4 + (int) (fB & 7u) - 1) * 16); nB.a = p_[0]; nB.b = p_[1]; nB.c = p_[2]; nB.d = p_[3]; }
-          if (fD & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gD * 4 + (int) (fD & 7u) - 1) * 16); nD.a = p_[0]; nD.b = p_[1]; nD.c = p_[2]; nD.d = p_[3]; }
+          if (fR & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gR * 4 + (int) (fR & 7u) - 1) * 16); nv[4] = p_[0]; nv[5] = p_[1]; nv[6] = p_[2]; nv[7] = p_[3]; }
+          if (fB & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gB * 4 + (int) (fB & 7u) - 1) * 16); nv[8] = p_[0]; nv[9] = p_[1]; nv[10] = p_[2]; nv[11] = p_[3]; }
+          if (fD & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gD * 4 + (int) (fD & 7u) - 1) * 16); nv[12] = p_[0]; nv[13] = p_[1]; nv[14] = p_[2]; nv[15] = p_[3]; }
         }
         for (int id = 0; id < gs; id++) {
-          const int pb = scan_blk(geo, ((g - 1) << lcg) + id), px = pb & (w - 1), py = pb >> lw;
-          int sumAbs = 0, sumAbs1 = 0, sumNum = 0, any = 0;
+          const unsigned wrd = (unsigned) __builtin_amdgcn_readlane((int) eosW, id);
+          int sumAbs = 0, sumAbs1 = 0, sumNum = 0;
 #pragma unroll
           for (int n = 0; n < 5; n++) {
-            const int xx = px + (n == 0 ? 1 : n == 1 ? 2 : n == 2 ? 1 : 0), yy = py + (n == 2 ? 1 : n == 3 ? 1 : n == 4 ? 2 : 0);
-            const int sx = xx >> lcw, sy = yy >> lch;
-            if (xx < nzw && yy < nzh && (sx != nsx || sy != nsy)) {
-              any = 1;
-              const int bi = cg_inv[((yy & ((1 << lch) - 1)) << lcw) | (xx & ((1 << lcw) - 1))];
-              const int a = (int) (sx != nsx ? (sy != nsy ? dq_get_b(nD, bi) : dq_get_b(nR, bi)) : dq_get_b(nB, bi));
+            const unsigned f = (wrd >> (6 * n)) & 63u;
+            if (f & 3u) {
+              const int a = (int) ((nv[(f & 3u) * 4 + (f >> 4)] >> (((f >> 2) & 3u) << 3)) & 255u);
               sumAbs += a; sumAbs1 += imin(4 + (a & 1), a); sumNum += a != 0;
             }
           }
-          if (alive) tmrows[k * 16 + id] = (uint16_t) (any ? (sumNum + (sumAbs1 << 3) + (imin(127, sumAbs) << 8)) : 0);      // row k: this state's entry into the next group
+          if (alive) tmrows[k * 16 + id] = (uint16_t) (sumNum + (sumAbs1 << 3) + (imin(127, sumAbs) << 8));      // row k: this state's entry into the next group
         }
         if (alive) {
           pk = dq_put(pk, 0, 5, 0); pk = dq_put(pk, 8, 2, 0); pk = dq_put(pk, 5, 3, k + 1); pk = dq_put(pk, 16, 2, sigN + 1);
@@ -407,9 +484,14 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
         }
       }
     }
+    DQ_U(u3);
+#ifdef VVCX_STAMP_DQ
+    sA += u1 - u0; sB += u2 - u1; sC += u3 - u2; if (eos) sE += u3 - u2;
+#endif
     if (spt == 1) { const DqK t = skp; skp.cost = prv.cost; skp.pk = prv.pk; skp.rem = prv.rem; skp.anc = prv.anc; prv.cost = t.cost; prv.pk = t.pk; prv.rem = t.rem; prv.anc = t.anc; }
   }
   }
+  DQ_T(t3);
   // ---- best final state and back-tracking (1709-1730), lane 0 of every quad for its item
   int prev = -2; long long minCost = 0;
 #pragma unroll
@@ -436,12 +518,22 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   }
   nPath = __shfl(nPath, qbase);
   wave_sync();
-  if (valid) for (int sp = k; sp < total; sp += 4) {
-    const int blk = scan_blk(geo, sp), c = cf[blk];
-    const int lv = sp < nPath ? (int) trel[sp] : 0;
-    cf[blk] = (int16_t) (c < 0 ? -lv : lv);
+  DQ_T(t4);
+  for (int i = 0; i < n_items; i++) {                      // all lanes on one item after the other
+    const int np = __builtin_amdgcn_readlane(nPath, i * 4);
+    int16_t *c_ = cf_base + i * cf_stride; const uint16_t *tr = (const uint16_t *) (wk + n_items * 80) + i * total;
+    for (int sp = lane; sp < total; sp += 64) {
+      const int blk = scan_blk(geo, sp), c = c_[blk];
+      const int lv = sp < np ? (int) tr[sp] : 0;
+      c_[blk] = (int16_t) (c < 0 ? -lv : lv);
+    }
   }
   wave_sync();
+#ifdef VVCX_STAMP_DQ
+  { const long long t5 = clock64(); int fs = valid && k == 0 ? first + 1 : 0; for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
+    if (lane == 0) { const long long v[14] = { t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, 1, top + 1, n_items, fs, total, sA, sB, sC, sE };
+      for (int i = 0; i < 14; i++) atomicAdd(&L.prof[16 + i], (unsigned long long) v[i]); } }
+#endif
 }
 
 // one block of the calling wave's own candidate: decisions in the wave's rate-estimator scratch and tmp (both free at that point of wave_code_block:
@@ -451,7 +543,12 @@ __device__ inline int wave_depquant(int16_t *cf_g, int buf_off, uint8_t *scratch
 {
   const int wave_ = uni(VTX >> 6);
   int16_t *cf = SMALL ? L.wm[wave_].slot + BUF + uni(buf_off) : cf_g;
-  wave_depquant_batch(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, (uint8_t *) &L.wm[wave_].ws, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
+  // the tables fit behind the decisions in the rate-estimator scratch + tmp for all but the 32 x 32-coefficient blocks
+  // (and pay for themselves from 64 positions on)
+  if (imin(32, w) * imin(32, h) >= 64 && 240 + 2 * imin(32, w) * imin(32, h) + DQ_TAB_BYTES <= (int) (sizeof(WaveScratch) + sizeof(int32_t) * BUF))
+    wave_depquant_batch<1>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, (uint8_t *) &L.wm[wave_].ws, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
+  else
+    wave_depquant_batch<0>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, (uint8_t *) &L.wm[wave_].ws, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
   return uni(L.dq_abs[64 + wave_]);
 }
 

@@ -109,7 +109,7 @@ struct Tables {                    // constant tables staged once per workgroup 
   int16_t  ang[32], inv_ang[32];
   int8_t   gauss[128], cubic[128];
   uint8_t  last_prefix[8], mode_shift[8];
-  uint8_t  ctx_rate[NCTX + 2], gorice_pars[32], gorice_pos0[96], group_idx[64], mode_num[36], intra_thr[8];
+  uint8_t  ctx_rate[NCTX + 2], gorice_pars[32], gorice_pos0[96], rice_len[128], group_idx[64], mode_num[36], intra_thr[8];
   alignas(16) int8_t dst7[16 + 64 + 256 + 1024];   // DST-VII 4..32 (explicit MTS); DCT-VIII[k][i] = (-1)^k DST-VII[k][n-1-i] is read from the same rows
   alignas(16) int8_t dct[4 + 16 + 64 + 256 + 1024];   // DCT-II 2..32 (the 64-point matrix is only used by 64x64 luma nodes, which never are LDS resident: read from constant memory)
   uint8_t  cg_scan[52], grp_scan[228];   // diagonal scans (CL/Rom.cpp:87-131) as x | y << 4: inside a coefficient group {4x4, 2x2, 8x2, 2x8}; of the groups, per (log2 wg, log2 hg)
@@ -118,6 +118,7 @@ struct Tables {                    // constant tables staged once per workgroup 
 
 #define RC_LIST 320
 // per-wave scratch that the rate estimator (pending bin list) and the dependent quantiser (decisions, path nodes) use at different times
+#define DQ_TAB_INTS (21 * 6 + 3 * 12 * 2 + 4)
 struct WaveRc { uint16_t binbuf[RC_LIST]; uint8_t binsort[RC_LIST + 8]; };
 struct WaveDq { int lastb[16][20]; uint16_t trel[256]; };      // last-position offsets per item; decisions (they continue into tmp / slot behind)
 union WaveScratch { WaveRc rc; WaveDq dq; };
@@ -145,7 +146,9 @@ struct Lds {
   int nx, ny, nw, nh, nd;          // node of the posted op (luma coordinates) and its level
   // candidates
   Cand cand[64]; double cand_cost[64]; double cand_had[64]; int n_cand;
-  uint2 cand_ipa[64];              // prediction parameters of each SATD-stage candidate (initPredIntraParams), packed, derived once per operation
+  // prediction parameters of each SATD-stage candidate (initPredIntraParams), packed, derived once per SATD operation; the full-RD operations keep the
+  // dependent quantiser's rate tables of the node here (dq_build_tables)
+  union { uint2 cand_ipa[64]; int dq_tab[DQ_TAB_INTS]; };
   Cand rd[16]; double rd_cost[16]; uint64_t rd_dist[16]; uint64_t rd_bits[16]; uint8_t rd_cbf[16]; uint8_t rd_mts[16]; int mts_evals[NW]; int n_rd;
   int do_save;                      // after_intra_op: the controller accepted the intra result
   int wave_best[NW], wave_slot[NW]; // candidate index of each wave's best and the slot that holds it
@@ -172,10 +175,11 @@ struct Lds {
   alignas(16) int16_t lm_in[BUF / 2]; int16_t lm_top[64], lm_left[64]; int lm_info[4], lm_ok, lm_nsatd; int lm_par[2][3][3]; int64_t lm_cost[8];
   int16_t fa_nb[5][4]; int fa_n, fa_res, fa_feat[27];      // FAST_ALGORITHM: neighbour CUs {x, y, w, h} of the node, forest answer, features
   Arith aw; uint8_t *aw_out; uint32_t aw_cap; int colm;      // bitstream pass: arithmetic coder, its output (HBM) and capacity; co-located luma mode of the chroma node
-  unsigned long long prof[48];    // shader-clock ticks per operation kind (diagnostic, see vvcx_get_profile)
+  unsigned long long prof[VVCX_STAMP ? 48 : 1];    // shader-clock ticks per operation kind (diagnostic build only, see vvcx_get_profile)
 };
 
 __shared__ Lds L;
+#define PROF(i) L.prof[VVCX_STAMP ? (i) : 0]
 #ifndef VX_POISON_LDS
 #define VX_POISON_LDS(obj) ((void) 0)
 #endif
@@ -784,7 +788,7 @@ __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const in
   const long long q3 = STAMP();
   const unsigned long long tot = wave_sum_u64(mybits);
   if (lane == 0) cb.bits += tot;
-  if (VVCX_STAMP && VTX == 0) { L.prof[32] += (unsigned long long) (q1 - q0); L.prof[34] += (unsigned long long) qe; L.prof[35] += (unsigned long long) qc; L.prof[36] += (unsigned long long) (STAMP() - q3); L.prof[37] += 1; }
+  if (VVCX_STAMP && VTX == 0) { PROF(32) += (unsigned long long) (q1 - q0); PROF(34) += (unsigned long long) qe; PROF(35) += (unsigned long long) qc; PROF(36) += (unsigned long long) (STAMP() - q3); PROF(37) += 1; }
 }
 
 #include "vvcx_depquant_dev.h"
@@ -1539,6 +1543,7 @@ __device__ void load_tables()
   if (tid < 32) { L.t.ang[tid] = ANG_TABLE[tid]; L.t.inv_ang[tid] = INV_ANG_TABLE[tid]; L.t.gorice_pars[tid] = VX_GORICE_PARS[tid]; }
   if (tid < 128) { L.t.gauss[tid] = GAUSS_FILTER[tid >> 2][tid & 3]; L.t.cubic[tid] = VX_CUBIC_FILTER[tid]; }
   if (tid < 96) L.t.gorice_pos0[tid] = VX_GORICE_POS0[tid];
+  if (tid < 128) L.t.rice_len[tid] = (uint8_t) rem_abs_len((unsigned) (tid & 31), (unsigned) (tid >> 5));      // [Rice parameter][value]: bits of the remainder code
   if (tid < 64) L.t.group_idx[tid] = VX_GROUP_IDX[tid];
   if (tid < 36) L.t.mode_num[tid] = VX_MODE_NUM_FAST_2D[tid];
   if (tid < 8) { L.t.intra_thr[tid] = INTRA_FILTER_THR[tid]; L.t.last_prefix[tid] = LAST_PREFIX_CTX[tid]; L.t.mode_shift[tid] = MODE_SHIFT[tid]; }
@@ -1918,7 +1923,7 @@ __device__ __noinline__ void op_luma_prep(const VxParams &p_, const VxFrameDev &
     if (s != 1 && (s == 0 || nsets == 3)) L.dc_val[s] = dc_value(L.refs[s][0], L.refs[s][1], w, h, s == 0 ? 0 : s == 2 ? 1 : 3);
   }
   __syncthreads();
-  if (VVCX_STAMP && VTX == 0) L.prof[14] += (unsigned long long) (STAMP() - ts);
+  if (VVCX_STAMP && VTX == 0) PROF(14) += (unsigned long long) (STAMP() - ts);
 }
 __device__ inline int luma_set(int mrl, int filt) { return mrl == 0 ? (filt ? 1 : 0) : (mrl == 1 ? 2 : 3); }
 
@@ -2042,7 +2047,7 @@ __device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     const long long tb = STAMP();
     unsigned long long sad, satd;
     wave_sad_satd<SMALL>(org_tile(scratch, P), pred, scr, w, h, lane, sad, satd);
-    if (VVCX_STAMP && VTX == 0) { const long long tc = STAMP(); L.prof[15] += (unsigned long long) (tb - ta); L.prof[11] += (unsigned long long) (tc - tb); }
+    if (VVCX_STAMP && VTX == 0) { const long long tc = STAMP(); PROF(15) += (unsigned long long) (tb - ta); PROF(11) += (unsigned long long) (tc - tb); }
     if (lane == step) {
       const unsigned long long msh = sad * 2 < satd ? sad * 2 : satd;
       const double a = (double) mbits * p.sqrt_lambda_fp;
@@ -2173,7 +2178,7 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
     }
     if (uni(cbf)) residual_coding_wave<SMALL>(cb, 0, lev, w, h, 0, lane, mts > 1);
     if (lane == 0) cost = rd_cost(p, cb.bits, sse);
-    if (VVCX_STAMP && VTX == 0) { const long long tb3 = STAMP(); L.prof[28] += (unsigned long long) (tb1 - tb0); L.prof[29] += (unsigned long long) (tb2 - tb1); L.prof[31] += (unsigned long long) (tb3 - tb2); }
+    if (VVCX_STAMP && VTX == 0) { const long long tb3 = STAMP(); PROF(28) += (unsigned long long) (tb1 - tb0); PROF(29) += (unsigned long long) (tb2 - tb1); PROF(31) += (unsigned long long) (tb3 - tb2); }
     cost = lane0_d(cost);
     if (cost < mbest) {
       mbest = cost;
@@ -2210,7 +2215,7 @@ __device__ void dq_trellis_phase(uint8_t *scratch, int n, int P, int total, int 
   int16_t *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF) + (size_t) item0 * P; uint8_t *poolNodes = scratch + VXD_OFF_POOL_NODES + (size_t) item0 * 4 * total;
   const int ipw = imin(16, (int) sizeof(WaveMem) / (240 + 2 * total));          // items one wave can hold decisions for
   for (int i0 = ((wave + NW - wave_shift) & (NW - 1)) * ipw; i0 < n; i0 += NW * ipw)
-    wave_depquant_batch(imin(ipw, n - i0), poolCoef + (size_t) i0 * P, P, poolNodes + (size_t) i0 * 4 * total, 4 * total, (uint8_t *) &L.wm[wave], abs0 + i0,
+    wave_depquant_batch<2>(imin(ipw, n - i0), poolCoef + (size_t) i0 * P, P, poolNodes + (size_t) i0 * 4 * total, 4 * total, (uint8_t *) &L.wm[wave], abs0 + i0,
                         CI_CUR, 0, VX_CTX_QtCbf[0], 0u, w, h, 0, zo, lfnst, lane);
 }
 template <bool SMALL>
@@ -2234,6 +2239,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
   const int specUse = lfOn && psMts && psGrp == 0 && uni((int) L.spec_n) > 0;
   const int specN = uni((int) L.spec_n);
   if (lane == 0) L.wave_best[wave] = -1;
+  dq_build_tables(0);
   double wbest = MAX_DOUBLE; int wkey = 1 << 30;         // the wave's best item so far: cost, and candidate * 8 + transform order as the tie break
   int cur = 0, nmts = 0;
   const int16_t *org = org_tile(scratch, P);
@@ -2345,7 +2351,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       dq_trellis_phase<SMALL>(scratch, nB, P, total, w, h, 1, wave, lane);
       __threadfence_block();
       __syncthreads();
-      if (VVCX_STAMP && VTX == 0) { L.prof[42] += (unsigned long long) (q4 - q3); L.prof[43] += (unsigned long long) (STAMP() - q4); L.prof[46] += (unsigned long long) nB; }
+      if (VVCX_STAMP && VTX == 0) { PROF(42) += (unsigned long long) (q4 - q3); PROF(43) += (unsigned long long) (STAMP() - q4); PROF(46) += (unsigned long long) nB; }
       // ---- B3
       for (int j = wave; j < nB; j += NW) {
         const int i = uni((int) pi_[j] >> 3), k = uni((int) pi_[j] & 7);
@@ -2379,7 +2385,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       __threadfence_block();
       __syncthreads();
     }
-    if (VVCX_STAMP && VTX == 0) { L.prof[38] += (unsigned long long) (q1 - q0); L.prof[39] += (unsigned long long) (q2 - q1); L.prof[40] += (unsigned long long) (q3 - q2); L.prof[41] += (unsigned long long) (STAMP() - q3); L.prof[44] += 1; L.prof[45] += (unsigned long long) nA; }
+    if (VVCX_STAMP && VTX == 0) { PROF(38) += (unsigned long long) (q1 - q0); PROF(39) += (unsigned long long) (q2 - q1); PROF(40) += (unsigned long long) (q3 - q2); PROF(41) += (unsigned long long) (STAMP() - q3); PROF(44) += 1; PROF(45) += (unsigned long long) nA; }
     // ---- per candidate: DCT-II, then its MTS items in transform order, strict < (xRecurIntraCodingLumaQT 3579-3616)
     if ((int) VTX < nA) {
       const int i = VTX, c = c0 + i;
@@ -2556,6 +2562,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
   const int16_t *org = org_tile(scratch, 2 * P);
   int16_t *poolPred = (int16_t *) (scratch + VXD_OFF_POOL), *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF); uint8_t *poolNodes = scratch + VXD_OFF_POOL_NODES;
   if (lane == 0) L.wave_best[wave] = -1;
+  dq_build_tables(1);
   double wbest = MAX_DOUBLE;
   int cur = 0;
   const int n_rd = uni(L.n_rd);
@@ -2585,7 +2592,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
   {
     const int ipw = imin(16, (int) sizeof(WaveMem) / (240 + 2 * total));
     for (int i0 = wave * ipw; i0 < n_rd; i0 += NW * ipw)
-      wave_depquant_batch(imin(ipw, n_rd - i0), poolCoef + (size_t) (2 * i0) * P, 2 * P, poolNodes + (size_t) (2 * i0) * 4 * total, 8 * total, (uint8_t *) &L.wm[wave], i0,
+      wave_depquant_batch<2>(imin(ipw, n_rd - i0), poolCoef + (size_t) (2 * i0) * P, 2 * P, poolNodes + (size_t) (2 * i0) * 4 * total, 8 * total, (uint8_t *) &L.wm[wave], i0,
                           CI_CUR, 0, VX_CTX_QtCbf[1], 0u, w, h, 1, 0, psLf, lane);
   }
   __threadfence_block();
@@ -2617,9 +2624,9 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
     {                                                       // Cr trellises of the modes c0 .. c0 + 3
       const int n4 = imin(NW, n_rd - c0);
       unsigned mask = 0; for (int i = 0; i < n4; i++) mask |= (unsigned) L.rb_pairs[i] << i;
-      if (crBatch) { if (wave == 0) wave_depquant_batch(n4, poolCoef + (size_t) (2 * c0 + 1) * P, 2 * P, poolNodes + (size_t) (2 * c0 + 1) * 4 * total, 8 * total, (uint8_t *) &L.wm[0].ws, c0,
+      if (crBatch) { if (wave == 0) wave_depquant_batch<0>(n4, poolCoef + (size_t) (2 * c0 + 1) * P, 2 * P, poolNodes + (size_t) (2 * c0 + 1) * 4 * total, 8 * total, (uint8_t *) &L.wm[0].ws, c0,
                                                         CI_W(0), 1, VX_CTX_QtCbf[2], mask, w, h, 2, 0, psLf, lane); }
-      else if (have) wave_depquant_batch(1, poolCoef + (size_t) (2 * c + 1) * P, 0, poolNodes + (size_t) (2 * c + 1) * 4 * total, 0, (uint8_t *) &L.wm[wave].ws, c,
+      else if (have) wave_depquant_batch<0>(1, poolCoef + (size_t) (2 * c + 1) * P, 0, poolNodes + (size_t) (2 * c + 1) * 4 * total, 0, (uint8_t *) &L.wm[wave].ws, c,
                                          CI_W(wave), 0, VX_CTX_QtCbf[2], (unsigned) cbfs[0], w, h, 2, 0, psLf, lane);
     }
     __threadfence_block();
@@ -3457,7 +3464,9 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
     const int d = L.d;
 #if VVCX_STAMP
     const long long tph = STAMP(); const int phs = f.phase;
-    struct PhStamp { long long t; int ph; __device__ ~PhStamp() { if (ph < 12) L.prof[16 + ph] += (unsigned long long) (STAMP() - t); L.prof[30] += 1; } } phstamp = { tph, phs };
+#ifndef VVCX_STAMP_DQ
+    struct PhStamp { long long t; int ph; __device__ ~PhStamp() { if (ph < 12) PROF(16 + ph) += (unsigned long long) (STAMP() - t); PROF(30) += 1; } } phstamp = { tph, phs };
+#endif
 #endif
     switch (f.phase) {
     case PH_ENTER: {                                    // xCompressCU entry (EL/EncCu.cpp:727-1286)
@@ -3850,15 +3859,15 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
     if (ctl_wave) { if (ctl_lane) {
       const long long t0 = STAMP();
       if (VVCX_STAMP) {
-        L.prof[prev_op] += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first)
+        PROF(prev_op) += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first)
 #ifndef VVCX_STAMP_ROUNDS
-        if (prev_op >= OP_LUMA_PREP && prev_op <= OP_CHROMA_RD) L.prof[38 + imin(9, imax(0, ilog2i(L.nw * L.nh) - 4))] += (unsigned long long) (t0 - t_prev);   // by node size
+        if (prev_op >= OP_LUMA_PREP && prev_op <= OP_CHROMA_RD) PROF(38 + imin(9, imax(0, ilog2i(L.nw * L.nh) - 4))) += (unsigned long long) (t0 - t_prev);   // by node size
 #endif
       }
       L.pre_copy_d = -1;
       control_step(p, fd, scratch);
       t_prev = STAMP();
-      if (VVCX_STAMP) L.prof[0] += (unsigned long long) (t_prev - t0);
+      if (VVCX_STAMP) PROF(0) += (unsigned long long) (t_prev - t0);
     } }
     __syncthreads();
     const int op = uni(L.op);
@@ -3893,7 +3902,7 @@ __device__ void run_stream(const VxParams &p, int stream_idx)
   Ctx *carry = (Ctx *) (p.stream_ctx + (size_t) (sd.frame * p.ntiles + sd.tile) * 2 * NCTX);
   const int tid = VTX;
   if (tid == 0) {
-    L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < 48; i++) L.prof[i] = 0;
+    L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < (VVCX_STAMP ? 48 : 1); i++) PROF(i) = 0;
     if (p.payload) writer_begin(p, sd.frame * p.ntiles + sd.tile, sd.done_before);
     if (p.tools & TOOL_CU_REUSE) L.cache_gen = (int) *(const uint32_t *) (scratch + VXD_OFF_META);
   }
@@ -3937,14 +3946,15 @@ __device__ void run_stream(const VxParams &p, int stream_idx)
       const long long t0 = STAMP();
       advance_ctx_ctu<T>(p, fd, sd.tile, ctu_x, ctu_y);
       if (p.payload) writer_end_of_ctu(sd.done_before + t + 1 == sd.tile_ctus, sd.tile == p.ntiles - 1);
-      L.prof[12] += (unsigned long long) (STAMP() - t0); p.results[sd.first_task + t] = res;
+      if (VVCX_STAMP) PROF(12) += (unsigned long long) (STAMP() - t0);
+      p.results[sd.first_task + t] = res;
     }
     __syncthreads();
   }
   ctx_copy_all(carry, &L.ctxs[CI_CUR]);
   if (tid == 0 && (p.tools & TOOL_CU_REUSE)) *(uint32_t *) (scratch + VXD_OFF_META) = (uint32_t) L.cache_gen;
   if (tid == 0 && p.payload) writer_suspend(p, sd.frame * p.ntiles + sd.tile);
-  if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); for (int i = 0; i < 48; i++) atomicAdd(&p.counters[4 + i], L.prof[i]); }
+  if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); if (VVCX_STAMP) for (int i = 0; i < 48; i++) atomicAdd(&p.counters[4 + i], PROF(i)); }
 }
 
 // ------------------------------------------------------------------------------------------------ leaf operators

@@ -25,3 +25,8 @@ print("steps",pr[30],"counters",enc.counters())
 print("search ops by luma node area (16,32,...,4096+):", ["%.2e" % v for v in pr[38:48]])
 if TOOLS & 0x40:
     print("rounds (thread 0 clocks): A1 %.3e  A2 trellis %.3e  A3 %.3e  B total %.3e (B1 %.3e, B2 trellis %.3e)  chunks %d  cands %d  mts items %d" % (pr[38], pr[39], pr[40], pr[41], pr[42], pr[43], pr[44], pr[45], pr[46]))
+if os.environ.get("VVCX_STAMP_DQ"):
+    c = pr[21]
+    print("trellis calls %d: first-position search %.3e  tables/last offsets %.3e  loop %.3e  back-tracking %.3e  write-back %.3e (wave clocks)" % (c, pr[16], pr[17], pr[18], pr[19], pr[20]))
+    print("  per call: positions run %.1f  items %.2f  positions per item %.1f  block positions %.1f" % (pr[22] / c, pr[23] / c, pr[24] / max(1, pr[23]), pr[25] / c))
+    print("  inside the loop: candidate costs %.3e  gather + decision %.3e  state update %.3e (of which group ends %.3e)" % (pr[26], pr[27], pr[28], pr[29]))
