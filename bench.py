@@ -44,8 +44,8 @@ def pmc_traffic(workload):
         except Exception:
             continue
         if d.get("workload") == workload and "hbm_traffic_bytes_per_launch" in d:
-            return d["hbm_traffic_bytes_per_launch"], os.path.relpath(p, ROOT)
-    return None, None
+            return d["hbm_traffic_bytes_per_launch"], os.path.relpath(p, ROOT), {"read": d.get("read_bytes_per_launch"), "write": d.get("write_bytes_per_launch")}
+    return None, None, None
 
 
 def pmc_valu(workload):
@@ -177,7 +177,7 @@ def main():
         achieved = ctus_per_step * b_ctu / avg_kernel_s / 1e9
         workload = ("%dx%d %d-bit 4:2:0 All-Intra QP%d full RDO, tools 0x%x, chroma texture %.2f, %d frame(s)/step/GPU, %dx%d uniform tiles = %d CTU streams per frame"
                     % (W, H, bd, args.qp, args.tools, args.chroma_texture, args.frames, tc, tr, tc * tr))
-        traffic, traffic_src = pmc_traffic(workload)
+        traffic, traffic_src, traffic_split = pmc_traffic(workload)
         valu = pmc_valu(workload)
         out = {
             "metric": "CTUs/sec (All-Intra, QP32)", "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps,
@@ -197,7 +197,7 @@ def main():
                                   else "%dx%d uniform tiles" % (tc, tr)),
                        "ctus_per_step": ctus_per_step, "parallelism": "1 workgroup per CTU stream over a work queue of resident slots, frames sharded over ranks"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "vvcx_compress_kernel_u8" if bd == 8 else "vvcx_compress_kernel_u16", "kernel_ms": 1e3 * avg_kernel_s,
+                         "traffic": traffic, "traffic_split": traffic_split, "traffic_source": traffic_src, "kernel": "vvcx_compress_kernel_u8" if bd == 8 else "vvcx_compress_kernel_u16", "kernel_ms": 1e3 * avg_kernel_s,
                          "algorithmic_bytes_per_launch": ctus_per_step * b_ctu, "valu": valu},
             "work": {"satd_candidates_per_launch": int(counters[0]), "rd_tu_evaluations_per_launch": int(counters[1]),
                      "rd_pixels_per_launch": int(counters[2]), "nodes_per_launch": int(counters[3]),

@@ -418,10 +418,16 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
           pk = dq_put(pk, 27, 3, trow);
           const int t = (int) tmrows[trow * 16 + nin];
           int sumAbs = t >> 8, sumAbs1 = (t >> 3) & 31, sumNum = t & 7;
+          {
+            // (the neighbours' places are the same for every lane: register-indexed reads instead of select trees)
+            typedef unsigned dq_v4u __attribute__((vector_size(16)));
+            const dq_v4u cl = { cur.lev.a, cur.lev.b, cur.lev.c, cur.lev.d };
 #pragma unroll
-          for (int n = 0; n < 5; n++) if (n < nbCnt) {
-            const int a = (int) dq_get_b(cur.lev, (nbl >> (4 * n)) & 15);
-            sumAbs += a; sumAbs1 += imin(4 + (a & 1), a); sumNum += a != 0;
+            for (int n = 0; n < 5; n++) if (n < nbCnt) {
+              const int bi = (nbl >> (4 * n)) & 15;
+              const int a = (int) ((cl[bi >> 2] >> ((bi & 3) << 3)) & 255u);
+              sumAbs += a; sumAbs1 += imin(4 + (a & 1), a); sumNum += a != 0;
+            }
           }
           if (cur.rem >= 4) {
             pk = dq_put(pk, 18, 4, sigOffN + imin((sumAbs1 + 1) >> 1, 3)); pk = dq_put(pk, 22, 5, gtxOffN + imin(sumAbs1 - sumNum, 4));

@@ -2199,6 +2199,8 @@ __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int 
   if (lane == 0) L.mts_evals[wave] = nmts;
 }
 // out of line: the MTS variant must not weigh on the register allocation of the DCT-II-only loop inlined into op_stage_b
+// (every variant out of line: the dispatcher below then needs few registers and saves few at its entry - it runs once per full-RD operation)
+template <bool SMALL> __device__ __noinline__ void stage_b_loop_dct2(uint8_t *scratch, int wave, int lane, int w, int h) { stage_b_loop<SMALL, false>(L.par, scratch, wave, lane, w, h); }
 template <bool SMALL> __device__ __noinline__ void stage_b_loop_mts(const VxParams &p_, uint8_t *scratch, int wave, int lane, int w, int h) { stage_b_loop<SMALL, true>(L.par, scratch, wave, lane, w, h); (void) p_; }
 // ---- full-RD stage with the dependent quantiser: the trellis of a block is serial and four lanes wide, so the candidates of the node are taken through the
 // stage together, in rounds (all threads; every wave meets the same barriers):
@@ -2405,7 +2407,7 @@ __device__ __noinline__ void op_stage_b(const VxParams &p_, uint8_t *scratch)
   const int w = uni(L.nw), h = uni(L.nh);
   if (uni(p.tools & TOOL_DEPQUANT)) { if (w * h <= BUF) stage_b_rounds<true>(scratch, wave, lane, w, h); else stage_b_rounds<false>(scratch, wave, lane, w, h); }
   else if (uni(p.tools & TOOL_MTS)) { if (w * h <= BUF) stage_b_loop_mts<true>(p, scratch, wave, lane, w, h); else stage_b_loop_mts<false>(p, scratch, wave, lane, w, h); }
-  else if (w * h <= BUF) stage_b_loop<true, false>(p, scratch, wave, lane, w, h); else stage_b_loop<false, false>(p, scratch, wave, lane, w, h);
+  else if (w * h <= BUF) stage_b_loop_dct2<true>(scratch, wave, lane, w, h); else stage_b_loop_dct2<false>(scratch, wave, lane, w, h);
   __threadfence_block();
   __syncthreads();
   // winner (strict <, list order ≙ EL/IntraSearch.cpp:1308) and its end contexts → wctx[0]; every thread computes the same

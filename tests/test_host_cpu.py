@@ -245,7 +245,7 @@ def test_mip_leaf_operator_on_cpu_emulator(emu_so):
 def test_tu_table_addresses_the_levels_of_every_cu(emu_so):
     """vvcx_get_tus (≙ cs.tus): one TU per CU in CU order; cbf[c] set exactly when the addressed block of the level plane holds a non-zero level; a joint chroma
     TU keeps its levels with the coded component."""
-    W, H = 64, 32
+    W, H = 32, 16
     tools = pkg.TOOL_MRL | pkg.TOOL_MIP | pkg.TOOL_MTS | pkg.TOOL_CCLM | pkg.TOOL_DEPQUANT | pkg.TOOL_LFNST | pkg.TOOL_JCCR | pkg.TOOL_CU_REUSE
     planes = pkg.synth_frame(W, H, 0, 8, 7, chroma_texture=1.0, oriented=30.0)
     sp = pkg.slice_params(32, dep_quant=True)

@@ -1,5 +1,6 @@
-import sys, importlib, numpy as np, torch, time
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import sys, os, importlib, numpy as np, torch, time
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests')); os.chdir(ROOT)
 pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
 W,H=int(sys.argv[1]),int(sys.argv[2]); tc,tr=(W+127)//128,(H+127)//128
 import os

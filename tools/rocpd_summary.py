@@ -43,8 +43,12 @@ def main():
             out["deblock_hbm_traffic_bytes_per_launch"] = int(pmc_db["FETCH_SIZE"] * 1024 * 2 + pmc_db["WRITE_SIZE"] * 1024)
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         out["hbm_traffic_bytes_per_launch"] = int(pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024)
-        out["note"] = ("FETCH_SIZE/WRITE_SIZE in KiB from separate --pmc passes; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); "
-                       "the kernel's accesses are 1-2 B/lane rows, for which the guide gives no calibration, so treat as an upper estimate")
+        out["read_bytes_per_launch"] = int(pmc["FETCH_SIZE"] * 1024 * 2)
+        out["write_bytes_per_launch"] = int(pmc["WRITE_SIZE"] * 1024)
+        out["note"] = ("FETCH_SIZE/WRITE_SIZE in KiB from separate --pmc passes; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B). Calibrated on this "
+                       "kernel's access shapes (tools/calib, profiles/r02n_counter_calibration.json): 2 B/lane rows and 32-B partial blocks count exactly; "
+                       "WRITE_SIZE counts every global store including rewrites of lines that stay cached (a write-through count: stores issued, scratch "
+                       "saves included, not lines evicted); FETCH_SIZE counts L2 misses only (re-reads of a cached region do not appear)")
     for r in c.execute("select average*1000 from top_kernels where name like 'vvcx_compress%'"):
         out["kernel_ms"] = r[0] / 1e6                       # average launch duration of the --kernel-trace run (ms)
     bj = os.path.join(src, "bench.json")
