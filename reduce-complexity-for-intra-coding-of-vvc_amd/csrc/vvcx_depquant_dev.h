@@ -328,7 +328,9 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
       // this lane as SOURCE state k: candidates A / B / zero (checkRdCosts 918-1030)
       const int stA = DQ_STEP(k < 2 ? 0 : 3), stB = DQ_STEP(k < 2 ? 2 : 1);
       const int levA = DQ_LEV(stA), levB = DQ_LEV(stB);
-      const long long ddA = dq_dd(q, scaledOrg, qIdx0, stA), ddB = dq_dd(q, scaledOrg, qIdx0, stB);
+      // the four candidates of the position (preQuantCoeff's pqData[0..3]) one per lane of the quad; a state's A / B pair: 0 / 2 (states 0, 1), 3 / 1 (states 2, 3)
+      const long long ddMine = dq_dd(q, scaledOrg, qIdx0, DQ_STEP(k));
+      const long long ddA = dq_quad_i64<0xF0>(ddMine), ddB = dq_quad_i64<0x5A>(ddMine);      // quad_perm [0,0,3,3] / [2,2,1,1]
       long long cA = prv.cost + ddA, cB = prv.cost + ddB, cZ = prv.cost;
       {
         const int ppk = prv.pk, rpar = DQ_RPAR(ppk);
@@ -352,14 +354,14 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
       // gather: target 0 <- {A, Z of state 0; B of state 1}, target 2 <- {B of 0; A, Z of 1}, target 1 <- {A, Z of 2; B of 3}, target 3 <- {B of 2; A, Z of 3}
       const long long azA = dq_quad_i64<0xD8>(cA), azZ = dq_quad_i64<0xD8>(cZ), bB = dq_quad_i64<0x8D>(cB);      // quad_perm [0,2,1,3] / [1,3,0,2]
       const int tLevA = DQ_LEV(DQ_STEP((k & 1) ? 3 : 0)), tLevB = DQ_LEV(DQ_STEP((k & 1) ? 1 : 2));
-      if (k < 2) {
-        if (azA < dc) { dc = azA; dsrc = 2; dnz = 1; dlev = tLevA; }
-        if (azZ < dc) { dc = azZ; dsrc = 2; dnz = 0; dlev = 0; }
-        if (bB < dc) { dc = bB; dsrc = 3; dnz = 1; dlev = tLevB; }
-      } else {
-        if (bB < dc) { dc = bB; dsrc = 3; dnz = 1; dlev = tLevB; }
-        if (azA < dc) { dc = azA; dsrc = 2; dnz = 1; dlev = tLevA; }
-        if (azZ < dc) { dc = azZ; dsrc = 2; dnz = 0; dlev = 0; }
+      {
+        // the reference tests A, zero, B for the targets 0 / 2 and B, A, zero for 1 / 3, each with a strict <: the first of equal costs stays.  One sequence for
+        // both: the better of A and zero (A on a tie), then B, which takes a tie only where it is tested first
+        long long m = azA; int msrc = 2, mnz = 1, mlev = tLevA;
+        if (azZ < m) { m = azZ; mnz = 0; mlev = 0; }
+        const bool bWins = k < 2 ? bB < m : bB <= m;
+        if (bWins) { m = bB; msrc = 3; mnz = 1; mlev = tLevB; }
+        if (m < dc) { dc = m; dsrc = msrc; dnz = mnz; dlev = mlev; }
       }
       if (spt == 2) {                                       // checkRdCostSkipSbb 1052-1061
         const long long c = skp.cost + (DQ_SBBC(skp.pk) >= 0 ? sbbBits(DQ_SBBC(skp.pk), 0) : 0);
@@ -367,7 +369,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
       }
       if (!(k & 1)) {                                       // checkRdCostStart 1032-1050 into decisions 0 (candidate 0) and 2 (candidate 2)
         const int stS = DQ_STEP(k), levS = DQ_LEV(stS);
-        const long long c = dq_dd(q, scaledOrg, qIdx0, stS) + (long long) (lastb[(gA >> 19) & 15] + lastb[10 + ((gA >> 23) & 15)]) + levBits(0, 0, levS);
+        const long long c = ddMine + (long long) (lastb[(gA >> 19) & 15] + lastb[10 + ((gA >> 23) & 15)]) + levBits(0, 0, levS);
         if (c < dc) { dc = c; dsrc = 1; dnz = 1; dlev = levS; }
       }
 #undef DQ_STEP
