@@ -384,7 +384,6 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
     DQ_U(u2);
     if (sp == 0) break;
     // ---- state update (xDecideAndUpdate 1527-1588)
-    const int prevId = dsrc == 2 ? ((k & 1) ? (k == 1 ? 2 : 3) : (k == 0 ? 0 : 1)) : dsrc == 3 ? ((k & 1) ? (k == 1 ? 3 : 2) : (k == 0 ? 1 : 0)) : dsrc == 4 ? 4 + k : dsrc == 1 ? -1 : -2;
     if (eos || !zeroed) {
       // parent state (a previous state of the quad) — every lane shuffles, the lanes whose decision has no such parent discard the result
       // (the "A/zero" source of target k is lane [0,2,1,3][k] of the quad, the "B" source lane [1,3,0,2][k]: two quad permutations and a select)
@@ -397,27 +396,28 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
         P.lev.a = (unsigned) DQ_PARENT(prv.lev.a); P.lev.b = (unsigned) DQ_PARENT(prv.lev.b); P.lev.c = (unsigned) DQ_PARENT(prv.lev.c); P.lev.d = (unsigned) DQ_PARENT(prv.lev.d);
 #undef DQ_PARENT
       }
-      const bool alive = act && prevId > -2, fromPrev = prevId >= 0 && prevId < 4;
+      const bool alive = act && dsrc != 0, fromPrev = dsrc == 2 || dsrc == 3;      // dsrc 1: the path starts here, 4: it skipped the group it leaves
       if (act) cur.cost = dc;
       if (!eos) {                                           // State::updateState 1109-1273
         // the template sums travel with the path; a lane without a parent in the quad starts from zeros (a path that does not exist never reads them)
         if (alive) {
+          // (selects instead of two paths: in most positions some lane of the wave continues a path and another starts one)
           int pk = cur.pk;
-          if (fromPrev) {
-            pk = dq_put(pk, 0, 5, DQ_NUMSIG(P.pk) + (dlev != 0)); pk = dq_put(pk, 5, 3, DQ_HIST(P.pk) + 1); pk = dq_put(pk, 16, 2, DQ_SBBC(P.pk) + 1); pk = dq_put(pk, 8, 2, DQ_RPAR(P.pk));
-            cur.rem = P.rem - 1; cur.anc = P.anc;
-            if (cur.rem >= 4) cur.rem -= dlev < 2 ? dlev : 3;
-            cur.lev = P.lev;
-          } else {
-            pk = dq_put(pk, 0, 5, 1); pk = dq_put(pk, 5, 3, 0); cur.anc = 0;
-            cur.rem = regFull - (dlev < 2 ? dlev : 3);
-            cur.lev = U4{ 0, 0, 0, 0 };
+          {
+            // continuing: counters of the path (non-zero levels + this one, state at the last group change, group-flag context) from the parent;
+            // starting: one non-zero level, no history.  The Rice parameter, contexts and template row are set below in both cases.
+            const int lowNew = fromPrev ? ((P.pk & ((7 << 5) | (3 << 16))) | ((P.pk + (dlev != 0)) & 31)) : 1;
+            pk = (pk & (fromPrev ? ~(0xFF | (3 << 16)) : ~0xFF)) | lowNew;
+            int rem = fromPrev ? P.rem - 1 : regFull;
+            rem -= rem >= 4 ? (dlev < 2 ? dlev : 3) : 0;
+            cur.rem = rem; cur.anc = fromPrev ? P.anc : 0ull;
+            cur.lev.a = fromPrev ? P.lev.a : 0u; cur.lev.b = fromPrev ? P.lev.b : 0u; cur.lev.c = fromPrev ? P.lev.c : 0u; cur.lev.d = fromPrev ? P.lev.d : 0u;
           }
           dq_set_b(cur.lev, inside, (unsigned) imin(255, dlev));
           // template of the next position: its neighbours inside the group (m_scanId2NbInfoSbb) on top of the sums over those outside
           // the sums over the neighbours outside the group travel with the path as the row its group entry state wrote; a path that starts here has none (row 4: zeros)
           const int trow = fromPrev ? ((P.pk >> 27) & 7) : 4;
-          pk = dq_put(pk, 27, 3, trow);
+          pk = (pk & ~(7 << 27)) | (trow << 27);
           const int t = (int) tmrows[trow * 16 + nin];
           int sumAbs = t >> 8, sumAbs1 = (t >> 3) & 31, sumNum = t & 7;
           {
@@ -432,8 +432,8 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
             }
           }
           if (cur.rem >= 4) {
-            pk = dq_put(pk, 18, 4, sigOffN + imin((sumAbs1 + 1) >> 1, 3)); pk = dq_put(pk, 22, 5, gtxOffN + imin(sumAbs1 - sumNum, 4));
-            pk = dq_put(pk, 8, 2, L.t.gorice_pars[imax(imin(31, sumAbs - 20), 0)]);
+            pk = (pk & ~((3 << 8) | (0x1FF << 18))) | ((int) L.t.gorice_pars[imax(imin(31, sumAbs - 20), 0)] << 8) | ((sigOffN + imin((sumAbs1 + 1) >> 1, 3)) << 18)
+                 | ((gtxOffN + imin(sumAbs1 - sumNum, 4)) << 22);
           } else {
             sumAbs = imin(31, sumAbs);
             pk = dq_put(pk, 8, 2, L.t.gorice_pars[sumAbs]); pk = dq_put(pk, 10, 6, L.t.gorice_pos0[imax(0, k - 1) * 32 + sumAbs]);
@@ -443,7 +443,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
       } else {                                              // State::updateStateEOS 1275-1315 + CommonCtx::update 1317-1398
         const int g = sp >> lcg;
         int pk = cur.pk; int numSig, pRem; unsigned long long pAnc; U4 lv = { 0, 0, 0, 0 };
-        if (prevId >= 4) { numSig = 0; pRem = skp.rem; pAnc = skp.anc; }
+        if (dsrc == 4) { numSig = 0; pRem = skp.rem; pAnc = skp.anc; }
         else if (fromPrev) { numSig = DQ_NUMSIG(P.pk) + (dlev != 0); pRem = P.rem; pAnc = P.anc; lv = P.lev; }
         else { numSig = 1; pRem = regFull; pAnc = 0; }
         dq_set_b(lv, 0, (unsigned) imin(255, imax(dlev, 0)));
