@@ -4,8 +4,8 @@
 A "step" = one pass of the hot path over one batch of 1920x1080 8-bit 4:2:0 All-Intra frames (135 CTUs of 128x128
 each) at QP 32, full RDO (no early termination) with the tool subset built so far (see config.tools).  Every frame is
 cut into a uniform 15x9 tile grid so that every CTU is an independent stream (one workgroup per stream, SURVEY.md
-§8e); the batch holds enough frames for ~4 full waves of resident streams (30 frames on a 256-CU part, --frames to
-override); original planes are resident in HBM before the timed region.  With --gpus N every rank encodes its own
+§8e); the batch holds enough frames for ~4 full waves of resident streams (30 frames on a 256-CU part; fewer, down to two
+waves, when steps + warmup would not fit the run budget at that size; --frames to override); original planes are resident in HBM before the timed region.  With --gpus N every rank encodes its own
 frames per step (weak scaling, no data-path collective; frames are independent in All-Intra).
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against HBM bandwidth with the
@@ -31,6 +31,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 B_CTU_8BIT = 49152          # 2 x 1.5 x 128 x 128 x 1 byte  
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+RUN_BUDGET_S = 380.0          # what all timed + warm-up steps of one run may take (auto batch size only)
+BUDGET_CTUS_PER_S = 170.0     # rate assumed for that (below every measured configuration of the full tool set)
 
 
 def pmc_traffic(workload):
@@ -79,7 +83,7 @@ def main():
     ap.add_argument("--qp", type=int, default=32)
     ap.add_argument("--bit-depth", type=int, default=8, choices=(8, 10), help="10: uint16 planes (BASELINE configs 4 and 5), algorithmic bytes double")
     ap.add_argument("--frames", type=str, default="auto",
-                    help="frames per step and rank; auto = enough frames for ~4 full waves of resident CTU streams")
+                    help="frames per step and rank; auto = enough frames for ~4 full waves of resident CTU streams, fewer for long runs (see RUN_BUDGET_S)")
     ap.add_argument("--tiles", type=str, default="auto",
                     help="CxR uniform tile grid (1x1 = the reference cfg's single tile: one stream per frame; 4x2; ...); auto = one tile per CTU")
     ap.add_argument("--lib", type=str, default=None, help="alternative build of the HIP library (experiments only)")
@@ -134,6 +138,10 @@ def main():
         probe = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, device=dev, lib_path=args.lib, tools=args.tools, forest=forest)
         args.frames = max(1, (4 * probe.resident_streams()) // (tc * tr))
         probe.close()
+        # A long run (the round-end driver times 20 steps after 5 of warm-up inside a 600 s limit) gets a smaller batch so that all its steps fit
+        # RUN_BUDGET_S at a conservative rate; never below two full waves of resident streams.  The batch is part of config.workload.
+        fit = int(RUN_BUDGET_S * BUDGET_CTUS_PER_S / ((args.steps + args.warmup) * tc * tr))
+        args.frames = max(min(args.frames, fit), max(1, args.frames // 2))
     else:
         args.frames = int(args.frames)
     emit = world > 1                                # the N-GPU job ends with the bitstream gather: its ranks run the slice_data writer too

@@ -39,13 +39,31 @@ def _run_gpu(frames, W, H, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=Tru
 
 
 def _check(frames, W, H, sp, **kw):
-    got, ms, cnt = _run_gpu(frames, W, H, sp, **kw)
+    # the device runs while the host computes the oracle's answer (the C-ABI call blocks in its own thread; the checker never feeds the device path)
+    import threading
+    box = {}
+
+    def gpu_job():
+        try:
+            box["out"] = _run_gpu(frames, W, H, sp, **kw)
+        except BaseException as e:                              # re-raised in the test's thread
+            box["err"] = e
+    th = threading.Thread(target=gpu_job)
+    th.start()
+    if kw.get("workers", 1) > 1:
+        th.join()                                               # the multi-process oracle forks: not while another thread is inside the HIP runtime
     okw = dict(bit_depth=kw.get("bit_depth", 8), tile_cols=kw.get("tile_cols", 1), tile_rows=kw.get("tile_rows", 1), chroma=int(kw.get("chroma", True)),
                tools=kw.get("tools", pkg.TOOLS_DEFAULT))
+    try:
+        want = [O.compress_frame_parallel(planes, W, H, sp, workers=kw.get("workers", 1), forest=_forest(kw.get("forest_qp", 32)) if okw["tools"] & pkg.TOOL_FAST else None, **okw)
+                for planes in frames]       # workers > 1: the oracle's tiles spread over host processes (same result, tiles are independent streams)
+    finally:
+        th.join()
+    if "err" in box:
+        raise box["err"]
+    got, ms, cnt = box["out"]
     ocnt_sum = np.zeros(4, np.uint64)
-    for planes, (res, cus, reco) in zip(frames, got):
-        # workers > 1: the oracle's tiles spread over host processes (same result, tiles are independent streams)
-        ores, ocus, oreco, ocnt = O.compress_frame_parallel(planes, W, H, sp, workers=kw.get("workers", 1), forest=_forest(kw.get("forest_qp", 32)) if okw["tools"] & pkg.TOOL_FAST else None, **okw)
+    for (ores, ocus, oreco, ocnt), (res, cus, reco) in zip(want, got):
         ocnt_sum += ocnt
         for k in ores.dtype.names:
             assert np.array_equal(ores[k], res[k]), (k, ores[k], res[k])
@@ -274,28 +292,42 @@ def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fix
     tools = int(g["tools"][0]) if "tools" in g else pkg.TOOLS_DEFAULT
     texture = float(g["chroma_texture"][0]) if "chroma_texture" in g else 0.0
     oriented = float(g["oriented"][0]) if "oriented" in g else 0.0
+    torch.cuda.init()
     off = 0
+    jobs = []
     for pic, ((W, H, qp, tc, tr, bd, seed, nbytes), sizes) in enumerate(zip(g["pic_meta"], g["pic_sizes"])):
         exp = g["pic_bytes"][off:off + nbytes]; off += int(nbytes)
         if pic >= 3 and fixture in ("bitstream_jccr.npz", "bitstream_lfnst.npz"):      # the CPU suite checks the oracle against every picture; three per fixture here
             continue
-        W, H, bd = int(W), int(H), int(bd)
-        sp = pkg.slice_params(int(qp), bit_depth=bd, dep_quant=bool(tools & pkg.TOOL_DEPQUANT))
-        planes = pkg.synth_frame(W, H, 0, bd, int(seed), chroma_texture=texture, oriented=oriented)
-        enc = pkg.VvcxEncoder(W, H, bd, tile_cols=int(tc), tile_rows=int(tr), emit_payload=True, tools=tools)
+        jobs.append((int(W), int(H), int(qp), int(tc), int(tr), int(bd), int(seed), exp, sizes))
+
+    def one_picture(job):
+        # one encoder and one HIP stream per picture: the pictures of a fixture are independent streams and run side by side
+        W, H, qp, tc, tr, bd, seed, exp, sizes = job
+        sp = pkg.slice_params(qp, bit_depth=bd, dep_quant=bool(tools & pkg.TOOL_DEPQUANT))
+        planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture, oriented=oriented)
+        stream = torch.cuda.Stream()
+        enc = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, emit_payload=True, tools=tools)
         enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
         conv = [p if p.dtype == np.uint8 else p.view(np.int16) for p in planes]
         org = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in conv]
         rec = [torch.zeros_like(t) for t in org]
+        torch.cuda.synchronize()
         enc.bind_frames([([t.data_ptr() for t in org], [t.data_ptr() for t in rec], [t.shape[1] for t in org])])
         if (W, H) == (256, 128):                           # CTU by CTU: the coder state persists between launches
-            enc.compress_ctus([(0, 0)]); enc.compress_ctus([(0, 1)])
+            enc.compress_ctus([(0, 0)], stream=stream.cuda_stream); enc.compress_ctus([(0, 1)], stream=stream.cuda_stream)
         else:
-            enc.compress_bound_frames()
-        got = np.concatenate([enc.get_payload(0, t) for t in range(int(tc) * int(tr))])
-        assert [len(enc.get_payload(0, t)) for t in range(int(tc) * int(tr))] == list(sizes[:int(tc) * int(tr)])
-        assert np.array_equal(got, exp), (W, H, qp, tc, tr, bd)
+            enc.compress_bound_frames(stream=stream.cuda_stream)
+        pay = [enc.get_payload(0, t) for t in range(tc * tr)]
         enc.close()
+        return [len(b) for b in pay], np.concatenate(pay)
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        outs = list(ex.map(one_picture, jobs))
+    for (W, H, qp, tc, tr, bd, seed, exp, sizes), (lens, got) in zip(jobs, outs):
+        assert lens == list(sizes[:tc * tr])
+        assert np.array_equal(got, exp), (W, H, qp, tc, tr, bd)
 
 
 def test_seeded_sweep_over_sizes_qps_tools_and_tiles():
