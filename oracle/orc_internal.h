@@ -133,5 +133,15 @@ void orc_deblock_chroma_segment(int16_t *s, int o, int step, int sizeP, int size
 /* residual_coding on the estimator (orc_rate.c) */
 void orc_residual_coding(orc_cabac *c, const int16_t *level, int w, int h, int is_chroma);
 void orc_residual_coding_mts(orc_cabac *c, const int16_t *level, int w, int h, int is_chroma, int mts_idx);
+void orc_residual_coding_tu(orc_cabac *c, const int16_t *level, int w, int h, int is_chroma, int ts_allowed, int mts_allowed, int mts_idx);
+void orc_enc_rem_abs(orc_cabac *cb, unsigned bins, unsigned rice);
+/* transform skip (orc_ts.c) */
+int  orc_ts_qp(int qp);
+void orc_ts_fwd(const int16_t *resi, int stride, int w, int h, int bit_depth, int *coef);
+void orc_ts_inv(const int *coef, int w, int h, int bit_depth, int16_t *resi, int stride);
+int  orc_ts_sumabs(const int16_t *resi, int stride, int w, int h, int bit_depth);
+void orc_dequant_ts(const int16_t *level, int w, int h, int bit_depth, int qp, int *coef);
+int  orc_rdoq_ts(const uint16_t *s0, const uint16_t *s1, const int *coef, int w, int h, int bit_depth, int qp, double lambda, int16_t *level);
+void orc_residual_coding_ts(orc_cabac *cb, const int16_t *coeff, int w, int h);
 
 #endif

@@ -73,7 +73,7 @@ static int tmpl_abs_sum(const cctx_t *c, const int16_t *coeff, int blk, int base
   return imax(imin(sum - 5 * base, 31), 0);
 }
 /* EL/BinEncoder.cpp:444-472 (useLimitedPrefixLength forced true) */
-static void enc_rem_abs(orc_cabac *cb, unsigned bins, unsigned rice)
+void orc_enc_rem_abs(orc_cabac *cb, unsigned bins, unsigned rice)
 {
   const unsigned thr = 5u << rice;
   if (bins < thr) {                                   /* unary prefix, then rice bits (EL/BinEncoder.cpp:222-229) */
@@ -90,14 +90,19 @@ static void enc_rem_abs(orc_cabac *cb, unsigned bins, unsigned rice)
   orc_enc_bins_ep(cb, ((code - ((1u << prefix) - 1)) << rice) | (bins & ((1u << rice) - 1)), (int) suffix);
 }
 
-void orc_residual_coding(orc_cabac *cb, const int16_t *coeff, int w, int h, int is_chroma) { orc_residual_coding_mts(cb, coeff, w, h, is_chroma, -1); }
+void orc_residual_coding(orc_cabac *cb, const int16_t *coeff, int w, int h, int is_chroma) { orc_residual_coding_tu(cb, coeff, w, h, is_chroma, 0, 0, 0); }
 /* mts_idx: -1 = no MTS syntax for this block (TU::isMTSAllowed false); otherwise tu.mtsIdx (0 DCT2, 2..5) */
-void orc_residual_coding_mts(orc_cabac *cb, const int16_t *coeff, int w, int h, int is_chroma, int mts_idx)
+void orc_residual_coding_mts(orc_cabac *cb, const int16_t *coeff, int w, int h, int is_chroma, int mts_idx) { orc_residual_coding_tu(cb, coeff, w, h, is_chroma, 0, mts_idx >= 0, mts_idx < 0 ? 0 : mts_idx); }
+/* residual_coding of one block: mts_coding (3885-3941, JVET_O0294 context assignment) with ts_allowed = TU::isTSAllowed and mts_allowed =
+ * TU::isMTSAllowed of the block, tu.mtsIdx = mts_idx (0 DCT2, 1 transform skip, 2..5 the explicit pairs), then the coefficients */
+void orc_residual_coding_tu(orc_cabac *cb, const int16_t *coeff, int w, int h, int is_chroma, int ts_allowed, int mts_allowed, int mts_idx)
 {
-  if (mts_idx >= 0) {                 /* mts_coding (3885-3941), transform skip not allowed, JVET_O0294 context assignment */
+  if (ts_allowed) orc_enc_bin(cb, mts_idx == 1, ORC_CTX_MTSIndex + 6);
+  if (mts_idx != 1 && mts_allowed) {
     orc_enc_bin(cb, mts_idx != 0, ORC_CTX_MTSIndex + 0);
     if (mts_idx) for (int i = 0; i < 3; i++) { const int sym = mts_idx > i + 2; orc_enc_bin(cb, (unsigned) sym, ORC_CTX_MTSIndex + 7 + i); if (!sym) break; }
   }
+  if (!is_chroma && mts_idx == 1) { orc_residual_coding_ts(cb, coeff, w, h); return; }      /* 3802-3806 */
   const int zo = mts_idx > 1;         /* 32-point DST-VII / DCT-VIII keep 16 coefficients (getTbAreaAfterCoefZeroOut, CL/Unit.cpp:872-890) */
   cctx_t c; memset(&c, 0, sizeof c);
   c.w = w; c.h = h; c.ch = is_chroma;
@@ -199,7 +204,7 @@ void orc_residual_coding_mts(orc_cabac *cb, const int16_t *coeff, int w, int h, 
       const unsigned absLevel = (unsigned) abs(coeff[blk]);
       if (absLevel >= 4) {
         const int sumAll = tmpl_abs_sum(&c, coeff, blk, 4);
-        enc_rem_abs(cb, (absLevel - 4) >> 1, ORC_GORICE_PARS[sumAll]);
+        orc_enc_rem_abs(cb, (absLevel - 4) >> 1, ORC_GORICE_PARS[sumAll]);
       }
     }
     /* 3rd pass: bypass-coded positions (4275-4294) */
@@ -209,7 +214,7 @@ void orc_residual_coding_mts(orc_cabac *cb, const int16_t *coeff, int w, int h, 
       const int sumAll = tmpl_abs_sum(&c, coeff, blk, 0);
       const unsigned rice = ORC_GORICE_PARS[sumAll], pos0 = ORC_GORICE_POS0[imax(0, state - 1) * 32 + sumAll];
       const unsigned rem = absLevel == 0 ? pos0 : absLevel <= pos0 ? absLevel - 1 : absLevel;
-      enc_rem_abs(cb, rem, rice);
+      orc_enc_rem_abs(cb, rem, rice);
       state = (stateTab >> ((state << 2) + ((absLevel & 1) << 1))) & 3;
       if (absLevel) { numNonZero++; signPattern = (signPattern << 1) | (coeff[blk] < 0); }
     }

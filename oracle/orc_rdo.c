@@ -81,6 +81,7 @@ struct orc_enc {
   double sqrt_lambda_fp;              /* sqrtLambdaForFirstPass */
   uint64_t cnt_satd, cnt_rd, cnt_rdpix, cnt_nodes, cnt_reuse;
   cache_ent *cache; int ctu_is_last;
+  int dct2_sum;                       /* sum |coefficient| of the luma block transformed last (the DCT-II entry of the transform-skip pruning, CL/TrQuant.cpp:1049-1124) */
   int tu_cbf_cb;                      /* tu.cbf[Cb] while Cr is quantised (context of its cbf in DepQuant's rate tables) */
   int jccr_sign;                      /* slice joint_cb_cr_sign_flag, from the picture's chroma planes (EL/EncSlice.cpp:1503-1538) */
   int16_t *pred_c[2], *resi_c[2];     /* JointCbCr: predictions and residuals of the chroma block pair */
@@ -93,11 +94,13 @@ struct orc_enc {
 /* ------------------------------------------------------------------------------------------------ */
 orc_enc *orc_create(const orc_cfg *cfg)
 {
-  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST | ORC_TOOL_JCCR)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, LFNST, MTS, DepQuant, CCLM, JointCbCr, CU reuse, FAST)", cfg->tools); return 0; }
+  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST | ORC_TOOL_JCCR | ORC_TOOL_TS)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, LFNST, MTS, TS, DepQuant, CCLM, JointCbCr, CU reuse, FAST)", cfg->tools); return 0; }
   /* the plain quantiser's LFNST branch (CL/Quant.cpp:1054-1058) keeps buffer positions the decoder's LFNST conditions reject: the reference only
    * ever runs LFNST over DepQuant / RDOQ */
   if ((cfg->tools & ORC_TOOL_JCCR) && !(cfg->tools & ORC_TOOL_DEPQUANT)) { snprintf(g_err, sizeof g_err, "oracle: JointCbCr is built over DepQuant (tool set 0x%x)", cfg->tools); return 0; }
   if ((cfg->tools & ORC_TOOL_LFNST) && !(cfg->tools & ORC_TOOL_DEPQUANT)) { snprintf(g_err, sizeof g_err, "oracle: LFNST needs DepQuant (tool set 0x%x)", cfg->tools); return 0; }
+  /* transform skip is built as the reference cfg runs it: the {DCT2, TS} candidates of the LFNST branch of xRecurIntraCodingLumaQT, RDOQ-TS behind DepQuant::quant */
+  if ((cfg->tools & ORC_TOOL_TS) && (~cfg->tools & (ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST))) { snprintf(g_err, sizeof g_err, "oracle: transform skip needs DepQuant and LFNST (tool set 0x%x)", cfg->tools); return 0; }
   if (!cfg->dual_tree || cfg->ctu_size != 128) { snprintf(g_err, sizeof g_err, "oracle: only DualITree=1, CTUSize=128"); return 0; }
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7)) { snprintf(g_err, sizeof g_err, "oracle: picture size must be a multiple of 8 (EncAppCfg.cpp:2709)"); return 0; }
   orc_enc *e = (orc_enc *) calloc(1, sizeof *e);
@@ -560,6 +563,7 @@ static uint64_t code_tu_block_ex(orc_enc *e, int comp, int x, int y, int w, int 
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) e->resi[j * w + i] = (int16_t) (org[j * st + i] - e->pred[j * w + i]);
   if (!comp) memcpy(e->resi_org, e->resi, (size_t) w * h * 2);      /* the MTS pruning works on the prediction residual */
   orc_fwd_2d_mts(e->resi, w, w, h, bd, mts_idx, e->coef);
+  if (!comp) { int sa = 0; for (int i = 0; i < w * h; i++) sa += abs(e->coef[i]); e->dct2_sum = sa; }
   if (lf) { orc_lfnst_keep(e->coef, w, h); orc_fwd_lfnst(e->coef, w, h, lmode, lf); }       /* xT's zero-out 855-868, xFwdLfnst 1220-1223 */
   int abs_sum;
   if (e->cfg.tools & ORC_TOOL_DEPQUANT) {
@@ -661,6 +665,24 @@ static void reduce_had_cand_list(minfo *list, double *costs, int *size, int *num
  * ---------------------------------------------------------------------------------------------- */
 /* TU::isMTSAllowed (CL/UnitTools.cpp:4549-4565) for an intra luma TU without ISP / BDPCM: explicit intra MTS on, both sides <= 32 */
 static int mts_allowed(const orc_enc *e, int w, int h) { return (e->cfg.tools & ORC_TOOL_MTS) && w <= 32 && h <= 32; }
+/* TU::isTSAllowed (CL/UnitTools.cpp:4524-4546) for a luma TU of an intra CU without ISP / BDPCM: SPS transform skip on, both sides <= 1 << TransformSkipLog2MaxSize (5 in the cfg) */
+static int ts_allowed(const orc_enc *e, int w, int h) { return (e->cfg.tools & ORC_TOOL_TS) && w <= 32 && h <= 32; }
+/* xIntraCodingTUBlock of a luma block with tu.mtsIdx = MTS_SKIP: prediction in e->pred; xTransformSkip, RDOQ-TS from the estimator's live contexts, Quant::dequant,
+ * xITransformSkip, reconstruction, SSE */
+static uint64_t code_tu_block_ts(orc_enc *e, int x, int y, int w, int h, int16_t *rec_out, int16_t *lev_out, int *cbf)
+{
+  const int st = e->stride[0], bd = e->cfg.bit_depth, qp = e->sl.qp + 6 * (bd - 8), mx = (1 << bd) - 1;
+  const int16_t *org = e->org[0] + y * st + x;
+  for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) e->resi[j * w + i] = (int16_t) (org[j * st + i] - e->pred[j * w + i]);
+  orc_ts_fwd(e->resi, w, w, h, bd, e->coef);
+  const int abs_sum = orc_rdoq_ts(e->cabac.s0, e->cabac.s1, e->coef, w, h, bd, qp, e->sl.lambda, lev_out);
+  if (abs_sum > 0) { orc_dequant_ts(lev_out, w, h, bd, qp, e->coef); orc_ts_inv(e->coef, w, h, bd, e->resi, w); }
+  else memset(e->resi, 0, (size_t) w * h * 2);
+  for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) { int v = e->pred[j * w + i] + e->resi[j * w + i]; rec_out[j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
+  *cbf = abs_sum > 0;
+  e->cnt_rd++; e->cnt_rdpix += (uint64_t) w * h;
+  return orc_sse(org, st, rec_out, w, w, h);
+}
 /* What IntraSearch keeps between the passes of one xCheckRDCostIntra call when LFNST is on (m_uiSavedRdModeListLFNST ... 534-566, m_savedRdModeList /
  * m_modeCostStore / m_bestModeCostStore 884-916, 1262-1290) and the parameters of a pass (cu.lfnstIdx, cu.mtsFlag, the MTS index range = the
  * transform group, moreProbMTSIdxFirst) */
@@ -819,11 +841,30 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, luma_passes *ps, int *
       if (mtsFlag) mtsIdx = ps->tr_grp == 0 ? 2 : ps->tr_grp == 1 ? (dir < 34 ? 4 : 3) : ps->tr_grp == 2 ? (dir < 34 ? 3 : 4) : 5;
       int cbf;
       const uint64_t dist = code_tu_block_ex(e, 0, x, y, w, h, mtsIdx, lfnstIdx, (mrl & MIP_FLAG) ? ORC_PLANAR : dir, e->tmp_rec[0], e->tmp_lev[0], &cbf);
+      /* 3349-3367, 3505-3517: in the pass without LFNST and MTS the TU also tries transform skip unless the pruning (sum |TS coefficients|, scaled for odd
+       * log2 sizes, against the DCT-II sum) drops it */
+      const int tsTest = ts_allowed(e, w, h) && !mtsFlag && !lfnstIdx && (double) orc_ts_sumabs(e->resi_org, w, w, h, bd) <= (double) e->dct2_sum;
       e->cabac.bits = 0;
       enc_intra_luma_pred_mode(e, x, y, w, h, dir, mrl);
       orc_enc_bin(&e->cabac, (unsigned) cbf, ORC_CTX_QtCbf[0] + 0);
-      if (cbf) orc_residual_coding_mts(&e->cabac, e->tmp_lev[0], w, h, 0, mtsAllowed ? mtsIdx : -1);
+      if (cbf) orc_residual_coding_tu(&e->cabac, e->tmp_lev[0], w, h, 0, ts_allowed(e, w, h), mtsAllowed, mtsIdx);
       modeCost = rd_cost(e, e->cabac.bits, dist); modeDist = dist; modeCbf = cbf; modeMts = mtsIdx;
+      if (tsTest) {                                      /* from the start contexts (3441-3444); an empty TS block is forbidden (3567-3571) */
+        orc_ctx_copy(&e->cabac, &ctxStart);
+        int cbfT;
+        const uint64_t distT = code_tu_block_ts(e, x, y, w, h, e->tmp_rec[1], e->tmp_lev[1], &cbfT);
+        if (cbfT) {
+          e->cabac.bits = 0;
+          enc_intra_luma_pred_mode(e, x, y, w, h, dir, mrl);
+          orc_enc_bin(&e->cabac, 1u, ORC_CTX_QtCbf[0] + 0);
+          orc_residual_coding_tu(&e->cabac, e->tmp_lev[1], w, h, 0, 1, mtsAllowed, 1);
+          const double costT = rd_cost(e, e->cabac.bits, distT);
+          if (costT < modeCost) {
+            modeCost = costT; modeDist = distT; modeCbf = 1; modeMts = 1;
+            memcpy(e->tmp_rec[0], e->tmp_rec[1], (size_t) w * h * 2); memcpy(e->tmp_lev[0], e->tmp_lev[1], (size_t) w * h * 2);
+          }
+        }
+      }
       if (mtsUsage == 1) ps->mode_cost[lfnstIdx][idxOf[m]] = modeCost;                       /* 1262-1265 */
     } else {
     /* xRecurIntraCodingLumaQT 3340-3640 without LFNST / transform skip: transform candidates {DCT2} or, where TU::isMTSAllowed,
@@ -1363,7 +1404,8 @@ static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int
   const int st = e->stride[comp], bd = e->cfg.bit_depth, mx = (1 << bd) - 1;
   const int16_t *org = e->org[comp] + y * st + x;
   const int qp = (comp ? e->sl.qp_c[comp - 1] : e->sl.qp) + 6 * (e->cfg.bit_depth - 8);    /* QpParam: + QpBDOffset (CL/Quant.cpp:68-106) */
-  if (cbf) { if (e->cfg.tools & ORC_TOOL_DEPQUANT) orc_dequant_dq(lev, w, h, bd, qp, e->coef); else orc_dequant(lev, w, h, bd, qp, e->coef); orc_inv_lfnst(e->coef, w, h, lmode, lf); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
+  if (cbf && !comp && mts_idx == 1) { orc_dequant_ts(lev, w, h, bd, qp, e->coef); orc_ts_inv(e->coef, w, h, bd, e->resi, w); }      /* a transform-skip block: Quant::dequant + xITransformSkip */
+  else if (cbf) { if (e->cfg.tools & ORC_TOOL_DEPQUANT) orc_dequant_dq(lev, w, h, bd, qp, e->coef); else orc_dequant(lev, w, h, bd, qp, e->coef); orc_inv_lfnst(e->coef, w, h, lmode, lf); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
   else memset(e->resi, 0, (size_t) w * h * 2);
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) { int v = e->pred[j * w + i] + e->resi[j * w + i]; rec_out[j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
   uint64_t dd = orc_sse(org, st, rec_out, w, w, h);
@@ -1431,7 +1473,7 @@ static void enc_cu_syntax(orc_enc *e, int ch, area_t a, int dir, int mrl, int cb
   if (!ch) {
     enc_intra_luma_pred_mode(e, a.x, a.y, a.w, a.h, dir, mrl);
     orc_enc_bin(&e->cabac, (unsigned) (cbf & 1), ORC_CTX_QtCbf[0]);
-    if (cbf & 1) { orc_residual_coding_mts(&e->cabac, lev0, a.w, a.h, 0, mts_allowed(e, a.w, a.h) ? mts : -1); lastPos |= e->cabac.last_scan_pos >= 1; violates |= e->cabac.last_scan_pos > maxPos; }
+    if (cbf & 1) { orc_residual_coding_tu(&e->cabac, lev0, a.w, a.h, 0, ts_allowed(e, a.w, a.h), mts_allowed(e, a.w, a.h), mts); if (mts != 1) { lastPos |= e->cabac.last_scan_pos >= 1; violates |= e->cabac.last_scan_pos > maxPos; } }      /* 3837-3850: not for transform-skip blocks */
   } else {
     enc_intra_chroma_pred_mode(e, a, dir, lm_ok);
     enc_chroma_tu(e, W, H, cbf, jccr, lev0, lev1, &lastPos, &violates);
@@ -1510,6 +1552,7 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
             store_save_intra(e, d, ch, a, &cu);
             orc_ctx_copy(ctxBest, &e->cabac);
             trGrpBestCost[trGrp] = best->cost; bestSelFlag[trGrp] = 1; bestMtsFlag = mtsFlag; bestLfnstIdx = lfnstIdx;      /* 2696-2701 */
+            if (lfnstOn && !ch && mts == 1 && ilog2(a.w) + ilog2(a.h) >= 6) endLfnstIdx = 0;                                 /* 2702-2712: a transform-skip winner of at least 64 samples ends the LFNST passes */
           }
           orc_ctx_copy(&e->cabac, ctxStart);
         }

@@ -2,11 +2,13 @@
 import numpy as np
 
 
-def synth_frame(width, height, frame=0, bit_depth=8, seed=1234, chroma_texture=0.0, oriented=0.0):
+def synth_frame(width, height, frame=0, bit_depth=8, seed=1234, chroma_texture=0.0, oriented=0.0, screen=0.0):
     """chroma_texture > 0 adds that fraction of the (2x2 averaged) luma texture to Cb and minus half of it to Cr: natural video has
     such cross-component correlation and the LM chroma modes (CCLM) only win on pictures that have it.  oriented > 0 adds gratings of that
     amplitude (8-bit scale) whose direction and period change from one 32x32 block to the next: directional detail is what the angular modes
-    predict and what the mode-dependent secondary transform (LFNST) compacts; white noise alone never selects it."""
+    predict and what the mode-dependent secondary transform (LFNST) compacts; white noise alone never selects it.  screen > 0 renders that fraction
+    of the 32x32 blocks as noise-free screen content (a flat background with one-sample-wide strokes and isolated dots of high contrast): the
+    residuals transform skip is made for."""
     s = 1 if bit_depth == 8 else 4
     mid, a1, a2 = (128, 60, 40) if bit_depth == 8 else (512, 240, 160)
     mx = (1 << bit_depth) - 1
@@ -18,6 +20,16 @@ def synth_frame(width, height, frame=0, bit_depth=8, seed=1234, chroma_texture=0
         h1 = (bx * 73856093 ^ by * 19349663 ^ (seed * 83492791)) & 0xffff
         theta = (h1 % 32) * (np.pi / 32.0); period = 2.5 + ((h1 >> 5) % 5)
         Y = Y + oriented * s * np.sin((x * np.cos(theta) + y * np.sin(theta)) * (2 * np.pi / period))
+    if screen:
+        bx, by = x // 32, y // 32
+        h2 = ((bx * 2654435761) ^ (by * 40503) ^ (seed * 97 + frame * 7919)) & 0xffffffff
+        sel = ((h2 >> 3) % 1000) < int(screen * 1000)
+        g2 = np.random.default_rng(seed + 77)
+        dots = g2.random((height, width)) < 0.04
+        strokes = ((x % 7 == (h2 >> 13) % 7) & ((y // 5) % 3 != 0)) | ((y % 9 == (h2 >> 17) % 9) & ((x // 6) % 2 == 0))
+        bg = mid + s * (((h2 >> 21) % 5) * 12 - 24)
+        fg = np.where(((h2 >> 25) & 1) == 1, bg + 90 * s, bg - 80 * s)
+        Y = np.where(sel, np.where(strokes | dots, fg, bg), Y)
     yc, xc = np.mgrid[0:height // 2, 0:width // 2]
     U = mid + 20 * s * np.sin(xc / 50.0) + rng.normal(0, 2 * s, (height // 2, width // 2))
     V = mid + 20 * s * np.cos(yc / 40.0) + rng.normal(0, 2 * s, (height // 2, width // 2))

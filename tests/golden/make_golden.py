@@ -623,6 +623,53 @@ def gen_bitstream_lfnst():
     np.savez_compressed(os.path.join(HERE, "bitstream_lfnst_c.npz"), **out)
 
 
+def gen_ts():
+    """Transform skip through the reference: the {DCT2, TS} pruning of TrQuant::transformNxN (CL/TrQuant.cpp:1049-1124), xTransformSkip, RDOQ-TS
+    (QuantRDOQ::xRateDistOptQuantTS, reached through DepQuant::quant for MTS_SKIP luma blocks) with rates from adapted context models, Quant::dequant
+    and xITransformSkip, for every luma shape up to 32x32 (TransformSkipLog2MaxSize 5), sparse (screen-content like) to dense residuals, 8 / 10 bit."""
+    R.ref_env_trquant_ts.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_double] + [C.c_void_p] * 8
+    R.ref_ctx_init.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 3
+    g = np.random.default_rng(20266)
+    nctx = R.ref_ctx_count()
+    meta, lam_all, ctx_all, resi_all, lev_all, out_all = [], [], [], [], [], []
+    shapes = [(w, h) for w in (4, 8, 16, 32) for h in (4, 8, 16, 32)]
+    for gi, (bd, qp) in enumerate(((8, 22), (8, 32), (8, 37), (10, 32), (10, 22), (8, 2))):
+        env = R.ref_env_create(192, 192, bd)
+        s0 = np.zeros(nctx, np.uint16); s1 = np.zeros(nctx, np.uint16); rate = np.zeros(nctx, np.uint8)
+        R.ref_ctx_init(qp, 2, P(s0), P(s1), P(rate))
+        for i in range(nctx):
+            n = int(g.integers(0, 24)); bins = (g.random(n) < g.random()).astype(np.uint8)
+            a = s0[i:i + 1].copy(); b = s1[i:i + 1].copy()
+            if n: R.ref_ctx_code_bins(P(a), P(b), int(rate[i]), P(bins), n)
+            s0[i] = a[0]; s1[i] = b[0]
+        ctx_all.append(np.stack([s0, s1]))
+        lam0 = 0.57 * 2.0 ** ((qp + 6 * (bd - 8) - 12) / 3.0) * 2.0 ** (0.25 / 3.0)
+        for (w, h) in shapes:
+            for kind in range(4):
+                R.ref_env_reset(env)
+                amp = (1 << bd) // 4
+                if kind == 0:      # a few isolated spikes
+                    resi = np.zeros((h, w)); k = max(1, w * h // 24)
+                    resi.ravel()[g.choice(w * h, k, replace=False)] = g.integers(-amp, amp, k)
+                elif kind == 1:    # step edges (text like)
+                    resi = np.where(np.add.outer(np.arange(h) // max(1, h // 3), np.arange(w) // max(1, w // 2)) % 2 == 0, amp // 2, -amp // 3) + g.normal(0, 1.5, (h, w))
+                elif kind == 2:    # dense noise
+                    resi = g.normal(0, amp / 6, (h, w))
+                else:              # nearly nothing
+                    resi = g.normal(0, 1.2, (h, w))
+                resi = np.ascontiguousarray(np.clip(np.round(resi), -(1 << bd) + 1, (1 << bd) - 1).astype(np.int16))
+                lam = lam0 * float(g.choice([0.5, 1.0, 2.0]))
+                lev = np.zeros(w * h, np.int32); ro = np.zeros(w * h, np.int16); a = C.c_int(); keep = C.c_int(); qu = C.c_int()
+                assert R.ref_env_trquant_ts(env, 0, 0, w, h, qp, lam, P(s0), P(s1), P(resi), P(lev), P(ro), C.byref(a), C.byref(keep), C.byref(qu)) == 0
+                assert np.abs(lev).max() < 32768
+                meta.append((bd, qp, w, h, kind, keep.value, qu.value, a.value, gi)); lam_all.append(lam)
+                resi_all.append(resi.ravel()); lev_all.append(lev.astype(np.int16)); out_all.append(ro)
+    np.savez_compressed(os.path.join(HERE, "ts.npz"), meta=np.array(meta, np.int32), lam=np.array(lam_all, np.float64), ctx=np.stack(ctx_all),
+                        resi=np.concatenate(resi_all), lev=np.concatenate(lev_all), resi_out=np.concatenate(out_all))
+    m = np.array(meta)
+    print("ts cases", len(meta), "non-zero", int((m[:, 7] > 0).sum()), "kept by the pruning", int(m[:, 5].sum()), "max abs level", int(np.abs(np.concatenate(lev_all)).max()))
+
+
 def gen_decision_helpers():
     """CommonLib pieces the decision level calls: updateCandList (CL/UnitTools.h:261-306) on random insertion sequences incl. ties and lists shorter / longer than
     fastNum, and the per-shape constants of the luma search (getNumModesMip, allowLfnstWithMip, g_aucIntraModeNumFast_UseMPM_2D, the MTS size limit)."""
@@ -678,7 +725,16 @@ def gen_bitstream_jccr():
     np.savez_compressed(os.path.join(HERE, "bitstream_jccr_plain.npz"), **out)
 
 
-def _pictures(cases, tools, texture, oriented=0.0):
+def gen_bitstream_ts():
+    """Decoder round trip with transform skip on (tools 0xb7b: every tool built so far): transform_skip_flag in mts_coding, residual_codingTS (sign contexts, level mapping
+    from the left / above neighbours, the 2 * samples budget of context-coded bins) are parsed back by the reference's CABACReader, and DecCu dequantises at the
+    transform-skip QP and applies xITransformSkip: every tu.mtsIdx, level and reconstructed sample must equal the oracle's.  Pictures carry screen-content blocks."""
+    R.ref_env_set_tools.argtypes = [C.c_void_p, C.c_uint]
+    out = _pictures(((128, 128, 32, 1, 1, 8, 7), (200, 136, 27, 1, 1, 8, 1234), (256, 128, 37, 2, 1, 8, 5), (128, 128, 22, 1, 1, 10, 3)), 0xb7b, 0.5, oriented=30.0, screen=0.4)
+    np.savez_compressed(os.path.join(HERE, "bitstream_ts.npz"), **out)
+
+
+def _pictures(cases, tools, texture, oriented=0.0, screen=0.0):
     import importlib, sys
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -691,10 +747,10 @@ def _pictures(cases, tools, texture, oriented=0.0):
     pic_meta, pic_bytes, pic_sizes = [], [], []
     for (W, H, qp, tc, tr, bd, seed) in cases:
         sp = pkg.slice_params(qp, bit_depth=bd, dep_quant=bool(tools & 0x40))
-        planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture, oriented=oriented)
+        planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture, oriented=oriented, screen=screen)
         payload, sizes, cus, lev = O.write_frame(planes, W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools)
         env = R.ref_env_create(W, H, bd); R.ref_env_set_tiles(env, tc, tr)
-        if tools & 0x35a:
+        if tools & 0x37a:
             R.ref_env_set_tools(env, tools)
         if tools & 0x200:
             cb, cr = planes[1].astype(np.int16), planes[2].astype(np.int16)
@@ -713,8 +769,8 @@ def _pictures(cases, tools, texture, oriented=0.0):
         nd = R.ref_dec_get_cus(env, P(rows), P(ss), len(rows)); assert nd == len(cus)
         dec = {(int(r[0]), int(r[1]), int(r[2])): (tuple(int(v) for v in r[3:]), int(s)) for r, s in zip(rows[:nd], ss[:nd])}
         for c in cus:
-            exp = ((int(c["w"]), int(c["h"]), int(c["qt_depth"]), int(c["bt_depth"]), int(c["mt_depth"]), int(c["depth"]), int(c["intra_dir"]), int(c["mrl_idx"]) | (int(c["mip_flag"]) << 7), int(c["cbf"]) | (int(c["mts_idx"]) << 8) | (int(c["lfnst_idx"]) << 16) | (int(c["joint_cb_cr"]) << 20)), int(c["split_series"]))
-            assert dec[(int(c["ch_type"]), int(c["x"]), int(c["y"]))] == exp, "decoded CU differs"
+            exp = ((int(c["w"]), int(c["h"]), int(c["qt_depth"]), int(c["bt_depth"]), int(c["mt_depth"]), int(c["depth"]), int(c["intra_dir"]), int(c["mrl_idx"]) | (int(c["mip_flag"]) << 7), int(c["cbf"]) | ((int(c["mts_idx"]) if c["cbf"] & 1 else 0) << 8) | (int(c["lfnst_idx"]) << 16) | (int(c["joint_cb_cr"]) << 20)), int(c["split_series"]))
+            assert dec[(int(c["ch_type"]), int(c["x"]), int(c["y"]))] == exp, ("decoded CU differs", (int(c["ch_type"]), int(c["x"]), int(c["y"])), dec[(int(c["ch_type"]), int(c["x"]), int(c["y"]))], exp)
         for comp in range(3):
             d = np.zeros_like(lev[comp]); R.ref_dec_get_levels(env, comp, P(d), d.shape[1])
             assert np.array_equal(d, lev[comp]), "decoded levels differ"
@@ -728,11 +784,13 @@ def _pictures(cases, tools, texture, oriented=0.0):
         pic_meta.append((W, H, qp, tc, tr, bd, seed, len(payload))); pic_bytes.append(payload); pic_sizes.append(np.pad(sizes, (0, 16 - len(sizes))))
         nlm = int(sum(1 for c in cus if c["ch_type"] == 1 and 67 <= c["intra_dir"] <= 69))
         nmts = int(sum(1 for c in cus if c["ch_type"] == 0 and c["mts_idx"] > 1))
-        print("picture", W, H, qp, tc, tr, bd, "payload", len(payload), "bytes, decoded by the reference:", nd, "CUs,", nlm, "with an LM chroma mode,", nmts, "with an MTS transform,", int(np.count_nonzero(cus["mip_flag"])), "MIP,", int(np.count_nonzero(cus["lfnst_idx"])), "LFNST,", int(np.count_nonzero(cus["joint_cb_cr"])), "JointCbCr")
+        print("picture", W, H, qp, tc, tr, bd, "payload", len(payload), "bytes, decoded by the reference:", nd, "CUs,", nlm, "with an LM chroma mode,", nmts, "with an MTS transform,", int(np.count_nonzero(cus["mip_flag"])), "MIP,", int(np.count_nonzero(cus["lfnst_idx"])), "LFNST,", int(np.count_nonzero(cus["joint_cb_cr"])), "JointCbCr,", int(sum(1 for c in cus if c["ch_type"] == 0 and c["mts_idx"] == 1)), "transform skip")
     out["pic_meta"] = np.array(pic_meta, np.int32); out["pic_bytes"] = np.concatenate(pic_bytes); out["pic_sizes"] = np.stack(pic_sizes).astype(np.int32)
     out["tools"] = np.array([tools], np.int32); out["chroma_texture"] = np.array([texture], np.float64)
     if oriented:
         out["oriented"] = np.array([oriented], np.float64)
+    if screen:
+        out["screen"] = np.array([screen], np.float64)
     return out
 
 
@@ -770,7 +828,11 @@ if __name__ == "__main__":
         gen_bitstream_lfnst(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lfnst":
         gen_lfnst(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bitstream_ts":
+        gen_bitstream_ts(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ts":
+        gen_ts(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict(); gen_decision_helpers()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict(); gen_decision_helpers(); gen_ts(); gen_bitstream_ts()
     print("done")

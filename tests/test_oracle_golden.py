@@ -168,10 +168,11 @@ def _check_pictures(g, pkg):
     tools = int(g["tools"][0]) if "tools" in g else O.TOOLS_DEFAULT
     texture = float(g["chroma_texture"][0]) if "chroma_texture" in g else 0.0
     oriented = float(g["oriented"][0]) if "oriented" in g else 0.0
+    screen = float(g["screen"][0]) if "screen" in g else 0.0
     off = 0
     for (W, H, qp, tc, tr, bd, seed, nbytes), sizes in zip(g["pic_meta"], g["pic_sizes"]):
         exp = g["pic_bytes"][off:off + nbytes]; off += int(nbytes)
-        planes = pkg.synth_frame(int(W), int(H), 0, int(bd), int(seed), chroma_texture=texture, oriented=oriented)
+        planes = pkg.synth_frame(int(W), int(H), 0, int(bd), int(seed), chroma_texture=texture, oriented=oriented, screen=screen)
         payload, sz, _, _ = O.write_frame(planes, int(W), int(H), pkg.slice_params(int(qp), bit_depth=int(bd), dep_quant=bool(tools & 0x40)),
                                           bit_depth=int(bd), tile_cols=int(tc), tile_rows=int(tr), tools=tools)
         assert np.array_equal(sz, sizes[:len(sz)]) and np.array_equal(payload, exp), (W, H, qp, tc, tr, bd)
@@ -458,4 +459,49 @@ def test_slice_data_payload_with_dependent_quantisation():
     import importlib
     g = np.load(os.path.join(G, "bitstream_dq.npz"))
     assert int(g["tools"][0]) & 0x40
+    _check_pictures(g, importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd"))
+
+
+def _ts_cases():
+    g = np.load(os.path.join(G, "ts.npz"))
+    off = 0
+    for k, row in enumerate(g["meta"]):
+        bd, qp, w, h, kind, keep, qp_used, asum, gi = (int(v) for v in row)
+        n = w * h
+        yield dict(bd=bd, qp=qp, w=w, h=h, kind=kind, keep=keep, qp_used=qp_used, asum=asum, lam=float(g["lam"][k]), ctx=g["ctx"][gi],
+                   resi=np.ascontiguousarray(g["resi"][off:off + n]), lev=g["lev"][off:off + n], out=g["resi_out"][off:off + n])
+        off += n
+
+
+def test_transform_skip_against_the_reference_rdoq_ts():
+    """Transform skip (CL/TrQuant.cpp:1394-1440, 996-1041) with RDOQ-TS (CL/QuantRDOQ.cpp:1243-1483): the {DCT2, TS} pruning decision, levels, absSum and the
+    reconstructed residual of 384 luma blocks (every shape up to 32x32, spikes / edges / noise / nearly empty, adapted context models, 8 / 10 bit, the
+    minimum TS QP) == the reference's TrQuant::transformNxN / invTransformNxN with tu.mtsIdx = MTS_SKIP."""
+    L = O.lib()
+    L.orc_trquant_ts.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_double] + [C.c_void_p] * 3
+    nz = 0
+    for c in _ts_cases():
+        w, h, n = c["w"], c["h"], c["w"] * c["h"]
+        lev = np.zeros(n, np.int16); out = np.zeros(n, np.int16); keep = C.c_int()
+        s0 = np.ascontiguousarray(c["ctx"][0]); s1 = np.ascontiguousarray(c["ctx"][1])
+        qp_prime = c["qp"] + 6 * (c["bd"] - 8)
+        a = L.orc_trquant_ts(P(s0), P(s1), P(c["resi"]), w, h, c["bd"], qp_prime, c["lam"], P(lev), P(out), C.byref(keep))
+        key = (c["bd"], c["qp"], w, h, c["kind"])
+        assert max(qp_prime, 4) == c["qp_used"], key
+        assert keep.value == c["keep"], ("pruning", key)
+        assert a == c["asum"], ("absSum", key, a, c["asum"])
+        assert np.array_equal(lev, c["lev"]), ("levels", key)
+        if a:
+            nz += 1
+            assert np.array_equal(out, c["out"]), ("resi", key)
+    assert nz > 250
+
+
+def test_slice_data_payload_with_transform_skip():
+    """tools 0xb7b (+ transform skip): payloads the reference's CABACReader parsed back including transform_skip_flag and residual_codingTS, and whose DecCu
+    reconstruction (Quant::dequant at the TS QP, xITransformSkip) was the oracle's, on pictures with screen-content blocks where transform skip wins
+    (tests/golden/make_golden.py bitstream_ts)."""
+    import importlib
+    g = np.load(os.path.join(G, "bitstream_ts.npz"))
+    assert int(g["tools"][0]) & 0x20 and float(g["screen"][0]) > 0
     _check_pictures(g, importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd"))
