@@ -113,6 +113,10 @@ typedef struct {
 } orc_ipa;
 
 void orc_init_pred_params(int w, int h, int is_luma, int mode, int mrl, orc_ipa *p);
+void orc_init_pred_params_isp(int cuw, int cuh, int w, int h, int mode, orc_ipa *p);
+void orc_pred_intra_isp(const int16_t *src, int st, int cuw, int cuh, int w, int h, int mode, int bit_depth, int16_t *pred, int ps);
+void orc_fwd_isp(const int16_t *resi, int stride, int w, int h, int bit_depth, int *coef);
+void orc_inv_isp(const int *coef, int w, int h, int bit_depth, int16_t *resi, int stride);
 void orc_cg_shape(int w, int h, int *lcw, int *lch);
 void orc_satd_tile_shape(int w, int h, int *bw, int *bh);
 const int8_t *orc_tr_matrix(int tr, int n);

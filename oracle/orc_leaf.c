@@ -102,6 +102,34 @@ void orc_inv_2d_mts(const int *coef, int w, int h, int bit_depth, int mts_idx, i
 }
 void orc_inv_2d(const int *coef, int w, int h, int bit_depth, int16_t *resi, int stride) { orc_inv_2d_mts(coef, w, h, bit_depth, 0, resi, stride); }
 
+/* xT / xIT for a luma block of an ISP CU (getTrTypes 752-780: DST-VII along a side of 4..16 samples, DCT-II otherwise; cfg MTS 1) incl. the 1-D forms for
+ * Nx1 / 1xN sub-partitions (895-914, 970-983) */
+void orc_fwd_isp(const int16_t *resi, int stride, int w, int h, int bit_depth, int *coef)
+{
+  const int trh = (w >= 4 && w <= 16) ? 2 : 0, trv = (h >= 4 && h <= 16) ? 2 : 0;
+  int *block = (int *) malloc(sizeof(int) * w * h * 2), *tmp = block + w * h;
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) block[y * w + x] = resi[y * stride + x];
+  if (w > 1 && h > 1) {
+    orc_fwd_1d(trh, w, block, tmp, ilog2(w) + bit_depth + 6 - 15, h, 0, 0);
+    orc_fwd_1d(trv, h, tmp, coef, ilog2(h) + 6, w, 0, 0);
+  } else if (h == 1) orc_fwd_1d(trh, w, block, coef, ilog2(w) + bit_depth + 6 - 15, 1, 0, 0);
+  else orc_fwd_1d(trv, h, block, coef, ilog2(h) + bit_depth + 6 - 15, 1, 0, 0);
+  free(block);
+}
+void orc_inv_isp(const int *coef, int w, int h, int bit_depth, int16_t *resi, int stride)
+{
+  const int trh = (w >= 4 && w <= 16) ? 2 : 0, trv = (h >= 4 && h <= 16) ? 2 : 0;
+  int *tmp = (int *) malloc(sizeof(int) * w * h * 2), *block = tmp + w * h;
+  const int cmin = -(1 << 15), cmax = (1 << 15) - 1, shift2 = (6 + 15 - 1) - bit_depth;
+  if (w > 1 && h > 1) {
+    orc_inv_1d(trv, h, coef, tmp, 6 + 1, w, 0, 0, cmin, cmax);
+    orc_inv_1d(trh, w, tmp, block, shift2, h, 0, 0, cmin, cmax);
+  } else if (w == 1) orc_inv_1d(trv, h, coef, block, shift2 + 1, 1, 0, 0, cmin, cmax);
+  else orc_inv_1d(trh, w, coef, block, shift2 + 1, 1, 0, 0, cmin, cmax);
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) resi[y * stride + x] = (int16_t) block[y * w + x];
+  free(tmp);
+}
+
 /* TrQuant::transformNxN, pruning overload (CL/TrQuant.cpp:1049-1124) for the candidate list {DCT2, 2, 3, 4, 5} (no transform skip):
  * sum |coeff| per transform; an entry stays when its sum <= fac * sum(DCT2) — list position 1 is compared against sum(DCT2) itself, the
  * reference's transform-skip threshold applied by position — and no more than max_cand + 1 entries are kept, in list order. */
@@ -552,18 +580,50 @@ static int16_t clip_pel(int v, int bit_depth) { const int mx = (1 << bit_depth) 
 
 /* CL/IntraPrediction.cpp:316-398 predIntraAng (dispatch + planar/DC PDPC), 426-479 planar,
  * 248-285/480 DC, 633-935 xPredIntraAng */
+/* initPredIntraParams for a prediction region (w x h) of an ISP CU (cuw x cuh): wide-angle mapping by the CU's shape, no reference smoothing, the cubic
+ * interpolation filter, PDPC by the region's size (487-618 with useISP, JVET_O0502) */
+void orc_init_pred_params_isp(int cuw, int cuh, int w, int h, int mode, orc_ipa *p)
+{
+  orc_ipa q; orc_init_pred_params(cuw, cuh, 1, mode, 0, &q);         /* pred_mode / is_ver / angle / inv_angle from the CU's shape */
+  *p = q;
+  p->ref_filter = 0; p->interp = 0;
+  p->pdpc = w >= 4 && h >= 4;
+  p->ang_scale = -1;
+  if (mode > ORC_DC && mode < ORC_NUM_LUMA_MODE) {
+    const int am = p->is_ver ? p->pred_mode - ORC_VER : -(p->pred_mode - ORC_HOR);
+    if (am < 0) p->pdpc = 0;
+    else if (am > 0) {
+      const int side = p->is_ver ? h : w;
+      int sc = ilog2(side) - (ilog2(3 * p->inv_angle - 2) - 8);
+      if (sc > 2) sc = 2;
+      p->ang_scale = sc;
+      p->pdpc &= sc >= 0;
+    }
+  }
+}
+static void pred_core(const int16_t *src, int st, int w, int h, int is_luma, int mode, const orc_ipa *ipp, int top_len, int left_len, int bit_depth, int16_t *pred, int ps);
 void orc_pred_intra(const int16_t *ref_unf, const int16_t *ref_flt, int w, int h, int is_luma, int mode, int mrl,
                     int bit_depth, int16_t *pred, int ps)
 {
   orc_ipa ip; orc_init_pred_params(w, h, is_luma, mode, mrl, &ip);
-  mrl = ip.mrl;
-  const int16_t *src = ip.ref_filter ? ref_flt : ref_unf;
-  const int st = 2 * w + 1 + mrl;
+  pred_core(ip.ref_filter ? ref_flt : ref_unf, 2 * w + 1 + ip.mrl, w, h, is_luma, mode, &ip, 2 * w, 2 * h, bit_depth, pred, ps);
+}
+/* prediction of one region of an ISP CU from its (unfiltered) reference buffer src (row 0: corner + top_len samples, column 0: left_len samples below the corner,
+ * stride st): m_topRefLength / m_leftRefLength = CU side + region side (CL/IntraPrediction.cpp:1092-1199) */
+void orc_pred_intra_isp(const int16_t *src, int st, int cuw, int cuh, int w, int h, int mode, int bit_depth, int16_t *pred, int ps)
+{
+  orc_ipa ip; orc_init_pred_params_isp(cuw, cuh, w, h, mode, &ip);
+  pred_core(src, st, w, h, 1, mode, &ip, cuw + w, cuh + h, bit_depth, pred, ps);
+}
+static void pred_core(const int16_t *src, int st, int w, int h, int is_luma, int mode, const orc_ipa *ipp, int top_len, int left_len, int bit_depth, int16_t *pred, int ps)
+{
+  const orc_ipa ip = *ipp;
+  const int mrl = ip.mrl;
 #define TOP(i) src[(i)]
 #define LEFT(i) src[(i) * st]
   if (mode == ORC_PLANAR) {
     int leftCol[ORC_MAX_CU + 1], topRow[ORC_MAX_CU + 1], bottomRow[ORC_MAX_CU], rightCol[ORC_MAX_CU];
-    const int l2w = ilog2(w), l2h = ilog2(h);
+    const int l2w = ilog2(w < 2 ? 2 : w), l2h = ilog2(h < 2 ? 2 : h);      /* 430-431: one-sample sides of ISP sub-partitions weigh like two */
     for (int k = 0; k < w + 1; k++) topRow[k] = TOP(k + 1);
     for (int k = 0; k < h + 1; k++) leftCol[k] = LEFT(k + 1);
     const int bl = leftCol[h], tr = topRow[w];
@@ -597,14 +657,14 @@ void orc_pred_intra(const int16_t *ref_unf, const int16_t *ref_flt, int w, int h
       const int sizeSide = ver ? h : w;
       for (int k = -sizeSide; k <= -1; k++) { int idx = (-k * inv + 256) >> 9; if (idx > sizeSide) idx = sizeSide; refMain[k] = refSide[idx]; }
     } else {
-      for (int x = 0; x <= 2 * w + mrl; x++) refAbove[x] = TOP(x);
-      for (int y = 0; y <= 2 * h + mrl; y++) refLeft[y] = LEFT(y);
+      for (int x = 0; x <= top_len + mrl; x++) refAbove[x] = TOP(x);
+      for (int y = 0; y <= left_len + mrl; y++) refLeft[y] = LEFT(y);
       refMain = ver ? refAbove : refLeft;
       refSide = ver ? refLeft : refAbove;
       const int lr = ilog2(w) - ilog2(h);
       int s = ver ? lr : -lr; if (s < 0) s = 0;
       const int maxIndex = (mrl << s) + 2;
-      const int refLength = ver ? 2 * w : 2 * h;
+      const int refLength = ver ? top_len : left_len;
       const int16_t val = refMain[refLength + mrl];
       for (int z = 1; z <= maxIndex; z++) refMain[refLength + mrl + z] = val;
     }
@@ -727,6 +787,8 @@ void orc_cg_shape(int w, int h, int *lcw, int *lch)
 {
   const int lw = ilog2(w), lh = ilog2(h);
   if (lw >= 2 && lh >= 2) { *lcw = 2; *lch = 2; return; }
+  if (lh == 0) { *lcw = lw > 4 ? 4 : lw; *lch = 0; return; }       /* Nx1 / 1xN blocks of ISP sub-partitions: one row / column of up to 16 */
+  if (lw == 0) { *lcw = 0; *lch = lh > 4 ? 4 : lh; return; }
   if (lh == 1) { *lcw = lw >= 3 ? 3 : lw; *lch = 1; if (lw == 2) *lcw = 1; return; }   /* Nx2: {1,1} for 4x2, {3,1} for >=8 */
   /* 2xN (not reachable in 4:2:0 dual tree) */
   *lcw = 1; *lch = lh >= 3 ? 3 : lh; if (lh == 2) *lch = 1;

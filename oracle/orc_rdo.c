@@ -34,6 +34,7 @@ typedef struct { int x, y, w, h; } area_t;   /* luma samples (UnitArea::Y) */
 
 typedef struct {       /* per 4x4-luma-unit record of the CU covering it, one map per channel type */
   uint8_t valid, tile, qt_depth, mt_depth, bt_depth, depth, dir, mrl, cbf, lw, lh, mts, lfnst, jccr;
+  uint8_t isp, tucbf;  /* cu.ispMode (0, 1 horizontal, 2 vertical split) and the cbf of each of its sub-partitions (bit k = TU k) */
   int16_t x, y;        /* CU origin in channel samples */
   uint64_t split_series;
 } unit_t;
@@ -60,7 +61,7 @@ typedef struct {       /* what the mode controller reads from a CodingStructure 
  * 4-sample units, log2 w, log2 h) like m_bestEncInfo[x][y][wIdx][hIdx] (EL/EncModeCtrl.cpp:706-760).  The reference
  * keeps entries across CTUs and rejects stale ones by comparing poc and absolute area (987-1024); clearing at every
  * CTU start is equivalent.  lev: w*h luma levels, or Cb then Cr (cw*ch each). */
-typedef struct { uint8_t valid, ch, dir, mrl, cbf, depth, mts, lfnst, jccr; uint64_t ss; int16_t *lev; } cache_ent;
+typedef struct { uint8_t valid, ch, dir, mrl, cbf, depth, mts, lfnst, jccr, isp, tucbf; uint64_t ss; int16_t *lev; } cache_ent;
 #define CACHE_ENTRIES (32 * 32 * 6 * 6)
 
 #define MAX_DEPTH 20
@@ -94,13 +95,15 @@ struct orc_enc {
 /* ------------------------------------------------------------------------------------------------ */
 orc_enc *orc_create(const orc_cfg *cfg)
 {
-  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST | ORC_TOOL_JCCR | ORC_TOOL_TS)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, LFNST, MTS, TS, DepQuant, CCLM, JointCbCr, CU reuse, FAST)", cfg->tools); return 0; }
+  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST | ORC_TOOL_JCCR | ORC_TOOL_TS | ORC_TOOL_ISP)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, ISP, LFNST, MTS, TS, DepQuant, CCLM, JointCbCr, CU reuse, FAST)", cfg->tools); return 0; }
   /* the plain quantiser's LFNST branch (CL/Quant.cpp:1054-1058) keeps buffer positions the decoder's LFNST conditions reject: the reference only
    * ever runs LFNST over DepQuant / RDOQ */
   if ((cfg->tools & ORC_TOOL_JCCR) && !(cfg->tools & ORC_TOOL_DEPQUANT)) { snprintf(g_err, sizeof g_err, "oracle: JointCbCr is built over DepQuant (tool set 0x%x)", cfg->tools); return 0; }
   if ((cfg->tools & ORC_TOOL_LFNST) && !(cfg->tools & ORC_TOOL_DEPQUANT)) { snprintf(g_err, sizeof g_err, "oracle: LFNST needs DepQuant (tool set 0x%x)", cfg->tools); return 0; }
   /* transform skip is built as the reference cfg runs it: the {DCT2, TS} candidates of the LFNST branch of xRecurIntraCodingLumaQT, RDOQ-TS behind DepQuant::quant */
   if ((cfg->tools & ORC_TOOL_TS) && (~cfg->tools & (ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST))) { snprintf(g_err, sizeof g_err, "oracle: transform skip needs DepQuant and LFNST (tool set 0x%x)", cfg->tools); return 0; }
+  /* ISP likewise: its candidates sit in the first pass of the LFNST pass loop, its blocks are quantised by DepQuant, their transforms follow getTrTypes with MTS on */
+  if ((cfg->tools & ORC_TOOL_ISP) && (~cfg->tools & (ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST | ORC_TOOL_MTS))) { snprintf(g_err, sizeof g_err, "oracle: ISP needs DepQuant, LFNST and MTS (tool set 0x%x)", cfg->tools); return 0; }
   if (!cfg->dual_tree || cfg->ctu_size != 128) { snprintf(g_err, sizeof g_err, "oracle: only DualITree=1, CTUSize=128"); return 0; }
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7)) { snprintf(g_err, sizeof g_err, "oracle: picture size must be a multiple of 8 (EncAppCfg.cpp:2709)"); return 0; }
   orc_enc *e = (orc_enc *) calloc(1, sizeof *e);
@@ -449,7 +452,19 @@ static int mip_signalled(const orc_enc *e, int w, int h) { return (e->cfg.tools 
 
 /* CABACWriter::intra_luma_pred_mode (1762-1845) with extend_ref_line (1566-1591); mip_flag / isp_mode
  * write nothing when the tools are off in the SPS.  mrl carries MIP_FLAG for a MIP CU (dir = MIP mode) */
-static void enc_intra_luma_pred_mode(orc_enc *e, int x, int y, int w, int h, int dir, int mrl)
+/* CU::canUseISP (CL/UnitTools.cpp:414-435): more than 16 samples, no side above MaxTbSize; CU::getISPSplitDim (437-459): the sub-partition size along the split
+ * direction (a quarter of the side, but at least 16 samples per sub-partition) */
+static int can_use_isp(const orc_enc *e, int w, int h) { return (e->cfg.tools & ORC_TOOL_ISP) && ilog2(w) + ilog2(h) > 4 && w <= 64 && h <= 64; }
+static int isp_split_dim(int w, int h, int hor)
+{
+  const int split = hor ? h : w, non = hor ? w : h;
+  const int factor = non < 16 ? 16 >> ilog2(non) : 1;
+  return (split >> 2) < factor ? factor : (split >> 2);
+}
+static void enc_intra_luma_pred_mode_isp(orc_enc *e, int x, int y, int w, int h, int dir, int mrl, int isp);
+static void enc_intra_luma_pred_mode(orc_enc *e, int x, int y, int w, int h, int dir, int mrl) { enc_intra_luma_pred_mode_isp(e, x, y, w, h, dir, mrl, 0); }
+/* isp: cu.ispMode.  isp_mode (EL/CABACWriter.cpp:3944-3965) follows the reference line index of every luma CU that could use ISP */
+static void enc_intra_luma_pred_mode_isp(orc_enc *e, int x, int y, int w, int h, int dir, int mrl, int isp)
 {
   orc_cabac *c = &e->cabac;
   if (mip_signalled(e, w, h)) {
@@ -469,12 +484,13 @@ static void enc_intra_luma_pred_mode(orc_enc *e, int x, int y, int w, int h, int
     orc_enc_bin(c, mrl != 0, ORC_CTX_MultiRefLineIdx + 0);
     if (mrl != 0) orc_enc_bin(c, mrl != 1, ORC_CTX_MultiRefLineIdx + 1);
   }
+  if (!mrl && can_use_isp(e, w, h)) { orc_enc_bin(c, isp != 0, ORC_CTX_ISPMode + 0); if (isp) orc_enc_bin(c, (unsigned) (isp - 1), ORC_CTX_ISPMode + 1); }
   unsigned mpm[6]; get_mpms(e, x, y, w, h, mpm);
   int mpm_idx = 6;
   for (int i = 0; i < 6; i++) if ((unsigned) dir == mpm[i]) { mpm_idx = i; break; }
   if (!mrl) orc_enc_bin(c, mpm_idx < 6, ORC_CTX_IntraLumaMpmFlag);
   if (mpm_idx < 6) {
-    if (mrl == 0) orc_enc_bin(c, mpm_idx > 0, ORC_CTX_IntraLumaPlanarFlag + 1);   /* ctx 1: ispMode == NOT_INTRA_SUBPARTITIONS */
+    if (mrl == 0) orc_enc_bin(c, mpm_idx > 0, ORC_CTX_IntraLumaPlanarFlag + (isp ? 0 : 1));   /* 1812: context by cu.ispMode */
     if (mpm_idx) orc_enc_bins_ep(c, mpm_idx > 1, 1);
     if (mpm_idx > 1) orc_enc_bins_ep(c, mpm_idx > 2, 1);
     if (mpm_idx > 2) orc_enc_bins_ep(c, mpm_idx > 3, 1);
@@ -659,6 +675,201 @@ static void reduce_had_cand_list(minfo *list, double *costs, int *size, int *num
   *size = tn; *numRd = tn;
 }
 
+
+/* ------------------------------------------------------------------------------------------------
+ * ISP (intra sub-partitions)
+ * ---------------------------------------------------------------------------------------------- */
+/* reference samples of one prediction region (pw x ph at offset ox, oy) of an ISP CU: IntraPrediction::initIntraPatternChTypeISP (CL/IntraPrediction.cpp:1092-1199).
+ * base = the CU's own reference samples (e->ref_unf of build_refs, stride 2 w + 1); rec = the CU's reconstruction so far (tile, stride w); ref gets the region's
+ * samples with stride w + pw + 1: row 0 = corner + (w + pw) top samples, column 0 = (h + ph) left samples */
+static void isp_sub_refs(const orc_enc *e, area_t a, int isp, int ox, int oy, int pw, int ph, const int16_t *rec, int16_t *ref)
+{
+  const int w = a.w, h = a.h, bs = 2 * w + 1, S = w + pw + 1, topLen = w + pw, leftLen = h + ph;
+  const int16_t *base = e->ref_unf;
+  if (!ox && !oy) {
+    for (int i = 0; i <= topLen; i++) ref[i] = base[i];
+    for (int j = 1; j <= leftLen; j++) ref[j * S] = base[j * bs];
+  } else if (isp == 1) {                      /* rows: the row above is the previous sub-partition's last reconstructed row, replicated to the right */
+    for (int j = 0; j <= leftLen; j++) ref[j * S] = base[(oy + j) * bs];
+    for (int i = 1; i <= pw; i++) ref[i] = rec[(oy - 1) * w + (i - 1)];
+    for (int i = pw + 1; i <= topLen; i++) ref[i] = rec[(oy - 1) * w + pw - 1];
+    const int leftDecomp = a.x > 0 && e->um[0][((a.y + oy) >> 2) * e->uw + ((a.x - 1) >> 2)].valid;       /* cs.isDecomp */
+    if (!leftDecomp) for (int j = 0; j <= leftLen; j++) ref[j * S] = rec[(oy - 1) * w];
+  } else {                                    /* columns */
+    for (int i = 0; i <= topLen; i++) ref[i] = base[ox + i];
+    for (int j = 1; j <= ph; j++) ref[j * S] = rec[(j - 1) * w + ox - 1];
+    for (int j = ph + 1; j <= leftLen; j++) ref[j * S] = rec[(ph - 1) * w + ox - 1];
+    const int aboveDecomp = a.y > 0 && e->um[0][((a.y - 1) >> 2) * e->uw + ((a.x + ox) >> 2)].valid;
+    if (!aboveDecomp) for (int i = 0; i <= topLen; i++) ref[i] = rec[ox - 1];
+  }
+}
+typedef struct { uint64_t dist, bits; double cost; int tucbf, ntu, valid, first_cbf; } isp_res;
+/* IntraSearch::xIntraCodingLumaISP (EL/IntraSearch.cpp:3171-3280) with xIntraCodingTUBlock per sub-partition: prediction regions of at least 4 columns
+ * (JVET_O0106), DST-VII / DCT-II by size, dependent quantisation from the estimator's live contexts (the cbf context of ISP blocks follows the previous
+ * sub-partition's cbf; the last cbf is inferred after all-zero ones), early exits against bestCostSoFar.  given != NULL: the levels (CU tile) and cbfs are taken as
+ * coded and only the decoder half runs (DecCu::xIntraRecQT of an ISP CU, xReuseCachedResult).  rec / lev: CU tiles, stride w. */
+static void isp_code_cu(orc_enc *e, area_t a, int dir, int isp, double bestCostSoFar, const int16_t *given, int given_tucbf, int16_t *rec, int16_t *lev, isp_res *r)
+{
+  const int x = a.x, y = a.y, w = a.w, h = a.h, bd = e->cfg.bit_depth, hor = isp == 1, mx = (1 << bd) - 1;
+  const int psz = isp_split_dim(w, h, hor), tw = hor ? w : psz, th = hor ? psz : h, n = hor ? h / psz : w / psz;
+  const int predRegDiff = !hor && ((w == 8 && h > 4) || w == 4);         /* CU::isPredRegDiffFromTB */
+  const int qp = e->sl.qp + 6 * (bd - 8), st = e->stride[0];
+  static int16_t sub[(64 + 64 + 1) * (64 + 64 + 1)], tlev[64 * 16], tres[64 * 16];
+  build_refs(e, 0, x, y, w, h, 0, 0);
+  memset(r, 0, sizeof *r);
+  double cost = 0; int early = 0, tucbf = 0, ntu = 0;
+  for (int k = 0; k < n; k++) {
+    const int ox = hor ? 0 : k * tw, oy = hor ? k * th : 0;
+    if (!predRegDiff || (ox & 3) == 0) {
+      const int pw = predRegDiff ? (tw > 4 ? tw : 4) : tw;
+      isp_sub_refs(e, a, isp, ox, oy, pw, th, rec, sub);
+      orc_pred_intra_isp(sub, w + pw + 1, w, h, pw, th, dir, bd, e->pred + oy * w + ox, w);
+    }
+    const int16_t *org = e->org[0] + (y + oy) * st + x + ox;
+    const int lastInferred = k == n - 1 && !tucbf, prevCbf = k ? (tucbf >> (k - 1)) & 1 : 0;
+    int abs_sum;
+    if (!given) {
+      for (int j = 0; j < th; j++) for (int i = 0; i < tw; i++) tres[j * tw + i] = (int16_t) (org[j * st + i] - e->pred[(oy + j) * w + ox + i]);
+      orc_fwd_isp(tres, tw, tw, th, bd, e->coef);
+      abs_sum = orc_depquant(e->cabac.s0, e->cabac.s1, e->coef, tw, th, 0, lastInferred ? -1 : ORC_CTX_QtCbf[0] + 2 + prevCbf, bd, qp, e->sl.lambda, 0, 0, tlev);
+      e->cnt_rd++; e->cnt_rdpix += (uint64_t) tw * th;
+      if (k == n - 1 && !tucbf && abs_sum <= 0) { r->ntu = n; r->cost = ORC_MAX_DOUBLE; return; }       /* 2990-2996: ISP needs one coded sub-partition */
+    } else {
+      for (int j = 0; j < th; j++) for (int i = 0; i < tw; i++) tlev[j * tw + i] = given[(oy + j) * w + ox + i];
+      abs_sum = (given_tucbf >> k) & 1;
+    }
+    if (abs_sum > 0) { orc_dequant_dq(tlev, tw, th, bd, qp, e->coef); orc_inv_isp(e->coef, tw, th, bd, tres, tw); tucbf |= 1 << k; }
+    else memset(tres, 0, (size_t) tw * th * 2);
+    for (int j = 0; j < th; j++) for (int i = 0; i < tw; i++) {
+      const int v = e->pred[(oy + j) * w + ox + i] + tres[j * tw + i];
+      rec[(oy + j) * w + ox + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v);
+      lev[(oy + j) * w + ox + i] = tlev[j * tw + i];
+    }
+    const uint64_t d = orc_sse(org, st, rec + oy * w + ox, w, tw, th);
+    ntu = k + 1;
+    if (given) { r->dist += d; continue; }
+    uint64_t fb = 0;
+    if (rd_cost(e, r->bits, r->dist + d) > bestCostSoFar) early = 1;       /* 3206-3210: the rate is not even computed */
+    else {
+      e->cabac.bits = 0;                       /* xGetIntraFracBitsQT: the CU header with the first sub-partition, cbf unless inferred, coefficients */
+      if (k == 0) enc_intra_luma_pred_mode_isp(e, x, y, w, h, dir, 0, isp);
+      if (!lastInferred) orc_enc_bin(&e->cabac, abs_sum > 0, ORC_CTX_QtCbf[0] + 2 + prevCbf);
+      if (abs_sum > 0) orc_residual_coding_tu(&e->cabac, tlev, tw, th, 0, 0, 0, 0);
+      fb = e->cabac.bits;
+    }
+    cost += rd_cost(e, fb, d); r->dist += d; r->bits += fb;
+    if (k + 1 < n) {
+      if (cost > bestCostSoFar) { early = 1; break; }
+      const double thr = n == 2 ? 0.95 : k + 1 == 1 ? 0.83 : 0.91;
+      if (cost > bestCostSoFar * thr) { early = 1; break; }
+    }
+  }
+  r->ntu = ntu; r->tucbf = tucbf; r->first_cbf = tucbf & 1;
+  if (given) { r->valid = 1; return; }
+  if (early) { r->cost = ORC_MAX_DOUBLE; return; }
+  r->cost = rd_cost(e, r->bits, r->dist);
+  if (r->cost < bestCostSoFar) { r->valid = 1; r->first_cbf = tucbf != 0; }          /* 3257-3268: cbf at depth 0 of every TU = any sub-partition coded */
+  else r->cost = ORC_MAX_DOUBLE;
+}
+/* ISPTestedModesInfo + the candidate lists of the ISP tests (EL/IntraSearch.h:211-320) */
+typedef struct {
+  int num_total[2], n_tested[2], cand_idx[2], stop[2], tested[2][40], best_mode_so_far, best_split_so_far, n_orig;
+  double best_cost[2];
+  uint8_t has[ORC_NUM_LUMA_MODE][2]; int nparts[ORC_NUM_LUMA_MODE][2]; double rdcost[ORC_NUM_LUMA_MODE][2];
+  int list[40], nlist;                       /* m_ispCandListHor == m_ispCandListVer up to the split type */
+  int reg_n, reg_mode[40]; double reg_cost[40];      /* m_regIntraRDListWithCosts */
+  int had_n, had_mode[40];                   /* the regular SATD-stage list saved for ISP (m_ispCandListHor before the sort) */
+} isp_state;
+static void isp_set_mode_results(isp_state *s, int isp, int mode, int nCompleted, double rdCost, double currentBest)
+{
+  const int st = isp - 1, maxParts = s->num_total[st];
+  s->nparts[mode][st] = nCompleted; s->rdcost[mode][st] = nCompleted == maxParts ? rdCost : ORC_MAX_DOUBLE;
+  s->tested[st][s->n_tested[st]++] = mode; s->has[mode][st] = 1;
+  if (nCompleted == maxParts && rdCost < s->best_cost[st]) s->best_cost[st] = rdCost;
+  if (nCompleted == maxParts && rdCost < currentBest) { s->best_mode_so_far = mode; s->best_split_so_far = isp; }
+}
+static int isp_num_parts(const isp_state *s, int isp, int mode) { return s->has[mode][isp - 1] ? s->nparts[mode][isp - 1] : -1; }
+/* xSortISPCandList (4614-4717) */
+static void isp_sort_cand_list(isp_state *s, double bestCostSoFar, double bestNonISPCost)
+{
+  if (bestNonISPCost > bestCostSoFar * 1.4) { s->stop[0] = s->stop[1] = 1; return; }         /* ISPFast 1 */
+  uint8_t in[ORC_NUM_LUMA_MODE]; memset(in, 0, sizeof in);
+  /* std::sort of at most 16 entries by cost: libstdc++'s insertion sort, which keeps equal costs in their order */
+  for (int i = 1; i < s->reg_n; i++) {
+    const int m = s->reg_mode[i]; const double c = s->reg_cost[i]; int j = i - 1;
+    while (j >= 0 && c < s->reg_cost[j]) { s->reg_mode[j + 1] = s->reg_mode[j]; s->reg_cost[j + 1] = s->reg_cost[j]; j--; }
+    s->reg_mode[j + 1] = m; s->reg_cost[j + 1] = c;
+  }
+  int bestAngle = -1;
+  for (int i = 0; i < s->reg_n; i++) if (s->reg_mode[i] > ORC_DC) { bestAngle = s->reg_mode[i]; break; }
+  s->nlist = 0;
+  s->list[s->nlist++] = ORC_PLANAR; in[ORC_PLANAR] = 1;
+  if (bestAngle != -1) { s->list[s->nlist++] = bestAngle; in[bestAngle] = 1; }
+  int dc = 0;
+  for (int i = 0; i < s->reg_n; i++) {
+    const int m = s->reg_mode[i];
+    if (m != ORC_PLANAR && m != bestAngle) { if (m > ORC_DC) { s->list[s->nlist++] = m; in[m] = 1; } else if (m == ORC_DC) dc = 1; }
+  }
+  if (dc) { s->list[s->nlist++] = ORC_DC; in[ORC_DC] = 1; }
+  s->n_orig = s->nlist;
+  for (int k = 0, added = 0; k < s->had_n && added < 3; k++) if (!in[s->had_mode[k]]) { s->list[s->nlist++] = s->had_mode[k]; added++; }
+}
+static void isp_find_nearby(const isp_state *s, int mode, int isp, int window, int *left, int *right)          /* xFindAlreadyTestedNearbyIntraModes 4591-4612 */
+{
+  *left = *right = -1;
+  for (int k = 1; k <= window; k++) {
+    const int off = mode - 2 - k;
+    const int lm = off < 0 ? ORC_NUM_LUMA_MODE + off : mode - k;
+    const int rm = mode > ORC_DC ? ((mode - 2 + k) % 65) + 2 : ORC_PLANAR;
+    const int lf = lm != mode ? s->has[lm][isp - 1] : 0, rf = rm != mode ? s->has[rm][isp - 1] : 0;
+    if (lf || rf) { *left = lf ? lm : -1; *right = rf ? rm : -1; break; }
+  }
+}
+/* xGetNextISPMode (4467-4589): prev_isp = ispMod of the previous entry of the RD list.  Returns 1 with the next candidate, 0 when the slot stays unused */
+static int isp_next_mode(isp_state *s, int prev_isp, int w, int h, int *mode, int *isp_out)
+{
+  int nxt;
+  if (!s->stop[0] && !s->stop[1]) nxt = prev_isp == 1 ? 2 : 1;
+  else if (!s->stop[0]) nxt = 1;
+  else if (!s->stop[1]) nxt = 2;
+  else return 0;
+  const int st = nxt - 1, maxParts = s->num_total[st];
+  if (s->n_tested[st] >= 2) {
+    int mode1 = s->tested[st][0]; mode1 = mode1 == ORC_DC ? -1 : mode1;
+    const int n1 = mode1 != -1 ? isp_num_parts(s, nxt, mode1) : -1;
+    int mode2 = s->tested[st][1]; mode2 = mode2 == ORC_DC ? -1 : mode2;
+    const int n2 = mode2 != -1 ? isp_num_parts(s, nxt, mode2) : -1;
+    if (n1 != -1 && n2 != -1 && n1 < maxParts && n2 < maxParts) { s->stop[st] = 1; return 0; }
+    const int other = nxt == 1 ? 2 : 1;
+    const int nOther = mode2 != -1 ? isp_num_parts(s, other, mode2) : -1;
+    int stopThis = 0;
+    if (nOther != -1 && n2 != -1) {
+      if (nOther > n2) stopThis = 1;
+      else if (nOther == n2 && nOther == maxParts) {
+        const double cThis = s->has[mode2][st] && s->nparts[mode2][st] == maxParts ? s->rdcost[mode2][st] : -1;
+        const double cOther = s->has[mode2][other - 1] && s->nparts[mode2][other - 1] == maxParts ? s->rdcost[mode2][other - 1] : -1;
+        if (cThis == ORC_MAX_DOUBLE || cOther < cThis * 1.3) stopThis = 1;
+      }
+    }
+    if (stopThis) { s->stop[st] = 1; return 0; }
+  }
+  if (s->cand_idx[st] < s->nlist) {
+    const int cand = s->list[s->cand_idx[st]];
+    s->cand_idx[st]++;
+    if (s->cand_idx[st] > s->n_orig) { if (s->best_split_so_far != nxt || s->best_mode_so_far == ORC_PLANAR) return 0; }      /* extra modes only while ISP is winning */
+    int test = 1;
+    if (cand >= ORC_DC && maxParts > 2 && s->n_tested[st] >= 2) {
+      const int window = cand > ORC_DC ? 5 : 1, numSamples = w << ilog2(h), limit = numSamples >= 256 ? maxParts - 1 : 2;
+      int lm, rm; isp_find_nearby(s, cand, nxt, window, &lm, &rm);
+      const int nl = lm != -1 ? isp_num_parts(s, nxt, lm) : -1, nr = rm != -1 ? isp_num_parts(s, nxt, rm) : -1;
+      const int nref = nl > nr ? nl : nr;
+      if (nref > 0) test = nref > limit;
+    }
+    if (test) { *mode = cand; *isp_out = nxt; return 1; }
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * estIntraPredLumaQT (EL/IntraSearch.cpp:289-1380), P0 subset.  Leaves the winner's reco/levels in
  * e->best_rec[0]/best_lev[0] (stride w).  Returns dist; *dir,*mrl,*cbf the winner.
@@ -691,7 +902,10 @@ typedef struct {
   int lfnst_num, lfnst_size; minfo lfnst_list[80]; double lfnst_cost[80];
   int rd_num[3]; minfo rd_list[3][80]; double mode_cost[3][80], best_cost[3]; int best_valid[3];
 } luma_passes;
-static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, luma_passes *ps, int *valid, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts)
+/* bestCostSoFar: what xCheckRDCostIntra hands over (the node's best cost without split flags, capped by the child budget); *noIspCost: ComprCUCtx's
+ * bestCostMtsFirstPassNoIsp; *out_isp / *out_tucbf: cu.ispMode of the winner and the cbfs of its sub-partitions */
+static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, luma_passes *ps, int *valid, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts,
+                                    double bestCostSoFar, double *noIspCost, int *out_isp, int *out_tucbf)
 {
   const int x = a.x, y = a.y, w = a.w, h = a.h, bd = e->cfg.bit_depth;
   orc_cabac ctxStart; orc_ctx_copy(&ctxStart, &e->cabac);
@@ -714,6 +928,14 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, luma_passes *ps, int *
   const int firstLine = (y & 127) == 0;
   const int numRefPasses = (firstLine || !(e->cfg.tools & ORC_TOOL_MRL)) ? 1 : 3;
   int idxOf[80];                                     /* rdModeIdxList 1097-1122: place of a stage-B candidate in the list before the MIP re-ordering */
+  /* 355-384: ISP is tested in the pass without LFNST and MTS */
+  const int testISP = lfnstOn && !mtsFlag && !lfnstIdx && can_use_isp(e, w, h);
+  static isp_state isp;
+  if (testISP) {
+    memset(&isp, 0, sizeof isp);
+    isp.best_cost[0] = isp.best_cost[1] = ORC_MAX_DOUBLE; isp.best_mode_so_far = -1; isp.n_orig = -1;
+    isp.num_total[0] = h >> ilog2(isp_split_dim(w, h, 1)); isp.num_total[1] = w >> ilog2(isp_split_dim(w, h, 0));
+  }
   if (mtsUsage != 2) {
   if (testMip) numRd += imax(numRd, ilog2(imin(w, h)) - 1);
   const int numHad = testMip ? 6 : 3;
@@ -757,6 +979,7 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, luma_passes *ps, int *
         }
     }
   }
+  if (testISP) { isp.had_n = rdSize; for (int i = 0; i < rdSize; i++) isp.had_mode[i] = rdList[i].mode; }      /* 624-632: the regular list, before the MRL candidates */
   {
     unsigned mpm[6]; get_mpms(e, x, y, w, h, mpm);
     static const int MRL_IDX[3] = { 0, 1, 3 };
@@ -800,6 +1023,11 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, luma_passes *ps, int *
       for (int i = 0; i < numRd; i++) incl |= (rdList[i].mode == (int) mpm[j] && rdList[i].mrl == 0);
       if (!incl) { rdList[numRd] = (minfo) { (int) mpm[j], 0 }; rdCost[numRd] = 0; numRd++; }
     }
+    if (testISP) for (int j = 0; j < numCand; j++) {      /* 803-820: the MPMs join the list saved for ISP as well */
+      int incl = 0;
+      for (int i = 0; i < isp.had_n; i++) incl |= isp.had_mode[i] == (int) mpm[j];
+      if (!incl) isp.had_mode[isp.had_n++] = (int) mpm[j];
+    }
   }
   if (lfnstOn && mtsUsage == 1) { ps->rd_num[lfnstIdx] = numRd; memcpy(ps->rd_list[lfnstIdx], rdList, sizeof(minfo) * (size_t) numRd); }      /* 884-889 */
   } else {
@@ -826,7 +1054,9 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, luma_passes *ps, int *
   }
 
   /* stage B: full RD (1158-1358) */
-  double bestCost = ORC_MAX_DOUBLE; uint64_t bestDist = 0; int bestDir = 0, bestMrl = 0, bestCbf = 0, bestMts = 0, any = 0;
+  double bestCost = ORC_MAX_DOUBLE; uint64_t bestDist = 0; int bestDir = 0, bestMrl = 0, bestCbf = 0, bestMts = 0, any = 0, bestIsp = 0, bestTuCbf = 0;
+  double bestCurrentCost = bestCostSoFar;
+  if (!mtsFlag) *noIspCost = ORC_MAX_DOUBLE;                    /* 1150-1153 */
   for (int m = 0; m < numRd; m++) {
     const int dir = rdList[m].mode, mrl = rdList[m].mrl;
     orc_ctx_copy(&e->cabac, &ctxStart);
@@ -897,15 +1127,40 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, luma_passes *ps, int *
     }
     }
     any = 1;
+    if (testISP && !mrl) { isp.reg_mode[isp.reg_n] = dir; isp.reg_cost[isp.reg_n] = modeCost; isp.reg_n++; }      /* 1263-1268: regular, line 0, not MIP (mrl carries the MIP flag) */
     if (modeCost < bestCost) {
       bestCost = modeCost; bestDist = modeDist; bestDir = dir; bestMrl = mrl; bestCbf = modeCbf; bestMts = modeMts;
       memcpy(e->best_rec[0], e->tmp_rec[0], (size_t) w * h * 2); memcpy(e->best_lev[0], e->tmp_lev[0], (size_t) w * h * 2);
       if (lfnstOn && mtsUsage == 1) { ps->best_cost[lfnstIdx] = bestCost; ps->best_valid[lfnstIdx] = 1; }     /* 1283-1287 */
+      if (bestCost < bestCurrentCost) bestCurrentCost = bestCost;                                             /* 1319-1322 */
+      if (!mtsFlag) *noIspCost = bestCost;                                                                    /* 1323-1326 */
+    }
+  }
+  if (testISP) {
+    /* 1032-1039, 1181-1192: sixteen reserved places behind the regular and MIP candidates; each asks xGetNextISPMode for the next ISP candidate */
+    int prevIsp = 0;
+    for (int slot = 0; slot < 16; slot++) {
+      if (slot == 0) isp_sort_cand_list(&isp, bestCurrentCost, bestCost);
+      int cmode = 0, cisp = 0;
+      if (!isp_next_mode(&isp, prevIsp, w, h, &cmode, &cisp)) { prevIsp = 3; continue; }
+      prevIsp = cisp;
+      orc_ctx_copy(&e->cabac, &ctxStart);
+      isp_res r;
+      isp_code_cu(e, a, cmode, cisp, bestCurrentCost, 0, 0, e->tmp_rec[1], e->tmp_lev[1], &r);
+      isp_set_mode_results(&isp, cisp, cmode, r.ntu, r.first_cbf ? r.cost : ORC_MAX_DOUBLE, bestCost);      /* 1241-1245 */
+      if (!r.first_cbf) r.valid = 0;                                                                        /* 1270-1288 */
+      if (!r.valid) continue;
+      any = 1;
+      if (r.cost < bestCost) {
+        bestCost = r.cost; bestDist = r.dist; bestDir = cmode; bestMrl = 0; bestCbf = 1; bestMts = 0; bestIsp = cisp; bestTuCbf = r.tucbf;
+        memcpy(e->best_rec[0], e->tmp_rec[1], (size_t) w * h * 2); memcpy(e->best_lev[0], e->tmp_lev[1], (size_t) w * h * 2);
+        if (bestCost < bestCurrentCost) bestCurrentCost = bestCost;
+      }
     }
   }
   orc_ctx_copy(&e->cabac, &ctxStart);
   *valid = any;
-  *out_dir = bestDir; *out_mrl = bestMrl; *out_cbf = bestCbf; *out_mts = bestMts;
+  *out_dir = bestDir; *out_mrl = bestMrl; *out_cbf = bestCbf; *out_mts = bestMts; *out_isp = bestIsp; *out_tucbf = bestTuCbf;
   return bestDist;
 }
 #undef LFNST_SAVE
@@ -986,6 +1241,16 @@ int orc_test_update_cand_list(int n, const int *modes, const double *costs, int 
 void orc_test_shape_constants(int w, int h, int *out)
 {
   out[0] = orc_mip_num_modes(w, h); out[1] = w >= 16 && h >= 16; out[2] = ORC_MODE_NUM_FAST_2D[(ilog2(w) - 2) * 6 + (ilog2(h) - 2)]; out[3] = w <= 32 && h <= 32;
+}
+/* test entry point (tests/golden isp.npz): the block of one ISP sub-partition (tw x th) through the implicit transform, dependent quantisation with the given cbf
+ * context (-1: inferred), dequantisation and the inverse */
+int orc_trquant_isp(const uint16_t *s0, const uint16_t *s1, const int16_t *resi, int tw, int th, int bit_depth, int qp, double lambda, int cbf_ctx, int16_t *level, int16_t *resi_out)
+{
+  static int coef[64 * 64];
+  orc_fwd_isp(resi, tw, tw, th, bit_depth, coef);
+  const int a = orc_depquant(s0, s1, coef, tw, th, 0, cbf_ctx, bit_depth, qp, lambda, 0, 0, level);
+  if (a > 0) { orc_dequant_dq(level, tw, th, bit_depth, qp, coef); orc_inv_isp(coef, tw, th, bit_depth, resi_out, tw); }
+  return a;
 }
 /* test hook: selectICTCandidates + the three joint residuals (joint[m - 1], n samples each) for a residual pair under a sign flag */
 int orc_test_ict(int sign, const int16_t *cb, const int16_t *cr, int n, int *masks, int16_t *joint)
@@ -1206,6 +1471,7 @@ typedef struct {            /* ComprCUCtx (EL/EncModeCtrl.h:182-249), intra-rele
   int did_horz, did_vert, did_quad, do_trih, do_triv, qt_before_bt, max_qt_sub_depth;
   cs_sum *best;             /* bestCS (NULL until a mode result was accepted) */
   int reusing, d;           /* IS_REUSING_CU; recursion level (index of the node's store) */
+  double best_cost_wo_split, no_isp_cost; int skip_second_mts;     /* bestCostWithoutSplitFlags, bestCostMtsFirstPassNoIsp, skipSecondMTSPass (EL/EncModeCtrl.h:205-247) */
 } cu_ctx;
 
 /* ---- BestEncInfoCache (EL/EncModeCtrl.cpp:663-1110), REUSE_CU_RESULTS ---- */
@@ -1236,7 +1502,7 @@ static void cache_set_from_cs(orc_enc *e, const partitioner *P, int d)
   const area_t a = P->cur; const int ch = P->ch;
   cache_ent *c = cache_entry(e, a);
   const unit_t *u = &e->store[d].units[0];
-  c->valid = 1; c->ch = (uint8_t) ch; c->dir = u->dir; c->mrl = u->mrl; c->cbf = u->cbf; c->depth = u->depth; c->mts = u->mts; c->lfnst = u->lfnst; c->jccr = u->jccr; c->ss = u->split_series;
+  c->valid = 1; c->ch = (uint8_t) ch; c->dir = u->dir; c->mrl = u->mrl; c->cbf = u->cbf; c->depth = u->depth; c->mts = u->mts; c->lfnst = u->lfnst; c->jccr = u->jccr; c->isp = u->isp; c->tucbf = u->tucbf; c->ss = u->split_series;
   if (!c->lev) c->lev = (int16_t *) malloc((size_t) a.w * a.h * 2);
   if (!ch) memcpy(c->lev, e->store[d].lev[0], (size_t) a.w * a.h * 2);
   else { const size_t n = (size_t) (a.w >> 1) * (a.h >> 1); memcpy(c->lev, e->store[d].lev[1], n * 2); memcpy(c->lev + n, e->store[d].lev[2], n * 2); }
@@ -1310,7 +1576,7 @@ static int next_mode(orc_enc *e, partitioner *P, cu_ctx *C)
 static void init_cu_level(orc_enc *e, partitioner *P, cu_ctx *C, int d)
 {
   memset(C, 0, sizeof *C);
-  C->d = d;
+  C->d = d; C->best_cost_wo_split = ORC_MAX_DOUBLE; C->no_isp_cost = ORC_MAX_DOUBLE;
   const int ch = P->ch, sh = ch ? 1 : 0;
   C->min_depth = 0; C->max_depth = 7 - ilog2(e->cfg.min_qt[ch]);     /* plain QTBTPartitioner: no adaptive depth (EL/EncCu.cpp:472) */
   const area_t a = P->cur;
@@ -1413,12 +1679,16 @@ static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int
   return dd;
 }
 /* xReuseCachedResult (EL/EncCu.cpp:5665-5771): cached mode + levels re-reconstructed against the current neighbourhood */
-static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts, int *out_lfnst, int *out_jccr)
+static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *out_mrl, int *out_cbf, int *out_mts, int *out_lfnst, int *out_jccr, int *out_isp, int *out_tucbf)
 {
   const cache_ent *c = cache_entry(e, a);
   uint64_t dist = 0;
   e->cnt_reuse++;
-  if (!ch) {
+  if (!ch && c->isp) {                               /* an ISP CU: every sub-partition predicted from the reconstruction of the one before */
+    isp_res r;
+    isp_code_cu(e, a, c->dir, c->isp, 0, c->lev, c->tucbf, e->best_rec[0], e->best_lev[0], &r);
+    dist = r.dist;
+  } else if (!ch) {
     pred_luma_cand(e, a.x, a.y, a.w, a.h, c->dir, c->mrl);
     dist = recon_from_levels(e, 0, a.x, a.y, a.w, a.h, c->lev, c->cbf & 1, c->mts, c->lfnst, (c->mrl & MIP_FLAG) ? ORC_PLANAR : c->dir, e->best_rec[0]);
     memcpy(e->best_lev[0], c->lev, (size_t) a.w * a.h * 2);
@@ -1456,7 +1726,7 @@ static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *ou
       memcpy(e->best_lev[k - 1], c->lev + (size_t) (k - 1) * cw * chh, (size_t) cw * chh * 2);
     }
   }
-  *out_dir = c->dir; *out_mrl = c->mrl; *out_cbf = c->cbf; *out_mts = c->mts; *out_lfnst = c->lfnst; *out_jccr = c->jccr;
+  *out_dir = c->dir; *out_mrl = c->mrl; *out_cbf = c->cbf; *out_mts = c->mts; *out_lfnst = c->lfnst; *out_jccr = c->jccr; *out_isp = c->isp; *out_tucbf = c->tucbf;
   return dist;
 }
 
@@ -1465,8 +1735,26 @@ static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *ou
  * (not a MIP CU below 16x16, chroma blocks of at least 4x4, at most 64x64 luma), some block's last position is not DC (lfnstLastScanPos 3844-3850),
  * no block has a coefficient beyond the LFNST region (violatesLfnstConstrained 3837-3842) and the luma transform is DCT-II.
  * lev0 / lev1: luma levels, or Cb / Cr levels (stride = block width).  *lfnst_last receives cuCtx.lfnstLastScanPos. */
+static void enc_cu_syntax_isp(orc_enc *e, int ch, area_t a, int dir, int mrl, int cbf, int mts, int lfnst, int jccr, int lm_ok, const int16_t *lev0, const int16_t *lev1, int *lfnst_last, int isp, int tucbf);
 static void enc_cu_syntax(orc_enc *e, int ch, area_t a, int dir, int mrl, int cbf, int mts, int lfnst, int jccr, int lm_ok, const int16_t *lev0, const int16_t *lev1, int *lfnst_last)
+{ enc_cu_syntax_isp(e, ch, a, dir, mrl, cbf, mts, lfnst, jccr, lm_ok, lev0, lev1, lfnst_last, 0, 0); }
+/* isp / tucbf: cu.ispMode and the cbf of each sub-partition: transform_tree splits the CU (EL/CABACWriter.cpp:3311-3330), transform_unit codes each luma cbf with the
+ * previous sub-partition's cbf as context and infers the last one after all-zero ones (3574-3600); residual_lfnst_mode is absent for ISP CUs (3994) */
+static void enc_cu_syntax_isp(orc_enc *e, int ch, area_t a, int dir, int mrl, int cbf, int mts, int lfnst, int jccr, int lm_ok, const int16_t *lev0, const int16_t *lev1, int *lfnst_last, int isp, int tucbf)
 {
+  if (!ch && isp) {
+    const int hor = isp == 1, psz = isp_split_dim(a.w, a.h, hor), tw = hor ? a.w : psz, th = hor ? psz : a.h, n = hor ? a.h / psz : a.w / psz;
+    static int16_t t[64 * 16];
+    enc_intra_luma_pred_mode_isp(e, a.x, a.y, a.w, a.h, dir, 0, isp);
+    for (int k = 0, sofar = 0; k < n; k++) {
+      const int ox = hor ? 0 : k * tw, oy = hor ? k * th : 0, c = (tucbf >> k) & 1;
+      if (!(k == n - 1 && !sofar)) orc_enc_bin(&e->cabac, (unsigned) c, ORC_CTX_QtCbf[0] + 2 + (k ? (tucbf >> (k - 1)) & 1 : 0));
+      if (c) { for (int j = 0; j < th; j++) for (int i = 0; i < tw; i++) t[j * tw + i] = lev0[(oy + j) * a.w + ox + i]; orc_residual_coding_tu(&e->cabac, t, tw, th, 0, 0, 0, 0); }
+      sofar |= c;
+    }
+    if (lfnst_last) *lfnst_last = 0;
+    return;
+  }
   int lastPos = 0, violates = 0;
   const int W = a.w >> (ch ? 1 : 0), H = a.h >> (ch ? 1 : 0);
   const int maxPos = ((W == 4 && H == 4) || (W == 8 && H == 8)) ? 7 : 15;
@@ -1489,7 +1777,7 @@ static void enc_cu_syntax(orc_enc *e, int ch, area_t a, int dir, int mrl, int cb
   if (lfnst) orc_enc_bins_ep(&e->cabac, (uint32_t) (lfnst - 1), 1);
 }
 
-static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs_sum *best, orc_cabac *ctxStart, orc_cabac *ctxBest, int reuse)
+static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs_sum *best, orc_cabac *ctxStart, orc_cabac *ctxBest, int reuse, double maxCostAllowed)
 {
   const area_t a = P->cur; const int ch = P->ch, sh = ch ? 1 : 0;
   unit_t cu; memset(&cu, 0, sizeof cu);
@@ -1508,23 +1796,25 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
   static luma_passes ps; memset(ps.best_valid, 0, sizeof ps.best_valid);                                  /* invalidateBestModeCost 2451 */
   for (int trGrp = 0; trGrp < grpNumMax; trGrp++) {
     const int startMtsFlag = trGrp > 0, endMtsFlag = lfnstOn ? considerMts : 0;
-    if ((trGrp == 0 || considerMts) && trGrpCheck[trGrp]) {
+    if ((trGrp == 0 || (!C->skip_second_mts && considerMts)) && trGrpCheck[trGrp]) {
       for (int lfnstIdx = startLfnstIdx; lfnstIdx <= endLfnstIdx; lfnstIdx++) {
         for (int mtsFlag = startMtsFlag; mtsFlag <= endMtsFlag; mtsFlag++) {
           if (mtsFlag > 0 && lfnstIdx > 0) continue;                                                      /* JVET_O0368 2463-2466 */
           cs_sum t; memset(&t, 0, sizeof t);
-          int dir = 0, mrl = 0, cbf = 0, mts = 0, lfnst = lfnstIdx, valid = 1, jccr = 0;
-          if (reuse) t.dist = reuse_cached(e, a, ch, &dir, &mrl, &cbf, &mts, &lfnst, &jccr);
+          int dir = 0, mrl = 0, cbf = 0, mts = 0, lfnst = lfnstIdx, valid = 1, jccr = 0, isp = 0, tucbf = 0;
+          if (reuse) t.dist = reuse_cached(e, a, ch, &dir, &mrl, &cbf, &mts, &lfnst, &jccr, &isp, &tucbf);
           else if (!ch) {
             ps.lfnst = lfnstIdx; ps.mts_flag = mtsFlag; ps.tr_grp = trGrp;
-            t.dist = est_intra_pred_luma(e, a, &ps, &valid, &dir, &mrl, &cbf, &mts); cbf = cbf ? 1 : 0;
+            /* 2503-2516: what ISP measures itself against: the node's best cost so far without split flags, capped by the budget the parent's split loop left */
+            const double bestCostSoFar = maxCostAllowed < C->best_cost_wo_split ? maxCostAllowed : C->best_cost_wo_split;
+            t.dist = est_intra_pred_luma(e, a, &ps, &valid, &dir, &mrl, &cbf, &mts, bestCostSoFar, &C->no_isp_cost, &isp, &tucbf); cbf = cbf ? 1 : 0;
             if (lfnstOn && !valid) continue;                                                              /* 2529-2532 */
           } else t.dist = est_intra_pred_chroma(e, a, lm_ok, lfnstIdx, &dir, &cbf, &jccr);
-          cu.dir = (uint8_t) dir; cu.mrl = (uint8_t) mrl; cu.cbf = (uint8_t) cbf; cu.mts = (uint8_t) mts; cu.lfnst = (uint8_t) lfnst; cu.jccr = (uint8_t) jccr;
+          cu.dir = (uint8_t) dir; cu.mrl = (uint8_t) mrl; cu.cbf = (uint8_t) cbf; cu.mts = (uint8_t) mts; cu.lfnst = (uint8_t) lfnst; cu.jccr = (uint8_t) jccr; cu.isp = (uint8_t) isp; cu.tucbf = (uint8_t) tucbf;
           /* CU-level rate from the node's start contexts (2593-2620) */
           e->cabac.bits = 0;
           int lfnstLast = 0;
-          enc_cu_syntax(e, ch, a, dir, mrl, cbf, mts, lfnst, jccr, lm_ok, e->best_lev[0], e->best_lev[1], &lfnstLast);
+          enc_cu_syntax_isp(e, ch, a, dir, mrl, cbf, mts, lfnst, jccr, lm_ok, e->best_lev[0], e->best_lev[1], &lfnstLast, isp, tucbf);
           if (ch && reuse && !e->ctu_is_last) {
             /* the reuse path prices the CU with CABACWriter::coding_unit, whose end_of_ctu (EL/CABACWriter.cpp:2118-2141) adds the
              * terminating bin after the last chroma CU of a CTU that does not end the slice */
@@ -1533,6 +1823,7 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
           }
           t.bits = e->cabac.bits;
           t.cost = rd_cost(e, t.bits, t.dist);
+          const double costWithoutSplitFlags = t.cost;                                                     /* 2622-2629: also bestIspCost of an ISP winner */
           /* xEncodeDontSplit (5649-5662) */
           e->cabac.bits = 0;
           enc_split_cu_mode(e, P, SPLIT_NONE);
@@ -1541,6 +1832,8 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
           /* 2633-2645: an LFNST index that cannot be signalled (no block with a last position beyond DC) while there are coefficients */
           if (!reuse && lfnstIdx && !lfnstLast && cbf) t.cost = ORC_MAX_DOUBLE;
           if (mtsFlag == 0 && lfnstIdx == 0) dct2Cost = t.cost;
+          if (!reuse && t.cost < best->cost) C->best_cost_wo_split = costWithoutSplitFlags;                 /* 2657-2660 */
+          if (!reuse && !isp) C->no_isp_cost = t.cost;                                                     /* useModeResult(ETM_INTRA), EL/EncModeCtrl.cpp:2120-2123 */
           /* checkSkipOtherLfnst (EL/EncModeCtrl.cpp:2070-2087): the intra passes are the first modes of a node, so its condition always holds */
           if (lfnstOn) skipOtherLfnst = !cbf;
           t.n_cu = 1; t.is_split = 0;
@@ -1555,6 +1848,12 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
             if (lfnstOn && !ch && mts == 1 && ilog2(a.w) + ilog2(a.h) >= 6) endLfnstIdx = 0;                                 /* 2702-2712: a transform-skip winner of at least 64 samples ends the LFNST passes */
           }
           orc_ctx_copy(&e->cabac, ctxStart);
+          /* 2714-2741 (ISPFast 1): an ISP winner of the first pass that beats the best regular mode by a margin ends the LFNST / MTS passes of this CU */
+          if (lfnstOn && (considerMts > 0 || endLfnstIdx > 0) && isp && !mtsFlag && !lfnstIdx) {
+            const double threshold = 1.4, lfnstThreshold = 1.01 * threshold;
+            if (C->no_isp_cost > costWithoutSplitFlags * lfnstThreshold) endLfnstIdx = lfnstIdx;
+            if (C->no_isp_cost > costWithoutSplitFlags * threshold) { C->skip_second_mts = 1; break; }
+          }
         }
         if (skipOtherLfnst) { startLfnstIdx = lfnstIdx; endLfnstIdx = lfnstIdx; break; }               /* 2754-2759 */
       }
@@ -1634,8 +1933,8 @@ static void compress_cu(orc_enc *e, partitioner *P, int d, double maxCostAllowed
   do {
     const int mode = C.modes[C.nmodes - 1];
     const cs_sum *before = C.best; const double costBefore = best->cost;
-    if (mode == ETM_INTRA) check_rd_cost_intra(e, P, d, &C, best, &ctxStart, &ctxBest, 0);
-    else if (mode == ETM_RECO_CACHED) check_rd_cost_intra(e, P, d, &C, best, &ctxStart, &ctxBest, 1);
+    if (mode == ETM_INTRA) check_rd_cost_intra(e, P, d, &C, best, &ctxStart, &ctxBest, 0, maxCostAllowed);
+    else if (mode == ETM_RECO_CACHED) check_rd_cost_intra(e, P, d, &C, best, &ctxStart, &ctxBest, 1, maxCostAllowed);
     else check_mode_split(e, P, d, &C, mode, maxCostAllowed, best, &ctxStart, &ctxBest);
     lastWasBest = (C.best != before) || (best->cost != costBefore);
   } while (next_mode(e, P, &C));
@@ -1667,7 +1966,7 @@ static void walk_tree(orc_enc *e, partitioner *P)
   int16_t *lv = e->tmp_lev[0], *lv1 = e->tmp_lev[1];
   if (!ch) {
     if (u->cbf & 1) for (int y = 0; y < H; y++) memcpy(lv + y * W, e->lev[0] + (a.y + y) * e->stride[0] + a.x, (size_t) W * 2);
-    enc_cu_syntax(e, 0, a, u->dir, u->mrl, u->cbf, u->mts, u->lfnst, 0, 0, lv, lv1, 0);
+    enc_cu_syntax_isp(e, 0, a, u->dir, u->mrl, u->cbf, u->mts, u->lfnst, 0, 0, lv, lv1, 0, u->isp, u->tucbf);
   } else {
     for (int c = 1; c <= 2; c++) if (u->cbf & (1 << c))
       for (int y = 0; y < H; y++) memcpy((c == 1 ? lv : lv1) + y * W, e->lev[c] + ((a.y >> 1) + y) * e->stride[c] + (a.x >> 1), (size_t) W * 2);
@@ -1738,7 +2037,7 @@ int orc_compress_tiles(orc_enc *e, int tile_first, int tile_count, orc_ctu_resul
           orc_cu *o = &cus[n];
           o->x = u->x; o->y = u->y; o->w = (int16_t) (1 << u->lw); o->h = (int16_t) (1 << u->lh); o->ch_type = (uint8_t) ch;
           o->qt_depth = u->qt_depth; o->bt_depth = u->bt_depth; o->mt_depth = u->mt_depth; o->depth = u->depth;
-          o->intra_dir = u->dir; o->mrl_idx = ch ? u->mrl : (u->mrl & ~MIP_FLAG); o->mip_flag = !ch && (u->mrl & MIP_FLAG) ? 1 : 0; o->cbf = u->cbf; o->mts_idx = u->mts; o->lfnst_idx = u->lfnst; o->joint_cb_cr = u->jccr; o->split_series = u->split_series;
+          o->intra_dir = u->dir; o->mrl_idx = ch ? u->mrl : (u->mrl & ~MIP_FLAG); o->mip_flag = !ch && (u->mrl & MIP_FLAG) ? 1 : 0; o->cbf = u->cbf; o->mts_idx = u->mts; o->lfnst_idx = u->lfnst; o->joint_cb_cr = u->jccr; o->isp_mode = ch ? 0 : u->isp; o->tu_cbf = ch ? 0 : u->tucbf; o->split_series = u->split_series;
         }
         n++;
       }

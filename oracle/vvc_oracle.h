@@ -76,6 +76,8 @@ typedef struct {
   uint8_t  mip_flag;       /* luma CU: cu.mipFlag; intra_dir is then the MIP mode */
   uint8_t  lfnst_idx;      /* cu.lfnstIdx (0..2) */
   uint8_t  joint_cb_cr;    /* chroma CU: tu.jointCbCr (0 separate, 1..3 = the cbf mask of the joint residual) */
+  uint8_t  isp_mode;       /* luma CU: cu.ispMode (0 none, 1 horizontal, 2 vertical sub-partitions) */
+  uint8_t  tu_cbf;         /* luma CU with ISP: cbf of each sub-partition, bit k = TU k (cbf bit 0 = any) */
   uint64_t split_series;
 } orc_cu;
 

@@ -670,6 +670,51 @@ def gen_ts():
     print("ts cases", len(meta), "non-zero", int((m[:, 7] > 0).sum()), "kept by the pruning", int(m[:, 5].sum()), "max abs level", int(np.abs(np.concatenate(lev_all)).max()))
 
 
+def gen_isp():
+    """The transform path of ISP sub-partitions through the reference: TrQuant::transformNxN / invTransformNxN of a TU of a CU with cu.ispMode set -- implicit DST-VII for
+    sides of 4..16 (getTrTypes), the 1-D transforms of Nx1 / 1xN blocks, DepQuant on 1xN / 2xN / Nx1 / Nx2 blocks with the ISP cbf contexts (previous sub-partition
+    coded or not, inferred last cbf) -- for every CU shape that can use ISP, both split directions, first / middle / last sub-partitions."""
+    R.ref_env_trquant_isp.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_double, C.c_int, C.c_int] + [C.c_void_p] * 8
+    R.ref_ctx_init.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 3
+    g = np.random.default_rng(20267)
+    nctx = R.ref_ctx_count()
+    meta, lam_all, ctx_all, resi_all, lev_all, out_all = [], [], [], [], [], []
+    shapes = [(w, h) for w in (4, 8, 16, 32, 64) for h in (4, 8, 16, 32, 64) if w * h > 16 and not (max(w, h) == 64 and min(w, h) < 64)]
+    for gi, (bd, qp) in enumerate(((8, 22), (8, 32), (8, 37), (10, 27))):
+        env = R.ref_env_create(192, 192, bd)
+        s0 = np.zeros(nctx, np.uint16); s1 = np.zeros(nctx, np.uint16); rate = np.zeros(nctx, np.uint8)
+        R.ref_ctx_init(qp, 2, P(s0), P(s1), P(rate))
+        for i in range(nctx):
+            n = int(g.integers(0, 24)); bins = (g.random(n) < g.random()).astype(np.uint8)
+            a = s0[i:i + 1].copy(); b = s1[i:i + 1].copy()
+            if n: R.ref_ctx_code_bins(P(a), P(b), int(rate[i]), P(bins), n)
+            s0[i] = a[0]; s1[i] = b[0]
+        ctx_all.append(np.stack([s0, s1]))
+        lam0 = 0.57 * 2.0 ** ((qp + 6 * (bd - 8) - 12) / 3.0) * 2.0 ** (0.25 / 3.0)
+        for (w, h) in shapes:
+            for isp in (1, 2):
+                split = (h if isp == 1 else w); non = (w if isp == 1 else h)
+                fac = (16 >> int(np.log2(non))) if non < 16 else 1
+                psz = max(split >> 2, fac); n = split // psz
+                tw, th = (w, psz) if isp == 1 else (psz, h)
+                for k, prev, anyb in ((0, 0, 0), (n - 1, 0, 0), (n - 1, 1, 1), (max(n - 2, 1) if n > 2 else n - 1, 1, 1), (n - 1, 0, 1)):
+                    if k == 1 and not prev and anyb: continue      # with one sub-partition before, "some earlier one coded" is the previous one
+                    R.ref_env_reset(env)
+                    amp = (1 << bd) // 4
+                    resi = g.normal(0, amp / float(g.choice([3, 10, 40])), (th, tw)) + (amp / 4) * np.sin(np.arange(tw)[None, :] / 3.0 + np.arange(th)[:, None] / 5.0)
+                    resi = np.ascontiguousarray(np.clip(resi.round(), -(1 << bd) + 1, (1 << bd) - 1).astype(np.int16))
+                    lev = np.zeros(tw * th, np.int32); ro = np.zeros(tw * th, np.int16); a = C.c_int(); tw_ = C.c_int(); th_ = C.c_int()
+                    assert R.ref_env_trquant_isp(env, 0, 0, w, h, isp, k, qp, lam0, prev, anyb, P(s0), P(s1), P(resi), P(lev), P(ro), C.byref(a), C.byref(tw_), C.byref(th_)) == 0
+                    assert (tw_.value, th_.value) == (tw, th)
+                    inferred = int(k == n - 1 and not anyb and not prev)
+                    meta.append((bd, qp, w, h, isp, k, n, tw, th, prev, inferred, a.value, gi)); lam_all.append(lam0)
+                    resi_all.append(resi.ravel()); lev_all.append(lev.astype(np.int16)); out_all.append(ro)
+    np.savez_compressed(os.path.join(HERE, "isp.npz"), meta=np.array(meta, np.int32), lam=np.array(lam_all, np.float64), ctx=np.stack(ctx_all),
+                        resi=np.concatenate(resi_all), lev=np.concatenate(lev_all), resi_out=np.concatenate(out_all))
+    m = np.array(meta)
+    print("isp cases", len(meta), "non-zero", int((m[:, 11] > 0).sum()), "TU shapes", sorted(set((int(r[7]), int(r[8])) for r in m)))
+
+
 def gen_decision_helpers():
     """CommonLib pieces the decision level calls: updateCandList (CL/UnitTools.h:261-306) on random insertion sequences incl. ties and lists shorter / longer than
     fastNum, and the per-shape constants of the luma search (getNumModesMip, allowLfnstWithMip, g_aucIntraModeNumFast_UseMPM_2D, the MTS size limit)."""
@@ -734,6 +779,18 @@ def gen_bitstream_ts():
     np.savez_compressed(os.path.join(HERE, "bitstream_ts.npz"), **out)
 
 
+def gen_bitstream_isp():
+    """Decoder round trip with ISP on (tools 0xb5f, and 0xb7f = the reference cfg's whole tool set but LMCS): isp_mode, the cbf chain of the sub-partitions with its
+    inferred last flag, residual_coding of 1xN / 2xN / Nx1 / Nx2 luma blocks are parsed back by the reference's CABACReader, and DecCu predicts every sub-partition
+    from the reconstruction of the one before (4-column prediction regions for 1xN / 2xN), with DST-VII / DCT-II by size: every ispMode, cbf, level and reconstructed
+    sample must equal the oracle's."""
+    R.ref_env_set_tools.argtypes = [C.c_void_p, C.c_uint]
+    out = _pictures(((128, 128, 32, 1, 1, 8, 7), (200, 136, 27, 1, 1, 8, 1234), (256, 128, 37, 2, 1, 8, 5), (128, 128, 22, 1, 1, 10, 3)), 0xb5f, 0.5, oriented=30.0, screen=0.5)
+    np.savez_compressed(os.path.join(HERE, "bitstream_isp.npz"), **out)
+    out = _pictures(((128, 128, 32, 1, 1, 8, 7), (136, 72, 24, 1, 1, 8, 12)), 0xb7f, 0.5, oriented=30.0, screen=0.3)
+    np.savez_compressed(os.path.join(HERE, "bitstream_full.npz"), **out)
+
+
 def _pictures(cases, tools, texture, oriented=0.0, screen=0.0):
     import importlib, sys
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -750,7 +807,7 @@ def _pictures(cases, tools, texture, oriented=0.0, screen=0.0):
         planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture, oriented=oriented, screen=screen)
         payload, sizes, cus, lev = O.write_frame(planes, W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools)
         env = R.ref_env_create(W, H, bd); R.ref_env_set_tiles(env, tc, tr)
-        if tools & 0x37a:
+        if tools & 0x37e:
             R.ref_env_set_tools(env, tools)
         if tools & 0x200:
             cb, cr = planes[1].astype(np.int16), planes[2].astype(np.int16)
@@ -769,7 +826,7 @@ def _pictures(cases, tools, texture, oriented=0.0, screen=0.0):
         nd = R.ref_dec_get_cus(env, P(rows), P(ss), len(rows)); assert nd == len(cus)
         dec = {(int(r[0]), int(r[1]), int(r[2])): (tuple(int(v) for v in r[3:]), int(s)) for r, s in zip(rows[:nd], ss[:nd])}
         for c in cus:
-            exp = ((int(c["w"]), int(c["h"]), int(c["qt_depth"]), int(c["bt_depth"]), int(c["mt_depth"]), int(c["depth"]), int(c["intra_dir"]), int(c["mrl_idx"]) | (int(c["mip_flag"]) << 7), int(c["cbf"]) | ((int(c["mts_idx"]) if c["cbf"] & 1 else 0) << 8) | (int(c["lfnst_idx"]) << 16) | (int(c["joint_cb_cr"]) << 20)), int(c["split_series"]))
+            exp = ((int(c["w"]), int(c["h"]), int(c["qt_depth"]), int(c["bt_depth"]), int(c["mt_depth"]), int(c["depth"]), int(c["intra_dir"]), int(c["mrl_idx"]) | (int(c["mip_flag"]) << 7), int(c["cbf"]) | ((int(c["mts_idx"]) if c["cbf"] & 1 else 0) << 8) | ((int(c["lfnst_idx"]) if c["cbf"] else 0) << 16) | (int(c["joint_cb_cr"]) << 20) | (int(c["isp_mode"]) << 24) | (int(c["tu_cbf"]) << 26)), int(c["split_series"]))
             assert dec[(int(c["ch_type"]), int(c["x"]), int(c["y"]))] == exp, ("decoded CU differs", (int(c["ch_type"]), int(c["x"]), int(c["y"])), dec[(int(c["ch_type"]), int(c["x"]), int(c["y"]))], exp)
         for comp in range(3):
             d = np.zeros_like(lev[comp]); R.ref_dec_get_levels(env, comp, P(d), d.shape[1])
@@ -784,7 +841,10 @@ def _pictures(cases, tools, texture, oriented=0.0, screen=0.0):
         pic_meta.append((W, H, qp, tc, tr, bd, seed, len(payload))); pic_bytes.append(payload); pic_sizes.append(np.pad(sizes, (0, 16 - len(sizes))))
         nlm = int(sum(1 for c in cus if c["ch_type"] == 1 and 67 <= c["intra_dir"] <= 69))
         nmts = int(sum(1 for c in cus if c["ch_type"] == 0 and c["mts_idx"] > 1))
-        print("picture", W, H, qp, tc, tr, bd, "payload", len(payload), "bytes, decoded by the reference:", nd, "CUs,", nlm, "with an LM chroma mode,", nmts, "with an MTS transform,", int(np.count_nonzero(cus["mip_flag"])), "MIP,", int(np.count_nonzero(cus["lfnst_idx"])), "LFNST,", int(np.count_nonzero(cus["joint_cb_cr"])), "JointCbCr,", int(sum(1 for c in cus if c["ch_type"] == 0 and c["mts_idx"] == 1)), "transform skip")
+        print("picture", W, H, qp, tc, tr, bd, "payload", len(payload), "bytes, decoded by the reference:", nd, "CUs,", nlm, "with an LM chroma mode,", nmts, "with an MTS transform,", int(np.count_nonzero(cus["mip_flag"])), "MIP,", int(np.count_nonzero(cus["lfnst_idx"])), "LFNST,", int(np.count_nonzero(cus["joint_cb_cr"])), "JointCbCr,", int(sum(1 for c in cus if c["ch_type"] == 0 and c["mts_idx"] == 1)), "transform skip,", int(np.count_nonzero(cus["isp_mode"])), "ISP")
+        if np.count_nonzero(cus["isp_mode"]):
+            from collections import Counter
+            print("   ISP CUs by (w, h, split):", sorted(Counter((int(c["w"]), int(c["h"]), int(c["isp_mode"])) for c in cus if c["isp_mode"]).items()))
     out["pic_meta"] = np.array(pic_meta, np.int32); out["pic_bytes"] = np.concatenate(pic_bytes); out["pic_sizes"] = np.stack(pic_sizes).astype(np.int32)
     out["tools"] = np.array([tools], np.int32); out["chroma_texture"] = np.array([texture], np.float64)
     if oriented:
@@ -828,11 +888,15 @@ if __name__ == "__main__":
         gen_bitstream_lfnst(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lfnst":
         gen_lfnst(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "isp":
+        gen_isp(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bitstream_isp":
+        gen_bitstream_isp(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream_ts":
         gen_bitstream_ts(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ts":
         gen_ts(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict(); gen_decision_helpers(); gen_ts(); gen_bitstream_ts()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict(); gen_decision_helpers(); gen_ts(); gen_bitstream_ts(); gen_isp(); gen_bitstream_isp()
     print("done")

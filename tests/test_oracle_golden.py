@@ -505,3 +505,48 @@ def test_slice_data_payload_with_transform_skip():
     g = np.load(os.path.join(G, "bitstream_ts.npz"))
     assert int(g["tools"][0]) & 0x20 and float(g["screen"][0]) > 0
     _check_pictures(g, importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd"))
+
+
+def _isp_cases():
+    g = np.load(os.path.join(G, "isp.npz"))
+    off = 0
+    for k, row in enumerate(g["meta"]):
+        bd, qp, w, h, isp, tu, n, tw, th, prev, inferred, asum, gi = (int(v) for v in row)
+        m = tw * th
+        yield dict(bd=bd, qp=qp, w=w, h=h, isp=isp, tu=tu, n=n, tw=tw, th=th, prev=prev, inferred=inferred, asum=asum, lam=float(g["lam"][k]), ctx=g["ctx"][gi],
+                   resi=np.ascontiguousarray(g["resi"][off:off + m]), lev=g["lev"][off:off + m], out=g["resi_out"][off:off + m])
+        off += m
+
+
+def test_isp_sub_partition_transform_path_against_the_reference():
+    """ISP sub-partitions (CL/TrQuant.cpp getTrTypes 752-780, xT / xIT incl. the 1-D forms, DepQuant with the ISP cbf contexts): levels, absSum and the reconstructed
+    residual of 624 blocks -- every sub-partition shape from 1x16 / 16x1 to 16x64 / 64x16, first / middle / last position, inferred last cbf -- == the reference's
+    TrQuant::transformNxN / invTransformNxN on a TU of a CU with cu.ispMode set."""
+    L = O.lib()
+    L.orc_trquant_isp.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_double, C.c_int] + [C.c_void_p] * 2
+    nz = 0
+    for c in _isp_cases():
+        n = c["tw"] * c["th"]
+        lev = np.zeros(n, np.int16); out = np.zeros(n, np.int16)
+        s0 = np.ascontiguousarray(c["ctx"][0]); s1 = np.ascontiguousarray(c["ctx"][1])
+        cbf_ctx = -1 if c["inferred"] else 72 + 2 + c["prev"]                 # ORC_CTX_QtCbf[0] + 2 + the previous sub-partition's cbf
+        a = L.orc_trquant_isp(P(s0), P(s1), P(c["resi"]), c["tw"], c["th"], c["bd"], c["qp"] + 6 * (c["bd"] - 8), c["lam"], cbf_ctx, P(lev), P(out))
+        key = (c["bd"], c["qp"], c["w"], c["h"], c["isp"], c["tu"], c["prev"], c["inferred"])
+        assert a == c["asum"], ("absSum", key, a, c["asum"])
+        assert np.array_equal(lev, c["lev"]), ("levels", key)
+        if a:
+            nz += 1
+            assert np.array_equal(out, c["out"]), ("resi", key)
+    assert nz > 500
+
+
+def test_slice_data_payload_with_isp_and_the_whole_tool_set():
+    """tools 0xb5f (+ ISP) on screen-content pictures (510 ISP CUs over 14 (shape, split) combinations incl. 1xN / Nx1 / 2xN sub-partitions) and 0xb7f (+ transform skip: every tool of
+    the reference cfg but LMCS): payloads the reference's CABACReader parsed back including isp_mode and the cbf chain of the sub-partitions, and whose DecCu reconstruction
+    (sub-partition by sub-partition, 4-column prediction regions, implicit DST-VII) was the oracle's (tests/golden/make_golden.py bitstream_isp)."""
+    import importlib
+    pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+    for name, mask in (("bitstream_isp.npz", 0x4), ("bitstream_full.npz", 0x24)):
+        g = np.load(os.path.join(G, name))
+        assert int(g["tools"][0]) & mask == mask
+        _check_pictures(g, pkg)
