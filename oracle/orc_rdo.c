@@ -82,6 +82,8 @@ struct orc_enc {
   double sqrt_lambda_fp;              /* sqrtLambdaForFirstPass */
   uint64_t cnt_satd, cnt_rd, cnt_rdpix, cnt_nodes, cnt_reuse;
   cache_ent *cache; int ctu_is_last;
+  int16_t lmcs_fwd[1024], lmcs_inv[1024]; int lmcs_pivot[17], lmcs_cadj[16]; int lmcs_on;      /* LMCS tables of the slice (orc_set_slice) */
+  int tu_cadj;                        /* chroma residual scale of the chroma TU being coded (0: no scaling) */
   int dct2_sum;                       /* sum |coefficient| of the luma block transformed last (the DCT-II entry of the transform-skip pruning, CL/TrQuant.cpp:1049-1124) */
   int tu_cbf_cb;                      /* tu.cbf[Cb] while Cr is quantised (context of its cbf in DepQuant's rate tables) */
   int jccr_sign;                      /* slice joint_cb_cr_sign_flag, from the picture's chroma planes (EL/EncSlice.cpp:1503-1538) */
@@ -95,7 +97,7 @@ struct orc_enc {
 /* ------------------------------------------------------------------------------------------------ */
 orc_enc *orc_create(const orc_cfg *cfg)
 {
-  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST | ORC_TOOL_JCCR | ORC_TOOL_TS | ORC_TOOL_ISP)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, ISP, LFNST, MTS, TS, DepQuant, CCLM, JointCbCr, CU reuse, FAST)", cfg->tools); return 0; }
+  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST | ORC_TOOL_JCCR | ORC_TOOL_TS | ORC_TOOL_ISP | ORC_TOOL_LMCS | ORC_TOOL_RDOQ)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, ISP, LFNST, MTS, TS, DepQuant (RDOQ only behind it: RDOQ-TS), LMCS, CCLM, JointCbCr, CU reuse, FAST)", cfg->tools); return 0; }
   /* the plain quantiser's LFNST branch (CL/Quant.cpp:1054-1058) keeps buffer positions the decoder's LFNST conditions reject: the reference only
    * ever runs LFNST over DepQuant / RDOQ */
   if ((cfg->tools & ORC_TOOL_JCCR) && !(cfg->tools & ORC_TOOL_DEPQUANT)) { snprintf(g_err, sizeof g_err, "oracle: JointCbCr is built over DepQuant (tool set 0x%x)", cfg->tools); return 0; }
@@ -168,6 +170,31 @@ int orc_forest_predict_rows(orc_enc *e, const int32_t *rows, int n, int32_t *out
 int orc_set_slice(orc_enc *e, const orc_slice *s)
 {
   e->sl = *s;
+  e->lmcs_on = 0;
+  if (s->lmcs_enable) {
+    if (!(e->cfg.tools & ORC_TOOL_LMCS)) { snprintf(g_err, sizeof g_err, "oracle: the slice enables LMCS, the tool set does not"); return -1; }
+    /* Reshape::constructReshaper (CL/Reshape.cpp:297-333, JVET_O0428 form) */
+    const int bd = e->cfg.bit_depth, n = 1 << bd, initCW = n / 16, lbin = ilog2(initCW);
+    int binCW[16], inPivot[17], fwdCoef[16], invCoef[16];
+    for (int i = 0; i < 16; i++) binCW[i] = (i < s->lmcs_min_bin || i > s->lmcs_max_bin) ? 0 : (uint16_t) (s->lmcs_delta_cw[i] + initCW);
+    e->lmcs_pivot[0] = 0; inPivot[0] = 0;
+    for (int i = 0; i < 16; i++) {
+      e->lmcs_pivot[i + 1] = e->lmcs_pivot[i] + binCW[i]; inPivot[i + 1] = inPivot[i] + initCW;
+      fwdCoef[i] = (binCW[i] * (1 << 11) + (1 << (lbin - 1))) >> lbin;
+      if (binCW[i] == 0) { invCoef[i] = 0; e->lmcs_cadj[i] = 1 << 11; } else { invCoef[i] = initCW * (1 << 11) / binCW[i]; e->lmcs_cadj[i] = invCoef[i]; }
+    }
+    for (int v = 0; v < n; v++) {
+      const int iy = v / initCW;
+      int t = e->lmcs_pivot[iy] + ((fwdCoef[iy] * (v - inPivot[iy]) + (1 << 10)) >> 11);
+      e->lmcs_fwd[v] = (int16_t) (t < 0 ? 0 : t > n - 1 ? n - 1 : t);
+      int ii = s->lmcs_min_bin;                      /* getPWLIdxInv 268-283 */
+      for (; ii <= s->lmcs_max_bin; ii++) if (v < e->lmcs_pivot[ii + 1]) break;
+      if (ii > 15) ii = 15;
+      t = inPivot[ii] + ((invCoef[ii] * (v - e->lmcs_pivot[ii]) + (1 << 10)) >> 11);
+      e->lmcs_inv[v] = (int16_t) (t < 0 ? 0 : t > n - 1 ? n - 1 : t);
+    }
+    e->lmcs_on = 1;
+  }
   /* EL/IntraSearch.cpp:297: getMotionLambda()*FRAC_BITS_SCALE = sqrt(lambda)/32768 (CL/RdCost.cpp:80) */
   e->sqrt_lambda_fp = sqrt(s->lambda) * (1.0 / (double) (1 << 15));
   return 0;
@@ -193,6 +220,8 @@ int orc_load_frame(orc_enc *e, const void *const org[3], const int stride[3], in
       e->org[c][y * e->stride[c] + x] = bps == 1 ? ((const uint8_t *) org[c])[y * stride[c] + x] : (int16_t) ((const uint16_t *) org[c])[y * stride[c] + x];
     memset(e->rec[c], 0, (size_t) w * h * 2); memset(e->lev[c], 0, (size_t) w * h * 2);
   }
+  /* EncGOP::xPicInitLMCS (EL/EncGOP.cpp:1689-1695): the original luma of an intra picture is forward mapped once, before the slice is compressed */
+  if (e->lmcs_on) for (int i = 0; i < e->wl * e->hl; i++) e->org[0][i] = e->lmcs_fwd[e->org[0][i]];
   for (int k = 0; k < 2; k++) { memset(e->um[k], 0, (size_t) e->uw * e->uh * sizeof(unit_t)); memset(e->avail[k], 0, (size_t) e->uw * e->uh); }
   e->jccr_sign = orc_jccr_sign(e->org[1], e->org[2], e->stride[1], e->wc, e->hc);
   /* uniform tile grid (CL/Slice.cpp PPS uniform spacing): boundary i = i*N/T */
@@ -213,6 +242,19 @@ int orc_get_reco(orc_enc *e, void *const reco[3], const int stride[3], int bps)
       if (bps == 1) ((uint8_t *) reco[c])[y * stride[c] + x] = (uint8_t) v; else ((uint16_t *) reco[c])[y * stride[c] + x] = (uint16_t) v;
     }
   }
+  return 0;
+}
+int orc_lmcs_tables(orc_enc *e, int16_t *fwd, int16_t *inv, int *pivot, int *cadj)
+{
+  if (!e->lmcs_on) return -1;
+  memcpy(fwd, e->lmcs_fwd, (size_t) (1 << e->cfg.bit_depth) * 2); memcpy(inv, e->lmcs_inv, (size_t) (1 << e->cfg.bit_depth) * 2);
+  memcpy(pivot, e->lmcs_pivot, sizeof e->lmcs_pivot); memcpy(cadj, e->lmcs_cadj, sizeof e->lmcs_cadj);
+  return 0;
+}
+int orc_lmcs_inverse_reco(orc_enc *e)
+{
+  if (!e->lmcs_on) return -1;
+  for (int i = 0; i < e->wl * e->hl; i++) e->rec[0][i] = e->lmcs_inv[e->rec[0][i]];
   return 0;
 }
 void orc_get_counters(orc_enc *e, uint64_t out[4]) { out[0] = e->cnt_satd; out[1] = e->cnt_rd; out[2] = e->cnt_rdpix; out[3] = e->cnt_nodes; }
@@ -560,11 +602,50 @@ static void enc_intra_chroma_pred_mode(orc_enc *e, area_t a, int dir, int lm_ok)
 static uint64_t code_tu_block_ex(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int lfnst_idx, int lfnst_dir, int16_t *rec_out, int16_t *lev_out, int *cbf);
 /* lambda the quantiser sees for a component (RDOQ_CHROMA_LAMBDA: EL/EncSlice.cpp:107-149 setLambdas, EL/IntraSearch.cpp:2889 selectLambda) */
 /* with JointCbCr on, every chroma block is quantised with 1.3 x that lambda above slice QP 18 (EL/IntraSearch.cpp:2937-2942) */
+/* with LMCS chroma residual scaling the lambda is first divided by the square of the scale (2919-2931): cResScale = 2048 / the TU's inverse scale */
+static double lmcs_lambda(const orc_enc *e, double l)
+{
+  if (!e->tu_cadj) return l;
+  const double cResScale = (double) (1 << 11) / (double) e->tu_cadj;
+  return l / (cResScale * cResScale);
+}
 static double quant_lambda(const orc_enc *e, int comp)
 {
   if (!comp) return e->sl.lambda;
-  const double l = e->sl.lambda / e->sl.dist_weight[comp - 1];
+  const double l = lmcs_lambda(e, e->sl.lambda / e->sl.dist_weight[comp - 1]);
   return ((e->cfg.tools & ORC_TOOL_JCCR) && e->sl.qp > 18) ? 1.3 * l : l;
+}
+/* AreaBuf<Pel>::scaleSignal (CL/Buffer.cpp:501-550): forward = division of the residual by the scale (11 fractional bits), inverse = multiplication */
+static void scale_residual(int16_t *r, int n, int scale, int fwd, int bd)
+{
+  const int mxa = (1 << bd) - 1;
+  for (int i = 0; i < n; i++) {
+    int v = r[i];
+    if (fwd) { const int sg = v >= 0 ? 1 : -1, a = sg * v; v = sg * (((a << 11) + (scale >> 1)) / scale); v = v < -mxa ? -mxa : v > mxa ? mxa : v; }
+    else { v = v < -mxa - 1 ? -mxa - 1 : v > mxa ? mxa : v; const int sg = v >= 0 ? 1 : -1, a = sg * v; v = sg * ((a * scale + (1 << 10)) >> 11); v = v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+    r[i] = (int16_t) v;
+  }
+}
+/* Reshape::calculateChromaAdjVpduNei (CL/Reshape.cpp:153-250): the scale of every chroma TU inside a 64x64 luma area comes from the average of the reconstructed luma
+ * samples left of and above the luma CU that holds the area's top-left sample (64 each, clamped at the picture edge), looked up in the model's piece-wise scale table.
+ * a: the chroma TU in luma coordinates.  Returns 0 when the slice does not scale chroma residuals. */
+static int chroma_adj(const orc_enc *e, area_t a)
+{
+  if (!e->lmcs_on || !e->sl.lmcs_chroma_adj) return 0;
+  const int vx = a.x / 64 * 64, vy = a.y / 64 * 64;
+  const unit_t *tl = &e->um[0][(vy >> 2) * e->uw + (vx >> 2)];
+  const int x = tl->x, y = tl->y, st = e->stride[0], bd = e->cfg.bit_depth;
+  const unit_t *cuA = get_cu(e, 0, x, y - 1), *cuL = get_cu(e, 0, x - 1, y);
+  int sum = 0, n = 0;
+  if (cuL) for (int i = 0; i < 64; i++) { const int k = (y + i) >= e->hl ? (e->hl - y - 1) : i; sum += e->rec[0][(y + k) * st + x - 1]; n++; }
+  if (cuA) for (int i = 0; i < 64; i++) { const int k = (x + i) >= e->wl ? (e->wl - x - 1) : i; sum += e->rec[0][(y - 1) * st + x + k]; n++; }
+  int v;
+  if (n == 64) v = (sum + 32) >> 6; else if (n == 128) v = (sum + 64) >> 7; else v = 1 << (bd - 1);
+  const int mx = (1 << bd) - 1; v = v < 0 ? 0 : v > mx ? mx : v;
+  int idx = e->sl.lmcs_min_bin;
+  for (; idx <= e->sl.lmcs_max_bin; idx++) if (v < e->lmcs_pivot[idx + 1]) break;
+  if (idx > 15) idx = 15;
+  return e->lmcs_cadj[idx];
 }
 static uint64_t code_tu_block(orc_enc *e, int comp, int x, int y, int w, int h, int16_t *rec_out, int16_t *lev_out, int *cbf) { return code_tu_block_ex(e, comp, x, y, w, h, 0, 0, 0, rec_out, lev_out, cbf); }
 static uint64_t code_tu_block_mts(orc_enc *e, int comp, int x, int y, int w, int h, int mts_idx, int16_t *rec_out, int16_t *lev_out, int *cbf) { return code_tu_block_ex(e, comp, x, y, w, h, mts_idx, 0, 0, rec_out, lev_out, cbf); }
@@ -578,6 +659,8 @@ static uint64_t code_tu_block_ex(orc_enc *e, int comp, int x, int y, int w, int 
   const int lf = (lfnst_idx && w >= 4 && h >= 4) ? lfnst_idx : 0, lmode = lf ? orc_lfnst_mode(lfnst_dir, w, h) : 0;
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) e->resi[j * w + i] = (int16_t) (org[j * st + i] - e->pred[j * w + i]);
   if (!comp) memcpy(e->resi_org, e->resi, (size_t) w * h * 2);      /* the MTS pruning works on the prediction residual */
+  const int cadj = (comp && w * h > 4) ? e->tu_cadj : 0;             /* 3884-3904 / 3060-3066: chroma residual scaling of blocks of more than 4 samples */
+  if (cadj) scale_residual(e->resi, w * h, cadj, 1, bd);
   orc_fwd_2d_mts(e->resi, w, w, h, bd, mts_idx, e->coef);
   if (!comp) { int sa = 0; for (int i = 0; i < w * h; i++) sa += abs(e->coef[i]); e->dct2_sum = sa; }
   if (lf) { orc_lfnst_keep(e->coef, w, h); orc_fwd_lfnst(e->coef, w, h, lmode, lf); }       /* xT's zero-out 855-868, xFwdLfnst 1220-1223 */
@@ -592,6 +675,7 @@ static uint64_t code_tu_block_ex(orc_enc *e, int comp, int x, int y, int w, int 
     if (abs_sum > 0) { orc_dequant(lev_out, w, h, bd, qp, e->coef); orc_inv_lfnst(e->coef, w, h, lmode, lf); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
   }
   if (abs_sum <= 0) memset(e->resi, 0, (size_t) w * h * 2);
+  else if (cadj) scale_residual(e->resi, w * h, cadj, 0, bd);
   const int mx = (1 << bd) - 1;
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) { int v = e->pred[j * w + i] + e->resi[j * w + i]; rec_out[j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
   *cbf = abs_sum > 0;
@@ -1276,7 +1360,8 @@ static uint64_t code_joint_block(orc_enc *e, int mask, int cx, int cy, int w, in
   if (lf) { orc_lfnst_keep(e->coef, w, h); orc_fwd_lfnst(e->coef, w, h, lmode, lf); }
   /* lambda: the Cb lambda (selectLambda(compID = Cb) 2889), loosened by 0.8 (modes +-1, +-3) or 0.5 (+-2), then the 1.3 of every chroma block */
   const int am = mode < 0 ? -mode : mode;
-  double lam = (am == 1 || am == 3 ? 0.8 : 0.5) * (e->sl.lambda / e->sl.dist_weight[0]);
+  const int cadj = n > 4 ? e->tu_cadj : 0;
+  double lam = (am == 1 || am == 3 ? 0.8 : 0.5) * (cadj ? lmcs_lambda(e, e->sl.lambda / e->sl.dist_weight[0]) : e->sl.lambda / e->sl.dist_weight[0]);
   if (e->sl.qp > 18) lam = 1.3 * lam;
   /* the other block's cbf is cleared first (3053-3058): Cr's cbf context sees tu.cbf[Cb] = 0 for mask 1 */
   const int abs_sum = orc_depquant(e->cabac.s0, e->cabac.s1, e->coef, w, h, comp, ORC_CTX_QtCbf[comp], bd, qp, lam, 0, lf, lev_out);
@@ -1292,9 +1377,10 @@ static uint64_t code_joint_block(orc_enc *e, int mask, int cx, int cy, int w, in
       /* invTransformCbCr (139-156): the coded block keeps its residual, the other one is derived */
       if (comp == 1) r = k == 0 ? c : (am == 1 ? ((mode < 0 ? -c : c) >> 1) : (mode < 0 ? -c : c));
       else r = k == 1 ? c : ((mode < 0 ? -c : c) >> 1);
-      const int v = e->pred_c[k][j * w + i] + r;
-      rec_out[k][j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v);
+      rec_out[k][j * w + i] = (int16_t) r;
     }
+    if (cadj) scale_residual(rec_out[k], n, cadj, 0, bd);              /* 3060-3070: both residuals back through the inverse chroma scaling */
+    for (int i = 0; i < n; i++) { const int v = e->pred_c[k][i] + rec_out[k][i]; rec_out[k][i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
     dist += (uint64_t) (e->sl.dist_weight[k] * (double) orc_sse(org, st, rec_out[k], w, w, h));
   }
   return dist;
@@ -1316,6 +1402,7 @@ static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int lm_ok, int lfnst
 {
   const int cx = a.x >> 1, cy = a.y >> 1, cw = a.w >> 1, chh = a.h >> 1;
   orc_cabac ctxStart; orc_ctx_copy(&ctxStart, &e->cabac);
+  e->tu_cadj = chroma_adj(e, a);                              /* 3884-3898: the TU's chroma residual scale (LMCS) */
   int cand[8]; chroma_cand_modes(e, a, cand);
   double bestCost = ORC_MAX_DOUBLE; uint64_t bestDist = 0; int bestMode = 0, bestCbf = 0, bestJccr = 0;
   int16_t *rec2[2], *lev2[2];
@@ -1364,6 +1451,7 @@ static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int lm_ok, int lfnst
         memcpy(e->pred_c[c - 1], e->pred, (size_t) cw * chh * 2);
         const int st = e->stride[c]; const int16_t *org = e->org[c] + cy * st + cx;
         for (int j = 0; j < chh; j++) for (int i = 0; i < cw; i++) e->resi_c[c - 1][j * cw + i] = (int16_t) (org[j * st + i] - e->pred[j * cw + i]);
+        if (e->tu_cadj && cw * chh > 4) scale_residual(e->resi_c[c - 1], cw * chh, e->tu_cadj, 1, e->cfg.bit_depth);      /* 3915-3925: the stored residuals are the scaled ones */
       }
       e->tu_cbf_cb = c == 2 ? cbf[0] : 0;
       compDist[c - 1] = code_tu_block_ex(e, c, cx, cy, cw, chh, 0, lfnst_idx, lfDir, rec2[c - 1], lev2[c - 1], &cbf[c - 1]);
@@ -1421,6 +1509,7 @@ static uint64_t est_intra_pred_chroma(orc_enc *e, area_t a, int lm_ok, int lfnst
     }
   }
   orc_ctx_copy(&e->cabac, &ctxStart);
+  e->tu_cadj = 0;
   *out_dir = bestMode; *out_cbf = bestCbf; *out_jccr = bestJccr;
   return bestDist;
 }
@@ -1673,6 +1762,7 @@ static uint64_t recon_from_levels(orc_enc *e, int comp, int x, int y, int w, int
   if (cbf && !comp && mts_idx == 1) { orc_dequant_ts(lev, w, h, bd, qp, e->coef); orc_ts_inv(e->coef, w, h, bd, e->resi, w); }      /* a transform-skip block: Quant::dequant + xITransformSkip */
   else if (cbf) { if (e->cfg.tools & ORC_TOOL_DEPQUANT) orc_dequant_dq(lev, w, h, bd, qp, e->coef); else orc_dequant(lev, w, h, bd, qp, e->coef); orc_inv_lfnst(e->coef, w, h, lmode, lf); orc_inv_2d_mts(e->coef, w, h, bd, mts_idx, e->resi, w); }
   else memset(e->resi, 0, (size_t) w * h * 2);
+  if (comp && cbf && e->tu_cadj && w * h > 4) scale_residual(e->resi, w * h, e->tu_cadj, 0, bd);      /* DL/DecCu.cpp:359-367 */
   for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) { int v = e->pred[j * w + i] + e->resi[j * w + i]; rec_out[j * w + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
   uint64_t dd = orc_sse(org, st, rec_out, w, w, h);
   if (comp) dd = (uint64_t) (e->sl.dist_weight[comp - 1] * (double) dd);
@@ -1694,6 +1784,7 @@ static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *ou
     memcpy(e->best_lev[0], c->lev, (size_t) a.w * a.h * 2);
   } else {
     const int cx = a.x >> 1, cy = a.y >> 1, cw = a.w >> 1, chh = a.h >> 1;
+    e->tu_cadj = (c->cbf & 6) ? chroma_adj(e, a) : 0;
     const int fm = c->dir == ORC_DM_CHROMA ? colocated_luma_mode(e, a) : c->dir;
     static int16_t tmpC[CCLM_TSTRIDE * CCLM_TSTRIDE]; int infoC[4] = { 0, 0, 0, 0 };
     if (fm >= 67 && fm <= 69) cclm_luma(e, cx, cy, cw, chh, fm != 67, tmpC, infoC);
@@ -1713,9 +1804,10 @@ static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *ou
           const int v0 = jres[j * cw + i]; int r;
           if (comp == 1) r = k == 0 ? v0 : (am == 1 ? ((mode < 0 ? -v0 : v0) >> 1) : (mode < 0 ? -v0 : v0));
           else r = k == 1 ? v0 : ((mode < 0 ? -v0 : v0) >> 1);
-          const int v = e->pred[j * cw + i] + r;
-          e->best_rec[k][j * cw + i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v);
+          e->best_rec[k][j * cw + i] = (int16_t) r;
         }
+        if (e->tu_cadj && cw * chh > 4) scale_residual(e->best_rec[k], cw * chh, e->tu_cadj, 0, bd);
+        for (int i = 0; i < cw * chh; i++) { const int v = e->pred[i] + e->best_rec[k][i]; e->best_rec[k][i] = (int16_t) (v < 0 ? 0 : v > mx ? mx : v); }
         dist += (uint64_t) (e->sl.dist_weight[k] * (double) orc_sse(org, st, e->best_rec[k], cw, cw, chh));
         memcpy(e->best_lev[k], c->lev + (size_t) k * cw * chh, (size_t) cw * chh * 2);
       }
@@ -1726,6 +1818,7 @@ static uint64_t reuse_cached(orc_enc *e, area_t a, int ch, int *out_dir, int *ou
       memcpy(e->best_lev[k - 1], c->lev + (size_t) (k - 1) * cw * chh, (size_t) cw * chh * 2);
     }
   }
+  e->tu_cadj = 0;
   *out_dir = c->dir; *out_mrl = c->mrl; *out_cbf = c->cbf; *out_mts = c->mts; *out_lfnst = c->lfnst; *out_jccr = c->jccr; *out_isp = c->isp; *out_tucbf = c->tucbf;
   return dist;
 }

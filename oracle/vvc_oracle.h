@@ -39,7 +39,7 @@ enum {
   ORC_TOOL_MRL   = 1 << 0,  /* multi-reference-line (compile-time always on in the reference) */
   ORC_TOOL_MIP   = 1 << 1, ORC_TOOL_ISP = 1 << 2, ORC_TOOL_LFNST = 1 << 3, ORC_TOOL_MTS = 1 << 4,
   ORC_TOOL_TS    = 1 << 5, ORC_TOOL_DEPQUANT = 1 << 6, ORC_TOOL_RDOQ = 1 << 7, ORC_TOOL_CCLM = 1 << 8,
-  ORC_TOOL_JCCR  = 1 << 9, ORC_TOOL_LMCS = 1 << 10, ORC_TOOL_CU_REUSE = 1 << 11,
+  ORC_TOOL_JCCR  = 1 << 9, ORC_TOOL_LMCS = 1 << 10 /* LMCS allowed: the slice's model (orc_slice) decides */, ORC_TOOL_CU_REUSE = 1 << 11,
   ORC_TOOL_FAST  = 1 << 12  /* the fork's FAST_ALGORITHM: features + forest decide the one partition mode a luma node tries (needs orc_set_forest) */
 };
 
@@ -62,6 +62,11 @@ typedef struct {
   int    qp_c[2];          /* mapped chroma QP for Cb, Cr */
   double lambda;           /* RdCost lambda (EL/EncSlice.cpp:754-845) */
   double dist_weight[2];   /* chroma distortion weights (EL/EncSlice.cpp:125) */
+  /* LMCS as the slice / its APS signal it (slice_lmcs_enabled_flag, slice_chroma_residual_scale_flag, lmcs_min_bin_idx, LmcsMaxBinIdx, the signed codeword deltas):
+   * the analysis that chooses the model is the caller's (EL/EncReshape.cpp); for an intra slice the search itself sees LMCS through the forward-mapped original
+   * luma (EL/EncGOP.cpp:1689-1695), the mapped-domain reconstruction and the scaling of the chroma residuals */
+  int    lmcs_enable, lmcs_chroma_adj, lmcs_min_bin, lmcs_max_bin;
+  int    lmcs_delta_cw[16];
 } orc_slice;
 
 /* one final coding unit, ≙ the fields D_BLOCK_STATISTICS_CODED prints (CL/dtrace_blockstatistics.cpp) */
@@ -100,6 +105,10 @@ int      orc_compress_frame(orc_enc *e, orc_ctu_result *res /* [n_ctus] */, orc_
 int      orc_compress_tiles(orc_enc *e, int tile_first, int tile_count, orc_ctu_result *res, orc_cu *cus, int max_cus, int *n_cus);   /* a range of tiles only (test runs spread tiles over processes) */
 int      orc_jccr_sign(const int16_t *cb, const int16_t *cr, int stride, int w, int h);
 int      orc_get_reco(orc_enc *e, void *const reco[3], const int stride[3], int bytes_per_sample);
+/* LMCS tables built from the slice's model (Reshape::constructReshaper, CL/Reshape.cpp:297-333): forward / inverse LUT (1 << bit_depth entries), 17 pivots, 16 chroma scales */
+int      orc_lmcs_tables(orc_enc *e, int16_t *fwd, int16_t *inv, int *pivot, int *cadj);
+/* inverse mapping of the reconstructed luma (what EncGOP does after the slice is coded, EL/EncGOP.cpp:2576-2594; orc_get_reco returns the mapped-domain samples the search left) */
+int      orc_lmcs_inverse_reco(orc_enc *e);
 const char *orc_last_error(void);
 /* work counters for the bench's diagnostic model */
 int      orc_arith_encode(int qp, const int32_t *ops, int nops, uint8_t *out, int cap);

@@ -2,13 +2,14 @@
 import numpy as np
 
 
-def synth_frame(width, height, frame=0, bit_depth=8, seed=1234, chroma_texture=0.0, oriented=0.0, screen=0.0):
+def synth_frame(width, height, frame=0, bit_depth=8, seed=1234, chroma_texture=0.0, oriented=0.0, screen=0.0, limited=False):
     """chroma_texture > 0 adds that fraction of the (2x2 averaged) luma texture to Cb and minus half of it to Cr: natural video has
     such cross-component correlation and the LM chroma modes (CCLM) only win on pictures that have it.  oriented > 0 adds gratings of that
     amplitude (8-bit scale) whose direction and period change from one 32x32 block to the next: directional detail is what the angular modes
     predict and what the mode-dependent secondary transform (LFNST) compacts; white noise alone never selects it.  screen > 0 renders that fraction
     of the 32x32 blocks as noise-free screen content (a flat background with one-sample-wide strokes and isolated dots of high contrast): the
-    residuals transform skip is made for."""
+    residuals transform skip is made for.  limited squeezes the luma into the video range (64 .. 223 at 8 bit): full-range pictures make the reference's LMCS
+    analysis switch the tool off (EL/EncReshape.cpp:444-446: samples in the first / last of its 16 bins)."""
     s = 1 if bit_depth == 8 else 4
     mid, a1, a2 = (128, 60, 40) if bit_depth == 8 else (512, 240, 160)
     mx = (1 << bit_depth) - 1
@@ -30,6 +31,8 @@ def synth_frame(width, height, frame=0, bit_depth=8, seed=1234, chroma_texture=0
         bg = mid + s * (((h2 >> 21) % 5) * 12 - 24)
         fg = np.where(((h2 >> 25) & 1) == 1, bg + 90 * s, bg - 80 * s)
         Y = np.where(sel, np.where(strokes | dots, fg, bg), Y)
+    if limited:
+        Y = 64 * s + np.clip(np.rint(Y), 0, mx) * 5 // 8
     yc, xc = np.mgrid[0:height // 2, 0:width // 2]
     U = mid + 20 * s * np.sin(xc / 50.0) + rng.normal(0, 2 * s, (height // 2, width // 2))
     V = mid + 20 * s * np.cos(yc / 40.0) + rng.normal(0, 2 * s, (height // 2, width // 2))

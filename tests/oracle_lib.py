@@ -16,7 +16,8 @@ class OrcCfg(C.Structure):
 
 
 class OrcSlice(C.Structure):
-    _fields_ = [("qp", C.c_int), ("qp_c", C.c_int * 2), ("lam", C.c_double), ("dist_weight", C.c_double * 2)]
+    _fields_ = [("qp", C.c_int), ("qp_c", C.c_int * 2), ("lam", C.c_double), ("dist_weight", C.c_double * 2),
+                ("lmcs_enable", C.c_int), ("lmcs_chroma_adj", C.c_int), ("lmcs_min_bin", C.c_int), ("lmcs_max_bin", C.c_int), ("lmcs_delta_cw", C.c_int * 16)]
 
 
 class OrcCu(C.Structure):
@@ -87,6 +88,11 @@ def make_slice(sp):
     s.qp_c[0], s.qp_c[1] = sp["qp_c"]
     s.lam = sp["lam"]
     s.dist_weight[0], s.dist_weight[1] = sp["dist_weight"]
+    m = sp.get("lmcs")                      # LMCS model of the slice: dict(enable, chroma_adj, min_bin, max_bin, delta_cw[16]) from the picture analysis (the caller's job)
+    if m:
+        s.lmcs_enable, s.lmcs_chroma_adj, s.lmcs_min_bin, s.lmcs_max_bin = int(m["enable"]), int(m["chroma_adj"]), int(m["min_bin"]), int(m["max_bin"])
+        for i in range(16):
+            s.lmcs_delta_cw[i] = int(m["delta_cw"][i])
     return s
 
 
@@ -113,7 +119,8 @@ def compress_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chro
         raise RuntimeError(L.orc_last_error().decode())
     try:
         sl = make_slice(sp)
-        L.orc_set_slice(e, C.byref(sl))
+        if L.orc_set_slice(e, C.byref(sl)) != 0:
+            raise RuntimeError(L.orc_last_error().decode())
         if forest is not None:
             set_forest(L, e, forest)
         dump = None
@@ -208,7 +215,8 @@ def write_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=
         raise RuntimeError(L.orc_last_error().decode())
     try:
         sl = make_slice(sp)
-        L.orc_set_slice(e, C.byref(sl))
+        if L.orc_set_slice(e, C.byref(sl)) != 0:
+            raise RuntimeError(L.orc_last_error().decode())
         planes = [np.ascontiguousarray(p) for p in planes]
         L.orc_load_frame(e, (C.c_void_p * 3)(*[p.ctypes.data for p in planes]), (C.c_int * 3)(*[p.shape[1] for p in planes]), planes[0].dtype.itemsize)
         nctu = ((w + 127) // 128) * ((h + 127) // 128)

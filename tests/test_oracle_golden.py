@@ -169,11 +169,16 @@ def _check_pictures(g, pkg):
     texture = float(g["chroma_texture"][0]) if "chroma_texture" in g else 0.0
     oriented = float(g["oriented"][0]) if "oriented" in g else 0.0
     screen = float(g["screen"][0]) if "screen" in g else 0.0
+    limited = bool(g["limited"][0]) if "limited" in g else False
     off = 0
-    for (W, H, qp, tc, tr, bd, seed, nbytes), sizes in zip(g["pic_meta"], g["pic_sizes"]):
+    for k, ((W, H, qp, tc, tr, bd, seed, nbytes), sizes) in enumerate(zip(g["pic_meta"], g["pic_sizes"])):
         exp = g["pic_bytes"][off:off + nbytes]; off += int(nbytes)
-        planes = pkg.synth_frame(int(W), int(H), 0, int(bd), int(seed), chroma_texture=texture, oriented=oriented, screen=screen)
-        payload, sz, _, _ = O.write_frame(planes, int(W), int(H), pkg.slice_params(int(qp), bit_depth=int(bd), dep_quant=bool(tools & 0x40)),
+        planes = pkg.synth_frame(int(W), int(H), 0, int(bd), int(seed), chroma_texture=texture, oriented=oriented, screen=screen, limited=limited)
+        sp = pkg.slice_params(int(qp), bit_depth=int(bd), dep_quant=bool(tools & 0x40))
+        if "pic_lmcs" in g:                     # the LMCS model the reference encoder's analysis chose for the picture (stored with the fixture)
+            r = [int(v) for v in g["pic_lmcs"][k]]
+            sp["lmcs"] = dict(enable=r[0], chroma_adj=r[1], min_bin=r[2], max_bin=r[3], delta_cw=r[4:])
+        payload, sz, _, _ = O.write_frame(planes, int(W), int(H), sp,
                                           bit_depth=int(bd), tile_cols=int(tc), tile_rows=int(tr), tools=tools)
         assert np.array_equal(sz, sizes[:len(sz)]) and np.array_equal(payload, exp), (W, H, qp, tc, tr, bd)
 
@@ -550,3 +555,27 @@ def test_slice_data_payload_with_isp_and_the_whole_tool_set():
         g = np.load(os.path.join(G, name))
         assert int(g["tools"][0]) & mask == mask
         _check_pictures(g, pkg)
+
+
+def test_lmcs_tables_and_slice_data_payload_with_the_whole_reference_tool_set():
+    """LMCS: (1) forward / inverse LUT, pivots and chroma scales the oracle builds from a signalled model == the tables the reference ENCODER built for the models its own
+    picture analysis chose (and == the reference decoder's Reshape::constructReshaper; tests/golden/make_golden.py lmcs); (2) tools 0xf7f = every tool of BIN/encoder_intra.cfg
+    with the slice's LMCS model on: payloads the reference decoder parsed and reconstructed (chroma residual scaling from the VPDU's luma neighbourhood) to the oracle's
+    mapped-domain samples."""
+    import importlib
+    L = O.lib()
+    g = np.load(os.path.join(G, "lmcs.npz"))
+    L.orc_lmcs_tables.argtypes = [C.c_void_p] * 5
+    for row, fwd, inv, piv, cadj in zip(g["models"], g["fwd"], g["inv"], g["pivot"], g["cadj"]):
+        cfg = O.default_cfg(128, 128, 10, tools=O.TOOLS_DEFAULT | 0x400)
+        e = L.orc_create(C.byref(cfg)); assert e
+        sp = dict(qp=int(row[2]), qp_c=(30, 30), lam=50.0, dist_weight=(1.0, 1.0), lmcs=dict(enable=int(row[4]), chroma_adj=int(row[5]), min_bin=int(row[6]), max_bin=int(row[7]), delta_cw=[int(v) for v in row[8:]]))
+        sl = O.make_slice(sp)
+        assert L.orc_set_slice(e, C.byref(sl)) == 0
+        f = np.zeros(1024, np.int16); i = np.zeros(1024, np.int16); p = np.zeros(17, np.int32); c = np.zeros(16, np.int32)
+        assert L.orc_lmcs_tables(e, P(f), P(i), P(p), P(c)) == 0
+        assert np.array_equal(f, fwd) and np.array_equal(i, inv) and np.array_equal(p, piv) and np.array_equal(c, cadj), tuple(row[:4])
+        L.orc_destroy(e)
+    gb = np.load(os.path.join(G, "bitstream_lmcs.npz"))
+    assert int(gb["tools"][0]) == 0xf7f and int(gb["pic_lmcs"][0][0]) == 1
+    _check_pictures(gb, importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd"))
