@@ -88,7 +88,7 @@ typedef struct {
   uint8_t  intra_dir;            /* luma mode 0..66; chroma mode (70 = DM) */
   uint8_t  mrl_idx;              /* multiRefIdx */
   uint8_t  cbf;                  /* bit0 Y, bit1 Cb, bit2 Cr */
-  uint8_t  mts_idx;              /* tu.mtsIdx of the luma TU: 0 DCT2xDCT2, 2..5 explicit MTS (VVCX_TOOL_MTS) */
+  uint8_t  mts_idx;              /* tu.mtsIdx of the luma TU: 0 DCT2xDCT2, 1 transform skip (VVCX_TOOL_TS), 2..5 explicit MTS (VVCX_TOOL_MTS) */
   uint8_t  mip_flag;             /* cu.mipFlag of a luma CU (VVCX_TOOL_MIP): intra_dir is then the MIP mode, mrl_idx 0 */
   uint8_t  lfnst_idx;            /* cu.lfnstIdx of the CU (VVCX_TOOL_LFNST): 0 none, 1 / 2 the kernel of the set */
   uint8_t  joint_cb_cr;          /* tu.jointCbCr of a chroma CU (VVCX_TOOL_JCCR): 0 separate residuals, 1..3 the cbf mask of the joint residual */
@@ -226,6 +226,12 @@ int  vvcx_depquant_batch(const int16_t *org, const int16_t *pred, int w, int h, 
  * mode for DM / CCLM chroma), from which the kernel set and the transposition follow after the wide-angle mapping of the block shape */
 int  vvcx_lfnst_depquant_batch(const int16_t *org, const int16_t *pred, int w, int h, int bit_depth, int qp, int comp, int lfnst_idx, int intra_dir, int cbf_cb, double lambda,
                                const uint16_t *s0, const uint16_t *s1, int n, int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device);
+/* transform skip of n luma residual blocks (4..32 per side; VVCX_TOOL_TS): ≙ the {DCT2, TS} pruning of TrQuant::transformNxN (CL/TrQuant.cpp:1049-1124; keep = the
+ * transform-skip candidate survives), xTransformSkip 1394-1440, QuantRDOQ::xRateDistOptQuantTS (CL/QuantRDOQ.cpp:1243-1483, reached through DepQuant::quant for
+ * MTS_SKIP blocks) with rates from the context models s0 / s1 and the quantiser's lambda, Quant::dequant + xITransformSkip 996-1041 (resi_out), and the fractional
+ * bits CABACWriter::residual_codingTS (EL/CABACWriter.cpp:4306-4555) spends on the levels.  qp = slice QP + QpBDOffset (the TS minimum QP 4 is applied inside). */
+int  vvcx_transform_skip_batch(const int16_t *resi, int w, int h, int bit_depth, int qp, double lambda, const uint16_t *s0, const uint16_t *s1, int n,
+                               int16_t *lev, int16_t *resi_out, int32_t *abs_sum, uint8_t *keep, uint64_t *frac_bits, int device);
 /* coefficient scan (diagonal, grouped) of a w x h block: idx[min(w,32) * min(h,32)] raster offsets in scan order */
 int  vvcx_scan_order(int w, int h, uint16_t *idx, int device);
 /* ≙ BIN/TEST.py GetPartition(C0..C25, 2): the forest of vvcx_set_forest on n rows of 26 int32 features (host pointers) → class per row */

@@ -30,6 +30,7 @@ extern "C" __global__ void vvcx_deblock_kernel_u16(VxDeblockParams p);
 extern "C" __global__ void vvcx_jccr_sign_kernel_u8(VxFrameDev *frames, int wc, int hc);
 extern "C" __global__ void vvcx_jccr_sign_kernel_u16(VxFrameDev *frames, int wc, int hc);
 extern "C" __global__ void vvcx_leaf_dq_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int qp, int comp, int mts, int cbf_cb, unsigned long long *out, int lf, int lfdir);
+extern "C" __global__ void vvcx_leaf_ts_kernel(VxParams p, const uint16_t *ctx, const int16_t *resi, int16_t *lev, int16_t *resi_out, int32_t *tmp, int w, int h, int qp, int *out, unsigned long long *bits);
 extern "C" __global__ void vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp, unsigned long long *out);
 
 static thread_local char g_err[512];
@@ -73,7 +74,8 @@ struct vvcx_handle {
 };
 
 #define VVCX_PAYLOAD_BYTES_PER_CTU 32768u
-static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_LFNST | VVCX_TOOL_MTS | VVCX_TOOL_JCCR | VVCX_TOOL_DEPQUANT | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST;
+static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_LFNST | VVCX_TOOL_MTS | VVCX_TOOL_JCCR | VVCX_TOOL_DEPQUANT | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST |
+                                    VVCX_TOOL_TS | VVCX_TOOL_RDOQ;
 
 // Quantizer::initQuantBlock (CL/DepQuant.cpp:694-739) for blocks with log2 w + log2 h = lsum: the quantiser's shift / scale / thresholds and the fixed-point
 // distortion normalisation, which the reference derives in fp64 from lambda.  qp: what QpParam hands over (with QpBDOffset).
@@ -112,6 +114,10 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   // and on the search's MIP form of the saved mode lists (EL/IntraSearch.cpp:750-775)
   if ((cfg->tools & VVCX_TOOL_LFNST) && (cfg->tools & (VVCX_TOOL_DEPQUANT | VVCX_TOOL_MIP)) != (VVCX_TOOL_DEPQUANT | VVCX_TOOL_MIP))
     return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_LFNST needs VVCX_TOOL_DEPQUANT and VVCX_TOOL_MIP (tool set 0x%x)", cfg->tools);
+  // transform skip is searched inside the LFNST pass structure and quantised by RDOQ-TS the way DepQuant::quant reaches it (CL/DepQuant.cpp:1755-1781); RDOQ alone (the
+  // cfg sets RDOQ / RDOQTS beside DepQuant) only acts on transform-skip blocks
+  if ((cfg->tools & VVCX_TOOL_TS) && (cfg->tools & (VVCX_TOOL_DEPQUANT | VVCX_TOOL_LFNST)) != (VVCX_TOOL_DEPQUANT | VVCX_TOOL_LFNST))
+    return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_TS needs VVCX_TOOL_DEPQUANT and VVCX_TOOL_LFNST (tool set 0x%x)", cfg->tools);
   if ((cfg->tools & VVCX_TOOL_JCCR) && !(cfg->tools & VVCX_TOOL_DEPQUANT)) return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_JCCR needs VVCX_TOOL_DEPQUANT (tool set 0x%x)", cfg->tools);
   if (cfg->ctu_size != 128 || !cfg->dual_tree) return fail(VVCX_ERR_UNSUPPORTED, "only CTUSize 128 with DualITree 1");
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7) || cfg->pic_w <= 0 || cfg->pic_h <= 0) return fail(VVCX_ERR_ARG, "picture size must be a positive multiple of 8");
@@ -838,6 +844,34 @@ extern "C" int vvcx_lfnst_depquant_batch(const int16_t *org, const int16_t *pred
 {
   if (lfnst_idx < 0 || lfnst_idx > 2 || intra_dir < 0 || intra_dir > 66) return fail(VVCX_ERR_ARG, "bad argument");
   return depquant_batch_impl(org, pred, w, h, bit_depth, qp, comp, 0, cbf_cb, lambda, s0, s1, n, lev, rec, sse, cbf, device, lfnst_idx, intra_dir);
+}
+
+// ≙ TrQuant::transformNxN / invTransformNxN of a luma TU with tu.mtsIdx = MTS_SKIP and the {DCT2, TS} pruning in front of it (CL/TrQuant.cpp:1049-1124, 1394-1440, 996-1041),
+// QuantRDOQ::xRateDistOptQuantTS (CL/QuantRDOQ.cpp:1243-1483), CABACWriter::residual_codingTS (EL/CABACWriter.cpp:4306-4555) for n residual blocks (host pointers, stride w):
+// levels, reconstructed residual, absSum, whether the pruning keeps the candidate, and the fractional bits of the levels from the given context models
+extern "C" int vvcx_transform_skip_batch(const int16_t *resi, int w, int h, int bit_depth, int qp, double lambda, const uint16_t *s0, const uint16_t *s1, int n,
+                                         int16_t *lev, int16_t *resi_out, int32_t *abs_sum, uint8_t *keep, uint64_t *frac_bits, int device)
+{
+  if (!resi || !lev || !resi_out || !abs_sum || !keep || !frac_bits || !s0 || !s1 || n < 0 || !pow2_block(w, h) || w < 4 || h < 4 || w > 32 || h > 32 || (bit_depth != 8 && bit_depth != 10) ||
+      qp < 0 || qp > 75 || !(lambda > 0.0)) return fail(VVCX_ERR_ARG, "bad argument");
+  if (n == 0) return VVCX_OK;
+  HIPCHK(hipSetDevice(device));
+  const size_t bytes = (size_t) n * w * h * 2;
+  DevBuf dres, dout, dlev, dtmp, do2, dbits, dctx;
+  HIPCHK(dres.alloc(bytes)); HIPCHK(dout.alloc(bytes)); HIPCHK(dlev.alloc(bytes)); HIPCHK(dtmp.alloc((size_t) n * 2048 * 4)); HIPCHK(do2.alloc((size_t) n * 8)); HIPCHK(dbits.alloc((size_t) n * 8));
+  HIPCHK(dctx.alloc(2 * VXD_NUM_CTX * 2));
+  HIPCHK(hipMemcpy(dres.p, resi, bytes, hipMemcpyHostToDevice)); HIPCHK(hipMemset(dout.p, 0, bytes));
+  HIPCHK(hipMemcpy(dctx.p, s0, VXD_NUM_CTX * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dctx.as<uint16_t>() + VXD_NUM_CTX, s1, VXD_NUM_CTX * 2, hipMemcpyHostToDevice));
+  VxParams p; memset(&p, 0, sizeof p);
+  p.bit_depth = bit_depth; p.tools = VVCX_TOOL_DEPQUANT | VVCX_TOOL_LFNST | VVCX_TOOL_TS; p.lambda = lambda;
+  hipLaunchKernelGGL(vvcx_leaf_ts_kernel, dim3((unsigned) n), dim3(VXD_NT), 0, 0, p, dctx.as<uint16_t>(), dres.as<int16_t>(), dlev.as<int16_t>(), dout.as<int16_t>(), dtmp.as<int32_t>(), w, h, qp,
+                     do2.as<int>(), dbits.as<unsigned long long>());
+  HIPCHK(hipGetLastError());
+  std::vector<int> o((size_t) n * 2);
+  HIPCHK(hipMemcpy(lev, dlev.p, bytes, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(resi_out, dout.p, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(o.data(), do2.p, (size_t) n * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(frac_bits, dbits.p, (size_t) n * 8, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) { abs_sum[i] = o[(size_t) i * 2]; keep[i] = (uint8_t) o[(size_t) i * 2 + 1]; }
+  return VVCX_OK;
 }
 
 // slice_data() payload of one tile of a bound frame (≙ the sub-stream EncSlice::encodeSlice hands to the NAL writer, EL/EncSlice.cpp:1884-2006)

@@ -121,9 +121,11 @@ struct VxRbItem { double cost; uint64_t dist, bits; int32_t cbf, sum0, test, wav
 #define VXD_OFF_POOL_COEF  (VXD_OFF_POOL + VXD_POOL_ELEMS * 2)
 #define VXD_OFF_POOL_NODES (VXD_OFF_POOL_COEF + VXD_POOL_ELEMS * 2)
 #define VXD_OFF_POOL_REC   (VXD_OFF_POOL_NODES + VXD_POOL_NODE_BYTES)
-#define VXD_OFF_CACHE   ((VXD_OFF_POOL_REC + 2 * VXD_POOL_ITEMS * (int) sizeof(VxRbItem) + 255) & ~255)
+// JointCbCr: per wave joint residual | its reconstruction | levels | best pair of reconstructions | best levels (6 x 1024 int16).  In front of the CU cache: a handle
+// without VVCX_TOOL_CU_REUSE gets VXD_OFF_CACHE bytes per stream and everything the other tools touch has to lie below that
+#define VXD_OFF_JCCR    ((VXD_OFF_POOL_REC + 2 * VXD_POOL_ITEMS * (int) sizeof(VxRbItem) + 255) & ~255)
+#define VXD_JCCR_WAVE   (6 * 1024 * 2)
+#define VXD_OFF_CACHE   ((VXD_OFF_JCCR + VXD_NW * VXD_JCCR_WAVE + 255) & ~255)
 #define VXD_OFF_CACHE_LEV (VXD_OFF_CACHE + VXD_CACHE_ENTRIES * (int) sizeof(VxCacheEnt))
 #define VXD_OFF_META    (VXD_OFF_CACHE_LEV + VXD_CACHE_DIM * VXD_CACHE_DIM * 2)      // uint32: CTU generations this scratch slot has seen (validates CU-cache entries)
-#define VXD_OFF_JCCR    (VXD_OFF_META + 256)                                          // JointCbCr: per wave joint residual | its reconstruction | levels | best pair of reconstructions | best levels (6 x 1024 int16)
-#define VXD_JCCR_WAVE   (6 * 1024 * 2)
-#define VXD_SCRATCH_BYTES (VXD_OFF_JCCR + VXD_NW * VXD_JCCR_WAVE)
+#define VXD_SCRATCH_BYTES (VXD_OFF_META + 256)

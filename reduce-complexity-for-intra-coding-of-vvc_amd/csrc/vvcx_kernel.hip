@@ -49,6 +49,7 @@ enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_B
 #define TOOL_LFNST (1u << 3)
 #define MIPF 0x80                  // a MIP CU: bit 7 of the unit's / candidate's mrl field (MIP forces multiRefIdx 0), the MIP mode in dir / mode
 #define TOOL_MTS (1u << 4)
+#define TOOL_TS (1u << 5)
 #define TOOL_DEPQUANT (1u << 6)
 #define TOOL_CCLM (1u << 8)
 #define TOOL_JCCR (1u << 9)
@@ -162,6 +163,7 @@ struct Lds {
   int8_t ps_lfnst, ps_mts, ps_grp, ps_pad; int rc_last[NW]; uint8_t rd_lfl[16];
   // the DST-VII pass prepared by the DCT-II pass (stage_b_rounds): number of prepared items (0: none), item of each candidate of the running pass, absSum per item
   int8_t spec_n; uint8_t rd_src[16]; int spec_abs[16];
+  int ts_tab[36]; uint8_t ts_keep[16];   // transform skip: fractional bits of the TS context sets at the node's start contexts (ts_build_tables); candidates of the chunk that try it
   int dc_val[4];
   int cur_tile, frame, ctu_x, ctu_y, tree_ch;
   int d;                           // current recursion level
@@ -1882,6 +1884,225 @@ __device__ inline void enc_lfnst_idx(Cab &cb, int ch, int w, int h, int mip, int
   if (lfnst) enc_ep<WR>(cb, (uint32_t) (lfnst - 1), 1);
 }
 
+// ------------------------------------------------------------------------------------------------ transform skip (VVCX_TOOL_TS)
+// A luma TU of at most 32x32 may skip the transform (tu.mtsIdx = MTS_SKIP = 1): xTransformSkip / xITransformSkip (CL/TrQuant.cpp:1394-1440, 996-1041) scale the residual,
+// QuantRDOQ::xRateDistOptQuantTS (CL/QuantRDOQ.cpp:1243-1483; DepQuant::quant hands MTS_SKIP luma blocks to it, CL/DepQuant.cpp:1755-1781) picks the levels with rates
+// read from the TS context sets, Quant::dequant (CL/Quant.cpp:423-549) without the sqrt(2) adjustment at max(QP', 4) inverts it, and residual_codingTS
+// (EL/CABACWriter.cpp:4306-4555) codes the levels in forward scan order with a budget of 2 * w * h context-coded bins.  BDPCM is off (BIN/encoder_intra.cfg).
+__device__ inline int ts_allowed(const VxParams &p, int w, int h) { return (p.tools & TOOL_TS) && w <= 32 && h <= 32; }      // TU::isTSAllowed (CL/UnitTools.cpp:4524-4546), TransformSkipLog2MaxSize 5
+__device__ inline int ts_shift(int w, int h, int bd) { return 15 - bd - ((ilog2i(w) + ilog2i(h)) >> 1); }                     // getTransformShift, TU::needsSqrt2Scale false for TS
+__device__ inline int ts_scale(int r, int sh) { return sh >= 0 ? r * (1 << sh) : (r + (1 << (-sh - 1))) >> -sh; }
+__device__ inline int ts_qp(int qp) { return imax(qp, 4); }                                                                   // QpParam::Qp(isTransformSkip), min_qp_prime_ts_minus4 0
+// CABACWriter::mts_coding 3885-3941 of a luma TU with cbf (not an ISP one): transform_skip_flag where TU::isTSAllowed, then the MTS index where TU::isMTSAllowed
+template <bool WR = false>
+__device__ inline void enc_tu_mts(Cab &cb, int w, int h, int mts)
+{
+  if (ts_allowed(L.par, w, h)) enc_bin<WR>(cb, (unsigned) (mts == 1), VX_CTX_MTSIndex + 6);
+  if (mts != 1 && mts_allowed(L.par, w, h)) enc_mts_idx<WR>(cb, mts);
+}
+// neighTS / deriveModCoeff / signCtxIdAbsTS / templateAbsSumTS (CL/ContextModelling.h:221-360, bdpcm 0)
+__device__ inline int ts_mod_coeff(int right, int below, int a) { const int pm = imax(iabs(below), iabs(right)); return a == pm ? 1 : (a < pm ? a + 1 : a); }
+__device__ inline int ts_sign_ctx(int right, int below) { if ((right == 0 && below == 0) || (right * below) < 0) return 0; return (right >= 0 && below >= 0) ? 1 : 2; }
+__device__ inline int ts_rice(int right, int below) { const int s = imin(iabs(right) + iabs(below), 31); return s < 12 ? 0 : s < 25 ? 1 : 2; }     // g_auiGoRiceParsCoeff-style table of templateAbsSumTS
+enum { TST_SIG = 0, TST_SIGN = 6, TST_GT1 = 12, TST_PAR = 18, TST_GTX = 20, TST_GRP = 28, TST_N = 34 };
+// fractional bits of the TS context sets at the estimator's current state ([set + 2 * ctx + bin]); all threads, the caller synchronises
+__device__ inline void ts_build_tables()
+{
+  const int t = VTX;
+  if (t < TST_N) {
+    int ctx;
+    if (t < TST_SIGN) ctx = VX_CTX_TsSigFlag + (t >> 1);
+    else if (t < TST_GT1) ctx = VX_CTX_TsResidualSign + ((t - TST_SIGN) >> 1);
+    else if (t < TST_PAR) ctx = VX_CTX_TsLrg1Flag + ((t - TST_GT1) >> 1);
+    else if (t < TST_GTX) ctx = VX_CTX_TsParFlag;
+    else if (t < TST_GRP) ctx = VX_CTX_TsGtxFlag + 1 + ((t - TST_GTX) >> 1);
+    else ctx = VX_CTX_TsSigCoeffGroup + ((t - TST_GRP) >> 1);
+    L.ts_tab[t] = (int) frac_bits_of(L.ctxs[CI_CUR], ctx, (unsigned) (t & 1));
+  }
+}
+// xGetICRateTS (CL/QuantRDOQ.cpp:1898-1976): bits of a level whose modified magnitude is a
+__device__ inline int ts_ic_rate(unsigned a, int signRate, int numPos, int rice)
+{
+  if (a == 0) return 0;
+  int rate = signRate;
+  if (a == 1) return rate + L.ts_tab[TST_GT1 + 2 * numPos];
+  rate += L.ts_tab[TST_GT1 + 2 * numPos + 1] + L.ts_tab[TST_PAR + ((a - 2) & 1)];
+  unsigned cutoff = 2;
+  for (int i = 0; i < 4; i++) { if (a >= cutoff) rate += L.ts_tab[TST_GTX + 2 * i + (a >= cutoff + 2)]; cutoff += 2; }
+  if (a >= cutoff) {
+    unsigned symbol = (a - cutoff) >> 1, length;
+    if (symbol < (5u << rice)) { length = symbol >> rice; rate += (int) ((length + 1 + (unsigned) rice) << 15); }
+    else { length = (unsigned) rice; symbol -= 5u << rice; while (symbol >= (1u << length)) symbol -= 1u << (length++); rate += (int) ((5 + length + 1 - (unsigned) rice + length) << 15); }
+  }
+  return rate;
+}
+// xRateDistOptQuantTS of one block by ONE lane (the decisions form a chain through the left / above levels and the running cost): cf holds the transform-skip
+// "coefficients" (stride w) and receives the levels; rates from L.ts_tab.  Returns absSum.  The blocks of a node's candidates run side by side on different lanes.
+__device__ __noinline__ int ts_rdoq_lane(int16_t *cf, int w, int h, int bd, int qp)
+{
+  const int q = ts_qp(qp), tshift = ts_shift(w, h, bd), qBits = 14 + q / 6 + tshift, qc = L.t.qscale[q % 6];
+  const int e2 = 15 - 2 * tshift;                                   // xGetErrScaleCoeff 383-392: 2^15 * 2^(-2 * transformShift) / scale^2
+  const double errorScale = (e2 >= 0 ? (double) (1ll << e2) : 1.0 / (double) (1ll << -e2)) / (double) qc / (double) qc;
+  const double lambda = L.par.lambda;
+  const int ecMax = (1 << 15) - 1, lw = ilog2i(w);
+  const ScanGeo g = scan_geo(w, h);
+  const int sbSize = 1 << g.lcg, sbNum = (w * h) >> g.lcg;
+  const long long cap = 2147483647ll - (1ll << (qBits - 1)), rnd = 1ll << (qBits - 1);
+  unsigned long long sigMap = 0; int anySigCG = 0, absSum = 0;
+  double baseCost = 0.0;
+  for (int sb = 0; sb < sbNum; sb++) {
+    const int cgx = g.grp[sb] & 15, cgy = g.grp[sb] >> 4, cgPos = cgy * g.wg + cgx;
+    const int sigLeft = cgx > 0 ? (int) ((sigMap >> (cgPos - 1)) & 1) : 0, sigAbove = cgy > 0 ? (int) ((sigMap >> (cgPos - g.wg)) & 1) : 0;
+    const int fGrp0 = L.ts_tab[TST_GRP + 2 * (sigLeft + sigAbove)], fGrp1 = L.ts_tab[TST_GRP + 2 * (sigLeft + sigAbove) + 1];
+    int noCoeffCoded = 0, cgSig = 0, cgAbs = 0;
+    double sigCost = 0, codedLevelandDist = 0, uncodedDist = 0;
+    for (int k = 0; k < sbSize; k++) {
+      const int blk = scan_blk(g, (sb << g.lcg) + k), y = blk >> lw, x = blk & (w - 1);
+      const int c = cf[blk];
+      const long long tmpLevel = (long long) iabs(c) * qc, levelDouble = tmpLevel < cap ? tmpLevel : cap;
+      const unsigned roundAbs = (unsigned) imin(ecMax, (int) ((levelDouble + rnd) >> qBits));
+      const unsigned minAbs = roundAbs > 1 ? roundAbs - 1 : 1;
+      const unsigned downAbs = (unsigned) imin(ecMax, (int) (levelDouble >> qBits)), upAbs = (unsigned) imin(ecMax, (int) downAbs + 1);
+      const int right = x > 0 ? cf[blk - 1] : 0, below = y > 0 ? cf[blk - w] : 0;
+      const unsigned l1 = minAbs != roundAbs ? minAbs : 0xffffffffu;                    // the levels tested after roundAbs (0xffffffff: none)
+      const unsigned l2 = (upAbs != roundAbs && upAbs != minAbs && ts_mod_coeff(right, below, (int) upAbs) == 1) ? upAbs : 0xffffffffu;
+      const double cost0 = (double) levelDouble * (double) levelDouble * errorScale;
+      const int numPos = (right != 0) + (below != 0);
+      const int rice = ts_rice(right, below);
+      const int signRate = L.ts_tab[TST_SIGN + 2 * ts_sign_ctx(right, below) + (c < 0)];
+      const int isLast = k == sbSize - 1 && noCoeffCoded == 0;
+      // xGetCodedLevelTSPred 1773-1836
+      unsigned best = 0; double costCoeff, costSig = 0, currCostSig = 0; int done = 0;
+      if (!isLast && roundAbs < 3) {
+        costSig = lambda * (double) L.ts_tab[TST_SIG + 2 * numPos];
+        costCoeff = cost0 + costSig;
+        if (roundAbs == 0) done = 1;
+      } else costCoeff = MAX_DOUBLE;
+      if (!done) {
+        if (!isLast) currCostSig = lambda * (double) L.ts_tab[TST_SIG + 2 * numPos + 1];
+        for (int e = 0; e < 3; e++) {
+          const unsigned a = e == 0 ? roundAbs : e == 1 ? l1 : l2;
+          if (a == 0xffffffffu) continue;
+          const double dErr = (double) (levelDouble - ((long long) a << qBits));
+          const double err = dErr * dErr * errorScale;
+          double cur = err + lambda * (double) ts_ic_rate((unsigned) ts_mod_coeff(right, below, (int) a), signRate, numPos, rice);
+          cur += currCostSig;
+          if (cur < costCoeff) { best = a; costCoeff = cur; costSig = currCostSig; }
+        }
+      }
+      if (best > 0) noCoeffCoded++;
+      cf[blk] = (int16_t) ((best != 0 && c < 0) ? -(int) best : (int) best);
+      baseCost += costCoeff;
+      sigCost += costSig;
+      if (best) { cgSig = 1; cgAbs += (int) best; codedLevelandDist += costCoeff - costSig; uncodedDist += cost0; }
+    }
+    if (!cgSig) baseCost += lambda * (double) fGrp0 - sigCost;
+    else {
+      sigMap |= 1ull << cgPos;
+      if (sb != sbNum - 1 || anySigCG) {
+        double costZeroSB = baseCost;
+        baseCost += lambda * (double) fGrp1;
+        costZeroSB += lambda * (double) fGrp0;
+        costZeroSB += uncodedDist;
+        costZeroSB -= codedLevelandDist;
+        costZeroSB -= sigCost;
+        if (costZeroSB < baseCost) {
+          sigMap &= ~(1ull << cgPos); baseCost = costZeroSB; cgAbs = 0;
+          for (int k = 0; k < sbSize; k++) cf[scan_blk(g, (sb << g.lcg) + k)] = 0;
+        } else anySigCG = 1;
+      }
+    }
+    absSum += cgAbs;
+  }
+  return absSum;
+}
+// residual_codingTS + residual_coding_subblockTS (EL/CABACWriter.cpp:4306-4555, JVET_O0122 / O0409 / O0619 forms) on the estimator / writer: one thread
+template <bool WR = false>
+__device__ __noinline__ void rc_ts_serial(Cab &cb, const int16_t *lv, int w, int h)
+{
+  const ScanGeo g = scan_geo(w, h);
+  const int n = w * h, cgSize = 1 << g.lcg, nsub = n >> g.lcg, lw = ilog2i(w);
+  int remBins = 2 * n;                                  // setNumCtxBins; isContextCoded() = --remaining >= 0
+#define TS_BIN(bin_, ctx_) { if (--remBins >= 0) enc_bin<WR>(cb, (unsigned) (bin_), (ctx_)); else enc_ep<WR>(cb, (uint32_t) (bin_), 1); }
+  unsigned long long sigScan = 0, sigR = 0;             // significant groups by scan index / those met so far by raster position
+  for (int sp = 0; sp < n; sp++) if (lv[scan_blk(g, sp)]) sigScan |= 1ull << (sp >> g.lcg);
+  int nSet = 0;                                         // m_sigCoeffGroupFlag.count()
+  for (int sub = 0; sub < nsub; sub++) {
+    const int cgx = g.grp[sub] & 15, cgy = g.grp[sub] >> 4, cgPos = cgy * g.wg + cgx;
+    const int sig = (int) ((sigScan >> sub) & 1);
+    if (sig && !((sigR >> cgPos) & 1)) { sigR |= 1ull << cgPos; nSet++; }
+    const int sigLeft = cgx > 0 ? (int) ((sigR >> (cgPos - 1)) & 1) : 0, sigAbove = cgy > 0 ? (int) ((sigR >> (cgPos - g.wg)) & 1) : 0;
+    const int grpCtx = VX_CTX_TsSigCoeffGroup + sigLeft + sigAbove;
+    const int minSub = sub << g.lcg, maxSub = minSub + cgSize - 1;
+    const int only1st = nSet - (int) ((sigR >> (nsub - 1)) & 1) == 0;      // only1stSigGroup: the last group's raster position is its scan index
+    if (sub != nsub - 1 || !only1st) {
+      enc_bin<WR>(cb, (unsigned) sig, grpCtx);
+      if (!sig) continue;
+    }
+    int numNonZero = 0;
+    for (int sp = minSub; sp <= maxSub; sp++) {
+      const int blk = scan_blk(g, sp), cf = lv[blk], y = blk >> lw, x = blk & (w - 1);
+      const int right = x > 0 ? lv[blk - 1] : 0, below = y > 0 ? lv[blk - w] : 0, numPos = (right != 0) + (below != 0);
+      if (numNonZero || sp != maxSub) TS_BIN(cf != 0, VX_CTX_TsSigFlag + numPos);
+      if (cf) {
+        TS_BIN(cf < 0, VX_CTX_TsResidualSign + ts_sign_ctx(right, below));
+        numNonZero++;
+        int rem = ts_mod_coeff(right, below, iabs(cf)) - 1;
+        TS_BIN(rem != 0, VX_CTX_TsLrg1Flag + numPos);
+        if (rem) { rem -= 1; TS_BIN(rem & 1, VX_CTX_TsParFlag); }
+      }
+    }
+    for (int sp = minSub; sp <= maxSub; sp++) {
+      const int blk = scan_blk(g, sp), y = blk >> lw, x = blk & (w - 1);
+      const unsigned a = (unsigned) ts_mod_coeff(x > 0 ? lv[blk - 1] : 0, y > 0 ? lv[blk - w] : 0, iabs(lv[blk]));
+      unsigned cutoff = 2;
+      for (int i = 0; i < 4; i++) { if (a >= cutoff) TS_BIN(a >= cutoff + 2, VX_CTX_TsGtxFlag + (int) (cutoff >> 1)); cutoff += 2; }
+    }
+    for (int sp = minSub; sp <= maxSub; sp++) {
+      const int blk = scan_blk(g, sp), y = blk >> lw, x = blk & (w - 1);
+      const int right = x > 0 ? lv[blk - 1] : 0, below = y > 0 ? lv[blk - w] : 0;
+      const unsigned a = (unsigned) ts_mod_coeff(right, below, iabs(lv[blk]));
+      if (a >= 10) enc_rem_abs<WR>(cb, (a - 10) >> 1, (unsigned) ts_rice(right, below));
+    }
+  }
+#undef TS_BIN
+}
+// sum |xTransformSkip(org - pred)| scaled as TrQuant::transformNxN (1049-1124) scales the transform-skip entry of its pruning; optionally the coefficients to coef_out
+__device__ inline int wave_ts_fwd(const int16_t *org, const int16_t *pred, int16_t *coef_out, int w, int h, int bd, int lane)
+{
+  const int P = w * h, sh = ts_shift(w, h, bd);
+  int sa = 0;
+  for (int e = lane; e < P; e += 64) { const int c = ts_scale(org[e] - pred[e], sh); if (coef_out) coef_out[e] = (int16_t) c; sa += iabs(c); }
+  sa = wave_sum_i32(sa);
+  const double scale = ((ilog2i(w) + ilog2i(h)) & 1) ? 1.0 / 1.414213562 : 1.0;
+  return (int) ((double) sa * scale);
+}
+// decoder half of a transform-skip block by one wave: Quant::dequant, xITransformSkip, reconstruction over the prediction in rec, SSE against org.
+// raw: rec receives the bare residual (leaf test).  cbf 0: the prediction is the reconstruction.
+__device__ __noinline__ void wave_ts_recon(const int16_t *org, int16_t *rec, const int16_t *lev, int w, int h, int bd, int qp, int cbf, int lane, unsigned long long &sse_out, int raw = 0)
+{
+  w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); cbf = uni(cbf);
+  const int P = w * h, q = ts_qp(qp), sh = ts_shift(w, h, bd), scale = L.t.iqscale[q % 6], right_shift = 6 - (sh + q / 6), mx = (1 << bd) - 1;
+  int tbd = 32 + right_shift - 7; if (tbd > 16) tbd = 16;
+  const int in_min = -(1 << (tbd - 1)), in_max = (1 << (tbd - 1)) - 1;
+  unsigned long long sse = 0;
+  for (int e = lane; e < P; e += 64) {
+    int r = 0;
+    if (cbf) {
+      int l = lev[e]; l = l < in_min ? in_min : l > in_max ? in_max : l;
+      int v = right_shift > 0 ? (l * scale + (1 << (right_shift - 1))) >> right_shift : (l * scale) * (1 << -right_shift);
+      v = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+      r = (int) (int16_t) (sh >= 0 ? (v + (sh == 0 ? 0 : 1 << (sh - 1))) >> sh : v * (1 << -sh));
+    }
+    if (raw) { rec[e] = (int16_t) r; continue; }
+    int v = rec[e] + r; v = v < 0 ? 0 : v > mx ? mx : v;
+    rec[e] = (int16_t) v;
+    const int d = org[e] - v; sse += (unsigned long long) (d * d);
+  }
+  wave_sync();
+  sse_out = wave_sum_u64(sse);
+}
+
 // ------------------------------------------------------------------------------------------------ parallel operations
 // candidate slots: nrec = reconstruction samples held (w*h luma, 2*cw*ch chroma).  Slot 0 of blocks up to 1024 samples is
 // in LDS; slot 1 (only used when a wave evaluates more than one full-RD candidate) and bigger blocks are in HBM scratch.
@@ -2229,6 +2450,8 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
   // LFNST on: one transform per pass for every candidate (DCT-II with the pass's LFNST kernel, or the pass's MTS pair), no per-block MTS pruning
   const int lfOn = uni((int) (p.tools & TOOL_LFNST)) != 0, psLf = lfOn ? uni((int) L.ps_lfnst) : 0, psMts = lfOn ? uni((int) L.ps_mts) : 0, psGrp = uni((int) L.ps_grp);
   const int pruneOk = mtsOk && !lfOn;
+  // transform skip: in the pass without LFNST and MTS every candidate's TU also tries MTS_SKIP (xRecurIntraCodingLumaQT 3349-3367, 3505-3517) unless the pruning drops it
+  const int tsOn = lfOn && !psLf && !psMts && ts_allowed(p, w, h);
   int16_t *poolPred = (int16_t *) (scratch + VXD_OFF_POOL), *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF);
   VxRbItem *recA = (VxRbItem *) (scratch + VXD_OFF_POOL_REC), *recB = recA + VXD_POOL_ITEMS;
   const int capItems = imin(VXD_POOL_ITEMS, imin(VXD_POOL_ELEMS / P, VXD_POOL_NODE_BYTES / (4 * total)));
@@ -2266,7 +2489,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       if (mtsC) wave_code_block_mts<SMALL>(org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, mtsC, lane, sse, cbf, -2);
       else wave_code_block<SMALL, true>(org, 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf, -2, &sum0, 0, 0, 0, psLf, psLf ? lfnst_mode(mip ? PLANAR : mode, w, h) : 0);
       for (int e = lane; e < P; e += 64) poolCoef[(size_t) i * P + e] = lev[e];
-      if (lane == 0) { recA[i].sum0 = sum0; recA[i].test = 0; }
+      if (lane == 0) { recA[i].sum0 = sum0; recA[i].test = 0; recB[i].sum0 = sum0; }      // recB: the DCT-II sum survives A3 for the transform-skip pruning
       if (specGen) {                                        // rec still holds the prediction (forward-only calls leave it alone)
         wave_code_block_mts<SMALL>(org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, 2, lane, sse, cbf, -2);
         for (int e = lane; e < P; e += 64) poolCoef[(size_t) (nA + i) * P + e] = lev[e];
@@ -2298,7 +2521,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       wave_sync();
       double cost = 0;
       Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
-      if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, mrl); enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[0]); if (cbf && mtsOk) enc_mts_idx(cb, mtsC); }
+      if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, mrl); enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[0]); if (cbf) enc_tu_mts(cb, w, h, mtsC); }
       if (cbf) residual_coding_wave<SMALL>(cb, 0, lev, w, h, 0, lane, mtsC > 1);
       if (lane == 0) { cost = rd_cost(p, cb.bits, sse); recA[i].cost = cost; recA[i].dist = sse; recA[i].bits = cb.bits; recA[i].cbf = cbf; recA[i].wave = wave; if (lfOn) { recA[i].sum0 = (mtsC << 8) | (cbf ? lfnst_flags(L.rc_last[wave], w, h) : 0); recA[i].test = 0; } }
       cost = lane0_d(cost);
@@ -2326,6 +2549,60 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
     }
     __threadfence_block();
     __syncthreads();
+    if (tsOn) {
+      // ---- T1: which candidates keep the transform-skip candidate (sum of its scaled residual against the DCT-II sum, TrQuant::transformNxN 1049-1124); their
+      // "coefficients" replace the consumed DCT-II levels in the coefficient pool
+      ts_build_tables();
+      for (int i = wave; i < nA; i += NW) {
+        const int sa = wave_ts_fwd(org, poolPred + (size_t) i * P, poolCoef + (size_t) i * P, w, h, bd, lane);
+        if (lane == 0) L.ts_keep[i] = (uint8_t) ((double) sa <= (double) recB[i].sum0);
+      }
+      __threadfence_block();
+      __syncthreads();
+      // ---- T2: RDOQ-TS of the kept blocks, one lane each (every block starts from the node's contexts), spread over the waves
+      {
+        const int j = lane * NW + wave;
+        int cnt = 0, mine = -1;
+        for (int i = 0; i < nA; i++) if (L.ts_keep[i]) { if (cnt == j) mine = i; cnt++; }
+        if (mine >= 0) L.dq_abs[mine] = ts_rdoq_lane(poolCoef + (size_t) mine * P, w, h, bd, p.qp_tr);
+      }
+      __threadfence_block();
+      __syncthreads();
+      // ---- T3: reconstruction, rate and cost of the non-empty ones (an empty transform-skip block is forbidden, 3567-3571); strict < against the candidate's DCT-II result
+      for (int i = wave; i < nA; i += NW) {
+        if (!uni((int) L.ts_keep[i])) continue;
+        nmts++;
+        if (uni(L.dq_abs[i]) <= 0) continue;
+        const int c = c0 + i, mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
+        int16_t *rec = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, P, wave, cur);
+        for (int e = lane; e < P; e += 64) { rec[e] = poolPred[(size_t) i * P + e]; lev[e] = poolCoef[(size_t) i * P + e]; }
+        { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s[e]; }
+        wave_sync();
+        unsigned long long sse;
+        wave_ts_recon(org, rec, lev, w, h, bd, p.qp_tr, 1, lane, sse);
+        double cost = 0; int better = 0;
+        Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
+        if (lane == 0) {
+          enc_intra_luma_pred_mode(cb, L.ny, mode, mrl); enc_bin(cb, 1u, VX_CTX_QtCbf[0]); enc_tu_mts(cb, w, h, 1);
+          rc_ts_serial(cb, lev, w, h);
+          cost = rd_cost(p, cb.bits, sse);
+          better = cost < recA[i].cost;
+          if (better) { recA[i].cost = cost; recA[i].dist = sse; recA[i].bits = cb.bits; recA[i].cbf = 1; recA[i].wave = wave; recA[i].sum0 = 1 << 8; }      // tu.mtsIdx 1; a transform-skip block leaves the LFNST conditions alone (3837-3850)
+        }
+        cost = lane0_d(cost);
+        wave_sync();
+        if (cost < wbest || (cost == wbest && c * 8 + 1 < wkey)) {
+          wbest = cost; wkey = c * 8 + 1;
+          if (lane == 0) { L.wave_best[wave] = c; L.wave_slot[wave] = SMALL ? 1 : cur; }
+          if (SMALL) { int16_t *pr = slot_rec(scratch, P, wave, 1), *pl = slot_lev(scratch, P, wave, 1); for (int e = lane; e < P; e += 64) { pr[e] = rec[e]; pl[e] = lev[e]; } }
+          else cur ^= 1;
+          { uint32_t *d = (uint32_t *) ctx_ptr(scratch, CTX_START, MAXD + wave, 0); const uint32_t *s = (const uint32_t *) &L.ctxs[CI_W(wave)]; for (int e = lane; e < NCTX; e += 64) d[e] = s[e]; }
+        }
+        wave_sync();
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
     // ---- the (candidate, MTS pair) items of this chunk, candidate by candidate in transform order; every thread builds the same list
     const long long q3 = STAMP();
     uint8_t *pi_ = L.rb_pairs;
@@ -2371,7 +2648,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
         wave_sync();
         double cost = 0;
         Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
-        if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, mrl); enc_bin(cb, 1u, VX_CTX_QtCbf[0]); enc_mts_idx(cb, mts); }
+        if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, mrl); enc_bin(cb, 1u, VX_CTX_QtCbf[0]); enc_tu_mts(cb, w, h, mts); }
         residual_coding_wave<SMALL>(cb, 0, lev, w, h, 0, lane, 1);
         if (lane == 0) { cost = rd_cost(p, cb.bits, sse); recB[j].cost = cost; recB[j].dist = sse; recB[j].bits = cb.bits; }
         cost = lane0_d(cost);
@@ -2854,11 +3131,13 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
     wave_sync();
     int cbf;
     const int mts = uni(L.rd_mts[0]), lf = uni((int) L.ps_lfnst);
-    if (mts > 1) wave_code_block_mts<SMALL>(org_tile(scratch, n), recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr, mts, lane, dist, cbf, cbfm & 1);
+    if (mts == 1) wave_ts_recon(org_tile(scratch, n), recb, levb, w, h, bd, p.qp_tr, cbfm & 1, lane, dist);      // a transform-skip block (DecCu::xIntraRecBlk -> xITransformSkip)
+    else if (mts > 1) wave_code_block_mts<SMALL>(org_tile(scratch, n), recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr, mts, lane, dist, cbf, cbfm & 1);
     else wave_code_block<SMALL>(org_tile(scratch, n), 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr, lane, dist, cbf, cbfm & 1, nullptr, 0, 0, 0, lf, lf ? lfnst_mode((fm & MIPF) ? PLANAR : mode, w, h) : 0);
-    if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, fm); enc_bin(cb, (unsigned) (cbfm & 1), VX_CTX_QtCbf[0]); if ((cbfm & 1) && mts_allowed(p, w, h)) enc_mts_idx(cb, mts); }
+    if (lane == 0) { enc_intra_luma_pred_mode(cb, L.ny, mode, fm); enc_bin(cb, (unsigned) (cbfm & 1), VX_CTX_QtCbf[0]); if (cbfm & 1) enc_tu_mts(cb, w, h, mts); }
     int fl = 0;
-    if (cbfm & 1) { residual_coding_wave<SMALL>(cb, 0, levb, w, h, 0, lane, mts > 1); fl = lfnst_flags(uni(L.rc_last[0]), w, h); }
+    if ((cbfm & 1) && mts == 1) { if (lane == 0) rc_ts_serial(cb, levb, w, h); wave_sync(); }
+    else if (cbfm & 1) { residual_coding_wave<SMALL>(cb, 0, levb, w, h, 0, lane, mts > 1); fl = lfnst_flags(uni(L.rc_last[0]), w, h); }
     if (lane == 0) enc_lfnst_idx(cb, 0, w, h, (fm & MIPF) != 0, (cbfm & 1) && mts != 0, fl, lf);
   } else {
     const int lf = (w >= 4 && h >= 4) ? uni((int) L.ps_lfnst) : 0;
@@ -3447,6 +3726,7 @@ __device__ __noinline__ int ctrl_b_done(const VxParams &p_, const VxFrameDev &fd
       }
       if (use_mode_result(p, f, ch, ETM_INTRA, t)) {
         if (S.lfOn) { S.grpBest[S.grp] = t.cost; S.bestSel[S.grp] = 1; S.bestMts = S.mts; S.bestLf = S.lf; }      // 2696-2701
+        if (S.lfOn && !ch && (cu.mts & 7) == 1 && ilog2i(f.w) + ilog2i(f.h) >= 6) S.endLf = 0;                       // 2702-2712: a transform-skip winner of at least 64 samples ends the LFNST passes
         f.best = t; f.has_best = 1;
         set_node(f, d);
         L.op_c = f.nmodes > 1;                          // ETM_POST_DONT_SPLIT still on the stack (not a single predicted mode): its setFromCs caches this result
@@ -3747,7 +4027,7 @@ __device__ __noinline__ void walk_tree(const VxParams &p_, const VxFrameDev &fd_
           enc_intra_luma_pred_mode<WR>(cb, f.y, u->dir, u->mrl);
           enc_bin<WR>(cb, u->cbf & 1, VX_CTX_QtCbf[0]);
           int fl = 0;
-          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; if (mts_allowed(p, W, H)) enc_mts_idx<WR>(cb, u->mts & 7); residual_coding<WR>(cb, lv, W, H, 0, (uint16_t *) (lv + 4096), (u->mts & 7) > 1); fl = lfnst_flags(L.rc_last[0], W, H); }
+          if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; enc_tu_mts<WR>(cb, W, H, u->mts & 7); if ((u->mts & 7) == 1) rc_ts_serial<WR>(cb, lv, W, H); else { residual_coding<WR>(cb, lv, W, H, 0, (uint16_t *) (lv + 4096), (u->mts & 7) > 1); fl = lfnst_flags(L.rc_last[0], W, H); } }
           enc_lfnst_idx<WR>(cb, 0, W, H, (u->mrl & MIPF) != 0, (u->cbf & 1) && (u->mts & 7) != 0, fl, u->mts >> 4);
         } else {
           int fl = 0;
@@ -4010,6 +4290,36 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_dq_kernel(Vx
   } else if (mts > 1) wave_code_block_mts<false>(org + b, rec + b, lev + b, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, mts, lane, sse, cbf);
   else wave_code_block<false>(org + b, 0, 0, rec + b, lev + b, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, lane, sse, cbf, -1, nullptr, comp, CI_CUR, cbf_cb, lf, lf ? lfnst_mode(lfdir, w, h) : 0);
   if (lane == 0) { out[blockIdx.x * 2] = sse; out[blockIdx.x * 2 + 1] = (unsigned long long) cbf; }
+}
+// transform skip of one residual block per workgroup (tests/golden/ts.npz): the pruning decision against the DCT-II sum, xTransformSkip, RDOQ-TS from the given context
+// models, Quant::dequant + xITransformSkip, and the bits residual_codingTS spends on the levels.  resi_out must be zero on entry; out = {absSum, keep} per block
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_ts_kernel(VxParams p, const uint16_t *ctx, const int16_t *resi, int16_t *lev, int16_t *resi_out, int32_t *tmp,
+                                                                              int w, int h, int qp, int *out, unsigned long long *bits)
+{
+  if (VTX == 0) L.par = p;
+  load_tables();
+  for (int i = VTX; i < NCTX; i += NT) { L.ctxs[CI_CUR].s0[i] = ctx[i]; L.ctxs[CI_CUR].s1[i] = ctx[NCTX + i]; }
+  __syncthreads();
+  ts_build_tables();
+  __syncthreads();
+  const int wave = uni(VTX >> 6), lane = VTX & 63, P = w * h, bd = p.bit_depth;
+  if (wave != 0) return;
+  const size_t b = (size_t) blockIdx.x * P;
+  unsigned long long sse; int cbf, sum0 = 0;
+  wave_code_block<false, true>(resi + b, 0, 0, resi_out + b, lev + b, tmp + (size_t) blockIdx.x * 2048, w, h, bd, qp, lane, sse, cbf, -2, &sum0);
+  wave_sync();
+  const int sa = wave_ts_fwd(resi + b, resi_out + b, lev + b, w, h, bd, lane);
+  wave_sync();
+  int a = 0;
+  if (lane == 0) a = ts_rdoq_lane(lev + b, w, h, bd, qp);
+  a = __builtin_amdgcn_readlane(a, 0);
+  wave_sync();
+  wave_ts_recon(resi + b, resi_out + b, lev + b, w, h, bd, qp, a > 0, lane, sse, 1);
+  if (lane == 0) {
+    Cab cb; cb.ci = CI_CUR; cb.bits = 0;
+    if (a > 0) rc_ts_serial(cb, lev + b, w, h);
+    out[blockIdx.x * 2] = a; out[blockIdx.x * 2 + 1] = sa <= sum0; bits[blockIdx.x] = cb.bits;
+  }
 }
 template <typename T>
 __device__ void leaf_pred(const VxParams &p, const VxLeafPred *cases, int16_t *out, const int *out_off)

@@ -19,6 +19,10 @@ TOOL_DEPQUANT = 1 << 6       # dependent quantisation (cfg DepQuant 1): trellis 
 TOOL_CU_REUSE = 1 << 11      # BestEncInfoCache, REUSE_CU_RESULTS (CL/TypeDef.h:291) - on in the reference build
 TOOL_CCLM = 1 << 8           # LM / MDLM chroma modes (cfg LMChroma 1, on in the reference's intra configuration)
 TOOL_FAST = 1 << 12          # the fork's FAST_ALGORITHM: features + random forest pick the one partition mode of a luma node
+TOOL_TS = 1 << 5             # transform skip of luma TUs up to 32x32 with RDOQ-TS (cfg TransformSkip 1, TransformSkipFast 1; needs DEPQUANT and LFNST)
+TOOL_RDOQ = 1 << 7           # cfg RDOQ / RDOQTS beside DepQuant: only reaches transform-skip blocks
+TOOL_ISP = 1 << 2            # intra sub-partitions (cfg ISP 1, ISPFast 1)
+TOOL_LMCS = 1 << 10          # luma mapping with chroma scaling (cfg LMCSEnable 1): the slice carries the model
 TOOLS_DEFAULT = TOOL_MRL | TOOL_CU_REUSE
 
 
@@ -391,6 +395,19 @@ def depquant_batch(org, pred, w, h, bit_depth, qp, comp, mts_idx, cbf_cb, lam, s
     _chk(L, L.vvcx_depquant_batch(org.ctypes.data, pred.ctypes.data, w, h, bit_depth, qp, comp, mts_idx, cbf_cb, lam, s0.ctypes.data, s1.ctypes.data, n,
                                   lev.ctypes.data, rec.ctypes.data, sse.ctypes.data, cbf.ctypes.data, device))
     return lev.reshape(n, h, w), rec.reshape(n, h, w), sse, cbf
+
+
+def transform_skip_batch(resi, w, h, bit_depth, qp, lam, s0, s1, device=0, lib_path=None):
+    """vvcx_transform_skip_batch: n residual blocks through the {DCT2, TS} pruning, xTransformSkip, RDOQ-TS, dequantisation + xITransformSkip and residual_codingTS's estimator"""
+    L = load_library(lib_path)
+    resi = np.ascontiguousarray(resi, np.int16).ravel()
+    s0 = np.ascontiguousarray(s0, np.uint16); s1 = np.ascontiguousarray(s1, np.uint16)
+    n = resi.size // (w * h)
+    lev = np.zeros(resi.size, np.int16); out = np.zeros(resi.size, np.int16); a = np.zeros(n, np.int32); keep = np.zeros(n, np.uint8); bits = np.zeros(n, np.uint64)
+    L.vvcx_transform_skip_batch.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_double, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
+    _chk(L, L.vvcx_transform_skip_batch(resi.ctypes.data, w, h, bit_depth, qp, lam, s0.ctypes.data, s1.ctypes.data, n, lev.ctypes.data, out.ctypes.data, a.ctypes.data,
+                                        keep.ctypes.data, bits.ctypes.data, device))
+    return lev.reshape(n, h, w), out.reshape(n, h, w), a, keep, bits
 
 
 def lfnst_depquant_batch(org, pred, w, h, bit_depth, qp, comp, lfnst_idx, intra_dir, cbf_cb, lam, s0, s1, device=0, lib_path=None):

@@ -180,6 +180,23 @@ def test_joint_cbcr_over_depquant_alone_and_with_classifier():
     _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=1.0, oriented=30.0)], 256, 128, pkg.slice_params(27, dep_quant=True), tools=ALL | pkg.TOOL_FAST)
 
 
+TSK = ALL | pkg.TOOL_TS | pkg.TOOL_RDOQ
+
+
+@pytest.mark.parametrize("case", [(128, 128, 32, 8, 1, 1, 9, 0.6), (200, 136, 27, 8, 1, 1, 1234, 0.4), (256, 128, 37, 8, 2, 1, 5, 0.8), (128, 128, 22, 10, 1, 1, 3, 0.5)])
+def test_transform_skip_in_the_search(case):
+    # tools 0xbfb: in the pass without LFNST and MTS every luma TU of at most 32x32 also tries transform skip unless the {DCT2, TS} pruning drops it: RDOQ-TS from the
+    # node's start contexts (one lane per candidate block), TS dequantisation / inverse, residual_codingTS in the rate, transform_skip_flag in every luma TU's rate,
+    # a TS winner of at least 64 samples ends the LFNST passes; screen-content pictures (flat areas with strokes), where it is selected; the work counters include it
+    W, H, qp, bd, tc, tr, seed, scr = case
+    _check([pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=0.6, oriented=25.0, screen=scr)], W, H, pkg.slice_params(qp, bit_depth=bd, dep_quant=True), bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=TSK)
+
+
+def test_transform_skip_without_cu_reuse_and_with_classifier():
+    _check([pkg.synth_frame(128, 128, 0, 8, 11, chroma_texture=0.5, screen=0.7)], 128, 128, pkg.slice_params(32, dep_quant=True), tools=TSK & ~pkg.TOOL_CU_REUSE)
+    _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=1.0, oriented=30.0, screen=0.5)], 256, 128, pkg.slice_params(27, dep_quant=True), tools=TSK | pkg.TOOL_FAST)
+
+
 FAST = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_FAST
 
 
@@ -282,7 +299,7 @@ def test_baseline_config_3_classifier_per_qp_forest_1080p_rows(qp):
     _check([pkg.synth_frame(W, H, 0, 8, 2000 + qp, chroma_texture=0.5)], W, H, pkg.slice_params(qp, dep_quant=True), tile_cols=15, tile_rows=2, tools=ALL | pkg.TOOL_FAST, forest_qp=qp, workers=12)
 
 
-@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz", "bitstream_dq.npz", "bitstream_lfnst.npz", "bitstream_lfnst_c.npz", "bitstream_jccr.npz", "bitstream_jccr_plain.npz"])
+@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz", "bitstream_dq.npz", "bitstream_lfnst.npz", "bitstream_lfnst_c.npz", "bitstream_jccr.npz", "bitstream_jccr_plain.npz", "bitstream_ts.npz"])
 def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fixture):
     """Device writer (arithmetic coding of the final CTU syntax in the estimator pass) against tests/golden/bitstream.npz: payloads
     that the reference's CABACReader parsed back into the coded CUs and levels when the fixture was generated."""
@@ -292,6 +309,7 @@ def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fix
     tools = int(g["tools"][0]) if "tools" in g else pkg.TOOLS_DEFAULT
     texture = float(g["chroma_texture"][0]) if "chroma_texture" in g else 0.0
     oriented = float(g["oriented"][0]) if "oriented" in g else 0.0
+    screen = float(g["screen"][0]) if "screen" in g else 0.0
     torch.cuda.init()
     off = 0
     jobs = []
@@ -305,7 +323,7 @@ def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fix
         # one encoder and one HIP stream per picture: the pictures of a fixture are independent streams and run side by side
         W, H, qp, tc, tr, bd, seed, exp, sizes = job
         sp = pkg.slice_params(qp, bit_depth=bd, dep_quant=bool(tools & pkg.TOOL_DEPQUANT))
-        planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture, oriented=oriented)
+        planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture, oriented=oriented, screen=screen)
         stream = torch.cuda.Stream()
         enc = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, emit_payload=True, tools=tools)
         enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])

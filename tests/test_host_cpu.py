@@ -89,6 +89,31 @@ def test_device_code_on_cpu_emulator_matches_oracle(emu_so, w, h, chroma, tiles,
     enc.close()
 
 
+def test_transform_skip_search_on_cpu_emulator_matches_oracle(emu_so):
+    """The device's transform-skip rounds (T1-T3 of stage_b_rounds, RDOQ-TS by lanes, residual_codingTS in the rate and in the writer) on the CPU debug emulation against
+    the oracle on a small screen-content picture where most luma CUs end up transform skipped; search result, CU table, reconstruction, work counters and slice data."""
+    w = h = 16
+    tools = 0xb7b | pkg.TOOL_RDOQ
+    planes = pkg.synth_frame(w, h, 0, 8, 3, chroma_texture=0.6, oriented=20.0, screen=1.0)
+    sp = pkg.slice_params(32, dep_quant=True)
+    enc = pkg.VvcxEncoder(w, h, 8, tools=tools, lib_path=emu_so, emit_payload=True)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    org = [np.ascontiguousarray(p) for p in planes]
+    rec = [np.zeros_like(p) for p in planes]
+    enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
+    res = enc.compress_bound_frames()[0]
+    cus = enc.get_cus(0)
+    ores, ocus, oreco, ocnt = O.compress_frame(planes, w, h, sp, tools=tools)
+    assert int(((ocus["ch_type"] == 0) & (ocus["mts_idx"] == 1)).sum()) >= 3
+    for k in ores.dtype.names:
+        assert np.array_equal(ores[k], res[k]), k
+    assert len(cus) == len(ocus) and all(np.array_equal(cus[k], ocus[k]) for k in cus.dtype.names)
+    assert all(np.array_equal(rec[c], oreco[c]) for c in range(3))
+    assert np.array_equal(enc.counters(), ocnt)
+    assert np.array_equal(enc.get_payload(0, 0), O.write_frame(planes, w, h, sp, tools=tools)[0])
+    enc.close()
+
+
 @pytest.mark.parametrize("tools", [pkg.TOOLS_DEFAULT, pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM, pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS,
                                    pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS | pkg.TOOL_MIP])
 def test_emulated_slice_data_writer_matches_oracle(emu_so, tools):

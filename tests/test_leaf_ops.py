@@ -150,6 +150,41 @@ def _lfnst(lib, limit):
     return n
 
 
+def _transform_skip(lib, limit):
+    """vvcx_transform_skip_batch (the {DCT2, TS} pruning, xTransformSkip, ts_rdoq_lane, wave_ts_recon as the search runs them) against the reference's TrQuant /
+    QuantRDOQ vectors (tests/golden/ts.npz); the bits of residual_codingTS against the oracle's estimator, whose syntax the reference decoder parsed (bitstream_ts.npz)"""
+    import ctypes as C
+    import oracle_lib as O
+    vv = importlib.import_module(PKGNAME + ".vvcx")
+    OL = O.lib()
+    OL.orc_residual_bits_ts.restype = C.c_uint64
+    OL.orc_residual_bits_ts.argtypes = [C.c_void_p] * 3 + [C.c_int] * 2
+    g = np.load(os.path.join(G, "ts.npz"))
+    off = n = 0
+    for i, (bd, qp, w, h, kind, keep, qu, a, gi) in enumerate(g["meta"]):
+        P = int(w) * int(h)
+        resi, lev, ro = g["resi"][off:off + P], g["lev"][off:off + P], g["resi_out"][off:off + P]
+        off += P
+        if limit and (n >= limit or P > 64):
+            continue
+        s0, s1 = g["ctx"][gi]
+        l, o, aa, kk, bits = vv.transform_skip_batch(resi, int(w), int(h), int(bd), int(qp + 6 * (bd - 8)), float(g["lam"][i]), s0, s1, lib_path=lib)
+        key = (int(bd), int(qp), int(w), int(h), int(kind))
+        assert np.array_equal(l.ravel(), lev) and int(aa[0]) == int(a), ("levels", key)
+        assert int(kk[0]) == int(keep), ("pruning", key)
+        if a > 0:
+            assert np.array_equal(o.ravel(), ro), ("residual", key)
+            t0, t1, lv = s0.copy(), s1.copy(), np.ascontiguousarray(lev)
+            assert int(bits[0]) == OL.orc_residual_bits_ts(t0.ctypes.data, t1.ctypes.data, lv.ctypes.data, int(w), int(h)), ("bits", key)
+        n += 1
+    return n
+
+
+@pytest.mark.gpu
+def test_gpu_transform_skip_matches_reference():
+    assert _transform_skip(None, None) == 384
+
+
 @pytest.mark.gpu
 def test_gpu_dependent_quantisation_matches_reference():
     assert _depquant(None, None) == 575
@@ -189,6 +224,7 @@ def test_emulated_leaf_operators_match_reference(emu_so):
     assert _trquant(emu_so, 8) == 8
     assert _depquant(emu_so, 12) == 12
     assert _lfnst(emu_so, 16) == 16
+    assert _transform_skip(emu_so, 40) == 40
 
 
 @pytest.mark.gpu
