@@ -59,6 +59,13 @@ typedef struct {
   int32_t qp_c[2];
   double  lambda;
   double  dist_weight[2];
+  /* LMCS (VVCX_TOOL_LMCS): the model the slice's LMCS APS carries (SliceReshapeInfo, CL/Slice.h; chosen per picture by EncReshape::preAnalyzerLMCS, which is the
+   * caller's job like lambda and QP).  The handle builds the forward / inverse LUTs and the chroma scale table from it the way Reshape::constructReshaper does
+   * (CL/Reshape.cpp:297-333).  lmcs_enable 0 (the analysis switched the tool off for this picture): the other fields are ignored. */
+  int32_t lmcs_enable;           /* slice_lmcs_enabled_flag */
+  int32_t lmcs_chroma_adj;       /* slice_chroma_residual_scale_flag */
+  int32_t lmcs_min_bin, lmcs_max_bin;   /* reshaperModelMinBinIdx / MaxBinIdx */
+  int32_t lmcs_delta_cw[16];     /* reshaperModelBinCWDelta: signed deviation of each bin's code words from (1 << bit_depth) / 16 */
 } vvcx_slice;
 
 /* one picture of a batch: DEVICE pointers to planar 4:2:0 samples (uint8 for 8 bit, uint16 for 10 bit),
@@ -171,6 +178,14 @@ int  vvcx_get_tus(vvcx_handle *h, int frame, vvcx_tu *tus, int max_tus, int *n_t
 /* ≙ tu.getCoeffs(compID) of the final TUs: the quantised levels of component comp (0 Y, 1 Cb, 2 Cr) at their sample positions, copied to
  * a host plane (what a caller needs to rebuild cs.tus for the reference's own CABACWriter instead of taking vvcx_get_payload) */
 int  vvcx_get_levels(vvcx_handle *h, int frame, int comp, int16_t *plane, int stride);
+/* LMCS: the search runs, and leaves the luma reconstruction, in the mapped domain (the original luma of a bound picture is forward mapped into a buffer of the handle
+ * when it is bound, ≙ EncGOP::xPicInitLMCS, EL/EncGOP.cpp:1689-1695; an SDR intra picture has no CTU-level weighted distortion: EL/EncSlice.cpp sets
+ * CTUFlag false for it, so the mapped-domain SSE is the reference's distortion).  This maps the luma reconstruction of every bound picture back through the
+ * inverse LUT in place (≙ the picture-level rspSignal before the loop filters, DL/DecLib.cpp executeLoopFilters); call it once all CTUs are coded and before
+ * vvcx_deblock_bound_frames.  VVCX_ERR_STATE when the slice does not enable LMCS. */
+int  vvcx_lmcs_inverse_reco(vvcx_handle *h, void *hip_stream);
+/* the LUTs and tables the handle derived from the slice's model: fwd / inv [1 << bit_depth], pivot[17] (mapped-domain bin borders), chroma_scale[16] (11 fractional bits) */
+int  vvcx_lmcs_tables(vvcx_handle *h, int16_t *fwd, int16_t *inv, int32_t pivot[17], int32_t chroma_scale[16]);
 /* ≙ LoopFilter::loopFilterPic (CL/LoopFilter.cpp:153; called from EncGOP after the slices of a picture are compressed): in-loop deblocking
  * of every bound picture, in place on its reconstruction planes; offsets = cfg LoopFilterBetaOffset_div2 / LoopFilterTcOffset_div2.
  * Every CTU of the pictures must have been compressed.  SAO and ALF, which follow in the reference, are not built. */

@@ -31,6 +31,8 @@ extern "C" __global__ void vvcx_jccr_sign_kernel_u8(VxFrameDev *frames, int wc, 
 extern "C" __global__ void vvcx_jccr_sign_kernel_u16(VxFrameDev *frames, int wc, int hc);
 extern "C" __global__ void vvcx_leaf_dq_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int qp, int comp, int mts, int cbf_cb, unsigned long long *out, int lf, int lfdir);
 extern "C" __global__ void vvcx_leaf_ts_kernel(VxParams p, const uint16_t *ctx, const int16_t *resi, int16_t *lev, int16_t *resi_out, int32_t *tmp, int w, int h, int qp, int *out, unsigned long long *bits);
+extern "C" __global__ void vvcx_lmcs_map_kernel_u8(const uint8_t *src, uint8_t *dst, int w, int h, int stride, const int16_t *lut);
+extern "C" __global__ void vvcx_lmcs_map_kernel_u16(const uint16_t *src, uint16_t *dst, int w, int h, int stride, const int16_t *lut);
 extern "C" __global__ void vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp, unsigned long long *out);
 
 static thread_local char g_err[512];
@@ -65,17 +67,20 @@ struct vvcx_handle {
   uint8_t *payload_d; uint64_t *payload_off_d; uint32_t *payload_cap_d; void *arith_d; std::vector<uint64_t> payload_off; std::vector<uint32_t> payload_cap;
   // FAST_ALGORITHM forest (vvcx_set_forest)
   VxForestNode *f_node_d; double *f_value_d; int32_t *f_root_d; int f_ntrees, f_nclasses; int32_t f_classes[8];
-  VxDqConst *dq_d;                              // dependent-quantiser constants per (component, log2 w + log2 h)
+  VxDqConst *dq_d;                              // dependent-quantiser constants per (chroma scale table, component, log2 w + log2 h)
+  // LMCS of the current slice (vvcx_set_slice): LUTs and tables, their device copy (fwd | inv), the forward-mapped original luma of the bound pictures
+  bool lmcs_on, lmcs_inverted; int16_t lmcs_fwd[1024], lmcs_inv[1024]; int32_t lmcs_pivot[17], lmcs_cadj[16];
+  int16_t *lmcs_lut_d; void *lmcs_org_d; size_t lmcs_org_cap;
   hipEvent_t ev0, ev1; float last_ms, last_deblock_ms;
   // a submitted, not yet collected launch (vvcx_submit_ctus .. vvcx_wait_ctus): staging the async copies read from / write to stays alive here
   bool pending; hipStream_t pend_stream; int pend_n; VxCtuRes *pend_res; int pend_cap;
-  std::vector<VxStreamDesc> pend_sd; std::vector<int32_t> pend_task_ctu; std::vector<int> pend_src, pend_next; VxDqConst pend_dq[96];
+  std::vector<VxStreamDesc> pend_sd; std::vector<int32_t> pend_task_ctu; std::vector<int> pend_src, pend_next; VxDqConst pend_dq[17 * 96];
   size_t lev_plane[3], lev_frame, units_plane, units_frame;
 };
 
 #define VVCX_PAYLOAD_BYTES_PER_CTU 32768u
 static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_LFNST | VVCX_TOOL_MTS | VVCX_TOOL_JCCR | VVCX_TOOL_DEPQUANT | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST |
-                                    VVCX_TOOL_TS | VVCX_TOOL_RDOQ;
+                                    VVCX_TOOL_TS | VVCX_TOOL_RDOQ | VVCX_TOOL_LMCS;
 
 // Quantizer::initQuantBlock (CL/DepQuant.cpp:694-739) for blocks with log2 w + log2 h = lsum: the quantiser's shift / scale / thresholds and the fixed-point
 // distortion normalisation, which the reference derives in fp64 from lambda.  qp: what QpParam hands over (with QpBDOffset).
@@ -118,6 +123,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   // cfg sets RDOQ / RDOQTS beside DepQuant) only acts on transform-skip blocks
   if ((cfg->tools & VVCX_TOOL_TS) && (cfg->tools & (VVCX_TOOL_DEPQUANT | VVCX_TOOL_LFNST)) != (VVCX_TOOL_DEPQUANT | VVCX_TOOL_LFNST))
     return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_TS needs VVCX_TOOL_DEPQUANT and VVCX_TOOL_LFNST (tool set 0x%x)", cfg->tools);
+  if ((cfg->tools & VVCX_TOOL_LMCS) && !(cfg->tools & VVCX_TOOL_DEPQUANT)) return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_LMCS needs VVCX_TOOL_DEPQUANT (tool set 0x%x)", cfg->tools);
   if ((cfg->tools & VVCX_TOOL_JCCR) && !(cfg->tools & VVCX_TOOL_DEPQUANT)) return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_JCCR needs VVCX_TOOL_DEPQUANT (tool set 0x%x)", cfg->tools);
   if (cfg->ctu_size != 128 || !cfg->dual_tree) return fail(VVCX_ERR_UNSUPPORTED, "only CTUSize 128 with DualITree 1");
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7) || cfg->pic_w <= 0 || cfg->pic_h <= 0) return fail(VVCX_ERR_ARG, "picture size must be a positive multiple of 8");
@@ -148,13 +154,13 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   h->frames_d = nullptr; h->lev_d = nullptr; h->units_d = nullptr; h->stream_ctx_d = nullptr; h->scratch_d = nullptr; h->scratch_cap = 0;
   h->payload_d = nullptr; h->payload_off_d = nullptr; h->payload_cap_d = nullptr; h->arith_d = nullptr;
   h->streams_d = nullptr; h->task_ctu_d = nullptr; h->results_d = nullptr; h->task_cap = 0; h->stream_cap = 0; h->counters_d = nullptr;
-  h->dq_d = nullptr;
+  h->dq_d = nullptr; h->lmcs_on = false; h->lmcs_inverted = false; h->lmcs_lut_d = nullptr; h->lmcs_org_d = nullptr; h->lmcs_org_cap = 0;
   const int F = cfg->max_frames;
   if (hipMalloc((void **) &h->frames_d, sizeof(VxFrameDev) * F) != hipSuccess || hipMalloc((void **) &h->lev_d, h->lev_frame * 2 * F) != hipSuccess ||
       hipMalloc((void **) &h->units_d, h->units_frame * sizeof(VxUnit) * F) != hipSuccess ||
       hipMalloc((void **) &h->stream_ctx_d, (size_t) F * h->ntiles * 2 * VXD_NUM_CTX * 2) != hipSuccess ||
       hipMalloc((void **) &h->counters_d, 56 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc((void **) &h->dq_d, 96 * sizeof(VxDqConst)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
+      hipMalloc((void **) &h->dq_d, 17 * 96 * sizeof(VxDqConst)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
   if (cfg->emit_payload) {                       // VVCX_PAYLOAD_BYTES_PER_CTU per CTU: a CTU of 8-bit video at QP >= 17 stays far below (raw samples are 24 KB)
     const size_t nstream = (size_t) F * h->ntiles;
     h->payload_off.resize(nstream); h->payload_cap.resize(nstream);
@@ -177,7 +183,7 @@ extern "C" void vvcx_destroy(vvcx_handle *h)
   (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d);
   (void) hipFree(h->payload_d); (void) hipFree(h->payload_off_d); (void) hipFree(h->payload_cap_d); (void) hipFree(h->arith_d);
   (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
-  (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d); (void) hipFree(h->dq_d);
+  (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d); (void) hipFree(h->dq_d); (void) hipFree(h->lmcs_lut_d); (void) hipFree(h->lmcs_org_d);
   if (h->pending) (void) hipStreamSynchronize(h->pend_stream);
   (void) hipHostFree(h->pend_res);
   (void) hipEventDestroy(h->ev0); (void) hipEventDestroy(h->ev1);
@@ -263,7 +269,49 @@ extern "C" int vvcx_set_slice(vvcx_handle *h, const vvcx_slice *s)
   NOT_PENDING(h);
   if (!h || !s) return fail(VVCX_ERR_ARG, "null argument");
   if (!(s->lambda > 0.0) || s->qp < -6 * (h->cfg.bit_depth - 8) || s->qp > 63) return fail(VVCX_ERR_ARG, "bad slice parameters (QP range -QpBDOffset..63, like vvcx_derive_slice)");
-  h->sl = *s; h->have_slice = true;
+  bool lmcs = false;
+  if (s->lmcs_enable) {
+    // the piece-wise linear model of the slice -> LUTs (Reshape::constructReshaper, CL/Reshape.cpp:297-333, JVET_O0428 form: 16 input bins of equal width,
+    // bin i owns orgCW + delta code words in the mapped domain; 11 fractional bits for the slopes; the inverse slope of a bin is also its chroma residual scale)
+    if (!(h->cfg.tools & VVCX_TOOL_LMCS)) return fail(VVCX_ERR_ARG, "the slice enables LMCS, the handle's tool set does not");
+    const int n = 1 << h->cfg.bit_depth, orgCW = n >> 4, lg = h->cfg.bit_depth - 4;
+    if (s->lmcs_min_bin < 0 || s->lmcs_max_bin > 15 || s->lmcs_min_bin > s->lmcs_max_bin) return fail(VVCX_ERR_ARG, "LMCS bin range %d..%d", s->lmcs_min_bin, s->lmcs_max_bin);
+    int cw[16], fwdSlope[16], invSlope[16], total = 0;
+    for (int b = 0; b < 16; b++) {
+      cw[b] = (b < s->lmcs_min_bin || b > s->lmcs_max_bin) ? 0 : orgCW + s->lmcs_delta_cw[b];
+      if (cw[b] < 0 || cw[b] > 0xffff) return fail(VVCX_ERR_ARG, "LMCS bin %d: %d code words", b, cw[b]);
+      total += cw[b];
+    }
+    if (total > n - 1) return fail(VVCX_ERR_ARG, "LMCS model uses %d code words of %d", total, n - 1);
+    h->lmcs_pivot[0] = 0;
+    for (int b = 0; b < 16; b++) {
+      h->lmcs_pivot[b + 1] = h->lmcs_pivot[b] + cw[b];
+      fwdSlope[b] = (cw[b] * 2048 + (1 << (lg - 1))) >> lg;
+      invSlope[b] = cw[b] ? orgCW * 2048 / cw[b] : 0;
+      h->lmcs_cadj[b] = cw[b] ? invSlope[b] : 2048;
+    }
+    for (int v = 0; v < n; v++) {
+      const int b = v >> lg;
+      int t = h->lmcs_pivot[b] + ((fwdSlope[b] * (v - b * orgCW) + 1024) >> 11);
+      h->lmcs_fwd[v] = (int16_t) (t < 0 ? 0 : t > n - 1 ? n - 1 : t);
+      int k = s->lmcs_min_bin;                           // getPWLIdxInv 268-283: the first bin whose upper border lies above v
+      while (k <= s->lmcs_max_bin && v >= h->lmcs_pivot[k + 1]) k++;
+      if (k > 15) k = 15;
+      t = k * orgCW + ((invSlope[k] * (v - h->lmcs_pivot[k]) + 1024) >> 11);
+      h->lmcs_inv[v] = (int16_t) (t < 0 ? 0 : t > n - 1 ? n - 1 : t);
+    }
+    lmcs = true;
+  }
+  h->sl = *s; h->have_slice = true; h->lmcs_on = lmcs;
+  return VVCX_OK;
+}
+
+extern "C" int vvcx_lmcs_tables(vvcx_handle *h, int16_t *fwd, int16_t *inv, int32_t pivot[17], int32_t chroma_scale[16])
+{
+  if (!h || !fwd || !inv || !pivot || !chroma_scale) return fail(VVCX_ERR_ARG, "null argument");
+  if (!h->have_slice || !h->lmcs_on) return fail(VVCX_ERR_STATE, "the slice does not enable LMCS");
+  memcpy(fwd, h->lmcs_fwd, (size_t) 2 << h->cfg.bit_depth); memcpy(inv, h->lmcs_inv, (size_t) 2 << h->cfg.bit_depth);
+  memcpy(pivot, h->lmcs_pivot, sizeof h->lmcs_pivot); memcpy(chroma_scale, h->lmcs_cadj, sizeof h->lmcs_cadj);
   return VVCX_OK;
 }
 
@@ -302,6 +350,28 @@ extern "C" int vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n)
     d.lev[0] = lev; d.lev[1] = lev + h->lev_plane[0]; d.lev[2] = lev + h->lev_plane[0] + h->lev_plane[1];
     d.lstride[0] = h->cfg.pic_w; d.lstride[1] = d.lstride[2] = h->cfg.pic_w >> 1;
     d.units[0] = h->units_d + (size_t) f * h->units_frame; d.units[1] = d.units[0] + h->units_plane;
+  }
+  h->lmcs_inverted = false;
+  if (h->lmcs_on) {
+    // EncGOP::xPicInitLMCS (EL/EncGOP.cpp:1689-1695): the original luma of an intra picture is forward mapped once, before the slice is compressed; the search
+    // reads the mapped copy (same stride as the caller's plane: the picture record has one stride per component)
+    const size_t bps = h->cfg.bit_depth == 8 ? 1 : 2;
+    size_t need = 0;
+    for (int f = 0; f < n; f++) need += (size_t) h->frames_h[(size_t) f].stride[0] * h->cfg.pic_h * bps;
+    if (need > h->lmcs_org_cap) { (void) hipFree(h->lmcs_org_d); h->lmcs_org_d = nullptr; h->lmcs_org_cap = 0; HIPCHK(hipMalloc(&h->lmcs_org_d, need)); h->lmcs_org_cap = need; }
+    if (!h->lmcs_lut_d) HIPCHK(hipMalloc((void **) &h->lmcs_lut_d, 2 * 1024 * 2));
+    HIPCHK(hipMemcpy(h->lmcs_lut_d, h->lmcs_fwd, 2048, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(h->lmcs_lut_d + 1024, h->lmcs_inv, 2048, hipMemcpyHostToDevice));
+    size_t off = 0;
+    for (int f = 0; f < n; f++) {
+      VxFrameDev &d = h->frames_h[(size_t) f];
+      void *dst = (uint8_t *) h->lmcs_org_d + off;
+      const unsigned blocks = (unsigned) (((size_t) h->cfg.pic_w * h->cfg.pic_h + VXD_NT - 1) / VXD_NT);
+      if (bps == 1) hipLaunchKernelGGL(vvcx_lmcs_map_kernel_u8, dim3(blocks), dim3(VXD_NT), 0, 0, (const uint8_t *) d.org[0], (uint8_t *) dst, h->cfg.pic_w, h->cfg.pic_h, d.stride[0], h->lmcs_lut_d);
+      else hipLaunchKernelGGL(vvcx_lmcs_map_kernel_u16, dim3(blocks), dim3(VXD_NT), 0, 0, (const uint16_t *) d.org[0], (uint16_t *) dst, h->cfg.pic_w, h->cfg.pic_h, d.stride[0], h->lmcs_lut_d);
+      HIPCHK(hipGetLastError());
+      d.org[0] = dst;
+      off += (size_t) d.stride[0] * h->cfg.pic_h * bps;
+    }
   }
   HIPCHK(hipMemcpy(h->frames_d, h->frames_h.data(), sizeof(VxFrameDev) * (size_t) n, hipMemcpyHostToDevice));
   if (h->cfg.tools & VVCX_TOOL_JCCR) {                    // the slice's joint_cb_cr_sign_flag from the bound picture (EL/EncSlice.cpp:1594-1597), left in its record
@@ -402,6 +472,9 @@ extern "C" int vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int 
   p.f_node = h->f_node_d; p.f_value = h->f_value_d; p.f_root = h->f_root_d; p.f_ntrees = h->f_ntrees; p.f_nclasses = h->f_nclasses;
   for (int c = 0; c < 8; c++) p.f_classes[c] = h->f_classes[c];
   p.n_streams = ns;
+  p.lmcs_on = h->lmcs_on; p.lmcs_cadj_on = h->lmcs_on && h->sl.lmcs_chroma_adj; p.lmcs_min_bin = h->sl.lmcs_min_bin; p.lmcs_max_bin = h->sl.lmcs_max_bin;
+  for (int b = 0; b < 17; b++) p.lmcs_pivot[b] = h->lmcs_on ? h->lmcs_pivot[b] : 0;
+  for (int b = 0; b < 16; b++) p.lmcs_cadj[b] = h->lmcs_on ? h->lmcs_cadj[b] : 0;
   if (h->cfg.tools & VVCX_TOOL_DEPQUANT) {
     // the quantiser's lambda of a component: TrQuant::setLambdas / selectLambda (EL/EncSlice.cpp:107-149, EL/IntraSearch.cpp:2889) = lambda / distortion weight for chroma
     VxDqConst *tab = h->pend_dq; memset(tab, 0, sizeof h->pend_dq);
@@ -417,6 +490,25 @@ extern "C" int vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int 
       if (h->sl.qp > 18) lam = 1.3 * lam;
       const int qp = mask == 3 ? p.qp_tr_j : p.qp_tr_c[(mask >> 1) ? 0 : 1];
       for (int lsum = 2; lsum <= 12; lsum++) tab[(2 + mask) * 16 + lsum] = dq_consts_of(lsum, h->cfg.bit_depth, qp, lam);
+    }
+    if (h->lmcs_on && h->sl.lmcs_chroma_adj) {
+      // chroma residual scaling: the quantiser's lambda of a scaled chroma block is first divided by the square of 2048 / scale (EL/IntraSearch.cpp:2919-2931), one
+      // table per bin of the model; the luma row is never read from these tables
+      for (int b = 0; b < 16; b++) {
+        const double cResScale = 2048.0 / (double) h->lmcs_cadj[b], cbBase = (h->sl.lambda / h->sl.dist_weight[0]) / (cResScale * cResScale);
+        VxDqConst *tb = tab + (1 + b) * 96;
+        for (int comp = 1; comp < 3; comp++) {
+          double lam = (h->sl.lambda / h->sl.dist_weight[comp - 1]) / (cResScale * cResScale);
+          if (jccr && h->sl.qp > 18) lam = 1.3 * lam;
+          for (int lsum = 2; lsum <= 12; lsum++) tb[comp * 16 + lsum] = dq_consts_of(lsum, h->cfg.bit_depth, p.qp_tr_c[comp - 1], lam);
+        }
+        if (jccr) for (int mask = 1; mask <= 3; mask++) {
+          double lam = (mask == 3 ? 0.5 : 0.8) * cbBase;
+          if (h->sl.qp > 18) lam = 1.3 * lam;
+          const int qp = mask == 3 ? p.qp_tr_j : p.qp_tr_c[(mask >> 1) ? 0 : 1];
+          for (int lsum = 2; lsum <= 12; lsum++) tb[(2 + mask) * 16 + lsum] = dq_consts_of(lsum, h->cfg.bit_depth, qp, lam);
+        }
+      }
     }
     HIPCHK(hipMemcpyAsync(h->dq_d, tab, sizeof h->pend_dq, hipMemcpyHostToDevice, stream));
     p.dq_consts = h->dq_d;
@@ -495,6 +587,29 @@ extern "C" int vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out, 
   return VVCX_OK;
 }
 
+// LMCS: luma reconstruction of every bound picture back to the original domain, in place (the picture-level inverse rspSignal in front of the loop filters)
+extern "C" int vvcx_lmcs_inverse_reco(vvcx_handle *h, void *hip_stream)
+{
+  NOT_PENDING(h);
+  if (!h) return fail(VVCX_ERR_ARG, "null handle");
+  if (!h->n_frames || !h->have_slice || !h->lmcs_on) return fail(VVCX_ERR_STATE, "no bound frames coded with an LMCS slice");
+  if (h->lmcs_inverted) return fail(VVCX_ERR_STATE, "the reconstruction has already been mapped back");
+  for (size_t i = 0; i < h->next_idx.size(); i++)
+    if (h->next_idx[i] != (int) h->tile_ctus[i % (size_t) h->ntiles].size()) return fail(VVCX_ERR_STATE, "every CTU of the bound pictures must be coded first (intra prediction reads mapped neighbours)");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  hipStream_t stream = (hipStream_t) hip_stream;
+  const unsigned blocks = (unsigned) (((size_t) h->cfg.pic_w * h->cfg.pic_h + VXD_NT - 1) / VXD_NT);
+  for (int f = 0; f < h->n_frames; f++) {
+    const VxFrameDev &d = h->frames_h[(size_t) f];
+    if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_lmcs_map_kernel_u8, dim3(blocks), dim3(VXD_NT), 0, stream, (const uint8_t *) d.rec[0], (uint8_t *) d.rec[0], h->cfg.pic_w, h->cfg.pic_h, d.stride[0], h->lmcs_lut_d + 1024);
+    else hipLaunchKernelGGL(vvcx_lmcs_map_kernel_u16, dim3(blocks), dim3(VXD_NT), 0, stream, (const uint16_t *) d.rec[0], (uint16_t *) d.rec[0], h->cfg.pic_w, h->cfg.pic_h, d.stride[0], h->lmcs_lut_d + 1024);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(stream));
+  h->lmcs_inverted = true;
+  return VVCX_OK;
+}
+
 // ≙ LoopFilter::loopFilterPic (CL/LoopFilter.cpp:153) on every bound picture, in place on the reconstruction planes the search wrote:
 // one launch for all vertical edges, one for all horizontal edges (vvcx_deblock.hip).  Every CTU of the pictures must have been coded.
 extern "C" int vvcx_deblock_bound_frames(vvcx_handle *h, int beta_offset_div2, int tc_offset_div2, void *hip_stream)
@@ -504,6 +619,7 @@ extern "C" int vvcx_deblock_bound_frames(vvcx_handle *h, int beta_offset_div2, i
   if (!h->n_frames || !h->have_slice) return fail(VVCX_ERR_STATE, "no bound frames / slice");
   for (size_t i = 0; i < h->next_idx.size(); i++)
     if (h->next_idx[i] != (int) h->tile_ctus[i % (size_t) h->ntiles].size()) return fail(VVCX_ERR_STATE, "deblocking needs every CTU of the bound pictures coded (frame %d tile %d is not)", (int) (i / (size_t) h->ntiles), (int) (i % (size_t) h->ntiles));
+  if (h->lmcs_on && !h->lmcs_inverted) return fail(VVCX_ERR_STATE, "LMCS slice: vvcx_lmcs_inverse_reco first (the loop filters work in the original domain)");
   if (beta_offset_div2 < -6 || beta_offset_div2 > 6 || tc_offset_div2 < -6 || tc_offset_div2 > 6) return fail(VVCX_ERR_ARG, "deblocking offsets outside -6..6");
   HIPCHK(hipSetDevice(h->cfg.device));
   hipStream_t stream = (hipStream_t) hip_stream;

@@ -157,7 +157,9 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
 {
   n_items = uni(n_items); w = uni(w); h = uni(h); comp = uni(comp); zo = uni(zo); lfnst = uni(lfnst); ci0 = uni(ci0); ci_step = uni(ci_step); cbf_ctx0 = uni(cbf_ctx0);
   const int ch = comp ? 1 : 0, lw = ilog2i(w), lh = ilog2i(h);
-  const VxDqConst q = L.par.dq_consts[(uni(qidx) < 0 ? comp : uni(qidx)) * 16 + lw + lh];      // qidx: another row of the table (joint chroma blocks)
+  // qidx: another row of the table (joint chroma blocks); chroma rows come from the table of the node's LMCS residual scale (table 0: unscaled)
+  const int qrow = uni(qidx) < 0 ? comp : uni(qidx);
+  const VxDqConst q = L.par.dq_consts[(qrow ? uni(L.lmcs_tab) * 96 : 0) + qrow * 16 + lw + lh];
   const ScanGeo geo = scan_geo(w, h);
   const int lcw = geo.lcw, lch = geo.lch, lcg = geo.lcg, gs = 1 << lcg, total = geo.nscan;
   const int nzw = imin(32, w), nzh = imin(32, h), wsbb = geo.wg, hsbb = geo.hg;

@@ -80,6 +80,10 @@ struct VxParams {
   int32_t             f_ntrees, f_nclasses;
   int32_t             f_classes[8];
   const VxDqConst    *dq_consts;     // [6 * 16] (VVCX_TOOL_DEPQUANT): Y, Cb, Cr, then the joint blocks of cbf masks 1, 2, 3 (VVCX_TOOL_JCCR)
+  // LMCS (the slice enables it): chroma residual scaling from the luma neighbourhood of the 64x64 area; the quantiser constants then have one table per scale
+  // (dq_consts[(1 + bin) * 96 ..], table 0 = no scaling)
+  int32_t             lmcs_on, lmcs_cadj_on, lmcs_min_bin, lmcs_max_bin;
+  int32_t             lmcs_pivot[17], lmcs_cadj[16];
   int32_t             n_streams;     // stream descriptors of the launch: the workgroups (at most one per resident slot) take them from a queue (counters[52])
 };
 

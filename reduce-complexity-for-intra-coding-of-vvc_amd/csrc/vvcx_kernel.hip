@@ -163,6 +163,7 @@ struct Lds {
   int8_t ps_lfnst, ps_mts, ps_grp, ps_pad; int rc_last[NW]; uint8_t rd_lfl[16];
   // the DST-VII pass prepared by the DCT-II pass (stage_b_rounds): number of prepared items (0: none), item of each candidate of the running pass, absSum per item
   int8_t spec_n; uint8_t rd_src[16]; int spec_abs[16];
+  int lmcs_cadj, lmcs_tab, lmcs_sum[2];   // LMCS: chroma residual scale of the chroma node being coded (0: none), its table of quantiser constants (1 + bin; 0: unscaled), partial sums
   int ts_tab[36]; uint8_t ts_keep[16];   // transform skip: fractional bits of the TS context sets at the node's start contexts (ts_build_tables); candidates of the chunk that try it
   int dc_val[4];
   int cur_tile, frame, ctu_x, ctu_y, tree_ch;
@@ -1572,6 +1573,57 @@ __device__ void load_tables()
   for (int i = tid; i < 256; i += NT) L.t.dct[84 + i] = VX_DCT2_16[i];
   for (int i = tid; i < 1024; i += NT) L.t.dct[340 + i] = VX_DCT2_32[i];
 }
+// ---- LMCS chroma residual scaling.  AreaBuf<Pel>::scaleSignal (CL/Buffer.cpp:501-550): the encoder divides the chroma residual by the scale (11 fractional bits), the
+// decoder half multiplies it back
+__device__ inline int lmcs_scale_fwd(int v, int scale, int bd)
+{
+  const int mxa = (1 << bd) - 1, sg = v >= 0 ? 1 : -1, a = sg * v;
+  const int r = sg * (((a << 11) + (scale >> 1)) / scale);
+  return r < -mxa ? -mxa : r > mxa ? mxa : r;
+}
+__device__ inline int lmcs_scale_inv(int v, int scale, int bd)
+{
+  const int mxa = (1 << bd) - 1;
+  v = v < -mxa - 1 ? -mxa - 1 : v > mxa ? mxa : v;
+  const int sg = v >= 0 ? 1 : -1, a = sg * v;
+  const int r = sg * ((a * scale + 1024) >> 11);
+  return r < -32768 ? -32768 : r > 32767 ? 32767 : r;
+}
+// Reshape::calculateChromaAdjVpduNei (CL/Reshape.cpp:153-250): every chroma TU inside a 64x64 luma area takes its scale from the average of the reconstructed luma samples
+// left of and above the luma CU that holds the area's top-left sample (64 each, clamped at the picture edge), looked up in the model's table.  All threads; the
+// result is left in L.lmcs_cadj / L.lmcs_tab.  (nx, ny): the chroma node in luma coordinates.
+template <typename T>
+__device__ __noinline__ void lmcs_chroma_adj(int nx, int ny)
+{
+  const VxParams &p = L.par; const VxFrameDev &fd = L.fdv;
+  if (!uni(p.lmcs_cadj_on)) { if (VTX == 0) { L.lmcs_cadj = 0; L.lmcs_tab = 0; } __syncthreads(); return; }
+  nx = uni(nx); ny = uni(ny);
+  const VxUnit tl = fd.units[0][((ny & ~63) >> 2) * p.uw + ((nx & ~63) >> 2)];
+  const int x = uni((int) tl.x), y = uni((int) tl.y), tile = uni(L.cur_tile);
+  const int availL = get_cu(p, fd, 0, x - 1, y, tile) != nullptr, availA = get_cu(p, fd, 0, x, y - 1, tile) != nullptr;
+  const int wave = uni(VTX >> 6), lane = VTX & 63;
+  const void *rec = fd.rec[0]; const int st = fd.stride[0];
+  if (wave < 2) {
+    int v = 0;
+    if (wave == 0 && availL) { const int k = (y + lane) >= p.pic_h ? p.pic_h - y - 1 : lane; v = ld_px<T>(rec, (y + k) * st + x - 1); }
+    if (wave == 1 && availA) { const int k = (x + lane) >= p.pic_w ? p.pic_w - x - 1 : lane; v = ld_px<T>(rec, (y - 1) * st + x + k); }
+    v = wave_sum_i32(v);
+    if (lane == 0) L.lmcs_sum[wave] = v;
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (VTX == 0) {
+    const int n = 64 * (availL + availA), sum = L.lmcs_sum[0] + L.lmcs_sum[1], mx = (1 << p.bit_depth) - 1;
+    int v = n == 64 ? (sum + 32) >> 6 : n == 128 ? (sum + 64) >> 7 : 1 << (p.bit_depth - 1);
+    v = v < 0 ? 0 : v > mx ? mx : v;
+    int idx = p.lmcs_min_bin;
+    while (idx <= p.lmcs_max_bin && v >= p.lmcs_pivot[idx + 1]) idx++;
+    if (idx > 15) idx = 15;
+    L.lmcs_cadj = p.lmcs_cadj[idx]; L.lmcs_tab = 1 + idx;
+  }
+  __threadfence_block();
+  __syncthreads();
+}
 // residual (org - pred) → DCT-II (TrQuant::xT 835-915) → plain quant (Quant::quant 994-1089) → levels;
 // if any level: dequant (423-549) → inverse DCT-II (xIT 917-992) → reco = clip(pred + resi) written over pred.
 // Returns SSE(org, reco) and abs-sum via out params.  rec/lev tiles have stride w.
@@ -1582,8 +1634,9 @@ __device__ void load_tables()
 template <bool SMALL, bool SUMABS = false>
 __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, int buf_off, int16_t *rec_g, int16_t *lev_g, int32_t *tmp_g, int w, int h, int bd, int qp,
                                 int lane, unsigned long long &sse_out, int &cbf_out, int given = -1, int *sumabs_out = nullptr, int comp = 0, int ci = 0, int cbf_cb = 0,
-                                int lf = 0, int lfmode = 0, int raw = 0, int qidx = -1)
+                                int lf = 0, int lfmode = 0, int raw = 0, int qidx = -1, int cadj = 0)
 {
+  // cadj: LMCS chroma residual scale of the block (0: none): the residual is divided by it in front of the transform and multiplied back behind the inverse
   // raw: the block is a bare residual (org = the residual, rec = zeros on entry): rec receives the reconstructed residual, unclipped (joint chroma blocks)
   // lf: cu.lfnstIdx for a block of at least 4x4 (0 otherwise), lfmode: lfnst_mode() of its final intra mode (dependent quantisation only)
   int coef_sum = 0;                                     // SUMABS: sum of |DCT-II coefficient| for the MTS pruning (TrQuant::transformNxN 1049-1124)
@@ -1601,11 +1654,17 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
   const int8_t *Mw = dct2_matrix<SMALL>(w), *Mh = dct2_matrix<SMALL>(h);
   const int shift1 = lw + bd + 6 - 15, shift2 = lh + 6;
   const int rnd1 = shift1 > 0 ? 1 << (shift1 - 1) : 0, rnd2 = 1 << (shift2 - 1);
+  cadj = uni(cadj);
+  if (cadj && given < 0) {                              // the scaled residual passes through the (still unused) level buffer
+    for (int o = lane; o < P; o += 64) lev[o] = (int16_t) lmcs_scale_fwd(org[o] - rec[o], cadj, bd);
+    wave_sync();
+  }
   // stage 1 (horizontal): tmp[k*h + j] = (sum_i Mw[k][i] * resi[j][i] + rnd) >> shift1, k < zw
   if (given < 0) for (int o = lane; o < fzw * h; o += 64) {
     const int k = o >> lh, j = o & (h - 1);
     int s = 0;
-    if (w >= 4) for (int i = 0; i < w; i += 4) s += dot4_resi(*(const uint32_t *) (Mw + k * w + i), *(const uint2 *) (org + j * w + i), *(const uint2 *) (rec + j * w + i));
+    if (cadj) { if (w >= 4) for (int i = 0; i < w; i += 4) s += dot4_s16(*(const uint32_t *) (Mw + k * w + i), *(const uint2 *) (lev + j * w + i)); else for (int i = 0; i < w; i++) s += Mw[k * w + i] * lev[j * w + i]; }
+    else if (w >= 4) for (int i = 0; i < w; i += 4) s += dot4_resi(*(const uint32_t *) (Mw + k * w + i), *(const uint2 *) (org + j * w + i), *(const uint2 *) (rec + j * w + i));
     else for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * w + i] - rec[j * w + i]);
     tmp[o] = (s + rnd1) >> shift1;
   }
@@ -1684,6 +1743,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
       int r = (s + irnd2) >> ishift2;
       r = r < -32768 ? -32768 : r > 32767 ? 32767 : r;
       if (raw) { rec[o] = (int16_t) r; continue; }
+      if (cadj) r = lmcs_scale_inv((int) (int16_t) r, cadj, bd);
       int v = rec[o] + (int) (int16_t) r;
       v = v < 0 ? 0 : v > mx ? mx : v;
       rec[o] = (int16_t) v;
@@ -2848,6 +2908,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
   // LFNST of the pass on both components of blocks of at least 4x4; kernel choice: the final mode, or the co-located luma mode for the LM modes (CL/TrQuant.cpp:449-457)
   const int psLf = (uni((int) (p.tools & TOOL_LFNST)) && w >= 4 && h >= 4) ? uni((int) L.ps_lfnst) : 0;
   const int jccrOn = uni((int) (p.tools & TOOL_JCCR)) != 0;
+  const int cadj = P > 4 ? uni(L.lmcs_cadj) : 0;             // LMCS chroma residual scaling of blocks of more than 4 samples (EL/IntraSearch.cpp:3884-3904, 3060-3066)
   int njoint = 0;
 #define CHROMA_LFMODE(c_) (psLf ? lfnst_mode((uni((int) L.rd[c_].mode) >= LM_CHROMA && uni((int) L.rd[c_].mode) <= MDLM_T) ? uni(L.colm) : uni((int) L.rd[c_].mrl), w, h) : 0)
   // ---- C1
@@ -2860,7 +2921,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
       wave_sync();
       for (int e = lane; e < P; e += 64) poolPred[(size_t) (2 * c + k) * P + e] = rec[e];
       unsigned long long sse; int cbf;
-      wave_code_block<SMALL>(org, k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[k], lane, sse, cbf, -2, nullptr, k + 1, CI_CUR, 0, psLf, lfm);
+      wave_code_block<SMALL>(org, k * P, k * P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[k], lane, sse, cbf, -2, nullptr, k + 1, CI_CUR, 0, psLf, lfm, 0, -1, cadj);
       for (int e = lane; e < P; e += 64) poolCoef[(size_t) (2 * c + k) * P + e] = lev[e];
       wave_sync();
     }
@@ -2891,7 +2952,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
       wave_sync();
       cbfs[0] = uni(L.dq_abs[c]) > 0;
       unsigned long long sse; int cbf2;
-      wave_code_block<SMALL>(org, 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[0], lane, sse, cbf2, cbfs[0], nullptr, 1, CI_W(wave), 0, psLf, lfm);
+      wave_code_block<SMALL>(org, 0, 0, recb, levb, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[0], lane, sse, cbf2, cbfs[0], nullptr, 1, CI_W(wave), 0, psLf, lfm, 0, -1, cadj);
       dist += (unsigned long long) (p.dist_weight[0] * (double) sse);
       { Cab cb; cb.ci = CI_W(wave); cb.bits = 0; if (lane == 0) enc_bin(cb, (unsigned) cbfs[0], VX_CTX_QtCbf[1]); if (cbfs[0]) residual_coding_wave<SMALL>(cb, 0, levb, w, h, 1, lane);
         double c0 = 0; if (lane == 0) c0 = rd_cost(p, cb.bits, dist); compCost = lane0_d(c0); }      // xGetIntraFracBitsQTChroma(Cb) 2625-2692
@@ -2916,7 +2977,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
       wave_sync();
       cbfs[1] = uni(L.dq_abs[c]) > 0;
       unsigned long long sse; int cbf2;
-      wave_code_block<SMALL>(org, P, P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[1], lane, sse, cbf2, cbfs[1], nullptr, 2, CI_W(wave), cbfs[0], psLf, lfm);
+      wave_code_block<SMALL>(org, P, P, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr_c[1], lane, sse, cbf2, cbfs[1], nullptr, 2, CI_W(wave), cbfs[0], psLf, lfm, 0, -1, cadj);
       const unsigned long long distCr = (unsigned long long) (p.dist_weight[1] * (double) sse);
       dist += distCr;
       { Cab cb; cb.ci = CI_W(wave); cb.bits = 0;
@@ -2932,7 +2993,8 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
         const int sign = uni(L.fdv.jccr_sign);
         long long d0 = 0, d1 = 0, e1 = 0, e2 = 0, e3 = 0;
         for (int e = lane; e < P; e += 64) {
-          const int b = org[e] - pCb[e], r = org[P + e] - pCr[e];
+          int b = org[e] - pCb[e], r = org[P + e] - pCr[e];
+          if (cadj) { b = lmcs_scale_fwd(b, cadj, bd); r = lmcs_scale_fwd(r, cadj, bd); }      // 3915-3925: the residuals the joint candidates are built from are the scaled ones
           d0 += (long long) b * b; d1 += (long long) r * r;
           ict_fwd(b, r, ict_mode(sign, 1), e1); ict_fwd(b, r, ict_mode(sign, 2), e2); ict_fwd(b, r, ict_mode(sign, 3), e3);
         }
@@ -2949,7 +3011,11 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
         unsigned long long bestJDist = 0;
         for (int q = 0; q < nm; q++) {
           const int mask = uni(masks[q]), mode = ict_mode(sign, mask), comp = (mask >> 1) ? 1 : 2;
-          for (int e = lane; e < P; e += 64) { long long dm = 0; jres[e] = (int16_t) ict_fwd(org[e] - pCb[e], org[P + e] - pCr[e], mode, dm); jout[e] = 0; }
+          for (int e = lane; e < P; e += 64) {
+            long long dm = 0; int b = org[e] - pCb[e], r = org[P + e] - pCr[e];
+            if (cadj) { b = lmcs_scale_fwd(b, cadj, bd); r = lmcs_scale_fwd(r, cadj, bd); }
+            jres[e] = (int16_t) ict_fwd(b, r, mode, dm); jout[e] = 0;
+          }
           wave_sync();
           njoint++;
           unsigned long long sseJ; int cbfJ;
@@ -2960,7 +3026,9 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
           const int mx = (1 << bd) - 1;
           for (int e = lane; e < P; e += 64) {
             const int cj = jout[e];
-            int vb = pCb[e] + ict_inv(cj, mode, 0), vr = pCr[e] + ict_inv(cj, mode, 1);
+            int rb = ict_inv(cj, mode, 0), rr = ict_inv(cj, mode, 1);
+            if (cadj) { rb = lmcs_scale_inv((int) (int16_t) rb, cadj, bd); rr = lmcs_scale_inv((int) (int16_t) rr, cadj, bd); }      // 3060-3070: both residuals back through the inverse chroma scaling
+            int vb = pCb[e] + rb, vr = pCr[e] + rr;
             vb = vb < 0 ? 0 : vb > mx ? mx : vb; vr = vr < 0 ? 0 : vr > mx ? mx : vr;
             jres[e] = (int16_t) vb; jout[e] = (int16_t) vr;          // the pair of reconstructions replaces the residuals
             const int db = org[e] - vb, dr = org[P + e] - vr;
@@ -3046,6 +3114,7 @@ __device__ __noinline__ void op_chroma_rd(const VxParams &p_, const VxFrameDev &
     build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
   }
   if (VTX < 2) L.dc_val[VTX] = dc_value(L.refs[VTX][0], L.refs[VTX][1], w, h, 0);
+  lmcs_chroma_adj<T>(uni(L.nx), uni(L.ny));
   if (uni(L.lm_ok)) cclm_prepare<T>(p, fd, scratch, x, y, w, h);
   __syncthreads();
   if (2 * P <= BUF) chroma_rd_loop<true>(p, scratch, wave, lane, w, h); else chroma_rd_loop<false>(p, scratch, wave, lane, w, h);
@@ -3143,6 +3212,7 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
     const int lf = (w >= 4 && h >= 4) ? uni((int) L.ps_lfnst) : 0;
     const int lfm = lf ? lfnst_mode((mode >= LM_CHROMA && mode <= MDLM_T) ? uni(L.colm) : fm, w, h) : 0;
     const int jm = (p.tools & TOOL_JCCR) ? uni((int) L.rd_mts[0]) : 0;
+    const int cadj = ((cbfm & 6) && P > 4) ? uni(L.lmcs_cadj) : 0;      // DL/DecCu.cpp:359-367
     if (jm) {
       // DecCu::xIntraRecQT of a joint TU (DL/DecCu.cpp:330-414): the coded block's residual at its QP, the other block through the inverse ICT
       int16_t *jb = (int16_t *) (scratch + VXD_OFF_JCCR), *jout = jb + 1024, *jlev = jb + 2048;
@@ -3158,7 +3228,7 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
         chroma_pred_wave(rec, lm_in_buf(scratch, n), k, fm, w, h, bd, lane);
         wave_sync();
         unsigned long long sse = 0;
-        for (int e = lane; e < P; e += 64) { int v = rec[e] + ict_inv(jout[e], mode, k); v = v < 0 ? 0 : v > mx ? mx : v; rec[e] = (int16_t) v; const int d = org[k * P + e] - v; sse += (unsigned long long) (d * d); }
+        for (int e = lane; e < P; e += 64) { int rr = ict_inv(jout[e], mode, k); if (cadj) rr = lmcs_scale_inv((int) (int16_t) rr, cadj, bd); int v = rec[e] + rr; v = v < 0 ? 0 : v > mx ? mx : v; rec[e] = (int16_t) v; const int d = org[k * P + e] - v; sse += (unsigned long long) (d * d); }
         dist += (unsigned long long) (p.dist_weight[k] * (double) wave_sum_u64(sse));
         wave_sync();
       }
@@ -3168,7 +3238,7 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
       chroma_pred_wave(rec, lm_in_buf(scratch, n), k, fm, w, h, bd, lane);
       wave_sync();
       unsigned long long sse; int cbf;
-      wave_code_block<SMALL>(org_tile(scratch, n), k * P, k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1, nullptr, k + 1, 0, 0, lf, lfm);
+      wave_code_block<SMALL>(org_tile(scratch, n), k * P, k * P, rec, levb + k * P, wave_tmp(scratch, imin(w, 32) * h, 0), w, h, bd, p.qp_tr_c[k], lane, sse, cbf, (cbfm >> (k + 1)) & 1, nullptr, k + 1, 0, 0, lf, lfm, 0, -1, cadj);
       dist += (unsigned long long) (p.dist_weight[k] * (double) sse);
     }
     if (lane == 0) {
@@ -3209,6 +3279,7 @@ __device__ __noinline__ void op_reuse(const VxParams &p_, const VxFrameDev &fd_,
       build_refs<T>(p, fd, c, x, y, w, h, uni(L.cur_tile), 1);
     }
     if (VTX < 2) L.dc_val[VTX] = dc_value(L.refs[VTX][0], L.refs[VTX][1], w, h, 0);
+    lmcs_chroma_adj<T>(uni(L.nx), uni(L.ny));
     { const int fm = uni(L.rd[0].mrl); if (fm >= LM_CHROMA && fm <= MDLM_T) cclm_prepare<T>(p, fd, scratch, x, y, w, h); }
   }
   int16_t *levb = slot_lev(scratch, n, 0, 0);
@@ -4184,7 +4255,7 @@ __device__ void run_stream(const VxParams &p, int stream_idx)
   Ctx *carry = (Ctx *) (p.stream_ctx + (size_t) (sd.frame * p.ntiles + sd.tile) * 2 * NCTX);
   const int tid = VTX;
   if (tid == 0) {
-    L.cur_tile = sd.tile; L.frame = sd.frame; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < (VVCX_STAMP ? 48 : 1); i++) PROF(i) = 0;
+    L.cur_tile = sd.tile; L.frame = sd.frame; L.lmcs_cadj = 0; L.lmcs_tab = 0; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < (VVCX_STAMP ? 48 : 1); i++) PROF(i) = 0;
     if (p.payload) writer_begin(p, sd.frame * p.ntiles + sd.tile, sd.done_before);
     if (p.tools & TOOL_CU_REUSE) L.cache_gen = (int) *(const uint32_t *) (scratch + VXD_OFF_META);
   }
@@ -4272,7 +4343,7 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_trq_kernel(c
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_dq_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp,
                                                                               int w, int h, int qp, int comp, int mts, int cbf_cb, unsigned long long *out, int lf, int lfdir)
 {
-  if (VTX == 0) L.par = p;
+  if (VTX == 0) { L.par = p; L.lmcs_tab = 0; }
   load_tables();
   for (int i = VTX; i < NCTX; i += NT) { L.ctxs[CI_CUR].s0[i] = ctx[i]; L.ctxs[CI_CUR].s1[i] = ctx[NCTX + i]; }
   __syncthreads();
@@ -4435,3 +4506,15 @@ __device__ void jccr_sign(VxFrameDev *frames, int wc, int hc)
 }
 extern "C" __global__ void __launch_bounds__(NT) vvcx_jccr_sign_kernel_u8(VxFrameDev *frames, int wc, int hc) { jccr_sign<uint8_t>(frames, wc, hc); }
 extern "C" __global__ void __launch_bounds__(NT) vvcx_jccr_sign_kernel_u16(VxFrameDev *frames, int wc, int hc) { jccr_sign<uint16_t>(frames, wc, hc); }
+
+// LMCS: one plane through a LUT (AreaBuf<Pel>::rspSignal, CL/Buffer.cpp:485-499): the forward map of a bound picture's original luma, the inverse map of its reconstruction
+template <typename T>
+__device__ void lmcs_map(const T *src, T *dst, int w, int h, int stride, const int16_t *lut)
+{
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= w * h) return;
+  const int y = i / w, x = i - y * w;
+  dst[y * stride + x] = (T) lut[src[y * stride + x]];
+}
+extern "C" __global__ void __launch_bounds__(NT) vvcx_lmcs_map_kernel_u8(const uint8_t *src, uint8_t *dst, int w, int h, int stride, const int16_t *lut) { lmcs_map<uint8_t>(src, dst, w, h, stride, lut); }
+extern "C" __global__ void __launch_bounds__(NT) vvcx_lmcs_map_kernel_u16(const uint16_t *src, uint16_t *dst, int w, int h, int stride, const int16_t *lut) { lmcs_map<uint16_t>(src, dst, w, h, stride, lut); }

@@ -38,7 +38,8 @@ class _Cfg(C.Structure):
 
 
 class _Slice(C.Structure):
-    _fields_ = [("qp", C.c_int32), ("qp_c", C.c_int32 * 2), ("lam", C.c_double), ("dist_weight", C.c_double * 2)]
+    _fields_ = [("qp", C.c_int32), ("qp_c", C.c_int32 * 2), ("lam", C.c_double), ("dist_weight", C.c_double * 2),
+                ("lmcs_enable", C.c_int32), ("lmcs_chroma_adj", C.c_int32), ("lmcs_min_bin", C.c_int32), ("lmcs_max_bin", C.c_int32), ("lmcs_delta_cw", C.c_int32 * 16)]
 
 
 class _Frame(C.Structure):
@@ -247,13 +248,30 @@ class VvcxEncoder:
         except Exception:
             pass
 
-    def set_slice(self, qp, qp_c, lam, dist_weight):
+    def set_slice(self, qp, qp_c, lam, dist_weight, lmcs=None):
+        """lmcs: None / dict(enable, chroma_adj, min_bin, max_bin, delta_cw[16]) = the LMCS model of the slice (TOOL_LMCS)"""
         s = _Slice()
         s.qp = qp
         s.qp_c[0], s.qp_c[1] = qp_c
         s.lam = lam
         s.dist_weight[0], s.dist_weight[1] = dist_weight
+        if lmcs and lmcs.get("enable"):
+            s.lmcs_enable = 1; s.lmcs_chroma_adj = int(lmcs["chroma_adj"]); s.lmcs_min_bin = int(lmcs["min_bin"]); s.lmcs_max_bin = int(lmcs["max_bin"])
+            for i in range(16):
+                s.lmcs_delta_cw[i] = int(lmcs["delta_cw"][i])
         self._chk(self.L.vvcx_set_slice(self.h, C.byref(s)))
+
+    def lmcs_inverse_reco(self, stream=None):
+        """vvcx_lmcs_inverse_reco: the luma reconstruction of the bound pictures back to the original domain (before deblocking)"""
+        self.L.vvcx_lmcs_inverse_reco.argtypes = [C.c_void_p, C.c_void_p]
+        self._chk(self.L.vvcx_lmcs_inverse_reco(self.h, C.c_void_p(stream or 0)))
+
+    def lmcs_tables(self):
+        n = 1 << self.cfg.bit_depth
+        fwd = np.zeros(n, np.int16); inv = np.zeros(n, np.int16); piv = np.zeros(17, np.int32); cs = np.zeros(16, np.int32)
+        self.L.vvcx_lmcs_tables.argtypes = [C.c_void_p] * 5
+        self._chk(self.L.vvcx_lmcs_tables(self.h, fwd.ctypes.data, inv.ctypes.data, piv.ctypes.data, cs.ctypes.data))
+        return fwd, inv, piv, cs
 
     def bind_frames(self, frames):
         """frames: list of (org_ptrs[3], reco_ptrs[3], strides[3]) with DEVICE pointers (ints)."""

@@ -114,6 +114,55 @@ def test_transform_skip_search_on_cpu_emulator_matches_oracle(emu_so):
     enc.close()
 
 
+def _lmcs_model_10bit():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bitstream_lmcs.npz"))
+    r = [int(v) for v in g["pic_lmcs"][0]]
+    return dict(enable=r[0], chroma_adj=r[1], min_bin=r[2], max_bin=r[3], delta_cw=r[4:])
+
+
+def test_lmcs_tables_of_the_handle_match_the_reference_encoder(emu_so):
+    """vvcx_set_slice builds the forward / inverse LUT, the pivots and the chroma scale table from the slice's model: against the tables the reference ENCODER built
+    (EncReshape::constructReshaperLMCS, == the decoder's Reshape::constructReshaper) for the models its picture analysis chose (tests/golden/lmcs.npz)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "lmcs.npz"))
+    enc = pkg.VvcxEncoder(128, 128, 10, tools=0xf7b, lib_path=emu_so)
+    for row, fwd, inv, piv, cadj in zip(g["models"], g["fwd"], g["inv"], g["pivot"], g["cadj"]):
+        enc.set_slice(int(row[2]), (30, 30), 50.0, (1.0, 1.0), lmcs=dict(enable=int(row[4]), chroma_adj=int(row[5]), min_bin=int(row[6]), max_bin=int(row[7]), delta_cw=[int(v) for v in row[8:]]))
+        f, i, p, c = enc.lmcs_tables()
+        assert np.array_equal(f, fwd) and np.array_equal(i, inv) and np.array_equal(p, piv) and np.array_equal(c, cadj), tuple(row[:4])
+    with pytest.raises(pkg.VvcxError):
+        pkg.VvcxEncoder(128, 128, 10, tools=0xb7b, lib_path=emu_so).set_slice(32, (30, 30), 50.0, (1.0, 1.0), lmcs=_lmcs_model_10bit())      # the tool set has no LMCS
+    enc.close()
+
+
+def test_lmcs_search_on_cpu_emulator_matches_oracle(emu_so):
+    """LMCS on the device path (CPU debug emulation): the original luma forward mapped when the picture is bound, chroma residual scaling from the luma neighbourhood of
+    the 64x64 area (scaled residuals into the transform and the joint candidates, the scale's own table of quantiser constants), mapped-domain reconstruction; then
+    vvcx_lmcs_inverse_reco against the oracle's inverse-mapped picture.  10-bit limited-range picture: what the reference's analysis enables the tool for."""
+    w = h = 16
+    tools, bd, lm = 0xf7b, 10, _lmcs_model_10bit()
+    planes = pkg.synth_frame(w, h, 0, bd, 5, chroma_texture=0.8, oriented=20.0, limited=True)
+    sp = pkg.slice_params(27, bit_depth=bd, dep_quant=True); sp["lmcs"] = lm
+    enc = pkg.VvcxEncoder(w, h, bd, tools=tools, lib_path=emu_so)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"], lmcs=lm)
+    org = [np.ascontiguousarray(p) for p in planes]
+    rec = [np.zeros_like(p) for p in planes]
+    enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
+    res = enc.compress_bound_frames()[0]
+    cus = enc.get_cus(0)
+    ores, ocus, oreco, ocnt = O.compress_frame(planes, w, h, sp, bit_depth=bd, tools=tools)
+    assert np.array_equal(org[0], planes[0])                                         # the caller's plane is left alone: the mapped copy belongs to the handle
+    for k in ores.dtype.names:
+        assert np.array_equal(ores[k], res[k]), k
+    assert len(cus) == len(ocus) and all(np.array_equal(cus[k], ocus[k]) for k in cus.dtype.names)
+    assert all(np.array_equal(rec[c], oreco[c]) for c in range(3))
+    assert np.array_equal(enc.counters(), ocnt)
+    with pytest.raises(pkg.VvcxError):
+        enc.deblock_bound_frames(0, 0)                                                            # the loop filters work in the original domain
+    enc.lmcs_inverse_reco()
+    assert np.array_equal(rec[0], enc.lmcs_tables()[1][oreco[0]].astype(rec[0].dtype))
+    enc.close()
+
+
 @pytest.mark.parametrize("tools", [pkg.TOOLS_DEFAULT, pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM, pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS,
                                    pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_MTS | pkg.TOOL_MIP])
 def test_emulated_slice_data_writer_matches_oracle(emu_so, tools):
