@@ -163,8 +163,7 @@ struct Lds {
   int8_t ps_lfnst, ps_mts, ps_grp, ps_pad; int rc_last[NW]; uint8_t rd_lfl[16];
   // the DST-VII pass prepared by the DCT-II pass (stage_b_rounds): number of prepared items (0: none), item of each candidate of the running pass, absSum per item
   int8_t spec_n; uint8_t rd_src[16]; int spec_abs[16];
-  int lmcs_cadj, lmcs_tab, lmcs_sum[2];   // LMCS: chroma residual scale of the chroma node being coded (0: none), its table of quantiser constants (1 + bin; 0: unscaled), partial sums
-  int ts_tab[36]; uint8_t ts_keep[16];   // transform skip: fractional bits of the TS context sets at the node's start contexts (ts_build_tables); candidates of the chunk that try it
+  int lmcs_cadj, lmcs_tab;         // LMCS: chroma residual scale of the chroma node being coded (0: none), its table of quantiser constants (1 + bin; 0: unscaled)
   int dc_val[4];
   int cur_tile, frame, ctu_x, ctu_y, tree_ch;
   int d;                           // current recursion level
@@ -175,7 +174,8 @@ struct Lds {
   VxParams par; VxFrameDev fdv;     // launch parameters and the stream's picture record: read from here inside the out-of-line functions (a reference
                                     // parameter to them is a generic pointer into the kernarg copy in scratch / into HBM: flat loads with full waits)
   // CCLM: down-sampled luma of the chroma node (nodes of at most BUF chroma samples; bigger ones in HBM scratch), availability and line parameters
-  alignas(16) int16_t lm_in[BUF / 2]; int16_t lm_top[64], lm_left[64]; int lm_info[4], lm_ok, lm_nsatd; int lm_par[2][3][3]; int64_t lm_cost[8];
+  // (the luma full-RD stage keeps the fractional bits of the transform-skip context sets where the chroma operations keep the CCLM neighbour lines: ts_build_tables)
+  alignas(16) int16_t lm_in[BUF / 2]; union { struct { int16_t lm_top[64], lm_left[64]; }; int ts_tab[36]; }; int lm_info[4], lm_ok, lm_nsatd; int lm_par[2][3][3]; int64_t lm_cost[8];
   int16_t fa_nb[5][4]; int fa_n, fa_res, fa_feat[27];      // FAST_ALGORITHM: neighbour CUs {x, y, w, h} of the node, forest answer, features
   Arith aw; uint8_t *aw_out; uint32_t aw_cap; int colm;      // bitstream pass: arithmetic coder, its output (HBM) and capacity; co-located luma mode of the chroma node
   unsigned long long prof[VVCX_STAMP ? 48 : 1];    // shader-clock ticks per operation kind (diagnostic build only, see vvcx_get_profile)
@@ -1608,12 +1608,12 @@ __device__ __noinline__ void lmcs_chroma_adj(int nx, int ny)
     if (wave == 0 && availL) { const int k = (y + lane) >= p.pic_h ? p.pic_h - y - 1 : lane; v = ld_px<T>(rec, (y + k) * st + x - 1); }
     if (wave == 1 && availA) { const int k = (x + lane) >= p.pic_w ? p.pic_w - x - 1 : lane; v = ld_px<T>(rec, (y - 1) * st + x + k); }
     v = wave_sum_i32(v);
-    if (lane == 0) L.lmcs_sum[wave] = v;
+    if (lane == 0) L.lm_info[wave] = v;                   // scratch: the CCLM set-up that follows writes it
   }
   __threadfence_block();
   __syncthreads();
   if (VTX == 0) {
-    const int n = 64 * (availL + availA), sum = L.lmcs_sum[0] + L.lmcs_sum[1], mx = (1 << p.bit_depth) - 1;
+    const int n = 64 * (availL + availA), sum = L.lm_info[0] + L.lm_info[1], mx = (1 << p.bit_depth) - 1;
     int v = n == 64 ? (sum + 32) >> 6 : n == 128 ? (sum + 64) >> 7 : 1 << (p.bit_depth - 1);
     v = v < 0 ? 0 : v > mx ? mx : v;
     int idx = p.lmcs_min_bin;
@@ -2615,7 +2615,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       ts_build_tables();
       for (int i = wave; i < nA; i += NW) {
         const int sa = wave_ts_fwd(org, poolPred + (size_t) i * P, poolCoef + (size_t) i * P, w, h, bd, lane);
-        if (lane == 0) L.ts_keep[i] = (uint8_t) ((double) sa <= (double) recB[i].sum0);
+        if (lane == 0) L.rb_pairs[i] = (uint8_t) ((double) sa <= (double) recB[i].sum0);      // keep flags (the list of MTS items is not built in this pass)
       }
       __threadfence_block();
       __syncthreads();
@@ -2623,14 +2623,14 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       {
         const int j = lane * NW + wave;
         int cnt = 0, mine = -1;
-        for (int i = 0; i < nA; i++) if (L.ts_keep[i]) { if (cnt == j) mine = i; cnt++; }
+        for (int i = 0; i < nA; i++) if (L.rb_pairs[i]) { if (cnt == j) mine = i; cnt++; }
         if (mine >= 0) L.dq_abs[mine] = ts_rdoq_lane(poolCoef + (size_t) mine * P, w, h, bd, p.qp_tr);
       }
       __threadfence_block();
       __syncthreads();
       // ---- T3: reconstruction, rate and cost of the non-empty ones (an empty transform-skip block is forbidden, 3567-3571); strict < against the candidate's DCT-II result
       for (int i = wave; i < nA; i += NW) {
-        if (!uni((int) L.ts_keep[i])) continue;
+        if (!uni((int) L.rb_pairs[i])) continue;
         nmts++;
         if (uni(L.dq_abs[i]) <= 0) continue;
         const int c = c0 + i, mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);

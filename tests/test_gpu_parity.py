@@ -18,7 +18,7 @@ def _run_gpu(frames, W, H, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=Tru
     import torch
     enc = pkg.VvcxEncoder(W, H, bit_depth, tile_cols=tile_cols, tile_rows=tile_rows, chroma=chroma, tools=tools, max_frames=len(frames),
                           forest=_forest(forest_qp) if tools & pkg.TOOL_FAST else None)
-    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"], lmcs=sp.get("lmcs"))
     dev = []
     for planes in frames:
         conv = [p if p.dtype == np.uint8 else p.view(np.int16) for p in planes]
@@ -195,6 +195,31 @@ def test_transform_skip_in_the_search(case):
 def test_transform_skip_without_cu_reuse_and_with_classifier():
     _check([pkg.synth_frame(128, 128, 0, 8, 11, chroma_texture=0.5, screen=0.7)], 128, 128, pkg.slice_params(32, dep_quant=True), tools=TSK & ~pkg.TOOL_CU_REUSE)
     _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=1.0, oriented=30.0, screen=0.5)], 256, 128, pkg.slice_params(27, dep_quant=True), tools=TSK | pkg.TOOL_FAST)
+
+
+def _lmcs_model(bd):
+    # a model the reference encoder's own picture analysis chose (10-bit limited-range fixture picture); scaled to the 8-bit code-word budget for 8-bit cases
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bitstream_lmcs.npz"))
+    r = [int(v) for v in g["pic_lmcs"][0]]
+    return dict(enable=r[0], chroma_adj=r[1], min_bin=r[2], max_bin=r[3], delta_cw=[v if bd == 10 else v // 4 for v in r[4:]])
+
+
+@pytest.mark.parametrize("case", [(128, 128, 32, 10, 1, 1, 9, 0.3), (200, 136, 27, 10, 1, 1, 1234, 0.0), (256, 128, 37, 8, 2, 1, 5, 0.4), (128, 128, 22, 8, 1, 1, 3, 0.0)])
+def test_lmcs_in_the_search(case):
+    # tools 0xffb: the slice carries an LMCS model: original luma forward mapped at bind time, the search in the mapped domain, chroma residual scaling per 64x64 area
+    # from its luma neighbourhood (scaled residuals into the transform / the joint candidates, inverse scaling at reconstruction and in the reuse path, the quantiser's
+    # lambda divided by the squared scale); limited-range pictures (what the reference's analysis enables the tool for)
+    W, H, qp, bd, tc, tr, seed, scr = case
+    sp = pkg.slice_params(qp, bit_depth=bd, dep_quant=True); sp["lmcs"] = _lmcs_model(bd)
+    _check([pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=0.8, oriented=25.0, screen=scr, limited=True)], W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=TSK | pkg.TOOL_LMCS)
+
+
+def test_lmcs_tool_with_a_slice_that_disables_it_and_without_cu_reuse():
+    # the reference's analysis switches LMCS off for full-range pictures: the tool bit alone must not change anything
+    _check([pkg.synth_frame(128, 128, 0, 8, 11, chroma_texture=0.5)], 128, 128, pkg.slice_params(32, dep_quant=True), tools=TSK | pkg.TOOL_LMCS)
+    sp = pkg.slice_params(32, bit_depth=10, dep_quant=True); sp["lmcs"] = _lmcs_model(10)
+    _check([pkg.synth_frame(128, 128, 0, 10, 12, chroma_texture=1.0, limited=True)], 128, 128, sp, bit_depth=10, tools=(TSK | pkg.TOOL_LMCS) & ~pkg.TOOL_CU_REUSE)
 
 
 FAST = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_FAST

@@ -391,6 +391,23 @@ def test_submit_and_wait_halves_equal_the_blocking_call(emu_so):
     a.close(); b.close()
 
 
+def test_resource_budget_of_the_compress_kernel(hip_lib):
+    """The stream kernel is sized for four workgroups per CU (128 VGPRs, 40 KB LDS, 1024 resident streams per GPU).  A field too many in the LDS object
+    drops the residency to three and makes the compiler give up the register target as well (seen in round 3: 41 008 B -> 257 VGPRs, one wave per SIMD), without any
+    test failing: check the built code object's metadata.  profiles/r03_codeobj.json is this report, committed with the build it describes."""
+    import importlib.util
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-readelf")):
+        pytest.skip("llvm tools not installed")
+    spec = importlib.util.spec_from_file_location("codeobj_report", os.path.join(ROOT, "tools", "codeobj_report.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    r = m.report(HIP_SO)
+    for name in ("vvcx_compress_kernel_u8", "vvcx_compress_kernel_u16"):
+        k = r["kernels"][name]
+        assert k["group_segment_fixed_size"] <= 40960, (name, k)
+        assert k["vgpr_count"] + k.get("agpr_count", 0) <= 128, (name, k)
+
+
 def test_barrier_shape_of_the_operation_loop(hip_lib):
     """Guard against the round-1 hang (a workgroup barrier reached by the controller's wave under a partial exec mask, DESIGN.md §5 note 1): in the built gfx950
     code object, every s_barrier of the operation loop (run_tree) and of its fused tail (after_intra_op) is reached with exec restored - the last instruction
