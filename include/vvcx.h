@@ -247,6 +247,12 @@ int  vvcx_lfnst_depquant_batch(const int16_t *org, const int16_t *pred, int w, i
  * bits CABACWriter::residual_codingTS (EL/CABACWriter.cpp:4306-4555) spends on the levels.  qp = slice QP + QpBDOffset (the TS minimum QP 4 is applied inside). */
 int  vvcx_transform_skip_batch(const int16_t *resi, int w, int h, int bit_depth, int qp, double lambda, const uint16_t *s0, const uint16_t *s1, int n,
                                int16_t *lev, int16_t *resi_out, int32_t *abs_sum, uint8_t *keep, uint64_t *frac_bits, int device);
+/* the block pipeline of n luma TUs of tw x th samples (1 x N, 2 x N, N x 1, N x 2 or larger; at least 16 samples) of CUs coded with intra sub-partitions (VVCX_TOOL_ISP): ≙
+ * TrQuant::transformNxN with the implicit DST-VII / DCT-II choice of ISP blocks (getTrTypes, CL/TrQuant.cpp:752-780) and the one-stage transforms of one-sample-wide
+ * blocks (895-914, 970-983), DepQuant::quant with the cbf context of ISP sub-partitions (prev_cbf = the previous sub-partition's cbf; cbf_inferred: the last
+ * sub-partition after all-zero ones, EL/CABACWriter.cpp:3574-3600), dequantisation, inverse, reconstruction over pred; qp = slice QP + QpBDOffset */
+int  vvcx_isp_tu_batch(const int16_t *org, const int16_t *pred, int tw, int th, int bit_depth, int qp, double lambda, int prev_cbf, int cbf_inferred,
+                       const uint16_t *s0, const uint16_t *s1, int n, int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device);
 /* coefficient scan (diagonal, grouped) of a w x h block: idx[min(w,32) * min(h,32)] raster offsets in scan order */
 int  vvcx_scan_order(int w, int h, uint16_t *idx, int device);
 /* ≙ BIN/TEST.py GetPartition(C0..C25, 2): the forest of vvcx_set_forest on n rows of 26 int32 features (host pointers) → class per row */

@@ -33,6 +33,7 @@ extern "C" __global__ void vvcx_leaf_dq_kernel(VxParams p, const uint16_t *ctx, 
 extern "C" __global__ void vvcx_leaf_ts_kernel(VxParams p, const uint16_t *ctx, const int16_t *resi, int16_t *lev, int16_t *resi_out, int32_t *tmp, int w, int h, int qp, int *out, unsigned long long *bits);
 extern "C" __global__ void vvcx_lmcs_map_kernel_u8(const uint8_t *src, uint8_t *dst, int w, int h, int stride, const int16_t *lut);
 extern "C" __global__ void vvcx_lmcs_map_kernel_u16(const uint16_t *src, uint16_t *dst, int w, int h, int stride, const int16_t *lut);
+extern "C" __global__ void vvcx_leaf_isp_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int qp, int cbf_ctx, unsigned long long *out);
 extern "C" __global__ void vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp, unsigned long long *out);
 
 static thread_local char g_err[512];
@@ -960,6 +961,37 @@ extern "C" int vvcx_lfnst_depquant_batch(const int16_t *org, const int16_t *pred
 {
   if (lfnst_idx < 0 || lfnst_idx > 2 || intra_dir < 0 || intra_dir > 66) return fail(VVCX_ERR_ARG, "bad argument");
   return depquant_batch_impl(org, pred, w, h, bit_depth, qp, comp, 0, cbf_cb, lambda, s0, s1, n, lev, rec, sse, cbf, device, lfnst_idx, intra_dir);
+}
+
+// ≙ TrQuant::transformNxN / DepQuant::quant / invTransformNxN of one luma TU (tw x th: 1 x N, 2 x N, N x 1, N x 2 or larger) of a CU with cu.ispMode set: implicit DST-VII /
+// DCT-II (getTrTypes 752-780), the one-stage transforms of one-sample-wide blocks, the cbf context of ISP sub-partitions (QtCbf[Y] + 2 + prev_cbf; inferred: no cbf rate)
+extern "C" int vvcx_isp_tu_batch(const int16_t *org, const int16_t *pred, int tw, int th, int bit_depth, int qp, double lambda, int prev_cbf, int cbf_inferred,
+                                 const uint16_t *s0, const uint16_t *s1, int n, int16_t *lev, int16_t *rec, uint64_t *sse, uint8_t *cbf, int device)
+{
+  const bool shape = tw >= 1 && th >= 1 && tw <= 64 && th <= 64 && !(tw & (tw - 1)) && !(th & (th - 1)) && tw * th >= 16;
+  if (!org || !pred || !lev || !rec || !sse || !cbf || !s0 || !s1 || n < 0 || !shape || (bit_depth != 8 && bit_depth != 10) || qp < 0 || qp > 75 || !(lambda > 0.0)) return fail(VVCX_ERR_ARG, "bad argument");
+  if (n == 0) return VVCX_OK;
+  HIPCHK(hipSetDevice(device));
+  const size_t bytes = (size_t) n * tw * th * 2;
+  DevBuf dorg, drec, dlev, dtmp, dout, dctx, dtab, dscr;
+  HIPCHK(dorg.alloc(bytes)); HIPCHK(drec.alloc(bytes)); HIPCHK(dlev.alloc(bytes)); HIPCHK(dtmp.alloc((size_t) n * 2048 * 4)); HIPCHK(dout.alloc((size_t) n * 16));
+  HIPCHK(dctx.alloc(2 * VXD_NUM_CTX * 2)); HIPCHK(dtab.alloc(96 * sizeof(VxDqConst))); HIPCHK(dscr.alloc((size_t) n * VXD_OFF_CACHE));
+  HIPCHK(hipMemcpy(dorg.p, org, bytes, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(drec.p, pred, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dctx.p, s0, VXD_NUM_CTX * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dctx.as<uint16_t>() + VXD_NUM_CTX, s1, VXD_NUM_CTX * 2, hipMemcpyHostToDevice));
+  VxDqConst tab[96]; memset(tab, 0, sizeof tab);
+  for (int lsum = 2; lsum <= 12; lsum++) tab[lsum] = dq_consts_of(lsum, bit_depth, qp, lambda);
+  HIPCHK(hipMemcpy(dtab.p, tab, sizeof tab, hipMemcpyHostToDevice));
+  VxParams p; memset(&p, 0, sizeof p);
+  p.bit_depth = bit_depth; p.tools = VVCX_TOOL_DEPQUANT | VVCX_TOOL_MTS | VVCX_TOOL_LFNST | VVCX_TOOL_ISP; p.dq_consts = dtab.as<VxDqConst>(); p.scratch = dscr.as<uint8_t>(); p.scratch_per_stream = VXD_OFF_CACHE;
+  p.lambda = lambda;
+  hipLaunchKernelGGL(vvcx_leaf_isp_kernel, dim3((unsigned) n), dim3(VXD_NT), 0, 0, p, dctx.as<uint16_t>(), dorg.as<int16_t>(), drec.as<int16_t>(), dlev.as<int16_t>(), dtmp.as<int32_t>(),
+                     tw, th, qp, cbf_inferred ? -1 : (int) VX_CTX_QtCbf[0] + 2 + (prev_cbf ? 1 : 0), dout.as<unsigned long long>());
+  HIPCHK(hipGetLastError());
+  std::vector<unsigned long long> o((size_t) n * 2);
+  HIPCHK(hipMemcpy(lev, dlev.p, bytes, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(rec, drec.p, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(o.data(), dout.p, (size_t) n * 16, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) { sse[i] = o[(size_t) i * 2]; cbf[i] = (uint8_t) o[(size_t) i * 2 + 1]; }
+  return VVCX_OK;
 }
 
 // ≙ TrQuant::transformNxN / invTransformNxN of a luma TU with tu.mtsIdx = MTS_SKIP and the {DCT2, TS} pruning in front of it (CL/TrQuant.cpp:1049-1124, 1394-1440, 996-1041),

@@ -163,7 +163,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   const ScanGeo geo = scan_geo(w, h);
   const int lcw = geo.lcw, lch = geo.lch, lcg = geo.lcg, gs = 1 << lcg, total = geo.nscan;
   const int nzw = imin(32, w), nzh = imin(32, h), wsbb = geo.wg, hsbb = geo.hg;
-  const uint8_t *cg_inv = L.t.cg_inv + (lcw == 2 ? 0 : lcw == 3 ? 20 : lch == 3 ? 36 : 16);
+  const uint8_t *cg_inv = L.t.cg_inv + cg_tab_off(lcw, lch);
   const uint8_t *grp_inv = L.t.grp_inv + 15 * (wsbb - 1) + wsbb * (hsbb - 1);
   int effW = w, effH = h, zeroOut = 0;
   if (zo && comp == 0) { effH = h == 32 ? 16 : h; effW = w == 32 ? 16 : w; zeroOut = effH < h || effW < w; }
@@ -272,7 +272,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   // neighbour's place in that group's level bytes
   unsigned eosW = 0;
   if (lane < gs) {
-    const int off = lcw == 2 ? 0 : lcw == 3 ? 20 : lch == 3 ? 36 : 16;
+    const int off = cg_tab_off(lcw, lch);
     const int xy = L.t.cg_scan[off + lane], gx = xy & 15, gy = xy >> 4;
 #pragma unroll
     for (int n = 0; n < 5; n++) {

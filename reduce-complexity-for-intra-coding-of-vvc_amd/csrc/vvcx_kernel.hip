@@ -113,8 +113,8 @@ struct Tables {                    // constant tables staged once per workgroup 
   uint8_t  ctx_rate[NCTX + 2], gorice_pars[32], gorice_pos0[96], rice_len[128], group_idx[64], mode_num[36], intra_thr[8];
   alignas(16) int8_t dst7[16 + 64 + 256 + 1024];   // DST-VII 4..32 (explicit MTS); DCT-VIII[k][i] = (-1)^k DST-VII[k][n-1-i] is read from the same rows
   alignas(16) int8_t dct[4 + 16 + 64 + 256 + 1024];   // DCT-II 2..32 (the 64-point matrix is only used by 64x64 luma nodes, which never are LDS resident: read from constant memory)
-  uint8_t  cg_scan[52], grp_scan[228];   // diagonal scans (CL/Rom.cpp:87-131) as x | y << 4: inside a coefficient group {4x4, 2x2, 8x2, 2x8}; of the groups, per (log2 wg, log2 hg)
-  uint8_t  cg_inv[52], grp_inv[228];     // their inverses: raster position (y * width + x) -> scan index, same table offsets
+  uint8_t  cg_scan[84], grp_scan[228];   // diagonal scans (CL/Rom.cpp:87-131) as x | y << 4: inside a coefficient group {4x4, 2x2, 8x2, 2x8, 16x1, 1x16}; of the groups, per (log2 wg, log2 hg)
+  uint8_t  cg_inv[84], grp_inv[228];     // their inverses: raster position (y * width + x) -> scan index, same table offsets
 };
 
 #define RC_LIST 320
@@ -146,7 +146,7 @@ struct Lds {
   int pre_copy_d;                  // >= 0: before the posted operation, snapshot the estimator's contexts as the start contexts of level pre_copy_d
   int nx, ny, nw, nh, nd;          // node of the posted op (luma coordinates) and its level
   // candidates
-  Cand cand[64]; double cand_cost[64]; double cand_had[64]; int n_cand;
+  Cand cand[64]; double cand_cost[64]; int n_cand;
   // prediction parameters of each SATD-stage candidate (initPredIntraParams), packed, derived once per SATD operation; the full-RD operations keep the
   // dependent quantiser's rate tables of the node here (dq_build_tables)
   union { uint2 cand_ipa[64]; int dq_tab[DQ_TAB_INTS]; };
@@ -354,9 +354,13 @@ __device__ void cg_shape(int w, int h, int &lcw, int &lch)     // g_log2SbbSize,
 {
   const int lw = ilog2i(w), lh = ilog2i(h);
   if (lw >= 2 && lh >= 2) { lcw = 2; lch = 2; return; }
+  if (lh == 0) { lcw = imin(lw, 4); lch = 0; return; }             // N x 1 / 1 x N sub-partitions of ISP CUs: groups of 16 x 1 / 1 x 16
+  if (lw == 0) { lcw = 0; lch = imin(lh, 4); return; }
   if (lh == 1) { lcw = lw >= 3 ? 3 : 1; lch = 1; return; }
   lcw = 1; lch = lh >= 3 ? 3 : 1;
 }
+// where the scan of a coefficient group shape starts in Tables::cg_scan / cg_inv: 4x4, 2x2, 8x2, 2x8, 16x1, 1x16
+__device__ inline int cg_tab_off(int lcw, int lch) { return lcw == 2 ? 0 : lcw == 3 ? 20 : lch == 3 ? 36 : lcw == 4 ? 52 : lch == 4 ? 68 : 16; }
 // position of scan index sp inside a bw x bh diagonal scan (CL/Rom.cpp:87-131), closed form by walking
 __device__ void diag_pos(int bw, int bh, int n, int &ox, int &oy)
 {
@@ -428,7 +432,7 @@ __device__ inline ScanGeo scan_geo(int w, int h)
   g.lcg = g.lcw + g.lch; g.w = w;
   const int zw = imin(32, w), zh = imin(32, h);
   g.wg = zw >> g.lcw; g.hg = zh >> g.lch; g.nscan = zw * zh;
-  g.cg = L.t.cg_scan + (g.lcw == 2 ? 0 : g.lcw == 3 ? 20 : g.lch == 3 ? 36 : 16);
+  g.cg = L.t.cg_scan + cg_tab_off(g.lcw, g.lch);
   const int a = ilog2i(g.wg), b = ilog2i(g.hg);
   g.grp = L.t.grp_scan + 15 * ((1 << a) - 1) + (1 << a) * ((1 << b) - 1);
   return g;
@@ -1556,6 +1560,10 @@ __device__ void load_tables()
     L.t.cg_scan[tid] = (uint8_t) (x | (y << 4));
     L.t.cg_inv[(t == 0 ? 0 : t == 1 ? 16 : t == 2 ? 20 : 36) + y * (t == 0 ? 4 : t == 2 ? 8 : 2) + x] = (uint8_t) n;
   }
+  if (tid < 32) {                                       // the one-dimensional groups of N x 1 / 1 x N blocks: positions in order
+    const int n = tid & 15;
+    L.t.cg_scan[52 + tid] = (uint8_t) (tid < 16 ? n : n << 4); L.t.cg_inv[52 + tid] = (uint8_t) n;
+  }
   for (int i = tid; i < 225; i += NT) {
     int a = 0, b = 0, off = 0;                           // table of (lwg = a, lhg = b) starts at 15 (2^a - 1) + 2^a (2^b - 1)
     for (int aa = 0; aa < 4; aa++) for (int bb = 0; bb < 4; bb++) { const int o = 15 * ((1 << aa) - 1) + (1 << aa) * ((1 << bb) - 1); if (o <= i) { a = aa; b = bb; off = o; } }
@@ -1907,6 +1915,108 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
     }
   } else {
     for (int o = lane; o < P; o += 64) { const int d = org[o] - rec[o]; sse += (unsigned long long) (d * d); }
+  }
+  wave_sync();
+  sse_out = wave_sum_u64(sse);
+  cbf_out = abs_sum > 0;
+}
+// The block pipeline of one sub-partition of an ISP CU (TU of tw x th samples; 1 x N, 2 x N, N x 1, N x 2 and larger): implicit transform selection (TrQuant::getTrTypes
+// 752-780: DST-VII along a side of 4..16 samples, DCT-II otherwise), the one-stage forms of N x 1 / 1 x N blocks (xT 895-914, xIT 970-983), dependent quantisation
+// against the context set ci (the estimator's live contexts: the sub-partitions of a CU are coded one after the other) with the cbf context cbf_ctx (< 0: the cbf is
+// inferred), dequantisation, inverse, reconstruction over the prediction in rec, SSE.  org / rec / lev: tiles of the CU (stride cst) at the TU's origin.
+// given >= 0: the levels in lev are taken as coded (cbf = given): decoder half only.  tmp: th * min(32, tw) int32 (and its int16 re-use).
+__device__ __noinline__ void wave_code_block_isp(const int16_t *org, int16_t *rec, int16_t *lev, int cst, int32_t *tmp, int16_t *cf, uint8_t *scratch, int w, int h, int bd, int qp,
+                                                 int lane, unsigned long long &sse_out, int &cbf_out, int given, int ci, int cbf_ctx)
+{
+  // cf: a dense w * h int16 tile for the coefficients / levels (the trellis and the residual syntax take stride w)
+  w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given); cst = uni(cst);
+  const int trh = (w >= 4 && w <= 16) ? 2 : 0, trv = (h >= 4 && h <= 16) ? 2 : 0;
+  const int P = w * h, lw = ilog2i(w), lh = ilog2i(h);
+  const int zw = imin(w, 32), zh = imin(h, 32), lzw = ilog2i(zw);
+  const int8_t *Mw = w > 1 ? tr_matrix<false>(trh, w) : nullptr, *Mh = h > 1 ? tr_matrix<false>(trv, h) : nullptr;
+  const int oneD = w == 1 || h == 1;
+  if (given < 0) {
+    if (!oneD) {
+      const int shift1 = lw + bd + 6 - 15, shift2 = lh + 6;
+      const int rnd1 = shift1 > 0 ? 1 << (shift1 - 1) : 0, rnd2 = 1 << (shift2 - 1);
+      for (int o = lane; o < zw * h; o += 64) {
+        const int k = o >> lh, j = o & (h - 1);
+        int s = 0;
+        for (int i = 0; i < w; i++) s += Mw[k * w + i] * (org[j * cst + i] - rec[j * cst + i]);
+        tmp[o] = (s + rnd1) >> shift1;
+      }
+      wave_sync();
+      for (int o = lane; o < P; o += 64) cf[o] = 0;
+      wave_sync();
+      for (int o = lane; o < zw * zh; o += 64) {
+        const int m = o >> lzw, k = o & (zw - 1);
+        int s = 0;
+        for (int j = 0; j < h; j++) s += Mh[m * h + j] * tmp[k * h + j];
+        cf[m * w + k] = (int16_t) ((s + rnd2) >> shift2);
+      }
+    } else {
+      const int n = w * h, ln = lw + lh, zn = imin(n, 32), shift = ln + bd + 6 - 15, rnd = shift > 0 ? 1 << (shift - 1) : 0, step = w == 1 ? cst : 1;
+      const int8_t *M = w == 1 ? Mh : Mw;
+      for (int o = lane; o < n; o += 64) {
+        int s = 0;
+        if (o < zn) for (int i = 0; i < n; i++) s += M[o * n + i] * (org[i * step] - rec[i * step]);
+        cf[o] = (int16_t) (o < zn ? (s + rnd) >> shift : 0);
+      }
+    }
+    wave_sync();
+  } else {
+    for (int o = lane; o < P; o += 64) cf[o] = lev[(o >> lw) * cst + (o & (w - 1))];
+    wave_sync();
+  }
+  int abs_sum = given;
+  if (given < 0) abs_sum = wave_depquant<false>(cf, 0, scratch, ci, w, h, 0, cbf_ctx, 0, 0, lane);
+  wave_sync();
+  if (given < 0) { for (int o = lane; o < P; o += 64) lev[(o >> lw) * cst + (o & (w - 1))] = cf[o]; }
+  unsigned long long sse = 0;
+  const int mx = (1 << bd) - 1;
+  if (abs_sum > 0) {
+    int16_t *deq = (int16_t *) tmp, *tcol = deq + zw * zh;
+    wave_dequant_dq(cf, deq, w, h, zw, zh, bd, qp, lane);
+    const int ishift2 = (6 + 15 - 1) - bd;
+    if (!oneD) {
+      for (int o = lane; o < zw * h; o += 64) {
+        const int j = o >> lh, i = o & (h - 1);
+        int s = 0;
+        for (int k = 0; k < zh; k++) s += Mh[k * h + i] * deq[(k << lzw) + j];
+        const int v = (s + 64) >> 7;
+        tcol[o] = (int16_t) (v < -32768 ? -32768 : v > 32767 ? 32767 : v);
+      }
+      wave_sync();
+      const int irnd2 = 1 << (ishift2 - 1);
+      for (int o = lane; o < P; o += 64) {
+        const int j2 = o >> lw, i2 = o & (w - 1);
+        int s = 0;
+        for (int k = 0; k < zw; k++) s += Mw[k * w + i2] * tcol[k * h + j2];
+        int r = (s + irnd2) >> ishift2;
+        r = r < -32768 ? -32768 : r > 32767 ? 32767 : r;
+        int v = rec[j2 * cst + i2] + (int) (int16_t) r;
+        v = v < 0 ? 0 : v > mx ? mx : v;
+        rec[j2 * cst + i2] = (int16_t) v;
+        const int d = org[j2 * cst + i2] - v;
+        sse += (unsigned long long) (d * d);
+      }
+    } else {
+      const int n = w * h, zn = imin(n, 32), sh = ishift2 + 1, rnd = 1 << (sh - 1), step = w == 1 ? cst : 1;
+      const int8_t *M = w == 1 ? Mh : Mw;
+      for (int o = lane; o < n; o += 64) {
+        int s = 0;
+        for (int k = 0; k < zn; k++) s += M[k * n + o] * deq[k];
+        int r = (s + rnd) >> sh;
+        r = r < -32768 ? -32768 : r > 32767 ? 32767 : r;
+        int v = rec[o * step] + (int) (int16_t) r;
+        v = v < 0 ? 0 : v > mx ? mx : v;
+        rec[o * step] = (int16_t) v;
+        const int d = org[o * step] - v;
+        sse += (unsigned long long) (d * d);
+      }
+    }
+  } else {
+    for (int o = lane; o < P; o += 64) { const int a = (o >> lw) * cst + (o & (w - 1)); const int d = org[a] - rec[a]; sse += (unsigned long long) (d * d); }
   }
   wave_sync();
   sse_out = wave_sum_u64(sse);
@@ -2264,7 +2374,6 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
       const unsigned long long msh = sd * 2 < st ? sd * 2 : st;
       const double a = (double) mbits * p.sqrt_lambda_fp;
       L.cand_cost[cc] = (double) msh + a;
-      L.cand_had[cc] = (double) msh;
     }
     wave_sync();
   }
@@ -2300,7 +2409,6 @@ __device__ __noinline__ void stage_a_mip(const VxParams &p, uint8_t *scratch, in
       const unsigned long long mbits = luma_mode_bits(L.ctxs[CI_CUR], L.ny, mode, MIPF);
       const double a = (double) mbits * p.sqrt_lambda_fp;
       L.cand_cost[c] = (double) msh + a;
-      L.cand_had[c] = (double) msh;
     }
     wave_sync();
   }
@@ -2333,7 +2441,6 @@ __device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int 
       const unsigned long long msh = sad * 2 < satd ? sad * 2 : satd;
       const double a = (double) mbits * p.sqrt_lambda_fp;
       L.cand_cost[c] = (double) msh + a;
-      L.cand_had[c] = (double) msh;
     }
     wave_sync();
   }
@@ -4391,6 +4498,22 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_ts_kernel(Vx
     if (a > 0) rc_ts_serial(cb, lev + b, w, h);
     out[blockIdx.x * 2] = a; out[blockIdx.x * 2 + 1] = sa <= sum0; bits[blockIdx.x] = cb.bits;
   }
+}
+// one sub-partition block of an ISP CU per workgroup (tests/golden/isp.npz): implicit transform, dependent quantisation with the ISP cbf context (cbf_ctx < 0: inferred),
+// dequantisation, inverse, reconstruction; rec holds the prediction on entry
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_isp_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp,
+                                                                               int w, int h, int qp, int cbf_ctx, unsigned long long *out)
+{
+  if (VTX == 0) { L.par = p; L.lmcs_tab = 0; }
+  load_tables();
+  for (int i = VTX; i < NCTX; i += NT) { L.ctxs[CI_CUR].s0[i] = ctx[i]; L.ctxs[CI_CUR].s1[i] = ctx[NCTX + i]; }
+  __syncthreads();
+  const int wave = uni(VTX >> 6), lane = VTX & 63, P = w * h;
+  if (wave != 0) return;
+  const size_t b = (size_t) blockIdx.x * P;
+  unsigned long long sse; int cbf;
+  wave_code_block_isp(org + b, rec + b, lev + b, w, tmp + (size_t) blockIdx.x * 2048, lev + b, p.scratch + (size_t) blockIdx.x * p.scratch_per_stream, w, h, p.bit_depth, qp, lane, sse, cbf, -1, CI_CUR, cbf_ctx);
+  if (lane == 0) { out[blockIdx.x * 2] = sse; out[blockIdx.x * 2 + 1] = (unsigned long long) cbf; }
 }
 template <typename T>
 __device__ void leaf_pred(const VxParams &p, const VxLeafPred *cases, int16_t *out, const int *out_off)

@@ -428,6 +428,19 @@ def transform_skip_batch(resi, w, h, bit_depth, qp, lam, s0, s1, device=0, lib_p
     return lev.reshape(n, h, w), out.reshape(n, h, w), a, keep, bits
 
 
+def isp_tu_batch(org, pred, tw, th, bit_depth, qp, lam, prev_cbf, cbf_inferred, s0, s1, device=0, lib_path=None):
+    """vvcx_isp_tu_batch: n sub-partition blocks of ISP CUs through the implicit transform, the dependent quantiser with the ISP cbf context, dequantiser and inverse"""
+    L = load_library(lib_path)
+    org = np.ascontiguousarray(org, np.int16).ravel(); pred = np.ascontiguousarray(pred, np.int16).ravel()
+    s0 = np.ascontiguousarray(s0, np.uint16); s1 = np.ascontiguousarray(s1, np.uint16)
+    n = org.size // (tw * th)
+    lev = np.zeros(org.size, np.int16); rec = np.zeros(org.size, np.int16); sse = np.zeros(n, np.uint64); cbf = np.zeros(n, np.uint8)
+    L.vvcx_isp_tu_batch.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int]
+    _chk(L, L.vvcx_isp_tu_batch(org.ctypes.data, pred.ctypes.data, tw, th, bit_depth, qp, lam, int(prev_cbf), int(cbf_inferred), s0.ctypes.data, s1.ctypes.data, n,
+                                lev.ctypes.data, rec.ctypes.data, sse.ctypes.data, cbf.ctypes.data, device))
+    return lev.reshape(n, th, tw), rec.reshape(n, th, tw), sse, cbf
+
+
 def lfnst_depquant_batch(org, pred, w, h, bit_depth, qp, comp, lfnst_idx, intra_dir, cbf_cb, lam, s0, s1, device=0, lib_path=None):
     """vvcx_lfnst_depquant_batch: n blocks through DCT-II (zeroed out), forward LFNST, dependent quantiser, dequantiser, inverse LFNST, inverse DCT-II"""
     L = load_library(lib_path)
