@@ -99,6 +99,8 @@ typedef struct {
   uint8_t  mip_flag;             /* cu.mipFlag of a luma CU (VVCX_TOOL_MIP): intra_dir is then the MIP mode, mrl_idx 0 */
   uint8_t  lfnst_idx;            /* cu.lfnstIdx of the CU (VVCX_TOOL_LFNST): 0 none, 1 / 2 the kernel of the set */
   uint8_t  joint_cb_cr;          /* tu.jointCbCr of a chroma CU (VVCX_TOOL_JCCR): 0 separate residuals, 1..3 the cbf mask of the joint residual */
+  uint8_t  isp_mode;             /* cu.ispMode of a luma CU (VVCX_TOOL_ISP): 0 none, 1 horizontal split (sub-partitions stacked), 2 vertical split */
+  uint8_t  tu_cbf;               /* ISP: bit k = cbf of sub-partition k (cbf bit 0 is then their OR) */
   uint64_t split_series;         /* CU::splitSeries, 5 bits per depth */
 } vvcx_cu;
 
@@ -106,7 +108,7 @@ typedef struct {
 typedef struct {
   int32_t  cu_index;             /* index of its CU in vvcx_get_cus order */
   int16_t  x, y, w, h;           /* like the CU: luma samples for ch_type 0, chroma samples for ch_type 1 */
-  uint8_t  ch_type, depth;       /* transform depth (0: the TU is the CU) */
+  uint8_t  ch_type, depth;       /* transform depth (0: the TU is the CU; 1: a sub-partition of an ISP CU) */
   uint8_t  mts_idx;              /* tu.mtsIdx (luma) */
   uint8_t  joint_cb_cr;          /* tu.jointCbCr (chroma) */
   uint8_t  cbf[3];               /* Y, Cb, Cr */
@@ -170,8 +172,8 @@ int  vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out /* [n_frame
 /* final CU table of one bound frame (CTU raster order; per CTU luma CUs then chroma CUs, by origin).
  * ≙ walking cs.cus after the CTU loop; same fields D_BLOCK_STATISTICS_CODED traces */
 int  vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus, int *n_cus);
-/* The TU records of the same picture (≙ cs.tus; EL/EncSlice.cpp reads them through CodingStructure::traverseTUs when it writes the slice): one per CU here
- * (every intra CU of a dual-tree I slice fits MaxTbSize 64), in vvcx_get_cus order.  coeff_offset[c] / coeff_stride[c] address the block's quantised levels
+/* The TU records of the same picture (≙ cs.tus; EL/EncSlice.cpp reads them through CodingStructure::traverseTUs when it writes the slice): one per CU
+ * (every intra CU of a dual-tree I slice fits MaxTbSize 64) or one per sub-partition of a luma CU coded with ISP (2 or 4, in coding order), CUs in vvcx_get_cus order.  coeff_offset[c] / coeff_stride[c] address the block's quantised levels
  * inside the plane vvcx_get_levels(h, frame, c, ...) returns (-1: the TU has no block of component c); a joint chroma TU keeps its levels with the coded
  * component (Cb for joint_cb_cr 2 / 3, Cr for 1).  tus may be NULL to query the count. */
 int  vvcx_get_tus(vvcx_handle *h, int frame, vvcx_tu *tus, int max_tus, int *n_tus);

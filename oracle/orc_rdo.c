@@ -777,13 +777,13 @@ static void isp_sub_refs(const orc_enc *e, area_t a, int isp, int ox, int oy, in
     for (int j = 0; j <= leftLen; j++) ref[j * S] = base[(oy + j) * bs];
     for (int i = 1; i <= pw; i++) ref[i] = rec[(oy - 1) * w + (i - 1)];
     for (int i = pw + 1; i <= topLen; i++) ref[i] = rec[(oy - 1) * w + pw - 1];
-    const int leftDecomp = a.x > 0 && e->um[0][((a.y + oy) >> 2) * e->uw + ((a.x - 1) >> 2)].valid;       /* cs.isDecomp */
+    const int leftDecomp = a.x > 0;            /* cs.isDecomp of the sample left of the sub-partition: inside the picture it is always coded before this CU, in whichever tile */
     if (!leftDecomp) for (int j = 0; j <= leftLen; j++) ref[j * S] = rec[(oy - 1) * w];
   } else {                                    /* columns */
     for (int i = 0; i <= topLen; i++) ref[i] = base[ox + i];
     for (int j = 1; j <= ph; j++) ref[j * S] = rec[(j - 1) * w + ox - 1];
     for (int j = ph + 1; j <= leftLen; j++) ref[j * S] = rec[(ph - 1) * w + ox - 1];
-    const int aboveDecomp = a.y > 0 && e->um[0][((a.y - 1) >> 2) * e->uw + ((a.x + ox) >> 2)].valid;
+    const int aboveDecomp = a.y > 0;
     if (!aboveDecomp) for (int i = 0; i <= topLen; i++) ref[i] = rec[ox - 1];
   }
 }
@@ -1063,6 +1063,7 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, luma_passes *ps, int *
         }
     }
   }
+  if (getenv("ORC_DBG")) { fprintf(stderr, "ORC node %d %d %dx%d satd %llu list", x, y, w, h, (unsigned long long) e->cnt_satd); for (int i = 0; i < rdSize; i++) fprintf(stderr, " %d:%d(%.1f)", rdList[i].mode, rdList[i].mrl, rdCost[i]); fprintf(stderr, "\n"); }
   if (testISP) { isp.had_n = rdSize; for (int i = 0; i < rdSize; i++) isp.had_mode[i] = rdList[i].mode; }      /* 624-632: the regular list, before the MRL candidates */
   {
     unsigned mpm[6]; get_mpms(e, x, y, w, h, mpm);
@@ -1929,6 +1930,7 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
           if (!reuse && !isp) C->no_isp_cost = t.cost;                                                     /* useModeResult(ETM_INTRA), EL/EncModeCtrl.cpp:2120-2123 */
           /* checkSkipOtherLfnst (EL/EncModeCtrl.cpp:2070-2087): the intra passes are the first modes of a node, so its condition always holds */
           if (lfnstOn) skipOtherLfnst = !cbf;
+          if (getenv("ORC_DBG")) fprintf(stderr, "RES ch %d node %d %d %dx%d lf %d mts %d dir %d isp %d tucbf %d cost %.3f dist %llu\n", ch, a.x, a.y, a.w, a.h, lfnstIdx, mtsFlag, dir, isp, tucbf, t.cost, (unsigned long long) t.dist);
           t.n_cu = 1; t.is_split = 0;
           t.f_bt = t.l_bt = P->bt_depth; t.f_depth = P->depth; t.f_mt = P->mt_depth; t.f_cbf = cbf != 0;
           t.f_w = t.l_w = a.w >> sh; t.f_h = t.l_h = a.h >> sh; t.max_qt = P->qt_depth;

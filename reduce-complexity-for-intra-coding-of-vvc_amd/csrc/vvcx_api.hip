@@ -80,7 +80,7 @@ struct vvcx_handle {
 };
 
 #define VVCX_PAYLOAD_BYTES_PER_CTU 32768u
-static const uint32_t kBuiltTools = VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_LFNST | VVCX_TOOL_MTS | VVCX_TOOL_JCCR | VVCX_TOOL_DEPQUANT | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST |
+static const uint32_t kBuiltTools = VVCX_TOOL_ISP | VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_LFNST | VVCX_TOOL_MTS | VVCX_TOOL_JCCR | VVCX_TOOL_DEPQUANT | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST |
                                     VVCX_TOOL_TS | VVCX_TOOL_RDOQ | VVCX_TOOL_LMCS;
 
 // Quantizer::initQuantBlock (CL/DepQuant.cpp:694-739) for blocks with log2 w + log2 h = lsum: the quantiser's shift / scale / thresholds and the fixed-point
@@ -124,6 +124,10 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   // cfg sets RDOQ / RDOQTS beside DepQuant) only acts on transform-skip blocks
   if ((cfg->tools & VVCX_TOOL_TS) && (cfg->tools & (VVCX_TOOL_DEPQUANT | VVCX_TOOL_LFNST)) != (VVCX_TOOL_DEPQUANT | VVCX_TOOL_LFNST))
     return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_TS needs VVCX_TOOL_DEPQUANT and VVCX_TOOL_LFNST (tool set 0x%x)", cfg->tools);
+  // ISP is one of the candidate kinds of the first (lfnstIdx 0, DCT-II) pass of the LFNST pass loop and its sub-partitions go through the dependent quantiser with
+  // the implicit DST-VII of explicit-MTS sequences (TrQuant::getTrTypes)
+  if ((cfg->tools & VVCX_TOOL_ISP) && (cfg->tools & (VVCX_TOOL_DEPQUANT | VVCX_TOOL_LFNST | VVCX_TOOL_MTS)) != (VVCX_TOOL_DEPQUANT | VVCX_TOOL_LFNST | VVCX_TOOL_MTS))
+    return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_ISP needs VVCX_TOOL_DEPQUANT, VVCX_TOOL_LFNST and VVCX_TOOL_MTS (tool set 0x%x)", cfg->tools);
   if ((cfg->tools & VVCX_TOOL_LMCS) && !(cfg->tools & VVCX_TOOL_DEPQUANT)) return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_LMCS needs VVCX_TOOL_DEPQUANT (tool set 0x%x)", cfg->tools);
   if ((cfg->tools & VVCX_TOOL_JCCR) && !(cfg->tools & VVCX_TOOL_DEPQUANT)) return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_JCCR needs VVCX_TOOL_DEPQUANT (tool set 0x%x)", cfg->tools);
   if (cfg->ctu_size != 128 || !cfg->dual_tree) return fail(VVCX_ERR_UNSUPPORTED, "only CTUSize 128 with DualITree 1");
@@ -674,7 +678,8 @@ extern "C" int vvcx_get_cus(vvcx_handle *h, int frame, vvcx_cu *cus, int max_cus
         if (cus && n < max_cus) {
           vvcx_cu &o = cus[n];
           o.x = u.x; o.y = u.y; o.w = (int16_t) (1 << u.lw); o.h = (int16_t) (1 << u.lh); o.ch_type = (uint8_t) ch;
-          o.qt_depth = u.qt; o.bt_depth = u.bt; o.mt_depth = u.mt; o.depth = u.depth; o.intra_dir = u.dir; o.mrl_idx = u.mrl & 0x7f; o.mip_flag = u.mrl >> 7; o.cbf = u.cbf; o.mts_idx = ch ? 0 : (u.mts & 7); o.joint_cb_cr = ch ? (u.mts & 7) : 0; o.lfnst_idx = u.mts >> 4; o.split_series = u.ss;
+          o.qt_depth = u.qt; o.bt_depth = u.bt; o.mt_depth = u.mt; o.depth = u.depth; o.intra_dir = u.dir; o.mrl_idx = u.mrl & 0x7f; o.mip_flag = u.mrl >> 7; o.cbf = u.cbf & 7; o.mts_idx = ch ? 0 : (u.mts & 7); o.joint_cb_cr = ch ? (u.mts & 7) : 0; o.lfnst_idx = (u.mts >> 4) & 3; o.split_series = u.ss;
+          o.isp_mode = ch ? 0 : u.mts >> 6; o.tu_cbf = ch ? 0 : u.cbf >> 4;
         }
         n++;
       }
@@ -689,25 +694,42 @@ extern "C" int vvcx_get_tus(vvcx_handle *h, int frame, vvcx_tu *tus, int max_tus
 {
   NOT_PENDING(h);
   if (!h || !n_tus || frame < 0 || frame >= h->n_frames) return fail(VVCX_ERR_ARG, "bad argument");
-  int n = 0;
-  const int rc = vvcx_get_cus(h, frame, nullptr, 0, &n);
+  int ncu = 0;
+  const int rc = vvcx_get_cus(h, frame, nullptr, 0, &ncu);
   if (rc != VVCX_OK) return rc;
+  std::vector<vvcx_cu> cus((size_t) ncu);
+  const int rc2 = vvcx_get_cus(h, frame, cus.data(), ncu, &ncu);
+  if (rc2 != VVCX_OK) return rc2;
+  // sub-partitions of a CU coded with ISP (CU::getISPSplitDim, CL/UnitTools.cpp:437-459): a quarter of the side along the split, at least 16 samples each
+  auto isp_parts = [](const vvcx_cu &c, int &tw, int &th) {
+    if (!c.isp_mode) { tw = c.w; th = c.h; return 1; }
+    const int hor = c.isp_mode == 1, split = hor ? c.h : c.w, non = hor ? c.w : c.h;
+    int factor = 1; if (non < 16) { int l = 0; while ((1 << (l + 1)) <= non) l++; factor = 16 >> l; }
+    const int psz = (split >> 2) < factor ? factor : (split >> 2);
+    tw = hor ? c.w : psz; th = hor ? psz : c.h;
+    return split / psz;
+  };
+  int n = 0;
+  for (int i = 0; i < ncu; i++) { int tw, th; n += isp_parts(cus[(size_t) i], tw, th); }
   *n_tus = n;
   if (!tus) return VVCX_OK;
   if (n > max_tus) return fail(VVCX_ERR_ARG, "TU table too small (%d > %d)", n, max_tus);
-  std::vector<vvcx_cu> cus((size_t) n);
-  const int rc2 = vvcx_get_cus(h, frame, cus.data(), n, &n);
-  if (rc2 != VVCX_OK) return rc2;
   const int wl = h->cfg.pic_w, wc = h->cfg.pic_w >> 1;
-  for (int i = 0; i < n; i++) {
-    const vvcx_cu &c = cus[(size_t) i]; vvcx_tu &t = tus[i];
-    memset(&t, 0, sizeof t);
-    t.cu_index = i; t.ch_type = c.ch_type; t.x = c.x; t.y = c.y; t.w = c.w; t.h = c.h; t.depth = 0;
-    t.mts_idx = c.mts_idx; t.joint_cb_cr = c.joint_cb_cr;
-    if (!c.ch_type) { t.cbf[0] = c.cbf & 1; t.coeff_offset[0] = (int32_t) c.y * wl + c.x; t.coeff_stride[0] = wl; t.coeff_offset[1] = t.coeff_offset[2] = -1; }
-    else {
-      t.cbf[1] = (c.cbf >> 1) & 1; t.cbf[2] = (c.cbf >> 2) & 1;
-      t.coeff_offset[0] = -1; t.coeff_offset[1] = t.coeff_offset[2] = (int32_t) c.y * wc + c.x; t.coeff_stride[1] = t.coeff_stride[2] = wc;
+  int o = 0;
+  for (int i = 0; i < ncu; i++) {
+    const vvcx_cu &c = cus[(size_t) i];
+    int tw, th; const int parts = isp_parts(c, tw, th);
+    for (int k = 0; k < parts; k++) {
+      vvcx_tu &t = tus[o++];
+      memset(&t, 0, sizeof t);
+      t.cu_index = i; t.ch_type = c.ch_type; t.w = (int16_t) tw; t.h = (int16_t) th; t.depth = c.isp_mode ? 1 : 0;
+      t.x = (int16_t) (c.x + (c.isp_mode == 2 ? k * tw : 0)); t.y = (int16_t) (c.y + (c.isp_mode == 1 ? k * th : 0));
+      t.mts_idx = c.mts_idx; t.joint_cb_cr = c.joint_cb_cr;
+      if (!c.ch_type) { t.cbf[0] = c.isp_mode ? (c.tu_cbf >> k) & 1 : c.cbf & 1; t.coeff_offset[0] = (int32_t) t.y * wl + t.x; t.coeff_stride[0] = wl; t.coeff_offset[1] = t.coeff_offset[2] = -1; }
+      else {
+        t.cbf[1] = (c.cbf >> 1) & 1; t.cbf[2] = (c.cbf >> 2) & 1;
+        t.coeff_offset[0] = -1; t.coeff_offset[1] = t.coeff_offset[2] = (int32_t) c.y * wc + c.x; t.coeff_stride[1] = t.coeff_stride[2] = wc;
+      }
     }
   }
   return VVCX_OK;

@@ -46,6 +46,7 @@ enum { SPLIT_NONE = 0, SPLIT_QT = 1, SPLIT_BH = 2, SPLIT_BV = 3, SPLIT_TH = 4, S
 enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_BT_V, ETM_SPLIT_TT_H, ETM_SPLIT_TT_V, ETM_RECO_CACHED };
 #define TOOL_CU_REUSE (1u << 11)
 #define TOOL_MIP (1u << 1)
+#define TOOL_ISP (1u << 2)
 #define TOOL_LFNST (1u << 3)
 #define MIPF 0x80                  // a MIP CU: bit 7 of the unit's / candidate's mrl field (MIP forces multiRefIdx 0), the MIP mode in dir / mode
 #define TOOL_MTS (1u << 4)
@@ -57,8 +58,8 @@ enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_B
 enum { LM_CHROMA = 67, MDLM_L = 68, MDLM_T = 69 };
 enum { PLANAR = 0, DC = 1, HOR = 18, DIA = 34, VER = 50, VDIA = 66, DM_CHROMA = 70 };
 enum { OP_NONE, OP_DONE, OP_LUMA_PREP, OP_STAGE_A, OP_STAGE_B, OP_CHROMA_RD, OP_SAVE_INTRA, OP_SAVE_PIC, OP_RESTORE_PIC,
-       OP_CLEAR_UNITS, OP_CTX_COPY, OP_REUSE, OP_FAST };
-enum { PH_ENTER, PH_FAST_DONE, PH_RUN, PH_A1_DONE, PH_A2_DONE, PH_B_DONE, PH_INTRA_SAVED, PH_CHILD, PH_CHILD_RET, PH_SPLIT_SAVED, PH_ADVANCE, PH_EXIT, PH_EXIT2, PH_A3_DONE, PH_PASS, PH_NEXT_PASS };
+       OP_CLEAR_UNITS, OP_CTX_COPY, OP_REUSE, OP_FAST, OP_ISP, OP_ISP_END };
+enum { PH_ENTER, PH_FAST_DONE, PH_RUN, PH_A1_DONE, PH_A2_DONE, PH_B_DONE, PH_INTRA_SAVED, PH_CHILD, PH_CHILD_RET, PH_SPLIT_SAVED, PH_ADVANCE, PH_EXIT, PH_EXIT2, PH_A3_DONE, PH_PASS, PH_NEXT_PASS, PH_ISP };
 enum { CTX_CUR = 0, CTX_START = 1, CTX_BEST = 2, CTX_WAVE = 3 };   // OP_CTX_COPY endpoints
 
 struct Ctx { uint16_t s0[NCTX], s1[NCTX]; };
@@ -101,6 +102,12 @@ struct CtlState {            // controller-private working set (touched by threa
   uint8_t grpCheck[4], bestSel[4], idxOf[16];
   double dct2Cost, grpBest[4], modeCost[16], bestCost0;
   int lfNum, lfSize, mtsNum; Cand lfList[16], mtsList[16];
+  // ISP (ISPTestedModesInfo and the candidate lists of the ISP tests, EL/IntraSearch.h:211-320): the tested (mode, split) pairs in test order with the sub-partitions
+  // they completed and their cost, the candidate list both splits walk, the regular full-RD results (stage-B places) by cost, the SATD-stage list saved before the MRL candidates
+  int8_t testIsp, ispSlot, ispPrev, ispNT, ispBestMode, ispBestSplit, ispNOrig, ispNList, ispRegN, ispHadN, skipMts2, ispBreak, ispStop[2], ispNumTotal[2], ispCandIdx[2], ispNTested[2];
+  uint8_t ispTMode[16], ispTInfo[16], ispList[28], ispReg[16], ispHad[24], ispWinMode, ispWinSplit, ispWinTucbf;      // ispTInfo: split << 4 | completed sub-partitions
+  double ispTCost[16], ispBestRd, ispCurBest, noIspCost;
+  unsigned long long ispWinDist, ispWinBits;
   uint8_t inv0[16], rdSrc[24];           // first pass: list place -> stage-B item; per list entry of an MTS pass: the first pass's item that carries its prepared DST-VII block
 };
 
@@ -158,11 +165,16 @@ struct Lds {
   CtlState S; VxUnit cu;           // controller working set; CU record of the intra candidate being evaluated
   unsigned mpm[6], mpm_sorted[6]; int mpm_n;
   int16_t mip_n, mip_ctx;          // MIP modes of the node (0: no mip_flag) and the context of its mip_flag (3: more than 2:1)
+  int16_t isp_ok, isp_pad_;        // CU::canUseISP of the node (isp_mode is then part of every line-0 luma mode's syntax)
   // LFNST: the pass of xCheckRDCostIntra being evaluated (cu.lfnstIdx, cu.mtsFlag, transform group); last scan position of the block a wave coded last;
   // per stage-B / chroma candidate: bit 0 some block's last position is beyond DC, bit 1 some block has a coefficient outside the LFNST region
-  int8_t ps_lfnst, ps_mts, ps_grp, ps_pad; int rc_last[NW]; uint8_t rd_lfl[16];
+  int8_t ps_lfnst, ps_mts, ps_grp, isp_wait; int rc_last[NW]; uint8_t rd_lfl[16];      // isp_wait: the ISP places follow the stage-B operation before the node's intra decision is taken
   // the DST-VII pass prepared by the DCT-II pass (stage_b_rounds): number of prepared items (0: none), item of each candidate of the running pass, absSum per item
   int8_t spec_n; uint8_t rd_src[16]; int spec_abs[16];
+  // ISP (intra sub-partitions): the candidate posted by the controller and what its evaluation returns; the best ISP candidate of the node so far
+  double isp_limit, isp_cost, isp_best;                  // bestCostSoFar handed to xIntraCodingLumaISP; cost of the candidate (MAX: early exit / not valid); cost the candidate has to beat
+  unsigned long long isp_dist, isp_bits;
+  uint8_t isp_mode, isp_split, isp_tucbf, isp_ntu, isp_valid, isp_first, isp_win, isp_evals;      // isp_win: the node's winner is the ISP candidate parked in slot ISP_BEST; isp_evals: TUs quantised (work counter)
   int lmcs_cadj, lmcs_tab;         // LMCS: chroma residual scale of the chroma node being coded (0: none), its table of quantiser constants (1 + bin; 0: unscaled)
   int dc_val[4];
   int cur_tile, frame, ctu_x, ctu_y, tree_ch;
@@ -941,6 +953,7 @@ __device__ __noinline__ void luma_neighbours(const VxParams &p, const VxFrameDev
   const VxUnit *uL = get_cu(p, fd, 0, x - 1, y + h - 1, tile); if (uL) Ld = unit_ldir(*uL);
   const VxUnit *uA = get_cu(p, fd, 0, x + w - 1, y - 1, tile); if (uA && ((y - 1) >> 7) == (y >> 7)) Ad = unit_ldir(*uA);
   L.mip_n = 0; L.mip_ctx = 0;
+  L.isp_ok = (int16_t) ((p.tools & TOOL_ISP) && ilog2i(w) + ilog2i(h) > 4 && w <= 64 && h <= 64);      // CU::canUseISP (CL/UnitTools.cpp:414-435)
   if ((p.tools & TOOL_MIP) && w <= 64 && h <= 64) {
     L.mip_n = (int16_t) mip_num_modes(w, h);
     const VxUnit *a = get_cu(p, fd, 0, x - 1, y, tile), *b = get_cu(p, fd, 0, x, y - 1, tile);
@@ -971,8 +984,9 @@ __device__ void derive_mpms(int Ld, int Ad, unsigned mpm[6])
 }
 // CABACWriter::intra_luma_pred_mode 1762-1845 + extend_ref_line 1566-1591 (ISP off); MPMs from L.mpm; mip_flag 4741-4767 with the node's
 // context (DeriveCtx::CtxMipFlag) and mip_pred_mode 4781-4787 = xWriteTruncBinCode(mode, numModes) from L.mip_n / L.mip_ctx
+// isp: cu.ispMode (0 none, 1 horizontal, 2 vertical split); isp_mode (3944-3965) follows the reference line index of every luma CU that could use ISP
 template <bool WR = false>
-__device__ void enc_intra_luma_pred_mode(Cab &cb, int y, int dir, int mrl)
+__device__ void enc_intra_luma_pred_mode(Cab &cb, int y, int dir, int mrl, int isp = 0)
 {
   if (L.mip_n) {
     enc_bin<WR>(cb, (unsigned) (mrl >> 7), VX_CTX_MipFlag + L.mip_ctx);
@@ -986,11 +1000,12 @@ __device__ void enc_intra_luma_pred_mode(Cab &cb, int y, int dir, int mrl)
     enc_bin<WR>(cb, mrl != 0, VX_CTX_MultiRefLineIdx + 0);
     if (mrl != 0) enc_bin<WR>(cb, mrl != 1, VX_CTX_MultiRefLineIdx + 1);
   }
+  if (!mrl && L.isp_ok) { enc_bin<WR>(cb, isp != 0, VX_CTX_ISPMode + 0); if (isp) enc_bin<WR>(cb, (unsigned) (isp - 1), VX_CTX_ISPMode + 1); }
   int mpm_idx = 6;
   for (int i = 0; i < 6; i++) if ((unsigned) dir == L.mpm[i]) { mpm_idx = i; break; }
   if (!mrl) enc_bin<WR>(cb, mpm_idx < 6, VX_CTX_IntraLumaMpmFlag);
   if (mpm_idx < 6) {
-    if (mrl == 0) enc_bin<WR>(cb, mpm_idx > 0, VX_CTX_IntraLumaPlanarFlag + 1);
+    if (mrl == 0) enc_bin<WR>(cb, mpm_idx > 0, VX_CTX_IntraLumaPlanarFlag + (isp ? 0 : 1));      // 1812: context by cu.ispMode
     if (mpm_idx) { const int nb = imin(mpm_idx, 4); enc_ep<WR>(cb, mpm_idx < 5 ? (1u << nb) - 2 : 15u, nb); }      // truncated unary, bypass (1791-1806)
   } else {
     unsigned m = (unsigned) dir;
@@ -1013,6 +1028,7 @@ __device__ unsigned long long luma_mode_bits(const Ctx &c, int y, int dir, int m
     bits += frac_bits_of(c, VX_CTX_MultiRefLineIdx, mrl != 0);
     if (mrl != 0) bits += frac_bits_of(c, VX_CTX_MultiRefLineIdx + 1, mrl != 1);
   }
+  if (!mrl && L.isp_ok) bits += frac_bits_of(c, VX_CTX_ISPMode + 0, 0);
   int mpm_idx = 6;
   for (int i = 0; i < 6; i++) if ((unsigned) dir == L.mpm[i]) { mpm_idx = i; break; }
   if (!mrl) bits += frac_bits_of(c, VX_CTX_IntraLumaMpmFlag, mpm_idx < 6);
@@ -1099,6 +1115,23 @@ __device__ void init_pred_params(int w, int h, int is_luma, int mode, int mrl, I
     if (diff > L.t.intra_thr[log2Size]) { const int is_int = (absAng & 0x1F) == 0; p.ref_filter = is_int; p.interp = !is_int; }
   }
 }
+// initPredIntraParams for a prediction region (w x h) of an ISP CU (cuw x cuh): wide-angle mapping by the CU's shape, no reference smoothing, the cubic interpolation
+// filter, PDPC by the region's size (487-618 with useISP, JVET_O0502)
+__device__ void init_pred_params_isp(int cuw, int cuh, int w, int h, int mode, Ipa &p)
+{
+  init_pred_params(cuw, cuh, 1, mode, 0, p);
+  p.ref_filter = 0; p.interp = 0; p.pdpc = w >= 4 && h >= 4; p.ang_scale = -1;
+  if (mode > DC && mode < 67) {
+    const int am = p.is_ver ? p.pred_mode - VER : -(p.pred_mode - HOR);
+    if (am < 0) p.pdpc = 0;
+    else if (am > 0) {
+      const int side = p.is_ver ? h : w;
+      int sc = ilog2i(side) - (ilog2i(3 * p.inv_angle - 2) - 8);
+      if (sc > 2) sc = 2;
+      p.ang_scale = sc; p.pdpc &= sc >= 0;
+    }
+  }
+}
 __device__ inline uint2 ipa_pack(const Ipa &p)
 {
   uint2 r;
@@ -1117,13 +1150,14 @@ __device__ inline int clip_bd(int v, int bd) { const int mx = (1 << bd) - 1; ret
 // one predicted sample.  top[i] = pSrc.at(i,0), left[i] = pSrc.at(0,i) of the (un)filtered reference
 // buffer for this mrl; closed forms of xPredIntraPlanar 426-479, DC 248-285, xPredIntraAng 633-935 and
 // the planar/DC PDPC 354-378.
+// ref_top / ref_left: m_topRefLength / m_leftRefLength when they are not twice the block's sides (prediction regions of ISP CUs: CU side + region side)
 __device__ int pred_sample(const int16_t *top, const int16_t *left, int w, int h, int px, int py, const Ipa &ip,
-                           int mode, int is_luma, int bd, int dcv)
+                           int mode, int is_luma, int bd, int dcv, int ref_top = 0, int ref_left = 0)
 {
   const int mrl = ip.mrl;
   int v;
   if (mode == PLANAR) {
-    const int l2w = ilog2i(w), l2h = ilog2i(h);
+    const int l2w = ilog2i(imax(w, 2)), l2h = ilog2i(imax(h, 2));      // 430-431: one-sample sides of ISP sub-partitions weigh like two
     const int lft = left[py + 1], tp = top[px + 1];
     const int hor = (lft << l2w) + (px + 1) * (top[w + 1] - lft);
     const int ver = (tp << l2h) + (py + 1) * (left[h + 1] - tp);
@@ -1136,7 +1170,7 @@ __device__ int pred_sample(const int16_t *top, const int16_t *left, int w, int h
     const int xx = ver ? px : py, yy = ver ? py : px;
     const int16_t *mainp = ver ? top : left, *sidep = ver ? left : top;
     const int sizeSide = H;
-    const int refLen = 2 * W;
+    const int refLen = ref_top ? (ver ? ref_top : ref_left) : 2 * W;
 #define MAINR(i_) ({ int k_ = (i_) + mrl; int r_; if (k_ >= 0) { if (ang >= 0 && k_ > refLen + mrl) k_ = refLen + mrl; r_ = mainp[k_]; } \
                      else { int j_ = (-k_ * inv + 256) >> 9; if (j_ > sizeSide) j_ = sizeSide; r_ = sidep[j_]; } r_; })
 #define SIDER(i_) ((int) sidep[(i_) + mrl])
@@ -2297,6 +2331,132 @@ __device__ Ctx *ctx_ptr(uint8_t *scratch, int which, int d, int wave)
   return (Ctx *) (scratch + VXD_OFF_CTX + (size_t) (d * 2 + (which == CTX_BEST ? 1 : 0)) * VXD_CTXSNAP);
 }
 
+// ------------------------------------------------------------------------------------------------ ISP (intra sub-partitions)
+// CU::getISPSplitDim (CL/UnitTools.cpp:437-459): size of a sub-partition along the split direction: a quarter of the side, but at least 16 samples per sub-partition
+__device__ inline int isp_split_dim(int w, int h, int hor)
+{
+  const int split = hor ? h : w, non = hor ? w : h;
+  const int factor = non < 16 ? 16 >> ilog2i(non) : 1;
+  return imax(split >> 2, factor);
+}
+// HBM buffers of the ISP evaluation (the node's stage-B winner stays parked in the slots of its wave): CU tiles rec | lev with stride w
+#define ISP_WAVE(ww_) (((ww_) + 1) & (NW - 1))
+__device__ inline int16_t *isp_buf(uint8_t *scratch, int wave, int which) { return (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS; }
+// IntraSearch::xIntraCodingLumaISP (EL/IntraSearch.cpp:3171-3280) of one (mode, split) candidate by ONE wave: the sub-partitions are predicted from the reconstruction
+// of the ones before (initIntraPatternChTypeISP, CL/IntraPrediction.cpp:1092-1199; prediction regions of at least four columns, JVET_O0106), each through
+// wave_code_block_isp against the live contexts L.ctxs[ci] (copied from the node's start contexts here), the rate of xGetIntraFracBitsQT per sub-partition and the
+// early exits against `limit` (3206-3245).  given != nullptr: the levels (CU tile, stride w) and cbfs are taken as coded (DecCu::xIntraRecQT of an ISP CU for
+// xReuseCachedResult).  The node's base references are L.refs[0]; region references go to L.refs[1].  Results -> L.isp_*; rec / lev: CU tiles (stride w, HBM).
+// aux: 4096 + 1024 int16 of HBM for the CU's prediction and the dense coefficient tile of a sub-partition (the candidate pools keep what the first pass prepared for the
+// DST-VII pass); the filtered reference set L.refs[1], which later passes of the node read again, is saved behind them and restored
+__device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir, int isp, double limit, const int16_t *given, int given_tucbf, int16_t *rec, int16_t *lev, int ci, int lane, int16_t *aux)
+{
+  const VxParams &p = L.par;
+  w = uni(w); h = uni(h); dir = uni(dir); isp = uni(isp); given_tucbf = uni(given_tucbf); ci = uni(ci);
+  const int bd = p.bit_depth, hor = isp == 1;
+  const int psz = isp_split_dim(w, h, hor), tw = hor ? w : psz, th = hor ? psz : h, n = hor ? h / psz : w / psz;
+  const int predRegDiff = !hor && ((w == 8 && h > 4) || w == 4);         // CU::isPredRegDiffFromTB
+  const int wave = uni(VTX >> 6), x0 = uni(L.nx), y0 = uni(L.ny);
+  const int16_t *org = org_tile(scratch, w * h);
+  int16_t *pred = aux, *cf = aux + 4096, *keep = aux + 5120;
+  int32_t *tmp = wave_tmp(scratch, imin(32, tw) * th, wave);
+  const int16_t *bt = L.refs[0][0], *bl = L.refs[0][1];
+  int16_t *rt = L.refs[1][0], *rl = L.refs[1][1];
+  for (int e = lane; e < 2 * 140; e += 64) keep[e] = rt[e];            // refs[1][0] | refs[1][1] are contiguous
+  { uint32_t *d = (uint32_t *) &L.ctxs[ci]; const uint32_t *s_ = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s_[e]; }
+  wave_sync();
+  double cost = 0; int early = 0, tucbf = 0, ntu = 0, evals = 0, noCbf = 0;
+  unsigned long long dist = 0, bits = 0;
+  Cab cb; cb.ci = ci; cb.bits = 0;
+  for (int k = 0; k < n; k++) {
+    const int ox = hor ? 0 : k * tw, oy = hor ? k * th : 0;
+    if (!predRegDiff || (ox & 3) == 0) {
+      const int pw = predRegDiff ? imax(tw, 4) : tw, ph = th, topLen = w + pw, leftLen = h + ph;
+      // reference samples of the region
+      if (!ox && !oy) {
+        for (int i = lane; i <= topLen; i += 64) rt[i] = bt[i];
+        for (int j = lane; j <= leftLen; j += 64) rl[j] = bl[j];
+      } else if (hor) {                        // the row above is the previous sub-partition's last reconstructed row, replicated to the right
+        const int leftDecomp = x0 > 0;         // cs.isDecomp of the sample left of the sub-partition
+        for (int j = lane; j <= leftLen; j += 64) rl[j] = leftDecomp ? bl[oy + j] : rec[(oy - 1) * w];
+        for (int i = lane; i <= topLen; i += 64) rt[i] = i == 0 ? (leftDecomp ? bl[oy] : rec[(oy - 1) * w]) : rec[(oy - 1) * w + imin(i, pw) - 1];
+      } else {                                 // columns
+        const int aboveDecomp = y0 > 0;
+        for (int i = lane; i <= topLen; i += 64) rt[i] = aboveDecomp ? bt[ox + i] : rec[ox - 1];
+        for (int j = lane; j <= leftLen; j += 64) rl[j] = j == 0 ? (aboveDecomp ? bt[ox] : rec[ox - 1]) : rec[(imin(j, ph) - 1) * w + ox - 1];
+      }
+      wave_sync();
+      Ipa ip; init_pred_params_isp(w, h, pw, ph, dir, ip);
+      int dcv = 0;
+      if (dir == DC) { if (lane == 0) dcv = dc_value(rt, rl, pw, ph, 0); dcv = __builtin_amdgcn_readlane(dcv, 0); }
+      const int lpw = ilog2i(pw);
+      for (int e = lane; e < pw * ph; e += 64) { const int py = e >> lpw, px = e & (pw - 1); pred[(oy + py) * w + ox + px] = (int16_t) pred_sample(rt, rl, pw, ph, px, py, ip, dir, 1, bd, dcv, topLen, leftLen); }
+      wave_sync();
+    }
+    const int ltw = ilog2i(tw);
+    for (int e = lane; e < tw * th; e += 64) { const int a = (oy + (e >> ltw)) * w + ox + (e & (tw - 1)); rec[a] = pred[a]; if (given) lev[a] = given[a]; }
+    wave_sync();
+    const int lastInferred = k == n - 1 && !tucbf, prevCbf = k ? (tucbf >> (k - 1)) & 1 : 0;
+    const int cbfCtx = lastInferred ? -1 : (int) VX_CTX_QtCbf[0] + 2 + prevCbf;
+    unsigned long long d; int cbf;
+    const int off = oy * w + ox;
+    wave_code_block_isp(org + off, rec + off, lev + off, w, tmp, cf, scratch, tw, th, bd, p.qp_tr, lane, d, cbf, given ? (given_tucbf >> k) & 1 : -1, ci, cbfCtx);
+    cbf = uni(cbf);
+    if (!given) { evals++; if (k == n - 1 && !tucbf && !cbf) { ntu = n; noCbf = 1; break; } }      // 2990-2996: ISP needs one coded sub-partition
+    if (cbf) tucbf |= 1 << k;
+    ntu = k + 1;
+    if (given) { dist += d; continue; }
+    unsigned long long fb = 0;
+    if (rd_cost(p, bits, dist + d) > limit) early = 1;       // 3206-3210: the rate is not even computed
+    else {
+      cb.bits = 0;                                            // xGetIntraFracBitsQT: the CU header with the first sub-partition, cbf unless inferred, coefficients
+      if (lane == 0) {
+        if (k == 0) enc_intra_luma_pred_mode(cb, L.ny, dir, 0, isp);
+        if (!lastInferred) enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[0] + 2 + prevCbf);
+      }
+      if (cbf) residual_coding_wave<false>(cb, 0, cf, tw, th, 0, lane);
+      { unsigned lo = (unsigned) cb.bits, hi = (unsigned) (cb.bits >> 32); lo = (unsigned) __builtin_amdgcn_readlane((int) lo, 0); hi = (unsigned) __builtin_amdgcn_readlane((int) hi, 0); fb = ((unsigned long long) hi << 32) | lo; }
+    }
+    cost += rd_cost(p, fb, d); dist += d; bits += fb;
+    if (k + 1 < n) {
+      if (cost > limit) { early = 1; break; }
+      const double thr = n == 2 ? 0.95 : k + 1 == 1 ? 0.83 : 0.91;
+      if (cost > limit * thr) { early = 1; break; }
+    }
+  }
+  if (lane == 0) {
+    int valid = 0, first = tucbf & 1; double rc = MAX_DOUBLE;
+    if (given) valid = 1;
+    else if (!noCbf && !early) {
+      rc = rd_cost(p, bits, dist);
+      if (rc < limit) { valid = 1; first = tucbf != 0; }      // 3257-3268: cbf at depth 0 of every TU = any sub-partition coded
+      else rc = MAX_DOUBLE;
+    }
+    L.isp_cost = rc; L.isp_dist = dist; L.isp_bits = bits; L.isp_tucbf = (uint8_t) tucbf; L.isp_ntu = (uint8_t) ntu; L.isp_valid = (uint8_t) valid; L.isp_first = (uint8_t) first; L.isp_evals = (uint8_t) evals;
+  }
+  wave_sync();
+  for (int e = lane; e < 2 * 140; e += 64) rt[e] = keep[e];
+  wave_sync();
+}
+// OP_ISP: one reserved place of the RD list (EL/IntraSearch.cpp:1181-1192): the candidate L.isp_mode / L.isp_split the controller took from xGetNextISPMode, by wave 0.
+// A candidate that is valid, has a coded first sub-partition and beats L.isp_best is parked (reconstruction, levels, end contexts) as the node's ISP winner so far.
+__device__ __noinline__ void op_isp(uint8_t *scratch)
+{
+  const int wave = uni(VTX >> 6), lane = VTX & 63;
+  const int w = uni(L.nw), h = uni(L.nh), P = w * h;
+  if (wave == 0) {
+    const int iw = ISP_WAVE(uni(L.win_wave));
+    int16_t *work = isp_buf(scratch, iw, 0), *best = isp_buf(scratch, iw, 1);
+    isp_code_cu(scratch, w, h, uni((int) L.isp_mode), uni((int) L.isp_split), uni_d(L.isp_limit), nullptr, 0, work, work + 4096, CI_W(1), lane, isp_buf(scratch, (iw + 1) & (NW - 1), 0));
+    if (uni((int) L.isp_valid) && uni((int) L.isp_first) && uni_d(L.isp_cost) < uni_d(L.isp_best)) {
+      for (int e = lane; e < P; e += 64) { best[e] = work[e]; best[4096 + e] = work[4096 + e]; }
+      uint32_t *d = (uint32_t *) ctx_ptr(scratch, CTX_START, MAXD + 1, 0); const uint32_t *s_ = (const uint32_t *) &L.ctxs[CI_W(1)]; for (int e = lane; e < NCTX; e += 64) d[e] = s_[e];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+
 // OP_LUMA_PREP: stage the node's original luma tile and its reference samples (mrl 0,1,3) in LDS
 template <typename T>
 __device__ __noinline__ void op_luma_prep(const VxParams &p_, const VxFrameDev &fd_)
@@ -2484,8 +2644,17 @@ __device__ __noinline__ void op_stage_a(const VxParams &p_, uint8_t *scratch)
         rank += (v < mine) || (v == mine && sj < myseq);
       }
       if (rank < numRd) { L.S.rdList[rank] = L.cand[c]; L.S.rdCost[rank] = mine; }
+      if (!first_phase && uni((int) L.S.testIsp) && !(c >= 35 && c < n1)) {      // 624-632: the list as it stands before the MRL candidates join is what ISP falls back on
+        int r2 = 0;
+        for (int j = 0; j < n; j++) if (!(j >= 35 && j < n1)) {
+          const double v = L.cand_cost[j];
+          const int sj = j < 35 ? j : 500 + j;
+          r2 += (v < mine) || (v == mine && sj < myseq);
+        }
+        if (r2 < numRd) L.S.ispHad[r2] = L.cand[c].mode;
+      }
     }
-    if (c == 0) L.S.rdSize = imin(numRd, n);
+    if (c == 0) { L.S.rdSize = imin(numRd, n); if (!first_phase && L.S.testIsp) L.S.ispHadN = (int8_t) imin(numRd, n - (n1 - 35)); }
   }
   __syncthreads();
 }
@@ -3296,7 +3465,25 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
   const int mode = uni(L.rd[0].mode), fm = uni(L.rd[0].mrl), cbfm = uni(L.rd_cbf[0]);
   Cab cb; cb.ci = CI_W(0); cb.bits = 0;
   unsigned long long dist = 0;
-  if (!ch) {
+  if (!ch && uni((int) L.isp_split)) {
+    // DecCu::xIntraRecQT of an ISP CU: every sub-partition predicted from the reconstruction of the one before, then the CU's bits from the node's start contexts
+    const int isp = uni((int) L.isp_split), tucbf = uni((int) L.isp_tucbf), hor = isp == 1;
+    const int psz = isp_split_dim(w, h, hor), tw = hor ? w : psz, th = hor ? psz : h, nsub = hor ? h / psz : w / psz, ltw = ilog2i(tw);
+    isp_code_cu(scratch, w, h, mode, isp, 0.0, levb, tucbf, recb, levb, CI_W(1), lane, isp_buf(scratch, 2, 0));
+    dist = L.isp_dist;
+    int16_t *cf = isp_buf(scratch, 2, 0) + 4096;
+    if (lane == 0) enc_intra_luma_pred_mode(cb, L.ny, mode, 0, isp);
+    for (int k = 0, sofar = 0; k < nsub; k++) {
+      const int ox = hor ? 0 : k * tw, oy = hor ? k * th : 0, c = (tucbf >> k) & 1;
+      if (lane == 0 && !(k == nsub - 1 && !sofar)) enc_bin(cb, (unsigned) c, VX_CTX_QtCbf[0] + 2 + (k ? (tucbf >> (k - 1)) & 1 : 0));
+      if (c) {
+        for (int e = lane; e < tw * th; e += 64) cf[e] = levb[(oy + (e >> ltw)) * w + ox + (e & (tw - 1))];
+        wave_sync();
+        residual_coding_wave<false>(cb, 0, cf, tw, th, 0, lane);
+      }
+      sofar |= c;
+    }
+  } else if (!ch) {
     if (fm & MIPF) wave_pred_mip(recb, w, h, mode, bd, 0, lane);
     else {
       Ipa ip; init_pred_params(w, h, 1, mode, fm, ip);
@@ -3816,6 +4003,124 @@ __device__ __noinline__ void ctrl_mip_merge(int w, int h)
   }
   S.rdSize = tn; S.numRd = tn;
 }
+// ---- ISP candidate selection (thread 0).  Sub-partitions a tested (mode, split) completed, -1 when the pair has not been tested (ISPTestedModesInfo::getNumCompletedSubParts)
+__device__ int isp_tested_at(int split, int mode)
+{
+  const CtlState &S = L.S;
+  for (int i = 0; i < S.ispNT; i++) if (S.ispTMode[i] == mode && (S.ispTInfo[i] >> 4) == split) return i;
+  return -1;
+}
+__device__ inline int isp_parts(int split, int mode) { const int i = isp_tested_at(split, mode); return i < 0 ? -1 : (L.S.ispTInfo[i] & 15); }
+__device__ int isp_nth_tested(int split, int k)           // the k-th mode tested with this split (m_ispTestedModes[...].intraMode in test order)
+{
+  const CtlState &S = L.S;
+  for (int i = 0; i < S.ispNT; i++) if ((S.ispTInfo[i] >> 4) == split && k-- == 0) return S.ispTMode[i];
+  return -1;
+}
+// xSortISPCandList (EL/IntraSearch.cpp:4614-4717): planar, the best angular mode of the regular full-RD results, the other angular ones by cost, DC; then up to three
+// modes of the SATD-stage list that are not among them.  bestNonISP: the best regular cost; stops both splits when ISP cannot win (ISPFast 1)
+__device__ __noinline__ void ctrl_isp_sort(double bestCostSoFar, double bestNonISP)
+{
+  CtlState &S = L.S;
+  if (bestNonISP > bestCostSoFar * 1.4) { S.ispStop[0] = S.ispStop[1] = 1; return; }
+  // the regular line-0, non-MIP results in list order, then std::sort by cost = insertion sort for at most 16 entries (equal costs keep their order)
+  int n = 0;
+  for (int c = 0; c < L.n_rd; c++) if (L.rd[c].mrl == 0) S.ispReg[n++] = (uint8_t) c;
+  for (int i = 1; i < n; i++) { const uint8_t m = S.ispReg[i]; const double cst = L.rd_cost[m]; int j = i - 1; while (j >= 0 && cst < L.rd_cost[S.ispReg[j]]) { S.ispReg[j + 1] = S.ispReg[j]; j--; } S.ispReg[j + 1] = m; }
+  S.ispRegN = (int8_t) n;
+  int bestAngle = -1;
+  for (int i = 0; i < n; i++) if (L.rd[S.ispReg[i]].mode > DC) { bestAngle = L.rd[S.ispReg[i]].mode; break; }
+  int nl = 0, dc = 0;
+  S.ispList[nl++] = PLANAR;
+  if (bestAngle != -1) S.ispList[nl++] = (uint8_t) bestAngle;
+  for (int i = 0; i < n; i++) { const int m = L.rd[S.ispReg[i]].mode; if (m != PLANAR && m != bestAngle) { if (m > DC) S.ispList[nl++] = (uint8_t) m; else if (m == DC) dc = 1; } }
+  if (dc) S.ispList[nl++] = DC;
+  S.ispNOrig = (int8_t) nl;
+  for (int k = 0, added = 0; k < S.ispHadN && added < 3; k++) {
+    int in = 0; for (int i = 0; i < nl; i++) in |= S.ispList[i] == S.ispHad[k];
+    if (!in) { S.ispList[nl++] = S.ispHad[k]; added++; }
+  }
+  S.ispNList = (int8_t) nl;
+}
+// xGetNextISPMode (4467-4589) with xFindAlreadyTestedNearbyIntraModes (4591-4612): 1 and the next candidate, 0 when the place of the RD list stays unused
+__device__ __noinline__ int ctrl_isp_next(int w, int h, int &mode, int &split)
+{
+  CtlState &S = L.S;
+  int nxt;
+  if (!S.ispStop[0] && !S.ispStop[1]) nxt = S.ispPrev == 1 ? 2 : 1;
+  else if (!S.ispStop[0]) nxt = 1;
+  else if (!S.ispStop[1]) nxt = 2;
+  else return 0;
+  const int st = nxt - 1, maxParts = S.ispNumTotal[st];
+  if (S.ispNTested[st] >= 2) {
+    int mode1 = isp_nth_tested(nxt, 0); mode1 = mode1 == DC ? -1 : mode1;
+    const int n1 = mode1 != -1 ? isp_parts(nxt, mode1) : -1;
+    int mode2 = isp_nth_tested(nxt, 1); mode2 = mode2 == DC ? -1 : mode2;
+    const int n2 = mode2 != -1 ? isp_parts(nxt, mode2) : -1;
+    if (n1 != -1 && n2 != -1 && n1 < maxParts && n2 < maxParts) { S.ispStop[st] = 1; return 0; }
+    const int other = nxt == 1 ? 2 : 1;
+    const int nOther = mode2 != -1 ? isp_parts(other, mode2) : -1;
+    int stopThis = 0;
+    if (nOther != -1 && n2 != -1) {
+      if (nOther > n2) stopThis = 1;
+      else if (nOther == n2 && nOther == maxParts) {
+        const int a = isp_tested_at(nxt, mode2), b = isp_tested_at(other, mode2);
+        const double cThis = (a >= 0 && (S.ispTInfo[a] & 15) == maxParts) ? S.ispTCost[a] : -1, cOther = (b >= 0 && (S.ispTInfo[b] & 15) == maxParts) ? S.ispTCost[b] : -1;
+        if (cThis == MAX_DOUBLE || cOther < cThis * 1.3) stopThis = 1;
+      }
+    }
+    if (stopThis) { S.ispStop[st] = 1; return 0; }
+  }
+  if (S.ispCandIdx[st] < S.ispNList) {
+    const int cand = S.ispList[S.ispCandIdx[st]];
+    S.ispCandIdx[st]++;
+    if (S.ispCandIdx[st] > S.ispNOrig) { if (S.ispBestSplit != nxt || S.ispBestMode == PLANAR) return 0; }      // the extra modes only while ISP is winning
+    int test = 1;
+    if (cand >= DC && maxParts > 2 && S.ispNTested[st] >= 2) {
+      const int window = cand > DC ? 5 : 1, limit = (w << ilog2i(h)) >= 256 ? maxParts - 1 : 2;
+      int lm = -1, rm = -1;
+      for (int k = 1; k <= window; k++) {
+        const int off = cand - 2 - k;
+        const int l_ = off < 0 ? 67 + off : cand - k, r_ = cand > DC ? ((cand - 2 + k) % 65) + 2 : PLANAR;
+        const int lf = l_ != cand ? isp_tested_at(nxt, l_) >= 0 : 0, rf = r_ != cand ? isp_tested_at(nxt, r_) >= 0 : 0;
+        if (lf || rf) { lm = lf ? l_ : -1; rm = rf ? r_ : -1; break; }
+      }
+      const int nl = lm != -1 ? isp_parts(nxt, lm) : -1, nr = rm != -1 ? isp_parts(nxt, rm) : -1;
+      const int nref = nl > nr ? nl : nr;
+      if (nref > 0) test = nref > limit;
+    }
+    if (test) { mode = cand; split = nxt; return 1; }
+  }
+  return 0;
+}
+// after the regular (and MIP) candidates of the first pass: the ISP state of the node (EL/IntraSearch.cpp:355-384, 1032-1039).  The node's budget is what the parent's
+// split loop left (EL/EncCu.cpp:2503-2516: intra is a node's first mode, so no own result caps it yet)
+__device__ __noinline__ void ctrl_isp_begin(const Frame &f)
+{
+  CtlState &S = L.S;
+  const double bestReg = L.rd_cost[L.win_idx];
+  S.ispBestRd = bestReg; S.ispCurBest = f.max_cost < bestReg ? f.max_cost : bestReg; S.noIspCost = bestReg;
+  S.ispNT = 0; S.ispBestMode = -1; S.ispBestSplit = 0; S.ispNOrig = -1; S.ispNList = 0; S.ispPrev = 0;
+  for (int k = 0; k < 2; k++) { S.ispStop[k] = 0; S.ispCandIdx[k] = 0; S.ispNTested[k] = 0; }
+  S.ispNumTotal[0] = (int8_t) (f.h / isp_split_dim(f.w, f.h, 1)); S.ispNumTotal[1] = (int8_t) (f.w / isp_split_dim(f.w, f.h, 0));
+  L.isp_win = 0;
+  ctrl_isp_sort(S.ispCurBest, bestReg);
+}
+// the result of the candidate just evaluated (1241-1245 ISPTestedModesInfo::setModeResults, 1270-1288, 1308-1326)
+__device__ __noinline__ void ctrl_isp_result(const Frame &f)
+{
+  CtlState &S = L.S;
+  const int mode = L.isp_mode, split = L.isp_split, st = split - 1, ntu = L.isp_ntu, maxParts = S.ispNumTotal[st];
+  const double rc = L.isp_first ? L.isp_cost : MAX_DOUBLE;
+  { const int psz = isp_split_dim(f.w, f.h, split == 1), tpix = split == 1 ? f.w * psz : psz * f.h; L.cnt[1] += (unsigned long long) L.isp_evals; L.cnt[2] += (unsigned long long) (L.isp_evals * tpix); }
+  S.ispTMode[S.ispNT] = (uint8_t) mode; S.ispTInfo[S.ispNT] = (uint8_t) ((split << 4) | ntu); S.ispTCost[S.ispNT] = ntu == maxParts ? rc : MAX_DOUBLE; S.ispNT++; S.ispNTested[st]++;
+  if (ntu == maxParts && rc < S.ispBestRd) { S.ispBestMode = (int8_t) mode; S.ispBestSplit = (int8_t) split; }
+  if (L.isp_valid && L.isp_first && L.isp_cost < S.ispBestRd) {
+    S.ispBestRd = L.isp_cost; L.isp_win = 1;
+    S.ispWinMode = (uint8_t) mode; S.ispWinSplit = (uint8_t) split; S.ispWinTucbf = L.isp_tucbf; S.ispWinDist = L.isp_dist; S.ispWinBits = L.isp_bits;
+    if (L.isp_cost < S.ispCurBest) S.ispCurBest = L.isp_cost;
+  }
+}
 // thread 0: the full-RD list of a luma pass is in S.rdList[0, numRd): MPM append (777-802) unless the list comes from the DCT-II pass (an MTS pass), the
 // MIP re-ordering (1097-1122) or removal of MIP candidates (1123-1141), then stage B
 __device__ __noinline__ void ctrl_post_stage_b(Frame &f, int append_mpm)
@@ -3826,6 +4131,11 @@ __device__ __noinline__ void ctrl_post_stage_b(Frame &f, int append_mpm)
       int incl = 0;
       for (int i = 0; i < S.numRd; i++) incl |= (S.rdList[i].mode == L.mpm[j] && S.rdList[i].mrl == 0);
       if (!incl) { S.rdList[S.numRd].mode = (uint8_t) L.mpm[j]; S.rdList[S.numRd].mrl = 0; S.rdCost[S.numRd] = 0; S.numRd++; }
+    }
+    if (S.testIsp) for (int j = 0; j < L.mpm_n; j++) {      // 803-820: the MPMs join the list saved for ISP as well
+      int incl = 0;
+      for (int i = 0; i < S.ispHadN; i++) incl |= S.ispHad[i] == L.mpm[j];
+      if (!incl) S.ispHad[S.ispHadN++] = (uint8_t) L.mpm[j];
     }
     if (S.lfOn && S.mtsUsage == 1 && S.lf == 0) { S.mtsNum = S.numRd; for (int i = 0; i < S.numRd; i++) S.mtsList[i] = S.rdList[i]; }      // 884-889 (only the list of lfnstIdx 0 is read again)
   }
@@ -3838,6 +4148,8 @@ __device__ __noinline__ void ctrl_post_stage_b(Frame &f, int append_mpm)
   L.n_rd = n;
   if (S.lf == 0 && S.mts == 0) for (int c = 0; c < n && c < 16; c++) S.inv0[S.idxOf[c]] = (uint8_t) c;      // where the first pass evaluates each place of its list
   f.phase = PH_B_DONE;
+  L.isp_wait = 0; L.isp_win = 0;
+  if (S.testIsp) { f.phase = PH_ISP; L.isp_wait = 1; S.ispSlot = -1; }      // sixteen reserved places behind the regular and MIP candidates (1032-1039)
   post(OP_STAGE_B);
 }
 // thread 0: step the (transform group, lfnstIdx, mtsFlag) loops of xCheckRDCostIntra (2453-2775) after a pass; returns 0 when no pass is left
@@ -3845,6 +4157,7 @@ __device__ __noinline__ int ctrl_next_pass()
 {
   CtlState &S = L.S;
   int g = S.grp, lf = S.lf, m = S.mts + 1;
+  if (S.ispBreak) { S.ispBreak = 0; m = S.considerMts + 1; }      // 2737-2740: the ISP winner ended the mtsFlag loop of this lfnstIdx
   for (;;) {
     const int endM = S.considerMts;
     if (m > endM) {                                        // the mtsFlag loop of this lfnstIdx is over
@@ -3858,7 +4171,7 @@ __device__ __noinline__ int ctrl_next_pass()
         }
         g++;
         if (g >= 4) return 0;
-        if (S.considerMts && S.grpCheck[g]) { lf = S.startLf; m = 1; endOfLf = lf > S.endLf; }
+        if (S.considerMts && !S.skipMts2 && S.grpCheck[g]) { lf = S.startLf; m = 1; endOfLf = lf > S.endLf; }
       }
       continue;
     }
@@ -3882,14 +4195,25 @@ __device__ __noinline__ int ctrl_b_done(const VxParams &p_, const VxFrameDev &fd
       t.dist = L.rd_dist[best];
       VxUnit &cu = L.cu;
       cu.dir = L.rd[best].mode; cu.mrl = ch ? 0 : L.rd[best].mrl; cu.cbf = L.rd_cbf[best]; cu.mts = (uint8_t) (((ch && !(p.tools & TOOL_JCCR)) ? 0 : L.rd_mts[best]) | (L.ps_lfnst << 4));      // luma: tu.mtsIdx, chroma: tu.jointCbCr; lfnstIdx rides in bits 4-5
+      const int ispWin = !ch && L.isp_win;              // 0 / cu.ispMode of an ISP winner (search) or of the cached CU (reuse); bits 6-7 of the unit's mts byte, the sub-partitions' cbfs in bits 4-7 of its cbf byte
+      if (ispWin && L.n_rd) {                           // the ISP candidate parked by OP_ISP beat the regular winner (1308-1326)
+        cu.dir = L.S.ispWinMode; cu.mrl = 0; cu.cbf = (uint8_t) (1 | (L.S.ispWinTucbf << 4)); cu.mts = (uint8_t) (L.S.ispWinSplit << 6);
+        t.dist = L.S.ispWinDist; L.cu_bits = L.S.ispWinBits;      // cu_pred_data + cu_residual of an ISP CU = what the sub-partitions were priced with (no residual_lfnst_mode, EL/CABACWriter.cpp:3994)
+        L.win_wave = ISP_WAVE(ww); L.op_a = 1;
+      }
       // cu_pred_data + cu_residual bits (EL/EncCu.cpp:2593-2619) and the CU's end contexts are left in cu_bits / wctx[0]
       // by the operation (luma: identical to the stage-B syntax from the same start contexts)
+      if (!ch && f.cur_mode == ETM_RECO_CACHED) cu.mts |= f.r_mts & 0xc0;      // cu.ispMode of the cached CU
       t.bits = L.cu_bits;
+      const double costWithoutSplitFlags = rd_cost(p, t.bits, t.dist);      // 2622-2629: also bestIspCost of an ISP winner
       Cab cb; cb.ci = CI_W(0); cb.bits = 0;
       enc_split_cu_mode(p, fd, cb, f, ch, tile, SPLIT_NONE);          // xEncodeDontSplit 5649-5662
       t.bits += cb.bits;
       t.cost = rd_cost(p, t.bits, t.dist);
       t.n_cu = 1; t.f_bt = t.l_bt = f.bt; t.f_cbf = cu.cbf != 0; t.f_w = t.l_w = (int16_t) (f.w >> sh); t.f_h = t.l_h = (int16_t) (f.h >> sh); t.max_qt = f.qt; t.valid = 1;
+#ifdef VX_TRACE
+      fprintf(stderr, "RES ch %d node %d %d %dx%d lf %d mts %d dir %d isp %d tucbf %d cost %.3f dist %llu\n", ch, f.x, f.y, f.w, f.h, L.S.lfOn ? L.S.lf : L.ps_lfnst, L.S.lfOn ? L.S.mts : 0, cu.dir, cu.mts >> 6, cu.cbf >> 4, t.cost, (unsigned long long) t.dist);
+#endif
       f.phase = PH_ADVANCE;
       CtlState &S = L.S;
       if (S.lfOn) {                                     // a pass of the LFNST / MTS loop (2633-2760)
@@ -3899,8 +4223,16 @@ __device__ __noinline__ int ctrl_b_done(const VxParams &p_, const VxFrameDev &fd
         }
         if (S.lf && !(L.rd_lfl[best] & 1) && cu.cbf) t.cost = MAX_DOUBLE;      // 2633-2645: an LFNST index that cannot be signalled
         if (S.mts == 0 && S.lf == 0) S.dct2Cost = t.cost;
+        if (!(cu.mts >> 6)) S.noIspCost = t.cost;        // useModeResult(ETM_INTRA), EL/EncModeCtrl.cpp:2120-2123: bestCostMtsFirstPassNoIsp
         S.skipOther = (int8_t) !cu.cbf;                 // checkSkipOtherLfnst (EL/EncModeCtrl.cpp:2070-2087): the intra passes are a node's first modes, its condition always holds
         f.phase = PH_NEXT_PASS;
+      }
+      // 2714-2741 (ISPFast 1): an ISP winner of the first pass that beats the best regular mode by a margin ends the LFNST / MTS passes of this CU (evaluated after
+      // xCheckBestMode in the reference; it reads nothing that call changes except endLfnstIdx, which a transform-skip winner - never an ISP CU - sets)
+      if (S.lfOn && (S.considerMts > 0 || S.endLf > 0) && (cu.mts >> 6) && !ch && !S.mts && !S.lf) {
+        const double threshold = 1.4, lfnstThreshold = 1.01 * threshold;
+        if (S.noIspCost > costWithoutSplitFlags * lfnstThreshold) S.endLf = S.lf;
+        if (S.noIspCost > costWithoutSplitFlags * threshold) { S.skipMts2 = 1; S.ispBreak = 1; }
       }
       if (use_mode_result(p, f, ch, ETM_INTRA, t)) {
         if (S.lfOn) { S.grpBest[S.grp] = t.cost; S.bestSel[S.grp] = 1; S.bestMts = S.mts; S.bestLf = S.lf; }      // 2696-2701
@@ -3927,6 +4259,9 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
 #ifndef VVCX_STAMP_DQ
     struct PhStamp { long long t; int ph; __device__ ~PhStamp() { if (ph < 12) PROF(16 + ph) += (unsigned long long) (STAMP() - t); PROF(30) += 1; } } phstamp = { tph, phs };
 #endif
+#endif
+#ifdef VX_TRACE
+    fprintf(stderr, "  step d %d phase %d nmodes %d\n", d, f.phase, f.nmodes);
 #endif
     switch (f.phase) {
     case PH_ENTER: {                                    // xCompressCU entry (EL/EncCu.cpp:727-1286)
@@ -3961,7 +4296,8 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         cu.qt = f.qt; cu.mt = f.mt; cu.bt = f.bt; cu.depth = f.depth; cu.dir = 0; cu.mrl = 0; cu.cbf = 0; cu.mts = 0; cu.tag = (uint16_t) (tile + 1);
         if (mode == ETM_RECO_CACHED) {                  // xReuseCachedResult (EL/EncCu.cpp:5665-5771)
           L.rd[0].mode = f.r_dir; L.rd[0].mrl = f.r_mrl; L.rd_cbf[0] = f.r_cbf; L.rd_mts[0] = (uint8_t) (f.r_mts & 7); L.n_rd = 0;
-          L.ps_lfnst = (int8_t) (f.r_mts >> 4); L.ps_mts = 0; L.ps_grp = 0; S.lfOn = 0;
+          L.isp_split = (uint8_t) (ch ? 0 : f.r_mts >> 6); L.isp_tucbf = (uint8_t) (f.r_cbf >> 4);      // a cached ISP CU
+          L.ps_lfnst = (int8_t) ((f.r_mts >> 4) & 3); L.ps_mts = 0; L.ps_grp = 0; S.lfOn = 0; L.isp_wait = 0; L.isp_win = 0;
           if (!ch) {                                    // MPM list for intra_luma_pred_modes
             int Ld, Ad; luma_neighbours(p, fd, f.x, f.y, f.w, f.h, tile, Ld, Ad);
             derive_mpms(Ld, Ad, L.mpm);
@@ -3980,7 +4316,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         S.grp = 0; S.lf = 0; S.mts = 0; S.startLf = 0; S.skipOther = 0; S.bestMts = 0; S.bestLf = 0; S.bestValid0 = 0; S.lfSaved = 0;
         S.endLf = (int8_t) ((!S.lfOn || (ch && (f.w < 8 || f.h < 8)) || f.w > 64 || f.h > 64) ? 0 : 2);                 // 2431-2449
         S.considerMts = (int8_t) (S.lfOn && (p.tools & TOOL_MTS) && !ch && f.w <= 32 && f.h <= 32);                      // 2409 (as the MTS passes' loop bound)
-        S.dct2Cost = MAX_DOUBLE;
+        S.dct2Cost = MAX_DOUBLE; S.testIsp = 0; S.skipMts2 = 0; S.ispBreak = 0; S.noIspCost = MAX_DOUBLE; L.isp_wait = 0; L.isp_win = 0;
         L.spec_n = 0;
         for (int i = 0; i < 4; i++) { S.grpCheck[i] = 1; S.bestSel[i] = 0; S.grpBest[i] = MAX_DOUBLE; }
         f.phase = PH_PASS;
@@ -4024,7 +4360,9 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
           int Ld, Ad; luma_neighbours(p, fd, f.x, f.y, f.w, f.h, tile, Ld, Ad);
           derive_mpms(Ld, Ad, L.mpm); L.mpm_n = (Ld == Ad) ? 1 : 2;
         }
-        S.testMip = (int8_t) (L.mip_n && (S.lf == 0 || (f.w >= 16 && f.h >= 16)));                                               // 404-418 (JVET_O0925) + allowLfnstWithMip
+        S.testMip = (int8_t) (L.mip_n && (S.lf == 0 || (f.w >= 16 && f.h >= 16)));
+        S.testIsp = (int8_t) (S.lfOn && S.lf == 0 && S.mts == 0 && L.isp_ok);      // 355-384: ISP is tested in the pass without LFNST and MTS
+        if (S.testIsp) S.ispHadN = 0;                                               // 404-418 (JVET_O0925) + allowLfnstWithMip
         if (S.lf == 0 && S.mts == 0) {
           // stage A candidate list, phase 1: 35 even modes + MRL MPM candidates (costs are order independent)
           int n = 0;
@@ -4069,6 +4407,19 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         post(OP_CHROMA_RD); return;
       }
     }
+    case PH_ISP: {                                      // the reserved places of the RD list: each asks xGetNextISPMode for the next ISP candidate (1181-1192)
+      if (S.ispSlot < 0) { ctrl_isp_begin(f); S.ispSlot = 0; } else ctrl_isp_result(f);
+      set_node(f, d);
+      while (S.ispSlot < 16) {
+        int mode = 0, split = 0;
+        S.ispSlot++;
+        if (!ctrl_isp_next(f.w, f.h, mode, split)) { S.ispPrev = 3; continue; }
+        S.ispPrev = (int8_t) split;
+        L.isp_mode = (uint8_t) mode; L.isp_split = (uint8_t) split; L.isp_limit = S.ispCurBest; L.isp_best = S.ispBestRd;
+        post(OP_ISP); return;
+      }
+      L.isp_wait = 0; f.phase = PH_B_DONE; post(OP_ISP_END); return;      // the node's intra decision with the ISP winner, if any
+    }
     case PH_NEXT_PASS: {
       if (ctrl_next_pass()) { VxUnit &cu = L.cu; cu.dir = 0; cu.mrl = 0; cu.cbf = 0; cu.mts = 0; f.phase = PH_PASS; }
       else f.phase = PH_ADVANCE;
@@ -4076,6 +4427,9 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
     }
     case PH_A1_DONE: {                                  // EL/IntraSearch.cpp:489-623; the top-numRd list was selected by the operation
       L.cnt[0] += (unsigned long long) L.n_cand;
+#ifdef VX_TRACE
+      fprintf(stderr, "DEV node %d %d %dx%d numRd %d isp_ok %d list", f.x, f.y, f.w, f.h, S.numRd, L.isp_ok); for (int i = 0; i < S.numRd; i++) fprintf(stderr, " %d:%d(%.1f)", S.rdList[i].mode, S.rdList[i].mrl, S.rdCost[i]); fprintf(stderr, "\n");
+#endif
       int n = L.n_cand; S.n_a2 = 0;
       for (int i = 0; i < S.numRd; i++) {                 // +-1 of the survivors, from a snapshot of the list (parentCandList 574)
         const int pm = S.rdList[i].mode;
@@ -4202,11 +4556,22 @@ __device__ __noinline__ void walk_tree(const VxParams &p_, const VxFrameDev &fd_
         if (!ch) {
           int Ld, Ad; luma_neighbours(p, fd, f.x, f.y, f.w, f.h, tile, Ld, Ad);
           derive_mpms(Ld, Ad, L.mpm);
+          if (u->mts >> 6) {                            // an ISP CU: transform_tree splits it (EL/CABACWriter.cpp:3311-3330); each luma cbf with the previous sub-partition's as context, the last one inferred after all-zero ones (3574-3600); no residual_lfnst_mode (3994)
+            const int isp = u->mts >> 6, hor = isp == 1, psz = isp_split_dim(W, H, hor), tw = hor ? W : psz, th = hor ? psz : H, n = hor ? H / psz : W / psz, tucbf = u->cbf >> 4;
+            enc_intra_luma_pred_mode<WR>(cb, f.y, u->dir, 0, isp);
+            for (int k = 0, sofar = 0; k < n; k++) {
+              const int ox = hor ? 0 : k * tw, oy = hor ? k * th : 0, c = (tucbf >> k) & 1;
+              if (!(k == n - 1 && !sofar)) enc_bin<WR>(cb, (unsigned) c, VX_CTX_QtCbf[0] + 2 + (k ? (tucbf >> (k - 1)) & 1 : 0));
+              if (c) { for (int yy = 0; yy < th; yy++) for (int xx = 0; xx < tw; xx++) lv[yy * tw + xx] = fd.lev[0][(f.y + oy + yy) * fd.lstride[0] + f.x + ox + xx]; residual_coding<WR>(cb, lv, tw, th, 0, (uint16_t *) (lv + 4096)); }
+              sofar |= c;
+            }
+            top--; continue;
+          }
           enc_intra_luma_pred_mode<WR>(cb, f.y, u->dir, u->mrl);
           enc_bin<WR>(cb, u->cbf & 1, VX_CTX_QtCbf[0]);
           int fl = 0;
           if (u->cbf & 1) { for (int yy = 0; yy < H; yy++) for (int xx = 0; xx < W; xx++) lv[yy * W + xx] = fd.lev[0][(f.y + yy) * fd.lstride[0] + f.x + xx]; enc_tu_mts<WR>(cb, W, H, u->mts & 7); if ((u->mts & 7) == 1) rc_ts_serial<WR>(cb, lv, W, H); else { residual_coding<WR>(cb, lv, W, H, 0, (uint16_t *) (lv + 4096), (u->mts & 7) > 1); fl = lfnst_flags(L.rc_last[0], W, H); } }
-          enc_lfnst_idx<WR>(cb, 0, W, H, (u->mrl & MIPF) != 0, (u->cbf & 1) && (u->mts & 7) != 0, fl, u->mts >> 4);
+          enc_lfnst_idx<WR>(cb, 0, W, H, (u->mrl & MIPF) != 0, (u->cbf & 1) && (u->mts & 7) != 0, fl, (u->mts >> 4) & 3);
         } else {
           int fl = 0;
           enc_intra_chroma_pred_mode<WR>(cb, u->dir, unit_ldir(fd.units[0][((f.y + (f.h >> 1)) >> 2) * p.uw + ((f.x + (f.w >> 1)) >> 2)]), cclm_allowed(p, fd, f.x, f.y, u->ss, u->depth));
@@ -4219,7 +4584,7 @@ __device__ __noinline__ void walk_tree(const VxParams &p_, const VxFrameDev &fd_
             residual_coding<WR>(cb, lv, W, H, 1, (uint16_t *) (lv + 4096));
             fl |= lfnst_flags(L.rc_last[0], W, H);
           }
-          enc_lfnst_idx<WR>(cb, 1, f.w, f.h, 0, 0, fl, u->mts >> 4);
+          enc_lfnst_idx<WR>(cb, 1, f.w, f.h, 0, 0, fl, (u->mts >> 4) & 3);
         }
         top--; continue;
       }
@@ -4326,6 +4691,9 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
       }
       L.pre_copy_d = -1;
       control_step(p, fd, scratch);
+#ifdef VX_TRACE
+      fprintf(stderr, "cnt0 %llu ch %d op %d a %d node %d %d %dx%d d %d phase %d isp slot %d mode %d split %d\n", L.cnt[0], L.tree_ch, L.op, L.op_a, L.nx, L.ny, L.nw, L.nh, L.d, L.d >= 0 ? L.fr[L.d].phase : -1, L.S.ispSlot, L.isp_mode, L.isp_split);
+#endif
       t_prev = STAMP();
       if (VVCX_STAMP) PROF(0) += (unsigned long long) (t_prev - t0);
     } }
@@ -4337,7 +4705,14 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
     switch (op) {
       case OP_LUMA_PREP: op_luma_prep<T>(p, fd); if (uni(L.op_c)) op_stage_a(p, scratch); break;
       case OP_STAGE_A: op_stage_a(p, scratch); break;
-      case OP_STAGE_B: op_stage_b(p, scratch); after_intra_op(p, fd, scratch); break;
+      case OP_STAGE_B: op_stage_b(p, scratch); if (!uni((int) L.isp_wait)) after_intra_op(p, fd, scratch); break;
+      case OP_ISP: op_isp(scratch); break;
+      case OP_ISP_END:                                    // every place used: the ISP winner's end contexts take the place of the regular winner's, then the node's intra decision
+        // (an operation kind of its own: the decision below rewrites the operation's parameters while other waves may still be dispatching)
+        if (uni((int) L.isp_win)) ctx_copy_all(&L.ctxs[CI_W(0)], ctx_ptr(scratch, CTX_START, MAXD + 1, 0));
+        __threadfence_block(); __syncthreads();
+        after_intra_op(p, fd, scratch);
+        break;
       case OP_CHROMA_RD: op_chroma_rd<T>(p, fd, scratch); after_intra_op(p, fd, scratch); break;
       case OP_SAVE_INTRA: op_save_intra(p, scratch, L.cu); break;
       case OP_SAVE_PIC: op_save_pic<T>(p, fd, scratch, 0); break;

@@ -55,7 +55,7 @@ TU_DTYPE = np.dtype([("cu_index", "<i4"), ("x", "<i2"), ("y", "<i2"), ("w", "<i2
 CTU_DTYPE = np.dtype([("dist", "<u8"), ("frac_bits", "<u8"), ("cost", "<f8"), ("n_cu", "<i4")], align=True)
 CU_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("ch_type", "u1"), ("qt_depth", "u1"),
                      ("bt_depth", "u1"), ("mt_depth", "u1"), ("depth", "u1"), ("intra_dir", "u1"), ("mrl_idx", "u1"),
-                     ("cbf", "u1"), ("mts_idx", "u1"), ("mip_flag", "u1"), ("lfnst_idx", "u1"), ("joint_cb_cr", "u1"), ("split_series", "<u8")], align=True)
+                     ("cbf", "u1"), ("mts_idx", "u1"), ("mip_flag", "u1"), ("lfnst_idx", "u1"), ("joint_cb_cr", "u1"), ("isp_mode", "u1"), ("tu_cbf", "u1"), ("split_series", "<u8")], align=True)
 
 _libs = {}
 

@@ -197,6 +197,23 @@ def test_transform_skip_without_cu_reuse_and_with_classifier():
     _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=1.0, oriented=30.0, screen=0.5)], 256, 128, pkg.slice_params(27, dep_quant=True), tools=TSK | pkg.TOOL_FAST)
 
 
+ISP = TSK | pkg.TOOL_ISP
+
+
+@pytest.mark.parametrize("case", [(128, 128, 32, 8, 1, 1, 9, 0.5, ISP), (200, 136, 27, 8, 1, 1, 1234, 0.5, ALL | pkg.TOOL_ISP), (256, 128, 37, 8, 2, 1, 5, 0.7, ISP), (128, 128, 22, 10, 1, 1, 3, 0.5, ALL | pkg.TOOL_ISP)])
+def test_isp_in_the_search(case):
+    # tools 0xbff / 0xb5f: intra sub-partitions: sixteen reserved places behind the regular and MIP candidates of the first pass, the lazily chosen (mode, split)
+    # candidates, sub-partitions predicted from the reconstruction of the one before, 1 x N / 2 x N / N x 1 / N x 2 TUs with the implicit DST-VII, cbf chain, early exits,
+    # the ISP rule that ends the LFNST / MTS passes, cached ISP CUs in the reuse path; screen-content pictures, with and without transform skip competing
+    W, H, qp, bd, tc, tr, seed, scr, tools = case
+    _check([pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=0.6, oriented=25.0, screen=scr)], W, H, pkg.slice_params(qp, bit_depth=bd, dep_quant=True), bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools)
+
+
+def test_isp_without_cu_reuse_and_with_classifier():
+    _check([pkg.synth_frame(128, 128, 0, 8, 11, chroma_texture=0.5, screen=0.6)], 128, 128, pkg.slice_params(32, dep_quant=True), tools=(ALL | pkg.TOOL_ISP) & ~pkg.TOOL_CU_REUSE)
+    _check([pkg.synth_frame(256, 128, 0, 8, 12, chroma_texture=1.0, oriented=30.0, screen=0.5)], 256, 128, pkg.slice_params(27, dep_quant=True), tools=ISP | pkg.TOOL_FAST)
+
+
 def _lmcs_model(bd):
     # a model the reference encoder's own picture analysis chose (10-bit limited-range fixture picture); scaled to the 8-bit code-word budget for 8-bit cases
     import os
@@ -324,7 +341,7 @@ def test_baseline_config_3_classifier_per_qp_forest_1080p_rows(qp):
     _check([pkg.synth_frame(W, H, 0, 8, 2000 + qp, chroma_texture=0.5)], W, H, pkg.slice_params(qp, dep_quant=True), tile_cols=15, tile_rows=2, tools=ALL | pkg.TOOL_FAST, forest_qp=qp, workers=12)
 
 
-@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz", "bitstream_dq.npz", "bitstream_lfnst.npz", "bitstream_lfnst_c.npz", "bitstream_jccr.npz", "bitstream_jccr_plain.npz", "bitstream_ts.npz"])
+@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz", "bitstream_dq.npz", "bitstream_lfnst.npz", "bitstream_lfnst_c.npz", "bitstream_jccr.npz", "bitstream_jccr_plain.npz", "bitstream_ts.npz", "bitstream_isp.npz", "bitstream_full.npz", "bitstream_lmcs.npz"])
 def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fixture):
     """Device writer (arithmetic coding of the final CTU syntax in the estimator pass) against tests/golden/bitstream.npz: payloads
     that the reference's CABACReader parsed back into the coded CUs and levels when the fixture was generated."""
@@ -335,6 +352,7 @@ def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fix
     texture = float(g["chroma_texture"][0]) if "chroma_texture" in g else 0.0
     oriented = float(g["oriented"][0]) if "oriented" in g else 0.0
     screen = float(g["screen"][0]) if "screen" in g else 0.0
+    limited = bool(g["limited"][0]) if "limited" in g else False
     torch.cuda.init()
     off = 0
     jobs = []
@@ -342,16 +360,20 @@ def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fix
         exp = g["pic_bytes"][off:off + nbytes]; off += int(nbytes)
         if pic >= 3 and fixture in ("bitstream_jccr.npz", "bitstream_lfnst.npz"):      # the CPU suite checks the oracle against every picture; three per fixture here
             continue
-        jobs.append((int(W), int(H), int(qp), int(tc), int(tr), int(bd), int(seed), exp, sizes))
+        lm = None
+        if "pic_lmcs" in g:                     # the LMCS model the reference encoder's analysis chose for the picture (stored with the fixture)
+            r = [int(v) for v in g["pic_lmcs"][pic]]
+            lm = dict(enable=r[0], chroma_adj=r[1], min_bin=r[2], max_bin=r[3], delta_cw=r[4:])
+        jobs.append((int(W), int(H), int(qp), int(tc), int(tr), int(bd), int(seed), exp, sizes, lm))
 
     def one_picture(job):
         # one encoder and one HIP stream per picture: the pictures of a fixture are independent streams and run side by side
-        W, H, qp, tc, tr, bd, seed, exp, sizes = job
+        W, H, qp, tc, tr, bd, seed, exp, sizes, lm = job
         sp = pkg.slice_params(qp, bit_depth=bd, dep_quant=bool(tools & pkg.TOOL_DEPQUANT))
-        planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture, oriented=oriented, screen=screen)
+        planes = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=texture, oriented=oriented, screen=screen, limited=limited)
         stream = torch.cuda.Stream()
         enc = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, emit_payload=True, tools=tools)
-        enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+        enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"], lmcs=lm)
         conv = [p if p.dtype == np.uint8 else p.view(np.int16) for p in planes]
         org = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in conv]
         rec = [torch.zeros_like(t) for t in org]
@@ -368,7 +390,7 @@ def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fix
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=4) as ex:
         outs = list(ex.map(one_picture, jobs))
-    for (W, H, qp, tc, tr, bd, seed, exp, sizes), (lens, got) in zip(jobs, outs):
+    for (W, H, qp, tc, tr, bd, seed, exp, sizes, lm), (lens, got) in zip(jobs, outs):
         assert lens == list(sizes[:tc * tr])
         assert np.array_equal(got, exp), (W, H, qp, tc, tr, bd)
 

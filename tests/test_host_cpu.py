@@ -53,7 +53,7 @@ def test_host_argument_checks(emu_so):
     with pytest.raises(pkg.VvcxError):
         pkg.VvcxEncoder(130, 128, 8, lib_path=emu_so)            # not a multiple of 8
     with pytest.raises(pkg.VvcxError):
-        pkg.VvcxEncoder(128, 128, 8, tools=1 | 4, lib_path=emu_so)  # ISP not built yet: refuse, never ignore
+        pkg.VvcxEncoder(128, 128, 8, tools=1 | 4, lib_path=emu_so)  # ISP without the tools it is built on (DepQuant, LFNST, MTS): refuse, never ignore
     enc = pkg.VvcxEncoder(128, 128, 8, lib_path=emu_so)
     with pytest.raises(pkg.VvcxError):
         enc.bind_frames([([1, 1, 1], [1, 1, 1], [128, 64, 64])])  # slice not set
@@ -111,6 +111,52 @@ def test_transform_skip_search_on_cpu_emulator_matches_oracle(emu_so):
     assert all(np.array_equal(rec[c], oreco[c]) for c in range(3))
     assert np.array_equal(enc.counters(), ocnt)
     assert np.array_equal(enc.get_payload(0, 0), O.write_frame(planes, w, h, sp, tools=tools)[0])
+    enc.close()
+
+
+def test_isp_search_on_cpu_emulator_matches_oracle(emu_so):
+    """Intra sub-partitions on the device path (CPU debug emulation): the sixteen reserved places of the RD list with xGetNextISPMode / xSortISPCandList on the controller,
+    OP_ISP evaluating one (mode, split) candidate (region references from the previous sub-partition's reconstruction, 1-D transforms, ISP cbf chain, early exits), the
+    ISP decision rule of xCheckRDCostIntra, isp_mode in every line-0 luma mode's syntax, the writer's transform_tree of an ISP CU; a picture where an ISP CU wins.
+    Also the TU table: one record per sub-partition (vvcx_get_tus)."""
+    w = h = 16
+    tools = 0xb7f | pkg.TOOL_RDOQ
+    planes = pkg.synth_frame(w, h, 0, 8, 3, chroma_texture=0.6, oriented=20.0, screen=1.0)
+    sp = pkg.slice_params(32, dep_quant=True)
+    enc = pkg.VvcxEncoder(w, h, 8, tools=tools, lib_path=emu_so, emit_payload=True)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    org = [np.ascontiguousarray(p) for p in planes]
+    rec = [np.zeros_like(p) for p in planes]
+    enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
+    res = enc.compress_bound_frames()[0]
+    cus = enc.get_cus(0)
+    ores, ocus, oreco, ocnt = O.compress_frame(planes, w, h, sp, tools=tools)
+    assert int(np.count_nonzero(ocus["isp_mode"])) >= 1
+    for k in ores.dtype.names:
+        assert np.array_equal(ores[k], res[k]), k
+    assert len(cus) == len(ocus) and all(np.array_equal(cus[k], ocus[k]) for k in cus.dtype.names)
+    assert all(np.array_equal(rec[c], oreco[c]) for c in range(3))
+    assert np.array_equal(enc.counters(), ocnt)
+    assert np.array_equal(enc.get_payload(0, 0), O.write_frame(planes, w, h, sp, tools=tools)[0])
+    tus = enc.get_tus(0)
+    lev = enc.get_levels(0)
+    k = 0
+    for i, c in enumerate(cus):
+        if c["isp_mode"]:
+            hor = c["isp_mode"] == 1
+            split, non = (c["h"], c["w"]) if hor else (c["w"], c["h"])
+            psz = max(split >> 2, (16 >> int(np.log2(non))) if non < 16 else 1); n = split // psz
+            for j in range(n):
+                t = tus[k + j]
+                assert t["cu_index"] == i and t["depth"] == 1 and (t["w"], t["h"]) == ((c["w"], psz) if hor else (psz, c["h"]))
+                assert (t["x"], t["y"]) == ((c["x"], c["y"] + j * psz) if hor else (c["x"] + j * psz, c["y"]))
+                blk = lev[0][t["y"]:t["y"] + t["h"], t["x"]:t["x"] + t["w"]]
+                assert int(t["cbf"][0]) == int((c["tu_cbf"] >> j) & 1) == int(np.any(blk != 0))
+            k += n
+        else:
+            assert tus[k]["cu_index"] == i and tus[k]["depth"] == 0
+            k += 1
+    assert k == len(tus)
     enc.close()
 
 

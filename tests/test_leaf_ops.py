@@ -180,6 +180,35 @@ def _transform_skip(lib, limit):
     return n
 
 
+def _isp_tu(lib, limit):
+    """vvcx_isp_tu_batch (wave_code_block_isp: implicit DST-VII / DCT-II, the one-stage transforms of one-sample-wide blocks, the trellis on 1 x 16 / 16 x 1 / 2 x 8 / 8 x 2
+    coefficient groups with the cbf contexts of ISP sub-partitions) against the reference's TrQuant / DepQuant vectors for TUs of ISP CUs (tests/golden/isp.npz)"""
+    vv = importlib.import_module(PKGNAME + ".vvcx")
+    g = np.load(os.path.join(G, "isp.npz"))
+    off = n = 0
+    for i, (bd, qp, w, h, isp, k, nsub, tw, th, prev, inferred, a, gi) in enumerate(g["meta"]):
+        P = int(tw) * int(th)
+        resi, lev, ro = g["resi"][off:off + P], g["lev"][off:off + P], g["resi_out"][off:off + P]
+        off += P
+        if limit and (n >= limit or P > 64 or i % 5):
+            continue
+        mid, mx = 1 << (bd - 1), (1 << bd) - 1
+        org = (mid + resi.astype(np.int32)).astype(np.int16); pred = np.full(P, mid, np.int16)
+        s0, s1 = g["ctx"][gi]
+        l, r, sse, cbf = vv.isp_tu_batch(org, pred, int(tw), int(th), int(bd), int(qp + 6 * (bd - 8)), float(g["lam"][i]), int(prev), int(inferred), s0, s1, lib_path=lib)
+        key = (int(bd), int(qp), int(w), int(h), int(isp), int(k), int(tw), int(th))
+        assert np.array_equal(l.ravel(), lev) and int(cbf[0]) == int(a > 0), ("levels", key)
+        rec_e = np.clip(mid + ro.astype(np.int32), 0, mx) if a > 0 else np.full(P, mid)
+        assert np.array_equal(r.ravel().astype(np.int32), rec_e), ("rec", key)
+        n += 1
+    return n
+
+
+@pytest.mark.gpu
+def test_gpu_isp_sub_partition_blocks_match_reference():
+    assert _isp_tu(None, None) == 624
+
+
 @pytest.mark.gpu
 def test_gpu_transform_skip_matches_reference():
     assert _transform_skip(None, None) == 384
@@ -225,6 +254,7 @@ def test_emulated_leaf_operators_match_reference(emu_so):
     assert _depquant(emu_so, 12) == 12
     assert _lfnst(emu_so, 16) == 16
     assert _transform_skip(emu_so, 40) == 40
+    assert _isp_tu(emu_so, 30) == 30
 
 
 @pytest.mark.gpu
