@@ -73,6 +73,18 @@ def pmc_valu(workload):
     return None
 
 
+def _cpu_job(job):
+    """one process of the frame-parallel CPU baseline: the oracle on the sample crop (module level: spawned workers import it)"""
+    crop, sw, sh, sp, kw, classifier = job
+    import oracle_lib as O
+    forest = None
+    if classifier:
+        pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+        forest = pkg.load_forest(os.path.join(ROOT, "reduce-complexity-for-intra-coding-of-vvc_amd", "forests", "partition_qp32.npz"))
+    O.compress_frame(crop, sw, sh, sp, forest=forest, **kw)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,14 +99,19 @@ def main():
     ap.add_argument("--tiles", type=str, default="auto",
                     help="CxR uniform tile grid (1x1 = the reference cfg's single tile: one stream per frame; 4x2; ...); auto = one tile per CTU")
     ap.add_argument("--lib", type=str, default=None, help="alternative build of the HIP library (experiments only)")
-    ap.add_argument("--tools", type=lambda v: int(v, 0), default=0xb5b,
-                    help="VVCX_TOOL_* bits; default MRL | MIP | LFNST | MTS | DepQuant | CCLM | JointCbCr | CU reuse = every tool of the reference's intra cfg that is built so far")
+    ap.add_argument("--tools", type=lambda v: int(v, 0), default=0xfff,
+                    help="VVCX_TOOL_* bits; default 0xfff = every tool of BIN/encoder_intra.cfg that reaches the path: MRL | MIP | ISP | LFNST | MTS | TransformSkip | DepQuant | "
+                         "RDOQ(TS) | CCLM | JointCbCr | LMCS | CU reuse (0xb5b = the round-2 tool set, for the same-tools delta)")
+    ap.add_argument("--lmcs", type=str, default="analysis", choices=("analysis", "model"),
+                    help="analysis: what the reference's picture analysis decides for this content: LMCS off for every 8-bit picture and for full-range 10-bit ones "
+                         "(EL/EncReshape.cpp, see DESIGN.md); model: the slice carries a typical SDR model (limited-range luma), to time chroma residual scaling")
     ap.add_argument("--classifier", action="store_true",
                     help="BASELINE config 3 flavour: the fork's FAST_ALGORITHM with the shipped forest (forests/partition_qp32.npz) on the device")
     ap.add_argument("--chroma-texture", type=float, default=0.5,
                     help="fraction of the luma texture mixed into the synthetic chroma planes (0 = smooth chroma)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-ctus", type=int, default=12)
+    ap.add_argument("--cpu-sample-ctus", type=int, default=8)
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the frame-parallel CPU baseline (0 = the host's usable cores, at most 16)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -146,10 +163,16 @@ def main():
         args.frames = int(args.frames)
     emit = world > 1                                # the N-GPU job ends with the bitstream gather: its ranks run the slice_data writer too
     enc = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, chroma=True, max_frames=args.frames, device=dev, lib_path=args.lib, tools=args.tools, forest=forest, emit_payload=emit)
-    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    lmcs = None
+    if args.lmcs == "model" and (args.tools & 0x400):
+        # what EncReshape::preAnalyzerLMCS typically signals for SDR limited-range content (tests/golden/lmcs.npz): bins 1..14, a few code words moved to the middle
+        d = 6 if bd == 10 else 1
+        lmcs = dict(enable=1, chroma_adj=1, min_bin=1, max_bin=14, delta_cw=[0] + [d] * 7 + [d + (2 if bd == 10 else 0)] * 2 + [d] * 5 + [0])
+        sp["lmcs"] = lmcs
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"], lmcs=lmcs)
     frames = []
     for poc in pkg.frames_of_rank(args.frames * world, rank, world):      # weak scaling: args.frames per rank
-        planes = pkg.synth_frame(W, H, poc, bd, 1000 + poc, chroma_texture=args.chroma_texture)
+        planes = pkg.synth_frame(W, H, poc, bd, 1000 + poc, chroma_texture=args.chroma_texture, limited=lmcs is not None)
         org = [torch.from_numpy(p if bd == 8 else p.view(np.int16)).cuda() for p in planes]      # 16-bit containers: same bits, a dtype torch can hold
         rec = [torch.zeros_like(t) for t in org]
         frames.append((org, rec))
@@ -183,8 +206,8 @@ def main():
         value = total_ctus / elapsed
         avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
         achieved = ctus_per_step * b_ctu / avg_kernel_s / 1e9
-        workload = ("%dx%d %d-bit 4:2:0 All-Intra QP%d full RDO, tools 0x%x, chroma texture %.2f, %d frame(s)/step/GPU, %dx%d uniform tiles = %d CTU streams per frame"
-                    % (W, H, bd, args.qp, args.tools, args.chroma_texture, args.frames, tc, tr, tc * tr))
+        workload = ("%dx%d %d-bit 4:2:0 All-Intra QP%d full RDO, tools 0x%x%s, chroma texture %.2f, %d frame(s)/step/GPU, %dx%d uniform tiles = %d CTU streams per frame"
+                    % (W, H, bd, args.qp, args.tools, " (LMCS model on, limited-range luma)" if lmcs else "", args.chroma_texture, args.frames, tc, tr, tc * tr))
         traffic, traffic_src, traffic_split = pmc_traffic(workload)
         valu = pmc_valu(workload)
         out = {
@@ -198,13 +221,15 @@ def main():
                                 + (", dependent quantisation (DepQuant 1)" if args.tools & 0x40 else ", plain quant") + ", dual tree" + (", CU-result reuse (REUSE_CU_RESULTS)" if args.tools & 0x800 else "")
                                 + (", FAST_ALGORITHM partition classifier (shipped forest)" if args.tools & 0x1000 else "")
                                 + (", JointCbCr" if args.tools & 0x200 else "")
-                                + "; not built yet from the reference's cfg: ISP, transform skip / BDPCM (+ RDOQ-TS), LMCS"
+                                + (", ISP (ISPFast 1)" if args.tools & 4 else "") + (", transform skip + RDOQ-TS (TransformSkipFast 1, log2 max size 5)" if args.tools & 0x20 else "")
+                                + ((", LMCS: slice model on" if lmcs else ", LMCS: tool on, switched off for these pictures by the reference's own analysis (8-bit / full-range content, EL/EncReshape.cpp)") if args.tools & 0x400 else "")
+                                + "; off: " + ", ".join(n for n, b in (("ISP", 4), ("transform skip", 0x20), ("LMCS", 0x400)) if not args.tools & b) + ("-" if (args.tools & 0x424) == 0x424 else "") + " (BDPCM is off in the cfg)"
                                 + ("" if args.tools & 8 else ", LFNST off") + ("" if args.tools & 0x40 else ", DepQuant off") + ("" if args.tools & 0x200 else ", JointCbCr off")
-                                + "; leaf operators, syntax and reconstruction are pinned to the reference (CommonLib + decoder), the search decisions (EncCu / EncModeCtrl / IntraSearch restatement) are unpinned",
+                                + "; leaf operators, syntax and reconstruction are pinned to the reference (CommonLib + decoder + EncReshape), the search decisions (EncCu / EncModeCtrl / IntraSearch restatement) are pinned only through the decoder accepting and reconstructing the streams",
                        "tiling": ("one tile per CTU (every CTU an independent stream; the reference's cfg codes one tile per picture)" if (tc, tr) == (ctus_w, ctus_h)
                                   else "%dx%d uniform tiles" % (tc, tr)),
                        "ctus_per_step": ctus_per_step, "parallelism": "1 workgroup per CTU stream over a work queue of resident slots, frames sharded over ranks"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "limiter": "not HBM: VALU issue and the serial chains of one CTU stream (mode controller, trellis, CABAC estimator); see valu.issue_frac and DESIGN.md", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_split": traffic_split, "traffic_source": traffic_src, "kernel": "vvcx_compress_kernel_u8" if bd == 8 else "vvcx_compress_kernel_u16", "kernel_ms": 1e3 * avg_kernel_s,
                          "algorithmic_bytes_per_launch": ctus_per_step * b_ctu, "valu": valu},
             "work": {"satd_candidates_per_launch": int(counters[0]), "rd_tu_evaluations_per_launch": int(counters[1]),
@@ -213,6 +238,8 @@ def main():
         }
         # secondary kernel (not part of the timed step): in-loop deblocking of the pictures just coded, an HBM-bound pass
         try:
+            if lmcs:
+                enc.lmcs_inverse_reco()                 # the loop filters work in the original domain
             db_ms = min(enc.deblock_bound_frames() for _ in range(1))
             db_bytes = args.frames * (W * H * 3 // 2) * (2 if bd == 10 else 1) * 2          # every sample read once and written once
             out["deblock"] = {"kernel": "vvcx_deblock_kernel_u8" if bd == 8 else "vvcx_deblock_kernel_u16", "launches": 2, "ms": db_ms, "frames": args.frames,
@@ -226,7 +253,7 @@ def main():
             cw = min(ctus_w, 4)
             chh = max(1, n // cw)
             sw, sh = min(W, cw * 128), min(H, chh * 128)
-            planes = pkg.synth_frame(W, H, 0, bd, 1000, chroma_texture=args.chroma_texture)
+            planes = pkg.synth_frame(W, H, 0, bd, 1000, chroma_texture=args.chroma_texture, limited=lmcs is not None)
             crop = [planes[0][:sh, :sw], planes[1][:sh // 2, :sw // 2], planes[2][:sh // 2, :sw // 2]]
             t1 = time.perf_counter()
             O.compress_frame(crop, sw, sh, sp, tile_cols=(sw + 127) // 128, tile_rows=(sh + 127) // 128, tools=args.tools, forest=forest, bit_depth=bd)
@@ -234,8 +261,23 @@ def main():
             nct = ((sw + 127) // 128) * ((sh + 127) // 128)
             out["cpu_baseline"] = {"value": nct / dt, "unit": "CTU/s", "cores": 1, "kind": "port",
                                    "sample": "top-left %dx%d crop (%d CTUs, one tile per CTU) of the same frame, same QP/tools, oracle/ built -O2 -mavx2, %.1f s" % (sw, sh, nct, dt),
-                                   "reference_encoder": {"value": 0.44, "unit": "CTU/s", "cores": 1,
-                                                         "note": "the reference's own EncoderApp (full encoder_intra.cfg, AVX2) on 416x240 QP32, measured once in the authoring container (BASELINE.md); not re-run here: its build needs OpenCV"}}
+                                   "reference_encoder": {"value": 0.44, "unit": "CTU/s", "cores": 1, "measured_here": False,
+                                                         "note": "QUOTED, not measured in this run: the reference's own EncoderApp (full encoder_intra.cfg, AVX2) on 416x240 QP32, measured once in the authoring container (BASELINE.md); its build needs OpenCV, which this image lacks"}}
+            # the frame-parallel CPU figure beside the one-core one: N processes, each coding the same sample (frames of an All-Intra sequence
+            # are independent, so N encoder processes on N frames is how the reference scales on a host)
+            try:
+                import multiprocessing as mp
+                nproc = args.cpu_procs or max(1, min(16, len(os.sched_getaffinity(0))))
+                if nproc > 1:
+                    job = (crop, sw, sh, sp, dict(tile_cols=(sw + 127) // 128, tile_rows=(sh + 127) // 128, tools=args.tools, bit_depth=bd), args.classifier)
+                    t2 = time.perf_counter()
+                    with mp.get_context("spawn").Pool(nproc) as pool:      # spawn: the parent has initialised the GPU runtime
+                        pool.map(_cpu_job, [job] * nproc)
+                    dtn = time.perf_counter() - t2
+                    out["cpu_baseline"]["frame_parallel"] = {"value": nproc * nct / dtn, "unit": "CTU/s", "cores": nproc, "kind": "port",
+                                                             "sample": "%d processes x the same %d-CTU sample, %.1f s wall incl. process start" % (nproc, nct, dtn)}
+            except Exception as ex:
+                out["cpu_baseline"]["frame_parallel"] = {"error": str(ex)}
         if gather:
             out["gather"] = gather
         print(json.dumps(out))
