@@ -1327,6 +1327,17 @@ void orc_test_shape_constants(int w, int h, int *out)
 {
   out[0] = orc_mip_num_modes(w, h); out[1] = w >= 16 && h >= 16; out[2] = ORC_MODE_NUM_FAST_2D[(ilog2(w) - 2) * 6 + (ilog2(h) - 2)]; out[3] = w <= 32 && h <= 32;
 }
+/* test entry point (tests/golden decision_helpers2.npz): the CU / TU level predicates of the search as this file states them, for a luma CU of w x h with cu.ispMode = isp
+ * and the tool set of e: out[0] can_use_isp, out[1] / out[2] isp_split_dim horizontal / vertical (0 when ISP cannot be used), out[3] the 4-column prediction-region rule
+ * of a vertical split (CU::isMinWidthPredEnabledForBlkSize), out[4] transform skip allowed for the luma TU, out[5] explicit MTS allowed (both never for ISP CUs) */
+void orc_decision_helpers(const orc_enc *e, int w, int h, int isp, int *out)
+{
+  const int can = can_use_isp(e, w, h);
+  out[0] = can; out[1] = can ? isp_split_dim(w, h, 1) : 0; out[2] = can ? isp_split_dim(w, h, 0) : 0;
+  out[3] = (w == 8 && h > 4) || w == 4;
+  out[4] = !isp && ts_allowed(e, w, h);
+  out[5] = !isp && mts_allowed(e, w, h);
+}
 /* test entry point (tests/golden isp.npz): the block of one ISP sub-partition (tw x th) through the implicit transform, dependent quantisation with the given cbf
  * context (-1: inferred), dequantisation and the inverse */
 int orc_trquant_isp(const uint16_t *s0, const uint16_t *s1, const int16_t *resi, int tw, int th, int bit_depth, int qp, double lambda, int cbf_ctx, int16_t *level, int16_t *resi_out)

@@ -906,8 +906,29 @@ def _pictures(cases, tools, texture, oriented=0.0, screen=0.0, limited=False):
     return out
 
 
+def gen_decision_helpers2():
+    """CommonLib predicates the decision level calls per CU / TU (CL/UnitTools.cpp): CU::canUseISP, CU::getISPSplitDim, CU::isMinWidthPredEnabledForBlkSize, CU::getISPType,
+    CU::isPredRegDiffFromTB, TU::isTSAllowed, TU::isMTSAllowed (luma and chroma), CS::isDualITree, PU::getLMSymbolList, for every CU shape of the partitioner and
+    cu.ispMode 0 / 1 / 2, with the cfg's SPS / PPS switches."""
+    R.ref_decision_helpers.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    env = R.ref_env_create(192, 192, 8)
+    rows = []
+    for w in (4, 8, 16, 32, 64):
+        for h in (4, 8, 16, 32, 64):
+            for isp in (0, 1, 2):
+                R.ref_env_reset(env)
+                out = np.zeros(16, np.int32)
+                assert R.ref_decision_helpers(env, w, h, isp, P(out)) == 0
+                rows.append([w, h, isp] + [int(v) for v in out[:15]])
+    a = np.array(rows, np.int32)
+    np.savez_compressed(os.path.join(HERE, "decision_helpers2.npz"), rows=a)
+    print("decision helper rows", len(a), "can use ISP", int(a[a[:, 2] == 0][:, 3].sum()), "TS allowed", int(a[:, 9].sum()), "MTS allowed", int(a[:, 10].sum()), "dual tree", set(a[:, 11].tolist()), "LM list", a[0, 14:18].tolist())
+
+
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "decision_helpers2":
+        gen_decision_helpers2(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "trquant":
         gen_trquant(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream":

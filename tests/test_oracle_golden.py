@@ -579,3 +579,25 @@ def test_lmcs_tables_and_slice_data_payload_with_the_whole_reference_tool_set():
     gb = np.load(os.path.join(G, "bitstream_lmcs.npz"))
     assert int(gb["tools"][0]) == 0xf7f and int(gb["pic_lmcs"][0][0]) == 1
     _check_pictures(gb, importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd"))
+
+
+def test_cu_and_tu_level_predicates_against_commonlib():
+    """CU::canUseISP / getISPSplitDim / isMinWidthPredEnabledForBlkSize / getISPType / isPredRegDiffFromTB, TU::isTSAllowed / isMTSAllowed, CS::isDualITree and
+    PU::getLMSymbolList of the reference (tests/golden/make_golden.py decision_helpers2: every CU shape x cu.ispMode, the cfg's SPS / PPS switches) against the predicates
+    the oracle's search uses (orc_decision_helpers) and the constants it builds in (dual tree, no TS / MTS for chroma, the LM mode order of the chroma list)."""
+    L = O.lib()
+    L.orc_decision_helpers.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_decision_helpers.restype = None
+    cfg = O.default_cfg(128, 128, 8, tools=0xfff)
+    e = L.orc_create(C.byref(cfg)); assert e
+    rows = np.load(os.path.join(G, "decision_helpers2.npz"))["rows"]
+    assert len(rows) == 75
+    for r in rows:
+        w, h, isp = int(r[0]), int(r[1]), int(r[2])
+        can, sh, sv, minw, itype, prd, tsY, mtsY, dual, tsC, mtsC, nlm = [int(v) for v in r[3:15]]
+        out = np.zeros(8, np.int32)
+        L.orc_decision_helpers(e, w, h, isp, P(out))
+        assert [int(v) for v in out[:6]] == [can, sh, sv, minw, tsY, mtsY], (w, h, isp)
+        assert itype == (7, 8, 9)[isp] and prd == int(isp == 2 and minw)            # TU_NO_ISP / TU_1D_HORZ_SPLIT / TU_1D_VERT_SPLIT; the 4-column regions only for vertical splits
+        assert dual == 1 and tsC == 0 and mtsC == 0 and nlm == 3 and [int(v) for v in r[15:18]] == [67, 68, 69]
+    L.orc_destroy(e)
