@@ -39,7 +39,8 @@ _lib = None
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+    from conftest import locked_make
+    locked_make(os.path.join(ROOT, "oracle"), "oracle")
 
 
 def lib():

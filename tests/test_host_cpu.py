@@ -21,13 +21,15 @@ EMU_SO = os.path.join(ROOT, "tools", "hipemu", "build", "libvvcx_emu.so")
 @pytest.fixture(scope="module")
 def hip_lib():
     if not os.path.exists(HIP_SO):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, PKGNAME, "csrc"), "all"])
+        from conftest import locked_make
+        locked_make(os.path.join(ROOT, PKGNAME, "csrc"), "all")
     return C.CDLL(HIP_SO)
 
 
 @pytest.fixture(scope="module")
 def emu_so():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, PKGNAME, "csrc"), "emu"])
+    from conftest import locked_make
+    locked_make(os.path.join(ROOT, PKGNAME, "csrc"), "emu")
     return EMU_SO
 
 

@@ -16,7 +16,8 @@ G = os.path.join(ROOT, "tests", "golden")
 
 @pytest.fixture(scope="module")
 def emu_so():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, PKGNAME, "csrc"), "emu"])
+    from conftest import locked_make
+    locked_make(os.path.join(ROOT, PKGNAME, "csrc"), "emu")
     return os.path.join(ROOT, "tools", "hipemu", "build", "libvvcx_emu.so")
 
 

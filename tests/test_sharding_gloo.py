@@ -29,7 +29,8 @@ def test_single_rank_timed_steps_counts_steps():
 
 @pytest.mark.timeout(600)
 def test_two_rank_gloo_job_matches_oracle(tmp_path):
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, PKGNAME, "csrc"), "emu"])
+    from conftest import locked_make
+    locked_make(os.path.join(ROOT, PKGNAME, "csrc"), "emu")
     emu_so = os.path.join(ROOT, "tools", "hipemu", "build", "libvvcx_emu.so")
     out = tmp_path / "r0.json"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
