@@ -177,6 +177,8 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   uint16_t *trel = (uint16_t *) (wk + n_items * 80) + it0 * total;
   // template-sum rows of the item: one per state (written when the state enters a coefficient group) + a row of zeros, 16 sums each
   uint16_t *tmrows = (uint16_t *) (wk + n_items * (80 + 2 * total)) + it0 * 80;
+  const int node_room = node_stride ? node_stride : VXD_DQ_WAVE;      // bytes of path nodes one item may use
+  VX_CHECK((total >> lcg) * 64 <= node_room);
   if (valid) for (int e = k; e < 80; e += 4) tmrows[e] = 0;
   const int ci = ci0 + it0 * ci_step;
   const int cbf_ctx = cbf_ctx0 < 0 ? -1 : cbf_ctx0 + (int) ((cbf_mask >> it0) & 1u);
@@ -380,6 +382,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
     {                                                       // the four decisions of the position: 4 bits each
       int e = ((dsrc << 1) | dnz) << (4 * k);
       e = seg_sum<4>(e);
+      VX_CHECK(sp >= 0 && sp < total);
       if (k == 0 && act) trel[sp] = (uint16_t) e;
     }
     if (act) decCost = dc;
@@ -419,6 +422,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
           // template of the next position: its neighbours inside the group (m_scanId2NbInfoSbb) on top of the sums over those outside
           // the sums over the neighbours outside the group travel with the path as the row its group entry state wrote; a path that starts here has none (row 4: zeros)
           const int trow = fromPrev ? ((P.pk >> 27) & 7) : 4;
+          VX_CHECK(trow <= 4 && nin < 16);
           pk = (pk & ~(7 << 27)) | (trow << 27);
           const int t = (int) tmrows[trow * 16 + nin];
           int sumAbs = t >> 8, sumAbs1 = (t >> 3) & 31, sumNum = t & 7;
@@ -451,6 +455,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
         dq_set_b(lv, 0, (unsigned) imin(255, imax(dlev, 0)));
         // the path as it leaves this group: field 0 = this state and the group's significance, the older groups one field up
         const unsigned long long anc = (pAnc << 4) | (unsigned long long) (unsigned) (k + 1) | ((numSig != 0) ? 8ull : 0ull);
+        VX_CHECK(g >= 1 && (g * 4 + k) * 16 + 16 <= node_room);
         if (alive) { uint32_t *hl = (uint32_t *) (nd + (size_t) (g * 4 + k) * 16); hl[0] = lv.a; hl[1] = lv.b; hl[2] = lv.c; hl[3] = lv.d; }
         wave_sync();
         // the groups right of, below and diagonally below the next group: their distance in group-scan order picks the ancestor field
@@ -465,6 +470,9 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
         typedef unsigned dq_v16u __attribute__((vector_size(64)));
         dq_v16u nv = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // [4..8) right, [8..12) below, [12..16) diagonal
         if (alive) {
+          VX_CHECK(!(fR & 7u) || (gR >= g && gR - g < 16 && (gR * 4 + (int) (fR & 7u) - 1) * 16 + 16 <= node_room));
+          VX_CHECK(!(fB & 7u) || (gB >= g && gB - g < 16 && (gB * 4 + (int) (fB & 7u) - 1) * 16 + 16 <= node_room));
+          VX_CHECK(!(fD & 7u) || (gD >= g && gD - g < 16 && (gD * 4 + (int) (fD & 7u) - 1) * 16 + 16 <= node_room));
           if (fR & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gR * 4 + (int) (fR & 7u) - 1) * 16); nv[4] = p_[0]; nv[5] = p_[1]; nv[6] = p_[2]; nv[7] = p_[3]; }
           if (fB & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gB * 4 + (int) (fB & 7u) - 1) * 16); nv[8] = p_[0]; nv[9] = p_[1]; nv[10] = p_[2]; nv[11] = p_[3]; }
           if (fD & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gD * 4 + (int) (fD & 7u) - 1) * 16); nv[12] = p_[0]; nv[13] = p_[1]; nv[14] = p_[2]; nv[15] = p_[3]; }
@@ -511,6 +519,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
     int sp = 0, absSum = 0;
     if (first < 0) prev = -2;
     while (prev >= 0) {
+      VX_CHECK(sp >= 0 && sp <= first && prev < 4);
       const int e = (trel[sp] >> (4 * prev)) & 15, src = e >> 1;
       int lev = 0;
       if (e & 1) {

@@ -198,6 +198,9 @@ __shared__ Lds L;
 #ifndef VX_POISON_LDS
 #define VX_POISON_LDS(obj) ((void) 0)
 #endif
+#ifndef VX_CHECK
+#define VX_CHECK(c) ((void) 0)      // the CPU emulation build asserts the ranges of derived addresses here (tools/hipemu)
+#endif
 
 // ------------------------------------------------------------------------------------------------ utilities
 __device__ inline int ilog2i(int v) { return 31 - __clz(v); }
@@ -4684,7 +4687,7 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
     if (ctl_wave) { if (ctl_lane) {
       const long long t0 = STAMP();
       if (VVCX_STAMP) {
-        PROF(prev_op) += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first)
+        PROF(imin(prev_op, 13)) += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first; [13]: the ISP operations)
 #ifndef VVCX_STAMP_ROUNDS
         if (prev_op >= OP_LUMA_PREP && prev_op <= OP_CHROMA_RD) PROF(38 + imin(9, imax(0, ilog2i(L.nw * L.nh) - 4))) += (unsigned long long) (t0 - t_prev);   // by node size
 #endif

@@ -24,6 +24,8 @@
 #define __forceinline__ inline
 #define VX_REG_BARRIER(x) ((void) 0)      // device builds: an empty asm that keeps a value in a register (see csrc/vvcx_depquant_dev.h)
 // workgroup-shared storage is not cleared between workgroups on the GPU: poison it at kernel entry so that reads of never-written fields misbehave here too
+// range assertions on derived addresses (path-node offsets from ancestor fields, template rows from packed state bits, decision slots): checked in the emulation only
+#define VX_CHECK(c) do { if (!(c)) { fprintf(stderr, "hipemu: VX_CHECK failed: %s (%s:%d), thread %u\n", #c, __FILE__, __LINE__, hipemu::g_cur->tidx.x); abort(); } } while (0)
 #define VX_POISON_LDS(obj) do { if (hipemu::g_cur->tidx.x == 0) memset((void *) &(obj), 0xA5, sizeof(obj)); hipemu::syncthreads(); } while (0)
 
 struct uint2 { unsigned x, y; };
@@ -119,8 +121,43 @@ inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
 enum { hipDeviceAttributeMultiprocessorCount = 0 };
 inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 1; return 0; }
 inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *v, const void *, int, size_t) { *v = 1; return 0; }
-inline hipError_t hipMalloc(void **p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : 2; }
-inline hipError_t hipFree(void *p) { free(p); return 0; }
+// Device allocations are NOT zeroed on the GPU and a write beyond one is a fault that only sometimes shows (whether pages happen to be mapped behind it - round 2's
+// "layout-dependent" abort was such a write, 3 MB behind a per-stream scratch slot).  The emulation therefore fills every allocation with a poison pattern (a read
+// before the first write differs from the oracle instead of reading zeros) and puts red zones of HIPEMU_REDZONE bytes on both sides that hipFree checks.
+#ifndef HIPEMU_REDZONE
+#define HIPEMU_REDZONE (4u << 20)
+#endif
+namespace hipemu {
+struct AllocHdr { size_t n; uint64_t magic; };
+inline void check_zone(const unsigned char *z, size_t n, const char *what, const void *user)
+{
+  for (size_t i = 0; i < n; i++) if (z[i] != 0xCB) { fprintf(stderr, "hipemu: write %s allocation %p (offset %zu of the red zone)\n", what, user, i); abort(); }
+}
+}
+inline hipError_t hipMalloc(void **p, size_t n)
+{
+  if (!n) n = 1;
+  unsigned char *raw = (unsigned char *) malloc(sizeof(hipemu::AllocHdr) + 2 * (size_t) HIPEMU_REDZONE + n);
+  if (!raw) return 2;
+  hipemu::AllocHdr *h = (hipemu::AllocHdr *) raw; h->n = n; h->magic = 0x48495045ull;
+  memset(raw + sizeof(hipemu::AllocHdr), 0xCB, HIPEMU_REDZONE);
+  memset(raw + sizeof(hipemu::AllocHdr) + HIPEMU_REDZONE, 0xA5, n);
+  memset(raw + sizeof(hipemu::AllocHdr) + HIPEMU_REDZONE + n, 0xCB, HIPEMU_REDZONE);
+  *p = raw + sizeof(hipemu::AllocHdr) + HIPEMU_REDZONE;
+  return 0;
+}
+inline hipError_t hipFree(void *p)
+{
+  if (!p) return 0;
+  unsigned char *raw = (unsigned char *) p - HIPEMU_REDZONE - sizeof(hipemu::AllocHdr);
+  hipemu::AllocHdr *h = (hipemu::AllocHdr *) raw;
+  if (h->magic != 0x48495045ull) { fprintf(stderr, "hipemu: hipFree of a pointer hipMalloc did not return (%p)\n", p); abort(); }
+  hipemu::check_zone(raw + sizeof(hipemu::AllocHdr), HIPEMU_REDZONE, "in front of", p);
+  hipemu::check_zone((unsigned char *) p + h->n, HIPEMU_REDZONE, "behind", p);
+  h->magic = 0;
+  free(raw);
+  return 0;
+}
 inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return 0; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }

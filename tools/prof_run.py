@@ -15,8 +15,8 @@ b=[([t.data_ptr() for t in org],[t.data_ptr() for t in rec],[t.shape[1] for t in
 for it in range(2):
     enc.bind_frames(b); t=time.time(); r=enc.compress_bound_frames(); torch.cuda.synchronize(); dt=time.time()-t
 print("ctus",tc*tr,"time",dt,"kernel ms",enc.last_kernel_ms(),"CTU/s",tc*tr/dt)
-pr=enc.profile().astype(float); tot=pr[:11].sum()+pr[12]
-names=["ctrl","-","LUMA_PREP+A1","STAGE_A2","STAGE_B","CHROMA_RD","SAVE_INTRA","SAVE_PIC","RESTORE_PIC","CLEAR_UNITS","CTX_COPY","REUSE(+A satd w0)","FAST(+est_pass)","-","(prep only)","(A pred w0)"]
+pr=enc.profile().astype(float); tot=pr[:11].sum()+pr[12]+pr[13]
+names=["ctrl","-","LUMA_PREP+A1","STAGE_A2","STAGE_B","CHROMA_RD","SAVE_INTRA","SAVE_PIC","RESTORE_PIC","CLEAR_UNITS","CTX_COPY","REUSE(+A satd w0)","FAST(+est_pass)","ISP","(prep only)","(A pred w0)"]
 for i,n in enumerate(names): print("%-14s %6.2f%%  %.3e"%(n,100*pr[i]/tot,pr[i]))
 phn=["ENTER","FAST_DONE","RUN","A1_DONE","A2_DONE","B_DONE","INTRA_SAVED","CHILD","CHILD_RET","SPLIT_SAVED","ADVANCE","EXIT"]
 for i,n in enumerate(phn): print("  ph %-12s %.3e"%(n,pr[16+i]))
