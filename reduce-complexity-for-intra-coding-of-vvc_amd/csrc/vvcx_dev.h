@@ -127,7 +127,12 @@ struct VxRbItem { double cost; uint64_t dist, bits; int32_t cbf, sum0, test, wav
 #define VXD_OFF_POOL_REC   (VXD_OFF_POOL_NODES + VXD_POOL_NODE_BYTES)
 // JointCbCr: per wave joint residual | its reconstruction | levels | best pair of reconstructions | best levels (6 x 1024 int16).  In front of the CU cache: a handle
 // without VVCX_TOOL_CU_REUSE gets VXD_OFF_CACHE bytes per stream and everything the other tools touch has to lie below that
-#define VXD_OFF_JCCR    ((VXD_OFF_POOL_REC + 2 * VXD_POOL_ITEMS * (int) sizeof(VxRbItem) + 255) & ~255)
+// ISP: per wave the CU tiles of the candidate it evaluates (rec | lev: 2 x 4096 int16), the CU's prediction (4096) and the dense coefficient tile of a sub-partition (1024),
+// then the node's best ISP candidate so far (rec | lev)
+#define VXD_ISP_WAVE    14336                                                          // int16 elements per wave
+#define VXD_OFF_ISP     ((VXD_OFF_POOL_REC + 2 * VXD_POOL_ITEMS * (int) sizeof(VxRbItem) + 255) & ~255)
+#define VXD_OFF_ISP_BEST (VXD_OFF_ISP + VXD_NW * VXD_ISP_WAVE * 2)
+#define VXD_OFF_JCCR    ((VXD_OFF_ISP_BEST + 2 * 4096 * 2 + 255) & ~255)
 #define VXD_JCCR_WAVE   (6 * 1024 * 2)
 #define VXD_OFF_CACHE   ((VXD_OFF_JCCR + VXD_NW * VXD_JCCR_WAVE + 255) & ~255)
 #define VXD_OFF_CACHE_LEV (VXD_OFF_CACHE + VXD_CACHE_ENTRIES * (int) sizeof(VxCacheEnt))

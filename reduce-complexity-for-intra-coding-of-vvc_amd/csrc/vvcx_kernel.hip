@@ -58,7 +58,7 @@ enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_B
 enum { LM_CHROMA = 67, MDLM_L = 68, MDLM_T = 69 };
 enum { PLANAR = 0, DC = 1, HOR = 18, DIA = 34, VER = 50, VDIA = 66, DM_CHROMA = 70 };
 enum { OP_NONE, OP_DONE, OP_LUMA_PREP, OP_STAGE_A, OP_STAGE_B, OP_CHROMA_RD, OP_SAVE_INTRA, OP_SAVE_PIC, OP_RESTORE_PIC,
-       OP_CLEAR_UNITS, OP_CTX_COPY, OP_REUSE, OP_FAST, OP_ISP, OP_ISP_END };
+       OP_CLEAR_UNITS, OP_CTX_COPY, OP_REUSE, OP_FAST, OP_ISP, OP_ISP_END, OP_ISP_PARK };
 enum { PH_ENTER, PH_FAST_DONE, PH_RUN, PH_A1_DONE, PH_A2_DONE, PH_B_DONE, PH_INTRA_SAVED, PH_CHILD, PH_CHILD_RET, PH_SPLIT_SAVED, PH_ADVANCE, PH_EXIT, PH_EXIT2, PH_A3_DONE, PH_PASS, PH_NEXT_PASS, PH_ISP };
 enum { CTX_CUR = 0, CTX_START = 1, CTX_BEST = 2, CTX_WAVE = 3 };   // OP_CTX_COPY endpoints
 
@@ -88,6 +88,9 @@ struct Frame {                     // one recursion level: partitioner level + C
 };
 
 struct Cand { uint8_t mode, mrl; };
+// one ISP candidate as its wave leaves it: per sub-partition the distortion and the bits of xGetIntraFracBitsQT (0 where the early exit skipped the rate), the cbfs, how
+// many sub-partitions ran; the controller replays the reference's exit logic on it (with a limit that can only be lower than the one the wave used)
+struct IspRes { unsigned long long d[4], fb[4]; uint8_t cbf, nrun, mode, split, used, pad_[3]; };
 // BinEncoderBase state + OutputBitstream position (EL/BinEncoder.cpp:106-371); persists in HBM between launches of a stream
 struct Arith { uint32_t low, range, buffered_byte; int32_t bits_left, num_buffered; uint32_t bit_acc; int32_t bit_n; uint32_t n; };
 
@@ -104,6 +107,7 @@ struct CtlState {            // controller-private working set (touched by threa
   int lfNum, lfSize, mtsNum; Cand lfList[16], mtsList[16];
   // ISP (ISPTestedModesInfo and the candidate lists of the ISP tests, EL/IntraSearch.h:211-320): the tested (mode, split) pairs in test order with the sub-partitions
   // they completed and their cost, the candidate list both splits walk, the regular full-RD results (stage-B places) by cost, the SATD-stage list saved before the MRL candidates
+  int8_t ispHave, ispPark, ispReqMode, ispReqSplit;      // a candidate the reference's order asks for; the wave of the current batch whose result is the node's best so far
   int8_t testIsp, ispSlot, ispPrev, ispNT, ispBestMode, ispBestSplit, ispNOrig, ispNList, ispRegN, ispHadN, skipMts2, ispBreak, ispStop[2], ispNumTotal[2], ispCandIdx[2], ispNTested[2];
   uint8_t ispTMode[16], ispTInfo[16], ispList[28], ispReg[16], ispHad[24], ispWinMode, ispWinSplit, ispWinTucbf;      // ispTInfo: split << 4 | completed sub-partitions
   double ispTCost[16], ispBestRd, ispCurBest, noIspCost;
@@ -153,7 +157,8 @@ struct Lds {
   int pre_copy_d;                  // >= 0: before the posted operation, snapshot the estimator's contexts as the start contexts of level pre_copy_d
   int nx, ny, nw, nh, nd;          // node of the posted op (luma coordinates) and its level
   // candidates
-  Cand cand[64]; double cand_cost[64]; int n_cand;
+  // (after the SATD stage the cost slots hold what the waves of an ISP batch report, one record per wave)
+  Cand cand[64]; union { double cand_cost[64]; IspRes isp_res[NW]; }; int n_cand;
   // prediction parameters of each SATD-stage candidate (initPredIntraParams), packed, derived once per SATD operation; the full-RD operations keep the
   // dependent quantiser's rate tables of the node here (dq_build_tables)
   union { uint2 cand_ipa[64]; int dq_tab[DQ_TAB_INTS]; };
@@ -172,9 +177,9 @@ struct Lds {
   // the DST-VII pass prepared by the DCT-II pass (stage_b_rounds): number of prepared items (0: none), item of each candidate of the running pass, absSum per item
   int8_t spec_n; uint8_t rd_src[16]; int spec_abs[16];
   // ISP (intra sub-partitions): the candidate posted by the controller and what its evaluation returns; the best ISP candidate of the node so far
-  double isp_limit, isp_cost, isp_best;                  // bestCostSoFar handed to xIntraCodingLumaISP; cost of the candidate (MAX: early exit / not valid); cost the candidate has to beat
-  unsigned long long isp_dist, isp_bits;
-  uint8_t isp_mode, isp_split, isp_tucbf, isp_ntu, isp_valid, isp_first, isp_win, isp_evals;      // isp_win: the node's winner is the ISP candidate parked in slot ISP_BEST; isp_evals: TUs quantised (work counter)
+  double isp_limit;                                      // bestCostSoFar handed to xIntraCodingLumaISP for the candidates of the posted batch
+  unsigned long long isp_dist;                           // reuse path: distortion of the cached ISP CU
+  uint8_t isp_nb, isp_park, isp_split, isp_tucbf, isp_win, isp_pad2_[3];      // candidates of the posted batch; wave whose tiles OP_ISP_PARK keeps; cached CU's ispMode / cbfs (reuse); isp_win: the node's winner is the parked ISP candidate
   int lmcs_cadj, lmcs_tab;         // LMCS: chroma residual scale of the chroma node being coded (0: none), its table of quantiser constants (1 + bin; 0: unscaled)
   int dc_val[4];
   int cur_tile, frame, ctu_x, ctu_y, tree_ch;
@@ -2342,17 +2347,17 @@ __device__ inline int isp_split_dim(int w, int h, int hor)
   const int factor = non < 16 ? 16 >> ilog2i(non) : 1;
   return imax(split >> 2, factor);
 }
-// HBM buffers of the ISP evaluation (the node's stage-B winner stays parked in the slots of its wave): CU tiles rec | lev with stride w
-#define ISP_WAVE(ww_) (((ww_) + 1) & (NW - 1))
-__device__ inline int16_t *isp_buf(uint8_t *scratch, int wave, int which) { return (int16_t *) (scratch + VXD_OFF_SLOTS) + (wave * 2 + which) * VXD_SLOT_ELEMS; }
+// HBM tiles of the ISP evaluation: per wave rec | lev (CU tiles, stride w), the CU's prediction, the dense coefficient tile of the sub-partition in work
+__device__ inline int16_t *isp_tile(uint8_t *scratch, int wave) { return (int16_t *) (scratch + VXD_OFF_ISP) + wave * VXD_ISP_WAVE; }
 // IntraSearch::xIntraCodingLumaISP (EL/IntraSearch.cpp:3171-3280) of one (mode, split) candidate by ONE wave: the sub-partitions are predicted from the reconstruction
 // of the ones before (initIntraPatternChTypeISP, CL/IntraPrediction.cpp:1092-1199; prediction regions of at least four columns, JVET_O0106), each through
 // wave_code_block_isp against the live contexts L.ctxs[ci] (copied from the node's start contexts here), the rate of xGetIntraFracBitsQT per sub-partition and the
-// early exits against `limit` (3206-3245).  given != nullptr: the levels (CU tile, stride w) and cbfs are taken as coded (DecCu::xIntraRecQT of an ISP CU for
-// xReuseCachedResult).  The node's base references are L.refs[0]; region references go to L.refs[1].  Results -> L.isp_*; rec / lev: CU tiles (stride w, HBM).
-// aux: 4096 + 1024 int16 of HBM for the CU's prediction and the dense coefficient tile of a sub-partition (the candidate pools keep what the first pass prepared for the
-// DST-VII pass); the filtered reference set L.refs[1], which later passes of the node read again, is saved behind them and restored
-__device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir, int isp, double limit, const int16_t *given, int given_tucbf, int16_t *rec, int16_t *lev, int ci, int lane, int16_t *aux)
+// early exits against `limit` (3206-3245).  What the wave reports (out) is the raw material of that logic per sub-partition: the controller replays it (ctrl_isp_replay), so
+// that candidates can be evaluated ahead of the reference's order under a limit that is at least the one they will be judged with.
+// given != nullptr (out == nullptr): the levels (CU tile, stride w) and cbfs are taken as coded (DecCu::xIntraRecQT of an ISP CU for xReuseCachedResult); distortion ->
+// L.isp_dist.  The node's base references are L.refs[0]; the region's go to the calling wave's LDS candidate slot (unused by this path).  tile: isp_tile() of a wave.
+__device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir, int isp, double limit, const int16_t *given, int given_tucbf, int16_t *rec, int16_t *lev, int ci, int lane,
+                                         int16_t *tile, IspRes *out, int refs_wave)
 {
   const VxParams &p = L.par;
   w = uni(w); h = uni(h); dir = uni(dir); isp = uni(isp); given_tucbf = uni(given_tucbf); ci = uni(ci);
@@ -2361,14 +2366,13 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
   const int predRegDiff = !hor && ((w == 8 && h > 4) || w == 4);         // CU::isPredRegDiffFromTB
   const int wave = uni(VTX >> 6), x0 = uni(L.nx), y0 = uni(L.ny);
   const int16_t *org = org_tile(scratch, w * h);
-  int16_t *pred = aux, *cf = aux + 4096, *keep = aux + 5120;
+  int16_t *pred = tile + 8192, *cf = tile + 12288;
   int32_t *tmp = wave_tmp(scratch, imin(32, tw) * th, wave);
   const int16_t *bt = L.refs[0][0], *bl = L.refs[0][1];
-  int16_t *rt = L.refs[1][0], *rl = L.refs[1][1];
-  for (int e = lane; e < 2 * 140; e += 64) keep[e] = rt[e];            // refs[1][0] | refs[1][1] are contiguous
+  int16_t *rt = L.wm[uni(refs_wave)].slot, *rl = L.wm[uni(refs_wave)].slot + 160;      // region references: an LDS candidate slot this path does not use otherwise
   { uint32_t *d = (uint32_t *) &L.ctxs[ci]; const uint32_t *s_ = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s_[e]; }
   wave_sync();
-  double cost = 0; int early = 0, tucbf = 0, ntu = 0, evals = 0, noCbf = 0;
+  double cost = 0; int tucbf = 0, nrun = 0;
   unsigned long long dist = 0, bits = 0;
   Cab cb; cb.ci = ci; cb.bits = 0;
   for (int k = 0; k < n; k++) {
@@ -2405,13 +2409,13 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
     const int off = oy * w + ox;
     wave_code_block_isp(org + off, rec + off, lev + off, w, tmp, cf, scratch, tw, th, bd, p.qp_tr, lane, d, cbf, given ? (given_tucbf >> k) & 1 : -1, ci, cbfCtx);
     cbf = uni(cbf);
-    if (!given) { evals++; if (k == n - 1 && !tucbf && !cbf) { ntu = n; noCbf = 1; break; } }      // 2990-2996: ISP needs one coded sub-partition
+    nrun = k + 1;
+    if (given) { if (cbf) tucbf |= 1 << k; dist += d; continue; }
+    if (lane == 0) { out->d[k] = d; out->fb[k] = 0; }
+    if (k == n - 1 && !tucbf && !cbf) break;                  // 2990-2996: ISP needs one coded sub-partition
     if (cbf) tucbf |= 1 << k;
-    ntu = k + 1;
-    if (given) { dist += d; continue; }
     unsigned long long fb = 0;
-    if (rd_cost(p, bits, dist + d) > limit) early = 1;       // 3206-3210: the rate is not even computed
-    else {
+    if (!(rd_cost(p, bits, dist + d) > limit)) {              // 3206-3210: beyond the limit the rate is not even computed
       cb.bits = 0;                                            // xGetIntraFracBitsQT: the CU header with the first sub-partition, cbf unless inferred, coefficients
       if (lane == 0) {
         if (k == 0) enc_intra_luma_pred_mode(cb, L.ny, dir, 0, isp);
@@ -2419,43 +2423,38 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
       }
       if (cbf) residual_coding_wave<false>(cb, 0, cf, tw, th, 0, lane);
       { unsigned lo = (unsigned) cb.bits, hi = (unsigned) (cb.bits >> 32); lo = (unsigned) __builtin_amdgcn_readlane((int) lo, 0); hi = (unsigned) __builtin_amdgcn_readlane((int) hi, 0); fb = ((unsigned long long) hi << 32) | lo; }
+      if (lane == 0) out->fb[k] = fb;
     }
     cost += rd_cost(p, fb, d); dist += d; bits += fb;
     if (k + 1 < n) {
-      if (cost > limit) { early = 1; break; }
+      if (cost > limit) break;
       const double thr = n == 2 ? 0.95 : k + 1 == 1 ? 0.83 : 0.91;
-      if (cost > limit * thr) { early = 1; break; }
+      if (cost > limit * thr) break;
     }
   }
-  if (lane == 0) {
-    int valid = 0, first = tucbf & 1; double rc = MAX_DOUBLE;
-    if (given) valid = 1;
-    else if (!noCbf && !early) {
-      rc = rd_cost(p, bits, dist);
-      if (rc < limit) { valid = 1; first = tucbf != 0; }      // 3257-3268: cbf at depth 0 of every TU = any sub-partition coded
-      else rc = MAX_DOUBLE;
-    }
-    L.isp_cost = rc; L.isp_dist = dist; L.isp_bits = bits; L.isp_tucbf = (uint8_t) tucbf; L.isp_ntu = (uint8_t) ntu; L.isp_valid = (uint8_t) valid; L.isp_first = (uint8_t) first; L.isp_evals = (uint8_t) evals;
-  }
-  wave_sync();
-  for (int e = lane; e < 2 * 140; e += 64) rt[e] = keep[e];
+  if (lane == 0) { if (given) L.isp_dist = dist; else { out->cbf = (uint8_t) tucbf; out->nrun = (uint8_t) nrun; } }
   wave_sync();
 }
-// OP_ISP: one reserved place of the RD list (EL/IntraSearch.cpp:1181-1192): the candidate L.isp_mode / L.isp_split the controller took from xGetNextISPMode, by wave 0.
-// A candidate that is valid, has a coded first sub-partition and beats L.isp_best is parked (reconstruction, levels, end contexts) as the node's ISP winner so far.
+// OP_ISP: up to NW candidates of the node's ISP test at once, one per wave: L.isp_res[w].mode / split name wave w's, all under the limit L.isp_limit
 __device__ __noinline__ void op_isp(uint8_t *scratch)
 {
   const int wave = uni(VTX >> 6), lane = VTX & 63;
-  const int w = uni(L.nw), h = uni(L.nh), P = w * h;
-  if (wave == 0) {
-    const int iw = ISP_WAVE(uni(L.win_wave));
-    int16_t *work = isp_buf(scratch, iw, 0), *best = isp_buf(scratch, iw, 1);
-    isp_code_cu(scratch, w, h, uni((int) L.isp_mode), uni((int) L.isp_split), uni_d(L.isp_limit), nullptr, 0, work, work + 4096, CI_W(1), lane, isp_buf(scratch, (iw + 1) & (NW - 1), 0));
-    if (uni((int) L.isp_valid) && uni((int) L.isp_first) && uni_d(L.isp_cost) < uni_d(L.isp_best)) {
-      for (int e = lane; e < P; e += 64) { best[e] = work[e]; best[4096 + e] = work[4096 + e]; }
-      uint32_t *d = (uint32_t *) ctx_ptr(scratch, CTX_START, MAXD + 1, 0); const uint32_t *s_ = (const uint32_t *) &L.ctxs[CI_W(1)]; for (int e = lane; e < NCTX; e += 64) d[e] = s_[e];
-    }
+  const int w = uni(L.nw), h = uni(L.nh);
+  if (wave < uni((int) L.isp_nb)) {
+    int16_t *t = isp_tile(scratch, wave);
+    isp_code_cu(scratch, w, h, uni((int) L.isp_res[wave].mode), uni((int) L.isp_res[wave].split), uni_d(L.isp_limit), nullptr, 0, t, t + 4096, CI_W(wave), lane, t, &L.isp_res[wave], wave);
   }
+  __threadfence_block();
+  __syncthreads();
+}
+// OP_ISP_PARK: the candidate wave L.isp_park evaluated became the node's best: its reconstruction, levels and end contexts are kept (1308-1326)
+__device__ __noinline__ void op_isp_park(uint8_t *scratch)
+{
+  const int src = uni((int) L.isp_park), P = uni(L.nw) * uni(L.nh);
+  const int16_t *t = isp_tile(scratch, src);
+  int16_t *best = (int16_t *) (scratch + VXD_OFF_ISP_BEST);
+  for (int e = VTX; e < P; e += NT) { best[e] = t[e]; best[4096 + e] = t[4096 + e]; }
+  ctx_copy_all(ctx_ptr(scratch, CTX_BEST, MAXD + 1, 0), &L.ctxs[CI_W(src)]);
   __threadfence_block();
   __syncthreads();
 }
@@ -3043,6 +3042,11 @@ __device__ __noinline__ void op_stage_b(const VxParams &p_, uint8_t *scratch)
     }
     __syncthreads();
   }
+  if (uni((int) L.isp_wait)) {                              // the ISP candidates that follow work in every wave's context set: the regular winner's end contexts wait in HBM
+    ctx_copy_all(ctx_ptr(scratch, CTX_BEST, MAXD + 0, 0), &L.ctxs[CI_W(0)]);
+    __threadfence_block();
+    __syncthreads();
+  }
 }
 
 template <bool SMALL> __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int lane, int w, int h);
@@ -3472,9 +3476,12 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
     // DecCu::xIntraRecQT of an ISP CU: every sub-partition predicted from the reconstruction of the one before, then the CU's bits from the node's start contexts
     const int isp = uni((int) L.isp_split), tucbf = uni((int) L.isp_tucbf), hor = isp == 1;
     const int psz = isp_split_dim(w, h, hor), tw = hor ? w : psz, th = hor ? psz : h, nsub = hor ? h / psz : w / psz, ltw = ilog2i(tw);
-    isp_code_cu(scratch, w, h, mode, isp, 0.0, levb, tucbf, recb, levb, CI_W(1), lane, isp_buf(scratch, 2, 0));
+    { int16_t *t = isp_tile(scratch, 0);                 // reconstructed in the HBM tile (the region references use the idle wave 1's LDS slot), then into the result slot
+      isp_code_cu(scratch, w, h, mode, isp, 0.0, levb, tucbf, t, t + 4096, CI_W(1), lane, t, nullptr, 1);
+      for (int e = lane; e < P; e += 64) recb[e] = t[e];
+      wave_sync(); }
     dist = L.isp_dist;
-    int16_t *cf = isp_buf(scratch, 2, 0) + 4096;
+    int16_t *cf = isp_tile(scratch, 0) + 12288;
     if (lane == 0) enc_intra_luma_pred_mode(cb, L.ny, mode, 0, isp);
     for (int k = 0, sofar = 0; k < nsub; k++) {
       const int ox = hor ? 0 : k * tw, oy = hor ? k * th : 0, c = (tucbf >> k) & 1;
@@ -3786,8 +3793,9 @@ __device__ __noinline__ void op_save_intra(const VxParams &p_, uint8_t *scratch,
   const int W = L.nw >> sh, H = L.nh >> sh, P = W * H;
   uint8_t *lvl = scratch + VXD_OFF_STORE + (size_t) d * VXD_STORE_LEVEL;
   const int wave = L.win_wave, which = L.op_a;
-  const int16_t *rec = slot_rec(scratch, ch ? 2 * P : P, wave, which);
-  const int16_t *lev = slot_lev(scratch, ch ? 2 * P : P, wave, which);
+  // (wave NW: the node's winner is the parked ISP candidate)
+  const int16_t *rec = wave == NW ? (const int16_t *) (scratch + VXD_OFF_ISP_BEST) : slot_rec(scratch, ch ? 2 * P : P, wave, which);
+  const int16_t *lev = wave == NW ? rec + 4096 : slot_lev(scratch, ch ? 2 * P : P, wave, which);
   int16_t *srec = (int16_t *) lvl, *slev = (int16_t *) (lvl + VXD_STORE_REC);
   const int n = ch ? 2 * P : P;
   for (int i = VTX; i < n; i += NT) { srec[i] = rec[i]; slev[i] = lev[i]; }
@@ -4109,20 +4117,76 @@ __device__ __noinline__ void ctrl_isp_begin(const Frame &f)
   L.isp_win = 0;
   ctrl_isp_sort(S.ispCurBest, bestReg);
 }
-// the result of the candidate just evaluated (1241-1245 ISPTestedModesInfo::setModeResults, 1270-1288, 1308-1326)
-__device__ __noinline__ void ctrl_isp_result(const Frame &f)
+// The exit logic of xIntraCodingLumaISP (3206-3268) on what a wave reported, under the limit the candidate is judged with (never above the one its wave stopped with, so
+// every sub-partition the logic looks at has been run, and every rate it adds has been computed): sub-partitions completed, cost (MAX: early exit / not below the limit),
+// cbfs, TUs quantised, and the candidate's result (setModeResults 1241-1245, 1270-1288, 1308-1326) into the ISP state
+// Returns 0 when the logic asks for a sub-partition the wave did not run (possible only under a lowered limit and a rounding-level tie: a skipped rate makes the running
+// cost smaller than the one the wave stopped on): the candidate is then evaluated again on its own under the current limit.
+__device__ __noinline__ int ctrl_isp_result(const Frame &f, int bw)
 {
   CtlState &S = L.S;
-  const int mode = L.isp_mode, split = L.isp_split, st = split - 1, ntu = L.isp_ntu, maxParts = S.ispNumTotal[st];
-  const double rc = L.isp_first ? L.isp_cost : MAX_DOUBLE;
-  { const int psz = isp_split_dim(f.w, f.h, split == 1), tpix = split == 1 ? f.w * psz : psz * f.h; L.cnt[1] += (unsigned long long) L.isp_evals; L.cnt[2] += (unsigned long long) (L.isp_evals * tpix); }
+  const VxParams &p = L.par;
+  const IspRes &R = L.isp_res[bw];
+  const int mode = R.mode, split = R.split, st = split - 1, maxParts = S.ispNumTotal[st], n = maxParts;
+  const double limit = S.ispCurBest;
+  double cost = 0; int early = 0, tucbf = 0, ntu = 0, evals = 0, noCbf = 0;
+  unsigned long long dist = 0, bits = 0;
+  for (int k = 0; k < n; k++) {
+    if (k >= R.nrun) return 0;
+    const int cbf = (R.cbf >> k) & 1; const unsigned long long d = R.d[k];
+    evals++;
+    if (k == n - 1 && !tucbf && !(cbf)) { ntu = n; noCbf = 1; break; }      // 2990-2996
+    if (cbf) tucbf |= 1 << k;
+    ntu = k + 1;
+    unsigned long long fb = 0;
+    if (rd_cost(p, bits, dist + d) > limit) early = 1; else fb = R.fb[k];
+    cost += rd_cost(p, fb, d); dist += d; bits += fb;
+    if (k + 1 < n) {
+      if (cost > limit) { early = 1; break; }
+      const double thr = n == 2 ? 0.95 : k + 1 == 1 ? 0.83 : 0.91;
+      if (cost > limit * thr) { early = 1; break; }
+    }
+  }
+  int valid = 0, first = tucbf & 1; double rcost = MAX_DOUBLE;
+  if (!noCbf && !early) {
+    rcost = rd_cost(p, bits, dist);
+    if (rcost < limit) { valid = 1; first = tucbf != 0; }      // 3257-3268: cbf at depth 0 of every TU = any sub-partition coded
+    else rcost = MAX_DOUBLE;
+  }
+  const double rc = first ? rcost : MAX_DOUBLE;
+  { const int psz = isp_split_dim(f.w, f.h, split == 1), tpix = split == 1 ? f.w * psz : psz * f.h; L.cnt[1] += (unsigned long long) evals; L.cnt[2] += (unsigned long long) (evals * tpix); }
   S.ispTMode[S.ispNT] = (uint8_t) mode; S.ispTInfo[S.ispNT] = (uint8_t) ((split << 4) | ntu); S.ispTCost[S.ispNT] = ntu == maxParts ? rc : MAX_DOUBLE; S.ispNT++; S.ispNTested[st]++;
   if (ntu == maxParts && rc < S.ispBestRd) { S.ispBestMode = (int8_t) mode; S.ispBestSplit = (int8_t) split; }
-  if (L.isp_valid && L.isp_first && L.isp_cost < S.ispBestRd) {
-    S.ispBestRd = L.isp_cost; L.isp_win = 1;
-    S.ispWinMode = (uint8_t) mode; S.ispWinSplit = (uint8_t) split; S.ispWinTucbf = L.isp_tucbf; S.ispWinDist = L.isp_dist; S.ispWinBits = L.isp_bits;
-    if (L.isp_cost < S.ispCurBest) S.ispCurBest = L.isp_cost;
+  if (valid && first && rcost < S.ispBestRd) {
+    S.ispBestRd = rcost; L.isp_win = 1; S.ispPark = (int8_t) bw;
+    S.ispWinMode = (uint8_t) mode; S.ispWinSplit = (uint8_t) split; S.ispWinTucbf = (uint8_t) tucbf; S.ispWinDist = dist; S.ispWinBits = bits;
+    if (rcost < S.ispCurBest) S.ispCurBest = rcost;
   }
+  return 1;
+}
+// The next batch: the candidate the reference's order asks for and, on the other waves, the ones it is likely to ask for next (the list walked by both splits in turn,
+// original entries only) - a wrong guess costs idle waves some work, never a result
+__device__ __noinline__ void ctrl_isp_batch(int reqMode, int reqSplit)
+{
+  CtlState &S = L.S;
+  int n = 0;
+  L.isp_res[n].mode = (uint8_t) reqMode; L.isp_res[n].split = (uint8_t) reqSplit; L.isp_res[n].used = 0; n++;
+  int ci[2] = { S.ispCandIdx[0], S.ispCandIdx[1] }, prev = reqSplit, idle = 0;
+  while (n < NW && idle < 2) {
+    int nxt;
+    if (!S.ispStop[0] && !S.ispStop[1]) nxt = prev == 1 ? 2 : 1;
+    else if (!S.ispStop[0]) nxt = 1;
+    else if (!S.ispStop[1]) nxt = 2;
+    else break;
+    prev = nxt;
+    const int st = nxt - 1;
+    if (ci[st] >= S.ispNOrig) { idle++; continue; }
+    idle = 0;
+    const int cand = S.ispList[ci[st]++];
+    if (isp_tested_at(nxt, cand) >= 0) continue;
+    L.isp_res[n].mode = (uint8_t) cand; L.isp_res[n].split = (uint8_t) nxt; L.isp_res[n].used = 0; n++;
+  }
+  L.isp_nb = (uint8_t) n;
 }
 // thread 0: the full-RD list of a luma pass is in S.rdList[0, numRd): MPM append (777-802) unless the list comes from the DCT-II pass (an MTS pass), the
 // MIP re-ordering (1097-1122) or removal of MIP candidates (1123-1141), then stage B
@@ -4202,7 +4266,7 @@ __device__ __noinline__ int ctrl_b_done(const VxParams &p_, const VxFrameDev &fd
       if (ispWin && L.n_rd) {                           // the ISP candidate parked by OP_ISP beat the regular winner (1308-1326)
         cu.dir = L.S.ispWinMode; cu.mrl = 0; cu.cbf = (uint8_t) (1 | (L.S.ispWinTucbf << 4)); cu.mts = (uint8_t) (L.S.ispWinSplit << 6);
         t.dist = L.S.ispWinDist; L.cu_bits = L.S.ispWinBits;      // cu_pred_data + cu_residual of an ISP CU = what the sub-partitions were priced with (no residual_lfnst_mode, EL/CABACWriter.cpp:3994)
-        L.win_wave = ISP_WAVE(ww); L.op_a = 1;
+        L.win_wave = NW; L.op_a = 0;                    // the parked ISP tiles (op_save_intra)
       }
       // cu_pred_data + cu_residual bits (EL/EncCu.cpp:2593-2619) and the CU's end contexts are left in cu_bits / wctx[0]
       // by the operation (luma: identical to the stage-B syntax from the same start contexts)
@@ -4410,17 +4474,31 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         post(OP_CHROMA_RD); return;
       }
     }
-    case PH_ISP: {                                      // the reserved places of the RD list: each asks xGetNextISPMode for the next ISP candidate (1181-1192)
-      if (S.ispSlot < 0) { ctrl_isp_begin(f); S.ispSlot = 0; } else ctrl_isp_result(f);
+    case PH_ISP: {                                      // the reserved places of the RD list: each asks xGetNextISPMode for the next ISP candidate (1181-1192); the candidates are
+      // evaluated in batches of up to NW, one per wave, ahead of that order (ctrl_isp_batch), and judged in it (ctrl_isp_result)
+      if (S.ispSlot < 0) { ctrl_isp_begin(f); S.ispSlot = 0; S.ispHave = 0; S.ispPark = -1; L.isp_nb = 0; }
       set_node(f, d);
-      while (S.ispSlot < 16) {
+      for (;;) {
+        if (S.ispHave) {
+          int bw = -1;
+          for (int i = 0; i < L.isp_nb; i++) if (!L.isp_res[i].used && L.isp_res[i].mode == (uint8_t) S.ispReqMode && L.isp_res[i].split == (uint8_t) S.ispReqSplit) bw = i;
+          if (bw < 0) {                                 // not evaluated yet: the tiles of a new best are kept first, then the next batch
+            if (S.ispPark >= 0) { L.isp_park = (uint8_t) S.ispPark; S.ispPark = -1; post(OP_ISP_PARK); return; }
+            ctrl_isp_batch(S.ispReqMode, S.ispReqSplit);
+            L.isp_limit = S.ispCurBest;
+            post(OP_ISP); return;
+          }
+          L.isp_res[bw].used = 1;
+          if (!ctrl_isp_result(f, bw)) continue;          // (evaluated again: the entry is used up, the request stays)
+          S.ispHave = 0;
+        }
+        if (S.ispSlot >= 16) break;
         int mode = 0, split = 0;
         S.ispSlot++;
         if (!ctrl_isp_next(f.w, f.h, mode, split)) { S.ispPrev = 3; continue; }
-        S.ispPrev = (int8_t) split;
-        L.isp_mode = (uint8_t) mode; L.isp_split = (uint8_t) split; L.isp_limit = S.ispCurBest; L.isp_best = S.ispBestRd;
-        post(OP_ISP); return;
+        S.ispPrev = (int8_t) split; S.ispReqMode = (int8_t) mode; S.ispReqSplit = (int8_t) split; S.ispHave = 1;
       }
+      if (S.ispPark >= 0) { L.isp_park = (uint8_t) S.ispPark; S.ispPark = -1; post(OP_ISP_PARK); return; }
       L.isp_wait = 0; f.phase = PH_B_DONE; post(OP_ISP_END); return;      // the node's intra decision with the ISP winner, if any
     }
     case PH_NEXT_PASS: {
@@ -4710,9 +4788,10 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
       case OP_STAGE_A: op_stage_a(p, scratch); break;
       case OP_STAGE_B: op_stage_b(p, scratch); if (!uni((int) L.isp_wait)) after_intra_op(p, fd, scratch); break;
       case OP_ISP: op_isp(scratch); break;
-      case OP_ISP_END:                                    // every place used: the ISP winner's end contexts take the place of the regular winner's, then the node's intra decision
+      case OP_ISP_PARK: op_isp_park(scratch); break;
+      case OP_ISP_END:                                    // every place used: the end contexts of the node's winner (regular or ISP) come back, then the node's intra decision
         // (an operation kind of its own: the decision below rewrites the operation's parameters while other waves may still be dispatching)
-        if (uni((int) L.isp_win)) ctx_copy_all(&L.ctxs[CI_W(0)], ctx_ptr(scratch, CTX_START, MAXD + 1, 0));
+        ctx_copy_all(&L.ctxs[CI_W(0)], ctx_ptr(scratch, CTX_BEST, MAXD + (uni((int) L.isp_win) ? 1 : 0), 0));
         __threadfence_block(); __syncthreads();
         after_intra_op(p, fd, scratch);
         break;
