@@ -34,6 +34,8 @@ extern "C" __global__ void vvcx_leaf_ts_kernel(VxParams p, const uint16_t *ctx, 
 extern "C" __global__ void vvcx_lmcs_map_kernel_u8(const uint8_t *src, uint8_t *dst, int w, int h, int stride, const int16_t *lut);
 extern "C" __global__ void vvcx_lmcs_map_kernel_u16(const uint16_t *src, uint16_t *dst, int w, int h, int stride, const int16_t *lut);
 extern "C" __global__ void vvcx_leaf_isp_kernel(VxParams p, const uint16_t *ctx, const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int qp, int cbf_ctx, unsigned long long *out);
+extern "C" __global__ void vvcx_ctu_activity_kernel_u8(const VxFrameDev *frames, int pic_w, int pic_h, int ctus_w, unsigned *out);
+extern "C" __global__ void vvcx_ctu_activity_kernel_u16(const VxFrameDev *frames, int pic_w, int pic_h, int ctus_w, unsigned *out);
 extern "C" __global__ void vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec, int16_t *lev, int32_t *tmp, int w, int h, int bd, int qp, unsigned long long *out);
 
 static thread_local char g_err[512];
@@ -72,6 +74,7 @@ struct vvcx_handle {
   // LMCS of the current slice (vvcx_set_slice): LUTs and tables, their device copy (fwd | inv), the forward-mapped original luma of the bound pictures
   bool lmcs_on, lmcs_inverted; int16_t lmcs_fwd[1024], lmcs_inv[1024]; int32_t lmcs_pivot[17], lmcs_cadj[16];
   int16_t *lmcs_lut_d; void *lmcs_org_d; size_t lmcs_org_cap;
+  std::vector<uint32_t> activity;               // per (frame, CTU) of the bound pictures: orders the stream queue of a launch, longest first
   hipEvent_t ev0, ev1; float last_ms, last_deblock_ms;
   // a submitted, not yet collected launch (vvcx_submit_ctus .. vvcx_wait_ctus): staging the async copies read from / write to stays alive here
   bool pending; hipStream_t pend_stream; int pend_n; VxCtuRes *pend_res; int pend_cap;
@@ -389,6 +392,19 @@ extern "C" int vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n)
   std::vector<uint16_t> ctx((size_t) n * h->ntiles * 2 * VXD_NUM_CTX);
   for (size_t s = 0; s < (size_t) n * h->ntiles; s++) ctx_init_islice(h->sl.qp, &ctx[s * 2 * VXD_NUM_CTX], &ctx[s * 2 * VXD_NUM_CTX + VXD_NUM_CTX]);
   HIPCHK(hipMemcpy(h->stream_ctx_d, ctx.data(), ctx.size() * 2, hipMemcpyHostToDevice));
+  {
+    // activity per CTU (read back here: binding is synchronous anyway); a failure only costs the ordering
+    const size_t nact = (size_t) n * h->ctus_w * h->ctus_h;
+    h->activity.assign(nact, 0);
+    unsigned *dact = nullptr;
+    if (hipMalloc((void **) &dact, nact * 4) == hipSuccess) {
+      const dim3 grid((unsigned) (h->ctus_w * h->ctus_h), (unsigned) n);
+      if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_ctu_activity_kernel_u8, grid, dim3(VXD_NT), 0, 0, h->frames_d, h->cfg.pic_w, h->cfg.pic_h, h->ctus_w, dact);
+      else hipLaunchKernelGGL(vvcx_ctu_activity_kernel_u16, grid, dim3(VXD_NT), 0, 0, h->frames_d, h->cfg.pic_w, h->cfg.pic_h, h->ctus_w, dact);
+      if (hipGetLastError() != hipSuccess || hipMemcpy(h->activity.data(), dact, nact * 4, hipMemcpyDeviceToHost) != hipSuccess) h->activity.assign(nact, 0);
+      (void) hipFree(dact);
+    }
+  }
   h->n_frames = n;
   h->next_idx.assign((size_t) n * h->ntiles, 0);
   return VVCX_OK;
@@ -440,6 +456,21 @@ extern "C" int vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int 
       task_ctu.push_back(tasks[i].ctu_rs_addr); task_src.push_back(i);
     }
     sd.push_back(d);
+  }
+  // longest first: the workgroups take the streams from the queue in this order; results are addressed through first_task, so the order is free
+  {
+    std::vector<uint64_t> key(sd.size());
+    for (size_t i = 0; i < sd.size(); i++) {
+      uint64_t a = 0;
+      for (int t = 0; t < sd[i].n_tasks; t++) a += h->activity.empty() ? 0 : h->activity[(size_t) sd[i].frame * nctu + (size_t) task_ctu[(size_t) sd[i].first_task + t]];
+      key[i] = a;
+    }
+    std::vector<size_t> order(sd.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key[a] > key[b]; });
+    std::vector<VxStreamDesc> sorted(sd.size());
+    for (size_t i = 0; i < order.size(); i++) sorted[i] = sd[order[i]];
+    sd.swap(sorted);
   }
   const int ns = (int) sd.size();
   if (ns > h->stream_cap) { (void) hipFree(h->streams_d); h->streams_d = nullptr; HIPCHK(hipMalloc((void **) &h->streams_d, sizeof(VxStreamDesc) * (size_t) ns)); h->stream_cap = ns; }

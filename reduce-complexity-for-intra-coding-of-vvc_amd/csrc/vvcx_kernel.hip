@@ -175,7 +175,7 @@ struct Lds {
   // per stage-B / chroma candidate: bit 0 some block's last position is beyond DC, bit 1 some block has a coefficient outside the LFNST region
   int8_t ps_lfnst, ps_mts, ps_grp, isp_wait; int rc_last[NW]; uint8_t rd_lfl[16];      // isp_wait: the ISP places follow the stage-B operation before the node's intra decision is taken
   // the DST-VII pass prepared by the DCT-II pass (stage_b_rounds): number of prepared items (0: none), item of each candidate of the running pass, absSum per item
-  int8_t spec_n; uint8_t rd_src[16]; int spec_abs[16];
+  int8_t spec_n, spec_kind; uint8_t rd_src[16]; int spec_abs[16];      // spec_kind: 1 the DST-VII pass of transform group 0, 2 the lfnstIdx 2 pass (prepared by the lfnstIdx 1 pass)
   // ISP (intra sub-partitions): the candidate posted by the controller and what its evaluation returns; the best ISP candidate of the node so far
   double isp_limit;                                      // bestCostSoFar handed to xIntraCodingLumaISP for the candidates of the posted batch
   unsigned long long isp_dist;                           // reuse path: distortion of the cached ISP CU
@@ -2799,7 +2799,11 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
   // DCT-II, the two trellis batches side by side on different waves (the serial chain is what a pass costs; the contexts both start from are the node's) - and
   // the DST-VII pass, whose candidate list is a subset chosen from this pass's costs, only reconstructs and prices the blocks it needs
   const int specGen = lfOn && !psLf && !psMts && mtsOk && 2 * n_rd <= capItems && n_rd <= 16;
-  const int specUse = lfOn && psMts && psGrp == 0 && uni((int) L.spec_n) > 0;
+  // the same between the two LFNST passes: they walk the same candidate list with the same predictions and differ in the kernel of the set only, so the lfnstIdx 1 pass
+  // (when lfnstIdx 2 is still in the loop bounds: it is dropped only if this pass's winner has no coefficients) also transforms with kernel 2 and runs both trellis batches
+  const int specGen2 = lfOn && psLf == 1 && !psMts && uni((int) L.S.endLf) >= 2 && 2 * n_rd <= capItems && n_rd <= 16;
+  const int specKind = uni((int) L.spec_kind);
+  const int specUse = lfOn && uni((int) L.spec_n) > 0 && ((psMts && psGrp == 0 && specKind == 1) || (psLf == 2 && !psMts && specKind == 2 && uni((int) L.spec_n) == n_rd));
   const int specN = uni((int) L.spec_n);
   if (lane == 0) L.wave_best[wave] = -1;
   dq_build_tables(0);
@@ -2832,22 +2836,27 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
         wave_code_block_mts<SMALL>(org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, 2, lane, sse, cbf, -2);
         for (int e = lane; e < P; e += 64) poolCoef[(size_t) (nA + i) * P + e] = lev[e];
       }
+      if (specGen2) {
+        wave_code_block<SMALL>(org, 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf, -2, nullptr, 0, 0, 0, 2, lfnst_mode(mip ? PLANAR : mode, w, h));
+        for (int e = lane; e < P; e += 64) poolCoef[(size_t) (nA + i) * P + e] = lev[e];
+      }
     }
     __threadfence_block();
     __syncthreads();
     const long long q1 = STAMP();
     if (!specUse) dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, psMts, wave, lane, psLf);
     if (specGen) dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, 1, wave, lane, 0, nA, 32, 1);
+    if (specGen2) dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, 0, wave, lane, 2, nA, 32, 1);
     __threadfence_block();
     __syncthreads();
     const long long q2 = STAMP();
-    if (specGen) { if ((int) VTX < nA) L.spec_abs[VTX] = L.dq_abs[32 + VTX]; if (VTX == 0) L.spec_n = (int8_t) nA; }      // read by the DST-VII pass
+    if (specGen || specGen2) { if ((int) VTX < nA) L.spec_abs[VTX] = L.dq_abs[32 + VTX]; if (VTX == 0) { L.spec_n = (int8_t) nA; L.spec_kind = (int8_t) (specGen ? 1 : 2); } }      // read by the DST-VII pass / the lfnstIdx 2 pass
     else if (VTX == 0) L.spec_n = 0;                        // consumed (or not valid for what follows)
     // ---- A3
     for (int i = wave; i < nA; i += NW) {
       const int c = c0 + i, mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
       int16_t *rec = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, P, wave, cur);
-      const int src = specUse ? uni((int) L.rd_src[c]) : i;          // a prepared DST-VII block sits behind the specN DCT-II blocks of the pass that made it
+      const int src = specUse ? (specKind == 2 ? i : uni((int) L.rd_src[c])) : i;          // a prepared block sits behind the specN blocks of the pass that made it (the lfnstIdx 2 pass walks the same list in the same order)
       for (int e = lane; e < P; e += 64) { rec[e] = poolPred[(size_t) src * P + e]; lev[e] = poolCoef[(size_t) (specUse ? specN + src : i) * P + e]; }
       wave_sync();
       const int cbf = (specUse ? uni(L.spec_abs[src]) : uni(L.dq_abs[i])) > 0;
@@ -5098,3 +5107,27 @@ __device__ void lmcs_map(const T *src, T *dst, int w, int h, int stride, const i
 }
 extern "C" __global__ void __launch_bounds__(NT) vvcx_lmcs_map_kernel_u8(const uint8_t *src, uint8_t *dst, int w, int h, int stride, const int16_t *lut) { lmcs_map<uint8_t>(src, dst, w, h, stride, lut); }
 extern "C" __global__ void __launch_bounds__(NT) vvcx_lmcs_map_kernel_u16(const uint16_t *src, uint16_t *dst, int w, int h, int stride, const int16_t *lut) { lmcs_map<uint16_t>(src, dst, w, h, stride, lut); }
+
+// A cheap activity measure per CTU of the bound pictures (sum of absolute horizontal and vertical luma differences): the launch's stream queue is ordered by it,
+// longest first, so that the streams that take longest do not start last (the tail of a launch).  One workgroup per (CTU, picture).
+template <typename T>
+__device__ void ctu_activity(const VxFrameDev *frames, int pic_w, int pic_h, int ctus_w, unsigned *out)
+{
+  __shared__ unsigned part[NT];
+  const VxFrameDev &fd = frames[blockIdx.y];
+  const T *y = (const T *) fd.org[0]; const int st = fd.stride[0];
+  const int x0 = (blockIdx.x % ctus_w) << 7, y0 = (blockIdx.x / ctus_w) << 7;
+  const int w = imin(128, pic_w - x0), h = imin(128, pic_h - y0);
+  unsigned sum = 0;
+  for (int i = threadIdx.x; i < (w - 1) * (h - 1); i += NT) {
+    const int r = i / (w - 1), c = i - r * (w - 1);
+    const T *p = y + (y0 + r) * st + x0 + c;
+    const int a = (int) p[0];
+    sum += (unsigned) (iabs(a - (int) p[1]) + iabs(a - (int) p[st]));
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) { unsigned t = 0; for (int i = 0; i < NT; i++) t += part[i]; out[blockIdx.y * gridDim.x + blockIdx.x] = t; }
+}
+extern "C" __global__ void __launch_bounds__(NT) vvcx_ctu_activity_kernel_u8(const VxFrameDev *frames, int pic_w, int pic_h, int ctus_w, unsigned *out) { ctu_activity<uint8_t>(frames, pic_w, pic_h, ctus_w, out); }
+extern "C" __global__ void __launch_bounds__(NT) vvcx_ctu_activity_kernel_u16(const VxFrameDev *frames, int pic_w, int pic_h, int ctus_w, unsigned *out) { ctu_activity<uint16_t>(frames, pic_w, pic_h, ctus_w, out); }
