@@ -557,6 +557,9 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
 
 // one block of the calling wave's own candidate: decisions in the wave's rate-estimator scratch and tmp (both free at that point of wave_code_block:
 // the transform's first stage has been consumed), path nodes in the wave's HBM area
+#ifndef VXD_DQ_TAB_MIN
+#define VXD_DQ_TAB_MIN 16      // positions from which a single-block trellis tabulates its rates (measured: 64 -> 16 is +1.8 % on the bench; the small TUs of ISP CUs)
+#endif
 template <bool SMALL>
 __device__ inline int wave_depquant(int16_t *cf_g, int buf_off, uint8_t *scratch, int ci, int w, int h, int comp, int cbf_ctx, int zo, int lfnst, int lane, int qidx = -1)
 {
@@ -564,7 +567,7 @@ __device__ inline int wave_depquant(int16_t *cf_g, int buf_off, uint8_t *scratch
   int16_t *cf = SMALL ? L.wm[wave_].slot + BUF + uni(buf_off) : cf_g;
   // the tables fit behind the decisions in the rate-estimator scratch + tmp for all but the 32 x 32-coefficient blocks
   // (and pay for themselves from 64 positions on)
-  if (imin(32, w) * imin(32, h) >= 64 && 240 + 2 * imin(32, w) * imin(32, h) + DQ_TAB_BYTES <= (int) (sizeof(WaveScratch) + sizeof(int32_t) * BUF))
+  if (imin(32, w) * imin(32, h) >= VXD_DQ_TAB_MIN && 240 + 2 * imin(32, w) * imin(32, h) + DQ_TAB_BYTES <= (int) (sizeof(WaveScratch) + sizeof(int32_t) * BUF))
     wave_depquant_batch<1>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, (uint8_t *) &L.wm[wave_].ws, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
   else
     wave_depquant_batch<0>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, (uint8_t *) &L.wm[wave_].ws, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);

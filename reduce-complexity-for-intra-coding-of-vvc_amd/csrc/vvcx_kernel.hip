@@ -1563,14 +1563,29 @@ __device__ __noinline__ void wave_sad_satd(const int16_t *org_g, const int16_t *
 // four matrix coefficients (int8, one 32-bit load) times four int16 samples (one 64-bit load) / four int32 values (one 128-bit load):
 // rows of the matrices and of the sample tiles start at multiples of their length (>= 4 elements) in 16-byte aligned buffers
 struct alignas(16) I32x4 { int x, y, z, w; };
+// The first transform stage multiplies int8 matrix rows with 16-bit samples: two packed dot products (v_dot2c_i32_i16: two int16 x int16 products accumulated into 32
+// bits, exact) per four samples; the residual pair comes from one packed subtraction (v_pk_sub_i16; samples and predictions are below 2^15).
+#ifndef VX_DOT2_I16
+typedef short vx_s2 __attribute__((ext_vector_type(2)));
+#define VX_DOT2_I16(a_, b_, c_) __builtin_amdgcn_sdot2(__builtin_bit_cast(vx_s2, (uint32_t) (a_)), __builtin_bit_cast(vx_s2, (uint32_t) (b_)), (c_), false)
+#define VX_PKSUB_I16(a_, b_) __builtin_bit_cast(uint32_t, __builtin_bit_cast(vx_s2, (uint32_t) (a_)) - __builtin_bit_cast(vx_s2, (uint32_t) (b_)))
+#endif
+__device__ inline uint2 m8x4_to_16(uint32_t m)                    // four int8 coefficients -> two words of packed int16 pairs
+{
+  uint2 r;
+  r.x = (uint32_t) (uint16_t) (int16_t) (int8_t) m | ((uint32_t) (int) (int8_t) (m >> 8) << 16);
+  r.y = (uint32_t) (uint16_t) (int16_t) (int8_t) (m >> 16) | ((uint32_t) ((int) m >> 24) << 16);
+  return r;
+}
 __device__ inline int dot4_s16(uint32_t m, uint2 d)
 {
-  return (int) (int8_t) m * (int) (int16_t) d.x + (int) (int8_t) (m >> 8) * (int) (int16_t) (d.x >> 16) + (int) (int8_t) (m >> 16) * (int) (int16_t) d.y + (int) (int8_t) (m >> 24) * (int) (int16_t) (d.y >> 16);
+  const uint2 c = m8x4_to_16(m);
+  return VX_DOT2_I16(c.y, d.y, VX_DOT2_I16(c.x, d.x, 0));
 }
 __device__ inline int dot4_resi(uint32_t m, uint2 a, uint2 b)     // coefficients times (a - b), element-wise int16
 {
-  return (int) (int8_t) m * ((int) (int16_t) a.x - (int) (int16_t) b.x) + (int) (int8_t) (m >> 8) * ((int) (int16_t) (a.x >> 16) - (int) (int16_t) (b.x >> 16))
-       + (int) (int8_t) (m >> 16) * ((int) (int16_t) a.y - (int) (int16_t) b.y) + (int) (int8_t) (m >> 24) * ((int) (int16_t) (a.y >> 16) - (int) (int16_t) (b.y >> 16));
+  const uint2 c = m8x4_to_16(m);
+  return VX_DOT2_I16(c.y, VX_PKSUB_I16(a.y, b.y), VX_DOT2_I16(c.x, VX_PKSUB_I16(a.x, b.x), 0));
 }
 __device__ inline int dot4_s32(uint32_t m, I32x4 d)
 {
@@ -1710,6 +1725,44 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
     wave_sync();
   }
   // stage 1 (horizontal): tmp[k*h + j] = (sum_i Mw[k][i] * resi[j][i] + rnd) >> shift1, k < zw
+#ifndef VX_NO_MFMA
+  // 32- and 64-point rows on the matrix cores: D[k][j] = sum_i Mw[k][i] * resi[j][i] is a 32 x w by w x h GEMM of an int8 matrix with 11-bit residuals.  The residual is
+  // split into a signed high byte and an unsigned low byte; the low byte is re-centred (lo - 128, so that it is an int8) and the 128 * (row sum of Mw) it leaves out is added back:
+  // the DCT-II rows sum to zero except row 0 (64 * w; tests/test_host_cpu.py checks the tables).  v_mfma_i32_32x32x16_i8: lane l feeds row l % 32 of A / column l % 32 of B
+  // with the eight k of half l / 32; the 16 results of a lane are rows 8 * (r / 4) + 4 * (l / 32) + r % 4 of column l % 32.  Exact: all partial sums stay far below 2^31.
+  if (!SMALL && given < 0 && !cadj && !lf && (w == 32 || w == 64)) {
+    typedef int vx_i16 __attribute__((ext_vector_type(16)));
+    const int col = lane & 31, half = lane >> 5;
+    for (int jt = 0; jt < h; jt += 32) {
+      vx_i16 accH = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, accL = accH;
+      const int j = jt + col;
+      for (int q = 0; q < w; q += 16) {
+        const int i0 = q + half * 8;
+        const uint32_t a0 = *(const uint32_t *) (Mw + col * w + i0), a1 = *(const uint32_t *) (Mw + col * w + i0 + 4);
+        const long a = (long) (((unsigned long long) a1 << 32) | a0);
+        unsigned long long bh = 0, bl = 0;
+        if (j < h) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const int r = org[j * w + i0 + e] - rec[j * w + i0 + e];
+            bh |= (unsigned long long) (unsigned) ((r >> 8) & 255) << (8 * e);
+            bl |= (unsigned long long) (unsigned) (((r & 255) - 128) & 255) << (8 * e);
+          }
+        }
+        accH = __builtin_amdgcn_mfma_i32_32x32x16_i8(a, (long) bh, accH, 0, 0, 0);
+        accL = __builtin_amdgcn_mfma_i32_32x32x16_i8(a, (long) bl, accL, 0, 0, 0);
+      }
+      if (j < h) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int k = 8 * (r >> 2) + 4 * half + (r & 3);
+          const int sacc = 256 * accH[r] + accL[r] + (k == 0 ? 128 * 64 * w : 0);
+          tmp[k * h + j] = (sacc + rnd1) >> shift1;
+        }
+      }
+    }
+  } else
+#endif
   if (given < 0) for (int o = lane; o < fzw * h; o += 64) {
     const int k = o >> lh, j = o & (h - 1);
     int s = 0;

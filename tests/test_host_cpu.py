@@ -439,6 +439,18 @@ def test_submit_and_wait_halves_equal_the_blocking_call(emu_so):
     a.close(); b.close()
 
 
+def test_dct2_rows_sum_to_zero_except_the_dc_row():
+    """The matrix-core form of the 32- / 64-point first transform stage (wave_code_block, v_mfma_i32_32x32x16_i8 on re-centred low bytes) adds 128 x (row sum) back in closed
+    form: rows 1.. of the DCT-II matrices sum to zero, row 0 to 64 x N.  Checked on the tables the device code is built from."""
+    import re
+    txt = open(os.path.join(ROOT, PKGNAME, "csrc", "vvcx_tables.h")).read()
+    for n in (32, 64):
+        m = re.search(r"VX_DCT2_%d\[%d\]\s*=\s*\{([^}]*)\}" % (n, n * n), txt)
+        a = np.array([int(v) for v in m.group(1).replace("\n", " ").split(",") if v.strip()], np.int64).reshape(n, n)
+        sums = a.sum(axis=1)
+        assert sums[0] == 64 * n and not sums[1:].any(), n
+
+
 def test_resource_budget_of_the_compress_kernel(hip_lib):
     """The stream kernel is sized for four workgroups per CU (128 VGPRs, 40 KB LDS, 1024 resident streams per GPU).  A field too many in the LDS object
     drops the residency to three and makes the compiler give up the register target as well (seen in round 3: 41 008 B -> 257 VGPRs, one wave per SIMD), without any

@@ -22,6 +22,10 @@
 #define __launch_bounds__(...)
 #define __noinline__ __attribute__((noinline))
 #define __forceinline__ inline
+#define VX_NO_MFMA 1      // the matrix-core form of the 32- / 64-point first transform stage exists on the device only; the emulation runs the general loop
+// packed 16-bit helpers of the transform stage (device: v_dot2c_i32_i16 / v_pk_sub_i16)
+#define VX_DOT2_I16(a_, b_, c_) ((c_) + (int) (int16_t) (a_) * (int) (int16_t) (b_) + (int) (int16_t) ((a_) >> 16) * (int) (int16_t) ((b_) >> 16))
+#define VX_PKSUB_I16(a_, b_) ((uint32_t) (uint16_t) ((a_) - (b_)) | ((uint32_t) (uint16_t) (((a_) >> 16) - ((b_) >> 16)) << 16))
 #define VX_REG_BARRIER(x) ((void) 0)      // device builds: an empty asm that keeps a value in a register (see csrc/vvcx_depquant_dev.h)
 // workgroup-shared storage is not cleared between workgroups on the GPU: poison it at kernel entry so that reads of never-written fields misbehave here too
 // range assertions on derived addresses (path-node offsets from ancestor fields, template rows from packed state bits, decision slots): checked in the emulation only
