@@ -2419,10 +2419,16 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
   const int predRegDiff = !hor && ((w == 8 && h > 4) || w == 4);         // CU::isPredRegDiffFromTB
   const int wave = uni(VTX >> 6), x0 = uni(L.nx), y0 = uni(L.ny);
   const int16_t *org = org_tile(scratch, w * h);
-  int16_t *pred = tile + 8192, *cf = tile + 12288;
+  // CUs of at most 128 samples (most of the nodes that test ISP) keep everything in LDS: the region references, the CU's reconstruction and levels in the candidate slot,
+  // the prediction and the dense coefficient tile behind the transform scratch (a TU has at most 64 coefficients then); the tiles are copied out at the end
+  const int small = w * h <= 128;
+  int16_t *const rec_out = rec, *const lev_out = lev;
+  int16_t *sl = L.wm[uni(refs_wave)].slot, *tl = (int16_t *) L.wm[wave].tmp;
+  if (small) { rec = sl + 132; lev = sl + 260; }
+  int16_t *pred = small ? tl + 192 : tile + 8192, *cf = small ? tl + 128 : tile + 12288;
   int32_t *tmp = wave_tmp(scratch, imin(32, tw) * th, wave);
   const int16_t *bt = L.refs[0][0], *bl = L.refs[0][1];
-  int16_t *rt = L.wm[uni(refs_wave)].slot, *rl = L.wm[uni(refs_wave)].slot + 160;      // region references: an LDS candidate slot this path does not use otherwise
+  int16_t *rt = sl, *rl = sl + (small ? 66 : 160);          // region references: an LDS candidate slot this path does not use otherwise
   { uint32_t *d = (uint32_t *) &L.ctxs[ci]; const uint32_t *s_ = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s_[e]; }
   wave_sync();
   double cost = 0; int tucbf = 0, nrun = 0;
@@ -2487,6 +2493,7 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
   }
   if (lane == 0) { if (given) L.isp_dist = dist; else { out->cbf = (uint8_t) tucbf; out->nrun = (uint8_t) nrun; } }
   wave_sync();
+  if (small) { for (int e = lane; e < w * h; e += 64) { rec_out[e] = rec[e]; lev_out[e] = lev[e]; } wave_sync(); }
 }
 // OP_ISP: up to NW candidates of the node's ISP test at once, one per wave: L.isp_res[w].mode / split name wave w's, all under the limit L.isp_limit
 __device__ __noinline__ void op_isp(uint8_t *scratch)
