@@ -193,6 +193,13 @@ int  vvcx_lmcs_tables(vvcx_handle *h, int16_t *fwd, int16_t *inv, int32_t pivot[
  * Every CTU of the pictures must have been compressed.  SAO and ALF, which follow in the reference, are not built. */
 int  vvcx_deblock_bound_frames(vvcx_handle *h, int beta_offset_div2, int tc_offset_div2, void *hip_stream);
 float vvcx_last_deblock_ms(const vvcx_handle *h);
+/* ≙ LoopFilter::loopFilterPic on a picture the caller describes itself (the way the reference's LoopFilter sees a CodingStructure: cs.cus + cs.tus + the reconstruction buffer):
+ * rows = n_rows x {channel type (0 luma tree, 1 chroma tree), x, y, w, h in luma samples, cu.ispMode (0, 1 = horizontal, 2 = vertical split; luma rows only)} covering both
+ * trees of the whole 4:2:0 picture, every CU intra at the slice QP (qp_cb / qp_cr = mapped chroma QPs); y / cb / cr = host planes of 16-bit samples, stride = plane width,
+ * filtered in place.  The transform edges of ISP sub-partitions are filtered as xDeblockCU does (CL/LoopFilter.cpp:306-317, filter lengths from the sub-partition sizes,
+ * 474-575).  Needs no handle: it is the filter of vvcx_deblock_bound_frames behind a table interface */
+int  vvcx_deblock_cu_table(int pic_w, int pic_h, int bit_depth, int qp, int qp_cb, int qp_cr, int beta_offset_div2, int tc_offset_div2,
+                           const int32_t *rows, int n_rows, uint16_t *y, uint16_t *cb, uint16_t *cr, int device);
 /* slice_data() payload of one completely coded tile of a bound frame: the bytes EncSlice::encodeSlice would hand to the NAL writer
  * for that brick (CABACWriter::coding_tree_unit per CTU, end_of_ctu / end_of_slice terminating bins, byte alignment;
  * EL/EncSlice.cpp:1884-2006).  Requires cfg.emit_payload.  buf is host memory */

@@ -2238,40 +2238,84 @@ int orc_test_mpm(int pic_w, int pic_h, const int *nb, int n_nb, int x, int y, in
  * the left and top edges of the CUs of each tree; all vertical edges first, then all horizontal ones; boundary strength 2 everywhere.
  * Luma edges lie on the 4x4 grid, chroma edges on the 8x8 chroma-sample grid (1217-1227); every CU has the slice QP.
  * ---------------------------------------------------------------------------------------------- */
-int orc_deblock_frame(orc_enc *e, int beta_offset_div2, int tc_offset_div2)
+/* size, across an edge of direction dir (0: vertical edges -> widths, 1: horizontal edges -> heights), of the transform unit a luma
+ * 4x4 unit lies in: the CU's size, or the ISP sub-partition's when the CU is split that way (CU::getISPSplitDim, CL/UnitTools.cpp) */
+static int dbk_tu_size(const unit_t *u, int dir)
 {
-  const int bd = e->cfg.bit_depth, qp = e->sl.qp;
+  const int w = 1 << u->lw, h = 1 << u->lh;
+  if (u->isp != (dir ? 1 : 2)) return dir ? h : w;
+  const int parts = ((w == 4 && h == 8) || (w == 8 && h == 4)) ? 2 : 4;
+  return (dir ? h : w) / parts;
+}
+static void dbk_picture(const unit_t *um0, const unit_t *um1, int uw, int uh, int16_t *const rec[3], const int stride[3], int qp, const int qp_c[2], int bd, int chroma,
+                        int beta_offset_div2, int tc_offset_div2)
+{
   for (int dir = 0; dir < 2; dir++) {                 /* 0: vertical edges, 1: horizontal edges */
-    for (int uy = 0; uy < e->uh; uy++) for (int ux = 0; ux < e->uw; ux++) {
-      const unit_t *u = &e->um[0][uy * e->uw + ux];
-      const int x = ux << 2, y = uy << 2, st = e->stride[0];
+    for (int uy = 0; uy < uh; uy++) for (int ux = 0; ux < uw; ux++) {
+      const unit_t *u = &um0[uy * uw + ux];
+      const int x = ux << 2, y = uy << 2, st = stride[0];
       if (!u->valid) continue;
-      if (dir == 0 && u->x == x && x > 0) {
-        const unit_t *p = &e->um[0][uy * e->uw + ux - 1];
-        orc_deblock_luma_segment(e->rec[0] + y * st + x, 1, st, 1 << p->lw, 1 << u->lw, 0, qp, bd, beta_offset_div2, tc_offset_div2);
+      /* transform edges (xDeblockCU 306-317): the CU border and, in an ISP CU, the borders between its sub-partitions that lie on the
+       * 4-sample grid; the filter lengths follow the TRANSFORM sizes on either side (xSetMaxFilterLengthPQFromTransformSizes 474-575),
+       * i.e. the sub-partition size where the CU is split across the edge direction */
+      if (dir == 0 && x > 0) {
+        const int tq = dbk_tu_size(u, 0), off = x - u->x;
+        if (off == 0) {
+          const unit_t *p = &um0[uy * uw + ux - 1];
+          orc_deblock_luma_segment(rec[0] + y * st + x, 1, st, dbk_tu_size(p, 0), tq, 0, qp, bd, beta_offset_div2, tc_offset_div2);
+        } else if (u->isp == 2 && off % tq == 0)
+          orc_deblock_luma_segment(rec[0] + y * st + x, 1, st, tq, tq, 0, qp, bd, beta_offset_div2, tc_offset_div2);
       }
-      if (dir == 1 && u->y == y && y > 0) {
-        const unit_t *p = &e->um[0][(uy - 1) * e->uw + ux];
-        orc_deblock_luma_segment(e->rec[0] + y * st + x, st, 1, 1 << p->lh, 1 << u->lh, (y & 127) == 0, qp, bd, beta_offset_div2, tc_offset_div2);
+      if (dir == 1 && y > 0) {
+        const int tq = dbk_tu_size(u, 1), off = y - u->y;
+        if (off == 0) {
+          const unit_t *p = &um0[(uy - 1) * uw + ux];
+          orc_deblock_luma_segment(rec[0] + y * st + x, st, 1, dbk_tu_size(p, 1), tq, (y & 127) == 0, qp, bd, beta_offset_div2, tc_offset_div2);
+        } else if (u->isp == 1 && off % tq == 0)
+          orc_deblock_luma_segment(rec[0] + y * st + x, st, 1, tq, tq, 0, qp, bd, beta_offset_div2, tc_offset_div2);
       }
     }
-    if (!e->cfg.chroma) continue;
-    for (int uy = 0; uy < e->uh; uy++) for (int ux = 0; ux < e->uw; ux++) {
-      const unit_t *u = &e->um[1][uy * e->uw + ux];
+    if (!chroma) continue;
+    for (int uy = 0; uy < uh; uy++) for (int ux = 0; ux < uw; ux++) {
+      const unit_t *u = &um1[uy * uw + ux];
       const int cx = ux << 1, cy = uy << 1;          /* chroma samples of this unit: 2x2 */
       if (!u->valid) continue;
       for (int k = 0; k < 2; k++) {
-        const int st = e->stride[k + 1], qpc = e->sl.qp_c[k] < 0 ? 0 : e->sl.qp_c[k] > 63 ? 63 : e->sl.qp_c[k];
+        const int st = stride[k + 1], qpc = qp_c[k] < 0 ? 0 : qp_c[k] > 63 ? 63 : qp_c[k];
         if (dir == 0 && u->x == cx && cx > 0 && (cx & 7) == 0) {
-          const unit_t *p = &e->um[1][uy * e->uw + ux - 1];
-          orc_deblock_chroma_segment(e->rec[k + 1] + cy * st + cx, 1, st, 1 << p->lw, 1 << u->lw, 0, qpc, bd, beta_offset_div2, tc_offset_div2);
+          const unit_t *p = &um1[uy * uw + ux - 1];
+          orc_deblock_chroma_segment(rec[k + 1] + cy * st + cx, 1, st, 1 << p->lw, 1 << u->lw, 0, qpc, bd, beta_offset_div2, tc_offset_div2);
         }
         if (dir == 1 && u->y == cy && cy > 0 && (cy & 7) == 0) {
-          const unit_t *p = &e->um[1][(uy - 1) * e->uw + ux];
-          orc_deblock_chroma_segment(e->rec[k + 1] + cy * st + cx, st, 1, 1 << p->lh, 1 << u->lh, (cy & 63) == 0, qpc, bd, beta_offset_div2, tc_offset_div2);
+          const unit_t *p = &um1[(uy - 1) * uw + ux];
+          orc_deblock_chroma_segment(rec[k + 1] + cy * st + cx, st, 1, 1 << p->lh, 1 << u->lh, (cy & 63) == 0, qpc, bd, beta_offset_div2, tc_offset_div2);
         }
       }
     }
   }
+}
+int orc_deblock_frame(orc_enc *e, int beta_offset_div2, int tc_offset_div2)
+{
+  dbk_picture(e->um[0], e->um[1], e->uw, e->uh, e->rec, e->stride, e->sl.qp, e->sl.qp_c, e->cfg.bit_depth, e->cfg.chroma, beta_offset_div2, tc_offset_div2);
+  return 0;
+}
+/* the same filter on a picture given as a CU table (rows of {ch, x, y, w, h, ispMode}, luma samples) and its planes (4:2:0, stride = plane width), so that the pin against
+ * the reference's LoopFilter can cover CU tables no search produced (tests/golden/make_golden.py deblock: forced ISP splits) */
+int orc_deblock_table(int w, int h, int bd, int qp, int qp_cb, int qp_cr, const int *rows, int nrows, int16_t *y, int16_t *cb, int16_t *cr)
+{
+  const int uw = (w + 3) >> 2, uh = (h + 3) >> 2;
+  unit_t *um[2] = { calloc((size_t) uw * uh, sizeof(unit_t)), calloc((size_t) uw * uh, sizeof(unit_t)) };
+  if (!um[0] || !um[1]) { free(um[0]); free(um[1]); return -1; }
+  for (int i = 0; i < nrows; i++) {
+    const int *r = rows + 6 * i, ch = r[0], sh = ch ? 1 : 0;
+    for (int v = r[2] >> 2; v < (r[2] + r[4]) >> 2 && v < uh; v++) for (int u = r[1] >> 2; u < (r[1] + r[3]) >> 2 && u < uw; u++) {
+      unit_t *t = &um[ch][v * uw + u];
+      t->valid = 1; t->x = (int16_t) (r[1] >> sh); t->y = (int16_t) (r[2] >> sh); t->lw = (uint8_t) ilog2(r[3] >> sh); t->lh = (uint8_t) ilog2(r[4] >> sh); t->isp = (uint8_t) r[5];
+    }
+  }
+  int16_t *rec[3] = { y, cb, cr };
+  const int stride[3] = { w, w >> 1, w >> 1 }, qpc[2] = { qp_cb, qp_cr };
+  dbk_picture(um[0], um[1], uw, uh, rec, stride, qp, qpc, bd, 1, 0, 0);
+  free(um[0]); free(um[1]);
   return 0;
 }

@@ -126,6 +126,8 @@ int      orc_fast_features(const int16_t *org, int stride, int w, int h, int fea
 int      orc_forest_predict_rows(orc_enc *e, const int32_t *rows, int n, int32_t *out);   /* test hook: forest on n rows of 26 ints */
 /* deblocking filter on the coded picture (CL/LoopFilter.cpp; after orc_compress_frame, before orc_get_reco): cfg LoopFilterBetaOffset_div2 / TcOffset_div2 */
 int      orc_deblock_frame(orc_enc *e, int beta_offset_div2, int tc_offset_div2);
+/* the same filter on a CU table {ch, x, y, w, h, ispMode} (luma samples) and 4:2:0 planes with stride = plane width; qp_cb / qp_cr = mapped chroma QPs */
+int      orc_deblock_table(int w, int h, int bd, int qp, int qp_cb, int qp_cr, const int *rows, int nrows, int16_t *y, int16_t *cb, int16_t *cr);
 void     orc_get_counters(orc_enc *e, uint64_t out[4]); /* satd candidates, rd candidates, rd pixels, nodes */
 
 /* ---------------- leaf operators (individually testable; used by the golden-vector tests) -------- */

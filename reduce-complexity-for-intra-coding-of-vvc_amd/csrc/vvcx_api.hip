@@ -677,6 +677,63 @@ extern "C" int vvcx_deblock_bound_frames(vvcx_handle *h, int beta_offset_div2, i
 }
 extern "C" float vvcx_last_deblock_ms(const vvcx_handle *h) { return h ? h->last_deblock_ms : 0.f; }
 
+// the same two kernels on a picture the caller describes by a CU table (host memory in, host memory out): the unit maps the kernels read are built here from the rows
+extern "C" int vvcx_deblock_cu_table(int pic_w, int pic_h, int bit_depth, int qp, int qp_cb, int qp_cr, int beta_offset_div2, int tc_offset_div2,
+                                     const int32_t *rows, int n_rows, uint16_t *y, uint16_t *cb, uint16_t *cr, int device)
+{
+  if (!rows || !y || !cb || !cr || n_rows <= 0) return fail(VVCX_ERR_ARG, "null argument");
+  if (pic_w < 8 || pic_h < 8 || (pic_w & 7) || (pic_h & 7) || pic_w > 16384 || pic_h > 16384) return fail(VVCX_ERR_ARG, "picture size must be a multiple of 8 (MinCUSize of the cfg) up to 16384");
+  if (bit_depth < 8 || bit_depth > 12 || qp < 0 || qp > 63 || beta_offset_div2 < -6 || beta_offset_div2 > 6 || tc_offset_div2 < -6 || tc_offset_div2 > 6) return fail(VVCX_ERR_ARG, "bit depth / QP / offsets out of range");
+  const int uw = pic_w >> 2, uh = pic_h >> 2;
+  std::vector<VxUnit> um((size_t) 2 * uw * uh);
+  memset(um.data(), 0, um.size() * sizeof(VxUnit));
+  for (int i = 0; i < n_rows; i++) {
+    const int32_t *r = rows + 6 * i;
+    const int ch = r[0], sh = ch ? 1 : 0;
+    const bool pow2 = r[3] > 0 && r[4] > 0 && !(r[3] & (r[3] - 1)) && !(r[4] & (r[4] - 1));
+    if (ch < 0 || ch > 1 || !pow2 || r[3] < 4 || r[4] < 4 || r[3] > 128 || r[4] > 128 || (r[1] & 3) || (r[2] & 3) || r[1] < 0 || r[2] < 0 || r[1] + r[3] > pic_w || r[2] + r[4] > pic_h ||
+        r[5] < 0 || r[5] > 2 || (r[5] && (ch || r[3] * r[4] <= 16 || r[3] > 64 || r[4] > 64)))
+      return fail(VVCX_ERR_ARG, "CU row %d is not a CU of a %dx%d picture", i, pic_w, pic_h);
+    int lw = 0, lh = 0;
+    while ((1 << lw) < (r[3] >> sh)) lw++;
+    while ((1 << lh) < (r[4] >> sh)) lh++;
+    for (int v = r[2] >> 2; v < (r[2] + r[4]) >> 2; v++) for (int u = r[1] >> 2; u < (r[1] + r[3]) >> 2; u++) {
+      VxUnit &t = um[(size_t) ch * uw * uh + (size_t) v * uw + u];
+      t.tag = 1; t.x = (int16_t) (r[1] >> sh); t.y = (int16_t) (r[2] >> sh); t.lw = (uint8_t) lw; t.lh = (uint8_t) lh; t.mts = (uint8_t) (r[5] << 6);
+    }
+  }
+  for (size_t i = 0; i < um.size(); i++) if (!um[i].tag) return fail(VVCX_ERR_ARG, "the CU table does not cover the picture (%s tree, 4x4 unit %d)", i < um.size() / 2 ? "luma" : "chroma", (int) (i % (um.size() / 2)));
+  DevGuard guard(device);
+  const size_t ny = (size_t) pic_w * pic_h, nc = ny >> 2;
+  VxUnit *um_d = nullptr; uint16_t *pl_d = nullptr; VxFrameDev *fd_d = nullptr;
+  int rc = VVCX_OK;
+  if (hipMalloc((void **) &um_d, um.size() * sizeof(VxUnit)) != hipSuccess || hipMalloc((void **) &pl_d, (ny + 2 * nc) * 2) != hipSuccess || hipMalloc((void **) &fd_d, sizeof(VxFrameDev)) != hipSuccess)
+    rc = fail(VVCX_ERR_DEVICE, "hipMalloc failed for the deblocking of a %dx%d CU table", pic_w, pic_h);
+  if (rc == VVCX_OK) {
+    VxFrameDev fd; memset(&fd, 0, sizeof fd);
+    fd.rec[0] = pl_d; fd.rec[1] = pl_d + ny; fd.rec[2] = pl_d + ny + nc;
+    fd.stride[0] = pic_w; fd.stride[1] = fd.stride[2] = pic_w >> 1;
+    fd.units[0] = um_d; fd.units[1] = um_d + (size_t) uw * uh;
+    VxDeblockParams p; memset(&p, 0, sizeof p);
+    p.frames = fd_d; p.uw = uw; p.uh = uh; p.bit_depth = bit_depth; p.chroma = 1; p.qp = qp; p.qp_c[0] = qp_cb; p.qp_c[1] = qp_cr; p.beta_off2 = beta_offset_div2; p.tc_off2 = tc_offset_div2;
+    bool ok = hipMemcpy(um_d, um.data(), um.size() * sizeof(VxUnit), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(fd_d, &fd, sizeof fd, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(pl_d, y, ny * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(pl_d + ny, cb, nc * 2, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(pl_d + ny + nc, cr, nc * 2, hipMemcpyHostToDevice) == hipSuccess;
+    for (int dir = 0; dir < 2 && ok; dir++) {
+      p.dir = dir;
+      hipLaunchKernelGGL(vvcx_deblock_kernel_u16, dim3((unsigned) ((2 * uw * uh + 255) / 256), 1), dim3(256), 0, 0, p);
+      ok = hipGetLastError() == hipSuccess;
+    }
+    ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(y, pl_d, ny * 2, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(cb, pl_d + ny, nc * 2, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(cr, pl_d + ny + nc, nc * 2, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) rc = fail(VVCX_ERR_DEVICE, "deblocking of a CU table: a HIP call failed");
+  }
+  if (um_d) (void) hipFree(um_d);
+  if (pl_d) (void) hipFree(pl_d);
+  if (fd_d) (void) hipFree(fd_d);
+  return rc;
+}
+
 // quantised levels of one component of a coded picture at their sample positions (≙ tu.getCoeffs(compID) of the final TUs), host plane
 extern "C" int vvcx_get_levels(vvcx_handle *h, int frame, int comp, int16_t *plane, int stride)
 {

@@ -201,6 +201,15 @@ __device__ void db_chroma_segment(T *s, int o, int step, int sizeP, int sizeQ, i
   _Pragma("unroll") for (int l = 0; l < 2; l++) db_store(s + l * step, o, L[l], wPQ, wPQ);
 }
 
+// size, across an edge of direction dir (0: vertical edge -> width, 1: horizontal edge -> height), of the transform unit a luma 4x4 unit lies in: the CU's, or the
+// sub-partition's where the CU is an ISP CU split across that direction (xSetMaxFilterLengthPQFromTransformSizes 474-575 takes the lengths from tuP / tuQ)
+__device__ inline int db_tu_size(const VxUnit &u, int dir)
+{
+  const int w = 1 << u.lw, h = 1 << u.lh, isp = (u.mts >> 6) & 3;
+  if (isp != (dir ? 1 : 2)) return dir ? h : w;
+  const int parts = ((w == 4 && h == 8) || (w == 8 && h == 4)) ? 2 : 4;
+  return (dir ? h : w) / parts;
+}
 // grid: ceil(2 * uw * uh / 256) x n_frames; the first uw*uh threads of a frame take the luma units, the next uw*uh the chroma units
 template <typename T>
 __device__ void deblock_pass(const VxDeblockParams &p)
@@ -216,8 +225,11 @@ __device__ void deblock_pass(const VxDeblockParams &p)
   if (!ch) {
     const int x = ux << 2, y = uy << 2, st = fd.stride[0];
     T *rec = (T *) fd.rec[0];
-    if (p.dir == 0) { if (u.x == x && x > 0) db_luma_segment(rec + y * st + x, 1, st, 1 << fd.units[0][id - 1].lw, 1 << u.lw, 0, p); }
-    else if (u.y == y && y > 0) db_luma_segment(rec + y * st + x, st, 1, 1 << fd.units[0][id - p.uw].lh, 1 << u.lh, (y & 127) == 0, p);
+    // transform edges (xDeblockCU 306-317): the CU border, and inside an ISP CU the sub-partition borders that lie on the 4-sample grid
+    const int tq = db_tu_size(u, p.dir), off = p.dir ? y - u.y : x - u.x, isp = (u.mts >> 6) & 3;
+    const int inner = off > 0 && isp == (p.dir ? 1 : 2) && off % tq == 0;
+    if (p.dir == 0) { if (x > 0 && (off == 0 || inner)) db_luma_segment(rec + y * st + x, 1, st, inner ? tq : db_tu_size(fd.units[0][id - 1], 0), tq, 0, p); }
+    else if (y > 0 && (off == 0 || inner)) db_luma_segment(rec + y * st + x, st, 1, inner ? tq : db_tu_size(fd.units[0][id - p.uw], 1), tq, (y & 127) == 0, p);
   } else {
     const int cx = ux << 1, cy = uy << 1;
     for (int k = 0; k < 2; k++) {

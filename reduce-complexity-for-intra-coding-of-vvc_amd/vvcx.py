@@ -428,6 +428,18 @@ def transform_skip_batch(resi, w, h, bit_depth, qp, lam, s0, s1, device=0, lib_p
     return lev.reshape(n, h, w), out.reshape(n, h, w), a, keep, bits
 
 
+def deblock_cu_table(planes, rows, bit_depth, qp, qp_c, beta_offset_div2=0, tc_offset_div2=0, device=0, lib_path=None):
+    """vvcx_deblock_cu_table: in-loop deblocking of a 4:2:0 picture described by a CU table (rows of {ch, x, y, w, h, ispMode}, luma samples); returns the filtered planes"""
+    L = load_library(lib_path)
+    out = [np.ascontiguousarray(p).astype(np.uint16) for p in planes]
+    rows = np.ascontiguousarray(rows, np.int32)
+    h, w = out[0].shape
+    L.vvcx_deblock_cu_table.argtypes = [C.c_int] * 8 + [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int]
+    _chk(L, L.vvcx_deblock_cu_table(w, h, bit_depth, qp, int(qp_c[0]), int(qp_c[1]), beta_offset_div2, tc_offset_div2, rows.ctypes.data, len(rows),
+                                    out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, device))
+    return out
+
+
 def isp_tu_batch(org, pred, tw, th, bit_depth, qp, lam, prev_cbf, cbf_inferred, s0, s1, device=0, lib_path=None):
     """vvcx_isp_tu_batch: n sub-partition blocks of ISP CUs through the implicit transform, the dependent quantiser with the ISP cbf context, dequantiser and inverse"""
     L = load_library(lib_path)

@@ -231,3 +231,32 @@ def write_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=
         return buf[:tot].copy(), sizes, cus[:n.value].copy(), lev
     finally:
         L.orc_destroy(e)
+
+
+def forced_isp_rows(cus, seed):
+    """CU table rows {ch, x, y, w, h, ispMode} (luma samples) with a random sub-partition split on about two thirds of the luma CUs that can have one."""
+    g = np.random.default_rng(seed)
+    rows = np.array([[c["ch_type"]] + [int(c[k]) * (2 if c["ch_type"] else 1) for k in ("x", "y", "w", "h")] + [0] for c in cus], np.int32)
+    for r in rows:
+        if r[0] == 0 and r[3] * r[4] > 16 and r[3] <= 64 and r[4] <= 64:
+            r[5] = int(g.integers(0, 3)) if g.random() < 0.85 else 0
+    return rows
+
+
+def check_forced_isp_deblock(pkg, which, lib_path=None):
+    """vvcx_deblock_cu_table on the CU tables with forced ISP splits of tests/golden/deblock.npz: the filtered planes the REFERENCE's LoopFilter produced are the expectation"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "deblock.npz"))
+    off = 0
+    for i, (W, H, qp, bd, seed) in enumerate(g["forced_meta"]):
+        W, H, qp, bd = int(W), int(H), int(qp), int(bd)
+        sizes = [W * H, W * H // 4, W * H // 4]
+        if i in which:
+            pl = pkg.synth_frame(W, H, 0, bd, int(seed), chroma_texture=0.5); sp = pkg.slice_params(qp, bit_depth=bd)
+            _, cus, pre, _ = compress_frame(pl, W, H, sp, bit_depth=bd, tools=0x911)
+            rows = forced_isp_rows(cus, int(seed))
+            got = pkg.vvcx.deblock_cu_table(pre, rows, bd, qp, sp["qp_c"], lib_path=lib_path)
+            o = off
+            for c in range(3):
+                assert np.array_equal(got[c].astype(np.int16).ravel(), g["forced_planes"][o:o + sizes[c]]), (W, H, qp, bd, c); o += sizes[c]
+            assert any((got[c] != pre[c]).any() for c in range(3))
+        off += sum(sizes)

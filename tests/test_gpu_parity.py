@@ -442,6 +442,12 @@ def test_deblocking_filter(case):
     enc.close()
 
 
+def test_deblocking_of_isp_transform_edges_against_the_reference():
+    """vvcx_deblock_cu_table on the GPU: CU tables with a forced random ispMode on most luma CUs; the expectation is the reference's own LoopFilter output
+    (tests/golden/deblock.npz, forced_planes), not the oracle's."""
+    O.check_forced_isp_deblock(pkg, (0, 1, 2))
+
+
 def _spot_check_tiles(planes, W, H, sp, bd, tc, tr, tools, res, tiles, forest_qp=32):
     """bit-exact oracle check of a few one-CTU tiles of a big picture (each tile is an independent stream: the oracle codes only those, one process each)"""
     import multiprocessing as mp

@@ -308,11 +308,35 @@ def test_deblocking_filter_against_the_reference_loop_filter():
     off = 0
     for (W, H, qp, bd, seed, tools) in g["meta"]:
         W, H, bd = int(W), int(H), int(bd)
-        pl = pkg.synth_frame(W, H, 0, bd, int(seed), chroma_texture=0.5)
-        reco = O.compress_frame(pl, W, H, pkg.slice_params(int(qp), bit_depth=bd), bit_depth=bd, tools=int(tools), deblock=True)[2]
+        tools = int(tools)                                        # the cases with ISP: content on which sub-partitions win, so their transform edges are in the picture
+        pl = pkg.synth_frame(W, H, 0, bd, int(seed), chroma_texture=0.5, **(dict(oriented=25.0, screen=0.5) if tools & 0x4 else {}))
+        reco = O.compress_frame(pl, W, H, pkg.slice_params(int(qp), bit_depth=bd, dep_quant=bool(tools & 0x40)), bit_depth=bd, tools=tools, deblock=True)[2]
         for c in range(3):
             n = reco[c].size
             assert np.array_equal(reco[c].astype(np.int16).ravel(), g["planes"][off:off + n]), (W, H, qp, bd, c); off += n
+
+
+def test_deblocking_of_isp_transform_edges_against_the_reference_loop_filter():
+    """Transform edges inside and around ISP CUs (xDeblockCU 306-317, xSetMaxFilterLengthPQFromTransformSizes): CU tables with a forced random ispMode on most luma CUs,
+    filtered by the reference (tests/golden/make_golden.py deblock, forced_isp_rows) and by orc_deblock_table on the same unfiltered reconstruction."""
+    import importlib
+    pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+    g = np.load(os.path.join(G, "deblock.npz"))
+    L = O.lib()
+    L.orc_deblock_table.argtypes = [C.c_int] * 6 + [C.c_void_p, C.c_int] + [C.c_void_p] * 3
+    off = nisp = 0
+    for (W, H, qp, bd, seed) in g["forced_meta"]:
+        W, H, qp, bd = int(W), int(H), int(qp), int(bd)
+        pl = pkg.synth_frame(W, H, 0, bd, int(seed), chroma_texture=0.5); sp = pkg.slice_params(qp, bit_depth=bd)
+        _, cus, pre, _ = O.compress_frame(pl, W, H, sp, bit_depth=bd, tools=0x911)
+        rows = O.forced_isp_rows(cus, int(seed))
+        nisp += int((rows[:, 5] > 0).sum())
+        p = [np.ascontiguousarray(a.astype(np.int16)) for a in pre]
+        assert L.orc_deblock_table(W, H, bd, qp, int(sp["qp_c"][0]), int(sp["qp_c"][1]), rows.ctypes.data, len(rows), *[a.ctypes.data for a in p]) == 0
+        for c in range(3):
+            n = p[c].size
+            assert np.array_equal(p[c].ravel(), g["forced_planes"][off:off + n]), (W, H, qp, bd, c); off += n
+    assert nisp > 150
 
 
 def test_matrix_based_intra_prediction():
