@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--lmcs", type=str, default="analysis", choices=("analysis", "model"),
                     help="analysis: what the reference's picture analysis decides for this content: LMCS off for every 8-bit picture and for full-range 10-bit ones "
                          "(EL/EncReshape.cpp, see DESIGN.md); model: the slice carries a typical SDR model (limited-range luma), to time chroma residual scaling")
+    ap.add_argument("--wpp", action="store_true", help="cfg WaveFrontSynchro 1 (VVCX_TOOL_WPP): the CTU rows of a tile as streams one CTU behind the row above; with --tiles 1x1 this is "
+                    "the standard's own parallelism for the reference's one-tile pictures (its bitstream differs from the default cfg's)")
     ap.add_argument("--classifier", action="store_true",
                     help="BASELINE config 3 flavour: the fork's FAST_ALGORITHM with the shipped forest (forests/partition_qp32.npz) on the device")
     ap.add_argument("--chroma-texture", type=float, default=0.5,
@@ -144,6 +146,8 @@ def main():
         tc, tr = ctus_w, ctus_h
     else:
         tc, tr = map(int, args.tiles.lower().split("x"))
+    if args.wpp:
+        args.tools |= pkg.TOOL_WPP
     sp = pkg.slice_params(args.qp, bit_depth=args.bit_depth, dep_quant=bool(args.tools & 0x40))
     bd = args.bit_depth
     b_ctu = B_CTU_8BIT * (2 if bd == 10 else 1)
@@ -153,11 +157,12 @@ def main():
         forest = pkg.load_forest(os.path.join(ROOT, "reduce-complexity-for-intra-coding-of-vvc_amd", "forests", "partition_qp32.npz"))
     if args.frames == "auto":
         probe = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, device=dev, lib_path=args.lib, tools=args.tools, forest=forest)
-        args.frames = max(1, (4 * probe.resident_streams()) // (tc * tr))
+        streams_per_frame = tc * tr if not args.wpp else sum(len(set(ry for ry in range(ctus_h) if max(i for i in range(tr) if ry >= (i * ctus_h) // tr) == t)) for t in range(tr)) * tc
+        args.frames = max(1, (4 * probe.resident_streams()) // streams_per_frame)
         probe.close()
         # A long run (the round-end driver times 20 steps after 5 of warm-up inside a 600 s limit) gets a smaller batch so that all its steps fit
         # RUN_BUDGET_S at a conservative rate; never below two full waves of resident streams.  The batch is part of config.workload.
-        fit = int(RUN_BUDGET_S * BUDGET_CTUS_PER_S / ((args.steps + args.warmup) * tc * tr))
+        fit = int(RUN_BUDGET_S * BUDGET_CTUS_PER_S / ((args.steps + args.warmup) * ctus_w * ctus_h))
         args.frames = max(min(args.frames, fit), max(1, args.frames // 2))
     else:
         args.frames = int(args.frames)
@@ -227,7 +232,7 @@ def main():
                                 + ("" if args.tools & 8 else ", LFNST off") + ("" if args.tools & 0x40 else ", DepQuant off") + ("" if args.tools & 0x200 else ", JointCbCr off")
                                 + "; leaf operators, syntax and reconstruction are pinned to the reference (CommonLib + decoder + EncReshape), the search decisions (EncCu / EncModeCtrl / IntraSearch restatement) are pinned only through the decoder accepting and reconstructing the streams",
                        "tiling": ("one tile per CTU (every CTU an independent stream; the reference's cfg codes one tile per picture)" if (tc, tr) == (ctus_w, ctus_h)
-                                  else "%dx%d uniform tiles" % (tc, tr)),
+                                  else "%dx%d uniform tiles" % (tc, tr)) + (", WaveFrontSynchro 1: every CTU row of a tile is a stream that runs one CTU behind the row above" if args.wpp else ""),
                        "ctus_per_step": ctus_per_step, "parallelism": "1 workgroup per CTU stream over a work queue of resident slots, frames sharded over ranks"},
             "roofline": {"bound": "hbm", "limiter": "not HBM: VALU issue and the serial chains of one CTU stream (mode controller, trellis, CABAC estimator); see valu.issue_frac and DESIGN.md", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_split": traffic_split, "traffic_source": traffic_src, "kernel": "vvcx_compress_kernel_u8" if bd == 8 else "vvcx_compress_kernel_u16", "kernel_ms": 1e3 * avg_kernel_s,

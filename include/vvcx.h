@@ -31,7 +31,10 @@ enum {
   VVCX_TOOL_MRL = 1 << 0, VVCX_TOOL_MIP = 1 << 1, VVCX_TOOL_ISP = 1 << 2, VVCX_TOOL_LFNST = 1 << 3, VVCX_TOOL_MTS = 1 << 4,
   VVCX_TOOL_TS = 1 << 5, VVCX_TOOL_DEPQUANT = 1 << 6, VVCX_TOOL_RDOQ = 1 << 7, VVCX_TOOL_CCLM = 1 << 8,
   VVCX_TOOL_JCCR = 1 << 9, VVCX_TOOL_LMCS = 1 << 10, VVCX_TOOL_CU_REUSE = 1 << 11,
-  VVCX_TOOL_FAST = 1 << 12      /* the fork's FAST_ALGORITHM (CL/TypeDef.h:54-56): features + forest pick the one partition mode of a luma node */
+  VVCX_TOOL_FAST = 1 << 12,     /* the fork's FAST_ALGORITHM (CL/TypeDef.h:54-56): features + forest pick the one partition mode of a luma node */
+  VVCX_TOOL_WPP = 1 << 13       /* cfg WaveFrontSynchro 1 (off in encoder_intra.cfg): a CTU row of a tile starts from the contexts behind the first CTU of the row above
+                                 * (EL/EncSlice.cpp:1648-1661, 1801-1805), the CTU above-right is unavailable (CL/CodingStructure.cpp:1634-1657), one sub-stream per CTU row.
+                                 * The rows of a tile become streams of their own that run one CTU behind the row above */
 };
 
 /* ≙ the EncCfg/SPS fields EncCu::create/init read (EL/EncCu.cpp:167-236, CL/Slice.h PreCalcValues 2229-2275) */
@@ -204,6 +207,9 @@ int  vvcx_deblock_cu_table(int pic_w, int pic_h, int bit_depth, int qp, int qp_c
  * for that brick (CABACWriter::coding_tree_unit per CTU, end_of_ctu / end_of_slice terminating bins, byte alignment;
  * EL/EncSlice.cpp:1884-2006).  Requires cfg.emit_payload.  buf is host memory */
 int  vvcx_get_payload(vvcx_handle *h, int frame, int tile, uint8_t *buf, int cap, int *nbytes);
+/* the sub-streams inside the bytes vvcx_get_payload returns for a tile, in order: one (the tile), or with VVCX_TOOL_WPP one per CTU row of the tile - what the slice header's
+ * entry points are made of (EL/EncSlice.cpp:1982-1990 addSubstreamSize).  sizes may be NULL to query the count */
+int  vvcx_get_substream_sizes(vvcx_handle *h, int frame, int tile, int *sizes, int max_sizes, int *n_sizes);
 /* device time of the last compress launch, measured with HIP events on the launch stream (ms) */
 float vvcx_last_kernel_ms(const vvcx_handle *h);
 /* work counters of the last launch: [0] SATD-stage candidates, [1] full-RD TU evaluations, [2] RD pixels, [3] nodes */

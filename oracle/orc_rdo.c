@@ -97,7 +97,7 @@ struct orc_enc {
 /* ------------------------------------------------------------------------------------------------ */
 orc_enc *orc_create(const orc_cfg *cfg)
 {
-  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST | ORC_TOOL_JCCR | ORC_TOOL_TS | ORC_TOOL_ISP | ORC_TOOL_LMCS | ORC_TOOL_RDOQ)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, ISP, LFNST, MTS, TS, DepQuant (RDOQ only behind it: RDOQ-TS), LMCS, CCLM, JointCbCr, CU reuse, FAST)", cfg->tools); return 0; }
+  if (cfg->tools & ~(uint32_t) (ORC_TOOL_MRL | ORC_TOOL_CU_REUSE | ORC_TOOL_CCLM | ORC_TOOL_FAST | ORC_TOOL_MTS | ORC_TOOL_MIP | ORC_TOOL_DEPQUANT | ORC_TOOL_LFNST | ORC_TOOL_JCCR | ORC_TOOL_TS | ORC_TOOL_ISP | ORC_TOOL_LMCS | ORC_TOOL_RDOQ | ORC_TOOL_WPP)) { snprintf(g_err, sizeof g_err, "oracle: tool set 0x%x not built yet (built: MRL, MIP, ISP, LFNST, MTS, TS, DepQuant (RDOQ only behind it: RDOQ-TS), LMCS, CCLM, JointCbCr, CU reuse, FAST, WPP)", cfg->tools); return 0; }
   /* the plain quantiser's LFNST branch (CL/Quant.cpp:1054-1058) keeps buffer positions the decoder's LFNST conditions reject: the reference only
    * ever runs LFNST over DepQuant / RDOQ */
   if ((cfg->tools & ORC_TOOL_JCCR) && !(cfg->tools & ORC_TOOL_DEPQUANT)) { snprintf(g_err, sizeof g_err, "oracle: JointCbCr is built over DepQuant (tool set 0x%x)", cfg->tools); return 0; }
@@ -2102,6 +2102,13 @@ static void compress_ctu(orc_enc *e, int rx, int ry, orc_ctu_result *res)
   for (int i = 0; i < CACHE_ENTRIES; i++) e->cache[i].valid = 0;
   e->ctu_is_last = ry * e->ctus_w + rx == e->ctus_w * e->ctus_h - 1;
   orc_cabac ctuStart; orc_ctx_copy(&ctuStart, &e->cabac);
+  /* WaveFrontSynchro: getCURestricted hides every CU of a CTU column to the right (CL/CodingStructure.cpp:1634-1638); the only such CUs a CTU can reach are the ones above-right of
+   * it (reference samples of blocks on its top row): their availability marks are taken away for the duration of this CTU */
+  uint8_t wpp_keep[2][32]; int wpp_n = 0;
+  if ((e->cfg.tools & ORC_TOOL_WPP) && ry > 0 && rx + 1 < e->ctus_w) {
+    wpp_n = imin(32, e->uw - (rx + 1) * 32);
+    for (int k = 0; k < 2; k++) for (int i = 0; i < wpp_n; i++) { uint8_t *a = &e->avail[k][(ry * 32 - 1) * e->uw + (rx + 1) * 32 + i]; wpp_keep[k][i] = *a; *a = 0; }
+  }
   partitioner P; cs_sum best;
   part_init_ctu(&P, ctu, 0);
   compress_cu(e, &P, 0, ORC_MAX_DOUBLE, &best);
@@ -2114,8 +2121,16 @@ static void compress_ctu(orc_enc *e, int rx, int ry, orc_ctu_result *res)
   }
   orc_ctx_copy(&e->cabac, &ctuStart);
   advance_ctx_ctu(e, ctu);
+  for (int k = 0; k < 2; k++) for (int i = 0; i < wpp_n; i++) e->avail[k][(ry * 32 - 1) * e->uw + (rx + 1) * 32 + i] = wpp_keep[k][i];
 }
 
+/* WaveFrontSynchro: 0 = not the first CTU of a tile's CTU row (or WPP off), 1 = the first CTU of the tile's first row, 2 = of a later row (contexts come from the row above) */
+static int wpp_row_start(const orc_enc *e, int rx, int ry, int t)
+{
+  if (!(e->cfg.tools & ORC_TOOL_WPP)) return 0;
+  if (rx > 0 && e->ctu_tile[ry * e->ctus_w + rx - 1] == t) return 0;
+  return (ry > 0 && e->ctu_tile[(ry - 1) * e->ctus_w + rx] == t) ? 2 : 1;
+}
 int orc_compress_frame(orc_enc *e, orc_ctu_result *res, orc_cu *cus, int max_cus, int *n_cus) { return orc_compress_tiles(e, 0, e->cfg.tile_cols * e->cfg.tile_rows, res, cus, max_cus, n_cus); }
 /* the tiles [tile_first, tile_first + tile_count) only (tiles are independent streams: test runs spread them over processes); res rows and CU
  * table entries of the other tiles' CTUs are left out */
@@ -2127,8 +2142,14 @@ int orc_compress_tiles(orc_enc *e, int tile_first, int tile_count, orc_ctu_resul
   for (int t = tile_first; t < tile_first + tile_count; t++) {
     e->cur_tile = t % 255; e->cur_tile_idx = t;
     orc_ctx_init(e->sl.qp, e->cabac.s0, e->cabac.s1);       /* contexts reset at tile start (EL/EncSlice.cpp:1640-1647) */
-    for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++)
-      if (e->ctu_tile[ry * e->ctus_w + rx] == t) compress_ctu(e, rx, ry, &res[ry * e->ctus_w + rx]);
+    orc_cabac sync;                                          /* m_entropyCodingSyncContextState */
+    for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++) {
+      if (e->ctu_tile[ry * e->ctus_w + rx] != t) continue;
+      const int row_start = wpp_row_start(e, rx, ry, t);
+      if (row_start == 2) orc_ctx_copy(&e->cabac, &sync);    /* 1648-1661: reset, then the state after the first CTU of the row above (always in this tile here) */
+      compress_ctu(e, rx, ry, &res[ry * e->ctus_w + rx]);
+      if (row_start) orc_ctx_copy(&sync, &e->cabac);         /* 1801-1805 */
+    }
   }
   /* final CU table: CTU raster order, per CTU luma CUs then chroma CUs, each in raster order of their origin */
   int n = 0;
@@ -2160,9 +2181,9 @@ int orc_compress_tiles(orc_enc *e, int tile_first, int tile_count, orc_ctu_resul
  * ---------------------------------------------------------------------------------------------- */
 long orc_write_tiles(orc_enc *e, uint8_t *buf, long cap, int *sizes)
 {
-  const int ntiles = e->cfg.tile_cols * e->cfg.tile_rows;
+  const int ntiles = e->cfg.tile_cols * e->cfg.tile_rows, wpp = (e->cfg.tools & ORC_TOOL_WPP) != 0;
   long total = 0;
-  int last_rx = 0, last_ry = 0;                    /* last CTU of the slice in tile-scan order */
+  int last_rx = 0, last_ry = 0, nsub = 0;          /* last CTU of the slice in tile-scan order */
   for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++) if (e->ctu_tile[ry * e->ctus_w + rx] == ntiles - 1) { last_rx = rx; last_ry = ry; }
   for (int t = 0; t < ntiles; t++) {
     orc_arith aw; memset(&aw, 0, sizeof aw);
@@ -2171,17 +2192,29 @@ long orc_write_tiles(orc_enc *e, uint8_t *buf, long cap, int *sizes)
     orc_ctx_init(e->sl.qp, e->cabac.s0, e->cabac.s1);
     orc_arith_start(&aw);
     e->cabac.aw = &aw;
+    orc_cabac sync;
     for (int ry = 0; ry < e->ctus_h; ry++) for (int rx = 0; rx < e->ctus_w; rx++) {
       if (e->ctu_tile[ry * e->ctus_w + rx] != t) continue;
       const area_t ctu = { rx << 7, ry << 7, 128, 128 };
+      const int row_start = wpp_row_start(e, rx, ry, t);
+      if (row_start == 2) { orc_arith *keep = e->cabac.aw; orc_ctx_copy(&e->cabac, &sync); e->cabac.aw = keep; }      /* EL/EncSlice.cpp:1945-1960 */
       advance_ctx_ctu(e, ctu);
-      if (!(rx == last_rx && ry == last_ry)) orc_arith_trm(&aw, 0);     /* end_of_ctu: not the last CTU of the slice */
+      if (row_start) orc_ctx_copy(&sync, &e->cabac);                                                                   /* 1972-1976 */
+      /* the sub-stream ends with the tile or, under WPP, with the CTU row: end_of_subset_one_bit / end_of_brick_one_bit = terminating bin 1, finish, byte alignment -
+       * what the reference's DECODER reads at the end of every CTU row (DL/DecSlice.cpp:236-247).  The reference's encoder means to write it there too, but its row test
+       * `(ctuRsAddr + 1 % widthInCtus) == tileXPosInCtus` (EL/EncSlice.cpp:1980) binds as ctuRsAddr + (1 % widthInCtus) and never fires, so its own WPP streams do not decode;
+       * this follows the decoder (and the syntax of the standard) */
+      const int row_end = wpp && (rx + 1 == e->ctus_w || e->ctu_tile[ry * e->ctus_w + rx + 1] != t);
+      const int tile_end = (rx + 1 == e->ctus_w || e->ctu_tile[ry * e->ctus_w + rx + 1] != t) && (ry + 1 == e->ctus_h || e->ctu_tile[(ry + 1) * e->ctus_w + rx] != t);
+      if (!(rx == last_rx && ry == last_ry)) orc_arith_trm(&aw, 0);     /* end_of_ctu (EL/CABACWriter.cpp:2118-2141): not the last CTU of the slice */
+      if (!row_end && !tile_end) continue;
+      orc_arith_trm(&aw, 1); orc_arith_finish(&aw);
+      orc_bs_write(&aw, 1, 1); while (aw.bit_n) orc_bs_write(&aw, 0, 1);   /* writeByteAlignment */
+      if (aw.n > aw.cap) { e->cabac.aw = 0; return -1; }
+      sizes[nsub++] = (int) aw.n; total += (long) aw.n;
+      if (!tile_end) { memset(&aw, 0, sizeof aw); aw.out = buf + total; aw.cap = (size_t) (cap - total); orc_arith_start(&aw); }
     }
-    orc_arith_trm(&aw, 1); orc_arith_finish(&aw);                        /* end_of_slice (brick) */
-    orc_bs_write(&aw, 1, 1); while (aw.bit_n) orc_bs_write(&aw, 0, 1);   /* writeByteAlignment */
     e->cabac.aw = 0;
-    if (aw.n > aw.cap) return -1;
-    sizes[t] = (int) aw.n; total += (long) aw.n;
   }
   return total;
 }

@@ -40,7 +40,9 @@ enum {
   ORC_TOOL_MIP   = 1 << 1, ORC_TOOL_ISP = 1 << 2, ORC_TOOL_LFNST = 1 << 3, ORC_TOOL_MTS = 1 << 4,
   ORC_TOOL_TS    = 1 << 5, ORC_TOOL_DEPQUANT = 1 << 6, ORC_TOOL_RDOQ = 1 << 7, ORC_TOOL_CCLM = 1 << 8,
   ORC_TOOL_JCCR  = 1 << 9, ORC_TOOL_LMCS = 1 << 10 /* LMCS allowed: the slice's model (orc_slice) decides */, ORC_TOOL_CU_REUSE = 1 << 11,
-  ORC_TOOL_FAST  = 1 << 12  /* the fork's FAST_ALGORITHM: features + forest decide the one partition mode a luma node tries (needs orc_set_forest) */
+  ORC_TOOL_FAST  = 1 << 12, /* the fork's FAST_ALGORITHM: features + forest decide the one partition mode a luma node tries (needs orc_set_forest) */
+  ORC_TOOL_WPP   = 1 << 13  /* cfg WaveFrontSynchro 1 (entropy_coding_sync): every CTU row of a tile starts from the contexts left by the first CTU of the row above, the
+                             * CTU above-right is not available (EL/EncSlice.cpp:1648-1661,1801-1805; CL/CodingStructure.cpp:1634-1657) */
 };
 
 typedef struct {
@@ -112,7 +114,7 @@ int      orc_lmcs_inverse_reco(orc_enc *e);
 const char *orc_last_error(void);
 /* work counters for the bench's diagnostic model */
 int      orc_arith_encode(int qp, const int32_t *ops, int nops, uint8_t *out, int cap);
-long     orc_write_tiles(orc_enc *e, uint8_t *buf, long cap, int *sizes);   /* slice_data payload per tile (after orc_compress_frame) */
+long     orc_write_tiles(orc_enc *e, uint8_t *buf, long cap, int *sizes);   /* slice_data payload per tile (after orc_compress_frame); with ORC_TOOL_WPP one sub-stream per CTU row of every tile */
 int      orc_get_levels(orc_enc *e, int16_t *const lev[3]);
 /* FAST_ALGORITHM (orc_fast.c): the flattened random forest (sklearn tree_ arrays; value = n_nodes x n_classes leaf distributions;
  * classes = label of each column, 0 no split, 1 QT, 2 BT_H, 3 BT_V, 4 TT_H, 5 TT_V like BIN/TEST.py's return value) */

@@ -1,5 +1,5 @@
 """MI355X-native VVC intra CU-partition RDO path.  Host-side Python mirror of include/vvcx.h."""
-from .vvcx import VvcxEncoder, VvcxError, load_library, TOOL_MRL, TOOL_MIP, TOOL_LFNST, TOOL_MTS, TOOL_JCCR, TOOL_DEPQUANT, TOOL_CU_REUSE, TOOL_CCLM, TOOL_FAST, TOOL_TS, TOOL_RDOQ, TOOL_ISP, TOOL_LMCS, TOOLS_DEFAULT  # noqa: F401
+from .vvcx import VvcxEncoder, VvcxError, load_library, TOOL_MRL, TOOL_MIP, TOOL_LFNST, TOOL_MTS, TOOL_JCCR, TOOL_DEPQUANT, TOOL_CU_REUSE, TOOL_CCLM, TOOL_FAST, TOOL_TS, TOOL_RDOQ, TOOL_ISP, TOOL_LMCS, TOOL_WPP, TOOLS_DEFAULT  # noqa: F401
 from .synth import synth_frame, slice_params  # noqa: F401
 from .vvcx import derive_slice  # noqa: F401
 from .sharding import frames_of_rank, timed_steps, gather_ctu_results, gather_payloads, max_over_ranks  # noqa: F401

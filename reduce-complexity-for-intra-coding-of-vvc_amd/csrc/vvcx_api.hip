@@ -60,7 +60,13 @@ struct vvcx_handle {
   std::vector<std::vector<int>> tile_ctus;      // CTUs of each tile in coding (raster-in-tile) order
   int n_frames;
   std::vector<VxFrameDev> frames_h;
-  std::vector<int> next_idx;                    // per (frame, tile): how many CTUs of the stream are done
+  // sub-streams: the units the search runs as independent (or, under WPP, lagged) sequences of CTUs and the arithmetic coder writes as one byte string each - a tile, or
+  // with VVCX_TOOL_WPP one CTU row of a tile (EL/EncSlice.cpp:1972-1990).  Per frame: nsub of them, numbered tile by tile, row by row
+  int nsub;
+  std::vector<int> ctu_sub, sub_tile, sub_above, tile_sub0, tile_nsub;      // sub-stream of each CTU; its tile; the sub-stream of the CTU row above in the same tile (-1: none); per tile: first sub-stream, count
+  std::vector<std::vector<int>> sub_ctus;       // CTUs of each sub-stream in coding order
+  int32_t *wpp_progress_d; uint16_t *wpp_sync_d;  // WPP: CTUs finished per (frame, sub-stream); the contexts behind the first CTU of each (m_entropyCodingSyncContextState)
+  std::vector<int> next_idx;                    // per (frame, sub-stream): how many CTUs of the stream are done
   // device memory
   VxFrameDev *frames_d; int16_t *lev_d; VxUnit *units_d; uint16_t *stream_ctx_d;
   uint8_t *scratch_d; size_t scratch_cap;
@@ -84,7 +90,7 @@ struct vvcx_handle {
 
 #define VVCX_PAYLOAD_BYTES_PER_CTU 32768u
 static const uint32_t kBuiltTools = VVCX_TOOL_ISP | VVCX_TOOL_MRL | VVCX_TOOL_MIP | VVCX_TOOL_LFNST | VVCX_TOOL_MTS | VVCX_TOOL_JCCR | VVCX_TOOL_DEPQUANT | VVCX_TOOL_CU_REUSE | VVCX_TOOL_CCLM | VVCX_TOOL_FAST |
-                                    VVCX_TOOL_TS | VVCX_TOOL_RDOQ | VVCX_TOOL_LMCS;
+                                    VVCX_TOOL_TS | VVCX_TOOL_RDOQ | VVCX_TOOL_LMCS | VVCX_TOOL_WPP;
 
 // Quantizer::initQuantBlock (CL/DepQuant.cpp:694-739) for blocks with log2 w + log2 h = lsum: the quantiser's shift / scale / thresholds and the fixed-point
 // distortion normalisation, which the reference derives in fp64 from lambda.  qp: what QpParam hands over (with QpBDOffset).
@@ -133,6 +139,9 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
     return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_ISP needs VVCX_TOOL_DEPQUANT, VVCX_TOOL_LFNST and VVCX_TOOL_MTS (tool set 0x%x)", cfg->tools);
   if ((cfg->tools & VVCX_TOOL_LMCS) && !(cfg->tools & VVCX_TOOL_DEPQUANT)) return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_LMCS needs VVCX_TOOL_DEPQUANT (tool set 0x%x)", cfg->tools);
   if ((cfg->tools & VVCX_TOOL_JCCR) && !(cfg->tools & VVCX_TOOL_DEPQUANT)) return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_JCCR needs VVCX_TOOL_DEPQUANT (tool set 0x%x)", cfg->tools);
+  // the classifier's features read the CUs above-right and below-left of a node through the unrestricted getCU (EL/EncCu.cpp:1126-1217): with the CTU rows running as lagged
+  // streams whether those exist yet would depend on timing
+  if ((cfg->tools & VVCX_TOOL_WPP) && (cfg->tools & VVCX_TOOL_FAST)) return fail(VVCX_ERR_UNSUPPORTED, "VVCX_TOOL_WPP cannot be combined with VVCX_TOOL_FAST (tool set 0x%x)", cfg->tools);
   if (cfg->ctu_size != 128 || !cfg->dual_tree) return fail(VVCX_ERR_UNSUPPORTED, "only CTUSize 128 with DualITree 1");
   if ((cfg->pic_w & 7) || (cfg->pic_h & 7) || cfg->pic_w <= 0 || cfg->pic_h <= 0) return fail(VVCX_ERR_ARG, "picture size must be a positive multiple of 8");
   if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return fail(VVCX_ERR_UNSUPPORTED, "bit depth %d", cfg->bit_depth);
@@ -153,6 +162,24 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
     h->ctu_tile[(size_t) ry * h->ctus_w + rx] = t;
     h->tile_ctus[(size_t) t].push_back(ry * h->ctus_w + rx);
   }
+  {
+    const bool wpp = (cfg->tools & VVCX_TOOL_WPP) != 0;
+    h->ctu_sub.assign(h->ctu_tile.size(), 0); h->tile_sub0.assign((size_t) h->ntiles, 0); h->tile_nsub.assign((size_t) h->ntiles, 1);
+    h->sub_ctus.clear(); h->sub_tile.clear(); h->sub_above.clear();
+    for (int t = 0; t < h->ntiles; t++) {
+      h->tile_sub0[(size_t) t] = (int) h->sub_ctus.size();
+      int prev_row = -1, n = 0;
+      for (int a : h->tile_ctus[(size_t) t]) {
+        const int row = a / h->ctus_w;
+        if (n == 0 || (wpp && row != prev_row)) { h->sub_ctus.push_back(std::vector<int>()); h->sub_tile.push_back(t); h->sub_above.push_back(n ? (int) h->sub_ctus.size() - 2 : -1); n++; }
+        prev_row = row;
+        h->sub_ctus.back().push_back(a); h->ctu_sub[(size_t) a] = (int) h->sub_ctus.size() - 1;
+      }
+      h->tile_nsub[(size_t) t] = n;
+    }
+    h->nsub = (int) h->sub_ctus.size();
+  }
+  h->wpp_progress_d = nullptr; h->wpp_sync_d = nullptr;
   DevGuard guard(cfg->device);
   if (!guard.ok) { delete h; return fail(VVCX_ERR_DEVICE, "hipSetDevice(%d) failed", cfg->device); }
   const int wc = cfg->pic_w >> 1, hc = cfg->pic_h >> 1;
@@ -166,14 +193,15 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   const int F = cfg->max_frames;
   if (hipMalloc((void **) &h->frames_d, sizeof(VxFrameDev) * F) != hipSuccess || hipMalloc((void **) &h->lev_d, h->lev_frame * 2 * F) != hipSuccess ||
       hipMalloc((void **) &h->units_d, h->units_frame * sizeof(VxUnit) * F) != hipSuccess ||
-      hipMalloc((void **) &h->stream_ctx_d, (size_t) F * h->ntiles * 2 * VXD_NUM_CTX * 2) != hipSuccess ||
+      hipMalloc((void **) &h->stream_ctx_d, (size_t) F * h->nsub * 2 * VXD_NUM_CTX * 2) != hipSuccess ||
+      ((cfg->tools & VVCX_TOOL_WPP) && (hipMalloc((void **) &h->wpp_progress_d, (size_t) F * h->nsub * 4) != hipSuccess || hipMalloc((void **) &h->wpp_sync_d, (size_t) F * h->nsub * 2 * VXD_NUM_CTX * 2) != hipSuccess)) ||
       hipMalloc((void **) &h->counters_d, 56 * sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc((void **) &h->dq_d, 17 * 96 * sizeof(VxDqConst)) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
   if (cfg->emit_payload) {                       // VVCX_PAYLOAD_BYTES_PER_CTU per CTU: a CTU of 8-bit video at QP >= 17 stays far below (raw samples are 24 KB)
-    const size_t nstream = (size_t) F * h->ntiles;
+    const size_t nstream = (size_t) F * h->nsub;
     h->payload_off.resize(nstream); h->payload_cap.resize(nstream);
     uint64_t off = 0;
-    for (size_t s2 = 0; s2 < nstream; s2++) { const uint32_t cap = (uint32_t) h->tile_ctus[s2 % h->ntiles].size() * VVCX_PAYLOAD_BYTES_PER_CTU; h->payload_off[s2] = off; h->payload_cap[s2] = cap; off += cap; }
+    for (size_t s2 = 0; s2 < nstream; s2++) { const uint32_t cap = (uint32_t) h->sub_ctus[s2 % (size_t) h->nsub].size() * VVCX_PAYLOAD_BYTES_PER_CTU; h->payload_off[s2] = off; h->payload_cap[s2] = cap; off += cap; }
     if (hipMalloc((void **) &h->payload_d, off) != hipSuccess || hipMalloc((void **) &h->payload_off_d, nstream * 8) != hipSuccess ||
         hipMalloc((void **) &h->payload_cap_d, nstream * 4) != hipSuccess || hipMalloc(&h->arith_d, nstream * 32) != hipSuccess) { vvcx_destroy(h); return fail(VVCX_ERR_DEVICE, "device allocation failed"); }
     (void) hipMemcpy(h->payload_off_d, h->payload_off.data(), nstream * 8, hipMemcpyHostToDevice);
@@ -188,7 +216,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
 extern "C" void vvcx_destroy(vvcx_handle *h)
 {
   if (!h) return;
-  (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d);
+  (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d); (void) hipFree(h->wpp_progress_d); (void) hipFree(h->wpp_sync_d);
   (void) hipFree(h->payload_d); (void) hipFree(h->payload_off_d); (void) hipFree(h->payload_cap_d); (void) hipFree(h->arith_d);
   (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
   (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d); (void) hipFree(h->dq_d); (void) hipFree(h->lmcs_lut_d); (void) hipFree(h->lmcs_org_d);
@@ -389,8 +417,8 @@ extern "C" int vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n)
   }
   HIPCHK(hipMemset(h->units_d, 0, h->units_frame * sizeof(VxUnit) * (size_t) n));
   HIPCHK(hipMemset(h->lev_d, 0, h->lev_frame * 2 * (size_t) n));
-  std::vector<uint16_t> ctx((size_t) n * h->ntiles * 2 * VXD_NUM_CTX);
-  for (size_t s = 0; s < (size_t) n * h->ntiles; s++) ctx_init_islice(h->sl.qp, &ctx[s * 2 * VXD_NUM_CTX], &ctx[s * 2 * VXD_NUM_CTX + VXD_NUM_CTX]);
+  std::vector<uint16_t> ctx((size_t) n * h->nsub * 2 * VXD_NUM_CTX);
+  for (size_t s = 0; s < (size_t) n * h->nsub; s++) ctx_init_islice(h->sl.qp, &ctx[s * 2 * VXD_NUM_CTX], &ctx[s * 2 * VXD_NUM_CTX + VXD_NUM_CTX]);
   HIPCHK(hipMemcpy(h->stream_ctx_d, ctx.data(), ctx.size() * 2, hipMemcpyHostToDevice));
   {
     // activity per CTU (read back here: binding is synchronous anyway); a failure only costs the ordering
@@ -406,7 +434,8 @@ extern "C" int vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n)
     }
   }
   h->n_frames = n;
-  h->next_idx.assign((size_t) n * h->ntiles, 0);
+  if (h->wpp_progress_d) HIPCHK(hipMemset(h->wpp_progress_d, 0, (size_t) n * h->nsub * 4));
+  h->next_idx.assign((size_t) n * h->nsub, 0);
   return VVCX_OK;
 }
 
@@ -435,21 +464,22 @@ extern "C" int vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int 
   hipStream_t stream = (hipStream_t) hip_stream;
   const int nctu = h->ctus_w * h->ctus_h;
   // group tasks by stream, keeping their order; validate that every stream continues in tile raster order
-  std::vector<std::vector<int>> by_stream((size_t) h->n_frames * h->ntiles);
+  std::vector<std::vector<int>> by_stream((size_t) h->n_frames * h->nsub);
   for (int i = 0; i < n; i++) {
     if (tasks[i].frame < 0 || tasks[i].frame >= h->n_frames || tasks[i].ctu_rs_addr < 0 || tasks[i].ctu_rs_addr >= nctu) return fail(VVCX_ERR_ARG, "task %d out of range", i);
-    by_stream[(size_t) tasks[i].frame * h->ntiles + h->ctu_tile[(size_t) tasks[i].ctu_rs_addr]].push_back(i);
+    by_stream[(size_t) tasks[i].frame * h->nsub + h->ctu_sub[(size_t) tasks[i].ctu_rs_addr]].push_back(i);
   }
   std::vector<VxStreamDesc> &sd = h->pend_sd; std::vector<int32_t> &task_ctu = h->pend_task_ctu; std::vector<int> &task_src = h->pend_src;
   sd.clear(); task_ctu.clear(); task_src.clear();
   std::vector<int> &new_next = h->pend_next; new_next = h->next_idx;
   for (size_t s = 0; s < by_stream.size(); s++) {
     if (by_stream[s].empty()) continue;
-    const int tile = (int) (s % h->ntiles);
-    VxStreamDesc d; d.frame = (int) (s / h->ntiles); d.tile = tile; d.first_task = (int) task_ctu.size(); d.n_tasks = (int) by_stream[s].size();
-    d.done_before = h->next_idx[s]; d.tile_ctus = (int) h->tile_ctus[(size_t) tile].size();
+    const int sub = (int) (s % (size_t) h->nsub), tile = h->sub_tile[(size_t) sub];
+    VxStreamDesc d; d.frame = (int) (s / (size_t) h->nsub); d.tile = tile; d.first_task = (int) task_ctu.size(); d.n_tasks = (int) by_stream[s].size();
+    d.done_before = h->next_idx[s]; d.tile_ctus = (int) h->sub_ctus[(size_t) sub].size();
+    d.sub = sub; d.above = (h->cfg.tools & VVCX_TOOL_WPP) ? h->sub_above[(size_t) sub] : -1;
     for (int i : by_stream[s]) {
-      const std::vector<int> &order = h->tile_ctus[(size_t) tile];
+      const std::vector<int> &order = h->sub_ctus[(size_t) sub];
       if (new_next[s] >= (int) order.size() || order[(size_t) new_next[s]] != tasks[i].ctu_rs_addr)
         return fail(VVCX_ERR_STATE, "task %d (frame %d, CTU %d) is not the next CTU of its stream", i, tasks[i].frame, tasks[i].ctu_rs_addr);
       new_next[s]++;
@@ -457,14 +487,25 @@ extern "C" int vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int 
     }
     sd.push_back(d);
   }
-  // longest first: the workgroups take the streams from the queue in this order; results are addressed through first_task, so the order is free
+  // WPP: a CTU row waits, CTU by CTU, for the row above it; whatever it waits for must be coded already or be part of this launch
+  if (h->cfg.tools & VVCX_TOOL_WPP)
+    for (size_t s = 0; s < by_stream.size(); s++) {
+      const int above = h->sub_above[s % (size_t) h->nsub];
+      if (by_stream[s].empty() || above < 0) continue;
+      const size_t sa = s - (s % (size_t) h->nsub) + (size_t) above;
+      if (new_next[sa] < new_next[s]) return fail(VVCX_ERR_STATE, "WPP: CTU row (sub-stream %d) of frame %d would wait for CTUs of the row above that are neither coded nor submitted", (int) (s % (size_t) h->nsub), (int) (s / (size_t) h->nsub));
+    }
+  // longest first: the workgroups take the streams from the queue in this order; results are addressed through first_task, so the order is free.  Under WPP the rows of a
+  // tile stay together and in order (a row's workgroup waits for the row above, which must therefore have been taken from the queue before it): the key is the tile's
   {
     std::vector<uint64_t> key(sd.size());
+    std::vector<uint64_t> group((size_t) h->n_frames * h->ntiles, 0);
     for (size_t i = 0; i < sd.size(); i++) {
       uint64_t a = 0;
       for (int t = 0; t < sd[i].n_tasks; t++) a += h->activity.empty() ? 0 : h->activity[(size_t) sd[i].frame * nctu + (size_t) task_ctu[(size_t) sd[i].first_task + t]];
-      key[i] = a;
+      key[i] = a; group[(size_t) sd[i].frame * h->ntiles + sd[i].tile] += a;
     }
+    if (h->cfg.tools & VVCX_TOOL_WPP) for (size_t i = 0; i < sd.size(); i++) key[i] = group[(size_t) sd[i].frame * h->ntiles + sd[i].tile];
     std::vector<size_t> order(sd.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key[a] > key[b]; });
@@ -504,7 +545,7 @@ extern "C" int vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int 
   p.sqrt_lambda_fp = sqrt(h->sl.lambda) * (1.0 / (double) (1 << 15));     // EL/IntraSearch.cpp:297
   p.frames = h->frames_d; p.streams = h->streams_d; p.task_ctu = h->task_ctu_d; p.results = h->results_d; p.stream_ctx = h->stream_ctx_d;
   p.payload = h->payload_d; p.payload_off = h->payload_off_d; p.payload_cap = h->payload_cap_d; p.arith_state = h->arith_d;
-  p.scratch = h->scratch_d; p.scratch_per_stream = per_stream; p.counters = h->counters_d; p.ntiles = h->ntiles;
+  p.scratch = h->scratch_d; p.scratch_per_stream = per_stream; p.counters = h->counters_d; p.ntiles = h->ntiles; p.nsub = h->nsub; p.wpp_progress = h->wpp_progress_d; p.wpp_sync = h->wpp_sync_d;
   p.f_node = h->f_node_d; p.f_value = h->f_value_d; p.f_root = h->f_root_d; p.f_ntrees = h->f_ntrees; p.f_nclasses = h->f_nclasses;
   for (int c = 0; c < 8; c++) p.f_classes[c] = h->f_classes[c];
   p.n_streams = ns;
@@ -612,9 +653,9 @@ extern "C" int vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out, 
   if (!h || !out) return fail(VVCX_ERR_ARG, "null argument");
   const int nctu = h->ctus_w * h->ctus_h;
   std::vector<vvcx_ctu_task> tasks; std::vector<int> dst;
-  for (int f = 0; f < h->n_frames; f++) for (int t = 0; t < h->ntiles; t++) {
-    const std::vector<int> &order = h->tile_ctus[(size_t) t];
-    for (size_t k = (size_t) h->next_idx[(size_t) f * h->ntiles + t]; k < order.size(); k++) { vvcx_ctu_task tk; tk.frame = f; tk.ctu_rs_addr = order[k]; tasks.push_back(tk); dst.push_back(f * nctu + order[k]); }
+  for (int f = 0; f < h->n_frames; f++) for (int t = 0; t < h->nsub; t++) {
+    const std::vector<int> &order = h->sub_ctus[(size_t) t];
+    for (size_t k = (size_t) h->next_idx[(size_t) f * h->nsub + t]; k < order.size(); k++) { vvcx_ctu_task tk; tk.frame = f; tk.ctu_rs_addr = order[k]; tasks.push_back(tk); dst.push_back(f * nctu + order[k]); }
   }
   std::vector<vvcx_ctu_result> tmp(tasks.size());
   const int rc = vvcx_compress_ctus(h, tasks.data(), (int) tasks.size(), tmp.data(), hip_stream);
@@ -631,7 +672,7 @@ extern "C" int vvcx_lmcs_inverse_reco(vvcx_handle *h, void *hip_stream)
   if (!h->n_frames || !h->have_slice || !h->lmcs_on) return fail(VVCX_ERR_STATE, "no bound frames coded with an LMCS slice");
   if (h->lmcs_inverted) return fail(VVCX_ERR_STATE, "the reconstruction has already been mapped back");
   for (size_t i = 0; i < h->next_idx.size(); i++)
-    if (h->next_idx[i] != (int) h->tile_ctus[i % (size_t) h->ntiles].size()) return fail(VVCX_ERR_STATE, "every CTU of the bound pictures must be coded first (intra prediction reads mapped neighbours)");
+    if (h->next_idx[i] != (int) h->sub_ctus[i % (size_t) h->nsub].size()) return fail(VVCX_ERR_STATE, "every CTU of the bound pictures must be coded first (intra prediction reads mapped neighbours)");
   HIPCHK(hipSetDevice(h->cfg.device));
   hipStream_t stream = (hipStream_t) hip_stream;
   const unsigned blocks = (unsigned) (((size_t) h->cfg.pic_w * h->cfg.pic_h + VXD_NT - 1) / VXD_NT);
@@ -654,7 +695,7 @@ extern "C" int vvcx_deblock_bound_frames(vvcx_handle *h, int beta_offset_div2, i
   if (!h) return fail(VVCX_ERR_ARG, "null handle");
   if (!h->n_frames || !h->have_slice) return fail(VVCX_ERR_STATE, "no bound frames / slice");
   for (size_t i = 0; i < h->next_idx.size(); i++)
-    if (h->next_idx[i] != (int) h->tile_ctus[i % (size_t) h->ntiles].size()) return fail(VVCX_ERR_STATE, "deblocking needs every CTU of the bound pictures coded (frame %d tile %d is not)", (int) (i / (size_t) h->ntiles), (int) (i % (size_t) h->ntiles));
+    if (h->next_idx[i] != (int) h->sub_ctus[i % (size_t) h->nsub].size()) return fail(VVCX_ERR_STATE, "deblocking needs every CTU of the bound pictures coded (frame %d tile %d is not)", (int) (i / (size_t) h->nsub), h->sub_tile[i % (size_t) h->nsub]);
   if (h->lmcs_on && !h->lmcs_inverted) return fail(VVCX_ERR_STATE, "LMCS slice: vvcx_lmcs_inverse_reco first (the loop filters work in the original domain)");
   if (beta_offset_div2 < -6 || beta_offset_div2 > 6 || tc_offset_div2 < -6 || tc_offset_div2 > 6) return fail(VVCX_ERR_ARG, "deblocking offsets outside -6..6");
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -1132,21 +1173,41 @@ extern "C" int vvcx_transform_skip_batch(const int16_t *resi, int w, int h, int 
   return VVCX_OK;
 }
 
-// slice_data() payload of one tile of a bound frame (≙ the sub-stream EncSlice::encodeSlice hands to the NAL writer, EL/EncSlice.cpp:1884-2006)
+// slice_data() payload of one tile of a bound frame (≙ the sub-streams EncSlice::encodeSlice hands to the NAL writer, EL/EncSlice.cpp:1884-2006): one byte string, or with
+// VVCX_TOOL_WPP the byte strings of the tile's CTU rows back to back (sizes: vvcx_get_substream_sizes)
+static int payload_of_tile(vvcx_handle *h, int frame, int tile, uint8_t *buf, int cap, int *nbytes, int *sizes, int max_sizes, int *n_sizes)
+{
+  if (!h || frame < 0 || frame >= h->n_frames || tile < 0 || tile >= h->ntiles) return fail(VVCX_ERR_ARG, "bad argument");
+  if (!h->payload_d) return fail(VVCX_ERR_STATE, "handle was created without emit_payload");
+  DevGuard guard(h->cfg.device);
+  const int sub0 = h->tile_sub0[(size_t) tile], ns = h->tile_nsub[(size_t) tile];
+  if (n_sizes) *n_sizes = ns;
+  if (sizes && max_sizes < ns) return fail(VVCX_ERR_ARG, "room for %d sub-stream sizes, the tile has %d", max_sizes, ns);
+  size_t total = 0;
+  for (int k = 0; k < ns; k++) {
+    const size_t s = (size_t) frame * h->nsub + (size_t) (sub0 + k);
+    if (h->next_idx[s] != (int) h->sub_ctus[(size_t) (sub0 + k)].size()) return fail(VVCX_ERR_STATE, "tile %d of frame %d is not completely coded yet", tile, frame);
+    uint32_t st[8];
+    HIPCHK(hipMemcpy(st, (const uint8_t *) h->arith_d + s * 32, 32, hipMemcpyDeviceToHost));
+    const uint32_t n = st[7];                        // Arith::n
+    if (n > h->payload_cap[s]) return fail(VVCX_ERR_STATE, "payload of tile %d exceeds the %u bytes reserved", tile, h->payload_cap[s]);
+    if (sizes) sizes[k] = (int) n;
+    if (buf && total + n <= (size_t) cap) HIPCHK(hipMemcpy(buf + total, h->payload_d + h->payload_off[s], n, hipMemcpyDeviceToHost));
+    total += n;
+  }
+  if (nbytes) *nbytes = (int) total;
+  if (buf && total > (size_t) cap) return fail(VVCX_ERR_ARG, "buffer too small: %zu bytes needed", total);
+  return VVCX_OK;
+}
 extern "C" int vvcx_get_payload(vvcx_handle *h, int frame, int tile, uint8_t *buf, int cap, int *nbytes)
 {
   NOT_PENDING(h);
-  if (!h || !buf || !nbytes || frame < 0 || frame >= h->n_frames || tile < 0 || tile >= h->ntiles) return fail(VVCX_ERR_ARG, "bad argument");
-  if (!h->payload_d) return fail(VVCX_ERR_STATE, "handle was created without emit_payload");
-  DevGuard guard(h->cfg.device);
-  const size_t s = (size_t) frame * h->ntiles + tile;
-  if (h->next_idx[s] != (int) h->tile_ctus[(size_t) tile].size()) return fail(VVCX_ERR_STATE, "tile %d of frame %d is not completely coded yet", tile, frame);
-  uint32_t st[8];
-  HIPCHK(hipMemcpy(st, (const uint8_t *) h->arith_d + s * 32, 32, hipMemcpyDeviceToHost));
-  const uint32_t n = st[7];                        // Arith::n
-  if (n > h->payload_cap[s]) return fail(VVCX_ERR_STATE, "payload of tile %d exceeds the %u bytes reserved", tile, h->payload_cap[s]);
-  *nbytes = (int) n;
-  if ((int) n > cap) return fail(VVCX_ERR_ARG, "buffer too small: %u bytes needed", n);
-  HIPCHK(hipMemcpy(buf, h->payload_d + h->payload_off[s], n, hipMemcpyDeviceToHost));
-  return VVCX_OK;
+  if (!buf || !nbytes) return fail(VVCX_ERR_ARG, "bad argument");
+  return payload_of_tile(h, frame, tile, buf, cap, nbytes, nullptr, 0, nullptr);
+}
+extern "C" int vvcx_get_substream_sizes(vvcx_handle *h, int frame, int tile, int *sizes, int max_sizes, int *n_sizes)
+{
+  NOT_PENDING(h);
+  if (!n_sizes) return fail(VVCX_ERR_ARG, "bad argument");
+  return payload_of_tile(h, frame, tile, nullptr, 0, nullptr, sizes, max_sizes, n_sizes);
 }

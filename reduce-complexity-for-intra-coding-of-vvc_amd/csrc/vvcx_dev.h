@@ -40,7 +40,8 @@ struct VxFrameDev {         // one bound picture
 
 struct VxLeafPred { int32_t comp, x, y, w, h, mode, mrl; };      // same layout as vvcx_pred_case
 
-struct VxStreamDesc { int32_t frame, tile, first_task, n_tasks, done_before /* CTUs of the tile coded by earlier launches */, tile_ctus; };
+struct VxStreamDesc { int32_t frame, tile, first_task, n_tasks, done_before /* CTUs of the sub-stream coded by earlier launches */, tile_ctus /* CTUs of the sub-stream */;
+                      int32_t sub /* sub-stream of the frame: the tile, or under WPP the CTU row of the tile */, above /* WPP: sub-stream of the row above in the tile, -1: none */; };
 
 struct VxCtuRes { uint64_t dist, bits; double cost; int32_t n_cu, pad; };
 
@@ -63,11 +64,13 @@ struct VxParams {
   const VxStreamDesc *streams;
   const int32_t      *task_ctu;      // CTU raster address per task
   VxCtuRes           *results;       // per task
-  uint16_t           *stream_ctx;    // per (frame*ntiles+tile): 2*VXD_NUM_CTX states carried CTU -> CTU
+  uint16_t           *stream_ctx;    // per (frame*nsub+sub): 2*VXD_NUM_CTX states carried CTU -> CTU
   uint8_t            *scratch;       // per workgroup of the launch (= per resident stream slot)
   uint64_t            scratch_per_stream;
   unsigned long long *counters;      // 4 global work counters
-  int32_t             ntiles;
+  int32_t             ntiles, nsub;  // tiles / sub-streams per frame (equal without WPP)
+  int32_t            *wpp_progress;  // WPP: per (frame*nsub+sub) the CTUs of the row that are finished and visible
+  uint16_t           *wpp_sync;      // WPP: per (frame*nsub+sub) the contexts behind the row's first CTU
   // slice_data writer (optional): per (frame, tile) byte range of the payload buffer and the persistent coder state (32 B each)
   uint8_t            *payload;
   const uint64_t     *payload_off;

@@ -55,6 +55,7 @@ enum { ETM_INTRA, ETM_POST_DONT_SPLIT, ETM_SPLIT_QT, ETM_SPLIT_BT_H, ETM_SPLIT_B
 #define TOOL_CCLM (1u << 8)
 #define TOOL_JCCR (1u << 9)
 #define TOOL_FAST (1u << 12)
+#define TOOL_WPP (1u << 13)
 enum { LM_CHROMA = 67, MDLM_L = 68, MDLM_T = 69 };
 enum { PLANAR = 0, DC = 1, HOR = 18, DIA = 34, VER = 50, VDIA = 66, DM_CHROMA = 70 };
 enum { OP_NONE, OP_DONE, OP_LUMA_PREP, OP_STAGE_A, OP_STAGE_B, OP_CHROMA_RD, OP_SAVE_INTRA, OP_SAVE_PIC, OP_RESTORE_PIC,
@@ -1259,6 +1260,9 @@ __device__ __noinline__ void build_refs(const VxParams &p_, const VxFrameDev &fd
     else { ux = x + (tid - totalLeft - 1) * unit; uy = y - 1; }
     int a = 0;
     if (ux >= 0 && uy >= 0 && ux < W && uy < H) a = fd.units[ch][(uy >> ul) * p.uw + (ux >> ul)].tag == (uint16_t) (tile + 1);
+    // WaveFrontSynchro: getCURestricted hides the CTU column to the right (CL/CodingStructure.cpp:1634-1638); and the CTU row below, which the reference has not coded yet
+    // (cu->idx <= curCu.idx, 1640) but whose stream may already have passed the CTU below-left of this one
+    if ((p.tools & TOOL_WPP) && ((((ux << (ch ? 1 : 0)) >> 7) > (L.ctu_x >> 7)) || (((uy << (ch ? 1 : 0)) >> 7) > (L.ctu_y >> 7)))) a = 0;
     L.flags[tid] = (uint8_t) a;
   }
   __syncthreads();
@@ -4393,7 +4397,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
 #if VVCX_STAMP
     const long long tph = STAMP(); const int phs = f.phase;
 #ifndef VVCX_STAMP_DQ
-    struct PhStamp { long long t; int ph; __device__ ~PhStamp() { if (ph < 12) PROF(16 + ph) += (unsigned long long) (STAMP() - t); PROF(30) += 1; } } phstamp = { tph, phs };
+    struct PhStamp { long long t; int ph; __device__ ~PhStamp() { const int slot = ph < 12 ? 16 + ph : ph == PH_EXIT2 ? 1 : ph == PH_A3_DONE ? 28 : ph == PH_PASS ? 29 : ph == PH_NEXT_PASS ? 31 : 47; PROF(slot) += (unsigned long long) (STAMP() - t); PROF(30) += 1; } } phstamp = { tph, phs };
 #endif
 #endif
 #ifdef VX_TRACE
@@ -4878,6 +4882,31 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
+// WPP hand-over between the workgroups of two CTU rows.  The row above publishes its count with release semantics at device scope after a device-scope fence of every thread
+// that wrote picture data; the waiting row's thread 0 polls it with acquire loads, and after the barrier every thread fences (acquire) before it reads the neighbour's
+// samples.  The row above was taken from the queue before this one (vvcx_submit_ctus keeps a tile's rows in order), so its workgroup is running or done: the wait ends.
+__device__ __noinline__ void wpp_wait(const int32_t *cnt, int need)
+{
+  if (VTX == 0) {
+#ifdef VX_EMU
+    if (*cnt < need) { fprintf(stderr, "WPP: row above at %d, %d needed - the emulator runs the workgroups one after the other, the queue order is wrong\n", *cnt, need); abort(); }
+#else
+    while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(32);
+#endif
+  }
+  __syncthreads();
+#ifndef VX_EMU
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+__device__ inline void wpp_publish(int32_t *cnt, int done)
+{
+#ifdef VX_EMU
+  *cnt = done;
+#else
+  __hip_atomic_store(cnt, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 template <typename T>
 __device__ void run_stream(const VxParams &p, int stream_idx)
 {
@@ -4885,19 +4914,25 @@ __device__ void run_stream(const VxParams &p, int stream_idx)
   if (VTX == 0) { L.par = p; L.fdv = p.frames[sd.frame]; }
   const VxFrameDev &fd = p.frames[sd.frame];
   uint8_t *scratch = p.scratch + (size_t) blockIdx.x * p.scratch_per_stream;
-  Ctx *carry = (Ctx *) (p.stream_ctx + (size_t) (sd.frame * p.ntiles + sd.tile) * 2 * NCTX);
+  const int sidx = sd.frame * p.nsub + sd.sub;
+  Ctx *carry = (Ctx *) (p.stream_ctx + (size_t) sidx * 2 * NCTX);
   const int tid = VTX;
   if (tid == 0) {
     L.cur_tile = sd.tile; L.frame = sd.frame; L.lmcs_cadj = 0; L.lmcs_tab = 0; for (int i = 0; i < 4; i++) L.cnt[i] = 0; for (int i = 0; i < (VVCX_STAMP ? 48 : 1); i++) PROF(i) = 0;
-    if (p.payload) writer_begin(p, sd.frame * p.ntiles + sd.tile, sd.done_before);
+    if (p.payload) writer_begin(p, sidx, sd.done_before);
     if (p.tools & TOOL_CU_REUSE) L.cache_gen = (int) *(const uint32_t *) (scratch + VXD_OFF_META);
   }
   load_tables();
-  ctx_copy_all(&L.ctxs[CI_CUR], carry);
+  // WPP: the row's first CTU starts from the contexts the row above left behind its own first CTU (EL/EncSlice.cpp:1648-1661); later launches of the row carry on from `carry`
+  const int wpp_above = sd.above >= 0 ? sd.frame * p.nsub + sd.above : -1;
+  if (wpp_above >= 0 && sd.done_before == 0) { wpp_wait(p.wpp_progress + wpp_above, 1); ctx_copy_all(&L.ctxs[CI_CUR], (const Ctx *) (p.wpp_sync + (size_t) wpp_above * 2 * NCTX)); }
+  else ctx_copy_all(&L.ctxs[CI_CUR], carry);
   __syncthreads();
   for (int t = 0; t < sd.n_tasks; t++) {
     const int addr = p.task_ctu[sd.first_task + t];
     const int ctu_x = (addr % p.ctus_w) << 7, ctu_y = (addr / p.ctus_w) << 7;
+    // WPP: CTU k of a row reads the reconstruction and the CU data of CTU k of the row above (the one further right is hidden from it, build_refs)
+    if (wpp_above >= 0) wpp_wait(p.wpp_progress + wpp_above, sd.done_before + t + 1);
     // contexts at CTU start → snapshot slot (MAXD-1) "start"
     ctx_copy_all(ctx_ptr(scratch, CTX_START, MAXD + NW, 0), &L.ctxs[CI_CUR]);
     if (p.tools & TOOL_CU_REUSE) {                       // entries of an earlier CTU can never match (987-1024: poc / absolute area): a new generation drops them
@@ -4931,15 +4966,24 @@ __device__ void run_stream(const VxParams &p, int stream_idx)
     if (tid == 0) {
       const long long t0 = STAMP();
       advance_ctx_ctu<T>(p, fd, sd.tile, ctu_x, ctu_y);
-      if (p.payload) writer_end_of_ctu(sd.done_before + t + 1 == sd.tile_ctus, sd.tile == p.ntiles - 1);
+      if (p.payload) writer_end_of_ctu(sd.done_before + t + 1 == sd.tile_ctus, sd.sub == p.nsub - 1);
       if (VVCX_STAMP) PROF(12) += (unsigned long long) (STAMP() - t0);
       p.results[sd.first_task + t] = res;
     }
     __syncthreads();
+    if (p.tools & TOOL_WPP) {                              // publish: first the contexts behind the row's first CTU (1801-1805), then the count the row below waits on
+      if (sd.done_before + t == 0) ctx_copy_all((Ctx *) (p.wpp_sync + (size_t) sidx * 2 * NCTX), &L.ctxs[CI_CUR]);
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) wpp_publish(p.wpp_progress + sidx, sd.done_before + t + 1);
+    }
   }
   ctx_copy_all(carry, &L.ctxs[CI_CUR]);
   if (tid == 0 && (p.tools & TOOL_CU_REUSE)) *(uint32_t *) (scratch + VXD_OFF_META) = (uint32_t) L.cache_gen;
-  if (tid == 0 && p.payload) writer_suspend(p, sd.frame * p.ntiles + sd.tile);
+  if (tid == 0 && p.payload) writer_suspend(p, sidx);
+#ifdef VX_DBG_STREAM
+  if (tid == 0) fprintf(stderr, "stream %d sub %d done_before %d tasks %d slot %d cnt %llu %llu %llu %llu gen %d\n", stream_idx, sd.sub, sd.done_before, sd.n_tasks, (int) blockIdx.x, L.cnt[0], L.cnt[1], L.cnt[2], L.cnt[3], L.cache_gen);
+#endif
   if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); if (VVCX_STAMP) for (int i = 0; i < 48; i++) atomicAdd(&p.counters[4 + i], PROF(i)); }
 }
 

@@ -23,6 +23,7 @@ TOOL_TS = 1 << 5             # transform skip of luma TUs up to 32x32 with RDOQ-
 TOOL_RDOQ = 1 << 7           # cfg RDOQ / RDOQTS beside DepQuant: only reaches transform-skip blocks
 TOOL_ISP = 1 << 2            # intra sub-partitions (cfg ISP 1, ISPFast 1)
 TOOL_LMCS = 1 << 10          # luma mapping with chroma scaling (cfg LMCSEnable 1): the slice carries the model
+TOOL_WPP = 1 << 13           # cfg WaveFrontSynchro 1: CTU rows as lagged streams (context hand-over behind the first CTU of the row above, above-right CTU unavailable), a sub-stream per row
 TOOLS_DEFAULT = TOOL_MRL | TOOL_CU_REUSE
 
 
@@ -214,6 +215,15 @@ class VvcxEncoder:
         buf = np.zeros(cap, np.uint8); n = C.c_int()
         self._chk(self.L.vvcx_get_payload(self.h, frame, tile, buf.ctypes.data, cap, C.byref(n)))
         return buf[:n.value].copy()
+
+    def get_substream_sizes(self, frame, tile):
+        """byte counts of the sub-streams inside get_payload(frame, tile): one, or with TOOL_WPP one per CTU row of the tile"""
+        n = C.c_int()
+        self.L.vvcx_get_substream_sizes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        self._chk(self.L.vvcx_get_substream_sizes(self.h, frame, tile, None, 0, C.byref(n)))
+        sizes = np.zeros(n.value, np.int32)
+        self._chk(self.L.vvcx_get_substream_sizes(self.h, frame, tile, sizes.ctypes.data, len(sizes), C.byref(n)))
+        return sizes
 
     def resident_streams(self):
         return int(self.L.vvcx_resident_streams(self.h))

@@ -849,6 +849,17 @@ def gen_bitstream_isp():
     np.savez_compressed(os.path.join(HERE, "bitstream_full.npz"), **out)
 
 
+def gen_bitstream_wpp():
+    """WaveFrontSynchro 1 (tool bit 0x2000) over the reference cfg's tool set but LMCS and over a lighter set with two tile columns: per CTU row one sub-stream, contexts of a
+    row from behind the first CTU of the row above, the CTU above-right unavailable to prediction.  The reference's DECODER (its DecSlice row loop restated in
+    ref_dec_tile_wpp around the real CABACReader; DecCu under entropy_coding_sync) parses and reconstructs them: CUs, levels and samples must be the oracle's."""
+    R.ref_env_set_tools.argtypes = [C.c_void_p, C.c_uint]
+    out = _pictures(((256, 256, 32, 1, 1, 8, 7), (384, 200, 37, 2, 1, 8, 5), (256, 384, 27, 1, 1, 10, 3)), 0x2000 | 0x953, 0.5)
+    np.savez_compressed(os.path.join(HERE, "bitstream_wpp.npz"), **out)
+    out = _pictures(((256, 256, 32, 1, 1, 8, 9), (392, 264, 30, 1, 2, 8, 12)), 0x2000 | 0xb7f, 0.5, oriented=30.0, screen=0.3)
+    np.savez_compressed(os.path.join(HERE, "bitstream_wpp_full.npz"), **out)
+
+
 def _pictures(cases, tools, texture, oriented=0.0, screen=0.0, limited=False):
     import importlib, sys
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -882,11 +893,19 @@ def _pictures(cases, tools, texture, oriented=0.0, screen=0.0, limited=False):
         R.ref_env_reset(env)
         cw, chh = (W + 127) // 128, (H + 127) // 128
         tile_of = lambda rx, ry: max(i for i in range(tr) if ry >= (i * chh) // tr) * tc + max(i for i in range(tc) if rx >= (i * cw) // tc)
-        off = 0
+        off = sub = 0
         for t in range(tc * tr):
             ctus = np.array([ry * cw + rx for ry in range(chh) for rx in range(cw) if tile_of(rx, ry) == t], np.int32)
+            if tools & 0x2000:                      # WaveFrontSynchro: one sub-stream per CTU row of the tile, the reference decoder's row loop (ref_dec_tile_wpp)
+                row_len = len(set(int(a) % cw for a in ctus)); nrows = len(ctus) // row_len
+                sz = np.ascontiguousarray(sizes[sub:sub + nrows], np.int32); sub += nrows
+                b = np.ascontiguousarray(payload[off:off + int(sz.sum())]); off += int(sz.sum())
+                R.ref_dec_tile_wpp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+                assert R.ref_dec_tile_wpp(env, sp["qp"], P(b), P(sz), nrows, P(ctus), len(ctus), row_len, int(t == tc * tr - 1)) == 0, "reference decoder rejected the WPP payload"
+                continue
             b = np.ascontiguousarray(payload[off:off + sizes[t]]); off += int(sizes[t])
             assert R.ref_dec_tile(env, sp["qp"], P(b), len(b), P(ctus), len(ctus), int(t == tc * tr - 1)) == 0, "reference decoder rejected the payload"
+        assert off == len(payload)
         rows = np.zeros((len(cus) + 16, 12), np.int32); ss = np.zeros(len(cus) + 16, np.uint64)
         nd = R.ref_dec_get_cus(env, P(rows), P(ss), len(rows)); assert nd == len(cus)
         dec = {(int(r[0]), int(r[1]), int(r[2])): (tuple(int(v) for v in r[3:]), int(s)) for r, s in zip(rows[:nd], ss[:nd])}
@@ -953,6 +972,8 @@ if __name__ == "__main__":
         gen_bitstream(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mip":
         gen_mip(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bitstream_wpp":
+        gen_bitstream_wpp(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "deblock":
         gen_deblock(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "chroma_qp":
@@ -991,5 +1012,5 @@ if __name__ == "__main__":
         gen_ts(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict(); gen_decision_helpers(); gen_ts(); gen_bitstream_ts(); gen_isp(); gen_bitstream_isp(); gen_lmcs()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict(); gen_decision_helpers(); gen_ts(); gen_bitstream_ts(); gen_isp(); gen_bitstream_isp(); gen_lmcs(); gen_bitstream_wpp()
     print("done")

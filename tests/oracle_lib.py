@@ -98,6 +98,7 @@ def make_slice(sp):
 
 
 TOOL_FAST = 1 << 12
+TOOL_WPP = 1 << 13     # cfg WaveFrontSynchro 1: context synchronisation per CTU row, above-right CTU unavailable, one sub-stream per CTU row
 TOOL_MIP = 1 << 1      # oracle only so far: the device refuses VVCX_TOOL_MIP
 
 
@@ -223,7 +224,7 @@ def write_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=
         nctu = ((w + 127) // 128) * ((h + 127) // 128)
         res = np.zeros(nctu, CTU_DTYPE); cus = np.zeros(nctu * 2048, CU_DTYPE); n = C.c_int()
         assert L.orc_compress_frame(e, res.ctypes.data, cus.ctypes.data, len(cus), C.byref(n)) == 0
-        buf = np.zeros(w * h * 4 + 4096, np.uint8); sizes = np.zeros(tile_cols * tile_rows, np.int32)
+        buf = np.zeros(w * h * 4 + 4096, np.uint8); sizes = np.zeros(tile_cols * tile_rows * (((h + 127) // 128) if tools & TOOL_WPP else 1), np.int32)      # under WPP one sub-stream per CTU row of each tile (unused tail stays 0)
         tot = L.orc_write_tiles(e, buf.ctypes.data, len(buf), sizes.ctypes.data)
         assert tot >= 0
         lev = [np.zeros((h >> (1 if c else 0), w >> (1 if c else 0)), np.int16) for c in range(3)]

@@ -342,7 +342,7 @@ def test_baseline_config_3_classifier_per_qp_forest_1080p_rows(qp):
     _check([pkg.synth_frame(W, H, 0, 8, 2000 + qp, chroma_texture=0.5)], W, H, pkg.slice_params(qp, dep_quant=True), tile_cols=15, tile_rows=2, tools=FULL | pkg.TOOL_FAST, forest_qp=qp, workers=12)
 
 
-@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz", "bitstream_dq.npz", "bitstream_lfnst.npz", "bitstream_lfnst_c.npz", "bitstream_jccr.npz", "bitstream_jccr_plain.npz", "bitstream_ts.npz", "bitstream_isp.npz", "bitstream_full.npz", "bitstream_lmcs.npz"])
+@pytest.mark.parametrize("fixture", ["bitstream.npz", "bitstream_cclm.npz", "bitstream_mts.npz", "bitstream_mip.npz", "bitstream_dq.npz", "bitstream_lfnst.npz", "bitstream_lfnst_c.npz", "bitstream_jccr.npz", "bitstream_jccr_plain.npz", "bitstream_ts.npz", "bitstream_isp.npz", "bitstream_full.npz", "bitstream_lmcs.npz", "bitstream_wpp.npz", "bitstream_wpp_full.npz"])
 def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fixture):
     """Device writer (arithmetic coding of the final CTU syntax in the estimator pass) against tests/golden/bitstream.npz: payloads
     that the reference's CABACReader parsed back into the coded CUs and levels when the fixture was generated."""
@@ -385,15 +385,28 @@ def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fix
         else:
             enc.compress_bound_frames(stream=stream.cuda_stream)
         pay = [enc.get_payload(0, t) for t in range(tc * tr)]
+        lens = [int(n) for t in range(tc * tr) for n in enc.get_substream_sizes(0, t)]      # one per tile, or under WPP one per CTU row of each tile
+        assert sum(lens) == sum(len(b) for b in pay)
         enc.close()
-        return [len(b) for b in pay], np.concatenate(pay)
+        return lens, np.concatenate(pay)
 
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=4) as ex:
         outs = list(ex.map(one_picture, jobs))
     for (W, H, qp, tc, tr, bd, seed, exp, sizes, lm), (lens, got) in zip(jobs, outs):
-        assert lens == list(sizes[:tc * tr])
+        assert lens == list(sizes[:len(lens)]) and not np.any(sizes[len(lens):])
         assert np.array_equal(got, exp), (W, H, qp, tc, tr, bd)
+
+
+@pytest.mark.parametrize("case", [(640, 384, 32, 8, 1, 1, 31, 0xbff, 2), (520, 392, 27, 8, 2, 1, 32, 0x953, 1), (384, 264, 37, 10, 1, 2, 33, 0x913, 1)])
+def test_wavefront_rows_as_lagged_streams(case):
+    """VVCX_TOOL_WPP (cfg WaveFrontSynchro 1): the CTU rows of a tile run as streams of their own, each one CTU behind the row above (workgroups waiting on the row above's
+    published count), with the context hand-over and the hidden above-right CTU; results, CU table, reconstruction and work counters equal the oracle's sequential WPP run,
+    whose payloads tests/golden/bitstream_wpp*.npz pin to the reference decoder.  Several frames, tiles, 10 bit (tests/test_host_cpu.py checks on the emulator that the WPP picture differs from the plain one)."""
+    W, H, qp, bd, tc, tr, seed, tools, nf = case
+    sp = pkg.slice_params(qp, bit_depth=bd, dep_quant=bool(tools & pkg.TOOL_DEPQUANT))
+    frames = [pkg.synth_frame(W, H, f, bd, seed + f, chroma_texture=0.5, oriented=20.0 if tools & 4 else 0.0, screen=0.3 if tools & 4 else 0.0) for f in range(nf)]
+    _check(frames, W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools | pkg.TOOL_WPP, workers=2 if tc * tr > 1 else 1)
 
 
 def test_seeded_sweep_over_sizes_qps_tools_and_tiles():

@@ -327,6 +327,42 @@ def test_deblocking_kernel_on_cpu_emulator_matches_oracle(emu_so, case):
     enc.close()
 
 
+def test_wavefront_rows_on_cpu_emulator_match_oracle(emu_so):
+    """VVCX_TOOL_WPP on the device path (CPU debug emulation): a CTU row as a stream of its own that starts from the contexts behind the first CTU of the row above and does not
+    see the CTU above-right; one sub-stream per CTU row in the payload.  2 x 2 CTUs (one whole CTU and three boundary slivers).  Also: a row cannot be submitted ahead of
+    the row above it."""
+    W = H = 136
+    tools = pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM | pkg.TOOL_WPP
+    planes = pkg.synth_frame(W, H, 0, 8, 3, chroma_texture=0.3)
+    sp = pkg.slice_params(42)
+    enc = pkg.VvcxEncoder(W, H, 8, tools=tools, lib_path=emu_so, emit_payload=True)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    org = [np.ascontiguousarray(p) for p in planes]
+    rec = [np.zeros_like(p) for p in planes]
+    enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
+    with pytest.raises(pkg.VvcxError):
+        enc.compress_ctus([(0, 2)])                    # first CTU of the second row before anything of the first
+    with pytest.raises(pkg.VvcxError):
+        enc.compress_ctus([(0, 0), (0, 2), (0, 3)])    # the second row would overtake the first
+    r1 = enc.compress_ctus([(0, 0), (0, 2)])           # the lag the wavefront allows: row 1 one CTU behind row 0 ...
+    cnt = np.asarray(enc.counters(), np.uint64)
+    r2 = enc.compress_ctus([(0, 1), (0, 3)])           # ... and the rest in a second launch (contexts and coder state carried per row)
+    cnt = cnt + np.asarray(enc.counters(), np.uint64)
+    ores, ocus, oreco, ocnt = O.compress_frame(planes, W, H, sp, tools=tools)
+    got = np.concatenate([r1, r2])[[0, 2, 1, 3]]
+    for k in ores.dtype.names:
+        assert np.array_equal(ores[k], got[k]), k
+    cus = enc.get_cus(0)
+    assert len(cus) == len(ocus) and all(np.array_equal(cus[k], ocus[k]) for k in cus.dtype.names)
+    assert all(np.array_equal(rec[c], oreco[c]) for c in range(3))
+    assert np.array_equal(cnt, ocnt)
+    opay, osz, _, _ = O.write_frame(planes, W, H, sp, tools=tools)
+    assert np.array_equal(enc.get_payload(0, 0), opay) and np.array_equal(enc.get_substream_sizes(0, 0), osz[:2]) and len(osz) == 2
+    enc.close()
+    plain = O.compress_frame(planes, W, H, sp, tools=tools & ~pkg.TOOL_WPP)[2]
+    assert any((a != b).any() for a, b in zip(oreco, plain))
+
+
 def test_deblocking_of_isp_transform_edges_on_cpu_emulator_matches_the_reference(emu_so):
     """the deblocking kernels (sources of vvcx_deblock.hip on the emulator) behind vvcx_deblock_cu_table: transform edges of ISP sub-partitions, filter lengths from the
     sub-partition sizes; expectation = the reference's LoopFilter output held in the fixture.  Also the argument checks of the entry point."""

@@ -22,6 +22,7 @@
 #define __launch_bounds__(...)
 #define __noinline__ __attribute__((noinline))
 #define __forceinline__ inline
+#define VX_EMU 1          // the sources are being compiled for the CPU debug emulator
 #define VX_NO_MFMA 1      // the matrix-core form of the 32- / 64-point first transform stage exists on the device only; the emulation runs the general loop
 // packed 16-bit helpers of the transform stage (device: v_dot2c_i32_i16 / v_pk_sub_i16)
 #define VX_DOT2_I16(a_, b_, c_) ((c_) + (int) (int16_t) (a_) * (int) (int16_t) (b_) + (int) (int16_t) ((a_) >> 16) * (int) (int16_t) ((b_) >> 16))

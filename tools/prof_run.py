@@ -20,7 +20,7 @@ names=["ctrl","-","LUMA_PREP+A1","STAGE_A2","STAGE_B","CHROMA_RD","SAVE_INTRA","
 for i,n in enumerate(names): print("%-14s %6.2f%%  %.3e"%(n,100*pr[i]/tot,pr[i]))
 phn=["ENTER","FAST_DONE","RUN","A1_DONE","A2_DONE","B_DONE","INTRA_SAVED","CHILD","CHILD_RET","SPLIT_SAVED","ADVANCE","EXIT"]
 for i,n in enumerate(phn): print("  ph %-12s %.3e"%(n,pr[16+i]))
-print("B wave0: pred %.3e code_block %.3e rate %.3e"%(pr[28],pr[29],pr[31]))
+print("  ph EXIT2 %.3e  A3_DONE %.3e  PASS %.3e  NEXT_PASS %.3e  ISP %.3e" % (pr[1], pr[28], pr[29], pr[31], pr[47]))
 print("rc wave0: prepass %.3e meta %.3e emit %.3e chain %.3e reduce %.3e calls %d"%(pr[32],pr[33],pr[34],pr[35],pr[36],pr[37]))
 print("steps",pr[30],"counters",enc.counters())
 print("search ops by luma node area (16,32,...,4096+):", ["%.2e" % v for v in pr[38:48]])
