@@ -207,6 +207,14 @@ int  vvcx_deblock_cu_table(int pic_w, int pic_h, int bit_depth, int qp, int qp_c
  * for that brick (CABACWriter::coding_tree_unit per CTU, end_of_ctu / end_of_slice terminating bins, byte alignment;
  * EL/EncSlice.cpp:1884-2006).  Requires cfg.emit_payload.  buf is host memory */
 int  vvcx_get_payload(vvcx_handle *h, int frame, int tile, uint8_t *buf, int cap, int *nbytes);
+/* ≙ the fork's GET_TRAINING_SET build (CL/TypeDef.h:54-56; EL/CABACWriter.cpp:515-855 writes the rows the forests of BIN/TEST.py are trained on): with a dump enabled every luma
+ * node of the search that qualifies for the classifier (EL/EncCu.cpp:810-846, 933) leaves one row of 28 int32: the 26 features (EL/EncCu.cpp:863-1123), the complexity class
+ * (0 simple, 1 fuzzy, 2 complex; 1127-1138) and the partition the full search chose at that node (0 none, 1 QT, 2 BT_H, 3 BT_V, 4 TT_H, 5 TT_V; -1: no encoding).  Rows
+ * accumulate from vvcx_bind_frames on, in no particular order across streams; cap_rows 0 switches the dump off.  vvcx_get_training_rows copies min(rows so far, capacity,
+ * max_rows) rows to host memory and reports in *n_rows how many the search produced.  Works with and without VVCX_TOOL_FAST (without: the plain full search labels the rows,
+ * which is how a forest is trained: tools/train_partition_forest.py) */
+int  vvcx_enable_training_dump(vvcx_handle *h, int cap_rows);
+int  vvcx_get_training_rows(vvcx_handle *h, int32_t *rows, int max_rows, int *n_rows);
 /* the sub-streams inside the bytes vvcx_get_payload returns for a tile, in order: one (the tile), or with VVCX_TOOL_WPP one per CTU row of the tile - what the slice header's
  * entry points are made of (EL/EncSlice.cpp:1982-1990 addSubstreamSize).  sizes may be NULL to query the count */
 int  vvcx_get_substream_sizes(vvcx_handle *h, int frame, int tile, int *sizes, int max_sizes, int *n_sizes);

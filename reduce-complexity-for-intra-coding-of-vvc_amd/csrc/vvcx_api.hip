@@ -65,6 +65,7 @@ struct vvcx_handle {
   int nsub;
   std::vector<int> ctu_sub, sub_tile, sub_above, tile_sub0, tile_nsub;      // sub-stream of each CTU; its tile; the sub-stream of the CTU row above in the same tile (-1: none); per tile: first sub-stream, count
   std::vector<std::vector<int>> sub_ctus;       // CTUs of each sub-stream in coding order
+  int32_t *train_rows_d; uint32_t *train_n_d; int train_cap;      // vvcx_enable_training_dump
   int32_t *wpp_progress_d; uint16_t *wpp_sync_d;  // WPP: CTUs finished per (frame, sub-stream); the contexts behind the first CTU of each (m_entropyCodingSyncContextState)
   std::vector<int> next_idx;                    // per (frame, sub-stream): how many CTUs of the stream are done
   // device memory
@@ -179,7 +180,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
     }
     h->nsub = (int) h->sub_ctus.size();
   }
-  h->wpp_progress_d = nullptr; h->wpp_sync_d = nullptr;
+  h->wpp_progress_d = nullptr; h->wpp_sync_d = nullptr; h->train_rows_d = nullptr; h->train_n_d = nullptr; h->train_cap = 0;
   DevGuard guard(cfg->device);
   if (!guard.ok) { delete h; return fail(VVCX_ERR_DEVICE, "hipSetDevice(%d) failed", cfg->device); }
   const int wc = cfg->pic_w >> 1, hc = cfg->pic_h >> 1;
@@ -216,7 +217,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
 extern "C" void vvcx_destroy(vvcx_handle *h)
 {
   if (!h) return;
-  (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d); (void) hipFree(h->wpp_progress_d); (void) hipFree(h->wpp_sync_d);
+  (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d); (void) hipFree(h->wpp_progress_d); (void) hipFree(h->wpp_sync_d); (void) hipFree(h->train_rows_d); (void) hipFree(h->train_n_d);
   (void) hipFree(h->payload_d); (void) hipFree(h->payload_off_d); (void) hipFree(h->payload_cap_d); (void) hipFree(h->arith_d);
   (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
   (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d); (void) hipFree(h->dq_d); (void) hipFree(h->lmcs_lut_d); (void) hipFree(h->lmcs_org_d);
@@ -435,6 +436,7 @@ extern "C" int vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n)
   }
   h->n_frames = n;
   if (h->wpp_progress_d) HIPCHK(hipMemset(h->wpp_progress_d, 0, (size_t) n * h->nsub * 4));
+  if (h->train_n_d) HIPCHK(hipMemset(h->train_n_d, 0, 4));
   h->next_idx.assign((size_t) n * h->nsub, 0);
   return VVCX_OK;
 }
@@ -546,6 +548,7 @@ extern "C" int vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int 
   p.frames = h->frames_d; p.streams = h->streams_d; p.task_ctu = h->task_ctu_d; p.results = h->results_d; p.stream_ctx = h->stream_ctx_d;
   p.payload = h->payload_d; p.payload_off = h->payload_off_d; p.payload_cap = h->payload_cap_d; p.arith_state = h->arith_d;
   p.scratch = h->scratch_d; p.scratch_per_stream = per_stream; p.counters = h->counters_d; p.ntiles = h->ntiles; p.nsub = h->nsub; p.wpp_progress = h->wpp_progress_d; p.wpp_sync = h->wpp_sync_d;
+  p.train_rows = h->train_rows_d; p.train_n = h->train_n_d; p.train_cap = h->train_cap;
   p.f_node = h->f_node_d; p.f_value = h->f_value_d; p.f_root = h->f_root_d; p.f_ntrees = h->f_ntrees; p.f_nclasses = h->f_nclasses;
   for (int c = 0; c < 8; c++) p.f_classes[c] = h->f_classes[c];
   p.n_streams = ns;
@@ -1197,6 +1200,35 @@ static int payload_of_tile(vvcx_handle *h, int frame, int tile, uint8_t *buf, in
   }
   if (nbytes) *nbytes = (int) total;
   if (buf && total > (size_t) cap) return fail(VVCX_ERR_ARG, "buffer too small: %zu bytes needed", total);
+  return VVCX_OK;
+}
+// GET_TRAINING_SET counterpart (the fork's CL/TypeDef.h:54-56 switch; EL/EncCu.cpp:863-1123 computes the features, the label is the partition the full search chose)
+extern "C" int vvcx_enable_training_dump(vvcx_handle *h, int cap_rows)
+{
+  NOT_PENDING(h);
+  if (!h || cap_rows < 0) return fail(VVCX_ERR_ARG, "bad argument");
+  DevGuard guard(h->cfg.device);
+  (void) hipFree(h->train_rows_d); (void) hipFree(h->train_n_d); h->train_rows_d = nullptr; h->train_n_d = nullptr; h->train_cap = 0;
+  if (cap_rows == 0) return VVCX_OK;
+  if (hipMalloc((void **) &h->train_rows_d, (size_t) cap_rows * 28 * 4) != hipSuccess || hipMalloc((void **) &h->train_n_d, 4) != hipSuccess) {
+    (void) hipFree(h->train_rows_d); h->train_rows_d = nullptr;
+    return fail(VVCX_ERR_DEVICE, "device allocation of %d training rows failed", cap_rows);
+  }
+  HIPCHK(hipMemset(h->train_n_d, 0, 4));
+  h->train_cap = cap_rows;
+  return VVCX_OK;
+}
+extern "C" int vvcx_get_training_rows(vvcx_handle *h, int32_t *rows, int max_rows, int *n_rows)
+{
+  NOT_PENDING(h);
+  if (!h || !n_rows || max_rows < 0 || (!rows && max_rows)) return fail(VVCX_ERR_ARG, "bad argument");
+  if (!h->train_rows_d) return fail(VVCX_ERR_STATE, "vvcx_enable_training_dump first");
+  DevGuard guard(h->cfg.device);
+  uint32_t n = 0;
+  HIPCHK(hipMemcpy(&n, h->train_n_d, 4, hipMemcpyDeviceToHost));
+  *n_rows = (int) n;                                  // rows asked for; more than the capacity means the tail was dropped
+  const int have = (int) (n < (uint32_t) h->train_cap ? n : (uint32_t) h->train_cap), take = have < max_rows ? have : max_rows;
+  if (take) HIPCHK(hipMemcpy(rows, h->train_rows_d, (size_t) take * 28 * 4, hipMemcpyDeviceToHost));
   return VVCX_OK;
 }
 extern "C" int vvcx_get_payload(vvcx_handle *h, int frame, int tile, uint8_t *buf, int cap, int *nbytes)

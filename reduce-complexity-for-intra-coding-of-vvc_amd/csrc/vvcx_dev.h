@@ -69,6 +69,9 @@ struct VxParams {
   uint64_t            scratch_per_stream;
   unsigned long long *counters;      // 4 global work counters
   int32_t             ntiles, nsub;  // tiles / sub-streams per frame (equal without WPP)
+  int32_t            *train_rows;    // GET_TRAINING_SET counterpart: 28 ints per qualifying luma node (26 features, complexity class, chosen partition); NULL: off
+  uint32_t           *train_n;       // rows handed out so far (atomic)
+  int32_t             train_cap, pad_train;
   int32_t            *wpp_progress;  // WPP: per (frame*nsub+sub) the CTUs of the row that are finished and visible
   uint16_t           *wpp_sync;      // WPP: per (frame*nsub+sub) the contexts behind the row's first CTU
   // slice_data writer (optional): per (frame, tile) byte range of the payload buffer and the persistent coder state (32 B each)

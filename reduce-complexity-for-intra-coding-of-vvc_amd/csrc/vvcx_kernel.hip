@@ -86,6 +86,7 @@ struct Frame {                     // one recursion level: partitioner level + C
   uint64_t ss;
   double max_cost;
   Sum best, temp;
+  int32_t train_row;               // row of the training dump this luma node filled at entry (-1: none): its label is written when the node is left
 };
 
 struct Cand { uint8_t mode, mrl; };
@@ -194,7 +195,7 @@ struct Lds {
   // CCLM: down-sampled luma of the chroma node (nodes of at most BUF chroma samples; bigger ones in HBM scratch), availability and line parameters
   // (the luma full-RD stage keeps the fractional bits of the transform-skip context sets where the chroma operations keep the CCLM neighbour lines: ts_build_tables)
   alignas(16) int16_t lm_in[BUF / 2]; union { struct { int16_t lm_top[64], lm_left[64]; }; int ts_tab[36]; }; int lm_info[4], lm_ok, lm_nsatd; int lm_par[2][3][3]; int64_t lm_cost[8];
-  int16_t fa_nb[5][4]; int fa_n, fa_res, fa_feat[27];      // FAST_ALGORITHM: neighbour CUs {x, y, w, h} of the node, forest answer, features
+  int16_t fa_nb[5][4]; int fa_n, fa_res, fa_row, fa_feat[27];      // FAST_ALGORITHM: neighbour CUs {x, y, w, h} of the node, forest answer, features
   Arith aw; uint8_t *aw_out; uint32_t aw_cap; int colm;      // bitstream pass: arithmetic coder, its output (HBM) and capacity; co-located luma mode of the chroma node
   unsigned long long prof[VVCX_STAMP ? 48 : 1];    // shader-clock ticks per operation kind (diagnostic build only, see vvcx_get_profile)
 };
@@ -3795,9 +3796,16 @@ __device__ __noinline__ void op_fast(const VxParams &p_, const VxFrameDev &fd_)
     }
     feat[12] = vmx; feat[13] = vmn; feat[14] = vsum / nn;
     feat[26] = feat[10] < feat[13] ? 0 : feat[10] > feat[12] ? 2 : 1;          // simple / complex / fuzzy (1127-1138)
+    L.fa_row = -1;
+    if (p.train_rows) {                                                        // the row of the training dump (oracle/orc_rdo.c fast_partition): features now, label when the node is left
+      const unsigned r = atomicAdd(p.train_n, 1u);
+      if (r < (unsigned) p.train_cap) { for (int k = 0; k < 27; k++) p.train_rows[(size_t) r * 28 + k] = feat[k]; p.train_rows[(size_t) r * 28 + 27] = -1; L.fa_row = (int) r; }
+    }
+    if (!(p.tools & TOOL_FAST)) L.fa_res = -1;                                 // features only: the mode list stays as it is
   }
   __threadfence_block();
   __syncthreads();
+  if (!(p.tools & TOOL_FAST)) return;
   // forest: one thread per tree walks to its leaf; thread 0 adds the leaf distributions in tree order (sklearn's predict_proba order)
   double acc[8];
   if (tid == 0) for (int c = 0; c < 8; c++) acc[c] = 0;
@@ -4411,11 +4419,13 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
       if (f.nmodes == 0) { f.phase = PH_EXIT2; break; }
       f.phase = PH_RUN; f.ctx_dirty = 0;
       L.pre_copy_d = d;                                   // m_CurrCtx->start = ctx: done by the dispatch that runs the node's first operation
-      if ((p.tools & TOOL_FAST) && !ch && fast_candidates(p, fd, f, tile)) { f.phase = PH_FAST_DONE; set_node(f, d); post(OP_FAST); return; }
+      f.train_row = -1;
+      if (((p.tools & TOOL_FAST) || p.train_rows) && !ch && fast_candidates(p, fd, f, tile)) { f.phase = PH_FAST_DONE; set_node(f, d); post(OP_FAST); return; }
       break;
     }
     case PH_FAST_DONE: {                                // EL/EncCu.cpp:1126-1217: replace the mode stack by the predicted mode if the controller accepts it
       const int res = L.fa_res;
+      f.train_row = L.fa_row;
       if (res >= 0 && res <= 5) {
         const int mode = res == 0 ? ETM_INTRA : res == 1 ? ETM_SPLIT_QT : res == 2 ? ETM_SPLIT_BT_H : res == 3 ? ETM_SPLIT_BT_V : res == 4 ? ETM_SPLIT_TT_H : ETM_SPLIT_TT_V;
         int valid = try_mode(p, d, ch, mode);                                             // tryModeMaster 1199
@@ -4683,7 +4693,14 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
       set_node(f, d);
       L.op_a = CTX_CUR; L.op_b = CTX_BEST; L.op_c = d; L.op_d = 1; post(OP_RESTORE_PIC); return;   // picture ← bestCS, ctx ← best
     }
-    case PH_EXIT2: { L.d = d - 1; break; }
+    case PH_EXIT2: {
+      if (f.train_row >= 0) {                           // the label of the node's training row: the partition the search chose here (PartSplit code, 0 = not split; -1: no encoding)
+        int label = -1;
+        if (f.best.cost != MAX_DOUBLE) label = (int) ((fd.units[0][(f.y >> 2) * p.uw + (f.x >> 2)].ss >> (f.depth * 5)) & 31);
+        p.train_rows[(size_t) f.train_row * 28 + 27] = label;
+      }
+      L.d = d - 1; break;
+    }
     }
   }
 }

@@ -216,6 +216,22 @@ class VvcxEncoder:
         self._chk(self.L.vvcx_get_payload(self.h, frame, tile, buf.ctypes.data, cap, C.byref(n)))
         return buf[:n.value].copy()
 
+    def enable_training_dump(self, cap_rows):
+        """vvcx_enable_training_dump: every qualifying luma node of the search leaves a row of 26 features + complexity class + chosen partition"""
+        self.L.vvcx_enable_training_dump.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self.L.vvcx_enable_training_dump(self.h, int(cap_rows)))
+        self._train_cap = int(cap_rows)
+
+    def training_rows(self):
+        """the (n, 28) int32 rows dumped since the frames were bound (order across streams is not defined)"""
+        n = C.c_int()
+        rows = np.zeros((self._train_cap, 28), np.int32)
+        self.L.vvcx_get_training_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        self._chk(self.L.vvcx_get_training_rows(self.h, rows.ctypes.data, len(rows), C.byref(n)))
+        if n.value > len(rows):
+            raise VvcxError("training dump overflow: %d rows produced, capacity %d" % (n.value, len(rows)))
+        return rows[:n.value].copy()
+
     def get_substream_sizes(self, frame, tile):
         """byte counts of the sub-streams inside get_payload(frame, tile): one, or with TOOL_WPP one per CTU row of the tile"""
         n = C.c_int()

@@ -409,6 +409,36 @@ def test_wavefront_rows_as_lagged_streams(case):
     _check(frames, W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=tools | pkg.TOOL_WPP, workers=2 if tc * tr > 1 else 1)
 
 
+@pytest.mark.parametrize("classifier", [False, True])
+def test_training_set_dump(classifier):
+    """vvcx_enable_training_dump on the GPU: the rows of every qualifying luma node (26 features, complexity class, chosen partition) from concurrently running
+    CTU streams equal the oracle's dump as a multiset, for the plain full search (how a forest is trained) and with the classifier steering the search; two frames."""
+    import torch
+    W, H, qp = 384, 256, 32
+    tools = FULL | (pkg.TOOL_FAST if classifier else 0)
+    sp = pkg.slice_params(qp, dep_quant=True)
+    frames = [pkg.synth_frame(W, H, f, 8, 40 + f, chroma_texture=0.5) for f in range(2)]
+    forest = _forest(qp) if classifier else None
+    enc = pkg.VvcxEncoder(W, H, 8, tile_cols=3, tile_rows=2, tools=tools, max_frames=2, forest=forest)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    enc.enable_training_dump(200000)
+    dev = []
+    for planes in frames:
+        org = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes]
+        dev.append((org, [torch.zeros_like(t) for t in org]))
+    enc.bind_frames([([t.data_ptr() for t in o], [t.data_ptr() for t in r], [t.shape[1] for t in o]) for o, r in dev])
+    enc.compress_bound_frames()
+    rows = enc.training_rows()
+    enc.close()
+    want = []
+    for planes in frames:
+        O.compress_frame(planes, W, H, sp, tile_cols=3, tile_rows=2, tools=tools, forest=forest, training_rows=want)
+    want = np.concatenate(want)
+    key = lambda r: r[np.lexsort(r.T[::-1])]
+    assert rows.shape == want.shape and np.array_equal(key(rows), key(want))
+    assert len(want) > 1000 and len(np.unique(want[:, 27])) >= 5
+
+
 def test_seeded_sweep_over_sizes_qps_tools_and_tiles():
     """A wider net for rare paths (cached LM mode reused where CCLM is not allowed, 32-point MTS zero-out, big nodes on the HBM path,
     boundary CTUs in both directions, classifier with tiles): nine seeded configurations, each bit-exact against the oracle."""

@@ -327,6 +327,39 @@ def test_deblocking_kernel_on_cpu_emulator_matches_oracle(emu_so, case):
     enc.close()
 
 
+def test_training_set_dump_on_cpu_emulator_matches_oracle(emu_so):
+    """vvcx_enable_training_dump / vvcx_get_training_rows (the fork's GET_TRAINING_SET): every qualifying luma node of the plain full search leaves its 26 features, its
+    complexity class and the partition the search chose; the rows equal the oracle's dump (orc_set_training_dump) - all six labels occur - and the search itself is unchanged."""
+    W, H, tools = 104, 72, pkg.TOOLS_DEFAULT | pkg.TOOL_CCLM
+    planes = pkg.synth_frame(W, H, 0, 8, 7, chroma_texture=0.5)
+    sp = pkg.slice_params(30)
+    enc = pkg.VvcxEncoder(W, H, 8, tools=tools, lib_path=emu_so)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    with pytest.raises(pkg.VvcxError):
+        enc._train_cap = 4; enc.training_rows()        # not enabled
+    enc.enable_training_dump(4096)
+    org = [np.ascontiguousarray(p) for p in planes]
+    rec = [np.zeros_like(p) for p in planes]
+    enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
+    res = enc.compress_bound_frames()[0]
+    rows = enc.training_rows()
+    want = []
+    ores, ocus, oreco, ocnt = O.compress_frame(planes, W, H, sp, tools=tools, training_rows=want)
+    want = want[0]
+    key = lambda r: r[np.lexsort(r.T[::-1])]
+    assert rows.shape == want.shape and np.array_equal(key(rows), key(want))
+    assert len(np.unique(want[:, 27])) >= 5 and want[:, 27].min() >= 0
+    for k in ores.dtype.names:
+        assert np.array_equal(ores[k], res[k]), k
+    assert all(np.array_equal(rec[c], oreco[c]) for c in range(3)) and np.array_equal(np.asarray(enc.counters(), np.uint64), ocnt)
+    enc.enable_training_dump(8)                        # too small: the overflow is reported, not hidden
+    enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
+    enc.compress_bound_frames()
+    with pytest.raises(pkg.VvcxError):
+        enc.training_rows()
+    enc.close()
+
+
 def test_wavefront_rows_on_cpu_emulator_match_oracle(emu_so):
     """VVCX_TOOL_WPP on the device path (CPU debug emulation): a CTU row as a stream of its own that starts from the contexts behind the first CTU of the row above and does not
     see the CTU above-right; one sub-stream per CTU row in the payload.  2 x 2 CTUs (one whole CTU and three boundary slivers).  Also: a row cannot be submitted ahead of
