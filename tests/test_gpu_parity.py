@@ -429,6 +429,12 @@ def test_training_set_dump(classifier):
     enc.bind_frames([([t.data_ptr() for t in o], [t.data_ptr() for t in r], [t.shape[1] for t in o]) for o, r in dev])
     enc.compress_bound_frames()
     rows = enc.training_rows()
+    if not classifier:                                   # a dump that is too small reports the overflow instead of hiding it
+        enc.enable_training_dump(8)
+        enc.bind_frames([([t.data_ptr() for t in o], [t.data_ptr() for t in r], [t.shape[1] for t in o]) for o, r in dev[:1]])
+        enc.compress_ctus([(0, 0)])
+        with pytest.raises(pkg.VvcxError):
+            enc.training_rows()
     enc.close()
     want = []
     for planes in frames:
