@@ -184,9 +184,14 @@ def main():
     bind = [([t.data_ptr() for t in o], [t.data_ptr() for t in r], [t.shape[1] for t in o]) for o, r in frames]
     ctus_per_step = args.frames * ctus_w * ctus_h
 
+    nstep = [0]
+
     def step():
         enc.bind_frames(bind)                      # resets every stream to its tile start; planes stay in HBM
         res = enc.compress_bound_frames()
+        nstep[0] += 1
+        if rank == 0:                              # a progress line per step on stderr (stdout carries the one JSON line): a run of several minutes must not look hung
+            print("[bench] step %d of %d (%d warm-up): %.1f s kernel, %d CTUs" % (nstep[0], args.steps + args.warmup, args.warmup, enc.last_kernel_ms() / 1e3, ctus_per_step), file=sys.stderr, flush=True)
         return res, enc.last_kernel_ms()
 
     elapsed, outs = pkg.timed_steps(step, args.steps, args.warmup, world, device_sync=torch.cuda.synchronize, device="cuda")
@@ -253,6 +258,7 @@ def main():
         except Exception as ex:                                   # an older --lib build without the kernel
             out["deblock"] = {"error": str(ex)}
         if not args.no_cpu_baseline and world == 1:
+            print("[bench] timed region done (%.1f s for %d steps); CPU baseline sample ..." % (elapsed, args.steps), file=sys.stderr, flush=True)
             import oracle_lib as O
             n = max(1, min(args.cpu_sample_ctus, ctus_w * ctus_h))
             cw = min(ctus_w, 4)
