@@ -69,11 +69,6 @@ struct VxParams {
   uint64_t            scratch_per_stream;
   unsigned long long *counters;      // 4 global work counters
   int32_t             ntiles, nsub;  // tiles / sub-streams per frame (equal without WPP)
-  int32_t            *train_rows;    // GET_TRAINING_SET counterpart: 28 ints per qualifying luma node (26 features, complexity class, chosen partition); NULL: off
-  uint32_t           *train_n;       // rows handed out so far (atomic)
-  int32_t             train_cap, pad_train;
-  int32_t            *wpp_progress;  // WPP: per (frame*nsub+sub) the CTUs of the row that are finished and visible
-  uint16_t           *wpp_sync;      // WPP: per (frame*nsub+sub) the contexts behind the row's first CTU
   // slice_data writer (optional): per (frame, tile) byte range of the payload buffer and the persistent coder state (32 B each)
   uint8_t            *payload;
   const uint64_t     *payload_off;
@@ -91,6 +86,12 @@ struct VxParams {
   int32_t             lmcs_on, lmcs_cadj_on, lmcs_min_bin, lmcs_max_bin;
   int32_t             lmcs_pivot[17], lmcs_cadj[16];
   int32_t             n_streams;     // stream descriptors of the launch: the workgroups (at most one per resident slot) take them from a queue (counters[52])
+  // (round-3 additions at the end: the members above keep their offsets in the LDS copy)
+  int32_t             train_cap;
+  int32_t            *train_rows;    // GET_TRAINING_SET counterpart: 28 ints per qualifying luma node (26 features, complexity class, chosen partition); NULL: off
+  uint32_t           *train_n;       // rows handed out so far (atomic)
+  int32_t            *wpp_progress;  // WPP: per (frame*nsub+sub) the CTUs of the row that are finished and visible
+  uint16_t           *wpp_sync;      // WPP: per (frame*nsub+sub) the contexts behind the row's first CTU
 };
 
 struct VxDeblockParams {     // vvcx_deblock.hip

@@ -86,7 +86,6 @@ struct Frame {                     // one recursion level: partitioner level + C
   uint64_t ss;
   double max_cost;
   Sum best, temp;
-  int32_t train_row;               // row of the training dump this luma node filled at entry (-1: none): its label is written when the node is left
 };
 
 struct Cand { uint8_t mode, mrl; };
@@ -195,7 +194,9 @@ struct Lds {
   // CCLM: down-sampled luma of the chroma node (nodes of at most BUF chroma samples; bigger ones in HBM scratch), availability and line parameters
   // (the luma full-RD stage keeps the fractional bits of the transform-skip context sets where the chroma operations keep the CCLM neighbour lines: ts_build_tables)
   alignas(16) int16_t lm_in[BUF / 2]; union { struct { int16_t lm_top[64], lm_left[64]; }; int ts_tab[36]; }; int lm_info[4], lm_ok, lm_nsatd; int lm_par[2][3][3]; int64_t lm_cost[8];
-  int16_t fa_nb[5][4]; int fa_n, fa_res, fa_row, fa_feat[27];      // FAST_ALGORITHM: neighbour CUs {x, y, w, h} of the node, forest answer, features
+  int16_t fa_nb[5][4]; int fa_n, fa_res, fa_row, fa_feat[27];
+  int train_row[MAXD];             // per recursion level: the row of the training dump the luma node filled at entry (-1: none); its label is written when the node is left
+                                   // (kept here, behind the hot fields, so that the Frame records and everything after them stay where they were)      // FAST_ALGORITHM: neighbour CUs {x, y, w, h} of the node, forest answer, features
   Arith aw; uint8_t *aw_out; uint32_t aw_cap; int colm;      // bitstream pass: arithmetic coder, its output (HBM) and capacity; co-located luma mode of the chroma node
   unsigned long long prof[VVCX_STAMP ? 48 : 1];    // shader-clock ticks per operation kind (diagnostic build only, see vvcx_get_profile)
 };
@@ -4394,6 +4395,15 @@ __device__ __noinline__ int ctrl_b_done(const VxParams &p_, const VxFrameDev &fd
 }
 
 // one controller step: runs until a parallel operation is posted (returns) or the CTU tree is finished (posts OP_DONE)
+// the label of a node's training row: the partition the search chose there (PartSplit code, 0 = not split; -1: no encoding), read from the split series the winner left in the
+// unit map.  Out of line: the controller loop keeps its registers
+__device__ __noinline__ void ctrl_train_label(const Frame &f, int row)
+{
+  const VxParams &p = L.par; const VxFrameDev &fd = L.fdv;
+  int label = -1;
+  if (f.best.cost != MAX_DOUBLE) label = (int) ((fd.units[0][(f.y >> 2) * p.uw + (f.x >> 2)].ss >> (f.depth * 5)) & 31);
+  p.train_rows[(size_t) row * 28 + 27] = label;
+}
 __device__ __attribute__((always_inline)) inline void control_step(const VxParams &p, const VxFrameDev &fd, uint8_t *scratch)
 {
   CtlState &S = L.S;
@@ -4419,13 +4429,13 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
       if (f.nmodes == 0) { f.phase = PH_EXIT2; break; }
       f.phase = PH_RUN; f.ctx_dirty = 0;
       L.pre_copy_d = d;                                   // m_CurrCtx->start = ctx: done by the dispatch that runs the node's first operation
-      f.train_row = -1;
+      L.train_row[d] = -1;
       if (((p.tools & TOOL_FAST) || p.train_rows) && !ch && fast_candidates(p, fd, f, tile)) { f.phase = PH_FAST_DONE; set_node(f, d); post(OP_FAST); return; }
       break;
     }
     case PH_FAST_DONE: {                                // EL/EncCu.cpp:1126-1217: replace the mode stack by the predicted mode if the controller accepts it
       const int res = L.fa_res;
-      f.train_row = L.fa_row;
+      L.train_row[d] = L.fa_row;
       if (res >= 0 && res <= 5) {
         const int mode = res == 0 ? ETM_INTRA : res == 1 ? ETM_SPLIT_QT : res == 2 ? ETM_SPLIT_BT_H : res == 3 ? ETM_SPLIT_BT_V : res == 4 ? ETM_SPLIT_TT_H : ETM_SPLIT_TT_V;
         int valid = try_mode(p, d, ch, mode);                                             // tryModeMaster 1199
@@ -4694,11 +4704,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
       L.op_a = CTX_CUR; L.op_b = CTX_BEST; L.op_c = d; L.op_d = 1; post(OP_RESTORE_PIC); return;   // picture ← bestCS, ctx ← best
     }
     case PH_EXIT2: {
-      if (f.train_row >= 0) {                           // the label of the node's training row: the partition the search chose here (PartSplit code, 0 = not split; -1: no encoding)
-        int label = -1;
-        if (f.best.cost != MAX_DOUBLE) label = (int) ((fd.units[0][(f.y >> 2) * p.uw + (f.x >> 2)].ss >> (f.depth * 5)) & 31);
-        p.train_rows[(size_t) f.train_row * 28 + 27] = label;
-      }
+      if (L.train_row[d] >= 0) ctrl_train_label(f, L.train_row[d]);
       L.d = d - 1; break;
     }
     }
