@@ -69,6 +69,10 @@ def pmc_valu(workload):
                    "source": os.path.relpath(p, ROOT)}
             if ms:
                 out["issue_frac"] = pl["SQ_INSTS_VALU"] * 4.0 / (ms * 1e-3 * 2.4e9 * 1024)
+            if pl.get("SQ_WAVE_CYCLES") and pl.get("SQ_WAIT_ANY") is not None:
+                out["wait_any_frac"] = pl["SQ_WAIT_ANY"] / pl["SQ_WAVE_CYCLES"]
+            if pl.get("SQ_LDS_IDX_ACTIVE") and pl.get("SQ_LDS_BANK_CONFLICT") is not None:      # cycles lost to bank conflicts per cycle the LDS index unit is busy
+                out["lds_bank_conflict_frac"] = pl["SQ_LDS_BANK_CONFLICT"] / pl["SQ_LDS_IDX_ACTIVE"]
             return out
     return None
 
@@ -244,8 +248,16 @@ def main():
                          "algorithmic_bytes_per_launch": ctus_per_step * b_ctu, "valu": valu},
             "work": {"satd_candidates_per_launch": int(counters[0]), "rd_tu_evaluations_per_launch": int(counters[1]),
                      "rd_pixels_per_launch": int(counters[2]), "nodes_per_launch": int(counters[3]),
-                     "rd_pixels_per_s": float(counters[2]) / avg_kernel_s},
+                     "rd_pixels_per_s": float(counters[2]) / avg_kernel_s, "satd_candidates_per_s": float(counters[0]) / avg_kernel_s,
+                     "rd_tu_evaluations_per_s": float(counters[1]) / avg_kernel_s},
         }
+        # SURVEY 8d (iii), the diagnostic traffic model: what an implementation that staged nothing in LDS would pull per launch - every full-RD TU evaluation its original
+        # samples and reference lines, every winner written and read once - from the work counters (TU shapes approximated by squares of the mean TU area)
+        if counters[1]:
+            side = (float(counters[2]) / float(counters[1])) ** 0.5
+            bps = 2 if bd == 10 else 1
+            out["work"]["diagnostic_traffic_model_bytes_per_launch"] = float(counters[2]) * bps + float(counters[1]) * (4 * side + 1) * 2 + ctus_per_step * b_ctu
+
         # secondary kernel (not part of the timed step): in-loop deblocking of the pictures just coded, an HBM-bound pass
         try:
             if lmcs:
