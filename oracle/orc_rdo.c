@@ -1063,7 +1063,6 @@ static uint64_t est_intra_pred_luma(orc_enc *e, area_t a, luma_passes *ps, int *
         }
     }
   }
-  if (getenv("ORC_DBG")) { fprintf(stderr, "ORC node %d %d %dx%d satd %llu list", x, y, w, h, (unsigned long long) e->cnt_satd); for (int i = 0; i < rdSize; i++) fprintf(stderr, " %d:%d(%.1f)", rdList[i].mode, rdList[i].mrl, rdCost[i]); fprintf(stderr, "\n"); }
   if (testISP) { isp.had_n = rdSize; for (int i = 0; i < rdSize; i++) isp.had_mode[i] = rdList[i].mode; }      /* 624-632: the regular list, before the MRL candidates */
   {
     unsigned mpm[6]; get_mpms(e, x, y, w, h, mpm);
@@ -1941,7 +1940,6 @@ static void check_rd_cost_intra(orc_enc *e, partitioner *P, int d, cu_ctx *C, cs
           if (!reuse && !isp) C->no_isp_cost = t.cost;                                                     /* useModeResult(ETM_INTRA), EL/EncModeCtrl.cpp:2120-2123 */
           /* checkSkipOtherLfnst (EL/EncModeCtrl.cpp:2070-2087): the intra passes are the first modes of a node, so its condition always holds */
           if (lfnstOn) skipOtherLfnst = !cbf;
-          if (getenv("ORC_DBG")) fprintf(stderr, "RES ch %d node %d %d %dx%d lf %d mts %d dir %d isp %d tucbf %d cost %.3f dist %llu\n", ch, a.x, a.y, a.w, a.h, lfnstIdx, mtsFlag, dir, isp, tucbf, t.cost, (unsigned long long) t.dist);
           t.n_cu = 1; t.is_split = 0;
           t.f_bt = t.l_bt = P->bt_depth; t.f_depth = P->depth; t.f_mt = P->mt_depth; t.f_cbf = cbf != 0;
           t.f_w = t.l_w = a.w >> sh; t.f_h = t.l_h = a.h >> sh; t.max_qt = P->qt_depth;
