@@ -178,10 +178,17 @@ def main():
         d = 6 if bd == 10 else 1
         lmcs = dict(enable=1, chroma_adj=1, min_bin=1, max_bin=14, delta_cw=[0] + [d] * 7 + [d + (2 if bd == 10 else 0)] * 2 + [d] * 5 + [0])
         sp["lmcs"] = lmcs
+    elif args.tools & 0x400:
+        # the reference's order of things: the picture analysis (vvcx_lmcs_analyze = EncReshape::preAnalyzerLMCS, run on the first picture of the batch) decides whether the
+        # slice uses LMCS; for 8-bit and for full-range 10-bit content it says no, like the reference
+        first = next(iter(pkg.frames_of_rank(args.frames * world, rank, world)))
+        m = pkg.vvcx.lmcs_analyze(pkg.synth_frame(W, H, first, bd, 1000 + first, chroma_texture=args.chroma_texture), bd, args.qp, lib_path=args.lib)
+        if m["enable"]:
+            lmcs = m; sp["lmcs"] = lmcs
     enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"], lmcs=lmcs)
     frames = []
     for poc in pkg.frames_of_rank(args.frames * world, rank, world):      # weak scaling: args.frames per rank
-        planes = pkg.synth_frame(W, H, poc, bd, 1000 + poc, chroma_texture=args.chroma_texture, limited=lmcs is not None)
+        planes = pkg.synth_frame(W, H, poc, bd, 1000 + poc, chroma_texture=args.chroma_texture, limited=(args.lmcs == "model" and lmcs is not None))
         org = [torch.from_numpy(p if bd == 8 else p.view(np.int16)).cuda() for p in planes]      # 16-bit containers: same bits, a dtype torch can hold
         rec = [torch.zeros_like(t) for t in org]
         frames.append((org, rec))
@@ -221,7 +228,7 @@ def main():
         avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
         achieved = ctus_per_step * b_ctu / avg_kernel_s / 1e9
         workload = ("%dx%d %d-bit 4:2:0 All-Intra QP%d full RDO, tools 0x%x%s, chroma texture %.2f, %d frame(s)/step/GPU, %dx%d uniform tiles = %d CTU streams per frame"
-                    % (W, H, bd, args.qp, args.tools, " (LMCS model on, limited-range luma)" if lmcs else "", args.chroma_texture, args.frames, tc, tr, tc * tr))
+                    % (W, H, bd, args.qp, args.tools, (" (LMCS model on, limited-range luma)" if args.lmcs == "model" else " (LMCS model chosen by the picture analysis)") if lmcs else "", args.chroma_texture, args.frames, tc, tr, tc * tr))
         traffic, traffic_src, traffic_split = pmc_traffic(workload)
         valu = pmc_valu(workload)
         out = {
@@ -276,7 +283,7 @@ def main():
             cw = min(ctus_w, 4)
             chh = max(1, n // cw)
             sw, sh = min(W, cw * 128), min(H, chh * 128)
-            planes = pkg.synth_frame(W, H, 0, bd, 1000, chroma_texture=args.chroma_texture, limited=lmcs is not None)
+            planes = pkg.synth_frame(W, H, 0, bd, 1000, chroma_texture=args.chroma_texture, limited=(args.lmcs == "model" and lmcs is not None))
             crop = [planes[0][:sh, :sw], planes[1][:sh // 2, :sw // 2], planes[2][:sh // 2, :sw // 2]]
             t1 = time.perf_counter()
             O.compress_frame(crop, sw, sh, sp, tile_cols=(sw + 127) // 128, tile_rows=(sh + 127) // 128, tools=args.tools, forest=forest, bit_depth=bd)

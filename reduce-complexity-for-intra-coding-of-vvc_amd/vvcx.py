@@ -128,6 +128,22 @@ class _SliceCfg(C.Structure):
                 ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32), ("gop_size", C.c_int32), ("dep_quant", C.c_int32)]
 
 
+def lmcs_analyze(planes, bit_depth, qp, update_ctrl=1, lib_path=None):
+    """vvcx_lmcs_analyze: the reference encoder's LMCS picture analysis for an intra picture (host planes) -> the model as set_slice(lmcs=...) takes it:
+    dict(enable, chroma_adj, min_bin, max_bin, delta_cw[16])"""
+    L = load_library(lib_path)
+    dt = np.uint8 if bit_depth < 10 else np.uint16
+    pl = [np.ascontiguousarray(p, dt) for p in planes]
+    h, w = pl[0].shape
+    org = (C.c_void_p * 3)(*[p.ctypes.data for p in pl]); st = (C.c_int * 3)(*[p.shape[1] for p in pl])
+    sl = _Slice()
+    L.vvcx_lmcs_analyze.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    rc = L.vvcx_lmcs_analyze(org, st, w, h, bit_depth, qp, update_ctrl, C.byref(sl))
+    if rc != 0:
+        raise VvcxError("vvcx_lmcs_analyze: error %d" % rc)
+    return dict(enable=int(sl.lmcs_enable), chroma_adj=int(sl.lmcs_chroma_adj), min_bin=int(sl.lmcs_min_bin), max_bin=int(sl.lmcs_max_bin), delta_cw=[int(v) for v in sl.lmcs_delta_cw])
+
+
 def chroma_qp_table(bit_depth=8, qp_in=(2, 31, 43), qp_out=(2, 32, 41), lib_path=None):
     """vvcx_chroma_qp_table: mapped chroma QP for q = -6*(bit_depth-8) .. 63 (host function of the library)"""
     L = load_library(lib_path)

@@ -261,3 +261,24 @@ def check_forced_isp_deblock(pkg, which, lib_path=None):
                 assert np.array_equal(got[c].astype(np.int16).ravel(), g["forced_planes"][o:o + sizes[c]]), (W, H, qp, bd, c); o += sizes[c]
             assert any((got[c] != pre[c]).any() for c in range(3))
         off += sum(sizes)
+
+
+def lmcs_test_picture(pkg, W, H, bd, seed, limited, tex100, ori100, scr100, kind):
+    """Pictures for the LMCS analysis fixture (tests/golden/lmcs_analysis.npz): the synthetic frame, then one of a few tone changes that move the luma histogram and the
+    local variances around (what the analysis looks at): 0 none, 1 dark (range squeezed into the lower third), 2 bright, 3 noisy shadows, 4 two plateaus with noise, 5 smooth ramp."""
+    pl = [np.array(p) for p in pkg.synth_frame(W, H, seed % 3, bd, seed, limited=bool(limited), chroma_texture=tex100 / 100.0, oriented=ori100 / 100.0, screen=scr100 / 100.0)]
+    g = np.random.default_rng(seed)
+    lo, hi = (16 << (bd - 8), 235 << (bd - 8)) if limited else (0, (1 << bd) - 1)
+    y = pl[0].astype(np.int64)
+    if kind == 1:
+        y = lo + (y - lo) // 3
+    elif kind == 2:
+        y = hi - (hi - y) // 3
+    elif kind == 3:
+        y = lo + (y - lo) // 4 + g.integers(0, 40 << (bd - 8), y.shape)
+    elif kind == 4:
+        y = np.where((np.arange(W)[None, :] // 64 + np.arange(H)[:, None] // 64) % 2 == 0, lo + (hi - lo) // 8, hi - (hi - lo) // 8) + g.integers(-6 << (bd - 8), 7 << (bd - 8), y.shape)
+    elif kind == 5:
+        y = lo + ((np.arange(W)[None, :] + np.arange(H)[:, None]) * (hi - lo)) // (W + H)
+    pl[0] = np.clip(y, lo, hi).astype(pl[0].dtype)
+    return pl

@@ -233,6 +233,18 @@ def test_lmcs_in_the_search(case):
     _check([pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=0.8, oriented=25.0, screen=scr, limited=True)], W, H, sp, bit_depth=bd, tile_cols=tc, tile_rows=tr, tools=TSK | pkg.TOOL_LMCS)
 
 
+def test_lmcs_from_the_picture_analysis_to_the_search():
+    """The whole LMCS chain of an intra picture as the reference runs it (EncGOP::xPicInitLMCS): vvcx_lmcs_analyze chooses the model from the original picture (pinned to the
+    reference's EncReshape by tests/golden/lmcs_analysis.npz), the slice carries it, the search runs in the mapped domain - against the oracle given the same model.  The
+    picture is the fixture's most perturbed model (screen content, limited-range 10 bit)."""
+    W, H, qp = 640, 360, 42
+    planes = O.lmcs_test_picture(pkg, W, H, 10, 78, 1, 0, 0, 80, 0)
+    m = pkg.vvcx.lmcs_analyze(planes, 10, qp)
+    assert m["enable"] and len(set(m["delta_cw"][1:15])) >= 3
+    sp = pkg.slice_params(qp, bit_depth=10, dep_quant=True); sp["lmcs"] = m
+    _check([planes], W, H, sp, bit_depth=10, tile_cols=5, tile_rows=3, tools=FULL, workers=8)
+
+
 def test_lmcs_tool_with_a_slice_that_disables_it_and_without_cu_reuse():
     # the reference's analysis switches LMCS off for full-range pictures: the tool bit alone must not change anything
     _check([pkg.synth_frame(128, 128, 0, 8, 11, chroma_texture=0.5)], 128, 128, pkg.slice_params(32, dep_quant=True), tools=TSK | pkg.TOOL_LMCS)

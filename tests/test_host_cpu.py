@@ -355,6 +355,29 @@ def test_training_set_dump_on_cpu_emulator_matches_oracle(emu_so):
     enc.close()
 
 
+def test_lmcs_picture_analysis_matches_the_reference_encoder(hip_lib):
+    """vvcx_lmcs_analyze (the picture analysis that chooses the LMCS model of an intra picture) against what the reference's own EncReshape, compiled in place,
+    decided for the same pictures (tests/golden/lmcs_analysis.npz: preAnalyzerLMCS + constructReshaperLMCS on 29 pictures - several codeword budgets and perturbations, the
+    extended range with negative deltas, chroma adjustment off above 5.18 M samples, both sides of the QP 22 rule, LMCS off for 8-bit and full-range content)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "lmcs_analysis.npz"))["rows"]
+    seen = set()
+    for r in g:
+        W, H, bd, qp, seed, limited, tex, ori, scr, kind = [int(v) for v in r[:10]]
+        if W * H > 2500000 and (W, H) in seen:
+            continue                                   # one 4K picture is enough for the CPU suite
+        seen.add((W, H))
+        planes = O.lmcs_test_picture(pkg, W, H, bd, seed, limited, tex, ori, scr, kind)
+        m = pkg.vvcx.lmcs_analyze(planes, bd, qp)
+        assert m["enable"] == int(r[10]), (W, H, bd, qp, seed, kind)
+        if m["enable"]:
+            assert [m["chroma_adj"], m["min_bin"], m["max_bin"]] + m["delta_cw"] == [int(v) for v in r[11:]], (W, H, bd, qp, seed, kind, m, r[11:])
+        else:
+            assert not any(m["delta_cw"]) and m["chroma_adj"] == 0
+    assert len({tuple(r[10:]) for r in g}) >= 7        # the fixture is not one model repeated
+    with pytest.raises(pkg.VvcxError):
+        pkg.vvcx.lmcs_analyze(O.lmcs_test_picture(pkg, 64, 64, 10, 1, 1, 0, 0, 0, 0), 10, 32, update_ctrl=2)
+
+
 def test_wavefront_rows_on_cpu_emulator_match_oracle(emu_so):
     """VVCX_TOOL_WPP on the device path (CPU debug emulation): a CTU row as a stream of its own that starts from the contexts behind the first CTU of the row above and does not
     see the CTU above-right; one sub-stream per CTU row in the payload.  2 x 2 CTUs (one whole CTU and three boundary slivers).  Also: a row cannot be submitted ahead of
