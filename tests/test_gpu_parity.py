@@ -410,7 +410,7 @@ def test_slice_data_payload_matches_the_bytes_the_reference_decoder_accepted(fix
         assert np.array_equal(got, exp), (W, H, qp, tc, tr, bd)
 
 
-@pytest.mark.parametrize("case", [(640, 384, 32, 8, 1, 1, 31, 0xbff, 2), (520, 392, 27, 8, 2, 1, 32, 0x953, 1), (384, 264, 37, 10, 1, 2, 33, 0x913, 1), (1920, 264, 32, 8, 1, 1, 34, FULL, 1)])
+@pytest.mark.parametrize("case", [(640, 384, 32, 8, 1, 1, 31, 0xbff, 2), (520, 392, 27, 8, 2, 1, 32, 0x953, 1), (384, 264, 37, 10, 1, 2, 33, 0x913, 1), (1152, 264, 32, 8, 1, 1, 34, FULL, 1)])
 def test_wavefront_rows_as_lagged_streams(case):
     """VVCX_TOOL_WPP (cfg WaveFrontSynchro 1): the CTU rows of a tile run as streams of their own, each one CTU behind the row above (workgroups waiting on the row above's
     published count), with the context hand-over and the hidden above-right CTU; results, CU table, reconstruction and work counters equal the oracle's sequential WPP run,
