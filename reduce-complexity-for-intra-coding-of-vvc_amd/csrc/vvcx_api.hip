@@ -16,6 +16,8 @@
 
 extern "C" __global__ void vvcx_compress_kernel_u8(VxParams p);
 extern "C" __global__ void vvcx_compress_kernel_u16(VxParams p);
+extern "C" __global__ void vvcx_compress_wpp_kernel_u8(VxParams p);
+extern "C" __global__ void vvcx_compress_wpp_kernel_u16(VxParams p);
 extern "C" __global__ void vvcx_leaf_dist_kernel(const int16_t *a, const int16_t *b, int w, int h, int16_t *scr, unsigned long long *out);
 extern "C" __global__ void vvcx_leaf_pred_kernel_u8(VxParams p, const VxLeafPred *cases, int16_t *out, const int *out_off);
 extern "C" __global__ void vvcx_leaf_pred_kernel_u16(VxParams p, const VxLeafPred *cases, int16_t *out, const int *out_off);
@@ -66,6 +68,7 @@ struct vvcx_handle {
   std::vector<int> ctu_sub, sub_tile, sub_above, tile_sub0, tile_nsub;      // sub-stream of each CTU; its tile; the sub-stream of the CTU row above in the same tile (-1: none); per tile: first sub-stream, count
   std::vector<std::vector<int>> sub_ctus;       // CTUs of each sub-stream in coding order
   int32_t *train_rows_d; uint32_t *train_n_d; int train_cap;      // vvcx_enable_training_dump
+  int32_t *wpp_sched_d; int wpp_sched_cap; int wpp_rr;      // the launch's WPP scheduler state (vvcx_kernel.hip run_streams_wpp); test mode (env VVCX_WPP_TEST_INTERLEAVE)
   int32_t *wpp_progress_d; uint16_t *wpp_sync_d;  // WPP: CTUs finished per (frame, sub-stream); the contexts behind the first CTU of each (m_entropyCodingSyncContextState)
   std::vector<int> next_idx;                    // per (frame, sub-stream): how many CTUs of the stream are done
   // device memory
@@ -180,6 +183,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
     }
     h->nsub = (int) h->sub_ctus.size();
   }
+  h->wpp_sched_d = nullptr; h->wpp_sched_cap = 0; { const char *e = getenv("VVCX_WPP_TEST_INTERLEAVE"); h->wpp_rr = e && *e == '1'; }
   h->wpp_progress_d = nullptr; h->wpp_sync_d = nullptr; h->train_rows_d = nullptr; h->train_n_d = nullptr; h->train_cap = 0;
   DevGuard guard(cfg->device);
   if (!guard.ok) { delete h; return fail(VVCX_ERR_DEVICE, "hipSetDevice(%d) failed", cfg->device); }
@@ -217,7 +221,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
 extern "C" void vvcx_destroy(vvcx_handle *h)
 {
   if (!h) return;
-  (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d); (void) hipFree(h->wpp_progress_d); (void) hipFree(h->wpp_sync_d); (void) hipFree(h->train_rows_d); (void) hipFree(h->train_n_d);
+  (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d); (void) hipFree(h->wpp_progress_d); (void) hipFree(h->wpp_sync_d); (void) hipFree(h->wpp_sched_d); (void) hipFree(h->train_rows_d); (void) hipFree(h->train_n_d);
   (void) hipFree(h->payload_d); (void) hipFree(h->payload_off_d); (void) hipFree(h->payload_cap_d); (void) hipFree(h->arith_d);
   (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
   (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d); (void) hipFree(h->dq_d); (void) hipFree(h->lmcs_lut_d); (void) hipFree(h->lmcs_org_d);
@@ -449,7 +453,8 @@ extern "C" int vvcx_resident_streams(const vvcx_handle *h)
   DevGuard guard(h->cfg.device);
   int cus = 0, per_cu = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess) return 0;
-  const void *k = h->cfg.bit_depth == 8 ? (const void *) vvcx_compress_kernel_u8 : (const void *) vvcx_compress_kernel_u16;
+  const bool wpp = (h->cfg.tools & VVCX_TOOL_WPP) != 0;
+  const void *k = h->cfg.bit_depth == 8 ? (wpp ? (const void *) vvcx_compress_wpp_kernel_u8 : (const void *) vvcx_compress_kernel_u8) : (wpp ? (const void *) vvcx_compress_wpp_kernel_u16 : (const void *) vvcx_compress_kernel_u16);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, VXD_NT, 0) != hipSuccess) return 0;
   return cus * per_cu;
 }
@@ -531,6 +536,12 @@ extern "C" int vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int 
     (void) hipFree(h->scratch_d); h->scratch_d = nullptr; HIPCHK(hipMalloc((void **) &h->scratch_d, need)); h->scratch_cap = need;
     HIPCHK(hipMemsetAsync(h->scratch_d, 0, need, stream));       // CU-cache entries and generation counters start empty
   }
+  if (h->cfg.tools & VVCX_TOOL_WPP) {                    // scheduler state of this launch: nothing finished, nothing owned, every stream with its tasks left
+    if (2 + 2 * ns > h->wpp_sched_cap) { (void) hipFree(h->wpp_sched_d); h->wpp_sched_d = nullptr; HIPCHK(hipMalloc((void **) &h->wpp_sched_d, sizeof(int32_t) * (size_t) (2 + 2 * ns))); h->wpp_sched_cap = 2 + 2 * ns; }
+    std::vector<int32_t> sched((size_t) (2 + 2 * ns), 0);
+    for (int i = 0; i < ns; i++) sched[(size_t) (2 + ns + i)] = sd[(size_t) i].n_tasks;
+    HIPCHK(hipMemcpy(h->wpp_sched_d, sched.data(), sched.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMemcpyAsync(h->streams_d, sd.data(), sizeof(VxStreamDesc) * (size_t) ns, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(h->task_ctu_d, task_ctu.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemsetAsync(h->counters_d, 0, 56 * sizeof(unsigned long long), stream));
@@ -548,7 +559,7 @@ extern "C" int vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int 
   p.frames = h->frames_d; p.streams = h->streams_d; p.task_ctu = h->task_ctu_d; p.results = h->results_d; p.stream_ctx = h->stream_ctx_d;
   p.payload = h->payload_d; p.payload_off = h->payload_off_d; p.payload_cap = h->payload_cap_d; p.arith_state = h->arith_d;
   p.scratch = h->scratch_d; p.scratch_per_stream = per_stream; p.counters = h->counters_d; p.ntiles = h->ntiles; p.nsub = h->nsub; p.wpp_progress = h->wpp_progress_d; p.wpp_sync = h->wpp_sync_d;
-  p.train_rows = h->train_rows_d; p.train_n = h->train_n_d; p.train_cap = h->train_cap;
+  p.train_rows = h->train_rows_d; p.train_n = h->train_n_d; p.train_cap = h->train_cap; p.wpp_sched = h->wpp_sched_d; p.wpp_rr = h->wpp_rr;
   p.f_node = h->f_node_d; p.f_value = h->f_value_d; p.f_root = h->f_root_d; p.f_ntrees = h->f_ntrees; p.f_nclasses = h->f_nclasses;
   for (int c = 0; c < 8; c++) p.f_classes[c] = h->f_classes[c];
   p.n_streams = ns;
@@ -595,7 +606,10 @@ extern "C" int vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int 
   }
 
   HIPCHK(hipEventRecord(h->ev0, stream));
-  if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_compress_kernel_u8, dim3((unsigned) grid), dim3(VXD_NT), 0, stream, p);
+  if (h->cfg.tools & VVCX_TOOL_WPP) {
+    if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_compress_wpp_kernel_u8, dim3((unsigned) grid), dim3(VXD_NT), 0, stream, p);
+    else hipLaunchKernelGGL(vvcx_compress_wpp_kernel_u16, dim3((unsigned) grid), dim3(VXD_NT), 0, stream, p);
+  } else if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_compress_kernel_u8, dim3((unsigned) grid), dim3(VXD_NT), 0, stream, p);
   else hipLaunchKernelGGL(vvcx_compress_kernel_u16, dim3((unsigned) grid), dim3(VXD_NT), 0, stream, p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, stream));
@@ -632,6 +646,11 @@ extern "C" int vvcx_wait_ctus(vvcx_handle *h, vvcx_ctu_result *out, int n)
   DevGuard guard(h->cfg.device);
   HIPCHK(hipStreamSynchronize(h->pend_stream));
   HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  if (h->cfg.tools & VVCX_TOOL_WPP) {
+    int32_t st[2] = { 0, 0 };
+    HIPCHK(hipMemcpy(st, h->wpp_sched_d, sizeof st, hipMemcpyDeviceToHost));
+    if (st[1]) return fail(VVCX_ERR_DEVICE, "WPP scheduler gave up: %d of the launch's CTU rows finished, the others never became ready", st[0]);
+  }
   h->next_idx = h->pend_next;
   const VxCtuRes *res = h->pend_res;
   for (int k = 0; k < n; k++) {

@@ -195,6 +195,7 @@ struct Lds {
   // (the luma full-RD stage keeps the fractional bits of the transform-skip context sets where the chroma operations keep the CCLM neighbour lines: ts_build_tables)
   alignas(16) int16_t lm_in[BUF / 2]; union { struct { int16_t lm_top[64], lm_left[64]; }; int ts_tab[36]; }; int lm_info[4], lm_ok, lm_nsatd; int lm_par[2][3][3]; int64_t lm_cost[8];
   int16_t fa_nb[5][4]; int fa_n, fa_res, fa_row, fa_feat[27];
+  int wpp_ok, wpp_pos;             // WPP scheduler: answer of the readiness test, position the picked row continues at
   int train_row[MAXD];             // per recursion level: the row of the training dump the luma node filled at entry (-1: none); its label is written when the node is left
                                    // (kept here, behind the hot fields, so that the Frame records and everything after them stay where they were)      // FAST_ALGORITHM: neighbour CUs {x, y, w, h} of the node, forest answer, features
   Arith aw; uint8_t *aw_out; uint32_t aw_cap; int colm;      // bitstream pass: arithmetic coder, its output (HBM) and capacity; co-located luma mode of the chroma node
@@ -4905,35 +4906,45 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
-// WPP hand-over between the workgroups of two CTU rows.  The row above publishes its count with release semantics at device scope after a device-scope fence of every thread
-// that wrote picture data; the waiting row's thread 0 polls it with acquire loads, and after the barrier every thread fences (acquire) before it reads the neighbour's
-// samples.  The row above was taken from the queue before this one (vvcx_submit_ctus keeps a tile's rows in order), so its workgroup is running or done: the wait ends.
-__device__ __noinline__ void wpp_wait(const int32_t *cnt, int need)
+// WPP hand-over between the workgroups that run the CTU rows of a tile.  A row publishes the number of its finished CTUs with release semantics at device scope after a
+// device-scope fence of every thread that wrote picture data; a workgroup that wants to run CTU k of the row below first reads that count with an acquire load (thread 0),
+// and after the barrier every thread fences (acquire) before it reads the neighbour's samples.  Nobody ever waits in place: a row whose next CTU is not ready is put back
+// (contexts, coder state and position are stream state in HBM) and the workgroup takes another row that is (run_streams_wpp).
+__device__ inline int wpp_count(const int32_t *cnt)
 {
-  if (VTX == 0) {
 #ifdef VX_EMU
-    if (*cnt < need) { fprintf(stderr, "WPP: row above at %d, %d needed - the emulator runs the workgroups one after the other, the queue order is wrong\n", *cnt, need); abort(); }
+  return *cnt;
 #else
-    while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(32);
+  return __hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-  }
+}
+__device__ inline void wpp_publish(int32_t *cnt, int v)
+{
+#ifdef VX_EMU
+  *cnt = v;
+#else
+  __hip_atomic_store(cnt, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// all threads: is CTU `need - 1` of the row above finished?  (thread 0 asks, everybody gets the answer and the acquire fence)
+__device__ __noinline__ int wpp_ready(const int32_t *cnt, int need)
+{
+  if (VTX == 0) L.wpp_ok = wpp_count(cnt) >= need;
   __syncthreads();
+  const int ok = uni(L.wpp_ok);
 #ifndef VX_EMU
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
+  __syncthreads();
+  return ok;
 }
-__device__ inline void wpp_publish(int32_t *cnt, int done)
-{
-#ifdef VX_EMU
-  *cnt = done;
-#else
-  __hip_atomic_store(cnt, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
+// Runs the tasks [pos0, ...) of a stream for as long as they are ready (always, without WPP) and returns the position it stopped at; the stream's state (contexts, coder,
+// position) is left in HBM, so that any workgroup can continue it.
 template <typename T>
-__device__ void run_stream(const VxParams &p, int stream_idx)
+__device__ int run_stream(const VxParams &p, int stream_idx, int pos0)
 {
-  const VxStreamDesc sd = p.streams[stream_idx];
+  VxStreamDesc sd = p.streams[stream_idx];
+  sd.done_before += pos0; sd.first_task += pos0; sd.n_tasks -= pos0;      // what is left of it in this launch
   if (VTX == 0) { L.par = p; L.fdv = p.frames[sd.frame]; }
   const VxFrameDev &fd = p.frames[sd.frame];
   uint8_t *scratch = p.scratch + (size_t) blockIdx.x * p.scratch_per_stream;
@@ -4948,14 +4959,16 @@ __device__ void run_stream(const VxParams &p, int stream_idx)
   load_tables();
   // WPP: the row's first CTU starts from the contexts the row above left behind its own first CTU (EL/EncSlice.cpp:1648-1661); later launches of the row carry on from `carry`
   const int wpp_above = sd.above >= 0 ? sd.frame * p.nsub + sd.above : -1;
-  if (wpp_above >= 0 && sd.done_before == 0) { wpp_wait(p.wpp_progress + wpp_above, 1); ctx_copy_all(&L.ctxs[CI_CUR], (const Ctx *) (p.wpp_sync + (size_t) wpp_above * 2 * NCTX)); }
+  if (wpp_above >= 0 && sd.done_before == 0) ctx_copy_all(&L.ctxs[CI_CUR], (const Ctx *) (p.wpp_sync + (size_t) wpp_above * 2 * NCTX));      // (the scheduler saw the row above past its first CTU)
   else ctx_copy_all(&L.ctxs[CI_CUR], carry);
   __syncthreads();
-  for (int t = 0; t < sd.n_tasks; t++) {
+  int t = 0;
+  for (; t < sd.n_tasks; t++) {
     const int addr = p.task_ctu[sd.first_task + t];
     const int ctu_x = (addr % p.ctus_w) << 7, ctu_y = (addr / p.ctus_w) << 7;
     // WPP: CTU k of a row reads the reconstruction and the CU data of CTU k of the row above (the one further right is hidden from it, build_refs)
-    if (wpp_above >= 0) wpp_wait(p.wpp_progress + wpp_above, sd.done_before + t + 1);
+    if (wpp_above >= 0 && !wpp_ready(p.wpp_progress + wpp_above, sd.done_before + t + 1)) break;
+    if (p.wpp_rr && t > 0) break;                          // test mode: one CTU per visit, so that the rows of a picture really interleave
     // contexts at CTU start → snapshot slot (MAXD-1) "start"
     ctx_copy_all(ctx_ptr(scratch, CTX_START, MAXD + NW, 0), &L.ctxs[CI_CUR]);
     if (p.tools & TOOL_CU_REUSE) {                       // entries of an earlier CTU can never match (987-1024: poc / absolute area): a new generation drops them
@@ -5008,6 +5021,7 @@ __device__ void run_stream(const VxParams &p, int stream_idx)
   if (tid == 0) fprintf(stderr, "stream %d sub %d done_before %d tasks %d slot %d cnt %llu %llu %llu %llu gen %d\n", stream_idx, sd.sub, sd.done_before, sd.n_tasks, (int) blockIdx.x, L.cnt[0], L.cnt[1], L.cnt[2], L.cnt[3], L.cache_gen);
 #endif
   if (tid == 0) { for (int i = 0; i < 4; i++) atomicAdd(&p.counters[i], L.cnt[i]); if (VVCX_STAMP) for (int i = 0; i < 48; i++) atomicAdd(&p.counters[4 + i], PROF(i)); }
+  return pos0 + t;
 }
 
 // ------------------------------------------------------------------------------------------------ leaf operators
@@ -5192,11 +5206,81 @@ __device__ void run_streams(const VxParams &p)
     __syncthreads();
     const int s = uni(L.cur_stream);
     if (s >= p.n_streams) break;
-    run_stream<T>(p, s);
+    run_stream<T>(p, s, 0);
+  }
+}
+// WPP: the streams are CTU rows that depend on each other, so a workgroup does not own a row for its lifetime.  Scheduler state in HBM (p.wpp_sched, set up per launch by the
+// host): [0] rows finished, [1] abort flag, then per stream an owner flag and the number of its tasks that are left.  A workgroup looks for a row that nobody runs, that has
+// tasks left and whose next CTU is ready (first fit in queue order = longest tile first, top row first), runs it while it stays ready, puts it back, and looks again; it leaves
+// when every row is finished.  No workgroup ever waits for another one while holding something the other needs, and every wave reaches the exit: either all rows finish, or
+// a workgroup that found nothing to do for two minutes raises the abort flag, which everybody sees at the next look (the host reports it).
+template <typename T>
+__device__ void run_streams_wpp(const VxParams &p)
+{
+  VX_POISON_LDS(L);
+  const int n = p.n_streams;
+  int32_t *done = p.wpp_sched, *abort_flag = p.wpp_sched + 1, *owner = p.wpp_sched + 2, *left = p.wpp_sched + 2 + n;
+  int start = 0;
+  for (;;) {
+    __syncthreads();
+    if (VTX == 0) {
+      int pick = -1, pos = 0;
+#ifndef VX_EMU
+      const long long t_idle = (long long) wall_clock64();
+#endif
+      for (;;) {
+        if (wpp_count(abort_flag) || wpp_count(done) >= n) break;
+        for (int i = 0; i < n && pick < 0; i++) {
+          const int s = p.wpp_rr ? (start + i) % n : i;
+          if (wpp_count(owner + s)) continue;
+          int l = wpp_count(left + s);
+          if (l <= 0) continue;
+          const VxStreamDesc sd = p.streams[s];
+          const int32_t *above = sd.above >= 0 ? p.wpp_progress + (sd.frame * p.nsub + sd.above) : nullptr;
+          if (above && wpp_count(above) < sd.done_before + (sd.n_tasks - l) + 1) continue;
+#ifdef VX_EMU
+          if (*(owner + s)) continue; *(owner + s) = 1;
+#else
+          if (atomicCAS((int *) owner + s, 0, 1) != 0) continue;
+#endif
+          l = wpp_count(left + s);                        // under the lock: somebody may have run the row in between
+          if (l <= 0 || (above && wpp_count(above) < sd.done_before + (sd.n_tasks - l) + 1)) { wpp_publish(owner + s, 0); continue; }
+          pick = s; pos = sd.n_tasks - l;
+        }
+        if (pick >= 0) break;
+#ifdef VX_EMU
+        wpp_publish(abort_flag, 1);                       // the emulator runs one workgroup at a time: rows that are left but not ready will never become ready
+#else
+        if ((long long) wall_clock64() - t_idle > 120ll * 100000000ll) wpp_publish(abort_flag, 1);      // 100 MHz counter
+        __builtin_amdgcn_s_sleep(127);
+#endif
+      }
+      L.cur_stream = pick; L.wpp_pos = pos;
+    }
+    __syncthreads();
+    const int s = uni(L.cur_stream);
+    if (s < 0) break;
+#ifndef VX_EMU
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // the row's state was written by the workgroup that ran it before
+#endif
+    const int pos0 = uni(L.wpp_pos);
+    const int pos1 = run_stream<T>(p, s, pos0);
+    __threadfence();
+    __syncthreads();
+    if (VTX == 0) {
+      const int ntasks = p.streams[s].n_tasks;
+      wpp_publish(left + s, ntasks - pos1);
+      if (pos1 >= ntasks) atomicAdd((int *) done, 1);
+      wpp_publish(owner + s, 0);
+    }
+    start = s + 1;
   }
 }
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_kernel_u8(VxParams p) { run_streams<uint8_t>(p); }
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_kernel_u16(VxParams p) { run_streams<uint16_t>(p); }
+// the same search under the WPP scheduler (VVCX_TOOL_WPP): kernels of their own, so that the default kernels stay what they were
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_wpp_kernel_u8(VxParams p) { run_streams_wpp<uint8_t>(p); }
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_compress_wpp_kernel_u16(VxParams p) { run_streams_wpp<uint16_t>(p); }
 
 // slice joint_cb_cr_sign_flag of a bound picture (setJointCbCrModes, EL/EncSlice.cpp:1503-1538): the sign of the correlation of the high-pass filtered Cb and
 // Cr planes over the interior samples; one workgroup per picture, launched when the pictures are bound

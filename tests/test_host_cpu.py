@@ -412,6 +412,22 @@ def test_wavefront_rows_on_cpu_emulator_match_oracle(emu_so):
     enc.close()
     plain = O.compress_frame(planes, W, H, sp, tools=tools & ~pkg.TOOL_WPP)[2]
     assert any((a != b).any() for a, b in zip(oreco, plain))
+    # the scheduler's test mode: one CTU per visit and round-robin choice, so that the rows take turns (row 0 CTU 0, row 1 CTU 0, row 0 CTU 1, ...) and every visit
+    # continues a row from the contexts, coder state and position it was put back with; one launch for the whole picture
+    os.environ["VVCX_WPP_TEST_INTERLEAVE"] = "1"
+    try:
+        enc = pkg.VvcxEncoder(W, H, 8, tools=tools, lib_path=emu_so, emit_payload=True)
+    finally:
+        del os.environ["VVCX_WPP_TEST_INTERLEAVE"]
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    rec2 = [np.zeros_like(p) for p in planes]
+    enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec2], [p.shape[1] for p in org])])
+    res2 = enc.compress_bound_frames()[0]
+    for k in ores.dtype.names:
+        assert np.array_equal(ores[k], res2[k]), k
+    assert all(np.array_equal(rec2[c], oreco[c]) for c in range(3)) and np.array_equal(np.asarray(enc.counters(), np.uint64), ocnt)
+    assert np.array_equal(enc.get_payload(0, 0), opay) and np.array_equal(enc.get_substream_sizes(0, 0), osz[:2])
+    enc.close()
 
 
 def test_deblocking_of_isp_transform_edges_on_cpu_emulator_matches_the_reference(emu_so):
@@ -565,7 +581,7 @@ def test_resource_budget_of_the_compress_kernel(hip_lib):
     spec = importlib.util.spec_from_file_location("codeobj_report", os.path.join(ROOT, "tools", "codeobj_report.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     r = m.report(HIP_SO)
-    for name in ("vvcx_compress_kernel_u8", "vvcx_compress_kernel_u16"):
+    for name in ("vvcx_compress_kernel_u8", "vvcx_compress_kernel_u16", "vvcx_compress_wpp_kernel_u8", "vvcx_compress_wpp_kernel_u16"):
         k = r["kernels"][name]
         assert k["group_segment_fixed_size"] <= 40960, (name, k)
         assert k["vgpr_count"] + k.get("agpr_count", 0) <= 128, (name, k)

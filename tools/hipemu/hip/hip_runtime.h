@@ -117,6 +117,7 @@ inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long) v)
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned) v); }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
 inline unsigned atomicAdd(unsigned *p, unsigned v) { const unsigned o = *p; *p += v; return o; }
+inline int atomicAdd(int *p, int v) { const int o = *p; *p += v; return o; }
 
 // ---- the few host runtime calls the C-ABI layer uses
 typedef int hipError_t; typedef void *hipStream_t; typedef void *hipEvent_t;
