@@ -537,9 +537,9 @@ extern "C" int vvcx_submit_ctus(vvcx_handle *h, const vvcx_ctu_task *tasks, int 
     HIPCHK(hipMemsetAsync(h->scratch_d, 0, need, stream));       // CU-cache entries and generation counters start empty
   }
   if (h->cfg.tools & VVCX_TOOL_WPP) {                    // scheduler state of this launch: nothing finished, nothing owned, every stream with its tasks left
-    if (2 + 2 * ns > h->wpp_sched_cap) { (void) hipFree(h->wpp_sched_d); h->wpp_sched_d = nullptr; HIPCHK(hipMalloc((void **) &h->wpp_sched_d, sizeof(int32_t) * (size_t) (2 + 2 * ns))); h->wpp_sched_cap = 2 + 2 * ns; }
-    std::vector<int32_t> sched((size_t) (2 + 2 * ns), 0);
-    for (int i = 0; i < ns; i++) sched[(size_t) (2 + ns + i)] = sd[(size_t) i].n_tasks;
+    if (4 + 2 * ns > h->wpp_sched_cap) { (void) hipFree(h->wpp_sched_d); h->wpp_sched_d = nullptr; HIPCHK(hipMalloc((void **) &h->wpp_sched_d, sizeof(int32_t) * (size_t) (4 + 2 * ns))); h->wpp_sched_cap = 4 + 2 * ns; }
+    std::vector<int32_t> sched((size_t) (4 + 2 * ns), 0);
+    for (int i = 0; i < ns; i++) sched[(size_t) (4 + ns + i)] = sd[(size_t) i].n_tasks;
     HIPCHK(hipMemcpy(h->wpp_sched_d, sched.data(), sched.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   HIPCHK(hipMemcpyAsync(h->streams_d, sd.data(), sizeof(VxStreamDesc) * (size_t) ns, hipMemcpyHostToDevice, stream));

@@ -92,7 +92,7 @@ struct VxParams {
   uint32_t           *train_n;       // rows handed out so far (atomic)
   int32_t            *wpp_progress;  // WPP: per (frame*nsub+sub) the CTUs of the row that are finished and visible
   uint16_t           *wpp_sync;      // WPP: per (frame*nsub+sub) the contexts behind the row's first CTU
-  int32_t            *wpp_sched;     // WPP scheduler of the launch: [0] rows finished, [1] abort, [2, 2 + n_streams) owner flags, then the tasks each stream has left
+  int32_t            *wpp_sched;     // WPP scheduler of the launch: [0] rows finished, [1] abort, [2] CTUs finished, [4, 4 + n_streams) owner flags, then the tasks each stream has left
   int32_t             wpp_rr, pad_wpp;    // test mode: one CTU per visit and round-robin choice, so that rows interleave also where nothing forces them to
 };
 

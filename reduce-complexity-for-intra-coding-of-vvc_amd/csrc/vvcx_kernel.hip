@@ -4918,6 +4918,16 @@ __device__ inline int wpp_count(const int32_t *cnt)
   return __hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
+// the same value without the acquire (an acquire load at device scope invalidates the CU's vector L1, which the three other workgroups of the CU live on): for looking
+// around; whoever acts on what it saw takes the lock and fences once
+__device__ inline int wpp_peek(const int32_t *cnt)
+{
+#ifdef VX_EMU
+  return *cnt;
+#else
+  return __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 __device__ inline void wpp_publish(int32_t *cnt, int v)
 {
 #ifdef VX_EMU
@@ -4929,7 +4939,7 @@ __device__ inline void wpp_publish(int32_t *cnt, int v)
 // all threads: is CTU `need - 1` of the row above finished?  (thread 0 asks, everybody gets the answer and the acquire fence)
 __device__ __noinline__ int wpp_ready(const int32_t *cnt, int need)
 {
-  if (VTX == 0) L.wpp_ok = wpp_count(cnt) >= need;
+  if (VTX == 0) L.wpp_ok = wpp_peek(cnt) >= need;
   __syncthreads();
   const int ok = uni(L.wpp_ok);
 #ifndef VX_EMU
@@ -5210,40 +5220,41 @@ __device__ void run_streams(const VxParams &p)
   }
 }
 // WPP: the streams are CTU rows that depend on each other, so a workgroup does not own a row for its lifetime.  Scheduler state in HBM (p.wpp_sched, set up per launch by the
-// host): [0] rows finished, [1] abort flag, then per stream an owner flag and the number of its tasks that are left.  A workgroup looks for a row that nobody runs, that has
+// host): [0] rows finished, [1] abort flag, [2] CTUs finished, then per stream an owner flag and the number of its tasks that are left.  A workgroup looks for a row that nobody runs, that has
 // tasks left and whose next CTU is ready (first fit in queue order = longest tile first, top row first), runs it while it stays ready, puts it back, and looks again; it leaves
 // when every row is finished.  No workgroup ever waits for another one while holding something the other needs, and every wave reaches the exit: either all rows finish, or
-// a workgroup that found nothing to do for two minutes raises the abort flag, which everybody sees at the next look (the host reports it).
+// a workgroup that found nothing to do while nobody finished a CTU for two minutes raises the abort flag, which everybody sees at the next look (the host reports it).
 template <typename T>
 __device__ void run_streams_wpp(const VxParams &p)
 {
   VX_POISON_LDS(L);
   const int n = p.n_streams;
-  int32_t *done = p.wpp_sched, *abort_flag = p.wpp_sched + 1, *owner = p.wpp_sched + 2, *left = p.wpp_sched + 2 + n;
+  int32_t *done = p.wpp_sched, *abort_flag = p.wpp_sched + 1, *ticks = p.wpp_sched + 2, *owner = p.wpp_sched + 4, *left = p.wpp_sched + 4 + n;
   int start = 0;
   for (;;) {
     __syncthreads();
     if (VTX == 0) {
       int pick = -1, pos = 0;
 #ifndef VX_EMU
-      const long long t_idle = (long long) wall_clock64();
+      long long t_idle = (long long) wall_clock64();
+      int seen = wpp_peek(ticks);
 #endif
       for (;;) {
-        if (wpp_count(abort_flag) || wpp_count(done) >= n) break;
+        if (wpp_peek(abort_flag) || wpp_peek(done) >= n) break;
         for (int i = 0; i < n && pick < 0; i++) {
           const int s = p.wpp_rr ? (start + i) % n : i;
-          if (wpp_count(owner + s)) continue;
-          int l = wpp_count(left + s);
+          if (wpp_peek(owner + s)) continue;
+          int l = wpp_peek(left + s);
           if (l <= 0) continue;
           const VxStreamDesc sd = p.streams[s];
           const int32_t *above = sd.above >= 0 ? p.wpp_progress + (sd.frame * p.nsub + sd.above) : nullptr;
-          if (above && wpp_count(above) < sd.done_before + (sd.n_tasks - l) + 1) continue;
+          if (above && wpp_peek(above) < sd.done_before + (sd.n_tasks - l) + 1) continue;
 #ifdef VX_EMU
           if (*(owner + s)) continue; *(owner + s) = 1;
 #else
           if (atomicCAS((int *) owner + s, 0, 1) != 0) continue;
 #endif
-          l = wpp_count(left + s);                        // under the lock: somebody may have run the row in between
+          l = wpp_count(left + s);                        // under the lock, with the acquire: somebody may have run the row in between
           if (l <= 0 || (above && wpp_count(above) < sd.done_before + (sd.n_tasks - l) + 1)) { wpp_publish(owner + s, 0); continue; }
           pick = s; pos = sd.n_tasks - l;
         }
@@ -5251,8 +5262,11 @@ __device__ void run_streams_wpp(const VxParams &p)
 #ifdef VX_EMU
         wpp_publish(abort_flag, 1);                       // the emulator runs one workgroup at a time: rows that are left but not ready will never become ready
 #else
-        if ((long long) wall_clock64() - t_idle > 120ll * 100000000ll) wpp_publish(abort_flag, 1);      // 100 MHz counter
-        __builtin_amdgcn_s_sleep(127);
+        // nothing to do right now.  Give up only when NOBODY has finished a CTU for two minutes (a row at the bottom of a picture legitimately waits much longer than a CTU takes)
+        const int now = wpp_peek(ticks);
+        if (now != seen) { seen = now; t_idle = (long long) wall_clock64(); }
+        else if ((long long) wall_clock64() - t_idle > 120ll * 100000000ll) wpp_publish(abort_flag, 1);      // 100 MHz counter
+        for (int k = 0; k < 32; k++) __builtin_amdgcn_s_sleep(127);      // ~0.1 ms: a CTU takes seconds
 #endif
       }
       L.cur_stream = pick; L.wpp_pos = pos;
@@ -5270,6 +5284,7 @@ __device__ void run_streams_wpp(const VxParams &p)
     if (VTX == 0) {
       const int ntasks = p.streams[s].n_tasks;
       wpp_publish(left + s, ntasks - pos1);
+      atomicAdd((int *) ticks, pos1 - pos0);
       if (pos1 >= ntasks) atomicAdd((int *) done, 1);
       wpp_publish(owner + s, 0);
     }
