@@ -456,6 +456,7 @@ extern "C" int vvcx_resident_streams(const vvcx_handle *h)
   const bool wpp = (h->cfg.tools & VVCX_TOOL_WPP) != 0;
   const void *k = h->cfg.bit_depth == 8 ? (wpp ? (const void *) vvcx_compress_wpp_kernel_u8 : (const void *) vvcx_compress_kernel_u8) : (wpp ? (const void *) vvcx_compress_wpp_kernel_u16 : (const void *) vvcx_compress_kernel_u16);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, VXD_NT, 0) != hipSuccess) return 0;
+  { const char *e = getenv("VVCX_MAX_WG_PER_CU"); const int cap = e ? atoi(e) : 0; if (cap > 0 && cap < per_cu) per_cu = cap; }      // diagnostic: the rate against the workgroups sharing a CU
   return cus * per_cu;
 }
 
