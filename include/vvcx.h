@@ -224,6 +224,9 @@ int  vvcx_get_training_rows(vvcx_handle *h, int32_t *rows, int max_rows, int *n_
 /* the sub-streams inside the bytes vvcx_get_payload returns for a tile, in order: one (the tile), or with VVCX_TOOL_WPP one per CTU row of the tile - what the slice header's
  * entry points are made of (EL/EncSlice.cpp:1982-1990 addSubstreamSize).  sizes may be NULL to query the count */
 int  vvcx_get_substream_sizes(vvcx_handle *h, int frame, int tile, int *sizes, int max_sizes, int *n_sizes);
+/* Diagnostic environment variables (read by vvcx_create / at launch; they never change a result):
+ *   VVCX_MAX_WG_PER_CU=n          at most n resident CTU streams per CU (the rate-against-occupancy curve of DESIGN.md §6)
+ *   VVCX_WPP_TEST_INTERLEAVE=1    VVCX_TOOL_WPP: one CTU per visit and round-robin choice of the next CTU row, so that the rows of a picture take turns */
 /* device time of the last compress launch, measured with HIP events on the launch stream (ms) */
 float vvcx_last_kernel_ms(const vvcx_handle *h);
 /* work counters of the last launch: [0] SATD-stage candidates, [1] full-RD TU evaluations, [2] RD pixels, [3] nodes */
