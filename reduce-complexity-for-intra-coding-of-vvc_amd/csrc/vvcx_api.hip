@@ -42,6 +42,8 @@ extern "C" __global__ void vvcx_leaf_trq_kernel(const int16_t *org, int16_t *rec
 
 static thread_local char g_err[512];
 extern "C" const char *vvcx_last_error(void) { return g_err; }
+// (for the other translation units of the library: csrc/vvcx_lmcs.hip)
+extern "C" __attribute__((visibility("hidden"))) int vvcx_fail_msg_(int code, const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); return code; }
 static int fail(int code, const char *fmt, ...)
 {
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);

@@ -14,6 +14,8 @@
 #include <vector>
 #include <algorithm>
 
+extern "C" int vvcx_fail_msg_(int code, const char *msg);      // vvcx_api.hip: sets what vvcx_last_error returns
+
 namespace {
 const int kBins = 16;                // PIC_CODE_CW_BINS (CL/CommonDef.h:517)
 const int kSegSize = kBins << 1;     // LMCS_SEG_SIZE (519)
@@ -235,10 +237,10 @@ struct Analyzer {
 
 extern "C" int vvcx_lmcs_analyze(const void *const org[3], const int stride[3], int pic_w, int pic_h, int bit_depth, int slice_qp, int update_ctrl, vvcx_slice *slice)
 {
-  if (!org || !stride || !slice || !org[0] || !org[1] || !org[2]) return VVCX_ERR_ARG;
-  if (pic_w < 8 || pic_h < 8 || (pic_w & 1) || (pic_h & 1) || stride[0] < pic_w || stride[1] < pic_w / 2 || stride[2] < pic_w / 2) return VVCX_ERR_ARG;
-  if (bit_depth < 8 || bit_depth > 12) return VVCX_ERR_ARG;
-  if (update_ctrl != 0 && update_ctrl != 1) return VVCX_ERR_UNSUPPORTED;      // 2 (low delay) analyses 32 bins and fits the codewords to the variances: not an intra configuration
+  if (!org || !stride || !slice || !org[0] || !org[1] || !org[2]) return vvcx_fail_msg_(VVCX_ERR_ARG, "vvcx_lmcs_analyze: null argument");
+  if (pic_w < 8 || pic_h < 8 || (pic_w & 1) || (pic_h & 1) || stride[0] < pic_w || stride[1] < pic_w / 2 || stride[2] < pic_w / 2) return vvcx_fail_msg_(VVCX_ERR_ARG, "vvcx_lmcs_analyze: picture size / strides");
+  if (bit_depth < 8 || bit_depth > 12) return vvcx_fail_msg_(VVCX_ERR_ARG, "vvcx_lmcs_analyze: bit depth");
+  if (update_ctrl != 0 && update_ctrl != 1) return vvcx_fail_msg_(VVCX_ERR_UNSUPPORTED, "vvcx_lmcs_analyze: LMCSUpdateCtrl 2 (low delay) is not an intra configuration");      // 2 (low delay) analyses 32 bins and fits the codewords to the variances: not an intra configuration
   slice->lmcs_enable = 0; slice->lmcs_chroma_adj = 0; slice->lmcs_min_bin = 0; slice->lmcs_max_bin = 0;
   for (int i = 0; i < 16; i++) slice->lmcs_delta_cw[i] = 0;
   // Below 10 bits calcSeqStats bins the luma with `>> (m_lumaBD - 10)`, a negative shift count: on x86 the count is masked and every sample lands in bin 0, whose share

@@ -139,8 +139,7 @@ def lmcs_analyze(planes, bit_depth, qp, update_ctrl=1, lib_path=None):
     sl = _Slice()
     L.vvcx_lmcs_analyze.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
     rc = L.vvcx_lmcs_analyze(org, st, w, h, bit_depth, qp, update_ctrl, C.byref(sl))
-    if rc != 0:
-        raise VvcxError("vvcx_lmcs_analyze: error %d" % rc)
+    _chk(L, rc)
     return dict(enable=int(sl.lmcs_enable), chroma_adj=int(sl.lmcs_chroma_adj), min_bin=int(sl.lmcs_min_bin), max_bin=int(sl.lmcs_max_bin), delta_cw=[int(v) for v in sl.lmcs_delta_cw])
 
 
