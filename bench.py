@@ -249,9 +249,10 @@ def main():
                                 + "; leaf operators, syntax and reconstruction are pinned to the reference (CommonLib + decoder + EncReshape), the search decisions (EncCu / EncModeCtrl / IntraSearch restatement) are pinned only through the decoder accepting and reconstructing the streams",
                        "tiling": ("one tile per CTU (every CTU an independent stream; the reference's cfg codes one tile per picture)" if (tc, tr) == (ctus_w, ctus_h)
                                   else "%dx%d uniform tiles" % (tc, tr)) + (", WaveFrontSynchro 1: every CTU row of a tile is a stream that runs one CTU behind the row above" if args.wpp else ""),
-                       "ctus_per_step": ctus_per_step, "parallelism": "1 workgroup per CTU stream over a work queue of resident slots, frames sharded over ranks"},
+                       "ctus_per_step": ctus_per_step, "parallelism": ("CTU rows as streams that migrate between the workgroups of the resident slots (a row is taken while its next CTU is ready and put back), frames sharded over ranks"
+                                       if args.wpp else "1 workgroup per CTU stream over a work queue of resident slots, frames sharded over ranks")},
             "roofline": {"bound": "hbm", "limiter": "not HBM: VALU issue and the serial chains of one CTU stream (mode controller, trellis, CABAC estimator); see valu.issue_frac and DESIGN.md", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_split": traffic_split, "traffic_source": traffic_src, "kernel": "vvcx_compress_kernel_u8" if bd == 8 else "vvcx_compress_kernel_u16", "kernel_ms": 1e3 * avg_kernel_s,
+                         "traffic": traffic, "traffic_split": traffic_split, "traffic_source": traffic_src, "kernel": ("vvcx_compress_wpp_kernel_" if args.wpp else "vvcx_compress_kernel_") + ("u8" if bd == 8 else "u16"), "kernel_ms": 1e3 * avg_kernel_s,
                          "algorithmic_bytes_per_launch": ctus_per_step * b_ctu, "valu": valu},
             "work": {"satd_candidates_per_launch": int(counters[0]), "rd_tu_evaluations_per_launch": int(counters[1]),
                      "rd_pixels_per_launch": int(counters[2]), "nodes_per_launch": int(counters[3]),

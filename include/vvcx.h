@@ -126,7 +126,9 @@ typedef struct vvcx_handle vvcx_handle;
 int  vvcx_create(const vvcx_cfg *cfg, vvcx_handle **h);
 /* ≙ EncCu::destroy() (EL/EncCu.h:173) */
 void vvcx_destroy(vvcx_handle *h);
-/* ≙ EncSlice::setUpLambda + slice QP (EL/EncSlice.cpp:107-149, 1568-1572) */
+/* ≙ EncSlice::setUpLambda + slice QP (EL/EncSlice.cpp:107-149, 1568-1572).  Precedes vvcx_bind_frames: binding prepares the pictures for the slice (start contexts of
+ * its QP, forward-mapped luma and device LUTs of its LMCS model).  A later call whose QP or LMCS model differs UNBINDS the pictures (the next search call then reports
+ * VVCX_ERR_STATE until they are bound again); one that changes only lambda / the distortion weights leaves them bound. */
 int  vvcx_set_slice(vvcx_handle *h, const vvcx_slice *s);
 /* ---- slice-level inputs: what the reference derives before the CTU loop, as pure host functions ---- */
 typedef struct {
@@ -218,7 +220,8 @@ int  vvcx_get_payload(vvcx_handle *h, int frame, int tile, uint8_t *buf, int cap
  * (0 simple, 1 fuzzy, 2 complex; 1127-1138) and the partition the full search chose at that node (0 none, 1 QT, 2 BT_H, 3 BT_V, 4 TT_H, 5 TT_V; -1: no encoding).  Rows
  * accumulate from vvcx_bind_frames on, in no particular order across streams; cap_rows 0 switches the dump off.  vvcx_get_training_rows copies min(rows so far, capacity,
  * max_rows) rows to host memory and reports in *n_rows how many the search produced.  Works with and without VVCX_TOOL_FAST (without: the plain full search labels the rows,
- * which is how a forest is trained: tools/train_partition_forest.py) */
+ * which is how a forest is trained: tools/train_partition_forest.py).  VVCX_ERR_UNSUPPORTED on a VVCX_TOOL_WPP handle (the features read neighbour CUs of other CTU rows,
+ * whose progress under WPP is a matter of timing - the reason vvcx_create refuses VVCX_TOOL_FAST with WPP) */
 int  vvcx_enable_training_dump(vvcx_handle *h, int cap_rows);
 int  vvcx_get_training_rows(vvcx_handle *h, int32_t *rows, int max_rows, int *n_rows);
 /* the sub-streams inside the bytes vvcx_get_payload returns for a tile, in order: one (the tile), or with VVCX_TOOL_WPP one per CTU row of the tile - what the slice header's

@@ -313,6 +313,9 @@ extern "C" int vvcx_set_slice(vvcx_handle *h, const vvcx_slice *s)
   if (!h || !s) return fail(VVCX_ERR_ARG, "null argument");
   if (!(s->lambda > 0.0) || s->qp < -6 * (h->cfg.bit_depth - 8) || s->qp > 63) return fail(VVCX_ERR_ARG, "bad slice parameters (QP range -QpBDOffset..63, like vvcx_derive_slice)");
   bool lmcs = false;
+  // what the bound pictures were prepared with (vvcx_bind_frames): start contexts of the slice QP, the forward-mapped luma and the device LUTs of the LMCS model
+  const bool was_bound = h->have_slice && h->n_frames > 0, lmcs_before = h->lmcs_on; const int qp_before = h->sl.qp;
+  int16_t fwd_before[1024]; if (was_bound && lmcs_before) memcpy(fwd_before, h->lmcs_fwd, sizeof fwd_before);
   if (s->lmcs_enable) {
     // the piece-wise linear model of the slice -> LUTs (Reshape::constructReshaper, CL/Reshape.cpp:297-333, JVET_O0428 form: 16 input bins of equal width,
     // bin i owns orgCW + delta code words in the mapped domain; 11 fractional bits for the slopes; the inverse slope of a bin is also its chroma residual scale)
@@ -346,6 +349,9 @@ extern "C" int vvcx_set_slice(vvcx_handle *h, const vvcx_slice *s)
     lmcs = true;
   }
   h->sl = *s; h->have_slice = true; h->lmcs_on = lmcs;
+  // a slice whose QP or LMCS model differs from the one the pictures were bound with unbinds them: searching them would start from the wrong contexts, on unmapped
+  // (or differently mapped) luma and with LUTs that are not on the device.  The caller binds again (header: "before vvcx_bind_frames").
+  if (was_bound && (qp_before != s->qp || lmcs_before != lmcs || (lmcs && memcmp(fwd_before, h->lmcs_fwd, (size_t) 2 << h->cfg.bit_depth) != 0))) h->n_frames = 0;
   return VVCX_OK;
 }
 
@@ -652,7 +658,11 @@ extern "C" int vvcx_wait_ctus(vvcx_handle *h, vvcx_ctu_result *out, int n)
   if (h->cfg.tools & VVCX_TOOL_WPP) {
     int32_t st[2] = { 0, 0 };
     HIPCHK(hipMemcpy(st, h->wpp_sched_d, sizeof st, hipMemcpyDeviceToHost));
-    if (st[1]) return fail(VVCX_ERR_DEVICE, "WPP scheduler gave up: %d of the launch's CTU rows finished, the others never became ready", st[0]);
+    if (st[1]) {
+      // the rows' contexts, coder states and progress counts on the device have advanced part of the way; the host's positions have not: the streams cannot be continued
+      h->n_frames = 0;
+      return fail(VVCX_ERR_DEVICE, "WPP scheduler gave up: %d of the launch's CTU rows finished, the others never became ready (the pictures are unbound: bind them again)", st[0]);
+    }
   }
   h->next_idx = h->pend_next;
   const VxCtuRes *res = h->pend_res;
@@ -676,6 +686,7 @@ extern "C" int vvcx_compress_bound_frames(vvcx_handle *h, vvcx_ctu_result *out, 
 {
   NOT_PENDING(h);
   if (!h || !out) return fail(VVCX_ERR_ARG, "null argument");
+  if (h->n_frames == 0) return fail(VVCX_ERR_STATE, "no frames bound");
   const int nctu = h->ctus_w * h->ctus_h;
   std::vector<vvcx_ctu_task> tasks; std::vector<int> dst;
   for (int f = 0; f < h->n_frames; f++) for (int t = 0; t < h->nsub; t++) {
@@ -695,6 +706,7 @@ extern "C" int vvcx_lmcs_inverse_reco(vvcx_handle *h, void *hip_stream)
   NOT_PENDING(h);
   if (!h) return fail(VVCX_ERR_ARG, "null handle");
   if (!h->n_frames || !h->have_slice || !h->lmcs_on) return fail(VVCX_ERR_STATE, "no bound frames coded with an LMCS slice");
+  if (!h->lmcs_lut_d) return fail(VVCX_ERR_STATE, "the bound pictures were not prepared with an LMCS slice: vvcx_bind_frames after vvcx_set_slice");
   if (h->lmcs_inverted) return fail(VVCX_ERR_STATE, "the reconstruction has already been mapped back");
   for (size_t i = 0; i < h->next_idx.size(); i++)
     if (h->next_idx[i] != (int) h->sub_ctus[i % (size_t) h->nsub].size()) return fail(VVCX_ERR_STATE, "every CTU of the bound pictures must be coded first (intra prediction reads mapped neighbours)");
@@ -1229,6 +1241,9 @@ extern "C" int vvcx_enable_training_dump(vvcx_handle *h, int cap_rows)
 {
   NOT_PENDING(h);
   if (!h || cap_rows < 0) return fail(VVCX_ERR_ARG, "bad argument");
+  // the features look at the CUs above-right and below-left of a node through the unrestricted neighbour lookup; under WPP those belong to rows that run at their own
+  // pace, so the rows would depend on timing (the same reason VVCX_TOOL_FAST is refused together with WPP)
+  if (cap_rows > 0 && (h->cfg.tools & VVCX_TOOL_WPP)) return fail(VVCX_ERR_UNSUPPORTED, "the training dump is not available on a WPP handle");
   DevGuard guard(h->cfg.device);
   (void) hipFree(h->train_rows_d); (void) hipFree(h->train_n_d); h->train_rows_d = nullptr; h->train_n_d = nullptr; h->train_cap = 0;
   if (cap_rows == 0) return VVCX_OK;

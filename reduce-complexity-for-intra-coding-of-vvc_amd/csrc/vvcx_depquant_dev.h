@@ -39,6 +39,14 @@ struct DqS { long long cost; int pk, rem; unsigned long long anc; U4 lev; };    
 __device__ inline int dq_put(int p, int sh, int nbits, int v) { const int m = ((1 << nbits) - 1) << sh; return (p & ~m) | ((v << sh) & m); }
 
 // (the register barrier keeps the compiler from folding the selects into one load with a computed address, which would pin the struct in scratch memory)
+// the path nodes live in HBM scratch: global_ accesses (a plain pointer argument is a generic one)
+#ifndef VX_GLOBAL
+#ifdef VX_EMU
+#define VX_GLOBAL
+#else
+#define VX_GLOBAL __attribute__((address_space(1)))
+#endif
+#endif
 #ifndef VX_REG_BARRIER
 #define VX_REG_BARRIER(x) asm volatile("" : "+v"(x))
 #endif
@@ -152,10 +160,13 @@ __device__ inline void dq_fill_tables(int *tab, int ci, int ch, int t, int nt)
 // all threads of the workgroup, at the start of a full-RD operation whose trellises price against the estimator's current models; a barrier follows
 __device__ inline void dq_build_tables(int ch) { dq_fill_tables(L.dq_tab, CI_CUR, ch, (int) VTX, NT); __syncthreads(); }
 template <int TAB>
-__device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, int cf_stride, uint8_t *nodes, int node_stride, uint8_t *wk, int abs0,
+__device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, int cf_stride, uint8_t *nodes, int node_stride, int wk_wave, int abs0,
                                                  int ci0, int ci_step, int cbf_ctx0, unsigned cbf_mask, int w, int h, int comp, int zo, int lfnst, int lane, int qidx = -1)
 {
   n_items = uni(n_items); w = uni(w); h = uni(h); comp = uni(comp); zo = uni(zo); lfnst = uni(lfnst); ci0 = uni(ci0); ci_step = uni(ci_step); cbf_ctx0 = uni(cbf_ctx0);
+  // the work area (decisions, last-position offsets, template rows, TAB 1 tables) is the LDS memory of wave wk_wave: formed from L here, so that every access in the serial
+  // loop is a ds_ instruction (a pointer argument would be a generic one: flat_ accesses that wait on both counters)
+  uint8_t *wk = (uint8_t *) &L.wm[uni(wk_wave)];
   const int ch = comp ? 1 : 0, lw = ilog2i(w), lh = ilog2i(h);
   // qidx: another row of the table (joint chroma blocks); chroma rows come from the table of the node's LMCS residual scale (table 0: unscaled)
   const int qrow = uni(qidx) < 0 ? comp : uni(qidx);
@@ -456,7 +467,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
         // the path as it leaves this group: field 0 = this state and the group's significance, the older groups one field up
         const unsigned long long anc = (pAnc << 4) | (unsigned long long) (unsigned) (k + 1) | ((numSig != 0) ? 8ull : 0ull);
         VX_CHECK(g >= 1 && (g * 4 + k) * 16 + 16 <= node_room);
-        if (alive) { uint32_t *hl = (uint32_t *) (nd + (size_t) (g * 4 + k) * 16); hl[0] = lv.a; hl[1] = lv.b; hl[2] = lv.c; hl[3] = lv.d; }
+        if (alive) { VX_GLOBAL uint32_t *hl = (VX_GLOBAL uint32_t *) (nd + (size_t) (g * 4 + k) * 16); hl[0] = lv.a; hl[1] = lv.b; hl[2] = lv.c; hl[3] = lv.d; }
         wave_sync();
         // the groups right of, below and diagonally below the next group: their distance in group-scan order picks the ancestor field
         const unsigned ng = geo.grp[g - 1]; const int nsx = (int) (ng & 15), nsy = (int) (ng >> 4);
@@ -473,9 +484,9 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
           VX_CHECK(!(fR & 7u) || (gR >= g && gR - g < 16 && (gR * 4 + (int) (fR & 7u) - 1) * 16 + 16 <= node_room));
           VX_CHECK(!(fB & 7u) || (gB >= g && gB - g < 16 && (gB * 4 + (int) (fB & 7u) - 1) * 16 + 16 <= node_room));
           VX_CHECK(!(fD & 7u) || (gD >= g && gD - g < 16 && (gD * 4 + (int) (fD & 7u) - 1) * 16 + 16 <= node_room));
-          if (fR & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gR * 4 + (int) (fR & 7u) - 1) * 16); nv[4] = p_[0]; nv[5] = p_[1]; nv[6] = p_[2]; nv[7] = p_[3]; }
-          if (fB & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gB * 4 + (int) (fB & 7u) - 1) * 16); nv[8] = p_[0]; nv[9] = p_[1]; nv[10] = p_[2]; nv[11] = p_[3]; }
-          if (fD & 7u) { const uint32_t *p_ = (const uint32_t *) (nd + (size_t) (gD * 4 + (int) (fD & 7u) - 1) * 16); nv[12] = p_[0]; nv[13] = p_[1]; nv[14] = p_[2]; nv[15] = p_[3]; }
+          if (fR & 7u) { const VX_GLOBAL uint32_t *p_ = (const VX_GLOBAL uint32_t *) (nd + (size_t) (gR * 4 + (int) (fR & 7u) - 1) * 16); nv[4] = p_[0]; nv[5] = p_[1]; nv[6] = p_[2]; nv[7] = p_[3]; }
+          if (fB & 7u) { const VX_GLOBAL uint32_t *p_ = (const VX_GLOBAL uint32_t *) (nd + (size_t) (gB * 4 + (int) (fB & 7u) - 1) * 16); nv[8] = p_[0]; nv[9] = p_[1]; nv[10] = p_[2]; nv[11] = p_[3]; }
+          if (fD & 7u) { const VX_GLOBAL uint32_t *p_ = (const VX_GLOBAL uint32_t *) (nd + (size_t) (gD * 4 + (int) (fD & 7u) - 1) * 16); nv[12] = p_[0]; nv[13] = p_[1]; nv[14] = p_[2]; nv[15] = p_[3]; }
         }
         for (int id = 0; id < gs; id++) {
           const unsigned wrd = (unsigned) __builtin_amdgcn_readlane((int) eosW, id);
@@ -568,9 +579,9 @@ __device__ inline int wave_depquant(int16_t *cf_g, int buf_off, uint8_t *scratch
   // the tables fit behind the decisions in the rate-estimator scratch + tmp for all but the 32 x 32-coefficient blocks
   // (and pay for themselves from 64 positions on)
   if (imin(32, w) * imin(32, h) >= VXD_DQ_TAB_MIN && 240 + 2 * imin(32, w) * imin(32, h) + DQ_TAB_BYTES <= (int) (sizeof(WaveScratch) + sizeof(int32_t) * BUF))
-    wave_depquant_batch<1>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, (uint8_t *) &L.wm[wave_].ws, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
+    wave_depquant_batch<1>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, wave_, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
   else
-    wave_depquant_batch<0>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, (uint8_t *) &L.wm[wave_].ws, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
+    wave_depquant_batch<0>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, wave_, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
   return uni(L.dq_abs[64 + wave_]);
 }
 

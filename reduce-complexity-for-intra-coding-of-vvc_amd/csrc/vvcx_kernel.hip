@@ -2843,7 +2843,7 @@ __device__ void dq_trellis_phase(uint8_t *scratch, int n, int P, int total, int 
   int16_t *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF) + (size_t) item0 * P; uint8_t *poolNodes = scratch + VXD_OFF_POOL_NODES + (size_t) item0 * 4 * total;
   const int ipw = imin(16, (int) sizeof(WaveMem) / (240 + 2 * total));          // items one wave can hold decisions for
   for (int i0 = ((wave + NW - wave_shift) & (NW - 1)) * ipw; i0 < n; i0 += NW * ipw)
-    wave_depquant_batch<2>(imin(ipw, n - i0), poolCoef + (size_t) i0 * P, P, poolNodes + (size_t) i0 * 4 * total, 4 * total, (uint8_t *) &L.wm[wave], abs0 + i0,
+    wave_depquant_batch<2>(imin(ipw, n - i0), poolCoef + (size_t) i0 * P, P, poolNodes + (size_t) i0 * 4 * total, 4 * total, wave, abs0 + i0,
                         CI_CUR, 0, VX_CTX_QtCbf[0], 0u, w, h, 0, zo, lfnst, lane);
 }
 template <bool SMALL>
@@ -3291,7 +3291,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
   {
     const int ipw = imin(16, (int) sizeof(WaveMem) / (240 + 2 * total));
     for (int i0 = wave * ipw; i0 < n_rd; i0 += NW * ipw)
-      wave_depquant_batch<2>(imin(ipw, n_rd - i0), poolCoef + (size_t) (2 * i0) * P, 2 * P, poolNodes + (size_t) (2 * i0) * 4 * total, 8 * total, (uint8_t *) &L.wm[wave], i0,
+      wave_depquant_batch<2>(imin(ipw, n_rd - i0), poolCoef + (size_t) (2 * i0) * P, 2 * P, poolNodes + (size_t) (2 * i0) * 4 * total, 8 * total, wave, i0,
                           CI_CUR, 0, VX_CTX_QtCbf[1], 0u, w, h, 1, 0, psLf, lane);
   }
   __threadfence_block();
@@ -3323,9 +3323,9 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
     {                                                       // Cr trellises of the modes c0 .. c0 + 3
       const int n4 = imin(NW, n_rd - c0);
       unsigned mask = 0; for (int i = 0; i < n4; i++) mask |= (unsigned) L.rb_pairs[i] << i;
-      if (crBatch) { if (wave == 0) wave_depquant_batch<0>(n4, poolCoef + (size_t) (2 * c0 + 1) * P, 2 * P, poolNodes + (size_t) (2 * c0 + 1) * 4 * total, 8 * total, (uint8_t *) &L.wm[0].ws, c0,
+      if (crBatch) { if (wave == 0) wave_depquant_batch<0>(n4, poolCoef + (size_t) (2 * c0 + 1) * P, 2 * P, poolNodes + (size_t) (2 * c0 + 1) * 4 * total, 8 * total, 0, c0,
                                                         CI_W(0), 1, VX_CTX_QtCbf[2], mask, w, h, 2, 0, psLf, lane); }
-      else if (have) wave_depquant_batch<0>(1, poolCoef + (size_t) (2 * c + 1) * P, 0, poolNodes + (size_t) (2 * c + 1) * 4 * total, 0, (uint8_t *) &L.wm[wave].ws, c,
+      else if (have) wave_depquant_batch<0>(1, poolCoef + (size_t) (2 * c + 1) * P, 0, poolNodes + (size_t) (2 * c + 1) * 4 * total, 0, wave, c,
                                          CI_W(wave), 0, VX_CTX_QtCbf[2], (unsigned) cbfs[0], w, h, 2, 0, psLf, lane);
     }
     __threadfence_block();
@@ -5021,7 +5021,7 @@ __device__ int run_stream(const VxParams &p, int stream_idx, int pos0)
       if (sd.done_before + t == 0) ctx_copy_all((Ctx *) (p.wpp_sync + (size_t) sidx * 2 * NCTX), &L.ctxs[CI_CUR]);
       __threadfence();
       __syncthreads();
-      if (tid == 0) wpp_publish(p.wpp_progress + sidx, sd.done_before + t + 1);
+      if (tid == 0) { wpp_publish(p.wpp_progress + sidx, sd.done_before + t + 1); atomicAdd(p.wpp_sched + 2, 1); }      // + the scheduler's sign of life: one tick per finished CTU
     }
   }
   ctx_copy_all(carry, &L.ctxs[CI_CUR]);
@@ -5223,7 +5223,7 @@ __device__ void run_streams(const VxParams &p)
 // host): [0] rows finished, [1] abort flag, [2] CTUs finished, then per stream an owner flag and the number of its tasks that are left.  A workgroup looks for a row that nobody runs, that has
 // tasks left and whose next CTU is ready (first fit in queue order = longest tile first, top row first), runs it while it stays ready, puts it back, and looks again; it leaves
 // when every row is finished.  No workgroup ever waits for another one while holding something the other needs, and every wave reaches the exit: either all rows finish, or
-// a workgroup that found nothing to do while nobody finished a CTU for two minutes raises the abort flag, which everybody sees at the next look (the host reports it).
+// a workgroup that found nothing to do while nobody finished a CTU for two minutes (run_stream ticks once per CTU) raises the abort flag, which everybody sees at the next look (the host reports it).
 template <typename T>
 __device__ void run_streams_wpp(const VxParams &p)
 {
@@ -5284,7 +5284,6 @@ __device__ void run_streams_wpp(const VxParams &p)
     if (VTX == 0) {
       const int ntasks = p.streams[s].n_tasks;
       wpp_publish(left + s, ntasks - pos1);
-      atomicAdd((int *) ticks, pos1 - pos0);
       if (pos1 >= ntasks) atomicAdd((int *) done, 1);
       wpp_publish(owner + s, 0);
     }

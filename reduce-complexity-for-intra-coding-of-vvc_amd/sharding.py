@@ -1,8 +1,8 @@
-"""Frame sharding of an All-Intra job over ranks.
+"""Frame and tile sharding of an All-Intra job over ranks.
 
 Every picture of an All-Intra sequence is independent (IntraPeriod 1, BIN/encoder_intra.cfg) and so is every tile
 of a picture (contexts and neighbour availability reset at tile starts, EL/EncSlice.cpp:1640-1647), so ranks get
-disjoint frames and there is NO collective inside the search.  The exchanges are: a barrier around the timed region, MAX
+disjoint frames - or, for a job with fewer frames than ranks, disjoint tile ranges of a frame (units_of_rank) - and there is NO collective inside the search.  The exchanges are: a barrier around the timed region, MAX
 of the elapsed time, (optionally) the per-CTU summaries on rank 0, and the one data-path step the job has - the final
 gather of every rank's slice_data bytes on rank 0 (gather_payloads; RCCL when the process group is "nccl").
 """
@@ -14,6 +14,36 @@ def frames_of_rank(n_frames, rank, world):
     base, rem = divmod(n_frames, world)
     lo = rank * base + min(rank, rem)
     return list(range(lo, lo + base + (1 if rank < rem else 0)))
+
+
+def tile_bounds(n_ctus, n_tiles):
+    """first CTU column / row of every tile of a uniform grid, plus the end (TileUniformSpacing: boundary i at i * n_ctus / n_tiles, EL/EncSlice / CL/Slice.cpp
+    uniform spacing rule that the handle's tile map follows)"""
+    return [(i * n_ctus) // n_tiles for i in range(n_tiles + 1)]
+
+
+def tile_ctus(ctus_w, ctus_h, tile_cols, tile_rows, tile):
+    """CTU raster addresses of one tile of the uniform tile grid, in the tile's own raster order = the order its stream codes them in"""
+    cb, rb = tile_bounds(ctus_w, tile_cols), tile_bounds(ctus_h, tile_rows)
+    tx, ty = tile % tile_cols, tile // tile_cols
+    return [y * ctus_w + x for y in range(rb[ty], rb[ty + 1]) for x in range(cb[tx], cb[tx + 1])]
+
+
+def units_of_rank(n_frames, tiles_per_frame, rank, world):
+    """Tile-level sharding for jobs with fewer frames than ranks (north_star: "independent CTUs shard across the GPUs"; a tile is the independent CTU stream).  The
+    job's (frame, tile) streams in frame-major raster order are cut into `world` contiguous blocks; returns this rank's block as a list of
+    (frame, first_tile, n_tiles) - at most one partial frame at either end, whole frames in between.  With tiles_per_frame == 1 this is frames_of_rank."""
+    total = n_frames * tiles_per_frame
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    units = []
+    while lo < hi:
+        f, t = divmod(lo, tiles_per_frame)
+        n = min(tiles_per_frame - t, hi - lo)
+        units.append((f, t, n))
+        lo += n
+    return units
 
 
 def _dist(world):

@@ -3,6 +3,7 @@ checking, the synthetic generator, and — through the CPU *debug emulation* bui
 (tools/hipemu) — the device code's control logic against the oracle on a tiny picture."""
 import ctypes as C
 import importlib
+import json
 import os
 import re
 import subprocess
@@ -470,6 +471,32 @@ def test_argument_and_state_errors_of_the_newer_entry_points(emu_so):
     with pytest.raises(pkg.VvcxError):
         vv.chroma_qp_table(9, (2, 31), (2, 32), lib_path=emu_so)   # bit depth
     enc.close()
+    # a slice that arrives after the pictures were bound: another lambda leaves them bound; an LMCS model (or another QP) they were not prepared with unbinds them -
+    # the search must refuse, not run on unmapped luma with LUTs that never reached the device
+    lm = _lmcs_model_10bit()
+    sp = pkg.slice_params(27, bit_depth=10, dep_quant=True)
+    planes = pkg.synth_frame(16, 16, 0, 10, 5, limited=True)
+    org = [np.ascontiguousarray(p) for p in planes]; rec = [np.zeros_like(p) for p in planes]
+    bind = [([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])]
+    enc = pkg.VvcxEncoder(16, 16, 10, tools=0xf7b, lib_path=emu_so)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    enc.bind_frames(bind)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"] * 1.5, sp["dist_weight"])       # still bound
+    enc.get_levels(0)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"], lmcs=lm)
+    with pytest.raises(pkg.VvcxError):
+        enc.compress_bound_frames()
+    with pytest.raises(pkg.VvcxError):
+        enc.lmcs_inverse_reco()
+    enc.bind_frames(bind)                                                        # bound again with the model: mapped luma, LUTs on the device
+    enc.set_slice(sp["qp"] + 1, sp["qp_c"], sp["lam"], sp["dist_weight"], lmcs=lm)   # another QP: the start contexts are the old QP's
+    with pytest.raises(pkg.VvcxError):
+        enc.compress_bound_frames()
+    enc.close()
+    wpp = pkg.VvcxEncoder(128, 128, 8, tools=pkg.TOOLS_DEFAULT | pkg.TOOL_WPP, lib_path=emu_so)
+    with pytest.raises(pkg.VvcxError):
+        wpp.enable_training_dump(100)                                            # neighbour CUs of other CTU rows: timing dependent under WPP
+    wpp.close()
 
 
 def test_mip_leaf_operator_on_cpu_emulator(emu_so):
@@ -573,7 +600,8 @@ def test_dct2_rows_sum_to_zero_except_the_dc_row():
 def test_resource_budget_of_the_compress_kernel(hip_lib):
     """The stream kernel is sized for four workgroups per CU (128 VGPRs, 40 KB LDS, 1024 resident streams per GPU).  A field too many in the LDS object
     drops the residency to three and makes the compiler give up the register target as well (seen in round 3: 41 008 B -> 257 VGPRs, one wave per SIMD), without any
-    test failing: check the built code object's metadata.  profiles/r03_codeobj.json is this report, committed with the build it describes."""
+    test failing: check the built code object's metadata.  profiles/r04_codeobj.json is this report, written by __graft_entry__.build() and committed with the build it
+    describes: the test fails when the two disagree (a stale report was quoted for a round once)."""
     import importlib.util
     llvm = "/opt/rocm/lib/llvm/bin"
     if not os.path.exists(os.path.join(llvm, "llvm-readelf")):
@@ -585,6 +613,8 @@ def test_resource_budget_of_the_compress_kernel(hip_lib):
         k = r["kernels"][name]
         assert k["group_segment_fixed_size"] <= 40960, (name, k)
         assert k["vgpr_count"] + k.get("agpr_count", 0) <= 128, (name, k)
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r04_codeobj.json")))
+    assert committed["kernels"] == r["kernels"], "profiles/r04_codeobj.json is not the report of the built libvvcx.so: run python tools/codeobj_report.py --out profiles/r04_codeobj.json (or __graft_entry__.build())"
 
 
 def test_barrier_shape_of_the_operation_loop(hip_lib):

@@ -39,3 +39,36 @@ def test_two_rank_gloo_job_matches_oracle(tmp_path):
     subprocess.check_call(cmd, env=env, cwd=ROOT, timeout=540)
     r = json.load(open(out))
     assert r["ok"] and r["frames"] == [0, 1, 2] and r["world"] == 2 and r["elapsed"] > 0
+
+
+def test_units_of_rank_partition_the_tile_streams():
+    for world in (1, 2, 3, 8):
+        for n, tiles in ((1, 1), (1, 8), (3, 8), (2, 135), (5, 1)):
+            seen = []
+            for r in range(world):
+                for f, t0, k in pkg.units_of_rank(n, tiles, r, world):
+                    assert 0 <= t0 and k >= 1 and t0 + k <= tiles
+                    seen += [f * tiles + t for t in range(t0, t0 + k)]
+            assert seen == list(range(n * tiles))                      # every (frame, tile) stream exactly once, in job order across the ranks
+            sizes = [sum(k for _, _, k in pkg.units_of_rank(n, tiles, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+        assert [pkg.units_of_rank(4, 1, r, world) for r in range(world)] == [[(f, 0, 1) for f in pkg.frames_of_rank(4, r, world)] for r in range(world)]
+    # the uniform 15 x 9 grid of a 1080p picture: one CTU per tile; a 4 x 2 grid covers every CTU once
+    assert [pkg.tile_ctus(15, 9, 15, 9, t) for t in range(135)] == [[t] for t in range(135)]
+    assert sorted(sum((pkg.tile_ctus(15, 9, 4, 2, t) for t in range(8)), [])) == list(range(135))
+    assert pkg.tile_ctus(15, 9, 4, 2, 5) == [y * 15 + x for y in range(4, 9) for x in range(3, 7)]
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_gloo_job_sharded_by_tiles_matches_oracle(tmp_path):
+    """one frame, two ranks, 2 x 1 tiles: each rank codes one tile of the same picture; slice data gathered in tile order == the oracle's bytes of the picture"""
+    from conftest import locked_make
+    locked_make(os.path.join(ROOT, PKGNAME, "csrc"), "emu")
+    emu_so = os.path.join(ROOT, "tools", "hipemu", "build", "libvvcx_emu.so")
+    out = tmp_path / "r0.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29573", os.path.join(ROOT, "tests", "_gloo_worker.py"), emu_so, "1", str(out), "tiles"]
+    subprocess.check_call(cmd, env=env, cwd=ROOT, timeout=840)
+    r = json.load(open(out))
+    assert r["ok"] and r["streams"] == [0, 1] and r["world"] == 2 and r["units"] == [[0, 0, 1]]

@@ -21,17 +21,32 @@ def extract(so, tmp):
 
 
 def kernel_metadata(co):
+    """amdhsa.kernels of the code object's notes: one YAML list item per kernel (its first key behind "  - ", the others at the same depth, nested lists such as
+    .args deeper).  The keys of an item are collected first and filed under the item's own .name (the keys are sorted, so half of them precede .name)."""
     notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co]).decode()
-    out, cur = {}, None
+    keep = ("vgpr_count", "agpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "group_segment_fixed_size", "private_segment_fixed_size", "max_flat_workgroup_size")
+    items, cur, inside = [], None, False
     for line in notes.split("\n"):
-        m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)$", line)
-        if not m:
+        if line.startswith("amdhsa.kernels:"):
+            inside = True
             continue
-        k, v = m.group(1), m.group(2).strip().strip("'")
-        if k == "name" and v.startswith("vvcx_") and v.endswith(("_u8", "_u16", "_kernel")):
-            cur = out.setdefault(v, {})
-        elif cur is not None and k in ("vgpr_count", "agpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "group_segment_fixed_size", "private_segment_fixed_size", "max_flat_workgroup_size"):
-            cur[k] = int(v)
+        if inside and line and not line.startswith(" "):       # next top-level key of the metadata document
+            inside = False
+        if not inside:
+            continue
+        m = re.match(r"^  - \.(\w+):\s*(.*)$", line)
+        if m:
+            cur = {}
+            items.append(cur)
+        else:
+            m = re.match(r"^    \.(\w+):\s*(.*)$", line)
+        if m and cur is not None:
+            cur[m.group(1)] = m.group(2).strip().strip("'")
+    out = {}
+    for it in items:
+        name = it.get("name", "")
+        if name.startswith("vvcx_") and name.endswith(("_u8", "_u16", "_kernel")):
+            out[name] = {k: int(it[k]) for k in keep if k in it}
     return out
 
 

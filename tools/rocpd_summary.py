@@ -27,7 +27,7 @@ def main():
             f.write('"%s",%d,%d,%d,%d,%d,%d,%d,%d,%d,%d\n' % r)
     pmc = {}
     pmc_db = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in sorted(d_ for d_ in os.listdir(src) if d_.startswith("pmc_")):
         p = os.path.join(src, sub, "p_results.db")
         if not os.path.exists(p):
             continue
@@ -51,7 +51,17 @@ def main():
                        "saves included, not lines evicted); FETCH_SIZE counts L2 misses only (re-reads of a cached region do not appear)")
     for r in c.execute("select average*1000 from top_kernels where name like 'vvcx_compress%'"):
         out["kernel_ms"] = r[0] / 1e6                       # average launch duration of the --kernel-trace run (ms)
+    # lane utilisation of the vector ALU: thread-cycles per cycle a wave spends in VALU instructions = active lanes per VALU instruction (64 = every lane works)
+    if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_THREAD_CYCLES_VALU") is not None:
+        out["valu_active_lanes"] = pmc["SQ_THREAD_CYCLES_VALU"] / pmc["SQ_ACTIVE_INST_VALU"]
+        out["valu_lane_utilisation"] = out["valu_active_lanes"] / 64.0
+    if pmc.get("SQ_WAVE_CYCLES"):
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS"):
+            if pmc.get(k) is not None:
+                out[k.lower()[3:] + "_per_wave_cycle"] = pmc[k] / pmc["SQ_WAVE_CYCLES"]
     bj = os.path.join(src, "bench.json")
+    if not os.path.exists(bj):
+        bj = os.path.join(src, "trace.json")
     if os.path.exists(bj):
         line = [l for l in open(bj) if l.startswith("{")][-1]
         out["workload"] = json.loads(line)["config"]["workload"]
