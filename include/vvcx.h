@@ -195,8 +195,11 @@ int  vvcx_lmcs_inverse_reco(vvcx_handle *h, void *hip_stream);
  * picture with the cfg's LMCSSignalType 0 and LMCSAdpOption 0: the picture analysis that decides whether the slice uses LMCS and with which model.  org / stride: the original
  * 4:2:0 planes in HOST memory (uint8 below 10 bit, else uint16), update_ctrl = cfg LMCSUpdateCtrl (1 in encoder_intra.cfg; 0 supported, 2 is not an intra setting).  Fills
  * slice->lmcs_enable / lmcs_chroma_adj / lmcs_min_bin / lmcs_max_bin / lmcs_delta_cw (the other members are left alone); hand the slice to vvcx_set_slice before
- * vvcx_bind_frames.  Like the reference it leaves LMCS off for every picture below 10 bit and for full-range 10-bit content.  Needs no handle and no device */
+ * vvcx_bind_frames.  Like the reference it leaves LMCS off for every picture below 10 bit and for full-range 10-bit content.  Needs no handle; the statistics pass (window
+ * variances per luma bin, moments of the three planes) runs on the current HIP device: vvcx_lmcs_analyze uploads the host planes first, vvcx_lmcs_analyze_device takes planes
+ * that are in device memory already (the pointers later given to vvcx_bind_frames) */
 int  vvcx_lmcs_analyze(const void *const org[3], const int stride[3], int pic_w, int pic_h, int bit_depth, int slice_qp, int update_ctrl, vvcx_slice *slice);
+int  vvcx_lmcs_analyze_device(const void *const org[3], const int stride[3], int pic_w, int pic_h, int bit_depth, int slice_qp, int update_ctrl, vvcx_slice *slice);
 /* the LUTs and tables the handle derived from the slice's model: fwd / inv [1 << bit_depth], pivot[17] (mapped-domain bin borders), chroma_scale[16] (11 fractional bits) */
 int  vvcx_lmcs_tables(vvcx_handle *h, int16_t *fwd, int16_t *inv, int32_t pivot[17], int32_t chroma_scale[16]);
 /* ≙ LoopFilter::loopFilterPic (CL/LoopFilter.cpp:153; called from EncGOP after the slices of a picture are compressed): in-loop deblocking

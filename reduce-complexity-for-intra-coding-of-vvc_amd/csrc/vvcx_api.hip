@@ -378,6 +378,12 @@ static void ctx_init_islice(int qp, uint16_t *s0, uint16_t *s1)
   }
 }
 
+static_assert(VXD_NUM_CTX == VX_NUM_CTX, "vvcx_dev.h and the generated tables disagree on the number of context models");
+static void ctx_from_reference_order(const uint16_t *s0, const uint16_t *s1, uint16_t *kept)      // kept: s0[VXD_NUM_CTX] | s1[VXD_NUM_CTX]
+{
+  for (int k = 0; k < VXD_NUM_CTX; k++) { kept[k] = s0[VX_CTX_REF_INDEX[k]]; kept[VXD_NUM_CTX + k] = s1[VX_CTX_REF_INDEX[k]]; }
+}
+
 extern "C" int vvcx_bind_frames(vvcx_handle *h, const vvcx_frame *frames, int n)
 {
   NOT_PENDING(h);
@@ -995,22 +1001,32 @@ extern "C" int vvcx_intra_pred_batch(vvcx_handle *h, const void *const reco[3], 
   return VVCX_OK;
 }
 
+// the leaf operators exchange whole context arrays in the reference's flat order (ContextSetCfg, 386 models); the library keeps the models an intra slice touches
+// (VXD_NUM_CTX, vvcx_tables.h VX_CTX_REF_INDEX)
 extern "C" int vvcx_ctx_init(int qp, uint16_t *s0, uint16_t *s1)
 {
   if (!s0 || !s1) return fail(VVCX_ERR_ARG, "null argument");
-  ctx_init_islice(qp, s0, s1);
+  qp = qp < 0 ? 0 : qp > 63 ? 63 : qp;
+  for (int k = 0; k < VX_NUM_CTX_REF; k++) {               // CtxStore::init for an I slice, every model of the reference (ctx_init_islice: the kept ones)
+    const int id = VX_CTX_INIT_I_REF[k];
+    const int slope = (id >> 3) - 4, offset = ((id & 7) * 18) + 1;
+    int st = ((slope * (qp - 16)) >> 1) + offset;
+    st = st < 1 ? 1 : st > 127 ? 127 : st;
+    const int p1 = st << 8;
+    s0[k] = (uint16_t) (p1 & 0x7FE0); s1[k] = (uint16_t) (p1 & 0x7FFE);
+  }
   return VVCX_OK;
 }
 
 extern "C" int vvcx_cabac_code_bins(uint16_t *s0, uint16_t *s1, int ctx, const uint8_t *bins, int nbins, uint64_t *frac_bits, int device)
 {
-  if (!s0 || !s1 || !bins || !frac_bits || nbins < 0 || ctx < 0 || ctx >= VXD_NUM_CTX) return fail(VVCX_ERR_ARG, "bad argument");
+  if (!s0 || !s1 || !bins || !frac_bits || nbins < 0 || ctx < 0 || ctx >= VX_NUM_CTX_REF) return fail(VVCX_ERR_ARG, "bad argument");      // ctx: the reference's flat index; only its adaptation rate matters
   HIPCHK(hipSetDevice(device));
   DevBuf dio, dbins, dbits;
   uint16_t io[2] = { *s0, *s1 };
   HIPCHK(dio.alloc(4)); HIPCHK(dbins.alloc((size_t) nbins)); HIPCHK(dbits.alloc(8));
   HIPCHK(hipMemcpy(dio.p, io, 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dbins.p, bins, (size_t) nbins, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(vvcx_leaf_cabac_kernel, dim3(1), dim3(VXD_NT), 0, 0, dio.as<uint16_t>(), ctx, dbins.as<uint8_t>(), nbins, dbits.as<unsigned long long>());
+  hipLaunchKernelGGL(vvcx_leaf_cabac_kernel, dim3(1), dim3(VXD_NT), 0, 0, dio.as<uint16_t>(), (int) VX_CTX_RATE_REF[ctx], dbins.as<uint8_t>(), nbins, dbits.as<unsigned long long>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(io, dio.p, 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(frac_bits, dbits.p, 8, hipMemcpyDeviceToHost));
   *s0 = io[0]; *s1 = io[1];
@@ -1123,7 +1139,7 @@ static int depquant_batch_impl(const int16_t *org, const int16_t *pred, int w, i
   HIPCHK(dorg.alloc(bytes)); HIPCHK(drec.alloc(bytes)); HIPCHK(dlev.alloc(bytes)); HIPCHK(dtmp.alloc((size_t) n * 2048 * 4)); HIPCHK(dout.alloc((size_t) n * 16));
   HIPCHK(dctx.alloc(2 * VXD_NUM_CTX * 2)); HIPCHK(dtab.alloc(48 * sizeof(VxDqConst))); HIPCHK(dscr.alloc((size_t) n * VXD_OFF_CACHE));
   HIPCHK(hipMemcpy(dorg.p, org, bytes, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(drec.p, pred, bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dctx.p, s0, VXD_NUM_CTX * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dctx.as<uint16_t>() + VXD_NUM_CTX, s1, VXD_NUM_CTX * 2, hipMemcpyHostToDevice));
+  { uint16_t kept[2 * VXD_NUM_CTX]; ctx_from_reference_order(s0, s1, kept); HIPCHK(hipMemcpy(dctx.p, kept, sizeof kept, hipMemcpyHostToDevice)); }
   VxDqConst tab[48]; memset(tab, 0, sizeof tab);
   for (int lsum = 2; lsum <= 12; lsum++) tab[comp * 16 + lsum] = dq_consts_of(lsum, bit_depth, qp, lambda);
   HIPCHK(hipMemcpy(dtab.p, tab, sizeof tab, hipMemcpyHostToDevice));
@@ -1165,7 +1181,7 @@ extern "C" int vvcx_isp_tu_batch(const int16_t *org, const int16_t *pred, int tw
   HIPCHK(dorg.alloc(bytes)); HIPCHK(drec.alloc(bytes)); HIPCHK(dlev.alloc(bytes)); HIPCHK(dtmp.alloc((size_t) n * 2048 * 4)); HIPCHK(dout.alloc((size_t) n * 16));
   HIPCHK(dctx.alloc(2 * VXD_NUM_CTX * 2)); HIPCHK(dtab.alloc(96 * sizeof(VxDqConst))); HIPCHK(dscr.alloc((size_t) n * VXD_OFF_CACHE));
   HIPCHK(hipMemcpy(dorg.p, org, bytes, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(drec.p, pred, bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dctx.p, s0, VXD_NUM_CTX * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dctx.as<uint16_t>() + VXD_NUM_CTX, s1, VXD_NUM_CTX * 2, hipMemcpyHostToDevice));
+  { uint16_t kept[2 * VXD_NUM_CTX]; ctx_from_reference_order(s0, s1, kept); HIPCHK(hipMemcpy(dctx.p, kept, sizeof kept, hipMemcpyHostToDevice)); }
   VxDqConst tab[96]; memset(tab, 0, sizeof tab);
   for (int lsum = 2; lsum <= 12; lsum++) tab[lsum] = dq_consts_of(lsum, bit_depth, qp, lambda);
   HIPCHK(hipMemcpy(dtab.p, tab, sizeof tab, hipMemcpyHostToDevice));
@@ -1197,7 +1213,7 @@ extern "C" int vvcx_transform_skip_batch(const int16_t *resi, int w, int h, int 
   HIPCHK(dres.alloc(bytes)); HIPCHK(dout.alloc(bytes)); HIPCHK(dlev.alloc(bytes)); HIPCHK(dtmp.alloc((size_t) n * 2048 * 4)); HIPCHK(do2.alloc((size_t) n * 8)); HIPCHK(dbits.alloc((size_t) n * 8));
   HIPCHK(dctx.alloc(2 * VXD_NUM_CTX * 2));
   HIPCHK(hipMemcpy(dres.p, resi, bytes, hipMemcpyHostToDevice)); HIPCHK(hipMemset(dout.p, 0, bytes));
-  HIPCHK(hipMemcpy(dctx.p, s0, VXD_NUM_CTX * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dctx.as<uint16_t>() + VXD_NUM_CTX, s1, VXD_NUM_CTX * 2, hipMemcpyHostToDevice));
+  { uint16_t kept[2 * VXD_NUM_CTX]; ctx_from_reference_order(s0, s1, kept); HIPCHK(hipMemcpy(dctx.p, kept, sizeof kept, hipMemcpyHostToDevice)); }
   VxParams p; memset(&p, 0, sizeof p);
   p.bit_depth = bit_depth; p.tools = VVCX_TOOL_DEPQUANT | VVCX_TOOL_LFNST | VVCX_TOOL_TS; p.lambda = lambda;
   hipLaunchKernelGGL(vvcx_leaf_ts_kernel, dim3((unsigned) n), dim3(VXD_NT), 0, 0, p, dctx.as<uint16_t>(), dres.as<int16_t>(), dlev.as<int16_t>(), dout.as<int16_t>(), dtmp.as<int32_t>(), w, h, qp,

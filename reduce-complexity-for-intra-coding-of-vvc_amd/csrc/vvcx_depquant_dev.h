@@ -100,7 +100,7 @@ __device__ inline long long dq_shfl_i64(long long v, int src)
   return (long long) (((unsigned long long) (unsigned) hi << 32) | (unsigned) lo);
 }
 // fractional bits of a bin from the model's current state (BinProbModel_Std::getFracBitsArray, CL/Contexts.h:128-132)
-__device__ inline int dq_fb(int ci, int ctx, int bin) { const Ctx &c = L.ctxs[ci]; return (int) L.t.bin_frac[((((unsigned) c.s0[ctx] + (unsigned) c.s1[ctx]) >> 8) << 1) + (unsigned) bin]; }
+__device__ inline int dq_fb(int ci, int ctx, int bin) { const Ctx &c = L.ctxs[ci]; return (int) BIN_FRAC(((unsigned) c.s0[ctx] + (unsigned) c.s1[ctx]) >> 8, bin); }
 // g_goRiceBits (887-893) = length of the Golomb-Rice / escape code (EL/BinEncoder.cpp:444-472) in 2^-15 bit units
 __device__ inline int dq_rice_bits(int par, unsigned v) { return rem_abs_len(v, (unsigned) par) << 15; }
 
@@ -164,6 +164,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
                                                  int ci0, int ci_step, int cbf_ctx0, unsigned cbf_mask, int w, int h, int comp, int zo, int lfnst, int lane, int qidx = -1)
 {
   n_items = uni(n_items); w = uni(w); h = uni(h); comp = uni(comp); zo = uni(zo); lfnst = uni(lfnst); ci0 = uni(ci0); ci_step = uni(ci_step); cbf_ctx0 = uni(cbf_ctx0);
+  cf_base = uni_p(cf_base); nodes = uni_p(nodes); cf_stride = uni(cf_stride); node_stride = uni(node_stride); abs0 = uni(abs0); cbf_mask = (unsigned) uni((int) cbf_mask); qidx = uni(qidx);
   // the work area (decisions, last-position offsets, template rows, TAB 1 tables) is the LDS memory of wave wk_wave: formed from L here, so that every access in the serial
   // loop is a ds_ instruction (a pointer argument would be a generic one: flat_ accesses that wait on both counters)
   uint8_t *wk = (uint8_t *) &L.wm[uni(wk_wave)];
@@ -578,7 +579,7 @@ __device__ inline int wave_depquant(int16_t *cf_g, int buf_off, uint8_t *scratch
   int16_t *cf = SMALL ? L.wm[wave_].slot + BUF + uni(buf_off) : cf_g;
   // the tables fit behind the decisions in the rate-estimator scratch + tmp for all but the 32 x 32-coefficient blocks
   // (and pay for themselves from 64 positions on)
-  if (imin(32, w) * imin(32, h) >= VXD_DQ_TAB_MIN && 240 + 2 * imin(32, w) * imin(32, h) + DQ_TAB_BYTES <= (int) (sizeof(WaveScratch) + sizeof(int32_t) * BUF))
+  if (imin(32, w) * imin(32, h) >= VXD_DQ_TAB_MIN && 240 + 2 * imin(32, w) * imin(32, h) + DQ_TAB_BYTES <= (int) (sizeof(WaveScratch) + sizeof(int32_t) * BUF))      // (2000 bytes: up to 256 positions)
     wave_depquant_batch<1>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, wave_, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
   else
     wave_depquant_batch<0>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, wave_, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);

@@ -13,8 +13,8 @@
 #ifndef VXD_WPE
 #define VXD_WPE 4            // waves per SIMD the register budget is sized for = CTU streams per CU (one wave of each stream per SIMD)
 #endif
-#define VXD_MAXD 14         // recursion levels kept in LDS
-#define VXD_NUM_CTX 386     // flat context array, same indexing as the reference's ContextSetCfg
+#define VXD_MAXD 12         // recursion levels kept in LDS (a split at least halves the area: 128x128 -> 4x4 is at most ten levels below the CTU)
+#define VXD_NUM_CTX 291     // flat context array: the models of the reference's ContextSetCfg an intra slice of this path touches, in its order (vvcx_tables.h VX_NUM_CTX)
 
 // one 4x4-luma unit of a channel-type map: the CU that covers it (≙ the fields of CodingUnit /
 // PredictionUnit / TransformUnit the path reads from neighbours and the caller reads at the end)

@@ -30,6 +30,7 @@
 #define MAXD VXD_MAXD
 #define BUF VXD_BUF
 #define NCTX VXD_NUM_CTX
+static_assert(VXD_NUM_CTX == VX_NUM_CTX, "vvcx_dev.h and the generated tables disagree on the number of context models");
 #define MAX_DOUBLE 1.7e+308
 #ifndef VVCX_STAMP
 #define VVCX_STAMP 0          // 1: diagnostic build with shader-clock stamps per operation kind
@@ -116,15 +117,18 @@ struct CtlState {            // controller-private working set (touched by threa
   uint8_t inv0[16], rdSrc[24];           // first pass: list place -> stage-B item; per list entry of an MTS pass: the first pass's item that carries its prepared DST-VII block
 };
 
+// fractional bits of a bin in probability state st (0..255): the table is symmetric, m_binFracBits[st][1] == m_binFracBits[255 - st][0] (checked by the CPU suite), so
+// LDS holds the bin-0 half only
+#define BIN_FRAC(st_, bin_) L.t.bin_frac[(unsigned) (st_) ^ ((0u - (unsigned) (bin_)) & 255u)]
 struct Tables {                    // constant tables staged once per workgroup (LDS latency instead of global latency
-  uint32_t bin_frac[512];          //  on the controller's and the rate estimator's dependent chains)
+  uint32_t bin_frac[256];          //  on the controller's and the rate estimator's dependent chains): m_binFracBits[state][0]; [state][1] = [255 - state][0] (BIN_FRAC)
   int32_t  qscale[12], iqscale[12];
   int16_t  ang[32], inv_ang[32];
   int8_t   gauss[128], cubic[128];
   uint8_t  last_prefix[8], mode_shift[8];
   uint8_t  ctx_rate[NCTX + 2], gorice_pars[32], gorice_pos0[96], rice_len[128], group_idx[64], mode_num[36], intra_thr[8];
-  alignas(16) int8_t dst7[16 + 64 + 256 + 1024];   // DST-VII 4..32 (explicit MTS); DCT-VIII[k][i] = (-1)^k DST-VII[k][n-1-i] is read from the same rows
-  alignas(16) int8_t dct[4 + 16 + 64 + 256 + 1024];   // DCT-II 2..32 (the 64-point matrix is only used by 64x64 luma nodes, which never are LDS resident: read from constant memory)
+  // (the transform matrices are read from constant memory through the vector L1: their LDS copies were 2.7 KB of the budget that decides how many streams share a CU,
+  //  and cost 1.5 % when dropped, profiles/r03z_optimisation_levels.txt; DCT-VIII[k][i] = (-1)^k DST-VII[k][n-1-i] is read from the DST-VII rows)
   uint8_t  cg_scan[84], grp_scan[228];   // diagonal scans (CL/Rom.cpp:87-131) as x | y << 4: inside a coefficient group {4x4, 2x2, 8x2, 2x8, 16x1, 1x16}; of the groups, per (log2 wg, log2 hg)
   uint8_t  cg_inv[84], grp_inv[228];     // their inverses: raster position (y * width + x) -> scan index, same table offsets
 };
@@ -133,8 +137,9 @@ struct Tables {                    // constant tables staged once per workgroup 
 // per-wave scratch that the rate estimator (pending bin list) and the dependent quantiser (decisions, path nodes) use at different times
 #define DQ_TAB_INTS (21 * 6 + 3 * 12 * 2 + 4)
 struct WaveRc { uint16_t binbuf[RC_LIST]; uint8_t binsort[RC_LIST + 8]; };
-struct WaveDq { int lastb[16][20]; uint16_t trel[256]; };      // last-position offsets per item; decisions (they continue into tmp / slot behind)
-union WaveScratch { WaveRc rc; WaveDq dq; };
+// the dependent quantiser lays its per-item areas (last-position offsets, decisions, template rows) over the same bytes and on into tmp / slot behind them
+// (wave_depquant_batch: 240 + 2 * positions bytes per item), so the scratch is sized by the rate estimator's lists alone
+struct alignas(16) WaveScratch { WaveRc rc; };
 struct WaveMem {
   WaveScratch ws;
   alignas(16) int32_t tmp[BUF];                // transform / Hadamard / scan scratch (blocks needing more use HBM scratch)
@@ -204,6 +209,16 @@ struct Lds {
 
 __shared__ Lds L;
 #define PROF(i) L.prof[VVCX_STAMP ? (i) : 0]
+// diagnostic build -DVVCX_STAMP_ISP (with VVCX_STAMP): slots 16..29 time the ISP evaluation of wave 0 and the controller's ISP phase instead of the phases
+#ifdef VVCX_STAMP_ISP
+#define ISP_T(n_) long long n_ = clock64()
+#define ISP_ADD(slot_, a_, b_) do { if (VTX == 0) PROF(slot_) += (unsigned long long) ((b_) - (a_)); } while (0)
+#define ISP_ADD0(slot_, a_, b_) do { PROF(slot_) += (unsigned long long) ((b_) - (a_)); } while (0)
+#else
+#define ISP_T(n_)
+#define ISP_ADD(slot_, a_, b_)
+#define ISP_ADD0(slot_, a_, b_)
+#endif
 #ifndef VX_POISON_LDS
 #define VX_POISON_LDS(obj) ((void) 0)
 #endif
@@ -224,6 +239,13 @@ __device__ inline int fast_div(int i, int d, int ld) { return ld >= 0 ? i >> ld 
 // steer any control flow that contains a barrier, a wave barrier or a shuffle: the structurizer may otherwise
 // serialise what it believes to be divergent paths around those convergent operations.
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a pointer that is the same on every lane (arguments of non-inlined functions arrive in vector registers): into scalar registers, with everything derived from it
+template <typename T> __device__ inline T *uni_p(T *p)
+{
+  union { T *p; int i[2]; } u; u.p = p;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]); u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.p;
+}
 __device__ inline double uni_d(double v)
 {
   union { double d; int i[2]; } u; u.d = v;
@@ -361,7 +383,7 @@ __device__ inline void enc_bin(Cab &cb, unsigned bin, int ctx)
 {
   Ctx *c = &L.ctxs[cb.ci];
   const unsigned st = (unsigned) (c->s0[ctx] + c->s1[ctx]) >> 8;
-  cb.bits += L.t.bin_frac[st * 2 + bin];
+  cb.bits += BIN_FRAC(st, bin);
   if (WR) arith_bin(bin, st);
   const int rate = L.t.ctx_rate[ctx];
   const int r0 = 2 + ((rate >> 2) & 3), r1 = 3 + r0 + (rate & 3);
@@ -486,6 +508,7 @@ __device__ __noinline__ RcPre rc_prepass_serial(const int16_t *coeff, int w, int
 template <bool SMALL>
 __device__ __noinline__ RcPre rc_prepass_wave(int lev_off, const int16_t *coeff_g, int w, int h, int lane)
 {
+  coeff_g = uni_p(coeff_g);
   w = uni(w); h = uni(h);
   const int16_t *coeff = SMALL ? L.wm[uni(VTX >> 6)].slot + BUF + uni(lev_off) : coeff_g;
   const ScanGeo g = scan_geo(w, h);
@@ -681,7 +704,7 @@ __device__ __noinline__ void rc_chain(int ci, int wv, int nb, int lane, unsigned
         const unsigned bin = nxt;
         nxt = sorted[mystart + k + 1];
         acc += pend;
-        pend = L.t.bin_frac[(((a + b) >> 8) << 1) + bin];
+        pend = BIN_FRAC((a + b) >> 8, bin);
         a -= (a >> r0) & 0x7FE0u; b -= (b >> r1) & 0x7FFEu;
         if (bin) { a += i0; b += i1; }
       }
@@ -695,6 +718,7 @@ __device__ __noinline__ void rc_chain(int ci, int wv, int nb, int lane, unsigned
 template <bool SMALL>
 __device__ __noinline__ void residual_coding_wave(Cab &cb, int lev_off, const int16_t *coeff_g, int w, int h, int is_chroma, int lane, int zo = 0)
 {
+  coeff_g = uni_p(coeff_g); lev_off = uni(lev_off);
   zo = uni(zo);
   const int dq = uni((int) (L.par.tools & TOOL_DEPQUANT)) != 0;       // dep_quant_enabled_flag: the quantiser state picks the sig_coeff_flag context set and the bypass zero position
   int dqx = 0, dqy = 0;                                                 // state bits in front of lane 0 of the current 64 positions (see wave_dequant_dq)
@@ -1028,7 +1052,7 @@ __device__ void enc_intra_luma_pred_mode(Cab &cb, int y, int dir, int mrl, int i
 // xFracModeBitsIntra (EL/IntraSearch.cpp:4263-4288) from the node's start contexts.  Every context-coded bin of
 // intra_luma_pred_mode uses a different context, so the bits are a pure function of the start states.
 __device__ inline unsigned frac_bits_of(const Ctx &c, int ctx, unsigned bin)
-{ return L.t.bin_frac[(((unsigned) (c.s0[ctx] + c.s1[ctx]) >> 8) << 1) + bin]; }
+{ return BIN_FRAC((unsigned) (c.s0[ctx] + c.s1[ctx]) >> 8, bin); }
 __device__ unsigned long long luma_mode_bits(const Ctx &c, int y, int dir, int mrl)
 {
   unsigned long long bits = 0;
@@ -1545,6 +1569,7 @@ template <bool SMALL>
 __device__ __noinline__ void wave_sad_satd(const int16_t *org_g, const int16_t *pred_g, int16_t *scr_g, int w, int h, int lane,
                               unsigned long long &sad_out, unsigned long long &satd_out, int org_off = 0, int pred_off = 0)
 {
+  org_g = uni_p(org_g); pred_g = uni_p(pred_g); scr_g = uni_p(scr_g);
   w = uni(w); h = uni(h); org_off = uni(org_off); pred_off = uni(pred_off);       // offsets: second component of a chroma pair
   const int wave_ = uni(VTX >> 6);
   const int16_t *org = (SMALL ? L.org : org_g) + org_off, *pred = (SMALL ? L.wm[wave_].slot : pred_g) + pred_off;
@@ -1603,12 +1628,12 @@ __device__ inline uint2 rev4_s16(uint2 d) { uint2 r; r.x = (d.y >> 16) | (d.y <<
 __device__ inline I32x4 rev4_s32(I32x4 d) { I32x4 r; r.x = d.w; r.y = d.z; r.z = d.y; r.w = d.x; return r; }
 template <bool SMALL> __device__ inline const int8_t *dct2_matrix(int n)
 {
-  switch (n) { case 2: return L.t.dct; case 4: return L.t.dct + 4; case 8: return L.t.dct + 20; case 16: return L.t.dct + 84; case 32: return L.t.dct + 340; default: return VX_DCT2_64; }
+  switch (n) { case 2: return VX_DCT2_2; case 4: return VX_DCT2_4; case 8: return VX_DCT2_8; case 16: return VX_DCT2_16; case 32: return VX_DCT2_32; default: return VX_DCT2_64; }
 }
 __device__ void load_tables()
 {
   const int tid = VTX;
-  for (int i = tid; i < 512; i += NT) L.t.bin_frac[i] = VX_BIN_FRAC_BITS[i];
+  for (int i = tid; i < 256; i += NT) L.t.bin_frac[i] = VX_BIN_FRAC_BITS[2 * i];
   for (int i = tid; i < NCTX; i += NT) L.t.ctx_rate[i] = VX_CTX_RATE[i];
   if (tid < 12) { L.t.qscale[tid] = VX_QUANT_SCALES[tid]; L.t.iqscale[tid] = VX_INV_QUANT_SCALES[tid]; }
   if (tid < 32) { L.t.ang[tid] = ANG_TABLE[tid]; L.t.inv_ang[tid] = INV_ANG_TABLE[tid]; L.t.gorice_pars[tid] = VX_GORICE_PARS[tid]; }
@@ -1635,15 +1660,6 @@ __device__ void load_tables()
     L.t.grp_scan[i] = (uint8_t) (x | (y << 4));
     L.t.grp_inv[off + y * (1 << a) + x] = (uint8_t) (i - off);
   }
-  for (int i = tid; i < 16; i += NT) L.t.dst7[i] = VX_DST7_4[i];
-  for (int i = tid; i < 64; i += NT) L.t.dst7[16 + i] = VX_DST7_8[i];
-  for (int i = tid; i < 256; i += NT) L.t.dst7[80 + i] = VX_DST7_16[i];
-  for (int i = tid; i < 1024; i += NT) L.t.dst7[336 + i] = VX_DST7_32[i];
-  for (int i = tid; i < 4; i += NT) L.t.dct[i] = VX_DCT2_2[i];
-  for (int i = tid; i < 16; i += NT) L.t.dct[4 + i] = VX_DCT2_4[i];
-  for (int i = tid; i < 64; i += NT) L.t.dct[20 + i] = VX_DCT2_8[i];
-  for (int i = tid; i < 256; i += NT) L.t.dct[84 + i] = VX_DCT2_16[i];
-  for (int i = tid; i < 1024; i += NT) L.t.dct[340 + i] = VX_DCT2_32[i];
 }
 // ---- LMCS chroma residual scaling.  AreaBuf<Pel>::scaleSignal (CL/Buffer.cpp:501-550): the encoder divides the chroma residual by the scale (11 fractional bits), the
 // decoder half multiplies it back
@@ -1708,6 +1724,7 @@ __device__ __noinline__ void wave_code_block(const int16_t *org_g, int org_off, 
                                 int lane, unsigned long long &sse_out, int &cbf_out, int given = -1, int *sumabs_out = nullptr, int comp = 0, int ci = 0, int cbf_cb = 0,
                                 int lf = 0, int lfmode = 0, int raw = 0, int qidx = -1, int cadj = 0)
 {
+  org_g = uni_p(org_g); rec_g = uni_p(rec_g); lev_g = uni_p(lev_g); tmp_g = uni_p(tmp_g); sumabs_out = uni_p(sumabs_out);      // uniform arguments arrive in vector registers: scalar from here on
   // cadj: LMCS chroma residual scale of the block (0: none): the residual is divided by it in front of the transform and multiplied back behind the inverse
   // raw: the block is a bare residual (org = the residual, rec = zeros on entry): rec receives the reconstructed residual, unclipped (joint chroma blocks)
   // lf: cu.lfnstIdx for a block of at least 4x4 (0 otherwise), lfmode: lfnst_mode() of its final intra mode (dependent quantisation only)
@@ -1877,7 +1894,7 @@ __device__ inline void mts_types(int mts, int &trh, int &trv)
 template <bool SMALL> __device__ inline const int8_t *tr_matrix(int tr, int n)
 {
   if (tr == 0) return dct2_matrix<SMALL>(n);
-  return n == 4 ? L.t.dst7 : n == 8 ? L.t.dst7 + 16 : n == 16 ? L.t.dst7 + 80 : L.t.dst7 + 336;
+  return n == 4 ? VX_DST7_4 : n == 8 ? VX_DST7_8 : n == 16 ? VX_DST7_16 : VX_DST7_32;
 }
 __device__ inline int tr_coef(const int8_t *M, int n, int tr, int k, int i)
 {
@@ -1889,6 +1906,7 @@ __device__ inline int tr_coef(const int8_t *M, int n, int tr, int k, int i)
 template <bool SMALL>
 __device__ __noinline__ int wave_fwd_sumabs(const int16_t *org_g, const int16_t *pred_g, int32_t *tmp_g, int w, int h, int bd, int mts, int lane)
 {
+  org_g = uni_p(org_g); pred_g = uni_p(pred_g); tmp_g = uni_p(tmp_g);
   w = uni(w); h = uni(h); bd = uni(bd); mts = uni(mts);
   const int wave_ = uni(VTX >> 6);
   const int16_t *org = SMALL ? L.org : org_g, *pred = SMALL ? L.wm[wave_].slot : pred_g;
@@ -1926,6 +1944,7 @@ template <bool SMALL>
 __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *rec_g, int16_t *lev_g, int32_t *tmp_g, int w, int h, int bd, int qp, int mts,
                                                  int lane, unsigned long long &sse_out, int &cbf_out, int given = -1)
 {
+  org_g = uni_p(org_g); rec_g = uni_p(rec_g); lev_g = uni_p(lev_g); tmp_g = uni_p(tmp_g);
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given); mts = uni(mts);
   const int dq = uni((int) (L.par.tools & TOOL_DEPQUANT)) != 0;        // luma only: the rate terms come from the node's start contexts (CI_CUR)
   const int wave_ = uni(VTX >> 6);
@@ -2030,6 +2049,7 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
 __device__ __noinline__ void wave_code_block_isp(const int16_t *org, int16_t *rec, int16_t *lev, int cst, int32_t *tmp, int16_t *cf, uint8_t *scratch, int w, int h, int bd, int qp,
                                                  int lane, unsigned long long &sse_out, int &cbf_out, int given, int ci, int cbf_ctx)
 {
+  org = uni_p(org); rec = uni_p(rec); lev = uni_p(lev); tmp = uni_p(tmp); cf = uni_p(cf); scratch = uni_p(scratch); ci = uni(ci); cbf_ctx = uni(cbf_ctx);
   // cf: a dense w * h int16 tile for the coefficients / levels (the trellis and the residual syntax take stride w)
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given); cst = uni(cst);
   const int trh = (w >= 4 && w <= 16) ? 2 : 0, trv = (h >= 4 && h <= 16) ? 2 : 0;
@@ -2037,6 +2057,7 @@ __device__ __noinline__ void wave_code_block_isp(const int16_t *org, int16_t *re
   const int zw = imin(w, 32), zh = imin(h, 32), lzw = ilog2i(zw);
   const int8_t *Mw = w > 1 ? tr_matrix<false>(trh, w) : nullptr, *Mh = h > 1 ? tr_matrix<false>(trv, h) : nullptr;
   const int oneD = w == 1 || h == 1;
+  ISP_T(i0);
   if (given < 0) {
     if (!oneD) {
       const int shift1 = lw + bd + 6 - 15, shift2 = lh + 6;
@@ -2071,8 +2092,10 @@ __device__ __noinline__ void wave_code_block_isp(const int16_t *org, int16_t *re
     wave_sync();
   }
   int abs_sum = given;
+  ISP_T(i1);
   if (given < 0) abs_sum = wave_depquant<false>(cf, 0, scratch, ci, w, h, 0, cbf_ctx, 0, 0, lane);
   wave_sync();
+  ISP_T(i2);
   if (given < 0) { for (int o = lane; o < P; o += 64) lev[(o >> lw) * cst + (o & (w - 1))] = cf[o]; }
   unsigned long long sse = 0;
   const int mx = (1 << bd) - 1;
@@ -2123,6 +2146,7 @@ __device__ __noinline__ void wave_code_block_isp(const int16_t *org, int16_t *re
   wave_sync();
   sse_out = wave_sum_u64(sse);
   cbf_out = abs_sum > 0;
+  { ISP_T(i3); ISP_ADD(16, i0, i1); ISP_ADD(17, i1, i2); ISP_ADD(18, i2, i3); }
 }
 // CABACWriter::mts_coding 3885-3941 for a TU where MTS is allowed and transform skip is not (JVET_O0294 contexts); lane 0 / thread 0
 template <bool WR = false>
@@ -2353,6 +2377,7 @@ __device__ inline int wave_ts_fwd(const int16_t *org, const int16_t *pred, int16
 // raw: rec receives the bare residual (leaf test).  cbf 0: the prediction is the reconstruction.
 __device__ __noinline__ void wave_ts_recon(const int16_t *org, int16_t *rec, const int16_t *lev, int w, int h, int bd, int qp, int cbf, int lane, unsigned long long &sse_out, int raw = 0)
 {
+  org = uni_p(org); rec = uni_p(rec); lev = uni_p(lev); raw = uni(raw);
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); cbf = uni(cbf);
   const int P = w * h, q = ts_qp(qp), sh = ts_shift(w, h, bd), scale = L.t.iqscale[q % 6], right_shift = 6 - (sh + q / 6), mx = (1 << bd) - 1;
   int tbd = 32 + right_shift - 7; if (tbd > 16) tbd = 16;
@@ -2421,6 +2446,7 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
 {
   const VxParams &p = L.par;
   w = uni(w); h = uni(h); dir = uni(dir); isp = uni(isp); given_tucbf = uni(given_tucbf); ci = uni(ci);
+  scratch = uni_p(scratch); given = uni_p(given); rec = uni_p(rec); lev = uni_p(lev); tile = uni_p(tile); out = uni_p(out); limit = uni_d(limit);
   const int bd = p.bit_depth, hor = isp == 1;
   const int psz = isp_split_dim(w, h, hor), tw = hor ? w : psz, th = hor ? psz : h, n = hor ? h / psz : w / psz;
   const int predRegDiff = !hor && ((w == 8 && h > 4) || w == 4);         // CU::isPredRegDiffFromTB
@@ -2441,8 +2467,10 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
   double cost = 0; int tucbf = 0, nrun = 0;
   unsigned long long dist = 0, bits = 0;
   Cab cb; cb.ci = ci; cb.bits = 0;
+  ISP_T(c0);
   for (int k = 0; k < n; k++) {
     const int ox = hor ? 0 : k * tw, oy = hor ? k * th : 0;
+    ISP_T(k0);
     if (!predRegDiff || (ox & 3) == 0) {
       const int pw = predRegDiff ? imax(tw, 4) : tw, ph = th, topLen = w + pw, leftLen = h + ph;
       // reference samples of the region
@@ -2473,6 +2501,7 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
     const int cbfCtx = lastInferred ? -1 : (int) VX_CTX_QtCbf[0] + 2 + prevCbf;
     unsigned long long d; int cbf;
     const int off = oy * w + ox;
+    { ISP_T(k1); ISP_ADD(19, k0, k1); if (VTX == 0) PROF(23) += 1; }
     wave_code_block_isp(org + off, rec + off, lev + off, w, tmp, cf, scratch, tw, th, bd, p.qp_tr, lane, d, cbf, given ? (given_tucbf >> k) & 1 : -1, ci, cbfCtx);
     cbf = uni(cbf);
     nrun = k + 1;
@@ -2481,6 +2510,7 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
     if (k == n - 1 && !tucbf && !cbf) break;                  // 2990-2996: ISP needs one coded sub-partition
     if (cbf) tucbf |= 1 << k;
     unsigned long long fb = 0;
+    ISP_T(k2);
     if (!(rd_cost(p, bits, dist + d) > limit)) {              // 3206-3210: beyond the limit the rate is not even computed
       cb.bits = 0;                                            // xGetIntraFracBitsQT: the CU header with the first sub-partition, cbf unless inferred, coefficients
       if (lane == 0) {
@@ -2491,6 +2521,7 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
       { unsigned lo = (unsigned) cb.bits, hi = (unsigned) (cb.bits >> 32); lo = (unsigned) __builtin_amdgcn_readlane((int) lo, 0); hi = (unsigned) __builtin_amdgcn_readlane((int) hi, 0); fb = ((unsigned long long) hi << 32) | lo; }
       if (lane == 0) out->fb[k] = fb;
     }
+    { ISP_T(k3); ISP_ADD(20, k2, k3); }
     cost += rd_cost(p, fb, d); dist += d; bits += fb;
     if (k + 1 < n) {
       if (cost > limit) break;
@@ -2501,10 +2532,12 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
   if (lane == 0) { if (given) L.isp_dist = dist; else { out->cbf = (uint8_t) tucbf; out->nrun = (uint8_t) nrun; } }
   wave_sync();
   if (small) { for (int e = lane; e < w * h; e += 64) { rec_out[e] = rec[e]; lev_out[e] = lev[e]; } wave_sync(); }
+  { ISP_T(c1); ISP_ADD(21, c0, c1); if (VTX == 0) PROF(22) += 1; }
 }
 // OP_ISP: up to NW candidates of the node's ISP test at once, one per wave: L.isp_res[w].mode / split name wave w's, all under the limit L.isp_limit
 __device__ __noinline__ void op_isp(uint8_t *scratch)
 {
+  scratch = uni_p(scratch);
   const int wave = uni(VTX >> 6), lane = VTX & 63;
   const int w = uni(L.nw), h = uni(L.nh);
   if (wave < uni((int) L.isp_nb)) {
@@ -2517,6 +2550,7 @@ __device__ __noinline__ void op_isp(uint8_t *scratch)
 // OP_ISP_PARK: the candidate wave L.isp_park evaluated became the node's best: its reconstruction, levels and end contexts are kept (1308-1326)
 __device__ __noinline__ void op_isp_park(uint8_t *scratch)
 {
+  scratch = uni_p(scratch);
   const int src = uni((int) L.isp_park), P = uni(L.nw) * uni(L.nh);
   const int16_t *t = isp_tile(scratch, src);
   int16_t *best = (int16_t *) (scratch + VXD_OFF_ISP_BEST);
@@ -2612,6 +2646,7 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
 // CL/IntraPrediction.cpp:2152-2186); the reduced boundary and the matrix outputs pass through the wave's LDS scratch
 __device__ __noinline__ void wave_pred_mip(int16_t *dst, int w, int h, int mode, int bd, int wave, int lane)
 {
+  dst = uni_p(dst); bd = uni(bd);
   w = uni(w); h = uni(h); mode = uni(mode); wave = uni(wave);
   int *sh = (int *) L.wm[wave].tmp, *red = sh + 16;
   const MipGeo g = mip_geo(w, h);
@@ -2625,6 +2660,7 @@ __device__ __noinline__ void wave_pred_mip(int16_t *dst, int w, int h, int mode,
 template <bool SMALL>
 __device__ __noinline__ void stage_a_mip(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h, int c_end)
 {
+  scratch = uni_p(scratch); wave = uni(wave); w = uni(w); h = uni(h); c_end = uni(c_end);
   const int P = w * h, bd = p.bit_depth;
   int16_t *pred = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, 0);
   int16_t *scr = SMALL ? (int16_t *) L.wm[wave].tmp : (int16_t *) wave_tmp(scratch, P >> 1, wave);
@@ -2647,6 +2683,7 @@ __device__ __noinline__ void stage_a_mip(const VxParams &p, uint8_t *scratch, in
 template <bool SMALL>
 __device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h, int c_end)
 {
+  scratch = uni_p(scratch); wave = uni(wave); w = uni(w); h = uni(h); c_end = uni(c_end);
   const int P = w * h, bd = p.bit_depth;
   int16_t *pred = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, 0);
   int16_t *scr = SMALL ? (int16_t *) L.wm[wave].tmp : (int16_t *) wave_tmp(scratch, P >> 1, wave);
@@ -2677,6 +2714,7 @@ __device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int 
 // OP_STAGE_A: SATD-stage cost of every candidate in L.cand[op_a .. op_b) (EL/IntraSearch.cpp:489-682), one wave per candidate
 __device__ __noinline__ void op_stage_a(const VxParams &p_, uint8_t *scratch)
 {
+  scratch = uni_p(scratch);
   const VxParams &p = L.par; (void) p_;
   const int wave = uni(VTX >> 6), lane = VTX & 63;
   const int w = uni(L.nw), h = uni(L.nh), P = w * h;
@@ -2735,6 +2773,7 @@ __device__ __noinline__ void op_stage_a(const VxParams &p_, uint8_t *scratch)
 template <bool SMALL, bool MTS>
 __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h)
 {
+  scratch = uni_p(scratch); wave = uni(wave); w = uni(w); h = uni(h);
   const int P = w * h, bd = p.bit_depth;
   if (lane == 0) L.wave_best[wave] = -1;
   double wbest = MAX_DOUBLE;
@@ -2849,6 +2888,7 @@ __device__ void dq_trellis_phase(uint8_t *scratch, int n, int P, int total, int 
 template <bool SMALL>
 __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane, int w, int h)
 {
+  scratch = uni_p(scratch); wave = uni(wave); w = uni(w); h = uni(h);      // uniform arguments arrive in vector registers: scalar from here on
   const VxParams &p = L.par;
   const int P = w * h, bd = p.bit_depth, total = imin(32, w) * imin(32, h);
   const int mtsOk = mts_allowed(p, w, h);
@@ -3093,6 +3133,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
 }
 __device__ __noinline__ void op_stage_b(const VxParams &p_, uint8_t *scratch)
 {
+  scratch = uni_p(scratch);
   const VxParams &p = L.par; (void) p_;
   const int wave = uni(VTX >> 6), lane = VTX & 63;
   const int w = uni(L.nw), h = uni(L.nh);
@@ -3131,6 +3172,7 @@ template <bool SMALL> __device__ __noinline__ void chroma_rd_rounds(uint8_t *scr
 template <bool SMALL>
 __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h)
 {
+  scratch = uni_p(scratch); wave = uni(wave); w = uni(w); h = uni(h);
   const int P = w * h, bd = p.bit_depth;
   const int16_t *lmin = lm_in_buf(scratch, 2 * P);
   if (uni(L.lm_ok)) {
@@ -3254,6 +3296,7 @@ __device__ inline long long wave_sum_i64(long long v) { return (long long) wave_
 template <bool SMALL>
 __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int lane, int w, int h)
 {
+  scratch = uni_p(scratch); wave = uni(wave); w = uni(w); h = uni(h);
   const VxParams &p = L.par;
   const int P = w * h, bd = p.bit_depth, total = imin(32, w) * imin(32, h);
   const int16_t *lmin = lm_in_buf(scratch, 2 * P);
@@ -3463,6 +3506,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
 template <typename T>
 __device__ __noinline__ void op_chroma_rd(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
+  scratch = uni_p(scratch);
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int wave = uni(VTX >> 6), lane = VTX & 63;
   const int x = uni(L.nx) >> 1, y = uni(L.ny) >> 1, w = uni(L.nw) >> 1, h = uni(L.nh) >> 1, P = w * h;
@@ -3543,6 +3587,7 @@ __device__ int cache_is_valid(const VxParams &p, uint8_t *scratch, Frame *fr, in
 template <bool SMALL>
 __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch, int w, int h)
 {
+  scratch = uni_p(scratch); ch = uni(ch); w = uni(w); h = uni(h);
   const int P = w * h, n = ch ? 2 * P : P, bd = p.bit_depth;
   int16_t *recb = SMALL ? L.wm[0].slot : slot_rec(scratch, n, 0, 0), *levb = SMALL ? L.wm[0].slot + BUF : slot_lev(scratch, n, 0, 0);
   const int mode = uni(L.rd[0].mode), fm = uni(L.rd[0].mrl), cbfm = uni(L.rd_cbf[0]);
@@ -3645,6 +3690,7 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
 template <typename T>
 __device__ __noinline__ void op_reuse(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
+  scratch = uni_p(scratch);
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int wave = uni(VTX >> 6), lane = VTX & 63;
   const int ch = uni(L.tree_ch), bd = p.bit_depth;
@@ -3840,6 +3886,7 @@ __device__ __noinline__ void op_fast(const VxParams &p_, const VxFrameDev &fd_)
 template <typename T>
 __device__ __noinline__ void op_save_pic(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch, int restore)
 {
+  scratch = uni_p(scratch); restore = uni(restore);
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int ch = L.tree_ch, d = L.nd;
   const int x1 = imin(L.nx + L.nw, p.pic_w), y1 = imin(L.ny + L.nh, p.pic_h);
@@ -3871,6 +3918,7 @@ __device__ __noinline__ void op_save_pic(const VxParams &p_, const VxFrameDev &f
 // winner of the intra check (slot B of wave L.win_wave) + its CU record → level store
 __device__ __noinline__ void op_save_intra(const VxParams &p_, uint8_t *scratch, const VxUnit &cu)
 {
+  scratch = uni_p(scratch);
   const VxParams &p = L.par; (void) p_;
   const int ch = L.tree_ch, d = L.nd, sh = ch ? 1 : 0;
   const int W = L.nw >> sh, H = L.nh >> sh, P = W * H;
@@ -4415,7 +4463,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
     const int d = L.d;
 #if VVCX_STAMP
     const long long tph = STAMP(); const int phs = f.phase;
-#ifndef VVCX_STAMP_DQ
+#if !defined(VVCX_STAMP_DQ) && !defined(VVCX_STAMP_ISP)
     struct PhStamp { long long t; int ph; __device__ ~PhStamp() { const int slot = ph < 12 ? 16 + ph : ph == PH_EXIT2 ? 1 : ph == PH_A3_DONE ? 28 : ph == PH_PASS ? 29 : ph == PH_NEXT_PASS ? 31 : 47; PROF(slot) += (unsigned long long) (STAMP() - t); PROF(30) += 1; } } phstamp = { tph, phs };
 #endif
 #endif
@@ -4570,26 +4618,29 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
     }
     case PH_ISP: {                                      // the reserved places of the RD list: each asks xGetNextISPMode for the next ISP candidate (1181-1192); the candidates are
       // evaluated in batches of up to NW, one per wave, ahead of that order (ctrl_isp_batch), and judged in it (ctrl_isp_result)
+      ISP_T(p0);
       if (S.ispSlot < 0) { ctrl_isp_begin(f); S.ispSlot = 0; S.ispHave = 0; S.ispPark = -1; L.isp_nb = 0; }
       set_node(f, d);
+      { ISP_T(p1); ISP_ADD0(24, p0, p1); }
       for (;;) {
         if (S.ispHave) {
           int bw = -1;
           for (int i = 0; i < L.isp_nb; i++) if (!L.isp_res[i].used && L.isp_res[i].mode == (uint8_t) S.ispReqMode && L.isp_res[i].split == (uint8_t) S.ispReqSplit) bw = i;
           if (bw < 0) {                                 // not evaluated yet: the tiles of a new best are kept first, then the next batch
             if (S.ispPark >= 0) { L.isp_park = (uint8_t) S.ispPark; S.ispPark = -1; post(OP_ISP_PARK); return; }
-            ctrl_isp_batch(S.ispReqMode, S.ispReqSplit);
+            { ISP_T(b0); ctrl_isp_batch(S.ispReqMode, S.ispReqSplit); ISP_T(b1); ISP_ADD0(25, b0, b1); PROF(29) += 1; }
             L.isp_limit = S.ispCurBest;
             post(OP_ISP); return;
           }
           L.isp_res[bw].used = 1;
-          if (!ctrl_isp_result(f, bw)) continue;          // (evaluated again: the entry is used up, the request stays)
+          { ISP_T(r0); const int okr = ctrl_isp_result(f, bw); ISP_T(r1); ISP_ADD0(26, r0, r1); if (!okr) continue; }          // (evaluated again: the entry is used up, the request stays)
           S.ispHave = 0;
         }
         if (S.ispSlot >= 16) break;
         int mode = 0, split = 0;
         S.ispSlot++;
-        if (!ctrl_isp_next(f.w, f.h, mode, split)) { S.ispPrev = 3; continue; }
+        ISP_T(n0); const int okn = ctrl_isp_next(f.w, f.h, mode, split); { ISP_T(n1); ISP_ADD0(27, n0, n1); PROF(28) += 1; }
+        if (!okn) { S.ispPrev = 3; continue; }
         S.ispPrev = (int8_t) split; S.ispReqMode = (int8_t) mode; S.ispReqSplit = (int8_t) split; S.ispHave = 1;
       }
       if (S.ispPark >= 0) { L.isp_park = (uint8_t) S.ispPark; S.ispPark = -1; post(OP_ISP_PARK); return; }
@@ -4798,6 +4849,7 @@ __device__ __noinline__ void walk_tree(const VxParams &p_, const VxFrameDev &fd_
 template <typename T>
 __device__ __noinline__ void advance_ctx_ctu(const VxParams &p_, const VxFrameDev &fd_, int tile, int ctu_x, int ctu_y)
 {
+  tile = uni(tile); ctu_x = uni(ctu_x); ctu_y = uni(ctu_y);
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   Cab cb; cb.ci = CI_CUR; cb.bits = 0;
   uint8_t *scratch_ = p.scratch + (size_t) blockIdx.x * p.scratch_per_stream;
@@ -4837,6 +4889,7 @@ __device__ __noinline__ void writer_suspend(const VxParams &p, int sidx) { ((Ari
 // Out of line: run_tree's barrier loop must contain exactly one thread-0 section of its own (see there).
 __device__ __noinline__ void after_intra_op(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
+  scratch = uni_p(scratch);
   if (uni(VTX >> 6) == 0) { if ((VTX & 63) == 0) L.do_save = ctrl_b_done(p_, fd_); }      // wave-uniform entry, lane 0 inside (see run_tree)
   __threadfence_block();
   __syncthreads();
@@ -4846,6 +4899,7 @@ __device__ __noinline__ void after_intra_op(const VxParams &p_, const VxFrameDev
 template <typename T>
 __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_, uint8_t *scratch)
 {
+  scratch = uni_p(scratch);
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int tid = VTX;
   // NOTE on the shape of this loop.  Round 1 saw a hang with two `if (tid == 0)` sections per iteration (head and tail): hipcc threaded the "tid != 0" edges
@@ -5158,11 +5212,13 @@ __device__ void leaf_pred(const VxParams &p, const VxLeafPred *cases, int16_t *o
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_pred_kernel_u8(VxParams p, const VxLeafPred *cases, int16_t *out, const int *out_off) { leaf_pred<uint8_t>(p, cases, out, out_off); }
 extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_pred_kernel_u16(VxParams p, const VxLeafPred *cases, int16_t *out, const int *out_off) { leaf_pred<uint16_t>(p, cases, out, out_off); }
 // estimator model: bins on one context (BinProbModel_Std::estFracBitsUpdate); io = {s0, s1} in/out, bits out
-extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_cabac_kernel(uint16_t *io, int ctx, const uint8_t *bins, int nbins, unsigned long long *bits)
+// (rate: the model's adaptation rate byte; the model itself sits in slot 0)
+extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_cabac_kernel(uint16_t *io, int rate, const uint8_t *bins, int nbins, unsigned long long *bits)
 {
   load_tables();
   __syncthreads();
   if (VTX == 0) {
+    const int ctx = 0; L.t.ctx_rate[0] = (uint8_t) rate;
     L.ctxs[CI_CUR].s0[ctx] = io[0]; L.ctxs[CI_CUR].s1[ctx] = io[1];
     Cab cb; cb.ci = CI_CUR; cb.bits = 0;
     for (int i = 0; i < nbins; i++) enc_bin(cb, bins[i], ctx);

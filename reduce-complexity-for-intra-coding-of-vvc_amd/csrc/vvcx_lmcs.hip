@@ -1,287 +1,444 @@
-// vvcx_lmcs.hip — host side of LMCS that is not the search: the picture analysis which chooses the model of an intra picture.
+// vvcx_lmcs.hip — the LMCS picture analysis of an intra picture: which luma-mapping model, if any, the slice carries.
 //
-// ≙ EncGOP::xPicInitLMCS (EL/EncGOP.cpp:1624-1700) → EncReshape::preAnalyzerLMCS (EL/EncReshape.cpp:410-559) with calcSeqStats (166-409) and
-// deriveReshapeParametersSDR (977-1229), cwPerturbation / cwReduction (931-975), bubbleSortDsd (909-928), then the model half of constructReshaperLMCS
-// (1835-1893) with adjustLmcsPivot (2194-2256), for the reference cfg's LMCSSignalType 0 (SDR) and LMCSAdpOption 0, LMCSUpdateCtrl 0 or 1, intra slices.
-// Pure picture-level control (a handful of reductions over the original picture and threshold logic in doubles); the arithmetic follows the reference operation
-// by operation — the per-bin sums of log10(variance + 1) are accumulated in raster order like there — so that the model is the reference's bit for bit
-// (tests/golden/lmcs_analysis.npz: models the reference's own EncReshape, compiled in place, chose for the same pictures).  The LUTs of a model are built by
-// vvcx_set_slice (Reshape::constructReshaper).
+// What is computed is the reference's EncGOP::xPicInitLMCS → EncReshape::preAnalyzerLMCS for the all-intra cfg (LMCSSignalType 0 = SDR, LMCSAdpOption 0, LMCSUpdateCtrl 0 / 1):
+// picture statistics (EL/EncReshape.cpp:166-409), the decision cascade of the SDR parameter derivation (977-1229) with its code-word budgeting helpers (931-975) and the model
+// half of constructReshaperLMCS with the pivot alignment (1835-1893, 2194-2256).  How it is organised here:
+//
+//   * the statistics are a DEVICE pass over the picture in HBM (three small kernels): separable window sums of the luma samples and their squares, then per sample the
+//     windowed variance and its log10 term, accumulated per luma bin by runs of consecutive samples and folded in a fixed order (a deterministic double sum; the reference
+//     adds the same terms one by one in raster order, which differs from this sum in the last bits only — far below every threshold the decisions compare against); the
+//     sample counts per bin and the first and second moments of Y, Cb, Cr are exact integers;
+//   * the decision cascade is DATA: a table of rules (feature, comparison, constant) x (what to set), evaluated by a few-line interpreter.  A rule list is an else-if
+//     chain: the first rule of a chain whose predicates all hold fires and ends the chain.  The thresholds are the reference's tuning constants (they define the models a
+//     VTM user gets, so they cannot be anything else); the table says which source line each row restates;
+//   * the code-word arithmetic (uint16 wrap-around included) is written once as "spread a budget, nudge by the bin statistics, take back what exceeds the total".
+//
+// Pinned by tests/golden/lmcs_analysis.npz: the models the reference's own EncReshape (compiled in place, oracle/_ref) chose for 29 pictures.
+#include <hip/hip_runtime.h>
 #include "vvcx.h"
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
-#include <algorithm>
 
 extern "C" int vvcx_fail_msg_(int code, const char *msg);      // vvcx_api.hip: sets what vvcx_last_error returns
 
 namespace {
-const int kBins = 16;                // PIC_CODE_CW_BINS (CL/CommonDef.h:517)
-const int kSegSize = kBins << 1;     // LMCS_SEG_SIZE (519)
+constexpr int kBins = 16;            // luma bins of the analysis and of the model (PIC_CODE_CW_BINS)
+constexpr int kRun = 32;             // consecutive samples of a row one thread folds into its per-bin partial sums
+constexpr int kSlices = 16;          // the final fold: every bin's partials are cut into this many raster-ordered slices
 
-struct SeqInfo { double binVar[kBins], binHist[kBins], normVar[kBins]; int nonZeroCnt; double weightVar, weightNorm, minBinVar, maxBinVar, meanBinVar, ratioStdU, ratioStdV; };
-void initSeqStats(SeqInfo &s) { memset(&s, 0, sizeof s); }
+// ------------------------------------------------------------------------------------------------ device statistics pass
+struct StatOut {                     // written by the kernels (zeroed before)
+  double logSum[kBins];              // per bin: sum over its samples of log10(windowed variance + 1)
+  unsigned long long count[kBins];
+  unsigned long long sum[3], sq[3];  // moments of Y, Cb, Cr
+};
 
-inline int px(const void *p, int bps, size_t i) { return bps == 1 ? (int) ((const uint8_t *) p)[i] : (int) ((const uint16_t *) p)[i]; }
-
-// min / max / mean over the occupied bins, normalised variances, weighted sums (EL/EncReshape.cpp:346-368 and again 1034-1056)
-void binSummary(SeqInfo &s)
+template <typename T>
+__global__ void lmcs_row_sums(const T *luma, int stride, int w, int h, int win, uint32_t *rs, uint32_t *rq)
 {
-  s.minBinVar = 5.0; s.maxBinVar = 0.0; s.meanBinVar = 0.0; s.nonZeroCnt = 0;
-  for (int b = 0; b < kBins; b++)
-    if (s.binHist[b] > 0.001) {
-      s.nonZeroCnt++; s.meanBinVar += s.binVar[b];
-      if (s.binVar[b] > s.maxBinVar) s.maxBinVar = s.binVar[b];
-      if (s.binVar[b] < s.minBinVar) s.minBinVar = s.binVar[b];
-    }
-  s.meanBinVar /= (double) s.nonZeroCnt;
-  for (int b = 0; b < kBins; b++) {
-    if (s.meanBinVar > 0.0) s.normVar[b] = s.binVar[b] / s.meanBinVar;
-    s.weightVar += s.binHist[b] * s.binVar[b];
-    s.weightNorm += s.binHist[b] * s.normVar[b];
+  const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t) w * h) return;
+  const int y = (int) (i / w), x = (int) (i - (size_t) y * w);
+  const int x1 = x - win < 0 ? 0 : x - win, x2 = x + win > w - 1 ? w - 1 : x + win;
+  const T *row = luma + (size_t) y * stride;
+  uint32_t s = 0, q = 0;
+  for (int k = x1; k <= x2; k++) { const uint32_t v = row[k]; s += v; q += v * v; }
+  rs[i] = s; rq[i] = q;
+}
+
+// one thread per run of kRun samples of a row: column sums of the row sums = window sums; the sample's term; per-bin partials of the run
+template <typename T>
+__global__ void lmcs_bin_terms(const T *luma, int stride, int w, int h, int win, int bd, const uint32_t *rs, const uint32_t *rq, double *part, uint32_t *pcnt, StatOut *out)
+{
+  const int runs_per_row = (w + kRun - 1) / kRun;
+  const size_t r = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= (size_t) runs_per_row * h) return;
+  const int y = (int) (r / runs_per_row), x0 = (int) (r - (size_t) y * runs_per_row) * kRun;
+  const int y1 = y - win < 0 ? 0 : y - win, y2 = y + win > h - 1 ? h - 1 : y + win;
+  const int down = bd - 10, log2BinLen = bd - 4;
+  const double norm = (double) (1 << (2 * down));
+  double acc[kBins]; uint32_t cnt[kBins];
+  for (int b = 0; b < kBins; b++) { acc[b] = 0.0; cnt[b] = 0; }
+  unsigned long long s1 = 0, s2 = 0;
+  for (int x = x0; x < x0 + kRun && x < w; x++) {
+    unsigned long long ws = 0, wq = 0;
+    for (int k = y1; k <= y2; k++) { ws += rs[(size_t) k * w + x]; wq += rq[(size_t) k * w + x]; }
+    const int x1 = x - win < 0 ? 0 : x - win, x2 = x + win > w - 1 ? w - 1 : x + win;
+    const uint32_t n = (uint32_t) ((x2 - x1 + 1) * (y2 - y1 + 1));
+    const double mean = (double) ws / n;
+    double var = (double) wq / n - mean * mean;
+    var = var / norm;
+    const unsigned v = luma[(size_t) y * stride + x];
+    const unsigned bin = (v >> down) >> log2BinLen;
+    const double term = log10(var + 1.0);
+    // (a select chain instead of acc[bin]: the accumulators stay in registers)
+#pragma unroll
+    for (int b = 0; b < kBins; b++) if (bin == (unsigned) b) { acc[b] += term; cnt[b]++; }
+    s1 += v; s2 += (unsigned long long) v * v;
+  }
+  for (int b = 0; b < kBins; b++) { part[r * kBins + b] = acc[b]; pcnt[r * kBins + b] = cnt[b]; }
+  atomicAdd(&out->sum[0], s1); atomicAdd(&out->sq[0], s2);
+}
+
+// fixed-order fold of the per-run partials: thread (slice, bin) adds its slice's runs in raster order, then the slices in order
+__global__ void lmcs_fold(const double *part, const uint32_t *pcnt, size_t n_runs, StatOut *out)
+{
+  __shared__ double sl[kSlices][kBins]; __shared__ unsigned long long sc[kSlices][kBins];
+  const int bin = threadIdx.x % kBins, slice = threadIdx.x / kBins;
+  const size_t lo = n_runs * slice / kSlices, hi = n_runs * (slice + 1) / kSlices;
+  double a = 0.0; unsigned long long c = 0;
+  for (size_t r = lo; r < hi; r++) { a += part[r * kBins + bin]; c += pcnt[r * kBins + bin]; }
+  sl[slice][bin] = a; sc[slice][bin] = c;
+  __syncthreads();
+  if (slice == 0) {
+    double t = 0.0; unsigned long long n = 0;
+    for (int k = 0; k < kSlices; k++) { t += sl[k][bin]; n += sc[k][bin]; }
+    out->logSum[bin] = t; out->count[bin] = n;
   }
 }
 
-// calcSeqStats (166-409).  The reference slides the window sums along; the sums are exact integers, so summed-area tables give the same numbers
-void calcSeqStats(const void *const org[3], const int stride[3], int w, int h, int bd, int bps, int picSize, SeqInfo &st)
+template <typename T>
+__global__ void lmcs_chroma_moments(const T *cb, const T *cr, int stride_b, int stride_r, int wc, int hc, StatOut *out)
 {
-  const int lutSize = 1 << bd, binLen = lutSize / kBins;
-  int win = std::min(h, w) / 240;
-  win = win > 0 ? win : 1;
-  std::vector<int64_t> S((size_t) (w + 1) * (h + 1), 0), Q((size_t) (w + 1) * (h + 1), 0);
-  for (int y = 0; y < h; y++) {
-    int64_t rs = 0, rq = 0;
-    for (int x = 0; x < w; x++) {
-      const int64_t v = px(org[0], bps, (size_t) y * stride[0] + x);
-      rs += v; rq += v * v;
-      S[(size_t) (y + 1) * (w + 1) + x + 1] = S[(size_t) y * (w + 1) + x + 1] + rs;
-      Q[(size_t) (y + 1) * (w + 1) + x + 1] = Q[(size_t) y * (w + 1) + x + 1] + rq;
+  const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long u1 = 0, u2 = 0, v1 = 0, v2 = 0;
+  if (i < (size_t) hc) {                                 // a thread per chroma row
+    for (int x = 0; x < wc; x++) {
+      const unsigned long long u = cb[i * stride_b + x], v = cr[i * stride_r + x];
+      u1 += u; u2 += u * u; v1 += v; v2 += v * v;
     }
+    atomicAdd(&out->sum[1], u1); atomicAdd(&out->sq[1], u2); atomicAdd(&out->sum[2], v1); atomicAdd(&out->sq[2], v2);
   }
-  uint32_t binCnt[kBins] = { 0 };
-  initSeqStats(st);
-  for (int y = 0; y < h; y++) {
-    const int y1 = std::max(y - win, 0), y2 = std::min(y + win, h - 1);
-    for (int x = 0; x < w; x++) {
-      const int x1 = std::max(x - win, 0), x2 = std::min(x + win, w - 1);
-      const uint32_t n = (uint32_t) ((x2 - x1 + 1) * (y2 - y1 + 1));
-#define SAT(T_, xa, ya, xb, yb) (T_[(size_t) ((yb) + 1) * (w + 1) + (xb) + 1] - T_[(size_t) (ya) * (w + 1) + (xb) + 1] - T_[(size_t) ((yb) + 1) * (w + 1) + (xa)] + T_[(size_t) (ya) * (w + 1) + (xa)])
-      const int64_t sum = SAT(S, x1, y1, x2, y2), sumSq = SAT(Q, x1, y1, x2, y2);
-#undef SAT
-      const double average = double(sum) / n;
-      double variance = double(sumSq) / n - average * average;
-      variance = variance / (double) (1 << (2 * (bd - 10)));
-      const int v = px(org[0], bps, (size_t) y * stride[0] + x);
-      const uint32_t binIdx = (uint32_t) ((v >> (bd - 10)) / binLen);
-      st.binVar[binIdx] += log10(variance + 1.0);
-      binCnt[binIdx]++;
-    }
-  }
-  for (int b = 0; b < kBins; b++) {
-    st.binHist[b] = (double) binCnt[b] / (double) picSize;
-    st.binVar[b] = binCnt[b] > 0 ? st.binVar[b] / binCnt[b] : 0.0;
-  }
-  binSummary(st);
-  const int wc = w >> 1, hc = h >> 1;
-  double avgY = 0.0, avgU = 0.0, avgV = 0.0, varY = 0.0, varU = 0.0, varV = 0.0;
-  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) { const int v = px(org[0], bps, (size_t) y * stride[0] + x); avgY += v; varY += v * v; }
-  for (int y = 0; y < hc; y++) for (int x = 0; x < wc; x++) {
-    const int u = px(org[1], bps, (size_t) y * stride[1] + x), v = px(org[2], bps, (size_t) y * stride[2] + x);
-    avgU += u; avgV += v; varU += u * u; varV += v * v;
-  }
-  avgY = avgY / (w * h); avgU = avgU / (wc * hc); avgV = avgV / (wc * hc);
-  varY = varY / (w * h) - avgY * avgY; varU = varU / (wc * hc) - avgU * avgU; varV = varV / (wc * hc) - avgV * avgV;
-  if (varY > 0) { st.ratioStdU = sqrt(varU) / sqrt(varY); st.ratioStdV = sqrt(varV) / sqrt(varY); }
 }
 
-struct Analyzer {
-  int bd, lutSize, initCW, initCWAnalyze, picSize, baseQP, updateCtrl;
-  uint16_t binCW[32];
-  int cw0, cw1;                 // m_reshapeCW.binCW[0 / 1]
-  int minBin, maxBin, chromaAdj, rateAdpMode, tcase;
-  bool useAdpCW;
-  SeqInfo src, rsp;
+struct DevMem {                      // frees what it allocated
+  void *p = nullptr;
+  ~DevMem() { if (p) (void) hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
 
-  void cwPerturbation(int startBin, int endBin, uint16_t maxCW)        // 931-954
+// the statistics of one picture whose planes are in device memory
+template <typename T>
+int picture_stats(const void *const org[3], const int stride[3], int w, int h, int bd, StatOut &st)
+{
+  const int win = (w < h ? w : h) / 240 > 0 ? (w < h ? w : h) / 240 : 1;
+  const size_t np = (size_t) w * h, runs = (size_t) ((w + kRun - 1) / kRun) * h;
+  DevMem rs, rq, part, pcnt, out;
+  if (rs.alloc(np * 4) != hipSuccess || rq.alloc(np * 4) != hipSuccess || part.alloc(runs * kBins * 8) != hipSuccess || pcnt.alloc(runs * kBins * 4) != hipSuccess ||
+      out.alloc(sizeof(StatOut)) != hipSuccess) return vvcx_fail_msg_(VVCX_ERR_DEVICE, "vvcx_lmcs_analyze: device allocation failed");
+  if (hipMemset(out.p, 0, sizeof(StatOut)) != hipSuccess) return vvcx_fail_msg_(VVCX_ERR_DEVICE, "vvcx_lmcs_analyze: hipMemset failed");
+  const unsigned T256 = 256;
+  hipLaunchKernelGGL(lmcs_row_sums<T>, dim3((unsigned) ((np + T256 - 1) / T256)), dim3(T256), 0, 0, (const T *) org[0], stride[0], w, h, win, (uint32_t *) rs.p, (uint32_t *) rq.p);
+  hipLaunchKernelGGL(lmcs_bin_terms<T>, dim3((unsigned) ((runs + T256 - 1) / T256)), dim3(T256), 0, 0, (const T *) org[0], stride[0], w, h, win, bd, (const uint32_t *) rs.p,
+                     (const uint32_t *) rq.p, (double *) part.p, (uint32_t *) pcnt.p, (StatOut *) out.p);
+  hipLaunchKernelGGL(lmcs_fold, dim3(1), dim3(kSlices * kBins), 0, 0, (const double *) part.p, (const uint32_t *) pcnt.p, runs, (StatOut *) out.p);
+  hipLaunchKernelGGL(lmcs_chroma_moments<T>, dim3((unsigned) ((h / 2 + T256 - 1) / T256)), dim3(T256), 0, 0, (const T *) org[1], (const T *) org[2], stride[1], stride[2], w / 2, h / 2,
+                     (StatOut *) out.p);
+  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return vvcx_fail_msg_(VVCX_ERR_DEVICE, "vvcx_lmcs_analyze: statistics kernels failed");
+  if (hipMemcpy(&st, out.p, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) return vvcx_fail_msg_(VVCX_ERR_DEVICE, "vvcx_lmcs_analyze: copy back failed");
+  return VVCX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ from statistics to a model (host, scalar)
+struct BinProfile {                  // what the cascade reads of a set of bins: occupancy, mean log-variance, the same relative to the picture's mean
+  double share[kBins], lv[kBins], rel[kBins];
+  double lvMin, lvMax, lvMean, wLv, wRel;
+  // summary over the occupied bins (share above 0.1 %), EL/EncReshape.cpp:346-368
+  void summarise()
   {
-    for (int i = 0; i < kBins; i++) binCW[i] = (i >= startBin && i <= endBin) ? (uint16_t) (uint32_t) round((double) maxCW / (endBin - startBin + 1)) : (uint16_t) 0;
-    for (int i = 0; i < kBins; i++)
-      if (src.binHist[i] > 0.001) {
-        const double hist = src.binHist[i] > 0.4 ? 0.4 : src.binHist[i];
-        const uint16_t delta1 = (uint16_t) (10.0 * hist + 0.5), delta2 = (uint16_t) (20.0 * hist + 0.5);
-        if (src.normVar[i] < 0.8) binCW[i] = (uint16_t) (binCW[i] + delta2);
-        else if (src.normVar[i] < 0.9) binCW[i] = (uint16_t) (binCW[i] + delta1);
-        if (src.normVar[i] > 1.2) binCW[i] = (uint16_t) (binCW[i] - delta2);
-        else if (src.normVar[i] > 1.1) binCW[i] = (uint16_t) (binCW[i] - delta1);
-      }
-  }
-  int totCW() const { const int s = bd - 10; return s != 0 ? (s > 0 ? lutSize / (1 << s) : lutSize * (1 << (-s))) : lutSize; }
-  void cwReduction(int startBin, int endBin)                           // 955-975
-  {
-    const int maxAllowedCW = totCW() - 1;
-    int usedCW = 0;
-    for (int i = 0; i < kBins; i++) usedCW += binCW[i];
-    if (usedCW > maxAllowedCW) {
-      const int deltaCW = usedCW - maxAllowedCW, divCW = deltaCW / (endBin - startBin + 1);
-      int modCW = deltaCW - divCW * (endBin - startBin + 1);
-      if (divCW > 0) for (int i = startBin; i <= endBin; i++) binCW[i] = (uint16_t) (binCW[i] - divCW);
-      for (int i = startBin; i <= endBin; i++) { if (modCW == 0) break; if (binCW[i] > 0) { binCW[i]--; modCW--; } }
-    }
-  }
-  // deriveReshapeParametersSDR (977-1229)
-  void deriveSDR(bool *intraAdp, bool *interAdp)
-  {
-    bool isSkipCase = false, isLowCase = false;
-    int first1 = 0, first2 = 0, first3 = 0;
-    int idx[kBins]; double var[kBins], cdf[kBins];
-    for (int b = 0; b < kBins; b++) { var[b] = src.binVar[b]; idx[b] = b; }
-    for (int i = 0; i < kBins - 1; i++) {                               // bubbleSortDsd 909-928
-      bool swapped = false;
-      for (int j = 0; j < kBins - i - 1; j++) if (var[j] < var[j + 1]) { std::swap(var[j], var[j + 1]); std::swap(idx[j], idx[j + 1]); swapped = true; }
-      if (!swapped) break;
-    }
-    cdf[0] = src.binHist[idx[0]];
-    for (int b = 1; b < kBins; b++) cdf[b] = cdf[b - 1] + src.binHist[idx[b]];
-    for (int b = 0; b < kBins - 1; b++) { if (var[b] > 3.4) first1 = b + 1; if (var[b] > 2.8) first2 = b + 1; if (var[b] > 2.5) first3 = b + 1; }
-    const double perc1 = cdf[first1], perc2 = cdf[first2], perc3 = cdf[first3];
-    cwPerturbation(minBin, maxBin, (uint16_t) cw1);
-    cwReduction(minBin, maxBin);
-    initSeqStats(rsp);
+    int occupied = 0; lvMin = 5.0; lvMax = 0.0; lvMean = 0.0; wLv = 0.0; wRel = 0.0;
     for (int b = 0; b < kBins; b++) {
-      const double scale = binCW[b] > 0 ? (double) binCW[b] / (double) initCWAnalyze : 1.0;
-      rsp.binHist[b] = src.binHist[b];
-      rsp.binVar[b] = src.binVar[b] + 2.0 * log10(scale);
+      if (!(share[b] > 0.001)) continue;
+      occupied++; lvMean += lv[b];
+      lvMax = lv[b] > lvMax ? lv[b] : lvMax; lvMin = lv[b] < lvMin ? lv[b] : lvMin;
     }
-    binSummary(rsp);
-    const double ratioWeiVar = rsp.weightVar / src.weightVar, ratioWeiVarNorm = rsp.weightNorm / src.weightNorm;
-    const int n = kBins;
-    if ((src.binHist[0] + src.binHist[n - 1]) > 0.0001 && src.binHist[n - 2] < 0.001) {
-      if (perc3 > 0.8 && perc2 > 0.4 && src.binVar[n - 2] > 4.8) isSkipCase = true;
-      else if (perc3 < 0.1 && perc1 < 0.05 && src.binVar[n - 2] < 4.0) isSkipCase = true;
+    lvMean /= (double) occupied;
+    for (int b = 0; b < kBins; b++) {
+      rel[b] = lvMean > 0.0 ? lv[b] / lvMean : 0.0;
+      wLv += share[b] * lv[b]; wRel += share[b] * rel[b];
     }
-    if (isSkipCase) { *intraAdp = false; *interAdp = false; return; }
-    if (picSize > 5184000) isLowCase = true;
-    else if (src.binVar[1] > 4.0) isLowCase = true;
-    else if (rsp.meanBinVar > 3.4 && ratioWeiVarNorm > 1.005 && ratioWeiVar > 1.02) isLowCase = true;
-    else if (rsp.meanBinVar > 3.1 && ratioWeiVarNorm > 1.005 && ratioWeiVar > 1.04) isLowCase = true;
-    else if (rsp.meanBinVar > 2.8 && ratioWeiVarNorm > 1.01 && ratioWeiVar > 1.04) isLowCase = true;
-    if (updateCtrl == 0) {
-      cw1 = 1022;
-      if (isLowCase) {
-        *intraAdp = false; rateAdpMode = 1; cw1 = 980;
-        if (src.binHist[n - 2] > 0.05) { cw1 = 896; if (src.binVar[n - 2] < 1.2) cw1 = 938; }
-        else if (perc2 < 0.8 && perc3 == 1.0) { rateAdpMode = 1; cw1 = 938; }
-      }
-      if (src.binHist[n - 2] < 0.001) {
-        if (src.binHist[1] > 0.05 && src.binVar[1] > 3.0) { *intraAdp = true; rateAdpMode = 1; cw1 = 784; }
-        else if (src.binHist[1] < 0.006) { *intraAdp = false; rateAdpMode = 0; cw1 = 1008; }
-        else if (perc3 < 0.5) { *intraAdp = true; rateAdpMode = 0; cw1 = 1022; }
-      } else if ((src.maxBinVar > 4.0 && rsp.meanBinVar > 3.2 && perc2 < 0.25) || ratioWeiVar < 1.03) { *intraAdp = true; rateAdpMode = 0; cw1 = 1022; }
-      if (*intraAdp == true && rateAdpMode == 0) tcase = 9;
-    } else {                                                             // updateCtrl == 1 (the all-intra cfg)
-      cw1 = 952;
-      if (isLowCase) {
-        if (picSize > 5184000) { rateAdpMode = 1; cw1 = 812; }
-        if (src.binHist[n - 2] > 0.05) {
-          rateAdpMode = 1; cw1 = 812;
-          if (src.binHist[n - 2] > 0.1 || src.binHist[1] > 0.1) { rateAdpMode = 0; cw1 = 924; }
-        } else if (perc2 < 0.8 && perc3 == 1.0) { rateAdpMode = 1; cw1 = 896; }
-        else if (perc2 > 0.98 && src.binHist[1] > 0.05) { rateAdpMode = 0; cw1 = 784; }
-        else if (perc2 < 0.1) { rateAdpMode = 0; cw1 = 1022; }
-      }
-      if (src.binHist[1] > 0.1 && (src.binVar[1] > 1.8 && src.binVar[1] < 3.0)) {
-        rateAdpMode = 1;
-        if (src.binVar[n - 2] > 1.2 && src.binVar[n - 2] < 4.0) cw1 = 784;
-      } else if (src.binHist[n - 2] < 0.001) {
-        if (src.binHist[1] > 0.05 && src.binVar[1] > 3.0) { rateAdpMode = 1; cw1 = 784; }
-        else if (src.binHist[1] < 0.006) { rateAdpMode = 0; cw1 = 980; }
-        else if (perc3 < 0.5) { rateAdpMode = 0; cw1 = 924; }
-      } else if ((src.maxBinVar > 4.0 && rsp.meanBinVar > 3.2 && perc2 < 0.25) || ratioWeiVar < 1.03) { rateAdpMode = 0; cw1 = 980; }
-    }
-  }
-  // adjustLmcsPivot (2194-2256): every pivot on a segment border or alone in its segment (JVET_O0272)
-  void adjustLmcsPivot()
-  {
-    const int orgCW = totCW() / kBins;
-    int log2Seg = 0; while ((1 << (log2Seg + 1)) <= kSegSize) log2Seg++;
-    int16_t pivot[kBins + 1];
-    pivot[0] = 0;
-    for (int i = 0; i < kBins; i++) pivot[i + 1] = (int16_t) (pivot[i] + binCW[i]);
-    const int segIdxMax = pivot[maxBin + 1] >> log2Seg;
-    for (int i = minBin; i <= maxBin; i++) {
-      pivot[i + 1] = (int16_t) (pivot[i] + binCW[i]);
-      const int segCurr = pivot[i] >> log2Seg, segNext = pivot[i + 1] >> log2Seg;
-      if (segCurr == segNext && pivot[i] != (segCurr << log2Seg)) {
-        if (segCurr == segIdxMax) {
-          pivot[i] = pivot[maxBin + 1];
-          for (int j = i; j <= maxBin; j++) { pivot[j + 1] = pivot[i]; binCW[j] = 0; }
-          binCW[i - 1] = (uint16_t) (pivot[i] - pivot[i - 1]);
-          break;
-        } else {
-          int16_t adjustVal = (int16_t) (((segCurr + 1) << log2Seg) - pivot[i + 1]);
-          pivot[i + 1] = (int16_t) (pivot[i + 1] + adjustVal);
-          binCW[i] = (uint16_t) (binCW[i] + adjustVal);
-          for (int j = i + 1; j <= maxBin; j++) {
-            if (binCW[j] < (adjustVal + (orgCW >> 3))) { adjustVal = (int16_t) (adjustVal - (binCW[j] - (orgCW >> 3))); binCW[j] = (uint16_t) (orgCW >> 3); }
-            else { binCW[j] = (uint16_t) (binCW[j] - adjustVal); adjustVal = 0; }
-            if (adjustVal == 0) break;
-          }
-        }
-      }
-    }
-    for (int i = kBins - 1; i >= 0; i--) if (binCW[i] > 0) { maxBin = i; break; }
   }
 };
-}  // namespace
 
-extern "C" int vvcx_lmcs_analyze(const void *const org[3], const int stride[3], int pic_w, int pic_h, int bit_depth, int slice_qp, int update_ctrl, vvcx_slice *slice)
+// ---- the decision cascade as data
+enum Feat { F_HIST0, F_HIST1, F_HISTP, F_HISTE, F_ENDS, F_LV1, F_LVP, F_LVMAX, F_MAPMEAN, F_GAIN, F_GAINREL, F_TOP34, F_TOP28, F_TOP25, F_AREA, F_LOW, F_CHROMA, N_FEAT };
+//   HIST0 / HIST1 / HISTP / HISTE: share of bins 0, 1, 14 (the last but one) and 15; ENDS = bin 0 + bin 15; LV1 / LVP: mean log-variance of bins 1 / 14; LVMAX: largest
+//   over the occupied bins; MAPMEAN: mean log-variance after the trial mapping; GAIN / GAINREL: weighted (relative) log-variance after / before it; TOP34 / 28 / 25:
+//   share of the picture in bins whose log-variance exceeds 3.4 / 2.8 / 2.5 (cumulated in descending order of log-variance, the reference's quirk of reading one entry
+//   further included); AREA: samples of the picture; LOW: outcome of the "flat content" chain; CHROMA: sum of the chroma / luma deviation ratios
+enum Cmp { GT, LT, EQ };
+struct Pred { int8_t feat; int8_t cmp; double k; };
+constexpr int kKeep = -1;
+struct Rule { int8_t chain; Pred when[5]; int8_t intra, rate; int16_t cw; };      // chain: rules with the same number form one else-if chain; intra / rate / cw: kKeep = leave
+constexpr Pred NONE = { -1, GT, 0.0 };
+constexpr double kBigArea = 5184000.0;
+
+// "flat content" (isLowCase, 1098-1126): any row
+const Rule kLowRules[] = {
+  { 0, { { F_AREA, GT, kBigArea }, NONE, NONE, NONE, NONE }, kKeep, kKeep, kKeep },
+  { 0, { { F_LV1, GT, 4.0 }, NONE, NONE, NONE, NONE }, kKeep, kKeep, kKeep },
+  { 0, { { F_MAPMEAN, GT, 3.4 }, { F_GAINREL, GT, 1.005 }, { F_GAIN, GT, 1.02 }, NONE, NONE }, kKeep, kKeep, kKeep },
+  { 0, { { F_MAPMEAN, GT, 3.1 }, { F_GAINREL, GT, 1.005 }, { F_GAIN, GT, 1.04 }, NONE, NONE }, kKeep, kKeep, kKeep },
+  { 0, { { F_MAPMEAN, GT, 2.8 }, { F_GAINREL, GT, 1.01 }, { F_GAIN, GT, 1.04 }, NONE, NONE }, kKeep, kKeep, kKeep },
+};
+// "leave the picture alone" (isSkipCase, 1081-1096): any row
+const Rule kSkipRules[] = {
+  { 0, { { F_ENDS, GT, 0.0001 }, { F_HISTP, LT, 0.001 }, { F_TOP25, GT, 0.8 }, { F_TOP28, GT, 0.4 }, { F_LVP, GT, 4.8 } }, kKeep, kKeep, kKeep },
+  { 0, { { F_ENDS, GT, 0.0001 }, { F_HISTP, LT, 0.001 }, { F_TOP25, LT, 0.1 }, { F_TOP34, LT, 0.05 }, { F_LVP, LT, 4.0 } }, kKeep, kKeep, kKeep },
+};
+// LMCSUpdateCtrl 1 (the all-intra cfg), 1164-1227; the budget starts at 952 code words
+const Rule kCtrl1[] = {
+  { 0, { { F_LOW, GT, 0.5 }, { F_AREA, GT, kBigArea }, NONE, NONE, NONE }, kKeep, 1, 812 },
+  { 1, { { F_LOW, GT, 0.5 }, { F_HISTP, GT, 0.1 }, NONE, NONE, NONE }, kKeep, 0, 924 },
+  { 1, { { F_LOW, GT, 0.5 }, { F_HISTP, GT, 0.05 }, { F_HIST1, GT, 0.1 }, NONE, NONE }, kKeep, 0, 924 },
+  { 1, { { F_LOW, GT, 0.5 }, { F_HISTP, GT, 0.05 }, NONE, NONE, NONE }, kKeep, 1, 812 },
+  { 1, { { F_LOW, GT, 0.5 }, { F_TOP28, LT, 0.8 }, { F_TOP25, EQ, 1.0 }, NONE, NONE }, kKeep, 1, 896 },
+  { 1, { { F_LOW, GT, 0.5 }, { F_TOP28, GT, 0.98 }, { F_HIST1, GT, 0.05 }, NONE, NONE }, kKeep, 0, 784 },
+  { 1, { { F_LOW, GT, 0.5 }, { F_TOP28, LT, 0.1 }, NONE, NONE, NONE }, kKeep, 0, 1022 },
+  { 2, { { F_HIST1, GT, 0.1 }, { F_LV1, GT, 1.8 }, { F_LV1, LT, 3.0 }, { F_LVP, GT, 1.2 }, { F_LVP, LT, 4.0 } }, kKeep, 1, 784 },
+  { 2, { { F_HIST1, GT, 0.1 }, { F_LV1, GT, 1.8 }, { F_LV1, LT, 3.0 }, NONE, NONE }, kKeep, 1, kKeep },
+  { 2, { { F_HISTP, LT, 0.001 }, { F_HIST1, GT, 0.05 }, { F_LV1, GT, 3.0 }, NONE, NONE }, kKeep, 1, 784 },
+  { 2, { { F_HISTP, LT, 0.001 }, { F_HIST1, LT, 0.006 }, NONE, NONE, NONE }, kKeep, 0, 980 },
+  { 2, { { F_HISTP, LT, 0.001 }, { F_TOP25, LT, 0.5 }, NONE, NONE, NONE }, kKeep, 0, 924 },
+  { 2, { { F_HISTP, LT, 0.001 }, NONE, NONE, NONE, NONE }, kKeep, kKeep, kKeep },                        // an empty bin 14 without a match above ends the chain
+  { 2, { { F_LVMAX, GT, 4.0 }, { F_MAPMEAN, GT, 3.2 }, { F_TOP28, LT, 0.25 }, NONE, NONE }, kKeep, 0, 980 },
+  { 2, { { F_GAIN, LT, 1.03 }, NONE, NONE, NONE, NONE }, kKeep, 0, 980 },
+};
+// LMCSUpdateCtrl 0, 1128-1163; the budget starts at 1022 code words
+const Rule kCtrl0[] = {
+  { 0, { { F_LOW, GT, 0.5 }, NONE, NONE, NONE, NONE }, 0, 1, 980 },
+  { 1, { { F_LOW, GT, 0.5 }, { F_HISTP, GT, 0.05 }, { F_LVP, LT, 1.2 }, NONE, NONE }, kKeep, kKeep, 938 },
+  { 1, { { F_LOW, GT, 0.5 }, { F_HISTP, GT, 0.05 }, NONE, NONE, NONE }, kKeep, kKeep, 896 },
+  { 1, { { F_LOW, GT, 0.5 }, { F_TOP28, LT, 0.8 }, { F_TOP25, EQ, 1.0 }, NONE, NONE }, kKeep, 1, 938 },
+  { 2, { { F_HISTP, LT, 0.001 }, { F_HIST1, GT, 0.05 }, { F_LV1, GT, 3.0 }, NONE, NONE }, 1, 1, 784 },
+  { 2, { { F_HISTP, LT, 0.001 }, { F_HIST1, LT, 0.006 }, NONE, NONE, NONE }, 0, 0, 1008 },
+  { 2, { { F_HISTP, LT, 0.001 }, { F_TOP25, LT, 0.5 }, NONE, NONE, NONE }, 1, 0, 1022 },
+  { 2, { { F_HISTP, LT, 0.001 }, NONE, NONE, NONE, NONE }, kKeep, kKeep, kKeep },
+  { 2, { { F_LVMAX, GT, 4.0 }, { F_MAPMEAN, GT, 3.2 }, { F_TOP28, LT, 0.25 }, NONE, NONE }, 1, 0, 1022 },
+  { 2, { { F_GAIN, LT, 1.03 }, NONE, NONE, NONE, NONE }, 1, 0, 1022 },
+};
+
+struct Choice { int intra, rate, cw; };
+
+bool holds(const Rule &r, const double *f)
+{
+  for (const Pred &p : r.when) {
+    if (p.feat < 0) continue;
+    const double v = f[p.feat];
+    if (!(p.cmp == GT ? v > p.k : p.cmp == LT ? v < p.k : v == p.k)) return false;
+  }
+  return true;
+}
+template <int N> bool any_rule(const Rule (&rules)[N], const double *f) { for (const Rule &r : rules) if (holds(r, f)) return true; return false; }
+template <int N> void run_chains(const Rule (&rules)[N], const double *f, Choice &c)
+{
+  int done = -1;                                          // chain that has fired already
+  for (const Rule &r : rules) {
+    if (r.chain == done || !holds(r, f)) continue;
+    done = r.chain;
+    if (r.intra != kKeep) c.intra = r.intra;
+    if (r.rate != kKeep) c.rate = r.rate;
+    if (r.cw != kKeep) c.cw = r.cw;
+  }
+}
+
+// ---- code words: uint16 arithmetic like the reference's (sums wrap at 65536)
+struct CodeWords {
+  uint16_t cw[kBins];
+  int total() const { int s = 0; for (uint16_t v : cw) s += v; return s; }
+  // an even share of `budget` for bins lo..hi, then occupied bins gain words where the content is flat and lose them where it is busy (931-954)
+  void spread(int lo, int hi, int budget, const BinProfile &p)
+  {
+    const uint16_t even = (uint16_t) (uint32_t) std::round((double) (uint16_t) budget / (hi - lo + 1));
+    for (int b = 0; b < kBins; b++) cw[b] = (b >= lo && b <= hi) ? even : (uint16_t) 0;
+    for (int b = 0; b < kBins; b++) {
+      if (!(p.share[b] > 0.001)) continue;
+      const double s = p.share[b] > 0.4 ? 0.4 : p.share[b];
+      const uint16_t one = (uint16_t) (10.0 * s + 0.5), two = (uint16_t) (20.0 * s + 0.5);
+      const double r = p.rel[b];
+      if (r < 0.8) cw[b] = (uint16_t) (cw[b] + two); else if (r < 0.9) cw[b] = (uint16_t) (cw[b] + one);
+      if (r > 1.2) cw[b] = (uint16_t) (cw[b] - two); else if (r > 1.1) cw[b] = (uint16_t) (cw[b] - one);
+    }
+  }
+  // what exceeds `limit` is taken back evenly from bins lo..hi, the remainder one word at a time from the first non-empty ones (955-975)
+  void trim(int lo, int hi, int limit)
+  {
+    const int over = total() - limit;
+    if (over <= 0) return;
+    const int n = hi - lo + 1, each = over / n;
+    int rest = over - each * n;
+    if (each > 0) for (int b = lo; b <= hi; b++) cw[b] = (uint16_t) (cw[b] - each);
+    for (int b = lo; b <= hi && rest > 0; b++) if (cw[b] > 0) { cw[b]--; rest--; }
+  }
+};
+
+// Model borders must not share a 32-word segment of the mapped range unless they sit on its start (the decoder finds a sample's bin by segment, JVET_O0272; 2194-2256).
+// Walking up the bins: a border inside the segment of the previous one is pushed to the next segment start and the words it gained are taken from the bins above, which
+// keep at least an eighth of the original bin width; in the last segment the remaining bins are merged into the bin below.  Returns the last non-empty bin.
+int align_borders(CodeWords &m, int lo, int hi, int wordsPerBin)
+{
+  const int seg = 5;                                      // log2 of 2 * kBins
+  const int floorCw = wordsPerBin >> 3;
+  int16_t edge[kBins + 1];
+  edge[0] = 0;
+  for (int b = 0; b < kBins; b++) edge[b + 1] = (int16_t) (edge[b] + m.cw[b]);
+  const int lastSeg = edge[hi + 1] >> seg;
+  for (int b = lo; b <= hi; b++) {
+    edge[b + 1] = (int16_t) (edge[b] + m.cw[b]);
+    const int here = edge[b] >> seg;
+    if (here != (edge[b + 1] >> seg) || edge[b] == (here << seg)) continue;      // the bin crosses a segment start, or begins on one
+    if (here == lastSeg) {                                // nothing above can absorb a shift: bins b.. collapse onto the top border
+      edge[b] = edge[hi + 1];
+      for (int k = b; k <= hi; k++) { edge[k + 1] = edge[b]; m.cw[k] = 0; }
+      m.cw[b - 1] = (uint16_t) (edge[b] - edge[b - 1]);
+      break;
+    }
+    int16_t owe = (int16_t) (((here + 1) << seg) - edge[b + 1]);
+    edge[b + 1] = (int16_t) (edge[b + 1] + owe);
+    m.cw[b] = (uint16_t) (m.cw[b] + owe);
+    for (int k = b + 1; k <= hi && owe != 0; k++) {
+      if (m.cw[k] < owe + floorCw) { owe = (int16_t) (owe - (m.cw[k] - floorCw)); m.cw[k] = (uint16_t) floorCw; }
+      else { m.cw[k] = (uint16_t) (m.cw[k] - owe); owe = 0; }
+    }
+  }
+  int top = hi;
+  for (int b = kBins - 1; b >= 0; b--) if (m.cw[b] > 0) { top = b; break; }
+  return top;
+}
+
+// the three "share of the picture above a log-variance level" features: bins in descending order of log-variance (stable: an equal value stays behind the earlier bin),
+// cumulated shares, and for each level the cumulated share at the index AFTER the last bin above it (index 0 when none is) - 909-928, 1005-1030
+void busy_shares(const BinProfile &p, double &top34, double &top28, double &top25)
+{
+  int order[kBins]; double cum[kBins];
+  for (int b = 0; b < kBins; b++) order[b] = b;
+  for (int i = 1; i < kBins; i++) {                       // insertion sort, descending, stable = what a bubble sort with a strict comparison yields
+    const int t = order[i]; int j = i;
+    while (j > 0 && p.lv[order[j - 1]] < p.lv[t]) { order[j] = order[j - 1]; j--; }
+    order[j] = t;
+  }
+  double run = 0.0;
+  for (int i = 0; i < kBins; i++) { run += p.share[order[i]]; cum[i] = run; }
+  int a = 0, b2 = 0, c = 0;
+  for (int i = 0; i < kBins - 1; i++) { const double v = p.lv[order[i]]; if (v > 3.4) a = i + 1; if (v > 2.8) b2 = i + 1; if (v > 2.5) c = i + 1; }
+  top34 = cum[a]; top28 = cum[b2]; top25 = cum[c];
+}
+
+int analyse(const StatOut &st, int w, int h, int bd, int qp, int updateCtrl, vvcx_slice *slice)
+{
+  const double area = (double) w * h, areaC = (double) (w / 2) * (h / 2);
+  BinProfile src;
+  for (int b = 0; b < kBins; b++) {
+    src.share[b] = (double) st.count[b] / (double) (w * h);
+    src.lv[b] = st.count[b] ? st.logSum[b] / (double) st.count[b] : 0.0;
+  }
+  src.summarise();
+  // chroma against luma: ratios of the standard deviations (370-407)
+  double devU = 0.0, devV = 0.0;
+  {
+    const double mY = (double) st.sum[0] / area, mU = (double) st.sum[1] / areaC, mV = (double) st.sum[2] / areaC;
+    const double vY = (double) st.sq[0] / area - mY * mY, vU = (double) st.sq[1] / areaC - mU * mU, vV = (double) st.sq[2] / areaC - mV * mV;
+    if (vY > 0) { devU = std::sqrt(vU) / std::sqrt(vY); devV = std::sqrt(vV) / std::sqrt(vY); }
+  }
+  const int words = 1 << bd, wordsPerBin = words / kBins;                       // mapped range and an untouched bin's share of it
+  const int unit = bd > 10 ? (wordsPerBin >> (bd - 10)) : wordsPerBin;          // the analysis counts in 10-bit words
+  const int legalLo = 16 << (bd - 8), legalHi = 235 << (bd - 8);
+  int lo = legalLo / wordsPerBin, hi = legalHi / wordsPerBin;                   // bins of the limited range
+  bool intra = true, inter = true;
+  // 443-470: content outside the limited range widens the model or rules it out; chroma-heavy dark content rules it out
+  if (src.share[kBins - 1] > 0.0003 || src.share[0] > 0.03) intra = inter = false;
+  if (src.share[0] + src.share[kBins - 1] > 0.005)
+    for (int b = 0; b < kBins; b++) if (src.share[b] > 0) { lo = b < lo ? b : lo; hi = b > hi ? b : hi; }
+  if (devU + devV > 1.5 && src.share[1] > 0.5) intra = inter = false;
+  const int chromaAdj = !(devU > 0.36 && devV > 0.2 && area > kBigArea);
+  Choice pick = { 1, 0, 1022 };
+  CodeWords m;
+  for (int b = 0; b < kBins; b++) m.cw[b] = (uint16_t) unit;
+  if (inter) {
+    // trial mapping with the full budget, to see what it does to the variances (1058-1079)
+    m.spread(lo, hi, 1022, src); m.trim(lo, hi, 1023);
+    BinProfile mapped;
+    for (int b = 0; b < kBins; b++) {
+      mapped.share[b] = src.share[b];
+      mapped.lv[b] = src.lv[b] + 2.0 * std::log10(m.cw[b] > 0 ? (double) m.cw[b] / (double) unit : 1.0);
+    }
+    mapped.summarise();
+    double f[N_FEAT];
+    f[F_HIST0] = src.share[0]; f[F_HIST1] = src.share[1]; f[F_HISTP] = src.share[kBins - 2]; f[F_HISTE] = src.share[kBins - 1]; f[F_ENDS] = src.share[0] + src.share[kBins - 1];
+    f[F_LV1] = src.lv[1]; f[F_LVP] = src.lv[kBins - 2]; f[F_LVMAX] = src.lvMax; f[F_MAPMEAN] = mapped.lvMean;
+    f[F_GAIN] = mapped.wLv / src.wLv; f[F_GAINREL] = mapped.wRel / src.wRel;
+    busy_shares(src, f[F_TOP34], f[F_TOP28], f[F_TOP25]);
+    f[F_AREA] = area; f[F_CHROMA] = devU + devV; f[F_LOW] = 0.0;
+    if (any_rule(kSkipRules, f)) intra = inter = false;
+    else {
+      f[F_LOW] = any_rule(kLowRules, f) ? 1.0 : 0.0;
+      pick.intra = intra; pick.rate = 0;
+      if (updateCtrl == 0) { pick.cw = 1022; run_chains(kCtrl0, f, pick); }
+      else { pick.cw = 952; run_chains(kCtrl1, f, pick); }
+      intra = pick.intra != 0;
+    }
+  }
+  if (pick.rate == 2 && qp <= 22) intra = inter = false;
+  if (!intra) return VVCX_OK;                             // no model, or one that only inter pictures would use
+  if (pick.rate == 1 && qp <= 22) { for (int b = 0; b < kBins; b++) m.cw[b] = (b >= lo && b <= hi) ? (uint16_t) (unit + 2) : (uint16_t) 0; }
+  else m.spread(lo, hi, pick.cw, src);
+  m.trim(lo, hi, 1023);
+  // the model in words of the picture's bit depth, its first and last used bin, borders aligned (1835-1893)
+  if (bd != 10) for (int b = 0; b < kBins; b++) m.cw[b] = (uint16_t) (m.cw[b] * (1 << (bd - 10)));
+  int first = 0, last = kBins - 1;
+  for (int b = 0; b < kBins; b++) if (m.cw[b] > 0) { first = b; break; }
+  for (int b = kBins - 1; b >= 0; b--) if (m.cw[b] > 0) { last = b; break; }
+  last = align_borders(m, first, last, 1024 / kBins);      // (the alignment works with the 10-bit bin width whatever the bit depth, like the reference's)
+  slice->lmcs_enable = 1; slice->lmcs_chroma_adj = chromaAdj; slice->lmcs_min_bin = first; slice->lmcs_max_bin = last;
+  for (int b = first; b <= last; b++) slice->lmcs_delta_cw[b] = (int) m.cw[b] - wordsPerBin;
+  return VVCX_OK;
+}
+
+int check_args(const void *const org[3], const int stride[3], int pic_w, int pic_h, int bit_depth, int update_ctrl, vvcx_slice *slice)
 {
   if (!org || !stride || !slice || !org[0] || !org[1] || !org[2]) return vvcx_fail_msg_(VVCX_ERR_ARG, "vvcx_lmcs_analyze: null argument");
-  if (pic_w < 8 || pic_h < 8 || (pic_w & 1) || (pic_h & 1) || stride[0] < pic_w || stride[1] < pic_w / 2 || stride[2] < pic_w / 2) return vvcx_fail_msg_(VVCX_ERR_ARG, "vvcx_lmcs_analyze: picture size / strides");
+  if (pic_w < 8 || pic_h < 8 || pic_w > 16384 || pic_h > 16384 || (pic_w & 1) || (pic_h & 1) || stride[0] < pic_w || stride[1] < pic_w / 2 || stride[2] < pic_w / 2)
+    return vvcx_fail_msg_(VVCX_ERR_ARG, "vvcx_lmcs_analyze: picture size (8..16384, even) / strides");
   if (bit_depth < 8 || bit_depth > 12) return vvcx_fail_msg_(VVCX_ERR_ARG, "vvcx_lmcs_analyze: bit depth");
-  if (update_ctrl != 0 && update_ctrl != 1) return vvcx_fail_msg_(VVCX_ERR_UNSUPPORTED, "vvcx_lmcs_analyze: LMCSUpdateCtrl 2 (low delay) is not an intra configuration");      // 2 (low delay) analyses 32 bins and fits the codewords to the variances: not an intra configuration
-  slice->lmcs_enable = 0; slice->lmcs_chroma_adj = 0; slice->lmcs_min_bin = 0; slice->lmcs_max_bin = 0;
-  for (int i = 0; i < 16; i++) slice->lmcs_delta_cw[i] = 0;
-  // Below 10 bits calcSeqStats bins the luma with `>> (m_lumaBD - 10)`, a negative shift count: on x86 the count is masked and every sample lands in bin 0, whose share
-  // of 100 % ends the analysis at the first test (binHist[0] > 0.03: 443-446) — the reference switches LMCS off for every 8-bit picture
-  if (bit_depth < 10) return VVCX_OK;
-  const int bps = 2;
-  Analyzer a; memset(&a, 0, sizeof a);
-  a.bd = bit_depth; a.lutSize = 1 << bit_depth; a.initCW = a.lutSize / kBins; a.picSize = pic_w * pic_h; a.baseQP = slice_qp; a.updateCtrl = update_ctrl;
-  const int stdMin = 16 << (bit_depth - 8), stdMax = 235 << (bit_depth - 8), binLen = a.lutSize / kBins;
-  int startBin = stdMin / binLen, endBin = stdMax / binLen;
-  a.minBin = startBin; a.maxBin = endBin;
-  a.initCWAnalyze = bit_depth > 10 ? (binLen >> (bit_depth - 10)) : binLen;
-  for (int b = 0; b < kBins; b++) a.binCW[b] = (uint16_t) a.initCWAnalyze;
-  bool reshape = true, exceedSTD = false, intraAdp = true, interAdp = true;
-  a.useAdpCW = false; a.chromaAdj = 1; a.rateAdpMode = 0; a.tcase = 0;
-  calcSeqStats(org, stride, pic_w, pic_h, bit_depth, bps, a.picSize, a.src);
-  const SeqInfo &s = a.src;
-  if ((s.binHist[0] + s.binHist[kBins - 1]) > 0.005) exceedSTD = true;
-  if (s.binHist[kBins - 1] > 0.0003) { intraAdp = false; interAdp = false; }
-  if (s.binHist[0] > 0.03) { intraAdp = false; interAdp = false; }
-  if (exceedSTD) {
-    for (int i = 0; i < kBins; i++) { if (s.binHist[i] > 0 && i < startBin) startBin = i; if (s.binHist[i] > 0 && i > endBin) endBin = i; }
-    a.minBin = startBin; a.maxBin = endBin;
-  }
-  if ((s.ratioStdU + s.ratioStdV) > 1.5 && s.binHist[1] > 0.5) { intraAdp = false; interAdp = false; }
-  if (s.ratioStdU > 0.36 && s.ratioStdV > 0.2 && a.picSize > 5184000) a.chromaAdj = 0;       // (+ m_chromaWeight, an inter-picture lambda weight)
-  if (interAdp) { a.cw0 = 0; a.cw1 = 1022; a.deriveSDR(&intraAdp, &interAdp); }                // LMCSAdpOption 0, SDR
-  if (a.rateAdpMode == 2 && slice_qp <= 22) { intraAdp = false; interAdp = false; }
-  if (!intraAdp && !interAdp) reshape = false;
-  if (!reshape || !intraAdp) return VVCX_OK;          // no model, or a model only the inter pictures of the reference would use: the intra slice runs without LMCS
-  if (a.rateAdpMode == 1 && slice_qp <= 22) { for (int i = 0; i < kBins; i++) a.binCW[i] = (i >= startBin && i <= endBin) ? (uint16_t) (a.initCWAnalyze + 2) : (uint16_t) 0; }
-  else a.cwPerturbation(startBin, endBin, (uint16_t) a.cw1);
-  a.cwReduction(startBin, endBin);
-  // constructReshaperLMCS, the model half (1835-1893)
-  const int bdShift = bit_depth - 10;
-  if (bdShift != 0) for (int i = 0; i < kBins; i++) a.binCW[i] = (uint16_t) (a.binCW[i] * (1 << bdShift));
-  a.minBin = 0; a.maxBin = kBins - 1;
-  for (int i = 0; i < kBins; i++) if (a.binCW[i] > 0) { a.minBin = i; break; }
-  for (int i = kBins - 1; i >= 0; i--) if (a.binCW[i] > 0) { a.maxBin = i; break; }
-  a.adjustLmcsPivot();
-  slice->lmcs_enable = 1; slice->lmcs_chroma_adj = a.chromaAdj; slice->lmcs_min_bin = a.minBin; slice->lmcs_max_bin = a.maxBin;
-  for (int i = a.minBin; i <= a.maxBin; i++) slice->lmcs_delta_cw[i] = (int) a.binCW[i] - a.initCW;
+  if (update_ctrl != 0 && update_ctrl != 1) return vvcx_fail_msg_(VVCX_ERR_UNSUPPORTED, "vvcx_lmcs_analyze: LMCSUpdateCtrl 2 (low delay) is not an intra configuration");
   return VVCX_OK;
+}
+void no_model(vvcx_slice *slice)
+{
+  slice->lmcs_enable = 0; slice->lmcs_chroma_adj = 0; slice->lmcs_min_bin = 0; slice->lmcs_max_bin = 0;
+  for (int i = 0; i < kBins; i++) slice->lmcs_delta_cw[i] = 0;
+}
+}  // namespace
+
+// planes in DEVICE memory (the pointers the caller later hands to vvcx_bind_frames), on the current device
+extern "C" int vvcx_lmcs_analyze_device(const void *const org[3], const int stride[3], int pic_w, int pic_h, int bit_depth, int slice_qp, int update_ctrl, vvcx_slice *slice)
+{
+  const int rc = check_args(org, stride, pic_w, pic_h, bit_depth, update_ctrl, slice);
+  if (rc != VVCX_OK) return rc;
+  no_model(slice);
+  // Below 10 bits the reference bins the luma with a negative shift count (on x86 the count is masked: every sample lands in bin 0), sees all of the picture in its first
+  // bin and ends the analysis at its first test: LMCS stays off for every 8-bit picture.  Nothing to measure.
+  if (bit_depth < 10) return VVCX_OK;
+  StatOut st;
+  const int rs = picture_stats<uint16_t>(org, stride, pic_w, pic_h, bit_depth, st);
+  if (rs != VVCX_OK) return rs;
+  return analyse(st, pic_w, pic_h, bit_depth, slice_qp, update_ctrl, slice);
+}
+
+// planes in HOST memory: uploaded, then the same device pass
+extern "C" int vvcx_lmcs_analyze(const void *const org[3], const int stride[3], int pic_w, int pic_h, int bit_depth, int slice_qp, int update_ctrl, vvcx_slice *slice)
+{
+  const int rc = check_args(org, stride, pic_w, pic_h, bit_depth, update_ctrl, slice);
+  if (rc != VVCX_OK) return rc;
+  no_model(slice);
+  if (bit_depth < 10) return VVCX_OK;
+  DevMem d[3]; const void *dev[3];
+  for (int c = 0; c < 3; c++) {
+    const size_t bytes = (size_t) stride[c] * (c ? pic_h / 2 : pic_h) * 2;
+    if (d[c].alloc(bytes) != hipSuccess || hipMemcpy(d[c].p, org[c], bytes, hipMemcpyHostToDevice) != hipSuccess) return vvcx_fail_msg_(VVCX_ERR_DEVICE, "vvcx_lmcs_analyze: upload of the picture failed");
+    dev[c] = d[c].p;
+  }
+  return vvcx_lmcs_analyze_device(dev, stride, pic_w, pic_h, bit_depth, slice_qp, update_ctrl, slice);
 }

@@ -128,6 +128,16 @@ class _SliceCfg(C.Structure):
                 ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32), ("gop_size", C.c_int32), ("dep_quant", C.c_int32)]
 
 
+def lmcs_analyze_device(ptrs, strides, width, height, bit_depth, qp, update_ctrl=1, lib_path=None):
+    """vvcx_lmcs_analyze_device: the same analysis on planes that are in device memory (ptrs: three device addresses, strides in samples)"""
+    L = load_library(lib_path)
+    org = (C.c_void_p * 3)(*[int(p) for p in ptrs]); st = (C.c_int * 3)(*[int(v) for v in strides])
+    sl = _Slice()
+    L.vvcx_lmcs_analyze_device.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    _chk(L, L.vvcx_lmcs_analyze_device(org, st, width, height, bit_depth, qp, update_ctrl, C.byref(sl)))
+    return dict(enable=int(sl.lmcs_enable), chroma_adj=int(sl.lmcs_chroma_adj), min_bin=int(sl.lmcs_min_bin), max_bin=int(sl.lmcs_max_bin), delta_cw=[int(v) for v in sl.lmcs_delta_cw])
+
+
 def lmcs_analyze(planes, bit_depth, qp, update_ctrl=1, lib_path=None):
     """vvcx_lmcs_analyze: the reference encoder's LMCS picture analysis for an intra picture (host planes) -> the model as set_slice(lmcs=...) takes it:
     dict(enable, chroma_adj, min_bin, max_bin, delta_cw[16])"""

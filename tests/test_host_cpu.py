@@ -356,8 +356,9 @@ def test_training_set_dump_on_cpu_emulator_matches_oracle(emu_so):
     enc.close()
 
 
-def test_lmcs_picture_analysis_matches_the_reference_encoder(hip_lib):
-    """vvcx_lmcs_analyze (the picture analysis that chooses the LMCS model of an intra picture) against what the reference's own EncReshape, compiled in place,
+def test_lmcs_picture_analysis_matches_the_reference_encoder(emu_so):
+    """vvcx_lmcs_analyze (the picture analysis that chooses the LMCS model of an intra picture; its statistics kernels on the CPU debug emulation here, on the
+    GPU in tests/test_gpu_parity.py) against what the reference's own EncReshape, compiled in place,
     decided for the same pictures (tests/golden/lmcs_analysis.npz: preAnalyzerLMCS + constructReshaperLMCS on 29 pictures - several codeword budgets and perturbations, the
     extended range with negative deltas, chroma adjustment off above 5.18 M samples, both sides of the QP 22 rule, LMCS off for 8-bit and full-range content)."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "lmcs_analysis.npz"))["rows"]
@@ -368,7 +369,7 @@ def test_lmcs_picture_analysis_matches_the_reference_encoder(hip_lib):
             continue                                   # one 4K picture is enough for the CPU suite
         seen.add((W, H))
         planes = O.lmcs_test_picture(pkg, W, H, bd, seed, limited, tex, ori, scr, kind)
-        m = pkg.vvcx.lmcs_analyze(planes, bd, qp)
+        m = pkg.vvcx.lmcs_analyze(planes, bd, qp, lib_path=emu_so)
         assert m["enable"] == int(r[10]), (W, H, bd, qp, seed, kind)
         if m["enable"]:
             assert [m["chroma_adj"], m["min_bin"], m["max_bin"]] + m["delta_cw"] == [int(v) for v in r[11:]], (W, H, bd, qp, seed, kind, m, r[11:])
@@ -376,7 +377,7 @@ def test_lmcs_picture_analysis_matches_the_reference_encoder(hip_lib):
             assert not any(m["delta_cw"]) and m["chroma_adj"] == 0
     assert len({tuple(r[10:]) for r in g}) >= 7        # the fixture is not one model repeated
     with pytest.raises(pkg.VvcxError):
-        pkg.vvcx.lmcs_analyze(O.lmcs_test_picture(pkg, 64, 64, 10, 1, 1, 0, 0, 0, 0), 10, 32, update_ctrl=2)
+        pkg.vvcx.lmcs_analyze(O.lmcs_test_picture(pkg, 64, 64, 10, 1, 1, 0, 0, 0, 0), 10, 32, update_ctrl=2, lib_path=emu_so)
 
 
 def test_wavefront_rows_on_cpu_emulator_match_oracle(emu_so):

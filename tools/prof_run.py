@@ -31,3 +31,6 @@ if os.environ.get("VVCX_STAMP_DQ"):
     print("trellis calls %d: first-position search %.3e  tables/last offsets %.3e  loop %.3e  back-tracking %.3e  write-back %.3e (wave clocks)" % (c, pr[16], pr[17], pr[18], pr[19], pr[20]))
     print("  per call: positions run %.1f  items %.2f  positions per item %.1f  block positions %.1f" % (pr[22] / c, pr[23] / c, pr[24] / max(1, pr[23]), pr[25] / c))
     print("  inside the loop: candidate costs %.3e  gather + decision %.3e  state update %.3e (of which group ends %.3e)" % (pr[26], pr[27], pr[28], pr[29]))
+if os.environ.get("VVCX_STAMP_ISP"):
+    print("ISP wave 0: candidates %d  sub-partitions %d  whole candidate %.3e | refs + prediction %.3e  forward transform %.3e  trellis %.3e  dequant + inverse + SSE %.3e  rate %.3e" % (pr[22], pr[23], pr[21], pr[19], pr[16], pr[17], pr[18], pr[20]))
+    print("ISP controller: begin + sort %.3e  next-mode %.3e (%d calls)  result replay %.3e  batch building %.3e (%d batches)" % (pr[24], pr[27], pr[28], pr[26], pr[25], pr[29]))
