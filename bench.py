@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 RUN_BUDGET_S = 380.0          # what all timed + warm-up steps of one run may take (auto batch size only)
-BUDGET_CTUS_PER_S = 120.0     # rate assumed for that (below every measured configuration of the full tool set: 133-140 CTU/s in round 3)
+BUDGET_CTUS_PER_S = 150.0     # rate assumed for that (below the measured rate of the full tool set: 160-173 CTU/s in round 4)
 
 
 def pmc_traffic(workload):
@@ -73,8 +73,30 @@ def pmc_valu(workload):
                 out["wait_any_frac"] = pl["SQ_WAIT_ANY"] / pl["SQ_WAVE_CYCLES"]
             if pl.get("SQ_LDS_IDX_ACTIVE") and pl.get("SQ_LDS_BANK_CONFLICT") is not None:      # cycles lost to bank conflicts per cycle the LDS index unit is busy
                 out["lds_bank_conflict_frac"] = pl["SQ_LDS_BANK_CONFLICT"] / pl["SQ_LDS_IDX_ACTIVE"]
+            if pl.get("SQ_ACTIVE_INST_VALU") and pl.get("SQ_THREAD_CYCLES_VALU") is not None:   # lanes that work per vector instruction (64 = all): SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU
+                out["active_lanes_per_valu_inst"] = pl["SQ_THREAD_CYCLES_VALU"] / pl["SQ_ACTIVE_INST_VALU"]
+                out["lane_utilisation"] = out["active_lanes_per_valu_inst"] / 64.0
+            if pl.get("SQ_INSTS_SALU") and pl.get("SQ_INSTS_VALU"):
+                out["salu_per_valu_inst"] = pl["SQ_INSTS_SALU"] / pl["SQ_INSTS_VALU"]
             return out
     return None
+
+
+def layout_variants():
+    """Other picture layouts of the same search, quoted from the newest committed bench lines under profiles/ (NOT measured in this run): the reference cfg's own layout -
+    one tile per picture - with WaveFrontSynchro rows as streams, and the plain one-tile-per-picture stream."""
+    import glob
+    out = {}
+    for key, pat in (("tiles_1x1_wpp_1080p", "r*_bench_1080p_tiles_1x1_wpp*.json"), ("tiles_1x1_wpp_4k10", "r*_bench_4k10_tiles_1x1_wpp*.json"), ("tiles_4x2_1080p", "r*_bench_tiles_4x2*.json")):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+        for f in reversed(files):
+            try:
+                d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+            except Exception:
+                continue
+            out[key] = {"value": d["value"], "unit": d["unit"], "workload": d["config"]["workload"], "tiling": d["config"].get("tiling"), "source": os.path.relpath(f, ROOT), "measured_here": False}
+            break
+    return out
 
 
 def _cpu_job(job):
@@ -115,6 +137,7 @@ def main():
                     help="BASELINE config 3 flavour: the fork's FAST_ALGORITHM with the shipped forest (forests/partition_qp32.npz) on the device")
     ap.add_argument("--chroma-texture", type=float, default=0.5,
                     help="fraction of the luma texture mixed into the synthetic chroma planes (0 = smooth chroma)")
+    ap.add_argument("--emit-payload", action="store_true", help="run the slice_data writer in the timed steps also at N = 1 (N > 1 always does: the job ends with the bitstream gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ctus", type=int, default=8)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the frame-parallel CPU baseline (0 = the host's usable cores, at most 16)")
@@ -170,7 +193,7 @@ def main():
         args.frames = max(min(args.frames, fit), max(1, args.frames // 2))
     else:
         args.frames = int(args.frames)
-    emit = world > 1                                # the N-GPU job ends with the bitstream gather: its ranks run the slice_data writer too
+    emit = world > 1 or args.emit_payload           # the N-GPU job ends with the bitstream gather: its ranks run the slice_data writer too
     enc = pkg.VvcxEncoder(W, H, bd, tile_cols=tc, tile_rows=tr, chroma=True, max_frames=args.frames, device=dev, lib_path=args.lib, tools=args.tools, forest=forest, emit_payload=emit)
     lmcs = None
     if args.lmcs == "model" and (args.tools & 0x400):
@@ -254,6 +277,8 @@ def main():
             "roofline": {"bound": "hbm", "limiter": "not HBM: VALU issue and the serial chains of one CTU stream (mode controller, trellis, CABAC estimator); see valu.issue_frac and DESIGN.md", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_split": traffic_split, "traffic_source": traffic_src, "kernel": ("vvcx_compress_wpp_kernel_" if args.wpp else "vvcx_compress_kernel_") + ("u8" if bd == 8 else "u16"), "kernel_ms": 1e3 * avg_kernel_s,
                          "algorithmic_bytes_per_launch": ctus_per_step * b_ctu, "valu": valu},
+            "variants": layout_variants(),
+            "emit_payload": bool(emit),
             "work": {"satd_candidates_per_launch": int(counters[0]), "rd_tu_evaluations_per_launch": int(counters[1]),
                      "rd_pixels_per_launch": int(counters[2]), "nodes_per_launch": int(counters[3]),
                      "rd_pixels_per_s": float(counters[2]) / avg_kernel_s, "satd_candidates_per_s": float(counters[0]) / avg_kernel_s,

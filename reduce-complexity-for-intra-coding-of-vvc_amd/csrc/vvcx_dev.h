@@ -4,14 +4,14 @@
 #include <stdint.h>
 
 #ifndef VXD_NW
-#define VXD_NW 4            // wavefronts (64 lanes) per workgroup = one CTU stream; 4 keeps LDS < 80 KB so two streams share a CU
+#define VXD_NW 4            // wavefronts (64 lanes) per workgroup = one CTU stream
 #endif
 #define VXD_NT (VXD_NW * 64) // threads per workgroup
 #ifndef VXD_BUF
 #define VXD_BUF 256          // samples of a node (luma w*h, chroma 2*cw*ch) up to which its candidates are evaluated in LDS buffers
 #endif
 #ifndef VXD_WPE
-#define VXD_WPE 4            // waves per SIMD the register budget is sized for = CTU streams per CU (one wave of each stream per SIMD)
+#define VXD_WPE 5            // waves per SIMD the register budget is sized for = CTU streams per CU (one wave of each stream per SIMD): 96 VGPRs and at most 32 KB of LDS
 #endif
 #define VXD_MAXD 12         // recursion levels kept in LDS (a split at least halves the area: 128x128 -> 4x4 is at most ten levels below the CTU)
 #define VXD_NUM_CTX 291     // flat context array: the models of the reference's ContextSetCfg an intra slice of this path touches, in its order (vvcx_tables.h VX_NUM_CTX)

@@ -599,8 +599,8 @@ def test_dct2_rows_sum_to_zero_except_the_dc_row():
 
 
 def test_resource_budget_of_the_compress_kernel(hip_lib):
-    """The stream kernel is sized for four workgroups per CU (128 VGPRs, 40 KB LDS, 1024 resident streams per GPU).  A field too many in the LDS object
-    drops the residency to three and makes the compiler give up the register target as well (seen in round 3: 41 008 B -> 257 VGPRs, one wave per SIMD), without any
+    """The stream kernel is sized for five workgroups per CU (96 VGPRs, 32 KB LDS, 1280 resident streams per GPU).  A field too many in the LDS object
+    drops the residency by one and makes the compiler give up the register target as well (seen in round 3: 41 008 B -> 257 VGPRs, one wave per SIMD), without any
     test failing: check the built code object's metadata.  profiles/r04_codeobj.json is this report, written by __graft_entry__.build() and committed with the build it
     describes: the test fails when the two disagree (a stale report was quoted for a round once)."""
     import importlib.util
@@ -612,8 +612,8 @@ def test_resource_budget_of_the_compress_kernel(hip_lib):
     r = m.report(HIP_SO)
     for name in ("vvcx_compress_kernel_u8", "vvcx_compress_kernel_u16", "vvcx_compress_wpp_kernel_u8", "vvcx_compress_wpp_kernel_u16"):
         k = r["kernels"][name]
-        assert k["group_segment_fixed_size"] <= 40960, (name, k)
-        assert k["vgpr_count"] + k.get("agpr_count", 0) <= 128, (name, k)
+        assert k["group_segment_fixed_size"] <= 32768, (name, k)                   # five workgroups per CU: 160 KB / 5
+        assert k["vgpr_count"] + k.get("agpr_count", 0) <= 96, (name, k)           # five waves per SIMD: 512 / 5, allocation granule 8
     committed = json.load(open(os.path.join(ROOT, "profiles", "r04_codeobj.json")))
     assert committed["kernels"] == r["kernels"], "profiles/r04_codeobj.json is not the report of the built libvvcx.so: run python tools/codeobj_report.py --out profiles/r04_codeobj.json (or __graft_entry__.build())"
 

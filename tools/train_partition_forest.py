@@ -61,13 +61,35 @@ def main():
     ap.add_argument("--balance", type=float, default=0.5)
     ap.add_argument("--device", action="store_true", help="rows from the device's training dump (needs an MI355X): 1080p pictures, tools 0xfff; writes forests/partition_qp<QP>_device.npz "
                     "and leaves the shipped forest and its golden vector alone")
+    ap.add_argument("--dump-rows", type=str, default=None, help="with --device: only dump the rows (a bounded random sample: train / held) to this .npz and stop - the GPU box's part of "
+                    "the job; the forest is then trained from the file where sklearn time is free (--rows)")
+    ap.add_argument("--rows", type=str, default=None, help="train from a --dump-rows file (device rows, tools 0xfff) and write the SHIPPED forest forests/partition_qp<QP>.npz "
+                    "(+ the golden vector of the QP 32 forest)")
+    ap.add_argument("--max-rows", type=int, default=400000)
     args = ap.parse_args()
+    if args.dump_rows:
+        pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+        train = rows_of_device(pkg, 1920, 1080, args.qp, [5000 + i for i in range(args.pictures)], 0.5, 0xfff)
+        held = rows_of_device(pkg, 1920, 1080, args.qp, [7000, 7001], 0.5, 0xfff)
+        g = np.random.default_rng(args.qp)
+        n_all = len(train)
+        if len(train) > args.max_rows:
+            train = train[g.permutation(len(train))[:args.max_rows]]
+        if len(held) > args.max_rows // 8:
+            held = held[g.permutation(len(held))[:args.max_rows // 8]]
+        np.savez_compressed(args.dump_rows, train=train.astype(np.int32), held=held.astype(np.int32), qp=np.array([args.qp]), rows_produced=np.array([n_all]), tools=np.array([0xfff]))
+        print("dumped", len(train), "of", n_all, "training rows and", len(held), "held-out rows to", args.dump_rows)
+        return
     from sklearn.ensemble import RandomForestClassifier
     import sklearn
     import oracle_lib as O
     pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
     from concurrent.futures import ProcessPoolExecutor
-    if args.device:
+    if args.rows:
+        d = np.load(args.rows)
+        assert int(d["qp"][0]) == args.qp, "the rows were dumped at another QP"
+        train, held = d["train"], d["held"]
+    elif args.device:
         train = rows_of_device(pkg, 1920, 1080, args.qp, [5000 + i for i in range(args.pictures)], 0.5, 0xfff)
         held = rows_of_device(pkg, 1920, 1080, args.qp, [7000, 7001], 0.5, 0xfff)
     else:
@@ -86,11 +108,12 @@ def main():
     print("held-out accuracy %.3f" % float((pred == held[:, 27]).mean()), "predicted histogram", np.bincount(pred, minlength=6))
     forest = pkg.forest_from_sklearn(clf)
     path = os.path.join(ROOT, "reduce-complexity-for-intra-coding-of-vvc_amd", "forests", "partition_qp%d%s.npz" % (args.qp, "_device" if args.device else ""))
-    pkg.save_forest(path, forest, qp=np.array([args.qp]), sklearn_version=np.array([sklearn.__version__]), training_rows=np.array([len(train)]))
+    pkg.save_forest(path, forest, qp=np.array([args.qp]), sklearn_version=np.array([sklearn.__version__]), training_rows=np.array([len(train)]),
+                    row_source=np.array(["device dump, tools 0xfff, 1080p" if (args.rows or args.device) else "oracle, luma tree, MRL + MTS, 256x256"]))
     print("wrote", path, "trees", len(forest["root"]), "nodes", len(forest["feature"]))
     order = np.random.default_rng(0).permutation(len(held))
     sel = np.concatenate([order[pred[order] == c][:120] for c in range(6)])         # up to 120 rows per predicted class
-    if args.qp == 32 and not args.device:                   # the golden vector belongs to the shipped QP 32 forest
+    if args.qp == 32 and not args.device:                   # the golden vector belongs to the shipped QP 32 forest (oracle rows or --rows: both write the shipped file)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", "forest.npz"), rows=held[sel, :26].astype(np.int32), sklearn_predict=pred[sel].astype(np.int32),
                             qp=np.array([args.qp]))
 
