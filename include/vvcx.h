@@ -207,6 +207,18 @@ int  vvcx_lmcs_tables(vvcx_handle *h, int16_t *fwd, int16_t *inv, int32_t pivot[
  * Every CTU of the pictures must have been compressed.  SAO and ALF, which follow in the reference, are not built. */
 int  vvcx_deblock_bound_frames(vvcx_handle *h, int beta_offset_div2, int tc_offset_div2, void *hip_stream);
 float vvcx_last_deblock_ms(const vvcx_handle *h);
+/* ≙ SampleAdaptiveOffset::SAOProcess(cs, saoBlkParams) (CL/SampleAdaptiveOffset.cpp:617-670): sample adaptive offset on every bound (completely coded) picture, in place on
+ * the reconstruction planes, with the caller's per-CTU parameters prm[frame][ctu raster address][component] (≙ SAOBlkParam, CL/TypeDef.h:1122-1140): mode 0 off / 1 new /
+ * 2 merge; type: for a new CTU 0..3 = edge class 0 / 90 / 135 / 45 degrees, 4 = band offset, for a merge 0 = from the CTU to the left, 1 = from the CTU above (which must be
+ * in the same tile); band = band position (0..31); offset[4] = the four coded offsets (edge: full valley, half valley, half peak, full peak; band: the four bands from the
+ * band position), multiplied by 2^log2_offset_scale.  lf_across_tiles = pps loop_filter_across_bricks_enabled_flag.  The parameter DECISION (EncSampleAdaptiveOffset) is
+ * not part of the library: the caller's encoder keeps it.  In the reference's order this follows vvcx_deblock_bound_frames. */
+typedef struct vvcx_sao_param { int8_t mode, type, band, offset[4]; } vvcx_sao_param;
+int   vvcx_sao_bound_frames(vvcx_handle *h, const vvcx_sao_param *prm, int lf_across_tiles, int log2_offset_scale, void *hip_stream);
+float vvcx_last_sao_ms(const vvcx_handle *h);
+/* the same filter on one picture in host memory (uint16 planes, stride = plane width, filtered in place; prm[ctu][component]): needs no handle */
+int   vvcx_sao_picture(int pic_w, int pic_h, int bit_depth, int tile_cols, int tile_rows, const vvcx_sao_param *prm, int lf_across_tiles, int log2_offset_scale,
+                       uint16_t *y, uint16_t *cb, uint16_t *cr, int device);
 /* ≙ LoopFilter::loopFilterPic on a picture the caller describes itself (the way the reference's LoopFilter sees a CodingStructure: cs.cus + cs.tus + the reconstruction buffer):
  * rows = n_rows x {channel type (0 luma tree, 1 chroma tree), x, y, w, h in luma samples, cu.ispMode (0, 1 = horizontal, 2 = vertical split; luma rows only)} covering both
  * trees of the whole 4:2:0 picture, every CU intra at the slice QP (qp_cb / qp_cr = mapped chroma QPs); y / cb / cr = host planes of 16-bit samples, stride = plane width,

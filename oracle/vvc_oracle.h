@@ -130,6 +130,9 @@ int      orc_forest_predict_rows(orc_enc *e, const int32_t *rows, int n, int32_t
 int      orc_deblock_frame(orc_enc *e, int beta_offset_div2, int tc_offset_div2);
 /* the same filter on a CU table {ch, x, y, w, h, ispMode} (luma samples) and 4:2:0 planes with stride = plane width; qp_cb / qp_cr = mapped chroma QPs */
 int      orc_deblock_table(int w, int h, int bd, int qp, int qp_cb, int qp_cr, const int *rows, int nrows, int16_t *y, int16_t *cb, int16_t *cr);
+/* sample adaptive offset with given parameters on 4:2:0 planes with stride = plane width (CL/SampleAdaptiveOffset.cpp SAOProcess; orc_sao.c) */
+typedef struct { int8_t mode, type, band, off[4]; } orc_sao_param;      /* per CTU and component: mode 0 off / 1 new / 2 merge; type: new 0..3 edge class, 4 band; merge 0 left, 1 above */
+int      orc_sao_picture(int w, int h, int bit_depth, int tile_cols, int tile_rows, int lf_across_tiles, int log2_offset_scale, const orc_sao_param *prm, int16_t *y, int16_t *cb, int16_t *cr);
 void     orc_get_counters(orc_enc *e, uint64_t out[4]); /* satd candidates, rd candidates, rd pixels, nodes */
 
 /* ---------------- leaf operators (individually testable; used by the golden-vector tests) -------- */

@@ -27,6 +27,10 @@ extern "C" __global__ void vvcx_leaf_scan_kernel(int w, int h, uint16_t *idx);
 extern "C" __global__ void vvcx_leaf_forest_kernel(VxParams p, const int32_t *rows, int n, int32_t *out);
 struct VxMipCase { int32_t w, h, mode, bit_depth, ref_off, pred_off; };
 extern "C" __global__ void vvcx_leaf_mip_kernel(const VxMipCase *cases, const int16_t *refs, int16_t *preds);
+extern "C" __global__ void vvcx_sao_copy_kernel_u8(VxSaoParams p);
+extern "C" __global__ void vvcx_sao_copy_kernel_u16(VxSaoParams p);
+extern "C" __global__ void vvcx_sao_kernel_u8(VxSaoParams p);
+extern "C" __global__ void vvcx_sao_kernel_u16(VxSaoParams p);
 extern "C" __global__ void vvcx_deblock_kernel_u8(VxDeblockParams p);
 extern "C" __global__ void vvcx_deblock_kernel_u16(VxDeblockParams p);
 extern "C" __global__ void vvcx_jccr_sign_kernel_u8(VxFrameDev *frames, int wc, int hc);
@@ -87,7 +91,8 @@ struct vvcx_handle {
   bool lmcs_on, lmcs_inverted; int16_t lmcs_fwd[1024], lmcs_inv[1024]; int32_t lmcs_pivot[17], lmcs_cadj[16];
   int16_t *lmcs_lut_d; void *lmcs_org_d; size_t lmcs_org_cap;
   std::vector<uint32_t> activity;               // per (frame, CTU) of the bound pictures: orders the stream queue of a launch, longest first
-  hipEvent_t ev0, ev1; float last_ms, last_deblock_ms;
+  hipEvent_t ev0, ev1; float last_ms, last_deblock_ms, last_sao_ms;
+  void *sao_tmp_d; size_t sao_tmp_cap; VxSaoEntry *sao_tab_d; size_t sao_tab_cap; uint8_t *sao_tile_d;      // vvcx_sao_bound_frames: picture copy, resolved parameters, CTU -> tile
   // a submitted, not yet collected launch (vvcx_submit_ctus .. vvcx_wait_ctus): staging the async copies read from / write to stays alive here
   bool pending; hipStream_t pend_stream; int pend_n; VxCtuRes *pend_res; int pend_cap;
   std::vector<VxStreamDesc> pend_sd; std::vector<int32_t> pend_task_ctu; std::vector<int> pend_src, pend_next; VxDqConst pend_dq[17 * 96];
@@ -196,6 +201,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   h->frames_d = nullptr; h->lev_d = nullptr; h->units_d = nullptr; h->stream_ctx_d = nullptr; h->scratch_d = nullptr; h->scratch_cap = 0;
   h->payload_d = nullptr; h->payload_off_d = nullptr; h->payload_cap_d = nullptr; h->arith_d = nullptr;
   h->streams_d = nullptr; h->task_ctu_d = nullptr; h->results_d = nullptr; h->task_cap = 0; h->stream_cap = 0; h->counters_d = nullptr;
+  h->sao_tmp_d = nullptr; h->sao_tmp_cap = 0; h->sao_tab_d = nullptr; h->sao_tab_cap = 0; h->sao_tile_d = nullptr; h->last_sao_ms = 0.f;
   h->dq_d = nullptr; h->lmcs_on = false; h->lmcs_inverted = false; h->lmcs_lut_d = nullptr; h->lmcs_org_d = nullptr; h->lmcs_org_cap = 0;
   const int F = cfg->max_frames;
   if (hipMalloc((void **) &h->frames_d, sizeof(VxFrameDev) * F) != hipSuccess || hipMalloc((void **) &h->lev_d, h->lev_frame * 2 * F) != hipSuccess ||
@@ -226,6 +232,7 @@ extern "C" void vvcx_destroy(vvcx_handle *h)
   (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d); (void) hipFree(h->wpp_progress_d); (void) hipFree(h->wpp_sync_d); (void) hipFree(h->wpp_sched_d); (void) hipFree(h->train_rows_d); (void) hipFree(h->train_n_d);
   (void) hipFree(h->payload_d); (void) hipFree(h->payload_off_d); (void) hipFree(h->payload_cap_d); (void) hipFree(h->arith_d);
   (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
+  (void) hipFree(h->sao_tmp_d); (void) hipFree(h->sao_tab_d); (void) hipFree(h->sao_tile_d);
   (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d); (void) hipFree(h->dq_d); (void) hipFree(h->lmcs_lut_d); (void) hipFree(h->lmcs_org_d);
   if (h->pending) (void) hipStreamSynchronize(h->pend_stream);
   (void) hipHostFree(h->pend_res);
@@ -760,6 +767,116 @@ extern "C" int vvcx_deblock_bound_frames(vvcx_handle *h, int beta_offset_div2, i
   return VVCX_OK;
 }
 extern "C" float vvcx_last_deblock_ms(const vvcx_handle *h) { return h ? h->last_deblock_ms : 0.f; }
+
+// ≙ SampleAdaptiveOffset::SAOProcess (CL/SampleAdaptiveOffset.cpp:617-670) with the caller's parameters prm[frame][ctu][component]: merges are resolved here
+// (xReconstructBlkSAOParams 265-290: the CTU to the left / above in the same tile, in raster order; invertQuantOffsets 147-170), the samples are filtered on the device
+// (vvcx_sao.hip) in place on the reconstruction planes.
+static int sao_resolve(const vvcx_sao_param *prm, int n_frames, int cw, int chh, int tc, int tr, int log2_offset_scale, std::vector<VxSaoEntry> &tab, std::vector<uint8_t> &tile)
+{
+  const int nctu = cw * chh;
+  tile.resize((size_t) nctu);
+  for (int a = 0; a < nctu; a++) {
+    int tx = 0, ty = 0;
+    for (int i = 0; i < tc; i++) if (a % cw >= (i * cw) / tc) tx = i;
+    for (int i = 0; i < tr; i++) if (a / cw >= (i * chh) / tr) ty = i;
+    tile[(size_t) a] = (uint8_t) (ty * tc + tx);
+  }
+  tab.resize((size_t) n_frames * nctu * 3);
+  for (int f = 0; f < n_frames; f++) for (int a = 0; a < nctu; a++) for (int c = 0; c < 3; c++) {
+    const vvcx_sao_param &p = prm[((size_t) f * nctu + a) * 3 + c];
+    VxSaoEntry &e = tab[((size_t) f * nctu + a) * 3 + c];
+    memset(&e, 0, sizeof e); e.type = -1;
+    if (p.mode == 0) continue;
+    if (p.mode == 1) {
+      if (p.type < 0 || p.type > 4 || p.band < 0 || p.band > 31) return fail(VVCX_ERR_ARG, "SAO parameters of frame %d CTU %d component %d: type %d band %d", f, a, c, p.type, p.band);
+      e.type = p.type; e.band = p.type == 4 ? p.band : 0;
+      for (int i = 0; i < 4; i++) e.off[i] = (int16_t) (p.offset[i] * (1 << log2_offset_scale));
+    } else if (p.mode == 2) {
+      const int left = p.type == 0, s = left ? a - 1 : a - cw;
+      if ((p.type != 0 && p.type != 1) || (left ? a % cw == 0 : a < cw) || tile[(size_t) s] != tile[(size_t) a])
+        return fail(VVCX_ERR_ARG, "SAO parameters of frame %d CTU %d component %d: no %s merge candidate in the tile", f, a, c, left ? "left" : "above");
+      e = tab[((size_t) f * nctu + s) * 3 + c];
+    } else return fail(VVCX_ERR_ARG, "SAO mode %d", p.mode);
+  }
+  return VVCX_OK;
+}
+static void sao_launch(VxSaoParams &p, int n_frames, size_t bps, hipStream_t stream)
+{
+  const dim3 grid((unsigned) ((p.pic_w + 255) / 256), (unsigned) p.pic_h, (unsigned) (3 * n_frames));
+  if (bps == 1) { hipLaunchKernelGGL(vvcx_sao_copy_kernel_u8, grid, dim3(256), 0, stream, p); hipLaunchKernelGGL(vvcx_sao_kernel_u8, grid, dim3(256), 0, stream, p); }
+  else { hipLaunchKernelGGL(vvcx_sao_copy_kernel_u16, grid, dim3(256), 0, stream, p); hipLaunchKernelGGL(vvcx_sao_kernel_u16, grid, dim3(256), 0, stream, p); }
+}
+extern "C" int vvcx_sao_bound_frames(vvcx_handle *h, const vvcx_sao_param *prm, int lf_across_tiles, int log2_offset_scale, void *hip_stream)
+{
+  NOT_PENDING(h);
+  if (!h || !prm) return fail(VVCX_ERR_ARG, "null argument");
+  if (!h->n_frames || !h->have_slice) return fail(VVCX_ERR_STATE, "no bound frames / slice");
+  if (log2_offset_scale < 0 || log2_offset_scale > 4) return fail(VVCX_ERR_ARG, "log2 offset scale outside 0..4");
+  for (size_t i = 0; i < h->next_idx.size(); i++)
+    if (h->next_idx[i] != (int) h->sub_ctus[i % (size_t) h->nsub].size()) return fail(VVCX_ERR_STATE, "the loop filters need every CTU of the bound pictures coded");
+  if (h->lmcs_on && !h->lmcs_inverted) return fail(VVCX_ERR_STATE, "LMCS slice: vvcx_lmcs_inverse_reco first (the loop filters work in the original domain)");
+  const int cw = h->ctus_w, chh = h->ctus_h, nctu = cw * chh;
+  std::vector<VxSaoEntry> tab; std::vector<uint8_t> tile;
+  const int rr = sao_resolve(prm, h->n_frames, cw, chh, h->cfg.tile_cols, h->cfg.tile_rows, log2_offset_scale, tab, tile);
+  if (rr != VVCX_OK) return rr;
+  DevGuard guard(h->cfg.device);
+  hipStream_t stream = (hipStream_t) hip_stream;
+  const size_t bps = h->cfg.bit_depth == 8 ? 1 : 2, ny = (size_t) h->cfg.pic_w * h->cfg.pic_h, per_frame = ny + 2 * (ny >> 2);
+  if (h->sao_tmp_cap < (size_t) h->n_frames * per_frame * bps) { (void) hipFree(h->sao_tmp_d); h->sao_tmp_d = nullptr; h->sao_tmp_cap = (size_t) h->n_frames * per_frame * bps; HIPCHK(hipMalloc(&h->sao_tmp_d, h->sao_tmp_cap)); }
+  if (h->sao_tab_cap < tab.size()) { (void) hipFree(h->sao_tab_d); h->sao_tab_d = nullptr; h->sao_tab_cap = tab.size(); HIPCHK(hipMalloc((void **) &h->sao_tab_d, tab.size() * sizeof(VxSaoEntry))); }
+  if (!h->sao_tile_d) HIPCHK(hipMalloc((void **) &h->sao_tile_d, (size_t) nctu));
+  HIPCHK(hipMemcpyAsync(h->sao_tab_d, tab.data(), tab.size() * sizeof(VxSaoEntry), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(h->sao_tile_d, tile.data(), (size_t) nctu, hipMemcpyHostToDevice, stream));
+  VxSaoParams p; memset(&p, 0, sizeof p);
+  p.frames = h->frames_d; p.table = h->sao_tab_d; p.tile_of_ctu = h->sao_tile_d; p.tmp = h->sao_tmp_d; p.tmp_frame = per_frame; p.tmp_comp[0] = 0; p.tmp_comp[1] = ny; p.tmp_comp[2] = ny + (ny >> 2);
+  p.pic_w = h->cfg.pic_w; p.pic_h = h->cfg.pic_h; p.ctus_w = cw; p.ctus_h = chh; p.bit_depth = h->cfg.bit_depth; p.chroma = h->cfg.chroma; p.lf_across_tiles = lf_across_tiles != 0;
+  HIPCHK(hipEventRecord(h->ev0, stream));
+  sao_launch(p, h->n_frames, bps, stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev1, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  HIPCHK(hipEventElapsedTime(&h->last_sao_ms, h->ev0, h->ev1));
+  return VVCX_OK;
+}
+// the same kernels on one picture in host memory (uint16 planes, stride = plane width; filtered in place): the leaf entry the filter is pinned through
+extern "C" int vvcx_sao_picture(int pic_w, int pic_h, int bit_depth, int tile_cols, int tile_rows, const vvcx_sao_param *prm, int lf_across_tiles, int log2_offset_scale,
+                                uint16_t *y, uint16_t *cb, uint16_t *cr, int device)
+{
+  if (!prm || !y || !cb || !cr) return fail(VVCX_ERR_ARG, "null argument");
+  if (pic_w < 8 || pic_h < 8 || (pic_w & 7) || (pic_h & 7) || pic_w > 16384 || pic_h > 16384 || bit_depth < 8 || bit_depth > 12 || tile_cols < 1 || tile_rows < 1 ||
+      tile_cols > (pic_w + 127) / 128 || tile_rows > (pic_h + 127) / 128 || tile_cols * tile_rows > 255 || log2_offset_scale < 0 || log2_offset_scale > 4)
+    return fail(VVCX_ERR_ARG, "vvcx_sao_picture: picture size / bit depth / tiles / offset scale");
+  const int cw = (pic_w + 127) / 128, chh = (pic_h + 127) / 128;
+  std::vector<VxSaoEntry> tab; std::vector<uint8_t> tile;
+  const int rr = sao_resolve(prm, 1, cw, chh, tile_cols, tile_rows, log2_offset_scale, tab, tile);
+  if (rr != VVCX_OK) return rr;
+  DevGuard guard(device);
+  const size_t ny = (size_t) pic_w * pic_h, nc = ny >> 2, per_frame = ny + 2 * nc;
+  uint16_t *pl_d = nullptr, *tmp_d = nullptr; VxFrameDev *fd_d = nullptr; VxSaoEntry *tab_d = nullptr; uint8_t *tile_d = nullptr;
+  int rc = VVCX_OK;
+  if (hipMalloc((void **) &pl_d, per_frame * 2) != hipSuccess || hipMalloc((void **) &tmp_d, per_frame * 2) != hipSuccess || hipMalloc((void **) &fd_d, sizeof(VxFrameDev)) != hipSuccess ||
+      hipMalloc((void **) &tab_d, tab.size() * sizeof(VxSaoEntry)) != hipSuccess || hipMalloc((void **) &tile_d, tile.size()) != hipSuccess)
+    rc = fail(VVCX_ERR_DEVICE, "hipMalloc failed for the SAO of a %dx%d picture", pic_w, pic_h);
+  if (rc == VVCX_OK) {
+    VxFrameDev fd; memset(&fd, 0, sizeof fd);
+    fd.rec[0] = pl_d; fd.rec[1] = pl_d + ny; fd.rec[2] = pl_d + ny + nc; fd.stride[0] = pic_w; fd.stride[1] = fd.stride[2] = pic_w >> 1;
+    VxSaoParams p; memset(&p, 0, sizeof p);
+    p.frames = fd_d; p.table = tab_d; p.tile_of_ctu = tile_d; p.tmp = tmp_d; p.tmp_frame = per_frame; p.tmp_comp[0] = 0; p.tmp_comp[1] = ny; p.tmp_comp[2] = ny + nc;
+    p.pic_w = pic_w; p.pic_h = pic_h; p.ctus_w = cw; p.ctus_h = chh; p.bit_depth = bit_depth; p.chroma = 1; p.lf_across_tiles = lf_across_tiles != 0;
+    bool ok = hipMemcpy(pl_d, y, ny * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(pl_d + ny, cb, nc * 2, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(pl_d + ny + nc, cr, nc * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(fd_d, &fd, sizeof fd, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(tab_d, tab.data(), tab.size() * sizeof(VxSaoEntry), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(tile_d, tile.data(), tile.size(), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+      sao_launch(p, 1, 2, 0);
+      ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipMemcpy(y, pl_d, ny * 2, hipMemcpyDeviceToHost) == hipSuccess &&
+           hipMemcpy(cb, pl_d + ny, nc * 2, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(cr, pl_d + ny + nc, nc * 2, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (!ok) rc = fail(VVCX_ERR_DEVICE, "SAO of a picture: a HIP call failed");
+  }
+  (void) hipFree(pl_d); (void) hipFree(tmp_d); (void) hipFree(fd_d); (void) hipFree(tab_d); (void) hipFree(tile_d);
+  return rc;
+}
+extern "C" float vvcx_last_sao_ms(const vvcx_handle *h) { return h ? h->last_sao_ms : 0.f; }
 
 // the same two kernels on a picture the caller describes by a CU table (host memory in, host memory out): the unit maps the kernels read are built here from the rows
 extern "C" int vvcx_deblock_cu_table(int pic_w, int pic_h, int bit_depth, int qp, int qp_cb, int qp_cr, int beta_offset_div2, int tc_offset_div2,

@@ -103,6 +103,18 @@ struct VxDeblockParams {     // vvcx_deblock.hip
   int32_t beta_off2, tc_off2, dir;      // cfg LoopFilterBetaOffset_div2 / LoopFilterTcOffset_div2; 0 = vertical edges, 1 = horizontal edges
 };
 
+// vvcx_sao.hip: resolved parameters of one (frame, CTU, component): type -1 off, 0..3 edge class (0 / 90 / 135 / 45 degrees), 4 band; offsets scaled, in the order
+// full valley, half valley, half peak, full peak (edge) or band, band + 1, band + 2, band + 3 (band)
+struct VxSaoEntry { int8_t type, band; int16_t off[4]; int16_t pad_; };
+struct VxSaoParams {
+  const VxFrameDev *frames;
+  const VxSaoEntry *table;        // [frame][ctu][3]
+  const uint8_t *tile_of_ctu;     // [ctu]
+  void *tmp;                      // copy of the deblocked pictures: per frame tmp_frame samples, component c at tmp_comp[c], rows of the plane's width
+  uint64_t tmp_frame, tmp_comp[3];
+  int32_t pic_w, pic_h, ctus_w, ctus_h, bit_depth, chroma, lf_across_tiles, pad_;
+};
+
 // per-stream scratch layout (bytes)
 #define VXD_STORE_REC   (128 * 128 * 2)
 #define VXD_STORE_UNITS (32 * 32 * (int) sizeof(VxUnit))

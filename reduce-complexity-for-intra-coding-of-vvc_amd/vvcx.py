@@ -128,6 +128,17 @@ class _SliceCfg(C.Structure):
                 ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32), ("gop_size", C.c_int32), ("dep_quant", C.c_int32)]
 
 
+def sao_picture(planes, bit_depth, prm, tile_cols=1, tile_rows=1, lf_across_tiles=1, log2_offset_scale=0, device=0, lib_path=None):
+    """vvcx_sao_picture: sample adaptive offset with per-CTU parameters prm int8 [ctus, 3, 7] on three host planes -> filtered uint16 planes"""
+    L = load_library(lib_path)
+    out = [np.ascontiguousarray(p.astype(np.uint16)) for p in planes]
+    h, w = out[0].shape
+    prm = np.ascontiguousarray(prm, np.int8)
+    L.vvcx_sao_picture.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    _chk(L, L.vvcx_sao_picture(w, h, bit_depth, tile_cols, tile_rows, prm.ctypes.data, int(lf_across_tiles), int(log2_offset_scale), out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, device))
+    return out
+
+
 def lmcs_analyze_device(ptrs, strides, width, height, bit_depth, qp, update_ctrl=1, lib_path=None):
     """vvcx_lmcs_analyze_device: the same analysis on planes that are in device memory (ptrs: three device addresses, strides in samples)"""
     L = load_library(lib_path)
@@ -215,6 +226,15 @@ class VvcxEncoder:
         self.L.vvcx_last_deblock_ms.argtypes = [C.c_void_p]
         self._chk(self.L.vvcx_deblock_bound_frames(self.h, beta_offset_div2, tc_offset_div2, None))
         return float(self.L.vvcx_last_deblock_ms(self.h))
+
+    def sao_bound_frames(self, prm, lf_across_tiles=1, log2_offset_scale=0):
+        """vvcx_sao_bound_frames: prm int8 [n_frames, ctus, 3, 7] = {mode, type, band, four offsets} per CTU and component; returns the kernel time in ms"""
+        prm = np.ascontiguousarray(prm, np.int8).reshape(self.n_frames, self.ctus_per_frame, 3, 7)
+        self.L.vvcx_sao_bound_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.L.vvcx_last_sao_ms.restype = C.c_float
+        self.L.vvcx_last_sao_ms.argtypes = [C.c_void_p]
+        self._chk(self.L.vvcx_sao_bound_frames(self.h, prm.ctypes.data, int(lf_across_tiles), int(log2_offset_scale), None))
+        return float(self.L.vvcx_last_sao_ms(self.h))
 
     def get_levels(self, frame):
         """quantised levels of the coded picture: three int16 planes (Y, Cb, Cr)"""

@@ -473,6 +473,32 @@ def gen_deblock():
                         forced_meta=np.array(fmeta, np.int32), forced_planes=np.concatenate(fplanes))
 
 
+def gen_sao():
+    """The reference's SampleAdaptiveOffset::SAOProcess with seeded per-CTU parameters (all five types, merges, every tile-border case) on seeded pictures: the fixture keeps
+    the filtered planes; the parameters and the pictures are regenerated by the tests (oracle_lib.sao_params / SAO_CASES)."""
+    import importlib, sys
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+    R.ref_env_sao.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    R.ref_env_set_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    planes_all = []
+    for (W, H, bd, tc, tr, lf, sc, seed) in O.SAO_CASES:
+        pl = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=0.6, oriented=20.0, screen=0.3)
+        prm = O.sao_params(seed, W, H, tc, tr)
+        env = R.ref_env_create(W, H, bd); R.ref_env_set_tiles(env, tc, tr); R.ref_env_reset(env)
+        for c in range(3):
+            a = np.ascontiguousarray(pl[c].astype(np.int16)); R.ref_env_set_reco(env, c, P(a), a.shape[1])
+        outs = [np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)]
+        assert R.ref_env_sao(env, P(np.ascontiguousarray(prm)), lf, sc, P(outs[0]), P(outs[1]), P(outs[2])) == 0
+        mine = O.sao_picture(pl, W, H, bd, prm, tc, tr, lf, sc)
+        changed = [int((outs[c] != pl[c]).sum()) for c in range(3)]
+        print("sao", W, H, bd, "tiles", tc, tr, "across", lf, "samples changed:", changed, "oracle equal:", [bool(np.array_equal(mine[c], outs[c])) for c in range(3)])
+        assert min(changed) > 0
+        planes_all += [o.ravel() for o in outs]
+    np.savez_compressed(os.path.join(HERE, "sao.npz"), planes=np.concatenate(planes_all))
+
+
 def gen_mip():
     """Matrix-based intra prediction (MatrixIntraPrediction::prepareInputForPred + predBlock of the reference) for every block shape MIP
     allows and every mode, from random reference samples."""
@@ -1002,6 +1028,8 @@ if __name__ == "__main__":
         gen_lmcs_analysis(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bitstream_wpp":
         gen_bitstream_wpp(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sao":
+        gen_sao(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "deblock":
         gen_deblock(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "chroma_qp":
@@ -1040,5 +1068,5 @@ if __name__ == "__main__":
         gen_ts(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict(); gen_decision_helpers(); gen_ts(); gen_bitstream_ts(); gen_isp(); gen_bitstream_isp(); gen_lmcs(); gen_bitstream_wpp(); gen_lmcs_analysis()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict(); gen_decision_helpers(); gen_ts(); gen_bitstream_ts(); gen_isp(); gen_bitstream_isp(); gen_lmcs(); gen_bitstream_wpp(); gen_lmcs_analysis(); gen_sao()
     print("done")

@@ -523,6 +523,36 @@ def test_deblocking_filter(case):
     enc.close()
 
 
+def test_sample_adaptive_offset_filter_on_the_gpu():
+    """The SAO kernels (csrc/vvcx_sao.hip) on the GPU: vvcx_sao_picture against the reference's planes (tests/golden/sao.npz), and vvcx_sao_bound_frames behind a search
+    and the deblocking filter against the oracle's filter on the same reconstruction (four pictures of 3 x 2 tiles, without filtering across tile borders)."""
+    import torch
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sao.npz"))["planes"]; off = 0
+    for (W, H, bd, tc, tr, lf, sc, seed) in O.SAO_CASES:
+        pl = pkg.synth_frame(W, H, 0, bd, seed, chroma_texture=0.6, oriented=20.0, screen=0.3)
+        prm = O.sao_params(seed, W, H, tc, tr)
+        got = pkg.vvcx.sao_picture(pl, bd, prm, tc, tr, lf, sc)
+        for c in range(3):
+            exp = g[off:off + pl[c].size].reshape(pl[c].shape); off += pl[c].size
+            assert np.array_equal(got[c].astype(np.int16), exp), (W, H, bd, c)
+    W, H, qp, n = 384, 256, 32, 4
+    sp = pkg.slice_params(qp)
+    frames = [pkg.synth_frame(W, H, i, 8, 60 + i, chroma_texture=0.5) for i in range(n)]
+    enc = pkg.VvcxEncoder(W, H, 8, tile_cols=3, tile_rows=2, tools=pkg.TOOLS_DEFAULT, max_frames=n)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    dev = [([torch.from_numpy(p).cuda() for p in f], [torch.zeros(p.shape, dtype=torch.uint8, device="cuda") for p in f]) for f in frames]
+    enc.bind_frames([([t.data_ptr() for t in o], [t.data_ptr() for t in r], [t.shape[1] for t in o]) for o, r in dev])
+    enc.compress_bound_frames(); enc.deblock_bound_frames()
+    before = [[t.cpu().numpy() for t in r] for _, r in dev]
+    prm = np.stack([O.sao_params(70 + i, W, H, 3, 2) for i in range(n)])
+    ms = enc.sao_bound_frames(prm, lf_across_tiles=0)
+    assert ms > 0
+    for i in range(n):
+        exp = O.sao_picture(before[i], W, H, 8, prm[i], 3, 2, 0, 0)
+        assert all(np.array_equal(dev[i][1][c].cpu().numpy().astype(np.int16), exp[c]) for c in range(3)), i
+    enc.close()
+
+
 def test_deblocking_of_isp_transform_edges_against_the_reference():
     """vvcx_deblock_cu_table on the GPU: CU tables with a forced random ispMode on most luma CUs; the expectation is the reference's own LoopFilter output
     (tests/golden/deblock.npz, forced_planes), not the oracle's."""

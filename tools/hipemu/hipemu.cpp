@@ -32,11 +32,11 @@ void launch(std::function<void()> body, dim3 grid, dim3 block)
 {
   const size_t STK = 256 * 1024;
   g_body = &body; g_blockDim = block; g_gridDim = grid;
-  for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
+  for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
     Block b; b.n = block.x; b.arrived = 0; b.gen = 0;
     memset(b.warrived, 0, sizeof b.warrived); memset(b.wgen, 0, sizeof b.wgen);
     b.fibers.resize(b.n);
-    g_block = &b; g_blockIdx = dim3(bx, by);
+    g_block = &b; g_blockIdx = dim3(bx, by, bz);
     for (unsigned t = 0; t < b.n; t++) {
       Fiber &f = b.fibers[t]; f.stack = (char *) malloc(STK); f.tidx = dim3(t); f.done = false;
       // initial frame: six zeroed callee-saved registers, then the return address = trampoline; keep the
