@@ -305,13 +305,12 @@ def main():
         # third kernel pair (not part of the timed step): sample adaptive offset with seeded per-CTU parameters on the deblocked pictures - an HBM-bound pass
         # (every sample read once and written once; the copy the filter reads its unfiltered neighbours from doubles the traffic)
         try:
-            import oracle_lib as O_
-            prm = np.stack([O_.sao_params(900 + i, W, H, tc, tr) for i in range(args.frames)])
+            prm = np.stack([pkg.sao_test_params(900 + i, W, H, tc, tr) for i in range(args.frames)])
             sao_ms = enc.sao_bound_frames(prm, lf_across_tiles=1)
             sao_bytes = args.frames * (W * H * 3 // 2) * (2 if bd == 10 else 1) * 2
             out["sao"] = {"kernel": "vvcx_sao_copy_kernel + vvcx_sao_kernel (%s)" % ("u8" if bd == 8 else "u16"), "launches": 2, "ms": sao_ms, "frames": args.frames, "algorithmic_bytes": sao_bytes,
                           "achieved_GBps": sao_bytes / (sao_ms / 1e3) / 1e9 if sao_ms > 0 else None, "frac_of_hbm_peak": sao_bytes / (sao_ms / 1e3) / 1e9 / HBM_PEAK_GBS if sao_ms > 0 else None,
-                          "note": "parameters are seeded test values (tests/oracle_lib.sao_params: about 80 % of the CTUs filtered); the parameter decision is not part of the library"}
+                          "note": "parameters are seeded test values (synth.sao_test_params: about 80 % of the CTUs filtered); the parameter decision is not part of the library"}
         except Exception as ex:
             out["sao"] = {"error": str(ex)}
         if not args.no_cpu_baseline and world == 1:

@@ -285,37 +285,10 @@ def lmcs_test_picture(pkg, W, H, bd, seed, limited, tex100, ori100, scr100, kind
 
 
 # ---- sample adaptive offset (oracle/orc_sao.c): the filter with given per-CTU parameters
-def _tile_of(i, n, t):
-    return max(k for k in range(t) if i >= (k * n) // t)
-
-
 def sao_params(seed, w, h, tile_cols=1, tile_rows=1):
-    """seeded per-CTU SAO parameters [nctu, 3, 7] int8 = {mode 0 off / 1 new / 2 merge, type (new: 0..3 edge class, 4 band; merge: 0 left, 1 above), band position,
-    four coded offsets}; a merge only where the candidate CTU exists in the same tile (shared by the fixture generator and the tests)"""
-    g = np.random.default_rng(seed)
-    cw, ch = (w + 127) // 128, (h + 127) // 128
-    prm = np.zeros((cw * ch, 3, 7), np.int8)
-    for a in range(cw * ch):
-        cx, cy = a % cw, a // cw
-        for c in range(3):
-            r = g.random()
-            mode = 0 if r < 0.2 else 2 if r < 0.45 else 1
-            if mode == 2:
-                left = bool(g.integers(0, 2))
-                ok_l = cx > 0 and _tile_of(cx - 1, cw, tile_cols) == _tile_of(cx, cw, tile_cols)
-                ok_a = cy > 0 and _tile_of(cy - 1, ch, tile_rows) == _tile_of(cy, ch, tile_rows)
-                if left and ok_l:
-                    prm[a, c, :2] = (2, 0)
-                elif ok_a:
-                    prm[a, c, :2] = (2, 1)
-                elif ok_l:
-                    prm[a, c, :2] = (2, 0)
-                else:
-                    mode = 1
-            if mode == 1:
-                t = int(g.integers(0, 5))
-                prm[a, c] = [1, t, int(g.integers(0, 32)) if t == 4 else 0] + [int(v) for v in g.integers(-7, 8, 4)]
-    return prm
+    """seeded per-CTU SAO parameters (the package's synthetic-input generator, shared by the fixture generator, the tests and bench.py)"""
+    import importlib
+    return importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd").sao_test_params(seed, w, h, tile_cols, tile_rows)
 
 
 def sao_picture(planes, w, h, bit_depth, prm, tile_cols=1, tile_rows=1, lf_across_tiles=1, log2_offset_scale=0):
