@@ -3119,6 +3119,10 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       __syncthreads();
     }
     if (VVCX_STAMP && VTX == 0) { PROF(38) += (unsigned long long) (q1 - q0); PROF(39) += (unsigned long long) (q2 - q1); PROF(40) += (unsigned long long) (q3 - q2); PROF(41) += (unsigned long long) (STAMP() - q3); PROF(44) += 1; PROF(45) += (unsigned long long) nA; }
+#ifdef VVCX_STAMP_PASS
+    // diagnostic build: per kind of pass (lfnstIdx 0 / 1 / 2 without MTS, then the MTS passes of transform groups 0..3) the number of chunks and the clocks of the trellis round
+    if (VTX == 0) { const int kind = psMts ? 3 + psGrp : psLf; PROF(16 + kind) += 1; PROF(23 + kind) += (unsigned long long) (q2 - q1); }
+#endif
     // ---- per candidate: DCT-II, then its MTS items in transform order, strict < (xRecurIntraCodingLumaQT 3579-3616)
     if ((int) VTX < nA) {
       const int i = VTX, c = c0 + i;
@@ -4463,7 +4467,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
     const int d = L.d;
 #if VVCX_STAMP
     const long long tph = STAMP(); const int phs = f.phase;
-#if !defined(VVCX_STAMP_DQ) && !defined(VVCX_STAMP_ISP)
+#if !defined(VVCX_STAMP_DQ) && !defined(VVCX_STAMP_ISP) && !defined(VVCX_STAMP_PASS)
     struct PhStamp { long long t; int ph; __device__ ~PhStamp() { const int slot = ph < 12 ? 16 + ph : ph == PH_EXIT2 ? 1 : ph == PH_A3_DONE ? 28 : ph == PH_PASS ? 29 : ph == PH_NEXT_PASS ? 31 : 47; PROF(slot) += (unsigned long long) (STAMP() - t); PROF(30) += 1; } } phstamp = { tph, phs };
 #endif
 #endif

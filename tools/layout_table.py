@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """What a picture layout costs: slice_data bytes (the device's arithmetic coder) and PSNR of the same 1080p pictures coded as one tile per picture (the reference cfg's
 layout), one tile + WaveFrontSynchro, 4 x 2 tiles and 15 x 9 tiles (one CTU per tile: bench.py's default), at QP 22 / 27 / 32 / 37 with the full tool set, and the
-Bjontegaard delta rate of every layout against the cfg's.  All sixteen encodes are submitted at once on streams of their own (vvcx_submit_ctus): the one-tile pictures
-are single 135-CTU chains that take minutes whatever else runs.
+Bjontegaard delta rate of every layout against the cfg's.  One process per QP, side by side on the GPU: the one-tile pictures are single 135-CTU chains that take about
+twelve minutes whatever else runs.
 
-  python tools/layout_table.py [--frames 8] [--out profiles/r04_layout_table.json]      (needs a GPU; ~15 minutes)
+  python tools/layout_table.py --layouts 1x1 --out a.json ; python tools/layout_table.py --layouts 1x1+wpp,4x2,15x9 --out b.json      (GPU; two calls of ~13 and ~7 minutes)
+  python tools/layout_table.py --merge a.json b.json --out profiles/r04_layout_table.json                                                (no GPU)
 """
 import argparse
 import importlib
@@ -21,23 +22,15 @@ from bd_rate import bd_rate      # noqa: E402
 LAYOUTS = (("1x1", 1, 1, False), ("1x1+wpp", 1, 1, True), ("4x2", 4, 2, False), ("15x9", 15, 9, False))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--frames", type=int, default=8)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--qps", type=str, default="22,27,32,37")
-    ap.add_argument("--layouts", type=str, default=",".join(l[0] for l in LAYOUTS))
-    ap.add_argument("--out", type=str, default=None)
-    a = ap.parse_args()
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # the encodes of a run overlap on streams of their own: do not let them share the default four hardware queues
+def encode_rows(a):
+    """child: the encodes of this process one after the other (blocking calls), rows as JSON on the last stdout line"""
     import torch
     pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
     W, H = a.width, a.height
-    ctus = ((W + 127) // 128) * ((H + 127) // 128)
+    cw, chh = (W + 127) // 128, (H + 127) // 128
     frames = [pkg.synth_frame(W, H, poc, 8, 1000 + poc, chroma_texture=0.5) for poc in range(a.frames)]
     org = [[torch.from_numpy(p).cuda() for p in f] for f in frames]
-    jobs = []
+    rows = []
     for qp in [int(v) for v in a.qps.split(",")]:
         for name, tc, tr, wpp in LAYOUTS:
             if name not in a.layouts.split(","):
@@ -48,57 +41,70 @@ def main():
             enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
             rec = [[torch.zeros_like(t) for t in f] for f in org]
             enc.bind_frames([([t.data_ptr() for t in o], [t.data_ptr() for t in r], [t.shape[1] for t in o]) for o, r in zip(org, rec)])
-            stream = torch.cuda.Stream()
-            tasks = [(f, c) for f in range(a.frames) for t in range(tc * tr) for c in pkg.tile_ctus((W + 127) // 128, (H + 127) // 128, tc, tr, t)]
-            if wpp:                                        # rows of a picture top-down, CTU by CTU along the anti-diagonals (no row ahead of the row above it)
-                cw, chh = (W + 127) // 128, (H + 127) // 128
-                tasks = [(f, y * cw + x) for f in range(a.frames) for y in range(chh) for x in range(cw)]
-            n = enc.submit_ctus(tasks, stream.cuda_stream)
-            jobs.append(dict(qp=qp, layout=name, tc=tc, tr=tr, enc=enc, rec=rec, n=n, stream=stream, t0=time.time(), done=False))
-    t0 = time.time()
-    while not all(j["done"] for j in jobs):
-        time.sleep(20)
-        for j in jobs:
-            if not j["done"] and j["enc"].poll_ctus():
-                j["enc"].wait_ctus(j["n"]); j["done"] = True; j["seconds"] = time.time() - j["t0"]
-        print("[layout] %4.0f s: %d of %d encodes finished" % (time.time() - t0, sum(j["done"] for j in jobs), len(jobs)), flush=True)
+            t0 = time.time()
+            enc.compress_bound_frames()
+            torch.cuda.synchronize()
+            secs = time.time() - t0
+            nbytes = sum(len(enc.get_payload(f, t)) for f in range(a.frames) for t in range(tc * tr))
+            sse = [0.0, 0.0, 0.0]; npx = [0, 0, 0]
+            for o, r in zip(org, rec):
+                for c in range(3):
+                    d = o[c].to(torch.float64) - r[c].to(torch.float64)
+                    sse[c] += float((d * d).sum().item()); npx[c] += d.numel()
+            psnr = [10 * np.log10(255.0 ** 2 / (sse[c] / npx[c])) for c in range(3)]
+            rows.append(dict(qp=qp, layout=name, bits=8 * nbytes, psnr_y=psnr[0], psnr_u=psnr[1], psnr_v=psnr[2], psnr_yuv=(6 * psnr[0] + psnr[1] + psnr[2]) / 8,
+                             seconds=secs, kernel_ms=enc.last_kernel_ms(), ctus=a.frames * cw * chh, sharing="one process per QP ran side by side on the GPU"))
+            print("QP %d %-8s %10d bits  %.3f dB Y  %.3f dB YUV  kernel %.1f s" % (qp, name, 8 * nbytes, psnr[0], rows[-1]["psnr_yuv"], enc.last_kernel_ms() / 1e3), flush=True)
+            enc.close()
+    print("ROWS " + json.dumps(rows), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--qps", type=str, default="22,27,32,37")
+    ap.add_argument("--layouts", type=str, default=",".join(l[0] for l in LAYOUTS))
+    ap.add_argument("--out", type=str, default=None)
+    ap.add_argument("--merge", type=str, nargs="*", default=None, help="no GPU: merge the rows of earlier runs' JSON files into --out and compute the delta rates")
+    ap.add_argument("--child", action="store_true")
+    a = ap.parse_args()
+    if a.child:
+        return encode_rows(a)
     rows = []
-    for j in jobs:
-        enc = j["enc"]
-        nbytes = sum(len(enc.get_payload(f, t)) for f in range(a.frames) for t in range(j["tc"] * j["tr"]))
-        sse = [0.0, 0.0, 0.0]; npx = [0, 0, 0]
-        for o, r in zip(org, j["rec"]):
-            for c in range(3):
-                d = o[c].to(torch.float64) - r[c].to(torch.float64)
-                sse[c] += float((d * d).sum().item()); npx[c] += d.numel()
-        psnr = [10 * np.log10(255.0 ** 2 / (sse[c] / npx[c])) for c in range(3)]
-        rows.append(dict(qp=j["qp"], layout=j["layout"], bits=8 * nbytes, psnr_y=psnr[0], psnr_u=psnr[1], psnr_v=psnr[2], psnr_yuv=(6 * psnr[0] + psnr[1] + psnr[2]) / 8,
-                         seconds_alone_or_shared=j["seconds"], kernel_ms=enc.last_kernel_ms(), ctus=a.frames * ctus))
-        print("QP %d %-8s %10d bits  %.3f dB Y  %.3f dB YUV  kernel %.1f s" % (j["qp"], j["layout"], 8 * nbytes, psnr[0], rows[-1]["psnr_yuv"], enc.last_kernel_ms() / 1e3), flush=True)
-        enc.close()
-    out = {"workload": "%dx%d 8-bit 4:2:0, %d synthetic frames, tools 0xfff, QP %s" % (W, H, a.frames, a.qps), "rows": rows, "bd_rate_vs_1x1_percent": {}}
+    if a.merge is not None:
+        for f in a.merge:
+            rows += json.load(open(f))["rows"]
+    else:
+        # one process per QP (each runs its layouts one after the other): the one-tile pictures are single 135-CTU chains of many minutes, and encodes of one process would
+        # queue behind each other's device allocations.  This process never touches the GPU; it prints a line while the children work.
+        import subprocess
+        kids = [(qp, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", "--frames", str(a.frames), "--width", str(a.width), "--height", str(a.height), "--qps", qp,
+                                       "--layouts", a.layouts], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)) for qp in a.qps.split(",")]
+        t0 = time.time()
+        while any(k.poll() is None for _, k in kids):
+            time.sleep(30)
+            print("[layout] %4.0f s: %d of %d processes finished" % (time.time() - t0, sum(k.poll() is not None for _, k in kids), len(kids)), flush=True)
+        for qp, k in kids:
+            outp = k.stdout.read()
+            line = [l for l in outp.split("\n") if l.startswith("ROWS ")]
+            if k.returncode != 0 or not line:
+                print("QP %s failed:\n%s" % (qp, outp[-2000:]), flush=True)
+                continue
+            print("\n".join(l for l in outp.split("\n") if l.startswith("QP ")), flush=True)
+            rows += json.loads(line[-1][5:])
+    out = {"workload": "%dx%d 8-bit 4:2:0, %d synthetic frames, tools 0xfff, QP %s" % (a.width, a.height, a.frames, a.qps), "rows": rows, "bd_rate_vs_1x1_percent": {}}
     ref = sorted([r for r in rows if r["layout"] == "1x1"], key=lambda r: r["qp"])
-    if len(ref) >= 4:
-        for name in sorted({r["layout"] for r in rows} - {"1x1"}):
-            t = sorted([r for r in rows if r["layout"] == name], key=lambda r: r["qp"])
+    for name in sorted({r["layout"] for r in rows} - {"1x1"}):
+        t = sorted([r for r in rows if r["layout"] == name], key=lambda r: r["qp"])
+        if len(ref) >= 4 and [r["qp"] for r in t] == [r["qp"] for r in ref]:
             out["bd_rate_vs_1x1_percent"][name] = {"y": bd_rate([r["bits"] for r in ref], [r["psnr_y"] for r in ref], [r["bits"] for r in t], [r["psnr_y"] for r in t]),
                                                    "yuv": bd_rate([r["bits"] for r in ref], [r["psnr_yuv"] for r in ref], [r["bits"] for r in t], [r["psnr_yuv"] for r in t]),
                                                    "bits_ratio_per_qp": [t_["bits"] / r_["bits"] for r_, t_ in zip(ref, t)]}
     print(json.dumps(out["bd_rate_vs_1x1_percent"]))
     if a.out:
-        path = os.path.join(ROOT, a.out) if not os.path.isabs(a.out) else a.out
-        if os.path.exists(path):                            # a second run with other --layouts adds its rows (the one-tile chains take a call of their own)
-            old = json.load(open(path))
-            rows = [r for r in old["rows"] if (r["qp"], r["layout"]) not in {(q["qp"], q["layout"]) for q in rows}] + rows
-            out["rows"] = rows
-            ref = sorted([r for r in rows if r["layout"] == "1x1"], key=lambda r: r["qp"])
-            for name in sorted({r["layout"] for r in rows} - {"1x1"}):
-                t = sorted([r for r in rows if r["layout"] == name], key=lambda r: r["qp"])
-                if len(ref) >= 4 and len(t) == len(ref):
-                    out["bd_rate_vs_1x1_percent"][name] = {"y": bd_rate([r["bits"] for r in ref], [r["psnr_y"] for r in ref], [r["bits"] for r in t], [r["psnr_y"] for r in t]),
-                                                           "yuv": bd_rate([r["bits"] for r in ref], [r["psnr_yuv"] for r in ref], [r["bits"] for r in t], [r["psnr_yuv"] for r in t]),
-                                                           "bits_ratio_per_qp": [t_["bits"] / r_["bits"] for r_, t_ in zip(ref, t)]}
-        json.dump(out, open(path, "w"), indent=1)
+        json.dump(out, open(os.path.join(ROOT, a.out) if not os.path.isabs(a.out) else a.out, "w"), indent=1)
 
 
 if __name__ == "__main__":

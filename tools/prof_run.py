@@ -34,3 +34,7 @@ if os.environ.get("VVCX_STAMP_DQ"):
 if os.environ.get("VVCX_STAMP_ISP"):
     print("ISP wave 0: candidates %d  sub-partitions %d  whole candidate %.3e | refs + prediction %.3e  forward transform %.3e  trellis %.3e  dequant + inverse + SSE %.3e  rate %.3e" % (pr[22], pr[23], pr[21], pr[19], pr[16], pr[17], pr[18], pr[20]))
     print("ISP controller: begin + sort %.3e  next-mode %.3e (%d calls)  result replay %.3e  batch building %.3e (%d batches)" % (pr[24], pr[27], pr[28], pr[26], pr[25], pr[29]))
+if os.environ.get("VVCX_STAMP_PASS"):
+    kinds = ["lfnst 0", "lfnst 1", "lfnst 2", "mts grp 0", "mts grp 1", "mts grp 2", "mts grp 3"]
+    for i, k in enumerate(kinds):
+        print("pass %-10s chunks %9d  trellis round clocks %.3e  (%.0f per chunk)" % (k, pr[16 + i], pr[23 + i], pr[23 + i] / max(1.0, pr[16 + i])))
