@@ -580,10 +580,10 @@ __device__ inline int wave_depquant(int16_t *cf_g, int buf_off, uint8_t *scratch
   // the tables fit behind the decisions in the rate-estimator scratch + tmp for all but the 32 x 32-coefficient blocks
   // (and pay for themselves from 64 positions on)
   if (imin(32, w) * imin(32, h) >= VXD_DQ_TAB_MIN && 240 + 2 * imin(32, w) * imin(32, h) + DQ_TAB_BYTES <= (int) (sizeof(WaveScratch) + sizeof(int32_t) * BUF))      // (2000 bytes: up to 256 positions)
-    wave_depquant_batch<1>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, wave_, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
+    wave_depquant_batch<1>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, wave_, DQ_ABS_SINGLE + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
   else
-    wave_depquant_batch<0>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, wave_, 64 + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
-  return uni(L.dq_abs[64 + wave_]);
+    wave_depquant_batch<0>(1, cf, 0, scratch + VXD_OFF_DQ + (size_t) wave_ * VXD_DQ_WAVE, 0, wave_, DQ_ABS_SINGLE + wave_, ci, 0, cbf_ctx, 0u, w, h, comp, zo, lfnst, lane, qidx);
+  return uni(L.dq_abs[DQ_ABS_SINGLE + wave_]);
 }
 
 // Quantizer::dequantBlock (741-810) for all coefficients of a block at once.  The quantiser state in front of a scan position is a function of the

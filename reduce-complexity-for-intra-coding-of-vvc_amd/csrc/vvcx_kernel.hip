@@ -133,6 +133,7 @@ struct Tables {                    // constant tables staged once per workgroup 
   uint8_t  cg_inv[84], grp_inv[228];     // their inverses: raster position (y * width + x) -> scan index, same table offsets
 };
 
+#define DQ_ABS_SINGLE 64
 #define RC_LIST 320
 // per-wave scratch that the rate estimator (pending bin list) and the dependent quantiser (decisions, path nodes) use at different times
 #define DQ_TAB_INTS (21 * 6 + 3 * 12 * 2 + 4)
@@ -156,7 +157,7 @@ struct Lds {
   int16_t refs[4][2][140];         // luma: set 0 mrl0 unfiltered, 1 mrl0 filtered, 2 mrl1, 3 mrl3; chroma: set 0 Cb, 1 Cr. [0]=top [1]=left
   uint8_t flags[72]; int8_t src_unit[72];
   int cache_gen, cur_stream;       // CTU generation of this scratch slot (CU-result cache validity); stream descriptor the workgroup is running
-  int dq_abs[64 + NW];             // wave_depquant_batch: absSum per item of a batch ([64 + wave]: a wave's own single block)
+  int dq_abs[DQ_ABS_SINGLE + NW];  // wave_depquant_batch: absSum per item of a batch: [0, 16) the pass's items, [32, 48) the prepared second batch; [DQ_ABS_SINGLE + wave]: a wave's own single block
   Frame fr[MAXD];
   // posted operation
   int op, op_a, op_b, op_c, op_d, op_ch;
@@ -246,6 +247,9 @@ template <typename T> __device__ inline T *uni_p(T *p)
   u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]); u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
   return u.p;
 }
+// a generic pointer known to point into the workgroup's LDS object, re-based on L: the accesses through it become ds_ instructions (a pointer that went through a
+// call or a select is a generic one: flat_ accesses, which wait on both counters)
+template <typename T> __device__ inline T *as_lds(T *p) { return (T *) ((char *) &L + (int) ((const char *) p - (const char *) &L)); }
 __device__ inline double uni_d(double v)
 {
   union { double d; int i[2]; } u; u.d = v;
@@ -2046,10 +2050,13 @@ __device__ __noinline__ void wave_code_block_mts(const int16_t *org_g, int16_t *
 // against the context set ci (the estimator's live contexts: the sub-partitions of a CU are coded one after the other) with the cbf context cbf_ctx (< 0: the cbf is
 // inferred), dequantisation, inverse, reconstruction over the prediction in rec, SSE.  org / rec / lev: tiles of the CU (stride cst) at the TU's origin.
 // given >= 0: the levels in lev are taken as coded (cbf = given): decoder half only.  tmp: th * min(32, tw) int32 (and its int16 re-use).
+// LDSP: every tile of the call lives in LDS (the search of ISP CUs of at most 128 samples)
+template <bool LDSP>
 __device__ __noinline__ void wave_code_block_isp(const int16_t *org, int16_t *rec, int16_t *lev, int cst, int32_t *tmp, int16_t *cf, uint8_t *scratch, int w, int h, int bd, int qp,
                                                  int lane, unsigned long long &sse_out, int &cbf_out, int given, int ci, int cbf_ctx)
 {
   org = uni_p(org); rec = uni_p(rec); lev = uni_p(lev); tmp = uni_p(tmp); cf = uni_p(cf); scratch = uni_p(scratch); ci = uni(ci); cbf_ctx = uni(cbf_ctx);
+  if (LDSP) { org = as_lds(org); rec = as_lds(rec); lev = as_lds(lev); tmp = as_lds(tmp); cf = as_lds(cf); }
   // cf: a dense w * h int16 tile for the coefficients / levels (the trellis and the residual syntax take stride w)
   w = uni(w); h = uni(h); bd = uni(bd); qp = uni(qp); given = uni(given); cst = uni(cst);
   const int trh = (w >= 4 && w <= 16) ? 2 : 0, trv = (h >= 4 && h <= 16) ? 2 : 0;
@@ -2093,7 +2100,8 @@ __device__ __noinline__ void wave_code_block_isp(const int16_t *org, int16_t *re
   }
   int abs_sum = given;
   ISP_T(i1);
-  if (given < 0) abs_sum = wave_depquant<false>(cf, 0, scratch, ci, w, h, 0, cbf_ctx, 0, 0, lane);
+  if (given < 0) abs_sum = LDSP ? wave_depquant<true>(nullptr, (int) (cf - (L.wm[uni(VTX >> 6)].slot + BUF)), scratch, ci, w, h, 0, cbf_ctx, 0, 0, lane)
+                                : wave_depquant<false>(cf, 0, scratch, ci, w, h, 0, cbf_ctx, 0, 0, lane);
   wave_sync();
   ISP_T(i2);
   if (given < 0) { for (int o = lane; o < P; o += 64) lev[(o >> lw) * cst + (o & (w - 1))] = cf[o]; }
@@ -2441,6 +2449,8 @@ __device__ inline int16_t *isp_tile(uint8_t *scratch, int wave) { return (int16_
 // that candidates can be evaluated ahead of the reference's order under a limit that is at least the one they will be judged with.
 // given != nullptr (out == nullptr): the levels (CU tile, stride w) and cbfs are taken as coded (DecCu::xIntraRecQT of an ISP CU for xReuseCachedResult); distortion ->
 // L.isp_dist.  The node's base references are L.refs[0]; the region's go to the calling wave's LDS candidate slot (unused by this path).  tile: isp_tile() of a wave.
+// LDSP (search path, CUs of at most 128 samples, refs_wave == the calling wave): all tiles are LDS objects addressed as such
+template <bool LDSP>
 __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir, int isp, double limit, const int16_t *given, int given_tucbf, int16_t *rec, int16_t *lev, int ci, int lane,
                                          int16_t *tile, IspRes *out, int refs_wave)
 {
@@ -2451,15 +2461,15 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
   const int psz = isp_split_dim(w, h, hor), tw = hor ? w : psz, th = hor ? psz : h, n = hor ? h / psz : w / psz;
   const int predRegDiff = !hor && ((w == 8 && h > 4) || w == 4);         // CU::isPredRegDiffFromTB
   const int wave = uni(VTX >> 6), x0 = uni(L.nx), y0 = uni(L.ny);
-  const int16_t *org = org_tile(scratch, w * h);
+  const int16_t *org = LDSP ? L.org : org_tile(scratch, w * h);
   // CUs of at most 128 samples (most of the nodes that test ISP) keep everything in LDS: the region references, the CU's reconstruction and levels in the candidate slot,
   // the prediction and the dense coefficient tile behind the transform scratch (a TU has at most 64 coefficients then); the tiles are copied out at the end
-  const int small = w * h <= 128;
+  const int small = LDSP || w * h <= 128;
   int16_t *const rec_out = rec, *const lev_out = lev;
   int16_t *sl = L.wm[uni(refs_wave)].slot, *tl = (int16_t *) L.wm[wave].tmp;
   if (small) { rec = sl + 132; lev = sl + 260; }
   int16_t *pred = small ? tl + 192 : tile + 8192, *cf = small ? tl + 128 : tile + 12288;
-  int32_t *tmp = wave_tmp(scratch, imin(32, tw) * th, wave);
+  int32_t *tmp = LDSP ? L.wm[wave].tmp : wave_tmp(scratch, imin(32, tw) * th, wave);
   const int16_t *bt = L.refs[0][0], *bl = L.refs[0][1];
   int16_t *rt = sl, *rl = sl + (small ? 66 : 160);          // region references: an LDS candidate slot this path does not use otherwise
   { uint32_t *d = (uint32_t *) &L.ctxs[ci]; const uint32_t *s_ = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s_[e]; }
@@ -2501,8 +2511,8 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
     const int cbfCtx = lastInferred ? -1 : (int) VX_CTX_QtCbf[0] + 2 + prevCbf;
     unsigned long long d; int cbf;
     const int off = oy * w + ox;
-    { ISP_T(k1); ISP_ADD(19, k0, k1); if (VTX == 0) PROF(23) += 1; }
-    wave_code_block_isp(org + off, rec + off, lev + off, w, tmp, cf, scratch, tw, th, bd, p.qp_tr, lane, d, cbf, given ? (given_tucbf >> k) & 1 : -1, ci, cbfCtx);
+    { ISP_T(k1); ISP_ADD(19, k0, k1); ISP_ADD(23, 0, 1); }
+    wave_code_block_isp<LDSP>(org + off, rec + off, lev + off, w, tmp, cf, scratch, tw, th, bd, p.qp_tr, lane, d, cbf, given ? (given_tucbf >> k) & 1 : -1, ci, cbfCtx);
     cbf = uni(cbf);
     nrun = k + 1;
     if (given) { if (cbf) tucbf |= 1 << k; dist += d; continue; }
@@ -2517,7 +2527,7 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
         if (k == 0) enc_intra_luma_pred_mode(cb, L.ny, dir, 0, isp);
         if (!lastInferred) enc_bin(cb, (unsigned) cbf, VX_CTX_QtCbf[0] + 2 + prevCbf);
       }
-      if (cbf) residual_coding_wave<false>(cb, 0, cf, tw, th, 0, lane);
+      if (cbf) { if (LDSP) residual_coding_wave<true>(cb, (int) (cf - (L.wm[wave].slot + BUF)), nullptr, tw, th, 0, lane); else residual_coding_wave<false>(cb, 0, cf, tw, th, 0, lane); }
       { unsigned lo = (unsigned) cb.bits, hi = (unsigned) (cb.bits >> 32); lo = (unsigned) __builtin_amdgcn_readlane((int) lo, 0); hi = (unsigned) __builtin_amdgcn_readlane((int) hi, 0); fb = ((unsigned long long) hi << 32) | lo; }
       if (lane == 0) out->fb[k] = fb;
     }
@@ -2532,7 +2542,7 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
   if (lane == 0) { if (given) L.isp_dist = dist; else { out->cbf = (uint8_t) tucbf; out->nrun = (uint8_t) nrun; } }
   wave_sync();
   if (small) { for (int e = lane; e < w * h; e += 64) { rec_out[e] = rec[e]; lev_out[e] = lev[e]; } wave_sync(); }
-  { ISP_T(c1); ISP_ADD(21, c0, c1); if (VTX == 0) PROF(22) += 1; }
+  { ISP_T(c1); ISP_ADD(21, c0, c1); ISP_ADD(22, 0, 1); }
 }
 // OP_ISP: up to NW candidates of the node's ISP test at once, one per wave: L.isp_res[w].mode / split name wave w's, all under the limit L.isp_limit
 __device__ __noinline__ void op_isp(uint8_t *scratch)
@@ -2542,7 +2552,8 @@ __device__ __noinline__ void op_isp(uint8_t *scratch)
   const int w = uni(L.nw), h = uni(L.nh);
   if (wave < uni((int) L.isp_nb)) {
     int16_t *t = isp_tile(scratch, wave);
-    isp_code_cu(scratch, w, h, uni((int) L.isp_res[wave].mode), uni((int) L.isp_res[wave].split), uni_d(L.isp_limit), nullptr, 0, t, t + 4096, CI_W(wave), lane, t, &L.isp_res[wave], wave);
+    if (w * h <= 128) isp_code_cu<true>(scratch, w, h, uni((int) L.isp_res[wave].mode), uni((int) L.isp_res[wave].split), uni_d(L.isp_limit), nullptr, 0, t, t + 4096, CI_W(wave), lane, t, &L.isp_res[wave], wave);
+    else isp_code_cu<false>(scratch, w, h, uni((int) L.isp_res[wave].mode), uni((int) L.isp_res[wave].split), uni_d(L.isp_limit), nullptr, 0, t, t + 4096, CI_W(wave), lane, t, &L.isp_res[wave], wave);
   }
   __threadfence_block();
   __syncthreads();
@@ -2963,12 +2974,12 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
     for (int i = wave; i < nA; i += NW) {
       const int c = c0 + i, mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
       int16_t *rec = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, P, wave, cur);
+      const int mtsC = psMts ? pass_mts_idx(psGrp, mode) : 0;
       const int src = specUse ? (specKind == 2 ? i : uni((int) L.rd_src[c])) : i;          // a prepared block sits behind the specN blocks of the pass that made it (the lfnstIdx 2 pass walks the same list in the same order)
       for (int e = lane; e < P; e += 64) { rec[e] = poolPred[(size_t) src * P + e]; lev[e] = poolCoef[(size_t) (specUse ? specN + src : i) * P + e]; }
       wave_sync();
       const int cbf = (specUse ? uni(L.spec_abs[src]) : uni(L.dq_abs[i])) > 0;
       unsigned long long sse; int cbf2;
-      const int mtsC = psMts ? pass_mts_idx(psGrp, mode) : 0;
       if (mtsC) wave_code_block_mts<SMALL>(org, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, mtsC, lane, sse, cbf2, cbf);
       else wave_code_block<SMALL>(org, 0, 0, rec, lev, wave_tmp(scratch, imin(w, 32) * h, wave), w, h, bd, p.qp_tr, lane, sse, cbf2, cbf, nullptr, 0, 0, 0, psLf, psLf ? lfnst_mode((mrl & MIPF) ? PLANAR : mode, w, h) : 0);
       { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s[e]; }
@@ -3602,7 +3613,7 @@ __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch
     const int isp = uni((int) L.isp_split), tucbf = uni((int) L.isp_tucbf), hor = isp == 1;
     const int psz = isp_split_dim(w, h, hor), tw = hor ? w : psz, th = hor ? psz : h, nsub = hor ? h / psz : w / psz, ltw = ilog2i(tw);
     { int16_t *t = isp_tile(scratch, 0);                 // reconstructed in the HBM tile (the region references use the idle wave 1's LDS slot), then into the result slot
-      isp_code_cu(scratch, w, h, mode, isp, 0.0, levb, tucbf, t, t + 4096, CI_W(1), lane, t, nullptr, 1);
+      isp_code_cu<false>(scratch, w, h, mode, isp, 0.0, levb, tucbf, t, t + 4096, CI_W(1), lane, t, nullptr, 1);
       for (int e = lane; e < P; e += 64) recb[e] = t[e];
       wave_sync(); }
     dist = L.isp_dist;
@@ -4632,7 +4643,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
           for (int i = 0; i < L.isp_nb; i++) if (!L.isp_res[i].used && L.isp_res[i].mode == (uint8_t) S.ispReqMode && L.isp_res[i].split == (uint8_t) S.ispReqSplit) bw = i;
           if (bw < 0) {                                 // not evaluated yet: the tiles of a new best are kept first, then the next batch
             if (S.ispPark >= 0) { L.isp_park = (uint8_t) S.ispPark; S.ispPark = -1; post(OP_ISP_PARK); return; }
-            { ISP_T(b0); ctrl_isp_batch(S.ispReqMode, S.ispReqSplit); ISP_T(b1); ISP_ADD0(25, b0, b1); PROF(29) += 1; }
+            { ISP_T(b0); ctrl_isp_batch(S.ispReqMode, S.ispReqSplit); ISP_T(b1); ISP_ADD0(25, b0, b1); ISP_ADD0(29, 0, 1); }
             L.isp_limit = S.ispCurBest;
             post(OP_ISP); return;
           }
@@ -4643,7 +4654,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         if (S.ispSlot >= 16) break;
         int mode = 0, split = 0;
         S.ispSlot++;
-        ISP_T(n0); const int okn = ctrl_isp_next(f.w, f.h, mode, split); { ISP_T(n1); ISP_ADD0(27, n0, n1); PROF(28) += 1; }
+        ISP_T(n0); const int okn = ctrl_isp_next(f.w, f.h, mode, split); { ISP_T(n1); ISP_ADD0(27, n0, n1); ISP_ADD0(28, 0, 1); }
         if (!okn) { S.ispPrev = 3; continue; }
         S.ispPrev = (int8_t) split; S.ispReqMode = (int8_t) mode; S.ispReqSplit = (int8_t) split; S.ispHave = 1;
       }
@@ -5187,7 +5198,7 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_isp_kernel(V
   if (wave != 0) return;
   const size_t b = (size_t) blockIdx.x * P;
   unsigned long long sse; int cbf;
-  wave_code_block_isp(org + b, rec + b, lev + b, w, tmp + (size_t) blockIdx.x * 2048, lev + b, p.scratch + (size_t) blockIdx.x * p.scratch_per_stream, w, h, p.bit_depth, qp, lane, sse, cbf, -1, CI_CUR, cbf_ctx);
+  wave_code_block_isp<false>(org + b, rec + b, lev + b, w, tmp + (size_t) blockIdx.x * 2048, lev + b, p.scratch + (size_t) blockIdx.x * p.scratch_per_stream, w, h, p.bit_depth, qp, lane, sse, cbf, -1, CI_CUR, cbf_ctx);
   if (lane == 0) { out[blockIdx.x * 2] = sse; out[blockIdx.x * 2 + 1] = (unsigned long long) cbf; }
 }
 template <typename T>

@@ -205,7 +205,7 @@ def compress_frame_parallel(planes, w, h, sp, workers=8, **kw):
     return res, cus[np.argsort(key, kind="stable")], reco, cnt
 
 
-def write_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOLS_DEFAULT):
+def write_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=1, tools=TOOLS_DEFAULT, reco_out=None):
     """Oracle: compress one frame, then its slice_data payload.  Returns (payload bytes, per-tile sizes, cu table, level planes)."""
     L = lib()
     L.orc_write_tiles.restype = C.c_long
@@ -229,6 +229,10 @@ def write_frame(planes, w, h, sp, bit_depth=8, tile_cols=1, tile_rows=1, chroma=
         assert tot >= 0
         lev = [np.zeros((h >> (1 if c else 0), w >> (1 if c else 0)), np.int16) for c in range(3)]
         L.orc_get_levels(e, (C.c_void_p * 3)(*[l.ctypes.data for l in lev]))
+        if reco_out is not None:                                          # the same search's reconstruction (layout tools: bytes and PSNR from one run)
+            reco = [np.zeros_like(p) for p in planes]
+            L.orc_get_reco(e, (C.c_void_p * 3)(*[p.ctypes.data for p in reco]), (C.c_int * 3)(*[p.shape[1] for p in planes]), planes[0].dtype.itemsize)
+            reco_out.extend(reco)
         return buf[:tot].copy(), sizes, cus[:n.value].copy(), lev
     finally:
         L.orc_destroy(e)

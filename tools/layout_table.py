@@ -55,6 +55,9 @@ def encode_rows(a):
             rows.append(dict(qp=qp, layout=name, bits=8 * nbytes, psnr_y=psnr[0], psnr_u=psnr[1], psnr_v=psnr[2], psnr_yuv=(6 * psnr[0] + psnr[1] + psnr[2]) / 8,
                              seconds=secs, kernel_ms=enc.last_kernel_ms(), ctus=a.frames * cw * chh, sharing="one process per QP ran side by side on the GPU"))
             print("QP %d %-8s %10d bits  %.3f dB Y  %.3f dB YUV  kernel %.1f s" % (qp, name, 8 * nbytes, psnr[0], rows[-1]["psnr_yuv"], enc.last_kernel_ms() / 1e3), flush=True)
+            if a.rows_file:                                 # every finished encode is on disk at once: a run that is cut off keeps what it has
+                with open(a.rows_file, "a") as f:
+                    f.write(json.dumps(rows[-1]) + "\n")
             enc.close()
     print("ROWS " + json.dumps(rows), flush=True)
 
@@ -69,19 +72,21 @@ def main():
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--merge", type=str, nargs="*", default=None, help="no GPU: merge the rows of earlier runs' JSON files into --out and compute the delta rates")
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--rows-file", type=str, default=None)
     a = ap.parse_args()
     if a.child:
         return encode_rows(a)
     rows = []
     if a.merge is not None:
         for f in a.merge:
-            rows += json.load(open(f))["rows"]
+            rows += [json.loads(l) for l in open(f) if l.strip()] if f.endswith(".jsonl") else json.load(open(f))["rows"]
     else:
         # one process per QP (each runs its layouts one after the other): the one-tile pictures are single 135-CTU chains of many minutes, and encodes of one process would
         # queue behind each other's device allocations.  This process never touches the GPU; it prints a line while the children work.
         import subprocess
         kids = [(qp, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", "--frames", str(a.frames), "--width", str(a.width), "--height", str(a.height), "--qps", qp,
-                                       "--layouts", a.layouts], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)) for qp in a.qps.split(",")]
+                                       "--layouts", a.layouts] + (["--rows-file", (os.path.join(ROOT, a.out) if not os.path.isabs(a.out) else a.out) + ".qp%s.jsonl" % qp] if a.out else []),
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)) for qp in a.qps.split(",")]
         t0 = time.time()
         while any(k.poll() is None for _, k in kids):
             time.sleep(30)
