@@ -18,6 +18,9 @@
 //   * a decision is stored in 4 bits (where it came from and whether the level is zero) in LDS; the level itself is recomputed from the
 //     coefficient when the winning path is walked back.
 #pragma once
+#ifndef VXD_SERIAL_PRIO
+#define VXD_SERIAL_PRIO 0      // s_setprio level of the serial phases (trellis position loop, mode controller).  Measured: 0 / 2 / 3 give 179.1 / 178.7 / 178.3 CTU/s (profiles/r04_ab_runs.txt): no gain, left off
+#endif
 
 // 16 bytes / 16 half-words kept as scalar members (arrays indexed with a run-time value would be placed in scratch memory by the compiler)
 struct U4 { unsigned a, b, c, d; };
@@ -299,6 +302,9 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
 #ifdef VVCX_STAMP_DQ
   long long sA = 0, sB = 0, sC = 0, sE = 0, u1 = 0, u2 = 0, u3 = 0;
 #endif
+  // the position loop is the longest serial chain of a stream and runs on one or two of the workgroup's waves while the others wait at the barrier: it takes issue
+  // priority over the waves of the CU's other streams that are in their wide phases (VALU issue is arbitrated by priority, then by age)
+  __builtin_amdgcn_s_setprio(VXD_SERIAL_PRIO);
   for (int top64 = top; top64 >= 0; top64 -= 64) {
   int pgA = 0, pgB = 0, pgC = 0;
   {
@@ -521,6 +527,7 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
     if (spt == 1) { const DqK t = skp; skp.cost = prv.cost; skp.pk = prv.pk; skp.rem = prv.rem; skp.anc = prv.anc; prv.cost = t.cost; prv.pk = t.pk; prv.rem = t.rem; prv.anc = t.anc; }
   }
   }
+  __builtin_amdgcn_s_setprio(0);
   DQ_T(t3);
   // ---- best final state and back-tracking (1709-1730), lane 0 of every quad for its item
   int prev = -2; long long minCost = 0;

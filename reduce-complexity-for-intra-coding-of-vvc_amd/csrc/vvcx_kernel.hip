@@ -25,7 +25,16 @@
 // Virtual thread index: the workgroup's wavefronts are rotated by a per-stream amount, so that the serial parts of a stream (the mode controller on thread 0,
 // the batched trellis on wave 0) do not all land on the same SIMD of a CU when its four resident streams run them (wave w of a workgroup sits on SIMD w).
 // Lanes keep their place inside the wavefront; every wave index in this file is the virtual one.
+#if (VXD_NW & (VXD_NW - 1)) == 0
 #define VTX ((threadIdx.x + ((((unsigned) blockIdx.x * 0x9E3779B1u) >> 30) << 6)) & (unsigned) (VXD_NT - 1))
+#else
+__device__ inline unsigned vtx_rotated()       // a wave count that is not a power of two: rotate by (hash of the workgroup) mod NW waves
+{
+  const unsigned t = threadIdx.x + ((((unsigned) blockIdx.x * 0x9E3779B1u) >> 24) % VXD_NW << 6);
+  return t >= VXD_NT ? t - VXD_NT : t;
+}
+#define VTX (vtx_rotated())
+#endif
 #define NW VXD_NW
 #define MAXD VXD_MAXD
 #define BUF VXD_BUF
@@ -114,6 +123,8 @@ struct CtlState {            // controller-private working set (touched by threa
   uint8_t ispTMode[16], ispTInfo[16], ispList[28], ispReg[16], ispHad[24], ispWinMode, ispWinSplit, ispWinTucbf;      // ispTInfo: split << 4 | completed sub-partitions
   double ispTCost[16], ispBestRd, ispCurBest, noIspCost;
   unsigned long long ispWinDist, ispWinBits;
+  // direct look-ups of the same records (ISPTestedModesInfo keeps per-mode tables): sub-partitions completed by (split, mode), -1 = not tested; the first two modes tested with a split
+  alignas(4) int8_t ispPartsOf[2][68]; int8_t ispFirst[2][2];
   uint8_t inv0[16], rdSrc[24];           // first pass: list place -> stage-B item; per list entry of an MTS pass: the first pass's item that carries its prepared DST-VII block
 };
 
@@ -2892,7 +2903,7 @@ __device__ void dq_trellis_phase(uint8_t *scratch, int n, int P, int total, int 
   // items item0 .. item0 + n of the pool, absSum -> L.dq_abs[abs0 ..]; wave_shift rotates which wave takes the first chunk (two batches of one operation run side by side)
   int16_t *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF) + (size_t) item0 * P; uint8_t *poolNodes = scratch + VXD_OFF_POOL_NODES + (size_t) item0 * 4 * total;
   const int ipw = imin(16, (int) sizeof(WaveMem) / (240 + 2 * total));          // items one wave can hold decisions for
-  for (int i0 = ((wave + NW - wave_shift) & (NW - 1)) * ipw; i0 < n; i0 += NW * ipw)
+  for (int i0 = ((wave + NW - wave_shift) % NW) * ipw; i0 < n; i0 += NW * ipw)
     wave_depquant_batch<2>(imin(ipw, n - i0), poolCoef + (size_t) i0 * P, P, poolNodes + (size_t) i0 * 4 * total, 4 * total, wave, abs0 + i0,
                         CI_CUR, 0, VX_CTX_QtCbf[0], 0u, w, h, 0, zo, lfnst, lane);
 }
@@ -2923,7 +2934,12 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
   const int specKind = uni((int) L.spec_kind);
   const int specUse = lfOn && uni((int) L.spec_n) > 0 && ((psMts && psGrp == 0 && specKind == 1) || (psLf == 2 && !psMts && specKind == 2 && uni((int) L.spec_n) == n_rd));
   const int specN = uni((int) L.spec_n);
+  // transform skip, early form: the pruning and the RDOQ-TS chains (rounds T1 / T2) need only the predictions, the original and the DCT-II sums of round A1, and the
+  // waves 2 and 3 have nothing to do while the trellis batches of the DCT-II and the DST-VII blocks run on waves 0 and 1: they take T1 and T2 there, each for the candidates
+  // it owns (no hand-over between them), into coefficient-pool items and absSum slots of their own (48 + candidate)
+  const int tsEarly = tsOn && NW >= 4 && n_rd <= 16 && (48 + 16) * P <= VXD_POOL_ELEMS, tsAt = tsEarly ? 48 : 0;
   if (lane == 0) L.wave_best[wave] = -1;
+  if (tsOn) ts_build_tables();
   dq_build_tables(0);
   double wbest = MAX_DOUBLE; int wkey = 1 << 30;         // the wave's best item so far: cost, and candidate * 8 + transform order as the tie break
   int cur = 0, nmts = 0;
@@ -2965,6 +2981,17 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
     if (!specUse) dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, psMts, wave, lane, psLf);
     if (specGen) dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, 1, wave, lane, 0, nA, 32, 1);
     if (specGen2) dq_trellis_phase<SMALL>(scratch, nA, P, total, w, h, 0, wave, lane, 2, nA, 32, 1);
+    if (tsEarly && wave >= 2) {
+      for (int i = wave - 2; i < nA; i += 2) {
+        const int sa = wave_ts_fwd(org, poolPred + (size_t) i * P, poolCoef + (size_t) (48 + i) * P, w, h, bd, lane);
+        if (lane == 0) L.rb_pairs[i] = (uint8_t) ((double) sa <= (double) recB[i].sum0);
+      }
+      __threadfence_block();
+      wave_sync();
+      int cnt = 0, mine = -1;
+      for (int i = wave - 2; i < nA; i += 2) if (L.rb_pairs[i]) { if (cnt == lane) mine = i; cnt++; }
+      if (mine >= 0) L.dq_abs[48 + mine] = ts_rdoq_lane(poolCoef + (size_t) (48 + mine) * P, w, h, bd, p.qp_tr);
+    }
     __threadfence_block();
     __syncthreads();
     const long long q2 = STAMP();
@@ -3014,10 +3041,9 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
     }
     __threadfence_block();
     __syncthreads();
-    if (tsOn) {
+    if (tsOn && !tsEarly) {
       // ---- T1: which candidates keep the transform-skip candidate (sum of its scaled residual against the DCT-II sum, TrQuant::transformNxN 1049-1124); their
       // "coefficients" replace the consumed DCT-II levels in the coefficient pool
-      ts_build_tables();
       for (int i = wave; i < nA; i += NW) {
         const int sa = wave_ts_fwd(org, poolPred + (size_t) i * P, poolCoef + (size_t) i * P, w, h, bd, lane);
         if (lane == 0) L.rb_pairs[i] = (uint8_t) ((double) sa <= (double) recB[i].sum0);      // keep flags (the list of MTS items is not built in this pass)
@@ -3033,14 +3059,16 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
       }
       __threadfence_block();
       __syncthreads();
+    }
+    if (tsOn) {
       // ---- T3: reconstruction, rate and cost of the non-empty ones (an empty transform-skip block is forbidden, 3567-3571); strict < against the candidate's DCT-II result
       for (int i = wave; i < nA; i += NW) {
         if (!uni((int) L.rb_pairs[i])) continue;
         nmts++;
-        if (uni(L.dq_abs[i]) <= 0) continue;
+        if (uni(L.dq_abs[tsAt + i]) <= 0) continue;
         const int c = c0 + i, mode = uni(L.rd[c].mode), mrl = uni(L.rd[c].mrl);
         int16_t *rec = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, cur), *lev = SMALL ? L.wm[wave].slot + BUF : slot_lev(scratch, P, wave, cur);
-        for (int e = lane; e < P; e += 64) { rec[e] = poolPred[(size_t) i * P + e]; lev[e] = poolCoef[(size_t) i * P + e]; }
+        for (int e = lane; e < P; e += 64) { rec[e] = poolPred[(size_t) i * P + e]; lev[e] = poolCoef[(size_t) (tsAt + i) * P + e]; }
         { uint32_t *d = (uint32_t *) &L.ctxs[CI_W(wave)]; const uint32_t *s = (const uint32_t *) &L.ctxs[CI_CUR]; for (int e = lane; e < NCTX; e += 64) d[e] = s[e]; }
         wave_sync();
         unsigned long long sse;
@@ -4167,12 +4195,10 @@ __device__ int isp_tested_at(int split, int mode)
   for (int i = 0; i < S.ispNT; i++) if (S.ispTMode[i] == mode && (S.ispTInfo[i] >> 4) == split) return i;
   return -1;
 }
-__device__ inline int isp_parts(int split, int mode) { const int i = isp_tested_at(split, mode); return i < 0 ? -1 : (L.S.ispTInfo[i] & 15); }
-__device__ int isp_nth_tested(int split, int k)           // the k-th mode tested with this split (m_ispTestedModes[...].intraMode in test order)
+__device__ inline int isp_parts(int split, int mode) { return L.S.ispPartsOf[split - 1][mode]; }
+__device__ inline int isp_nth_tested(int split, int k)    // the k-th mode (k = 0, 1) tested with this split (m_ispTestedModes[...].intraMode in test order)
 {
-  const CtlState &S = L.S;
-  for (int i = 0; i < S.ispNT; i++) if ((S.ispTInfo[i] >> 4) == split && k-- == 0) return S.ispTMode[i];
-  return -1;
+  return k < L.S.ispNTested[split - 1] ? L.S.ispFirst[split - 1][k] : -1;
 }
 // xSortISPCandList (EL/IntraSearch.cpp:4614-4717): planar, the best angular mode of the regular full-RD results, the other angular ones by cost, DC; then up to three
 // modes of the SATD-stage list that are not among them.  bestNonISP: the best regular cost; stops both splits when ISP cannot win (ISPFast 1)
@@ -4239,7 +4265,7 @@ __device__ __noinline__ int ctrl_isp_next(int w, int h, int &mode, int &split)
       for (int k = 1; k <= window; k++) {
         const int off = cand - 2 - k;
         const int l_ = off < 0 ? 67 + off : cand - k, r_ = cand > DC ? ((cand - 2 + k) % 65) + 2 : PLANAR;
-        const int lf = l_ != cand ? isp_tested_at(nxt, l_) >= 0 : 0, rf = r_ != cand ? isp_tested_at(nxt, r_) >= 0 : 0;
+        const int lf = l_ != cand ? isp_parts(nxt, l_) >= 0 : 0, rf = r_ != cand ? isp_parts(nxt, r_) >= 0 : 0;
         if (lf || rf) { lm = lf ? l_ : -1; rm = rf ? r_ : -1; break; }
       }
       const int nl = lm != -1 ? isp_parts(nxt, lm) : -1, nr = rm != -1 ? isp_parts(nxt, rm) : -1;
@@ -4259,6 +4285,7 @@ __device__ __noinline__ void ctrl_isp_begin(const Frame &f)
   S.ispBestRd = bestReg; S.ispCurBest = f.max_cost < bestReg ? f.max_cost : bestReg; S.noIspCost = bestReg;
   S.ispNT = 0; S.ispBestMode = -1; S.ispBestSplit = 0; S.ispNOrig = -1; S.ispNList = 0; S.ispPrev = 0;
   for (int k = 0; k < 2; k++) { S.ispStop[k] = 0; S.ispCandIdx[k] = 0; S.ispNTested[k] = 0; }
+  { uint32_t *t = (uint32_t *) S.ispPartsOf; for (int k = 0; k < 34; k++) t[k] = 0xffffffffu; }
   S.ispNumTotal[0] = (int8_t) (f.h / isp_split_dim(f.w, f.h, 1)); S.ispNumTotal[1] = (int8_t) (f.w / isp_split_dim(f.w, f.h, 0));
   L.isp_win = 0;
   ctrl_isp_sort(S.ispCurBest, bestReg);
@@ -4301,6 +4328,8 @@ __device__ __noinline__ int ctrl_isp_result(const Frame &f, int bw)
   }
   const double rc = first ? rcost : MAX_DOUBLE;
   { const int psz = isp_split_dim(f.w, f.h, split == 1), tpix = split == 1 ? f.w * psz : psz * f.h; L.cnt[1] += (unsigned long long) evals; L.cnt[2] += (unsigned long long) (evals * tpix); }
+  if (S.ispNTested[st] < 2) S.ispFirst[st][S.ispNTested[st]] = (int8_t) mode;
+  S.ispPartsOf[st][mode] = (int8_t) ntu;
   S.ispTMode[S.ispNT] = (uint8_t) mode; S.ispTInfo[S.ispNT] = (uint8_t) ((split << 4) | ntu); S.ispTCost[S.ispNT] = ntu == maxParts ? rc : MAX_DOUBLE; S.ispNT++; S.ispNTested[st]++;
   if (ntu == maxParts && rc < S.ispBestRd) { S.ispBestMode = (int8_t) mode; S.ispBestSplit = (int8_t) split; }
   if (valid && first && rcost < S.ispBestRd) {
@@ -4329,7 +4358,7 @@ __device__ __noinline__ void ctrl_isp_batch(int reqMode, int reqSplit)
     if (ci[st] >= S.ispNOrig) { idle++; continue; }
     idle = 0;
     const int cand = S.ispList[ci[st]++];
-    if (isp_tested_at(nxt, cand) >= 0) continue;
+    if (isp_parts(nxt, cand) >= 0) continue;
     L.isp_res[n].mode = (uint8_t) cand; L.isp_res[n].split = (uint8_t) nxt; L.isp_res[n].used = 0; n++;
   }
   L.isp_nb = (uint8_t) n;
@@ -4928,7 +4957,7 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
   (void) tid;
   int prev_op = 13; long long t_prev = STAMP();
   for (;;) {
-    if (ctl_wave) { if (ctl_lane) {
+    if (ctl_wave) { __builtin_amdgcn_s_setprio(VXD_SERIAL_PRIO); if (ctl_lane) {
       const long long t0 = STAMP();
       if (VVCX_STAMP) {
         PROF(imin(prev_op, 13)) += (unsigned long long) (t0 - t_prev);     // previous operation (prof[0] absorbs the first; [13]: the ISP operations)
@@ -4943,7 +4972,7 @@ __device__ __noinline__ void run_tree(const VxParams &p_, const VxFrameDev &fd_,
 #endif
       t_prev = STAMP();
       if (VVCX_STAMP) PROF(0) += (unsigned long long) (t_prev - t0);
-    } }
+    } __builtin_amdgcn_s_setprio(0); }
     __syncthreads();
     const int op = uni(L.op);
     { const int pd = uni(L.pre_copy_d); if (pd >= 0) ctx_copy_all(ctx_ptr(scratch, CTX_START, pd, 0), &L.ctxs[CI_CUR]); }      // reads only; every operation leaves L.ctxs[CI_CUR] alone until its own barrier

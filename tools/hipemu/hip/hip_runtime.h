@@ -82,6 +82,7 @@ template <typename T> inline T __shfl(T v, int src) { return hipemu::shfl_idx(v,
 inline long long clock64() { return 0; }
 inline long long wall_clock64() { return 0; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+inline void __builtin_amdgcn_s_setprio(int) {}
 inline unsigned long long __ballot(int pred)
 {
   hipemu::Block &b = *hipemu::g_block; const unsigned w = hipemu::g_cur->tidx.x >> 6, l = hipemu::g_cur->tidx.x & 63;
