@@ -102,6 +102,11 @@ __device__ inline long long dq_shfl_i64(long long v, int src)
   const int lo = __shfl((int) v, src), hi = __shfl((int) (v >> 32), src);
   return (long long) (((unsigned long long) (unsigned) hi << 32) | (unsigned) lo);
 }
+__device__ inline long long dq_uni_ll(long long v)
+{
+  const int lo = __builtin_amdgcn_readfirstlane((int) v), hi = __builtin_amdgcn_readfirstlane((int) (v >> 32));
+  return (long long) (((unsigned long long) (unsigned) hi << 32) | (unsigned) lo);
+}
 // fractional bits of a bin from the model's current state (BinProbModel_Std::getFracBitsArray, CL/Contexts.h:128-132)
 __device__ inline int dq_fb(int ci, int ctx, int bin) { const Ctx &c = L.ctxs[ci]; return (int) BIN_FRAC(((unsigned) c.s0[ctx] + (unsigned) c.s1[ctx]) >> 8, bin); }
 // g_goRiceBits (887-893) = length of the Golomb-Rice / escape code (EL/BinEncoder.cpp:444-472) in 2^-15 bit units
@@ -174,7 +179,12 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
   const int ch = comp ? 1 : 0, lw = ilog2i(w), lh = ilog2i(h);
   // qidx: another row of the table (joint chroma blocks); chroma rows come from the table of the node's LMCS residual scale (table 0: unscaled)
   const int qrow = uni(qidx) < 0 ? comp : uni(qidx);
-  const VxDqConst q = L.par.dq_consts[(qrow ? uni(L.lmcs_tab) * 96 : 0) + qrow * 16 + lw + lh];
+  // (the block's quantiser constants are the same on every lane: an LDS load leaves them in 13 vector registers - in the position loop they cost five reloads from scratch
+  // per position - so they move to scalar ones)
+  VxDqConst q;
+  { const VxDqConst &qv = L.par.dq_consts[(qrow ? uni(L.lmcs_tab) * 96 : 0) + qrow * 16 + lw + lh];
+    q.qshift = uni(qv.qshift); q.max_qidx = uni(qv.max_qidx); q.thres = uni(qv.thres); q.dshift = uni(qv.dshift);
+    q.qadd = dq_uni_ll(qv.qadd); q.qscale = dq_uni_ll(qv.qscale); q.dadd = dq_uni_ll(qv.dadd); q.dstep = dq_uni_ll(qv.dstep); q.dorg = dq_uni_ll(qv.dorg); }
   const ScanGeo geo = scan_geo(w, h);
   const int lcw = geo.lcw, lch = geo.lch, lcg = geo.lcg, gs = 1 << lcg, total = geo.nscan;
   const int nzw = imin(32, w), nzh = imin(32, h), wsbb = geo.wg, hsbb = geo.hg;
@@ -456,7 +466,8 @@ __device__ __noinline__ void wave_depquant_batch(int n_items, int16_t *cf_base, 
             }
           }
           if (cur.rem >= 4) {
-            pk = (pk & ~((3 << 8) | (0x1FF << 18))) | ((int) L.t.gorice_pars[imax(imin(31, sumAbs - 20), 0)] << 8) | ((sigOffN + imin((sumAbs1 + 1) >> 1, 3)) << 18)
+            // (g_auiGoRiceParsCoeff[clamp(sumAbs - 20, 0, 31)] steps at 7, 14 and 28: three compares instead of a dependent LDS read)
+            pk = (pk & ~((3 << 8) | (0x1FF << 18))) | (((sumAbs >= 27) + (sumAbs >= 34) + (sumAbs >= 48)) << 8) | ((sigOffN + imin((sumAbs1 + 1) >> 1, 3)) << 18)
                  | ((gtxOffN + imin(sumAbs1 - sumNum, 4)) << 22);
           } else {
             sumAbs = imin(31, sumAbs);
