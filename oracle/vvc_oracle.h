@@ -130,6 +130,16 @@ int      orc_forest_predict_rows(orc_enc *e, const int32_t *rows, int n, int32_t
 int      orc_deblock_frame(orc_enc *e, int beta_offset_div2, int tc_offset_div2);
 /* the same filter on a CU table {ch, x, y, w, h, ispMode} (luma samples) and 4:2:0 planes with stride = plane width; qp_cb / qp_cr = mapped chroma QPs */
 int      orc_deblock_table(int w, int h, int bd, int qp, int qp_cb, int qp_cr, const int *rows, int nrows, int16_t *y, int16_t *cb, int16_t *cr);
+/* adaptive loop filter with given parameter sets on 4:2:0 planes with stride = plane width (CL/AdaptiveLoopFilter.cpp ALFProcess; orc_alf.c) */
+typedef struct {                      /* what an ALF parameter set carries (AlfParam, CL/AlfParameters.h) */
+  int32_t num_luma_filters; uint8_t class_to_filter[25]; uint8_t nonlinear_luma; int16_t luma_coeff[25][12]; uint8_t luma_clip_idx[25][12];
+  int32_t num_chroma_alt; uint8_t nonlinear_chroma[8]; int16_t chroma_coeff[8][6]; uint8_t chroma_clip_idx[8][6];
+} orc_alf_aps;
+typedef struct { uint8_t flag[3]; int8_t set; uint8_t alt[2]; } orc_alf_ctu;      /* per CTU: enable Y / Cb / Cr, luma filter set (0..15 fixed, 16 + k: k-th set of the slice), chroma alternatives */
+int      orc_alf_clip_value(int chroma, int bit_depth, int idx);
+void     orc_alf_reconstruct(const orc_alf_aps *a, int bit_depth, int16_t *luma_coeff /* [25][13] */, int16_t *luma_clip, int16_t *chroma_coeff /* [n_alt][7] */, int16_t *chroma_clip);
+int      orc_alf_picture(int w, int h, int bit_depth, int n_sets, const int16_t *luma_coeff, const int16_t *luma_clip, int n_alt, const int16_t *chroma_coeff, const int16_t *chroma_clip,
+                         const orc_alf_ctu *ctu, int16_t *y, int16_t *cb, int16_t *cr, uint8_t *cls_out);
 /* sample adaptive offset with given parameters on 4:2:0 planes with stride = plane width (CL/SampleAdaptiveOffset.cpp SAOProcess; orc_sao.c) */
 typedef struct { int8_t mode, type, band, off[4]; } orc_sao_param;      /* per CTU and component: mode 0 off / 1 new / 2 merge; type: new 0..3 edge class, 4 band; merge 0 left, 1 above */
 int      orc_sao_picture(int w, int h, int bit_depth, int tile_cols, int tile_rows, int lf_across_tiles, int log2_offset_scale, const orc_sao_param *prm, int16_t *y, int16_t *cb, int16_t *cr);

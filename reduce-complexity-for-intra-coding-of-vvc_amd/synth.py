@@ -109,3 +109,51 @@ def sao_test_params(seed, w, h, tile_cols=1, tile_rows=1):
                 t = int(g.integers(0, 5))
                 prm[a, c] = [1, t, int(g.integers(0, 32)) if t == 4 else 0] + [int(v) for v in g.integers(-7, 8, 4)]
     return prm
+
+
+ALF_APS_INTS = 732      # one ALF parameter set as a row of ints (the layout tests/golden/make_golden.py hands to the reference and vvcx.AlfAps.from_row reads)
+
+
+def alf_test_params(seed, w, h, n_aps=3):
+    """seeded adaptive-loop-filter inputs: parameter sets [n_aps, 732] int32 = {number of luma filters, class -> filter [25], luma clip flag, luma coefficients [25][12],
+    luma clipping indices [25][12], number of chroma alternatives, their clip flags [8], chroma coefficients [8][6], chroma clipping indices [8][6]}; the sets the slice
+    filters luma with (filter set 16 + k), the set of the chroma alternatives; per CTU {enable Y, Cb, Cr, luma filter set, alternative Cb, Cr} [nctu, 6] int32
+    (shared by the fixture generator, the tests and bench.py)"""
+    g = np.random.default_rng(seed)
+    nctu = ((w + 127) // 128) * ((h + 127) // 128)
+    aps = np.zeros((n_aps, ALF_APS_INTS), np.int32)
+    lw = np.array([4, 6, 8, 6, 6, 10, 16, 10, 6, 6, 10, 20])          # larger taps next to the centre
+    cwt = np.array([6, 8, 14, 8, 8, 18])
+    for i in range(n_aps):
+        nf = 25 if i == 0 else int(g.integers(1, 26))
+        aps[i, 0] = nf
+        aps[i, 1:26] = np.arange(25) if i == 0 else g.integers(0, nf, 25)
+        aps[i, 26] = int(g.integers(0, 2)) if i else 1
+        aps[i, 27:327] = (g.integers(-1, 2, (25, 12)) * g.integers(0, lw + 1, (25, 12))).ravel()
+        aps[i, 327:627] = g.integers(0, 4, 300)
+        aps[i, 627] = int(g.integers(1, 9))
+        aps[i, 628:636] = g.integers(0, 2, 8)
+        aps[i, 636:684] = (g.integers(-1, 2, (8, 6)) * g.integers(0, cwt + 1, (8, 6))).ravel()
+        aps[i, 684:732] = g.integers(0, 4, 48)
+    n_luma = int(g.integers(1, n_aps + 1))
+    luma_aps = [int(v) for v in g.permutation(n_aps)[:n_luma]]
+    chroma_aps = int(g.integers(0, n_aps))
+    ctu = np.zeros((nctu, 6), np.int32)
+    ctu[:, 0:3] = (g.random((nctu, 3)) < 0.8) | (nctu == 1)
+    ctu[:, 3] = g.integers(0, 16 + n_luma, nctu)
+    ctu[:, 4:6] = g.integers(0, aps[chroma_aps, 627], (nctu, 2))
+    return dict(aps=aps, luma_aps=luma_aps, chroma_aps=chroma_aps, ctu=ctu)
+
+
+def alf_test_frame(width, height, bit_depth, seed):
+    """a picture for the adaptive loop filter's classifier: synth_frame's gratings and screen content with the detail of every 16 x 16 block scaled by a factor of its own
+    (0 .. 2), so that the blocks spread over the activity classes as well as over the directions"""
+    pl = synth_frame(width, height, 0, bit_depth, seed, chroma_texture=0.6, oriented=20.0, screen=0.2)
+    g = np.random.default_rng(seed + 5)
+    y = pl[0].astype(np.float64)
+    by, bx = (height + 15) // 16, (width + 15) // 16
+    f = np.array([0.0, 0.05, 0.15, 0.3, 0.6, 1.0, 2.0])[g.integers(0, 7, (by, bx))]
+    f = np.kron(f, np.ones((16, 16)))[:height, :width]
+    m = np.kron(np.add.reduceat(np.add.reduceat(y, np.arange(0, height, 16), 0), np.arange(0, width, 16), 1) / 256.0, np.ones((16, 16)))[:height, :width]
+    pl[0] = np.clip(np.rint(m + f * (y - m)), 0, (1 << bit_depth) - 1).astype(pl[0].dtype)
+    return pl

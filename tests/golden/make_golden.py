@@ -499,6 +499,35 @@ def gen_sao():
     np.savez_compressed(os.path.join(HERE, "sao.npz"), planes=np.concatenate(planes_all))
 
 
+def gen_alf():
+    """The reference's AdaptiveLoopFilter::ALFProcess with seeded parameter sets (up to 25 luma filters with clipping, chroma alternatives), per-CTU enable flags, filter sets
+    (fixed and signalled) and alternatives on seeded pictures: the fixture keeps the filtered planes and the class / transpose of every luma 4 x 4 block; parameters and
+    pictures are regenerated by the tests (oracle_lib.alf_params / ALF_CASES)."""
+    import importlib, sys
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+    R.ref_env_alf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    planes_all, cls_all = [], []
+    for (W, H, bd, seed) in O.ALF_CASES:
+        pl = pkg.alf_test_frame(W, H, bd, seed)
+        prm = O.alf_params(seed, W, H)
+        env = R.ref_env_create(W, H, bd); R.ref_env_reset(env)
+        for c in range(3):
+            a = np.ascontiguousarray(pl[c].astype(np.int16)); R.ref_env_set_reco(env, c, P(a), a.shape[1])
+        outs = [np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)]
+        cls = np.zeros((H // 4, W // 4), np.uint8)
+        aps = np.ascontiguousarray(prm["aps"], np.int32); la = np.ascontiguousarray(prm["luma_aps"], np.int32); ctu = np.ascontiguousarray(prm["ctu"], np.int32)
+        assert R.ref_env_alf(env, bd, len(aps), P(aps), len(la), P(la), prm["chroma_aps"], P(ctu), P(outs[0]), P(outs[1]), P(outs[2]), P(cls)) == 0
+        mine, mcls = O.alf_picture(pl, W, H, bd, prm, want_classes=True)
+        changed = [int((outs[c] != pl[c]).sum()) for c in range(3)]
+        print("alf", W, H, bd, "samples changed:", changed, "classes equal:", bool(np.array_equal(mcls, cls)), "oracle equal:", [bool(np.array_equal(mine[c], outs[c])) for c in range(3)],
+              "classes used:", len(np.unique(cls[cls != 255] & 31)), "transposes:", sorted(set((cls[cls != 255] >> 5).tolist())))
+        assert min(changed) > 0
+        planes_all += [o.ravel() for o in outs]; cls_all.append(cls.ravel())
+    np.savez_compressed(os.path.join(HERE, "alf.npz"), planes=np.concatenate(planes_all), classes=np.concatenate(cls_all))
+
+
 def gen_mip():
     """Matrix-based intra prediction (MatrixIntraPrediction::prepareInputForPred + predBlock of the reference) for every block shape MIP
     allows and every mode, from random reference samples."""
@@ -1030,6 +1059,8 @@ if __name__ == "__main__":
         gen_bitstream_wpp(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sao":
         gen_sao(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "alf":
+        gen_alf(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "deblock":
         gen_deblock(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "chroma_qp":
@@ -1068,5 +1099,5 @@ if __name__ == "__main__":
         gen_ts(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cclm":
         gen_cclm(); sys.exit(0)      # added later: leaves the earlier fixtures (and the shared rng stream they used) untouched
-    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict(); gen_decision_helpers(); gen_ts(); gen_bitstream_ts(); gen_isp(); gen_bitstream_isp(); gen_lmcs(); gen_bitstream_wpp(); gen_lmcs_analysis(); gen_sao()
+    gen_transforms(); gen_dist(); gen_cabac(); gen_scan(); gen_intra(); gen_partition(); gen_trquant(); gen_bitstream(); gen_cclm(); gen_bitstream_cclm(); gen_trquant_mts(); gen_bitstream_mts(); gen_bitstream_mip(); gen_chroma_qp(); gen_deblock(); gen_mip(); gen_depquant(); gen_bitstream_dq(); gen_lfnst(); gen_bitstream_lfnst(); gen_bitstream_jccr(); gen_ict(); gen_decision_helpers(); gen_ts(); gen_bitstream_ts(); gen_isp(); gen_bitstream_isp(); gen_lmcs(); gen_bitstream_wpp(); gen_lmcs_analysis(); gen_sao(); gen_alf()
     print("done")

@@ -307,5 +307,58 @@ def sao_picture(planes, w, h, bit_depth, prm, tile_cols=1, tile_rows=1, lf_acros
     return out
 
 
+# ---- adaptive loop filter (oracle/orc_alf.c): the filter with given parameter sets and per-CTU choices
+class OrcAlfAps(C.Structure):
+    _fields_ = [("num_luma_filters", C.c_int32), ("class_to_filter", C.c_uint8 * 25), ("nonlinear_luma", C.c_uint8), ("luma_coeff", (C.c_int16 * 12) * 25), ("luma_clip_idx", (C.c_uint8 * 12) * 25),
+                ("num_chroma_alt", C.c_int32), ("nonlinear_chroma", C.c_uint8 * 8), ("chroma_coeff", (C.c_int16 * 6) * 8), ("chroma_clip_idx", (C.c_uint8 * 6) * 8)]
+
+
+def alf_aps_struct(row, cls=OrcAlfAps):
+    """a parameter-set row of alf_test_params as the C structure"""
+    a = cls()
+    a.num_luma_filters = int(row[0]); a.nonlinear_luma = int(row[26]); a.num_chroma_alt = int(row[627])
+    for c in range(25):
+        a.class_to_filter[c] = int(row[1 + c])
+        for k in range(12):
+            a.luma_coeff[c][k] = int(row[27 + c * 12 + k]); a.luma_clip_idx[c][k] = int(row[327 + c * 12 + k])
+    for t in range(8):
+        a.nonlinear_chroma[t] = int(row[628 + t])
+        for k in range(6):
+            a.chroma_coeff[t][k] = int(row[636 + t * 6 + k]); a.chroma_clip_idx[t][k] = int(row[684 + t * 6 + k])
+    return a
+
+
+def alf_params(seed, w, h):
+    import importlib
+    return importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd").alf_test_params(seed, w, h)
+
+
+def alf_picture(planes, w, h, bit_depth, prm, want_classes=False):
+    """orc_alf_reconstruct for the slice's parameter sets + orc_alf_picture on copies of the planes -> three int16 planes (and the class bytes of the luma 4 x 4 blocks)"""
+    L = lib()
+    L.orc_alf_reconstruct.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
+    L.orc_alf_picture.argtypes = [C.c_int] * 4 + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 7
+    n_sets = len(prm["luma_aps"])
+    lco = np.zeros((max(n_sets, 1), 25, 13), np.int16); lcl = np.zeros_like(lco); cco = np.zeros((8, 7), np.int16); ccl = np.zeros_like(cco)
+    scratch_c = (np.zeros((8, 7), np.int16), np.zeros((8, 7), np.int16)); scratch_l = (np.zeros((25, 13), np.int16), np.zeros((25, 13), np.int16))
+    for k, i in enumerate(prm["luma_aps"]):
+        a = alf_aps_struct(prm["aps"][i])
+        L.orc_alf_reconstruct(C.addressof(a), bit_depth, lco[k].ctypes.data, lcl[k].ctypes.data, scratch_c[0].ctypes.data, scratch_c[1].ctypes.data)
+    a = alf_aps_struct(prm["aps"][prm["chroma_aps"]])
+    L.orc_alf_reconstruct(C.addressof(a), bit_depth, scratch_l[0].ctypes.data, scratch_l[1].ctypes.data, cco.ctypes.data, ccl.ctypes.data)
+    ctu = np.zeros((len(prm["ctu"]), 6), np.uint8); ctu[:] = prm["ctu"]           # {flag[3], set, alt[2]}: six bytes per CTU
+    out = [np.ascontiguousarray(p.astype(np.int16)) for p in planes]
+    cls = np.zeros((h // 4, w // 4), np.uint8)
+    rc = L.orc_alf_picture(w, h, bit_depth, n_sets, lco.ctypes.data, lcl.ctypes.data, int(a.num_chroma_alt), cco.ctypes.data, ccl.ctypes.data, ctu.ctypes.data,
+                           out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, cls.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_alf_picture: %d" % rc)
+    return (out, cls) if want_classes else out
+
+
+ALF_CASES = ((128, 128, 8, 51), (256, 256, 8, 52), (384, 264, 10, 53), (320, 200, 8, 54), (64, 48, 10, 55), (200, 392, 8, 56))
+# (width, height, bit depth, seed): one CTU (the lower border of a picture of at most 128 rows acts as a virtual boundary), whole CTUs, partial CTUs right and below, a small picture
+
+
 SAO_CASES = ((128, 128, 8, 1, 1, 1, 0, 41), (256, 256, 8, 1, 1, 1, 0, 42), (384, 264, 10, 2, 2, 1, 0, 43), (320, 200, 8, 3, 2, 0, 0, 44), (512, 136, 10, 4, 1, 0, 1, 45), (200, 392, 8, 1, 3, 0, 0, 46))
 # (width, height, bit depth, tile columns, tile rows, filters across tile borders, log2 offset scale, seed)

@@ -334,6 +334,32 @@ def test_sample_adaptive_offset_filter_against_the_reference():
     assert len({int(v) for v in O.sao_params(41, 256, 256)[:, :, 1].ravel()}) >= 5 and (O.sao_params(43, 384, 264, 2, 2)[:, :, 0] == 2).any()      # all types, merges present
 
 
+def test_adaptive_loop_filter_against_the_reference():
+    """oracle/orc_alf.c (per-block closed form of the classifier, per-sample form of the diamond filters with the virtual-boundary rules) against what the reference's
+    AdaptiveLoopFilter::ALFProcess produced for the same seeded pictures, parameter sets and per-CTU choices (tests/golden/alf.npz; oracle_lib.ALF_CASES): the filtered
+    planes and the class / transpose index of every luma 4 x 4 block."""
+    import importlib
+    pkg = importlib.import_module("reduce-complexity-for-intra-coding-of-vvc_amd")
+    z = np.load(os.path.join(G, "alf.npz")); g, gc = z["planes"], z["classes"]; off = coff = 0
+    seen = set()
+    for (W, H, bd, seed) in O.ALF_CASES:
+        pl = pkg.alf_test_frame(W, H, bd, seed)
+        prm = O.alf_params(seed, W, H)
+        got, cls = O.alf_picture(pl, W, H, bd, prm, want_classes=True)
+        exp_cls = gc[coff:coff + cls.size].reshape(cls.shape); coff += cls.size
+        assert np.array_equal(cls, exp_cls), (W, H, bd)
+        seen |= {int(v) for v in exp_cls[exp_cls != 255].ravel()}
+        for c in range(3):
+            exp = g[off:off + pl[c].size].reshape(pl[c].shape); off += pl[c].size
+            assert np.array_equal(got[c], exp), (W, H, bd, c)
+            assert (exp != pl[c]).any()
+    assert off == len(g) and coff == len(gc)
+    assert {v & 31 for v in seen} == set(range(25)) and {v >> 5 for v in seen} == {0, 1, 2, 3}      # every class and every transpose occurs
+    # the clipping values of AdaptiveLoopFilter::create for 8 and 10 bit
+    L = O.lib(); L.orc_alf_clip_value.argtypes = [O.C.c_int] * 3
+    assert [L.orc_alf_clip_value(0, 8, i) for i in range(4)] == [256, 64, 16, 4] and [L.orc_alf_clip_value(1, 10, i) for i in range(4)] == [1024, 161, 25, 4]
+
+
 def test_deblocking_of_isp_transform_edges_against_the_reference_loop_filter():
     """Transform edges inside and around ISP CUs (xDeblockCU 306-317, xSetMaxFilterLengthPQFromTransformSizes): CU tables with a forced random ispMode on most luma CUs,
     filtered by the reference (tests/golden/make_golden.py deblock, forced_isp_rows) and by orc_deblock_table on the same unfiltered reconstruction."""
