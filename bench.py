@@ -314,6 +314,19 @@ def main():
                           "note": "parameters are seeded test values (synth.sao_test_params: about 80 % of the CTUs filtered); the parameter decision is not part of the library"}
         except Exception as ex:
             out["sao"] = {"error": str(ex)}
+        # fourth kernel pair (not part of the timed step): the adaptive loop filter with seeded parameter sets and per-CTU choices on the pictures SAO left - an HBM-bound
+        # stencil pass (every sample read once and written once; the taps and the classifier's window come from an LDS tile)
+        try:
+            base = pkg.alf_test_params(950, W, H)
+            nalt = int(base["aps"][base["chroma_aps"], 627])
+            prms = [dict(base, ctu=pkg.alf_test_params(951 + i, W, H)["ctu"] % np.array([2, 2, 2, 16 + len(base["luma_aps"]), nalt, nalt])) for i in range(args.frames)]
+            alf_ms = enc.alf_bound_frames(prms)
+            alf_bytes = args.frames * (W * H * 3 // 2) * (2 if bd == 10 else 1) * 2
+            out["alf"] = {"kernel": "vvcx_alf_copy_kernel + vvcx_alf_kernel (%s)" % ("u8" if bd == 8 else "u16"), "launches": 2, "ms": alf_ms, "frames": args.frames, "algorithmic_bytes": alf_bytes,
+                          "achieved_GBps": alf_bytes / (alf_ms / 1e3) / 1e9 if alf_ms > 0 else None, "frac_of_hbm_peak": alf_bytes / (alf_ms / 1e3) / 1e9 / HBM_PEAK_GBS if alf_ms > 0 else None,
+                          "note": "parameter sets and per-CTU choices are seeded test values (synth.alf_test_params: about 80 % of the CTUs filtered, fixed and signalled filter sets); the parameter decision is not part of the library"}
+        except Exception as ex:
+            out["alf"] = {"error": str(ex)}
         if not args.no_cpu_baseline and world == 1:
             print("[bench] timed region done (%.1f s for %d steps); CPU baseline sample ..." % (elapsed, args.steps), file=sys.stderr, flush=True)
             import oracle_lib as O

@@ -219,6 +219,27 @@ float vvcx_last_sao_ms(const vvcx_handle *h);
 /* the same filter on one picture in host memory (uint16 planes, stride = plane width, filtered in place; prm[ctu][component]): needs no handle */
 int   vvcx_sao_picture(int pic_w, int pic_h, int bit_depth, int tile_cols, int tile_rows, const vvcx_sao_param *prm, int lf_across_tiles, int log2_offset_scale,
                        uint16_t *y, uint16_t *cb, uint16_t *cr, int device);
+/* ≙ AdaptiveLoopFilter::ALFProcess(cs) (CL/AdaptiveLoopFilter.cpp:205-383): the adaptive loop filter on every bound (completely coded) picture, in place on the
+ * reconstruction planes, with the caller's parameter sets and per-CTU choices.  aps[n_aps] (n_aps <= 8) = what the ALF parameter sets carry (≙ AlfParam,
+ * CL/AlfParameters.h:134-160, JVET_O0669 form: no coefficient prediction): up to 25 luma filters of 12 coefficients + clipping indices (used when nonlinear_luma), the filter of
+ * each of the 25 classes (filterCoeffDeltaIdx), up to 8 chroma alternatives of 6 coefficients + clipping indices.  slices[frame] (≙ the slice header): the parameter sets luma
+ * is filtered with (luma_aps[k] -> filter set 16 + k; sets 0..15 are the standard's fixed ones) and the set of the chroma alternatives (chroma_aps < 0: chroma stays).
+ * ctus[frame][ctu raster address]: enable flags Y / Cb / Cr (≙ Picture::getAlfCtuEnableFlag), luma filter set (getAlfCtbFilterIndex), chroma alternatives
+ * (getAlfCtuAlternativeData).  Class derivation (deriveClassificationBlk 792-1002), the 7 x 7 / 5 x 5 diamond filters with clipping (filterBlk 1005-1296) and the virtual
+ * boundary above every lower CTU border are the reference's; tiles are not looked at (its ALF of this version does not either).  The parameter DECISION
+ * (EncAdaptiveLoopFilter) is not part of the library.  In the reference's order this follows vvcx_sao_bound_frames. */
+typedef struct vvcx_alf_aps {
+  int32_t num_luma_filters; uint8_t class_to_filter[25]; uint8_t nonlinear_luma; int16_t luma_coeff[25][12]; uint8_t luma_clip_idx[25][12];
+  int32_t num_chroma_alt; uint8_t nonlinear_chroma[8]; int16_t chroma_coeff[8][6]; uint8_t chroma_clip_idx[8][6];
+} vvcx_alf_aps;
+typedef struct vvcx_alf_slice { int32_t n_luma_aps, luma_aps[8], chroma_aps; } vvcx_alf_slice;
+typedef struct vvcx_alf_ctu { uint8_t flag[3]; int8_t set; uint8_t alt[2]; } vvcx_alf_ctu;
+int   vvcx_alf_bound_frames(vvcx_handle *h, const vvcx_alf_aps *aps, int n_aps, const vvcx_alf_slice *slices, const vvcx_alf_ctu *ctus, void *hip_stream);
+float vvcx_last_alf_ms(const vvcx_handle *h);
+/* the same filter on one picture in host memory (uint16 planes, stride = plane width, filtered in place): needs no handle.  classes (may be NULL): class | transpose << 5 of
+ * every luma 4 x 4 block of the CTUs with luma enabled (255 elsewhere), (pic_w / 4) per row */
+int   vvcx_alf_picture(int pic_w, int pic_h, int bit_depth, const vvcx_alf_aps *aps, int n_aps, const vvcx_alf_slice *slice, const vvcx_alf_ctu *ctus,
+                       uint16_t *y, uint16_t *cb, uint16_t *cr, uint8_t *classes, int device);
 /* ≙ LoopFilter::loopFilterPic on a picture the caller describes itself (the way the reference's LoopFilter sees a CodingStructure: cs.cus + cs.tus + the reconstruction buffer):
  * rows = n_rows x {channel type (0 luma tree, 1 chroma tree), x, y, w, h in luma samples, cu.ispMode (0, 1 = horizontal, 2 = vertical split; luma rows only)} covering both
  * trees of the whole 4:2:0 picture, every CU intra at the slice QP (qp_cb / qp_cr = mapped chroma QPs); y / cb / cr = host planes of 16-bit samples, stride = plane width,

@@ -31,6 +31,10 @@ extern "C" __global__ void vvcx_sao_copy_kernel_u8(VxSaoParams p);
 extern "C" __global__ void vvcx_sao_copy_kernel_u16(VxSaoParams p);
 extern "C" __global__ void vvcx_sao_kernel_u8(VxSaoParams p);
 extern "C" __global__ void vvcx_sao_kernel_u16(VxSaoParams p);
+extern "C" __global__ void vvcx_alf_copy_kernel_u8(VxAlfParams p);
+extern "C" __global__ void vvcx_alf_copy_kernel_u16(VxAlfParams p);
+extern "C" __global__ void vvcx_alf_kernel_u8(VxAlfParams p);
+extern "C" __global__ void vvcx_alf_kernel_u16(VxAlfParams p);
 extern "C" __global__ void vvcx_deblock_kernel_u8(VxDeblockParams p);
 extern "C" __global__ void vvcx_deblock_kernel_u16(VxDeblockParams p);
 extern "C" __global__ void vvcx_jccr_sign_kernel_u8(VxFrameDev *frames, int wc, int hc);
@@ -93,6 +97,7 @@ struct vvcx_handle {
   std::vector<uint32_t> activity;               // per (frame, CTU) of the bound pictures: orders the stream queue of a launch, longest first
   hipEvent_t ev0, ev1; float last_ms, last_deblock_ms, last_sao_ms;
   void *sao_tmp_d; size_t sao_tmp_cap; VxSaoEntry *sao_tab_d; size_t sao_tab_cap; uint8_t *sao_tile_d;      // vvcx_sao_bound_frames: picture copy, resolved parameters, CTU -> tile
+  VxAlfFrame *alf_tab_d; VxAlfCtu *alf_ctu_d; size_t alf_cap; float last_alf_ms;      // vvcx_alf_bound_frames: per-frame tables and per-CTU choices (the picture copy is the SAO one)
   // a submitted, not yet collected launch (vvcx_submit_ctus .. vvcx_wait_ctus): staging the async copies read from / write to stays alive here
   bool pending; hipStream_t pend_stream; int pend_n; VxCtuRes *pend_res; int pend_cap;
   std::vector<VxStreamDesc> pend_sd; std::vector<int32_t> pend_task_ctu; std::vector<int> pend_src, pend_next; VxDqConst pend_dq[17 * 96];
@@ -201,7 +206,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   h->frames_d = nullptr; h->lev_d = nullptr; h->units_d = nullptr; h->stream_ctx_d = nullptr; h->scratch_d = nullptr; h->scratch_cap = 0;
   h->payload_d = nullptr; h->payload_off_d = nullptr; h->payload_cap_d = nullptr; h->arith_d = nullptr;
   h->streams_d = nullptr; h->task_ctu_d = nullptr; h->results_d = nullptr; h->task_cap = 0; h->stream_cap = 0; h->counters_d = nullptr;
-  h->sao_tmp_d = nullptr; h->sao_tmp_cap = 0; h->sao_tab_d = nullptr; h->sao_tab_cap = 0; h->sao_tile_d = nullptr; h->last_sao_ms = 0.f;
+  h->sao_tmp_d = nullptr; h->sao_tmp_cap = 0; h->sao_tab_d = nullptr; h->sao_tab_cap = 0; h->sao_tile_d = nullptr; h->last_sao_ms = 0.f; h->alf_tab_d = nullptr; h->alf_ctu_d = nullptr; h->alf_cap = 0; h->last_alf_ms = 0.f;
   h->dq_d = nullptr; h->lmcs_on = false; h->lmcs_inverted = false; h->lmcs_lut_d = nullptr; h->lmcs_org_d = nullptr; h->lmcs_org_cap = 0;
   const int F = cfg->max_frames;
   if (hipMalloc((void **) &h->frames_d, sizeof(VxFrameDev) * F) != hipSuccess || hipMalloc((void **) &h->lev_d, h->lev_frame * 2 * F) != hipSuccess ||
@@ -232,7 +237,7 @@ extern "C" void vvcx_destroy(vvcx_handle *h)
   (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d); (void) hipFree(h->wpp_progress_d); (void) hipFree(h->wpp_sync_d); (void) hipFree(h->wpp_sched_d); (void) hipFree(h->train_rows_d); (void) hipFree(h->train_n_d);
   (void) hipFree(h->payload_d); (void) hipFree(h->payload_off_d); (void) hipFree(h->payload_cap_d); (void) hipFree(h->arith_d);
   (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
-  (void) hipFree(h->sao_tmp_d); (void) hipFree(h->sao_tab_d); (void) hipFree(h->sao_tile_d);
+  (void) hipFree(h->sao_tmp_d); (void) hipFree(h->sao_tab_d); (void) hipFree(h->sao_tile_d); (void) hipFree(h->alf_tab_d); (void) hipFree(h->alf_ctu_d);
   (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d); (void) hipFree(h->dq_d); (void) hipFree(h->lmcs_lut_d); (void) hipFree(h->lmcs_org_d);
   if (h->pending) (void) hipStreamSynchronize(h->pend_stream);
   (void) hipHostFree(h->pend_res);
@@ -877,6 +882,149 @@ extern "C" int vvcx_sao_picture(int pic_w, int pic_h, int bit_depth, int tile_co
   return rc;
 }
 extern "C" float vvcx_last_sao_ms(const vvcx_handle *h) { return h ? h->last_sao_ms : 0.f; }
+
+// ---- adaptive loop filter (≙ AdaptiveLoopFilter::ALFProcess, CL/AdaptiveLoopFilter.cpp:205-383) with the caller's parameter sets: the per-class tables of every frame's
+// slice are built here (≙ reconstructCoeffAPSs 385-418 / reconstructCoeff 420-608, JVET_O0669 form), the kernels (vvcx_alf.hip) classify and filter.
+static int alf_clip_value(int chroma, int bit_depth, int idx)      // create() 633-654
+{
+  if (!chroma) return (int) std::round(std::pow(2., (double) (bit_depth * (4 - idx)) / 4));
+  if (idx == 0) return 1 << bit_depth;
+  return (int) std::round(std::pow(2., bit_depth - 8 + 8. * (4 - idx - 1) / 3));
+}
+static int alf_build(const vvcx_alf_aps *aps, int n_aps, const vvcx_alf_slice *slices, const vvcx_alf_ctu *ctus, int n_frames, int nctu, int bit_depth, int chroma, std::vector<VxAlfFrame> &tabs)
+{
+  if (n_aps < 0 || n_aps > 8) return fail(VVCX_ERR_ARG, "ALF: %d parameter sets (0..8)", n_aps);
+  for (int i = 0; i < n_aps; i++) {
+    const vvcx_alf_aps &a = aps[i];
+    if (a.num_luma_filters < 1 || a.num_luma_filters > 25 || a.num_chroma_alt < 0 || a.num_chroma_alt > 8) return fail(VVCX_ERR_ARG, "ALF parameter set %d: %d luma filters / %d chroma alternatives", i, a.num_luma_filters, a.num_chroma_alt);
+    for (int c = 0; c < 25; c++) if (a.class_to_filter[c] >= a.num_luma_filters) return fail(VVCX_ERR_ARG, "ALF parameter set %d: class %d uses filter %d of %d", i, c, a.class_to_filter[c], a.num_luma_filters);
+    for (int f = 0; f < a.num_luma_filters; f++) for (int k = 0; k < 12; k++) if (a.luma_clip_idx[f][k] > 3) return fail(VVCX_ERR_ARG, "ALF parameter set %d: clipping index above 3", i);
+    for (int t = 0; t < a.num_chroma_alt; t++) for (int k = 0; k < 6; k++) if (a.chroma_clip_idx[t][k] > 3) return fail(VVCX_ERR_ARG, "ALF parameter set %d: clipping index above 3", i);
+  }
+  tabs.assign((size_t) n_frames, VxAlfFrame());
+  for (int f = 0; f < n_frames; f++) {
+    const vvcx_alf_slice &sl = slices[f];
+    VxAlfFrame &t = tabs[(size_t) f];
+    memset(&t, 0, sizeof t);
+    if (sl.n_luma_aps < 0 || sl.n_luma_aps > 8 || sl.chroma_aps >= n_aps) return fail(VVCX_ERR_ARG, "ALF slice of frame %d: %d luma sets / chroma set %d of %d", f, sl.n_luma_aps, sl.chroma_aps, n_aps);
+    t.n_sets = sl.n_luma_aps;
+    for (int k = 0; k < sl.n_luma_aps; k++) {
+      if (sl.luma_aps[k] < 0 || sl.luma_aps[k] >= n_aps) return fail(VVCX_ERR_ARG, "ALF slice of frame %d: luma set %d of %d", f, sl.luma_aps[k], n_aps);
+      const vvcx_alf_aps &a = aps[sl.luma_aps[k]];
+      for (int c = 0; c < 25; c++) for (int i = 0; i < 12; i++) {
+        const int fl = a.class_to_filter[c];
+        t.luma_coeff[k][c][i] = a.luma_coeff[fl][i];
+        t.luma_clip[k][c][i] = (int16_t) alf_clip_value(0, bit_depth, a.nonlinear_luma ? a.luma_clip_idx[fl][i] : 0);
+      }
+    }
+    const bool chromaOn = chroma && sl.chroma_aps >= 0;
+    if (chromaOn) {
+      const vvcx_alf_aps &a = aps[sl.chroma_aps];
+      t.n_alt = a.num_chroma_alt;
+      for (int alt = 0; alt < a.num_chroma_alt; alt++) for (int i = 0; i < 6; i++) {
+        t.chroma_coeff[alt][i] = a.chroma_coeff[alt][i];
+        t.chroma_clip[alt][i] = (int16_t) alf_clip_value(1, bit_depth, a.nonlinear_chroma[alt] ? a.chroma_clip_idx[alt][i] : 0);
+      }
+    }
+    for (int a = 0; a < nctu; a++) {
+      const vvcx_alf_ctu &u = ctus[(size_t) f * nctu + a];
+      if (u.flag[0] && (u.set < 0 || u.set >= 16 + t.n_sets)) return fail(VVCX_ERR_ARG, "ALF: frame %d CTU %d uses luma filter set %d of %d", f, a, u.set, 16 + t.n_sets);
+      for (int c = 1; c < 3; c++) if (chromaOn && u.flag[c] && u.alt[c - 1] >= t.n_alt) return fail(VVCX_ERR_ARG, "ALF: frame %d CTU %d uses chroma alternative %d of %d", f, a, u.alt[c - 1], t.n_alt);
+    }
+  }
+  return VVCX_OK;
+}
+// the per-CTU choices as the kernels read them: chroma flags cleared where the slice has no chroma set (≙ slice-level alf_chroma_idc)
+static void alf_ctus(const vvcx_alf_slice *slices, const vvcx_alf_ctu *ctus, int n_frames, int nctu, int chroma, std::vector<VxAlfCtu> &out)
+{
+  out.resize((size_t) n_frames * nctu);
+  for (int f = 0; f < n_frames; f++) for (int a = 0; a < nctu; a++) {
+    const vvcx_alf_ctu &u = ctus[(size_t) f * nctu + a]; VxAlfCtu &o = out[(size_t) f * nctu + a];
+    const bool con = chroma && slices[f].chroma_aps >= 0;
+    o.flag[0] = u.flag[0] != 0; o.flag[1] = con && u.flag[1]; o.flag[2] = con && u.flag[2]; o.set = u.set; o.alt[0] = u.alt[0]; o.alt[1] = u.alt[1];
+  }
+}
+static void alf_launch(VxAlfParams &p, int n_frames, size_t bps, hipStream_t stream)
+{
+  const dim3 gridC((unsigned) ((p.pic_w + 255) / 256), (unsigned) p.pic_h, (unsigned) (3 * n_frames));
+  const dim3 gridF((unsigned) ((p.pic_w + 63) / 64), (unsigned) ((p.pic_h + 15) / 16), (unsigned) (3 * n_frames));
+  if (bps == 1) { hipLaunchKernelGGL(vvcx_alf_copy_kernel_u8, gridC, dim3(256), 0, stream, p); hipLaunchKernelGGL(vvcx_alf_kernel_u8, gridF, dim3(256), 0, stream, p); }
+  else { hipLaunchKernelGGL(vvcx_alf_copy_kernel_u16, gridC, dim3(256), 0, stream, p); hipLaunchKernelGGL(vvcx_alf_kernel_u16, gridF, dim3(256), 0, stream, p); }
+}
+extern "C" int vvcx_alf_bound_frames(vvcx_handle *h, const vvcx_alf_aps *aps, int n_aps, const vvcx_alf_slice *slices, const vvcx_alf_ctu *ctus, void *hip_stream)
+{
+  NOT_PENDING(h);
+  if (!h || !slices || !ctus || (n_aps > 0 && !aps)) return fail(VVCX_ERR_ARG, "null argument");
+  if (!h->n_frames || !h->have_slice) return fail(VVCX_ERR_STATE, "no bound frames / slice");
+  for (size_t i = 0; i < h->next_idx.size(); i++)
+    if (h->next_idx[i] != (int) h->sub_ctus[i % (size_t) h->nsub].size()) return fail(VVCX_ERR_STATE, "the loop filters need every CTU of the bound pictures coded");
+  if (h->lmcs_on && !h->lmcs_inverted) return fail(VVCX_ERR_STATE, "LMCS slice: vvcx_lmcs_inverse_reco first (the loop filters work in the original domain)");
+  const int cw = h->ctus_w, chh = h->ctus_h, nctu = cw * chh;
+  std::vector<VxAlfFrame> tabs; std::vector<VxAlfCtu> cts;
+  const int rr = alf_build(aps, n_aps, slices, ctus, h->n_frames, nctu, h->cfg.bit_depth, h->cfg.chroma, tabs);
+  if (rr != VVCX_OK) return rr;
+  alf_ctus(slices, ctus, h->n_frames, nctu, h->cfg.chroma, cts);
+  DevGuard guard(h->cfg.device);
+  hipStream_t stream = (hipStream_t) hip_stream;
+  const size_t bps = h->cfg.bit_depth == 8 ? 1 : 2, ny = (size_t) h->cfg.pic_w * h->cfg.pic_h, per_frame = ny + 2 * (ny >> 2);
+  if (h->sao_tmp_cap < (size_t) h->n_frames * per_frame * bps) { (void) hipFree(h->sao_tmp_d); h->sao_tmp_d = nullptr; h->sao_tmp_cap = (size_t) h->n_frames * per_frame * bps; HIPCHK(hipMalloc(&h->sao_tmp_d, h->sao_tmp_cap)); }
+  if (h->alf_cap < (size_t) h->n_frames) {
+    (void) hipFree(h->alf_tab_d); (void) hipFree(h->alf_ctu_d); h->alf_tab_d = nullptr; h->alf_ctu_d = nullptr; h->alf_cap = (size_t) h->n_frames;
+    HIPCHK(hipMalloc((void **) &h->alf_tab_d, h->alf_cap * sizeof(VxAlfFrame))); HIPCHK(hipMalloc((void **) &h->alf_ctu_d, h->alf_cap * nctu * sizeof(VxAlfCtu)));
+  }
+  HIPCHK(hipMemcpyAsync(h->alf_tab_d, tabs.data(), tabs.size() * sizeof(VxAlfFrame), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(h->alf_ctu_d, cts.data(), cts.size() * sizeof(VxAlfCtu), hipMemcpyHostToDevice, stream));
+  VxAlfParams p; memset(&p, 0, sizeof p);
+  p.frames = h->frames_d; p.tabs = h->alf_tab_d; p.ctus = h->alf_ctu_d; p.tmp = h->sao_tmp_d; p.tmp_frame = per_frame; p.tmp_comp[0] = 0; p.tmp_comp[1] = ny; p.tmp_comp[2] = ny + (ny >> 2);
+  p.classes = nullptr; p.pic_w = h->cfg.pic_w; p.pic_h = h->cfg.pic_h; p.ctus_w = cw; p.ctus_h = chh; p.bit_depth = h->cfg.bit_depth; p.chroma = h->cfg.chroma;
+  HIPCHK(hipEventRecord(h->ev0, stream));
+  alf_launch(p, h->n_frames, bps, stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev1, stream));
+  HIPCHK(hipStreamSynchronize(stream));             // (the host tables above must outlive the copies)
+  HIPCHK(hipEventElapsedTime(&h->last_alf_ms, h->ev0, h->ev1));
+  return VVCX_OK;
+}
+// the same kernels on one picture in host memory (uint16 planes, stride = plane width; filtered in place): the leaf entry the filter is pinned through
+extern "C" int vvcx_alf_picture(int pic_w, int pic_h, int bit_depth, const vvcx_alf_aps *aps, int n_aps, const vvcx_alf_slice *slice, const vvcx_alf_ctu *ctus,
+                                uint16_t *y, uint16_t *cb, uint16_t *cr, uint8_t *classes, int device)
+{
+  if (!slice || !ctus || !y || !cb || !cr || (n_aps > 0 && !aps)) return fail(VVCX_ERR_ARG, "null argument");
+  if (pic_w < 8 || pic_h < 8 || (pic_w & 7) || (pic_h & 7) || pic_w > 16384 || pic_h > 16384 || bit_depth < 8 || bit_depth > 12) return fail(VVCX_ERR_ARG, "vvcx_alf_picture: picture size / bit depth");
+  const int cw = (pic_w + 127) / 128, chh = (pic_h + 127) / 128, nctu = cw * chh;
+  std::vector<VxAlfFrame> tabs; std::vector<VxAlfCtu> cts;
+  const int rr = alf_build(aps, n_aps, slice, ctus, 1, nctu, bit_depth, 1, tabs);
+  if (rr != VVCX_OK) return rr;
+  alf_ctus(slice, ctus, 1, nctu, 1, cts);
+  DevGuard guard(device);
+  const size_t ny = (size_t) pic_w * pic_h, nc = ny >> 2, per_frame = ny + 2 * nc, ncls = (size_t) (pic_w >> 2) * (pic_h >> 2);
+  uint16_t *pl_d = nullptr, *tmp_d = nullptr; VxFrameDev *fd_d = nullptr; VxAlfFrame *tab_d = nullptr; VxAlfCtu *ctu_d = nullptr; uint8_t *cls_d = nullptr;
+  int rc = VVCX_OK;
+  if (hipMalloc((void **) &pl_d, per_frame * 2) != hipSuccess || hipMalloc((void **) &tmp_d, per_frame * 2) != hipSuccess || hipMalloc((void **) &fd_d, sizeof(VxFrameDev)) != hipSuccess ||
+      hipMalloc((void **) &tab_d, sizeof(VxAlfFrame)) != hipSuccess || hipMalloc((void **) &ctu_d, cts.size() * sizeof(VxAlfCtu)) != hipSuccess || hipMalloc((void **) &cls_d, ncls) != hipSuccess)
+    rc = fail(VVCX_ERR_DEVICE, "hipMalloc failed for the ALF of a %dx%d picture", pic_w, pic_h);
+  if (rc == VVCX_OK) {
+    VxFrameDev fd; memset(&fd, 0, sizeof fd);
+    fd.rec[0] = pl_d; fd.rec[1] = pl_d + ny; fd.rec[2] = pl_d + ny + nc; fd.stride[0] = pic_w; fd.stride[1] = fd.stride[2] = pic_w >> 1;
+    VxAlfParams p; memset(&p, 0, sizeof p);
+    p.frames = fd_d; p.tabs = tab_d; p.ctus = ctu_d; p.tmp = tmp_d; p.tmp_frame = per_frame; p.tmp_comp[0] = 0; p.tmp_comp[1] = ny; p.tmp_comp[2] = ny + nc;
+    p.classes = cls_d; p.pic_w = pic_w; p.pic_h = pic_h; p.ctus_w = cw; p.ctus_h = chh; p.bit_depth = bit_depth; p.chroma = 1;
+    bool ok = hipMemcpy(pl_d, y, ny * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(pl_d + ny, cb, nc * 2, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(pl_d + ny + nc, cr, nc * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(fd_d, &fd, sizeof fd, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(tab_d, tabs.data(), sizeof(VxAlfFrame), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(ctu_d, cts.data(), cts.size() * sizeof(VxAlfCtu), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemset(cls_d, 255, ncls) == hipSuccess;
+    if (ok) {
+      alf_launch(p, 1, 2, 0);
+      ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipMemcpy(y, pl_d, ny * 2, hipMemcpyDeviceToHost) == hipSuccess &&
+           hipMemcpy(cb, pl_d + ny, nc * 2, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(cr, pl_d + ny + nc, nc * 2, hipMemcpyDeviceToHost) == hipSuccess &&
+           (!classes || hipMemcpy(classes, cls_d, ncls, hipMemcpyDeviceToHost) == hipSuccess);
+    }
+    if (!ok) rc = fail(VVCX_ERR_DEVICE, "ALF of a picture: a HIP call failed");
+  }
+  (void) hipFree(pl_d); (void) hipFree(tmp_d); (void) hipFree(fd_d); (void) hipFree(tab_d); (void) hipFree(ctu_d); (void) hipFree(cls_d);
+  return rc;
+}
+extern "C" float vvcx_last_alf_ms(const vvcx_handle *h) { return h ? h->last_alf_ms : 0.f; }
 
 // the same two kernels on a picture the caller describes by a CU table (host memory in, host memory out): the unit maps the kernels read are built here from the rows
 extern "C" int vvcx_deblock_cu_table(int pic_w, int pic_h, int bit_depth, int qp, int qp_cb, int qp_cr, int beta_offset_div2, int tc_offset_div2,

@@ -115,6 +115,19 @@ struct VxSaoParams {
   int32_t pic_w, pic_h, ctus_w, ctus_h, bit_depth, chroma, lf_across_tiles, pad_;
 };
 
+// adaptive loop filter (vvcx_alf.hip): per frame the per-class tables of the slice's parameter sets, per CTU the caller's choices
+struct VxAlfCtu { uint8_t flag[3]; int8_t set; uint8_t alt[2]; };
+struct VxAlfFrame { int16_t luma_coeff[8][25][12], luma_clip[8][25][12], chroma_coeff[8][6], chroma_clip[8][6]; int32_t n_sets, n_alt; };
+struct VxAlfParams {
+  const VxFrameDev *frames;
+  const VxAlfFrame *tabs;         // [frame]
+  const VxAlfCtu *ctus;           // [frame][ctu]
+  void *tmp;                      // copy of the pictures before the filter: per frame tmp_frame samples, component c at tmp_comp[c], rows of the plane's width
+  uint64_t tmp_frame, tmp_comp[3];
+  uint8_t *classes;               // optional: class | transpose << 5 per luma 4 x 4 block, per frame (pic_w / 4) * (pic_h / 4)
+  int32_t pic_w, pic_h, ctus_w, ctus_h, bit_depth, chroma;
+};
+
 // per-stream scratch layout (bytes)
 #define VXD_STORE_REC   (128 * 128 * 2)
 #define VXD_STORE_UNITS (32 * 32 * (int) sizeof(VxUnit))

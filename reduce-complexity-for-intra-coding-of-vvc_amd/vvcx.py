@@ -139,6 +139,56 @@ def sao_picture(planes, bit_depth, prm, tile_cols=1, tile_rows=1, lf_across_tile
     return out
 
 
+class AlfAps(C.Structure):
+    """vvcx_alf_aps: what an ALF parameter set carries (AlfParam of the reference)"""
+    _fields_ = [("num_luma_filters", C.c_int32), ("class_to_filter", C.c_uint8 * 25), ("nonlinear_luma", C.c_uint8), ("luma_coeff", (C.c_int16 * 12) * 25), ("luma_clip_idx", (C.c_uint8 * 12) * 25),
+                ("num_chroma_alt", C.c_int32), ("nonlinear_chroma", C.c_uint8 * 8), ("chroma_coeff", (C.c_int16 * 6) * 8), ("chroma_clip_idx", (C.c_uint8 * 6) * 8)]
+
+    @classmethod
+    def from_row(cls, row):
+        """from a row of synth.alf_test_params (ALF_APS_INTS ints)"""
+        a = cls()
+        a.num_luma_filters = int(row[0]); a.nonlinear_luma = int(row[26]); a.num_chroma_alt = int(row[627])
+        for c in range(25):
+            a.class_to_filter[c] = int(row[1 + c])
+            for k in range(12):
+                a.luma_coeff[c][k] = int(row[27 + c * 12 + k]); a.luma_clip_idx[c][k] = int(row[327 + c * 12 + k])
+        for t in range(8):
+            a.nonlinear_chroma[t] = int(row[628 + t])
+            for k in range(6):
+                a.chroma_coeff[t][k] = int(row[636 + t * 6 + k]); a.chroma_clip_idx[t][k] = int(row[684 + t * 6 + k])
+        return a
+
+
+class AlfSlice(C.Structure):
+    _fields_ = [("n_luma_aps", C.c_int32), ("luma_aps", C.c_int32 * 8), ("chroma_aps", C.c_int32)]
+
+
+def _alf_args(prms):
+    """the C arrays of one or more frames' ALF inputs (dicts of synth.alf_test_params' form; the parameter sets of the first one are the sets of the call)"""
+    aps = (AlfAps * len(prms[0]["aps"]))(*[AlfAps.from_row(r) for r in prms[0]["aps"]])
+    sl = (AlfSlice * len(prms))()
+    for i, p in enumerate(prms):
+        sl[i].n_luma_aps = len(p["luma_aps"]); sl[i].chroma_aps = int(p["chroma_aps"])
+        for k, v in enumerate(p["luma_aps"]):
+            sl[i].luma_aps[k] = int(v)
+    ctu = np.ascontiguousarray(np.concatenate([np.asarray(p["ctu"]) for p in prms]).astype(np.int8))      # {flag[3], set, alt[2]}: six bytes per CTU
+    return aps, sl, ctu
+
+
+def alf_picture(planes, bit_depth, prm, want_classes=False, device=0, lib_path=None):
+    """vvcx_alf_picture: the adaptive loop filter with parameter sets / slice / per-CTU choices (a dict of synth.alf_test_params' form) on three host planes -> filtered
+    uint16 planes (and the class | transpose << 5 bytes of the luma 4 x 4 blocks)"""
+    L = load_library(lib_path)
+    out = [np.ascontiguousarray(p.astype(np.uint16)) for p in planes]
+    h, w = out[0].shape
+    aps, sl, ctu = _alf_args([prm])
+    cls = np.zeros((h // 4, w // 4), np.uint8)
+    L.vvcx_alf_picture.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    _chk(L, L.vvcx_alf_picture(w, h, bit_depth, C.addressof(aps), len(aps), C.addressof(sl), ctu.ctypes.data, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, cls.ctypes.data, device))
+    return (out, cls) if want_classes else out
+
+
 def lmcs_analyze_device(ptrs, strides, width, height, bit_depth, qp, update_ctrl=1, lib_path=None):
     """vvcx_lmcs_analyze_device: the same analysis on planes that are in device memory (ptrs: three device addresses, strides in samples)"""
     L = load_library(lib_path)
@@ -235,6 +285,16 @@ class VvcxEncoder:
         self.L.vvcx_last_sao_ms.argtypes = [C.c_void_p]
         self._chk(self.L.vvcx_sao_bound_frames(self.h, prm.ctypes.data, int(lf_across_tiles), int(log2_offset_scale), None))
         return float(self.L.vvcx_last_sao_ms(self.h))
+
+    def alf_bound_frames(self, prms):
+        """vvcx_alf_bound_frames: prms = one dict of synth.alf_test_params' form per bound frame (the parameter sets of the first are the call's); returns the kernel time in ms"""
+        assert len(prms) == self.n_frames
+        aps, sl, ctu = _alf_args(prms)
+        self.L.vvcx_alf_bound_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.vvcx_last_alf_ms.restype = C.c_float
+        self.L.vvcx_last_alf_ms.argtypes = [C.c_void_p]
+        self._chk(self.L.vvcx_alf_bound_frames(self.h, C.addressof(aps), len(aps), C.addressof(sl), ctu.ctypes.data, None))
+        return float(self.L.vvcx_last_alf_ms(self.h))
 
     def get_levels(self, frame):
         """quantised levels of the coded picture: three int16 planes (Y, Cb, Cr)"""

@@ -553,6 +553,40 @@ def test_sample_adaptive_offset_filter_on_the_gpu():
     enc.close()
 
 
+def test_adaptive_loop_filter_on_the_gpu():
+    """The ALF kernels (csrc/vvcx_alf.hip) on the GPU: vvcx_alf_picture against the reference's planes and block classes (tests/golden/alf.npz), and vvcx_alf_bound_frames
+    behind a search, the deblocking filter and SAO against the oracle's filter on the same reconstruction (four pictures, each with parameter choices of its own; 8 and 10 bit)."""
+    import torch
+    z = np.load(os.path.join(ROOT, "tests", "golden", "alf.npz")); g, gc = z["planes"], z["classes"]; off = coff = 0
+    for (W, H, bd, seed) in O.ALF_CASES:
+        pl = pkg.alf_test_frame(W, H, bd, seed)
+        prm = O.alf_params(seed, W, H)
+        got, cls = pkg.vvcx.alf_picture(pl, bd, prm, want_classes=True)
+        assert np.array_equal(cls, gc[coff:coff + cls.size].reshape(cls.shape)), (W, H, bd); coff += cls.size
+        for c in range(3):
+            exp = g[off:off + pl[c].size].reshape(pl[c].shape); off += pl[c].size
+            assert np.array_equal(got[c].astype(np.int16), exp), (W, H, bd, c)
+    for bd in (8, 10):
+        W, H, qp, n = 384, 256, 32, 4
+        sp = pkg.slice_params(qp, bit_depth=bd)
+        frames = [pkg.synth_frame(W, H, i, bd, 60 + i, chroma_texture=0.5) for i in range(n)]
+        enc = pkg.VvcxEncoder(W, H, bd, tile_cols=3, tile_rows=2, tools=pkg.TOOLS_DEFAULT, max_frames=n)
+        enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+        dt = torch.uint8 if bd == 8 else torch.int16
+        dev = [([torch.from_numpy(p if bd == 8 else p.view(np.int16)).cuda() for p in f], [torch.zeros(p.shape, dtype=dt, device="cuda") for p in f]) for f in frames]
+        enc.bind_frames([([t.data_ptr() for t in o], [t.data_ptr() for t in r], [t.shape[1] for t in o]) for o, r in dev])
+        enc.compress_bound_frames(); enc.deblock_bound_frames(); enc.sao_bound_frames(np.stack([O.sao_params(70 + i, W, H, 3, 2) for i in range(n)]), lf_across_tiles=0)
+        before = [[t.cpu().numpy() for t in r] for _, r in dev]
+        base = O.alf_params(80, W, H)
+        prms = [dict(base, ctu=O.alf_params(80 + i, W, H)["ctu"] % np.array([2, 2, 2, 16 + len(base["luma_aps"]), base["aps"][base["chroma_aps"], 627], base["aps"][base["chroma_aps"], 627]])) for i in range(n)]
+        ms = enc.alf_bound_frames(prms)
+        assert ms > 0
+        for i in range(n):
+            exp = O.alf_picture(before[i], W, H, bd, prms[i])
+            assert all(np.array_equal(dev[i][1][c].cpu().numpy().astype(np.int16), exp[c]) for c in range(3)), (bd, i)
+        enc.close()
+
+
 def test_deblocking_of_isp_transform_edges_against_the_reference():
     """vvcx_deblock_cu_table on the GPU: CU tables with a forced random ispMode on most luma CUs; the expectation is the reference's own LoopFilter output
     (tests/golden/deblock.npz, forced_planes), not the oracle's."""
