@@ -808,8 +808,9 @@ static int sao_resolve(const vvcx_sao_param *prm, int n_frames, int cw, int chh,
 static void sao_launch(VxSaoParams &p, int n_frames, size_t bps, hipStream_t stream)
 {
   const dim3 grid((unsigned) ((p.pic_w + 255) / 256), (unsigned) p.pic_h, (unsigned) (3 * n_frames));
-  if (bps == 1) { hipLaunchKernelGGL(vvcx_sao_copy_kernel_u8, grid, dim3(256), 0, stream, p); hipLaunchKernelGGL(vvcx_sao_kernel_u8, grid, dim3(256), 0, stream, p); }
-  else { hipLaunchKernelGGL(vvcx_sao_copy_kernel_u16, grid, dim3(256), 0, stream, p); hipLaunchKernelGGL(vvcx_sao_kernel_u16, grid, dim3(256), 0, stream, p); }
+  const dim3 gridC((unsigned) ((p.pic_w + 1023) / 1024), (unsigned) ((p.pic_h + 3) / 4), (unsigned) (3 * n_frames));      // the copy: strips of 4 rows x 1024 samples
+  if (bps == 1) { hipLaunchKernelGGL(vvcx_sao_copy_kernel_u8, gridC, dim3(256), 0, stream, p); hipLaunchKernelGGL(vvcx_sao_kernel_u8, grid, dim3(256), 0, stream, p); }
+  else { hipLaunchKernelGGL(vvcx_sao_copy_kernel_u16, gridC, dim3(256), 0, stream, p); hipLaunchKernelGGL(vvcx_sao_kernel_u16, grid, dim3(256), 0, stream, p); }
 }
 extern "C" int vvcx_sao_bound_frames(vvcx_handle *h, const vvcx_sao_param *prm, int lf_across_tiles, int log2_offset_scale, void *hip_stream)
 {
@@ -946,7 +947,7 @@ static void alf_ctus(const vvcx_alf_slice *slices, const vvcx_alf_ctu *ctus, int
 }
 static void alf_launch(VxAlfParams &p, int n_frames, size_t bps, hipStream_t stream)
 {
-  const dim3 gridC((unsigned) ((p.pic_w + 255) / 256), (unsigned) p.pic_h, (unsigned) (3 * n_frames));
+  const dim3 gridC((unsigned) ((p.pic_w + 1023) / 1024), (unsigned) ((p.pic_h + 3) / 4), (unsigned) (3 * n_frames));      // the copy: strips of 4 rows x 1024 samples
   const dim3 gridF((unsigned) ((p.pic_w + 63) / 64), (unsigned) ((p.pic_h + 15) / 16), (unsigned) (3 * n_frames));
   if (bps == 1) { hipLaunchKernelGGL(vvcx_alf_copy_kernel_u8, gridC, dim3(256), 0, stream, p); hipLaunchKernelGGL(vvcx_alf_kernel_u8, gridF, dim3(256), 0, stream, p); }
   else { hipLaunchKernelGGL(vvcx_alf_copy_kernel_u16, gridC, dim3(256), 0, stream, p); hipLaunchKernelGGL(vvcx_alf_kernel_u16, gridF, dim3(256), 0, stream, p); }

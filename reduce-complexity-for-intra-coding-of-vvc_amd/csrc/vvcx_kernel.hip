@@ -2468,7 +2468,7 @@ __device__ __noinline__ void isp_code_cu(uint8_t *scratch, int w, int h, int dir
   const VxParams &p = L.par;
   w = uni(w); h = uni(h); dir = uni(dir); isp = uni(isp); given_tucbf = uni(given_tucbf); ci = uni(ci);
   scratch = uni_p(scratch); given = uni_p(given); rec = uni_p(rec); lev = uni_p(lev); tile = uni_p(tile); out = uni_p(out); limit = uni_d(limit);
-  const int bd = p.bit_depth, hor = isp == 1;
+  const int bd = uni(p.bit_depth), hor = isp == 1;
   const int psz = isp_split_dim(w, h, hor), tw = hor ? w : psz, th = hor ? psz : h, n = hor ? h / psz : w / psz;
   const int predRegDiff = !hor && ((w == 8 && h > 4) || w == 4);         // CU::isPredRegDiffFromTB
   const int wave = uni(VTX >> 6), x0 = uni(L.nx), y0 = uni(L.ny);
@@ -2613,7 +2613,7 @@ __device__ void stage_a_small(const VxParams &p, int wave, int lane, int c_begin
   const int py = pl / BW, px = pl - py * BW;
   int16_t *pred = &L.wm[wave].slot[0];
   int16_t *scr = (int16_t *) L.wm[wave].tmp;
-  const int bd = p.bit_depth;
+  const int bd = uni(p.bit_depth);
   // mode bits of all candidates of this wave up front, one candidate per lane: lane l serves step l / G, slot l % G
   unsigned long long mbits = 0;
   { const int cc = c_begin + wave * G + (lane / G) * (NW * G) + (lane % G); if (cc < c_end) mbits = luma_mode_bits(L.ctxs[CI_CUR], L.ny, L.cand[cc].mode, L.cand[cc].mrl); }
@@ -2683,7 +2683,7 @@ template <bool SMALL>
 __device__ __noinline__ void stage_a_mip(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h, int c_end)
 {
   scratch = uni_p(scratch); wave = uni(wave); w = uni(w); h = uni(h); c_end = uni(c_end);
-  const int P = w * h, bd = p.bit_depth;
+  const int P = w * h, bd = uni(p.bit_depth);
   int16_t *pred = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, 0);
   int16_t *scr = SMALL ? (int16_t *) L.wm[wave].tmp : (int16_t *) wave_tmp(scratch, P >> 1, wave);
   for (int c = wave; c < c_end; c += NW) {
@@ -2706,7 +2706,7 @@ template <bool SMALL>
 __device__ void stage_a_loop(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h, int c_end)
 {
   scratch = uni_p(scratch); wave = uni(wave); w = uni(w); h = uni(h); c_end = uni(c_end);
-  const int P = w * h, bd = p.bit_depth;
+  const int P = w * h, bd = uni(p.bit_depth);
   int16_t *pred = SMALL ? L.wm[wave].slot : slot_rec(scratch, P, wave, 0);
   int16_t *scr = SMALL ? (int16_t *) L.wm[wave].tmp : (int16_t *) wave_tmp(scratch, P >> 1, wave);
   unsigned long long mbits = 0;                         // mode bits of this wave's candidates up front, lane j serves step j
@@ -2796,7 +2796,7 @@ template <bool SMALL, bool MTS>
 __device__ void stage_b_loop(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h)
 {
   scratch = uni_p(scratch); wave = uni(wave); w = uni(w); h = uni(h);
-  const int P = w * h, bd = p.bit_depth;
+  const int P = w * h, bd = uni(p.bit_depth);
   if (lane == 0) L.wave_best[wave] = -1;
   double wbest = MAX_DOUBLE;
   int cur = 0;                                    // !SMALL: slot being written; the other one holds the wave's best so far
@@ -2912,7 +2912,7 @@ __device__ __noinline__ void stage_b_rounds(uint8_t *scratch, int wave, int lane
 {
   scratch = uni_p(scratch); wave = uni(wave); w = uni(w); h = uni(h);      // uniform arguments arrive in vector registers: scalar from here on
   const VxParams &p = L.par;
-  const int P = w * h, bd = p.bit_depth, total = imin(32, w) * imin(32, h);
+  const int P = w * h, bd = uni(p.bit_depth), total = imin(32, w) * imin(32, h);
   const int mtsOk = mts_allowed(p, w, h);
   // LFNST on: one transform per pass for every candidate (DCT-II with the pass's LFNST kernel, or the pass's MTS pair), no per-block MTS pruning
   const int lfOn = uni((int) (p.tools & TOOL_LFNST)) != 0, psLf = lfOn ? uni((int) L.ps_lfnst) : 0, psMts = lfOn ? uni((int) L.ps_mts) : 0, psGrp = uni((int) L.ps_grp);
@@ -3216,7 +3216,7 @@ template <bool SMALL>
 __device__ void chroma_rd_loop(const VxParams &p, uint8_t *scratch, int wave, int lane, int w, int h)
 {
   scratch = uni_p(scratch); wave = uni(wave); w = uni(w); h = uni(h);
-  const int P = w * h, bd = p.bit_depth;
+  const int P = w * h, bd = uni(p.bit_depth);
   const int16_t *lmin = lm_in_buf(scratch, 2 * P);
   if (uni(L.lm_ok)) {
     // SATD pre-selection (1479-1582): the first seven candidates except LM, planar (and DM, which is the eighth) are ranked by
@@ -3341,7 +3341,7 @@ __device__ __noinline__ void chroma_rd_rounds(uint8_t *scratch, int wave, int la
 {
   scratch = uni_p(scratch); wave = uni(wave); w = uni(w); h = uni(h);
   const VxParams &p = L.par;
-  const int P = w * h, bd = p.bit_depth, total = imin(32, w) * imin(32, h);
+  const int P = w * h, bd = uni(p.bit_depth), total = imin(32, w) * imin(32, h);
   const int16_t *lmin = lm_in_buf(scratch, 2 * P);
   const int16_t *org = org_tile(scratch, 2 * P);
   int16_t *poolPred = (int16_t *) (scratch + VXD_OFF_POOL), *poolCoef = (int16_t *) (scratch + VXD_OFF_POOL_COEF); uint8_t *poolNodes = scratch + VXD_OFF_POOL_NODES;
@@ -3631,7 +3631,7 @@ template <bool SMALL>
 __device__ void reuse_eval(const VxParams &p, uint8_t *scratch, int lane, int ch, int w, int h)
 {
   scratch = uni_p(scratch); ch = uni(ch); w = uni(w); h = uni(h);
-  const int P = w * h, n = ch ? 2 * P : P, bd = p.bit_depth;
+  const int P = w * h, n = ch ? 2 * P : P, bd = uni(p.bit_depth);
   int16_t *recb = SMALL ? L.wm[0].slot : slot_rec(scratch, n, 0, 0), *levb = SMALL ? L.wm[0].slot + BUF : slot_lev(scratch, n, 0, 0);
   const int mode = uni(L.rd[0].mode), fm = uni(L.rd[0].mrl), cbfm = uni(L.rd_cbf[0]);
   Cab cb; cb.ci = CI_W(0); cb.bits = 0;
@@ -3736,7 +3736,7 @@ __device__ __noinline__ void op_reuse(const VxParams &p_, const VxFrameDev &fd_,
   scratch = uni_p(scratch);
   const VxParams &p = L.par; (void) p_; const VxFrameDev &fd = L.fdv; (void) fd_;
   const int wave = uni(VTX >> 6), lane = VTX & 63;
-  const int ch = uni(L.tree_ch), bd = p.bit_depth;
+  const int ch = uni(L.tree_ch), bd = uni(p.bit_depth);
   const int sh = ch ? 1 : 0;
   const int x = uni(L.nx) >> sh, y = uni(L.ny) >> sh, w = uni(L.nw) >> sh, h = uni(L.nh) >> sh, P = w * h, n = ch ? 2 * P : P;
   if (!ch) op_luma_prep<T>(p, fd);
@@ -5169,7 +5169,7 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_dq_kernel(Vx
   load_tables();
   for (int i = VTX; i < NCTX; i += NT) { L.ctxs[CI_CUR].s0[i] = ctx[i]; L.ctxs[CI_CUR].s1[i] = ctx[NCTX + i]; }
   __syncthreads();
-  const int wave = uni(VTX >> 6), lane = VTX & 63, P = w * h, bd = p.bit_depth;
+  const int wave = uni(VTX >> 6), lane = VTX & 63, P = w * h, bd = uni(p.bit_depth);
   if (wave != 0) return;
   const size_t b = (size_t) blockIdx.x * P;
   unsigned long long sse; int cbf;
@@ -5195,7 +5195,7 @@ extern "C" __global__ void __launch_bounds__(NT, VXD_WPE) vvcx_leaf_ts_kernel(Vx
   __syncthreads();
   ts_build_tables();
   __syncthreads();
-  const int wave = uni(VTX >> 6), lane = VTX & 63, P = w * h, bd = p.bit_depth;
+  const int wave = uni(VTX >> 6), lane = VTX & 63, P = w * h, bd = uni(p.bit_depth);
   if (wave != 0) return;
   const size_t b = (size_t) blockIdx.x * P;
   unsigned long long sse; int cbf, sum0 = 0;

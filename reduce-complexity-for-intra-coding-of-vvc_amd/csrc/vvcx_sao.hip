@@ -11,14 +11,21 @@
 #include <stdint.h>
 #include "vvcx_dev.h"
 
+// a workgroup copies a strip of 4 rows x 1024 samples: four consecutive samples per lane and row (one word of 8-bit samples, two of 16-bit ones, when both sides are aligned)
 template <typename T>
 __device__ void sao_copy(const VxSaoParams &p)
 {
   const int f = blockIdx.z / 3, c = blockIdx.z % 3, sh = c ? 1 : 0, pw = p.pic_w >> sh, ph = p.pic_h >> sh;
-  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= pw || y >= ph || (c && !p.chroma)) return;
+  const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y0 = blockIdx.y * 4;
+  if (x >= pw || (c && !p.chroma)) return;                 // (the picture is a multiple of 8 wide: the four samples are inside the plane)
   const VxFrameDev &fd = p.frames[f];
-  ((T *) p.tmp)[p.tmp_frame * (size_t) f + p.tmp_comp[c] + (size_t) y * pw + x] = ((const T *) fd.rec[c])[(size_t) y * fd.stride[c] + x];
+  struct alignas(4 * sizeof(T)) Quad { T v[4]; };
+  for (int r = 0; r < 4 && y0 + r < ph; r++) {
+    const T *s = (const T *) fd.rec[c] + (size_t) (y0 + r) * fd.stride[c] + x;
+    T *d = (T *) p.tmp + p.tmp_frame * (size_t) f + p.tmp_comp[c] + (size_t) (y0 + r) * pw + x;
+    if ((((uintptr_t) s | (uintptr_t) d) & (4 * sizeof(T) - 1)) == 0) *(Quad *) d = *(const Quad *) s;
+    else for (int j = 0; j < 4; j++) d[j] = s[j];
+  }
 }
 
 template <typename T>
