@@ -1,6 +1,6 @@
 set -e
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04k; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG:-r04k}; mkdir -p $O; cd $R
 run() { name=$1; shift; timeout -k 10 400 python bench.py --no-cpu-baseline "$@" > $O/bench_$name.json 2> $O/bench_$name.err; python3 -c "import json; d=json.loads([l for l in open('$O/bench_$name.json') if l.startswith('{')][-1]); print('$name', round(d['value'],2), 'CTU/s', round(d['roofline']['kernel_ms'],1), 'ms')"; }
 run qp22 --qp 22 --frames 19 --steps 2 --warmup 1
 run qp27 --qp 27 --frames 19 --steps 2 --warmup 1
