@@ -384,6 +384,23 @@ def test_alf_kernels_on_cpu_emulator_match_the_reference(emu_so):
     with pytest.raises(pkg.VvcxError):
         enc.alf_bound_frames([bad])
     enc.close()
+    # edges of the interface on one small picture: no parameter set at all (fixed filter sets only, chroma off), every CTU off (the picture stays), a slice without chroma set
+    W, H, bd = 136, 72, 8
+    pl = pkg.alf_test_frame(W, H, bd, 9)
+    base = O.alf_params(9, W, H)
+    fixed = dict(aps=base["aps"][:0], luma_aps=[], chroma_aps=-1, ctu=base["ctu"] % np.array([2, 2, 2, 16, 1, 1]) | np.array([1, 0, 0, 0, 0, 0]))
+    got = vv.alf_picture(pl, bd, fixed, lib_path=emu_so)
+    exp = O.alf_picture(pl, W, H, bd, dict(fixed, aps=base["aps"], chroma_aps=0, ctu=fixed["ctu"] * np.array([1, 0, 0, 1, 0, 0])))
+    assert all(np.array_equal(got[c].astype(np.int16), exp[c]) for c in range(3)) and (got[0] != pl[0]).any() and np.array_equal(got[1], pl[1]) and np.array_equal(got[2], pl[2])
+    off = dict(base, ctu=base["ctu"] * np.array([0, 0, 0, 1, 1, 1]))
+    got = vv.alf_picture(pl, bd, off, lib_path=emu_so)
+    assert all(np.array_equal(got[c], pl[c]) for c in range(3))
+    nochroma = dict(base, chroma_aps=-1, ctu=base["ctu"] | np.array([1, 1, 1, 0, 0, 0]))
+    got = vv.alf_picture(pl, bd, nochroma, lib_path=emu_so)
+    exp = O.alf_picture(pl, W, H, bd, dict(base, ctu=nochroma["ctu"] * np.array([1, 0, 0, 1, 1, 1])))
+    assert all(np.array_equal(got[c].astype(np.int16), exp[c]) for c in range(3)) and np.array_equal(got[1], pl[1])
+    with pytest.raises(pkg.VvcxError):
+        vv.alf_picture([p[:, :60] for p in pl], bd, base, lib_path=emu_so)      # a width that is no multiple of 8
 
 
 @pytest.mark.parametrize("case", [(64, 48, 32, (1, 1)), (72, 40, 37, (1, 1))])
