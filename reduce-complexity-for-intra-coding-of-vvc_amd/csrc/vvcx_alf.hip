@@ -16,7 +16,8 @@
 #define ALF_TW 64
 #define ALF_TH 16
 #define ALF_HALO 3
-#define ALF_LW (ALF_TW + 2 * ALF_HALO)
+#define ALF_PAD 4                        // the LDS tile starts four samples left of the tile: whole aligned groups of four samples are staged
+#define ALF_LW (ALF_TW + 2 * ALF_PAD)
 #define ALF_LH (ALF_TH + 2 * ALF_HALO)
 
 __device__ static const uint8_t ALF_PERM7[4][12] = { { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11 }, { 9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6 }, { 0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11 }, { 9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6 } };
@@ -58,15 +59,24 @@ __device__ void alf_filter(const VxAlfParams &p)
   const VxAlfCtu u = p.ctus[(size_t) f * nctu + ctuY * p.ctus_w + (tx0 >> lcs)];
   if (!u.flag[c]) return;
   const T *src = (const T *) p.tmp + p.tmp_frame * (size_t) f + p.tmp_comp[c];
-  for (int i = tid; i < ALF_LH * ALF_LW; i += 256) {
-    const int ly = i / ALF_LW, lx = i - ly * ALF_LW;
-    tile[ly][lx] = (int16_t) src[(size_t) alf_clampi(ty0 - ALF_HALO + ly, 0, ph - 1) * pw + alf_clampi(tx0 - ALF_HALO + lx, 0, pw - 1)];
+  // staged in groups of four samples (the copy's rows are dense and its planes start on multiples of 16 samples: one word of 8-bit samples, two of 16-bit ones); a group
+  // left or right of the picture repeats the edge sample, a row above or below it the edge row (the reference's extendBorderPel)
+  {
+    struct alignas(4 * sizeof(T)) Quad { T v[4]; };
+    for (int i = tid; i < ALF_LH * (ALF_LW / 4); i += 256) {
+      const int ly = i / (ALF_LW / 4), g = i - ly * (ALF_LW / 4), gx = tx0 - ALF_PAD + 4 * g;
+      const T *row = src + (size_t) alf_clampi(ty0 - ALF_HALO + ly, 0, ph - 1) * pw;
+      int16_t *d = &tile[ly][4 * g];
+      if (gx < 0) { const int16_t v = (int16_t) row[0]; d[0] = d[1] = d[2] = d[3] = v; }
+      else if (gx >= pw) { const int16_t v = (int16_t) row[pw - 1]; d[0] = d[1] = d[2] = d[3] = v; }
+      else { const Quad q = *(const Quad *) (row + gx); d[0] = (int16_t) q.v[0]; d[1] = (int16_t) q.v[1]; d[2] = (int16_t) q.v[2]; d[3] = (int16_t) q.v[3]; }
+    }
   }
   // the virtual boundary of this CTU row; in the last one the reference passes the LUMA height for every component (ALFProcess 296, 313): only a picture of at most 128
   // rows reaches it
   const int vbPos = ctuY == p.ctus_h - 1 ? p.pic_h : ctuS - (c ? 2 : 4);
   __syncthreads();
-#define TL(x_, y_) ((int) tile[(y_) - ty0 + ALF_HALO][(x_) - tx0 + ALF_HALO])
+#define TL(x_, y_) ((int) tile[(y_) - ty0 + ALF_HALO][(x_) - tx0 + ALF_PAD])
   if (c == 0) {
     // ---- classes: lane (block, r) takes the window's row pair r of its block
     const int b = tid >> 2, r = tid & 3, X = tx0 + ((b & 15) << 2), Y = ty0 + ((b >> 4) << 2), yIn = Y & (ctuS - 1);
@@ -162,8 +172,12 @@ __device__ void alf_filter(const VxAlfParams &p)
 #undef TL
   const VxFrameDev &fd = p.frames[f];
   T *dst = (T *) fd.rec[c] + (size_t) Y * fd.stride[c] + X;      // the picture is a multiple of 8 wide: the four samples are inside it
+  struct alignas(4 * sizeof(T)) QuadO { T v[4]; };
+  if (((uintptr_t) dst & (4 * sizeof(T) - 1)) == 0) { QuadO q; q.v[0] = (T) out[0]; q.v[1] = (T) out[1]; q.v[2] = (T) out[2]; q.v[3] = (T) out[3]; *(QuadO *) dst = q; }
+  else {
 #pragma unroll
-  for (int j = 0; j < 4; j++) dst[j] = (T) out[j];
+    for (int j = 0; j < 4; j++) dst[j] = (T) out[j];
+  }
 }
 
 extern "C" __global__ void __launch_bounds__(256) vvcx_alf_copy_kernel_u8(VxAlfParams p) { alf_copy<uint8_t>(p); }

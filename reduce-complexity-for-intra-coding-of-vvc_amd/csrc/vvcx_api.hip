@@ -807,7 +807,7 @@ static int sao_resolve(const vvcx_sao_param *prm, int n_frames, int cw, int chh,
 }
 static void sao_launch(VxSaoParams &p, int n_frames, size_t bps, hipStream_t stream)
 {
-  const dim3 grid((unsigned) ((p.pic_w + 255) / 256), (unsigned) p.pic_h, (unsigned) (3 * n_frames));
+  const dim3 grid((unsigned) ((p.pic_w + 1023) / 1024), (unsigned) p.pic_h, (unsigned) (3 * n_frames));      // the filter: four samples per lane
   const dim3 gridC((unsigned) ((p.pic_w + 1023) / 1024), (unsigned) ((p.pic_h + 3) / 4), (unsigned) (3 * n_frames));      // the copy: strips of 4 rows x 1024 samples
   if (bps == 1) { hipLaunchKernelGGL(vvcx_sao_copy_kernel_u8, gridC, dim3(256), 0, stream, p); hipLaunchKernelGGL(vvcx_sao_kernel_u8, grid, dim3(256), 0, stream, p); }
   else { hipLaunchKernelGGL(vvcx_sao_copy_kernel_u16, gridC, dim3(256), 0, stream, p); hipLaunchKernelGGL(vvcx_sao_kernel_u16, grid, dim3(256), 0, stream, p); }

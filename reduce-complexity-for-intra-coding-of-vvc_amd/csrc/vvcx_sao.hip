@@ -4,7 +4,7 @@
 // offset of its class - band offset: one of four consecutive 1/32 bands of the sample range from the band position; edge offset: sign(c - a) + sign(c - b) over the two
 // neighbours along the class direction (0 / 90 / 135 / 45 degrees), which both have to be available: inside the picture and, unless the loop filters may cross tile
 // borders, inside the tile of the sample's CTU (deriveLoopFilterBoundaryAvailibility 818-883, one slice).  The reference walks a CTU with sign line buffers; here every
-// sample is independent: one thread per sample reads its value and its two neighbours from a copy of the deblocked picture (the filter must see unfiltered neighbours)
+// sample is independent: one lane per four samples of a row reads them and the rows of their two neighbours from a copy of the deblocked picture (the filter must see unfiltered neighbours)
 // and writes the picture in place.  Two launches per batch (copy, filter) over all frames and components; an HBM-bound pass: algorithmic bytes = every reconstructed
 // sample read once and written once (the copy doubles the traffic).  Merge parameters are resolved on the host (vvcx_api.hip: vvcx_sao_bound_frames).
 #include <hip/hip_runtime.h>
@@ -28,38 +28,64 @@ __device__ void sao_copy(const VxSaoParams &p)
   }
 }
 
+// four neighbouring samples of one row per lane (a CTU is a multiple of four wide: they share its parameters): the row itself and the rows of the two neighbours come as
+// aligned groups of four samples from the dense copy, the result leaves as one group
 template <typename T>
 __device__ void sao_filter(const VxSaoParams &p)
 {
   const int f = blockIdx.z / 3, c = blockIdx.z % 3, sh = c ? 1 : 0, pw = p.pic_w >> sh, ph = p.pic_h >> sh;
-  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= pw || y >= ph || (c && !p.chroma)) return;
-  const int lcs = 7 - sh, cx = x >> lcs, cy = y >> lcs, ctu = cy * p.ctus_w + cx;
+  const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+  if (x0 >= pw || y >= ph || (c && !p.chroma)) return;
+  const int lcs = 7 - sh, cx = x0 >> lcs, cy = y >> lcs, ctu = cy * p.ctus_w + cx;
   const VxSaoEntry e = p.table[((size_t) f * p.ctus_w * p.ctus_h + ctu) * 3 + c];
   if (e.type < 0) return;
+  struct alignas(4 * sizeof(T)) Quad { T v[4]; };
   const T *src = (const T *) p.tmp + p.tmp_frame * (size_t) f + p.tmp_comp[c];
-  const int v = src[(size_t) y * pw + x];
-  int r;
-  if (e.type == 4) {
-    const int k = ((v >> (p.bit_depth - 5)) - e.band) & 31;
-    if (k >= 4) return;
-    r = v + e.off[k];
-  } else {
-    const int dx = e.type == 1 ? 0 : 1, dy = e.type == 0 ? 0 : 1;
-    const int ax = e.type == 3 ? x + 1 : x - dx, ay = y - dy, bx = e.type == 3 ? x - 1 : x + dx, by = y + dy;      // 45 degrees: above-right and below-left
-    if (ax < 0 || ax >= pw || ay < 0 || ay >= ph || bx < 0 || bx >= pw || by < 0 || by >= ph) return;
-    if (!p.lf_across_tiles) {
-      const uint8_t t = p.tile_of_ctu[ctu];
-      if (p.tile_of_ctu[(ay >> lcs) * p.ctus_w + (ax >> lcs)] != t || p.tile_of_ctu[(by >> lcs) * p.ctus_w + (bx >> lcs)] != t) return;
-    }
-    const int a = src[(size_t) ay * pw + ax], b = src[(size_t) by * pw + bx];
-    const int s = ((v > a) - (v < a)) + ((v > b) - (v < b));
-    if (s == 0) return;
-    r = v + e.off[s < 0 ? s + 2 : s + 1];                 // -2, -1, 1, 2 -> full valley, half valley, half peak, full peak
-  }
+  const Quad cur = *(const Quad *) (src + (size_t) y * pw + x0);
   const int mx = (1 << p.bit_depth) - 1;
+  int out[4]; bool any = false;
+  if (e.type == 4) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int v = cur.v[j], k = ((v >> (p.bit_depth - 5)) - e.band) & 31;
+      out[j] = k < 4 ? v + e.off[k] : v; any |= k < 4;
+    }
+  } else {
+    // the two neighbours of sample x: (x + oa, y - dy) and (x - oa, y + dy); 0 degrees: left / right, 90: above / below, 135: above-left / below-right, 45: above-right / below-left
+    const int dy = e.type == 0 ? 0 : 1, oa = e.type == 1 ? 0 : e.type == 3 ? 1 : -1, ay = y - dy, by = y + dy;
+    int wa[12], wb[12];                                     // samples x0 - 4 .. x0 + 7 of the rows ay / by (what lies outside the plane is never used)
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      const int gx = x0 - 4 + 4 * g;
+      const bool inx = gx >= 0 && gx < pw && (g == 1 || oa != 0);
+      Quad qa = cur, qb = cur;
+      if (inx && ay >= 0 && (dy || g != 1)) qa = *(const Quad *) (src + (size_t) ay * pw + gx);
+      if (inx && by < ph && (dy || g != 1)) qb = *(const Quad *) (src + (size_t) by * pw + gx);
+#pragma unroll
+      for (int j = 0; j < 4; j++) { wa[4 * g + j] = qa.v[j]; wb[4 * g + j] = qb.v[j]; }
+    }
+    const uint8_t t = p.lf_across_tiles ? 0 : p.tile_of_ctu[ctu];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int x = x0 + j, v = cur.v[j], ax = x + oa, bx = x - oa;
+      out[j] = v;
+      if (ax < 0 || ax >= pw || ay < 0 || bx < 0 || bx >= pw || by >= ph) continue;
+      if (!p.lf_across_tiles && (p.tile_of_ctu[(ay >> lcs) * p.ctus_w + (ax >> lcs)] != t || p.tile_of_ctu[(by >> lcs) * p.ctus_w + (bx >> lcs)] != t)) continue;
+      const int a = wa[4 + j + oa], b = wb[4 + j - oa];
+      const int s = ((v > a) - (v < a)) + ((v > b) - (v < b));
+      if (s == 0) continue;
+      out[j] = v + e.off[s < 0 ? s + 2 : s + 1];            // -2, -1, 1, 2 -> full valley, half valley, half peak, full peak
+      any = true;
+    }
+  }
+  if (!any) return;
   const VxFrameDev &fd = p.frames[f];
-  ((T *) fd.rec[c])[(size_t) y * fd.stride[c] + x] = (T) (r < 0 ? 0 : r > mx ? mx : r);
+  T *dst = (T *) fd.rec[c] + (size_t) y * fd.stride[c] + x0;
+  Quad q;
+#pragma unroll
+  for (int j = 0; j < 4; j++) q.v[j] = (T) (out[j] < 0 ? 0 : out[j] > mx ? mx : out[j]);
+  if (((uintptr_t) dst & (4 * sizeof(T) - 1)) == 0) *(Quad *) dst = q;
+  else for (int j = 0; j < 4; j++) dst[j] = q.v[j];
 }
 
 extern "C" __global__ void __launch_bounds__(256) vvcx_sao_copy_kernel_u8(VxSaoParams p) { sao_copy<uint8_t>(p); }
