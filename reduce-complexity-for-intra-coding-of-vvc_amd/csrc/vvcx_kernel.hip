@@ -4684,7 +4684,7 @@ __device__ __attribute__((always_inline)) inline void control_step(const VxParam
         int mode = 0, split = 0;
         S.ispSlot++;
         ISP_T(n0); const int okn = ctrl_isp_next(f.w, f.h, mode, split); { ISP_T(n1); ISP_ADD0(27, n0, n1); ISP_ADD0(28, 0, 1); }
-        if (!okn) { S.ispPrev = 3; continue; }
+        if (!okn) { S.ispPrev = 3; if (S.ispStop[0] && S.ispStop[1]) S.ispSlot = 16; continue; }      // both splits stopped: the remaining places ask in vain (most of the 16 do)
         S.ispPrev = (int8_t) split; S.ispReqMode = (int8_t) mode; S.ispReqSplit = (int8_t) split; S.ispHave = 1;
       }
       if (S.ispPark >= 0) { L.isp_park = (uint8_t) S.ispPark; S.ispPark = -1; post(OP_ISP_PARK); return; }

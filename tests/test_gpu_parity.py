@@ -553,6 +553,21 @@ def test_sample_adaptive_offset_filter_on_the_gpu():
     enc.close()
 
 
+@pytest.mark.parametrize("seed", range(14))
+def test_randomised_sweep_of_sizes_qps_bit_depths_and_tool_sets(seed):
+    """Seeded random corner of the configuration space per case: picture size (multiples of 8, partial CTUs in both directions), QP 20..39, 8 / 10 bit, one of the legal tool
+    sets, one or two tile columns, texture mix of the synthetic picture; the device equals the oracle in results, CUs, reconstruction and work counters like everywhere else."""
+    g = np.random.default_rng(4000 + seed)
+    W, H = 8 * int(g.integers(4, 25)), 8 * int(g.integers(4, 17))
+    bd = 10 if g.random() < 0.3 else 8
+    qp = int(g.integers(20, 40))
+    tools = [0xfff, 0xffb, 0xfdf, 0xfdb, 0xb5b, 0x913, pkg.TOOLS_DEFAULT][int(g.integers(0, 7))]
+    tc = 2 if W > 136 and g.random() < 0.5 else 1
+    frame = pkg.synth_frame(W, H, int(g.integers(0, 3)), bd, int(g.integers(0, 10000)), chroma_texture=float(g.choice([0.0, 0.5, 1.0])), oriented=float(g.choice([0.0, 15.0, 30.0])),
+                            screen=float(g.choice([0.0, 0.3])))
+    _check([frame], W, H, pkg.slice_params(qp, bit_depth=bd, dep_quant=bool(tools & pkg.TOOL_DEPQUANT)), bit_depth=bd, tile_cols=tc, tools=tools, workers=4)
+
+
 def test_adaptive_loop_filter_on_the_gpu():
     """The ALF kernels (csrc/vvcx_alf.hip) on the GPU: vvcx_alf_picture against the reference's planes and block classes (tests/golden/alf.npz), and vvcx_alf_bound_frames
     behind a search, the deblocking filter and SAO against the oracle's filter on the same reconstruction (four pictures, each with parameter choices of its own; 8 and 10 bit)."""
