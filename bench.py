@@ -303,6 +303,15 @@ def main():
                               "note": "deblocks the pictures of the last step once (a second call would filter filtered samples)"}
         except Exception as ex:                                   # an older --lib build without the kernel
             out["deblock"] = {"error": str(ex)}
+        # the encoder's SAO statistics on the deblocked pictures (the O(samples) half of the SAO parameter decision): original and reconstruction read once
+        try:
+            if not lmcs:
+                _, st_ms = enc.sao_statistics_bound_frames(1)
+                st_bytes = args.frames * (W * H * 3 // 2) * (2 if bd == 10 else 1) * 2          # original + deblocked samples read once
+                out["sao_statistics"] = {"kernel": "vvcx_sao_stats_kernel_%s" % ("u8" if bd == 8 else "u16"), "launches": 1, "ms": st_ms, "frames": args.frames, "algorithmic_bytes": st_bytes,
+                                         "achieved_GBps": st_bytes / (st_ms / 1e3) / 1e9 if st_ms > 0 else None, "frac_of_hbm_peak": st_bytes / (st_ms / 1e3) / 1e9 / HBM_PEAK_GBS if st_ms > 0 else None}
+        except Exception as ex:
+            out["sao_statistics"] = {"error": str(ex)}
         # third kernel pair (not part of the timed step): sample adaptive offset with seeded per-CTU parameters on the deblocked pictures - an HBM-bound pass
         # (every sample read once and written once; the copy the filter reads its unfiltered neighbours from doubles the traffic)
         try:

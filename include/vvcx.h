@@ -216,6 +216,14 @@ float vvcx_last_deblock_ms(const vvcx_handle *h);
 typedef struct vvcx_sao_param { int8_t mode, type, band, offset[4]; } vvcx_sao_param;
 int   vvcx_sao_bound_frames(vvcx_handle *h, const vvcx_sao_param *prm, int lf_across_tiles, int log2_offset_scale, void *hip_stream);
 float vvcx_last_sao_ms(const vvcx_handle *h);
+/* ≙ EncSampleAdaptiveOffset::getStatistics (EL/EncSampleAdaptiveOffset.cpp:284-353 with getBlkStats 1135-1549, SAOLcuBoundary 0 as in the cfg): the statistics the
+ * reference's parameter decision (decideBlkParams) works from, gathered on the device from the bound original and the deblocked reconstruction - the O(samples) half of that
+ * decision; its RD half stays with the caller's encoder.  stats (host memory): [frame][ctu raster address][component][type 0..3 = edge class 0 / 90 / 135 / 45 degrees,
+ * 4 = band][0: count, 1: sum of (original - deblocked)][32] int64 (≙ SAOStatData::count / ::diff; edge types use entries 0..4 = the classes full valley, half valley, plain,
+ * half peak, full peak; band: 32 bands).  Call it after vvcx_deblock_bound_frames and before vvcx_sao_bound_frames.  Not available for an LMCS slice (the handle keeps the
+ * mapped original only): VVCX_ERR_UNSUPPORTED. */
+int   vvcx_sao_statistics_bound_frames(vvcx_handle *h, int lf_across_tiles, int64_t *stats, void *hip_stream);
+float vvcx_last_sao_stats_ms(const vvcx_handle *h);
 /* the same filter on one picture in host memory (uint16 planes, stride = plane width, filtered in place; prm[ctu][component]): needs no handle */
 int   vvcx_sao_picture(int pic_w, int pic_h, int bit_depth, int tile_cols, int tile_rows, const vvcx_sao_param *prm, int lf_across_tiles, int log2_offset_scale,
                        uint16_t *y, uint16_t *cb, uint16_t *cr, int device);

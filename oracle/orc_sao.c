@@ -79,3 +79,63 @@ int orc_sao_picture(int w, int h, int bit_depth, int tile_cols, int tile_rows, i
   free(type); free(off);
   return rc;
 }
+
+/*
+ * The encoder's SAO statistics (EL/EncSampleAdaptiveOffset.cpp getStatistics 284-353 / getBlkStats 1135-1549 with SAOLcuBoundary 0, i.e. isCalculatePreDeblockSamples
+ * false and the skip lines of createEncData 131-134): per CTU, component and type the number of samples of every class and the sum of (original - deblocked) over them.
+ * PARITY UNPINNED for the region rules: EncSampleAdaptiveOffset is an EncoderLib unit behind CABACWriter.h (which includes OpenCV in this fork) and does not compile
+ * here, so which samples are counted follows the reference by reading only; the class of a sample is the pinned filter's (tests tie the two: with offsets o the sums predict
+ * the SSE change of that filter on the counted samples).
+ *
+ * The reference walks a CTU with sign line buffers; per sample that is: EO class = 2 + sign(c - a) + sign(c - b) over the same two neighbours as the filter (classes
+ * 0..4, 2 = plain), band = c >> (bitDepth - 5).  Counted are the samples of the CTU except: the last 5 luma / 3 chroma columns when a CTU follows to the right and the last 4 / 2
+ * rows when one follows below (their deblocking is not final when a pipelined encoder decides the CTU); for the edge types also the column / row whose neighbour lies outside
+ * the picture, or left of / above the CTU in another tile when the filters do not cross tile borders (deriveLoopFilterBoundaryAvailibility 1551-1576; right and below only
+ * the picture border counts, 309-313), with the reference's treatment of the first row of the diagonal types (1318-1321, 1426-1431).
+ * out: [ctu][component][type 0..4][0: count, 1: diff][32] int64 (edge types use entries 0..4).
+ */
+int orc_sao_statistics(int w, int h, int bit_depth, int tile_cols, int tile_rows, int lf_across_tiles, const int16_t *const org[3], const int16_t *const rec[3], int64_t *out)
+{
+  const int cw = (w + 127) >> 7, chh = (h + 127) >> 7, nctu = cw * chh;
+  memset(out, 0, (size_t) nctu * 3 * 5 * 64 * sizeof(int64_t));
+  for (int a = 0; a < nctu; a++) {
+    const int cx = a % cw, cy = a / cw;
+    const int tx = tile_of(cx, cw, tile_cols), ty = tile_of(cy, chh, tile_rows);
+    const int left = cx > 0 && (lf_across_tiles || tile_of(cx - 1, cw, tile_cols) == tx), above = cy > 0 && (lf_across_tiles || tile_of(cy - 1, chh, tile_rows) == ty);
+    const int aboveLeft = cx > 0 && cy > 0 && (lf_across_tiles || (tile_of(cx - 1, cw, tile_cols) == tx && tile_of(cy - 1, chh, tile_rows) == ty));
+    const int right = cx + 1 < cw, below = cy + 1 < chh;
+    for (int c = 0; c < 3; c++) {
+      const int sh = c ? 1 : 0, pw = w >> sh, ph = h >> sh, cs = 128 >> sh, x0 = cx * cs, y0 = cy * cs;
+      const int cwid = (x0 + cs > pw ? pw - x0 : cs), chei = (y0 + cs > ph ? ph - y0 : cs), skipR = c ? 3 : 5, skipB = c ? 2 : 4;
+      const int16_t *s = rec[c], *o = org[c];
+      for (int t = 0; t < 5; t++) {
+        int64_t *cnt = out + ((size_t) (a * 3 + c) * 5 + t) * 64, *dif = cnt + 32;
+        const int endXr = right ? cwid - skipR : cwid;          /* right end when no right neighbour is needed */
+        const int endXn = right ? cwid - skipR : cwid - 1;      /* ... when it is */
+        const int startXn = left ? 0 : 1;
+        for (int y = 0; y < chei; y++) for (int x = 0; x < cwid; x++) {
+          int in;
+          switch (t) {
+            case 0: in = y < (below ? chei - skipB : chei) && x >= startXn && x < endXn; break;
+            case 1: in = x < endXr && y >= (above ? 0 : 1) && y < (below ? chei - skipB : chei - 1); break;
+            case 2: in = y == 0 ? (x >= (aboveLeft ? 0 : 1) && x < (above ? endXn : 1)) : (x >= startXn && x < endXn && y < (below ? chei - skipB : chei - 1)); break;
+            case 3: in = x >= startXn && x < endXn && (y == 0 ? above : y < (below ? chei - skipB : chei - 1)); break;
+            default: in = x < endXr && y < (below ? chei - skipB : chei); break;
+          }
+          if (!in) continue;
+          const int X = x0 + x, Y = y0 + y, v = s[(size_t) Y * pw + X];
+          int k;
+          if (t == 4) k = v >> (bit_depth - 5);
+          else {
+            const int dx = t == 1 ? 0 : 1, dy = t == 0 ? 0 : 1;
+            const int ax = t == 3 ? X + 1 : X - dx, ay = Y - dy, bx = t == 3 ? X - 1 : X + dx, by = Y + dy;
+            if (ax < 0 || ax >= pw || ay < 0 || ay >= ph || bx < 0 || bx >= pw || by < 0 || by >= ph) return -1;      /* the region rules keep every neighbour inside the picture */
+            k = 2 + sgn_(v - s[(size_t) ay * pw + ax]) + sgn_(v - s[(size_t) by * pw + bx]);
+          }
+          cnt[k]++; dif[k] += o[(size_t) Y * pw + X] - v;
+        }
+      }
+    }
+  }
+  return 0;
+}

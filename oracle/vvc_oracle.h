@@ -130,6 +130,9 @@ int      orc_forest_predict_rows(orc_enc *e, const int32_t *rows, int n, int32_t
 int      orc_deblock_frame(orc_enc *e, int beta_offset_div2, int tc_offset_div2);
 /* the same filter on a CU table {ch, x, y, w, h, ispMode} (luma samples) and 4:2:0 planes with stride = plane width; qp_cb / qp_cr = mapped chroma QPs */
 int      orc_deblock_table(int w, int h, int bd, int qp, int qp_cb, int qp_cr, const int *rows, int nrows, int16_t *y, int16_t *cb, int16_t *cr);
+/* the encoder's SAO statistics (EL/EncSampleAdaptiveOffset.cpp getStatistics, SAOLcuBoundary 0): out [ctu][component][type 0..4][count | diff][32] int64.  PARITY UNPINNED
+ * for the region rules (see orc_sao.c) */
+int      orc_sao_statistics(int w, int h, int bit_depth, int tile_cols, int tile_rows, int lf_across_tiles, const int16_t *const org[3], const int16_t *const rec[3], int64_t *out);
 /* adaptive loop filter with given parameter sets on 4:2:0 planes with stride = plane width (CL/AdaptiveLoopFilter.cpp ALFProcess; orc_alf.c) */
 typedef struct {                      /* what an ALF parameter set carries (AlfParam, CL/AlfParameters.h) */
   int32_t num_luma_filters; uint8_t class_to_filter[25]; uint8_t nonlinear_luma; int16_t luma_coeff[25][12]; uint8_t luma_clip_idx[25][12];

@@ -31,6 +31,8 @@ extern "C" __global__ void vvcx_sao_copy_kernel_u8(VxSaoParams p);
 extern "C" __global__ void vvcx_sao_copy_kernel_u16(VxSaoParams p);
 extern "C" __global__ void vvcx_sao_kernel_u8(VxSaoParams p);
 extern "C" __global__ void vvcx_sao_kernel_u16(VxSaoParams p);
+extern "C" __global__ void vvcx_sao_stats_kernel_u8(VxSaoStatParams p);
+extern "C" __global__ void vvcx_sao_stats_kernel_u16(VxSaoStatParams p);
 extern "C" __global__ void vvcx_alf_copy_kernel_u8(VxAlfParams p);
 extern "C" __global__ void vvcx_alf_copy_kernel_u16(VxAlfParams p);
 extern "C" __global__ void vvcx_alf_kernel_u8(VxAlfParams p);
@@ -97,6 +99,7 @@ struct vvcx_handle {
   std::vector<uint32_t> activity;               // per (frame, CTU) of the bound pictures: orders the stream queue of a launch, longest first
   hipEvent_t ev0, ev1; float last_ms, last_deblock_ms, last_sao_ms;
   void *sao_tmp_d; size_t sao_tmp_cap; VxSaoEntry *sao_tab_d; size_t sao_tab_cap; uint8_t *sao_tile_d;      // vvcx_sao_bound_frames: picture copy, resolved parameters, CTU -> tile
+  long long *sao_stat_d; size_t sao_stat_cap; float last_sao_stats_ms;      // vvcx_sao_statistics_bound_frames
   VxAlfFrame *alf_tab_d; VxAlfCtu *alf_ctu_d; size_t alf_cap; float last_alf_ms;      // vvcx_alf_bound_frames: per-frame tables and per-CTU choices (the picture copy is the SAO one)
   // a submitted, not yet collected launch (vvcx_submit_ctus .. vvcx_wait_ctus): staging the async copies read from / write to stays alive here
   bool pending; hipStream_t pend_stream; int pend_n; VxCtuRes *pend_res; int pend_cap;
@@ -206,7 +209,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   h->frames_d = nullptr; h->lev_d = nullptr; h->units_d = nullptr; h->stream_ctx_d = nullptr; h->scratch_d = nullptr; h->scratch_cap = 0;
   h->payload_d = nullptr; h->payload_off_d = nullptr; h->payload_cap_d = nullptr; h->arith_d = nullptr;
   h->streams_d = nullptr; h->task_ctu_d = nullptr; h->results_d = nullptr; h->task_cap = 0; h->stream_cap = 0; h->counters_d = nullptr;
-  h->sao_tmp_d = nullptr; h->sao_tmp_cap = 0; h->sao_tab_d = nullptr; h->sao_tab_cap = 0; h->sao_tile_d = nullptr; h->last_sao_ms = 0.f; h->alf_tab_d = nullptr; h->alf_ctu_d = nullptr; h->alf_cap = 0; h->last_alf_ms = 0.f;
+  h->sao_tmp_d = nullptr; h->sao_tmp_cap = 0; h->sao_tab_d = nullptr; h->sao_tab_cap = 0; h->sao_tile_d = nullptr; h->last_sao_ms = 0.f; h->alf_tab_d = nullptr; h->alf_ctu_d = nullptr; h->alf_cap = 0; h->last_alf_ms = 0.f; h->sao_stat_d = nullptr; h->sao_stat_cap = 0; h->last_sao_stats_ms = 0.f;
   h->dq_d = nullptr; h->lmcs_on = false; h->lmcs_inverted = false; h->lmcs_lut_d = nullptr; h->lmcs_org_d = nullptr; h->lmcs_org_cap = 0;
   const int F = cfg->max_frames;
   if (hipMalloc((void **) &h->frames_d, sizeof(VxFrameDev) * F) != hipSuccess || hipMalloc((void **) &h->lev_d, h->lev_frame * 2 * F) != hipSuccess ||
@@ -237,7 +240,7 @@ extern "C" void vvcx_destroy(vvcx_handle *h)
   (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d); (void) hipFree(h->wpp_progress_d); (void) hipFree(h->wpp_sync_d); (void) hipFree(h->wpp_sched_d); (void) hipFree(h->train_rows_d); (void) hipFree(h->train_n_d);
   (void) hipFree(h->payload_d); (void) hipFree(h->payload_off_d); (void) hipFree(h->payload_cap_d); (void) hipFree(h->arith_d);
   (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
-  (void) hipFree(h->sao_tmp_d); (void) hipFree(h->sao_tab_d); (void) hipFree(h->sao_tile_d); (void) hipFree(h->alf_tab_d); (void) hipFree(h->alf_ctu_d);
+  (void) hipFree(h->sao_tmp_d); (void) hipFree(h->sao_tab_d); (void) hipFree(h->sao_tile_d); (void) hipFree(h->alf_tab_d); (void) hipFree(h->alf_ctu_d); (void) hipFree(h->sao_stat_d);
   (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d); (void) hipFree(h->dq_d); (void) hipFree(h->lmcs_lut_d); (void) hipFree(h->lmcs_org_d);
   if (h->pending) (void) hipStreamSynchronize(h->pend_stream);
   (void) hipHostFree(h->pend_res);
@@ -883,6 +886,47 @@ extern "C" int vvcx_sao_picture(int pic_w, int pic_h, int bit_depth, int tile_co
   return rc;
 }
 extern "C" float vvcx_last_sao_ms(const vvcx_handle *h) { return h ? h->last_sao_ms : 0.f; }
+
+// ≙ EncSampleAdaptiveOffset::getStatistics (EL/EncSampleAdaptiveOffset.cpp:284-353, SAOLcuBoundary 0) on the bound, deblocked pictures: the statistics the reference's
+// decideBlkParams works from, in host memory as [frame][ctu][component][type 0..4][count | diff][32] int64 (≙ SAOStatData per CTU, component and type)
+extern "C" int vvcx_sao_statistics_bound_frames(vvcx_handle *h, int lf_across_tiles, int64_t *stats, void *hip_stream)
+{
+  NOT_PENDING(h);
+  if (!h || !stats) return fail(VVCX_ERR_ARG, "null argument");
+  if (!h->n_frames || !h->have_slice) return fail(VVCX_ERR_STATE, "no bound frames / slice");
+  for (size_t i = 0; i < h->next_idx.size(); i++)
+    if (h->next_idx[i] != (int) h->sub_ctus[i % (size_t) h->nsub].size()) return fail(VVCX_ERR_STATE, "the loop filters need every CTU of the bound pictures coded");
+  if (h->lmcs_on) return fail(VVCX_ERR_UNSUPPORTED, "SAO statistics of an LMCS slice: the handle keeps the mapped original only");
+  const int cw = h->ctus_w, chh = h->ctus_h, nctu = cw * chh;
+  std::vector<uint8_t> tile((size_t) nctu);
+  for (int a = 0; a < nctu; a++) {
+    int tx = 0, ty = 0;
+    for (int i = 0; i < h->cfg.tile_cols; i++) if (a % cw >= (i * cw) / h->cfg.tile_cols) tx = i;
+    for (int i = 0; i < h->cfg.tile_rows; i++) if (a / cw >= (i * chh) / h->cfg.tile_rows) ty = i;
+    tile[(size_t) a] = (uint8_t) (ty * h->cfg.tile_cols + tx);
+  }
+  DevGuard guard(h->cfg.device);
+  hipStream_t stream = (hipStream_t) hip_stream;
+  const size_t n64 = (size_t) h->n_frames * nctu * 3 * 5 * 64;
+  if (h->sao_stat_cap < n64) { (void) hipFree(h->sao_stat_d); h->sao_stat_d = nullptr; h->sao_stat_cap = n64; HIPCHK(hipMalloc((void **) &h->sao_stat_d, n64 * sizeof(long long))); }
+  if (!h->sao_tile_d) HIPCHK(hipMalloc((void **) &h->sao_tile_d, (size_t) nctu));
+  HIPCHK(hipMemcpyAsync(h->sao_tile_d, tile.data(), (size_t) nctu, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemsetAsync(h->sao_stat_d, 0, n64 * sizeof(long long), stream));
+  VxSaoStatParams p; memset(&p, 0, sizeof p);
+  p.frames = h->frames_d; p.tile_of_ctu = h->sao_tile_d; p.out = h->sao_stat_d;
+  p.pic_w = h->cfg.pic_w; p.pic_h = h->cfg.pic_h; p.ctus_w = cw; p.ctus_h = chh; p.bit_depth = h->cfg.bit_depth; p.chroma = h->cfg.chroma; p.lf_across_tiles = lf_across_tiles != 0;
+  HIPCHK(hipEventRecord(h->ev0, stream));
+  const dim3 grid((unsigned) nctu, 3u, (unsigned) h->n_frames);
+  if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_sao_stats_kernel_u8, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(vvcx_sao_stats_kernel_u16, grid, dim3(256), 0, stream, p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev1, stream));
+  HIPCHK(hipMemcpyAsync(stats, h->sao_stat_d, n64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  HIPCHK(hipEventElapsedTime(&h->last_sao_stats_ms, h->ev0, h->ev1));
+  return VVCX_OK;
+}
+extern "C" float vvcx_last_sao_stats_ms(const vvcx_handle *h) { return h ? h->last_sao_stats_ms : 0.f; }
 
 // ---- adaptive loop filter (≙ AdaptiveLoopFilter::ALFProcess, CL/AdaptiveLoopFilter.cpp:205-383) with the caller's parameter sets: the per-class tables of every frame's
 // slice are built here (≙ reconstructCoeffAPSs 385-418 / reconstructCoeff 420-608, JVET_O0669 form), the kernels (vvcx_alf.hip) classify and filter.

@@ -115,6 +115,13 @@ struct VxSaoParams {
   int32_t pic_w, pic_h, ctus_w, ctus_h, bit_depth, chroma, lf_across_tiles, pad_;
 };
 
+struct VxSaoStatParams {
+  const VxFrameDev *frames;
+  const uint8_t *tile_of_ctu;     // [ctu]
+  long long *out;                 // [frame][ctu][3][5 types][count | diff][32]
+  int32_t pic_w, pic_h, ctus_w, ctus_h, bit_depth, chroma, lf_across_tiles, pad_;
+};
+
 // adaptive loop filter (vvcx_alf.hip): per frame the per-class tables of the slice's parameter sets, per CTU the caller's choices
 struct VxAlfCtu { uint8_t flag[3]; int8_t set; uint8_t alt[2]; };
 struct VxAlfFrame { int16_t luma_coeff[8][25][12], luma_clip[8][25][12], chroma_coeff[8][6], chroma_clip[8][6]; int32_t n_sets, n_alt; };

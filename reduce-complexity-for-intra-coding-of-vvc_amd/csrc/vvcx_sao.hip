@@ -88,6 +88,54 @@ __device__ void sao_filter(const VxSaoParams &p)
   else for (int j = 0; j < 4; j++) dst[j] = q.v[j];
 }
 
+// The encoder's SAO statistics (EL/EncSampleAdaptiveOffset.cpp getStatistics 284-353 / getBlkStats 1135-1549, SAOLcuBoundary 0): per CTU, component and type the number of
+// samples of every class and the sum of (original - deblocked) over them - the O(samples) half of the parameter decision, whose RD half (a few hundred operations per CTU
+// against the CABAC estimator) stays with the caller's encoder.  One workgroup per (CTU, component, frame): every lane classifies its samples for the five types (the same
+// neighbours and band rule as the filter above) and adds them to 5 x 32 counter pairs in LDS; which samples count follows the reference's region rules: not the last 5 luma /
+// 3 chroma columns and 4 / 2 rows in front of a following CTU, for the edge types not the column / row whose neighbour is outside the picture or - left and above, when
+// the filters do not cross tiles - in another tile, with its treatment of the first row of the diagonal types.  HBM-bound: original and deblocked samples read once.
+template <typename T>
+__device__ void sao_stats(const VxSaoStatParams &p)
+{
+  __shared__ int cnt[5][32], dif[5][32];
+  const int a = blockIdx.x, c = blockIdx.y, f = blockIdx.z, tid = threadIdx.x;
+  if (c && !p.chroma) return;
+  for (int i = tid; i < 5 * 32; i += 256) { (&cnt[0][0])[i] = 0; (&dif[0][0])[i] = 0; }
+  __syncthreads();
+  const int cx = a % p.ctus_w, cy = a / p.ctus_w, sh = c ? 1 : 0, pw = p.pic_w >> sh, ph = p.pic_h >> sh, cs = 128 >> sh, x0 = cx * cs, y0 = cy * cs;
+  const int cwid = x0 + cs > pw ? pw - x0 : cs, chei = y0 + cs > ph ? ph - y0 : cs, skipR = c ? 3 : 5, skipB = c ? 2 : 4;
+  const uint8_t t0 = p.tile_of_ctu[a];
+  const bool across = p.lf_across_tiles != 0;
+  const bool left = cx > 0 && (across || p.tile_of_ctu[a - 1] == t0), above = cy > 0 && (across || p.tile_of_ctu[a - p.ctus_w] == t0);
+  const bool aboveLeft = cx > 0 && cy > 0 && (across || p.tile_of_ctu[a - p.ctus_w - 1] == t0);
+  const bool right = cx + 1 < p.ctus_w, below = cy + 1 < p.ctus_h;
+  const int endXr = right ? cwid - skipR : cwid, endXn = right ? cwid - skipR : cwid - 1, startXn = left ? 0 : 1;
+  const int endYa = below ? chei - skipB : chei, endYn = below ? chei - skipB : chei - 1;
+  const VxFrameDev &fd = p.frames[f];
+  const T *rec = (const T *) fd.rec[c], *org = (const T *) fd.org[c];
+  const int st = fd.stride[c];
+  for (int i = tid; i < cwid * chei; i += 256) {
+    const int y = i / cwid, x = i - y * cwid;
+    const size_t at = (size_t) (y0 + y) * st + x0 + x;
+    const int v = rec[at], d = (int) org[at] - v;
+    if (x < endXr && y < endYa) { const int k = v >> (p.bit_depth - 5); atomicAdd(&cnt[4][k], 1); atomicAdd(&dif[4][k], d); }
+    const bool xn = x >= startXn && x < endXn;
+    const bool in0 = y < endYa && xn;
+    const bool in1 = x < endXr && y >= (above ? 0 : 1) && y < endYn;
+    const bool in2 = y == 0 ? (x >= (aboveLeft ? 0 : 1) && x < (above ? endXn : 1)) : (xn && y < endYn);
+    const bool in3 = xn && (y == 0 ? above : y < endYn);
+    if (in0) { const int k = 2 + ((v > (int) rec[at - 1]) - (v < (int) rec[at - 1])) + ((v > (int) rec[at + 1]) - (v < (int) rec[at + 1])); atomicAdd(&cnt[0][k], 1); atomicAdd(&dif[0][k], d); }
+    if (in1) { const int n0 = rec[at - st], n1 = rec[at + st]; const int k = 2 + ((v > n0) - (v < n0)) + ((v > n1) - (v < n1)); atomicAdd(&cnt[1][k], 1); atomicAdd(&dif[1][k], d); }
+    if (in2) { const int n0 = rec[at - st - 1], n1 = rec[at + st + 1]; const int k = 2 + ((v > n0) - (v < n0)) + ((v > n1) - (v < n1)); atomicAdd(&cnt[2][k], 1); atomicAdd(&dif[2][k], d); }
+    if (in3) { const int n0 = rec[at - st + 1], n1 = rec[at + st - 1]; const int k = 2 + ((v > n0) - (v < n0)) + ((v > n1) - (v < n1)); atomicAdd(&cnt[3][k], 1); atomicAdd(&dif[3][k], d); }
+  }
+  __syncthreads();
+  long long *o = p.out + (((size_t) f * p.ctus_w * p.ctus_h + a) * 3 + c) * 5 * 64;
+  for (int i = tid; i < 5 * 32; i += 256) { const int t = i >> 5, k = i & 31; o[t * 64 + k] = cnt[t][k]; o[t * 64 + 32 + k] = dif[t][k]; }
+}
+extern "C" __global__ void __launch_bounds__(256) vvcx_sao_stats_kernel_u8(VxSaoStatParams p) { sao_stats<uint8_t>(p); }
+extern "C" __global__ void __launch_bounds__(256) vvcx_sao_stats_kernel_u16(VxSaoStatParams p) { sao_stats<uint16_t>(p); }
+
 extern "C" __global__ void __launch_bounds__(256) vvcx_sao_copy_kernel_u8(VxSaoParams p) { sao_copy<uint8_t>(p); }
 extern "C" __global__ void __launch_bounds__(256) vvcx_sao_copy_kernel_u16(VxSaoParams p) { sao_copy<uint16_t>(p); }
 extern "C" __global__ void __launch_bounds__(256) vvcx_sao_kernel_u8(VxSaoParams p) { sao_filter<uint8_t>(p); }

@@ -286,6 +286,15 @@ class VvcxEncoder:
         self._chk(self.L.vvcx_sao_bound_frames(self.h, prm.ctypes.data, int(lf_across_tiles), int(log2_offset_scale), None))
         return float(self.L.vvcx_last_sao_ms(self.h))
 
+    def sao_statistics_bound_frames(self, lf_across_tiles=1):
+        """vvcx_sao_statistics_bound_frames -> (int64 [n_frames, ctus, 3, 5, 2, 32] = count | diff per type and class, kernel ms)"""
+        out = np.zeros((self.n_frames, self.ctus_per_frame, 3, 5, 2, 32), np.int64)
+        self.L.vvcx_sao_statistics_bound_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.L.vvcx_last_sao_stats_ms.restype = C.c_float
+        self.L.vvcx_last_sao_stats_ms.argtypes = [C.c_void_p]
+        self._chk(self.L.vvcx_sao_statistics_bound_frames(self.h, int(lf_across_tiles), out.ctypes.data, None))
+        return out, float(self.L.vvcx_last_sao_stats_ms(self.h))
+
     def alf_bound_frames(self, prms):
         """vvcx_alf_bound_frames: prms = one dict of synth.alf_test_params' form per bound frame (the parameter sets of the first are the call's); returns the kernel time in ms"""
         assert len(prms) == self.n_frames

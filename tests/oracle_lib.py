@@ -360,5 +360,18 @@ ALF_CASES = ((128, 128, 8, 51), (256, 256, 8, 52), (384, 264, 10, 53), (320, 200
 # (width, height, bit depth, seed): one CTU (the lower border of a picture of at most 128 rows acts as a virtual boundary), whole CTUs, partial CTUs right and below, a small picture
 
 
+def sao_statistics(org, rec, w, h, bit_depth, tile_cols=1, tile_rows=1, lf_across_tiles=1):
+    """orc_sao_statistics -> int64 [ctus, 3, 5, 2, 32] (count | diff per type and class)"""
+    L = lib()
+    L.orc_sao_statistics.argtypes = [C.c_int] * 6 + [C.c_void_p] * 3
+    o = [np.ascontiguousarray(p.astype(np.int16)) for p in org]; r = [np.ascontiguousarray(p.astype(np.int16)) for p in rec]
+    po = (C.c_void_p * 3)(*[a.ctypes.data for a in o]); pr = (C.c_void_p * 3)(*[a.ctypes.data for a in r])
+    out = np.zeros((((w + 127) // 128) * ((h + 127) // 128), 3, 5, 2, 32), np.int64)
+    rc = L.orc_sao_statistics(w, h, bit_depth, tile_cols, tile_rows, lf_across_tiles, po, pr, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_sao_statistics: %d" % rc)
+    return out
+
+
 SAO_CASES = ((128, 128, 8, 1, 1, 1, 0, 41), (256, 256, 8, 1, 1, 1, 0, 42), (384, 264, 10, 2, 2, 1, 0, 43), (320, 200, 8, 3, 2, 0, 0, 44), (512, 136, 10, 4, 1, 0, 1, 45), (200, 392, 8, 1, 3, 0, 0, 46))
 # (width, height, bit depth, tile columns, tile rows, filters across tile borders, log2 offset scale, seed)

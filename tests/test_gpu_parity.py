@@ -568,6 +568,29 @@ def test_randomised_sweep_of_sizes_qps_bit_depths_and_tool_sets(seed):
     _check([frame], W, H, pkg.slice_params(qp, bit_depth=bd, dep_quant=bool(tools & pkg.TOOL_DEPQUANT)), bit_depth=bd, tile_cols=tc, tools=tools, workers=4)
 
 
+def test_sao_statistics_on_the_gpu():
+    """vvcx_sao_statistics_bound_frames on the GPU behind a search and the deblocking filter against orc_sao_statistics on the same planes: four pictures of 3 x 2 tiles with and
+    without filtering across tile borders, 8 and 10 bit."""
+    import torch
+    for bd, lf in ((8, 0), (10, 1)):
+        W, H, qp, n = 384, 264, 32, 4
+        sp = pkg.slice_params(qp, bit_depth=bd)
+        frames = [pkg.synth_frame(W, H, i, bd, 60 + i, chroma_texture=0.5) for i in range(n)]
+        enc = pkg.VvcxEncoder(W, H, bd, tile_cols=3, tile_rows=2, tools=pkg.TOOLS_DEFAULT, max_frames=n)
+        enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+        dt = torch.uint8 if bd == 8 else torch.int16
+        dev = [([torch.from_numpy(p if bd == 8 else p.view(np.int16)).cuda() for p in f], [torch.zeros(p.shape, dtype=dt, device="cuda") for p in f]) for f in frames]
+        enc.bind_frames([([t.data_ptr() for t in o], [t.data_ptr() for t in r], [t.shape[1] for t in o]) for o, r in dev])
+        enc.compress_bound_frames(); enc.deblock_bound_frames()
+        got, ms = enc.sao_statistics_bound_frames(lf)
+        assert ms > 0
+        for i in range(n):
+            rec = [t.cpu().numpy() for t in dev[i][1]]
+            exp = O.sao_statistics(frames[i], rec, W, H, bd, 3, 2, lf)
+            assert np.array_equal(got[i], exp), (bd, lf, i)
+        enc.close()
+
+
 def test_adaptive_loop_filter_on_the_gpu():
     """The ALF kernels (csrc/vvcx_alf.hip) on the GPU: vvcx_alf_picture against the reference's planes and block classes (tests/golden/alf.npz), and vvcx_alf_bound_frames
     behind a search, the deblocking filter and SAO against the oracle's filter on the same reconstruction (four pictures, each with parameter choices of its own; 8 and 10 bit)."""

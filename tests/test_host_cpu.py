@@ -344,6 +344,26 @@ def test_sao_kernels_on_cpu_emulator_match_the_reference(emu_so):
     enc.close()
 
 
+def test_sao_statistics_kernel_on_cpu_emulator_matches_oracle(emu_so):
+    """vvcx_sao_statistics_bound_frames (the sources of vvcx_sao.hip on the emulator) behind a search and the deblocking filter, against orc_sao_statistics on the same original
+    and deblocked planes: two tile columns with and without filtering across them, 8 and 10 bit; state errors."""
+    for (w, h, bd, tc, lf) in ((136, 40, 8, 2, 0), (136, 40, 8, 2, 1), (72, 136, 10, 1, 1)):
+        planes = pkg.synth_frame(w, h, 0, bd, 7, chroma_texture=0.5)
+        sp = pkg.slice_params(32, bit_depth=bd)
+        enc = pkg.VvcxEncoder(w, h, bd, tile_cols=tc, tile_rows=1, tools=pkg.TOOLS_DEFAULT, lib_path=emu_so)
+        enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+        org = [np.ascontiguousarray(p) for p in planes]; rec = [np.zeros_like(p) for p in planes]
+        enc.bind_frames([([p.ctypes.data for p in org], [p.ctypes.data for p in rec], [p.shape[1] for p in org])])
+        with pytest.raises(pkg.VvcxError):
+            enc.sao_statistics_bound_frames(lf)           # nothing coded yet
+        enc.compress_bound_frames(); enc.deblock_bound_frames()
+        got, _ = enc.sao_statistics_bound_frames(lf)
+        exp = O.sao_statistics(org, rec, w, h, bd, tc, 1, lf)
+        assert np.array_equal(got[0], exp), (w, h, bd, tc, lf)
+        assert exp[:, :, :, 0].sum() > 0 and (exp[:, :, :4, 0, 5:] == 0).all()
+        enc.close()
+
+
 def _alf_fixture():
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alf.npz")); g, gc = z["planes"], z["classes"]; off = coff = 0
     for case in O.ALF_CASES:
