@@ -306,21 +306,29 @@ def main():
         # the encoder's SAO statistics on the deblocked pictures (the O(samples) half of the SAO parameter decision): original and reconstruction read once
         try:
             if not lmcs:
-                _, st_ms = enc.sao_statistics_bound_frames(1)
+                sao_stats, st_ms = enc.sao_statistics_bound_frames(1)
                 st_bytes = args.frames * (W * H * 3 // 2) * (2 if bd == 10 else 1) * 2          # original + deblocked samples read once
                 out["sao_statistics"] = {"kernel": "vvcx_sao_stats_kernel_%s" % ("u8" if bd == 8 else "u16"), "launches": 1, "ms": st_ms, "frames": args.frames, "algorithmic_bytes": st_bytes,
                                          "achieved_GBps": st_bytes / (st_ms / 1e3) / 1e9 if st_ms > 0 else None, "frac_of_hbm_peak": st_bytes / (st_ms / 1e3) / 1e9 / HBM_PEAK_GBS if st_ms > 0 else None}
+                # the RD half of the decision: host code of the library, serial over the CTUs of a picture (the SAO context models travel from CTU to CTU)
+                t0 = time.time()
+                lam3 = [sp["lam"], sp["lam"] / sp["dist_weight"][0], sp["lam"] / sp["dist_weight"][1]]
+                sao_decided = np.stack([pkg.vvcx.sao_decide(sao_stats[f], W, H, bd, lam3, sp["qp"], tc, tr, lib_path=args.lib) for f in range(args.frames)])
+                out["sao_statistics"]["decision_host_ms_per_picture"] = (time.time() - t0) * 1e3 / args.frames
+                out["sao_statistics"]["decided_modes_off_new_merge"] = [int(v) for v in np.bincount(sao_decided[:, :, :, 0].ravel(), minlength=3)]
         except Exception as ex:
             out["sao_statistics"] = {"error": str(ex)}
         # third kernel pair (not part of the timed step): sample adaptive offset with seeded per-CTU parameters on the deblocked pictures - an HBM-bound pass
         # (every sample read once and written once; the copy the filter reads its unfiltered neighbours from doubles the traffic)
         try:
-            prm = np.stack([pkg.sao_test_params(900 + i, W, H, tc, tr) for i in range(args.frames)])
+            decided = "sao_statistics" in out and "decision_host_ms_per_picture" in out["sao_statistics"]
+            prm = sao_decided if decided else np.stack([pkg.sao_test_params(900 + i, W, H, tc, tr) for i in range(args.frames)])
             sao_ms = enc.sao_bound_frames(prm, lf_across_tiles=1)
             sao_bytes = args.frames * (W * H * 3 // 2) * (2 if bd == 10 else 1) * 2
             out["sao"] = {"kernel": "vvcx_sao_copy_kernel + vvcx_sao_kernel (%s)" % ("u8" if bd == 8 else "u16"), "launches": 2, "ms": sao_ms, "frames": args.frames, "algorithmic_bytes": sao_bytes,
                           "achieved_GBps": sao_bytes / (sao_ms / 1e3) / 1e9 if sao_ms > 0 else None, "frac_of_hbm_peak": sao_bytes / (sao_ms / 1e3) / 1e9 / HBM_PEAK_GBS if sao_ms > 0 else None,
-                          "note": "parameters are seeded test values (synth.sao_test_params: about 80 % of the CTUs filtered); the parameter decision is not part of the library"}
+                          "note": ("parameters decided by the library from the statistics above (vvcx_sao_decide)" if decided else
+                                   "parameters are seeded test values (synth.sao_test_params: about 80 % of the CTUs filtered)")}
         except Exception as ex:
             out["sao"] = {"error": str(ex)}
         # fourth kernel pair (not part of the timed step): the adaptive loop filter with seeded parameter sets and per-CTU choices on the pictures SAO left - an HBM-bound

@@ -224,6 +224,15 @@ float vvcx_last_sao_ms(const vvcx_handle *h);
  * mapped original only): VVCX_ERR_UNSUPPORTED. */
 int   vvcx_sao_statistics_bound_frames(vvcx_handle *h, int lf_across_tiles, int64_t *stats, void *hip_stream);
 float vvcx_last_sao_stats_ms(const vvcx_handle *h);
+/* ≙ EncSampleAdaptiveOffset::decideBlkParams (EL/EncSampleAdaptiveOffset.cpp:793-1098, SAOGreedyEnc 0; deriveModeNewRDO 597-735, deriveModeMergeRDO 737-791, deriveOffsets
+ * 481-595): the RD half of the SAO parameter decision for ONE picture from its statistics (the [ctu][component][type][count | diff][32] block of that picture as
+ * vvcx_sao_statistics_bound_frames returns it): per CTU the better of new parameters (per component the type and offsets with the least distortion + lambda * bits; Cb and Cr
+ * share the type) and a merge with the CTU to the left / above in the same tile, bits as CABACWriter::sao_block_pars codes them against the two SAO context models, which
+ * start from the I-slice initialisation at slice_qp and adapt from CTU to CTU.  lambda[3] = the slice's lambdas per component (≙ Slice::getLambdas); every component is
+ * enabled (what decidePicParams decides for temporal layer 0).  Host code, needs no handle.  prm[ctu][component] = the coded parameters vvcx_sao_bound_frames takes.
+ * Parity with the reference is unpinned (the unit does not compile in this environment). */
+int   vvcx_sao_decide(int pic_w, int pic_h, int bit_depth, int tile_cols, int tile_rows, int slice_qp, const double *lambda, int log2_offset_scale,
+                      const int64_t *stats, vvcx_sao_param *prm);
 /* the same filter on one picture in host memory (uint16 planes, stride = plane width, filtered in place; prm[ctu][component]): needs no handle */
 int   vvcx_sao_picture(int pic_w, int pic_h, int bit_depth, int tile_cols, int tile_rows, const vvcx_sao_param *prm, int lf_across_tiles, int log2_offset_scale,
                        uint16_t *y, uint16_t *cb, uint16_t *cr, int device);

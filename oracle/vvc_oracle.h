@@ -146,6 +146,8 @@ int      orc_alf_picture(int w, int h, int bit_depth, int n_sets, const int16_t 
 /* sample adaptive offset with given parameters on 4:2:0 planes with stride = plane width (CL/SampleAdaptiveOffset.cpp SAOProcess; orc_sao.c) */
 typedef struct { int8_t mode, type, band, off[4]; } orc_sao_param;      /* per CTU and component: mode 0 off / 1 new / 2 merge; type: new 0..3 edge class, 4 band; merge 0 left, 1 above */
 int      orc_sao_picture(int w, int h, int bit_depth, int tile_cols, int tile_rows, int lf_across_tiles, int log2_offset_scale, const orc_sao_param *prm, int16_t *y, int16_t *cb, int16_t *cr);
+/* the RD half of the SAO parameter decision from those statistics (decideBlkParams: new / merge per CTU against the SAO context models).  PARITY UNPINNED (see orc_sao.c) */
+int      orc_sao_decide(int w, int h, int bit_depth, int tile_cols, int tile_rows, int slice_qp, const double *lambda, int log2_offset_scale, const int64_t *stats, orc_sao_param *prm);
 void     orc_get_counters(orc_enc *e, uint64_t out[4]); /* satd candidates, rd candidates, rd pixels, nodes */
 
 /* ---------------- leaf operators (individually testable; used by the golden-vector tests) -------- */

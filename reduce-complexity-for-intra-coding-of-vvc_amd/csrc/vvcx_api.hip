@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <limits>
+#include <algorithm>
 #include <vector>
 #include <algorithm>
 #include "vvcx.h"
@@ -927,6 +929,226 @@ extern "C" int vvcx_sao_statistics_bound_frames(vvcx_handle *h, int lf_across_ti
   return VVCX_OK;
 }
 extern "C" float vvcx_last_sao_stats_ms(const vvcx_handle *h) { return h ? h->last_sao_stats_ms : 0.f; }
+
+// ---- the RD half of the SAO parameter decision (≙ EncSampleAdaptiveOffset::decideBlkParams, EL/EncSampleAdaptiveOffset.cpp:793-1098 without SAOGreedyEnc): host code, a few
+// hundred operations per CTU, serial over the CTUs of a picture because the two SAO context models (and the merge candidates) travel from one CTU to the next.
+namespace {
+struct SaoSet { int mode = 0, type = 0, band = 0; int off[32] = { 0 }; };      // one component of one CTU: off / new / merge; offsets by class (coded or reconstructed)
+struct SaoCtu { SaoSet c[3]; };
+// the bit estimator of the SAO syntax (sao_block_pars / sao_offset_pars, EL/CABACWriter.cpp:354-462): models SaoMergeFlag and SaoTypeIdx, everything else bypass
+class SaoRate {
+public:
+  void init(int qp)
+  {
+    for (int k = 0; k < 2; k++) {
+      const int id = VX_CTX_INIT_I_REF[kFirst + k], slope = (id >> 3) - 4, offset = ((id & 7) * 18) + 1;
+      int st = ((slope * ((qp < 0 ? 0 : qp > 63 ? 63 : qp) - 16)) >> 1) + offset;
+      st = st < 1 ? 1 : st > 127 ? 127 : st;
+      s0_[k] = (uint16_t) ((st << 8) & 0x7FE0); s1_[k] = (uint16_t) ((st << 8) & 0x7FFE);
+    }
+    bits = 0;
+  }
+  uint64_t bits = 0;
+  void block(const SaoCtu &u, int bd, bool leftAvail, bool aboveAvail, bool mergeFlagsOnly)
+  {
+    bool left = false, above = false;
+    if (leftAvail) { left = u.c[0].mode == 2 && u.c[0].type == 0; coded(0, left); }
+    if (aboveAvail && !left) { above = u.c[0].mode == 2 && u.c[0].type == 1; coded(0, above); }
+    if (mergeFlagsOnly || left || above) return;
+    for (int k = 0; k < 3; k++) component(u.c[k], k, bd);
+  }
+  void component(const SaoSet &p, int comp, int bd)
+  {
+    const bool first = comp < 2;                       // Y and Cb carry the type of their channel
+    if (first) { coded(1, p.mode != 0); if (p.mode != 0) bypass(1); }
+    if (p.mode != 1) return;
+    const int mx = max_q(bd);
+    int o[4];
+    for (int i = 0; i < 4; i++) o[i] = p.off[p.type == 4 ? (p.band + i) & 31 : (i < 2 ? i : i + 1)];
+    for (int i = 0; i < 4; i++) { const int a = std::abs(o[i]); if (mx) bypass(a < mx ? a + 1 : mx); }      // truncated unary
+    if (p.type == 4) { for (int i = 0; i < 4; i++) if (o[i]) bypass(1); bypass(5); }
+    else if (first) bypass(2);
+  }
+  static int max_q(int bd) { return (1 << (std::min(bd, 10) - 5)) - 1; }      // SampleAdaptiveOffset::getMaxOffsetQVal
+private:
+  static const int kFirst = 287;                        // Ctx::SaoMergeFlag in the reference's flat order (ContextSetCfg); SaoTypeIdx follows
+  uint16_t s0_[2], s1_[2];
+  void bypass(int n) { bits += (uint64_t) n << 15; }
+  void coded(int which, bool bin)
+  {
+    const unsigned st = (unsigned) (s0_[which] + s1_[which]) >> 8;
+    bits += VX_BIN_FRAC_BITS[st * 2 + (bin ? 1 : 0)];
+    const int rate = VX_CTX_RATE_REF[kFirst + which], r0 = 2 + ((rate >> 2) & 3), r1 = 3 + r0 + (rate & 3);
+    s0_[which] -= (s0_[which] >> r0) & 0x7FE0; s1_[which] -= (s1_[which] >> r1) & 0x7FFE;
+    if (bin) { s0_[which] += (0x7fffu >> r0) & 0x7FE0; s1_[which] += (0x7fffu >> r1) & 0x7FFE; }
+  }
+};
+// the statistics of one (CTU, component, type)
+struct SaoStat { const int64_t *count, *diff; };
+class SaoDecision {
+public:
+  SaoDecision(const int64_t *stats, int bd, const double *lambda, int step) : st_(stats), bd_(bd), lam_(lambda), step_(step) {}
+  SaoStat stat(int ctu, int comp, int type) const { const int64_t *b = st_ + (((size_t) ctu * 3 + comp) * 5 + type) * 64; return SaoStat{ b, b + 32 }; }
+  static int64_t gain(int64_t n, int64_t o, int64_t d) { return n * o * o - d * o * 2; }      // estSaoDist: SSE change of adding o to n samples with difference sum d
+  int64_t distortion(const SaoSet &p, const int *scaled, const SaoStat &s) const
+  {
+    int64_t d = 0;
+    if (p.type == 4) for (int i = p.band; i < p.band + 4; i++) d += gain(s.count[i & 31], scaled[i & 31], s.diff[i & 31]);
+    else for (int k = 0; k < 5; k++) d += gain(s.count[k], scaled[k], s.diff[k]);
+    return d;
+  }
+  void scale(const SaoSet &p, int *dst) const
+  {
+    std::fill(dst, dst + 32, 0);
+    if (p.type == 4) for (int i = 0; i < 4; i++) dst[(p.band + i) & 31] = p.off[(p.band + i) & 31] * (1 << step_);
+    else for (int k = 0; k < 5; k++) dst[k] = p.off[k] * (1 << step_);
+  }
+  // deriveOffsets 481-595: the mean difference of a class, rounded and clipped, then lowered towards zero while distortion + lambda * bits improves (estIterOffset)
+  SaoSet offsets(int comp, int type, const SaoStat &s) const
+  {
+    SaoSet p; p.mode = 1; p.type = type;
+    const int th = SaoRate::max_q(bd_), n = type == 4 ? 32 : 5;
+    const double lambda = lam_[comp];
+    double cost[32];
+    for (int k = 0; k < n; k++) {
+      cost[k] = lambda;
+      if ((type != 4 && k == 2) || s.count[k] == 0) continue;
+      const double mean = (double) s.diff[k] / (double) (s.count[k] << step_);
+      int q = mean >= 0 ? (int) (mean + 0.5) : (int) (mean - 0.5);
+      q = std::max(-th, std::min(th, q));
+      if (type != 4 && ((k < 2 && q < 0) || (k > 2 && q > 0))) q = 0;            // a valley is never lowered, a peak never raised
+      int best = 0; double bestCost = lambda;
+      for (int it = q; it != 0; it += it > 0 ? -1 : 1) {
+        const int a = std::abs(it);
+        const int64_t bitsOf = (type == 4 ? a + 2 : a + 1) - (a == th ? 1 : 0);
+        const double c = (double) gain(s.count[k], (int64_t) it << step_, s.diff[k]) + lambda * (double) bitsOf;
+        if (c < bestCost) { bestCost = c; best = it; }
+      }
+      p.off[k] = best; cost[k] = bestCost;
+    }
+    if (type == 4) {                                    // the four consecutive bands with the smallest cost
+      double least = std::numeric_limits<double>::max();
+      for (int b = 0; b <= 28; b++) { const double c = cost[b] + cost[b + 1] + cost[b + 2] + cost[b + 3]; if (c < least) { least = c; p.band = b; } }
+      for (int k = 0; k < 32; k++) if (((k - p.band) & 31) >= 4) p.off[k] = 0;
+    }
+    return p;
+  }
+  // deriveModeNewRDO 597-735
+  double explicit_mode(int ctu, SaoRate &rate, bool leftAvail, bool aboveAvail, SaoCtu &out) const
+  {
+    int64_t dist[3] = { 0, 0, 0 };
+    int scaled[32];
+    const SaoRate atStart = rate;
+    out = SaoCtu();
+    rate.block(out, bd_, leftAvail, aboveAvail, true);
+    const SaoRate beforeLuma = rate;
+    SaoRate afterLuma;
+    {
+      rate.bits = 0; rate.component(out.c[0], 0, bd_);
+      double least = lam_[0] * ((double) rate.bits / 32768.0);
+      afterLuma = rate;
+      for (int t = 0; t < 5; t++) {
+        const SaoStat s = stat(ctu, 0, t);
+        const SaoSet cand = offsets(0, t, s);
+        scale(cand, scaled);
+        const int64_t d = distortion(cand, scaled, s);
+        rate = beforeLuma; rate.bits = 0; rate.component(cand, 0, bd_);
+        const double c = (double) d + lam_[0] * ((double) rate.bits / 32768.0);
+        if (c < least) { least = c; dist[0] = d; out.c[0] = cand; afterLuma = rate; }
+      }
+      rate = afterLuma;
+    }
+    {
+      double c = 0; uint64_t seen = 0;
+      rate.bits = 0;
+      for (int k = 1; k < 3; k++) { rate.component(out.c[k], k, bd_); c += lam_[k] * (1.0 / 32768.0) * (double) (rate.bits - seen); seen = rate.bits; }
+      double least = c;
+      for (int t = 0; t < 5; t++) {
+        SaoSet cand[3]; int64_t d[3] = { 0, 0, 0 };
+        rate = afterLuma; rate.bits = 0; seen = 0; c = 0;
+        for (int k = 1; k < 3; k++) {
+          const SaoStat s = stat(ctu, k, t);
+          cand[k] = offsets(k, t, s);
+          scale(cand[k], scaled);
+          d[k] = distortion(cand[k], scaled, s);
+          rate.component(cand[k], k, bd_);
+          c += (double) d[k] + lam_[k] * (1.0 / 32768.0) * (double) (rate.bits - seen); seen = rate.bits;
+        }
+        if (c < least) { least = c; for (int k = 1; k < 3; k++) { dist[k] = d[k]; out.c[k] = cand[k]; } }
+      }
+    }
+    double norm = 0;
+    for (int k = 0; k < 3; k++) norm += (double) dist[k] / lam_[k];
+    rate = atStart; rate.bits = 0;
+    rate.block(out, bd_, leftAvail, aboveAvail, false);
+    return norm + (double) rate.bits / 32768.0;
+  }
+  // deriveModeMergeRDO 737-791: cand = the reconstructed parameters of the CTU to the left / above (nullptr: none)
+  double merge_mode(int ctu, SaoRate &rate, const SaoCtu *const cand[2], SaoCtu &out) const
+  {
+    const SaoRate atStart = rate; SaoRate best = rate;
+    double least = std::numeric_limits<double>::max();
+    for (int m = 0; m < 2; m++) {
+      if (!cand[m]) continue;
+      SaoCtu test = *cand[m]; double nd = 0;
+      for (int k = 0; k < 3; k++) {
+        const SaoSet &from = cand[m]->c[k];
+        test.c[k].mode = 2; test.c[k].type = m;
+        if (from.mode != 0) nd += (double) distortion(from, from.off, stat(ctu, k, from.type)) / lam_[k];
+      }
+      rate = atStart; rate.bits = 0;
+      rate.block(test, bd_, cand[0] != nullptr, cand[1] != nullptr, false);
+      const double c = nd + (double) rate.bits / 32768.0;
+      if (c < least) { least = c; out = test; best = rate; }
+    }
+    if (least < std::numeric_limits<double>::max()) rate = best;
+    return least;
+  }
+private:
+  const int64_t *st_; int bd_; const double *lam_; int step_;
+};
+}      // namespace
+
+extern "C" int vvcx_sao_decide(int pic_w, int pic_h, int bit_depth, int tile_cols, int tile_rows, int slice_qp, const double *lambda, int log2_offset_scale,
+                               const int64_t *stats, vvcx_sao_param *prm)
+{
+  if (!lambda || !stats || !prm) return fail(VVCX_ERR_ARG, "null argument");
+  if (pic_w < 8 || pic_h < 8 || bit_depth < 8 || bit_depth > 12 || tile_cols < 1 || tile_rows < 1 || tile_cols > (pic_w + 127) / 128 || tile_rows > (pic_h + 127) / 128 ||
+      log2_offset_scale < 0 || log2_offset_scale > 4 || !(lambda[0] > 0) || !(lambda[1] > 0) || !(lambda[2] > 0))
+    return fail(VVCX_ERR_ARG, "vvcx_sao_decide: picture size / bit depth / tiles / offset scale / lambdas");
+  const int cw = (pic_w + 127) / 128, chh = (pic_h + 127) / 128, nctu = cw * chh;
+  auto tile_of = [](int c, int n, int tiles) { int t = 0; for (int i = 0; i < tiles; i++) if (c >= (i * n) / tiles) t = i; return t; };
+  std::vector<SaoCtu> recon((size_t) nctu);
+  SaoDecision rdo(stats, bit_depth, lambda, log2_offset_scale);
+  SaoRate rate; rate.init(slice_qp);
+  for (int a = 0; a < nctu; a++) {
+    const int cx = a % cw, cy = a / cw;
+    const SaoCtu *cand[2] = { nullptr, nullptr };
+    if (cx > 0 && tile_of(cx - 1, cw, tile_cols) == tile_of(cx, cw, tile_cols)) cand[0] = &recon[(size_t) a - 1];
+    if (cy > 0 && tile_of(cy - 1, chh, tile_rows) == tile_of(cy, chh, tile_rows)) cand[1] = &recon[(size_t) a - cw];
+    const SaoRate atStart = rate;
+    SaoCtu chosen, other;
+    double least = rdo.explicit_mode(a, rate, cand[0] != nullptr, cand[1] != nullptr, chosen);
+    SaoRate after = rate;
+    rate = atStart;
+    const double mc = rdo.merge_mode(a, rate, cand, other);
+    if (mc < least) { least = mc; chosen = other; after = rate; }
+    rate = after;
+    for (int k = 0; k < 3; k++) {
+      const SaoSet &cd = chosen.c[k]; SaoSet &rc = recon[(size_t) a].c[k];
+      if (cd.mode == 2) rc = cand[cd.type]->c[k];
+      else { rc = cd; if (cd.mode == 1) rdo.scale(cd, rc.off); }
+      vvcx_sao_param &o = prm[(size_t) a * 3 + k];
+      memset(&o, 0, sizeof o);
+      o.mode = (int8_t) cd.mode; o.type = (int8_t) cd.type;
+      if (cd.mode == 1) {
+        o.band = (int8_t) (cd.type == 4 ? cd.band : 0);
+        for (int i = 0; i < 4; i++) o.offset[i] = (int8_t) (cd.type == 4 ? cd.off[(cd.band + i) & 31] : cd.off[i < 2 ? i : i + 1]);
+      }
+    }
+  }
+  return VVCX_OK;
+}
 
 // ---- adaptive loop filter (≙ AdaptiveLoopFilter::ALFProcess, CL/AdaptiveLoopFilter.cpp:205-383) with the caller's parameter sets: the per-class tables of every frame's
 // slice are built here (≙ reconstructCoeffAPSs 385-418 / reconstructCoeff 420-608, JVET_O0669 form), the kernels (vvcx_alf.hip) classify and filter.

@@ -139,6 +139,16 @@ def sao_picture(planes, bit_depth, prm, tile_cols=1, tile_rows=1, lf_across_tile
     return out
 
 
+def sao_decide(stats, width, height, bit_depth, lambdas, slice_qp, tile_cols=1, tile_rows=1, log2_offset_scale=0, lib_path=None):
+    """vvcx_sao_decide: the RD half of the SAO decision of one picture from its statistics [ctus, 3, 5, 2, 32] -> int8 [ctus, 3, 7] parameters"""
+    L = load_library(lib_path)
+    st = np.ascontiguousarray(stats, np.int64); lam = np.ascontiguousarray(lambdas, np.float64)
+    prm = np.zeros((st.shape[0], 3, 7), np.int8)
+    L.vvcx_sao_decide.argtypes = [C.c_int] * 6 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    _chk(L, L.vvcx_sao_decide(width, height, bit_depth, tile_cols, tile_rows, int(slice_qp), lam.ctypes.data, int(log2_offset_scale), st.ctypes.data, prm.ctypes.data))
+    return prm
+
+
 class AlfAps(C.Structure):
     """vvcx_alf_aps: what an ALF parameter set carries (AlfParam of the reference)"""
     _fields_ = [("num_luma_filters", C.c_int32), ("class_to_filter", C.c_uint8 * 25), ("nonlinear_luma", C.c_uint8), ("luma_coeff", (C.c_int16 * 12) * 25), ("luma_clip_idx", (C.c_uint8 * 12) * 25),

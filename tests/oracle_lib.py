@@ -373,5 +373,17 @@ def sao_statistics(org, rec, w, h, bit_depth, tile_cols=1, tile_rows=1, lf_acros
     return out
 
 
+def sao_decide(stats, w, h, bit_depth, lambdas, slice_qp=32, tile_cols=1, tile_rows=1, log2_offset_scale=0):
+    """orc_sao_decide -> int8 [ctus, 3, 7] parameters in the form sao_picture takes"""
+    L = lib()
+    L.orc_sao_decide.argtypes = [C.c_int] * 6 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    st = np.ascontiguousarray(stats, np.int64); lam = np.ascontiguousarray(lambdas, np.float64)
+    prm = np.zeros((st.shape[0], 3, 7), np.int8)
+    rc = L.orc_sao_decide(w, h, bit_depth, tile_cols, tile_rows, slice_qp, lam.ctypes.data, log2_offset_scale, st.ctypes.data, prm.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_sao_decide: %d" % rc)
+    return prm
+
+
 SAO_CASES = ((128, 128, 8, 1, 1, 1, 0, 41), (256, 256, 8, 1, 1, 1, 0, 42), (384, 264, 10, 2, 2, 1, 0, 43), (320, 200, 8, 3, 2, 0, 0, 44), (512, 136, 10, 4, 1, 0, 1, 45), (200, 392, 8, 1, 3, 0, 0, 46))
 # (width, height, bit depth, tile columns, tile rows, filters across tile borders, log2 offset scale, seed)
