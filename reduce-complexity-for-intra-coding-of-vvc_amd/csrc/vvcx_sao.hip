@@ -97,10 +97,12 @@ __device__ void sao_filter(const VxSaoParams &p)
 template <typename T>
 __device__ void sao_stats(const VxSaoStatParams &p)
 {
-  __shared__ int cnt[5][32], dif[5][32];
-  const int a = blockIdx.x, c = blockIdx.y, f = blockIdx.z, tid = threadIdx.x;
+  // counters per wave (same-address LDS atomics of one wave serialise: four copies quarter the collisions); the plain class of the edge types - most samples, and the one
+  // class no offset belongs to - is counted in registers and added once per lane
+  __shared__ int cnt[4][5][32], dif[4][5][32];
+  const int a = blockIdx.x, c = blockIdx.y, f = blockIdx.z, tid = threadIdx.x, wv = tid >> 6;
   if (c && !p.chroma) return;
-  for (int i = tid; i < 5 * 32; i += 256) { (&cnt[0][0])[i] = 0; (&dif[0][0])[i] = 0; }
+  for (int i = tid; i < 4 * 5 * 32; i += 256) { (&cnt[0][0][0])[i] = 0; (&dif[0][0][0])[i] = 0; }
   __syncthreads();
   const int cx = a % p.ctus_w, cy = a / p.ctus_w, sh = c ? 1 : 0, pw = p.pic_w >> sh, ph = p.pic_h >> sh, cs = 128 >> sh, x0 = cx * cs, y0 = cy * cs;
   const int cwid = x0 + cs > pw ? pw - x0 : cs, chei = y0 + cs > ph ? ph - y0 : cs, skipR = c ? 3 : 5, skipB = c ? 2 : 4;
@@ -114,24 +116,29 @@ __device__ void sao_stats(const VxSaoStatParams &p)
   const VxFrameDev &fd = p.frames[f];
   const T *rec = (const T *) fd.rec[c], *org = (const T *) fd.org[c];
   const int st = fd.stride[c];
+  int pc[4] = { 0, 0, 0, 0 }, pd[4] = { 0, 0, 0, 0 };            // the plain class per edge type
+#define SAO_EDGE(t_, n0_, n1_) { const int n0 = (n0_), n1 = (n1_); const int k = 2 + ((v > n0) - (v < n0)) + ((v > n1) - (v < n1)); \
+                                 if (k == 2) { pc[t_]++; pd[t_] += d; } else { atomicAdd(&cnt[wv][t_][k], 1); atomicAdd(&dif[wv][t_][k], d); } }
   for (int i = tid; i < cwid * chei; i += 256) {
     const int y = i / cwid, x = i - y * cwid;
     const size_t at = (size_t) (y0 + y) * st + x0 + x;
     const int v = rec[at], d = (int) org[at] - v;
-    if (x < endXr && y < endYa) { const int k = v >> (p.bit_depth - 5); atomicAdd(&cnt[4][k], 1); atomicAdd(&dif[4][k], d); }
+    if (x < endXr && y < endYa) { const int k = v >> (p.bit_depth - 5); atomicAdd(&cnt[wv][4][k], 1); atomicAdd(&dif[wv][4][k], d); }
     const bool xn = x >= startXn && x < endXn;
-    const bool in0 = y < endYa && xn;
-    const bool in1 = x < endXr && y >= (above ? 0 : 1) && y < endYn;
-    const bool in2 = y == 0 ? (x >= (aboveLeft ? 0 : 1) && x < (above ? endXn : 1)) : (xn && y < endYn);
-    const bool in3 = xn && (y == 0 ? above : y < endYn);
-    if (in0) { const int k = 2 + ((v > (int) rec[at - 1]) - (v < (int) rec[at - 1])) + ((v > (int) rec[at + 1]) - (v < (int) rec[at + 1])); atomicAdd(&cnt[0][k], 1); atomicAdd(&dif[0][k], d); }
-    if (in1) { const int n0 = rec[at - st], n1 = rec[at + st]; const int k = 2 + ((v > n0) - (v < n0)) + ((v > n1) - (v < n1)); atomicAdd(&cnt[1][k], 1); atomicAdd(&dif[1][k], d); }
-    if (in2) { const int n0 = rec[at - st - 1], n1 = rec[at + st + 1]; const int k = 2 + ((v > n0) - (v < n0)) + ((v > n1) - (v < n1)); atomicAdd(&cnt[2][k], 1); atomicAdd(&dif[2][k], d); }
-    if (in3) { const int n0 = rec[at - st + 1], n1 = rec[at + st - 1]; const int k = 2 + ((v > n0) - (v < n0)) + ((v > n1) - (v < n1)); atomicAdd(&cnt[3][k], 1); atomicAdd(&dif[3][k], d); }
+    if (y < endYa && xn) SAO_EDGE(0, (int) rec[at - 1], (int) rec[at + 1])
+    if (x < endXr && y >= (above ? 0 : 1) && y < endYn) SAO_EDGE(1, (int) rec[at - st], (int) rec[at + st])
+    if (y == 0 ? (x >= (aboveLeft ? 0 : 1) && x < (above ? endXn : 1)) : (xn && y < endYn)) SAO_EDGE(2, (int) rec[at - st - 1], (int) rec[at + st + 1])
+    if (xn && (y == 0 ? above : y < endYn)) SAO_EDGE(3, (int) rec[at - st + 1], (int) rec[at + st - 1])
   }
+#undef SAO_EDGE
+  for (int t = 0; t < 4; t++) if (pc[t]) { atomicAdd(&cnt[wv][t][2], pc[t]); atomicAdd(&dif[wv][t][2], pd[t]); }
   __syncthreads();
   long long *o = p.out + (((size_t) f * p.ctus_w * p.ctus_h + a) * 3 + c) * 5 * 64;
-  for (int i = tid; i < 5 * 32; i += 256) { const int t = i >> 5, k = i & 31; o[t * 64 + k] = cnt[t][k]; o[t * 64 + 32 + k] = dif[t][k]; }
+  for (int i = tid; i < 5 * 32; i += 256) {
+    const int t = i >> 5, k = i & 31;
+    o[t * 64 + k] = (long long) cnt[0][t][k] + cnt[1][t][k] + cnt[2][t][k] + cnt[3][t][k];
+    o[t * 64 + 32 + k] = (long long) dif[0][t][k] + dif[1][t][k] + dif[2][t][k] + dif[3][t][k];
+  }
 }
 extern "C" __global__ void __launch_bounds__(256) vvcx_sao_stats_kernel_u8(VxSaoStatParams p) { sao_stats<uint8_t>(p); }
 extern "C" __global__ void __launch_bounds__(256) vvcx_sao_stats_kernel_u16(VxSaoStatParams p) { sao_stats<uint16_t>(p); }
