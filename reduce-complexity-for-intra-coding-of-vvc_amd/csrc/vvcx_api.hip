@@ -39,6 +39,7 @@ extern "C" __global__ void vvcx_alf_copy_kernel_u8(VxAlfParams p);
 extern "C" __global__ void vvcx_alf_copy_kernel_u16(VxAlfParams p);
 extern "C" __global__ void vvcx_alf_kernel_u8(VxAlfParams p);
 extern "C" __global__ void vvcx_alf_kernel_u16(VxAlfParams p);
+extern "C" __global__ void vvcx_deblock_edges_kernel(VxDeblockParams p);
 extern "C" __global__ void vvcx_deblock_kernel_u8(VxDeblockParams p);
 extern "C" __global__ void vvcx_deblock_kernel_u16(VxDeblockParams p);
 extern "C" __global__ void vvcx_jccr_sign_kernel_u8(VxFrameDev *frames, int wc, int hc);
@@ -101,6 +102,7 @@ struct vvcx_handle {
   std::vector<uint32_t> activity;               // per (frame, CTU) of the bound pictures: orders the stream queue of a launch, longest first
   hipEvent_t ev0, ev1; float last_ms, last_deblock_ms, last_sao_ms;
   void *sao_tmp_d; size_t sao_tmp_cap; VxSaoEntry *sao_tab_d; size_t sao_tab_cap; uint8_t *sao_tile_d;      // vvcx_sao_bound_frames: picture copy, resolved parameters, CTU -> tile
+  uint8_t *db_edges_d; size_t db_edges_cap;      // vvcx_deblock_bound_frames: one edge byte per unit, map and direction
   long long *sao_stat_d; size_t sao_stat_cap; float last_sao_stats_ms;      // vvcx_sao_statistics_bound_frames
   VxAlfFrame *alf_tab_d; VxAlfCtu *alf_ctu_d; size_t alf_cap; float last_alf_ms;      // vvcx_alf_bound_frames: per-frame tables and per-CTU choices (the picture copy is the SAO one)
   // a submitted, not yet collected launch (vvcx_submit_ctus .. vvcx_wait_ctus): staging the async copies read from / write to stays alive here
@@ -211,7 +213,7 @@ extern "C" int vvcx_create(const vvcx_cfg *cfg, vvcx_handle **out)
   h->frames_d = nullptr; h->lev_d = nullptr; h->units_d = nullptr; h->stream_ctx_d = nullptr; h->scratch_d = nullptr; h->scratch_cap = 0;
   h->payload_d = nullptr; h->payload_off_d = nullptr; h->payload_cap_d = nullptr; h->arith_d = nullptr;
   h->streams_d = nullptr; h->task_ctu_d = nullptr; h->results_d = nullptr; h->task_cap = 0; h->stream_cap = 0; h->counters_d = nullptr;
-  h->sao_tmp_d = nullptr; h->sao_tmp_cap = 0; h->sao_tab_d = nullptr; h->sao_tab_cap = 0; h->sao_tile_d = nullptr; h->last_sao_ms = 0.f; h->alf_tab_d = nullptr; h->alf_ctu_d = nullptr; h->alf_cap = 0; h->last_alf_ms = 0.f; h->sao_stat_d = nullptr; h->sao_stat_cap = 0; h->last_sao_stats_ms = 0.f;
+  h->sao_tmp_d = nullptr; h->sao_tmp_cap = 0; h->sao_tab_d = nullptr; h->sao_tab_cap = 0; h->sao_tile_d = nullptr; h->last_sao_ms = 0.f; h->alf_tab_d = nullptr; h->alf_ctu_d = nullptr; h->alf_cap = 0; h->last_alf_ms = 0.f; h->sao_stat_d = nullptr; h->sao_stat_cap = 0; h->last_sao_stats_ms = 0.f; h->db_edges_d = nullptr; h->db_edges_cap = 0;
   h->dq_d = nullptr; h->lmcs_on = false; h->lmcs_inverted = false; h->lmcs_lut_d = nullptr; h->lmcs_org_d = nullptr; h->lmcs_org_cap = 0;
   const int F = cfg->max_frames;
   if (hipMalloc((void **) &h->frames_d, sizeof(VxFrameDev) * F) != hipSuccess || hipMalloc((void **) &h->lev_d, h->lev_frame * 2 * F) != hipSuccess ||
@@ -242,7 +244,7 @@ extern "C" void vvcx_destroy(vvcx_handle *h)
   (void) hipFree(h->frames_d); (void) hipFree(h->lev_d); (void) hipFree(h->units_d); (void) hipFree(h->stream_ctx_d); (void) hipFree(h->scratch_d); (void) hipFree(h->wpp_progress_d); (void) hipFree(h->wpp_sync_d); (void) hipFree(h->wpp_sched_d); (void) hipFree(h->train_rows_d); (void) hipFree(h->train_n_d);
   (void) hipFree(h->payload_d); (void) hipFree(h->payload_off_d); (void) hipFree(h->payload_cap_d); (void) hipFree(h->arith_d);
   (void) hipFree(h->streams_d); (void) hipFree(h->task_ctu_d); (void) hipFree(h->results_d); (void) hipFree(h->counters_d);
-  (void) hipFree(h->sao_tmp_d); (void) hipFree(h->sao_tab_d); (void) hipFree(h->sao_tile_d); (void) hipFree(h->alf_tab_d); (void) hipFree(h->alf_ctu_d); (void) hipFree(h->sao_stat_d);
+  (void) hipFree(h->sao_tmp_d); (void) hipFree(h->sao_tab_d); (void) hipFree(h->sao_tile_d); (void) hipFree(h->alf_tab_d); (void) hipFree(h->alf_ctu_d); (void) hipFree(h->sao_stat_d); (void) hipFree(h->db_edges_d);
   (void) hipFree(h->f_node_d); (void) hipFree(h->f_value_d); (void) hipFree(h->f_root_d); (void) hipFree(h->dq_d); (void) hipFree(h->lmcs_lut_d); (void) hipFree(h->lmcs_org_d);
   if (h->pending) (void) hipStreamSynchronize(h->pend_stream);
   (void) hipHostFree(h->pend_res);
@@ -764,7 +766,12 @@ extern "C" int vvcx_deblock_bound_frames(vvcx_handle *h, int beta_offset_div2, i
   p.frames = h->frames_d; p.uw = h->uw; p.uh = h->uh; p.bit_depth = h->cfg.bit_depth; p.chroma = h->cfg.chroma;
   p.qp = h->sl.qp; p.qp_c[0] = h->sl.qp_c[0]; p.qp_c[1] = h->sl.qp_c[1]; p.beta_off2 = beta_offset_div2; p.tc_off2 = tc_offset_div2;
   const dim3 grid((unsigned) ((2 * h->uw * h->uh + 255) / 256), (unsigned) h->n_frames);
+  const size_t nedge = (size_t) h->n_frames * 4 * h->uw * h->uh;
+  if (h->db_edges_cap < nedge) { (void) hipFree(h->db_edges_d); h->db_edges_d = nullptr; h->db_edges_cap = nedge; HIPCHK(hipMalloc((void **) &h->db_edges_d, nedge)); }
+  p.edges = h->db_edges_d;
   HIPCHK(hipEventRecord(h->ev0, stream));
+  hipLaunchKernelGGL(vvcx_deblock_edges_kernel, grid, dim3(256), 0, stream, p);      // the unit records -> one edge byte per unit, map and direction
+  HIPCHK(hipGetLastError());
   for (int dir = 0; dir < 2; dir++) {
     p.dir = dir;
     if (h->cfg.bit_depth == 8) hipLaunchKernelGGL(vvcx_deblock_kernel_u8, grid, dim3(256), 0, stream, p);
@@ -1321,9 +1328,9 @@ extern "C" int vvcx_deblock_cu_table(int pic_w, int pic_h, int bit_depth, int qp
   for (size_t i = 0; i < um.size(); i++) if (!um[i].tag) return fail(VVCX_ERR_ARG, "the CU table does not cover the picture (%s tree, 4x4 unit %d)", i < um.size() / 2 ? "luma" : "chroma", (int) (i % (um.size() / 2)));
   DevGuard guard(device);
   const size_t ny = (size_t) pic_w * pic_h, nc = ny >> 2;
-  VxUnit *um_d = nullptr; uint16_t *pl_d = nullptr; VxFrameDev *fd_d = nullptr;
+  VxUnit *um_d = nullptr; uint16_t *pl_d = nullptr; VxFrameDev *fd_d = nullptr; uint8_t *ed_d = nullptr;
   int rc = VVCX_OK;
-  if (hipMalloc((void **) &um_d, um.size() * sizeof(VxUnit)) != hipSuccess || hipMalloc((void **) &pl_d, (ny + 2 * nc) * 2) != hipSuccess || hipMalloc((void **) &fd_d, sizeof(VxFrameDev)) != hipSuccess)
+  if (hipMalloc((void **) &ed_d, (size_t) 4 * uw * uh) != hipSuccess || hipMalloc((void **) &um_d, um.size() * sizeof(VxUnit)) != hipSuccess || hipMalloc((void **) &pl_d, (ny + 2 * nc) * 2) != hipSuccess || hipMalloc((void **) &fd_d, sizeof(VxFrameDev)) != hipSuccess)
     rc = fail(VVCX_ERR_DEVICE, "hipMalloc failed for the deblocking of a %dx%d CU table", pic_w, pic_h);
   if (rc == VVCX_OK) {
     VxFrameDev fd; memset(&fd, 0, sizeof fd);
@@ -1331,10 +1338,11 @@ extern "C" int vvcx_deblock_cu_table(int pic_w, int pic_h, int bit_depth, int qp
     fd.stride[0] = pic_w; fd.stride[1] = fd.stride[2] = pic_w >> 1;
     fd.units[0] = um_d; fd.units[1] = um_d + (size_t) uw * uh;
     VxDeblockParams p; memset(&p, 0, sizeof p);
-    p.frames = fd_d; p.uw = uw; p.uh = uh; p.bit_depth = bit_depth; p.chroma = 1; p.qp = qp; p.qp_c[0] = qp_cb; p.qp_c[1] = qp_cr; p.beta_off2 = beta_offset_div2; p.tc_off2 = tc_offset_div2;
+    p.frames = fd_d; p.uw = uw; p.uh = uh; p.bit_depth = bit_depth; p.chroma = 1; p.qp = qp; p.qp_c[0] = qp_cb; p.qp_c[1] = qp_cr; p.beta_off2 = beta_offset_div2; p.tc_off2 = tc_offset_div2; p.edges = ed_d;
     bool ok = hipMemcpy(um_d, um.data(), um.size() * sizeof(VxUnit), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(fd_d, &fd, sizeof fd, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(pl_d, y, ny * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(pl_d + ny, cb, nc * 2, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(pl_d + ny + nc, cr, nc * 2, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) { hipLaunchKernelGGL(vvcx_deblock_edges_kernel, dim3((unsigned) ((2 * uw * uh + 255) / 256), 1), dim3(256), 0, 0, p); ok = hipGetLastError() == hipSuccess; }
     for (int dir = 0; dir < 2 && ok; dir++) {
       p.dir = dir;
       hipLaunchKernelGGL(vvcx_deblock_kernel_u16, dim3((unsigned) ((2 * uw * uh + 255) / 256), 1), dim3(256), 0, 0, p);
@@ -1344,6 +1352,7 @@ extern "C" int vvcx_deblock_cu_table(int pic_w, int pic_h, int bit_depth, int qp
          hipMemcpy(cr, pl_d + ny + nc, nc * 2, hipMemcpyDeviceToHost) == hipSuccess;
     if (!ok) rc = fail(VVCX_ERR_DEVICE, "deblocking of a CU table: a HIP call failed");
   }
+  if (ed_d) (void) hipFree(ed_d);
   if (um_d) (void) hipFree(um_d);
   if (pl_d) (void) hipFree(pl_d);
   if (fd_d) (void) hipFree(fd_d);

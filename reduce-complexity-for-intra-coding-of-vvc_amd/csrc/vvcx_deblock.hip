@@ -210,7 +210,44 @@ __device__ inline int db_tu_size(const VxUnit &u, int dir)
   const int parts = ((w == 4 && h == 8) || (w == 8 && h == 4)) ? 2 : 4;
   return (dir ? h : w) / parts;
 }
+// Pre-pass: the 24-byte unit records the search left are read once and boiled down to one byte per unit, map and direction - is the unit's left / upper border an edge to
+// filter (a CU border, or a sub-partition border of an ISP CU on the 4-sample grid), and the transform sizes on either side (powers of two: their logarithms) - so that
+// the two filter passes read a byte per unit instead of one or two records (which were three times their sample traffic).
 // grid: ceil(2 * uw * uh / 256) x n_frames; the first uw*uh threads of a frame take the luma units, the next uw*uh the chroma units
+__device__ inline int db_log2(int v) { return 31 - __clz(v); }
+__device__ void deblock_edges(const VxDeblockParams &p)
+{
+  const VxFrameDev &fd = p.frames[blockIdx.y];
+  const int n = p.uw * p.uh;
+  int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= 2 * n) return;
+  const int ch = id >= n; id -= ch ? n : 0;
+  uint8_t *e = p.edges + (size_t) blockIdx.y * 4 * n;
+  uint8_t ev = 0, eh = 0;
+  if (!ch || p.chroma) {
+    const int uy = id / p.uw, ux = id - uy * p.uw;
+    const VxUnit u = fd.units[ch][id];
+    if (u.tag) {
+      if (!ch) {
+        const int x = ux << 2, y = uy << 2, isp = (u.mts >> 6) & 3;
+        for (int dir = 0; dir < 2; dir++) {                   // transform edges (xDeblockCU 306-317): the CU border, and inside an ISP CU the sub-partition borders on the 4-sample grid
+          const int tq = db_tu_size(u, dir), off = dir ? y - u.y : x - u.x;
+          const int inner = off > 0 && isp == (dir ? 1 : 2) && off % tq == 0;
+          if ((dir ? y : x) > 0 && (off == 0 || inner)) {
+            const int tp = inner ? tq : db_tu_size(fd.units[0][dir ? id - p.uw : id - 1], dir);
+            (dir ? eh : ev) = (uint8_t) (0x80 | (db_log2(tp) << 3) | db_log2(tq));
+          }
+        }
+      } else {
+        const int cx = ux << 1, cy = uy << 1;
+        if (u.x == cx && cx > 0 && (cx & 7) == 0) ev = (uint8_t) (0x80 | (fd.units[1][id - 1].lw << 3) | u.lw);
+        if (u.y == cy && cy > 0 && (cy & 7) == 0) eh = (uint8_t) (0x80 | (fd.units[1][id - p.uw].lh << 3) | u.lh);
+      }
+    }
+  }
+  e[(size_t) ch * n + id] = ev; e[(size_t) (2 + ch) * n + id] = eh;
+}
+// the filter passes: same grid; a thread whose unit has no edge in the pass's direction leaves after one byte
 template <typename T>
 __device__ void deblock_pass(const VxDeblockParams &p)
 {
@@ -219,26 +256,24 @@ __device__ void deblock_pass(const VxDeblockParams &p)
   int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= 2 * n || (id >= n && !p.chroma)) return;
   const int ch = id >= n; id -= ch ? n : 0;
-  const int uy = id / p.uw, ux = id - uy * p.uw;
-  const VxUnit u = fd.units[ch][id];
-  if (!u.tag) return;
+  const uint8_t e = p.edges[(size_t) blockIdx.y * 4 * n + (size_t) (2 * p.dir + ch) * n + id];
+  if (!e) return;
+  const int uy = id / p.uw, ux = id - uy * p.uw, sizeP = 1 << ((e >> 3) & 7), sizeQ = 1 << (e & 7);
   if (!ch) {
     const int x = ux << 2, y = uy << 2, st = fd.stride[0];
     T *rec = (T *) fd.rec[0];
-    // transform edges (xDeblockCU 306-317): the CU border, and inside an ISP CU the sub-partition borders that lie on the 4-sample grid
-    const int tq = db_tu_size(u, p.dir), off = p.dir ? y - u.y : x - u.x, isp = (u.mts >> 6) & 3;
-    const int inner = off > 0 && isp == (p.dir ? 1 : 2) && off % tq == 0;
-    if (p.dir == 0) { if (x > 0 && (off == 0 || inner)) db_luma_segment(rec + y * st + x, 1, st, inner ? tq : db_tu_size(fd.units[0][id - 1], 0), tq, 0, p); }
-    else if (y > 0 && (off == 0 || inner)) db_luma_segment(rec + y * st + x, st, 1, inner ? tq : db_tu_size(fd.units[0][id - p.uw], 1), tq, (y & 127) == 0, p);
+    if (p.dir == 0) db_luma_segment(rec + y * st + x, 1, st, sizeP, sizeQ, 0, p);
+    else db_luma_segment(rec + y * st + x, st, 1, sizeP, sizeQ, (y & 127) == 0, p);
   } else {
     const int cx = ux << 1, cy = uy << 1;
     for (int k = 0; k < 2; k++) {
       const int st = fd.stride[k + 1], qpc = db_clip3(0, 63, p.qp_c[k]);
       T *rec = (T *) fd.rec[k + 1];
-      if (p.dir == 0) { if (u.x == cx && cx > 0 && (cx & 7) == 0) db_chroma_segment(rec + cy * st + cx, 1, st, 1 << fd.units[1][id - 1].lw, 1 << u.lw, 0, qpc, p); }
-      else if (u.y == cy && cy > 0 && (cy & 7) == 0) db_chroma_segment(rec + cy * st + cx, st, 1, 1 << fd.units[1][id - p.uw].lh, 1 << u.lh, (cy & 63) == 0, qpc, p);
+      if (p.dir == 0) db_chroma_segment(rec + cy * st + cx, 1, st, sizeP, sizeQ, 0, qpc, p);
+      else db_chroma_segment(rec + cy * st + cx, st, 1, sizeP, sizeQ, (cy & 63) == 0, qpc, p);
     }
   }
 }
+extern "C" __global__ void __launch_bounds__(256) vvcx_deblock_edges_kernel(VxDeblockParams p) { deblock_edges(p); }
 extern "C" __global__ void __launch_bounds__(256) vvcx_deblock_kernel_u8(VxDeblockParams p) { deblock_pass<uint8_t>(p); }
 extern "C" __global__ void __launch_bounds__(256) vvcx_deblock_kernel_u16(VxDeblockParams p) { deblock_pass<uint16_t>(p); }

@@ -101,6 +101,7 @@ struct VxDeblockParams {     // vvcx_deblock.hip
   int32_t uw, uh, bit_depth, chroma;
   int32_t qp, qp_c[2];       // every CU carries the slice QP; mapped chroma QPs (+ offsets)
   int32_t beta_off2, tc_off2, dir;      // cfg LoopFilterBetaOffset_div2 / LoopFilterTcOffset_div2; 0 = vertical edges, 1 = horizontal edges
+  uint8_t *edges;            // per frame [direction][luma | chroma map][unit]: 0 = no edge to filter at the unit's left / upper border, else 0x80 | log2 sizeP << 3 | log2 sizeQ
 };
 
 // vvcx_sao.hip: resolved parameters of one (frame, CTU, component): type -1 off, 0..3 edge class (0 / 90 / 135 / 45 degrees), 4 band; offsets scaled, in the order
