@@ -588,6 +588,9 @@ def test_sao_statistics_on_the_gpu():
             rec = [t.cpu().numpy() for t in dev[i][1]]
             exp = O.sao_statistics(frames[i], rec, W, H, bd, 3, 2, lf)
             assert np.array_equal(got[i], exp), (bd, lf, i)
+            # the host half of the decision as the gfx950 library carries it (its tables are device constants the host code reads) against the oracle's
+            lam = [sp["lam"], sp["lam"] / sp["dist_weight"][0], sp["lam"] / sp["dist_weight"][1]]
+            assert np.array_equal(pkg.vvcx.sao_decide(got[i], W, H, bd, lam, sp["qp"], 3, 2), O.sao_decide(exp, W, H, bd, lam, sp["qp"], 3, 2)), (bd, lf, i)
         enc.close()
 
 
