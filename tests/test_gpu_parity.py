@@ -594,6 +594,38 @@ def test_sao_statistics_on_the_gpu():
         enc.close()
 
 
+def test_loop_filter_chain_at_full_size():
+    """BASELINE.json's configuration 2 (one 1920 x 1080 picture, QP 32, tools 0xfff, the benchmark's tiling) through the whole in-loop chain on the device - deblocking,
+    SAO statistics, SAO decision, SAO filter, ALF - with every stage after the search checked against the oracle's stage on the planes the device's previous stage left
+    (the deblocking itself is checked against the oracle's search + deblocking at the sizes of test_deblocking_filter)."""
+    import torch
+    W, H, qp, bd = 1920, 1080, 32, 8
+    sp = pkg.slice_params(qp, dep_quant=True)
+    frame = pkg.synth_frame(W, H, 0, bd, 1000, chroma_texture=0.5)
+    enc = pkg.VvcxEncoder(W, H, bd, tile_cols=15, tile_rows=9, tools=FULL, max_frames=1)
+    enc.set_slice(sp["qp"], sp["qp_c"], sp["lam"], sp["dist_weight"])
+    org = [torch.from_numpy(p).cuda() for p in frame]; rec = [torch.zeros_like(t) for t in org]
+    enc.bind_frames([([t.data_ptr() for t in org], [t.data_ptr() for t in rec], [t.shape[1] for t in org])])
+    enc.compress_bound_frames(); enc.deblock_bound_frames()
+    deblocked = [t.cpu().numpy() for t in rec]
+    stats, _ = enc.sao_statistics_bound_frames(1)
+    exp_stats = O.sao_statistics(frame, deblocked, W, H, bd, 15, 9, 1)
+    assert np.array_equal(stats[0], exp_stats)
+    lam = [sp["lam"], sp["lam"] / sp["dist_weight"][0], sp["lam"] / sp["dist_weight"][1]]
+    prm = pkg.vvcx.sao_decide(stats[0], W, H, bd, lam, sp["qp"], 15, 9)
+    assert np.array_equal(prm, O.sao_decide(exp_stats, W, H, bd, lam, sp["qp"], 15, 9))
+    prm[::7, 0] = (1, 2, 0, 2, 1, -1, -2)                  # the decision leaves most of this picture off: switch some CTUs on so that the filter has work
+    enc.sao_bound_frames(prm[None], lf_across_tiles=1)
+    after_sao = [t.cpu().numpy() for t in rec]
+    want = O.sao_picture(deblocked, W, H, bd, prm, 15, 9, 1, 0)
+    assert all(np.array_equal(after_sao[c].astype(np.int16), want[c]) for c in range(3)) and (after_sao[0] != deblocked[0]).any()
+    alf = O.alf_params(123, W, H)
+    enc.alf_bound_frames([alf])
+    want = O.alf_picture(after_sao, W, H, bd, alf)
+    assert all(np.array_equal(rec[c].cpu().numpy().astype(np.int16), want[c]) for c in range(3))
+    enc.close()
+
+
 def test_adaptive_loop_filter_on_the_gpu():
     """The ALF kernels (csrc/vvcx_alf.hip) on the GPU: vvcx_alf_picture against the reference's planes and block classes (tests/golden/alf.npz), and vvcx_alf_bound_frames
     behind a search, the deblocking filter and SAO against the oracle's filter on the same reconstruction (four pictures, each with parameter choices of its own; 8 and 10 bit)."""
