@@ -594,6 +594,21 @@ def test_sao_statistics_on_the_gpu():
         enc.close()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_sweep_with_wavefronts_and_the_classifier(seed):
+    """The sweep above over the two switches it leaves out: WaveFrontSynchro (CTU rows as streams; pictures of at least two CTU rows) and the fork's partition classifier
+    (tools 0x1fff with the shipped forest of the nearest QP), two frames per call."""
+    g = np.random.default_rng(5000 + seed)
+    wpp = seed % 2 == 0
+    W, H = 8 * int(g.integers(8, 33)), 8 * int(g.integers(17 if wpp else 4, 33 if wpp else 17))
+    bd = 10 if g.random() < 0.25 else 8
+    qp = int(g.choice([22, 27, 32, 37])) if not wpp else int(g.integers(22, 40))
+    tools = (FULL | pkg.TOOL_WPP) if wpp else (FULL | pkg.TOOL_FAST)
+    tc = 2 if W > 136 and g.random() < 0.5 else 1
+    frames = [pkg.synth_frame(W, H, f, bd, int(g.integers(0, 10000)), chroma_texture=float(g.choice([0.0, 0.5])), oriented=float(g.choice([0.0, 20.0]))) for f in range(2)]
+    _check(frames, W, H, pkg.slice_params(qp, bit_depth=bd, dep_quant=True), bit_depth=bd, tile_cols=tc, tools=tools, workers=4, forest_qp=qp)
+
+
 def test_loop_filter_chain_at_full_size():
     """BASELINE.json's configuration 2 (one 1920 x 1080 picture, QP 32, tools 0xfff, the benchmark's tiling) through the whole in-loop chain on the device - deblocking,
     SAO statistics, SAO decision, SAO filter, ALF - with every stage after the search checked against the oracle's stage on the planes the device's previous stage left
