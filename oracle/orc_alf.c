@@ -5,8 +5,9 @@
  * Follows CL/AdaptiveLoopFilter.cpp: ALFProcess 205-383 (per CTU: luma classified and filtered with the CTU's filter set - sets 0..15 are the fixed ones, 16 + k the
  * k-th parameter set of the slice - chroma with the CTU's alternative; source = a copy of the picture whose borders repeat the edge samples, extendBorderPel), the per-class
  * tables of a parameter set (reconstructCoeff 420-608 in its JVET_O0669 form: class -> filter through filterCoeffDeltaIdx, clipping index -> value through the table of
- * create() 633-654), deriveClassificationBlk 792-1002 and filterBlk 1005-1296 with the virtual boundary four luma / two chroma rows above the lower CTU border (not in the
- * last CTU row).  No PPS virtual boundaries, no PCM (JVET_O0525), tiles are not looked at (the reference's ALF of this version does not either).
+ * create() 633-654), deriveClassificationBlk 792-1002 and filterBlk 1005-1296 with the virtual boundary four luma / two chroma rows above the lower CTU border (in the
+ * last CTU row the reference passes the luma picture height as the boundary position for every component, which only a picture of at most 128 rows reaches: its lower edge
+ * then acts as a boundary).  No PPS virtual boundaries, no PCM (JVET_O0525), tiles are not looked at (the reference's ALF of this version does not either).
  *
  * The reference walks 32 x 32 areas with row buffers of half-resolution Laplacians; per 4 x 4 block that is: sums over the 8 x 8 window around the block (rows and columns
  * -2 .. +5) of the Laplacians at the samples (even, even) and (odd, odd) of every 2 x 2 cell, in the directions vertical, horizontal and the two diagonals; at a virtual
